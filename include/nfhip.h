@@ -1,0 +1,195 @@
+/* nfhip.h -- C ABI of libnfhip.so: the MI355X (gfx950) implementation of the
+ * ELBO / reverse-KL hot path of TuringLang/NormalizingFlows.jl.
+ *
+ * This is the drop-in boundary.  The reference is pure
+ * Julia with no FFI of its own; the seams it offers for a device back end are
+ * generic functions selected by dispatch.  Every entry point below names the
+ * reference interface it stands behind (paths relative to the reference
+ * checkout).  The Julia-side binding (`ccall`) is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - Every function returns an int status: 0 = ok, > 0 = hipError_t of a failed
+ *     HIP call, < 0 = NF_ERR_* argument / capability error.  Nothing throws or
+ *     aborts; the host wrapper turns non-zero into error(nf_strerror(code)).
+ *   - All array pointers are DEVICE pointers owned by the caller (AMDGPU.jl
+ *     ROCArray -> pointer(A); torch tensor -> data_ptr()), unless the parameter
+ *     name ends in _host.
+ *   - A batch is d x N column-major with one sample per column, i.e. x[j*d + i]
+ *     (reference: src/objectives/elbo.jl:52,60; src/flows/realnvp.jl:29).
+ *   - theta is the flat parameter vector produced by Optimisers.destructure(flow)
+ *     (src/NormalizingFlows.jl:67); its layout is documented in DESIGN.md and
+ *     matches oracle/nf_oracle.py:layers_flat_order.
+ *   - Work is enqueued on the context's HIP stream and is asynchronous unless
+ *     the function returns a host scalar.
+ *   - A context is not thread-safe (the reference's caller is one Julia task).
+ */
+#ifndef NFHIP_H
+#define NFHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NF_ABI_VERSION 1
+
+/* status codes (< 0: library errors; > 0: hipError_t) */
+#define NF_OK 0
+#define NF_ERR_ARG -1          /* null pointer, negative size, bad enum            */
+#define NF_ERR_UNSUPPORTED -2  /* flow shape / dtype not built into this library   */
+#define NF_ERR_NO_DEVICE -3    /* no gfx950 device visible                         */
+#define NF_ERR_NONFINITE -4    /* reserved: loss became non-finite                 */
+
+/* flow kinds: the constructors of src/flows/*.jl */
+#define NF_KIND_PLANAR 0    /* planarflow  src/flows/planar_radial.jl:21-29        */
+#define NF_KIND_RADIAL 1    /* radialflow  src/flows/planar_radial.jl:52-60        */
+#define NF_KIND_REALNVP 2   /* realnvp     src/flows/realnvp.jl:170-180            */
+#define NF_KIND_NSF 3       /* nsf         src/flows/neuralspline.jl:218-234       */
+#define NF_KIND_MEANFIELD 4 /* Shift o Scale, test/interface.jl:22-25              */
+
+#define NF_DTYPE_F32 0
+#define NF_DTYPE_F64 1
+
+#define NF_TARGET_DIAGGAUSS 0 /* MvNormal(mu, Diagonal(var)), test/flow.jl:43-46        */
+#define NF_TARGET_BANANA 1    /* Banana(d, b, var), example/targets/banana.jl:58-83     */
+
+#define NF_MAX_HIDDEN 4
+
+/* Static (non-trainable) description of a flow: the fields of the reference's
+ * layer structs that Optimisers.destructure leaves out (dim, mask, K, B, hidden
+ * sizes; src/flows/realnvp.jl:33-38, src/flows/neuralspline.jl:35-42). */
+typedef struct nf_flow_desc {
+  int32_t kind;                 /* NF_KIND_*                                         */
+  int32_t dtype;                /* NF_DTYPE_*                                        */
+  int32_t d;                    /* length(q0)                                        */
+  int32_t nlayers;              /* planar/radial: layers; realnvp/nsf: RealNVP_layer /
+                                   NSF_layer blocks (two couplings each)             */
+  int32_t n_hidden;             /* length(hdims)                                     */
+  int32_t hdims[NF_MAX_HIDDEN]; /* conditioner hidden widths, src/flows/utils.jl:71  */
+  int32_t K;                    /* spline bins (nsf)                                 */
+  float B;                      /* spline box bound (nsf)                            */
+} nf_flow_desc;
+
+/* Built-in target log-densities (the `logp` closure of src/objectives/elbo.jl:68
+ * for the benchmark/test targets).  p0/p1 are device pointers for DIAGGAUSS
+ * (mu[d], var[d]); for BANANA they are ignored and (b, var) are the scalars. */
+typedef struct nf_target {
+  int32_t kind;
+  const void *p0;
+  const void *p1;
+  double s0;
+  double s1;
+} nf_target;
+
+typedef struct nf_ctx nf_ctx;
+
+/* ---- library / context --------------------------------------------------- */
+int nf_abi_version(void);
+const char *nf_strerror(int code);
+/* hip_stream: a hipStream_t to enqueue on (NULL = the device's default stream). */
+int nf_ctx_create(int device, void *hip_stream, nf_ctx **out);
+int nf_ctx_destroy(nf_ctx *ctx);
+int nf_ctx_set_stream(nf_ctx *ctx, void *hip_stream);
+int nf_ctx_synchronize(nf_ctx *ctx);
+
+/* ---- layout -------------------------------------------------------------- */
+/* length(first(Optimisers.destructure(flow)))  (src/NormalizingFlows.jl:67) */
+int64_t nf_param_count(const nf_flow_desc *desc);
+/* number of bijector layers in execution terms (couplings count individually) */
+int32_t nf_layer_count(const nf_flow_desc *desc);
+
+/* ---- a4 + a5: base distribution ------------------------------------------ */
+/* _device_specific_rand(rng, MvNormal(zeros(d), I), N) fused with
+ * logpdf(flow.dist, xs)  (src/NormalizingFlows.jl:94-115, ext/NormalizingFlowsCUDAExt.jl:43-48,
+ * src/objectives/elbo.jl:68,94).  Philox4x32-10 keyed by `seed`, counter =
+ * (sample_offset + j, feature_group, stream_id): the draw for global sample j
+ * does not depend on how the batch is sharded.  logq_out may be NULL. */
+int nf_base_sample_logpdf(nf_ctx *ctx, int32_t dtype, int32_t d, int64_t N, uint64_t seed,
+                          uint64_t sample_offset, uint32_t stream_id, void *x_out, void *logq_out);
+/* logpdf(MvNormal(zeros(d), I), xs) for caller-supplied xs */
+int nf_base_logpdf(nf_ctx *ctx, int32_t dtype, int32_t d, int64_t N, const void *x, void *logq_out);
+
+/* ---- a6, a7, a10, a12, a13: transforms ----------------------------------- */
+/* Bijectors.with_logabsdet_jacobian(flow.transform, xs)  (src/objectives/elbo.jl:67):
+ * applies the layers last-listed first and sums per-sample logdets.
+ * y_out may alias x_in.  ladj_out[N] is overwritten. */
+int nf_flow_fwd(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *x_in,
+                int64_t N, void *y_out, void *ladj_out);
+/* with_logabsdet_jacobian(inverse(flow.transform), ys)  (src/flows/realnvp.jl:99-110,
+ * src/flows/neuralspline.jl:134-140; reached from loglikelihood.jl:31 via logpdf). */
+int nf_flow_inv(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *y_in,
+                int64_t N, void *x_out, void *ladj_out);
+/* One bijector layer, `layer` in FLAT order (0 = L1, the outermost / last applied):
+ * Bijectors.with_logabsdet_jacobian(layer, x)  (src/flows/realnvp.jl:77-83,
+ * src/flows/neuralspline.jl:102-108).  inverse != 0 selects Inverse{layer}.
+ * ladj_out[N] is overwritten. */
+int nf_layer_apply(nf_ctx *ctx, const nf_flow_desc *desc, int32_t layer, int32_t inverse,
+                   const void *theta, const void *x_in, int64_t N, void *y_out, void *ladj_out);
+
+/* Pullback of nf_flow_fwd (what a ChainRules rrule for with_logabsdet_jacobian
+ * needs; the mechanism MonotonicSplines uses, test/ad.jl:126-127).
+ * Inputs: x (flow input), y (flow output), ybar[d*N], lbar[N] (cotangent of ladj).
+ * Outputs: xbar_out[d*N] (may alias ybar), gtheta_out[P] (overwritten). */
+int nf_flow_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *x,
+                const void *y, const void *ybar, const void *lbar, int64_t N, void *xbar_out,
+                void *gtheta_out);
+
+/* ---- a14: built-in targets ------------------------------------------------ */
+/* logp(ys) per column and (optionally) its gradient w.r.t. ys. */
+int nf_target_logp(nf_ctx *ctx, int32_t dtype, const nf_target *target, int32_t d, int64_t N,
+                   const void *y, void *logp_out, void *grad_out);
+
+/* ---- a1, a2, a3: objectives ------------------------------------------------ */
+/* elbo_batch(flow, logp, xs) / elbo(flow, logp, xs)  (src/objectives/elbo.jl:31-34,89-92):
+ * mean_j[logp(y_j) - log q0(x_j) + ladj_j] for caller-supplied xs.
+ * elbos_out[N] (optional) receives the per-sample terms (_batched_elbos, :65-70). */
+int nf_elbo_batch(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target,
+                  const void *theta, const void *xs, int64_t N, void *elbos_out,
+                  double *elbo_host);
+/* elbo_batch(rng, flow, logp, n)  (src/objectives/elbo.jl:93-97): draws xs in-library. */
+int nf_elbo_batch_rng(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target,
+                      const void *theta, int64_t N, uint64_t seed, uint64_t sample_offset,
+                      uint32_t stream_id, double *elbo_host);
+/* a16: loglikelihood(rng, flow, ys)  (src/objectives/loglikelihood.jl:26-33):
+ * mean_j[log q0(T^-1 y_j) + ladj_inv_j]; logliks_out[N] optional. */
+int nf_loglikelihood(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *ys,
+                     int64_t N, void *logliks_out, double *ll_host);
+
+/* ---- a15: the training step ------------------------------------------------ */
+/* loss(theta) = -elbo_batch(rng, re(theta), logp, n) and its gradient
+ * (_value_and_gradient, src/optimize.jl:12-14,86; loss closure src/NormalizingFlows.jl:69)
+ * for THIS rank's shard of a global batch:
+ *   samples [sample_offset, sample_offset + N_local) of N_global,
+ *   out[0..P)  = sum_{j in shard} d(-elbo_j / N_global)/dtheta,
+ *   out[P]     = sum_{j in shard} (-elbo_j / N_global).
+ * Summing `out` over ranks (one all-reduce of P+1 elements) gives (grad, loss).
+ * xs may be NULL (draw in-library from Philox as nf_base_sample_logpdf does) or a
+ * caller-supplied d x N_local batch (the elbo_batch(flow, logp, xs) form). */
+int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target,
+                           const void *theta, const void *xs, int64_t N_local, int64_t N_global,
+                           uint64_t seed, uint64_t sample_offset, uint32_t stream_id,
+                           void *out_grad_loss);
+/* Optimisers.update!(st, theta, g) for Optimisers.Adam (src/optimize.jl:99), in place on
+ * theta/m/v; t = 1-based step count.  gnorm_out (device scalar, optional) receives
+ * norm(g) (src/optimize.jl:89). */
+int nf_adam_update(nf_ctx *ctx, int32_t dtype, void *theta, const void *g, void *m, void *v,
+                   int64_t P, double lr, double beta1, double beta2, double eps, int64_t t,
+                   void *gnorm_out);
+/* Single-GPU convenience: nf_elbo_value_and_grad + nf_adam_update in one call; returns the
+ * loss and gradient norm of the step (the stat tuple of src/optimize.jl:89). */
+int nf_elbo_step(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, void *theta,
+                 void *m, void *v, int64_t N, uint64_t seed, uint32_t step, double lr,
+                 double beta1, double beta2, double eps, double *loss_host, double *gnorm_host);
+
+/* ---- measurement support ---------------------------------------------------- */
+/* Average duration (ms) of the dominant kernel launches recorded with HIP events on the
+ * context stream since the last reset (used by bench.py's roofline object). */
+int nf_prof_enable(nf_ctx *ctx, int32_t on);
+int nf_prof_read(nf_ctx *ctx, const char *kernel_name, double *avg_ms_host, int64_t *count_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NFHIP_H */

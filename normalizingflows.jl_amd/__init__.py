@@ -1,0 +1,22 @@
+"""normalizingflows.jl_amd -- MI355X-native ELBO / reverse-KL hot path of NormalizingFlows.jl.
+
+Python host mirror of the reference's public names (src/NormalizingFlows.jl:17,138-141 and
+docs/src/api.md) over the C ABI of libnfhip.so (include/nfhip.h).  There is no CPU path:
+importing works anywhere, computing needs a gfx950 GPU and the built library.
+"""
+from ._lib import LIB_PATH, SYMBOLS, Context, NFHipError, context_for, load_library
+from .flows import (BananaTarget, DiagGaussTarget, Flow, MvNormal, PhiloxRNG, Transform, as_batch, base_logpdf,
+                    device_specific_rand, inverse, layer, logpdf, meanfield, new_batch, nsf, planarflow, radialflow,
+                    rand, realnvp, target_logp, transform, with_logabsdet_jacobian)
+from .objectives import (Adam, AdamState, adam_update, batched_elbos, elbo, elbo_batch, loglikelihood, optimize,
+                         train_flow, value_and_gradient)
+
+_device_specific_rand = device_specific_rand  # the reference's (underscored) extension hook name
+
+__all__ = [
+    "train_flow", "elbo", "elbo_batch", "loglikelihood", "optimize",
+    "planarflow", "radialflow", "realnvp", "nsf", "meanfield",
+    "with_logabsdet_jacobian", "transform", "inverse", "logpdf", "rand", "layer",
+    "MvNormal", "PhiloxRNG", "device_specific_rand", "_device_specific_rand",
+    "DiagGaussTarget", "BananaTarget", "Adam", "value_and_gradient",
+]

@@ -1,0 +1,525 @@
+// nf_api.hip -- extern "C" entry points of libnfhip.so (see include/nfhip.h for the
+// reference interface each one stands behind).  Host-side orchestration only: every
+// arithmetic operation happens in a gfx950 kernel; there is no CPU fallback.
+#include "nf_common.h"
+
+// ---- kernels' host launchers (other translation units) ---------------------------------
+int nf_launch_base_sample(nf_ctx *, int, int, long, uint64_t, uint64_t, uint32_t, void *, void *);
+int nf_launch_base_logpdf(nf_ctx *, int, int, long, const void *, void *);
+long nf_target_nblocks(long N);
+int nf_launch_target(nf_ctx *, int, const nf_target *, int, long, const void *, const void *, const void *, void *,
+                     void *, double, void *, double *, double);
+long nf_sum2_nblocks(long N);
+int nf_launch_sum2(nf_ctx *, int, long, const void *, const void *, void *, double *, double);
+int nf_launch_finish_sum(nf_ctx *, const double *, long, int, double *, float *, double *);
+int nf_launch_reduce_slabs(nf_ctx *, int, const void *, int, long, void *);
+long nf_adam_nblocks(long P);
+int nf_launch_adam(nf_ctx *, int, void *, const void *, void *, void *, long, double, double, double, double, long,
+                   double *);
+int nf_launch_fill(nf_ctx *, int, void *, long, double);
+
+bool nf_affine_supported(const nf_flow_desc *desc);
+int nf_affine_apply(nf_ctx *, const nf_flow_desc *, int k, bool inverse, const float *theta, const float *x, long N,
+                    float *y, float *ladj, int accumulate);
+int nf_affine_bwd_grid(nf_ctx *, long N);
+int nf_affine_bwd(nf_ctx *, const nf_flow_desc *, int k, const float *theta, float *y, float *ybar, const float *lbar,
+                  float lbar_const, long N, float *slab, long slab_stride, int grid);
+
+// planar / radial / mean-field flows (nf_simple.hip)
+bool nf_simple_supported(const nf_flow_desc *desc);
+int nf_simple_apply(nf_ctx *, const nf_flow_desc *, int layer_lo, int layer_hi, bool inverse, const void *theta,
+                    const void *x, long N, void *y, void *ladj);
+size_t nf_simple_bwd_ws_bytes(nf_ctx *, const nf_flow_desc *, long N);
+int nf_simple_bwd(nf_ctx *, const nf_flow_desc *, const void *theta, const void *x, const void *ybar, const void *lbar,
+                  double lbar_const, long N, void *xbar_out, void *gtheta_out, void *ws);
+
+// ---- helpers -----------------------------------------------------------------------------
+static inline size_t esize(int dtype) { return dtype == NF_DTYPE_F64 ? 8 : 4; }
+
+static int check_desc(const nf_flow_desc *d) {
+  if (!d) return NF_ERR_ARG;
+  if (d->d < 1 || d->nlayers < 1) return NF_ERR_ARG;
+  if (d->dtype != NF_DTYPE_F32 && d->dtype != NF_DTYPE_F64) return NF_ERR_ARG;
+  switch (d->kind) {
+    case NF_KIND_PLANAR:
+    case NF_KIND_RADIAL:
+    case NF_KIND_MEANFIELD:
+      return nf_simple_supported(d) ? NF_OK : NF_ERR_UNSUPPORTED;
+    case NF_KIND_REALNVP:
+      if (d->n_hidden < 1 || d->n_hidden > NF_MAX_HIDDEN) return NF_ERR_ARG;
+      if (d->d < 2) return NF_ERR_ARG;
+      if (d->dtype != NF_DTYPE_F32) return NF_ERR_UNSUPPORTED;
+      return nf_affine_supported(d) ? NF_OK : NF_ERR_UNSUPPORTED;
+    case NF_KIND_NSF:
+      return NF_ERR_UNSUPPORTED;
+    default:
+      return NF_ERR_ARG;
+  }
+}
+
+static long mlp_params(int nin, const nf_flow_desc *d, int nout) {
+  long n = 0;
+  int prev = nin;
+  for (int i = 0; i < d->n_hidden; ++i) {
+    n += (long)prev * d->hdims[i] + d->hdims[i];
+    prev = d->hdims[i];
+  }
+  return n + (long)prev * nout + nout;
+}
+
+CouplingInfo nf_coupling_info(const nf_flow_desc *desc, int k) {
+  const int d = desc->d;
+  const int c_odd = (d + 1) / 2, c_even = d / 2;  // mask 1:2:d / 2:2:d
+  auto npar = [&](int c) {
+    const int m = d - c;
+    if (desc->kind == NF_KIND_REALNVP) return 2 * mlp_params(m, desc, c);
+    return mlp_params(m, desc, (3 * desc->K - 1) * c);
+  };
+  CouplingInfo ci;
+  const long pair = npar(c_odd) + npar(c_even);
+  ci.theta_off = (long)(k / 2) * pair + ((k & 1) ? npar(c_odd) : 0);
+  ci.par_t = k & 1;
+  ci.c = (k & 1) ? c_even : c_odd;
+  ci.m = d - ci.c;
+  ci.nparams = npar(ci.c);
+  return ci;
+}
+
+extern "C" int64_t nf_param_count(const nf_flow_desc *d) {
+  if (!d) return NF_ERR_ARG;
+  switch (d->kind) {
+    case NF_KIND_PLANAR: return (int64_t)d->nlayers * (2 * d->d + 1);
+    case NF_KIND_RADIAL: return (int64_t)d->nlayers * (d->d + 2);
+    case NF_KIND_MEANFIELD: return 2 * (int64_t)d->d;
+    case NF_KIND_REALNVP:
+    case NF_KIND_NSF: {
+      CouplingInfo last = nf_coupling_info(d, 2 * d->nlayers - 1);
+      return last.theta_off + last.nparams;
+    }
+    default: return NF_ERR_ARG;
+  }
+}
+
+extern "C" int32_t nf_layer_count(const nf_flow_desc *d) {
+  if (!d) return NF_ERR_ARG;
+  switch (d->kind) {
+    case NF_KIND_PLANAR:
+    case NF_KIND_RADIAL: return d->nlayers;
+    case NF_KIND_MEANFIELD: return 2;
+    case NF_KIND_REALNVP:
+    case NF_KIND_NSF: return 2 * d->nlayers;
+    default: return NF_ERR_ARG;
+  }
+}
+
+// ---- library / context -------------------------------------------------------------------
+extern "C" int nf_abi_version(void) { return NF_ABI_VERSION; }
+
+extern "C" const char *nf_strerror(int code) {
+  switch (code) {
+    case NF_OK: return "ok";
+    case NF_ERR_ARG: return "nfhip: invalid argument";
+    case NF_ERR_UNSUPPORTED: return "nfhip: flow shape/dtype not built into this library";
+    case NF_ERR_NO_DEVICE: return "nfhip: no usable HIP device";
+    case NF_ERR_NONFINITE: return "nfhip: non-finite loss";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "nfhip: unknown error";
+  }
+}
+
+extern "C" int nf_ctx_create(int device, void *hip_stream, nf_ctx **out) {
+  if (!out) return NF_ERR_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return NF_ERR_NO_DEVICE;
+  if (device < 0 || device >= ndev) return NF_ERR_ARG;
+  NF_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  NF_HIP(hipGetDeviceProperties(&prop, device));
+  nf_ctx *c = new nf_ctx();
+  c->device = device;
+  c->stream = (hipStream_t)hip_stream;
+  c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  hipError_t e = hipHostMalloc((void **)&c->host_scratch, 8 * sizeof(double), hipHostMallocDefault);
+  if (e != hipSuccess) {
+    delete c;
+    return (int)e;
+  }
+  *out = c;
+  return NF_OK;
+}
+
+extern "C" int nf_ctx_destroy(nf_ctx *ctx) {
+  if (!ctx) return NF_ERR_ARG;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  for (auto &kv : ctx->prof_events)
+    for (auto &p : kv.second) {
+      hipEventDestroy(p.first);
+      hipEventDestroy(p.second);
+    }
+  if (ctx->ws) hipFree(ctx->ws);
+  if (ctx->gbuf) hipFree(ctx->gbuf);
+  if (ctx->host_scratch) hipHostFree(ctx->host_scratch);
+  delete ctx;
+  return NF_OK;
+}
+
+extern "C" int nf_ctx_set_stream(nf_ctx *ctx, void *hip_stream) {
+  if (!ctx) return NF_ERR_ARG;
+  ctx->stream = (hipStream_t)hip_stream;
+  return NF_OK;
+}
+
+extern "C" int nf_ctx_synchronize(nf_ctx *ctx) {
+  if (!ctx) return NF_ERR_ARG;
+  NF_HIP(hipStreamSynchronize(ctx->stream));
+  return NF_OK;
+}
+
+int nf_ws_reserve(nf_ctx *ctx, size_t bytes) {
+  if (bytes <= ctx->ws_bytes) return NF_OK;
+  NF_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->ws) NF_HIP(hipFree(ctx->ws));
+  ctx->ws = nullptr;
+  ctx->ws_bytes = 0;
+  const size_t want = bytes + bytes / 8;
+  NF_HIP(hipMalloc(&ctx->ws, want));
+  ctx->ws_bytes = want;
+  return NF_OK;
+}
+
+static int read_scalar(nf_ctx *ctx, const double *dev, double *host) {
+  NF_HIP(hipMemcpyAsync(ctx->host_scratch, dev, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  NF_HIP(hipStreamSynchronize(ctx->stream));
+  *host = ctx->host_scratch[0];
+  return NF_OK;
+}
+
+// ---- base distribution ---------------------------------------------------------------------
+extern "C" int nf_base_sample_logpdf(nf_ctx *ctx, int32_t dtype, int32_t d, int64_t N, uint64_t seed,
+                                     uint64_t sample_offset, uint32_t stream_id, void *x_out, void *logq_out) {
+  if (!ctx || !x_out || d < 1 || N < 0) return NF_ERR_ARG;
+  if (dtype != NF_DTYPE_F32 && dtype != NF_DTYPE_F64) return NF_ERR_ARG;
+  NF_HIP(hipSetDevice(ctx->device));
+  return nf_launch_base_sample(ctx, dtype, d, N, seed, sample_offset, stream_id, x_out, logq_out);
+}
+
+extern "C" int nf_base_logpdf(nf_ctx *ctx, int32_t dtype, int32_t d, int64_t N, const void *x, void *logq_out) {
+  if (!ctx || !x || !logq_out || d < 1 || N < 0) return NF_ERR_ARG;
+  if (dtype != NF_DTYPE_F32 && dtype != NF_DTYPE_F64) return NF_ERR_ARG;
+  NF_HIP(hipSetDevice(ctx->device));
+  return nf_launch_base_logpdf(ctx, dtype, d, N, x, logq_out);
+}
+
+// ---- transforms ----------------------------------------------------------------------------
+// applies couplings/layers in execution order (last flat layer first) or its inverse
+static int chain_apply(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, const void *theta, const void *x_in,
+                       long N, void *y_out, void *ladj) {
+  const size_t es = esize(desc->dtype);
+  if (N == 0) return NF_OK;
+  if (desc->kind == NF_KIND_REALNVP) {
+    const int nc = 2 * desc->nlayers;
+    if (y_out != x_in)
+      NF_HIP(hipMemcpyAsync(y_out, x_in, (size_t)N * desc->d * es, hipMemcpyDeviceToDevice, ctx->stream));
+    for (int s = 0; s < nc; ++s) {
+      const int k = inverse ? s : nc - 1 - s;
+      NF_TRY(nf_affine_apply(ctx, desc, k, inverse, (const float *)theta, (const float *)y_out, N, (float *)y_out,
+                             (float *)ladj, s > 0));
+    }
+    return NF_OK;
+  }
+  const int nl = nf_layer_count(desc);
+  return nf_simple_apply(ctx, desc, 0, nl, inverse, theta, x_in, N, y_out, ladj);
+}
+
+extern "C" int nf_flow_fwd(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *x_in, int64_t N,
+                           void *y_out, void *ladj_out) {
+  if (!ctx || !theta || !x_in || !y_out || !ladj_out || N < 0) return NF_ERR_ARG;
+  NF_TRY(check_desc(desc));
+  NF_HIP(hipSetDevice(ctx->device));
+  return chain_apply(ctx, desc, false, theta, x_in, N, y_out, ladj_out);
+}
+
+extern "C" int nf_flow_inv(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *y_in, int64_t N,
+                           void *x_out, void *ladj_out) {
+  if (!ctx || !theta || !y_in || !x_out || !ladj_out || N < 0) return NF_ERR_ARG;
+  NF_TRY(check_desc(desc));
+  NF_HIP(hipSetDevice(ctx->device));
+  return chain_apply(ctx, desc, true, theta, y_in, N, x_out, ladj_out);
+}
+
+extern "C" int nf_layer_apply(nf_ctx *ctx, const nf_flow_desc *desc, int32_t layer, int32_t inverse, const void *theta,
+                              const void *x_in, int64_t N, void *y_out, void *ladj_out) {
+  if (!ctx || !theta || !x_in || !y_out || !ladj_out || N < 0) return NF_ERR_ARG;
+  NF_TRY(check_desc(desc));
+  if (layer < 0 || layer >= nf_layer_count(desc)) return NF_ERR_ARG;
+  NF_HIP(hipSetDevice(ctx->device));
+  if (N == 0) return NF_OK;
+  if (desc->kind == NF_KIND_REALNVP) {
+    if (y_out != x_in)
+      NF_HIP(hipMemcpyAsync(y_out, x_in, (size_t)N * desc->d * esize(desc->dtype), hipMemcpyDeviceToDevice, ctx->stream));
+    return nf_affine_apply(ctx, desc, layer, inverse != 0, (const float *)theta, (const float *)y_out, N,
+                           (float *)y_out, (float *)ladj_out, 0);
+  }
+  return nf_simple_apply(ctx, desc, layer, layer + 1, inverse != 0, theta, x_in, N, y_out, ladj_out);
+}
+
+// reverse pass over the chain.  `state` (d x N) holds the flow OUTPUT on entry and the flow INPUT
+// on exit (invertible recompute); `gbar` holds ybar on entry and xbar on exit.
+static int realnvp_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta, float *state, float *gbar,
+                       const float *lbar, float lbar_const, long N, float *slab, int grid, float *g_out) {
+  const long P = nf_param_count(desc);
+  const int nc = 2 * desc->nlayers;
+  for (int k = 0; k < nc; ++k)  // flat order = reverse of execution order
+    NF_TRY(nf_affine_bwd(ctx, desc, k, theta, state, gbar, lbar, lbar_const, N, slab, P, grid));
+  return nf_launch_reduce_slabs(ctx, NF_DTYPE_F32, slab, grid, P, g_out);
+}
+
+extern "C" int nf_flow_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *x, const void *y,
+                           const void *ybar, const void *lbar, int64_t N, void *xbar_out, void *gtheta_out) {
+  if (!ctx || !theta || !x || !y || !ybar || !lbar || !xbar_out || !gtheta_out || N < 0) return NF_ERR_ARG;
+  NF_TRY(check_desc(desc));
+  NF_HIP(hipSetDevice(ctx->device));
+  const long P = nf_param_count(desc);
+  const size_t es = esize(desc->dtype);
+  if (N == 0) return nf_launch_fill(ctx, desc->dtype, gtheta_out, P, 0.0);
+  if (desc->kind == NF_KIND_REALNVP) {
+    const int grid = nf_affine_bwd_grid(ctx, N);
+    const size_t need = carve_bytes((size_t)N * desc->d * 4) + carve_bytes((size_t)grid * P * 4);
+    NF_TRY(nf_ws_reserve(ctx, need));
+    Carver cv(ctx->ws);
+    float *state = cv.take<float>((size_t)N * desc->d);
+    float *slab = cv.take<float>((size_t)grid * P);
+    NF_HIP(hipMemcpyAsync(state, y, (size_t)N * desc->d * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    if (xbar_out != ybar)
+      NF_HIP(hipMemcpyAsync(xbar_out, ybar, (size_t)N * desc->d * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    return realnvp_bwd(ctx, desc, (const float *)theta, state, (float *)xbar_out, (const float *)lbar, 0.f, N, slab,
+                       grid, (float *)gtheta_out);
+  }
+  NF_TRY(nf_ws_reserve(ctx, nf_simple_bwd_ws_bytes(ctx, desc, N)));
+  (void)es;
+  return nf_simple_bwd(ctx, desc, theta, x, ybar, lbar, 0.0, N, xbar_out, gtheta_out, ctx->ws);
+}
+
+// ---- targets -------------------------------------------------------------------------------
+extern "C" int nf_target_logp(nf_ctx *ctx, int32_t dtype, const nf_target *target, int32_t d, int64_t N, const void *y,
+                              void *logp_out, void *grad_out) {
+  if (!ctx || !target || !y || d < 1 || N < 0) return NF_ERR_ARG;
+  if (dtype != NF_DTYPE_F32 && dtype != NF_DTYPE_F64) return NF_ERR_ARG;
+  NF_HIP(hipSetDevice(ctx->device));
+  return nf_launch_target(ctx, dtype, target, d, N, y, nullptr, nullptr, logp_out, grad_out, 1.0, nullptr, nullptr, 0.0);
+}
+
+// ---- objectives ----------------------------------------------------------------------------
+static int elbo_forward(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, const void *theta,
+                        const void *xs, long N, uint64_t seed, uint64_t off, uint32_t stream_id, void *elbos_out,
+                        double *elbo_host) {
+  const size_t es = esize(desc->dtype);
+  const long nb = nf_target_nblocks(N);
+  const size_t need = carve_bytes((size_t)N * desc->d * es) + 2 * carve_bytes((size_t)N * es) +
+                      carve_bytes((size_t)nb * 8) + carve_bytes(64);
+  NF_TRY(nf_ws_reserve(ctx, need));
+  Carver cv(ctx->ws);
+  char *x = cv.take<char>((size_t)N * desc->d * es);
+  char *logq = cv.take<char>((size_t)N * es);
+  char *ladj = cv.take<char>((size_t)N * es);
+  double *partial = cv.take<double>(nb);
+  double *result = cv.take<double>(8);
+  if (xs) {
+    NF_HIP(hipMemcpyAsync(x, xs, (size_t)N * desc->d * es, hipMemcpyDeviceToDevice, ctx->stream));
+    NF_TRY(nf_launch_base_logpdf(ctx, desc->dtype, desc->d, N, x, logq));
+  } else {
+    NF_TRY(nf_launch_base_sample(ctx, desc->dtype, desc->d, N, seed, off, stream_id, x, logq));
+  }
+  NF_TRY(chain_apply(ctx, desc, false, theta, x, N, x, ladj));
+  NF_TRY(nf_launch_target(ctx, desc->dtype, target, desc->d, N, x, logq, ladj, nullptr, nullptr, 0.0, elbos_out,
+                          partial, 1.0 / (double)N));
+  NF_TRY(nf_launch_finish_sum(ctx, partial, nb, 0, result, nullptr, nullptr));
+  return read_scalar(ctx, result, elbo_host);
+}
+
+extern "C" int nf_elbo_batch(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, const void *theta,
+                             const void *xs, int64_t N, void *elbos_out, double *elbo_host) {
+  if (!ctx || !target || !theta || !xs || !elbo_host || N < 1) return NF_ERR_ARG;
+  NF_TRY(check_desc(desc));
+  NF_HIP(hipSetDevice(ctx->device));
+  return elbo_forward(ctx, desc, target, theta, xs, N, 0, 0, 0, elbos_out, elbo_host);
+}
+
+extern "C" int nf_elbo_batch_rng(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, const void *theta,
+                                 int64_t N, uint64_t seed, uint64_t sample_offset, uint32_t stream_id,
+                                 double *elbo_host) {
+  if (!ctx || !target || !theta || !elbo_host || N < 1) return NF_ERR_ARG;
+  NF_TRY(check_desc(desc));
+  NF_HIP(hipSetDevice(ctx->device));
+  return elbo_forward(ctx, desc, target, theta, nullptr, N, seed, sample_offset, stream_id, nullptr, elbo_host);
+}
+
+extern "C" int nf_loglikelihood(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *ys, int64_t N,
+                                void *logliks_out, double *ll_host) {
+  if (!ctx || !theta || !ys || !ll_host || N < 1) return NF_ERR_ARG;
+  NF_TRY(check_desc(desc));
+  NF_HIP(hipSetDevice(ctx->device));
+  const size_t es = esize(desc->dtype);
+  const long nb = nf_sum2_nblocks(N);
+  const size_t need = carve_bytes((size_t)N * desc->d * es) + 2 * carve_bytes((size_t)N * es) +
+                      carve_bytes((size_t)nb * 8) + carve_bytes(64);
+  NF_TRY(nf_ws_reserve(ctx, need));
+  Carver cv(ctx->ws);
+  char *x = cv.take<char>((size_t)N * desc->d * es);
+  char *logq = cv.take<char>((size_t)N * es);
+  char *ladj = cv.take<char>((size_t)N * es);
+  double *partial = cv.take<double>(nb);
+  double *result = cv.take<double>(8);
+  NF_TRY(chain_apply(ctx, desc, true, theta, ys, N, x, ladj));
+  NF_TRY(nf_launch_base_logpdf(ctx, desc->dtype, desc->d, N, x, logq));
+  NF_TRY(nf_launch_sum2(ctx, desc->dtype, N, logq, ladj, logliks_out, partial, 1.0 / (double)N));
+  NF_TRY(nf_launch_finish_sum(ctx, partial, nb, 0, result, nullptr, nullptr));
+  return read_scalar(ctx, result, ll_host);
+}
+
+// ---- training step -------------------------------------------------------------------------
+extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target,
+                                      const void *theta, const void *xs, int64_t N_local, int64_t N_global,
+                                      uint64_t seed, uint64_t sample_offset, uint32_t stream_id, void *out) {
+  if (!ctx || !target || !theta || !out || N_local < 0 || N_global < 1) return NF_ERR_ARG;
+  NF_TRY(check_desc(desc));
+  NF_HIP(hipSetDevice(ctx->device));
+  const long N = N_local;
+  const long P = nf_param_count(desc);
+  const int dt = desc->dtype;
+  const size_t es = esize(dt);
+  if (N == 0) return nf_launch_fill(ctx, dt, out, P + 1, 0.0);
+  const double inv = 1.0 / (double)N_global;
+  const long nb = nf_target_nblocks(N);
+  const bool coupling = desc->kind == NF_KIND_REALNVP;
+  const int grid = coupling ? nf_affine_bwd_grid(ctx, N) : 0;
+  const size_t simple_ws = coupling ? 0 : nf_simple_bwd_ws_bytes(ctx, desc, N);
+  const size_t need = 3 * carve_bytes((size_t)N * desc->d * es) + 2 * carve_bytes((size_t)N * es) +
+                      carve_bytes((size_t)nb * 8) + carve_bytes(64) + carve_bytes((size_t)grid * P * es) +
+                      carve_bytes(simple_ws);
+  NF_TRY(nf_ws_reserve(ctx, need));
+  Carver cv(ctx->ws);
+  char *x = cv.take<char>((size_t)N * desc->d * es);
+  char *gbar = cv.take<char>((size_t)N * desc->d * es);
+  char *x0 = cv.take<char>((size_t)N * desc->d * es);  // flow input kept for non-invertible recompute
+  char *logq = cv.take<char>((size_t)N * es);
+  char *ladj = cv.take<char>((size_t)N * es);
+  double *partial = cv.take<double>(nb);
+  double *result = cv.take<double>(8);
+  char *slab = cv.take<char>((size_t)grid * P * es);
+  char *sws = cv.take<char>(simple_ws);
+
+  char *xin = coupling ? x : x0;
+  if (xs) {
+    NF_HIP(hipMemcpyAsync(xin, xs, (size_t)N * desc->d * es, hipMemcpyDeviceToDevice, ctx->stream));
+    NF_TRY(nf_launch_base_logpdf(ctx, dt, desc->d, N, xin, logq));
+  } else {
+    NF_TRY(nf_launch_base_sample(ctx, dt, desc->d, N, seed, sample_offset, stream_id, xin, logq));
+  }
+  NF_TRY(chain_apply(ctx, desc, false, theta, xin, N, x, ladj));
+  // gbar = d(-elbo/Ng)/dy = -(1/Ng) grad logp(y);  partial sums of -elbo_j/Ng
+  NF_TRY(nf_launch_target(ctx, dt, target, desc->d, N, x, logq, ladj, nullptr, gbar, -inv, nullptr, partial, -inv));
+  if (coupling) {
+    NF_TRY(realnvp_bwd(ctx, desc, (const float *)theta, (float *)x, (float *)gbar, nullptr, (float)(-inv), N,
+                       (float *)slab, grid, (float *)out));
+  } else {
+    NF_TRY(nf_simple_bwd(ctx, desc, theta, x0, gbar, nullptr, -inv, N, gbar, out, sws));
+  }
+  if (dt == NF_DTYPE_F32)
+    return nf_launch_finish_sum(ctx, partial, nb, 0, nullptr, (float *)out + P, nullptr);
+  return nf_launch_finish_sum(ctx, partial, nb, 0, (double *)out + P, nullptr, nullptr);
+}
+
+extern "C" int nf_adam_update(nf_ctx *ctx, int32_t dtype, void *theta, const void *g, void *m, void *v, int64_t P,
+                              double lr, double beta1, double beta2, double eps, int64_t t, void *gnorm_out) {
+  if (!ctx || !theta || !g || !m || !v || P < 0 || t < 1) return NF_ERR_ARG;
+  if (dtype != NF_DTYPE_F32 && dtype != NF_DTYPE_F64) return NF_ERR_ARG;
+  NF_HIP(hipSetDevice(ctx->device));
+  if (P == 0) return NF_OK;
+  double *partial = nullptr;
+  const long nb = nf_adam_nblocks(P);
+  if (gnorm_out) {
+    // the arena may be in use by a preceding call on the same stream: stream order makes reuse safe
+    NF_TRY(nf_ws_reserve(ctx, carve_bytes((size_t)nb * 8)));
+    partial = (double *)((char *)ctx->ws + ctx->ws_bytes - carve_bytes((size_t)nb * 8));
+  }
+  NF_TRY(nf_launch_adam(ctx, dtype, theta, g, m, v, P, lr, beta1, beta2, eps, t, partial));
+  if (gnorm_out) {
+    if (dtype == NF_DTYPE_F32) return nf_launch_finish_sum(ctx, partial, nb, 1, nullptr, (float *)gnorm_out, nullptr);
+    return nf_launch_finish_sum(ctx, partial, nb, 1, (double *)gnorm_out, nullptr, nullptr);
+  }
+  return NF_OK;
+}
+
+extern "C" int nf_elbo_step(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, void *theta, void *m,
+                            void *v, int64_t N, uint64_t seed, uint32_t step, double lr, double beta1, double beta2,
+                            double eps, double *loss_host, double *gnorm_host) {
+  if (!ctx || !theta || !m || !v || N < 1) return NF_ERR_ARG;
+  NF_TRY(check_desc(desc));
+  NF_HIP(hipSetDevice(ctx->device));
+  const long P = nf_param_count(desc);
+  const size_t es = esize(desc->dtype);
+  const size_t gneed = (size_t)(P + 2) * es;
+  if (gneed > ctx->gbuf_bytes) {
+    NF_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->gbuf) NF_HIP(hipFree(ctx->gbuf));
+    ctx->gbuf = nullptr;
+    ctx->gbuf_bytes = 0;
+    NF_HIP(hipMalloc(&ctx->gbuf, gneed));
+    ctx->gbuf_bytes = gneed;
+  }
+  void *gbuf = ctx->gbuf;
+  NF_TRY(nf_elbo_value_and_grad(ctx, desc, target, theta, nullptr, N, N, seed, 0, step, gbuf));
+  char *gnorm_dev = (char *)gbuf + (size_t)(P + 1) * es;
+  NF_TRY(nf_adam_update(ctx, desc->dtype, theta, gbuf, m, v, P, lr, beta1, beta2, eps, (int64_t)step + 1,
+                        (loss_host || gnorm_host) ? gnorm_dev : nullptr));
+  if (loss_host || gnorm_host) {
+    NF_HIP(hipMemcpyAsync(ctx->host_scratch, (char *)gbuf + (size_t)P * es, 2 * es, hipMemcpyDeviceToHost, ctx->stream));
+    NF_HIP(hipStreamSynchronize(ctx->stream));
+    double l, gnv;
+    if (desc->dtype == NF_DTYPE_F32) {
+      l = ((float *)ctx->host_scratch)[0];
+      gnv = ((float *)ctx->host_scratch)[1];
+    } else {
+      l = ctx->host_scratch[0];
+      gnv = ctx->host_scratch[1];
+    }
+    if (loss_host) *loss_host = l;
+    if (gnorm_host) *gnorm_host = gnv;
+  }
+  return NF_OK;
+}
+
+// ---- measurement support -------------------------------------------------------------------
+extern "C" int nf_prof_enable(nf_ctx *ctx, int32_t on) {
+  if (!ctx) return NF_ERR_ARG;
+  NF_HIP(hipStreamSynchronize(ctx->stream));
+  for (auto &kv : ctx->prof_events)
+    for (auto &p : kv.second) {
+      hipEventDestroy(p.first);
+      hipEventDestroy(p.second);
+    }
+  ctx->prof_events.clear();
+  ctx->prof = on != 0;
+  return NF_OK;
+}
+
+extern "C" int nf_prof_read(nf_ctx *ctx, const char *kernel_name, double *avg_ms_host, int64_t *count_host) {
+  if (!ctx || !kernel_name || !avg_ms_host) return NF_ERR_ARG;
+  NF_HIP(hipStreamSynchronize(ctx->stream));
+  auto it = ctx->prof_events.find(kernel_name);
+  if (it == ctx->prof_events.end() || it->second.empty()) {
+    *avg_ms_host = 0.0;
+    if (count_host) *count_host = 0;
+    return NF_OK;
+  }
+  double tot = 0.0;
+  for (auto &p : it->second) {
+    float ms = 0.f;
+    NF_HIP(hipEventElapsedTime(&ms, p.first, p.second));
+    tot += ms;
+  }
+  *avg_ms_host = tot / (double)it->second.size();
+  if (count_host) *count_host = (int64_t)it->second.size();
+  return NF_OK;
+}

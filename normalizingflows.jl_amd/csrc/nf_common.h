@@ -1,0 +1,90 @@
+// nf_common.h -- context, status handling and launch helpers shared by the
+// translation units of libnfhip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/nfhip.h"
+
+#define NF_HIP(call)                         \
+  do {                                       \
+    hipError_t e__ = (call);                 \
+    if (e__ != hipSuccess) return (int)e__;  \
+  } while (0)
+
+#define NF_TRY(call)            \
+  do {                          \
+    int s__ = (call);           \
+    if (s__ != NF_OK) return s__; \
+  } while (0)
+
+struct nf_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int num_cu = 256;
+  // grow-only device arena for intermediates (never freed until destroy, so steady-state
+  // steps allocate nothing)
+  void *ws = nullptr;
+  size_t ws_bytes = 0;
+  // pinned host scalars for results that are returned by value
+  double *host_scratch = nullptr;
+  // device gradient buffer of nf_elbo_step (P + 2 elements), grow-only
+  void *gbuf = nullptr;
+  size_t gbuf_bytes = 0;
+  // per-kernel HIP-event timing (bench.py roofline): name -> list of (start, stop)
+  bool prof = false;
+  std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof_events;
+};
+
+int nf_ws_reserve(nf_ctx *ctx, size_t bytes);
+
+// carve helper over the arena: returns 256-byte aligned sub-buffers
+struct Carver {
+  char *base;
+  size_t off = 0;
+  explicit Carver(void *b) : base((char *)b) {}
+  template <class T>
+  T *take(size_t n) {
+    T *p = (T *)(base + off);
+    off += ((n * sizeof(T) + 255) / 256) * 256;
+    return p;
+  }
+};
+inline size_t carve_bytes(size_t nbytes) { return ((nbytes + 255) / 256) * 256; }
+
+// RAII-less profiling bracket: records events on ctx->stream around a launch
+struct ProfScope {
+  nf_ctx *ctx;
+  hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(nf_ctx *c, const char *name) : ctx(c) {
+    if (ctx->prof) {
+      hipEventCreate(&a);
+      hipEventCreate(&b);
+      hipEventRecord(a, ctx->stream);
+      ctx->prof_events[name].push_back({a, b});
+    }
+  }
+  ~ProfScope() {
+    if (a) hipEventRecord(b, ctx->stream);
+  }
+};
+
+// layer bookkeeping shared by host code --------------------------------------------
+struct CouplingInfo {
+  long theta_off;   // offset of this coupling's parameters in theta
+  long nparams;
+  int par_t;        // transformed features are 2p + par_t  (mask 1:2:d -> 0, 2:2:d -> 1)
+  int c, m;         // transformed / conditioner sizes
+};
+
+inline int nf_desc_h(const nf_flow_desc *d, int i) { return d->hdims[i]; }
+
+// coupling `k` in FLAT order (k even: odd mask 1:2:d, k odd: even mask 2:2:d);
+// reference: src/flows/realnvp.jl:138-144, src/flows/neuralspline.jl:176-183.
+CouplingInfo nf_coupling_info(const nf_flow_desc *desc, int k);

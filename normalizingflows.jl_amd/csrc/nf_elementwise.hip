@@ -1,0 +1,391 @@
+// nf_elementwise.hip -- HBM-bound kernels around the coupling chain (gfx950):
+//   base sampler + log q0 (a4, a5), built-in targets and ELBO assembly (a2, a14),
+//   partial-sum reductions, gradient-slab reduction, Adam + gradient norm (a15).
+//
+// Layout reminder: batch is d x N, sample j contiguous (x[j*d + i]).  These kernels use
+// LPS = 16 lanes per sample: lane q of a sample group owns features q, q+16, q+32, ... so a
+// 16-lane group reads 64 contiguous bytes per step, and per-sample sums (||x||^2, log p)
+// are 4-step DPP/shuffle reductions inside the group.
+#include "nf_common.h"
+
+#define LPS 16
+#define EW_BLOCK 256
+#define SPB (EW_BLOCK / LPS)  // samples per block
+
+template <class T>
+__device__ __forceinline__ T group16_sum(T v) {
+  v += __shfl_xor(v, 8, 16);
+  v += __shfl_xor(v, 4, 16);
+  v += __shfl_xor(v, 2, 16);
+  v += __shfl_xor(v, 1, 16);
+  return v;
+}
+
+// block-wide sum of one double per thread -> thread 0 (EW_BLOCK threads)
+__device__ __forceinline__ double block_sum(double v, double *sm) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) sm[wave] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r += sm[w];
+  __syncthreads();
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. 2011); specification mirrored in oracle/nf_oracle.py
+// ---------------------------------------------------------------------------------------
+struct U4 {
+  uint32_t x, y, z, w;
+};
+__device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c.x;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
+    U4 n;
+    n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
+    n.y = (uint32_t)p1;
+    n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
+    n.w = (uint32_t)p0;
+    c = n;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return c;
+}
+template <class T>
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, T &z0, T &z1);
+template <>
+__device__ __forceinline__ void box_muller<float>(uint32_t a, uint32_t b, float &z0, float &z1) {
+  const float u0 = ((float)(a >> 9) + 0.5f) * 1.1920928955078125e-07f;  // 2^-23, exact in fp32
+  const float u1 = ((float)(b >> 9) + 0.5f) * 1.1920928955078125e-07f;
+  const float rad = sqrtf(-2.0f * logf(u0));
+  float s, c;
+  sincospif(2.0f * u1, &s, &c);
+  z0 = rad * c;
+  z1 = rad * s;
+}
+template <>
+__device__ __forceinline__ void box_muller<double>(uint32_t a, uint32_t b, double &z0, double &z1) {
+  const double u0 = ((double)(a >> 9) + 0.5) * 1.1920928955078125e-07;
+  const double u1 = ((double)(b >> 9) + 0.5) * 1.1920928955078125e-07;
+  const double rad = sqrt(-2.0 * log(u0));
+  double s, c;
+  sincospi(2.0 * u1, &s, &c);
+  z0 = rad * c;
+  z1 = rad * s;
+}
+
+// x ~ N(0, I), logq = logpdf(MvNormal(0, I), x).  Reference seam: _device_specific_rand
+// (src/NormalizingFlows.jl:109-115; device version ext/NormalizingFlowsCUDAExt.jl:43-48).
+template <class T>
+__global__ __launch_bounds__(EW_BLOCK) void k_base_sample(int d, long N, uint32_t k0, uint32_t k1, uint64_t off,
+                                                          uint32_t stream, T *__restrict__ x, T *__restrict__ logq) {
+  const int q = threadIdx.x & (LPS - 1);
+  const long j = (long)blockIdx.x * SPB + (threadIdx.x / LPS);
+  const bool valid = j < N;
+  const int ng = (d + 3) / 4;
+  T ss = 0;
+  if (valid) {
+    const uint64_t gj = off + (uint64_t)j;
+    for (int g = q; g < ng; g += LPS) {
+      U4 c = {(uint32_t)gj, (uint32_t)(gj >> 32), (uint32_t)g, stream};
+      const U4 r = philox4x32_10(c, k0, k1);
+      T z[4];
+      box_muller<T>(r.x, r.y, z[0], z[1]);
+      box_muller<T>(r.z, r.w, z[2], z[3]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * g + e;
+        if (i < d) {
+          x[j * d + i] = z[e];
+          ss += z[e] * z[e];
+        }
+      }
+    }
+  }
+  ss = group16_sum(ss);
+  if (valid && q == 0 && logq) logq[j] = (T)(-0.5 * 1.8378770664093453 * d) - (T)0.5 * ss;
+}
+
+template <class T>
+__global__ __launch_bounds__(EW_BLOCK) void k_base_logpdf(int d, long N, const T *__restrict__ x, T *__restrict__ logq) {
+  const int q = threadIdx.x & (LPS - 1);
+  const long j = (long)blockIdx.x * SPB + (threadIdx.x / LPS);
+  const bool valid = j < N;
+  T ss = 0;
+  if (valid)
+    for (int i = q; i < d; i += LPS) {
+      const T v = x[j * d + i];
+      ss += v * v;
+    }
+  ss = group16_sum(ss);
+  if (valid && q == 0) logq[j] = (T)(-0.5 * 1.8378770664093453 * d) - (T)0.5 * ss;
+}
+
+// ---------------------------------------------------------------------------------------
+// targets + ELBO assembly
+// ---------------------------------------------------------------------------------------
+// logp per sample, optional outputs:
+//   logp_out[j]                                 (nf_target_logp)
+//   grad_out[j*d+i] = gscale * dlogp/dy_i        (gscale = 1 for the API, -1/N for the loss)
+//   elbos_out[j]   = logp - logq + ladj          (src/objectives/elbo.jl:68)
+//   partial[blockIdx.x] = sum over the block's samples of pscale * (logp - logq + ladj)
+template <class T>
+__global__ __launch_bounds__(EW_BLOCK) void k_target(int kind, int d, long N, const T *__restrict__ y,
+                                                     const T *__restrict__ mu, const T *__restrict__ var, T b_ban,
+                                                     T var_ban, const T *__restrict__ logq, const T *__restrict__ ladj,
+                                                     T *__restrict__ logp_out, T *__restrict__ grad_out, T gscale,
+                                                     T *__restrict__ elbos_out, double *__restrict__ partial,
+                                                     double pscale) {
+  __shared__ double sm[EW_BLOCK / 64];
+  const int q = threadIdx.x & (LPS - 1);
+  const long j = (long)blockIdx.x * SPB + (threadIdx.x / LPS);
+  const bool valid = j < N;
+  T acc = 0;
+  if (valid) {
+    const T *yr = y + j * d;
+    if (kind == NF_TARGET_DIAGGAUSS) {
+      for (int i = q; i < d; i += LPS) {
+        const T v = var[i];
+        const T r = yr[i] - mu[i];
+        acc += (T)1.8378770664093453 + log(v) + r * r / v;
+        if (grad_out) grad_out[j * d + i] = gscale * (-r / v);
+      }
+      acc = (T)-0.5 * acc;
+    } else {  // Banana: example/targets/banana.jl:58-63,77-83
+      const T y0 = yr[0];
+      const T y2 = yr[1] + b_ban * y0 * y0 - var_ban * b_ban;
+      for (int i = q; i < d; i += LPS) {
+        const T v = yr[i];
+        T term, g;
+        if (i == 0) {
+          term = v * v / var_ban;
+          g = -v / var_ban - (T)2 * b_ban * v * y2;
+        } else if (i == 1) {
+          term = y2 * y2;
+          g = -y2;
+        } else {
+          term = v * v;
+          g = -v;
+        }
+        acc += term;
+        if (grad_out) grad_out[j * d + i] = gscale * g;
+      }
+      acc = (T)-0.5 * acc;
+      if (q == 0) acc -= (log(var_ban) / (T)d + (T)1.8378770664093453) * (T)d / (T)2;
+    }
+  }
+  acc = group16_sum(acc);
+  double contrib = 0.0;
+  if (valid && q == 0) {
+    if (logp_out) logp_out[j] = acc;
+    T e = acc;
+    if (logq) e -= logq[j];
+    if (ladj) e += ladj[j];
+    if (elbos_out) elbos_out[j] = e;
+    contrib = pscale * (double)e;
+  }
+  if (partial) {
+    const double s = block_sum(contrib, sm);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+  }
+}
+
+// partial sums of (a[j] + b[j]) * scale over blocks (loglikelihood: log q0(x) + ladj)
+template <class T>
+__global__ __launch_bounds__(EW_BLOCK) void k_sum2(long N, const T *__restrict__ a, const T *__restrict__ b,
+                                                   T *__restrict__ out, double *__restrict__ partial, double scale) {
+  __shared__ double sm[EW_BLOCK / 64];
+  const long j = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
+  double c = 0.0;
+  if (j < N) {
+    const T v = a[j] + (b ? b[j] : (T)0);
+    if (out) out[j] = v;
+    c = scale * (double)v;
+  }
+  const double s = block_sum(c, sm);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// deterministic final reduction of block partials (single block); optional sqrt.
+// dst_d (double*) and/or dst_f (float*, element `idx`) receive the result.
+__global__ __launch_bounds__(EW_BLOCK) void k_finish_sum(const double *__restrict__ partial, long n, int take_sqrt,
+                                                         double *__restrict__ dst_d, float *__restrict__ dst_f,
+                                                         double *__restrict__ dst_d2) {
+  __shared__ double sm[EW_BLOCK / 64];
+  double c = 0.0;
+  for (long i = threadIdx.x; i < n; i += EW_BLOCK) c += partial[i];
+  double s = block_sum(c, sm);
+  if (threadIdx.x == 0) {
+    if (take_sqrt) s = sqrt(s);
+    if (dst_d) *dst_d = s;
+    if (dst_f) *dst_f = (float)s;
+    if (dst_d2) *dst_d2 = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// gradient slabs -> gradient ; Adam
+// ---------------------------------------------------------------------------------------
+// g[p] = sum_s slab[s*P + p]   (deterministic: fixed summation order)
+template <class T>
+__global__ __launch_bounds__(EW_BLOCK) void k_reduce_slabs(const T *__restrict__ slab, int nslab, long P,
+                                                           T *__restrict__ g) {
+  const long p = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
+  if (p >= P) return;
+  T a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  int s = 0;
+  for (; s + 3 < nslab; s += 4) {
+    a0 += slab[(long)s * P + p];
+    a1 += slab[(long)(s + 1) * P + p];
+    a2 += slab[(long)(s + 2) * P + p];
+    a3 += slab[(long)(s + 3) * P + p];
+  }
+  for (; s < nslab; ++s) a0 += slab[(long)s * P + p];
+  g[p] = (a0 + a1) + (a2 + a3);
+}
+
+// Optimisers.Adam (Optimisers.jl 0.4 `apply!`): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+// theta -= lr * (m / (1 - b1^t)) / (sqrt(v / (1 - b2^t)) + eps).  Also block partials of g^2
+// for gradient_norm (src/optimize.jl:89).
+template <class T>
+__global__ __launch_bounds__(EW_BLOCK) void k_adam(T *__restrict__ theta, const T *__restrict__ g, T *__restrict__ m,
+                                                   T *__restrict__ v, long P, T lr, T b1, T b2, T eps, T c1, T c2,
+                                                   double *__restrict__ partial) {
+  __shared__ double sm[EW_BLOCK / 64];
+  const long p = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
+  double gg = 0.0;
+  if (p < P) {
+    const T gi = g[p];
+    const T mi = b1 * m[p] + ((T)1 - b1) * gi;
+    const T vi = b2 * v[p] + ((T)1 - b2) * gi * gi;
+    m[p] = mi;
+    v[p] = vi;
+    theta[p] -= lr * (mi / c1) / (sqrt(vi / c2) + eps);
+    gg = (double)gi * (double)gi;
+  }
+  if (partial) {
+    const double s = block_sum(gg, sm);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+  }
+}
+
+template <class T>
+__global__ void k_fill(T *p, long n, T v) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------
+// host launchers (typed on NF_DTYPE_*)
+// ---------------------------------------------------------------------------------------
+static inline unsigned nblk(long n, int per) { return (unsigned)((n + per - 1) / per > 0 ? (n + per - 1) / per : 1); }
+
+int nf_launch_base_sample(nf_ctx *ctx, int dtype, int d, long N, uint64_t seed, uint64_t off, uint32_t stream, void *x,
+                          void *logq) {
+  if (N <= 0) return NF_OK;
+  ProfScope ps(ctx, "base_sample");
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  if (dtype == NF_DTYPE_F32)
+    hipLaunchKernelGGL(k_base_sample<float>, dim3(nblk(N, SPB)), dim3(EW_BLOCK), 0, ctx->stream, d, N, k0, k1, off,
+                       stream, (float *)x, (float *)logq);
+  else
+    hipLaunchKernelGGL(k_base_sample<double>, dim3(nblk(N, SPB)), dim3(EW_BLOCK), 0, ctx->stream, d, N, k0, k1, off,
+                       stream, (double *)x, (double *)logq);
+  return (int)hipGetLastError();
+}
+
+int nf_launch_base_logpdf(nf_ctx *ctx, int dtype, int d, long N, const void *x, void *logq) {
+  if (N <= 0) return NF_OK;
+  if (dtype == NF_DTYPE_F32)
+    hipLaunchKernelGGL(k_base_logpdf<float>, dim3(nblk(N, SPB)), dim3(EW_BLOCK), 0, ctx->stream, d, N, (const float *)x,
+                       (float *)logq);
+  else
+    hipLaunchKernelGGL(k_base_logpdf<double>, dim3(nblk(N, SPB)), dim3(EW_BLOCK), 0, ctx->stream, d, N,
+                       (const double *)x, (double *)logq);
+  return (int)hipGetLastError();
+}
+
+// number of block partials k_target produces for a batch of N
+long nf_target_nblocks(long N) { return nblk(N, SPB); }
+
+int nf_launch_target(nf_ctx *ctx, int dtype, const nf_target *t, int d, long N, const void *y, const void *logq,
+                     const void *ladj, void *logp_out, void *grad_out, double gscale, void *elbos_out, double *partial,
+                     double pscale) {
+  if (N <= 0) return NF_OK;
+  if (t->kind != NF_TARGET_DIAGGAUSS && t->kind != NF_TARGET_BANANA) return NF_ERR_ARG;
+  if (t->kind == NF_TARGET_DIAGGAUSS && (!t->p0 || !t->p1)) return NF_ERR_ARG;
+  if (t->kind == NF_TARGET_BANANA && d < 2) return NF_ERR_ARG;
+  ProfScope ps(ctx, "target");
+  if (dtype == NF_DTYPE_F32)
+    hipLaunchKernelGGL(k_target<float>, dim3(nblk(N, SPB)), dim3(EW_BLOCK), 0, ctx->stream, t->kind, d, N,
+                       (const float *)y, (const float *)t->p0, (const float *)t->p1, (float)t->s0, (float)t->s1,
+                       (const float *)logq, (const float *)ladj, (float *)logp_out, (float *)grad_out, (float)gscale,
+                       (float *)elbos_out, partial, pscale);
+  else
+    hipLaunchKernelGGL(k_target<double>, dim3(nblk(N, SPB)), dim3(EW_BLOCK), 0, ctx->stream, t->kind, d, N,
+                       (const double *)y, (const double *)t->p0, (const double *)t->p1, (double)t->s0, (double)t->s1,
+                       (const double *)logq, (const double *)ladj, (double *)logp_out, (double *)grad_out, gscale,
+                       (double *)elbos_out, partial, pscale);
+  return (int)hipGetLastError();
+}
+
+long nf_sum2_nblocks(long N) { return nblk(N, EW_BLOCK); }
+
+int nf_launch_sum2(nf_ctx *ctx, int dtype, long N, const void *a, const void *b, void *out, double *partial,
+                   double scale) {
+  if (dtype == NF_DTYPE_F32)
+    hipLaunchKernelGGL(k_sum2<float>, dim3(nblk(N, EW_BLOCK)), dim3(EW_BLOCK), 0, ctx->stream, N, (const float *)a,
+                       (const float *)b, (float *)out, partial, scale);
+  else
+    hipLaunchKernelGGL(k_sum2<double>, dim3(nblk(N, EW_BLOCK)), dim3(EW_BLOCK), 0, ctx->stream, N, (const double *)a,
+                       (const double *)b, (double *)out, partial, scale);
+  return (int)hipGetLastError();
+}
+
+int nf_launch_finish_sum(nf_ctx *ctx, const double *partial, long n, int take_sqrt, double *dst_d, float *dst_f,
+                         double *dst_d2) {
+  hipLaunchKernelGGL(k_finish_sum, dim3(1), dim3(EW_BLOCK), 0, ctx->stream, partial, n, take_sqrt, dst_d, dst_f, dst_d2);
+  return (int)hipGetLastError();
+}
+
+int nf_launch_reduce_slabs(nf_ctx *ctx, int dtype, const void *slab, int nslab, long P, void *g) {
+  ProfScope ps(ctx, "reduce_slabs");
+  if (dtype == NF_DTYPE_F32)
+    hipLaunchKernelGGL(k_reduce_slabs<float>, dim3(nblk(P, EW_BLOCK)), dim3(EW_BLOCK), 0, ctx->stream,
+                       (const float *)slab, nslab, P, (float *)g);
+  else
+    hipLaunchKernelGGL(k_reduce_slabs<double>, dim3(nblk(P, EW_BLOCK)), dim3(EW_BLOCK), 0, ctx->stream,
+                       (const double *)slab, nslab, P, (double *)g);
+  return (int)hipGetLastError();
+}
+
+long nf_adam_nblocks(long P) { return nblk(P, EW_BLOCK); }
+
+int nf_launch_adam(nf_ctx *ctx, int dtype, void *theta, const void *g, void *m, void *v, long P, double lr, double b1,
+                   double b2, double eps, long t, double *partial) {
+  ProfScope ps(ctx, "adam");
+  const double c1 = 1.0 - pow(b1, (double)t), c2 = 1.0 - pow(b2, (double)t);
+  if (dtype == NF_DTYPE_F32)
+    hipLaunchKernelGGL(k_adam<float>, dim3(nblk(P, EW_BLOCK)), dim3(EW_BLOCK), 0, ctx->stream, (float *)theta,
+                       (const float *)g, (float *)m, (float *)v, P, (float)lr, (float)b1, (float)b2, (float)eps,
+                       (float)c1, (float)c2, partial);
+  else
+    hipLaunchKernelGGL(k_adam<double>, dim3(nblk(P, EW_BLOCK)), dim3(EW_BLOCK), 0, ctx->stream, (double *)theta,
+                       (const double *)g, (double *)m, (double *)v, P, lr, b1, b2, eps, c1, c2, partial);
+  return (int)hipGetLastError();
+}
+
+int nf_launch_fill(nf_ctx *ctx, int dtype, void *p, long n, double v) {
+  if (n <= 0) return NF_OK;
+  if (dtype == NF_DTYPE_F32)
+    hipLaunchKernelGGL(k_fill<float>, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, (float *)p, n, (float)v);
+  else
+    hipLaunchKernelGGL(k_fill<double>, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, (double *)p, n, v);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,270 @@
+// nf_mfma.h -- register-chained fp32 MFMA primitives for the conditioner MLPs
+// of the coupling layers (reference: Flux Dense chain built by fnn,
+// src/flows/utils.jl:71-100; used at src/flows/realnvp.jl:50-52,79-80).
+//
+// gfx950 only.  One wavefront (64 lanes) owns a TILE of 32 samples.
+//
+// Register layout ("C layout") of a [features x 32 samples] activation block:
+// it is exactly the C/D layout of v_mfma_f32_32x32x2_f32 --
+//     lane l, register r  <->  sample  j = l & 31,
+//                              feature f = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
+// (one f32x16 per block of 32 features).
+//
+// The trick that keeps activations out of LDS: in D = A * B the B operand of
+// k-step t is, per lane, "feature k_t of sample l&31" with k_t split over the
+// two half-waves.  The contraction order over k is free, so we choose
+//     k_t(l) = (t & 3) + 8 * (t >> 2) + 4 * (l >> 5),   t = 0..15
+// which makes B-operand t of the NEXT layer identical to accumulator register
+// t of THIS layer: bias/activation are applied in place and the registers are
+// fed straight back into the matrix pipe.  Only the weight (A) operands are
+// fetched, from an LDS image in the reference's own memory order
+// (Dense weight is out x in column-major => [in][out], `out` contiguous).
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define NF_TILE 32  // samples per wave tile
+
+__device__ __forceinline__ int nf_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+__device__ __forceinline__ float nf_lrelu(float z) { return z > 0.f ? z : 0.01f * z; }
+
+// LDS image of one Dense layer: W[i][o] at w[i * S + o], S = 32*OB + 1 (odd stride so
+// that both the forward (lanes along o) and the transposed (lanes along i) operand
+// reads are bank-conflict free with ds_read_b32), followed by the bias.
+struct DenseLds {
+  const float *w;
+  const float *b;
+};
+
+// All MFMA loops below are software-pipelined by hand in groups of four k-steps: the A
+// operands of group g+1 are fetched from LDS while the matrix pipe works on group g, and
+// __builtin_amdgcn_sched_barrier(0) pins that order.  Without the pins hipcc hoists every
+// ds_read of a layer (hundreds) above the first MFMA and spills.
+
+// out[ob] = W * in + b   (no activation).  IB input blocks, OB output blocks.
+template <int IB, int OB>
+__device__ __forceinline__ void dense_fwd(const float *__restrict__ w, const float *__restrict__ b,
+                                          const f32x16 (&in)[IB], f32x16 (&out)[OB], int l31, int hi) {
+  constexpr int S = 32 * OB + 1;
+  constexpr int NG = IB * 4;  // groups of 4 k-steps
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[ob][r] = b[ob * 32 + nf_row(r, hi)];
+  const float *wl = w + (4 * hi) * S + l31;  // lane-dependent part of the address
+  float an[OB][4], ac[OB][4];
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) an[ob][e] = wl[e * S + ob * 32];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ac[ob][e] = an[ob][e];
+    if (g + 1 < NG) {
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) an[ob][e] = wl[((g + 1) * 8 + e) * S + ob * 32];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob)
+        out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[ob][e], in[g / 4][(g % 4) * 4 + e], out[ob], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// din[ib] = W^T * delta : the dX GEMM of the reverse pass, same register chaining.
+template <int IB, int OB>
+__device__ __forceinline__ void dense_bwd_x(const float *__restrict__ w, const f32x16 (&delta)[OB],
+                                            f32x16 (&din)[IB], int l31, int hi) {
+  constexpr int S = 32 * OB + 1;
+  constexpr int NG = OB * 4;
+#pragma unroll
+  for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) din[ib][r] = 0.f;
+  const float *wl = w + l31 * S + 4 * hi;
+  float an[IB][4], ac[IB][4];
+#pragma unroll
+  for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) an[ib][e] = wl[ib * 32 * S + e];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ac[ib][e] = an[ib][e];
+    if (g + 1 < NG) {
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) an[ib][e] = wl[ib * 32 * S + (g + 1) * 8 + e];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib)
+        din[ib] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[ib][e], delta[g / 4][(g % 4) * 4 + e], din[ib], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// ---- weight-gradient GEMM: contraction over SAMPLES -------------------------------
+// dW^T[i][o] += sum_j a[i][j] * delta[o][j].  Both operands must have lane <-> feature,
+// i.e. the transpose of the C layout, so they take one round trip through a per-wave
+// LDS scratch tile [feature][sample] with row stride 33 (conflict-free both ways).
+#define NF_TS 33
+
+template <int NB>
+__device__ __forceinline__ void tile_to_scratch(float *__restrict__ sc, const f32x16 (&v)[NB], int l31, int hi) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[(b * 32 + nf_row(r, hi)) * NF_TS + l31] = v[b][r];
+}
+
+// acc[ib][ob] (C layout: col = o, rows = i) += A(a) * B(delta); bsum[ob] += sum over this
+// half-wave's samples of delta (lane <-> feature o).  sa/sd: scratch tiles of a and delta.
+template <int IB, int OB>
+__device__ __forceinline__ void dw_accumulate(const float *__restrict__ sa, const float *__restrict__ sd,
+                                              f32x16 (&acc)[IB][OB], float (&bsum)[OB], int l31, int hi) {
+  constexpr int TG = 2;        // k-steps (sample pairs) per pipeline group
+  constexpr int NG = 16 / TG;
+  const float *pa = sa + l31 * NF_TS + hi;
+  const float *pd = sd + l31 * NF_TS + hi;
+  float an[TG][IB], dn[TG][OB], ac[TG][IB], dc[TG][OB];
+#pragma unroll
+  for (int u = 0; u < TG; ++u) {
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib) an[u][ib] = pa[ib * 32 * NF_TS + 2 * u];
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob) dn[u][ob] = pd[ob * 32 * NF_TS + 2 * u];
+  }
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+#pragma unroll
+    for (int u = 0; u < TG; ++u) {
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib) ac[u][ib] = an[u][ib];
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob) dc[u][ob] = dn[u][ob];
+    }
+    if (g + 1 < NG) {
+#pragma unroll
+      for (int u = 0; u < TG; ++u) {
+#pragma unroll
+        for (int ib = 0; ib < IB; ++ib) an[u][ib] = pa[ib * 32 * NF_TS + 2 * ((g + 1) * TG + u)];
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob) dn[u][ob] = pd[ob * 32 * NF_TS + 2 * ((g + 1) * TG + u)];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < TG; ++u) {
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob) bsum[ob] += dc[u][ob];
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob)
+          acc[ib][ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u][ib], dc[u][ob], acc[ib][ob], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Orders a wave's own LDS writes before its own LDS reads (cross-lane exchange inside
+// one wavefront: no s_barrier needed, the LDS queue is in order per wave).
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- LDS image of a 2-hidden-layer conditioner net ----------------------------------
+// Geometry in blocks of 32: MB (conditioner inputs), H1B, H2B (hidden), CB (outputs).
+template <int MB_, int H1B_, int H2B_, int CB_>
+struct NetGeo {
+  static constexpr int MB = MB_, H1B = H1B_, H2B = H2B_, CB = CB_;
+  static constexpr int S1 = 32 * H1B + 1, S2 = 32 * H2B + 1, S3 = 32 * CB + 1;
+  static constexpr int W1 = 0;
+  static constexpr int B1 = W1 + 32 * MB * S1;
+  static constexpr int W2 = B1 + 32 * H1B;
+  static constexpr int B2 = W2 + 32 * H1B * S2;
+  static constexpr int W3 = B2 + 32 * H2B;
+  static constexpr int B3 = W3 + 32 * H2B * S3;
+  static constexpr int SIZE = ((B3 + 32 * CB + 3) / 4) * 4;  // floats, 16-byte multiple
+  static constexpr int NACC = MB * H1B + H1B * H2B + H2B * CB;  // f32x16 dW accumulators
+};
+
+// Actual (unpadded) sizes and theta offsets of one net.
+struct NetDims {
+  int m, h1, h2, c;  // fan-in, hidden, hidden, fan-out
+  long w1, b1, w2, b2, w3, b3;  // offsets into theta (Optimisers.destructure order)
+};
+
+__host__ __device__ inline NetDims make_net_dims(long off, int m, int h1, int h2, int c) {
+  NetDims n;
+  n.m = m; n.h1 = h1; n.h2 = h2; n.c = c;
+  n.w1 = off; n.b1 = n.w1 + (long)m * h1;
+  n.w2 = n.b1 + h1; n.b2 = n.w2 + (long)h1 * h2;
+  n.w3 = n.b2 + h2; n.b3 = n.w3 + (long)h2 * c;
+  return n;
+}
+__host__ __device__ inline long net_param_count(int m, int h1, int h2, int c) {
+  return (long)m * h1 + h1 + (long)h1 * h2 + h2 + (long)h2 * c + c;
+}
+
+// Copy one Dense layer theta[in][out] -> padded LDS image, zero fill.
+template <int S>
+__device__ __forceinline__ void stage_dense(float *__restrict__ img, int rows_pad, const float *__restrict__ theta,
+                                            int nin, int nout, int tid, int nthreads) {
+  for (int idx = tid; idx < rows_pad * S; idx += nthreads) {
+    const int i = idx / S, o = idx - i * S;
+    img[idx] = (i < nin && o < nout) ? theta[(long)i * nout + o] : 0.f;
+  }
+}
+__device__ __forceinline__ void stage_bias(float *__restrict__ img, int n_pad, const float *__restrict__ theta,
+                                           int n, int tid, int nthreads) {
+  for (int idx = tid; idx < n_pad; idx += nthreads) img[idx] = idx < n ? theta[idx] : 0.f;
+}
+
+template <class G>
+__device__ __forceinline__ void stage_net(float *__restrict__ img, const float *__restrict__ theta, const NetDims &nd,
+                                          int tid, int nthreads) {
+  stage_dense<G::S1>(img + G::W1, 32 * G::MB, theta + nd.w1, nd.m, nd.h1, tid, nthreads);
+  stage_bias(img + G::B1, 32 * G::H1B, theta + nd.b1, nd.h1, tid, nthreads);
+  stage_dense<G::S2>(img + G::W2, 32 * G::H1B, theta + nd.w2, nd.h1, nd.h2, tid, nthreads);
+  stage_bias(img + G::B2, 32 * G::H2B, theta + nd.b2, nd.h2, tid, nthreads);
+  stage_dense<G::S3>(img + G::W3, 32 * G::H2B, theta + nd.w3, nd.h2, nd.c, tid, nthreads);
+  stage_bias(img + G::B3, 32 * G::CB, theta + nd.b3, nd.c, tid, nthreads);
+}
+
+// Forward through the 2-hidden-layer net.  a1/a2 are the post-leakyrelu activations
+// (kept for the reverse pass), out the pre-output-activation result.
+template <class G>
+__device__ __forceinline__ void net_forward(const float *__restrict__ img, const f32x16 (&x)[G::MB],
+                                            f32x16 (&a1)[G::H1B], f32x16 (&a2)[G::H2B], f32x16 (&out)[G::CB],
+                                            int l31, int hi) {
+  dense_fwd<G::MB, G::H1B>(img + G::W1, img + G::B1, x, a1, l31, hi);
+#pragma unroll
+  for (int b = 0; b < G::H1B; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a1[b][r] = nf_lrelu(a1[b][r]);
+  dense_fwd<G::H1B, G::H2B>(img + G::W2, img + G::B2, a1, a2, l31, hi);
+#pragma unroll
+  for (int b = 0; b < G::H2B; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a2[b][r] = nf_lrelu(a2[b][r]);
+  dense_fwd<G::H2B, G::CB>(img + G::W3, img + G::B3, a2, out, l31, hi);
+}

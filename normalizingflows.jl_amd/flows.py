@@ -1,0 +1,336 @@
+"""Host-side mirror of the reference's flow constructors and of the Bijectors.jl surface the
+hot path uses.  All arithmetic is done by libnfhip.so (HIP, gfx950); this module only owns
+descriptors, the flat parameter vector and argument marshalling.
+
+Reference files mirrored (paths in the reference checkout):
+  src/flows/utils.jl            create_flow, fnn layout
+  src/flows/planar_radial.jl    planarflow, radialflow
+  src/flows/realnvp.jl          AffineCoupling, RealNVP_layer, realnvp
+  src/flows/neuralspline.jl     NeuralSplineCoupling, NSF_layer, nsf
+  src/NormalizingFlows.jl       _device_specific_rand (:94-127)
+
+Array convention = the reference's: a batch is a (d, N) matrix with one sample per COLUMN,
+stored column-major (here: a torch tensor of shape (d, N) whose transpose is contiguous).
+A vector of shape (d,) is a single sample and gives scalar log-determinants
+(src/flows/realnvp.jl:69-75).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import FlowDesc, NFHipError, Target, check, context_for
+
+
+def _dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return _lib.NF_DTYPE_F32
+    if dt == torch.float64:
+        return _lib.NF_DTYPE_F64
+    raise NFHipError(f"unsupported parameter type {dt}")
+
+
+def new_batch(d: int, n: int, dtype, device) -> torch.Tensor:
+    """(d, n) matrix in the reference's column-major layout."""
+    return torch.empty((n, d), dtype=dtype, device=device).t()
+
+
+def as_batch(x: torch.Tensor):
+    """Returns (matrix (d, N) column-major, was_vector)."""
+    vec = x.dim() == 1
+    if vec:
+        x = x.reshape(-1, 1)
+    if x.dim() != 2:
+        raise NFHipError("expected a vector (d,) or a matrix (d, N)")
+    if not x.t().is_contiguous():
+        x = x.t().contiguous().t()
+    return x, vec
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+# --------------------------------------------------------------------------------------
+# base distribution and RNG seam
+# --------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class MvNormal:
+    """MvNormal(zeros(T, d), I) -- the base distribution of every reference flow config
+    (test/flow.jl:9, example/demo_planar_flow.jl:24)."""
+
+    d: int
+
+    def __len__(self):
+        return self.d
+
+
+class PhiloxRNG:
+    """Device RNG handle (the analogue of CUDA.RNG in ext/NormalizingFlowsCUDAExt.jl).
+    Philox4x32-10 keyed by `seed`; every draw call consumes one stream id, so successive
+    calls give independent batches, and `sample_offset` places a shard inside a global batch."""
+
+    def __init__(self, seed: int = 0, sample_offset: int = 0):
+        self.seed = int(seed)
+        self.stream = 0
+        self.sample_offset = int(sample_offset)
+
+    def next_stream(self) -> int:
+        s = self.stream
+        self.stream += 1
+        return s
+
+
+def device_specific_rand(rng: PhiloxRNG, dist, n: Optional[int] = None, *, device=None, dtype=torch.float32):
+    """NormalizingFlows._device_specific_rand(rng, dist[, n])  (src/NormalizingFlows.jl:94-127).
+    `dist` is an MvNormal base or a Flow (then base draws are pushed through the transform,
+    as rand(td, n) does)."""
+    if isinstance(dist, Flow):
+        xs = device_specific_rand(rng, dist.dist, n, device=dist.theta.device, dtype=dist.theta.dtype)
+        return dist.transform(xs)
+    device = torch.device(device if device is not None else "cuda")
+    nn = 1 if n is None else int(n)
+    x = new_batch(dist.d, nn, dtype, device)
+    ctx = context_for(device)
+    check(
+        ctx.lib.nf_base_sample_logpdf(
+            ctx.ptr, _dtype_code(dtype), dist.d, nn, rng.seed, rng.sample_offset, rng.next_stream(), _ptr(x), _ptr(None)
+        )
+    )
+    return x[:, 0] if n is None else x
+
+
+# --------------------------------------------------------------------------------------
+# flows
+# --------------------------------------------------------------------------------------
+class Transform:
+    """flow.transform: a composed bijector.  `inverse(t)` gives the Inverse{...} view."""
+
+    def __init__(self, flow: "Flow", inverted: bool = False, layer: Optional[int] = None):
+        self.flow = flow
+        self.inverted = inverted
+        self.layer = layer
+
+    def __call__(self, x):
+        return with_logabsdet_jacobian(self, x)[0]
+
+
+class Flow:
+    """Bijectors.TransformedDistribution: `dist` (base) + `transform`.  `theta` is the flat
+    parameter vector of Optimisers.destructure(flow) (src/NormalizingFlows.jl:67)."""
+
+    def __init__(self, kind: str, dist: MvNormal, nlayers: int, hdims: Sequence[int] = (), K: int = 0, B: float = 0.0,
+                 dtype=torch.float32, device="cuda", theta: Optional[torch.Tensor] = None):
+        self.kind, self.dist, self.nlayers = kind, dist, int(nlayers)
+        self.hdims, self.K, self.B = tuple(int(h) for h in hdims), int(K), float(B)
+        if len(self.hdims) > _lib.NF_MAX_HIDDEN:
+            raise NFHipError("at most 4 hidden layers")
+        self.desc = FlowDesc()
+        self.desc.kind = _lib.NF_KIND[kind]
+        self.desc.dtype = _dtype_code(dtype)
+        self.desc.d = dist.d
+        self.desc.nlayers = self.nlayers
+        self.desc.n_hidden = len(self.hdims)
+        for i, h in enumerate(self.hdims):
+            self.desc.hdims[i] = h
+        self.desc.K = self.K
+        self.desc.B = self.B
+        self.P = int(_lib.load_library().nf_param_count(C.byref(self.desc)))
+        if self.P < 0:
+            check(self.P)
+        dev = torch.device(device)
+        self.theta = theta if theta is not None else torch.zeros(self.P, dtype=dtype, device=dev)
+        if self.theta.numel() != self.P:
+            raise NFHipError(f"theta has {self.theta.numel()} entries, flow has {self.P} parameters")
+        self.transform = Transform(self)
+
+    # Optimisers.destructure(flow) -> (theta_flat, re)
+    def destructure(self):
+        def re(theta):
+            return self.with_theta(theta)
+
+        return self.theta.clone(), re
+
+    def with_theta(self, theta: torch.Tensor) -> "Flow":
+        return Flow(self.kind, self.dist, self.nlayers, self.hdims, self.K, self.B, self.theta.dtype,
+                    self.theta.device, theta)
+
+    @property
+    def ctx(self):
+        return context_for(self.theta.device)
+
+
+def inverse(t: Transform) -> Transform:
+    """Bijectors.inverse"""
+    return Transform(t.flow, not t.inverted, t.layer)
+
+
+def layer(flow: Flow, index: int) -> Transform:
+    """The `index`-th bijector of the composition in FLAT order (0 = outermost = applied last)."""
+    return Transform(flow, False, index)
+
+
+def with_logabsdet_jacobian(t: Transform, x: torch.Tensor):
+    """Bijectors.with_logabsdet_jacobian(t, x) -> (y, logabsdetjac)
+    (src/flows/realnvp.jl:69-110, src/flows/neuralspline.jl:94-140; ComposedFunction recursion
+    reached from src/objectives/elbo.jl:67)."""
+    flow = t.flow
+    xm, vec = as_batch(x.to(flow.theta.dtype))
+    d, n = xm.shape
+    if d != flow.dist.d:
+        raise NFHipError(f"dimension mismatch: flow has d={flow.dist.d}, input has {d}")
+    y = new_batch(d, n, xm.dtype, xm.device)
+    ladj = torch.empty(n, dtype=xm.dtype, device=xm.device)
+    ctx = flow.ctx
+    if t.layer is None:
+        fn = ctx.lib.nf_flow_inv if t.inverted else ctx.lib.nf_flow_fwd
+        check(fn(ctx.ptr, C.byref(flow.desc), _ptr(flow.theta), _ptr(xm), n, _ptr(y), _ptr(ladj)))
+    else:
+        check(ctx.lib.nf_layer_apply(ctx.ptr, C.byref(flow.desc), t.layer, int(t.inverted), _ptr(flow.theta), _ptr(xm),
+                                     n, _ptr(y), _ptr(ladj)))
+    if vec:
+        return y[:, 0], ladj[0]
+    return y, ladj
+
+
+def transform(t: Transform, x: torch.Tensor):
+    """Bijectors.transform(t, x)"""
+    return with_logabsdet_jacobian(t, x)[0]
+
+
+def base_logpdf(dist: MvNormal, xs: torch.Tensor):
+    """logpdf(MvNormal(zeros, I), xs) per column"""
+    xm, vec = as_batch(xs)
+    d, n = xm.shape
+    out = torch.empty(n, dtype=xm.dtype, device=xm.device)
+    ctx = context_for(xm.device)
+    check(ctx.lib.nf_base_logpdf(ctx.ptr, _dtype_code(xm.dtype), d, n, _ptr(xm), _ptr(out)))
+    return out[0] if vec else out
+
+
+def logpdf(flow, ys: torch.Tensor):
+    """logpdf(td, y) = logpdf(td.dist, x) + ladj_inv  (Bijectors; used by
+    src/objectives/loglikelihood.jl:23,31 and test/flow.jl:15)."""
+    if isinstance(flow, MvNormal):
+        return base_logpdf(flow, ys)
+    xs, ladj = with_logabsdet_jacobian(inverse(flow.transform), ys)
+    return base_logpdf(flow.dist, xs) + ladj
+
+
+def rand(flow, n: Optional[int] = None, rng: Optional[PhiloxRNG] = None):
+    """rand(rng, flow, n): base draws pushed through the transform (batched)."""
+    rng = rng if rng is not None else _default_rng
+    if isinstance(flow, MvNormal):
+        return device_specific_rand(rng, flow, n)
+    return device_specific_rand(rng, flow, n)
+
+
+_default_rng = PhiloxRNG(0)
+
+
+# --------------------------------------------------------------------------------------
+# constructors (parameter initialisation follows the reference's init distributions:
+# Flux.Dense Glorot-uniform weights / zero bias; PlanarLayer / RadialLayer randn)
+# --------------------------------------------------------------------------------------
+def _mlp_shapes(nin, hdims, nout):
+    dims = [nin] + list(hdims) + [nout]
+    return list(zip(dims[:-1], dims[1:]))
+
+
+def _init_couplings(flow: Flow, gen: torch.Generator, outs_per_c):
+    d = flow.dist.d
+    parts = []
+    for _ in range(flow.nlayers):
+        for start in (0, 1):  # mask 1:2:d then 2:2:d (src/flows/realnvp.jl:138-139)
+            c = len(range(start, d, 2))
+            m = d - c
+            for nout in outs_per_c(c):
+                for (a, b) in _mlp_shapes(m, flow.hdims, nout):
+                    lim = math.sqrt(6.0 / (a + b))
+                    w = (torch.rand(a * b, generator=gen, dtype=torch.float64) * 2 - 1) * lim
+                    parts += [w, torch.zeros(b, dtype=torch.float64)]
+    return torch.cat(parts)
+
+
+def _finish(flow: Flow, theta64: torch.Tensor) -> Flow:
+    assert theta64.numel() == flow.P, (theta64.numel(), flow.P)
+    flow.theta = theta64.to(flow.theta.dtype).to(flow.theta.device)
+    return flow
+
+
+def realnvp(q0: MvNormal, hdims: Sequence[int] = (32, 32), nlayers: int = 10, *, paramtype=torch.float64,
+            device="cuda", seed: int = 0) -> Flow:
+    """realnvp(q0, hdims, nlayers; paramtype)  (src/flows/realnvp.jl:170-192)."""
+    flow = Flow("realnvp", q0, nlayers, hdims, dtype=paramtype, device=device)
+    gen = torch.Generator().manual_seed(seed)
+    return _finish(flow, _init_couplings(flow, gen, lambda c: (c, c)))
+
+
+def nsf(q0: MvNormal, hdims: Sequence[int] = (32, 32), K: int = 10, B: float = 30.0, nlayers: int = 10, *,
+        paramtype=torch.float64, device="cuda", seed: int = 0) -> Flow:
+    """nsf(q0, hdims, K, B, nlayers; paramtype)  (src/flows/neuralspline.jl:218-234)."""
+    flow = Flow("nsf", q0, nlayers, hdims, K, B, dtype=paramtype, device=device)
+    gen = torch.Generator().manual_seed(seed)
+    return _finish(flow, _init_couplings(flow, gen, lambda c: ((3 * K - 1) * c,)))
+
+
+def planarflow(q0: MvNormal, nlayers: int, *, paramtype=torch.float64, device="cuda", seed: int = 0) -> Flow:
+    """planarflow(q0, nlayers; paramtype)  (src/flows/planar_radial.jl:21-29)."""
+    flow = Flow("planar", q0, nlayers, dtype=paramtype, device=device)
+    gen = torch.Generator().manual_seed(seed)
+    return _finish(flow, torch.randn(flow.P, generator=gen, dtype=torch.float64))
+
+
+def radialflow(q0: MvNormal, nlayers: int, *, paramtype=torch.float64, device="cuda", seed: int = 0) -> Flow:
+    """radialflow(q0, nlayers; paramtype)  (src/flows/planar_radial.jl:52-60)."""
+    flow = Flow("radial", q0, nlayers, dtype=paramtype, device=device)
+    gen = torch.Generator().manual_seed(seed)
+    return _finish(flow, torch.randn(flow.P, generator=gen, dtype=torch.float64))
+
+
+def meanfield(q0: MvNormal, *, paramtype=torch.float64, device="cuda") -> Flow:
+    """transformed(q0, Shift(zeros) o Scale(ones))  (test/interface.jl:22-25)."""
+    flow = Flow("meanfield", q0, 1, dtype=paramtype, device=device)
+    d = q0.d
+    return _finish(flow, torch.cat([torch.zeros(d, dtype=torch.float64), torch.ones(d, dtype=torch.float64)]))
+
+
+# --------------------------------------------------------------------------------------
+# built-in targets (the `logp` closures of the reference's tests / demos)
+# --------------------------------------------------------------------------------------
+class DiagGaussTarget:
+    """logp(z) = logpdf(MvNormal(mu, Diagonal(var)), z)  (test/flow.jl:43-46)."""
+
+    def __init__(self, mu: torch.Tensor, var: torch.Tensor):
+        self.mu, self.var = mu.contiguous(), var.contiguous()
+        self.c = Target(_lib.NF_TARGET_DIAGGAUSS, self.mu.data_ptr(), self.var.data_ptr(), 0.0, 0.0)
+
+    def __call__(self, ys):
+        return target_logp(self, ys)
+
+
+class BananaTarget:
+    """Banana(d, b, var)  (example/targets/banana.jl; demo_planar_flow.jl:16)."""
+
+    def __init__(self, d: int, b: float, var: float):
+        self.d, self.b, self.variance = d, float(b), float(var)
+        self.c = Target(_lib.NF_TARGET_BANANA, 0, 0, self.b, self.variance)
+
+    def __call__(self, ys):
+        return target_logp(self, ys)
+
+
+def target_logp(target, ys: torch.Tensor, with_grad: bool = False):
+    ym, vec = as_batch(ys)
+    d, n = ym.shape
+    out = torch.empty(n, dtype=ym.dtype, device=ym.device)
+    grad = new_batch(d, n, ym.dtype, ym.device) if with_grad else None
+    ctx = context_for(ym.device)
+    check(ctx.lib.nf_target_logp(ctx.ptr, _dtype_code(ym.dtype), C.byref(target.c), d, n, _ptr(ym), _ptr(out), _ptr(grad)))
+    res = out[0] if vec else out
+    return (res, grad) if with_grad else res

@@ -1,0 +1,236 @@
+"""Variational objectives and the training loop: host mirror of
+src/objectives/elbo.jl, src/objectives/loglikelihood.jl, src/optimize.jl and
+src/NormalizingFlows.jl:train_flow.  The arithmetic runs in libnfhip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Callable, Optional
+
+import torch
+
+from ._lib import NFHipError, check
+from .flows import (BananaTarget, DiagGaussTarget, Flow, PhiloxRNG, _dtype_code, _ptr, as_batch, base_logpdf,
+                    device_specific_rand, new_batch, with_logabsdet_jacobian)
+
+_BUILTIN = (DiagGaussTarget, BananaTarget)
+
+
+def _host_double():
+    return C.c_double(0.0)
+
+
+# --------------------------------------------------------------------------------------
+# reverse KL
+# --------------------------------------------------------------------------------------
+def batched_elbos(flow: Flow, logp, xs: torch.Tensor) -> torch.Tensor:
+    """_batched_elbos(flow, logp, xs)  (src/objectives/elbo.jl:65-70)."""
+    xm, _ = as_batch(xs.to(flow.theta.dtype))
+    d, n = xm.shape
+    if isinstance(logp, _BUILTIN):
+        out = torch.empty(n, dtype=xm.dtype, device=xm.device)
+        val = _host_double()
+        ctx = flow.ctx
+        check(ctx.lib.nf_elbo_batch(ctx.ptr, C.byref(flow.desc), C.byref(logp.c), _ptr(flow.theta), _ptr(xm), n,
+                                    _ptr(out), C.byref(val)))
+        return out
+    ys, ladj = with_logabsdet_jacobian(flow.transform, xm)
+    return logp(ys) - base_logpdf(flow.dist, xm) + ladj
+
+
+def elbo_batch(*args):
+    """elbo_batch(flow, logp, xs) / elbo_batch([rng,] flow, logp, n_samples)
+    (src/objectives/elbo.jl:89-99)."""
+    rng, flow, logp, last = _split_args(args)
+    if isinstance(last, int):
+        if isinstance(logp, _BUILTIN):
+            val = _host_double()
+            ctx = flow.ctx
+            check(ctx.lib.nf_elbo_batch_rng(ctx.ptr, C.byref(flow.desc), C.byref(logp.c), _ptr(flow.theta), last,
+                                            rng.seed, rng.sample_offset, rng.next_stream(), C.byref(val)))
+            return val.value
+        last = device_specific_rand(rng, flow.dist, last, device=flow.theta.device, dtype=flow.theta.dtype)
+    xm, _ = as_batch(last.to(flow.theta.dtype))
+    if isinstance(logp, _BUILTIN):
+        val = _host_double()
+        ctx = flow.ctx
+        check(ctx.lib.nf_elbo_batch(ctx.ptr, C.byref(flow.desc), C.byref(logp.c), _ptr(flow.theta), _ptr(xm),
+                                    xm.shape[1], _ptr(None), C.byref(val)))
+        return val.value
+    return float(batched_elbos(flow, logp, xm).double().mean())
+
+
+def elbo(*args):
+    """elbo(flow, logp, xs) / elbo([rng,] flow, logp, n_samples): per-column map of
+    elbo_single_sample (src/objectives/elbo.jl:4-7,26-46).  Each column goes through the same
+    kernels as the batched path with N = 1, so the value equals elbo_batch up to summation order."""
+    rng, flow, logp, last = _split_args(args)
+    if isinstance(last, int):
+        last = device_specific_rand(rng, flow.dist, last, device=flow.theta.device, dtype=flow.theta.dtype)
+    xm, _ = as_batch(last.to(flow.theta.dtype))
+    vals = [float(batched_elbos(flow, logp, xm[:, j : j + 1])[0]) for j in range(xm.shape[1])]
+    return sum(vals) / len(vals)
+
+
+def _split_args(args):
+    if isinstance(args[0], PhiloxRNG):
+        rng, flow, logp, last = args
+    else:
+        from .flows import _default_rng
+
+        rng = _default_rng
+        flow, logp, last = args
+    return rng, flow, logp, last
+
+
+# --------------------------------------------------------------------------------------
+# forward KL
+# --------------------------------------------------------------------------------------
+def loglikelihood(rng, flow: Flow, xs: torch.Tensor) -> float:
+    """loglikelihood(rng, flow, xs)  (src/objectives/loglikelihood.jl:26-33); `rng` is the
+    unused placeholder argument the reference keeps for a uniform objective signature."""
+    xm, _ = as_batch(xs.to(flow.theta.dtype))
+    val = _host_double()
+    ctx = flow.ctx
+    check(ctx.lib.nf_loglikelihood(ctx.ptr, C.byref(flow.desc), _ptr(flow.theta), _ptr(xm), xm.shape[1], _ptr(None),
+                                   C.byref(val)))
+    return val.value
+
+
+# --------------------------------------------------------------------------------------
+# gradients (the device analogue of _value_and_gradient, src/optimize.jl:12-14)
+# --------------------------------------------------------------------------------------
+def value_and_gradient(vo, flow: Flow, logp, xs_or_n, rng: Optional[PhiloxRNG] = None, n_global: Optional[int] = None):
+    """(loss, grad) of loss(theta) = -vo(rng, re(theta), logp, ...) (src/NormalizingFlows.jl:69).
+
+    Built-in targets run the whole step inside the library (nf_elbo_value_and_grad).  An
+    arbitrary `logp` callable takes the split path: library forward, the callable's own
+    torch-autograd gradient w.r.t. ys, library pullback (nf_flow_bwd).
+    Returns (loss: float, grad: tensor[P]) -- for a shard of a global batch pass n_global and
+    all-reduce the returned grad and loss over ranks.
+    """
+    if vo not in (elbo, elbo_batch):
+        raise NFHipError("value_and_gradient supports elbo and elbo_batch")
+    dt, dev = flow.theta.dtype, flow.theta.device
+    ctx = flow.ctx
+    P = flow.P
+    if isinstance(xs_or_n, int):
+        n = xs_or_n
+        xm = None
+    else:
+        xm, _ = as_batch(xs_or_n.to(dt))
+        n = xm.shape[1]
+    ng = n if n_global is None else int(n_global)
+    rng = rng if rng is not None else PhiloxRNG(0)
+    if isinstance(logp, _BUILTIN):
+        out = torch.empty(P + 1, dtype=dt, device=dev)
+        check(ctx.lib.nf_elbo_value_and_grad(ctx.ptr, C.byref(flow.desc), C.byref(logp.c), _ptr(flow.theta), _ptr(xm), n,
+                                             ng, rng.seed, rng.sample_offset, rng.next_stream() if xm is None else 0,
+                                             _ptr(out)))
+        return float(out[P]), out[:P]
+    # generic closure
+    if xm is None:
+        xm = device_specific_rand(rng, flow.dist, n, device=dev, dtype=dt)
+    ys, ladj = with_logabsdet_jacobian(flow.transform, xm)
+    yreq = ys.detach().clone().requires_grad_(True)
+    lp = logp(yreq)
+    (glp,) = torch.autograd.grad(lp.sum(), yreq)
+    elbos = lp.detach() - base_logpdf(flow.dist, xm) + ladj
+    ybar, _ = as_batch((-glp / ng).to(dt))
+    lbar = torch.full((n,), -1.0 / ng, dtype=dt, device=dev)
+    xbar = new_batch(xm.shape[0], n, dt, dev)
+    g = torch.empty(P, dtype=dt, device=dev)
+    check(ctx.lib.nf_flow_bwd(ctx.ptr, C.byref(flow.desc), _ptr(flow.theta), _ptr(xm), _ptr(ys), _ptr(ybar), _ptr(lbar),
+                              n, _ptr(xbar), _ptr(g)))
+    return float(-elbos.double().sum() / ng), g
+
+
+# --------------------------------------------------------------------------------------
+# optimiser + training loop
+# --------------------------------------------------------------------------------------
+@dataclass
+class Adam:
+    """Optimisers.Adam(eta, beta, epsilon)"""
+
+    eta: float = 1e-3
+    beta: tuple = (0.9, 0.999)
+    epsilon: float = 1e-8
+
+
+@dataclass
+class AdamState:
+    """st returned by optimize: Adam moments and step count (src/optimize.jl:106-107)."""
+
+    m: torch.Tensor
+    v: torch.Tensor
+    t: int = 0
+
+
+def adam_update(opt: Adam, st: AdamState, theta: torch.Tensor, g: torch.Tensor, want_norm: bool = True):
+    """Optimisers.update!(st, theta, g)  (src/optimize.jl:99); also returns norm(g) (:89)."""
+    from ._lib import context_for
+
+    ctx = context_for(theta.device)
+    st.t += 1
+    gn = torch.empty(1, dtype=theta.dtype, device=theta.device) if want_norm else None
+    check(ctx.lib.nf_adam_update(ctx.ptr, _dtype_code(theta.dtype), _ptr(theta), _ptr(g), _ptr(st.m), _ptr(st.v),
+                                 theta.numel(), opt.eta, opt.beta[0], opt.beta[1], opt.epsilon, st.t, _ptr(gn)))
+    return gn
+
+
+def optimize(loss_and_grad: Callable, theta0: torch.Tensor, reconstruct, *, max_iters: int = 10000,
+             optimiser: Adam = None, show_progress: bool = False, callback=None,
+             hasconverged=lambda i, stats, re, theta, st: False, all_reduce=None):
+    """optimize(adbackend, loss, theta0, re, args...; kwargs...)  (src/optimize.jl:57-108).
+    `loss_and_grad(theta) -> (loss, grad)` plays the role of DI.value_and_gradient(loss, ...).
+    `all_reduce(buf)` (optional) sums [grad ; loss] over data-parallel ranks."""
+    optimiser = optimiser or Adam()
+    theta = theta0.clone()
+    st = AdamState(torch.zeros_like(theta), torch.zeros_like(theta), 0)
+    opt_stats = []
+    converged = False
+    i = 1
+    while i <= max_iters and not converged:
+        ls, g = loss_and_grad(theta)
+        if all_reduce is not None:
+            buf = torch.cat([g, torch.tensor([ls], dtype=g.dtype, device=g.device)])
+            all_reduce(buf)
+            g, ls = buf[:-1], float(buf[-1])
+        gn = adam_update(optimiser, st, theta, g)
+        stat = {"iteration": i, "loss": ls, "gradient_norm": float(gn)}
+        if callback is not None:
+            new_stat = callback(i, opt_stats, reconstruct, theta)
+            if new_stat is not None:
+                stat.update(new_stat)
+        opt_stats.append(stat)
+        i += 1
+        converged = hasconverged(i, stat, reconstruct, theta, st)
+        if show_progress and (i % 100 == 0):
+            print(f"Training iter {i}: loss {ls:.6g} |g| {stat['gradient_norm']:.3g}")
+    return theta, opt_stats, st
+
+
+def train_flow(*args, max_iters: int = 1000, optimiser: Adam = None, ADbackend=None, **kwargs):
+    """train_flow([rng,] vo, flow, args...; max_iters, optimiser, ADbackend, kwargs...)
+    (src/NormalizingFlows.jl:51-86) -> (flow_trained, opt_stats, st).
+
+    `ADbackend` is accepted for signature compatibility; gradients come from the library's
+    hand-derived reverse pass (the role a custom ADTypes backend plays in the reference)."""
+    if isinstance(args[0], PhiloxRNG):
+        rng, vo, flow, *rest = args
+    else:
+        rng = PhiloxRNG(0)
+        vo, flow, *rest = args
+    theta_flat, re = flow.destructure()
+
+    def loss_and_grad(theta):
+        f = re(theta)
+        if vo in (elbo, elbo_batch):
+            logp, n = rest
+            return value_and_gradient(vo, f, logp, n, rng)
+        raise NFHipError("train_flow: objective has no device gradient yet")
+
+    theta, stats, st = optimize(loss_and_grad, theta_flat, re, max_iters=max_iters, optimiser=optimiser, **kwargs)
+    return re(theta), stats, st

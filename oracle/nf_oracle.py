@@ -821,7 +821,8 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 def base_sample(d: int, n: int, seed: int, sample_offset: int = 0, stream: int = 0, dtype=np.float64):
     """x ~ N(0, I) of shape (d, n).  Features are generated four at a time:
     counter = (global_sample_lo, global_sample_hi, feature_group, stream),
-    key = (seed_lo, seed_hi); u = (r >> 8 + 0.5) * 2^-24; Box-Muller on
+    key = (seed_lo, seed_hi); u = ((r >> 9) + 0.5) * 2^-23 (exactly representable in
+    fp32, so the fp32 and fp64 device paths see identical uniforms); Box-Muller on
     (u0,u1) -> features 4g, 4g+1 and (u2,u3) -> 4g+2, 4g+3.  The global sample
     index makes the batch invariant to how it is sharded over GPUs."""
     ng = (d + 3) // 4
@@ -835,7 +836,7 @@ def base_sample(d: int, n: int, seed: int, sample_offset: int = 0, stream: int =
         np.uint32(seed & 0xFFFFFFFF),
         np.uint32((seed >> 32) & 0xFFFFFFFF),
     )
-    u = [((ri >> np.uint32(8)).astype(np.float64) + 0.5) * (2.0**-24) for ri in r]
+    u = [((ri >> np.uint32(9)).astype(np.float64) + 0.5) * (2.0**-23) for ri in r]
     out = np.empty((n, ng, 4), dtype=np.float64)
     for a in (0, 1):
         rad = np.sqrt(-2.0 * np.log(u[2 * a]))

@@ -1,0 +1,68 @@
+"""Generates the committed golden fixtures tests/golden/*.npz from the CPU oracle
+(oracle/nf_oracle.py, float64).  Run from the repo root:  python tests/golden/make_golden.py
+
+The reference itself (Julia) cannot run in the build container and ships no golden vectors
+(SURVEY.md 8c), so these vectors pin the HIP path to the oracle, and the oracle is pinned by
+tests/test_oracle.py.  Each fixture holds: flow spec, theta, base draws xs, ys, ladj, per-sample
+elbos, loss = -elbo_batch, grad, and theta after one Adam(1e-3) step.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", "..", "oracle"))
+import nf_oracle as o  # noqa: E402
+
+CASES = {
+    # name: (spec, N, target kind, storage dtype of inputs)
+    "realnvp_d5_h32": (o.FlowSpec("realnvp", 5, 2, (32, 32)), 10, "diaggauss", np.float32),  # test/flow.jl:2-38
+    "realnvp_d64_h64": (o.FlowSpec("realnvp", 64, 4, (64, 64)), 96, "diaggauss", np.float32),  # cfg 2 shape
+    "realnvp_d64_h32": (o.FlowSpec("realnvp", 64, 1, (32, 32)), 33, "diaggauss", np.float32),
+    "planar_d2_banana": (o.FlowSpec("planar", 2, 10), 64, "banana", np.float64),  # cfg 1
+    "planar_d5": (o.FlowSpec("planar", 5, 10), 10, "diaggauss", np.float32),  # test/flow.jl:137
+    "radial_d5": (o.FlowSpec("radial", 5, 10), 10, "diaggauss", np.float32),  # test/flow.jl:203
+    "meanfield_d4": (o.FlowSpec("meanfield", 4, 1), 16, "diaggauss", np.float64),
+    "nsf_d5_k10": (o.FlowSpec("nsf", 5, 2, (32, 32), K=10, B=5.0), 10, "diaggauss", np.float32),  # test/flow.jl:68
+    "nsf_d32_k8": (o.FlowSpec("nsf", 32, 1, (32, 32), K=8, B=5.0), 40, "diaggauss", np.float32),  # cfg 3 shape
+}
+
+
+def main():
+    for name, (spec, n, tkind, dt) in CASES.items():
+        rng = np.random.default_rng(abs(hash(name)) % (2**31) if False else sum(map(ord, name)))
+        theta = o.init_params(spec, rng)
+        if spec.kind in ("realnvp", "nsf"):
+            theta = theta + 0.05 * rng.standard_normal(theta.shape)  # non-zero biases
+        if spec.kind == "meanfield":
+            theta = theta + 0.3 * rng.standard_normal(theta.shape)
+        theta = theta.astype(dt).astype(np.float64)  # values exactly representable in the storage dtype
+        xs = o.base_sample(spec.d, n, seed=123).astype(dt).astype(np.float64)
+        if tkind == "diaggauss":
+            mu = rng.standard_normal(spec.d).astype(dt).astype(np.float64)
+            var = (rng.uniform(size=spec.d) + 0.5).astype(dt).astype(np.float64)
+            tgt = ("diaggauss", mu, var)
+            tp = np.stack([mu, var])
+        else:
+            tgt = ("banana", 1.0, 10.0)  # Banana(2, 1.0, 10.0): example/demo_planar_flow.jl:16
+            tp = np.array([[1.0], [10.0]])
+        ys, ladj = o.flow_fwd(spec, theta, xs)
+        xr, ladj_inv = o.flow_inv(spec, theta, ys)
+        elbos = o.batched_elbos(spec, theta, tgt, xs)
+        loss, grad = o.neg_elbo_value_and_grad(spec, theta, tgt, xs)
+        th1 = theta.copy()
+        o.adam_update(th1, grad, np.zeros_like(theta), np.zeros_like(theta), 1)
+        ll = o.loglikelihood(spec, theta, ys)
+        np.savez_compressed(
+            os.path.join(HERE, name + ".npz"),
+            kind=spec.kind, d=spec.d, nlayers=spec.nlayers, hdims=np.array(spec.hdims, dtype=np.int64), K=spec.K,
+            B=spec.B, dtype=np.dtype(dt).name, target=tkind, target_params=tp,
+            theta=theta.astype(dt), xs=xs.astype(dt), ys=ys, ladj=ladj, ladj_inv=ladj_inv, elbos=elbos, loss=loss,
+            grad=grad.astype(dt), theta_adam1=th1.astype(dt), loglik_of_ys=ll,
+        )
+        print(f"{name}: P={theta.size} N={n} loss={loss:.6f} |g|inf={np.abs(grad).max():.3e} inv_err={np.abs(xr-xs).max():.1e}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,100 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/nfhip.h declares, the layout functions (host-only, no GPU) agree with the oracle, the
+golden fixtures are what the oracle produces, and the product package never imports oracle/."""
+import ctypes as C
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+
+import nf_oracle as o
+from __graft_entry__ import ROOT, build, load_package
+
+
+@pytest.fixture(scope="module")
+def nf():
+    build()  # no-op when libnfhip.so is up to date
+    return load_package()
+
+
+def test_header_symbols_all_exported(nf):
+    hdr = open(os.path.join(ROOT, "include", "nfhip.h")).read()
+    declared = set(re.findall(r"^(?:int|int32_t|int64_t|const char \*)\s*\*?\s*(nf_\w+)\s*\(", hdr, re.M))
+    assert len(declared) >= 20
+    lib = C.CDLL(nf.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"libnfhip.so does not export {name}"
+    assert declared == set(nf.SYMBOLS), declared ^ set(nf.SYMBOLS)
+    assert nf.load_library().nf_abi_version() == 1
+
+
+def _desc(nf, kind, d, nlayers, hdims=(), K=0, B=0.0, dtype=0):
+    from normalizingflows_jl_amd._lib import NF_KIND, FlowDesc
+
+    desc = FlowDesc()
+    desc.kind, desc.dtype, desc.d, desc.nlayers, desc.n_hidden, desc.K, desc.B = NF_KIND[kind], dtype, d, nlayers, len(hdims), K, B
+    for i, h in enumerate(hdims):
+        desc.hdims[i] = h
+    return desc
+
+
+@pytest.mark.parametrize(
+    "spec",
+    [
+        o.FlowSpec("realnvp", 64, 4, (64, 64)),
+        o.FlowSpec("realnvp", 64, 4, (32, 32)),
+        o.FlowSpec("realnvp", 5, 2, (32, 32)),
+        o.FlowSpec("realnvp", 256, 8, (256, 256)),
+        o.FlowSpec("nsf", 32, 4, (32, 32), K=8, B=5.0),
+        o.FlowSpec("nsf", 5, 2, (32, 32), K=10, B=5.0),
+        o.FlowSpec("planar", 2, 10),
+        o.FlowSpec("radial", 5, 10),
+        o.FlowSpec("meanfield", 4, 1),
+    ],
+)
+def test_param_count_matches_oracle_layout(nf, spec):
+    lib = nf.load_library()
+    desc = _desc(nf, spec.kind, spec.d, spec.nlayers, spec.hdims, spec.K, spec.B)
+    assert lib.nf_param_count(C.byref(desc)) == o.param_count(spec)
+    assert lib.nf_layer_count(C.byref(desc)) == len(o.layers_flat_order(spec))
+
+
+def test_error_conventions(nf):
+    lib = nf.load_library()
+    assert lib.nf_param_count(None) < 0
+    bad = _desc(nf, "planar", 2, 1)
+    bad.kind = 99
+    assert lib.nf_param_count(C.byref(bad)) < 0
+    assert b"invalid argument" in lib.nf_strerror(-1)
+    assert b"not built" in lib.nf_strerror(-2)
+    assert lib.nf_ctx_destroy(None) == -1
+
+
+def test_golden_fixtures_are_oracle_outputs():
+    files = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "*.npz")))
+    assert len(files) >= 7
+    for f in files:
+        z = np.load(f)
+        spec = o.FlowSpec(str(z["kind"]), int(z["d"]), int(z["nlayers"]), tuple(int(h) for h in z["hdims"]), int(z["K"]), float(z["B"]))
+        th, xs = z["theta"].astype(np.float64), z["xs"].astype(np.float64)
+        ys, ladj = o.flow_fwd(spec, th, xs)
+        np.testing.assert_allclose(ys, z["ys"], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(ladj, z["ladj"], rtol=1e-12, atol=1e-12)
+
+
+def test_product_does_not_import_oracle():
+    for f in glob.glob(os.path.join(ROOT, "normalizingflows.jl_amd", "**", "*"), recursive=True):
+        if f.endswith((".py", ".hip", ".h")):
+            src = open(f).read()
+            assert "import nf_oracle" not in src and "from oracle" not in src, f
+
+
+def test_missing_library_fails_loudly(nf, monkeypatch):
+    from normalizingflows_jl_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libnfhip.so")
+    with pytest.raises(nf.NFHipError):
+        _lib.load_library()

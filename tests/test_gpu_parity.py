@@ -1,0 +1,243 @@
+"""GPU parity tests (`-m gpu`): the HIP path, called through the C ABI, against the CPU oracle
+and the committed golden fixtures, plus the reference's own property tests.
+
+Stated tolerances (fp32 device arithmetic vs float64 oracle):
+  per-sample y / ladj : norm-wise rtol 2e-5  (isapprox semantics, as the reference tests use)
+  ELBO / loss         : rtol 2e-5
+  gradient            : max-abs error <= 2e-4 * ||g||_inf
+  float64 paths       : rtol 1e-10
+  invertibility       : the reference's own tolerances (test/flow.jl: 1e-6 RealNVP Float64;
+                        for Float32 we use 2e-5, fp32 round-off through 4-8 couplings)
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import nf_oracle as o
+from __graft_entry__ import ROOT, load_package
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+GOLDEN = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "*.npz")))
+
+
+@pytest.fixture(scope="module")
+def nf():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return load_package()
+
+
+def approx(a, b, rtol):
+    """Julia isapprox: norm(a-b) <= rtol * max(norm(a), norm(b))."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) <= rtol * max(np.linalg.norm(a), np.linalg.norm(b)) + 1e-30
+
+
+def tdt(name):
+    return torch.float32 if name == "float32" else torch.float64
+
+
+def cm(a, dt, dev="cuda"):
+    """numpy (d, N) -> column-major torch (d, N)"""
+    return torch.tensor(np.ascontiguousarray(a.T), dtype=dt, device=dev).t()
+
+
+def load_case(nf, path):
+    z = np.load(path)
+    dt = tdt(str(z["dtype"]))
+    kind, d, nl = str(z["kind"]), int(z["d"]), int(z["nlayers"])
+    hd, K, B = tuple(int(h) for h in z["hdims"]), int(z["K"]), float(z["B"])
+    theta = torch.tensor(z["theta"], dtype=dt, device="cuda")
+    flow = nf.Flow(kind, nf.MvNormal(d), nl, hd, K, B, dtype=dt, device="cuda", theta=theta)
+    if str(z["target"]) == "diaggauss":
+        tgt = nf.DiagGaussTarget(torch.tensor(z["target_params"][0], dtype=dt, device="cuda"),
+                                 torch.tensor(z["target_params"][1], dtype=dt, device="cuda"))
+        otgt = ("diaggauss", z["target_params"][0], z["target_params"][1])
+    else:
+        tgt = nf.BananaTarget(d, float(z["target_params"][0, 0]), float(z["target_params"][1, 0]))
+        otgt = ("banana", float(z["target_params"][0, 0]), float(z["target_params"][1, 0]))
+    spec = o.FlowSpec(kind, d, nl, hd, K, B)
+    return z, dt, flow, tgt, spec, otgt
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_golden_forward_inverse_elbo_grad_adam(nf, path):
+    z, dt, flow, tgt, spec, otgt = load_case(nf, path)
+    f64 = dt == torch.float64
+    rt = 1e-10 if f64 else 2e-5
+    xs = cm(z["xs"], dt)
+    try:
+        ys, ladj = nf.with_logabsdet_jacobian(flow.transform, xs)
+    except nf.NFHipError as e:  # shapes the library does not build yet are reported, not hidden
+        if "not built" in str(e):
+            pytest.skip(f"{flow.kind}: {e}")
+        raise
+    assert ys.shape == xs.shape and ladj.shape == (xs.shape[1],) and ys.dtype == dt  # test/flow.jl:17-21
+    assert approx(ys.cpu().numpy(), z["ys"], rt)
+    assert approx(ladj.cpu().numpy(), z["ladj"], rt)
+    # inverse: x ~= inv(fwd(x)), lj_fwd ~= -lj_bwd   (test/flow.jl:26-38)
+    xr, lb = nf.with_logabsdet_jacobian(nf.inverse(flow.transform), ys)
+    inv_rt = 1e-9 if f64 else (2e-4 if flow.kind in ("nsf", "planar", "radial") else 2e-5)
+    assert approx(xr.cpu().numpy(), z["xs"], inv_rt)
+    assert approx(lb.cpu().numpy(), -z["ladj"], inv_rt)
+    # objective values
+    el = nf.batched_elbos(flow, tgt, xs)
+    assert approx(el.cpu().numpy(), z["elbos"], rt)
+    assert nf.elbo_batch(flow, tgt, xs) == pytest.approx(-float(z["loss"]), rel=rt)
+    ll = nf.loglikelihood(None, flow, ys)
+    assert ll == pytest.approx(float(z["loglik_of_ys"]), rel=10 * rt, abs=10 * rt)
+    # loss + gradient of -elbo_batch, then one Adam step
+    loss, g = nf.value_and_gradient(nf.elbo_batch, flow, tgt, xs)
+    assert loss == pytest.approx(float(z["loss"]), rel=rt)
+    gref = z["grad"].astype(np.float64)
+    gerr = np.abs(g.cpu().numpy() - gref).max() / np.abs(gref).max()
+    assert gerr < (1e-9 if f64 else 2e-4), gerr
+    theta = flow.theta.clone()
+    st = nf.AdamState(torch.zeros_like(theta), torch.zeros_like(theta), 0)
+    gn = nf.adam_update(nf.Adam(1e-3), st, theta, g)
+    assert float(gn) == pytest.approx(np.linalg.norm(gref), rel=1e-4)
+    np.testing.assert_allclose(theta.cpu().numpy(), z["theta_adam1"], rtol=0, atol=(1e-12 if f64 else 2e-6))
+
+
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 257])
+def test_ragged_batches_and_vector_input(nf, n):
+    """N not a multiple of the 32-sample wave tile; a vector equals a 1-column matrix
+    (test/flow.jl:26-31,53-55; src/flows/neuralspline.jl:76)."""
+    spec = o.FlowSpec("realnvp", 7, 1, (16, 16))
+    rng = np.random.default_rng(n)
+    th = o.init_params(spec, rng) + 0.05 * rng.standard_normal(o.param_count(spec))
+    flow = nf.Flow("realnvp", nf.MvNormal(7), 1, (16, 16), dtype=torch.float32, device="cuda",
+                   theta=torch.tensor(th, dtype=torch.float32, device="cuda"))
+    xs = rng.standard_normal((7, n)).astype(np.float32)
+    ys_ref, l_ref = o.flow_fwd(spec, th.astype(np.float32).astype(np.float64), xs.astype(np.float64))
+    ys, ladj = nf.with_logabsdet_jacobian(flow.transform, cm(xs, torch.float32))
+    assert approx(ys.cpu().numpy(), ys_ref, 2e-5) and approx(ladj.cpu().numpy(), l_ref, 2e-5)
+    yv, lv = nf.with_logabsdet_jacobian(flow.transform, torch.tensor(xs[:, 0], device="cuda"))
+    assert yv.shape == (7,) and lv.dim() == 0
+    np.testing.assert_array_equal(yv.cpu().numpy(), ys[:, 0].cpu().numpy())
+    # gradient on a ragged batch
+    mu, var = rng.standard_normal(7), rng.uniform(size=7) + 0.5
+    tgt = nf.DiagGaussTarget(torch.tensor(mu, dtype=torch.float32, device="cuda"), torch.tensor(var, dtype=torch.float32, device="cuda"))
+    loss, g = nf.value_and_gradient(nf.elbo_batch, flow, tgt, cm(xs, torch.float32))
+    l_ref, g_ref = o.neg_elbo_value_and_grad(spec, th.astype(np.float32).astype(np.float64),
+                                             ("diaggauss", mu.astype(np.float32).astype(np.float64), var.astype(np.float32).astype(np.float64)),
+                                             xs.astype(np.float64))
+    assert loss == pytest.approx(l_ref, rel=2e-5)
+    assert np.abs(g.cpu().numpy() - g_ref).max() <= 2e-4 * np.abs(g_ref).max()
+
+
+def test_per_layer_apply_matches_chain(nf):
+    """with_logabsdet_jacobian on single bijectors composes to the flow (a6)."""
+    flow = nf.realnvp(nf.MvNormal(6), [32, 32], 2, paramtype=torch.float32, seed=3)
+    xs = nf.device_specific_rand(nf.PhiloxRNG(5), flow.dist, 50)
+    y, l = xs, torch.zeros(50, device="cuda")
+    for k in reversed(range(4)):
+        y, lk = nf.with_logabsdet_jacobian(nf.layer(flow, k), y)
+        l = l + lk
+    y2, l2 = nf.with_logabsdet_jacobian(flow.transform, xs)
+    assert approx(y.cpu().numpy(), y2.cpu().numpy(), 1e-6) and approx(l.cpu().numpy(), l2.cpu().numpy(), 1e-5)
+    xb, lb = nf.with_logabsdet_jacobian(nf.inverse(nf.layer(flow, 0)), y2)
+    yb, lf = nf.with_logabsdet_jacobian(nf.layer(flow, 0), xb)
+    assert approx(yb.cpu().numpy(), y2.cpu().numpy(), 1e-5) and approx(lb.cpu().numpy(), -lf.cpu().numpy(), 1e-5)
+
+
+def test_base_sampler_matches_spec_and_is_shard_invariant(nf):
+    d, n = 10, 1000
+    x = nf.device_specific_rand(nf.PhiloxRNG(123), nf.MvNormal(d), n).cpu().numpy()
+    ref = o.base_sample(d, n, seed=123)
+    np.testing.assert_allclose(x, ref, rtol=0, atol=3e-6)
+    r2 = nf.PhiloxRNG(123, sample_offset=600)
+    xb = nf.device_specific_rand(r2, nf.MvNormal(d), 400).cpu().numpy()
+    np.testing.assert_array_equal(xb, x[:, 600:])
+    x64 = nf.device_specific_rand(nf.PhiloxRNG(123), nf.MvNormal(d), n, dtype=torch.float64).cpu().numpy()
+    np.testing.assert_allclose(x64, ref, rtol=0, atol=1e-13)
+    lq = nf.logpdf(nf.MvNormal(d), torch.tensor(x64.T.copy(), device="cuda").t()).cpu().numpy()
+    np.testing.assert_allclose(lq, o.std_normal_logpdf(ref), rtol=1e-12)
+    big = nf.device_specific_rand(nf.PhiloxRNG(7), nf.MvNormal(64), 65536)
+    assert abs(float(big.mean())) < 2e-3 and abs(float(big.var()) - 1.0) < 5e-3
+
+
+def test_elbo_of_exact_posterior_is_zero(nf):
+    """test/objectives.jl:3-25 on the device: flow == target => every ELBO term is 0."""
+    for dt, tol in ((torch.float32, 1e-5), (torch.float64, 1e-12)):
+        mu = torch.randn(2, dtype=dt, device="cuda")
+        var = torch.rand(2, dtype=dt, device="cuda") + 1e-3
+        flow = nf.meanfield(nf.MvNormal(2), paramtype=dt).with_theta(torch.cat([mu, var.sqrt()]))
+        tgt = nf.DiagGaussTarget(mu, var)
+        rng = nf.PhiloxRNG(1)
+        assert abs(nf.elbo(rng, flow, tgt, 10)) <= tol
+        assert abs(nf.elbo_batch(rng, flow, tgt, 10)) <= tol
+        x = torch.randn(2, dtype=dt, device="cuda")
+        assert float(nf.logpdf(flow, x)) == pytest.approx(float(tgt(x)), rel=1e-5)
+
+
+def test_elbo_equals_elbo_batch_and_rng_forms(nf):
+    flow = nf.realnvp(nf.MvNormal(5), [32, 32], 2, paramtype=torch.float32, seed=0)
+    tgt = nf.DiagGaussTarget(torch.randn(5, device="cuda"), torch.rand(5, device="cuda") + 1e-3)
+    xs = nf.device_specific_rand(nf.PhiloxRNG(2), flow.dist, 64)
+    a, b = nf.elbo(flow, tgt, xs), nf.elbo_batch(flow, tgt, xs)
+    assert np.isfinite(a) and np.isfinite(b) and a == pytest.approx(b, rel=1e-5)
+    assert np.isfinite(nf.elbo(nf.PhiloxRNG(3), flow, tgt, 1))  # batchsize 1 (test/flow.jl:53-55)
+    # in-library draws == caller-supplied draws from the same RNG state
+    v1 = nf.elbo_batch(nf.PhiloxRNG(9), flow, tgt, 128)
+    v2 = nf.elbo_batch(flow, tgt, nf.device_specific_rand(nf.PhiloxRNG(9), flow.dist, 128))
+    assert v1 == pytest.approx(v2, rel=1e-6)
+
+
+def test_generic_logp_closure_path_matches_builtin(nf):
+    """arbitrary `logp` callable: library forward + closure's autograd + library pullback."""
+    flow = nf.realnvp(nf.MvNormal(6), [32, 32], 1, paramtype=torch.float32, seed=4)
+    mu, var = torch.randn(6, device="cuda"), torch.rand(6, device="cuda") + 0.5
+    tgt = nf.DiagGaussTarget(mu, var)
+
+    def logp(ys):
+        return (-0.5 * (np.log(2 * np.pi) + var.log())[:, None] - 0.5 * (ys - mu[:, None]) ** 2 / var[:, None]).sum(0)
+
+    xs = nf.device_specific_rand(nf.PhiloxRNG(11), flow.dist, 100)
+    l1, g1 = nf.value_and_gradient(nf.elbo_batch, flow, tgt, xs)
+    l2, g2 = nf.value_and_gradient(nf.elbo_batch, flow, logp, xs)
+    assert l1 == pytest.approx(l2, rel=1e-5)
+    assert float((g1 - g2).abs().max()) <= 1e-4 * float(g1.abs().max())
+
+
+def test_train_meanfield_recovers_target(nf):
+    """test/interface.jl:14-50: mean-field VI to N(10*1, 4I), Adam(0.01)."""
+    for dt in (torch.float32, torch.float64):
+        flow = nf.meanfield(nf.MvNormal(2), paramtype=dt)
+        tgt = nf.DiagGaussTarget(torch.full((2,), 10.0, dtype=dt, device="cuda"), torch.full((2,), 4.0, dtype=dt, device="cuda"))
+        el0 = nf.elbo_batch(nf.PhiloxRNG(1), flow, tgt, 1000)
+        trained, stats, st = nf.train_flow(nf.PhiloxRNG(0), nf.elbo_batch, flow, tgt, 10, max_iters=3000,
+                                           optimiser=nf.Adam(0.01))
+        th = trained.theta.cpu().numpy()
+        assert np.all(np.abs(th[:2] - 10.0) < 0.2) and np.all(np.abs(th[2:] - 2.0) < 0.2)
+        el1 = nf.elbo_batch(nf.PhiloxRNG(1), trained, tgt, 1000)
+        assert el1 > el0 and el1 > -1.0
+        assert stats[-1]["iteration"] == 3000 and st.t == 3000 and "gradient_norm" in stats[0]
+
+
+def test_full_size_properties_cfg2(nf):
+    """BASELINE cfg 2 at full size (d=64, 8 couplings, h=64, N=65536): size-independent
+    properties -- round trip, ladj antisymmetry, in-library == supplied draws, finite loss/grad,
+    gradient consistent between two half-batches (linearity of the sum over samples)."""
+    d, n = 64, 65536
+    flow = nf.realnvp(nf.MvNormal(d), [64, 64], 4, paramtype=torch.float32, seed=123)
+    rng = np.random.default_rng(0)
+    tgt = nf.DiagGaussTarget(torch.tensor(rng.standard_normal(d), dtype=torch.float32, device="cuda"),
+                             torch.tensor(rng.uniform(size=d) + 1e-3 + 0.5, dtype=torch.float32, device="cuda"))
+    xs = nf.device_specific_rand(nf.PhiloxRNG(123), flow.dist, n)
+    ys, lf = nf.with_logabsdet_jacobian(flow.transform, xs)
+    xr, lb = nf.with_logabsdet_jacobian(nf.inverse(flow.transform), ys)
+    assert float((xr - xs).norm() / xs.norm()) < 2e-5
+    assert float((lf + lb).norm() / lf.norm().clamp_min(1e-6)) < 2e-5
+    loss, g = nf.value_and_gradient(nf.elbo_batch, flow, tgt, xs)
+    assert np.isfinite(loss) and bool(torch.isfinite(g).all())
+    la, ga = nf.value_and_gradient(nf.elbo_batch, flow, tgt, xs[:, : n // 2], n_global=n)
+    lb2, gb = nf.value_and_gradient(nf.elbo_batch, flow, tgt, xs[:, n // 2 :], n_global=n)
+    assert la + lb2 == pytest.approx(loss, rel=1e-5)
+    assert float((ga + gb - g).abs().max()) <= 1e-4 * float(g.abs().max())
+    l_rng, g_rng = nf.value_and_gradient(nf.elbo_batch, flow, tgt, n, rng=nf.PhiloxRNG(123))
+    assert l_rng == pytest.approx(loss, rel=1e-6)
+    assert float((g_rng - g).abs().max()) <= 1e-5 * float(g.abs().max())
