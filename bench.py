@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Benchmark of the reverse-KL (ELBO) training step on MI355X.
+
+One "step" = what one iteration of the reference's `optimize` loop does around
+`_value_and_gradient` (src/optimize.jl:85-99) for loss = -elbo_batch(rng, flow, logp, n):
+  draw n base samples (Philox, in-kernel) + log q0, flow forward + sum log|det J|, target logp,
+  mean, full reverse pass to grad theta, [all-reduce of [grad ; loss] when >1 GPU], Adam update
+  and gradient norm.
+
+Workload (BASELINE.json configs[1]): RealNVP, d = 64, 8 affine couplings (= realnvp(q0,
+[64, 64], 4)), 2-hidden-layer conditioners of width 64, batch 65 536 PER GPU (weak scaling),
+fp32, diag-Gaussian target, synthetic Glorot weights.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the coupling reverse
+pass, fp32 MFMA bound); `cpu_baseline` is the CPU oracle (a numpy/BLAS port of the reference
+algorithm; the Julia reference cannot run on this box) timed on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+
+D, HDIMS, NLAYERS, BATCH = 64, (64, 64), 4, 65536
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+# algorithmic flops of ONE coupling's reverse pass per sample (step 786 432 =
+# fwd 262 144 + dX 262 144 + dW 262 144 over 8 couplings; recompute is not counted)
+MACS_NET = 32 * 64 + 64 * 64 + 64 * 32
+FLOPS_BWD_PER_SAMPLE_PER_COUPLING = 2 * (2 * MACS_NET) * 2  # 2 nets x (dX + dW) x 2 flop/MAC = 65 536
+FLOPS_STEP_PER_SAMPLE = 786432
+
+
+def cpu_baseline(seconds_budget: float = 12.0):
+    """numpy (BLAS-threaded) port of the same step on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import nf_oracle as orc
+
+    try:
+        from threadpoolctl import threadpool_info
+
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count() or 1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    n = 8192
+    spec = orc.FlowSpec("realnvp", D, NLAYERS, HDIMS)
+    rng = np.random.default_rng(123)
+    theta = orc.init_params(spec, rng, dtype=np.float32)
+    mu = rng.standard_normal(D).astype(np.float32)
+    var = (rng.uniform(size=D) + 1e-3).astype(np.float32)
+    m, v = np.zeros_like(theta), np.zeros_like(theta)
+    reps, t_used = 0, 0.0
+    t_all0 = time.perf_counter()
+    while True:
+        t0 = time.perf_counter()
+        xs = rng.standard_normal((D, n)).astype(np.float32)  # the reference's randn-based draw
+        loss, g = orc.neg_elbo_value_and_grad(spec, theta, ("diaggauss", mu, var), xs)
+        orc.adam_update(theta, g.astype(np.float32), m, v, reps + 1)
+        gn = float(np.linalg.norm(g))
+        t_used += time.perf_counter() - t0
+        reps += 1
+        if time.perf_counter() - t_all0 > seconds_budget or reps >= 50:
+            break
+    return {
+        "value": n * reps / t_used,
+        "unit": "samples/s",
+        "cores": int(threads),
+        "kind": "port",
+        "sample": f"{reps} steps of batch {n} (same flow/target/dtype as the GPU workload), numpy float32 + BLAS, "
+                  f"{os.cpu_count()} host cpus visible",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=BATCH, help="samples per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+        local_rank = 0
+    dev = torch.device("cuda", local_rank)
+
+    nf = load_package()
+    lib = nf.load_library()
+    n_local, n_global = args.batch, args.batch * world
+    flow = nf.realnvp(nf.MvNormal(D), HDIMS, NLAYERS, paramtype=torch.float32, device=dev, seed=123)
+    g0 = torch.Generator().manual_seed(123)
+    mu = torch.randn(D, generator=g0).to(dev)
+    var = (torch.rand(D, generator=g0) + 1e-3).to(dev)
+    target = nf.DiagGaussTarget(mu, var)
+    ctx = nf.context_for(dev)
+    P = flow.P
+    theta = flow.theta.clone()
+    m, v = torch.zeros_like(theta), torch.zeros_like(theta)
+    out = torch.zeros(P + 1, dtype=torch.float32, device=dev)
+    gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+    vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    desc, tgt = C.byref(flow.desc), C.byref(target.c)
+
+    def step(i: int):
+        nf._lib.check(lib.nf_elbo_value_and_grad(ctx.ptr, desc, tgt, vp(theta), None, n_local, n_global, 123,
+                                                 rank * n_local, i, vp(out)))
+        if dist is not None:
+            dist.all_reduce(out)  # one RCCL all-reduce of [grad ; loss] (P + 1 floats)
+        nf._lib.check(lib.nf_adam_update(ctx.ptr, 0, vp(theta), vp(out), vp(m), vp(v), P, 1e-3, 0.9, 0.999, 1e-8,
+                                         i + 1, vp(gnorm)))
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    nf._lib.check(lib.nf_prof_enable(ctx.ptr, 1))  # HIP events on the launch stream, over the timed region
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    loss = float(out[P])
+    assert np.isfinite(loss) and np.isfinite(float(gnorm)), "non-finite loss / gradient norm"
+
+    avg_ms, cnt = C.c_double(0.0), C.c_int64(0)
+    nf._lib.check(lib.nf_prof_read(ctx.ptr, b"affine_bwd", C.byref(avg_ms), C.byref(cnt)))
+    kernel_ms = {}
+    for name in (b"base_sample", b"affine_apply", b"target", b"affine_bwd", b"reduce_slabs", b"adam"):
+        a, c = C.c_double(0.0), C.c_int64(0)
+        lib.nf_prof_read(ctx.ptr, name, C.byref(a), C.byref(c))
+        kernel_ms[name.decode()] = {"avg_ms": round(a.value, 5), "launches_per_step": c.value / max(1, args.steps)}
+    nf._lib.check(lib.nf_prof_enable(ctx.ptr, 0))
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = n_global * args.steps / elapsed
+        achieved = FLOPS_BWD_PER_SAMPLE_PER_COUPLING * n_local / (avg_ms.value * 1e-3) / 1e12 if avg_ms.value > 0 else 0.0
+        rec = {
+            "metric": "elbo_samples_per_sec",
+            "value": value,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "reverse-KL ELBO step: RealNVP d=64, 8 affine couplings, conditioner 32-64-64-32 "
+                            "(hdims [64,64]), diag-Gaussian target, Philox base draws, Adam",
+                "batch_per_gpu": n_local,
+                "global_batch": n_global,
+                "params": P,
+                "parallelism": f"dp{world} (sample-sharded, one all-reduce of P+1 floats per step)",
+                "final_loss": loss,
+            },
+            "roofline": {
+                "kernel": "k_affine_bwd (one coupling reverse pass: recompute + dX + dW)",
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                "traffic": None,
+                "avg_launch_ms": avg_ms.value,
+                "launches_timed": cnt.value,
+                "algorithmic_flop_per_launch": FLOPS_BWD_PER_SAMPLE_PER_COUPLING * n_local,
+                "whole_step_tflops": FLOPS_STEP_PER_SAMPLE * n_local / (ms_per_step * 1e-3) / 1e12,
+            },
+            "kernels": kernel_ms,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline()
+            rec["gpu_over_cpu"] = value / rec["cpu_baseline"]["value"]
+        print(json.dumps(rec))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -188,6 +188,9 @@ int nf_elbo_step(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target,
  * context stream since the last reset (used by bench.py's roofline object). */
 int nf_prof_enable(nf_ctx *ctx, int32_t on);
 int nf_prof_read(nf_ctx *ctx, const char *kernel_name, double *avg_ms_host, int64_t *count_host);
+/* Kernel-tuning aid: when on, block 0 / wave 0 of the coupling reverse pass writes s_memtime
+ * stamps at its phase boundaries; a later call copies up to 128 of them to stamps_host. */
+int nf_debug_trace(nf_ctx *ctx, int32_t on, int64_t *stamps_host, int32_t n);
 
 #ifdef __cplusplus
 }

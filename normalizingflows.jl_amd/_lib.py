@@ -76,6 +76,7 @@ SYMBOLS = {
     "nf_elbo_step": (C.c_int, [_P, _DESC, _TGT, _P, _P, _P, _I64, _U64, _U32, _D, _D, _D, _D, _PD, _PD]),
     "nf_prof_enable": (C.c_int, [_P, _I32]),
     "nf_prof_read": (C.c_int, [_P, C.c_char_p, _PD, C.POINTER(C.c_int64)]),
+    "nf_debug_trace": (C.c_int, [_P, _I32, C.POINTER(C.c_int64), _I32]),
 }
 
 _lib = None

@@ -17,11 +17,20 @@ long nf_adam_nblocks(long P);
 int nf_launch_adam(nf_ctx *, int, void *, const void *, void *, void *, long, double, double, double, double, long,
                    double *);
 int nf_launch_fill(nf_ctx *, int, void *, long, double);
+int nf_launch_base_sample_tiled(nf_ctx *, int d, long N, uint64_t seed, uint64_t off, uint32_t stream, float *xt, float *logq);
+int nf_launch_base_logpdf_tiled(nf_ctx *, int d, long N, const float *xt, float *logq);
+long nf_target_tiled_nblocks(long N);
+int nf_launch_target_tiled(nf_ctx *, const nf_target *, int d, long N, const float *yt, const float *logq,
+                           const float *ladj, float *gt, double gscale, float *elbos_out, double *partial, double pscale);
+int nf_launch_layout_convert(nf_ctx *, int d, long N, const float *src, float *dst, int to_tiled);
 
 bool nf_affine_supported(const nf_flow_desc *desc);
 int nf_affine_apply(nf_ctx *, const nf_flow_desc *, int k, bool inverse, const float *theta, const float *x, long N,
                     float *y, float *ladj, int accumulate);
 int nf_affine_bwd_grid(nf_ctx *, long N);
+int nf_affine_pack(nf_ctx *, const nf_flow_desc *, const float *theta);
+long nf_affine_slab_floats(const nf_flow_desc *desc);
+int nf_affine_reduce_slabs(nf_ctx *, const nf_flow_desc *, const float *slab, int nslab, float *g);
 int nf_affine_bwd(nf_ctx *, const nf_flow_desc *, int k, const float *theta, float *y, float *ybar, const float *lbar,
                   float lbar_const, long N, float *slab, long slab_stride, int grid);
 
@@ -158,6 +167,8 @@ extern "C" int nf_ctx_destroy(nf_ctx *ctx) {
     }
   if (ctx->ws) hipFree(ctx->ws);
   if (ctx->gbuf) hipFree(ctx->gbuf);
+  if (ctx->wimg) hipFree(ctx->wimg);
+  if (ctx->trace) hipFree(ctx->trace);
   if (ctx->host_scratch) hipHostFree(ctx->host_scratch);
   delete ctx;
   return NF_OK;
@@ -211,23 +222,37 @@ extern "C" int nf_base_logpdf(nf_ctx *ctx, int32_t dtype, int32_t d, int64_t N, 
 }
 
 // ---- transforms ----------------------------------------------------------------------------
-// applies couplings/layers in execution order (last flat layer first) or its inverse
-static int chain_apply(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, const void *theta, const void *x_in,
-                       long N, void *y_out, void *ladj) {
-  const size_t es = esize(desc->dtype);
+// Coupling flows work on the TILED batch layout internally (nf_elementwise.hip); user-facing
+// batches are converted at the API edge.  Element count of a tiled buffer:
+static inline size_t tiled_elems(const nf_flow_desc *desc, long N) { return (size_t)((N + 31) / 32) * 32 * desc->d; }
+static inline bool is_coupling(const nf_flow_desc *desc) { return desc->kind == NF_KIND_REALNVP; }
+
+// all couplings (or one, if k_only >= 0) in execution order / inverse order, in place on `xt`
+static int coupling_chain_tiled(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, const float *theta, float *xt,
+                                long N, float *ladj, int k_only) {
+  NF_TRY(nf_affine_pack(ctx, desc, theta));
+  if (k_only >= 0) return nf_affine_apply(ctx, desc, k_only, inverse, theta, xt, N, xt, ladj, 0);
+  const int nc = 2 * desc->nlayers;
+  for (int s = 0; s < nc; ++s) {
+    const int k = inverse ? s : nc - 1 - s;
+    NF_TRY(nf_affine_apply(ctx, desc, k, inverse, theta, xt, N, xt, ladj, s > 0));
+  }
+  return NF_OK;
+}
+
+// standard-layout in/out wrapper used by nf_flow_fwd / nf_flow_inv / nf_layer_apply
+static int apply_std(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, int layer, const void *theta,
+                     const void *x_in, long N, void *y_out, void *ladj) {
   if (N == 0) return NF_OK;
-  if (desc->kind == NF_KIND_REALNVP) {
-    const int nc = 2 * desc->nlayers;
-    if (y_out != x_in)
-      NF_HIP(hipMemcpyAsync(y_out, x_in, (size_t)N * desc->d * es, hipMemcpyDeviceToDevice, ctx->stream));
-    for (int s = 0; s < nc; ++s) {
-      const int k = inverse ? s : nc - 1 - s;
-      NF_TRY(nf_affine_apply(ctx, desc, k, inverse, (const float *)theta, (const float *)y_out, N, (float *)y_out,
-                             (float *)ladj, s > 0));
-    }
-    return NF_OK;
+  if (is_coupling(desc)) {
+    NF_TRY(nf_ws_reserve(ctx, carve_bytes(tiled_elems(desc, N) * 4)));
+    float *xt = (float *)ctx->ws;
+    NF_TRY(nf_launch_layout_convert(ctx, desc->d, N, (const float *)x_in, xt, 1));
+    NF_TRY(coupling_chain_tiled(ctx, desc, inverse, (const float *)theta, xt, N, (float *)ladj, layer));
+    return nf_launch_layout_convert(ctx, desc->d, N, xt, (float *)y_out, 0);
   }
   const int nl = nf_layer_count(desc);
+  if (layer >= 0) return nf_simple_apply(ctx, desc, layer, layer + 1, inverse, theta, x_in, N, y_out, ladj);
   return nf_simple_apply(ctx, desc, 0, nl, inverse, theta, x_in, N, y_out, ladj);
 }
 
@@ -236,7 +261,7 @@ extern "C" int nf_flow_fwd(nf_ctx *ctx, const nf_flow_desc *desc, const void *th
   if (!ctx || !theta || !x_in || !y_out || !ladj_out || N < 0) return NF_ERR_ARG;
   NF_TRY(check_desc(desc));
   NF_HIP(hipSetDevice(ctx->device));
-  return chain_apply(ctx, desc, false, theta, x_in, N, y_out, ladj_out);
+  return apply_std(ctx, desc, false, -1, theta, x_in, N, y_out, ladj_out);
 }
 
 extern "C" int nf_flow_inv(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *y_in, int64_t N,
@@ -244,7 +269,7 @@ extern "C" int nf_flow_inv(nf_ctx *ctx, const nf_flow_desc *desc, const void *th
   if (!ctx || !theta || !y_in || !x_out || !ladj_out || N < 0) return NF_ERR_ARG;
   NF_TRY(check_desc(desc));
   NF_HIP(hipSetDevice(ctx->device));
-  return chain_apply(ctx, desc, true, theta, y_in, N, x_out, ladj_out);
+  return apply_std(ctx, desc, true, -1, theta, y_in, N, x_out, ladj_out);
 }
 
 extern "C" int nf_layer_apply(nf_ctx *ctx, const nf_flow_desc *desc, int32_t layer, int32_t inverse, const void *theta,
@@ -253,25 +278,18 @@ extern "C" int nf_layer_apply(nf_ctx *ctx, const nf_flow_desc *desc, int32_t lay
   NF_TRY(check_desc(desc));
   if (layer < 0 || layer >= nf_layer_count(desc)) return NF_ERR_ARG;
   NF_HIP(hipSetDevice(ctx->device));
-  if (N == 0) return NF_OK;
-  if (desc->kind == NF_KIND_REALNVP) {
-    if (y_out != x_in)
-      NF_HIP(hipMemcpyAsync(y_out, x_in, (size_t)N * desc->d * esize(desc->dtype), hipMemcpyDeviceToDevice, ctx->stream));
-    return nf_affine_apply(ctx, desc, layer, inverse != 0, (const float *)theta, (const float *)y_out, N,
-                           (float *)y_out, (float *)ladj_out, 0);
-  }
-  return nf_simple_apply(ctx, desc, layer, layer + 1, inverse != 0, theta, x_in, N, y_out, ladj_out);
+  return apply_std(ctx, desc, inverse != 0, layer, theta, x_in, N, y_out, ladj_out);
 }
 
-// reverse pass over the chain.  `state` (d x N) holds the flow OUTPUT on entry and the flow INPUT
-// on exit (invertible recompute); `gbar` holds ybar on entry and xbar on exit.
+// reverse pass over the coupling chain (tiled buffers).  `state` holds the flow OUTPUT on entry and
+// the flow INPUT on exit (invertible recompute); `gbar` holds ybar on entry and xbar on exit.
 static int realnvp_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta, float *state, float *gbar,
                        const float *lbar, float lbar_const, long N, float *slab, int grid, float *g_out) {
-  const long P = nf_param_count(desc);
+  const long stride = nf_affine_slab_floats(desc);
   const int nc = 2 * desc->nlayers;
   for (int k = 0; k < nc; ++k)  // flat order = reverse of execution order
-    NF_TRY(nf_affine_bwd(ctx, desc, k, theta, state, gbar, lbar, lbar_const, N, slab, P, grid));
-  return nf_launch_reduce_slabs(ctx, NF_DTYPE_F32, slab, grid, P, g_out);
+    NF_TRY(nf_affine_bwd(ctx, desc, k, theta, state, gbar, lbar, lbar_const, N, slab, stride, grid));
+  return nf_affine_reduce_slabs(ctx, desc, slab, grid, g_out);
 }
 
 extern "C" int nf_flow_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *x, const void *y,
@@ -280,23 +298,24 @@ extern "C" int nf_flow_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const void *th
   NF_TRY(check_desc(desc));
   NF_HIP(hipSetDevice(ctx->device));
   const long P = nf_param_count(desc);
-  const size_t es = esize(desc->dtype);
   if (N == 0) return nf_launch_fill(ctx, desc->dtype, gtheta_out, P, 0.0);
-  if (desc->kind == NF_KIND_REALNVP) {
+  if (is_coupling(desc)) {
     const int grid = nf_affine_bwd_grid(ctx, N);
-    const size_t need = carve_bytes((size_t)N * desc->d * 4) + carve_bytes((size_t)grid * P * 4);
-    NF_TRY(nf_ws_reserve(ctx, need));
+    const size_t te = tiled_elems(desc, N);
+    const size_t slabf = (size_t)grid * nf_affine_slab_floats(desc);
+    NF_TRY(nf_ws_reserve(ctx, 2 * carve_bytes(te * 4) + carve_bytes(slabf * 4)));
     Carver cv(ctx->ws);
-    float *state = cv.take<float>((size_t)N * desc->d);
-    float *slab = cv.take<float>((size_t)grid * P);
-    NF_HIP(hipMemcpyAsync(state, y, (size_t)N * desc->d * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    if (xbar_out != ybar)
-      NF_HIP(hipMemcpyAsync(xbar_out, ybar, (size_t)N * desc->d * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    return realnvp_bwd(ctx, desc, (const float *)theta, state, (float *)xbar_out, (const float *)lbar, 0.f, N, slab,
-                       grid, (float *)gtheta_out);
+    float *state = cv.take<float>(te);
+    float *gt = cv.take<float>(te);
+    float *slab = cv.take<float>(slabf);
+    NF_TRY(nf_affine_pack(ctx, desc, (const float *)theta));
+    NF_TRY(nf_launch_layout_convert(ctx, desc->d, N, (const float *)y, state, 1));
+    NF_TRY(nf_launch_layout_convert(ctx, desc->d, N, (const float *)ybar, gt, 1));
+    NF_TRY(realnvp_bwd(ctx, desc, (const float *)theta, state, gt, (const float *)lbar, 0.f, N, slab, grid,
+                       (float *)gtheta_out));
+    return nf_launch_layout_convert(ctx, desc->d, N, gt, (float *)xbar_out, 0);
   }
   NF_TRY(nf_ws_reserve(ctx, nf_simple_bwd_ws_bytes(ctx, desc, N)));
-  (void)es;
   return nf_simple_bwd(ctx, desc, theta, x, ybar, lbar, 0.0, N, xbar_out, gtheta_out, ctx->ws);
 }
 
@@ -314,25 +333,39 @@ static int elbo_forward(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *
                         const void *xs, long N, uint64_t seed, uint64_t off, uint32_t stream_id, void *elbos_out,
                         double *elbo_host) {
   const size_t es = esize(desc->dtype);
-  const long nb = nf_target_nblocks(N);
-  const size_t need = carve_bytes((size_t)N * desc->d * es) + 2 * carve_bytes((size_t)N * es) +
-                      carve_bytes((size_t)nb * 8) + carve_bytes(64);
+  const bool cp = is_coupling(desc);
+  const long nb = cp ? nf_target_tiled_nblocks(N) : nf_target_nblocks(N);
+  const size_t xe = cp ? tiled_elems(desc, N) : (size_t)N * desc->d;
+  const size_t need = carve_bytes(xe * es) + 2 * carve_bytes((size_t)N * es) + carve_bytes((size_t)nb * 8) + carve_bytes(64);
   NF_TRY(nf_ws_reserve(ctx, need));
   Carver cv(ctx->ws);
-  char *x = cv.take<char>((size_t)N * desc->d * es);
+  char *x = cv.take<char>(xe * es);
   char *logq = cv.take<char>((size_t)N * es);
   char *ladj = cv.take<char>((size_t)N * es);
   double *partial = cv.take<double>(nb);
   double *result = cv.take<double>(8);
-  if (xs) {
-    NF_HIP(hipMemcpyAsync(x, xs, (size_t)N * desc->d * es, hipMemcpyDeviceToDevice, ctx->stream));
-    NF_TRY(nf_launch_base_logpdf(ctx, desc->dtype, desc->d, N, x, logq));
+  if (cp) {
+    float *xt = (float *)x;
+    if (xs) {
+      NF_TRY(nf_launch_layout_convert(ctx, desc->d, N, (const float *)xs, xt, 1));
+      NF_TRY(nf_launch_base_logpdf_tiled(ctx, desc->d, N, xt, (float *)logq));
+    } else {
+      NF_TRY(nf_launch_base_sample_tiled(ctx, desc->d, N, seed, off, stream_id, xt, (float *)logq));
+    }
+    NF_TRY(coupling_chain_tiled(ctx, desc, false, (const float *)theta, xt, N, (float *)ladj, -1));
+    NF_TRY(nf_launch_target_tiled(ctx, target, desc->d, N, xt, (const float *)logq, (const float *)ladj, nullptr, 0.0,
+                                  (float *)elbos_out, partial, 1.0 / (double)N));
   } else {
-    NF_TRY(nf_launch_base_sample(ctx, desc->dtype, desc->d, N, seed, off, stream_id, x, logq));
+    if (xs) {
+      NF_HIP(hipMemcpyAsync(x, xs, (size_t)N * desc->d * es, hipMemcpyDeviceToDevice, ctx->stream));
+      NF_TRY(nf_launch_base_logpdf(ctx, desc->dtype, desc->d, N, x, logq));
+    } else {
+      NF_TRY(nf_launch_base_sample(ctx, desc->dtype, desc->d, N, seed, off, stream_id, x, logq));
+    }
+    NF_TRY(nf_simple_apply(ctx, desc, 0, nf_layer_count(desc), false, theta, x, N, x, ladj));
+    NF_TRY(nf_launch_target(ctx, desc->dtype, target, desc->d, N, x, logq, ladj, nullptr, nullptr, 0.0, elbos_out,
+                            partial, 1.0 / (double)N));
   }
-  NF_TRY(chain_apply(ctx, desc, false, theta, x, N, x, ladj));
-  NF_TRY(nf_launch_target(ctx, desc->dtype, target, desc->d, N, x, logq, ladj, nullptr, nullptr, 0.0, elbos_out,
-                          partial, 1.0 / (double)N));
   NF_TRY(nf_launch_finish_sum(ctx, partial, nb, 0, result, nullptr, nullptr));
   return read_scalar(ctx, result, elbo_host);
 }
@@ -360,18 +393,26 @@ extern "C" int nf_loglikelihood(nf_ctx *ctx, const nf_flow_desc *desc, const voi
   NF_TRY(check_desc(desc));
   NF_HIP(hipSetDevice(ctx->device));
   const size_t es = esize(desc->dtype);
+  const bool cp = is_coupling(desc);
   const long nb = nf_sum2_nblocks(N);
-  const size_t need = carve_bytes((size_t)N * desc->d * es) + 2 * carve_bytes((size_t)N * es) +
-                      carve_bytes((size_t)nb * 8) + carve_bytes(64);
+  const size_t xe = cp ? tiled_elems(desc, N) : (size_t)N * desc->d;
+  const size_t need = carve_bytes(xe * es) + 2 * carve_bytes((size_t)N * es) + carve_bytes((size_t)nb * 8) + carve_bytes(64);
   NF_TRY(nf_ws_reserve(ctx, need));
   Carver cv(ctx->ws);
-  char *x = cv.take<char>((size_t)N * desc->d * es);
+  char *x = cv.take<char>(xe * es);
   char *logq = cv.take<char>((size_t)N * es);
   char *ladj = cv.take<char>((size_t)N * es);
   double *partial = cv.take<double>(nb);
   double *result = cv.take<double>(8);
-  NF_TRY(chain_apply(ctx, desc, true, theta, ys, N, x, ladj));
-  NF_TRY(nf_launch_base_logpdf(ctx, desc->dtype, desc->d, N, x, logq));
+  if (cp) {
+    float *xt = (float *)x;
+    NF_TRY(nf_launch_layout_convert(ctx, desc->d, N, (const float *)ys, xt, 1));
+    NF_TRY(coupling_chain_tiled(ctx, desc, true, (const float *)theta, xt, N, (float *)ladj, -1));
+    NF_TRY(nf_launch_base_logpdf_tiled(ctx, desc->d, N, xt, (float *)logq));
+  } else {
+    NF_TRY(nf_simple_apply(ctx, desc, 0, nf_layer_count(desc), true, theta, ys, N, x, ladj));
+    NF_TRY(nf_launch_base_logpdf(ctx, desc->dtype, desc->d, N, x, logq));
+  }
   NF_TRY(nf_launch_sum2(ctx, desc->dtype, N, logq, ladj, logliks_out, partial, 1.0 / (double)N));
   NF_TRY(nf_launch_finish_sum(ctx, partial, nb, 0, result, nullptr, nullptr));
   return read_scalar(ctx, result, ll_host);
@@ -390,41 +431,54 @@ extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, con
   const size_t es = esize(dt);
   if (N == 0) return nf_launch_fill(ctx, dt, out, P + 1, 0.0);
   const double inv = 1.0 / (double)N_global;
-  const long nb = nf_target_nblocks(N);
-  const bool coupling = desc->kind == NF_KIND_REALNVP;
-  const int grid = coupling ? nf_affine_bwd_grid(ctx, N) : 0;
-  const size_t simple_ws = coupling ? 0 : nf_simple_bwd_ws_bytes(ctx, desc, N);
-  const size_t need = 3 * carve_bytes((size_t)N * desc->d * es) + 2 * carve_bytes((size_t)N * es) +
-                      carve_bytes((size_t)nb * 8) + carve_bytes(64) + carve_bytes((size_t)grid * P * es) +
-                      carve_bytes(simple_ws);
+  const bool cp = is_coupling(desc);
+  const long nb = cp ? nf_target_tiled_nblocks(N) : nf_target_nblocks(N);
+  const int grid = cp ? nf_affine_bwd_grid(ctx, N) : 0;
+  const size_t simple_ws = cp ? 0 : nf_simple_bwd_ws_bytes(ctx, desc, N);
+  const size_t slabf = cp ? (size_t)grid * nf_affine_slab_floats(desc) : 0;
+  const size_t xe = cp ? tiled_elems(desc, N) : (size_t)N * desc->d;
+  const size_t need = 3 * carve_bytes(xe * es) + 2 * carve_bytes((size_t)N * es) + carve_bytes((size_t)nb * 8) +
+                      carve_bytes(64) + carve_bytes(slabf * es) + carve_bytes(simple_ws);
   NF_TRY(nf_ws_reserve(ctx, need));
   Carver cv(ctx->ws);
-  char *x = cv.take<char>((size_t)N * desc->d * es);
-  char *gbar = cv.take<char>((size_t)N * desc->d * es);
-  char *x0 = cv.take<char>((size_t)N * desc->d * es);  // flow input kept for non-invertible recompute
+  char *x = cv.take<char>(xe * es);
+  char *gbar = cv.take<char>(xe * es);
+  char *x0 = cv.take<char>(xe * es);  // flow input kept for the non-invertible (planar/radial) recompute
   char *logq = cv.take<char>((size_t)N * es);
   char *ladj = cv.take<char>((size_t)N * es);
   double *partial = cv.take<double>(nb);
   double *result = cv.take<double>(8);
-  char *slab = cv.take<char>((size_t)grid * P * es);
+  (void)result;
+  char *slab = cv.take<char>(slabf * es);
   char *sws = cv.take<char>(simple_ws);
 
-  char *xin = coupling ? x : x0;
-  if (xs) {
-    NF_HIP(hipMemcpyAsync(xin, xs, (size_t)N * desc->d * es, hipMemcpyDeviceToDevice, ctx->stream));
-    NF_TRY(nf_launch_base_logpdf(ctx, dt, desc->d, N, xin, logq));
+  if (cp) {
+    float *xt = (float *)x, *gt = (float *)gbar;
+    if (xs) {
+      NF_TRY(nf_launch_layout_convert(ctx, desc->d, N, (const float *)xs, xt, 1));
+      NF_TRY(nf_launch_base_logpdf_tiled(ctx, desc->d, N, xt, (float *)logq));
+    } else {
+      NF_TRY(nf_launch_base_sample_tiled(ctx, desc->d, N, seed, sample_offset, stream_id, xt, (float *)logq));
+    }
+    NF_TRY(coupling_chain_tiled(ctx, desc, false, (const float *)theta, xt, N, (float *)ladj, -1));
+    // gt = d(-elbo/Ng)/dy = -(1/Ng) grad logp(y);  partial sums of -elbo_j/Ng
+    NF_TRY(nf_launch_target_tiled(ctx, target, desc->d, N, xt, (const float *)logq, (const float *)ladj, gt, -inv,
+                                  nullptr, partial, -inv));
+    NF_TRY(nf_launch_finish_sum(ctx, partial, nb, 0, nullptr, (float *)out + P, nullptr));
+    NF_TRY(realnvp_bwd(ctx, desc, (const float *)theta, xt, gt, nullptr, (float)(-inv), N, (float *)slab, grid,
+                       (float *)out));
   } else {
-    NF_TRY(nf_launch_base_sample(ctx, dt, desc->d, N, seed, sample_offset, stream_id, xin, logq));
-  }
-  NF_TRY(chain_apply(ctx, desc, false, theta, xin, N, x, ladj));
-  // gbar = d(-elbo/Ng)/dy = -(1/Ng) grad logp(y);  partial sums of -elbo_j/Ng
-  NF_TRY(nf_launch_target(ctx, dt, target, desc->d, N, x, logq, ladj, nullptr, gbar, -inv, nullptr, partial, -inv));
-  if (coupling) {
-    NF_TRY(realnvp_bwd(ctx, desc, (const float *)theta, (float *)x, (float *)gbar, nullptr, (float)(-inv), N,
-                       (float *)slab, grid, (float *)out));
-  } else {
+    if (xs) {
+      NF_HIP(hipMemcpyAsync(x0, xs, (size_t)N * desc->d * es, hipMemcpyDeviceToDevice, ctx->stream));
+      NF_TRY(nf_launch_base_logpdf(ctx, dt, desc->d, N, x0, logq));
+    } else {
+      NF_TRY(nf_launch_base_sample(ctx, dt, desc->d, N, seed, sample_offset, stream_id, x0, logq));
+    }
+    NF_TRY(nf_simple_apply(ctx, desc, 0, nf_layer_count(desc), false, theta, x0, N, x, ladj));
+    NF_TRY(nf_launch_target(ctx, dt, target, desc->d, N, x, logq, ladj, nullptr, gbar, -inv, nullptr, partial, -inv));
     NF_TRY(nf_simple_bwd(ctx, desc, theta, x0, gbar, nullptr, -inv, N, gbar, out, sws));
   }
+  if (cp) return NF_OK;
   if (dt == NF_DTYPE_F32)
     return nf_launch_finish_sum(ctx, partial, nb, 0, nullptr, (float *)out + P, nullptr);
   return nf_launch_finish_sum(ctx, partial, nb, 0, (double *)out + P, nullptr, nullptr);
@@ -521,5 +575,21 @@ extern "C" int nf_prof_read(nf_ctx *ctx, const char *kernel_name, double *avg_ms
   }
   *avg_ms_host = tot / (double)it->second.size();
   if (count_host) *count_host = (int64_t)it->second.size();
+  return NF_OK;
+}
+
+// in-kernel timeline of the coupling reverse pass (block 0 / wave 0), for kernel tuning only
+extern "C" int nf_debug_trace(nf_ctx *ctx, int32_t on, int64_t *stamps_host, int32_t n) {
+  if (!ctx) return NF_ERR_ARG;
+  NF_HIP(hipStreamSynchronize(ctx->stream));
+  if (stamps_host && ctx->trace && n > 0)
+    NF_HIP(hipMemcpy(stamps_host, ctx->trace, sizeof(int64_t) * (size_t)(n < 128 ? n : 128), hipMemcpyDeviceToHost));
+  if (on && !ctx->trace) {
+    NF_HIP(hipMalloc(&ctx->trace, 128 * sizeof(int64_t)));
+    NF_HIP(hipMemset(ctx->trace, 0, 128 * sizeof(int64_t)));
+  } else if (!on && ctx->trace) {
+    NF_HIP(hipFree(ctx->trace));
+    ctx->trace = nullptr;
+  }
   return NF_OK;
 }

@@ -34,6 +34,11 @@ struct nf_ctx {
   size_t ws_bytes = 0;
   // pinned host scalars for results that are returned by value
   double *host_scratch = nullptr;
+  // packed (padded) LDS images of the conditioner nets, rebuilt from theta once per API call
+  void *wimg = nullptr;
+  size_t wimg_bytes = 0;
+  // optional in-kernel s_memtime trace (nf_debug_trace): 128 slots, device memory
+  void *trace = nullptr;
   // device gradient buffer of nf_elbo_step (P + 2 elements), grow-only
   void *gbuf = nullptr;
   size_t gbuf_bytes = 0;

@@ -12,8 +12,38 @@
 #include "nf_common.h"
 #include "nf_mfma.h"
 
+// ---- tile I/O through buffer descriptors ---------------------------------------------------
+// One descriptor per (array, tile): base = array + tile * d * 32 floats (wave-uniform), extent =
+// d * 32 floats.  Element (feature f, lane's sample) is at byte f * 128 + (lane & 31) * 4, and in
+// the MFMA register layout f = const(block, reg) + 8 * (lane >> 5) + parity, so ONE per-lane
+// voffset serves every access and the rest is a scalar offset: no 64-bit per-lane addresses.
+// Features >= d fall outside the descriptor: the hardware returns 0 for such loads and drops such
+// stores, which is exactly the PartitionMask edge handling (odd d, c != m) -- no branches.
+struct TileIO {
+  __amdgpu_buffer_rsrc_t rs;
+  int voff;
+};
+__device__ __forceinline__ TileIO make_tile_io(float *array, long tile, int d, int l31, int hi) {
+  TileIO t;
+  t.rs = __builtin_amdgcn_make_buffer_rsrc(array + tile * d * NF_TILE, 0, d * NF_TILE * 4, 0x00020000);
+  t.voff = l31 * 4 + hi * (8 * NF_TILE * 4);
+  return t;
+}
+// feature index without the lane-dependent 8*hi term: f0 = 2 * (b*32 + (r&3) + 8*(r>>2)) + parity
+__device__ __forceinline__ int tile_soff(int b, int r, int parity) {
+  return (2 * (b * 32 + (r & 3) + 8 * (r >> 2)) + parity) * (NF_TILE * 4);
+}
+__device__ __forceinline__ float tile_load(const TileIO &t, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(t.rs, t.voff, soff, 0));
+}
+__device__ __forceinline__ void tile_store(const TileIO &t, int soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), t.rs, t.voff, soff, 0);
+}
+
 struct CouplingArgs {
   const float *theta;
+  const float *img_s, *img_t;  // pre-packed LDS images of the s / t nets (k_pack_net_images)
+  long long *trace;            // optional s_memtime stamps of block 0 / wave 0 (nf_debug_trace)
   NetDims s, t;
   int d, c, m, par_t;
   long N;
@@ -22,7 +52,7 @@ struct CouplingArgs {
 // ------------------------------------------------------------------------------------
 // forward / inverse of one coupling (no gradients): both nets resident in LDS
 // ------------------------------------------------------------------------------------
-template <class G, bool INVERSE>
+template <class G, bool INVERSE, bool FULL>
 __global__ __launch_bounds__(512) void k_affine_apply(CouplingArgs a, const float *x_in,
                                                       float *y_out, float *__restrict__ ladj,
                                                       int ladj_accumulate) {
@@ -30,11 +60,11 @@ __global__ __launch_bounds__(512) void k_affine_apply(CouplingArgs a, const floa
   float *img_s = lds;
   float *img_t = lds + G::SIZE;
   const int tid = threadIdx.x;
-  stage_net<G>(img_s, a.theta, a.s, tid, 512);
-  stage_net<G>(img_t, a.theta, a.t, tid, 512);
+  stage_packed<G::SIZE, 512>(img_s, a.img_s, tid);
+  stage_packed<G::SIZE, 512>(img_t, a.img_t, tid);
   __syncthreads();
 
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform
   const int l31 = lane & 31, hi = lane >> 5;
   const int par_c = 1 - a.par_t;
   const long ntiles = (a.N + NF_TILE - 1) / NF_TILE;
@@ -42,21 +72,23 @@ __global__ __launch_bounds__(512) void k_affine_apply(CouplingArgs a, const floa
 
   for (long tile = (long)blockIdx.x * 8 + wave; tile < ntiles; tile += (long)gridDim.x * 8) {
     const long j = tile * NF_TILE + l31;
-    const bool valid = j < a.N;
-    const float *xr = x_in + j * a.d;
-    float *yr = y_out + j * a.d;
+    const bool valid = FULL ? true : j < a.N;
+    const TileIO xin = make_tile_io(const_cast<float *>(x_in), tile, a.d, l31, hi);
+    const TileIO yout = make_tile_io(y_out, tile, a.d, l31, hi);
 
-    f32x16 xb[G::MB];
+    f32x16 xb[G::MB], x1[G::CB];
 #pragma unroll
     for (int b = 0; b < G::MB; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int q = b * 32 + nf_row(r, hi);
-        const bool ok = valid && q < a.m;
-        const float v = ok ? xr[2 * q + par_c] : 0.f;
-        xb[b][r] = v;
-        if (copy_cond && ok) yr[2 * q + par_c] = v;
+        const float v = tile_load(xin, tile_soff(b, r, par_c));
+        xb[b][r] = valid ? v : 0.f;
+        if (copy_cond) tile_store(yout, tile_soff(b, r, par_c), v);
       }
+#pragma unroll
+    for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x1[b][r] = tile_load(xin, tile_soff(b, r, a.par_t));
 
     f32x16 S[G::CB], T[G::CB];
     {
@@ -73,18 +105,15 @@ __global__ __launch_bounds__(512) void k_affine_apply(CouplingArgs a, const floa
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int p = b * 32 + nf_row(r, hi);
-        const bool ok = valid && p < a.c;
-        const float s = tanhf(S[b][r]);
-        const float v = ok ? xr[2 * p + a.par_t] : 0.f;
+        const float s = tanhf(S[b][r]);  // padded rows: zero weights and bias => s = 0
+        const float v = x1[b][r];
         float o;
         if (INVERSE)
           o = (v - T[b][r]) * expf(-s);
         else
           o = v * expf(s) + T[b][r];
-        if (ok) {
-          yr[2 * p + a.par_t] = o;
-          lsum += s;
-        }
+        tile_store(yout, tile_soff(b, r, a.par_t), o);  // rows >= c are outside the descriptor
+        lsum += (FULL || p < a.c) ? s : 0.f;
       }
     lsum += __shfl_xor(lsum, 32);
     if (hi == 0 && valid) {
@@ -160,6 +189,11 @@ __device__ __forceinline__ void unstage_dense(const float *__restrict__ img, int
   }
 }
 
+#define NF_TS_STAMP(slot)                                                  \
+  do {                                                                     \
+    if (tr) { __builtin_amdgcn_sched_barrier(0); tr[slot] = clock64(); }   \
+  } while (0)
+
 // sign masks of post-leakyrelu activations (bit r set <=> a[r] > 0): all the reverse pass
 // needs of a1/a2 besides their LDS copies, so the activations themselves can die early.
 template <int NB>
@@ -194,18 +228,24 @@ struct BwdLds {
   static constexpr size_t BYTES = (size_t)(G::SIZE + WAVES * SCRATCH) * sizeof(float);
 };
 
-template <class G, bool PHASE_S>
+template <class G, bool PHASE_S, bool FULL>
 __device__ __forceinline__ void bwd_tile(const CouplingArgs &a, const float *__restrict__ img, float *__restrict__ sc,
                                          BwdAcc<G> &acc, float *__restrict__ y, float *__restrict__ ybar,
-                                         const float *__restrict__ lbar, float lbar_const, long tile, int l31, int hi) {
+                                         const float *__restrict__ lbar, float lbar_const, long tile, int l31, int hi,
+                                         long long *tr) {
   using L = BwdLds<G>;
+  NF_TS_STAMP(0);
   const long j = tile * NF_TILE + l31;
-  const bool valid = j < a.N;
+  // FULL: every feature block is full (m = 32*MB, c = 32*CB) and N is a multiple of the tile, so
+  // no load, store or mask below needs a predicate (no exec-mask branches in the hot loop).
+  const bool valid = FULL ? true : j < a.N;
   const int par_c = 1 - a.par_t;
-  float *yr = y + j * a.d;
-  float *gr = ybar + j * a.d;
+  // tiled layout, one buffer descriptor per array and tile: coalesced (one 128-byte line per
+  // half-wave per feature), bounds-checked by the hardware, one shared per-lane offset register
+  const TileIO yio = make_tile_io(y, tile, a.d, l31, hi);
+  const TileIO gio = make_tile_io(ybar, tile, a.d, l31, hi);
 
-  f32x16 d3[G::CB];
+  f32x16 d3[G::CB], y1[G::CB], g1[G::CB];
   unsigned m1[G::H1B], m2[G::H2B];
   {
     f32x16 xb[G::MB];
@@ -213,10 +253,11 @@ __device__ __forceinline__ void bwd_tile(const CouplingArgs &a, const float *__r
     for (int b = 0; b < G::MB; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int q = b * 32 + nf_row(r, hi);
-        xb[b][r] = (valid && q < a.m) ? yr[2 * q + par_c] : 0.f;
+        const float v = tile_load(yio, tile_soff(b, r, par_c));  // features >= d read as 0
+        xb[b][r] = valid ? v : 0.f;
       }
     tile_to_scratch<G::MB>(sc + L::OFF_X, xb, l31, hi);
+    NF_TS_STAMP(1);
     f32x16 a1[G::H1B];
     dense_fwd<G::MB, G::H1B>(img + G::W1, img + G::B1, xb, a1, l31, hi);
 #pragma unroll
@@ -233,82 +274,103 @@ __device__ __forceinline__ void bwd_tile(const CouplingArgs &a, const float *__r
       for (int r = 0; r < 16; ++r) a2[b][r] = nf_lrelu(a2[b][r]);
     sign_masks<G::H2B>(a2, m2);
     tile_to_scratch<G::H2B>(sc + L::OFF_A2, a2, l31, hi);
+    // operands of the element-wise stage: issued here, consumed after the last forward layer
+#pragma unroll
+    for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        y1[b][r] = tile_load(yio, tile_soff(b, r, a.par_t));
+        g1[b][r] = tile_load(gio, tile_soff(b, r, a.par_t));
+      }
     dense_fwd<G::H2B, G::CB>(img + G::W3, img + G::B3, a2, d3, l31, hi);  // T (phase T) or pre-tanh S
   }
+  NF_TS_STAMP(2);
 
-  const float lb = valid ? (lbar ? lbar[j] : lbar_const) : 0.f;
+  const float lb = valid ? (lbar ? lbar[FULL ? j : (j < a.N ? j : 0)] : lbar_const) : 0.f;
 #pragma unroll
   for (int b = 0; b < G::CB; ++b)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int p = b * 32 + nf_row(r, hi);
-      const bool ok = valid && p < a.c;
-      const float y1 = ok ? yr[2 * p + a.par_t] : 0.f;
-      const float g1 = ok ? gr[2 * p + a.par_t] : 0.f;
+      const bool okf = FULL ? true : p < a.c;  // padded samples may be stored to (never read unmasked)
+      const bool ok = okf && valid;
+      const float yv = y1[b][r], gv = g1[b][r];
       if (!PHASE_S) {
-        if (ok) yr[2 * p + a.par_t] = y1 - d3[b][r];  // u = x1 * exp(S)
-        d3[b][r] = g1;                                 // T-bar = ybar1
+        tile_store(yio, tile_soff(b, r, a.par_t), yv - d3[b][r]);  // u = x1 * exp(S)
+        d3[b][r] = ok ? gv : 0.f;                                   // T-bar = ybar1
       } else {
         const float s = tanhf(d3[b][r]);
-        if (ok) {
-          yr[2 * p + a.par_t] = y1 * expf(-s);  // x1
-          gr[2 * p + a.par_t] = g1 * expf(s);   // x1bar
-        }
-        d3[b][r] = ok ? (g1 * y1 + lb) * (1.f - s * s) : 0.f;  // S-bar through tanh
+        tile_store(yio, tile_soff(b, r, a.par_t), yv * expf(-s));  // x1
+        tile_store(gio, tile_soff(b, r, a.par_t), gv * expf(s));   // x1bar
+        d3[b][r] = ok ? (gv * yv + lb) * (1.f - s * s) : 0.f;      // S-bar through tanh
       }
     }
 
+  NF_TS_STAMP(3);
   float *sd = sc + L::OFF_D;
   // ---- layer 3: dW3^T += a2 * d3^T ; d2 = (W3^T d3) .* lrelu'(a2)
   tile_to_scratch<G::CB>(sd, d3, l31, hi);
   wave_lds_fence();
+  NF_TS_STAMP(4);
   dw_accumulate<G::H2B, G::CB>(sc + L::OFF_A2, sd, acc.w3, acc.b3, l31, hi);
+  NF_TS_STAMP(5);
   f32x16 d2[G::H2B];
   dense_bwd_x<G::H2B, G::CB>(img + G::W3, d3, d2, l31, hi);
   apply_lrelu_grad<G::H2B>(d2, m2);
+  NF_TS_STAMP(6);
   wave_lds_fence();
   // ---- layer 2
   tile_to_scratch<G::H2B>(sd, d2, l31, hi);
   wave_lds_fence();
   dw_accumulate<G::H1B, G::H2B>(sc + L::OFF_A1, sd, acc.w2, acc.b2, l31, hi);
+  NF_TS_STAMP(7);
   f32x16 d1[G::H1B];
   dense_bwd_x<G::H1B, G::H2B>(img + G::W2, d2, d1, l31, hi);
   apply_lrelu_grad<G::H1B>(d1, m1);
+  NF_TS_STAMP(8);
   wave_lds_fence();
   // ---- layer 1
   tile_to_scratch<G::H1B>(sd, d1, l31, hi);
   wave_lds_fence();
   dw_accumulate<G::MB, G::H1B>(sc + L::OFF_X, sd, acc.w1, acc.b1, l31, hi);
-  f32x16 g2[G::MB];
+  NF_TS_STAMP(9);
+  // x2bar accumulates ybar2 + W1t^T d1t (phase T) + W1s^T d1s (phase S): old value fetched here,
+  // behind the last dX GEMM
+  f32x16 g2[G::MB], gold[G::MB];
+#pragma unroll
+  for (int b = 0; b < G::MB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gold[b][r] = tile_load(gio, tile_soff(b, r, par_c));
   dense_bwd_x<G::MB, G::H1B>(img + G::W1, d1, g2, l31, hi);
   wave_lds_fence();
 #pragma unroll
   for (int b = 0; b < G::MB; ++b)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int q = b * 32 + nf_row(r, hi);
-      if (valid && q < a.m) gr[2 * q + par_c] += g2[b][r];
-    }
+    for (int r = 0; r < 16; ++r) tile_store(gio, tile_soff(b, r, par_c), gold[b][r] + g2[b][r]);
+  NF_TS_STAMP(10);
 }
 
-template <class G>
+template <class G, bool FULL>
 __global__ __launch_bounds__(256, 1) void k_affine_bwd(CouplingArgs a, float *__restrict__ y, float *__restrict__ ybar,
                                                        const float *__restrict__ lbar, float lbar_const,
                                                        float *__restrict__ slab, long slab_stride) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *img = lds;
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform
   const int l31 = lane & 31, hi = lane >> 5;
   float *sc = lds + G::SIZE + wave * BwdLds<G>::SCRATCH;
-  float *my_slab = slab + (long)blockIdx.x * slab_stride;
   const long ntiles = (a.N + NF_TILE - 1) / NF_TILE;
+  long long *tr0 = (a.trace && blockIdx.x == 0 && tid == 0) ? a.trace : nullptr;
+  if (tr0) tr0[0] = clock64();
 
 #pragma unroll 1
   for (int phase = 0; phase < 2; ++phase) {
+    long long *tr = tr0 ? tr0 + 8 + phase * 40 : nullptr;  // [8 + phase*40 + tileidx*12 + slot]
     const NetDims &nd = phase == 0 ? a.t : a.s;
-    stage_net<G>(img, a.theta, nd, tid, 256);
+    stage_packed<G::SIZE, 256>(img, phase == 0 ? a.img_t : a.img_s, tid);
     __syncthreads();
+    if (tr0) tr0[1 + phase * 3] = clock64();
     BwdAcc<G> acc;
     zero_acc(acc.w1, acc.b1);
     zero_acc(acc.w2, acc.b2);
@@ -316,28 +378,92 @@ __global__ __launch_bounds__(256, 1) void k_affine_bwd(CouplingArgs a, float *__
 #pragma unroll 1
     for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
       if (phase == 0)
-        bwd_tile<G, false>(a, img, sc, acc, y, ybar, lbar, lbar_const, tile, l31, hi);
+        bwd_tile<G, false, FULL>(a, img, sc, acc, y, ybar, lbar, lbar_const, tile, l31, hi, tr);
       else
-        bwd_tile<G, true>(a, img, sc, acc, y, ybar, lbar, lbar_const, tile, l31, hi);
+        bwd_tile<G, true, FULL>(a, img, sc, acc, y, ybar, lbar, lbar_const, tile, l31, hi, tr);
+      if (tr) tr += 12;
     }
-    __syncthreads();  // every wave is done reading the weight image
-#pragma unroll 1
-    for (int w = 0; w < 4; ++w) {
-      if (wave == w) {
-        fold_acc(img + G::W1, img + G::B1, acc.w1, acc.b1, w == 0, l31, hi);
-        fold_acc(img + G::W2, img + G::B2, acc.w2, acc.b2, w == 0, l31, hi);
-        fold_acc(img + G::W3, img + G::B3, acc.w3, acc.b3, w == 0, l31, hi);
+    if (tr0) tr0[2 + phase * 3] = clock64();
+    __syncthreads();  // every wave is done with the weight image and its scratch
+    // Each wave drops its accumulators, in image layout, into its own G::SIZE-float region of the
+    // (now free) LDS; then all threads add the four copies and write the workgroup's slab with
+    // 16-byte stores.  Slabs keep the padded image layout; k_reduce_image_slabs maps them to theta.
+    {
+      float *mine = lds + wave * G::SIZE;
+      fold_acc(mine + G::W1, mine + G::B1, acc.w1, acc.b1, true, l31, hi);
+      fold_acc(mine + G::W2, mine + G::B2, acc.w2, acc.b2, true, l31, hi);
+      fold_acc(mine + G::W3, mine + G::B3, acc.w3, acc.b3, true, l31, hi);
+    }
+    __syncthreads();
+    {
+      const float4 *c0 = reinterpret_cast<const float4 *>(lds);
+      float4 *dst = reinterpret_cast<float4 *>(slab + ((long)blockIdx.x * slab_stride + (phase == 0 ? 1 : 0) * (long)G::SIZE));
+      constexpr int NV4 = G::SIZE / 4;
+      for (int i = tid; i < NV4; i += 256) {
+        const float4 p0 = c0[i], p1 = c0[i + NV4], p2 = c0[i + 2 * NV4], p3 = c0[i + 3 * NV4];
+        float4 r;
+        r.x = (p0.x + p1.x) + (p2.x + p3.x);
+        r.y = (p0.y + p1.y) + (p2.y + p3.y);
+        r.z = (p0.z + p1.z) + (p2.z + p3.z);
+        r.w = (p0.w + p1.w) + (p2.w + p3.w);
+        dst[i] = r;
       }
-      __syncthreads();
     }
-    unstage_dense<G::S1>(img + G::W1, 32 * G::MB, my_slab + nd.w1, nd.m, nd.h1, tid, 256);
-    unstage_dense<G::S2>(img + G::W2, 32 * G::H1B, my_slab + nd.w2, nd.h1, nd.h2, tid, 256);
-    unstage_dense<G::S3>(img + G::W3, 32 * G::H2B, my_slab + nd.w3, nd.h2, nd.c, tid, 256);
-    for (int i = tid; i < nd.h1; i += 256) my_slab[nd.b1 + i] = img[G::B1 + i];
-    for (int i = tid; i < nd.h2; i += 256) my_slab[nd.b2 + i] = img[G::B2 + i];
-    for (int i = tid; i < nd.c; i += 256) my_slab[nd.b3 + i] = img[G::B3 + i];
     __syncthreads();  // image is restaged next phase
+    if (tr0) tr0[3 + phase * 3] = clock64();
   }
+}
+
+// ------------------------------------------------------------------------------------
+// weight packing: theta -> padded LDS images, one per (coupling, net), once per call
+// ------------------------------------------------------------------------------------
+struct PackArgs {
+  int d, h1, h2, ncoup;
+  long pair_params;   // parameters of one RealNVP_layer (two couplings)
+  long odd_params;    // parameters of the odd-mask coupling
+};
+
+template <class G>
+__global__ __launch_bounds__(256) void k_pack_net_images(PackArgs p, const float *__restrict__ theta,
+                                                         float *__restrict__ out) {
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)p.ncoup * 2 * G::SIZE;
+  if (gid >= total) return;
+  const int img = (int)(gid / G::SIZE), e = (int)(gid - (long)img * G::SIZE);
+  const int k = img >> 1, net = img & 1;
+  const int c = (k & 1) ? p.d / 2 : (p.d + 1) / 2, m = p.d - c;
+  long off = (long)(k >> 1) * p.pair_params + ((k & 1) ? p.odd_params : 0);
+  if (net) off += net_param_count(m, p.h1, p.h2, c);
+  const NetDims nd = make_net_dims(off, m, p.h1, p.h2, c);
+  const long ti = e < G::B3 + 32 * G::CB ? image_theta_index<G>(nd, e) : -1;
+  out[gid] = ti >= 0 ? theta[ti] : 0.f;
+}
+
+// g[theta index] = sum over workgroup slabs of the image-layout partial gradients
+template <class G>
+__global__ __launch_bounds__(256) void k_reduce_image_slabs(PackArgs p, const float *__restrict__ slab, int nslab,
+                                                            long slab_stride, float *__restrict__ g) {
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)p.ncoup * 2 * G::SIZE;
+  if (gid >= total) return;
+  const int img = (int)(gid / G::SIZE), e = (int)(gid - (long)img * G::SIZE);
+  const int k = img >> 1, net = img & 1;
+  const int c = (k & 1) ? p.d / 2 : (p.d + 1) / 2, m = p.d - c;
+  long off = (long)(k >> 1) * p.pair_params + ((k & 1) ? p.odd_params : 0);
+  if (net) off += net_param_count(m, p.h1, p.h2, c);
+  const NetDims nd = make_net_dims(off, m, p.h1, p.h2, c);
+  const long ti = e < G::B3 + 32 * G::CB ? image_theta_index<G>(nd, e) : -1;
+  if (ti < 0) return;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int s = 0;
+  for (; s + 3 < nslab; s += 4) {
+    a0 += slab[(long)s * slab_stride + gid];
+    a1 += slab[(long)(s + 1) * slab_stride + gid];
+    a2 += slab[(long)(s + 2) * slab_stride + gid];
+    a3 += slab[(long)(s + 3) * slab_stride + gid];
+  }
+  for (; s < nslab; ++s) a0 += slab[(long)s * slab_stride + gid];
+  g[ti] = (a0 + a1) + (a2 + a3);
 }
 
 // ------------------------------------------------------------------------------------
@@ -345,11 +471,76 @@ __global__ __launch_bounds__(256, 1) void k_affine_bwd(CouplingArgs a, float *__
 // ------------------------------------------------------------------------------------
 static inline int blocks32(int n) { return (n + 31) / 32; }
 
-static int make_args(const nf_flow_desc *desc, int k, const float *theta, long N, CouplingArgs *out) {
+static int geo_size(const nf_flow_desc *desc) {
+  const int c = (desc->d + 1) / 2;
+  const int mb = blocks32(c), h1b = blocks32(desc->hdims[0]), h2b = blocks32(desc->hdims[1]);
+  if (mb == 1 && h1b == 1 && h2b == 1) return NetGeo<1, 1, 1, 1>::SIZE;
+  if (mb == 1 && h1b == 2 && h2b == 2) return NetGeo<1, 2, 2, 1>::SIZE;
+  return 0;
+}
+
+static PackArgs make_pack_args(const nf_flow_desc *desc) {
+  PackArgs p;
+  p.d = desc->d; p.h1 = desc->hdims[0]; p.h2 = desc->hdims[1]; p.ncoup = 2 * desc->nlayers;
+  const CouplingInfo c0 = nf_coupling_info(desc, 0), c1 = nf_coupling_info(desc, 1);
+  p.odd_params = c0.nparams;
+  p.pair_params = c0.nparams + c1.nparams;
+  return p;
+}
+
+// floats of one workgroup's gradient slab (image layout): [coupling][net s|t][G::SIZE]
+long nf_affine_slab_floats(const nf_flow_desc *desc) { return (long)2 * desc->nlayers * 2 * geo_size(desc); }
+
+int nf_affine_reduce_slabs(nf_ctx *ctx, const nf_flow_desc *desc, const float *slab, int nslab, float *g) {
+  const int size = geo_size(desc);
+  if (!size) return NF_ERR_UNSUPPORTED;
+  const PackArgs p = make_pack_args(desc);
+  const long total = (long)p.ncoup * 2 * size;
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  ProfScope ps(ctx, "reduce_slabs");
+  if (size == NetGeo<1, 1, 1, 1>::SIZE)
+    hipLaunchKernelGGL((k_reduce_image_slabs<NetGeo<1, 1, 1, 1>>), dim3(grid), dim3(256), 0, ctx->stream, p, slab, nslab, total, g);
+  else
+    hipLaunchKernelGGL((k_reduce_image_slabs<NetGeo<1, 2, 2, 1>>), dim3(grid), dim3(256), 0, ctx->stream, p, slab, nslab, total, g);
+  return (int)hipGetLastError();
+}
+
+// packs every net of the flow into ctx->wimg (grow-only) -- call once per API entry
+int nf_affine_pack(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta) {
+  if (desc->n_hidden != 2) return NF_ERR_UNSUPPORTED;
+  const int size = geo_size(desc);
+  if (!size) return NF_ERR_UNSUPPORTED;
+  const int nc = 2 * desc->nlayers;
+  const size_t bytes = (size_t)nc * 2 * size * sizeof(float);
+  if (bytes > ctx->wimg_bytes) {
+    NF_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->wimg) NF_HIP(hipFree(ctx->wimg));
+    ctx->wimg = nullptr;
+    ctx->wimg_bytes = 0;
+    NF_HIP(hipMalloc(&ctx->wimg, bytes));
+    ctx->wimg_bytes = bytes;
+  }
+  const PackArgs p = make_pack_args(desc);
+  const long total = (long)nc * 2 * size;
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  ProfScope ps(ctx, "pack_weights");
+  if (size == NetGeo<1, 1, 1, 1>::SIZE)
+    hipLaunchKernelGGL((k_pack_net_images<NetGeo<1, 1, 1, 1>>), dim3(grid), dim3(256), 0, ctx->stream, p, theta, (float *)ctx->wimg);
+  else
+    hipLaunchKernelGGL((k_pack_net_images<NetGeo<1, 2, 2, 1>>), dim3(grid), dim3(256), 0, ctx->stream, p, theta, (float *)ctx->wimg);
+  return (int)hipGetLastError();
+}
+
+static int make_args(nf_ctx *ctx, const nf_flow_desc *desc, int k, const float *theta, long N, CouplingArgs *out) {
   if (desc->n_hidden != 2) return NF_ERR_UNSUPPORTED;
   CouplingInfo ci = nf_coupling_info(desc, k);
   CouplingArgs a;
   a.theta = theta;
+  const int size = geo_size(desc);
+  if (!size || !ctx->wimg) return NF_ERR_UNSUPPORTED;
+  a.img_s = (const float *)ctx->wimg + (size_t)(2 * k) * size;
+  a.img_t = a.img_s + size;
+  a.trace = (long long *)ctx->trace;
   a.d = desc->d; a.c = ci.c; a.m = ci.m; a.par_t = ci.par_t; a.N = N;
   const int h1 = desc->hdims[0], h2 = desc->hdims[1];
   a.s = make_net_dims(ci.theta_off, ci.m, h1, h2, ci.c);
@@ -364,12 +555,12 @@ static int make_args(const nf_flow_desc *desc, int k, const float *theta, long N
     BODY                                                                    \
   }
 
-template <class G, bool INV>
-static int launch_apply(nf_ctx *ctx, const CouplingArgs &a, const float *x, float *y, float *ladj, int accumulate) {
+template <class G, bool INV, bool FULL>
+static int launch_apply_v(nf_ctx *ctx, const CouplingArgs &a, const float *x, float *y, float *ladj, int accumulate) {
   const size_t lds = 2 * (size_t)G::SIZE * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    NF_HIP(hipFuncSetAttribute((const void *)k_affine_apply<G, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NF_HIP(hipFuncSetAttribute((const void *)k_affine_apply<G, INV, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
   const long ntiles = (a.N + NF_TILE - 1) / NF_TILE;
@@ -378,14 +569,20 @@ static int launch_apply(nf_ctx *ctx, const CouplingArgs &a, const float *x, floa
   if (grid > cap) grid = cap;
   if (grid < 1) grid = 1;
   ProfScope ps(ctx, "affine_apply");
-  hipLaunchKernelGGL((k_affine_apply<G, INV>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, x, y, ladj, accumulate);
+  hipLaunchKernelGGL((k_affine_apply<G, INV, FULL>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, x, y, ladj, accumulate);
   return (int)hipGetLastError();
+}
+template <class G, bool INV>
+static int launch_apply(nf_ctx *ctx, const CouplingArgs &a, const float *x, float *y, float *ladj, int accumulate) {
+  const bool full = a.m == 32 * G::MB && a.c == 32 * G::CB && a.N % NF_TILE == 0;
+  return full ? launch_apply_v<G, INV, true>(ctx, a, x, y, ladj, accumulate)
+              : launch_apply_v<G, INV, false>(ctx, a, x, y, ladj, accumulate);
 }
 
 int nf_affine_apply(nf_ctx *ctx, const nf_flow_desc *desc, int k, bool inverse, const float *theta, const float *x,
                     long N, float *y, float *ladj, int accumulate) {
   CouplingArgs a;
-  NF_TRY(make_args(desc, k, theta, N, &a));
+  NF_TRY(make_args(ctx, desc, k, theta, N, &a));
   const int mb = blocks32(a.m > a.c ? a.m : a.c), h1b = blocks32(desc->hdims[0]), h2b = blocks32(desc->hdims[1]), cb = mb;
 #define BODY_APPLY                                                              \
   return inverse ? launch_apply<G, true>(ctx, a, x, y, ladj, accumulate)        \
@@ -396,19 +593,26 @@ int nf_affine_apply(nf_ctx *ctx, const nf_flow_desc *desc, int k, bool inverse, 
   return NF_ERR_UNSUPPORTED;
 }
 
-template <class G>
-static int launch_bwd(nf_ctx *ctx, const CouplingArgs &a, float *y, float *ybar, const float *lbar, float lbar_const,
-                      float *slab, long slab_stride, int grid) {
+template <class G, bool FULL>
+static int launch_bwd_v(nf_ctx *ctx, const CouplingArgs &a, float *y, float *ybar, const float *lbar, float lbar_const,
+                        float *slab, long slab_stride, int grid) {
   const size_t lds = BwdLds<G>::BYTES;
   static bool attr_done = false;
   if (!attr_done) {
-    NF_HIP(hipFuncSetAttribute((const void *)k_affine_bwd<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NF_HIP(hipFuncSetAttribute((const void *)k_affine_bwd<G, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
   ProfScope ps(ctx, "affine_bwd");
-  hipLaunchKernelGGL((k_affine_bwd<G>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, y, ybar, lbar, lbar_const,
-                     slab, slab_stride);
+  hipLaunchKernelGGL((k_affine_bwd<G, FULL>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, y, ybar, lbar,
+                     lbar_const, slab, slab_stride);
   return (int)hipGetLastError();
+}
+template <class G>
+static int launch_bwd(nf_ctx *ctx, const CouplingArgs &a, float *y, float *ybar, const float *lbar, float lbar_const,
+                      float *slab, long slab_stride, int grid) {
+  const bool full = a.m == 32 * G::MB && a.c == 32 * G::CB && a.N % NF_TILE == 0;
+  return full ? launch_bwd_v<G, true>(ctx, a, y, ybar, lbar, lbar_const, slab, slab_stride, grid)
+              : launch_bwd_v<G, false>(ctx, a, y, ybar, lbar, lbar_const, slab, slab_stride, grid);
 }
 
 // number of workgroups (= partial-gradient slabs) the reverse pass uses for a batch of N
@@ -423,9 +627,9 @@ int nf_affine_bwd_grid(nf_ctx *ctx, long N) {
 int nf_affine_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const float *theta, float *y, float *ybar,
                   const float *lbar, float lbar_const, long N, float *slab, long slab_stride, int grid) {
   CouplingArgs a;
-  NF_TRY(make_args(desc, k, theta, N, &a));
+  NF_TRY(make_args(ctx, desc, k, theta, N, &a));
   const int mb = blocks32(a.m > a.c ? a.m : a.c), h1b = blocks32(desc->hdims[0]), h2b = blocks32(desc->hdims[1]), cb = mb;
-#define BODY_BWD return launch_bwd<G>(ctx, a, y, ybar, lbar, lbar_const, slab, slab_stride, grid);
+#define BODY_BWD return launch_bwd<G>(ctx, a, y, ybar, lbar, lbar_const, slab + (long)k * 2 * G::SIZE, slab_stride, grid);
   NF_GEO_DISPATCH(1, 1, 1, 1, BODY_BWD)
   NF_GEO_DISPATCH(1, 2, 2, 1, BODY_BWD)
 #undef BODY_BWD

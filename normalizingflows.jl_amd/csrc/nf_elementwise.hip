@@ -275,6 +275,151 @@ __global__ __launch_bounds__(EW_BLOCK) void k_adam(T *__restrict__ theta, const 
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// TILED batch layout used between the coupling kernels (internal to the library):
+// samples are grouped in tiles of 32; element (feature f, sample s of tile t) lives at
+// [(t * d + f) * 32 + s].  A half-wave then reads/writes one full 128-byte line per feature,
+// which is exactly the register layout of the MFMA operands (nf_mfma.h).  Buffers are padded
+// to whole tiles.  Here: one thread per sample (lane <-> sample), loops over features.
+// ---------------------------------------------------------------------------------------
+#define TL 32
+
+__global__ __launch_bounds__(EW_BLOCK) void k_base_sample_tiled(int d, long N, uint32_t k0, uint32_t k1, uint64_t off,
+                                                                uint32_t stream, float *__restrict__ xt,
+                                                                float *__restrict__ logq) {
+  const long j = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
+  if (j >= (N + TL - 1) / TL * TL) return;  // beyond the last (padded) tile: nothing is allocated there
+  const long tile = j / TL;
+  const int s = (int)(j - tile * TL);
+  const bool valid = j < N;
+  float *base = xt + tile * d * TL + s;
+  const int ng = (d + 3) / 4;
+  const uint64_t gj = off + (uint64_t)j;
+  float ss = 0.f;
+  for (int g = 0; g < ng; ++g) {
+    U4 c = {(uint32_t)gj, (uint32_t)(gj >> 32), (uint32_t)g, stream};
+    const U4 r = philox4x32_10(c, k0, k1);
+    float z[4];
+    box_muller<float>(r.x, r.y, z[0], z[1]);
+    box_muller<float>(r.z, r.w, z[2], z[3]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = 4 * g + e;
+      if (i < d) {
+        base[(long)i * TL] = valid ? z[e] : 0.f;  // padding samples are kept finite
+        ss += z[e] * z[e];
+      }
+    }
+  }
+  if (valid && logq) logq[j] = (float)(-0.5 * 1.8378770664093453 * d) - 0.5f * ss;
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void k_base_logpdf_tiled(int d, long N, const float *__restrict__ xt,
+                                                                float *__restrict__ logq) {
+  const long j = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
+  if (j >= N) return;
+  const long tile = j / TL;
+  const float *base = xt + tile * d * TL + (j - tile * TL);
+  float ss = 0.f;
+  for (int i = 0; i < d; ++i) {
+    const float v = base[(long)i * TL];
+    ss += v * v;
+  }
+  logq[j] = (float)(-0.5 * 1.8378770664093453 * d) - 0.5f * ss;
+}
+
+// tiled version of k_target (same outputs)
+__global__ __launch_bounds__(EW_BLOCK) void k_target_tiled(int kind, int d, long N, const float *__restrict__ yt,
+                                                           const float *__restrict__ mu, const float *__restrict__ var,
+                                                           float b_ban, float var_ban, const float *__restrict__ logq,
+                                                           const float *__restrict__ ladj, float *__restrict__ gt,
+                                                           float gscale, float *__restrict__ elbos_out,
+                                                           double *__restrict__ partial, double pscale) {
+  __shared__ double sm[EW_BLOCK / 64];
+  const long jraw = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
+  const bool in_buf = jraw < (N + TL - 1) / TL * TL;  // threads past the last padded tile touch nothing
+  const long j = in_buf ? jraw : 0;
+  const long tile = j / TL;
+  const int s = (int)(j - tile * TL);
+  const bool valid = jraw < N;
+  const float *yb = yt + tile * d * TL + s;
+  float *gb = (gt && in_buf) ? gt + tile * d * TL + s : nullptr;
+  float acc = 0.f;
+  if (kind == NF_TARGET_DIAGGAUSS) {
+    for (int i = 0; i < d; ++i) {
+      const float v = var[i];
+      const float r = yb[(long)i * TL] - mu[i];
+      acc += 1.8378770664093453f + logf(v) + r * r / v;
+      if (gb) gb[(long)i * TL] = valid ? gscale * (-r / v) : 0.f;
+    }
+    acc = -0.5f * acc;
+  } else {
+    const float y0 = yb[0];
+    const float y2 = yb[TL] + b_ban * y0 * y0 - var_ban * b_ban;
+    for (int i = 0; i < d; ++i) {
+      const float v = yb[(long)i * TL];
+      float term, g;
+      if (i == 0) {
+        term = v * v / var_ban;
+        g = -v / var_ban - 2.f * b_ban * v * y2;
+      } else if (i == 1) {
+        term = y2 * y2;
+        g = -y2;
+      } else {
+        term = v * v;
+        g = -v;
+      }
+      acc += term;
+      if (gb) gb[(long)i * TL] = valid ? gscale * g : 0.f;
+    }
+    acc = -0.5f * acc - (logf(var_ban) / (float)d + 1.8378770664093453f) * (float)d / 2.f;
+  }
+  double contrib = 0.0;
+  if (valid) {
+    float e = acc;
+    if (logq) e -= logq[j];
+    if (ladj) e += ladj[j];
+    if (elbos_out) elbos_out[j] = e;
+    contrib = pscale * (double)e;
+  }
+  if (partial) {
+    const double sum = block_sum(contrib, sm);
+    if (threadIdx.x == 0) partial[blockIdx.x] = sum;
+  }
+}
+
+// standard (sample-major, x[j*d + i]) <-> tiled.  One block per tile: the tile is a contiguous
+// run of 32*d floats in the standard layout; it goes through LDS as a [32][d+1] transpose.
+__global__ __launch_bounds__(EW_BLOCK) void k_layout_convert(int d, long N, const float *__restrict__ src,
+                                                             float *__restrict__ dst, int to_tiled) {
+  extern __shared__ float tsm[];  // 32 * (d + 1)
+  const long tile = blockIdx.x;
+  const long j0 = tile * TL;
+  const int nvalid = (int)((N - j0) < TL ? (N - j0) : TL);
+  const int total = TL * d;
+  if (to_tiled) {
+    for (int idx = threadIdx.x; idx < total; idx += EW_BLOCK) {
+      const int sI = idx / d, f = idx - sI * d;
+      tsm[sI * (d + 1) + f] = sI < nvalid ? src[j0 * d + idx] : 0.f;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < total; idx += EW_BLOCK) {
+      const int f = idx / TL, sI = idx - f * TL;
+      dst[tile * total + idx] = tsm[sI * (d + 1) + f];
+    }
+  } else {
+    for (int idx = threadIdx.x; idx < total; idx += EW_BLOCK) {
+      const int f = idx / TL, sI = idx - f * TL;
+      tsm[sI * (d + 1) + f] = src[tile * total + idx];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < total; idx += EW_BLOCK) {
+      const int sI = idx / d;
+      if (sI < nvalid) dst[j0 * d + idx] = tsm[sI * (d + 1) + (idx - sI * d)];
+    }
+  }
+}
+
 template <class T>
 __global__ void k_fill(T *p, long n, T v) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -387,5 +532,48 @@ int nf_launch_fill(nf_ctx *ctx, int dtype, void *p, long n, double v) {
     hipLaunchKernelGGL(k_fill<float>, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, (float *)p, n, (float)v);
   else
     hipLaunchKernelGGL(k_fill<double>, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, (double *)p, n, v);
+  return (int)hipGetLastError();
+}
+
+// ---- tiled-layout launchers (RealNVP / NSF internal path, fp32) ---------------------------
+static inline long ntiles32(long N) { return (N + TL - 1) / TL; }
+
+int nf_launch_base_sample_tiled(nf_ctx *ctx, int d, long N, uint64_t seed, uint64_t off, uint32_t stream, float *xt,
+                                float *logq) {
+  if (N <= 0) return NF_OK;
+  ProfScope ps(ctx, "base_sample");
+  const long padded = ntiles32(N) * TL;
+  hipLaunchKernelGGL(k_base_sample_tiled, dim3(nblk(padded, EW_BLOCK)), dim3(EW_BLOCK), 0, ctx->stream, d, N,
+                     (uint32_t)seed, (uint32_t)(seed >> 32), off, stream, xt, logq);
+  return (int)hipGetLastError();
+}
+
+int nf_launch_base_logpdf_tiled(nf_ctx *ctx, int d, long N, const float *xt, float *logq) {
+  if (N <= 0) return NF_OK;
+  hipLaunchKernelGGL(k_base_logpdf_tiled, dim3(nblk(N, EW_BLOCK)), dim3(EW_BLOCK), 0, ctx->stream, d, N, xt, logq);
+  return (int)hipGetLastError();
+}
+
+long nf_target_tiled_nblocks(long N) { return nblk(ntiles32(N) * TL, EW_BLOCK); }
+
+int nf_launch_target_tiled(nf_ctx *ctx, const nf_target *t, int d, long N, const float *yt, const float *logq,
+                           const float *ladj, float *gt, double gscale, float *elbos_out, double *partial,
+                           double pscale) {
+  if (N <= 0) return NF_OK;
+  if (t->kind != NF_TARGET_DIAGGAUSS && t->kind != NF_TARGET_BANANA) return NF_ERR_ARG;
+  if (t->kind == NF_TARGET_DIAGGAUSS && (!t->p0 || !t->p1)) return NF_ERR_ARG;
+  if (t->kind == NF_TARGET_BANANA && d < 2) return NF_ERR_ARG;
+  ProfScope ps(ctx, "target");
+  hipLaunchKernelGGL(k_target_tiled, dim3((unsigned)nf_target_tiled_nblocks(N)), dim3(EW_BLOCK), 0, ctx->stream,
+                     t->kind, d, N, yt, (const float *)t->p0, (const float *)t->p1, (float)t->s0, (float)t->s1, logq,
+                     ladj, gt, (float)gscale, elbos_out, partial, pscale);
+  return (int)hipGetLastError();
+}
+
+int nf_launch_layout_convert(nf_ctx *ctx, int d, long N, const float *src, float *dst, int to_tiled) {
+  if (N <= 0) return NF_OK;
+  ProfScope ps(ctx, "layout_convert");
+  hipLaunchKernelGGL(k_layout_convert, dim3((unsigned)ntiles32(N)), dim3(EW_BLOCK), (size_t)TL * (d + 1) * sizeof(float),
+                     ctx->stream, d, N, src, dst, to_tiled);
   return (int)hipGetLastError();
 }

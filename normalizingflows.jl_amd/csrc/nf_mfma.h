@@ -250,6 +250,45 @@ __device__ __forceinline__ void stage_net(float *__restrict__ img, const float *
   stage_bias(img + G::B3, 32 * G::CB, theta + nd.b3, nd.c, tid, nthreads);
 }
 
+// Stage a PRE-PACKED image (k_pack_net_images: same layout, already padded and zero filled)
+// from global memory: a straight 16-byte-vector copy with every load issued before the first
+// LDS store, so the HBM/L2 latency is paid once per staging instead of once per element.
+template <int SIZE, int NTHREADS>
+__device__ __forceinline__ void stage_packed(float *__restrict__ img, const float *__restrict__ packed, int tid) {
+  constexpr int NV4 = SIZE / 4;
+  constexpr int PER = (NV4 + NTHREADS - 1) / NTHREADS;
+  const float4 *src = reinterpret_cast<const float4 *>(packed);
+  float4 *dst = reinterpret_cast<float4 *>(img);
+  float4 tmp[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int idx = tid + k * NTHREADS;
+    tmp[k] = idx < NV4 ? src[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int idx = tid + k * NTHREADS;
+    if (idx < NV4) dst[idx] = tmp[k];
+  }
+}
+
+// theta index of element `e` of a net's padded image, or -1 for padding
+template <class G>
+__device__ __forceinline__ long image_theta_index(const NetDims &nd, int e) {
+  int rows, S, nin, nout, base;
+  long w, b;
+  if (e < G::W2) { base = G::W1; rows = 32 * G::MB; S = G::S1; nin = nd.m; nout = nd.h1; w = nd.w1; b = nd.b1; }
+  else if (e < G::W3) { base = G::W2; rows = 32 * G::H1B; S = G::S2; nin = nd.h1; nout = nd.h2; w = nd.w2; b = nd.b2; }
+  else { base = G::W3; rows = 32 * G::H2B; S = G::S3; nin = nd.h2; nout = nd.c; w = nd.w3; b = nd.b3; }
+  const int r = e - base;
+  if (r < rows * S) {
+    const int i = r / S, o = r - i * S;
+    return (i < nin && o < nout) ? w + (long)i * nout + o : -1;
+  }
+  const int o = r - rows * S;
+  return o < nout ? b + o : -1;
+}
+
 // Forward through the 2-hidden-layer net.  a1/a2 are the post-leakyrelu activations
 // (kept for the reverse pass), out the pre-output-activation result.
 template <class G>
