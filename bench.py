@@ -51,7 +51,7 @@ def cpu_baseline(seconds_budget: float = 12.0):
         threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count() or 1])
     except Exception:
         threads = os.cpu_count() or 1
-    n = 8192
+    n = 16384
     spec = orc.FlowSpec("realnvp", D, NLAYERS, HDIMS)
     rng = np.random.default_rng(123)
     theta = orc.init_params(spec, rng, dtype=np.float32)
@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=BATCH, help="samples per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="do not bracket kernels with HIP events in the timed region (roofline object is then empty)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -140,7 +142,8 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
-    nf._lib.check(lib.nf_prof_enable(ctx.ptr, 1))  # HIP events on the launch stream, over the timed region
+    if not args.no_kernel_events:
+        nf._lib.check(lib.nf_prof_enable(ctx.ptr, 1))  # HIP events on the launch stream, over the timed region
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         step(i)
@@ -155,11 +158,17 @@ def main():
 
     avg_ms, cnt = C.c_double(0.0), C.c_int64(0)
     nf._lib.check(lib.nf_prof_read(ctx.ptr, b"affine_bwd", C.byref(avg_ms), C.byref(cnt)))
+    # per-kernel breakdown: a few extra, UNTIMED steps with every kernel bracketed
     kernel_ms = {}
-    for name in (b"base_sample", b"affine_apply", b"target", b"affine_bwd", b"reduce_slabs", b"adam"):
+    nbreak = 5
+    nf._lib.check(lib.nf_prof_enable(ctx.ptr, 2))
+    for i in range(nbreak):
+        step(args.warmup + args.steps + i)
+    torch.cuda.synchronize(dev)
+    for name in (b"base_sample", b"pack_weights", b"affine_chain", b"target", b"affine_bwd", b"reduce_slabs", b"adam"):
         a, c = C.c_double(0.0), C.c_int64(0)
         lib.nf_prof_read(ctx.ptr, name, C.byref(a), C.byref(c))
-        kernel_ms[name.decode()] = {"avg_ms": round(a.value, 5), "launches_per_step": c.value / max(1, args.steps)}
+        kernel_ms[name.decode()] = {"avg_ms": round(a.value, 5), "launches_per_step": c.value / nbreak}
     nf._lib.check(lib.nf_prof_enable(ctx.ptr, 0))
 
     if rank == 0:

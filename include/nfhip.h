@@ -184,9 +184,10 @@ int nf_elbo_step(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target,
                  double beta1, double beta2, double eps, double *loss_host, double *gnorm_host);
 
 /* ---- measurement support ---------------------------------------------------- */
-/* Average duration (ms) of the dominant kernel launches recorded with HIP events on the
- * context stream since the last reset (used by bench.py's roofline object). */
-int nf_prof_enable(nf_ctx *ctx, int32_t on);
+/* Kernel durations from HIP events recorded on the context stream around launches since the
+ * last nf_prof_enable (used by bench.py's roofline object).  mode 0 = off, 1 = bracket only the
+ * dominant kernel (the coupling reverse pass), 2 = bracket every kernel. */
+int nf_prof_enable(nf_ctx *ctx, int32_t mode);
 int nf_prof_read(nf_ctx *ctx, const char *kernel_name, double *avg_ms_host, int64_t *count_host);
 /* Kernel-tuning aid: when on, block 0 / wave 0 of the coupling reverse pass writes s_memtime
  * stamps at its phase boundaries; a later call copies up to 128 of them to stamps_host. */

@@ -29,6 +29,7 @@ int nf_affine_apply(nf_ctx *, const nf_flow_desc *, int k, bool inverse, const f
                     float *y, float *ladj, int accumulate);
 int nf_affine_bwd_grid(nf_ctx *, long N);
 int nf_affine_pack(nf_ctx *, const nf_flow_desc *, const float *theta);
+int nf_affine_chain(nf_ctx *, const nf_flow_desc *, bool inverse, float *xt, long N, float *ladj);
 long nf_affine_slab_floats(const nf_flow_desc *desc);
 int nf_affine_reduce_slabs(nf_ctx *, const nf_flow_desc *, const float *slab, int nslab, float *g);
 int nf_affine_bwd(nf_ctx *, const nf_flow_desc *, int k, const float *theta, float *y, float *ybar, const float *lbar,
@@ -160,11 +161,7 @@ extern "C" int nf_ctx_destroy(nf_ctx *ctx) {
   if (!ctx) return NF_ERR_ARG;
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
-  for (auto &kv : ctx->prof_events)
-    for (auto &p : kv.second) {
-      hipEventDestroy(p.first);
-      hipEventDestroy(p.second);
-    }
+  for (auto &e : ctx->prof_pool) hipEventDestroy(e);
   if (ctx->ws) hipFree(ctx->ws);
   if (ctx->gbuf) hipFree(ctx->gbuf);
   if (ctx->wimg) hipFree(ctx->wimg);
@@ -232,12 +229,7 @@ static int coupling_chain_tiled(nf_ctx *ctx, const nf_flow_desc *desc, bool inve
                                 long N, float *ladj, int k_only) {
   NF_TRY(nf_affine_pack(ctx, desc, theta));
   if (k_only >= 0) return nf_affine_apply(ctx, desc, k_only, inverse, theta, xt, N, xt, ladj, 0);
-  const int nc = 2 * desc->nlayers;
-  for (int s = 0; s < nc; ++s) {
-    const int k = inverse ? s : nc - 1 - s;
-    NF_TRY(nf_affine_apply(ctx, desc, k, inverse, theta, xt, N, xt, ladj, s > 0));
-  }
-  return NF_OK;
+  return nf_affine_chain(ctx, desc, inverse, xt, N, ladj);
 }
 
 // standard-layout in/out wrapper used by nf_flow_fwd / nf_flow_inv / nf_layer_apply
@@ -545,16 +537,16 @@ extern "C" int nf_elbo_step(nf_ctx *ctx, const nf_flow_desc *desc, const nf_targ
 }
 
 // ---- measurement support -------------------------------------------------------------------
-extern "C" int nf_prof_enable(nf_ctx *ctx, int32_t on) {
-  if (!ctx) return NF_ERR_ARG;
+extern "C" int nf_prof_enable(nf_ctx *ctx, int32_t mode) {
+  if (!ctx || mode < 0 || mode > 2) return NF_ERR_ARG;
   NF_HIP(hipStreamSynchronize(ctx->stream));
-  for (auto &kv : ctx->prof_events)
-    for (auto &p : kv.second) {
-      hipEventDestroy(p.first);
-      hipEventDestroy(p.second);
-    }
   ctx->prof_events.clear();
-  ctx->prof = on != 0;
+  ctx->prof_pool_next = 0;
+  if (mode && ctx->prof_pool.empty()) {
+    ctx->prof_pool.resize(16384);
+    for (auto &e : ctx->prof_pool) NF_HIP(hipEventCreate(&e));
+  }
+  ctx->prof_mode = mode;
   return NF_OK;
 }
 

@@ -43,7 +43,9 @@ struct nf_ctx {
   void *gbuf = nullptr;
   size_t gbuf_bytes = 0;
   // per-kernel HIP-event timing (bench.py roofline): name -> list of (start, stop)
-  bool prof = false;
+  int prof_mode = 0;
+  std::vector<hipEvent_t> prof_pool;  // pre-created events, reused
+  size_t prof_pool_next = 0;
   std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof_events;
 };
 
@@ -63,20 +65,22 @@ struct Carver {
 };
 inline size_t carve_bytes(size_t nbytes) { return ((nbytes + 255) / 256) * 256; }
 
-// RAII-less profiling bracket: records events on ctx->stream around a launch
+// profiling bracket: records a pair of pooled HIP events on ctx->stream around a launch.
+// prof_mode 1 brackets only the dominant kernel ("affine_bwd" / "rqs_bwd"), 2 brackets all.
 struct ProfScope {
   nf_ctx *ctx;
-  hipEvent_t a = nullptr, b = nullptr;
+  hipEvent_t b = nullptr;
   ProfScope(nf_ctx *c, const char *name) : ctx(c) {
-    if (ctx->prof) {
-      hipEventCreate(&a);
-      hipEventCreate(&b);
-      hipEventRecord(a, ctx->stream);
-      ctx->prof_events[name].push_back({a, b});
-    }
+    if (!ctx->prof_mode) return;
+    if (ctx->prof_mode == 1 && std::strcmp(name, "affine_bwd") != 0 && std::strcmp(name, "rqs_bwd") != 0) return;
+    if (ctx->prof_pool_next + 2 > ctx->prof_pool.size()) return;  // pool exhausted: stop sampling
+    hipEvent_t a = ctx->prof_pool[ctx->prof_pool_next++];
+    b = ctx->prof_pool[ctx->prof_pool_next++];
+    hipEventRecord(a, ctx->stream);
+    ctx->prof_events[name].push_back({a, b});
   }
   ~ProfScope() {
-    if (a) hipEventRecord(b, ctx->stream);
+    if (b) hipEventRecord(b, ctx->stream);
   }
 };
 

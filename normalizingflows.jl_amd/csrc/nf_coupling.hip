@@ -105,13 +105,13 @@ __global__ __launch_bounds__(512) void k_affine_apply(CouplingArgs a, const floa
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int p = b * 32 + nf_row(r, hi);
-        const float s = tanhf(S[b][r]);  // padded rows: zero weights and bias => s = 0
+        const float s = nf_tanh(S[b][r]);  // padded rows: zero weights and bias => s = 0
         const float v = x1[b][r];
         float o;
         if (INVERSE)
-          o = (v - T[b][r]) * expf(-s);
+          o = (v - T[b][r]) * nf_exp(-s);
         else
-          o = v * expf(s) + T[b][r];
+          o = v * nf_exp(s) + T[b][r];
         tile_store(yout, tile_soff(b, r, a.par_t), o);  // rows >= c are outside the descriptor
         lsum += (FULL || p < a.c) ? s : 0.f;
       }
@@ -119,6 +119,148 @@ __global__ __launch_bounds__(512) void k_affine_apply(CouplingArgs a, const floa
     if (hi == 0 && valid) {
       const float base = ladj_accumulate ? ladj[j] : 0.f;
       ladj[j] = INVERSE ? base - lsum : base + lsum;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// whole-flow forward / inverse in ONE launch (with_logabsdet_jacobian of the ComposedFunction,
+// reached from src/objectives/elbo.jl:67; inverse chain from loglikelihood.jl:31)
+// ------------------------------------------------------------------------------------
+// A workgroup (8 waves) takes a group of 8 tiles through every coupling.  The state of a tile
+// lives in registers for the whole chain, split by feature parity: E = features 0,2,4,..
+// (transformed by the 1:2:d couplings), O = features 1,3,5,.. (transformed by the 2:2:d ones),
+// so "partition/combine" is just which of the two register blocks plays x1 and which x2.
+// The two nets of the NEXT coupling are fetched from their packed images (L2) while the current
+// coupling computes, into the other half of a double-buffered LDS image.
+struct ChainArgs {
+  const float *wimg;  // [coupling][s|t][G::SIZE] packed images
+  int d, ncoup;
+  long N;
+};
+
+template <class G, bool INVERSE>
+__device__ __forceinline__ float coupling_step(const float *__restrict__ img_s, const float *__restrict__ img_t,
+                                               f32x16 (&x1)[G::CB], const f32x16 (&xb)[G::MB], int l31, int hi) {
+  f32x16 S[G::CB], T[G::CB];
+  {
+    f32x16 a1[G::H1B], a2[G::H2B];
+    net_forward<G>(img_s, xb, a1, a2, S, l31, hi);
+  }
+  {
+    f32x16 a1[G::H1B], a2[G::H2B];
+    net_forward<G>(img_t, xb, a1, a2, T, l31, hi);
+  }
+  float lsum = 0.f;
+#pragma unroll
+  for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      // rows >= c have zero weights and biases in the packed image: s = 0, T = 0, x1 stays 0
+      const float s = nf_tanh(S[b][r]);
+      if (INVERSE)
+        x1[b][r] = __fdividef(x1[b][r] - T[b][r], nf_exp(s));
+      else
+        x1[b][r] = x1[b][r] * nf_exp(s) + T[b][r];
+      lsum += s;
+    }
+  return lsum;
+}
+
+template <class G, bool INVERSE>
+__global__ __launch_bounds__(512) void k_affine_chain(ChainArgs a, float *xt, float *__restrict__ ladj) {
+  static_assert(G::MB == G::CB, "parity blocks must have equal padded size");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int IMG2 = 2 * G::SIZE;  // s and t images of one coupling are adjacent in wimg
+  constexpr int NV4 = IMG2 / 4;
+  constexpr int PER = (NV4 + 511) / 512;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const long ntiles = (a.N + NF_TILE - 1) / NF_TILE;
+  const long ngroups = (ntiles + 7) / 8;
+  // coupling executed at position s of the chain: forward applies the LAST flat coupling first
+  auto coupling_at = [&](int s) { return INVERSE ? s : a.ncoup - 1 - s; };
+
+  // prologue: image of the first coupling -> buffer 0
+  {
+    const float4 *src = reinterpret_cast<const float4 *>(a.wimg + (long)coupling_at(0) * IMG2);
+    float4 *dst = reinterpret_cast<float4 *>(lds);
+    for (int i = tid; i < NV4; i += 512) dst[i] = src[i];
+  }
+  __syncthreads();
+
+  int buf = 0;
+  for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const long tile = grp * 8 + wave;
+    const bool live = tile < ntiles;          // wave-uniform
+    const long tl = live ? tile : 0;
+    const long j = tl * NF_TILE + l31;
+    const bool valid = live && j < a.N;
+    const TileIO io = make_tile_io(xt, tl, a.d, l31, hi);
+    f32x16 E[G::CB], O[G::MB];
+#pragma unroll
+    for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = tile_load(io, tile_soff(b, r, 0));  // features >= d read as 0
+        const float o = tile_load(io, tile_soff(b, r, 1));
+        E[b][r] = valid ? e : 0.f;
+        O[b][r] = valid ? o : 0.f;
+      }
+    float lsum = 0.f;
+    const bool more_groups = grp + gridDim.x < ngroups;
+#pragma unroll 1
+    for (int s = 0; s < a.ncoup; s += 2) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int pos = s + half;
+        // prefetch the next coupling's images (wraps to the first coupling for the next tile group)
+        const bool have_next = pos + 1 < a.ncoup || more_groups;
+        const int knext = coupling_at(pos + 1 < a.ncoup ? pos + 1 : 0);
+        float4 tmp[PER];
+        if (have_next) {
+          const float4 *src = reinterpret_cast<const float4 *>(a.wimg + (long)knext * IMG2);
+#pragma unroll
+          for (int q = 0; q < PER; ++q) {
+            const int idx = tid + q * 512;
+            tmp[q] = idx < NV4 ? src[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
+        const float *img_s = lds + buf * IMG2;
+        const float *img_t = img_s + G::SIZE;
+        // forward order: position 0 is the last flat coupling (odd index => mask 2:2:d => x1 = O)
+        const bool x1_is_O = (coupling_at(pos) & 1) != 0;  // compile-time per (INVERSE, half) when ncoup is even
+        float ls;
+        if (INVERSE ? (half == 1) : (half == 0)) {
+          (void)x1_is_O;
+          ls = coupling_step<G, INVERSE>(img_s, img_t, O, E, l31, hi);
+        } else {
+          ls = coupling_step<G, INVERSE>(img_s, img_t, E, O, l31, hi);
+        }
+        lsum += ls;
+        if (have_next) {
+          float4 *dst = reinterpret_cast<float4 *>(lds + (buf ^ 1) * IMG2);
+#pragma unroll
+          for (int q = 0; q < PER; ++q) {
+            const int idx = tid + q * 512;
+            if (idx < NV4) dst[idx] = tmp[q];
+          }
+        }
+        __syncthreads();
+        buf ^= 1;
+      }
+    }
+    if (live) {
+#pragma unroll
+      for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          tile_store(io, tile_soff(b, r, 0), E[b][r]);
+          tile_store(io, tile_soff(b, r, 1), O[b][r]);
+        }
+      lsum += __shfl_xor(lsum, 32);
+      if (hi == 0 && valid) ladj[j] = INVERSE ? -lsum : lsum;
     }
   }
 }
@@ -299,9 +441,10 @@ __device__ __forceinline__ void bwd_tile(const CouplingArgs &a, const float *__r
         tile_store(yio, tile_soff(b, r, a.par_t), yv - d3[b][r]);  // u = x1 * exp(S)
         d3[b][r] = ok ? gv : 0.f;                                   // T-bar = ybar1
       } else {
-        const float s = tanhf(d3[b][r]);
-        tile_store(yio, tile_soff(b, r, a.par_t), yv * expf(-s));  // x1
-        tile_store(gio, tile_soff(b, r, a.par_t), gv * expf(s));   // x1bar
+        const float s = nf_tanh(d3[b][r]);
+        const float es = nf_exp(s);
+        tile_store(yio, tile_soff(b, r, a.par_t), __fdividef(yv, es));  // x1 = u * exp(-s)
+        tile_store(gio, tile_soff(b, r, a.par_t), gv * es);             // x1bar
         d3[b][r] = ok ? (gv * yv + lb) * (1.f - s * s) : 0.f;      // S-bar through tanh
       }
     }
@@ -607,6 +750,39 @@ static int launch_bwd_v(nf_ctx *ctx, const CouplingArgs &a, float *y, float *yba
                      lbar_const, slab, slab_stride);
   return (int)hipGetLastError();
 }
+template <class G>
+static int launch_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, float *xt, long N, float *ladj) {
+  const size_t lds = 4 * (size_t)G::SIZE * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  ChainArgs a;
+  a.wimg = (const float *)ctx->wimg;
+  a.d = desc->d;
+  a.ncoup = 2 * desc->nlayers;
+  a.N = N;
+  const long ngroups = ((N + NF_TILE - 1) / NF_TILE + 7) / 8;
+  long grid = ngroups < ctx->num_cu ? ngroups : ctx->num_cu;
+  if (grid < 1) grid = 1;
+  ProfScope ps(ctx, "affine_chain");
+  if (inverse)
+    hipLaunchKernelGGL((k_affine_chain<G, true>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj);
+  else
+    hipLaunchKernelGGL((k_affine_chain<G, false>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj);
+  return (int)hipGetLastError();
+}
+
+// whole chain in one launch, in place on the tiled buffer (packed images must be current)
+int nf_affine_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, float *xt, long N, float *ladj) {
+  const int size = geo_size(desc);
+  if (!size || !ctx->wimg) return NF_ERR_UNSUPPORTED;
+  if (size == NetGeo<1, 1, 1, 1>::SIZE) return launch_chain<NetGeo<1, 1, 1, 1>>(ctx, desc, inverse, xt, N, ladj);
+  return launch_chain<NetGeo<1, 2, 2, 1>>(ctx, desc, inverse, xt, N, ladj);
+}
+
 template <class G>
 static int launch_bwd(nf_ctx *ctx, const CouplingArgs &a, float *y, float *ybar, const float *lbar, float lbar_const,
                       float *slab, long slab_stride, int grid) {

@@ -284,19 +284,25 @@ __global__ __launch_bounds__(EW_BLOCK) void k_adam(T *__restrict__ theta, const 
 // ---------------------------------------------------------------------------------------
 #define TL 32
 
+// Thread mapping of the tiled element-wise kernels: a block of 256 threads = 32 samples (one tile,
+// lane & 31) x 8 feature slices (threadIdx.x >> 5); slice q owns features q, q+8, ... (groups of 4
+// for the sampler).  Every access is one 128-byte line per 32 lanes; per-sample sums are combined
+// across the 8 slices through LDS.
+#define FS 8  // feature slices per tile
+
 __global__ __launch_bounds__(EW_BLOCK) void k_base_sample_tiled(int d, long N, uint32_t k0, uint32_t k1, uint64_t off,
                                                                 uint32_t stream, float *__restrict__ xt,
                                                                 float *__restrict__ logq) {
-  const long j = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
-  if (j >= (N + TL - 1) / TL * TL) return;  // beyond the last (padded) tile: nothing is allocated there
-  const long tile = j / TL;
-  const int s = (int)(j - tile * TL);
+  __shared__ float red[FS][TL];
+  const long tile = blockIdx.x;
+  const int s = threadIdx.x & (TL - 1), q = threadIdx.x >> 5;
+  const long j = tile * TL + s;
   const bool valid = j < N;
   float *base = xt + tile * d * TL + s;
   const int ng = (d + 3) / 4;
   const uint64_t gj = off + (uint64_t)j;
   float ss = 0.f;
-  for (int g = 0; g < ng; ++g) {
+  for (int g = q; g < ng; g += FS) {
     U4 c = {(uint32_t)gj, (uint32_t)(gj >> 32), (uint32_t)g, stream};
     const U4 r = philox4x32_10(c, k0, k1);
     float z[4];
@@ -311,52 +317,65 @@ __global__ __launch_bounds__(EW_BLOCK) void k_base_sample_tiled(int d, long N, u
       }
     }
   }
-  if (valid && logq) logq[j] = (float)(-0.5 * 1.8378770664093453 * d) - 0.5f * ss;
+  red[q][s] = ss;
+  __syncthreads();
+  if (q == 0 && valid && logq) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < FS; ++k) t += red[k][s];
+    logq[j] = (float)(-0.5 * 1.8378770664093453 * d) - 0.5f * t;
+  }
 }
 
 __global__ __launch_bounds__(EW_BLOCK) void k_base_logpdf_tiled(int d, long N, const float *__restrict__ xt,
                                                                 float *__restrict__ logq) {
-  const long j = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
-  if (j >= N) return;
-  const long tile = j / TL;
-  const float *base = xt + tile * d * TL + (j - tile * TL);
+  __shared__ float red[FS][TL];
+  const long tile = blockIdx.x;
+  const int s = threadIdx.x & (TL - 1), q = threadIdx.x >> 5;
+  const long j = tile * TL + s;
+  const float *base = xt + tile * d * TL + s;
   float ss = 0.f;
-  for (int i = 0; i < d; ++i) {
+  for (int i = q; i < d; i += FS) {
     const float v = base[(long)i * TL];
     ss += v * v;
   }
-  logq[j] = (float)(-0.5 * 1.8378770664093453 * d) - 0.5f * ss;
+  red[q][s] = ss;
+  __syncthreads();
+  if (q == 0 && j < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < FS; ++k) t += red[k][s];
+    logq[j] = (float)(-0.5 * 1.8378770664093453 * d) - 0.5f * t;
+  }
 }
 
-// tiled version of k_target (same outputs)
+// tiled version of k_target (same outputs); one block per tile
 __global__ __launch_bounds__(EW_BLOCK) void k_target_tiled(int kind, int d, long N, const float *__restrict__ yt,
                                                            const float *__restrict__ mu, const float *__restrict__ var,
                                                            float b_ban, float var_ban, const float *__restrict__ logq,
                                                            const float *__restrict__ ladj, float *__restrict__ gt,
                                                            float gscale, float *__restrict__ elbos_out,
                                                            double *__restrict__ partial, double pscale) {
+  __shared__ float red[FS][TL];
   __shared__ double sm[EW_BLOCK / 64];
-  const long jraw = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
-  const bool in_buf = jraw < (N + TL - 1) / TL * TL;  // threads past the last padded tile touch nothing
-  const long j = in_buf ? jraw : 0;
-  const long tile = j / TL;
-  const int s = (int)(j - tile * TL);
-  const bool valid = jraw < N;
+  const long tile = blockIdx.x;
+  const int s = threadIdx.x & (TL - 1), q = threadIdx.x >> 5;
+  const long j = tile * TL + s;
+  const bool valid = j < N;
   const float *yb = yt + tile * d * TL + s;
-  float *gb = (gt && in_buf) ? gt + tile * d * TL + s : nullptr;
+  float *gb = gt ? gt + tile * d * TL + s : nullptr;
   float acc = 0.f;
   if (kind == NF_TARGET_DIAGGAUSS) {
-    for (int i = 0; i < d; ++i) {
+    for (int i = q; i < d; i += FS) {
       const float v = var[i];
       const float r = yb[(long)i * TL] - mu[i];
       acc += 1.8378770664093453f + logf(v) + r * r / v;
       if (gb) gb[(long)i * TL] = valid ? gscale * (-r / v) : 0.f;
     }
-    acc = -0.5f * acc;
-  } else {
+  } else {  // Banana: example/targets/banana.jl:58-63,77-83
     const float y0 = yb[0];
     const float y2 = yb[TL] + b_ban * y0 * y0 - var_ban * b_ban;
-    for (int i = 0; i < d; ++i) {
+    for (int i = q; i < d; i += FS) {
       const float v = yb[(long)i * TL];
       float term, g;
       if (i == 0) {
@@ -372,11 +391,16 @@ __global__ __launch_bounds__(EW_BLOCK) void k_target_tiled(int kind, int d, long
       acc += term;
       if (gb) gb[(long)i * TL] = valid ? gscale * g : 0.f;
     }
-    acc = -0.5f * acc - (logf(var_ban) / (float)d + 1.8378770664093453f) * (float)d / 2.f;
   }
+  red[q][s] = acc;
+  __syncthreads();
   double contrib = 0.0;
-  if (valid) {
-    float e = acc;
+  if (q == 0 && valid) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < FS; ++k) t += red[k][s];
+    float e = -0.5f * t;
+    if (kind != NF_TARGET_DIAGGAUSS) e -= (logf(var_ban) / (float)d + 1.8378770664093453f) * (float)d / 2.f;
     if (logq) e -= logq[j];
     if (ladj) e += ladj[j];
     if (elbos_out) elbos_out[j] = e;
@@ -542,19 +566,18 @@ int nf_launch_base_sample_tiled(nf_ctx *ctx, int d, long N, uint64_t seed, uint6
                                 float *logq) {
   if (N <= 0) return NF_OK;
   ProfScope ps(ctx, "base_sample");
-  const long padded = ntiles32(N) * TL;
-  hipLaunchKernelGGL(k_base_sample_tiled, dim3(nblk(padded, EW_BLOCK)), dim3(EW_BLOCK), 0, ctx->stream, d, N,
+  hipLaunchKernelGGL(k_base_sample_tiled, dim3((unsigned)ntiles32(N)), dim3(EW_BLOCK), 0, ctx->stream, d, N,
                      (uint32_t)seed, (uint32_t)(seed >> 32), off, stream, xt, logq);
   return (int)hipGetLastError();
 }
 
 int nf_launch_base_logpdf_tiled(nf_ctx *ctx, int d, long N, const float *xt, float *logq) {
   if (N <= 0) return NF_OK;
-  hipLaunchKernelGGL(k_base_logpdf_tiled, dim3(nblk(N, EW_BLOCK)), dim3(EW_BLOCK), 0, ctx->stream, d, N, xt, logq);
+  hipLaunchKernelGGL(k_base_logpdf_tiled, dim3((unsigned)ntiles32(N)), dim3(EW_BLOCK), 0, ctx->stream, d, N, xt, logq);
   return (int)hipGetLastError();
 }
 
-long nf_target_tiled_nblocks(long N) { return nblk(ntiles32(N) * TL, EW_BLOCK); }
+long nf_target_tiled_nblocks(long N) { return ntiles32(N); }
 
 int nf_launch_target_tiled(nf_ctx *ctx, const nf_target *t, int d, long N, const float *yt, const float *logq,
                            const float *ladj, float *gt, double gscale, float *elbos_out, double *partial,

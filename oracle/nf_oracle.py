@@ -181,7 +181,7 @@ def sigmoid(x):
 def leakyrelu(x, slope=0.01):
     """Flux.leakyrelu default slope 0.01 (NNlib); hidden activation of fnn,
     src/flows/utils.jl:76."""
-    return np.where(x > 0, x, x.dtype.type(slope) * x)
+    return np.maximum(x, x.dtype.type(slope) * x)  # == where(x > 0, x, slope*x) for 0 < slope < 1
 
 
 def _dense_views(theta, net):
@@ -220,7 +220,7 @@ def mlp_backward(theta, net, acts, dout, grad, out_act=None):
             if out_act == "tanh":
                 delta = delta * (1.0 - a_out * a_out)
         else:
-            delta = delta * np.where(a_out > 0, 1.0, 0.01).astype(delta.dtype)
+            delta = delta * (delta.dtype.type(0.01) + delta.dtype.type(0.99) * (a_out > 0))
         (w_off, b_off, nout, nin) = net[li]
         dW = delta @ acts[li].T  # (nout, nin)
         grad[w_off : w_off + nout * nin] += dW.T.reshape(-1)  # column-major out x in
