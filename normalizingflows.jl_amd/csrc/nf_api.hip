@@ -35,6 +35,16 @@ int nf_affine_reduce_slabs(nf_ctx *, const nf_flow_desc *, const float *slab, in
 int nf_affine_bwd(nf_ctx *, const nf_flow_desc *, int k, const float *theta, float *y, float *ybar, const float *lbar,
                   float lbar_const, long N, float *slab, long slab_stride, int grid);
 
+// neural spline couplings (nf_rqs.hip)
+bool nf_rqs_supported(const nf_flow_desc *desc);
+int nf_rqs_pack(nf_ctx *, const nf_flow_desc *, const float *theta);
+int nf_rqs_chain(nf_ctx *, const nf_flow_desc *, bool inverse, float *xt, long N, float *ladj, int k_only);
+int nf_rqs_bwd_grid(nf_ctx *, long N);
+int nf_rqs_bwd(nf_ctx *, const nf_flow_desc *, int k, float *y, float *ybar, const float *lbar, float lbar_const, long N,
+               float *slab, long slab_stride, int grid);
+long nf_rqs_slab_floats(const nf_flow_desc *desc);
+int nf_rqs_reduce_slabs(nf_ctx *, const nf_flow_desc *, const float *slab, int nslab, float *g);
+
 // planar / radial / mean-field flows (nf_simple.hip)
 bool nf_simple_supported(const nf_flow_desc *desc);
 int nf_simple_apply(nf_ctx *, const nf_flow_desc *, int layer_lo, int layer_hi, bool inverse, const void *theta,
@@ -61,7 +71,9 @@ static int check_desc(const nf_flow_desc *d) {
       if (d->dtype != NF_DTYPE_F32) return NF_ERR_UNSUPPORTED;
       return nf_affine_supported(d) ? NF_OK : NF_ERR_UNSUPPORTED;
     case NF_KIND_NSF:
-      return NF_ERR_UNSUPPORTED;
+      if (d->n_hidden < 1 || d->n_hidden > NF_MAX_HIDDEN || d->d < 2 || d->K < 2) return NF_ERR_ARG;
+      if (d->dtype != NF_DTYPE_F32) return NF_ERR_UNSUPPORTED;
+      return nf_rqs_supported(d) ? NF_OK : NF_ERR_UNSUPPORTED;
     default:
       return NF_ERR_ARG;
   }
@@ -222,12 +234,25 @@ extern "C" int nf_base_logpdf(nf_ctx *ctx, int32_t dtype, int32_t d, int64_t N, 
 // Coupling flows work on the TILED batch layout internally (nf_elementwise.hip); user-facing
 // batches are converted at the API edge.  Element count of a tiled buffer:
 static inline size_t tiled_elems(const nf_flow_desc *desc, long N) { return (size_t)((N + 31) / 32) * 32 * desc->d; }
-static inline bool is_coupling(const nf_flow_desc *desc) { return desc->kind == NF_KIND_REALNVP; }
+static inline bool is_coupling(const nf_flow_desc *desc) {
+  return desc->kind == NF_KIND_REALNVP || desc->kind == NF_KIND_NSF;
+}
+static inline bool is_nsf(const nf_flow_desc *desc) { return desc->kind == NF_KIND_NSF; }
+static int coupling_pack(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta) {
+  return is_nsf(desc) ? nf_rqs_pack(ctx, desc, theta) : nf_affine_pack(ctx, desc, theta);
+}
+static int coupling_bwd_grid(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
+  return is_nsf(desc) ? nf_rqs_bwd_grid(ctx, N) : nf_affine_bwd_grid(ctx, N);
+}
+static long coupling_slab_floats(const nf_flow_desc *desc) {
+  return is_nsf(desc) ? nf_rqs_slab_floats(desc) : nf_affine_slab_floats(desc);
+}
 
 // all couplings (or one, if k_only >= 0) in execution order / inverse order, in place on `xt`
 static int coupling_chain_tiled(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, const float *theta, float *xt,
                                 long N, float *ladj, int k_only) {
-  NF_TRY(nf_affine_pack(ctx, desc, theta));
+  NF_TRY(coupling_pack(ctx, desc, theta));
+  if (is_nsf(desc)) return nf_rqs_chain(ctx, desc, inverse, xt, N, ladj, k_only);
   if (k_only >= 0) return nf_affine_apply(ctx, desc, k_only, inverse, theta, xt, N, xt, ladj, 0);
   return nf_affine_chain(ctx, desc, inverse, xt, N, ladj);
 }
@@ -277,10 +302,15 @@ extern "C" int nf_layer_apply(nf_ctx *ctx, const nf_flow_desc *desc, int32_t lay
 // the flow INPUT on exit (invertible recompute); `gbar` holds ybar on entry and xbar on exit.
 static int realnvp_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta, float *state, float *gbar,
                        const float *lbar, float lbar_const, long N, float *slab, int grid, float *g_out) {
-  const long stride = nf_affine_slab_floats(desc);
+  const long stride = coupling_slab_floats(desc);
   const int nc = 2 * desc->nlayers;
-  for (int k = 0; k < nc; ++k)  // flat order = reverse of execution order
-    NF_TRY(nf_affine_bwd(ctx, desc, k, theta, state, gbar, lbar, lbar_const, N, slab, stride, grid));
+  for (int k = 0; k < nc; ++k) {  // flat order = reverse of execution order
+    if (is_nsf(desc))
+      NF_TRY(nf_rqs_bwd(ctx, desc, k, state, gbar, lbar, lbar_const, N, slab, stride, grid));
+    else
+      NF_TRY(nf_affine_bwd(ctx, desc, k, theta, state, gbar, lbar, lbar_const, N, slab, stride, grid));
+  }
+  if (is_nsf(desc)) return nf_rqs_reduce_slabs(ctx, desc, slab, grid, g_out);
   return nf_affine_reduce_slabs(ctx, desc, slab, grid, g_out);
 }
 
@@ -292,15 +322,15 @@ extern "C" int nf_flow_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const void *th
   const long P = nf_param_count(desc);
   if (N == 0) return nf_launch_fill(ctx, desc->dtype, gtheta_out, P, 0.0);
   if (is_coupling(desc)) {
-    const int grid = nf_affine_bwd_grid(ctx, N);
+    const int grid = coupling_bwd_grid(ctx, desc, N);
     const size_t te = tiled_elems(desc, N);
-    const size_t slabf = (size_t)grid * nf_affine_slab_floats(desc);
+    const size_t slabf = (size_t)grid * coupling_slab_floats(desc);
     NF_TRY(nf_ws_reserve(ctx, 2 * carve_bytes(te * 4) + carve_bytes(slabf * 4)));
     Carver cv(ctx->ws);
     float *state = cv.take<float>(te);
     float *gt = cv.take<float>(te);
     float *slab = cv.take<float>(slabf);
-    NF_TRY(nf_affine_pack(ctx, desc, (const float *)theta));
+    NF_TRY(coupling_pack(ctx, desc, (const float *)theta));
     NF_TRY(nf_launch_layout_convert(ctx, desc->d, N, (const float *)y, state, 1));
     NF_TRY(nf_launch_layout_convert(ctx, desc->d, N, (const float *)ybar, gt, 1));
     NF_TRY(realnvp_bwd(ctx, desc, (const float *)theta, state, gt, (const float *)lbar, 0.f, N, slab, grid,
@@ -425,9 +455,9 @@ extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, con
   const double inv = 1.0 / (double)N_global;
   const bool cp = is_coupling(desc);
   const long nb = cp ? nf_target_tiled_nblocks(N) : nf_target_nblocks(N);
-  const int grid = cp ? nf_affine_bwd_grid(ctx, N) : 0;
+  const int grid = cp ? coupling_bwd_grid(ctx, desc, N) : 0;
   const size_t simple_ws = cp ? 0 : nf_simple_bwd_ws_bytes(ctx, desc, N);
-  const size_t slabf = cp ? (size_t)grid * nf_affine_slab_floats(desc) : 0;
+  const size_t slabf = cp ? (size_t)grid * coupling_slab_floats(desc) : 0;
   const size_t xe = cp ? tiled_elems(desc, N) : (size_t)N * desc->d;
   const size_t need = 3 * carve_bytes(xe * es) + 2 * carve_bytes((size_t)N * es) + carve_bytes((size_t)nb * 8) +
                       carve_bytes(64) + carve_bytes(slabf * es) + carve_bytes(simple_ws);

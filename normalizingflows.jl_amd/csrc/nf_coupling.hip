@@ -12,34 +12,6 @@
 #include "nf_common.h"
 #include "nf_mfma.h"
 
-// ---- tile I/O through buffer descriptors ---------------------------------------------------
-// One descriptor per (array, tile): base = array + tile * d * 32 floats (wave-uniform), extent =
-// d * 32 floats.  Element (feature f, lane's sample) is at byte f * 128 + (lane & 31) * 4, and in
-// the MFMA register layout f = const(block, reg) + 8 * (lane >> 5) + parity, so ONE per-lane
-// voffset serves every access and the rest is a scalar offset: no 64-bit per-lane addresses.
-// Features >= d fall outside the descriptor: the hardware returns 0 for such loads and drops such
-// stores, which is exactly the PartitionMask edge handling (odd d, c != m) -- no branches.
-struct TileIO {
-  __amdgpu_buffer_rsrc_t rs;
-  int voff;
-};
-__device__ __forceinline__ TileIO make_tile_io(float *array, long tile, int d, int l31, int hi) {
-  TileIO t;
-  t.rs = __builtin_amdgcn_make_buffer_rsrc(array + tile * d * NF_TILE, 0, d * NF_TILE * 4, 0x00020000);
-  t.voff = l31 * 4 + hi * (8 * NF_TILE * 4);
-  return t;
-}
-// feature index without the lane-dependent 8*hi term: f0 = 2 * (b*32 + (r&3) + 8*(r>>2)) + parity
-__device__ __forceinline__ int tile_soff(int b, int r, int parity) {
-  return (2 * (b * 32 + (r & 3) + 8 * (r >> 2)) + parity) * (NF_TILE * 4);
-}
-__device__ __forceinline__ float tile_load(const TileIO &t, int soff) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(t.rs, t.voff, soff, 0));
-}
-__device__ __forceinline__ void tile_store(const TileIO &t, int soff, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), t.rs, t.voff, soff, 0);
-}
-
 struct CouplingArgs {
   const float *theta;
   const float *img_s, *img_t;  // pre-packed LDS images of the s / t nets (k_pack_net_images)

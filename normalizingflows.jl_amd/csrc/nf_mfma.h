@@ -55,10 +55,9 @@ struct DenseLds {
 // ds_read of a layer (hundreds) above the first MFMA and spills.
 
 // out[ob] = W * in + b   (no activation).  IB input blocks, OB output blocks.
-template <int IB, int OB>
+template <int IB, int OB, int S = 32 * OB + 1>
 __device__ __forceinline__ void dense_fwd(const float *__restrict__ w, const float *__restrict__ b,
                                           const f32x16 (&in)[IB], f32x16 (&out)[OB], int l31, int hi) {
-  constexpr int S = 32 * OB + 1;
   constexpr int NG = IB * 4;  // groups of 4 k-steps
 #pragma unroll
   for (int ob = 0; ob < OB; ++ob)
@@ -93,15 +92,16 @@ __device__ __forceinline__ void dense_fwd(const float *__restrict__ w, const flo
 }
 
 // din[ib] = W^T * delta : the dX GEMM of the reverse pass, same register chaining.
-template <int IB, int OB>
+template <int IB, int OB, int S = 32 * OB + 1, bool ACCUM = false>
 __device__ __forceinline__ void dense_bwd_x(const float *__restrict__ w, const f32x16 (&delta)[OB],
                                             f32x16 (&din)[IB], int l31, int hi) {
-  constexpr int S = 32 * OB + 1;
   constexpr int NG = OB * 4;
+  if (!ACCUM) {
 #pragma unroll
-  for (int ib = 0; ib < IB; ++ib)
+    for (int ib = 0; ib < IB; ++ib)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) din[ib][r] = 0.f;
+      for (int r = 0; r < 16; ++r) din[ib][r] = 0.f;
+  }
   const float *wl = w + l31 * S + 4 * hi;
   float an[IB][4], ac[IB][4];
 #pragma unroll
@@ -189,6 +189,55 @@ __device__ __forceinline__ void dw_accumulate(const float *__restrict__ sa, cons
 #pragma unroll
         for (int ob = 0; ob < OB; ++ob)
           acc[ib][ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u][ib], dc[u][ob], acc[ib][ob], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// same, accumulating into columns [o0, o0 + OB) of a wider accumulator array (o0 is a constant
+// after unrolling at every call site)
+template <int IB, int OB, int OBTOT>
+__device__ __forceinline__ void dw_accumulate_at(const float *__restrict__ sa, const float *__restrict__ sd,
+                                                 f32x16 (&acc)[IB][OBTOT], float (&bsum)[OBTOT], int o0, int l31,
+                                                 int hi) {
+  const float *pa = sa + l31 * NF_TS + hi;
+  const float *pd = sd + l31 * NF_TS + hi;
+  float an[2][IB], dn[2][OB], ac[2][IB], dc[2][OB];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib) an[u][ib] = pa[ib * 32 * NF_TS + 2 * u];
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob) dn[u][ob] = pd[ob * 32 * NF_TS + 2 * u];
+  }
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib) ac[u][ib] = an[u][ib];
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob) dc[u][ob] = dn[u][ob];
+    }
+    if (g + 1 < 8) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int ib = 0; ib < IB; ++ib) an[u][ib] = pa[ib * 32 * NF_TS + 2 * ((g + 1) * 2 + u)];
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob) dn[u][ob] = pd[ob * 32 * NF_TS + 2 * ((g + 1) * 2 + u)];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob) bsum[o0 + ob] += dc[u][ob];
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob)
+          acc[ib][o0 + ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u][ib], dc[u][ob], acc[ib][o0 + ob], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -318,3 +367,32 @@ __device__ __forceinline__ void net_forward(const float *__restrict__ img, const
     for (int r = 0; r < 16; ++r) a2[b][r] = nf_lrelu(a2[b][r]);
   dense_fwd<G::H2B, G::CB>(img + G::W3, img + G::B3, a2, out, l31, hi);
 }
+
+// ---- tile I/O through buffer descriptors ---------------------------------------------------
+// One descriptor per (array, tile): base = array + tile * d * 32 floats (wave-uniform), extent =
+// d * 32 floats.  Element (feature f, lane's sample) is at byte f * 128 + (lane & 31) * 4, and in
+// the MFMA register layout f = const(block, reg) + 8 * (lane >> 5) + parity, so ONE per-lane
+// voffset serves every access and the rest is a scalar offset: no 64-bit per-lane addresses.
+// Features >= d fall outside the descriptor: the hardware returns 0 for such loads and drops such
+// stores, which is exactly the PartitionMask edge handling (odd d, c != m) -- no branches.
+struct TileIO {
+  __amdgpu_buffer_rsrc_t rs;
+  int voff;
+};
+__device__ __forceinline__ TileIO make_tile_io(float *array, long tile, int d, int l31, int hi) {
+  TileIO t;
+  t.rs = __builtin_amdgcn_make_buffer_rsrc(array + tile * d * NF_TILE, 0, d * NF_TILE * 4, 0x00020000);
+  t.voff = l31 * 4 + hi * (8 * NF_TILE * 4);
+  return t;
+}
+// feature index without the lane-dependent 8*hi term: f0 = 2 * (b*32 + (r&3) + 8*(r>>2)) + parity
+__device__ __forceinline__ int tile_soff(int b, int r, int parity) {
+  return (2 * (b * 32 + (r & 3) + 8 * (r >> 2)) + parity) * (NF_TILE * 4);
+}
+__device__ __forceinline__ float tile_load(const TileIO &t, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(t.rs, t.voff, soff, 0));
+}
+__device__ __forceinline__ void tile_store(const TileIO &t, int soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), t.rs, t.voff, soff, 0);
+}
+

@@ -1,0 +1,879 @@
+// nf_rqs.hip -- NeuralSplineCoupling (rational-quadratic spline coupling) kernels for gfx950.
+//
+// Reference: src/flows/neuralspline.jl:65-140 (get_nsc_params + rqs_forward / rqs_inverse call
+// sites); spline arithmetic from MonotonicSplines.jl 0.3.3 (rqs_params_from_nn, rqs_forward,
+// rqs_inverse) restated in oracle/nf_oracle.py and SURVEY.md App. A.4:
+//   raw = nn(x2), (3K-1)*c x N; per transformed dim: K widths, K heights, K-1 derivatives;
+//   knots = -B + 2B * cumsum(softmax(.)), boundary derivatives 1, interior softplus;
+//   identity (zero log-derivative) outside [-B, B].
+//
+// Design.  The conditioner MLP uses the register-chained fp32 MFMA primitives of nf_mfma.h.
+// The raw parameter tensor ((3K-1)*c x N, 193 MB at the cfg-3 size in the reference) never
+// exists: the output layer is evaluated in CHUNKS of 2*QCH transformed dims, and the rows of W3
+// are PERMUTED when the weights are packed so that, in the MFMA accumulator layout, the
+// 3K-1 parameters of a dim land in consecutive registers of the one lane that also holds
+// that dim's x1 value:
+//   transformed dim p  <->  lane half hi = (p >> 2) & 1,  local index q = (p & 3) + 4 * (p >> 3)
+//   (exactly the register index of x1 in the C layout), chunk = q / QCH,
+//   parameter prm of local dim ql = q % QCH  ->  slot = ql * P + prm  ->  accumulator block
+//   slot / 16, register slot % 16.
+// The spline (softmax / cumsum / bin search / rational quadratic, and its hand-derived
+// reverse pass) then runs entirely in registers, one (dim, sample) per lane at a time.
+#include "nf_common.h"
+#include "nf_mfma.h"
+
+template <int MB_, int H1B_, int H2B_, int K_, int NCH_, int QCH_ = 2>
+struct RqsGeo {
+  static constexpr int MB = MB_, H1B = H1B_, H2B = H2B_, CB = MB_, K = K_, NCH = NCH_;
+  static constexpr int P = 3 * K - 1;            // raw parameters per transformed dim
+  static constexpr int QCH = QCH_;               // local dims per lane half per chunk
+  static constexpr int OBC = (QCH * P + 15) / 16;  // accumulator blocks per chunk
+  static constexpr int OB3 = OBC * NCH;          // output blocks of the last layer
+  static constexpr int NCOLS = OB3 * 32;
+  static constexpr int CMAX = 2 * QCH * NCH;     // transformed dims covered
+  static constexpr int S1 = 32 * H1B + 1, S2 = 32 * H2B + 1, S3 = NCOLS + 1;
+  static constexpr int W1 = 0;
+  static constexpr int B1 = W1 + 32 * MB * S1;
+  static constexpr int W2 = B1 + 32 * H1B;
+  static constexpr int B2 = W2 + 32 * H1B * S2;
+  static constexpr int W3 = B2 + 32 * H2B;
+  static constexpr int B3 = W3 + 32 * H2B * S3;
+  static constexpr int END = B3 + NCOLS;
+  static constexpr int SIZE = ((END + 3) / 4) * 4;
+};
+
+struct RqsDims {
+  int m, h1, h2, c;              // conditioner fan-in, hidden sizes, transformed dims
+  long w1, b1, w2, b2, w3, b3;   // theta offsets (Optimisers.destructure order)
+};
+__host__ __device__ inline long rqs_param_count(int m, int h1, int h2, int c, int P) {
+  return (long)m * h1 + h1 + (long)h1 * h2 + h2 + (long)h2 * c * P + (long)c * P;
+}
+__host__ __device__ inline RqsDims make_rqs_dims(long off, int m, int h1, int h2, int c, int P) {
+  RqsDims n;
+  n.m = m; n.h1 = h1; n.h2 = h2; n.c = c;
+  n.w1 = off; n.b1 = n.w1 + (long)m * h1;
+  n.w2 = n.b1 + h1; n.b2 = n.w2 + (long)h1 * h2;
+  n.w3 = n.b2 + h2; n.b3 = n.w3 + (long)h2 * c * P;
+  return n;
+}
+
+// theta index of element e of the padded / permuted image, or -1 for padding
+template <class G>
+__device__ __forceinline__ long rqs_image_theta_index(const RqsDims &nd, int e) {
+  if (e < G::W2) {
+    const int r = e - G::W1;
+    if (r < 32 * G::MB * G::S1) {
+      const int i = r / G::S1, o = r - i * G::S1;
+      return (i < nd.m && o < nd.h1) ? nd.w1 + (long)i * nd.h1 + o : -1;
+    }
+    const int o = r - 32 * G::MB * G::S1;
+    return o < nd.h1 ? nd.b1 + o : -1;
+  }
+  if (e < G::W3) {
+    const int r = e - G::W2;
+    if (r < 32 * G::H1B * G::S2) {
+      const int i = r / G::S2, o = r - i * G::S2;
+      return (i < nd.h1 && o < nd.h2) ? nd.w2 + (long)i * nd.h2 + o : -1;
+    }
+    const int o = r - 32 * G::H1B * G::S2;
+    return o < nd.h2 ? nd.b2 + o : -1;
+  }
+  if (e >= G::END) return -1;
+  int i = -1, col;
+  if (e < G::B3) {
+    const int r = e - G::W3;
+    i = r / G::S3;
+    col = r - i * G::S3;
+    if (col >= G::NCOLS || i >= nd.h2) return -1;
+  } else {
+    col = e - G::B3;
+  }
+  // column -> (chunk, block, row-in-block) -> (lane half, register) -> slot -> (local dim, param)
+  const int ch = col / (G::OBC * 32), cc = col - ch * (G::OBC * 32);
+  const int b = cc >> 5, rr = cc & 31;
+  const int hi = (rr >> 2) & 1, reg = (rr & 3) + 4 * (rr >> 3);
+  const int slot = b * 16 + reg;
+  if (slot >= G::QCH * G::P) return -1;
+  const int ql = slot / G::P, prm = slot - ql * G::P;
+  const int q = ch * G::QCH + ql;
+  const int p = (q & 3) + 8 * (q >> 2) + 4 * hi;
+  if (p >= nd.c) return -1;
+  const int orig = p * G::P + prm;  // row of the reference's output layer
+  const int nout = nd.c * G::P;
+  return i >= 0 ? nd.w3 + (long)i * nout + orig : nd.b3 + orig;
+}
+
+struct RqsPackArgs {
+  int d, h1, h2, ncoup;
+  long pair_params, odd_params;
+};
+
+template <class G>
+__device__ __forceinline__ RqsDims rqs_dims_of(const RqsPackArgs &p, int k) {
+  const int c = (k & 1) ? p.d / 2 : (p.d + 1) / 2, m = p.d - c;
+  const long off = (long)(k >> 1) * p.pair_params + ((k & 1) ? p.odd_params : 0);
+  return make_rqs_dims(off, m, p.h1, p.h2, c, G::P);
+}
+
+template <class G>
+__global__ __launch_bounds__(256) void k_rqs_pack(RqsPackArgs p, const float *__restrict__ theta,
+                                                  float *__restrict__ out) {
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long)p.ncoup * G::SIZE) return;
+  const int k = (int)(gid / G::SIZE), e = (int)(gid - (long)k * G::SIZE);
+  const long ti = rqs_image_theta_index<G>(rqs_dims_of<G>(p, k), e);
+  out[gid] = ti >= 0 ? theta[ti] : 0.f;
+}
+
+template <class G>
+__global__ __launch_bounds__(256) void k_rqs_reduce_slabs(RqsPackArgs p, const float *__restrict__ slab, int nslab,
+                                                          long slab_stride, float *__restrict__ g) {
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long)p.ncoup * G::SIZE) return;
+  const int k = (int)(gid / G::SIZE), e = (int)(gid - (long)k * G::SIZE);
+  const long ti = rqs_image_theta_index<G>(rqs_dims_of<G>(p, k), e);
+  if (ti < 0) return;
+  float a0 = 0.f, a1 = 0.f;
+  int s = 0;
+  for (; s + 1 < nslab; s += 2) {
+    a0 += slab[(long)s * slab_stride + gid];
+    a1 += slab[(long)(s + 1) * slab_stride + gid];
+  }
+  if (s < nslab) a0 += slab[(long)s * slab_stride + gid];
+  g[ti] = a0 + a1;
+}
+
+// ---------------------------------------------------------------------------------------
+// the spline, one (dim, sample) per lane, everything in registers
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float softplus_f(float x) { return log1pf(__expf(-fabsf(x))) + fmaxf(x, 0.f); }
+__device__ __forceinline__ float sigmoid_f(float x) {
+  const float e = __expf(-fabsf(x));
+  return x >= 0.f ? __fdividef(1.f, 1.f + e) : __fdividef(e, 1.f + e);
+}
+
+template <int K>
+struct Knots {
+  float pX[K + 1], pY[K + 1], dd[K + 1], smw[K], smh[K];
+};
+
+template <int K>
+__device__ __forceinline__ void softmax_knots(const float *v, float B, float *sm, float *p) {
+  float mx = v[0];
+#pragma unroll
+  for (int k = 1; k < K; ++k) mx = fmaxf(mx, v[k]);
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    sm[k] = __expf(v[k] - mx);
+    sum += sm[k];
+  }
+  const float inv = __fdividef(1.f, sum);
+  float cs = 0.f;
+  p[0] = -B;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    sm[k] *= inv;
+    cs += sm[k];
+    p[k + 1] = -B + 2.f * B * cs;
+  }
+}
+
+// raw[0:K] widths, raw[K:2K] heights, raw[2K:3K-1] interior derivatives
+template <int K>
+__device__ __forceinline__ void build_knots(const float *raw, float B, Knots<K> &kn) {
+  softmax_knots<K>(raw, B, kn.smw, kn.pX);
+  softmax_knots<K>(raw + K, B, kn.smh, kn.pY);
+  kn.dd[0] = 1.f;
+  kn.dd[K] = 1.f;
+#pragma unroll
+  for (int k = 1; k < K; ++k) kn.dd[k] = softplus_f(raw[2 * K + k - 1]);
+}
+
+struct Bin {
+  float xk, xk1, yk, yk1, d0, d1;
+  int k;
+  bool inside;
+};
+
+// bin with p[k] <= v < p[k+1] on the knot vector `p` (pX forward, pY inverse)
+template <int K>
+__device__ __forceinline__ Bin find_bin(const Knots<K> &kn, const float *p, float v) {
+  Bin b;
+  b.inside = (v >= p[0]) && (v < p[K]);
+  int k = 0;
+#pragma unroll
+  for (int j = 1; j < K; ++j) k += (v >= p[j]) ? 1 : 0;
+  b.k = k;
+  b.xk = kn.pX[0]; b.xk1 = kn.pX[1]; b.yk = kn.pY[0]; b.yk1 = kn.pY[1]; b.d0 = kn.dd[0]; b.d1 = kn.dd[1];
+#pragma unroll
+  for (int j = 1; j < K; ++j) {
+    const bool is = (k == j);
+    b.xk = is ? kn.pX[j] : b.xk;
+    b.xk1 = is ? kn.pX[j + 1] : b.xk1;
+    b.yk = is ? kn.pY[j] : b.yk;
+    b.yk1 = is ? kn.pY[j + 1] : b.yk1;
+    b.d0 = is ? kn.dd[j] : b.d0;
+    b.d1 = is ? kn.dd[j + 1] : b.d1;
+  }
+  return b;
+}
+
+__device__ __forceinline__ float rq_logderiv(float s, float d0, float d1, float xi) {
+  const float om = 1.f - xi;
+  const float den = s + (d1 + d0 - 2.f * s) * xi * om;
+  return 2.f * __logf(s) + __logf(d1 * xi * xi + 2.f * s * xi * om + d0 * om * om) - 2.f * __logf(den);
+}
+
+// rqs_forward for one element: returns y, adds log dy/dx to logd
+template <int K>
+__device__ __forceinline__ float rqs_fwd_elem(const Knots<K> &kn, float x, float &logd) {
+  const Bin b = find_bin<K>(kn, kn.pX, x);
+  const float dx = b.xk1 - b.xk, dy = b.yk1 - b.yk;
+  const float s = __fdividef(dy, dx);
+  const float xi = __fdividef(x - b.xk, dx), om = 1.f - xi;
+  const float den = s + (b.d1 + b.d0 - 2.f * s) * xi * om;
+  const float y = b.yk + __fdividef(dy * (s * xi * xi + b.d0 * xi * om), den);
+  logd += b.inside ? rq_logderiv(s, b.d0, b.d1, xi) : 0.f;
+  return b.inside ? y : x;
+}
+
+// rqs_inverse for one element: returns x and the bin / xi it lies in; adds -log dy/dx to logd
+template <int K>
+__device__ __forceinline__ float rqs_inv_elem(const Knots<K> &kn, float y, float &logd, Bin &b, float &xi_out) {
+  b = find_bin<K>(kn, kn.pY, y);
+  const float dx = b.xk1 - b.xk, dy = b.yk1 - b.yk;
+  const float s = __fdividef(dy, dx);
+  const float yy = y - b.yk;
+  const float q = b.d1 + b.d0 - 2.f * s;
+  const float a = dy * (s - b.d0) + yy * q;
+  const float bb = dy * b.d0 - yy * q;
+  const float c = -s * yy;
+  const float disc = fmaxf(bb * bb - 4.f * a * c, 0.f);
+  const float xi = __fdividef(2.f * c, -bb - sqrtf(disc));
+  xi_out = xi;
+  logd -= b.inside ? rq_logderiv(s, b.d0, b.d1, xi) : 0.f;
+  return b.inside ? xi * dx + b.xk : y;
+}
+
+// reverse pass of rqs_forward at (x in bin b, xi): ybar, lbar -> xbar and raw-parameter gradients
+template <int K>
+__device__ __forceinline__ float rqs_bwd_elem(const Knots<K> &kn, const float *raw, const Bin &b, float xi, float B,
+                                              float ybar, float lbar, float *thbar) {
+  const float dx = b.xk1 - b.xk, dy = b.yk1 - b.yk;
+  const float s = __fdividef(dy, dx), om = 1.f - xi;
+  const float d0 = b.d0, d1 = b.d1;
+  const float q = d1 + d0 - 2.f * s;
+  const float den = s + q * xi * om;
+  const float num = s * xi * xi + d0 * xi * om;
+  const float nd = d1 * xi * xi + 2.f * s * xi * om + d0 * om * om;
+  const float iden = __fdividef(1.f, den), ind = __fdividef(1.f, nd), idx = __fdividef(1.f, dx);
+  const float iden2 = iden * iden;
+  const float dnum_dxi = 2.f * s * xi + d0 * (1.f - 2.f * xi);
+  const float dden_dxi = q * (1.f - 2.f * xi);
+  const float dnd_dxi = 2.f * d1 * xi + 2.f * s * (1.f - 2.f * xi) - 2.f * d0 * om;
+  const float dy_dxi = dy * (dnum_dxi * den - num * dden_dxi) * iden2;
+  const float dL_dxi = dnd_dxi * ind - 2.f * dden_dxi * iden;
+  const float dden_ds = 1.f - 2.f * xi * om;
+  const float dy_ds = dy * (xi * xi * den - num * dden_ds) * iden2;
+  const float dL_ds = __fdividef(2.f, s) + 2.f * xi * om * ind - 2.f * dden_ds * iden;
+  const float dy_dd0 = dy * (xi * om * den - num * xi * om) * iden2;
+  const float dL_dd0 = om * om * ind - 2.f * xi * om * iden;
+  const float dy_dd1 = dy * (-num * xi * om) * iden2;
+  const float dL_dd1 = xi * xi * ind - 2.f * xi * om * iden;
+  const float xibar = ybar * dy_dxi + lbar * dL_dxi;
+  const float sbar = ybar * dy_ds + lbar * dL_ds;
+  const float d0bar = ybar * dy_dd0 + lbar * dL_dd0;
+  const float d1bar = ybar * dy_dd1 + lbar * dL_dd1;
+  const float dybar = ybar * num * iden + sbar * idx;
+  const float dxbar = -sbar * s * idx - xibar * xi * idx;
+  const float xkbar = -xibar * idx - dxbar, xk1bar = dxbar;
+  const float ykbar = ybar - dybar, yk1bar = dybar;
+  // knots: p[j] = -B + 2B sum_{i<j} sm_i  =>  dL/dsm_i = 2B * sum_{j>i} pbar[j]; only pbar[k], pbar[k+1] != 0
+  float dotw = 0.f, doth = 0.f;
+  float sbw[K], sbh[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    sbw[i] = 2.f * B * ((i < b.k) ? (xkbar + xk1bar) : ((i == b.k) ? xk1bar : 0.f));
+    sbh[i] = 2.f * B * ((i < b.k) ? (ykbar + yk1bar) : ((i == b.k) ? yk1bar : 0.f));
+    dotw += sbw[i] * kn.smw[i];
+    doth += sbh[i] * kn.smh[i];
+  }
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    thbar[i] = b.inside ? kn.smw[i] * (sbw[i] - dotw) : 0.f;
+    thbar[K + i] = b.inside ? kn.smh[i] * (sbh[i] - doth) : 0.f;
+  }
+#pragma unroll
+  for (int j = 1; j < K; ++j) {
+    const float ddb = ((j == b.k) ? d0bar : 0.f) + ((j == b.k + 1) ? d1bar : 0.f);
+    thbar[2 * K + j - 1] = b.inside ? ddb * sigmoid_f(raw[2 * K + j - 1]) : 0.f;
+  }
+  return b.inside ? xibar * idx : ybar;
+}
+
+// pull the P raw parameters of local dim `ql` of a chunk out of its accumulator blocks
+template <class G>
+__device__ __forceinline__ void chunk_get(const f32x16 (&out)[G::OBC], int ql, float *raw) {
+#pragma unroll
+  for (int prm = 0; prm < G::P; ++prm) {
+    const int slot = ql * G::P + prm;
+    raw[prm] = out[slot / 16][slot % 16];
+  }
+}
+template <class G>
+__device__ __forceinline__ void chunk_put(f32x16 (&out)[G::OBC], int ql, const float *v) {
+#pragma unroll
+  for (int prm = 0; prm < G::P; ++prm) {
+    const int slot = ql * G::P + prm;
+    out[slot / 16][slot % 16] = v[prm];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// whole-flow forward / inverse in one launch (same structure as k_affine_chain)
+// ---------------------------------------------------------------------------------------
+struct RqsChainArgs {
+  const float *wimg;  // [coupling][G::SIZE]
+  int d, ncoup;
+  int k_only;  // -1: every coupling; otherwise only the coupling with this flat index
+  float B;
+  long N;
+};
+
+template <class G, bool INVERSE>
+__device__ __forceinline__ float rqs_coupling_step(const float *__restrict__ img, f32x16 (&x1)[G::CB],
+                                                   const f32x16 (&xb)[G::MB], int c, float B, int l31, int hi) {
+  f32x16 a2[G::H2B];
+  {
+    f32x16 a1[G::H1B];
+    dense_fwd<G::MB, G::H1B>(img + G::W1, img + G::B1, xb, a1, l31, hi);
+#pragma unroll
+    for (int b = 0; b < G::H1B; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a1[b][r] = nf_lrelu(a1[b][r]);
+    dense_fwd<G::H1B, G::H2B>(img + G::W2, img + G::B2, a1, a2, l31, hi);
+#pragma unroll
+    for (int b = 0; b < G::H2B; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a2[b][r] = nf_lrelu(a2[b][r]);
+  }
+  float lsum = 0.f;
+#pragma unroll
+  for (int ch = 0; ch < G::NCH; ++ch) {
+    f32x16 out[G::OBC];
+    dense_fwd<G::H2B, G::OBC, G::S3>(img + G::W3 + ch * G::OBC * 32, img + G::B3 + ch * G::OBC * 32, a2, out, l31, hi);
+#pragma unroll
+    for (int ql = 0; ql < G::QCH; ++ql) {
+      const int q = ch * G::QCH + ql;            // register index of x1 (block q / 16)
+      const int p = (q & 3) + 8 * (q >> 2) + 4 * hi;
+      float raw[G::P];
+      chunk_get<G>(out, ql, raw);
+      Knots<G::K> kn;
+      build_knots<G::K>(raw, B, kn);
+      const float v = x1[q / 16][q % 16];
+      float logd = 0.f, res;
+      if (INVERSE) {
+        Bin bn;
+        float xi;
+        res = rqs_inv_elem<G::K>(kn, v, logd, bn, xi);
+      } else {
+        res = rqs_fwd_elem<G::K>(kn, v, logd);
+      }
+      const bool ok = p < c;  // padded dims: keep the zero, contribute nothing
+      x1[q / 16][q % 16] = ok ? res : v;
+      lsum += ok ? logd : 0.f;
+    }
+  }
+  return lsum;
+}
+
+template <class G, bool INVERSE>
+__global__ __launch_bounds__(512) void k_rqs_chain(RqsChainArgs a, float *xt, float *__restrict__ ladj) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NV4 = G::SIZE / 4;
+  constexpr int PER = (NV4 + 511) / 512;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const long ntiles = (a.N + NF_TILE - 1) / NF_TILE;
+  const long ngroups = (ntiles + 7) / 8;
+  auto coupling_at = [&](int s) { return INVERSE ? s : a.ncoup - 1 - s; };
+  {
+    const float4 *src = reinterpret_cast<const float4 *>(a.wimg + (long)coupling_at(0) * G::SIZE);
+    float4 *dst = reinterpret_cast<float4 *>(lds);
+    for (int i = tid; i < NV4; i += 512) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int c_odd = (a.d + 1) / 2, c_even = a.d / 2;  // mask 1:2:d / 2:2:d
+  int buf = 0;
+  for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const long tile = grp * 8 + wave;
+    const bool live = tile < ntiles;
+    const long tl = live ? tile : 0;
+    const long j = tl * NF_TILE + l31;
+    const bool valid = live && j < a.N;
+    const TileIO io = make_tile_io(xt, tl, a.d, l31, hi);
+    f32x16 E[G::CB], O[G::MB];
+#pragma unroll
+    for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = tile_load(io, tile_soff(b, r, 0));
+        const float o = tile_load(io, tile_soff(b, r, 1));
+        E[b][r] = valid ? e : 0.f;
+        O[b][r] = valid ? o : 0.f;
+      }
+    float lsum = 0.f;
+    const bool more_groups = grp + gridDim.x < ngroups;
+#pragma unroll 1
+    for (int s = 0; s < a.ncoup; s += 2) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int pos = s + half;
+        const bool have_next = pos + 1 < a.ncoup || more_groups;
+        const int knext = coupling_at(pos + 1 < a.ncoup ? pos + 1 : 0);
+        float4 tmp[PER];
+        if (have_next) {
+          const float4 *src = reinterpret_cast<const float4 *>(a.wimg + (long)knext * G::SIZE);
+#pragma unroll
+          for (int q = 0; q < PER; ++q) {
+            const int idx = tid + q * 512;
+            tmp[q] = idx < NV4 ? src[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
+        const float *img = lds + buf * G::SIZE;
+        // forward: position 0 is the last flat coupling (odd index, mask 2:2:d): x1 = O
+        if (a.k_only < 0 || a.k_only == coupling_at(pos)) {
+          if (INVERSE ? (half == 1) : (half == 0))
+            lsum += rqs_coupling_step<G, INVERSE>(img, O, E, c_even, a.B, l31, hi);
+          else
+            lsum += rqs_coupling_step<G, INVERSE>(img, E, O, c_odd, a.B, l31, hi);
+        }
+        if (have_next) {
+          float4 *dst = reinterpret_cast<float4 *>(lds + (buf ^ 1) * G::SIZE);
+#pragma unroll
+          for (int q = 0; q < PER; ++q) {
+            const int idx = tid + q * 512;
+            if (idx < NV4) dst[idx] = tmp[q];
+          }
+        }
+        __syncthreads();
+        buf ^= 1;
+      }
+    }
+    if (live) {
+#pragma unroll
+      for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          tile_store(io, tile_soff(b, r, 0), E[b][r]);
+          tile_store(io, tile_soff(b, r, 1), O[b][r]);
+        }
+      lsum += __shfl_xor(lsum, 32);
+      if (hi == 0 && valid) ladj[j] = lsum;  // inverse: rqs_inv_elem already accumulates -log dy/dx
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// reverse pass of one coupling (invertible recompute), one net
+// ---------------------------------------------------------------------------------------
+struct RqsBwdArgs {
+  const float *img;  // packed image of this coupling
+  int d, c, m, par_t;
+  float B;
+  long N;
+  long long *trace;
+};
+
+template <class G>
+struct RqsAcc {
+  f32x16 w1[G::MB][G::H1B];
+  f32x16 w2[G::H1B][G::H2B];
+  f32x16 w3[G::H2B][G::OB3];
+  float b1[G::H1B], b2[G::H2B], b3[G::OB3];
+};
+
+template <class G>
+struct RqsLds {
+  static constexpr int DROWS = (G::H1B > G::H2B ? G::H1B : G::H2B) > 2 ? (G::H1B > G::H2B ? G::H1B : G::H2B) : 2;
+  static constexpr int OFF_X = 0;
+  static constexpr int OFF_A1 = OFF_X + G::MB * 32 * NF_TS;
+  static constexpr int OFF_A2 = OFF_A1 + G::H1B * 32 * NF_TS;
+  static constexpr int OFF_D = OFF_A2 + G::H2B * 32 * NF_TS;
+  static constexpr int SCRATCH = OFF_D + DROWS * 32 * NF_TS;
+  static constexpr int WAVES = 4;
+  static constexpr size_t BYTES = (size_t)(G::SIZE + WAVES * SCRATCH) * sizeof(float);
+};
+
+template <int IB, int OB>
+__device__ __forceinline__ void rqs_zero(f32x16 (&a)[IB][OB], float (&b)[OB]) {
+#pragma unroll
+  for (int i = 0; i < IB; ++i)
+#pragma unroll
+    for (int o = 0; o < OB; ++o)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a[i][o][r] = 0.f;
+#pragma unroll
+  for (int o = 0; o < OB; ++o) b[o] = 0.f;
+}
+
+template <int IB, int OB, int S>
+__device__ __forceinline__ void rqs_fold(float *__restrict__ w, float *__restrict__ b, const f32x16 (&a)[IB][OB],
+                                         const float (&bs)[OB], bool first, int l31, int hi) {
+#pragma unroll
+  for (int i = 0; i < IB; ++i)
+#pragma unroll
+    for (int o = 0; o < OB; ++o)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float *p = w + (i * 32 + nf_row(r, hi)) * S + o * 32 + l31;
+        *p = first ? a[i][o][r] : *p + a[i][o][r];
+      }
+#pragma unroll
+  for (int o = 0; o < OB; ++o) {
+    const float v = bs[o] + __shfl_xor(bs[o], 32);
+    if (hi == 0) {
+      float *p = b + o * 32 + l31;
+      *p = first ? v : *p + v;
+    }
+  }
+}
+
+template <class G>
+__device__ __forceinline__ void rqs_bwd_tile(const RqsBwdArgs &a, const float *__restrict__ img, float *__restrict__ sc,
+                                             RqsAcc<G> &acc, float *__restrict__ y, float *__restrict__ ybar,
+                                             const float *__restrict__ lbar, float lbar_const, long tile, int l31,
+                                             int hi) {
+  using L = RqsLds<G>;
+  const long j = tile * NF_TILE + l31;
+  const bool valid = j < a.N;
+  const int par_c = 1 - a.par_t;
+  const TileIO yio = make_tile_io(y, tile, a.d, l31, hi);
+  const TileIO gio = make_tile_io(ybar, tile, a.d, l31, hi);
+
+  unsigned m1[G::H1B], m2[G::H2B];
+  f32x16 a2[G::H2B], y1[G::CB], g1[G::CB];
+  {
+    f32x16 xb[G::MB];
+#pragma unroll
+    for (int b = 0; b < G::MB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = tile_load(yio, tile_soff(b, r, par_c));
+        xb[b][r] = valid ? v : 0.f;
+      }
+#pragma unroll
+    for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        y1[b][r] = tile_load(yio, tile_soff(b, r, a.par_t));
+        g1[b][r] = tile_load(gio, tile_soff(b, r, a.par_t));
+      }
+    tile_to_scratch<G::MB>(sc + L::OFF_X, xb, l31, hi);
+    f32x16 a1[G::H1B];
+    dense_fwd<G::MB, G::H1B>(img + G::W1, img + G::B1, xb, a1, l31, hi);
+#pragma unroll
+    for (int b = 0; b < G::H1B; ++b) {
+      unsigned bits = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        a1[b][r] = nf_lrelu(a1[b][r]);
+        bits |= (a1[b][r] > 0.f ? 1u : 0u) << r;
+      }
+      m1[b] = bits;
+    }
+    tile_to_scratch<G::H1B>(sc + L::OFF_A1, a1, l31, hi);
+    dense_fwd<G::H1B, G::H2B>(img + G::W2, img + G::B2, a1, a2, l31, hi);
+#pragma unroll
+    for (int b = 0; b < G::H2B; ++b) {
+      unsigned bits = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        a2[b][r] = nf_lrelu(a2[b][r]);
+        bits |= (a2[b][r] > 0.f ? 1u : 0u) << r;
+      }
+      m2[b] = bits;
+    }
+    tile_to_scratch<G::H2B>(sc + L::OFF_A2, a2, l31, hi);
+  }
+  const float lb = valid ? (lbar ? lbar[j] : lbar_const) : 0.f;
+
+  f32x16 d2[G::H2B];
+#pragma unroll
+  for (int b = 0; b < G::H2B; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d2[b][r] = 0.f;
+  float *sd = sc + L::OFF_D;
+
+#pragma unroll
+  for (int ch = 0; ch < G::NCH; ++ch) {
+    f32x16 out[G::OBC];
+    dense_fwd<G::H2B, G::OBC, G::S3>(img + G::W3 + ch * G::OBC * 32, img + G::B3 + ch * G::OBC * 32, a2, out, l31, hi);
+#pragma unroll
+    for (int ql = 0; ql < G::QCH; ++ql) {
+      const int q = ch * G::QCH + ql;
+      const int p = (q & 3) + 8 * (q >> 2) + 4 * hi;
+      const bool ok = valid && p < a.c;
+      float raw[G::P], thb[G::P];
+      chunk_get<G>(out, ql, raw);
+      Knots<G::K> kn;
+      build_knots<G::K>(raw, a.B, kn);
+      const float yv = y1[q / 16][q % 16];
+      const float gv = ok ? g1[q / 16][q % 16] : 0.f;
+      // invert to the coupling input (src/flows/neuralspline.jl:134-140), then differentiate the
+      // forward map at that point
+      float dummy = 0.f, xi;
+      Bin bn;
+      const float xv = rqs_inv_elem<G::K>(kn, yv, dummy, bn, xi);
+      const float xbar = rqs_bwd_elem<G::K>(kn, raw, bn, xi, a.B, gv, ok ? lb : 0.f, thb);
+#pragma unroll
+      for (int prm = 0; prm < G::P; ++prm) thb[prm] = ok ? thb[prm] : 0.f;
+      chunk_put<G>(out, ql, thb);
+      y1[q / 16][q % 16] = xv;
+      g1[q / 16][q % 16] = xbar;
+    }
+    // unused slots of the chunk (beyond QCH * P) carry raw outputs of zero-weight rows: clear them
+#pragma unroll
+    for (int slot = G::QCH * G::P; slot < G::OBC * 16; ++slot) out[slot / 16][slot % 16] = 0.f;
+    // dX through the last layer, accumulated over chunks
+    dense_bwd_x<G::H2B, G::OBC, G::S3, true>(img + G::W3 + ch * G::OBC * 32, out, d2, l31, hi);
+    // dW3^T: two accumulator blocks of delta at a time through the scratch transpose
+#pragma unroll
+    for (int pc = 0; pc < G::OBC; pc += 2) {
+      constexpr int dummy_unused = 0;
+      (void)dummy_unused;
+      if (pc + 1 < G::OBC) {
+        f32x16 two[2] = {out[pc], out[pc + 1]};
+        tile_to_scratch<2>(sd, two, l31, hi);
+        wave_lds_fence();
+        dw_accumulate_at<G::H2B, 2, G::OB3>(sc + L::OFF_A2, sd, acc.w3, acc.b3, ch * G::OBC + pc, l31, hi);
+      } else {
+        f32x16 one[1] = {out[pc]};
+        tile_to_scratch<1>(sd, one, l31, hi);
+        wave_lds_fence();
+        dw_accumulate_at<G::H2B, 1, G::OB3>(sc + L::OFF_A2, sd, acc.w3, acc.b3, ch * G::OBC + pc, l31, hi);
+      }
+      wave_lds_fence();
+    }
+  }
+  // element-wise results: coupling input x1 and its cotangent
+#pragma unroll
+  for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      tile_store(yio, tile_soff(b, r, a.par_t), y1[b][r]);
+      tile_store(gio, tile_soff(b, r, a.par_t), g1[b][r]);
+    }
+  // ---- layer 2
+#pragma unroll
+  for (int b = 0; b < G::H2B; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d2[b][r] *= ((m2[b] >> r) & 1u) ? 1.f : 0.01f;
+  tile_to_scratch<G::H2B>(sd, d2, l31, hi);
+  wave_lds_fence();
+  dw_accumulate<G::H1B, G::H2B>(sc + L::OFF_A1, sd, acc.w2, acc.b2, l31, hi);
+  f32x16 d1[G::H1B];
+  dense_bwd_x<G::H1B, G::H2B>(img + G::W2, d2, d1, l31, hi);
+#pragma unroll
+  for (int b = 0; b < G::H1B; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d1[b][r] *= ((m1[b] >> r) & 1u) ? 1.f : 0.01f;
+  wave_lds_fence();
+  // ---- layer 1
+  tile_to_scratch<G::H1B>(sd, d1, l31, hi);
+  wave_lds_fence();
+  dw_accumulate<G::MB, G::H1B>(sc + L::OFF_X, sd, acc.w1, acc.b1, l31, hi);
+  f32x16 g2[G::MB], gold[G::MB];
+#pragma unroll
+  for (int b = 0; b < G::MB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gold[b][r] = tile_load(gio, tile_soff(b, r, par_c));
+  dense_bwd_x<G::MB, G::H1B>(img + G::W1, d1, g2, l31, hi);
+  wave_lds_fence();
+#pragma unroll
+  for (int b = 0; b < G::MB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tile_store(gio, tile_soff(b, r, par_c), gold[b][r] + g2[b][r]);
+}
+
+template <class G>
+__global__ __launch_bounds__(256, 1) void k_rqs_bwd(RqsBwdArgs a, float *__restrict__ y, float *__restrict__ ybar,
+                                                    const float *__restrict__ lbar, float lbar_const,
+                                                    float *__restrict__ slab, long slab_stride) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *img = lds;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  float *sc = lds + G::SIZE + wave * RqsLds<G>::SCRATCH;
+  const long ntiles = (a.N + NF_TILE - 1) / NF_TILE;
+  stage_packed<G::SIZE, 256>(img, a.img, tid);
+  __syncthreads();
+  RqsAcc<G> acc;
+  rqs_zero(acc.w1, acc.b1);
+  rqs_zero(acc.w2, acc.b2);
+  rqs_zero(acc.w3, acc.b3);
+#pragma unroll 1
+  for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4)
+    rqs_bwd_tile<G>(a, img, sc, acc, y, ybar, lbar, lbar_const, tile, l31, hi);
+  __syncthreads();  // the weight image is dead: it becomes the (deterministic, wave-ordered) fold target
+#pragma unroll 1
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+      rqs_fold<G::MB, G::H1B, G::S1>(img + G::W1, img + G::B1, acc.w1, acc.b1, w == 0, l31, hi);
+      rqs_fold<G::H1B, G::H2B, G::S2>(img + G::W2, img + G::B2, acc.w2, acc.b2, w == 0, l31, hi);
+      rqs_fold<G::H2B, G::OB3, G::S3>(img + G::W3, img + G::B3, acc.w3, acc.b3, w == 0, l31, hi);
+    }
+    __syncthreads();
+  }
+  {
+    const float4 *c0 = reinterpret_cast<const float4 *>(img);
+    float4 *dst = reinterpret_cast<float4 *>(slab + (long)blockIdx.x * slab_stride);
+    for (int i = tid; i < G::SIZE / 4; i += 256) dst[i] = c0[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+using GeoK8 = RqsGeo<1, 1, 1, 8, 4>;    // d <= 32, hidden <= 32, K = 8   (cfg 3)
+using GeoK10 = RqsGeo<1, 1, 1, 10, 2>;  // d <= 16, hidden <= 32, K = 10  (test/flow.jl:65-78)
+
+static inline int b32(int n) { return (n + 31) / 32; }
+
+// 1 -> GeoK8, 2 -> GeoK10, 0 -> unsupported
+static int rqs_geo_id(const nf_flow_desc *desc) {
+  if (desc->n_hidden != 2) return 0;
+  const int cmax = (desc->d + 1) / 2;
+  if (b32(desc->hdims[0]) != 1 || b32(desc->hdims[1]) != 1 || b32(cmax) != 1) return 0;
+  if (desc->K == 8 && cmax <= GeoK8::CMAX) return 1;
+  if (desc->K == 10 && cmax <= GeoK10::CMAX) return 2;
+  return 0;
+}
+
+bool nf_rqs_supported(const nf_flow_desc *desc) { return desc->d >= 2 && desc->B > 0.f && rqs_geo_id(desc) != 0; }
+
+static int rqs_geo_size(const nf_flow_desc *desc) {
+  const int id = rqs_geo_id(desc);
+  return id == 1 ? GeoK8::SIZE : (id == 2 ? GeoK10::SIZE : 0);
+}
+
+static RqsPackArgs rqs_pack_args(const nf_flow_desc *desc) {
+  RqsPackArgs p;
+  p.d = desc->d; p.h1 = desc->hdims[0]; p.h2 = desc->hdims[1]; p.ncoup = 2 * desc->nlayers;
+  const CouplingInfo c0 = nf_coupling_info(desc, 0), c1 = nf_coupling_info(desc, 1);
+  p.odd_params = c0.nparams;
+  p.pair_params = c0.nparams + c1.nparams;
+  return p;
+}
+
+long nf_rqs_slab_floats(const nf_flow_desc *desc) { return (long)2 * desc->nlayers * rqs_geo_size(desc); }
+
+int nf_rqs_pack(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta) {
+  const int id = rqs_geo_id(desc);
+  if (!id) return NF_ERR_UNSUPPORTED;
+  const int size = rqs_geo_size(desc);
+  const int nc = 2 * desc->nlayers;
+  const size_t bytes = (size_t)nc * size * sizeof(float);
+  if (bytes > ctx->wimg_bytes) {
+    NF_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->wimg) NF_HIP(hipFree(ctx->wimg));
+    ctx->wimg = nullptr;
+    ctx->wimg_bytes = 0;
+    NF_HIP(hipMalloc(&ctx->wimg, bytes));
+    ctx->wimg_bytes = bytes;
+  }
+  const RqsPackArgs p = rqs_pack_args(desc);
+  const long total = (long)nc * size;
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  ProfScope ps(ctx, "pack_weights");
+  if (id == 1)
+    hipLaunchKernelGGL((k_rqs_pack<GeoK8>), dim3(grid), dim3(256), 0, ctx->stream, p, theta, (float *)ctx->wimg);
+  else
+    hipLaunchKernelGGL((k_rqs_pack<GeoK10>), dim3(grid), dim3(256), 0, ctx->stream, p, theta, (float *)ctx->wimg);
+  return (int)hipGetLastError();
+}
+
+int nf_rqs_reduce_slabs(nf_ctx *ctx, const nf_flow_desc *desc, const float *slab, int nslab, float *g) {
+  const int id = rqs_geo_id(desc);
+  if (!id) return NF_ERR_UNSUPPORTED;
+  const RqsPackArgs p = rqs_pack_args(desc);
+  const long total = (long)p.ncoup * rqs_geo_size(desc);
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  ProfScope ps(ctx, "reduce_slabs");
+  if (id == 1)
+    hipLaunchKernelGGL((k_rqs_reduce_slabs<GeoK8>), dim3(grid), dim3(256), 0, ctx->stream, p, slab, nslab, total, g);
+  else
+    hipLaunchKernelGGL((k_rqs_reduce_slabs<GeoK10>), dim3(grid), dim3(256), 0, ctx->stream, p, slab, nslab, total, g);
+  return (int)hipGetLastError();
+}
+
+template <class G>
+static int launch_rqs_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, float *xt, long N, float *ladj,
+                            int k_only) {
+  const size_t lds = 2 * (size_t)G::SIZE * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    NF_HIP(hipFuncSetAttribute((const void *)k_rqs_chain<G, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NF_HIP(hipFuncSetAttribute((const void *)k_rqs_chain<G, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  RqsChainArgs a;
+  a.wimg = (const float *)ctx->wimg;
+  a.d = desc->d; a.ncoup = 2 * desc->nlayers; a.B = desc->B; a.N = N; a.k_only = k_only;
+  const long ngroups = ((N + NF_TILE - 1) / NF_TILE + 7) / 8;
+  long grid = ngroups < ctx->num_cu ? ngroups : ctx->num_cu;
+  if (grid < 1) grid = 1;
+  ProfScope ps(ctx, "rqs_chain");
+  if (inverse)
+    hipLaunchKernelGGL((k_rqs_chain<G, true>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj);
+  else
+    hipLaunchKernelGGL((k_rqs_chain<G, false>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj);
+  return (int)hipGetLastError();
+}
+
+// whole chain (k_only < 0) or a single coupling (flat index k_only), in place on the tiled buffer
+int nf_rqs_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, float *xt, long N, float *ladj, int k_only) {
+  const int id = rqs_geo_id(desc);
+  if (!id || !ctx->wimg) return NF_ERR_UNSUPPORTED;
+  if (id == 1) return launch_rqs_chain<GeoK8>(ctx, desc, inverse, xt, N, ladj, k_only);
+  return launch_rqs_chain<GeoK10>(ctx, desc, inverse, xt, N, ladj, k_only);
+}
+
+int nf_rqs_bwd_grid(nf_ctx *ctx, long N) {
+  const long ntiles = (N + NF_TILE - 1) / NF_TILE;
+  long grid = (ntiles + 3) / 4;
+  if (grid > ctx->num_cu) grid = ctx->num_cu;
+  return (int)(grid < 1 ? 1 : grid);
+}
+
+template <class G>
+static int launch_rqs_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, float *y, float *ybar, const float *lbar,
+                          float lbar_const, long N, float *slab, long slab_stride, int grid) {
+  const size_t lds = RqsLds<G>::BYTES;
+  static bool attr_done = false;
+  if (!attr_done) {
+    NF_HIP(hipFuncSetAttribute((const void *)k_rqs_bwd<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  const CouplingInfo ci = nf_coupling_info(desc, k);
+  RqsBwdArgs a;
+  a.img = (const float *)ctx->wimg + (size_t)k * G::SIZE;
+  a.d = desc->d; a.c = ci.c; a.m = ci.m; a.par_t = ci.par_t; a.B = desc->B; a.N = N;
+  a.trace = nullptr;
+  ProfScope ps(ctx, "rqs_bwd");
+  hipLaunchKernelGGL((k_rqs_bwd<G>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, y, ybar, lbar, lbar_const,
+                     slab + (long)k * G::SIZE, slab_stride);
+  return (int)hipGetLastError();
+}
+
+int nf_rqs_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, float *y, float *ybar, const float *lbar, float lbar_const,
+               long N, float *slab, long slab_stride, int grid) {
+  const int id = rqs_geo_id(desc);
+  if (!id || !ctx->wimg) return NF_ERR_UNSUPPORTED;
+  if (id == 1) return launch_rqs_bwd<GeoK8>(ctx, desc, k, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid);
+  return launch_rqs_bwd<GeoK10>(ctx, desc, k, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid);
+}
