@@ -8,6 +8,7 @@ from ._lib import LIB_PATH, SYMBOLS, Context, NFHipError, context_for, load_libr
 from .flows import (BananaTarget, DiagGaussTarget, Flow, MvNormal, PhiloxRNG, Transform, as_batch, base_logpdf,
                     device_specific_rand, inverse, layer, logpdf, meanfield, new_batch, nsf, planarflow, radialflow,
                     rand, realnvp, target_logp, transform, with_logabsdet_jacobian)
+from .parallel import ShardedObjective, allreduce_grad_loss, make_gpu_local_step, shard_range
 from .objectives import (Adam, AdamState, adam_update, batched_elbos, elbo, elbo_batch, loglikelihood, optimize,
                          train_flow, value_and_gradient)
 

@@ -1,0 +1,87 @@
+"""Times the BASELINE.json configurations other than the headline one (they are parity-test cases,
+not bench.py lines) and prints a small table.  Usage: python tools/bench_configs.py [--steps K]
+
+cfg1  planar flow d=2, 10 layers, Banana target, batch 1024, Float64  (ELBO step)
+cfg2  RealNVP d=64, 8 couplings, h=64, batch 65536                     (ELBO step)   [headline]
+cfg2b RealNVP d=64, 8 couplings, h=32 (reference default widths)       (ELBO step)
+cfg3  NSF d=32, 8 RQ-spline couplings, K=8, B=5, h=32, batch 131072    (ELBO step)
+cfg5  RealNVP d=64 inverse + logdet + log q0 on 1 M samples           (loglikelihood)
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from __graft_entry__ import load_package
+
+nf = load_package()
+lib = nf.load_library()
+dev = torch.device("cuda", 0)
+vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+
+
+def time_step(flow, tgt, n, steps, warmup=5):
+    ctx = nf.context_for(dev)
+    theta = flow.theta.clone()
+    m, v = torch.zeros_like(theta), torch.zeros_like(theta)
+    out = torch.zeros(flow.P + 1, dtype=theta.dtype, device=dev)
+    gn = torch.zeros(1, dtype=theta.dtype, device=dev)
+    dt = 0 if theta.dtype == torch.float32 else 1
+
+    def step(i):
+        nf._lib.check(lib.nf_elbo_value_and_grad(ctx.ptr, C.byref(flow.desc), C.byref(tgt.c), vp(theta), None, n, n, 123, 0, i, vp(out)))
+        nf._lib.check(lib.nf_adam_update(ctx.ptr, dt, vp(theta), vp(out), vp(m), vp(v), flow.P, 1e-3, 0.9, 0.999, 1e-8, i + 1, vp(gn)))
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(warmup, warmup + steps):
+        step(i)
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    return {"ms_per_step": 1e3 * el, "samples_per_s": n / el, "loss": float(out[flow.P])}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=30)
+    args = ap.parse_args()
+    res = {}
+    g = torch.Generator().manual_seed(1)
+
+    def dg(d, dt=torch.float32):
+        return nf.DiagGaussTarget(torch.randn(d, generator=g).to(dev, dt), (torch.rand(d, generator=g) + 1e-3).to(dev, dt))
+
+    flow = nf.planarflow(nf.MvNormal(2), 10, paramtype=torch.float64, device=dev, seed=123)
+    res["cfg1_planar_d2_f64_n1024"] = time_step(flow, nf.BananaTarget(2, 1.0, 10.0), 1024, args.steps)
+    flow = nf.realnvp(nf.MvNormal(64), (64, 64), 4, paramtype=torch.float32, device=dev, seed=123)
+    res["cfg2_realnvp_d64_h64_n65536"] = time_step(flow, dg(64), 65536, args.steps)
+    flow = nf.realnvp(nf.MvNormal(64), (32, 32), 4, paramtype=torch.float32, device=dev, seed=123)
+    res["cfg2b_realnvp_d64_h32_n65536"] = time_step(flow, dg(64), 65536, args.steps)
+    flow = nf.nsf(nf.MvNormal(32), (32, 32), 8, 5.0, 4, paramtype=torch.float32, device=dev, seed=123)
+    res["cfg3_nsf_d32_k8_n131072"] = time_step(flow, dg(32), 131072, args.steps)
+    # cfg 5: forward-KL path
+    flow = nf.realnvp(nf.MvNormal(64), (64, 64), 4, paramtype=torch.float32, device=dev, seed=123)
+    n = 1 << 20
+    ys = nf.device_specific_rand(nf.PhiloxRNG(123), nf.MvNormal(64), n) * 2 + 1
+    for _ in range(3):
+        ll = nf.loglikelihood(None, flow, ys)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        ll = nf.loglikelihood(None, flow, ys)
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / 10
+    res["cfg5_loglik_realnvp_d64_n1M"] = {"ms_per_call": 1e3 * el, "samples_per_s": n / el, "loglik": ll}
+    for k, v in res.items():
+        print(k, json.dumps(v))
+
+
+if __name__ == "__main__":
+    main()
