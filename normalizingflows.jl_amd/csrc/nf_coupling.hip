@@ -350,15 +350,19 @@ __device__ __forceinline__ void bwd_tile(const CouplingArgs &a, const float *__r
   using L = BwdLds<G>;
   NF_TS_STAMP(0);
   const long j = tile * NF_TILE + l31;
-  // FULL: every feature block is full (m = 32*MB, c = 32*CB) and N is a multiple of the tile, so
-  // no load, store or mask below needs a predicate (no exec-mask branches in the hot loop).
+  // FULL: N is a multiple of the tile, so no sample mask is needed (feature bounds are handled by
+  // the buffer descriptors either way).
   const bool valid = FULL ? true : j < a.N;
   const int par_c = 1 - a.par_t;
-  // tiled layout, one buffer descriptor per array and tile: coalesced (one 128-byte line per
-  // half-wave per feature), bounds-checked by the hardware, one shared per-lane offset register
   const TileIO yio = make_tile_io(y, tile, a.d, l31, hi);
   const TileIO gio = make_tile_io(ybar, tile, a.d, l31, hi);
+  float *sd = sc + L::OFF_D;
 
+  // Every LDS stash write / activation-derivative scaling / tile store below is a SIDE JOB of the
+  // neighbouring GEMM (nf_mfma.h): program order is
+  //   L1 [stash x2] -> L2 [stash a1] -> L3 [stash a2] -> element-wise ->
+  //   dX3 [stash d3] -> dW3 [d2 *= lrelu'] -> dX2 [stash d2] -> dW2 [d1 *= lrelu'] ->
+  //   dX1 [stash d1] -> dW1 [x2bar stores]
   f32x16 d3[G::CB], y1[G::CB], g1[G::CB];
   unsigned m1[G::H1B], m2[G::H2B];
   {
@@ -370,24 +374,23 @@ __device__ __forceinline__ void bwd_tile(const CouplingArgs &a, const float *__r
         const float v = tile_load(yio, tile_soff(b, r, par_c));  // features >= d read as 0
         xb[b][r] = valid ? v : 0.f;
       }
-    tile_to_scratch<G::MB>(sc + L::OFF_X, xb, l31, hi);
     NF_TS_STAMP(1);
     f32x16 a1[G::H1B];
-    dense_fwd<G::MB, G::H1B>(img + G::W1, img + G::B1, xb, a1, l31, hi);
+    dense_fwd<G::MB, G::H1B>(img + G::W1, img + G::B1, xb, a1, l31, hi,
+                             [&](int e) { scratch_put<G::MB>(sc + L::OFF_X, xb, e, l31, hi); });
 #pragma unroll
     for (int b = 0; b < G::H1B; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) a1[b][r] = nf_lrelu(a1[b][r]);
     sign_masks<G::H1B>(a1, m1);
-    tile_to_scratch<G::H1B>(sc + L::OFF_A1, a1, l31, hi);
     f32x16 a2[G::H2B];
-    dense_fwd<G::H1B, G::H2B>(img + G::W2, img + G::B2, a1, a2, l31, hi);
+    dense_fwd<G::H1B, G::H2B>(img + G::W2, img + G::B2, a1, a2, l31, hi,
+                              [&](int e) { scratch_put<G::H1B>(sc + L::OFF_A1, a1, e, l31, hi); });
 #pragma unroll
     for (int b = 0; b < G::H2B; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) a2[b][r] = nf_lrelu(a2[b][r]);
     sign_masks<G::H2B>(a2, m2);
-    tile_to_scratch<G::H2B>(sc + L::OFF_A2, a2, l31, hi);
     // operands of the element-wise stage: issued here, consumed after the last forward layer
 #pragma unroll
     for (int b = 0; b < G::CB; ++b)
@@ -396,7 +399,8 @@ __device__ __forceinline__ void bwd_tile(const CouplingArgs &a, const float *__r
         y1[b][r] = tile_load(yio, tile_soff(b, r, a.par_t));
         g1[b][r] = tile_load(gio, tile_soff(b, r, a.par_t));
       }
-    dense_fwd<G::H2B, G::CB>(img + G::W3, img + G::B3, a2, d3, l31, hi);  // T (phase T) or pre-tanh S
+    dense_fwd<G::H2B, G::CB>(img + G::W3, img + G::B3, a2, d3, l31, hi,
+                             [&](int e) { scratch_put<G::H2B>(sc + L::OFF_A2, a2, e, l31, hi); });
   }
   NF_TS_STAMP(2);
 
@@ -406,8 +410,7 @@ __device__ __forceinline__ void bwd_tile(const CouplingArgs &a, const float *__r
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int p = b * 32 + nf_row(r, hi);
-      const bool okf = FULL ? true : p < a.c;  // padded samples may be stored to (never read unmasked)
-      const bool ok = okf && valid;
+      const bool ok = (p < a.c) && valid;  // rows >= c: the loads returned 0, the stores are dropped
       const float yv = y1[b][r], gv = g1[b][r];
       if (!PHASE_S) {
         tile_store(yio, tile_soff(b, r, a.par_t), yv - d3[b][r]);  // u = x1 * exp(S)
@@ -417,51 +420,45 @@ __device__ __forceinline__ void bwd_tile(const CouplingArgs &a, const float *__r
         const float es = nf_exp(s);
         tile_store(yio, tile_soff(b, r, a.par_t), __fdividef(yv, es));  // x1 = u * exp(-s)
         tile_store(gio, tile_soff(b, r, a.par_t), gv * es);             // x1bar
-        d3[b][r] = ok ? (gv * yv + lb) * (1.f - s * s) : 0.f;      // S-bar through tanh
+        d3[b][r] = ok ? (gv * yv + lb) * (1.f - s * s) : 0.f;           // S-bar through tanh
       }
     }
-
   NF_TS_STAMP(3);
-  float *sd = sc + L::OFF_D;
-  // ---- layer 3: dW3^T += a2 * d3^T ; d2 = (W3^T d3) .* lrelu'(a2)
-  tile_to_scratch<G::CB>(sd, d3, l31, hi);
-  wave_lds_fence();
-  NF_TS_STAMP(4);
-  dw_accumulate<G::H2B, G::CB>(sc + L::OFF_A2, sd, acc.w3, acc.b3, l31, hi);
-  NF_TS_STAMP(5);
+
+  // ---- layer 3
   f32x16 d2[G::H2B];
-  dense_bwd_x<G::H2B, G::CB>(img + G::W3, d3, d2, l31, hi);
-  apply_lrelu_grad<G::H2B>(d2, m2);
-  NF_TS_STAMP(6);
+  dense_bwd_x<G::H2B, G::CB>(img + G::W3, d3, d2, l31, hi, [&](int e) { scratch_put<G::CB>(sd, d3, e, l31, hi); });
+  NF_TS_STAMP(4);
+  wave_lds_fence();
+  dw_accumulate<G::H2B, G::CB>(sc + L::OFF_A2, sd, acc.w3, acc.b3, l31, hi, [&](int e) {
+    if (e < G::H2B * 16) d2[e >> 4][e & 15] *= ((m2[e >> 4] >> (e & 15)) & 1u) ? 1.f : 0.01f;
+  });
+  NF_TS_STAMP(5);
   wave_lds_fence();
   // ---- layer 2
-  tile_to_scratch<G::H2B>(sd, d2, l31, hi);
-  wave_lds_fence();
-  dw_accumulate<G::H1B, G::H2B>(sc + L::OFF_A1, sd, acc.w2, acc.b2, l31, hi);
-  NF_TS_STAMP(7);
   f32x16 d1[G::H1B];
-  dense_bwd_x<G::H1B, G::H2B>(img + G::W2, d2, d1, l31, hi);
-  apply_lrelu_grad<G::H1B>(d1, m1);
-  NF_TS_STAMP(8);
+  dense_bwd_x<G::H1B, G::H2B>(img + G::W2, d2, d1, l31, hi, [&](int e) { scratch_put<G::H2B>(sd, d2, e, l31, hi); });
+  NF_TS_STAMP(6);
   wave_lds_fence();
-  // ---- layer 1
-  tile_to_scratch<G::H1B>(sd, d1, l31, hi);
+  dw_accumulate<G::H1B, G::H2B>(sc + L::OFF_A1, sd, acc.w2, acc.b2, l31, hi, [&](int e) {
+    if (e < G::H1B * 16) d1[e >> 4][e & 15] *= ((m1[e >> 4] >> (e & 15)) & 1u) ? 1.f : 0.01f;
+  });
+  NF_TS_STAMP(7);
   wave_lds_fence();
-  dw_accumulate<G::MB, G::H1B>(sc + L::OFF_X, sd, acc.w1, acc.b1, l31, hi);
-  NF_TS_STAMP(9);
-  // x2bar accumulates ybar2 + W1t^T d1t (phase T) + W1s^T d1s (phase S): old value fetched here,
-  // behind the last dX GEMM
+  // ---- layer 1: x2bar accumulates ybar2 + W1t^T d1t (phase T) + W1s^T d1s (phase S)
   f32x16 g2[G::MB], gold[G::MB];
 #pragma unroll
   for (int b = 0; b < G::MB; ++b)
 #pragma unroll
     for (int r = 0; r < 16; ++r) gold[b][r] = tile_load(gio, tile_soff(b, r, par_c));
-  dense_bwd_x<G::MB, G::H1B>(img + G::W1, d1, g2, l31, hi);
+  dense_bwd_x<G::MB, G::H1B>(img + G::W1, d1, g2, l31, hi, [&](int e) { scratch_put<G::H1B>(sd, d1, e, l31, hi); });
+  NF_TS_STAMP(8);
   wave_lds_fence();
-#pragma unroll
-  for (int b = 0; b < G::MB; ++b)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) tile_store(gio, tile_soff(b, r, par_c), gold[b][r] + g2[b][r]);
+  dw_accumulate<G::MB, G::H1B>(sc + L::OFF_X, sd, acc.w1, acc.b1, l31, hi, [&](int e) {
+    if (e < G::MB * 16) tile_store(gio, tile_soff(e >> 4, e & 15, par_c), gold[e >> 4][e & 15] + g2[e >> 4][e & 15]);
+  });
+  NF_TS_STAMP(9);
+  wave_lds_fence();
   NF_TS_STAMP(10);
 }
 

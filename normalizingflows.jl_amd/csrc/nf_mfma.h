@@ -55,9 +55,19 @@ struct DenseLds {
 // ds_read of a layer (hundreds) above the first MFMA and spills.
 
 // out[ob] = W * in + b   (no activation).  IB input blocks, OB output blocks.
-template <int IB, int OB, int S = 32 * OB + 1>
+// Side jobs.  The MFMA loops take an optional functor `sj(slot)` invoked once after every MFMA
+// (slot = running MFMA index) with small independent pieces of work (LDS stash of the previous
+// activations, leaky-ReLU' scaling of the previous dX result, tile stores).  hipcc is left free to
+// place them: measured on MI355X, PINNING a VALU/LDS instruction between two fp32 MFMAs costs more
+// than it hides (+6 % on the reverse pass), because back-to-back MFMAs on one accumulator lose their
+// fast issue path -- so this only removes separate loops, it does not buy overlap.
+struct NoSideJob {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+template <int IB, int OB, int S = 32 * OB + 1, class SJ = NoSideJob>
 __device__ __forceinline__ void dense_fwd(const float *__restrict__ w, const float *__restrict__ b,
-                                          const f32x16 (&in)[IB], f32x16 (&out)[OB], int l31, int hi) {
+                                          const f32x16 (&in)[IB], f32x16 (&out)[OB], int l31, int hi,
+                                          SJ sj = SJ()) {
   constexpr int NG = IB * 4;  // groups of 4 k-steps
 #pragma unroll
   for (int ob = 0; ob < OB; ++ob)
@@ -85,16 +95,18 @@ __device__ __forceinline__ void dense_fwd(const float *__restrict__ w, const flo
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int ob = 0; ob < OB; ++ob)
+      for (int ob = 0; ob < OB; ++ob) {
         out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[ob][e], in[g / 4][(g % 4) * 4 + e], out[ob], 0, 0, 0);
+        sj((g * 4 + e) * OB + ob);
+      }
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
 // din[ib] = W^T * delta : the dX GEMM of the reverse pass, same register chaining.
-template <int IB, int OB, int S = 32 * OB + 1, bool ACCUM = false>
+template <int IB, int OB, int S = 32 * OB + 1, bool ACCUM = false, class SJ = NoSideJob>
 __device__ __forceinline__ void dense_bwd_x(const float *__restrict__ w, const f32x16 (&delta)[OB],
-                                            f32x16 (&din)[IB], int l31, int hi) {
+                                            f32x16 (&din)[IB], int l31, int hi, SJ sj = SJ()) {
   constexpr int NG = OB * 4;
   if (!ACCUM) {
 #pragma unroll
@@ -124,8 +136,10 @@ __device__ __forceinline__ void dense_bwd_x(const float *__restrict__ w, const f
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int ib = 0; ib < IB; ++ib)
+      for (int ib = 0; ib < IB; ++ib) {
         din[ib] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[ib][e], delta[g / 4][(g % 4) * 4 + e], din[ib], 0, 0, 0);
+        sj((g * 4 + e) * IB + ib);
+      }
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -144,11 +158,18 @@ __device__ __forceinline__ void tile_to_scratch(float *__restrict__ sc, const f3
     for (int r = 0; r < 16; ++r) sc[(b * 32 + nf_row(r, hi)) * NF_TS + l31] = v[b][r];
 }
 
+// one element (flat index e = block * 16 + reg) of tile_to_scratch, for use in side jobs
+template <int NB>
+__device__ __forceinline__ void scratch_put(float *__restrict__ sc, const f32x16 (&v)[NB], int e, int l31, int hi) {
+  if (e < NB * 16) sc[((e >> 4) * 32 + nf_row(e & 15, hi)) * NF_TS + l31] = v[e >> 4][e & 15];
+}
+
 // acc[ib][ob] (C layout: col = o, rows = i) += A(a) * B(delta); bsum[ob] += sum over this
 // half-wave's samples of delta (lane <-> feature o).  sa/sd: scratch tiles of a and delta.
-template <int IB, int OB>
+template <int IB, int OB, class SJ = NoSideJob>
 __device__ __forceinline__ void dw_accumulate(const float *__restrict__ sa, const float *__restrict__ sd,
-                                              f32x16 (&acc)[IB][OB], float (&bsum)[OB], int l31, int hi) {
+                                              f32x16 (&acc)[IB][OB], float (&bsum)[OB], int l31, int hi,
+                                              SJ sj = SJ()) {
   constexpr int TG = 2;        // k-steps (sample pairs) per pipeline group
   constexpr int NG = 16 / TG;
   const float *pa = sa + l31 * NF_TS + hi;
@@ -187,8 +208,10 @@ __device__ __forceinline__ void dw_accumulate(const float *__restrict__ sa, cons
 #pragma unroll
       for (int ib = 0; ib < IB; ++ib)
 #pragma unroll
-        for (int ob = 0; ob < OB; ++ob)
+        for (int ob = 0; ob < OB; ++ob) {
           acc[ib][ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u][ib], dc[u][ob], acc[ib][ob], 0, 0, 0);
+          sj(((g * TG + u) * IB + ib) * OB + ob);
+          }
     }
     __builtin_amdgcn_sched_barrier(0);
   }

@@ -45,7 +45,19 @@ def time_step(flow, tgt, n, steps, warmup=5):
         step(i)
     torch.cuda.synchronize()
     el = (time.perf_counter() - t0) / steps
-    return {"ms_per_step": 1e3 * el, "samples_per_s": n / el, "loss": float(out[flow.P])}
+    lib.nf_prof_enable(ctx.ptr, 2)
+    for i in range(3):
+        step(warmup + steps + i)
+    torch.cuda.synchronize()
+    kern = {}
+    for name in (b"base_sample", b"pack_weights", b"affine_chain", b"rqs_chain", b"simple_apply", b"target", b"affine_bwd",
+                 b"rqs_bwd", b"simple_bwd", b"reduce_slabs", b"adam"):
+        a, c = C.c_double(0.0), C.c_int64(0)
+        lib.nf_prof_read(ctx.ptr, name, C.byref(a), C.byref(c))
+        if c.value:
+            kern[name.decode()] = [round(1e3 * a.value, 1), c.value // 3]  # [avg us, launches per step]
+    lib.nf_prof_enable(ctx.ptr, 0)
+    return {"ms_per_step": round(1e3 * el, 4), "samples_per_s": round(n / el), "loss": float(out[flow.P]), "kernels_us": kern}
 
 
 def main():
