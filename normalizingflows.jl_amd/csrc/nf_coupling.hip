@@ -308,24 +308,30 @@ __device__ __forceinline__ void unstage_dense(const float *__restrict__ img, int
     if (tr) { __builtin_amdgcn_sched_barrier(0); tr[slot] = clock64(); }   \
   } while (0)
 
-// sign masks of post-leakyrelu activations (bit r set <=> a[r] > 0): all the reverse pass
-// needs of a1/a2 besides their LDS copies, so the activations themselves can die early.
+// Sign masks of the hidden pre-activations (bit r set <=> z[r] has its sign bit set, i.e. the
+// leaky-ReLU slope is 0.01): all the reverse pass needs of a1/a2 besides their LDS copies, so the
+// activations themselves can die early.  leakyrelu keeps the sign, so the mask is taken from the
+// post-activation value.  z = +0 counts as slope 1 where the oracle uses 0.01; the zero-padded rows
+// (z = 0 exactly) carry a zero cotangent, so the two agree.  (A shift-based form of this test,
+// (bits(v) >> 31) << r, produced wrong masks under hipcc 7.2 for some shapes; the integer compare
+// below is what the parity tests pin.)
 template <int NB>
 __device__ __forceinline__ void sign_masks(const f32x16 (&v)[NB], unsigned (&m)[NB]) {
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     unsigned bits = 0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bits |= (v[b][r] > 0.f ? 1u : 0u) << r;
+    for (int r = 0; r < 16; ++r) bits |= (__float_as_int(v[b][r]) < 0 ? 1u : 0u) << r;
     m[b] = bits;
   }
 }
+__device__ __forceinline__ float lrelu_slope(unsigned mask, int r) { return ((mask >> r) & 1u) ? 0.01f : 1.f; }
 template <int NB>
 __device__ __forceinline__ void apply_lrelu_grad(f32x16 (&d)[NB], const unsigned (&m)[NB]) {
 #pragma unroll
   for (int b = 0; b < NB; ++b)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) d[b][r] *= ((m[b] >> r) & 1u) ? 1.f : 0.01f;
+    for (int r = 0; r < 16; ++r) d[b][r] *= lrelu_slope(m[b], r);
 }
 
 // per-wave LDS scratch of the reverse pass, [feature][sample] tiles with row stride NF_TS:
@@ -431,7 +437,7 @@ __device__ __forceinline__ void bwd_tile(const CouplingArgs &a, const float *__r
   NF_TS_STAMP(4);
   wave_lds_fence();
   dw_accumulate<G::H2B, G::CB>(sc + L::OFF_A2, sd, acc.w3, acc.b3, l31, hi, [&](int e) {
-    if (e < G::H2B * 16) d2[e >> 4][e & 15] *= ((m2[e >> 4] >> (e & 15)) & 1u) ? 1.f : 0.01f;
+    if (e < G::H2B * 16) d2[e >> 4][e & 15] *= lrelu_slope(m2[e >> 4], e & 15);
   });
   NF_TS_STAMP(5);
   wave_lds_fence();
@@ -441,7 +447,7 @@ __device__ __forceinline__ void bwd_tile(const CouplingArgs &a, const float *__r
   NF_TS_STAMP(6);
   wave_lds_fence();
   dw_accumulate<G::H1B, G::H2B>(sc + L::OFF_A1, sd, acc.w2, acc.b2, l31, hi, [&](int e) {
-    if (e < G::H1B * 16) d1[e >> 4][e & 15] *= ((m1[e >> 4] >> (e & 15)) & 1u) ? 1.f : 0.01f;
+    if (e < G::H1B * 16) d1[e >> 4][e & 15] *= lrelu_slope(m1[e >> 4], e & 15);
   });
   NF_TS_STAMP(7);
   wave_lds_fence();

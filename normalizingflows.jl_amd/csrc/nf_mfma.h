@@ -28,7 +28,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ int nf_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
-__device__ __forceinline__ float nf_lrelu(float z) { return z > 0.f ? z : 0.01f * z; }
+// Flux.leakyrelu, slope 0.01: max(z, 0.01 z) (2 VALU ops; identical to z > 0 ? z : 0.01 z)
+__device__ __forceinline__ float nf_lrelu(float z) { return fmaxf(z, 0.01f * z); }
 
 // tanh / exp for the coupling's scale branch (s = tanh(.), exp(+-s); src/flows/realnvp.jl:50,79).
 // Hardware exp2-based forms: absolute error of tanh < 1e-7 (the reference itself runs NNlib's

@@ -585,7 +585,7 @@ __device__ __forceinline__ void rqs_bwd_tile(const RqsBwdArgs &a, const float *_
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         a1[b][r] = nf_lrelu(a1[b][r]);
-        bits |= (a1[b][r] > 0.f ? 1u : 0u) << r;
+        bits |= (a1[b][r] < 0.f ? 1u : 0u) << r;  // set <=> slope 0.01
       }
       m1[b] = bits;
     }
@@ -597,7 +597,7 @@ __device__ __forceinline__ void rqs_bwd_tile(const RqsBwdArgs &a, const float *_
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         a2[b][r] = nf_lrelu(a2[b][r]);
-        bits |= (a2[b][r] > 0.f ? 1u : 0u) << r;
+        bits |= (a2[b][r] < 0.f ? 1u : 0u) << r;
       }
       m2[b] = bits;
     }
@@ -673,7 +673,7 @@ __device__ __forceinline__ void rqs_bwd_tile(const RqsBwdArgs &a, const float *_
 #pragma unroll
   for (int b = 0; b < G::H2B; ++b)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) d2[b][r] *= ((m2[b] >> r) & 1u) ? 1.f : 0.01f;
+    for (int r = 0; r < 16; ++r) d2[b][r] *= ((m2[b] >> r) & 1u) ? 0.01f : 1.f;
   tile_to_scratch<G::H2B>(sd, d2, l31, hi);
   wave_lds_fence();
   dw_accumulate<G::H1B, G::H2B>(sc + L::OFF_A1, sd, acc.w2, acc.b2, l31, hi);
@@ -682,7 +682,7 @@ __device__ __forceinline__ void rqs_bwd_tile(const RqsBwdArgs &a, const float *_
 #pragma unroll
   for (int b = 0; b < G::H1B; ++b)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) d1[b][r] *= ((m1[b] >> r) & 1u) ? 1.f : 0.01f;
+    for (int r = 0; r < 16; ++r) d1[b][r] *= ((m1[b] >> r) & 1u) ? 0.01f : 1.f;
   wave_lds_fence();
   // ---- layer 1
   tile_to_scratch<G::H1B>(sd, d1, l31, hi);
