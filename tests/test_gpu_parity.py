@@ -241,3 +241,63 @@ def test_full_size_properties_cfg2(nf):
     l_rng, g_rng = nf.value_and_gradient(nf.elbo_batch, flow, tgt, n, rng=nf.PhiloxRNG(123))
     assert l_rng == pytest.approx(loss, rel=1e-6)
     assert float((g_rng - g).abs().max()) <= 1e-5 * float(g.abs().max())
+
+
+def test_fused_elbo_step_matches_split_calls(nf):
+    """nf_elbo_step (one call: draw, forward, reverse, Adam, norm) == nf_elbo_value_and_grad + nf_adam_update."""
+    import ctypes as C
+
+    lib = nf.load_library()
+    flow = nf.realnvp(nf.MvNormal(8), [32, 32], 2, paramtype=torch.float32, seed=5)
+    tgt = nf.DiagGaussTarget(torch.randn(8, device="cuda"), torch.rand(8, device="cuda") + 0.5)
+    n, P = 512, flow.P
+    ctx = flow.ctx
+    vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    th_a, th_b = flow.theta.clone(), flow.theta.clone()
+    ma, va = torch.zeros_like(th_a), torch.zeros_like(th_a)
+    mb, vb = torch.zeros_like(th_a), torch.zeros_like(th_a)
+    out = torch.empty(P + 1, device="cuda")
+    gn = torch.empty(1, device="cuda")
+    for step in range(3):
+        loss, gnorm = C.c_double(0), C.c_double(0)
+        nf._lib.check(lib.nf_elbo_step(ctx.ptr, C.byref(flow.desc), C.byref(tgt.c), vp(th_a), vp(ma), vp(va), n, 77, step,
+                                       1e-3, 0.9, 0.999, 1e-8, C.byref(loss), C.byref(gnorm)))
+        nf._lib.check(lib.nf_elbo_value_and_grad(ctx.ptr, C.byref(flow.desc), C.byref(tgt.c), vp(th_b), None, n, n, 77, 0,
+                                                 step, vp(out)))
+        nf._lib.check(lib.nf_adam_update(ctx.ptr, 0, vp(th_b), vp(out), vp(mb), vp(vb), P, 1e-3, 0.9, 0.999, 1e-8,
+                                         step + 1, vp(gn)))
+        assert loss.value == pytest.approx(float(out[P]), rel=1e-6)
+        assert gnorm.value == pytest.approx(float(gn), rel=1e-6)
+        np.testing.assert_array_equal(th_a.cpu().numpy(), th_b.cpu().numpy())  # deterministic, bit-identical
+
+
+def test_unsupported_shapes_fail_loudly(nf):
+    """Shapes the library does not build are reported (NF_ERR_UNSUPPORTED), never approximated."""
+    big = nf.realnvp(nf.MvNormal(256), [256, 256], 1, paramtype=torch.float32)
+    with pytest.raises(nf.NFHipError, match="not built"):
+        nf.with_logabsdet_jacobian(big.transform, torch.zeros(256, 4, device="cuda").t().contiguous().t())
+    f64 = nf.realnvp(nf.MvNormal(4), [8, 8], 1, paramtype=torch.float64)
+    with pytest.raises(nf.NFHipError, match="not built"):
+        nf.with_logabsdet_jacobian(f64.transform, torch.zeros(4, 2, dtype=torch.float64, device="cuda"))
+    with pytest.raises(nf.NFHipError):
+        nf.with_logabsdet_jacobian(nf.realnvp(nf.MvNormal(6), [8, 8], 1, paramtype=torch.float32).transform,
+                                   torch.zeros(5, 2, device="cuda"))  # dimension mismatch
+
+
+def test_nsf_properties_cfg3_shape(nf):
+    """NSF at the cfg-3 shape (d=32, K=8, B=5): round trip at the reference tolerance (test/flow.jl:97-105),
+    identity outside the box, shard linearity of the gradient."""
+    flow = nf.nsf(nf.MvNormal(32), [32, 32], 8, 5.0, 4, paramtype=torch.float32, seed=11)
+    xs = nf.device_specific_rand(nf.PhiloxRNG(3), flow.dist, 4096)
+    ys, lf = nf.with_logabsdet_jacobian(flow.transform, xs)
+    xr, lb = nf.with_logabsdet_jacobian(nf.inverse(flow.transform), ys)
+    assert float((xr - xs).norm() / xs.norm()) < 1e-4 and float((lf + lb).norm() / lf.norm().clamp_min(1e-6)) < 1e-4
+    far = torch.full((32, 64), 9.0, device="cuda")
+    yf, lfar = nf.with_logabsdet_jacobian(flow.transform, far)
+    assert torch.equal(yf, far) and float(lfar.abs().max()) == 0.0
+    tgt = nf.DiagGaussTarget(torch.randn(32, device="cuda"), torch.rand(32, device="cuda") + 0.5)
+    l, g = nf.value_and_gradient(nf.elbo_batch, flow, tgt, xs)
+    la, ga = nf.value_and_gradient(nf.elbo_batch, flow, tgt, xs[:, :1000], n_global=4096)
+    lb2, gb = nf.value_and_gradient(nf.elbo_batch, flow, tgt, xs[:, 1000:], n_global=4096)
+    assert la + lb2 == pytest.approx(l, rel=1e-5)
+    assert float((ga + gb - g).abs().max()) <= 1e-4 * float(g.abs().max())
