@@ -1,6 +1,8 @@
 // nf_api.hip -- extern "C" entry points of libnfhip.so (see include/nfhip.h for the
 // reference interface each one stands behind).  Host-side orchestration only: every
 // arithmetic operation happens in a gfx950 kernel; there is no CPU fallback.
+#include <cstdlib>
+
 #include "nf_common.h"
 
 // ---- kernels' host launchers (other translation units) ---------------------------------
@@ -34,6 +36,15 @@ long nf_affine_slab_floats(const nf_flow_desc *desc);
 int nf_affine_reduce_slabs(nf_ctx *, const nf_flow_desc *, const float *slab, int nslab, float *g);
 int nf_affine_bwd(nf_ctx *, const nf_flow_desc *, int k, const float *theta, float *y, float *ybar, const float *lbar,
                   float lbar_const, long N, float *slab, long slab_stride, int grid);
+
+// 16-sample-tile reverse pass (nf_coupling16.hip)
+bool nf_bwd16_supported(const nf_flow_desc *desc);
+long nf_bwd16_slab_floats(const nf_flow_desc *desc);
+int nf_bwd16_pack(nf_ctx *, const nf_flow_desc *, const float *theta);
+int nf_bwd16_reduce_slabs(nf_ctx *, const nf_flow_desc *, const float *slab, int nslab, float *g);
+int nf_bwd16_grid(nf_ctx *, long N);
+int nf_bwd16(nf_ctx *, const nf_flow_desc *, int k, float *y, float *ybar, const float *lbar, float lbar_const, long N,
+             float *slab, long stride, int grid);
 
 // neural spline couplings (nf_rqs.hip)
 bool nf_rqs_supported(const nf_flow_desc *desc);
@@ -177,6 +188,7 @@ extern "C" int nf_ctx_destroy(nf_ctx *ctx) {
   if (ctx->ws) hipFree(ctx->ws);
   if (ctx->gbuf) hipFree(ctx->gbuf);
   if (ctx->wimg) hipFree(ctx->wimg);
+  if (ctx->wimg16) hipFree(ctx->wimg16);
   if (ctx->trace) hipFree(ctx->trace);
   if (ctx->host_scratch) hipHostFree(ctx->host_scratch);
   delete ctx;
@@ -238,13 +250,25 @@ static inline bool is_coupling(const nf_flow_desc *desc) {
   return desc->kind == NF_KIND_REALNVP || desc->kind == NF_KIND_NSF;
 }
 static inline bool is_nsf(const nf_flow_desc *desc) { return desc->kind == NF_KIND_NSF; }
+// RealNVP reverse pass: the 16-sample-tile kernel (two waves per SIMD, nf_coupling16.hip) is an
+// EXPERIMENT, off by default: it is parity-green but measured slower on MI355X (128 us vs 75 us per
+// coupling at the benchmark shape; register spills at 256 registers/wave).  NF_BWD16=1 selects it.
+static bool use_bwd16(const nf_flow_desc *desc) {
+  static const bool enabled = [] {
+    const char *e = getenv("NF_BWD16");
+    return e && e[0] == '1';
+  }();
+  return enabled && !is_nsf(desc) && nf_bwd16_supported(desc);
+}
 static int coupling_pack(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta) {
   return is_nsf(desc) ? nf_rqs_pack(ctx, desc, theta) : nf_affine_pack(ctx, desc, theta);
 }
 static int coupling_bwd_grid(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
+  if (use_bwd16(desc)) return nf_bwd16_grid(ctx, N);
   return is_nsf(desc) ? nf_rqs_bwd_grid(ctx, N) : nf_affine_bwd_grid(ctx, N);
 }
 static long coupling_slab_floats(const nf_flow_desc *desc) {
+  if (use_bwd16(desc)) return nf_bwd16_slab_floats(desc);
   return is_nsf(desc) ? nf_rqs_slab_floats(desc) : nf_affine_slab_floats(desc);
 }
 
@@ -304,6 +328,12 @@ static int realnvp_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta
                        const float *lbar, float lbar_const, long N, float *slab, int grid, float *g_out) {
   const long stride = coupling_slab_floats(desc);
   const int nc = 2 * desc->nlayers;
+  if (use_bwd16(desc)) {
+    NF_TRY(nf_bwd16_pack(ctx, desc, theta));
+    for (int k = 0; k < nc; ++k)
+      NF_TRY(nf_bwd16(ctx, desc, k, state, gbar, lbar, lbar_const, N, slab, stride, grid));
+    return nf_bwd16_reduce_slabs(ctx, desc, slab, grid, g_out);
+  }
   for (int k = 0; k < nc; ++k) {  // flat order = reverse of execution order
     if (is_nsf(desc))
       NF_TRY(nf_rqs_bwd(ctx, desc, k, state, gbar, lbar, lbar_const, N, slab, stride, grid));

@@ -277,10 +277,12 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 // ---- LDS image of a 2-hidden-layer conditioner net ----------------------------------
 // Geometry in blocks of 32: MB (conditioner inputs), H1B, H2B (hidden), CB (outputs).
-template <int MB_, int H1B_, int H2B_, int CB_>
+// PAD = row padding in floats (odd for the 32-sample kernels; 4 for the 16-sample kernel, which
+// reads four consecutive rows' worth of one column group with ds_read_b128).
+template <int MB_, int H1B_, int H2B_, int CB_, int PAD_ = 1>
 struct NetGeo {
-  static constexpr int MB = MB_, H1B = H1B_, H2B = H2B_, CB = CB_;
-  static constexpr int S1 = 32 * H1B + 1, S2 = 32 * H2B + 1, S3 = 32 * CB + 1;
+  static constexpr int MB = MB_, H1B = H1B_, H2B = H2B_, CB = CB_, PAD = PAD_;
+  static constexpr int S1 = 32 * H1B + PAD, S2 = 32 * H2B + PAD, S3 = 32 * CB + PAD;
   static constexpr int W1 = 0;
   static constexpr int B1 = W1 + 32 * MB * S1;
   static constexpr int W2 = B1 + 32 * H1B;
