@@ -46,6 +46,14 @@ int nf_bwd16_grid(nf_ctx *, long N);
 int nf_bwd16(nf_ctx *, const nf_flow_desc *, int k, float *y, float *ybar, const float *lbar, float lbar_const, long N,
              float *slab, long stride, int grid);
 
+// RealNVP with conditioner nets streamed from L2 (nf_wide.hip): d <= 256, hidden <= 256
+bool nf_wide_supported(const nf_flow_desc *desc);
+int nf_wide_pack(nf_ctx *, const nf_flow_desc *, const float *theta);
+int nf_wide_apply(nf_ctx *, const nf_flow_desc *, int k, bool inverse, float *xt, long N, float *ladj, int accumulate);
+size_t nf_wide_bwd_ws_floats(nf_ctx *, const nf_flow_desc *, long N);
+int nf_wide_bwd(nf_ctx *, const nf_flow_desc *, float *state, float *gbar, const float *lbar, float lbar_const, long N,
+                float *ws, float *g_out);
+
 // neural spline couplings (nf_rqs.hip)
 bool nf_rqs_supported(const nf_flow_desc *desc);
 int nf_rqs_pack(nf_ctx *, const nf_flow_desc *, const float *theta);
@@ -80,7 +88,7 @@ static int check_desc(const nf_flow_desc *d) {
       if (d->n_hidden < 1 || d->n_hidden > NF_MAX_HIDDEN) return NF_ERR_ARG;
       if (d->d < 2) return NF_ERR_ARG;
       if (d->dtype != NF_DTYPE_F32) return NF_ERR_UNSUPPORTED;
-      return nf_affine_supported(d) ? NF_OK : NF_ERR_UNSUPPORTED;
+      return (nf_affine_supported(d) || nf_wide_supported(d)) ? NF_OK : NF_ERR_UNSUPPORTED;
     case NF_KIND_NSF:
       if (d->n_hidden < 1 || d->n_hidden > NF_MAX_HIDDEN || d->d < 2 || d->K < 2) return NF_ERR_ARG;
       if (d->dtype != NF_DTYPE_F32) return NF_ERR_UNSUPPORTED;
@@ -250,6 +258,10 @@ static inline bool is_coupling(const nf_flow_desc *desc) {
   return desc->kind == NF_KIND_REALNVP || desc->kind == NF_KIND_NSF;
 }
 static inline bool is_nsf(const nf_flow_desc *desc) { return desc->kind == NF_KIND_NSF; }
+// RealNVP shapes whose nets do not fit in LDS take the weight-streaming kernels
+static inline bool is_wide(const nf_flow_desc *desc) {
+  return desc->kind == NF_KIND_REALNVP && !nf_affine_supported(desc) && nf_wide_supported(desc);
+}
 // RealNVP reverse pass: the 16-sample-tile kernel (two waves per SIMD, nf_coupling16.hip) is an
 // EXPERIMENT, off by default: it is parity-green but measured slower on MI355X (128 us vs 75 us per
 // coupling at the benchmark shape; register spills at 256 registers/wave).  NF_BWD16=1 selects it.
@@ -261,13 +273,17 @@ static bool use_bwd16(const nf_flow_desc *desc) {
   return enabled && !is_nsf(desc) && nf_bwd16_supported(desc);
 }
 static int coupling_pack(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta) {
+  if (is_wide(desc)) return nf_wide_pack(ctx, desc, theta);
   return is_nsf(desc) ? nf_rqs_pack(ctx, desc, theta) : nf_affine_pack(ctx, desc, theta);
 }
 static int coupling_bwd_grid(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
+  if (is_wide(desc)) return 1;
   if (use_bwd16(desc)) return nf_bwd16_grid(ctx, N);
   return is_nsf(desc) ? nf_rqs_bwd_grid(ctx, N) : nf_affine_bwd_grid(ctx, N);
 }
-static long coupling_slab_floats(const nf_flow_desc *desc) {
+// floats of reverse-pass workspace per workgroup slab (wide path: the whole stash + split-K area)
+static long coupling_slab_floats(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
+  if (is_wide(desc)) return (long)nf_wide_bwd_ws_floats(ctx, desc, N);
   if (use_bwd16(desc)) return nf_bwd16_slab_floats(desc);
   return is_nsf(desc) ? nf_rqs_slab_floats(desc) : nf_affine_slab_floats(desc);
 }
@@ -277,6 +293,13 @@ static int coupling_chain_tiled(nf_ctx *ctx, const nf_flow_desc *desc, bool inve
                                 long N, float *ladj, int k_only) {
   NF_TRY(coupling_pack(ctx, desc, theta));
   if (is_nsf(desc)) return nf_rqs_chain(ctx, desc, inverse, xt, N, ladj, k_only);
+  if (is_wide(desc)) {
+    if (k_only >= 0) return nf_wide_apply(ctx, desc, k_only, inverse, xt, N, ladj, 0);
+    const int nc = 2 * desc->nlayers;
+    for (int s = 0; s < nc; ++s)  // forward applies the LAST flat coupling first
+      NF_TRY(nf_wide_apply(ctx, desc, inverse ? s : nc - 1 - s, inverse, xt, N, ladj, s > 0));
+    return NF_OK;
+  }
   if (k_only >= 0) return nf_affine_apply(ctx, desc, k_only, inverse, theta, xt, N, xt, ladj, 0);
   return nf_affine_chain(ctx, desc, inverse, xt, N, ladj);
 }
@@ -326,7 +349,8 @@ extern "C" int nf_layer_apply(nf_ctx *ctx, const nf_flow_desc *desc, int32_t lay
 // the flow INPUT on exit (invertible recompute); `gbar` holds ybar on entry and xbar on exit.
 static int realnvp_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta, float *state, float *gbar,
                        const float *lbar, float lbar_const, long N, float *slab, int grid, float *g_out) {
-  const long stride = coupling_slab_floats(desc);
+  if (is_wide(desc)) return nf_wide_bwd(ctx, desc, state, gbar, lbar, lbar_const, N, slab, g_out);
+  const long stride = coupling_slab_floats(ctx, desc, N);
   const int nc = 2 * desc->nlayers;
   if (use_bwd16(desc)) {
     NF_TRY(nf_bwd16_pack(ctx, desc, theta));
@@ -354,7 +378,7 @@ extern "C" int nf_flow_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const void *th
   if (is_coupling(desc)) {
     const int grid = coupling_bwd_grid(ctx, desc, N);
     const size_t te = tiled_elems(desc, N);
-    const size_t slabf = (size_t)grid * coupling_slab_floats(desc);
+    const size_t slabf = (size_t)grid * coupling_slab_floats(ctx, desc, N);
     NF_TRY(nf_ws_reserve(ctx, 2 * carve_bytes(te * 4) + carve_bytes(slabf * 4)));
     Carver cv(ctx->ws);
     float *state = cv.take<float>(te);
@@ -487,7 +511,7 @@ extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, con
   const long nb = cp ? nf_target_tiled_nblocks(N) : nf_target_nblocks(N);
   const int grid = cp ? coupling_bwd_grid(ctx, desc, N) : 0;
   const size_t simple_ws = cp ? 0 : nf_simple_bwd_ws_bytes(ctx, desc, N);
-  const size_t slabf = cp ? (size_t)grid * coupling_slab_floats(desc) : 0;
+  const size_t slabf = cp ? (size_t)grid * coupling_slab_floats(ctx, desc, N) : 0;
   const size_t xe = cp ? tiled_elems(desc, N) : (size_t)N * desc->d;
   const size_t need = 3 * carve_bytes(xe * es) + 2 * carve_bytes((size_t)N * es) + carve_bytes((size_t)nb * 8) +
                       carve_bytes(64) + carve_bytes(slabf * es) + carve_bytes(simple_ws);

@@ -1,0 +1,820 @@
+// nf_wide.hip -- AffineCoupling (RealNVP) kernels for conditioner nets that do NOT fit in LDS
+// (BASELINE cfg 4: d = 256, 16 couplings, hidden [256,256]: one net is 512 KB of weights).
+//
+// Reference arithmetic: src/flows/realnvp.jl:57-110 (same as nf_coupling.hip); conditioner
+// src/flows/utils.jl:71-100.
+//
+// Design (MI355X): a workgroup is 4 wavefronts, each owning one 32-sample tile whose activations
+// stay in registers in the MFMA C layout (nf_mfma.h).  The weights are STREAMED: the packed image
+// of a net (nf_pack.h, rows padded to an odd stride) is cut into chunks of 32 input rows; chunk
+// q+1 is copied global -> LDS by the DMA path (global_load_lds, no staging registers) into the
+// other half of a double buffer while the matrix pipe works on chunk q.  One chunk feeds
+// 16 x OB MFMAs per wave, so one barrier per chunk costs ~1 % at OB = 8.
+//   forward/inverse : k_wide_apply   (S net, T net, affine update, ladj)
+//   reverse pass    : k_wide_bwd<PHASE>  recompute + dX chain for ONE net; activations and
+//                     deltas go to an HBM stash in [tile][feature][32 samples] layout, and
+//                     k_wide_dw turns the stash into weight gradients: a split-K (over sample
+//                     tiles) MFMA GEMM whose operands are transposed through LDS (row stride 33).
+// The dW accumulators of a 256x256 layer (64 MFMA blocks = 1024 registers) cannot stay resident
+// per wave the way nf_coupling.hip keeps them, hence the stash.  Per sample and net it is
+// (2*h1 + 2*h2 + c) floats, written once and read once.
+#include "nf_common.h"
+#include "nf_mfma.h"
+#include "nf_pack.h"
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+using GW = NetGeo<4, 8, 8, 4>;  // every wide flow is zero-padded into this geometry
+
+template <class G>
+struct Wide {
+  static constexpr int CF1 = 32 * G::S1, CF2 = 32 * G::S2, CF3 = 32 * G::S3;  // chunk sizes (floats)
+  static constexpr int CFMAX = CF1 > CF2 ? (CF1 > CF3 ? CF1 : CF3) : (CF2 > CF3 ? CF2 : CF3);
+  static constexpr int CHBUF = ((CFMAX * 4 + 1023) / 1024) * 256;  // floats per buffer, whole 1-KiB DMA pieces
+  static constexpr int NBIAS = 32 * (G::H1B + G::H2B + G::CB);
+  static constexpr int WAVES = 4;
+  static constexpr size_t LDS_APPLY = (size_t)(2 * CHBUF + 2 * NBIAS) * sizeof(float);
+  static constexpr size_t LDS_BWD = (size_t)(2 * CHBUF + NBIAS) * sizeof(float);
+};
+
+// DMA one chunk global -> LDS (buffer_load_dwordx4 ... lds): 1 KiB (64 lanes x 16 B) per
+// instruction, pieces dealt round-robin to the 4 waves.  `img` is a buffer descriptor over one
+// net's packed image, `off` the chunk's offset in floats: all address arithmetic is scalar, the
+// only vector register is lane * 16.  The last piece may run past the chunk into the following
+// image bytes (descriptor bound: reads as 0; the LDS buffer is a whole number of pieces).
+typedef __amdgpu_buffer_rsrc_t wide_img_t;
+__device__ __forceinline__ wide_img_t make_img(const float *img, int nfloats) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(img), 0, nfloats * 4, 0x00020000);
+}
+__device__ __forceinline__ void issue_chunk(wide_img_t img, int off, int nfloats, float *ldst, int wave, int lane) {
+  for (int p = wave; p * 256 < nfloats; p += 4)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(img, (lds_void_t *)(ldst + p * 256), 16, lane * 16, (off + p * 256) * 4, 0, 0);
+}
+
+// out[ob] += W[rows of this chunk][:] * in_blk   (chunk = 32 input rows, all output columns)
+template <int OB, int S>
+__device__ __forceinline__ void wide_fwd_chunk(const float *__restrict__ ch, const f32x16 &in, f32x16 (&out)[OB], int l31,
+                                               int hi) {
+  const float *wl = ch + (4 * hi) * S + l31;
+  float an[OB], ac[OB];
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob) an[ob] = wl[ob * 32];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob) ac[ob] = an[ob];
+    if (t + 1 < 16) {
+      const int row = ((t + 1) & 3) + 8 * ((t + 1) >> 2);
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob) an[ob] = wl[row * S + ob * 32];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob) out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[ob], in[t], out[ob], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// din = W[rows of this chunk][:]^T-contracted with delta: din[i] = sum_o W[i][o] delta[o]
+template <int OB, int S>
+__device__ __forceinline__ void wide_bwdx_chunk(const float *__restrict__ ch, const f32x16 (&delta)[OB], f32x16 &din,
+                                                int l31, int hi) {
+  const float *wl = ch + l31 * S + 4 * hi;
+  constexpr int NG = OB * 4;
+  float an[4], ac[4];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) din[r] = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) an[e] = wl[e];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ac[e] = an[e];
+    if (g + 1 < NG) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) an[e] = wl[(g + 1) * 8 + e];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      din = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[e], delta[g / 4][(g % 4) * 4 + e], din, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+struct NoPost {
+  template <class T>
+  __device__ __forceinline__ void operator()(T &) const {}
+};
+
+template <int NB>
+__device__ __forceinline__ void init_bias(f32x16 (&v)[NB], const float *__restrict__ b, int hi) {
+#pragma unroll
+  for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[ob][r] = b[ob * 32 + nf_row(r, hi)];
+}
+
+// Streams one net forward.  On entry the chunk (W1, rows 0..31) of `img` is resident in
+// cb[buf]; on exit the chunk (next_src, next_floats) is resident in cb[buf] (or nothing if
+// next_floats == 0).  post1/post2 see the post-activation hidden layers (reverse pass: masks, stash).
+template <class G, class P1, class P2>
+__device__ __forceinline__ void wide_net_fwd(wide_img_t img, const float *__restrict__ bias, float *cb, int &buf,
+                                             wide_img_t next_img, int next_off, int next_floats,
+                                             const f32x16 (&xb)[G::MB], f32x16 (&out)[G::CB], int wave, int lane, P1 post1,
+                                             P2 post2) {
+  using W = Wide<G>;
+  const int l31 = lane & 31, hi = lane >> 5;
+  f32x16 a1[G::H1B];
+  init_bias<G::H1B>(a1, bias, hi);
+#pragma unroll
+  for (int ib = 0; ib < G::MB; ++ib) {
+    if (ib + 1 < G::MB)
+      issue_chunk(img, G::W1 + (ib + 1) * W::CF1, W::CF1, cb + (buf ^ 1) * W::CHBUF, wave, lane);
+    else
+      issue_chunk(img, G::W2, W::CF2, cb + (buf ^ 1) * W::CHBUF, wave, lane);
+    wide_fwd_chunk<G::H1B, G::S1>(cb + buf * W::CHBUF, xb[ib], a1, l31, hi);
+    __syncthreads();
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int b = 0; b < G::H1B; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a1[b][r] = nf_lrelu(a1[b][r]);
+  post1(a1);
+  f32x16 a2[G::H2B];
+  init_bias<G::H2B>(a2, bias + 32 * G::H1B, hi);
+#pragma unroll
+  for (int ib = 0; ib < G::H1B; ++ib) {
+    if (ib + 1 < G::H1B)
+      issue_chunk(img, G::W2 + (ib + 1) * W::CF2, W::CF2, cb + (buf ^ 1) * W::CHBUF, wave, lane);
+    else
+      issue_chunk(img, G::W3, W::CF3, cb + (buf ^ 1) * W::CHBUF, wave, lane);
+    wide_fwd_chunk<G::H2B, G::S2>(cb + buf * W::CHBUF, a1[ib], a2, l31, hi);
+    __syncthreads();
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int b = 0; b < G::H2B; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a2[b][r] = nf_lrelu(a2[b][r]);
+  post2(a2);
+  init_bias<G::CB>(out, bias + 32 * (G::H1B + G::H2B), hi);
+#pragma unroll
+  for (int ib = 0; ib < G::H2B; ++ib) {
+    if (ib + 1 < G::H2B)
+      issue_chunk(img, G::W3 + (ib + 1) * W::CF3, W::CF3, cb + (buf ^ 1) * W::CHBUF, wave, lane);
+    else if (next_floats)
+      issue_chunk(next_img, next_off, next_floats, cb + (buf ^ 1) * W::CHBUF, wave, lane);
+    wide_fwd_chunk<G::CB, G::S3>(cb + buf * W::CHBUF, a2[ib], out, l31, hi);
+    __syncthreads();
+    buf ^= 1;
+  }
+}
+
+template <class G>
+__device__ __forceinline__ void stage_biases(float *__restrict__ dst, const float *__restrict__ img, int tid) {
+  for (int i = tid; i < Wide<G>::NBIAS; i += 256) {
+    int src;
+    if (i < 32 * G::H1B) src = G::B1 + i;
+    else if (i < 32 * (G::H1B + G::H2B)) src = G::B2 + i - 32 * G::H1B;
+    else src = G::B3 + i - 32 * (G::H1B + G::H2B);
+    dst[i] = img[src];
+  }
+}
+
+struct WideArgs {
+  const float *img_s, *img_t;
+  int d, c, m, par_t;
+  long N;
+};
+
+// ------------------------------------------------------------------------------------
+// forward / inverse of one coupling, in place on the tiled batch
+// ------------------------------------------------------------------------------------
+template <class G, bool INVERSE>
+__global__ __launch_bounds__(256, 1) void k_wide_apply(WideArgs a, float *xt, float *__restrict__ ladj, int accumulate) {
+  using W = Wide<G>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *cb = lds;
+  float *bias = lds + 2 * W::CHBUF;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int par_c = 1 - a.par_t;
+  const long ntiles = (a.N + NF_TILE - 1) / NF_TILE;
+  const long ngroups = (ntiles + 3) / 4;
+
+  const wide_img_t img_s = make_img(a.img_s, G::SIZE), img_t = make_img(a.img_t, G::SIZE);
+  issue_chunk(img_s, G::W1, W::CF1, cb, wave, lane);
+  stage_biases<G>(bias, a.img_s, tid);
+  stage_biases<G>(bias + W::NBIAS, a.img_t, tid);
+  __syncthreads();
+  int buf = 0;
+
+  for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const long tile = grp * 4 + wave;
+    const bool live = tile < ntiles;
+    const long tl = live ? tile : 0;
+    const long j = tl * NF_TILE + l31;
+    const bool valid = live && j < a.N;
+    const bool more = grp + gridDim.x < ngroups;
+    const TileIO io = make_tile_io(xt, tl, a.d, l31, hi);
+    f32x16 S[G::CB], T[G::CB];
+    {
+      f32x16 xb[G::MB];
+#pragma unroll
+      for (int b = 0; b < G::MB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = tile_load(io, tile_soff(b, r, par_c));
+          xb[b][r] = valid ? v : 0.f;
+        }
+      wide_net_fwd<G>(img_s, bias, cb, buf, img_t, G::W1, W::CF1, xb, S, wave, lane, NoPost(), NoPost());
+    }
+    {
+      f32x16 xb[G::MB];
+#pragma unroll
+      for (int b = 0; b < G::MB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = tile_load(io, tile_soff(b, r, par_c));
+          xb[b][r] = valid ? v : 0.f;
+        }
+      wide_net_fwd<G>(img_t, bias + W::NBIAS, cb, buf, img_s, G::W1, more ? W::CF1 : 0, xb, T, wave, lane, NoPost(),
+                      NoPost());
+    }
+    float lsum = 0.f;
+#pragma unroll
+    for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float s = nf_tanh(S[b][r]);  // padded rows: zero weights and bias => s = 0
+        const float v = tile_load(io, tile_soff(b, r, a.par_t));
+        const float o = INVERSE ? __fdividef(v - T[b][r], nf_exp(s)) : v * nf_exp(s) + T[b][r];
+        if (live) tile_store(io, tile_soff(b, r, a.par_t), o);  // rows >= c fall outside the descriptor
+        lsum += s;
+      }
+    lsum += __shfl_xor(lsum, 32);
+    if (hi == 0 && valid) {
+      const float base = accumulate ? ladj[j] : 0.f;
+      ladj[j] = INVERSE ? base - lsum : base + lsum;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// reverse pass, one net per launch (PHASE_S = false: t net, true: s net); see nf_coupling.hip
+// for the two-phase algebra.  Stash tensors: [tile][feature][32 samples].
+// ------------------------------------------------------------------------------------
+struct WideStash {
+  float *a1, *a2, *d1, *d2, *d3;
+};
+
+struct StashIO {
+  __amdgpu_buffer_rsrc_t rs;
+  int voff;
+};
+__device__ __forceinline__ StashIO make_stash_io(float *t, long tile, int F, int l31, int hi) {
+  StashIO s;
+  s.rs = __builtin_amdgcn_make_buffer_rsrc(t + tile * F * NF_TILE, 0, F * NF_TILE * 4, 0x00020000);
+  s.voff = l31 * 4 + hi * (4 * NF_TILE * 4);
+  return s;
+}
+template <int NB>
+__device__ __forceinline__ void stash_store(const StashIO &s, const f32x16 (&v)[NB]) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float val = v[b][r];  // (bit_cast straight from the vector-element expression reads element 0)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), s.rs, s.voff,
+                                            (b * 32 + (r & 3) + 8 * (r >> 2)) * (NF_TILE * 4), 0);
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ void wide_sign_masks(const f32x16 (&v)[NB], unsigned (&m)[NB]) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    unsigned bits = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bits |= (__float_as_int(v[b][r]) < 0 ? 1u : 0u) << r;
+    // pin the mask HERE: left alone, hipcc sinks this computation to the mask's first use and keeps
+    // all 128 activations alive (in scratch) until then
+    asm volatile("" : "+v"(bits));
+    m[b] = bits;
+  }
+}
+
+template <class G, bool PHASE_S>
+__global__ __launch_bounds__(256, 1) void k_wide_bwd(WideArgs a, float *__restrict__ y, float *__restrict__ ybar,
+                                                     const float *__restrict__ lbar, float lbar_const, WideStash st) {
+  using W = Wide<G>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *cb = lds;
+  float *bias = lds + 2 * W::CHBUF;
+  const float *imgp = PHASE_S ? a.img_s : a.img_t;
+  const wide_img_t img = make_img(imgp, G::SIZE);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int par_c = 1 - a.par_t;
+  const long ntiles = (a.N + NF_TILE - 1) / NF_TILE;
+  const long ngroups = (ntiles + 3) / 4;
+
+  issue_chunk(img, G::W1, W::CF1, cb, wave, lane);
+  stage_biases<G>(bias, imgp, tid);
+  __syncthreads();
+  int buf = 0;
+
+  for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const long tile = grp * 4 + wave;
+    const bool live = tile < ntiles;
+    const long tl = live ? tile : 0;
+    const long j = tl * NF_TILE + l31;
+    const bool valid = live && j < a.N;
+    const bool more = grp + gridDim.x < ngroups;
+    const TileIO yio = make_tile_io(y, tl, a.d, l31, hi);
+    const TileIO gio = make_tile_io(ybar, tl, a.d, l31, hi);
+    // a dead wave (tile >= ntiles) keeps the barriers company; its stash descriptors are empty
+    const StashIO sa1 = make_stash_io(st.a1, tl, live ? 32 * G::H1B : 0, l31, hi);
+    const StashIO sa2 = make_stash_io(st.a2, tl, live ? 32 * G::H2B : 0, l31, hi);
+    const StashIO sd1 = make_stash_io(st.d1, tl, live ? 32 * G::H1B : 0, l31, hi);
+    const StashIO sd2 = make_stash_io(st.d2, tl, live ? 32 * G::H2B : 0, l31, hi);
+    const StashIO sd3 = make_stash_io(st.d3, tl, live ? 32 * G::CB : 0, l31, hi);
+
+    unsigned m1[G::H1B], m2[G::H2B];
+    f32x16 d3[G::CB];
+    {
+      f32x16 xb[G::MB];
+#pragma unroll
+      for (int b = 0; b < G::MB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = tile_load(yio, tile_soff(b, r, par_c));
+          xb[b][r] = valid ? v : 0.f;
+        }
+      wide_net_fwd<G>(
+          img, bias, cb, buf, img, G::W3, W::CF3, xb, d3, wave, lane,
+          [&](f32x16(&a1)[G::H1B]) {
+            wide_sign_masks<G::H1B>(a1, m1);
+            stash_store<G::H1B>(sa1, a1);
+          },
+          [&](f32x16(&a2)[G::H2B]) {
+            wide_sign_masks<G::H2B>(a2, m2);
+            stash_store<G::H2B>(sa2, a2);
+          });
+    }
+    // element-wise stage (same algebra as bwd_tile in nf_coupling.hip)
+    const float lb = valid ? (lbar ? lbar[j] : lbar_const) : 0.f;
+#pragma unroll
+    for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int p = b * 32 + nf_row(r, hi);
+        const bool ok = (p < a.c) && valid;
+        const float yv = tile_load(yio, tile_soff(b, r, a.par_t));
+        const float gv = tile_load(gio, tile_soff(b, r, a.par_t));
+        if (!PHASE_S) {
+          if (live) tile_store(yio, tile_soff(b, r, a.par_t), yv - d3[b][r]);  // u = x1 * exp(S)
+          d3[b][r] = ok ? gv : 0.f;
+        } else {
+          const float s = nf_tanh(d3[b][r]);
+          const float es = nf_exp(s);
+          if (live) {
+            tile_store(yio, tile_soff(b, r, a.par_t), __fdividef(yv, es));  // x1 = u * exp(-s)
+            tile_store(gio, tile_soff(b, r, a.par_t), gv * es);             // x1bar
+          }
+          d3[b][r] = ok ? (gv * yv + lb) * (1.f - s * s) : 0.f;
+        }
+      }
+    stash_store<G::CB>(sd3, d3);
+
+    // ---- dX chain: W3^T, W2^T, W1^T, one output block per chunk
+    f32x16 d2[G::H2B];
+#pragma unroll
+    for (int ib = 0; ib < G::H2B; ++ib) {
+      if (ib + 1 < G::H2B)
+        issue_chunk(img, G::W3 + (ib + 1) * W::CF3, W::CF3, cb + (buf ^ 1) * W::CHBUF, wave, lane);
+      else
+        issue_chunk(img, G::W2, W::CF2, cb + (buf ^ 1) * W::CHBUF, wave, lane);
+      wide_bwdx_chunk<G::CB, G::S3>(cb + buf * W::CHBUF, d3, d2[ib], l31, hi);
+      __syncthreads();
+      buf ^= 1;
+    }
+#pragma unroll
+    for (int b = 0; b < G::H2B; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) d2[b][r] *= ((m2[b] >> r) & 1u) ? 0.01f : 1.f;
+    stash_store<G::H2B>(sd2, d2);
+    f32x16 d1[G::H1B];
+#pragma unroll
+    for (int ib = 0; ib < G::H1B; ++ib) {
+      if (ib + 1 < G::H1B)
+        issue_chunk(img, G::W2 + (ib + 1) * W::CF2, W::CF2, cb + (buf ^ 1) * W::CHBUF, wave, lane);
+      else
+        issue_chunk(img, G::W1, W::CF1, cb + (buf ^ 1) * W::CHBUF, wave, lane);
+      wide_bwdx_chunk<G::H2B, G::S2>(cb + buf * W::CHBUF, d2, d1[ib], l31, hi);
+      __syncthreads();
+      buf ^= 1;
+    }
+#pragma unroll
+    for (int b = 0; b < G::H1B; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) d1[b][r] *= ((m1[b] >> r) & 1u) ? 0.01f : 1.f;
+    stash_store<G::H1B>(sd1, d1);
+#pragma unroll
+    for (int ib = 0; ib < G::MB; ++ib) {
+      if (ib + 1 < G::MB)
+        issue_chunk(img, G::W1 + (ib + 1) * W::CF1, W::CF1, cb + (buf ^ 1) * W::CHBUF, wave, lane);
+      else if (more)
+        issue_chunk(img, G::W1, W::CF1, cb + (buf ^ 1) * W::CHBUF, wave, lane);
+      f32x16 g2;
+      wide_bwdx_chunk<G::H1B, G::S1>(cb + buf * W::CHBUF, d1, g2, l31, hi);
+      if (live) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float gold = tile_load(gio, tile_soff(ib, r, par_c));
+          tile_store(gio, tile_soff(ib, r, par_c), gold + g2[r]);
+        }
+      }
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// weight gradients from the stash: split-K GEMM  dW^T[i][o] = sum_samples A[i][j] D[o][j]
+// ------------------------------------------------------------------------------------
+// A workgroup (4 waves) owns one JOB = a block of the weight image and one slice of the sample
+// tiles (ks of KS).  Per sample tile it brings 384 stash rows ([feature][32 samples]) into LDS with
+// row stride 33 -- the transposition the MFMA operands need (lane <-> feature, k <-> sample) -- and
+// every wave accumulates a 4 x 2 arrangement of 32x32 blocks.  Wave grid WI x WO (WI*WO = 4): the
+// job covers 128*WI rows of A and 64*WO rows of D.
+struct DwJob {
+  const float *A;     // A-operand tensor
+  const float *D;     // delta tensor
+  long a_tile_stride; // floats between tiles of A
+  int a_extent;       // bytes of one A tile (buffer bound: rows past it read 0)
+  int a_rstride;      // row r lives at ((a_row0 + r) * a_rstride + a_roff) * 128 bytes
+  int a_roff;
+  int a_row0;
+  long d_tile_stride;
+  int d_extent;
+  int d_row0;
+  int cfg;            // 0: WI=1,WO=4   1: WI=2,WO=2
+  int w_off, w_stride;// image offset / row stride of this layer's weight block
+  int b_off;          // image offset of the bias block, or -1 if another job owns it
+  int ib_tot, ob_tot; // layer size in blocks (writes beyond are dropped)
+};
+#define NF_WIDE_MAXJOBS 12
+struct DwArgs {
+  DwJob job[NF_WIDE_MAXJOBS];
+  int njobs, ksplit;
+  long ntiles;
+  long slab_stride;  // floats between ksplit partials
+};
+
+#define DW_TS 33
+#define DW_ROWS 384
+
+template <int WI, int WO>
+__device__ __forceinline__ void dw_job(const DwJob &jb, const DwArgs &a, int ks, float *__restrict__ out, float *lds) {
+  constexpr int AROWS = 128 * WI;
+  constexpr int NLD = DW_ROWS * 8 / 256;  // float4 loads per thread per tile = 12
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wi = wave / WO, wo = wave % WO;
+  const int lrow = tid >> 3, part = tid & 7;
+
+  f32x16 acc[4][2];
+  float bsum[2] = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][o][r] = 0.f;
+
+  float4 stg[NLD];
+  auto load_tile = [&](long tile) {
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(jb.A) + tile * jb.a_tile_stride, 0, jb.a_extent, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(jb.D) + tile * jb.d_tile_stride, 0, jb.d_extent, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int row = lrow + 32 * k;
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      u32x4 v;
+      if (32 * k < AROWS)
+        v = __builtin_amdgcn_raw_buffer_load_b128(ra, ((jb.a_row0 + row) * jb.a_rstride + jb.a_roff) * 128 + part * 16, 0, 0);
+      else
+        v = __builtin_amdgcn_raw_buffer_load_b128(rd, (jb.d_row0 + row - AROWS) * 128 + part * 16, 0, 0);
+      const unsigned v0 = v.x, v1 = v.y, v2 = v.z, v3 = v.w;  // (bit_cast of a vector-element expression reads element 0)
+      stg[k] = make_float4(__builtin_bit_cast(float, v0), __builtin_bit_cast(float, v1), __builtin_bit_cast(float, v2),
+                           __builtin_bit_cast(float, v3));
+    }
+  };
+  auto put_tile = [&](float *dst) {
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      float *p = dst + (lrow + 32 * k) * DW_TS + part * 4;
+      p[0] = stg[k].x; p[1] = stg[k].y; p[2] = stg[k].z; p[3] = stg[k].w;
+    }
+  };
+
+  long tile = ks;
+  if (tile < a.ntiles) {
+    load_tile(tile);
+    put_tile(lds);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (; tile < a.ntiles; tile += a.ksplit) {
+    const bool has_next = tile + a.ksplit < a.ntiles;
+    if (has_next) load_tile(tile + a.ksplit);
+    const float *cur = lds + buf * (DW_ROWS * DW_TS);
+    const float *pa = cur + (wi * 128 + l31) * DW_TS + hi;
+    const float *pd = cur + (AROWS + wo * 64 + l31) * DW_TS + hi;
+    float an[2][4], dn[2][2], ac[2][4], dc[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int ib = 0; ib < 4; ++ib) an[u][ib] = pa[ib * 32 * DW_TS + 2 * u];
+#pragma unroll
+      for (int ob = 0; ob < 2; ++ob) dn[u][ob] = pd[ob * 32 * DW_TS + 2 * u];
+    }
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) ac[u][ib] = an[u][ib];
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) dc[u][ob] = dn[u][ob];
+      }
+      if (g + 1 < 8) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+          for (int ib = 0; ib < 4; ++ib) an[u][ib] = pa[ib * 32 * DW_TS + 2 * ((g + 1) * 2 + u)];
+#pragma unroll
+          for (int ob = 0; ob < 2; ++ob) dn[u][ob] = pd[ob * 32 * DW_TS + 2 * ((g + 1) * 2 + u)];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) bsum[ob] += dc[u][ob];
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+          for (int ob = 0; ob < 2; ++ob)
+            acc[ib][ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u][ib], dc[u][ob], acc[ib][ob], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (has_next) put_tile(lds + (buf ^ 1) * (DW_ROWS * DW_TS));
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // partial result in image layout
+#pragma unroll
+  for (int ib = 0; ib < 4; ++ib) {
+    const int iblk = jb.a_row0 / 32 + wi * 4 + ib;
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob) {
+      const int oblk = jb.d_row0 / 32 + wo * 2 + ob;
+      if (iblk < jb.ib_tot && oblk < jb.ob_tot) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          out[jb.w_off + (iblk * 32 + nf_row(r, hi)) * jb.w_stride + oblk * 32 + l31] = acc[ib][ob][r];
+      }
+    }
+  }
+  if (jb.b_off >= 0 && wi == 0) {
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob) {
+      const int oblk = jb.d_row0 / 32 + wo * 2 + ob;
+      const float v = bsum[ob] + __shfl_xor(bsum[ob], 32);
+      if (hi == 0 && oblk < jb.ob_tot) out[jb.b_off + oblk * 32 + l31] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void k_wide_dw(DwArgs a, float *__restrict__ slab) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int j = blockIdx.x % a.njobs, ks = blockIdx.x / a.njobs;
+  const DwJob &jb = a.job[j];
+  float *out = slab + (long)ks * a.slab_stride;
+  if (jb.cfg == 0)
+    dw_job<1, 4>(jb, a, ks, out, lds);
+  else
+    dw_job<2, 2>(jb, a, ks, out, lds);
+}
+
+// g[theta index] = sum over split-K partials of ONE net's image
+template <class G>
+__global__ __launch_bounds__(256) void k_wide_reduce(NetDims nd, const float *__restrict__ slab, int nslab, long slab_stride,
+                                                     float *__restrict__ g) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= G::B3 + 32 * G::CB) return;
+  const long ti = image_theta_index<G>(nd, e);
+  if (ti < 0) return;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int s = 0;
+  for (; s + 3 < nslab; s += 4) {
+    a0 += slab[(long)s * slab_stride + e];
+    a1 += slab[(long)(s + 1) * slab_stride + e];
+    a2 += slab[(long)(s + 2) * slab_stride + e];
+    a3 += slab[(long)(s + 3) * slab_stride + e];
+  }
+  for (; s < nslab; ++s) a0 += slab[(long)s * slab_stride + e];
+  g[ti] = (a0 + a1) + (a2 + a3);
+}
+
+// ------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------
+static inline int wblocks32(int n) { return (n + 31) / 32; }
+
+bool nf_wide_supported(const nf_flow_desc *desc) {
+  if (desc->kind != NF_KIND_REALNVP || desc->n_hidden != 2 || desc->dtype != NF_DTYPE_F32) return false;
+  const int c = (desc->d + 1) / 2;
+  return wblocks32(c) <= GW::MB && wblocks32(desc->hdims[0]) <= GW::H1B && wblocks32(desc->hdims[1]) <= GW::H2B;
+}
+
+// packed images of every net: [coupling][s|t][GW::SIZE] in ctx->wimg, plus DMA slack at the end
+int nf_wide_pack(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta) {
+  if (!nf_wide_supported(desc)) return NF_ERR_UNSUPPORTED;
+  const int nc = 2 * desc->nlayers;
+  const size_t bytes = (size_t)nc * 2 * GW::SIZE * sizeof(float) + 4096;
+  if (bytes > ctx->wimg_bytes) {
+    NF_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->wimg) NF_HIP(hipFree(ctx->wimg));
+    ctx->wimg = nullptr;
+    ctx->wimg_bytes = 0;
+    NF_HIP(hipMalloc(&ctx->wimg, bytes));
+    ctx->wimg_bytes = bytes;
+  }
+  const PackArgs p = make_pack_args(desc);
+  const long total = (long)nc * 2 * GW::SIZE;
+  ProfScope ps(ctx, "pack_weights");
+  hipLaunchKernelGGL((k_pack_net_images<GW>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, p, theta,
+                     (float *)ctx->wimg);
+  return (int)hipGetLastError();
+}
+
+static WideArgs make_wide_args(nf_ctx *ctx, const nf_flow_desc *desc, int k, long N) {
+  const CouplingInfo ci = nf_coupling_info(desc, k);
+  WideArgs a;
+  a.img_s = (const float *)ctx->wimg + (size_t)(2 * k) * GW::SIZE;
+  a.img_t = a.img_s + GW::SIZE;
+  a.d = desc->d; a.c = ci.c; a.m = ci.m; a.par_t = ci.par_t; a.N = N;
+  return a;
+}
+
+static long wide_groups(long N) { return ((N + NF_TILE - 1) / NF_TILE + 3) / 4; }
+
+int nf_wide_apply(nf_ctx *ctx, const nf_flow_desc *desc, int k, bool inverse, float *xt, long N, float *ladj,
+                  int accumulate) {
+  if (!ctx->wimg) return NF_ERR_UNSUPPORTED;
+  const WideArgs a = make_wide_args(ctx, desc, k, N);
+  const size_t lds = Wide<GW>::LDS_APPLY;
+  static bool attr_done = false;
+  if (!attr_done) {
+    NF_HIP(hipFuncSetAttribute((const void *)k_wide_apply<GW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NF_HIP(hipFuncSetAttribute((const void *)k_wide_apply<GW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  long grid = wide_groups(N);
+  if (grid > ctx->num_cu) grid = ctx->num_cu;
+  if (grid < 1) grid = 1;
+  ProfScope ps(ctx, "wide_apply");
+  if (inverse)
+    hipLaunchKernelGGL((k_wide_apply<GW, true>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, xt, ladj, accumulate);
+  else
+    hipLaunchKernelGGL((k_wide_apply<GW, false>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, xt, ladj, accumulate);
+  return (int)hipGetLastError();
+}
+
+// split-K factor of the weight-gradient GEMM and its job list (one net)
+static int wide_ksplit(nf_ctx *ctx, long ntiles, int njobs) {
+  long ks = (ctx->num_cu + njobs - 1) / njobs;  // one workgroup per CU
+  if (ks > ntiles) ks = ntiles;
+  if (ks < 1) ks = 1;
+  return (int)ks;
+}
+
+static int build_jobs(DwArgs *args, const float *x2src, long x2_tile_stride, int x2_extent, int x2_roff,
+                      const WideStash &st) {
+  using G = GW;
+  int n = 0;
+  auto add_layer = [&](const float *A, long ats, int aext, int arstride, int aroff, int IB, const float *D, int OB,
+                       int w_off, int w_stride, int b_off) {
+    int cfg, imac, omac;  // macro tile in blocks
+    if (OB >= 8) { cfg = 0; imac = 4; omac = 8; }
+    else { cfg = 1; imac = 8; omac = 4; }
+    for (int i0 = 0; i0 < IB; i0 += imac)
+      for (int o0 = 0; o0 < OB; o0 += omac) {
+        DwJob &j = args->job[n++];
+        j.A = A; j.D = D;
+        j.a_tile_stride = ats; j.a_extent = aext; j.a_rstride = arstride; j.a_roff = aroff; j.a_row0 = 32 * i0;
+        j.d_tile_stride = (long)OB * 32 * NF_TILE; j.d_extent = OB * 32 * NF_TILE * 4; j.d_row0 = 32 * o0;
+        j.cfg = cfg; j.w_off = w_off; j.w_stride = w_stride; j.b_off = (i0 == 0) ? b_off : -1;
+        j.ib_tot = IB; j.ob_tot = OB;
+      }
+  };
+  add_layer(x2src, x2_tile_stride, x2_extent, 2, x2_roff, G::MB, st.d1, G::H1B, G::W1, G::S1, G::B1);
+  add_layer(st.a1, (long)G::H1B * 32 * NF_TILE, G::H1B * 32 * NF_TILE * 4, 1, 0, G::H1B, st.d2, G::H2B, G::W2, G::S2, G::B2);
+  add_layer(st.a2, (long)G::H2B * 32 * NF_TILE, G::H2B * 32 * NF_TILE * 4, 1, 0, G::H2B, st.d3, G::CB, G::W3, G::S3, G::B3);
+  args->njobs = n;
+  return n;
+}
+
+static int wide_njobs() {
+  DwArgs tmp;
+  WideStash st = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  return build_jobs(&tmp, nullptr, 0, 0, 0, st);
+}
+
+// floats of device workspace the reverse pass needs for a batch of N
+size_t nf_wide_bwd_ws_floats(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
+  (void)desc;
+  const long ntiles = (N + NF_TILE - 1) / NF_TILE;
+  const size_t stash = (size_t)ntiles * NF_TILE * 32 * (2 * GW::H1B + 2 * GW::H2B + GW::CB);
+  const int ks = wide_ksplit(ctx, ntiles, wide_njobs());
+  return stash + (size_t)ks * GW::SIZE + 1024;
+}
+
+// reverse pass over the whole chain; state/gbar as in realnvp_bwd (nf_api.hip)
+int nf_wide_bwd(nf_ctx *ctx, const nf_flow_desc *desc, float *state, float *gbar, const float *lbar, float lbar_const,
+                long N, float *ws, float *g_out) {
+  if (!ctx->wimg) return NF_ERR_UNSUPPORTED;
+  using G = GW;
+  const long ntiles = (N + NF_TILE - 1) / NF_TILE;
+  const size_t per = (size_t)ntiles * NF_TILE * 32;
+  WideStash st;
+  float *p = ws;
+  st.a1 = p; p += per * G::H1B;
+  st.a2 = p; p += per * G::H2B;
+  st.d1 = p; p += per * G::H1B;
+  st.d2 = p; p += per * G::H2B;
+  st.d3 = p; p += per * G::CB;
+  float *slab = p;
+  const int njobs = wide_njobs();
+  const int ks = wide_ksplit(ctx, ntiles, njobs);
+
+  static bool attr_done = false;
+  const size_t lds_bwd = Wide<G>::LDS_BWD;
+  const size_t lds_dw = (size_t)2 * DW_ROWS * DW_TS * sizeof(float);
+  if (!attr_done) {
+    NF_HIP(hipFuncSetAttribute((const void *)k_wide_bwd<G, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bwd));
+    NF_HIP(hipFuncSetAttribute((const void *)k_wide_bwd<G, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bwd));
+    NF_HIP(hipFuncSetAttribute((const void *)k_wide_dw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dw));
+    attr_done = true;
+  }
+  long grid = wide_groups(N);
+  if (grid > ctx->num_cu) grid = ctx->num_cu;
+  if (grid < 1) grid = 1;
+  const int nc = 2 * desc->nlayers;
+  const int h1 = desc->hdims[0], h2 = desc->hdims[1];
+  for (int k = 0; k < nc; ++k) {  // flat order = reverse of execution order
+    const WideArgs a = make_wide_args(ctx, desc, k, N);
+    const CouplingInfo ci = nf_coupling_info(desc, k);
+    for (int phase = 0; phase < 2; ++phase) {  // 0: t net, 1: s net
+      {
+        ProfScope ps(ctx, "wide_bwd");
+        if (phase == 0)
+          hipLaunchKernelGGL((k_wide_bwd<G, false>), dim3((unsigned)grid), dim3(256), lds_bwd, ctx->stream, a, state, gbar, lbar, lbar_const, st);
+        else
+          hipLaunchKernelGGL((k_wide_bwd<G, true>), dim3((unsigned)grid), dim3(256), lds_bwd, ctx->stream, a, state, gbar, lbar, lbar_const, st);
+        NF_HIP(hipGetLastError());
+      }
+      DwArgs da;
+      build_jobs(&da, state, (long)desc->d * NF_TILE, desc->d * NF_TILE * 4, 1 - ci.par_t, st);
+      da.ksplit = ks;
+      da.ntiles = ntiles;
+      da.slab_stride = G::SIZE;
+      {
+        ProfScope ps(ctx, "wide_dw");
+        hipLaunchKernelGGL(k_wide_dw, dim3((unsigned)(da.njobs * ks)), dim3(256), lds_dw, ctx->stream, da, slab);
+        NF_HIP(hipGetLastError());
+      }
+      long off = ci.theta_off;
+      if (phase == 0) off += net_param_count(ci.m, h1, h2, ci.c);  // t net follows the s net in theta
+      const NetDims nd = make_net_dims(off, ci.m, h1, h2, ci.c);
+      {
+        ProfScope ps(ctx, "reduce_slabs");
+        constexpr int NE = G::B3 + 32 * G::CB;
+        hipLaunchKernelGGL((k_wide_reduce<G>), dim3((NE + 255) / 256), dim3(256), 0, ctx->stream, nd, slab, ks, (long)G::SIZE, g_out);
+        NF_HIP(hipGetLastError());
+      }
+    }
+  }
+  return NF_OK;
+}

@@ -273,9 +273,12 @@ def test_fused_elbo_step_matches_split_calls(nf):
 
 def test_unsupported_shapes_fail_loudly(nf):
     """Shapes the library does not build are reported (NF_ERR_UNSUPPORTED), never approximated."""
-    big = nf.realnvp(nf.MvNormal(256), [256, 256], 1, paramtype=torch.float32)
+    big = nf.realnvp(nf.MvNormal(600), [32, 32], 1, paramtype=torch.float32)  # d > 256
     with pytest.raises(nf.NFHipError, match="not built"):
-        nf.with_logabsdet_jacobian(big.transform, torch.zeros(256, 4, device="cuda").t().contiguous().t())
+        nf.with_logabsdet_jacobian(big.transform, torch.zeros(4, 600, device="cuda").t())
+    big = nf.realnvp(nf.MvNormal(16), [512, 512], 1, paramtype=torch.float32)  # hidden > 256
+    with pytest.raises(nf.NFHipError, match="not built"):
+        nf.with_logabsdet_jacobian(big.transform, torch.zeros(4, 16, device="cuda").t())
     f64 = nf.realnvp(nf.MvNormal(4), [8, 8], 1, paramtype=torch.float64)
     with pytest.raises(nf.NFHipError, match="not built"):
         nf.with_logabsdet_jacobian(f64.transform, torch.zeros(4, 2, dtype=torch.float64, device="cuda"))
@@ -300,4 +303,58 @@ def test_nsf_properties_cfg3_shape(nf):
     la, ga = nf.value_and_gradient(nf.elbo_batch, flow, tgt, xs[:, :1000], n_global=4096)
     lb2, gb = nf.value_and_gradient(nf.elbo_batch, flow, tgt, xs[:, 1000:], n_global=4096)
     assert la + lb2 == pytest.approx(l, rel=1e-5)
+    assert float((ga + gb - g).abs().max()) <= 1e-4 * float(g.abs().max())
+
+
+@pytest.mark.parametrize("d,hd,nl,n", [(256, (256, 256), 1, 200), (100, (96, 130), 1, 77), (129, (40, 256), 2, 33)],
+                         ids=["cfg4_d256_h256", "d100_h96_130", "d129_h40_256"])
+def test_wide_realnvp_matches_oracle(nf, d, hd, nl, n):
+    """RealNVP shapes whose conditioner nets do not fit in LDS (BASELINE cfg 4: d=256, h=256) run on the
+    weight-streaming kernels; same parity bar as the resident path (forward, inverse, ELBO, gradient)."""
+    spec = o.FlowSpec("realnvp", d, nl, hd)
+    rng = np.random.default_rng(d + n)
+    th = (o.init_params(spec, rng) + 0.02 * rng.standard_normal(o.param_count(spec))).astype(np.float32)
+    flow = nf.Flow("realnvp", nf.MvNormal(d), nl, hd, dtype=torch.float32, device="cuda",
+                   theta=torch.tensor(th, device="cuda"))
+    xs = rng.standard_normal((d, n)).astype(np.float32)
+    th64, xs64 = th.astype(np.float64), xs.astype(np.float64)
+    ys_ref, l_ref = o.flow_fwd(spec, th64, xs64)
+    ys, ladj = nf.with_logabsdet_jacobian(flow.transform, cm(xs, torch.float32))
+    assert approx(ys.cpu().numpy(), ys_ref, 2e-5) and approx(ladj.cpu().numpy(), l_ref, 2e-5)
+    xr, lb = nf.with_logabsdet_jacobian(nf.inverse(flow.transform), ys)
+    assert approx(xr.cpu().numpy(), xs64, 2e-5) and approx(lb.cpu().numpy(), -l_ref, 2e-5)
+    # single couplings compose to the chain
+    z, tot = cm(xs, torch.float32), torch.zeros(n, device="cuda")
+    for k in reversed(range(2 * nl)):
+        z, lj = nf.with_logabsdet_jacobian(nf.layer(flow, k), z)
+        tot = tot + lj
+    assert approx(z.cpu().numpy(), ys_ref, 2e-5) and approx(tot.cpu().numpy(), l_ref, 2e-5)
+    mu, var = rng.standard_normal(d).astype(np.float32), (rng.uniform(size=d) + 0.5).astype(np.float32)
+    tgt = nf.DiagGaussTarget(torch.tensor(mu, device="cuda"), torch.tensor(var, device="cuda"))
+    loss, g = nf.value_and_gradient(nf.elbo_batch, flow, tgt, cm(xs, torch.float32))
+    lr, gr = o.neg_elbo_value_and_grad(spec, th64, ("diaggauss", mu.astype(np.float64), var.astype(np.float64)), xs64)
+    assert loss == pytest.approx(lr, rel=2e-5)
+    assert np.abs(g.cpu().numpy() - gr).max() <= 2e-4 * np.abs(gr).max()
+    ll = nf.loglikelihood(None, flow, ys)
+    ll_ref = float(np.mean(o.std_normal_logpdf(xs64) - l_ref))
+    assert ll == pytest.approx(ll_ref, rel=2e-4, abs=2e-4)
+
+
+def test_wide_cfg4_shard_properties(nf):
+    """BASELINE cfg 4 geometry (d=256, hidden [256,256]) at one GPU's shard size of the 8-GPU job
+    (32768 samples), with 2 of the 16 couplings to bound the run time: round trip, and the gradient
+    of the whole shard equals the sum over two sub-shards (what the all-reduce relies on)."""
+    d, n = 256, 32768
+    flow = nf.realnvp(nf.MvNormal(d), [256, 256], 1, paramtype=torch.float32, seed=4)
+    xs = nf.device_specific_rand(nf.PhiloxRNG(123), flow.dist, n)
+    ys, lf = nf.with_logabsdet_jacobian(flow.transform, xs)
+    xr, lb = nf.with_logabsdet_jacobian(nf.inverse(flow.transform), ys)
+    assert float((xr - xs).norm() / xs.norm()) < 2e-5
+    assert float((lf + lb).norm() / lf.norm().clamp_min(1e-6)) < 2e-5
+    tgt = nf.DiagGaussTarget(torch.randn(d, device="cuda"), torch.rand(d, device="cuda") + 0.5)
+    loss, g = nf.value_and_gradient(nf.elbo_batch, flow, tgt, xs)
+    assert np.isfinite(loss) and bool(torch.isfinite(g).all())
+    la, ga = nf.value_and_gradient(nf.elbo_batch, flow, tgt, xs[:, :10000], n_global=n)
+    lb2, gb = nf.value_and_gradient(nf.elbo_batch, flow, tgt, xs[:, 10000:], n_global=n)
+    assert la + lb2 == pytest.approx(loss, rel=1e-5)
     assert float((ga + gb - g).abs().max()) <= 1e-4 * float(g.abs().max())
