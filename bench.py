@@ -38,6 +38,26 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dens
 MACS_NET = 32 * 64 + 64 * 64 + 64 * 32
 FLOPS_BWD_PER_SAMPLE_PER_COUPLING = 2 * (2 * MACS_NET) * 2  # 2 nets x (dX + dW) x 2 flop/MAC = 65 536
 FLOPS_STEP_PER_SAMPLE = 786432
+WORKLOAD_TEXT = ("reverse-KL ELBO step: RealNVP d=64, 8 affine couplings, conditioner 32-64-64-32 "
+                 "(hdims [64,64]), diag-Gaussian target, Philox base draws, Adam")
+DOMINANT = (b"affine_bwd", "k_affine_bwd (one coupling reverse pass: recompute + dX + dW)")
+KERNEL_NAMES = (b"base_sample", b"pack_weights", b"affine_chain", b"target", b"affine_bwd", b"reduce_slabs", b"adam")
+
+
+def select_cfg4(world: int):
+    """BASELINE.json configs[3] (--workload cfg4; NOT the default bench line): RealNVP d=256, 16 couplings,
+    hidden [256,256], 262 144 samples in total, sharded over the ranks (strong scaling).  Dominant kernel:
+    k_wide_bwd, one launch = recompute + dX chain of ONE net (its dW GEMM is k_wide_dw)."""
+    global D, HDIMS, NLAYERS, BATCH, MACS_NET, FLOPS_BWD_PER_SAMPLE_PER_COUPLING, FLOPS_STEP_PER_SAMPLE
+    global WORKLOAD_TEXT, DOMINANT, KERNEL_NAMES
+    D, HDIMS, NLAYERS, BATCH = 256, (256, 256), 8, 262144 // world
+    MACS_NET = 128 * 256 + 256 * 256 + 256 * 128
+    FLOPS_BWD_PER_SAMPLE_PER_COUPLING = 2 * MACS_NET  # per launch: dX of one net
+    FLOPS_STEP_PER_SAMPLE = 16 * 2 * 3 * 2 * MACS_NET  # 16 couplings x 2 nets x (fwd + dX + dW)
+    WORKLOAD_TEXT = ("reverse-KL ELBO step: RealNVP d=256, 16 affine couplings, conditioner 128-256-256-128 "
+                     "(hdims [256,256]), diag-Gaussian target, Philox base draws, Adam; 262144 samples in total")
+    DOMINANT = (b"wide_bwd", "k_wide_bwd (reverse pass of one conditioner net: recompute + dX chain; dW is k_wide_dw)")
+    KERNEL_NAMES = (b"base_sample", b"pack_weights", b"wide_apply", b"target", b"wide_bwd", b"wide_dw", b"reduce_slabs", b"adam")
 
 
 def cpu_baseline(seconds_budget: float = 12.0):
@@ -85,7 +105,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=BATCH, help="samples per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="samples per GPU per step")
+    ap.add_argument("--workload", choices=("cfg2", "cfg4"), default="cfg2",
+                    help="cfg2 = the headline line (default); cfg4 = d=256 / 16 couplings / h=256, 262144 samples sharded")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket kernels with HIP events in the timed region (roofline object is then empty)")
@@ -108,6 +130,10 @@ def main():
         local_rank = 0
     dev = torch.device("cuda", local_rank)
 
+    if args.workload == "cfg4":
+        select_cfg4(world)
+    if args.batch is None:
+        args.batch = BATCH
     nf = load_package()
     lib = nf.load_library()
     n_local, n_global = args.batch, args.batch * world
@@ -157,7 +183,7 @@ def main():
     assert np.isfinite(loss) and np.isfinite(float(gnorm)), "non-finite loss / gradient norm"
 
     avg_ms, cnt = C.c_double(0.0), C.c_int64(0)
-    nf._lib.check(lib.nf_prof_read(ctx.ptr, b"affine_bwd", C.byref(avg_ms), C.byref(cnt)))
+    nf._lib.check(lib.nf_prof_read(ctx.ptr, DOMINANT[0], C.byref(avg_ms), C.byref(cnt)))
     # per-kernel breakdown: a few extra, UNTIMED steps with every kernel bracketed
     kernel_ms = {}
     nbreak = 5
@@ -165,7 +191,7 @@ def main():
     for i in range(nbreak):
         step(args.warmup + args.steps + i)
     torch.cuda.synchronize(dev)
-    for name in (b"base_sample", b"pack_weights", b"affine_chain", b"target", b"affine_bwd", b"reduce_slabs", b"adam"):
+    for name in KERNEL_NAMES:
         a, c = C.c_double(0.0), C.c_int64(0)
         lib.nf_prof_read(ctx.ptr, name, C.byref(a), C.byref(c))
         kernel_ms[name.decode()] = {"avg_ms": round(a.value, 5), "launches_per_step": c.value / nbreak}
@@ -184,13 +210,12 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if args.workload == "cfg2" else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "reverse-KL ELBO step: RealNVP d=64, 8 affine couplings, conditioner 32-64-64-32 "
-                            "(hdims [64,64]), diag-Gaussian target, Philox base draws, Adam",
+                "workload": WORKLOAD_TEXT,
                 "batch_per_gpu": n_local,
                 "global_batch": n_global,
                 "params": P,
@@ -198,7 +223,7 @@ def main():
                 "final_loss": loss,
             },
             "roofline": {
-                "kernel": "k_affine_bwd (one coupling reverse pass: recompute + dX + dW)",
+                "kernel": DOMINANT[1],
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": PEAK_F32_MFMA_TFLOPS,
@@ -212,7 +237,7 @@ def main():
             },
             "kernels": kernel_ms,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "cfg2":
             rec["cpu_baseline"] = cpu_baseline()
             rec["gpu_over_cpu"] = value / rec["cpu_baseline"]["value"]
         print(json.dumps(rec))

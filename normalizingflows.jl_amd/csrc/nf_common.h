@@ -68,13 +68,15 @@ struct Carver {
 inline size_t carve_bytes(size_t nbytes) { return ((nbytes + 255) / 256) * 256; }
 
 // profiling bracket: records a pair of pooled HIP events on ctx->stream around a launch.
-// prof_mode 1 brackets only the dominant kernel ("affine_bwd" / "rqs_bwd"), 2 brackets all.
+// prof_mode 1 brackets only the dominant kernel ("affine_bwd" / "rqs_bwd" / "wide_bwd"), 2 brackets all.
 struct ProfScope {
   nf_ctx *ctx;
   hipEvent_t b = nullptr;
   ProfScope(nf_ctx *c, const char *name) : ctx(c) {
     if (!ctx->prof_mode) return;
-    if (ctx->prof_mode == 1 && std::strcmp(name, "affine_bwd") != 0 && std::strcmp(name, "rqs_bwd") != 0) return;
+    if (ctx->prof_mode == 1 && std::strcmp(name, "affine_bwd") != 0 && std::strcmp(name, "rqs_bwd") != 0 &&
+        std::strcmp(name, "wide_bwd") != 0)
+      return;
     if (ctx->prof_pool_next + 2 > ctx->prof_pool.size()) return;  // pool exhausted: stop sampling
     hipEvent_t a = ctx->prof_pool[ctx->prof_pool_next++];
     b = ctx->prof_pool[ctx->prof_pool_next++];

@@ -323,6 +323,7 @@ __device__ __forceinline__ void sign_masks(const f32x16 (&v)[NB], unsigned (&m)[
     unsigned bits = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) bits |= (__float_as_int(v[b][r]) < 0 ? 1u : 0u) << r;
+    asm volatile("" : "+v"(bits));  // compute the mask here (hipcc otherwise sinks it to its first use)
     m[b] = bits;
   }
 }

@@ -5,6 +5,7 @@ cfg1  planar flow d=2, 10 layers, Banana target, batch 1024, Float64  (ELBO step
 cfg2  RealNVP d=64, 8 couplings, h=64, batch 65536                     (ELBO step)   [headline]
 cfg2b RealNVP d=64, 8 couplings, h=32 (reference default widths)       (ELBO step)
 cfg3  NSF d=32, 8 RQ-spline couplings, K=8, B=5, h=32, batch 131072    (ELBO step)
+cfg4  RealNVP d=256, 16 couplings, h=256, batch 32768 = one GPU's shard of 262144/8  (ELBO step)
 cfg5  RealNVP d=64 inverse + logdet + log q0 on 1 M samples           (loglikelihood)
 """
 import argparse
@@ -51,7 +52,7 @@ def time_step(flow, tgt, n, steps, warmup=5):
     torch.cuda.synchronize()
     kern = {}
     for name in (b"base_sample", b"pack_weights", b"affine_chain", b"rqs_chain", b"simple_apply", b"target", b"affine_bwd",
-                 b"rqs_bwd", b"simple_bwd", b"reduce_slabs", b"adam"):
+                 b"rqs_bwd", b"simple_bwd", b"wide_apply", b"wide_bwd", b"wide_dw", b"reduce_slabs", b"adam"):
         a, c = C.c_double(0.0), C.c_int64(0)
         lib.nf_prof_read(ctx.ptr, name, C.byref(a), C.byref(c))
         if c.value:
@@ -78,6 +79,8 @@ def main():
     res["cfg2b_realnvp_d64_h32_n65536"] = time_step(flow, dg(64), 65536, args.steps)
     flow = nf.nsf(nf.MvNormal(32), (32, 32), 8, 5.0, 4, paramtype=torch.float32, device=dev, seed=123)
     res["cfg3_nsf_d32_k8_n131072"] = time_step(flow, dg(32), 131072, args.steps)
+    flow = nf.realnvp(nf.MvNormal(256), (256, 256), 8, paramtype=torch.float32, device=dev, seed=123)
+    res["cfg4_realnvp_d256_h256_n32768_per_gpu"] = time_step(flow, dg(256), 32768, max(5, args.steps // 3), warmup=3)
     # cfg 5: forward-KL path
     flow = nf.realnvp(nf.MvNormal(64), (64, 64), 4, paramtype=torch.float32, device=dev, seed=123)
     n = 1 << 20
