@@ -24,6 +24,12 @@
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 
+// optional clock stamps of block 0 / wave 0 (nf_debug_trace, tools/trace_wide.py)
+#define WIDE_STAMP(slot)                                                  \
+  do {                                                                    \
+    if (tr) { __builtin_amdgcn_sched_barrier(0); tr[slot] = clock64(); }  \
+  } while (0)
+
 using GW = NetGeo<4, 8, 8, 4>;  // every wide flow is zero-padded into this geometry
 
 template <class G>
@@ -51,10 +57,25 @@ __device__ __forceinline__ void issue_chunk(wide_img_t img, int off, int nfloats
     __builtin_amdgcn_raw_ptr_buffer_load_lds(img, (lds_void_t *)(ldst + p * 256), 16, lane * 16, (off + p * 256) * 4, 0, 0);
 }
 
+// The DMA of the NEXT chunk, handed to the chunk routines, which issue it in one block in front of
+// their MFMA loop.  (Measured: spreading the pieces between the MFMAs of the loop is slower --
+// 157 vs 146 us forward, 179 vs 169 us reverse per launch -- anything placed between two fp32 MFMAs
+// costs more issue time than it hides.)
+struct DmaJob {
+  wide_img_t img;
+  int off, nfloats;
+  float *ldst;
+  int wave, lane;
+  __device__ __forceinline__ void issue() const {
+    if (nfloats) issue_chunk(img, off, nfloats, ldst, wave, lane);
+  }
+};
+
 // out[ob] += W[rows of this chunk][:] * in_blk   (chunk = 32 input rows, all output columns)
 template <int OB, int S>
 __device__ __forceinline__ void wide_fwd_chunk(const float *__restrict__ ch, const f32x16 &in, f32x16 (&out)[OB], int l31,
-                                               int hi) {
+                                               int hi, const DmaJob &dma) {
+  dma.issue();
   const float *wl = ch + (4 * hi) * S + l31;
   float an[OB], ac[OB];
 #pragma unroll
@@ -78,7 +99,8 @@ __device__ __forceinline__ void wide_fwd_chunk(const float *__restrict__ ch, con
 // din = W[rows of this chunk][:]^T-contracted with delta: din[i] = sum_o W[i][o] delta[o]
 template <int OB, int S>
 __device__ __forceinline__ void wide_bwdx_chunk(const float *__restrict__ ch, const f32x16 (&delta)[OB], f32x16 &din,
-                                                int l31, int hi) {
+                                                int l31, int hi, const DmaJob &dma) {
+  dma.issue();
   const float *wl = ch + l31 * S + 4 * hi;
   constexpr int NG = OB * 4;
   float an[4], ac[4];
@@ -102,9 +124,19 @@ __device__ __forceinline__ void wide_bwdx_chunk(const float *__restrict__ ch, co
   }
 }
 
-struct NoPost {
+// Hooks of wide_net_fwd.  after_l1/after_l2 see the post-activation hidden layers; l2_step(ib) /
+// l3_step(ib) run right before the MFMAs of chunk `ib` of layer 2 / 3 -- the reverse pass uses them
+// to trickle its stash stores and tile loads out a few per chunk, so that they drain behind the
+// matrix pipe instead of in one HBM-bound burst.
+struct NoHooks {
   template <class T>
-  __device__ __forceinline__ void operator()(T &) const {}
+  __device__ __forceinline__ void after_l1(T &) const {}
+  template <class T>
+  __device__ __forceinline__ void after_l2(T &) const {}
+  template <class T>
+  __device__ __forceinline__ void l2_step(int, T &) const {}
+  template <class T>
+  __device__ __forceinline__ void l3_step(int, T &) const {}
 };
 
 template <int NB>
@@ -117,23 +149,24 @@ __device__ __forceinline__ void init_bias(f32x16 (&v)[NB], const float *__restri
 
 // Streams one net forward.  On entry the chunk (W1, rows 0..31) of `img` is resident in
 // cb[buf]; on exit the chunk (next_src, next_floats) is resident in cb[buf] (or nothing if
-// next_floats == 0).  post1/post2 see the post-activation hidden layers (reverse pass: masks, stash).
-template <class G, class P1, class P2>
+// next_floats == 0).
+template <class G, class HK>
 __device__ __forceinline__ void wide_net_fwd(wide_img_t img, const float *__restrict__ bias, float *cb, int &buf,
                                              wide_img_t next_img, int next_off, int next_floats,
-                                             const f32x16 (&xb)[G::MB], f32x16 (&out)[G::CB], int wave, int lane, P1 post1,
-                                             P2 post2) {
+                                             const f32x16 (&xb)[G::MB], f32x16 (&out)[G::CB], int wave, int lane, HK &hk,
+                                             long long *tr = nullptr) {
   using W = Wide<G>;
   const int l31 = lane & 31, hi = lane >> 5;
   f32x16 a1[G::H1B];
   init_bias<G::H1B>(a1, bias, hi);
 #pragma unroll
   for (int ib = 0; ib < G::MB; ++ib) {
+    DmaJob dj{img, 0, 0, cb, wave, lane};
     if (ib + 1 < G::MB)
-      issue_chunk(img, G::W1 + (ib + 1) * W::CF1, W::CF1, cb + (buf ^ 1) * W::CHBUF, wave, lane);
+      dj = DmaJob{img, G::W1 + (ib + 1) * W::CF1, W::CF1, cb + (buf ^ 1) * W::CHBUF, wave, lane};
     else
-      issue_chunk(img, G::W2, W::CF2, cb + (buf ^ 1) * W::CHBUF, wave, lane);
-    wide_fwd_chunk<G::H1B, G::S1>(cb + buf * W::CHBUF, xb[ib], a1, l31, hi);
+      dj = DmaJob{img, G::W2, W::CF2, cb + (buf ^ 1) * W::CHBUF, wave, lane};
+    wide_fwd_chunk<G::H1B, G::S1>(cb + buf * W::CHBUF, xb[ib], a1, l31, hi, dj);
     __syncthreads();
     buf ^= 1;
   }
@@ -141,16 +174,20 @@ __device__ __forceinline__ void wide_net_fwd(wide_img_t img, const float *__rest
   for (int b = 0; b < G::H1B; ++b)
 #pragma unroll
     for (int r = 0; r < 16; ++r) a1[b][r] = nf_lrelu(a1[b][r]);
-  post1(a1);
+  WIDE_STAMP(2);
+  hk.after_l1(a1);
+  WIDE_STAMP(3);
   f32x16 a2[G::H2B];
   init_bias<G::H2B>(a2, bias + 32 * G::H1B, hi);
 #pragma unroll
   for (int ib = 0; ib < G::H1B; ++ib) {
+    DmaJob dj{img, 0, 0, cb, wave, lane};
     if (ib + 1 < G::H1B)
-      issue_chunk(img, G::W2 + (ib + 1) * W::CF2, W::CF2, cb + (buf ^ 1) * W::CHBUF, wave, lane);
+      dj = DmaJob{img, G::W2 + (ib + 1) * W::CF2, W::CF2, cb + (buf ^ 1) * W::CHBUF, wave, lane};
     else
-      issue_chunk(img, G::W3, W::CF3, cb + (buf ^ 1) * W::CHBUF, wave, lane);
-    wide_fwd_chunk<G::H2B, G::S2>(cb + buf * W::CHBUF, a1[ib], a2, l31, hi);
+      dj = DmaJob{img, G::W3, W::CF3, cb + (buf ^ 1) * W::CHBUF, wave, lane};
+    hk.l2_step(ib, a1);
+    wide_fwd_chunk<G::H2B, G::S2>(cb + buf * W::CHBUF, a1[ib], a2, l31, hi, dj);
     __syncthreads();
     buf ^= 1;
   }
@@ -158,15 +195,19 @@ __device__ __forceinline__ void wide_net_fwd(wide_img_t img, const float *__rest
   for (int b = 0; b < G::H2B; ++b)
 #pragma unroll
     for (int r = 0; r < 16; ++r) a2[b][r] = nf_lrelu(a2[b][r]);
-  post2(a2);
+  WIDE_STAMP(4);
+  hk.after_l2(a2);
+  WIDE_STAMP(5);
   init_bias<G::CB>(out, bias + 32 * (G::H1B + G::H2B), hi);
 #pragma unroll
   for (int ib = 0; ib < G::H2B; ++ib) {
+    DmaJob dj{img, 0, 0, cb, wave, lane};
     if (ib + 1 < G::H2B)
-      issue_chunk(img, G::W3 + (ib + 1) * W::CF3, W::CF3, cb + (buf ^ 1) * W::CHBUF, wave, lane);
+      dj = DmaJob{img, G::W3 + (ib + 1) * W::CF3, W::CF3, cb + (buf ^ 1) * W::CHBUF, wave, lane};
     else if (next_floats)
-      issue_chunk(next_img, next_off, next_floats, cb + (buf ^ 1) * W::CHBUF, wave, lane);
-    wide_fwd_chunk<G::CB, G::S3>(cb + buf * W::CHBUF, a2[ib], out, l31, hi);
+      dj = DmaJob{next_img, next_off, next_floats, cb + (buf ^ 1) * W::CHBUF, wave, lane};
+    hk.l3_step(ib, a2);
+    wide_fwd_chunk<G::CB, G::S3>(cb + buf * W::CHBUF, a2[ib], out, l31, hi, dj);
     __syncthreads();
     buf ^= 1;
   }
@@ -185,6 +226,7 @@ __device__ __forceinline__ void stage_biases(float *__restrict__ dst, const floa
 
 struct WideArgs {
   const float *img_s, *img_t;
+  long long *trace;  // optional clock stamps of block 0 / wave 0 (nf_debug_trace)
   int d, c, m, par_t;
   long N;
 };
@@ -220,7 +262,7 @@ __global__ __launch_bounds__(256, 1) void k_wide_apply(WideArgs a, float *xt, fl
     const bool valid = live && j < a.N;
     const bool more = grp + gridDim.x < ngroups;
     const TileIO io = make_tile_io(xt, tl, a.d, l31, hi);
-    f32x16 S[G::CB], T[G::CB];
+    f32x16 S[G::CB], T[G::CB], x1[G::CB];
     {
       f32x16 xb[G::MB];
 #pragma unroll
@@ -230,7 +272,8 @@ __global__ __launch_bounds__(256, 1) void k_wide_apply(WideArgs a, float *xt, fl
           const float v = tile_load(io, tile_soff(b, r, par_c));
           xb[b][r] = valid ? v : 0.f;
         }
-      wide_net_fwd<G>(img_s, bias, cb, buf, img_t, G::W1, W::CF1, xb, S, wave, lane, NoPost(), NoPost());
+      NoHooks nh;
+      wide_net_fwd<G>(img_s, bias, cb, buf, img_t, G::W1, W::CF1, xb, S, wave, lane, nh);
     }
     {
       f32x16 xb[G::MB];
@@ -241,8 +284,23 @@ __global__ __launch_bounds__(256, 1) void k_wide_apply(WideArgs a, float *xt, fl
           const float v = tile_load(io, tile_soff(b, r, par_c));
           xb[b][r] = valid ? v : 0.f;
         }
-      wide_net_fwd<G>(img_t, bias + W::NBIAS, cb, buf, img_s, G::W1, more ? W::CF1 : 0, xb, T, wave, lane, NoPost(),
-                      NoPost());
+      // the transformed half is fetched while the last layer of the t net runs (one batch of loads,
+      // not interleaved with the stores below: the compiler must keep load/store order on one buffer)
+      struct X1Hook : NoHooks {
+        const TileIO &io;
+        f32x16 (&x1)[G::CB];
+        int par_t;
+        __device__ __forceinline__ X1Hook(const TileIO &i, f32x16 (&x)[G::CB], int p) : io(i), x1(x), par_t(p) {}
+        __device__ __forceinline__ void l3_step(int ib, f32x16 (&)[G::H2B]) const {
+          if (ib == 0) {
+#pragma unroll
+            for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) x1[b][r] = tile_load(io, tile_soff(b, r, par_t));
+          }
+        }
+      } xh(io, x1, a.par_t);
+      wide_net_fwd<G>(img_t, bias + W::NBIAS, cb, buf, img_s, G::W1, more ? W::CF1 : 0, xb, T, wave, lane, xh);
     }
     float lsum = 0.f;
 #pragma unroll
@@ -250,7 +308,7 @@ __global__ __launch_bounds__(256, 1) void k_wide_apply(WideArgs a, float *xt, fl
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float s = nf_tanh(S[b][r]);  // padded rows: zero weights and bias => s = 0
-        const float v = tile_load(io, tile_soff(b, r, a.par_t));
+        const float v = x1[b][r];
         const float o = INVERSE ? __fdividef(v - T[b][r], nf_exp(s)) : v * nf_exp(s) + T[b][r];
         if (live) tile_store(io, tile_soff(b, r, a.par_t), o);  // rows >= c fall outside the descriptor
         lsum += s;
@@ -290,6 +348,18 @@ __device__ __forceinline__ void stash_store(const StashIO &s, const f32x16 (&v)[
       const float val = v[b][r];  // (bit_cast straight from the vector-element expression reads element 0)
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), s.rs, s.voff,
                                             (b * 32 + (r & 3) + 8 * (r >> 2)) * (NF_TILE * 4), 0);
+    }
+}
+
+// elements [e0, e0 + n) of the flattened (block, reg) index space
+template <int NB>
+__device__ __forceinline__ void stash_store_range(const StashIO &s, const f32x16 (&v)[NB], int e0, int n) {
+#pragma unroll
+  for (int q = 0; q < NB * 16; ++q)
+    if (q >= e0 && q < e0 + n) {
+      const float val = v[q >> 4][q & 15];
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), s.rs, s.voff,
+                                            ((q >> 4) * 32 + (q & 3) + 8 * ((q & 15) >> 2)) * (NF_TILE * 4), 0);
     }
 }
 
@@ -344,8 +414,10 @@ __global__ __launch_bounds__(256, 1) void k_wide_bwd(WideArgs a, float *__restri
     const StashIO sd2 = make_stash_io(st.d2, tl, live ? 32 * G::H2B : 0, l31, hi);
     const StashIO sd3 = make_stash_io(st.d3, tl, live ? 32 * G::CB : 0, l31, hi);
 
+    long long *tr = (a.trace && blockIdx.x == 0 && tid == 0 && grp == blockIdx.x) ? a.trace + (PHASE_S ? 32 : 0) : nullptr;
+    WIDE_STAMP(0);
     unsigned m1[G::H1B], m2[G::H2B];
-    f32x16 d3[G::CB];
+    f32x16 d3[G::CB], y1[G::CB], g1[G::CB];
     {
       f32x16 xb[G::MB];
 #pragma unroll
@@ -355,17 +427,36 @@ __global__ __launch_bounds__(256, 1) void k_wide_bwd(WideArgs a, float *__restri
           const float v = tile_load(yio, tile_soff(b, r, par_c));
           xb[b][r] = valid ? v : 0.f;
         }
-      wide_net_fwd<G>(
-          img, bias, cb, buf, img, G::W3, W::CF3, xb, d3, wave, lane,
-          [&](f32x16(&a1)[G::H1B]) {
-            wide_sign_masks<G::H1B>(a1, m1);
-            stash_store<G::H1B>(sa1, a1);
-          },
-          [&](f32x16(&a2)[G::H2B]) {
-            wide_sign_masks<G::H2B>(a2, m2);
-            stash_store<G::H2B>(sa2, a2);
-          });
+      WIDE_STAMP(1);
+      // masks right after each hidden layer; the stash stores of a1 / a2 and the loads of the
+      // element-wise stage's operands go out a block per chunk, behind the MFMAs of layers 2 / 3
+      struct BwdHooks {
+        unsigned (&m1)[G::H1B];
+        unsigned (&m2)[G::H2B];
+        const StashIO &sa1, &sa2;
+        const TileIO &yio, &gio;
+        f32x16 (&y1)[G::CB];
+        f32x16 (&g1)[G::CB];
+        int par_t;
+        __device__ __forceinline__ void after_l1(f32x16 (&a1)[G::H1B]) const { wide_sign_masks<G::H1B>(a1, m1); }
+        __device__ __forceinline__ void after_l2(f32x16 (&a2)[G::H2B]) const { wide_sign_masks<G::H2B>(a2, m2); }
+        __device__ __forceinline__ void l2_step(int ib, f32x16 (&a1)[G::H1B]) const {
+          stash_store_range<G::H1B>(sa1, a1, ib * 16, 16);
+        }
+        __device__ __forceinline__ void l3_step(int ib, f32x16 (&a2)[G::H2B]) const {
+          stash_store_range<G::H2B>(sa2, a2, ib * 16, 16);
+          constexpr int PER = (G::CB * 16 + G::H2B - 1) / G::H2B;
+#pragma unroll
+          for (int q = 0; q < G::CB * 16; ++q)
+            if (q >= ib * PER && q < (ib + 1) * PER) {
+              y1[q >> 4][q & 15] = tile_load(yio, tile_soff(q >> 4, q & 15, par_t));
+              g1[q >> 4][q & 15] = tile_load(gio, tile_soff(q >> 4, q & 15, par_t));
+            }
+        }
+      } hk{m1, m2, sa1, sa2, yio, gio, y1, g1, a.par_t};
+      wide_net_fwd<G>(img, bias, cb, buf, img, G::W3, W::CF3, xb, d3, wave, lane, hk, tr);
     }
+    WIDE_STAMP(6);
     // element-wise stage (same algebra as bwd_tile in nf_coupling.hip)
     const float lb = valid ? (lbar ? lbar[j] : lbar_const) : 0.f;
 #pragma unroll
@@ -374,8 +465,7 @@ __global__ __launch_bounds__(256, 1) void k_wide_bwd(WideArgs a, float *__restri
       for (int r = 0; r < 16; ++r) {
         const int p = b * 32 + nf_row(r, hi);
         const bool ok = (p < a.c) && valid;
-        const float yv = tile_load(yio, tile_soff(b, r, a.par_t));
-        const float gv = tile_load(gio, tile_soff(b, r, a.par_t));
+        const float yv = y1[b][r], gv = g1[b][r];
         if (!PHASE_S) {
           if (live) tile_store(yio, tile_soff(b, r, a.par_t), yv - d3[b][r]);  // u = x1 * exp(S)
           d3[b][r] = ok ? gv : 0.f;
@@ -389,59 +479,78 @@ __global__ __launch_bounds__(256, 1) void k_wide_bwd(WideArgs a, float *__restri
           d3[b][r] = ok ? (gv * yv + lb) * (1.f - s * s) : 0.f;
         }
       }
-    stash_store<G::CB>(sd3, d3);
+    WIDE_STAMP(7);
 
-    // ---- dX chain: W3^T, W2^T, W1^T, one output block per chunk
+    // ---- dX chain: W3^T, W2^T, W1^T, one output block per chunk; every chunk step also sends a
+    // slice of the pending stash stores on its way
     f32x16 d2[G::H2B];
 #pragma unroll
     for (int ib = 0; ib < G::H2B; ++ib) {
+      DmaJob dj{img, 0, 0, cb, wave, lane};
       if (ib + 1 < G::H2B)
-        issue_chunk(img, G::W3 + (ib + 1) * W::CF3, W::CF3, cb + (buf ^ 1) * W::CHBUF, wave, lane);
+        dj = DmaJob{img, G::W3 + (ib + 1) * W::CF3, W::CF3, cb + (buf ^ 1) * W::CHBUF, wave, lane};
       else
-        issue_chunk(img, G::W2, W::CF2, cb + (buf ^ 1) * W::CHBUF, wave, lane);
-      wide_bwdx_chunk<G::CB, G::S3>(cb + buf * W::CHBUF, d3, d2[ib], l31, hi);
+        dj = DmaJob{img, G::W2, W::CF2, cb + (buf ^ 1) * W::CHBUF, wave, lane};
+      {
+        constexpr int PER = (G::CB * 16 + G::H2B - 1) / G::H2B;
+        stash_store_range<G::CB>(sd3, d3, ib * PER, PER);
+      }
+      if (ib > 0) stash_store_range<G::H2B>(sd2, d2, (ib - 1) * 16, 16);
+      wide_bwdx_chunk<G::CB, G::S3>(cb + buf * W::CHBUF, d3, d2[ib], l31, hi, dj);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) d2[ib][r] *= ((m2[ib] >> r) & 1u) ? 0.01f : 1.f;
       __syncthreads();
       buf ^= 1;
     }
-#pragma unroll
-    for (int b = 0; b < G::H2B; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) d2[b][r] *= ((m2[b] >> r) & 1u) ? 0.01f : 1.f;
-    stash_store<G::H2B>(sd2, d2);
+    WIDE_STAMP(8);
+    WIDE_STAMP(9);
+    WIDE_STAMP(10);
     f32x16 d1[G::H1B];
 #pragma unroll
     for (int ib = 0; ib < G::H1B; ++ib) {
+      DmaJob dj{img, 0, 0, cb, wave, lane};
       if (ib + 1 < G::H1B)
-        issue_chunk(img, G::W2 + (ib + 1) * W::CF2, W::CF2, cb + (buf ^ 1) * W::CHBUF, wave, lane);
+        dj = DmaJob{img, G::W2 + (ib + 1) * W::CF2, W::CF2, cb + (buf ^ 1) * W::CHBUF, wave, lane};
       else
-        issue_chunk(img, G::W1, W::CF1, cb + (buf ^ 1) * W::CHBUF, wave, lane);
-      wide_bwdx_chunk<G::H2B, G::S2>(cb + buf * W::CHBUF, d2, d1[ib], l31, hi);
+        dj = DmaJob{img, G::W1, W::CF1, cb + (buf ^ 1) * W::CHBUF, wave, lane};
+      if (ib == 0) stash_store_range<G::H2B>(sd2, d2, (G::H2B - 1) * 16, 16);
+      if (ib > 0) stash_store_range<G::H1B>(sd1, d1, (ib - 1) * 16, 16);
+      wide_bwdx_chunk<G::H2B, G::S2>(cb + buf * W::CHBUF, d2, d1[ib], l31, hi, dj);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) d1[ib][r] *= ((m1[ib] >> r) & 1u) ? 0.01f : 1.f;
       __syncthreads();
       buf ^= 1;
     }
-#pragma unroll
-    for (int b = 0; b < G::H1B; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) d1[b][r] *= ((m1[b] >> r) & 1u) ? 0.01f : 1.f;
-    stash_store<G::H1B>(sd1, d1);
+    WIDE_STAMP(11);
+    WIDE_STAMP(12);
+    f32x16 g2p;  // x2bar block of the previous chunk, stored behind the next chunk's MFMAs
 #pragma unroll
     for (int ib = 0; ib < G::MB; ++ib) {
+      DmaJob dj{img, 0, 0, cb, wave, lane};
       if (ib + 1 < G::MB)
-        issue_chunk(img, G::W1 + (ib + 1) * W::CF1, W::CF1, cb + (buf ^ 1) * W::CHBUF, wave, lane);
+        dj = DmaJob{img, G::W1 + (ib + 1) * W::CF1, W::CF1, cb + (buf ^ 1) * W::CHBUF, wave, lane};
       else if (more)
-        issue_chunk(img, G::W1, W::CF1, cb + (buf ^ 1) * W::CHBUF, wave, lane);
-      f32x16 g2;
-      wide_bwdx_chunk<G::H1B, G::S1>(cb + buf * W::CHBUF, d1, g2, l31, hi);
-      if (live) {
+        dj = DmaJob{img, G::W1, W::CF1, cb + (buf ^ 1) * W::CHBUF, wave, lane};
+      if (ib == 0) stash_store_range<G::H1B>(sd1, d1, (G::H1B - 1) * 16, 16);
+      if (ib > 0 && live) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float gold = tile_load(gio, tile_soff(ib, r, par_c));
-          tile_store(gio, tile_soff(ib, r, par_c), gold + g2[r]);
-        }
+        for (int r = 0; r < 16; ++r) tile_store(gio, tile_soff(ib - 1, r, par_c), g2p[r]);
       }
+      f32x16 gold;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gold[r] = tile_load(gio, tile_soff(ib, r, par_c));
+      f32x16 g2;
+      wide_bwdx_chunk<G::H1B, G::S1>(cb + buf * W::CHBUF, d1, g2, l31, hi, dj);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) g2p[r] = gold[r] + g2[r];
       __syncthreads();
       buf ^= 1;
     }
+    if (live) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tile_store(gio, tile_soff(G::MB - 1, r, par_c), g2p[r]);
+    }
+    WIDE_STAMP(13);
   }
 }
 
@@ -674,6 +783,7 @@ static WideArgs make_wide_args(nf_ctx *ctx, const nf_flow_desc *desc, int k, lon
   WideArgs a;
   a.img_s = (const float *)ctx->wimg + (size_t)(2 * k) * GW::SIZE;
   a.img_t = a.img_s + GW::SIZE;
+  a.trace = (long long *)ctx->trace;
   a.d = desc->d; a.c = ci.c; a.m = ci.m; a.par_t = ci.par_t; a.N = N;
   return a;
 }
