@@ -60,6 +60,26 @@ def select_cfg4(world: int):
     KERNEL_NAMES = (b"base_sample", b"pack_weights", b"wide_apply", b"target", b"wide_bwd", b"wide_dw", b"reduce_slabs", b"adam")
 
 
+def pmc_traffic(kernel_substr: str):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 counter passes
+    (profiles/*_pmc_summary.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this
+    same command by tools/collect_profiles.sh; rocprofv3 reports both in KiB).  The loads of this kernel
+    are 4 B/lane tile loads, for which MI355X_MICROARCH.md gives no calibrated correction factor, so the
+    counters are taken as reported.  None if no profile is committed."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        summ = json.load(f)
+    for name, counters in summ.items():
+        if kernel_substr in name and "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
+            kib = counters["FETCH_SIZE"]["avg_per_launch"] + counters["WRITE_SIZE"]["avg_per_launch"]
+            return kib * 1024.0, os.path.relpath(files[-1], ROOT)
+    return None, None
+
+
 def cpu_baseline(seconds_budget: float = 12.0):
     """numpy (BLAS-threaded) port of the same step on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -201,6 +221,7 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         value = n_global * args.steps / elapsed
         achieved = FLOPS_BWD_PER_SAMPLE_PER_COUPLING * n_local / (avg_ms.value * 1e-3) / 1e12 if avg_ms.value > 0 else 0.0
+        traffic, traffic_src = (pmc_traffic("k_affine_bwd") if args.workload == "cfg2" and n_local == BATCH else (None, None))
         rec = {
             "metric": "elbo_samples_per_sec",
             "value": value,
@@ -229,7 +250,9 @@ def main():
                 "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_unit": "bytes per launch (HBM fetch + write, rocprofv3 PMC)",
+                "traffic_source": traffic_src,
                 "avg_launch_ms": avg_ms.value,
                 "launches_timed": cnt.value,
                 "algorithmic_flop_per_launch": FLOPS_BWD_PER_SAMPLE_PER_COUPLING * n_local,
