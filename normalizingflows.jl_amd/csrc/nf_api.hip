@@ -32,6 +32,10 @@ int nf_affine_apply(nf_ctx *, const nf_flow_desc *, int k, bool inverse, const f
 int nf_affine_bwd_grid(nf_ctx *, long N);
 int nf_affine_pack(nf_ctx *, const nf_flow_desc *, const float *theta);
 int nf_affine_chain(nf_ctx *, const nf_flow_desc *, bool inverse, float *xt, long N, float *ladj);
+long nf_affine_chain_grid(nf_ctx *, long N);
+int nf_affine_chain_elbo(nf_ctx *, const nf_flow_desc *, long N, uint64_t seed, uint64_t off, uint32_t stream,
+                         const float *mu, const float *var, float *yt, float *gt, double gscale, double *partial,
+                         double pscale);
 long nf_affine_slab_floats(const nf_flow_desc *desc);
 int nf_affine_reduce_slabs(nf_ctx *, const nf_flow_desc *, const float *slab, int nslab, float *g);
 int nf_affine_bwd(nf_ctx *, const nf_flow_desc *, int k, const float *theta, float *y, float *ybar, const float *lbar,
@@ -288,6 +292,13 @@ static long coupling_slab_floats(nf_ctx *ctx, const nf_flow_desc *desc, long N) 
   return is_nsf(desc) ? nf_rqs_slab_floats(desc) : nf_affine_slab_floats(desc);
 }
 
+// The ELBO forward of a training step fuses into ONE launch (draws + chain + target + partial sums)
+// when the draws are in-library, the nets are LDS-resident and the target is the diagonal Gaussian.
+static inline bool elbo_fusable(const nf_flow_desc *desc, const nf_target *target, const void *xs) {
+  return !xs && desc->kind == NF_KIND_REALNVP && nf_affine_supported(desc) && target->kind == NF_TARGET_DIAGGAUSS &&
+         target->p0 && target->p1;
+}
+
 // all couplings (or one, if k_only >= 0) in execution order / inverse order, in place on `xt`
 static int coupling_chain_tiled(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, const float *theta, float *xt,
                                 long N, float *ladj, int k_only) {
@@ -420,6 +431,13 @@ static int elbo_forward(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *
   char *ladj = cv.take<char>((size_t)N * es);
   double *partial = cv.take<double>(nb);
   double *result = cv.take<double>(8);
+  if (cp && !elbos_out && elbo_fusable(desc, target, xs)) {
+    NF_TRY(coupling_pack(ctx, desc, (const float *)theta));
+    NF_TRY(nf_affine_chain_elbo(ctx, desc, N, seed, off, stream_id, (const float *)target->p0, (const float *)target->p1,
+                                (float *)x, nullptr, 0.0, partial, 1.0 / (double)N));
+    NF_TRY(nf_launch_finish_sum(ctx, partial, nf_affine_chain_grid(ctx, N), 0, result, nullptr, nullptr));
+    return read_scalar(ctx, result, elbo_host);
+  }
   if (cp) {
     float *xt = (float *)x;
     if (xs) {
@@ -528,6 +546,14 @@ extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, con
   char *slab = cv.take<char>(slabf * es);
   char *sws = cv.take<char>(simple_ws);
 
+  if (cp && elbo_fusable(desc, target, xs)) {
+    float *xt = (float *)x, *gt = (float *)gbar;
+    NF_TRY(coupling_pack(ctx, desc, (const float *)theta));
+    NF_TRY(nf_affine_chain_elbo(ctx, desc, N, seed, sample_offset, stream_id, (const float *)target->p0,
+                                (const float *)target->p1, xt, gt, -inv, partial, -inv));
+    NF_TRY(nf_launch_finish_sum(ctx, partial, nf_affine_chain_grid(ctx, N), 0, nullptr, (float *)out + P, nullptr));
+    return realnvp_bwd(ctx, desc, (const float *)theta, xt, gt, nullptr, (float)(-inv), N, (float *)slab, grid, (float *)out);
+  }
   if (cp) {
     float *xt = (float *)x, *gt = (float *)gbar;
     if (xs) {

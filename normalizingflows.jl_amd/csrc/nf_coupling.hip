@@ -12,6 +12,7 @@
 #include "nf_common.h"
 #include "nf_mfma.h"
 #include "nf_pack.h"
+#include "nf_philox.h"
 
 struct CouplingArgs {
   const float *theta;
@@ -140,8 +141,23 @@ __device__ __forceinline__ float coupling_step(const float *__restrict__ img_s, 
   return lsum;
 }
 
-template <class G, bool INVERSE>
-__global__ __launch_bounds__(512) void k_affine_chain(ChainArgs a, float *xt, float *__restrict__ ladj) {
+// FUSED (forward only): the ELBO forward of the training step in the same launch -- the tile's base
+// draws are generated in registers (Philox4x32-10 + Box-Muller, same counters as k_base_sample_tiled:
+// (sample lo, sample hi, feature group, stream)), log q0 and log|det J| never touch memory, and after
+// the last coupling the diagonal-Gaussian target, ybar = gscale * grad log p(y) and the workgroup's
+// partial sum of pscale * elbo_j are computed from the registers (src/objectives/elbo.jl:65-70,93-97).
+struct FusedArgs {
+  uint32_t k0, k1, stream;
+  uint64_t off;           // global index of this shard's first sample
+  const float *mu, *var;  // diagonal-Gaussian target (test/flow.jl:43-46)
+  float *gt;              // ybar out (tiled), or nullptr
+  float gscale;
+  double *partial;        // [gridDim.x] out
+  double pscale;
+};
+
+template <class G, bool INVERSE, bool FUSED = false>
+__global__ __launch_bounds__(512) void k_affine_chain(ChainArgs a, float *xt, float *__restrict__ ladj, FusedArgs fa) {
   static_assert(G::MB == G::CB, "parity blocks must have equal padded size");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int IMG2 = 2 * G::SIZE;  // s and t images of one coupling are adjacent in wimg
@@ -161,6 +177,22 @@ __global__ __launch_bounds__(512) void k_affine_chain(ChainArgs a, float *xt, fl
     float4 *dst = reinterpret_cast<float4 *>(lds);
     for (int i = tid; i < NV4; i += 512) dst[i] = src[i];
   }
+  // FUSED: target parameters by feature, zero padded: tmu[f], tiv[f] = 1/var[f]; tc0 = d log 2pi + sum log var
+  constexpr int TP = 64 * G::CB;  // padded feature count (E and O halves)
+  float *tmu = lds + 2 * IMG2, *tiv = tmu + TP, *tc0 = tiv + TP;
+  double *wsum = reinterpret_cast<double *>(tc0 + 2);  // [8] per-wave partial sums (8-byte aligned: TP even)
+  if (FUSED) {
+    for (int i = tid; i < TP; i += 512) {
+      tmu[i] = i < a.d ? fa.mu[i] : 0.f;
+      tiv[i] = i < a.d ? 1.f / fa.var[i] : 0.f;
+    }
+    if (tid == 0) {
+      float c = 1.8378770664093453f * (float)a.d;
+      for (int i = 0; i < a.d; ++i) c += logf(fa.var[i]);
+      tc0[0] = c;
+    }
+  }
+  double wg_total = 0.0;
   __syncthreads();
 
   int buf = 0;
@@ -172,15 +204,45 @@ __global__ __launch_bounds__(512) void k_affine_chain(ChainArgs a, float *xt, fl
     const bool valid = live && j < a.N;
     const TileIO io = make_tile_io(xt, tl, a.d, l31, hi);
     f32x16 E[G::CB], O[G::MB];
+    float zz = 0.f;  // FUSED: this lane's share of ||x||^2
+    if (!FUSED) {
 #pragma unroll
-    for (int b = 0; b < G::CB; ++b)
+      for (int b = 0; b < G::CB; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = tile_load(io, tile_soff(b, r, 0));  // features >= d read as 0
-        const float o = tile_load(io, tile_soff(b, r, 1));
-        E[b][r] = valid ? e : 0.f;
-        O[b][r] = valid ? o : 0.f;
-      }
+        for (int r = 0; r < 16; ++r) {
+          const float e = tile_load(io, tile_soff(b, r, 0));  // features >= d read as 0
+          const float o = tile_load(io, tile_soff(b, r, 1));
+          E[b][r] = valid ? e : 0.f;
+          O[b][r] = valid ? o : 0.f;
+        }
+    } else {
+      // registers (b, 4q..4q+3) of E and O are features base..base+7, base = 64b + 16q + 8hi:
+      // Philox groups base/4 (-> E0 O0 E1 O1) and base/4 + 1 (-> E2 O2 E3 O3)
+      const uint64_t gj = fa.off + (uint64_t)j;
+#pragma unroll
+      for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int base = 64 * b + 16 * q + 8 * hi;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int g = base / 4 + h;
+            U4 c = {(uint32_t)gj, (uint32_t)(gj >> 32), (uint32_t)g, fa.stream};
+            const U4 rr = philox4x32_10(c, fa.k0, fa.k1);
+            float z[4];
+            box_muller<float>(rr.x, rr.y, z[0], z[1]);
+            box_muller<float>(rr.z, rr.w, z[2], z[3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const bool in = (4 * g + e < a.d) && valid;  // features >= d and padding samples stay 0
+              const float v = in ? z[e] : 0.f;
+              zz += v * v;
+              if (e & 1) O[b][4 * q + 2 * h + (e >> 1)] = v;
+              else E[b][4 * q + 2 * h + (e >> 1)] = v;
+            }
+          }
+        }
+    }
     float lsum = 0.f;
     const bool more_groups = grp + gridDim.x < ngroups;
 #pragma unroll 1
@@ -233,9 +295,48 @@ __global__ __launch_bounds__(512) void k_affine_chain(ChainArgs a, float *xt, fl
           tile_store(io, tile_soff(b, r, 1), O[b][r]);
         }
       lsum += __shfl_xor(lsum, 32);
-      if (hi == 0 && valid) ladj[j] = INVERSE ? -lsum : lsum;
+      if (!FUSED) {
+        if (hi == 0 && valid) ladj[j] = INVERSE ? -lsum : lsum;
+      }
+    }
+    if (FUSED) {
+      // elbo_j = log p(y_j) - log q0(x_j) + ladj_j ;  ybar = gscale * grad log p(y)
+      const TileIO gio = make_tile_io(fa.gt ? fa.gt : xt, tl, a.d, l31, hi);
+      float t = 0.f;
+#pragma unroll
+      for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int fe = 2 * (b * 32 + nf_row(r, hi));
+          const float re = E[b][r] - tmu[fe], ro = O[b][r] - tmu[fe + 1];
+          const float ge = re * tiv[fe], go = ro * tiv[fe + 1];
+          t += re * ge + ro * go;
+          if (fa.gt && live) {
+            tile_store(gio, tile_soff(b, r, 0), valid ? -fa.gscale * ge : 0.f);
+            tile_store(gio, tile_soff(b, r, 1), valid ? -fa.gscale * go : 0.f);
+          }
+        }
+      t += __shfl_xor(t, 32);
+      zz += __shfl_xor(zz, 32);
+      double contrib = 0.0;
+      if (hi == 0 && valid) {
+        const float logq = (float)(-0.5 * 1.8378770664093453 * a.d) - 0.5f * zz;
+        const float e = -0.5f * (tc0[0] + t) - logq + lsum;
+        contrib = fa.pscale * (double)e;
+      }
+#pragma unroll
+      for (int sft = 16; sft >= 1; sft >>= 1) contrib += __shfl_xor(contrib, sft);  // lanes 0..31 carry the terms
+      if (lane == 0) wsum[wave] = contrib;
+      __syncthreads();
+      if (tid == 0) {
+        double sgrp = 0.0;
+        for (int w = 0; w < 8; ++w) sgrp += wsum[w];
+        wg_total += sgrp;
+      }
+      __syncthreads();
     }
   }
+  if (FUSED && tid == 0) fa.partial[blockIdx.x] = wg_total;
 }
 
 // ------------------------------------------------------------------------------------
@@ -667,12 +768,15 @@ static int launch_bwd_v(nf_ctx *ctx, const CouplingArgs &a, float *y, float *yba
   return (int)hipGetLastError();
 }
 template <class G>
-static int launch_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, float *xt, long N, float *ladj) {
-  const size_t lds = 4 * (size_t)G::SIZE * sizeof(float);
+static int launch_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, float *xt, long N, float *ladj,
+                        const FusedArgs *fused = nullptr) {
+  // two double-buffered (s,t) image pairs + target parameters and per-wave sums of the fused variant
+  const size_t lds = (4 * (size_t)G::SIZE + 2 * 64 * G::CB + 2) * sizeof(float) + 8 * sizeof(double);
   static bool attr_done = false;
   if (!attr_done) {
     NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
   ChainArgs a;
@@ -684,11 +788,36 @@ static int launch_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, flo
   long grid = ngroups < ctx->num_cu ? ngroups : ctx->num_cu;
   if (grid < 1) grid = 1;
   ProfScope ps(ctx, "affine_chain");
-  if (inverse)
-    hipLaunchKernelGGL((k_affine_chain<G, true>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj);
+  FusedArgs none{};
+  if (fused)
+    hipLaunchKernelGGL((k_affine_chain<G, false, true>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, *fused);
+  else if (inverse)
+    hipLaunchKernelGGL((k_affine_chain<G, true>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, none);
   else
-    hipLaunchKernelGGL((k_affine_chain<G, false>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj);
+    hipLaunchKernelGGL((k_affine_chain<G, false>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, none);
   return (int)hipGetLastError();
+}
+
+// number of workgroups (= entries of `partial`) the fused ELBO-forward launch uses
+long nf_affine_chain_grid(nf_ctx *ctx, long N) {
+  const long ngroups = ((N + NF_TILE - 1) / NF_TILE + 7) / 8;
+  long grid = ngroups < ctx->num_cu ? ngroups : ctx->num_cu;
+  return grid < 1 ? 1 : grid;
+}
+
+// base draws + whole chain forward + diagonal-Gaussian target + ELBO partial sums in one launch
+// (packed images must be current).  yt <- flow output (tiled), gt <- gscale * grad log p(y) (or null),
+// partial[nf_affine_chain_grid] <- sums of pscale * elbo_j.
+int nf_affine_chain_elbo(nf_ctx *ctx, const nf_flow_desc *desc, long N, uint64_t seed, uint64_t off, uint32_t stream,
+                         const float *mu, const float *var, float *yt, float *gt, double gscale, double *partial,
+                         double pscale) {
+  const int size = geo_size(desc);
+  if (!size || !ctx->wimg) return NF_ERR_UNSUPPORTED;
+  FusedArgs fa;
+  fa.k0 = (uint32_t)seed; fa.k1 = (uint32_t)(seed >> 32); fa.stream = stream; fa.off = off;
+  fa.mu = mu; fa.var = var; fa.gt = gt; fa.gscale = (float)gscale; fa.partial = partial; fa.pscale = pscale;
+  if (size == NetGeo<1, 1, 1, 1>::SIZE) return launch_chain<NetGeo<1, 1, 1, 1>>(ctx, desc, false, yt, N, nullptr, &fa);
+  return launch_chain<NetGeo<1, 2, 2, 1>>(ctx, desc, false, yt, N, nullptr, &fa);
 }
 
 // whole chain in one launch, in place on the tiled buffer (packed images must be current)

@@ -7,6 +7,7 @@
 // 16-lane group reads 64 contiguous bytes per step, and per-sample sums (||x||^2, log p)
 // are 4-step DPP/shuffle reductions inside the group.
 #include "nf_common.h"
+#include "nf_philox.h"
 
 #define LPS 16
 #define EW_BLOCK 256
@@ -35,50 +36,6 @@ __device__ __forceinline__ double block_sum(double v, double *sm) {
   return r;
 }
 
-// ---------------------------------------------------------------------------------------
-// Philox4x32-10 (Salmon et al. 2011); specification mirrored in oracle/nf_oracle.py
-// ---------------------------------------------------------------------------------------
-struct U4 {
-  uint32_t x, y, z, w;
-};
-__device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c.x;
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
-    U4 n;
-    n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
-    n.y = (uint32_t)p1;
-    n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
-    n.w = (uint32_t)p0;
-    c = n;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  return c;
-}
-template <class T>
-__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, T &z0, T &z1);
-template <>
-__device__ __forceinline__ void box_muller<float>(uint32_t a, uint32_t b, float &z0, float &z1) {
-  const float u0 = ((float)(a >> 9) + 0.5f) * 1.1920928955078125e-07f;  // 2^-23, exact in fp32
-  const float u1 = ((float)(b >> 9) + 0.5f) * 1.1920928955078125e-07f;
-  const float rad = sqrtf(-2.0f * logf(u0));
-  float s, c;
-  sincospif(2.0f * u1, &s, &c);
-  z0 = rad * c;
-  z1 = rad * s;
-}
-template <>
-__device__ __forceinline__ void box_muller<double>(uint32_t a, uint32_t b, double &z0, double &z1) {
-  const double u0 = ((double)(a >> 9) + 0.5) * 1.1920928955078125e-07;
-  const double u1 = ((double)(b >> 9) + 0.5) * 1.1920928955078125e-07;
-  const double rad = sqrt(-2.0 * log(u0));
-  double s, c;
-  sincospi(2.0 * u1, &s, &c);
-  z0 = rad * c;
-  z1 = rad * s;
-}
 
 // x ~ N(0, I), logq = logpdf(MvNormal(0, I), x).  Reference seam: _device_specific_rand
 // (src/NormalizingFlows.jl:109-115; device version ext/NormalizingFlowsCUDAExt.jl:43-48).
