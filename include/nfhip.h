@@ -54,6 +54,9 @@ extern "C" {
 
 #define NF_TARGET_DIAGGAUSS 0 /* MvNormal(mu, Diagonal(var)), test/flow.jl:43-46        */
 #define NF_TARGET_BANANA 1    /* Banana(d, b, var), example/targets/banana.jl:58-83     */
+#define NF_TARGET_FUNNEL 2    /* Funnel(d, mu, sigma), example/targets/neal_funnel.jl:53-72 (s0 = mu, s1 = sigma) */
+#define NF_TARGET_WARPED 3    /* WarpedGauss(s1, s2), d = 2, example/targets/warped_gaussian.jl:51-87 (s0, s1) */
+#define NF_TARGET_CROSS 4     /* Cross(mu, sigma), d = 2, example/targets/cross.jl:30-37 (s0 = mu, s1 = sigma) */
 
 #define NF_MAX_HIDDEN 4
 

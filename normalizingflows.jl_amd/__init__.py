@@ -5,7 +5,7 @@ docs/src/api.md) over the C ABI of libnfhip.so (include/nfhip.h).  There is no C
 importing works anywhere, computing needs a gfx950 GPU and the built library.
 """
 from ._lib import LIB_PATH, SYMBOLS, Context, NFHipError, context_for, load_library
-from .flows import (BananaTarget, DiagGaussTarget, Flow, MvNormal, PhiloxRNG, Transform, as_batch, base_logpdf,
+from .flows import (BananaTarget, CrossTarget, DiagGaussTarget, FunnelTarget, WarpedGaussTarget, Flow, MvNormal, PhiloxRNG, Transform, as_batch, base_logpdf,
                     device_specific_rand, inverse, layer, logpdf, meanfield, new_batch, nsf, planarflow, radialflow,
                     rand, realnvp, target_logp, transform, with_logabsdet_jacobian)
 from .parallel import ShardedObjective, allreduce_grad_loss, make_gpu_local_step, shard_range
@@ -19,5 +19,5 @@ __all__ = [
     "planarflow", "radialflow", "realnvp", "nsf", "meanfield",
     "with_logabsdet_jacobian", "transform", "inverse", "logpdf", "rand", "layer",
     "MvNormal", "PhiloxRNG", "device_specific_rand", "_device_specific_rand",
-    "DiagGaussTarget", "BananaTarget", "Adam", "value_and_gradient",
+    "DiagGaussTarget", "BananaTarget", "FunnelTarget", "WarpedGaussTarget", "CrossTarget", "Adam", "value_and_gradient",
 ]

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libnfhip.so")
 
 NF_KIND = {"planar": 0, "radial": 1, "realnvp": 2, "nsf": 3, "meanfield": 4}
 NF_DTYPE_F32, NF_DTYPE_F64 = 0, 1
-NF_TARGET_DIAGGAUSS, NF_TARGET_BANANA = 0, 1
+NF_TARGET_DIAGGAUSS, NF_TARGET_BANANA, NF_TARGET_FUNNEL, NF_TARGET_WARPED, NF_TARGET_CROSS = 0, 1, 2, 3, 4
 NF_MAX_HIDDEN = 4
 
 

@@ -87,6 +87,81 @@ __global__ __launch_bounds__(EW_BLOCK) void k_base_logpdf(int d, long N, const T
 // ---------------------------------------------------------------------------------------
 // targets + ELBO assembly
 // ---------------------------------------------------------------------------------------
+// Built-in targets.  target_term returns feature i's additive share of log p(y) (their sum over
+// i = 0..d-1 is log p) and g = d log p / d y_i.  y0, y1 are the sample's first two coordinates and
+// s2 = sum_{i>=1} y_i^2 (Funnel only).  s0, s1 are the two scalar parameters of the target:
+//   DIAGGAUSS  MvNormal(mu, Diagonal(var))                   test/flow.jl:43-46
+//   BANANA     (b, var)       example/targets/banana.jl:58-63,77-83
+//   FUNNEL     (mu, sigma)    example/targets/neal_funnel.jl:53-72 (`score` is the gradient)
+//   WARPED     (sigma1, sigma2), d = 2   example/targets/warped_gaussian.jl:51-87 (with its + log r term)
+//   CROSS      (mu, sigma), d = 2        example/targets/cross.jl:30-37 (components as the code builds them)
+template <class T>
+__device__ __forceinline__ T target_term(int kind, int d, int i, T v, T y0, T y1, T s2, const T *__restrict__ mu,
+                                         const T *__restrict__ var, T s0, T s1, T &g) {
+  const T L2PI = (T)1.8378770664093453;
+  if (kind == NF_TARGET_DIAGGAUSS) {
+    const T vv = var[i];
+    const T r = v - mu[i];
+    g = -r / vv;
+    return (T)-0.5 * (L2PI + log(vv) + r * r / vv);
+  }
+  if (kind == NF_TARGET_BANANA) {
+    const T y2 = y1 + s0 * y0 * y0 - s1 * s0;
+    if (i == 0) {
+      g = -v / s1 - (T)2 * s0 * v * y2;
+      return (T)-0.5 * v * v / s1 - (log(s1) / (T)d + L2PI) * (T)d / (T)2;
+    }
+    if (i == 1) {
+      g = -y2;
+      return (T)-0.5 * y2 * y2;
+    }
+    g = -v;
+    return (T)-0.5 * v * v;
+  }
+  if (kind == NF_TARGET_FUNNEL) {
+    const T a = exp(-y0);
+    if (i == 0) {
+      const T z = (y0 - s0) / s1;
+      g = -z / s1 - (T)(d - 1) / (T)2 + a * s2 / (T)2;
+      return (T)-0.5 * L2PI - log(s1) - (T)0.5 * z * z - (T)0.5 * (T)(d - 1) * (L2PI + y0);
+    }
+    g = -a * v;
+    return (T)-0.5 * a * v * v;
+  }
+  if (kind == NF_TARGET_WARPED) {
+    const T r = sqrt(y0 * y0 + y1 * y1);
+    const T th = atan2(y1, y0) + r / (T)2;
+    const T c = cos(th), sn = sin(th);
+    const T zx = r * c, zy = r * sn;
+    const T dr = (i == 0 ? y0 : y1) / r;
+    const T dth = i == 0 ? -y1 / (r * r) + y0 / ((T)2 * r) : y0 / (r * r) + y1 / ((T)2 * r);
+    g = -zx / (s0 * s0) * (dr * c - r * sn * dth) - zy / (s1 * s1) * (dr * sn + r * c * dth) + dr / r;
+    if (i != 0) return (T)0;
+    return (T)-0.5 * (zx * zx / (s0 * s0) + zy * zy / (s1 * s1)) - L2PI - log(s0) - log(s1) + log(r);
+  }
+  // CROSS: equal-weight mixture of 4 diagonal Gaussians
+  const T mx[4] = {(T)0, -s0, s0, (T)0}, my[4] = {s0, (T)1, (T)1, -s0};
+  const T sx[4] = {s1, (T)1, (T)1, s1}, sy[4] = {(T)1, s1, s1, (T)1};
+  T lg[4], m = (T)-1e300;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const T a = (y0 - mx[k]) / sx[k], b = (y1 - my[k]) / sy[k];
+    lg[k] = -L2PI - log(sx[k]) - log(sy[k]) - (T)0.5 * (a * a + b * b);
+    m = lg[k] > m ? lg[k] : m;
+  }
+  T sw = 0, gw = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const T w = exp(lg[k] - m);
+    sw += w;
+    gw += w * (i == 0 ? -(y0 - mx[k]) / (sx[k] * sx[k]) : -(y1 - my[k]) / (sy[k] * sy[k]));
+  }
+  g = gw / sw;
+  if (i != 0) return (T)0;
+  return log((T)0.25) + m + log(sw);
+}
+__host__ __device__ inline bool target_needs_d2(int kind) { return kind == NF_TARGET_WARPED || kind == NF_TARGET_CROSS; }
+
 // logp per sample, optional outputs:
 //   logp_out[j]                                 (nf_target_logp)
 //   grad_out[j*d+i] = gscale * dlogp/dy_i        (gscale = 1 for the API, -1/N for the loss)
@@ -104,37 +179,20 @@ __global__ __launch_bounds__(EW_BLOCK) void k_target(int kind, int d, long N, co
   const long j = (long)blockIdx.x * SPB + (threadIdx.x / LPS);
   const bool valid = j < N;
   T acc = 0;
+  T s2 = 0;
+  if (kind == NF_TARGET_FUNNEL) {  // sum_{i>=1} y_i^2 of the sample, needed by feature 0's gradient
+    if (valid)
+      for (int i = q; i < d; i += LPS)
+        if (i >= 1) s2 += y[j * d + i] * y[j * d + i];
+    s2 = group16_sum(s2);
+  }
   if (valid) {
     const T *yr = y + j * d;
-    if (kind == NF_TARGET_DIAGGAUSS) {
-      for (int i = q; i < d; i += LPS) {
-        const T v = var[i];
-        const T r = yr[i] - mu[i];
-        acc += (T)1.8378770664093453 + log(v) + r * r / v;
-        if (grad_out) grad_out[j * d + i] = gscale * (-r / v);
-      }
-      acc = (T)-0.5 * acc;
-    } else {  // Banana: example/targets/banana.jl:58-63,77-83
-      const T y0 = yr[0];
-      const T y2 = yr[1] + b_ban * y0 * y0 - var_ban * b_ban;
-      for (int i = q; i < d; i += LPS) {
-        const T v = yr[i];
-        T term, g;
-        if (i == 0) {
-          term = v * v / var_ban;
-          g = -v / var_ban - (T)2 * b_ban * v * y2;
-        } else if (i == 1) {
-          term = y2 * y2;
-          g = -y2;
-        } else {
-          term = v * v;
-          g = -v;
-        }
-        acc += term;
-        if (grad_out) grad_out[j * d + i] = gscale * g;
-      }
-      acc = (T)-0.5 * acc;
-      if (q == 0) acc -= (log(var_ban) / (T)d + (T)1.8378770664093453) * (T)d / (T)2;
+    const T y0 = yr[0], y1 = d > 1 ? yr[1] : (T)0;
+    for (int i = q; i < d; i += LPS) {
+      T g;
+      acc += target_term<T>(kind, d, i, yr[i], y0, y1, s2, mu, var, b_ban, var_ban, g);
+      if (grad_out) grad_out[j * d + i] = gscale * g;
     }
   }
   acc = group16_sum(acc);
@@ -322,30 +380,22 @@ __global__ __launch_bounds__(EW_BLOCK) void k_target_tiled(int kind, int d, long
   const float *yb = yt + tile * d * TL + s;
   float *gb = gt ? gt + tile * d * TL + s : nullptr;
   float acc = 0.f;
-  if (kind == NF_TARGET_DIAGGAUSS) {
+  float s2 = 0.f;
+  if (kind == NF_TARGET_FUNNEL) {
+    for (int i = q; i < d; i += FS)
+      if (i >= 1) s2 += yb[(long)i * TL] * yb[(long)i * TL];
+    red[q][s] = s2;
+    __syncthreads();
+    s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < FS; ++k) s2 += red[k][s];
+    __syncthreads();
+  }
+  {
+    const float y0 = yb[0], y1 = d > 1 ? yb[TL] : 0.f;
     for (int i = q; i < d; i += FS) {
-      const float v = var[i];
-      const float r = yb[(long)i * TL] - mu[i];
-      acc += 1.8378770664093453f + logf(v) + r * r / v;
-      if (gb) gb[(long)i * TL] = valid ? gscale * (-r / v) : 0.f;
-    }
-  } else {  // Banana: example/targets/banana.jl:58-63,77-83
-    const float y0 = yb[0];
-    const float y2 = yb[TL] + b_ban * y0 * y0 - var_ban * b_ban;
-    for (int i = q; i < d; i += FS) {
-      const float v = yb[(long)i * TL];
-      float term, g;
-      if (i == 0) {
-        term = v * v / var_ban;
-        g = -v / var_ban - 2.f * b_ban * v * y2;
-      } else if (i == 1) {
-        term = y2 * y2;
-        g = -y2;
-      } else {
-        term = v * v;
-        g = -v;
-      }
-      acc += term;
+      float g;
+      acc += target_term<float>(kind, d, i, yb[(long)i * TL], y0, y1, s2, mu, var, b_ban, var_ban, g);
       if (gb) gb[(long)i * TL] = valid ? gscale * g : 0.f;
     }
   }
@@ -356,8 +406,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_target_tiled(int kind, int d, long
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < FS; ++k) t += red[k][s];
-    float e = -0.5f * t;
-    if (kind != NF_TARGET_DIAGGAUSS) e -= (logf(var_ban) / (float)d + 1.8378770664093453f) * (float)d / 2.f;
+    float e = t;
     if (logq) e -= logq[j];
     if (ladj) e += ladj[j];
     if (elbos_out) elbos_out[j] = e;
@@ -438,15 +487,25 @@ int nf_launch_base_logpdf(nf_ctx *ctx, int dtype, int d, long N, const void *x, 
 }
 
 // number of block partials k_target produces for a batch of N
+// argument conventions of the built-in targets
+int nf_target_check(const nf_target *t, int d) {
+  switch (t->kind) {
+    case NF_TARGET_DIAGGAUSS: return (t->p0 && t->p1) ? NF_OK : NF_ERR_ARG;
+    case NF_TARGET_BANANA: return (d >= 2 && t->s1 > 0) ? NF_OK : NF_ERR_ARG;       // banana.jl:40-44
+    case NF_TARGET_FUNNEL: return (d >= 2 && t->s1 > 0) ? NF_OK : NF_ERR_ARG;       // neal_funnel.jl:31-35
+    case NF_TARGET_WARPED: return (d == 2 && t->s0 > 0 && t->s1 > 0) ? NF_OK : NF_ERR_ARG;  // warped_gaussian.jl:29-33,79
+    case NF_TARGET_CROSS: return (d == 2 && t->s1 > 0) ? NF_OK : NF_ERR_ARG;
+    default: return NF_ERR_ARG;
+  }
+}
+
 long nf_target_nblocks(long N) { return nblk(N, SPB); }
 
 int nf_launch_target(nf_ctx *ctx, int dtype, const nf_target *t, int d, long N, const void *y, const void *logq,
                      const void *ladj, void *logp_out, void *grad_out, double gscale, void *elbos_out, double *partial,
                      double pscale) {
   if (N <= 0) return NF_OK;
-  if (t->kind != NF_TARGET_DIAGGAUSS && t->kind != NF_TARGET_BANANA) return NF_ERR_ARG;
-  if (t->kind == NF_TARGET_DIAGGAUSS && (!t->p0 || !t->p1)) return NF_ERR_ARG;
-  if (t->kind == NF_TARGET_BANANA && d < 2) return NF_ERR_ARG;
+  NF_TRY(nf_target_check(t, d));
   ProfScope ps(ctx, "target");
   if (dtype == NF_DTYPE_F32)
     hipLaunchKernelGGL(k_target<float>, dim3(nblk(N, SPB)), dim3(EW_BLOCK), 0, ctx->stream, t->kind, d, N,
@@ -540,9 +599,7 @@ int nf_launch_target_tiled(nf_ctx *ctx, const nf_target *t, int d, long N, const
                            const float *ladj, float *gt, double gscale, float *elbos_out, double *partial,
                            double pscale) {
   if (N <= 0) return NF_OK;
-  if (t->kind != NF_TARGET_DIAGGAUSS && t->kind != NF_TARGET_BANANA) return NF_ERR_ARG;
-  if (t->kind == NF_TARGET_DIAGGAUSS && (!t->p0 || !t->p1)) return NF_ERR_ARG;
-  if (t->kind == NF_TARGET_BANANA && d < 2) return NF_ERR_ARG;
+  NF_TRY(nf_target_check(t, d));
   ProfScope ps(ctx, "target");
   hipLaunchKernelGGL(k_target_tiled, dim3((unsigned)nf_target_tiled_nblocks(N)), dim3(EW_BLOCK), 0, ctx->stream,
                      t->kind, d, N, yt, (const float *)t->p0, (const float *)t->p1, (float)t->s0, (float)t->s1, logq,

@@ -325,6 +325,47 @@ class BananaTarget:
         return target_logp(self, ys)
 
 
+class FunnelTarget:
+    """Funnel(d, mu, sigma)  (example/targets/neal_funnel.jl:26-44; default Funnel(d) = Funnel(d, 0, 9))."""
+
+    def __init__(self, d: int, mu: float = 0.0, sigma: float = 9.0):
+        if d < 2:
+            raise ValueError("dim must be >= 2")  # neal_funnel.jl:32
+        if not sigma > 0:
+            raise ValueError("σ must be > 0")  # neal_funnel.jl:33
+        self.d, self.mu, self.sigma = d, float(mu), float(sigma)
+        self.c = Target(_lib.NF_TARGET_FUNNEL, 0, 0, self.mu, self.sigma)
+
+    def __call__(self, ys):
+        return target_logp(self, ys)
+
+
+class WarpedGaussTarget:
+    """WarpedGauss(σ1, σ2), 2-dimensional  (example/targets/warped_gaussian.jl:25-37; default (1.0, 0.12))."""
+
+    def __init__(self, sigma1: float = 1.0, sigma2: float = 0.12):
+        if not (sigma1 > 0 and sigma2 > 0):
+            raise ValueError("σ₁, σ₂ must be > 0")  # warped_gaussian.jl:31-32
+        self.d, self.sigma1, self.sigma2 = 2, float(sigma1), float(sigma2)
+        self.c = Target(_lib.NF_TARGET_WARPED, 0, 0, self.sigma1, self.sigma2)
+
+    def __call__(self, ys):
+        return target_logp(self, ys)
+
+
+class CrossTarget:
+    """Cross(μ, σ), 2-dimensional 4-component mixture  (example/targets/cross.jl:29-38; default (2.0, 0.15))."""
+
+    def __init__(self, mu: float = 2.0, sigma: float = 0.15):
+        if not sigma > 0:
+            raise ValueError("σ must be > 0")
+        self.d, self.mu, self.sigma = 2, float(mu), float(sigma)
+        self.c = Target(_lib.NF_TARGET_CROSS, 0, 0, self.mu, self.sigma)
+
+    def __call__(self, ys):
+        return target_logp(self, ys)
+
+
 def target_logp(target, ys: torch.Tensor, with_grad: bool = False):
     ym, vec = as_batch(ys)
     d, n = ym.shape

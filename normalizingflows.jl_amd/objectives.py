@@ -12,10 +12,10 @@ from typing import Callable, Optional
 import torch
 
 from ._lib import NFHipError, check
-from .flows import (BananaTarget, DiagGaussTarget, Flow, PhiloxRNG, _dtype_code, _ptr, as_batch, base_logpdf,
+from .flows import (BananaTarget, CrossTarget, DiagGaussTarget, FunnelTarget, WarpedGaussTarget, Flow, PhiloxRNG, _dtype_code, _ptr, as_batch, base_logpdf,
                     device_specific_rand, new_batch, with_logabsdet_jacobian)
 
-_BUILTIN = (DiagGaussTarget, BananaTarget)
+_BUILTIN = (DiagGaussTarget, BananaTarget, FunnelTarget, WarpedGaussTarget, CrossTarget)
 
 
 def _host_double():

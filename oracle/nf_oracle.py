@@ -727,7 +727,91 @@ def banana_grad(y, b, var):
     return g.astype(y.dtype)
 
 
+def funnel_logp(y, mu, sigma):
+    """Neal's funnel, example/targets/neal_funnel.jl:53-60: y1 ~ N(mu, sigma^2), y_{2..d} | y1 ~ N(0, exp(y1) I)."""
+    d = y.shape[0]
+    l1 = -0.5 * LOG2PI - np.log(sigma) - 0.5 * ((y[0] - mu) / sigma) ** 2
+    l2 = -0.5 * (d - 1) * (LOG2PI + y[0]) - 0.5 * np.exp(-y[0]) * (y[1:] ** 2).sum(axis=0)
+    return (l1 + l2).astype(y.dtype)
+
+
+def funnel_grad(y, mu, sigma):
+    """`score`, example/targets/neal_funnel.jl:62-72."""
+    d = y.shape[0]
+    a = np.exp(-y[0])
+    g = -a * y
+    g[0] = (mu - y[0]) / sigma**2 - (d - 1) / 2.0 + a * (y[1:] ** 2).sum(axis=0) / 2.0
+    return g.astype(y.dtype)
+
+
+def _warped_parts(y):
+    r = np.hypot(y[0], y[1])
+    th = np.arctan2(y[1], y[0]) + r / 2.0
+    return r, th
+
+
+def warped_logp(y, s1, s2):
+    """WarpedGauss(s1, s2), example/targets/warped_gaussian.jl:51-87: z = phi^-1(y) (rotate the angle by
+    r/2), logJ = log r."""
+    r, th = _warped_parts(y)
+    zx, zy = r * np.cos(th), r * np.sin(th)
+    return (-0.5 * (zx**2 / s1**2 + zy**2 / s2**2) - LOG2PI - np.log(s1) - np.log(s2) + np.log(r)).astype(y.dtype)
+
+
+def warped_grad(y, s1, s2):
+    x, yy = y[0], y[1]
+    r, th = _warped_parts(y)
+    c, sn = np.cos(th), np.sin(th)
+    zx, zy = r * c, r * sn
+    out = np.empty_like(y)
+    for k, (dr, dth) in enumerate(((x / r, -yy / r**2 + x / (2 * r)), (yy / r, x / r**2 + yy / (2 * r)))):
+        dzx = dr * c - r * sn * dth
+        dzy = dr * sn + r * c * dth
+        out[k] = -zx / s1**2 * dzx - zy / s2**2 * dzy + dr / r
+    return out.astype(y.dtype)
+
+
+def _cross_components(mu, sigma):
+    """Cross(mu, sigma), example/targets/cross.jl:30-37, components exactly as the code builds them
+    (means and per-coordinate standard deviations; equal weights)."""
+    means = np.array([[0.0, mu], [-mu, 1.0], [mu, 1.0], [0.0, -mu]])
+    stds = np.array([[sigma, 1.0], [1.0, sigma], [1.0, sigma], [sigma, 1.0]])
+    return means, stds
+
+
+def _cross_comp_logs(y, mu, sigma):
+    means, stds = _cross_components(mu, sigma)
+    logs = []
+    for m, sd in zip(means, stds):
+        logs.append(-LOG2PI - np.log(sd[0]) - np.log(sd[1])
+                    - 0.5 * (((y[0] - m[0]) / sd[0]) ** 2 + ((y[1] - m[1]) / sd[1]) ** 2))
+    return np.stack(logs), means, stds
+
+
+def cross_logp(y, mu, sigma):
+    logs, _, _ = _cross_comp_logs(y, mu, sigma)
+    mx = logs.max(axis=0)
+    return (np.log(0.25) + mx + np.log(np.exp(logs - mx).sum(axis=0))).astype(y.dtype)
+
+
+def cross_grad(y, mu, sigma):
+    logs, means, stds = _cross_comp_logs(y, mu, sigma)
+    w = np.exp(logs - logs.max(axis=0))
+    w = w / w.sum(axis=0)
+    g = np.zeros_like(y)
+    for k in range(4):
+        g[0] += w[k] * (-(y[0] - means[k, 0]) / stds[k, 0] ** 2)
+        g[1] += w[k] * (-(y[1] - means[k, 1]) / stds[k, 1] ** 2)
+    return g.astype(y.dtype)
+
+
 def target_logp(target, y):
+    if target[0] == "funnel":
+        return funnel_logp(y, target[1], target[2])
+    if target[0] == "warped":
+        return warped_logp(y, target[1], target[2])
+    if target[0] == "cross":
+        return cross_logp(y, target[1], target[2])
     if target[0] == "diaggauss":
         return diaggauss_logp(y, target[1], target[2])
     if target[0] == "banana":
@@ -736,6 +820,12 @@ def target_logp(target, y):
 
 
 def target_grad(target, y):
+    if target[0] == "funnel":
+        return funnel_grad(y, target[1], target[2])
+    if target[0] == "warped":
+        return warped_grad(y, target[1], target[2])
+    if target[0] == "cross":
+        return cross_grad(y, target[1], target[2])
     if target[0] == "diaggauss":
         return diaggauss_grad(y, target[1], target[2])
     if target[0] == "banana":

@@ -358,3 +358,54 @@ def test_wide_cfg4_shard_properties(nf):
     lb2, gb = nf.value_and_gradient(nf.elbo_batch, flow, tgt, xs[:, 10000:], n_global=n)
     assert la + lb2 == pytest.approx(loss, rel=1e-5)
     assert float((ga + gb - g).abs().max()) <= 1e-4 * float(g.abs().max())
+
+
+@pytest.mark.parametrize("name", ["funnel", "warped", "cross"])
+@pytest.mark.parametrize("dtn", ["float32", "float64"])
+def test_synthetic_targets_logp_and_score(nf, name, dtn):
+    """Device versions of the demos' synthetic targets (example/targets/*.jl): log-density and score
+    against the oracle, in both layouts' kernels (nf_target_logp here; the tiled kernel through the ELBO
+    of a coupling flow below)."""
+    dt = tdt(dtn)
+    if name == "funnel":
+        d, tgt, otgt = 6, nf.FunnelTarget(6, 0.3, 2.0), ("funnel", 0.3, 2.0)
+    elif name == "warped":
+        d, tgt, otgt = 2, nf.WarpedGaussTarget(1.0, 0.12), ("warped", 1.0, 0.12)
+    else:
+        d, tgt, otgt = 2, nf.CrossTarget(2.0, 0.15), ("cross", 2.0, 0.15)
+    rng = np.random.default_rng(7)
+    y = (rng.standard_normal((d, 333)) * 1.2).astype(np.float32 if dtn == "float32" else np.float64)
+    lp, g = nf.target_logp(tgt, cm(y, dt), with_grad=True)
+    y64 = y.astype(np.float64)
+    rt = 2e-5 if dtn == "float32" else 1e-10
+    assert approx(lp.cpu().numpy(), o.target_logp(otgt, y64), rt)
+    assert approx(g.cpu().numpy(), o.target_grad(otgt, y64), rt)
+    # ELBO value and gradient with a planar flow (standard layout) ...
+    pd = torch.float64 if dtn == "float64" else torch.float32
+    flow = nf.planarflow(nf.MvNormal(d), 3, paramtype=pd, seed=2)
+    spec = o.FlowSpec("planar", d, 3)
+    xs = rng.standard_normal((d, 200)).astype(y.dtype)
+    th64 = flow.theta.cpu().numpy().astype(np.float64)
+    loss, gr = nf.value_and_gradient(nf.elbo_batch, flow, tgt, cm(xs, dt))
+    lref, gref = o.neg_elbo_value_and_grad(spec, th64, otgt, xs.astype(np.float64))
+    assert loss == pytest.approx(lref, rel=10 * rt)
+    assert np.abs(gr.cpu().numpy() - gref).max() <= (2e-4 if dtn == "float32" else 1e-9) * np.abs(gref).max()
+    # ... and with a coupling flow (tiled layout)
+    if dtn == "float32":
+        fl2 = nf.realnvp(nf.MvNormal(d), [16, 16], 1, paramtype=torch.float32, seed=4)
+        sp2 = o.FlowSpec("realnvp", d, 1, (16, 16))
+        l2, g2 = nf.value_and_gradient(nf.elbo_batch, fl2, tgt, cm(xs, dt))
+        lr2, gr2 = o.neg_elbo_value_and_grad(sp2, fl2.theta.cpu().numpy().astype(np.float64), otgt, xs.astype(np.float64))
+        assert l2 == pytest.approx(lr2, rel=2e-5)
+        assert np.abs(g2.cpu().numpy() - gr2).max() <= 2e-4 * np.abs(gr2).max()
+
+
+def test_target_argument_conventions(nf):
+    """Constructor checks of the reference's target types (banana.jl:40-44, neal_funnel.jl:31-35,
+    warped_gaussian.jl:29-33) and the dimension contract of the 2-d targets."""
+    with pytest.raises(ValueError):
+        nf.FunnelTarget(1)
+    with pytest.raises(ValueError):
+        nf.WarpedGaussTarget(1.0, -0.1)
+    with pytest.raises(nf.NFHipError):
+        nf.target_logp(nf.CrossTarget(), torch.zeros(3, 4, device="cuda"))  # Cross is 2-dimensional

@@ -215,3 +215,35 @@ def test_meanfield_training_recovers_target():
     assert np.all(np.abs(th[:2] - 10.0) < 0.2) and np.all(np.abs(th[2:] - 2.0) < 0.2)
     el1 = o.elbo_batch(spec, th, tgt, rng.standard_normal((2, 1000)))
     assert el1 > el0 and el1 > -1.0
+
+
+@pytest.mark.parametrize("tgt,d", [(("funnel", 0.3, 2.0), 5), (("warped", 1.0, 0.12), 2), (("cross", 2.0, 0.15), 2)],
+                         ids=["funnel", "warped", "cross"])
+def test_synthetic_targets_gradient_matches_finite_differences(tgt, d):
+    """example/targets/{neal_funnel,warped_gaussian,cross}.jl restated; the hand-derived scores are
+    checked against central differences of the log-density."""
+    rng = np.random.default_rng(3)
+    y = rng.standard_normal((d, 9)) * 1.3
+    g = o.target_grad(tgt, y)
+    eps, gn = 1e-6, np.zeros_like(y)
+    for i in range(d):
+        yp, ym = y.copy(), y.copy()
+        yp[i] += eps
+        ym[i] -= eps
+        gn[i] = (o.target_logp(tgt, yp) - o.target_logp(tgt, ym)) / (2 * eps)
+    assert np.abs(g - gn).max() <= 1e-7 * max(1.0, np.abs(gn).max())
+
+
+def test_synthetic_targets_analytic_anchors():
+    """Known values: the funnel at y = (mu, 0, ..) ; the cross mixture integrates to one; the funnel's
+    conditional is N(0, exp(y1)) (neal_funnel.jl:14-16)."""
+    d, mu, sg = 4, 0.5, 3.0
+    y = np.zeros((d, 1))
+    y[0] = mu
+    expect = -0.5 * o.LOG2PI - np.log(sg) - 0.5 * (d - 1) * (o.LOG2PI + mu)
+    assert o.target_logp(("funnel", mu, sg), y)[0] == pytest.approx(expect, rel=1e-13)
+    xs = np.linspace(-8, 8, 801)
+    X, Y = np.meshgrid(xs, xs)
+    P = np.stack([X.ravel(), Y.ravel()])
+    mass = np.exp(o.target_logp(("cross", 2.0, 0.3), P)).sum() * (xs[1] - xs[0]) ** 2
+    assert mass == pytest.approx(1.0, abs=1e-6)
