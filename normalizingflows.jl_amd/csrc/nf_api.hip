@@ -57,6 +57,10 @@ int nf_wide_apply(nf_ctx *, const nf_flow_desc *, int k, bool inverse, float *xt
 size_t nf_wide_bwd_ws_floats(nf_ctx *, const nf_flow_desc *, long N);
 int nf_wide_bwd(nf_ctx *, const nf_flow_desc *, float *state, float *gbar, const float *lbar, float lbar_const, long N,
                 float *ws, float *g_out);
+size_t nf_wide_train_ws_floats(nf_ctx *, const nf_flow_desc *, long N);
+int nf_wide_train_forward(nf_ctx *, const nf_flow_desc *, float *xt, long N, float *ladj, float *ws);
+int nf_wide_train_backward(nf_ctx *, const nf_flow_desc *, float *state, float *gbar, const float *lbar,
+                           float lbar_const, long N, float *ws, float *g_out);
 
 // neural spline couplings (nf_rqs.hip)
 bool nf_rqs_supported(const nf_flow_desc *desc);
@@ -529,7 +533,8 @@ extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, con
   const long nb = cp ? nf_target_tiled_nblocks(N) : nf_target_nblocks(N);
   const int grid = cp ? coupling_bwd_grid(ctx, desc, N) : 0;
   const size_t simple_ws = cp ? 0 : nf_simple_bwd_ws_bytes(ctx, desc, N);
-  const size_t slabf = cp ? (size_t)grid * coupling_slab_floats(ctx, desc, N) : 0;
+  const bool wide = cp && is_wide(desc);
+  const size_t slabf = wide ? nf_wide_train_ws_floats(ctx, desc, N) : cp ? (size_t)grid * coupling_slab_floats(ctx, desc, N) : 0;
   const size_t xe = cp ? tiled_elems(desc, N) : (size_t)N * desc->d;
   const size_t need = 3 * carve_bytes(xe * es) + 2 * carve_bytes((size_t)N * es) + carve_bytes((size_t)nb * 8) +
                       carve_bytes(64) + carve_bytes(slabf * es) + carve_bytes(simple_ws);
@@ -553,6 +558,22 @@ extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, con
                                 (const float *)target->p1, xt, gt, -inv, partial, -inv));
     NF_TRY(nf_launch_finish_sum(ctx, partial, nf_affine_chain_grid(ctx, N), 0, nullptr, (float *)out + P, nullptr));
     return realnvp_bwd(ctx, desc, (const float *)theta, xt, gt, nullptr, (float)(-inv), N, (float *)slab, grid, (float *)out);
+  }
+  if (wide) {
+    // wide RealNVP: the forward pass keeps its activations (HBM stash), the reverse pass recomputes nothing
+    float *xt = (float *)x, *gt = (float *)gbar;
+    if (xs) {
+      NF_TRY(nf_launch_layout_convert(ctx, desc->d, N, (const float *)xs, xt, 1));
+      NF_TRY(nf_launch_base_logpdf_tiled(ctx, desc->d, N, xt, (float *)logq));
+    } else {
+      NF_TRY(nf_launch_base_sample_tiled(ctx, desc->d, N, seed, sample_offset, stream_id, xt, (float *)logq));
+    }
+    NF_TRY(coupling_pack(ctx, desc, (const float *)theta));
+    NF_TRY(nf_wide_train_forward(ctx, desc, xt, N, (float *)ladj, (float *)slab));
+    NF_TRY(nf_launch_target_tiled(ctx, target, desc->d, N, xt, (const float *)logq, (const float *)ladj, gt, -inv,
+                                  nullptr, partial, -inv));
+    NF_TRY(nf_launch_finish_sum(ctx, partial, nb, 0, nullptr, (float *)out + P, nullptr));
+    return nf_wide_train_backward(ctx, desc, xt, gt, nullptr, (float)(-inv), N, (float *)slab, (float *)out);
   }
   if (cp) {
     float *xt = (float *)x, *gt = (float *)gbar;

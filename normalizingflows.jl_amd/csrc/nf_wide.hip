@@ -234,97 +234,6 @@ struct WideArgs {
 // ------------------------------------------------------------------------------------
 // forward / inverse of one coupling, in place on the tiled batch
 // ------------------------------------------------------------------------------------
-template <class G, bool INVERSE>
-__global__ __launch_bounds__(256, 1) void k_wide_apply(WideArgs a, float *xt, float *__restrict__ ladj, int accumulate) {
-  using W = Wide<G>;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float *cb = lds;
-  float *bias = lds + 2 * W::CHBUF;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, hi = lane >> 5;
-  const int par_c = 1 - a.par_t;
-  const long ntiles = (a.N + NF_TILE - 1) / NF_TILE;
-  const long ngroups = (ntiles + 3) / 4;
-
-  const wide_img_t img_s = make_img(a.img_s, G::SIZE), img_t = make_img(a.img_t, G::SIZE);
-  issue_chunk(img_s, G::W1, W::CF1, cb, wave, lane);
-  stage_biases<G>(bias, a.img_s, tid);
-  stage_biases<G>(bias + W::NBIAS, a.img_t, tid);
-  __syncthreads();
-  int buf = 0;
-
-  for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    const long tile = grp * 4 + wave;
-    const bool live = tile < ntiles;
-    const long tl = live ? tile : 0;
-    const long j = tl * NF_TILE + l31;
-    const bool valid = live && j < a.N;
-    const bool more = grp + gridDim.x < ngroups;
-    const TileIO io = make_tile_io(xt, tl, a.d, l31, hi);
-    f32x16 S[G::CB], T[G::CB], x1[G::CB];
-    {
-      f32x16 xb[G::MB];
-#pragma unroll
-      for (int b = 0; b < G::MB; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = tile_load(io, tile_soff(b, r, par_c));
-          xb[b][r] = valid ? v : 0.f;
-        }
-      NoHooks nh;
-      wide_net_fwd<G>(img_s, bias, cb, buf, img_t, G::W1, W::CF1, xb, S, wave, lane, nh);
-    }
-    {
-      f32x16 xb[G::MB];
-#pragma unroll
-      for (int b = 0; b < G::MB; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = tile_load(io, tile_soff(b, r, par_c));
-          xb[b][r] = valid ? v : 0.f;
-        }
-      // the transformed half is fetched while the last layer of the t net runs (one batch of loads,
-      // not interleaved with the stores below: the compiler must keep load/store order on one buffer)
-      struct X1Hook : NoHooks {
-        const TileIO &io;
-        f32x16 (&x1)[G::CB];
-        int par_t;
-        __device__ __forceinline__ X1Hook(const TileIO &i, f32x16 (&x)[G::CB], int p) : io(i), x1(x), par_t(p) {}
-        __device__ __forceinline__ void l3_step(int ib, f32x16 (&)[G::H2B]) const {
-          if (ib == 0) {
-#pragma unroll
-            for (int b = 0; b < G::CB; ++b)
-#pragma unroll
-              for (int r = 0; r < 16; ++r) x1[b][r] = tile_load(io, tile_soff(b, r, par_t));
-          }
-        }
-      } xh(io, x1, a.par_t);
-      wide_net_fwd<G>(img_t, bias + W::NBIAS, cb, buf, img_s, G::W1, more ? W::CF1 : 0, xb, T, wave, lane, xh);
-    }
-    float lsum = 0.f;
-#pragma unroll
-    for (int b = 0; b < G::CB; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float s = nf_tanh(S[b][r]);  // padded rows: zero weights and bias => s = 0
-        const float v = x1[b][r];
-        const float o = INVERSE ? __fdividef(v - T[b][r], nf_exp(s)) : v * nf_exp(s) + T[b][r];
-        if (live) tile_store(io, tile_soff(b, r, a.par_t), o);  // rows >= c fall outside the descriptor
-        lsum += s;
-      }
-    lsum += __shfl_xor(lsum, 32);
-    if (hi == 0 && valid) {
-      const float base = accumulate ? ladj[j] : 0.f;
-      ladj[j] = INVERSE ? base - lsum : base + lsum;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------
-// reverse pass, one net per launch (PHASE_S = false: t net, true: s net); see nf_coupling.hip
-// for the two-phase algebra.  Stash tensors: [tile][feature][32 samples].
-// ------------------------------------------------------------------------------------
 struct WideStash {
   float *a1, *a2, *d1, *d2, *d3;
 };
@@ -374,6 +283,226 @@ __device__ __forceinline__ void wide_sign_masks(const f32x16 (&v)[NB], unsigned 
     // all 128 activations alive (in scratch) until then
     asm volatile("" : "+v"(bits));
     m[b] = bits;
+  }
+}
+
+// hooks of the forward kernel: optional stash (STASH) and, for the t net, the prefetch of the
+// transformed half x1 behind the last layer
+template <class G, bool STASH>
+struct ApplyHooks {
+  StashIO sa1, sa2;
+  unsigned *mask;  // this lane's slot in the tile's mask block, or nullptr
+  const TileIO *io;
+  f32x16 (*x1)[G::CB];
+  int par_t;
+  __device__ __forceinline__ void after_l1(f32x16 (&a1)[G::H1B]) const {
+    if (STASH) {
+      unsigned m[G::H1B];
+      wide_sign_masks<G::H1B>(a1, m);
+      if (mask) {
+#pragma unroll
+        for (int b = 0; b < G::H1B; ++b) mask[b * 64] = m[b];
+      }
+    }
+  }
+  __device__ __forceinline__ void after_l2(f32x16 (&a2)[G::H2B]) const {
+    if (STASH) {
+      unsigned m[G::H2B];
+      wide_sign_masks<G::H2B>(a2, m);
+      if (mask) {
+#pragma unroll
+        for (int b = 0; b < G::H2B; ++b) mask[(8 + b) * 64] = m[b];
+      }
+    }
+  }
+  __device__ __forceinline__ void l2_step(int ib, f32x16 (&a1)[G::H1B]) const {
+    if (STASH) stash_store_range<G::H1B>(sa1, a1, ib * 16, 16);
+  }
+  __device__ __forceinline__ void l3_step(int ib, f32x16 (&a2)[G::H2B]) const {
+    if (STASH) stash_store_range<G::H2B>(sa2, a2, ib * 16, 16);
+    if (io && ib == 0) {
+#pragma unroll
+      for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) (*x1)[b][r] = tile_load(*io, tile_soff(b, r, par_t));
+    }
+  }
+};
+
+// Forward stash of the TRAINING step (memory is cheap on this part: 86 KB per sample for the whole
+// cfg-4 flow): per coupling and net the hidden activations a1, a2 (the dW GEMM's A operands), the
+// output layer's result (S before tanh, or T) and the leaky-ReLU sign masks, so that the reverse pass
+// needs no recompute at all.  Index 0 = s net, 1 = t net.  Masks: [tile][16 words][64 lanes].
+struct FwdStash {
+  float *a1[2], *a2[2], *out[2];
+  unsigned *mask[2];
+};
+
+template <class G, bool INVERSE, bool STASH = false>
+__global__ __launch_bounds__(256, 1) void k_wide_apply(WideArgs a, float *xt, float *__restrict__ ladj, int accumulate,
+                                                       FwdStash fs) {
+  using W = Wide<G>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *cb = lds;
+  float *bias = lds + 2 * W::CHBUF;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int par_c = 1 - a.par_t;
+  const long ntiles = (a.N + NF_TILE - 1) / NF_TILE;
+  const long ngroups = (ntiles + 3) / 4;
+
+  const wide_img_t img_s = make_img(a.img_s, G::SIZE), img_t = make_img(a.img_t, G::SIZE);
+  issue_chunk(img_s, G::W1, W::CF1, cb, wave, lane);
+  stage_biases<G>(bias, a.img_s, tid);
+  stage_biases<G>(bias + W::NBIAS, a.img_t, tid);
+  __syncthreads();
+  int buf = 0;
+
+  for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const long tile = grp * 4 + wave;
+    const bool live = tile < ntiles;
+    const long tl = live ? tile : 0;
+    const long j = tl * NF_TILE + l31;
+    const bool valid = live && j < a.N;
+    const bool more = grp + gridDim.x < ngroups;
+    const TileIO io = make_tile_io(xt, tl, a.d, l31, hi);
+    f32x16 S[G::CB], T[G::CB], x1[G::CB];
+    {
+      f32x16 xb[G::MB];
+#pragma unroll
+      for (int b = 0; b < G::MB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = tile_load(io, tile_soff(b, r, par_c));
+          xb[b][r] = valid ? v : 0.f;
+        }
+      ApplyHooks<G, STASH> hk{make_stash_io(fs.a1[0], tl, (STASH && live) ? 32 * G::H1B : 0, l31, hi),
+                              make_stash_io(fs.a2[0], tl, (STASH && live) ? 32 * G::H2B : 0, l31, hi),
+                              (STASH && live) ? fs.mask[0] + tl * (16 * 64) + lane : nullptr, nullptr, nullptr, 0};
+      wide_net_fwd<G>(img_s, bias, cb, buf, img_t, G::W1, W::CF1, xb, S, wave, lane, hk);
+      if (STASH) stash_store<G::CB>(make_stash_io(fs.out[0], tl, live ? 32 * G::CB : 0, l31, hi), S);
+    }
+    {
+      f32x16 xb[G::MB];
+#pragma unroll
+      for (int b = 0; b < G::MB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = tile_load(io, tile_soff(b, r, par_c));
+          xb[b][r] = valid ? v : 0.f;
+        }
+      // the transformed half is fetched while the last layer of the t net runs (one batch of loads,
+      // not interleaved with the stores below: the compiler must keep load/store order on one buffer)
+      ApplyHooks<G, STASH> hk{make_stash_io(fs.a1[1], tl, (STASH && live) ? 32 * G::H1B : 0, l31, hi),
+                              make_stash_io(fs.a2[1], tl, (STASH && live) ? 32 * G::H2B : 0, l31, hi),
+                              (STASH && live) ? fs.mask[1] + tl * (16 * 64) + lane : nullptr, &io, &x1, a.par_t};
+      wide_net_fwd<G>(img_t, bias + W::NBIAS, cb, buf, img_s, G::W1, more ? W::CF1 : 0, xb, T, wave, lane, hk);
+      if (STASH) stash_store<G::CB>(make_stash_io(fs.out[1], tl, live ? 32 * G::CB : 0, l31, hi), T);
+    }
+    float lsum = 0.f;
+#pragma unroll
+    for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float s = nf_tanh(S[b][r]);  // padded rows: zero weights and bias => s = 0
+        const float v = x1[b][r];
+        const float o = INVERSE ? __fdividef(v - T[b][r], nf_exp(s)) : v * nf_exp(s) + T[b][r];
+        if (live) tile_store(io, tile_soff(b, r, a.par_t), o);  // rows >= c fall outside the descriptor
+        lsum += s;
+      }
+    lsum += __shfl_xor(lsum, 32);
+    if (hi == 0 && valid) {
+      const float base = accumulate ? ladj[j] : 0.f;
+      ladj[j] = INVERSE ? base - lsum : base + lsum;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// reverse pass, one net per launch (PHASE_S = false: t net, true: s net); see nf_coupling.hip
+// for the two-phase algebra.  Stash tensors: [tile][feature][32 samples].
+// ------------------------------------------------------------------------------------
+// dX chain of the reverse pass: W3^T, W2^T, W1^T, one output block per chunk; every chunk step also
+// sends a slice of the pending stash stores (d3, d2, d1) on its way.  On entry chunk (W3, rows 0..31)
+// is resident in cb[buf]; on exit chunk (next_off, next_floats) is (or nothing if next_floats == 0).
+// x2bar: ybar's conditioner half += W1^T d1.
+template <class G>
+__device__ __forceinline__ void wide_dx_chain(wide_img_t img, float *cb, int &buf, f32x16 (&d3)[G::CB],
+                                              const unsigned (&m1)[G::H1B], const unsigned (&m2)[G::H2B],
+                                              const StashIO &sd1, const StashIO &sd2, const StashIO &sd3,
+                                              const TileIO &gio, int par_c, bool live, int next_off, int next_floats,
+                                              int wave, int lane, long long *tr) {
+  using W = Wide<G>;
+  const int l31 = lane & 31, hi = lane >> 5;
+  // ---- dX chain: W3^T, W2^T, W1^T, one output block per chunk; every chunk step also sends a
+  // slice of the pending stash stores on its way
+  f32x16 d2[G::H2B];
+#pragma unroll
+  for (int ib = 0; ib < G::H2B; ++ib) {
+    DmaJob dj{img, 0, 0, cb, wave, lane};
+    if (ib + 1 < G::H2B)
+      dj = DmaJob{img, G::W3 + (ib + 1) * W::CF3, W::CF3, cb + (buf ^ 1) * W::CHBUF, wave, lane};
+    else
+      dj = DmaJob{img, G::W2, W::CF2, cb + (buf ^ 1) * W::CHBUF, wave, lane};
+    {
+      constexpr int PER = (G::CB * 16 + G::H2B - 1) / G::H2B;
+      stash_store_range<G::CB>(sd3, d3, ib * PER, PER);
+    }
+    if (ib > 0) stash_store_range<G::H2B>(sd2, d2, (ib - 1) * 16, 16);
+    wide_bwdx_chunk<G::CB, G::S3>(cb + buf * W::CHBUF, d3, d2[ib], l31, hi, dj);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d2[ib][r] *= ((m2[ib] >> r) & 1u) ? 0.01f : 1.f;
+    __syncthreads();
+    buf ^= 1;
+  }
+  WIDE_STAMP(8);
+  WIDE_STAMP(9);
+  WIDE_STAMP(10);
+  f32x16 d1[G::H1B];
+#pragma unroll
+  for (int ib = 0; ib < G::H1B; ++ib) {
+    DmaJob dj{img, 0, 0, cb, wave, lane};
+    if (ib + 1 < G::H1B)
+      dj = DmaJob{img, G::W2 + (ib + 1) * W::CF2, W::CF2, cb + (buf ^ 1) * W::CHBUF, wave, lane};
+    else
+      dj = DmaJob{img, G::W1, W::CF1, cb + (buf ^ 1) * W::CHBUF, wave, lane};
+    if (ib == 0) stash_store_range<G::H2B>(sd2, d2, (G::H2B - 1) * 16, 16);
+    if (ib > 0) stash_store_range<G::H1B>(sd1, d1, (ib - 1) * 16, 16);
+    wide_bwdx_chunk<G::H2B, G::S2>(cb + buf * W::CHBUF, d2, d1[ib], l31, hi, dj);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d1[ib][r] *= ((m1[ib] >> r) & 1u) ? 0.01f : 1.f;
+    __syncthreads();
+    buf ^= 1;
+  }
+  WIDE_STAMP(11);
+  WIDE_STAMP(12);
+  f32x16 g2p;  // x2bar block of the previous chunk, stored behind the next chunk's MFMAs
+#pragma unroll
+  for (int ib = 0; ib < G::MB; ++ib) {
+    DmaJob dj{img, 0, 0, cb, wave, lane};
+    if (ib + 1 < G::MB)
+      dj = DmaJob{img, G::W1 + (ib + 1) * W::CF1, W::CF1, cb + (buf ^ 1) * W::CHBUF, wave, lane};
+    else if (next_floats)
+      dj = DmaJob{img, next_off, next_floats, cb + (buf ^ 1) * W::CHBUF, wave, lane};
+    if (ib == 0) stash_store_range<G::H1B>(sd1, d1, (G::H1B - 1) * 16, 16);
+    if (ib > 0 && live) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tile_store(gio, tile_soff(ib - 1, r, par_c), g2p[r]);
+    }
+    f32x16 gold;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gold[r] = tile_load(gio, tile_soff(ib, r, par_c));
+    f32x16 g2;
+    wide_bwdx_chunk<G::H1B, G::S1>(cb + buf * W::CHBUF, d1, g2, l31, hi, dj);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g2p[r] = gold[r] + g2[r];
+    __syncthreads();
+    buf ^= 1;
+  }
+  if (live) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tile_store(gio, tile_soff(G::MB - 1, r, par_c), g2p[r]);
   }
 }
 
@@ -481,76 +610,90 @@ __global__ __launch_bounds__(256, 1) void k_wide_bwd(WideArgs a, float *__restri
       }
     WIDE_STAMP(7);
 
-    // ---- dX chain: W3^T, W2^T, W1^T, one output block per chunk; every chunk step also sends a
-    // slice of the pending stash stores on its way
-    f32x16 d2[G::H2B];
-#pragma unroll
-    for (int ib = 0; ib < G::H2B; ++ib) {
-      DmaJob dj{img, 0, 0, cb, wave, lane};
-      if (ib + 1 < G::H2B)
-        dj = DmaJob{img, G::W3 + (ib + 1) * W::CF3, W::CF3, cb + (buf ^ 1) * W::CHBUF, wave, lane};
-      else
-        dj = DmaJob{img, G::W2, W::CF2, cb + (buf ^ 1) * W::CHBUF, wave, lane};
-      {
-        constexpr int PER = (G::CB * 16 + G::H2B - 1) / G::H2B;
-        stash_store_range<G::CB>(sd3, d3, ib * PER, PER);
-      }
-      if (ib > 0) stash_store_range<G::H2B>(sd2, d2, (ib - 1) * 16, 16);
-      wide_bwdx_chunk<G::CB, G::S3>(cb + buf * W::CHBUF, d3, d2[ib], l31, hi, dj);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) d2[ib][r] *= ((m2[ib] >> r) & 1u) ? 0.01f : 1.f;
-      __syncthreads();
-      buf ^= 1;
-    }
-    WIDE_STAMP(8);
-    WIDE_STAMP(9);
-    WIDE_STAMP(10);
-    f32x16 d1[G::H1B];
-#pragma unroll
-    for (int ib = 0; ib < G::H1B; ++ib) {
-      DmaJob dj{img, 0, 0, cb, wave, lane};
-      if (ib + 1 < G::H1B)
-        dj = DmaJob{img, G::W2 + (ib + 1) * W::CF2, W::CF2, cb + (buf ^ 1) * W::CHBUF, wave, lane};
-      else
-        dj = DmaJob{img, G::W1, W::CF1, cb + (buf ^ 1) * W::CHBUF, wave, lane};
-      if (ib == 0) stash_store_range<G::H2B>(sd2, d2, (G::H2B - 1) * 16, 16);
-      if (ib > 0) stash_store_range<G::H1B>(sd1, d1, (ib - 1) * 16, 16);
-      wide_bwdx_chunk<G::H2B, G::S2>(cb + buf * W::CHBUF, d2, d1[ib], l31, hi, dj);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) d1[ib][r] *= ((m1[ib] >> r) & 1u) ? 0.01f : 1.f;
-      __syncthreads();
-      buf ^= 1;
-    }
-    WIDE_STAMP(11);
-    WIDE_STAMP(12);
-    f32x16 g2p;  // x2bar block of the previous chunk, stored behind the next chunk's MFMAs
-#pragma unroll
-    for (int ib = 0; ib < G::MB; ++ib) {
-      DmaJob dj{img, 0, 0, cb, wave, lane};
-      if (ib + 1 < G::MB)
-        dj = DmaJob{img, G::W1 + (ib + 1) * W::CF1, W::CF1, cb + (buf ^ 1) * W::CHBUF, wave, lane};
-      else if (more)
-        dj = DmaJob{img, G::W1, W::CF1, cb + (buf ^ 1) * W::CHBUF, wave, lane};
-      if (ib == 0) stash_store_range<G::H1B>(sd1, d1, (G::H1B - 1) * 16, 16);
-      if (ib > 0 && live) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) tile_store(gio, tile_soff(ib - 1, r, par_c), g2p[r]);
-      }
-      f32x16 gold;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) gold[r] = tile_load(gio, tile_soff(ib, r, par_c));
-      f32x16 g2;
-      wide_bwdx_chunk<G::H1B, G::S1>(cb + buf * W::CHBUF, d1, g2, l31, hi, dj);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) g2p[r] = gold[r] + g2[r];
-      __syncthreads();
-      buf ^= 1;
-    }
-    if (live) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) tile_store(gio, tile_soff(G::MB - 1, r, par_c), g2p[r]);
-    }
+    wide_dx_chain<G>(img, cb, buf, d3, m1, m2, sd1, sd2, sd3, gio, par_c, live, G::W1, more ? W::CF1 : 0, wave, lane, tr);
     WIDE_STAMP(13);
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// reverse pass of the TRAINING step: no recompute.  The forward stash supplies the output layer's
+// result and the sign masks; what is left per net is the element-wise stage and the dX chain.
+// ------------------------------------------------------------------------------------
+template <class G, bool PHASE_S>
+__global__ __launch_bounds__(256, 1) void k_wide_bwd_stashed(WideArgs a, float *__restrict__ y, float *__restrict__ ybar,
+                                                             const float *__restrict__ lbar, float lbar_const,
+                                                             WideStash st, const float *__restrict__ fout,
+                                                             const unsigned *__restrict__ fmask) {
+  using W = Wide<G>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *cb = lds;
+  const float *imgp = PHASE_S ? a.img_s : a.img_t;
+  const wide_img_t img = make_img(imgp, G::SIZE);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int par_c = 1 - a.par_t;
+  const long ntiles = (a.N + NF_TILE - 1) / NF_TILE;
+  const long ngroups = (ntiles + 3) / 4;
+
+  issue_chunk(img, G::W3, W::CF3, cb, wave, lane);
+  __syncthreads();
+  int buf = 0;
+
+  for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const long tile = grp * 4 + wave;
+    const bool live = tile < ntiles;
+    const long tl = live ? tile : 0;
+    const long j = tl * NF_TILE + l31;
+    const bool valid = live && j < a.N;
+    const bool more = grp + gridDim.x < ngroups;
+    const TileIO yio = make_tile_io(y, tl, a.d, l31, hi);
+    const TileIO gio = make_tile_io(ybar, tl, a.d, l31, hi);
+    const StashIO sd1 = make_stash_io(st.d1, tl, live ? 32 * G::H1B : 0, l31, hi);
+    const StashIO sd2 = make_stash_io(st.d2, tl, live ? 32 * G::H2B : 0, l31, hi);
+    const StashIO sd3 = make_stash_io(st.d3, tl, live ? 32 * G::CB : 0, l31, hi);
+    const StashIO so = make_stash_io(const_cast<float *>(fout), tl, 32 * G::CB, l31, hi);
+    long long *tr = nullptr;
+
+    unsigned m1[G::H1B], m2[G::H2B];
+    {
+      const unsigned *mp = fmask + tl * (16 * 64) + lane;
+#pragma unroll
+      for (int b = 0; b < G::H1B; ++b) m1[b] = mp[b * 64];
+#pragma unroll
+      for (int b = 0; b < G::H2B; ++b) m2[b] = mp[(8 + b) * 64];
+    }
+    f32x16 d3[G::CB], y1[G::CB], g1[G::CB];
+#pragma unroll
+    for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        d3[b][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(so.rs, so.voff, (b * 32 + (r & 3) + 8 * (r >> 2)) * (NF_TILE * 4), 0));
+        y1[b][r] = tile_load(yio, tile_soff(b, r, a.par_t));
+        g1[b][r] = tile_load(gio, tile_soff(b, r, a.par_t));
+      }
+    const float lb = valid ? (lbar ? lbar[j] : lbar_const) : 0.f;
+#pragma unroll
+    for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int p = b * 32 + nf_row(r, hi);
+        const bool ok = (p < a.c) && valid;
+        const float yv = y1[b][r], gv = g1[b][r];
+        if (!PHASE_S) {
+          if (live) tile_store(yio, tile_soff(b, r, a.par_t), yv - d3[b][r]);  // u = x1 * exp(S)
+          d3[b][r] = ok ? gv : 0.f;
+        } else {
+          const float s = nf_tanh(d3[b][r]);
+          const float es = nf_exp(s);
+          if (live) {
+            tile_store(yio, tile_soff(b, r, a.par_t), __fdividef(yv, es));  // x1 = u * exp(-s)
+            tile_store(gio, tile_soff(b, r, a.par_t), gv * es);             // x1bar
+          }
+          d3[b][r] = ok ? (gv * yv + lb) * (1.f - s * s) : 0.f;
+        }
+      }
+    wide_dx_chain<G>(img, cb, buf, d3, m1, m2, sd1, sd2, sd3, gio, par_c, live, G::W3, more ? W::CF3 : 0, wave, lane, tr);
   }
 }
 
@@ -805,10 +948,11 @@ int nf_wide_apply(nf_ctx *ctx, const nf_flow_desc *desc, int k, bool inverse, fl
   if (grid > ctx->num_cu) grid = ctx->num_cu;
   if (grid < 1) grid = 1;
   ProfScope ps(ctx, "wide_apply");
+  const FwdStash none{};
   if (inverse)
-    hipLaunchKernelGGL((k_wide_apply<GW, true>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, xt, ladj, accumulate);
+    hipLaunchKernelGGL((k_wide_apply<GW, true>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, xt, ladj, accumulate, none);
   else
-    hipLaunchKernelGGL((k_wide_apply<GW, false>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, xt, ladj, accumulate);
+    hipLaunchKernelGGL((k_wide_apply<GW, false>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, xt, ladj, accumulate, none);
   return (int)hipGetLastError();
 }
 
@@ -917,6 +1061,129 @@ int nf_wide_bwd(nf_ctx *ctx, const nf_flow_desc *desc, float *state, float *gbar
       }
       long off = ci.theta_off;
       if (phase == 0) off += net_param_count(ci.m, h1, h2, ci.c);  // t net follows the s net in theta
+      const NetDims nd = make_net_dims(off, ci.m, h1, h2, ci.c);
+      {
+        ProfScope ps(ctx, "reduce_slabs");
+        constexpr int NE = G::B3 + 32 * G::CB;
+        hipLaunchKernelGGL((k_wide_reduce<G>), dim3((NE + 255) / 256), dim3(256), 0, ctx->stream, nd, slab, ks, (long)G::SIZE, g_out);
+        NF_HIP(hipGetLastError());
+      }
+    }
+  }
+  return NF_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// training step (nf_elbo_value_and_grad): forward with stash, reverse pass without recompute
+// ------------------------------------------------------------------------------------
+// workspace layout (floats): [forward stash: per (coupling, net) a1 | a2 | out | masks] [d1 d2 d3] [split-K slab]
+static size_t fwd_stash_floats_per_net(long ntiles) {
+  return (size_t)ntiles * ((size_t)NF_TILE * 32 * (GW::H1B + GW::H2B + GW::CB) + 16 * 64);
+}
+static FwdStash fwd_stash_at(float *base, long ntiles, int k) {
+  FwdStash fs;
+  const size_t per = (size_t)ntiles * NF_TILE * 32;
+  for (int net = 0; net < 2; ++net) {
+    float *p = base + (size_t)(2 * k + net) * fwd_stash_floats_per_net(ntiles);
+    fs.a1[net] = p; p += per * GW::H1B;
+    fs.a2[net] = p; p += per * GW::H2B;
+    fs.out[net] = p; p += per * GW::CB;
+    fs.mask[net] = (unsigned *)p;
+  }
+  return fs;
+}
+
+size_t nf_wide_train_ws_floats(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
+  const long ntiles = (N + NF_TILE - 1) / NF_TILE;
+  const size_t fwd = (size_t)2 * desc->nlayers * 2 * fwd_stash_floats_per_net(ntiles);
+  const size_t dstash = (size_t)ntiles * NF_TILE * 32 * (GW::H1B + GW::H2B + GW::CB);
+  const int ks = wide_ksplit(ctx, ntiles, wide_njobs());
+  return fwd + dstash + (size_t)ks * GW::SIZE + 1024;
+}
+
+// whole chain forward on a base draw (in place on xt), stashing for the reverse pass
+int nf_wide_train_forward(nf_ctx *ctx, const nf_flow_desc *desc, float *xt, long N, float *ladj, float *ws) {
+  if (!ctx->wimg) return NF_ERR_UNSUPPORTED;
+  const long ntiles = (N + NF_TILE - 1) / NF_TILE;
+  const size_t lds = Wide<GW>::LDS_APPLY;
+  static bool attr_done = false;
+  if (!attr_done) {
+    NF_HIP(hipFuncSetAttribute((const void *)k_wide_apply<GW, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  long grid = wide_groups(N);
+  if (grid > ctx->num_cu) grid = ctx->num_cu;
+  if (grid < 1) grid = 1;
+  const int nc = 2 * desc->nlayers;
+  for (int s = 0; s < nc; ++s) {  // forward applies the LAST flat coupling first
+    const int k = nc - 1 - s;
+    const WideArgs a = make_wide_args(ctx, desc, k, N);
+    const FwdStash fs = fwd_stash_at(ws, ntiles, k);
+    ProfScope ps(ctx, "wide_apply");
+    hipLaunchKernelGGL((k_wide_apply<GW, false, true>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, xt, ladj, s > 0 ? 1 : 0, fs);
+    NF_HIP(hipGetLastError());
+  }
+  return NF_OK;
+}
+
+int nf_wide_train_backward(nf_ctx *ctx, const nf_flow_desc *desc, float *state, float *gbar, const float *lbar,
+                           float lbar_const, long N, float *ws, float *g_out) {
+  if (!ctx->wimg) return NF_ERR_UNSUPPORTED;
+  using G = GW;
+  const long ntiles = (N + NF_TILE - 1) / NF_TILE;
+  const size_t per = (size_t)ntiles * NF_TILE * 32;
+  const int nc = 2 * desc->nlayers;
+  float *p = ws + (size_t)nc * 2 * fwd_stash_floats_per_net(ntiles);
+  WideStash st;
+  st.a1 = nullptr; st.a2 = nullptr;
+  st.d1 = p; p += per * G::H1B;
+  st.d2 = p; p += per * G::H2B;
+  st.d3 = p; p += per * G::CB;
+  float *slab = p;
+  const int njobs = wide_njobs();
+  const int ks = wide_ksplit(ctx, ntiles, njobs);
+  static bool attr_done = false;
+  const size_t lds_bwd = (size_t)2 * Wide<G>::CHBUF * sizeof(float);
+  const size_t lds_dw = (size_t)2 * DW_ROWS * DW_TS * sizeof(float);
+  if (!attr_done) {
+    NF_HIP(hipFuncSetAttribute((const void *)k_wide_bwd_stashed<G, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bwd));
+    NF_HIP(hipFuncSetAttribute((const void *)k_wide_bwd_stashed<G, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bwd));
+    NF_HIP(hipFuncSetAttribute((const void *)k_wide_dw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dw));
+    attr_done = true;
+  }
+  long grid = wide_groups(N);
+  if (grid > ctx->num_cu) grid = ctx->num_cu;
+  if (grid < 1) grid = 1;
+  const int h1 = desc->hdims[0], h2 = desc->hdims[1];
+  for (int k = 0; k < nc; ++k) {  // flat order = reverse of execution order
+    const WideArgs a = make_wide_args(ctx, desc, k, N);
+    const CouplingInfo ci = nf_coupling_info(desc, k);
+    const FwdStash fs = fwd_stash_at(ws, ntiles, k);
+    for (int phase = 0; phase < 2; ++phase) {  // 0: t net, 1: s net
+      const int net = phase == 0 ? 1 : 0;
+      {
+        ProfScope ps(ctx, "wide_bwd");
+        if (phase == 0)
+          hipLaunchKernelGGL((k_wide_bwd_stashed<G, false>), dim3((unsigned)grid), dim3(256), lds_bwd, ctx->stream, a, state, gbar, lbar, lbar_const, st, (const float *)fs.out[net], (const unsigned *)fs.mask[net]);
+        else
+          hipLaunchKernelGGL((k_wide_bwd_stashed<G, true>), dim3((unsigned)grid), dim3(256), lds_bwd, ctx->stream, a, state, gbar, lbar, lbar_const, st, (const float *)fs.out[net], (const unsigned *)fs.mask[net]);
+        NF_HIP(hipGetLastError());
+      }
+      WideStash sj = st;
+      sj.a1 = fs.a1[net];
+      sj.a2 = fs.a2[net];
+      DwArgs da;
+      build_jobs(&da, state, (long)desc->d * NF_TILE, desc->d * NF_TILE * 4, 1 - ci.par_t, sj);
+      da.ksplit = ks;
+      da.ntiles = ntiles;
+      da.slab_stride = G::SIZE;
+      {
+        ProfScope ps(ctx, "wide_dw");
+        hipLaunchKernelGGL(k_wide_dw, dim3((unsigned)(da.njobs * ks)), dim3(256), lds_dw, ctx->stream, da, slab);
+        NF_HIP(hipGetLastError());
+      }
+      long off = ci.theta_off;
+      if (phase == 0) off += net_param_count(ci.m, h1, h2, ci.c);
       const NetDims nd = make_net_dims(off, ci.m, h1, h2, ci.c);
       {
         ProfScope ps(ctx, "reduce_slabs");
