@@ -550,8 +550,13 @@ template <class G>
 __device__ __forceinline__ void rqs_bwd_tile(const RqsBwdArgs &a, const float *__restrict__ img, float *__restrict__ sc,
                                              RqsAcc<G> &acc, float *__restrict__ y, float *__restrict__ ybar,
                                              const float *__restrict__ lbar, float lbar_const, long tile, int l31,
-                                             int hi) {
+                                             int hi, long long *tr) {
   using L = RqsLds<G>;
+#define RQS_STAMP(slot)                                                   \
+  do {                                                                    \
+    if (tr) { __builtin_amdgcn_sched_barrier(0); tr[slot] = clock64(); }  \
+  } while (0)
+  RQS_STAMP(0);
   const long j = tile * NF_TILE + l31;
   const bool valid = j < a.N;
   const int par_c = 1 - a.par_t;
@@ -604,6 +609,7 @@ __device__ __forceinline__ void rqs_bwd_tile(const RqsBwdArgs &a, const float *_
     tile_to_scratch<G::H2B>(sc + L::OFF_A2, a2, l31, hi);
   }
   const float lb = valid ? (lbar ? lbar[j] : lbar_const) : 0.f;
+  RQS_STAMP(1);
 
   f32x16 d2[G::H2B];
 #pragma unroll
@@ -616,6 +622,7 @@ __device__ __forceinline__ void rqs_bwd_tile(const RqsBwdArgs &a, const float *_
   for (int ch = 0; ch < G::NCH; ++ch) {
     f32x16 out[G::OBC];
     dense_fwd<G::H2B, G::OBC, G::S3>(img + G::W3 + ch * G::OBC * 32, img + G::B3 + ch * G::OBC * 32, a2, out, l31, hi);
+    RQS_STAMP(2 + 4 * ch);
 #pragma unroll
     for (int ql = 0; ql < G::QCH; ++ql) {
       const int q = ch * G::QCH + ql;
@@ -640,8 +647,10 @@ __device__ __forceinline__ void rqs_bwd_tile(const RqsBwdArgs &a, const float *_
     // unused slots of the chunk (beyond QCH * P) carry raw outputs of zero-weight rows: clear them
 #pragma unroll
     for (int slot = G::QCH * G::P; slot < G::OBC * 16; ++slot) out[slot / 16][slot % 16] = 0.f;
+    RQS_STAMP(3 + 4 * ch);
     // dX through the last layer, accumulated over chunks
     dense_bwd_x<G::H2B, G::OBC, G::S3, true>(img + G::W3 + ch * G::OBC * 32, out, d2, l31, hi);
+    RQS_STAMP(4 + 4 * ch);
     // dW3^T: two accumulator blocks of delta at a time through the scratch transpose
 #pragma unroll
     for (int pc = 0; pc < G::OBC; pc += 2) {
@@ -660,6 +669,7 @@ __device__ __forceinline__ void rqs_bwd_tile(const RqsBwdArgs &a, const float *_
       }
       wave_lds_fence();
     }
+    RQS_STAMP(5 + 4 * ch);
   }
   // element-wise results: coupling input x1 and its cotangent
 #pragma unroll
@@ -699,6 +709,8 @@ __device__ __forceinline__ void rqs_bwd_tile(const RqsBwdArgs &a, const float *_
   for (int b = 0; b < G::MB; ++b)
 #pragma unroll
     for (int r = 0; r < 16; ++r) tile_store(gio, tile_soff(b, r, par_c), gold[b][r] + g2[b][r]);
+  RQS_STAMP(2 + 4 * G::NCH);
+#undef RQS_STAMP
 }
 
 template <class G>
@@ -720,7 +732,8 @@ __global__ __launch_bounds__(256, 1) void k_rqs_bwd(RqsBwdArgs a, float *__restr
   rqs_zero(acc.w3, acc.b3);
 #pragma unroll 1
   for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4)
-    rqs_bwd_tile<G>(a, img, sc, acc, y, ybar, lbar, lbar_const, tile, l31, hi);
+    rqs_bwd_tile<G>(a, img, sc, acc, y, ybar, lbar, lbar_const, tile, l31, hi,
+                    (a.trace && blockIdx.x == 0 && tid == 0 && tile == (long)wave) ? a.trace : nullptr);
   __syncthreads();  // the weight image is dead: it becomes the (deterministic, wave-ordered) fold target
 #pragma unroll 1
   for (int w = 0; w < 4; ++w) {
@@ -865,7 +878,7 @@ static int launch_rqs_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, float *y
   RqsBwdArgs a;
   a.img = (const float *)ctx->wimg + (size_t)k * G::SIZE;
   a.d = desc->d; a.c = ci.c; a.m = ci.m; a.par_t = ci.par_t; a.B = desc->B; a.N = N;
-  a.trace = nullptr;
+  a.trace = (long long *)ctx->trace;
   ProfScope ps(ctx, "rqs_bwd");
   hipLaunchKernelGGL((k_rqs_bwd<G>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, y, ybar, lbar, lbar_const,
                      slab + (long)k * G::SIZE, slab_stride);

@@ -64,23 +64,34 @@ def time_step(flow, tgt, n, steps, warmup=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--only", default="", help="comma-separated subset, e.g. cfg3,cfg4")
     args = ap.parse_args()
+    want = lambda name: not args.only or any(name.startswith(o) for o in args.only.split(","))  # noqa: E731
     res = {}
     g = torch.Generator().manual_seed(1)
 
     def dg(d, dt=torch.float32):
         return nf.DiagGaussTarget(torch.randn(d, generator=g).to(dev, dt), (torch.rand(d, generator=g) + 1e-3).to(dev, dt))
 
-    flow = nf.planarflow(nf.MvNormal(2), 10, paramtype=torch.float64, device=dev, seed=123)
-    res["cfg1_planar_d2_f64_n1024"] = time_step(flow, nf.BananaTarget(2, 1.0, 10.0), 1024, args.steps)
-    flow = nf.realnvp(nf.MvNormal(64), (64, 64), 4, paramtype=torch.float32, device=dev, seed=123)
-    res["cfg2_realnvp_d64_h64_n65536"] = time_step(flow, dg(64), 65536, args.steps)
-    flow = nf.realnvp(nf.MvNormal(64), (32, 32), 4, paramtype=torch.float32, device=dev, seed=123)
-    res["cfg2b_realnvp_d64_h32_n65536"] = time_step(flow, dg(64), 65536, args.steps)
-    flow = nf.nsf(nf.MvNormal(32), (32, 32), 8, 5.0, 4, paramtype=torch.float32, device=dev, seed=123)
-    res["cfg3_nsf_d32_k8_n131072"] = time_step(flow, dg(32), 131072, args.steps)
-    flow = nf.realnvp(nf.MvNormal(256), (256, 256), 8, paramtype=torch.float32, device=dev, seed=123)
-    res["cfg4_realnvp_d256_h256_n32768_per_gpu"] = time_step(flow, dg(256), 32768, max(5, args.steps // 3), warmup=3)
+    if want("cfg1"):
+        flow = nf.planarflow(nf.MvNormal(2), 10, paramtype=torch.float64, device=dev, seed=123)
+        res["cfg1_planar_d2_f64_n1024"] = time_step(flow, nf.BananaTarget(2, 1.0, 10.0), 1024, args.steps)
+    if want("cfg2_"):
+        flow = nf.realnvp(nf.MvNormal(64), (64, 64), 4, paramtype=torch.float32, device=dev, seed=123)
+        res["cfg2_realnvp_d64_h64_n65536"] = time_step(flow, dg(64), 65536, args.steps)
+    if want("cfg2b"):
+        flow = nf.realnvp(nf.MvNormal(64), (32, 32), 4, paramtype=torch.float32, device=dev, seed=123)
+        res["cfg2b_realnvp_d64_h32_n65536"] = time_step(flow, dg(64), 65536, args.steps)
+    if want("cfg3"):
+        flow = nf.nsf(nf.MvNormal(32), (32, 32), 8, 5.0, 4, paramtype=torch.float32, device=dev, seed=123)
+        res["cfg3_nsf_d32_k8_n131072"] = time_step(flow, dg(32), 131072, args.steps)
+    if want("cfg4"):
+        flow = nf.realnvp(nf.MvNormal(256), (256, 256), 8, paramtype=torch.float32, device=dev, seed=123)
+        res["cfg4_realnvp_d256_h256_n32768_per_gpu"] = time_step(flow, dg(256), 32768, max(5, args.steps // 3), warmup=3)
+    if not want("cfg5"):
+        for k, v in res.items():
+            print(k, json.dumps(v))
+        return
     # cfg 5: forward-KL path
     flow = nf.realnvp(nf.MvNormal(64), (64, 64), 4, paramtype=torch.float32, device=dev, seed=123)
     n = 1 << 20
