@@ -133,7 +133,7 @@ __device__ __forceinline__ float coupling_step(const float *__restrict__ img_s, 
       // rows >= c have zero weights and biases in the packed image: s = 0, T = 0, x1 stays 0
       const float s = nf_tanh(S[b][r]);
       if (INVERSE)
-        x1[b][r] = __fdividef(x1[b][r] - T[b][r], nf_exp(s));
+        x1[b][r] = nf_fdiv(x1[b][r] - T[b][r], nf_exp(s));
       else
         x1[b][r] = x1[b][r] * nf_exp(s) + T[b][r];
       lsum += s;
@@ -405,30 +405,28 @@ __device__ __forceinline__ void unstage_dense(const float *__restrict__ img, int
   }
 }
 
+#ifdef NF_KERNEL_TRACE
 #define NF_TS_STAMP(slot)                                                  \
   do {                                                                     \
     if (tr) { __builtin_amdgcn_sched_barrier(0); tr[slot] = clock64(); }   \
   } while (0)
+#else
+#define NF_TS_STAMP(slot) do { (void)tr; } while (0)
+#endif
 
 // Sign masks of the hidden pre-activations (bit r set <=> z[r] has its sign bit set, i.e. the
 // leaky-ReLU slope is 0.01): all the reverse pass needs of a1/a2 besides their LDS copies, so the
 // activations themselves can die early.  leakyrelu keeps the sign, so the mask is taken from the
 // post-activation value.  z = +0 counts as slope 1 where the oracle uses 0.01; the zero-padded rows
-// (z = 0 exactly) carry a zero cotangent, so the two agree.  (A shift-based form of this test,
-// (bits(v) >> 31) << r, produced wrong masks under hipcc 7.2 for some shapes; the integer compare
-// below is what the parity tests pin.)
+// (z = 0 exactly) carry a zero cotangent, so the two agree.  Built by nf_sign_mask16 (nf_mfma.h), one
+// v_alignbit per element.  (Note for maintainers: __builtin_bit_cast applied directly to a
+// vector-element expression such as v[b][r] reads element 0 under hipcc 7.2 -- copy to a scalar first.)
 template <int NB>
 __device__ __forceinline__ void sign_masks(const f32x16 (&v)[NB], unsigned (&m)[NB]) {
 #pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    unsigned bits = 0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) bits |= (__float_as_int(v[b][r]) < 0 ? 1u : 0u) << r;
-    asm volatile("" : "+v"(bits));  // compute the mask here (hipcc otherwise sinks it to its first use)
-    m[b] = bits;
-  }
+  for (int b = 0; b < NB; ++b) m[b] = nf_sign_mask16(v[b]);
 }
-__device__ __forceinline__ float lrelu_slope(unsigned mask, int r) { return ((mask >> r) & 1u) ? 0.01f : 1.f; }
+__device__ __forceinline__ float lrelu_slope(unsigned mask, int r) { return nf_mask_slope(mask, r); }
 template <int NB>
 __device__ __forceinline__ void apply_lrelu_grad(f32x16 (&d)[NB], const unsigned (&m)[NB]) {
 #pragma unroll
@@ -527,7 +525,7 @@ __device__ __forceinline__ void bwd_tile(const CouplingArgs &a, const float *__r
       } else {
         const float s = nf_tanh(d3[b][r]);
         const float es = nf_exp(s);
-        tile_store(yio, tile_soff(b, r, a.par_t), __fdividef(yv, es));  // x1 = u * exp(-s)
+        tile_store(yio, tile_soff(b, r, a.par_t), nf_fdiv(yv, es));  // x1 = u * exp(-s)
         tile_store(gio, tile_soff(b, r, a.par_t), gv * es);             // x1bar
         d3[b][r] = ok ? (gv * yv + lb) * (1.f - s * s) : 0.f;           // S-bar through tanh
       }

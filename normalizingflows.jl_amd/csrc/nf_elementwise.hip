@@ -6,6 +6,8 @@
 // LPS = 16 lanes per sample: lane q of a sample group owns features q, q+16, q+32, ... so a
 // 16-lane group reads 64 contiguous bytes per step, and per-sample sums (||x||^2, log p)
 // are 4-step DPP/shuffle reductions inside the group.
+#include <type_traits>
+
 #include "nf_common.h"
 #include "nf_philox.h"
 
@@ -95,8 +97,8 @@ __global__ __launch_bounds__(EW_BLOCK) void k_base_logpdf(int d, long N, const T
 //   FUNNEL     (mu, sigma)    example/targets/neal_funnel.jl:53-72 (`score` is the gradient)
 //   WARPED     (sigma1, sigma2), d = 2   example/targets/warped_gaussian.jl:51-87 (with its + log r term)
 //   CROSS      (mu, sigma), d = 2        example/targets/cross.jl:30-37 (components as the code builds them)
-template <class T>
-__device__ __forceinline__ T target_term(int kind, int d, int i, T v, T y0, T y1, T s2, const T *__restrict__ mu,
+template <int kind, class T>
+__device__ __forceinline__ T target_term(int d, int i, T v, T y0, T y1, T s2, const T *__restrict__ mu,
                                          const T *__restrict__ var, T s0, T s1, T &g) {
   const T L2PI = (T)1.8378770664093453;
   if (kind == NF_TARGET_DIAGGAUSS) {
@@ -189,10 +191,20 @@ __global__ __launch_bounds__(EW_BLOCK) void k_target(int kind, int d, long N, co
   if (valid) {
     const T *yr = y + j * d;
     const T y0 = yr[0], y1 = d > 1 ? yr[1] : (T)0;
-    for (int i = q; i < d; i += LPS) {
-      T g;
-      acc += target_term<T>(kind, d, i, yr[i], y0, y1, s2, mu, var, b_ban, var_ban, g);
-      if (grad_out) grad_out[j * d + i] = gscale * g;
+    auto run = [&](auto kc) {  // the target kind is resolved once, outside the feature loop
+      constexpr int KD = decltype(kc)::value;
+      for (int i = q; i < d; i += LPS) {
+        T g;
+        acc += target_term<KD, T>(d, i, yr[i], y0, y1, s2, mu, var, b_ban, var_ban, g);
+        if (grad_out) grad_out[j * d + i] = gscale * g;
+      }
+    };
+    switch (kind) {
+      case NF_TARGET_DIAGGAUSS: run(std::integral_constant<int, NF_TARGET_DIAGGAUSS>{}); break;
+      case NF_TARGET_BANANA: run(std::integral_constant<int, NF_TARGET_BANANA>{}); break;
+      case NF_TARGET_FUNNEL: run(std::integral_constant<int, NF_TARGET_FUNNEL>{}); break;
+      case NF_TARGET_WARPED: run(std::integral_constant<int, NF_TARGET_WARPED>{}); break;
+      default: run(std::integral_constant<int, NF_TARGET_CROSS>{}); break;
     }
   }
   acc = group16_sum(acc);
@@ -393,10 +405,20 @@ __global__ __launch_bounds__(EW_BLOCK) void k_target_tiled(int kind, int d, long
   }
   {
     const float y0 = yb[0], y1 = d > 1 ? yb[TL] : 0.f;
-    for (int i = q; i < d; i += FS) {
-      float g;
-      acc += target_term<float>(kind, d, i, yb[(long)i * TL], y0, y1, s2, mu, var, b_ban, var_ban, g);
-      if (gb) gb[(long)i * TL] = valid ? gscale * g : 0.f;
+    auto run = [&](auto kc) {
+      constexpr int KD = decltype(kc)::value;
+      for (int i = q; i < d; i += FS) {
+        float g;
+        acc += target_term<KD, float>(d, i, yb[(long)i * TL], y0, y1, s2, mu, var, b_ban, var_ban, g);
+        if (gb) gb[(long)i * TL] = valid ? gscale * g : 0.f;
+      }
+    };
+    switch (kind) {
+      case NF_TARGET_DIAGGAUSS: run(std::integral_constant<int, NF_TARGET_DIAGGAUSS>{}); break;
+      case NF_TARGET_BANANA: run(std::integral_constant<int, NF_TARGET_BANANA>{}); break;
+      case NF_TARGET_FUNNEL: run(std::integral_constant<int, NF_TARGET_FUNNEL>{}); break;
+      case NF_TARGET_WARPED: run(std::integral_constant<int, NF_TARGET_WARPED>{}); break;
+      default: run(std::integral_constant<int, NF_TARGET_CROSS>{}); break;
     }
   }
   red[q][s] = acc;

@@ -35,11 +35,28 @@ __device__ __forceinline__ float nf_lrelu(float z) { return fmaxf(z, 0.01f * z);
 // Hardware exp2-based forms: absolute error of tanh < 1e-7 (the reference itself runs NNlib's
 // rational tanh_fast, a few ulp from libm), relative error of exp ~1 ulp -- far inside the
 // stated 2e-5 parity tolerance, and ~4x fewer VALU instructions than the libm-accurate calls.
+// x / y through the hardware reciprocal (v_rcp_f32, 1 ulp): two instructions.  hipcc lowers
+// __fdividef to the full IEEE sequence (div_scale x2, rcp, 4 fma, div_fmas, div_fixup).
+__device__ __forceinline__ float nf_fdiv(float x, float y) { return x * __builtin_amdgcn_rcpf(y); }
+
 __device__ __forceinline__ float nf_tanh(float x) {
   const float xc = fminf(fmaxf(x, -10.f), 10.f);
   const float e2 = __expf(2.f * xc);
-  return __fdividef(e2 - 1.f, e2 + 1.f);
+  return nf_fdiv(e2 - 1.f, e2 + 1.f);
 }
+
+// Leaky-ReLU sign masks: one v_alignbit per element shifts the sign bit of v[r] into the mask, so
+// element r ends up at bit 15 - r.  leakyrelu keeps the sign, so the mask may be taken from the
+// post-activation value.  The empty asm pins the computation where it is written (hipcc otherwise
+// sinks it to the mask's first use and keeps the 16 activations alive until then).
+__device__ __forceinline__ unsigned nf_sign_mask16(const f32x16 &v) {
+  unsigned bits = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bits = __builtin_amdgcn_alignbit(bits, (unsigned)__float_as_int(v[r]), 31);
+  asm volatile("" : "+v"(bits));
+  return bits;
+}
+__device__ __forceinline__ float nf_mask_slope(unsigned mask, int r) { return ((mask >> (15 - r)) & 1u) ? 0.01f : 1.f; }
 __device__ __forceinline__ float nf_exp(float x) { return __expf(x); }
 
 // LDS image of one Dense layer: W[i][o] at w[i * S + o], S = 32*OB + 1 (odd stride so

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void k_rqs_reduce_slabs(RqsPackArgs p, const f
 __device__ __forceinline__ float softplus_f(float x) { return __logf(1.f + __expf(-fabsf(x))) + fmaxf(x, 0.f); }
 __device__ __forceinline__ float sigmoid_f(float x) {
   const float e = __expf(-fabsf(x));
-  return x >= 0.f ? __fdividef(1.f, 1.f + e) : __fdividef(e, 1.f + e);
+  return x >= 0.f ? nf_fdiv(1.f, 1.f + e) : nf_fdiv(e, 1.f + e);
 }
 
 template <int K>
@@ -170,7 +170,7 @@ __device__ __forceinline__ void softmax_knots(const float *v, float B, float *sm
     sm[k] = __expf(v[k] - mx);
     sum += sm[k];
   }
-  const float inv = __fdividef(1.f, sum);
+  const float inv = nf_fdiv(1.f, sum);
   float cs = 0.f;
   p[0] = -B;
 #pragma unroll
@@ -232,10 +232,10 @@ template <int K>
 __device__ __forceinline__ float rqs_fwd_elem(const Knots<K> &kn, float x, float &logd) {
   const Bin b = find_bin<K>(kn, kn.pX, x);
   const float dx = b.xk1 - b.xk, dy = b.yk1 - b.yk;
-  const float s = __fdividef(dy, dx);
-  const float xi = __fdividef(x - b.xk, dx), om = 1.f - xi;
+  const float s = nf_fdiv(dy, dx);
+  const float xi = nf_fdiv(x - b.xk, dx), om = 1.f - xi;
   const float den = s + (b.d1 + b.d0 - 2.f * s) * xi * om;
-  const float y = b.yk + __fdividef(dy * (s * xi * xi + b.d0 * xi * om), den);
+  const float y = b.yk + nf_fdiv(dy * (s * xi * xi + b.d0 * xi * om), den);
   logd += b.inside ? rq_logderiv(s, b.d0, b.d1, xi) : 0.f;
   return b.inside ? y : x;
 }
@@ -245,14 +245,14 @@ template <int K>
 __device__ __forceinline__ float rqs_inv_elem(const Knots<K> &kn, float y, float &logd, Bin &b, float &xi_out) {
   b = find_bin<K>(kn, kn.pY, y);
   const float dx = b.xk1 - b.xk, dy = b.yk1 - b.yk;
-  const float s = __fdividef(dy, dx);
+  const float s = nf_fdiv(dy, dx);
   const float yy = y - b.yk;
   const float q = b.d1 + b.d0 - 2.f * s;
   const float a = dy * (s - b.d0) + yy * q;
   const float bb = dy * b.d0 - yy * q;
   const float c = -s * yy;
   const float disc = fmaxf(bb * bb - 4.f * a * c, 0.f);
-  const float xi = __fdividef(2.f * c, -bb - sqrtf(disc));
+  const float xi = nf_fdiv(2.f * c, -bb - sqrtf(disc));
   xi_out = xi;
   logd -= b.inside ? rq_logderiv(s, b.d0, b.d1, xi) : 0.f;
   return b.inside ? xi * dx + b.xk : y;
@@ -263,13 +263,13 @@ template <int K>
 __device__ __forceinline__ float rqs_bwd_elem(const Knots<K> &kn, const float *raw, const Bin &b, float xi, float B,
                                               float ybar, float lbar, float *thbar) {
   const float dx = b.xk1 - b.xk, dy = b.yk1 - b.yk;
-  const float s = __fdividef(dy, dx), om = 1.f - xi;
+  const float s = nf_fdiv(dy, dx), om = 1.f - xi;
   const float d0 = b.d0, d1 = b.d1;
   const float q = d1 + d0 - 2.f * s;
   const float den = s + q * xi * om;
   const float num = s * xi * xi + d0 * xi * om;
   const float nd = d1 * xi * xi + 2.f * s * xi * om + d0 * om * om;
-  const float iden = __fdividef(1.f, den), ind = __fdividef(1.f, nd), idx = __fdividef(1.f, dx);
+  const float iden = nf_fdiv(1.f, den), ind = nf_fdiv(1.f, nd), idx = nf_fdiv(1.f, dx);
   const float iden2 = iden * iden;
   const float dnum_dxi = 2.f * s * xi + d0 * (1.f - 2.f * xi);
   const float dden_dxi = q * (1.f - 2.f * xi);
@@ -278,7 +278,7 @@ __device__ __forceinline__ float rqs_bwd_elem(const Knots<K> &kn, const float *r
   const float dL_dxi = dnd_dxi * ind - 2.f * dden_dxi * iden;
   const float dden_ds = 1.f - 2.f * xi * om;
   const float dy_ds = dy * (xi * xi * den - num * dden_ds) * iden2;
-  const float dL_ds = __fdividef(2.f, s) + 2.f * xi * om * ind - 2.f * dden_ds * iden;
+  const float dL_ds = nf_fdiv(2.f, s) + 2.f * xi * om * ind - 2.f * dden_ds * iden;
   const float dy_dd0 = dy * (xi * om * den - num * xi * om) * iden2;
   const float dL_dd0 = om * om * ind - 2.f * xi * om * iden;
   const float dy_dd1 = dy * (-num * xi * om) * iden2;
@@ -552,10 +552,14 @@ __device__ __forceinline__ void rqs_bwd_tile(const RqsBwdArgs &a, const float *_
                                              const float *__restrict__ lbar, float lbar_const, long tile, int l31,
                                              int hi, long long *tr) {
   using L = RqsLds<G>;
+#ifdef NF_KERNEL_TRACE
 #define RQS_STAMP(slot)                                                   \
   do {                                                                    \
     if (tr) { __builtin_amdgcn_sched_barrier(0); tr[slot] = clock64(); }  \
   } while (0)
+#else
+#define RQS_STAMP(slot) do { (void)tr; } while (0)
+#endif
   RQS_STAMP(0);
   const long j = tile * NF_TILE + l31;
   const bool valid = j < a.N;
@@ -586,25 +590,17 @@ __device__ __forceinline__ void rqs_bwd_tile(const RqsBwdArgs &a, const float *_
     dense_fwd<G::MB, G::H1B>(img + G::W1, img + G::B1, xb, a1, l31, hi);
 #pragma unroll
     for (int b = 0; b < G::H1B; ++b) {
-      unsigned bits = 0;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        a1[b][r] = nf_lrelu(a1[b][r]);
-        bits |= (a1[b][r] < 0.f ? 1u : 0u) << r;  // set <=> slope 0.01
-      }
-      m1[b] = bits;
+      for (int r = 0; r < 16; ++r) a1[b][r] = nf_lrelu(a1[b][r]);
+      m1[b] = nf_sign_mask16(a1[b]);  // bit set <=> slope 0.01
     }
     tile_to_scratch<G::H1B>(sc + L::OFF_A1, a1, l31, hi);
     dense_fwd<G::H1B, G::H2B>(img + G::W2, img + G::B2, a1, a2, l31, hi);
 #pragma unroll
     for (int b = 0; b < G::H2B; ++b) {
-      unsigned bits = 0;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        a2[b][r] = nf_lrelu(a2[b][r]);
-        bits |= (a2[b][r] < 0.f ? 1u : 0u) << r;
-      }
-      m2[b] = bits;
+      for (int r = 0; r < 16; ++r) a2[b][r] = nf_lrelu(a2[b][r]);
+      m2[b] = nf_sign_mask16(a2[b]);
     }
     tile_to_scratch<G::H2B>(sc + L::OFF_A2, a2, l31, hi);
   }
@@ -683,7 +679,7 @@ __device__ __forceinline__ void rqs_bwd_tile(const RqsBwdArgs &a, const float *_
 #pragma unroll
   for (int b = 0; b < G::H2B; ++b)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) d2[b][r] *= ((m2[b] >> r) & 1u) ? 0.01f : 1.f;
+    for (int r = 0; r < 16; ++r) d2[b][r] *= nf_mask_slope(m2[b], r);
   tile_to_scratch<G::H2B>(sd, d2, l31, hi);
   wave_lds_fence();
   dw_accumulate<G::H1B, G::H2B>(sc + L::OFF_A1, sd, acc.w2, acc.b2, l31, hi);
@@ -692,7 +688,7 @@ __device__ __forceinline__ void rqs_bwd_tile(const RqsBwdArgs &a, const float *_
 #pragma unroll
   for (int b = 0; b < G::H1B; ++b)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) d1[b][r] *= ((m1[b] >> r) & 1u) ? 0.01f : 1.f;
+    for (int r = 0; r < 16; ++r) d1[b][r] *= nf_mask_slope(m1[b], r);
   wave_lds_fence();
   // ---- layer 1
   tile_to_scratch<G::H1B>(sd, d1, l31, hi);

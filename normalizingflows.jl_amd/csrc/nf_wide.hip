@@ -25,10 +25,14 @@
 typedef __attribute__((address_space(3))) void lds_void_t;
 
 // optional clock stamps of block 0 / wave 0 (nf_debug_trace, tools/trace_wide.py)
+#ifdef NF_KERNEL_TRACE
 #define WIDE_STAMP(slot)                                                  \
   do {                                                                    \
     if (tr) { __builtin_amdgcn_sched_barrier(0); tr[slot] = clock64(); }  \
   } while (0)
+#else
+#define WIDE_STAMP(slot) do { (void)tr; } while (0)
+#endif
 
 using GW = NetGeo<4, 8, 8, 4>;  // every wide flow is zero-padded into this geometry
 
@@ -275,15 +279,7 @@ __device__ __forceinline__ void stash_store_range(const StashIO &s, const f32x16
 template <int NB>
 __device__ __forceinline__ void wide_sign_masks(const f32x16 (&v)[NB], unsigned (&m)[NB]) {
 #pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    unsigned bits = 0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) bits |= (__float_as_int(v[b][r]) < 0 ? 1u : 0u) << r;
-    // pin the mask HERE: left alone, hipcc sinks this computation to the mask's first use and keeps
-    // all 128 activations alive (in scratch) until then
-    asm volatile("" : "+v"(bits));
-    m[b] = bits;
-  }
+  for (int b = 0; b < NB; ++b) m[b] = nf_sign_mask16(v[b]);
 }
 
 // hooks of the forward kernel: optional stash (STASH) and, for the t net, the prefetch of the
@@ -407,7 +403,7 @@ __global__ __launch_bounds__(256, 1) void k_wide_apply(WideArgs a, float *xt, fl
       for (int r = 0; r < 16; ++r) {
         const float s = nf_tanh(S[b][r]);  // padded rows: zero weights and bias => s = 0
         const float v = x1[b][r];
-        const float o = INVERSE ? __fdividef(v - T[b][r], nf_exp(s)) : v * nf_exp(s) + T[b][r];
+        const float o = INVERSE ? nf_fdiv(v - T[b][r], nf_exp(s)) : v * nf_exp(s) + T[b][r];
         if (live) tile_store(io, tile_soff(b, r, a.par_t), o);  // rows >= c fall outside the descriptor
         lsum += s;
       }
@@ -452,7 +448,7 @@ __device__ __forceinline__ void wide_dx_chain(wide_img_t img, float *cb, int &bu
     if (ib > 0) stash_store_range<G::H2B>(sd2, d2, (ib - 1) * 16, 16);
     wide_bwdx_chunk<G::CB, G::S3>(cb + buf * W::CHBUF, d3, d2[ib], l31, hi, dj);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) d2[ib][r] *= ((m2[ib] >> r) & 1u) ? 0.01f : 1.f;
+    for (int r = 0; r < 16; ++r) d2[ib][r] *= nf_mask_slope(m2[ib], r);
     __syncthreads();
     buf ^= 1;
   }
@@ -471,7 +467,7 @@ __device__ __forceinline__ void wide_dx_chain(wide_img_t img, float *cb, int &bu
     if (ib > 0) stash_store_range<G::H1B>(sd1, d1, (ib - 1) * 16, 16);
     wide_bwdx_chunk<G::H2B, G::S2>(cb + buf * W::CHBUF, d2, d1[ib], l31, hi, dj);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) d1[ib][r] *= ((m1[ib] >> r) & 1u) ? 0.01f : 1.f;
+    for (int r = 0; r < 16; ++r) d1[ib][r] *= nf_mask_slope(m1[ib], r);
     __syncthreads();
     buf ^= 1;
   }
@@ -602,7 +598,7 @@ __global__ __launch_bounds__(256, 1) void k_wide_bwd(WideArgs a, float *__restri
           const float s = nf_tanh(d3[b][r]);
           const float es = nf_exp(s);
           if (live) {
-            tile_store(yio, tile_soff(b, r, a.par_t), __fdividef(yv, es));  // x1 = u * exp(-s)
+            tile_store(yio, tile_soff(b, r, a.par_t), nf_fdiv(yv, es));  // x1 = u * exp(-s)
             tile_store(gio, tile_soff(b, r, a.par_t), gv * es);             // x1bar
           }
           d3[b][r] = ok ? (gv * yv + lb) * (1.f - s * s) : 0.f;
@@ -687,7 +683,7 @@ __global__ __launch_bounds__(256, 1) void k_wide_bwd_stashed(WideArgs a, float *
           const float s = nf_tanh(d3[b][r]);
           const float es = nf_exp(s);
           if (live) {
-            tile_store(yio, tile_soff(b, r, a.par_t), __fdividef(yv, es));  // x1 = u * exp(-s)
+            tile_store(yio, tile_soff(b, r, a.par_t), nf_fdiv(yv, es));  // x1 = u * exp(-s)
             tile_store(gio, tile_soff(b, r, a.par_t), gv * es);             // x1bar
           }
           d3[b][r] = ok ? (gv * yv + lb) * (1.f - s * s) : 0.f;

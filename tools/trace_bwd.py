@@ -1,5 +1,5 @@
 """Kernel-tuning aid: prints the in-kernel timeline (s_memtime deltas, block 0 / wave 0) of the
-coupling reverse pass on the benchmark workload.  Usage: python tools/trace_bwd.py"""
+coupling reverse pass on the benchmark workload.  Usage (needs a library built with NF_KERNEL_TRACE=1 python __graft_entry__.py --force): python tools/trace_bwd.py"""
 import ctypes as C
 import os
 import sys

@@ -1,5 +1,5 @@
 """Kernel-tuning aid: in-kernel timeline (clock64 deltas, block 0 / wave 0, first tile) of the
-neural-spline reverse kernel k_rqs_bwd at the cfg-3 shape.  Usage: python tools/trace_rqs.py"""
+neural-spline reverse kernel k_rqs_bwd at the cfg-3 shape.  Usage (needs a library built with NF_KERNEL_TRACE=1 python __graft_entry__.py --force): python tools/trace_rqs.py"""
 import ctypes as C
 import os
 import sys

@@ -1,5 +1,5 @@
 """Kernel-tuning aid: in-kernel timeline (clock64 deltas, block 0 / wave 0, first tile group) of the
-weight-streaming reverse kernel k_wide_bwd at the cfg-4 shape.  Usage: python tools/trace_wide.py"""
+weight-streaming reverse kernel k_wide_bwd at the cfg-4 shape.  Usage (needs a library built with NF_KERNEL_TRACE=1 python __graft_entry__.py --force): python tools/trace_wide.py"""
 import ctypes as C
 import os
 import sys
