@@ -568,7 +568,7 @@ __device__ __forceinline__ void rqs_bwd_tile(const RqsBwdArgs &a, const float *_
   const TileIO gio = make_tile_io(ybar, tile, a.d, l31, hi);
 
   unsigned m1[G::H1B], m2[G::H2B];
-  f32x16 a2[G::H2B], y1[G::CB], g1[G::CB];
+  f32x16 a2[G::H2B];
   {
     f32x16 xb[G::MB];
 #pragma unroll
@@ -577,13 +577,6 @@ __device__ __forceinline__ void rqs_bwd_tile(const RqsBwdArgs &a, const float *_
       for (int r = 0; r < 16; ++r) {
         const float v = tile_load(yio, tile_soff(b, r, par_c));
         xb[b][r] = valid ? v : 0.f;
-      }
-#pragma unroll
-    for (int b = 0; b < G::CB; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        y1[b][r] = tile_load(yio, tile_soff(b, r, a.par_t));
-        g1[b][r] = tile_load(gio, tile_soff(b, r, a.par_t));
       }
     tile_to_scratch<G::MB>(sc + L::OFF_X, xb, l31, hi);
     f32x16 a1[G::H1B];
@@ -616,6 +609,15 @@ __device__ __forceinline__ void rqs_bwd_tile(const RqsBwdArgs &a, const float *_
 
 #pragma unroll
   for (int ch = 0; ch < G::NCH; ++ch) {
+    // this chunk's transformed values and cotangents: fetched here (two registers per local dim
+    // instead of the whole tile held for the duration), consumed after the chunk's output GEMM
+    float yq[G::QCH], gq[G::QCH];
+#pragma unroll
+    for (int ql = 0; ql < G::QCH; ++ql) {
+      const int q = ch * G::QCH + ql;
+      yq[ql] = tile_load(yio, tile_soff(q / 16, q % 16, a.par_t));
+      gq[ql] = tile_load(gio, tile_soff(q / 16, q % 16, a.par_t));
+    }
     f32x16 out[G::OBC];
     dense_fwd<G::H2B, G::OBC, G::S3>(img + G::W3 + ch * G::OBC * 32, img + G::B3 + ch * G::OBC * 32, a2, out, l31, hi);
     RQS_STAMP(2 + 4 * ch);
@@ -628,8 +630,8 @@ __device__ __forceinline__ void rqs_bwd_tile(const RqsBwdArgs &a, const float *_
       chunk_get<G>(out, ql, raw);
       Knots<G::K> kn;
       build_knots<G::K>(raw, a.B, kn);
-      const float yv = y1[q / 16][q % 16];
-      const float gv = ok ? g1[q / 16][q % 16] : 0.f;
+      const float yv = yq[ql];
+      const float gv = ok ? gq[ql] : 0.f;
       // invert to the coupling input (src/flows/neuralspline.jl:134-140), then differentiate the
       // forward map at that point
       float dummy = 0.f, xi;
@@ -637,8 +639,8 @@ __device__ __forceinline__ void rqs_bwd_tile(const RqsBwdArgs &a, const float *_
       const float xv = rqs_inv_elem<G::K>(kn, yv, dummy, bn, xi);
       const float xbar = rqs_bwd_elem<G::K>(kn, raw, bn, xi, a.B, gv, ok ? lb : 0.f, thb);  // gv, lb are 0 when !ok
       chunk_put<G>(out, ql, thb);
-      y1[q / 16][q % 16] = xv;
-      g1[q / 16][q % 16] = xbar;
+      tile_store(yio, tile_soff(q / 16, q % 16, a.par_t), xv);    // coupling input x1
+      tile_store(gio, tile_soff(q / 16, q % 16, a.par_t), xbar);  // its cotangent
     }
     // unused slots of the chunk (beyond QCH * P) carry raw outputs of zero-weight rows: clear them
 #pragma unroll
@@ -667,14 +669,6 @@ __device__ __forceinline__ void rqs_bwd_tile(const RqsBwdArgs &a, const float *_
     }
     RQS_STAMP(5 + 4 * ch);
   }
-  // element-wise results: coupling input x1 and its cotangent
-#pragma unroll
-  for (int b = 0; b < G::CB; ++b)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      tile_store(yio, tile_soff(b, r, a.par_t), y1[b][r]);
-      tile_store(gio, tile_soff(b, r, a.par_t), g1[b][r]);
-    }
   // ---- layer 2
 #pragma unroll
   for (int b = 0; b < G::H2B; ++b)
