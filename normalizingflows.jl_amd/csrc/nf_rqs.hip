@@ -252,7 +252,7 @@ __device__ __forceinline__ float rqs_inv_elem(const Knots<K> &kn, float y, float
   const float bb = dy * b.d0 - yy * q;
   const float c = -s * yy;
   const float disc = fmaxf(bb * bb - 4.f * a * c, 0.f);
-  const float xi = nf_fdiv(2.f * c, -bb - sqrtf(disc));
+  const float xi = nf_fdiv(2.f * c, -bb - __builtin_amdgcn_sqrtf(disc));
   xi_out = xi;
   logd -= b.inside ? rq_logderiv(s, b.d0, b.d1, xi) : 0.f;
   return b.inside ? xi * dx + b.xk : y;
