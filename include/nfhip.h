@@ -189,7 +189,8 @@ int nf_elbo_step(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target,
 /* ---- measurement support ---------------------------------------------------- */
 /* Kernel durations from HIP events recorded on the context stream around launches since the
  * last nf_prof_enable (used by bench.py's roofline object).  mode 0 = off, 1 = bracket only the
- * dominant kernel (the coupling reverse pass), 2 = bracket every kernel. */
+ * dominant kernel (the coupling reverse pass), 2 = bracket every kernel, 3 = bracket every 4th launch
+ * of the dominant kernel (what bench.py uses inside its timed region). */
 int nf_prof_enable(nf_ctx *ctx, int32_t mode);
 int nf_prof_read(nf_ctx *ctx, const char *kernel_name, double *avg_ms_host, int64_t *count_host);
 /* Kernel-tuning aid: when on, block 0 / wave 0 of the coupling reverse pass writes s_memtime

@@ -669,7 +669,7 @@ extern "C" int nf_elbo_step(nf_ctx *ctx, const nf_flow_desc *desc, const nf_targ
 
 // ---- measurement support -------------------------------------------------------------------
 extern "C" int nf_prof_enable(nf_ctx *ctx, int32_t mode) {
-  if (!ctx || mode < 0 || mode > 2) return NF_ERR_ARG;
+  if (!ctx || mode < 0 || mode > 3) return NF_ERR_ARG;
   NF_HIP(hipStreamSynchronize(ctx->stream));
   ctx->prof_events.clear();
   ctx->prof_pool_next = 0;
@@ -678,6 +678,7 @@ extern "C" int nf_prof_enable(nf_ctx *ctx, int32_t mode) {
     for (auto &e : ctx->prof_pool) NF_HIP(hipEventCreate(&e));
   }
   ctx->prof_mode = mode;
+  ctx->prof_tick = 0;
   return NF_OK;
 }
 

@@ -46,6 +46,7 @@ struct nf_ctx {
   size_t gbuf_bytes = 0;
   // per-kernel HIP-event timing (bench.py roofline): name -> list of (start, stop)
   int prof_mode = 0;
+  unsigned prof_tick = 0;
   std::vector<hipEvent_t> prof_pool;  // pre-created events, reused
   size_t prof_pool_next = 0;
   std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof_events;
@@ -68,15 +69,18 @@ struct Carver {
 inline size_t carve_bytes(size_t nbytes) { return ((nbytes + 255) / 256) * 256; }
 
 // profiling bracket: records a pair of pooled HIP events on ctx->stream around a launch.
-// prof_mode 1 brackets only the dominant kernel ("affine_bwd" / "rqs_bwd" / "wide_bwd"), 2 brackets all.
+// prof_mode 1 brackets only the dominant kernel ("affine_bwd" / "rqs_bwd" / "wide_bwd"), 2 brackets all,
+// 3 brackets every 4th launch of the dominant kernel (lowest perturbation of a timed region).
 struct ProfScope {
   nf_ctx *ctx;
   hipEvent_t b = nullptr;
   ProfScope(nf_ctx *c, const char *name) : ctx(c) {
     if (!ctx->prof_mode) return;
-    if (ctx->prof_mode == 1 && std::strcmp(name, "affine_bwd") != 0 && std::strcmp(name, "rqs_bwd") != 0 &&
-        std::strcmp(name, "wide_bwd") != 0)
-      return;
+    if (ctx->prof_mode != 2) {
+      if (std::strcmp(name, "affine_bwd") != 0 && std::strcmp(name, "rqs_bwd") != 0 && std::strcmp(name, "wide_bwd") != 0)
+        return;
+      if (ctx->prof_mode == 3 && (ctx->prof_tick++ & 3) != 0) return;
+    }
     if (ctx->prof_pool_next + 2 > ctx->prof_pool.size()) return;  // pool exhausted: stop sampling
     hipEvent_t a = ctx->prof_pool[ctx->prof_pool_next++];
     b = ctx->prof_pool[ctx->prof_pool_next++];
