@@ -154,9 +154,15 @@ __device__ __forceinline__ float sigmoid_f(float x) {
   return x >= 0.f ? nf_fdiv(1.f, 1.f + e) : nf_fdiv(e, 1.f + e);
 }
 
+// Knot positions and the softmax weights behind them.  The knot DERIVATIVES are not built here: only
+// the two at the ends of the bin an element falls into are ever used (forward, inverse and reverse
+// pass alike), so find_bin selects their raw parameters and evaluates those two softplus' -- 4
+// transcendentals instead of 2(K-1), at 16 clocks each on a kernel that is VALU-bound.
 template <int K>
 struct Knots {
-  float pX[K + 1], pY[K + 1], dd[K + 1], smw[K], smh[K];
+  float pX[K + 1], pY[K + 1], smw[K], smh[K];
+  const float *rawd;  // raw[2K .. 3K-2]: interior derivative parameters (registers, compile-time indexed)
+  float dd[K + 1];    // EAGER mode only: all knot derivatives (see build_knots)
 };
 
 template <int K>
@@ -182,14 +188,20 @@ __device__ __forceinline__ void softmax_knots(const float *v, float B, float *sm
 }
 
 // raw[0:K] widths, raw[K:2K] heights, raw[2K:3K-1] interior derivatives
-template <int K>
+// LAZY (forward / inverse chain): derivatives are evaluated by find_bin.  EAGER (reverse kernel): all of
+// them here, as before -- there the lazy form lengthens the live range of the raw parameters and tips
+// hipcc's register allocation into 140 spilled registers (212 vs 168 us per launch).
+template <int K, bool LAZY>
 __device__ __forceinline__ void build_knots(const float *raw, float B, Knots<K> &kn) {
   softmax_knots<K>(raw, B, kn.smw, kn.pX);
   softmax_knots<K>(raw + K, B, kn.smh, kn.pY);
-  kn.dd[0] = 1.f;
-  kn.dd[K] = 1.f;
+  kn.rawd = raw + 2 * K;
+  if (!LAZY) {
+    kn.dd[0] = 1.f;
+    kn.dd[K] = 1.f;
 #pragma unroll
-  for (int k = 1; k < K; ++k) kn.dd[k] = softplus_f(raw[2 * K + k - 1]);
+    for (int k = 1; k < K; ++k) kn.dd[k] = softplus_f(raw[2 * K + k - 1]);
+  }
 }
 
 struct Bin {
@@ -199,7 +211,7 @@ struct Bin {
 };
 
 // bin with p[k] <= v < p[k+1] on the knot vector `p` (pX forward, pY inverse)
-template <int K>
+template <int K, bool LAZY>
 __device__ __forceinline__ Bin find_bin(const Knots<K> &kn, const float *p, float v) {
   Bin b;
   b.inside = (v >= p[0]) && (v < p[K]);
@@ -207,16 +219,34 @@ __device__ __forceinline__ Bin find_bin(const Knots<K> &kn, const float *p, floa
 #pragma unroll
   for (int j = 1; j < K; ++j) k += (v >= p[j]) ? 1 : 0;
   b.k = k;
-  b.xk = kn.pX[0]; b.xk1 = kn.pX[1]; b.yk = kn.pY[0]; b.yk1 = kn.pY[1]; b.d0 = kn.dd[0]; b.d1 = kn.dd[1];
+  b.xk = kn.pX[0]; b.xk1 = kn.pX[1]; b.yk = kn.pY[0]; b.yk1 = kn.pY[1];
+  if (LAZY) {
+    float r0 = 0.f, r1 = kn.rawd[0];  // raw derivative parameters of knots k and k+1 (knot j <-> rawd[j-1])
 #pragma unroll
-  for (int j = 1; j < K; ++j) {
-    const bool is = (k == j);
-    b.xk = is ? kn.pX[j] : b.xk;
-    b.xk1 = is ? kn.pX[j + 1] : b.xk1;
-    b.yk = is ? kn.pY[j] : b.yk;
-    b.yk1 = is ? kn.pY[j + 1] : b.yk1;
-    b.d0 = is ? kn.dd[j] : b.d0;
-    b.d1 = is ? kn.dd[j + 1] : b.d1;
+    for (int j = 1; j < K; ++j) {
+      const bool is = (k == j);
+      b.xk = is ? kn.pX[j] : b.xk;
+      b.xk1 = is ? kn.pX[j + 1] : b.xk1;
+      b.yk = is ? kn.pY[j] : b.yk;
+      b.yk1 = is ? kn.pY[j + 1] : b.yk1;
+      r0 = is ? kn.rawd[j - 1] : r0;
+      if (j < K - 1) r1 = is ? kn.rawd[j] : r1;
+    }
+    b.d0 = (k == 0) ? 1.f : softplus_f(r0);  // boundary derivatives are 1
+    b.d1 = (k == K - 1) ? 1.f : softplus_f(r1);
+  } else {
+    b.d0 = kn.dd[0];
+    b.d1 = kn.dd[1];
+#pragma unroll
+    for (int j = 1; j < K; ++j) {
+      const bool is = (k == j);
+      b.xk = is ? kn.pX[j] : b.xk;
+      b.xk1 = is ? kn.pX[j + 1] : b.xk1;
+      b.yk = is ? kn.pY[j] : b.yk;
+      b.yk1 = is ? kn.pY[j + 1] : b.yk1;
+      b.d0 = is ? kn.dd[j] : b.d0;
+      b.d1 = is ? kn.dd[j + 1] : b.d1;
+    }
   }
   return b;
 }
@@ -228,9 +258,9 @@ __device__ __forceinline__ float rq_logderiv(float s, float d0, float d1, float 
 }
 
 // rqs_forward for one element: returns y, adds log dy/dx to logd
-template <int K>
+template <int K, bool LAZY>
 __device__ __forceinline__ float rqs_fwd_elem(const Knots<K> &kn, float x, float &logd) {
-  const Bin b = find_bin<K>(kn, kn.pX, x);
+  const Bin b = find_bin<K, LAZY>(kn, kn.pX, x);
   const float dx = b.xk1 - b.xk, dy = b.yk1 - b.yk;
   const float s = nf_fdiv(dy, dx);
   const float xi = nf_fdiv(x - b.xk, dx), om = 1.f - xi;
@@ -241,9 +271,9 @@ __device__ __forceinline__ float rqs_fwd_elem(const Knots<K> &kn, float x, float
 }
 
 // rqs_inverse for one element: returns x and the bin / xi it lies in; adds -log dy/dx to logd
-template <int K>
+template <int K, bool LAZY>
 __device__ __forceinline__ float rqs_inv_elem(const Knots<K> &kn, float y, float &logd, Bin &b, float &xi_out) {
-  b = find_bin<K>(kn, kn.pY, y);
+  b = find_bin<K, LAZY>(kn, kn.pY, y);
   const float dx = b.xk1 - b.xk, dy = b.yk1 - b.yk;
   const float s = nf_fdiv(dy, dx);
   const float yy = y - b.yk;
@@ -309,11 +339,10 @@ __device__ __forceinline__ float rqs_bwd_elem(const Knots<K> &kn, const float *r
     thbar[i] = kn.smw[i] * (sbw[i] - dotw);
     thbar[K + i] = kn.smh[i] * (sbh[i] - doth);
   }
+  // d/draw softplus = sigmoid(raw) = 1 - exp(-softplus(raw)); only knots k and k+1 carry a cotangent
+  const float g0 = d0bar * (1.f - __expf(-d0)), g1 = d1bar * (1.f - __expf(-d1));
 #pragma unroll
-  for (int j = 1; j < K; ++j) {
-    const float ddb = ((j == b.k) ? d0bar : 0.f) + ((j == b.k + 1) ? d1bar : 0.f);
-    thbar[2 * K + j - 1] = ddb * (1.f - __expf(-kn.dd[j]));  // d/draw softplus = sigmoid(raw) = 1 - exp(-softplus(raw))
-  }
+  for (int j = 1; j < K; ++j) thbar[2 * K + j - 1] = ((j == b.k) ? g0 : 0.f) + ((j == b.k + 1) ? g1 : 0.f);
   return b.inside ? xibar * idx : ybar;
 }
 
@@ -375,15 +404,15 @@ __device__ __forceinline__ float rqs_coupling_step(const float *__restrict__ img
       float raw[G::P];
       chunk_get<G>(out, ql, raw);
       Knots<G::K> kn;
-      build_knots<G::K>(raw, B, kn);
+      build_knots<G::K, true>(raw, B, kn);
       const float v = x1[q / 16][q % 16];
       float logd = 0.f, res;
       if (INVERSE) {
         Bin bn;
         float xi;
-        res = rqs_inv_elem<G::K>(kn, v, logd, bn, xi);
+        res = rqs_inv_elem<G::K, true>(kn, v, logd, bn, xi);
       } else {
-        res = rqs_fwd_elem<G::K>(kn, v, logd);
+        res = rqs_fwd_elem<G::K, true>(kn, v, logd);
       }
       const bool ok = p < c;  // padded dims: keep the zero, contribute nothing
       x1[q / 16][q % 16] = ok ? res : v;
@@ -629,14 +658,14 @@ __device__ __forceinline__ void rqs_bwd_tile(const RqsBwdArgs &a, const float *_
       float raw[G::P], thb[G::P];
       chunk_get<G>(out, ql, raw);
       Knots<G::K> kn;
-      build_knots<G::K>(raw, a.B, kn);
+      build_knots<G::K, false>(raw, a.B, kn);
       const float yv = yq[ql];
       const float gv = ok ? gq[ql] : 0.f;
       // invert to the coupling input (src/flows/neuralspline.jl:134-140), then differentiate the
       // forward map at that point
       float dummy = 0.f, xi;
       Bin bn;
-      const float xv = rqs_inv_elem<G::K>(kn, yv, dummy, bn, xi);
+      const float xv = rqs_inv_elem<G::K, false>(kn, yv, dummy, bn, xi);
       const float xbar = rqs_bwd_elem<G::K>(kn, raw, bn, xi, a.B, gv, ok ? lb : 0.f, thb);  // gv, lb are 0 when !ok
       chunk_put<G>(out, ql, thb);
       tile_store(yio, tile_soff(q / 16, q % 16, a.par_t), xv);    // coupling input x1
