@@ -80,6 +80,15 @@ size_t nf_simple_bwd_ws_bytes(nf_ctx *, const nf_flow_desc *, long N);
 int nf_simple_bwd(nf_ctx *, const nf_flow_desc *, const void *theta, const void *x, const void *ybar, const void *lbar,
                   double lbar_const, long N, void *xbar_out, void *gtheta_out, void *ws);
 
+// general coupling kernels (nf_generic64.hip): Float64, and the Float32 shapes the MFMA paths do not
+// build; one thread per sample, standard layout
+bool nf_g64_supported(const nf_flow_desc *desc);
+int nf_g64_apply(nf_ctx *, const nf_flow_desc *, int layer_lo, int layer_hi, bool inverse, const void *theta,
+                 const void *x, long N, void *y, void *ladj);
+size_t nf_g64_bwd_ws_bytes(const nf_flow_desc *desc, long N);
+int nf_g64_bwd(nf_ctx *, const nf_flow_desc *, const void *theta, const void *x, const void *ybar, const void *lbar,
+               double lbar_const, long N, void *xbar_out, void *gtheta_out, void *ws);
+
 // ---- helpers -----------------------------------------------------------------------------
 static inline size_t esize(int dtype) { return dtype == NF_DTYPE_F64 ? 8 : 4; }
 
@@ -95,12 +104,12 @@ static int check_desc(const nf_flow_desc *d) {
     case NF_KIND_REALNVP:
       if (d->n_hidden < 1 || d->n_hidden > NF_MAX_HIDDEN) return NF_ERR_ARG;
       if (d->d < 2) return NF_ERR_ARG;
-      if (d->dtype != NF_DTYPE_F32) return NF_ERR_UNSUPPORTED;
-      return (nf_affine_supported(d) || nf_wide_supported(d)) ? NF_OK : NF_ERR_UNSUPPORTED;
+      if (d->dtype != NF_DTYPE_F32) return nf_g64_supported(d) ? NF_OK : NF_ERR_UNSUPPORTED;
+      return (nf_affine_supported(d) || nf_wide_supported(d) || nf_g64_supported(d)) ? NF_OK : NF_ERR_UNSUPPORTED;
     case NF_KIND_NSF:
       if (d->n_hidden < 1 || d->n_hidden > NF_MAX_HIDDEN || d->d < 2 || d->K < 2) return NF_ERR_ARG;
-      if (d->dtype != NF_DTYPE_F32) return NF_ERR_UNSUPPORTED;
-      return nf_rqs_supported(d) ? NF_OK : NF_ERR_UNSUPPORTED;
+      if (d->dtype != NF_DTYPE_F32) return nf_g64_supported(d) ? NF_OK : NF_ERR_UNSUPPORTED;
+      return (nf_rqs_supported(d) || nf_g64_supported(d)) ? NF_OK : NF_ERR_UNSUPPORTED;
     default:
       return NF_ERR_ARG;
   }
@@ -262,8 +271,32 @@ extern "C" int nf_base_logpdf(nf_ctx *ctx, int32_t dtype, int32_t d, int64_t N, 
 // Coupling flows work on the TILED batch layout internally (nf_elementwise.hip); user-facing
 // batches are converted at the API edge.  Element count of a tiled buffer:
 static inline size_t tiled_elems(const nf_flow_desc *desc, long N) { return (size_t)((N + 31) / 32) * 32 * desc->d; }
+// coupling flows on the tiled fp32 MFMA path; Float64 couplings and the Float32 shapes those kernels do
+// not build (other than two hidden layers, wider NSF nets, other K) take the standard-layout route below
 static inline bool is_coupling(const nf_flow_desc *desc) {
-  return desc->kind == NF_KIND_REALNVP || desc->kind == NF_KIND_NSF;
+  if (desc->dtype != NF_DTYPE_F32) return false;
+  if (desc->kind == NF_KIND_REALNVP) return nf_affine_supported(desc) || nf_wide_supported(desc);
+  if (desc->kind == NF_KIND_NSF) return nf_rqs_supported(desc);
+  return false;
+}
+static inline bool is_g64(const nf_flow_desc *desc) {
+  return (desc->kind == NF_KIND_REALNVP || desc->kind == NF_KIND_NSF) && !is_coupling(desc);
+}
+// standard-layout flows: planar / radial / mean-field (nf_simple.hip) and Float64 couplings
+static int flat_apply(nf_ctx *ctx, const nf_flow_desc *desc, int lo, int hi, bool inverse, const void *theta,
+                      const void *x, long N, void *y, void *ladj) {
+  if (is_g64(desc))
+    return nf_g64_apply(ctx, desc, lo, hi, inverse, theta, x, N, y, ladj);
+  return nf_simple_apply(ctx, desc, lo, hi, inverse, theta, x, N, y, ladj);
+}
+static size_t flat_bwd_ws_bytes(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
+  return is_g64(desc) ? nf_g64_bwd_ws_bytes(desc, N) : nf_simple_bwd_ws_bytes(ctx, desc, N);
+}
+static int flat_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *x, const void *ybar,
+                    const void *lbar, double lbar_const, long N, void *xbar_out, void *gtheta_out, void *ws) {
+  if (is_g64(desc))
+    return nf_g64_bwd(ctx, desc, theta, x, ybar, lbar, lbar_const, N, xbar_out, gtheta_out, ws);
+  return nf_simple_bwd(ctx, desc, theta, x, ybar, lbar, lbar_const, N, xbar_out, gtheta_out, ws);
 }
 static inline bool is_nsf(const nf_flow_desc *desc) { return desc->kind == NF_KIND_NSF; }
 // RealNVP shapes whose nets do not fit in LDS take the weight-streaming kernels
@@ -331,8 +364,8 @@ static int apply_std(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, int la
     return nf_launch_layout_convert(ctx, desc->d, N, xt, (float *)y_out, 0);
   }
   const int nl = nf_layer_count(desc);
-  if (layer >= 0) return nf_simple_apply(ctx, desc, layer, layer + 1, inverse, theta, x_in, N, y_out, ladj);
-  return nf_simple_apply(ctx, desc, 0, nl, inverse, theta, x_in, N, y_out, ladj);
+  if (layer >= 0) return flat_apply(ctx, desc, layer, layer + 1, inverse, theta, x_in, N, y_out, ladj);
+  return flat_apply(ctx, desc, 0, nl, inverse, theta, x_in, N, y_out, ladj);
 }
 
 extern "C" int nf_flow_fwd(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *x_in, int64_t N,
@@ -406,8 +439,8 @@ extern "C" int nf_flow_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const void *th
                        (float *)gtheta_out));
     return nf_launch_layout_convert(ctx, desc->d, N, gt, (float *)xbar_out, 0);
   }
-  NF_TRY(nf_ws_reserve(ctx, nf_simple_bwd_ws_bytes(ctx, desc, N)));
-  return nf_simple_bwd(ctx, desc, theta, x, ybar, lbar, 0.0, N, xbar_out, gtheta_out, ctx->ws);
+  NF_TRY(nf_ws_reserve(ctx, flat_bwd_ws_bytes(ctx, desc, N)));
+  return flat_bwd(ctx, desc, theta, x, ybar, lbar, 0.0, N, xbar_out, gtheta_out, ctx->ws);
 }
 
 // ---- targets -------------------------------------------------------------------------------
@@ -460,7 +493,7 @@ static int elbo_forward(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *
     } else {
       NF_TRY(nf_launch_base_sample(ctx, desc->dtype, desc->d, N, seed, off, stream_id, x, logq));
     }
-    NF_TRY(nf_simple_apply(ctx, desc, 0, nf_layer_count(desc), false, theta, x, N, x, ladj));
+    NF_TRY(flat_apply(ctx, desc, 0, nf_layer_count(desc), false, theta, x, N, x, ladj));
     NF_TRY(nf_launch_target(ctx, desc->dtype, target, desc->d, N, x, logq, ladj, nullptr, nullptr, 0.0, elbos_out,
                             partial, 1.0 / (double)N));
   }
@@ -508,7 +541,7 @@ extern "C" int nf_loglikelihood(nf_ctx *ctx, const nf_flow_desc *desc, const voi
     NF_TRY(coupling_chain_tiled(ctx, desc, true, (const float *)theta, xt, N, (float *)ladj, -1));
     NF_TRY(nf_launch_base_logpdf_tiled(ctx, desc->d, N, xt, (float *)logq));
   } else {
-    NF_TRY(nf_simple_apply(ctx, desc, 0, nf_layer_count(desc), true, theta, ys, N, x, ladj));
+    NF_TRY(flat_apply(ctx, desc, 0, nf_layer_count(desc), true, theta, ys, N, x, ladj));
     NF_TRY(nf_launch_base_logpdf(ctx, desc->dtype, desc->d, N, x, logq));
   }
   NF_TRY(nf_launch_sum2(ctx, desc->dtype, N, logq, ladj, logliks_out, partial, 1.0 / (double)N));
@@ -532,7 +565,7 @@ extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, con
   const bool cp = is_coupling(desc);
   const long nb = cp ? nf_target_tiled_nblocks(N) : nf_target_nblocks(N);
   const int grid = cp ? coupling_bwd_grid(ctx, desc, N) : 0;
-  const size_t simple_ws = cp ? 0 : nf_simple_bwd_ws_bytes(ctx, desc, N);
+  const size_t simple_ws = cp ? 0 : flat_bwd_ws_bytes(ctx, desc, N);
   const bool wide = cp && is_wide(desc);
   const size_t slabf = wide ? nf_wide_train_ws_floats(ctx, desc, N) : cp ? (size_t)grid * coupling_slab_floats(ctx, desc, N) : 0;
   const size_t xe = cp ? tiled_elems(desc, N) : (size_t)N * desc->d;
@@ -597,9 +630,9 @@ extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, con
     } else {
       NF_TRY(nf_launch_base_sample(ctx, dt, desc->d, N, seed, sample_offset, stream_id, x0, logq));
     }
-    NF_TRY(nf_simple_apply(ctx, desc, 0, nf_layer_count(desc), false, theta, x0, N, x, ladj));
+    NF_TRY(flat_apply(ctx, desc, 0, nf_layer_count(desc), false, theta, x0, N, x, ladj));
     NF_TRY(nf_launch_target(ctx, dt, target, desc->d, N, x, logq, ladj, nullptr, gbar, -inv, nullptr, partial, -inv));
-    NF_TRY(nf_simple_bwd(ctx, desc, theta, x0, gbar, nullptr, -inv, N, gbar, out, sws));
+    NF_TRY(flat_bwd(ctx, desc, theta, x0, gbar, nullptr, -inv, N, gbar, out, sws));
   }
   if (cp) return NF_OK;
   if (dt == NF_DTYPE_F32)

@@ -279,7 +279,7 @@ def test_unsupported_shapes_fail_loudly(nf):
     big = nf.realnvp(nf.MvNormal(16), [512, 512], 1, paramtype=torch.float32)  # hidden > 256
     with pytest.raises(nf.NFHipError, match="not built"):
         nf.with_logabsdet_jacobian(big.transform, torch.zeros(4, 16, device="cuda").t())
-    f64 = nf.realnvp(nf.MvNormal(4), [8, 8], 1, paramtype=torch.float64)
+    f64 = nf.realnvp(nf.MvNormal(4), [200, 8], 1, paramtype=torch.float64)  # Float64 couplings: hidden <= 128
     with pytest.raises(nf.NFHipError, match="not built"):
         nf.with_logabsdet_jacobian(f64.transform, torch.zeros(4, 2, dtype=torch.float64, device="cuda"))
     with pytest.raises(nf.NFHipError):
@@ -427,3 +427,64 @@ def test_wide_pullback_with_recompute_matches_stashed_training_path(nf):
     l2, g2 = nf.value_and_gradient(nf.elbo_batch, flow, logp, xs)
     assert l1 == pytest.approx(l2, rel=1e-5)
     assert float((g1 - g2).abs().max()) <= 1e-4 * float(g1.abs().max())
+
+
+@pytest.mark.parametrize("kind,d,hd,nl,K", [("realnvp", 5, (32, 32), 2, 0), ("realnvp", 8, (16,), 1, 0), ("nsf", 5, (32, 32), 2, 10),
+                                            ("nsf", 6, (24, 16, 8), 1, 8)],
+                         ids=["realnvp_d5", "realnvp_d8_1hidden", "nsf_d5_k10", "nsf_d6_3hidden"])
+def test_float64_coupling_flows_match_oracle(nf, kind, d, hd, nl, K):
+    """The reference's flow tests run RealNVP and NSF in Float64 too (test/flow.jl:7,72; eltype in =
+    eltype out, :20-21; invertibility at rtol 1e-6, :26-38).  Float64 couplings take the general
+    one-thread-per-sample kernels (nf_generic64.hip), any number of hidden layers up to 4."""
+    spec = o.FlowSpec(kind, d, nl, hd, K, 5.0) if kind == "nsf" else o.FlowSpec(kind, d, nl, hd)
+    rng = np.random.default_rng(d)
+    th = o.init_params(spec, rng) + 0.05 * rng.standard_normal(o.param_count(spec))
+    flow = nf.Flow(kind, nf.MvNormal(d), nl, hd, K, 5.0, dtype=torch.float64, device="cuda",
+                   theta=torch.tensor(th, dtype=torch.float64, device="cuda"))
+    n = 97
+    xs = rng.standard_normal((d, n)) * 1.5
+    ys_ref, l_ref = o.flow_fwd(spec, th, xs)
+    ys, ladj = nf.with_logabsdet_jacobian(flow.transform, cm(xs, torch.float64))
+    assert ys.dtype == torch.float64 and ladj.dtype == torch.float64
+    assert approx(ys.cpu().numpy(), ys_ref, 1e-12) and approx(ladj.cpu().numpy(), l_ref, 1e-11)
+    xr, lb = nf.with_logabsdet_jacobian(nf.inverse(flow.transform), ys)
+    assert approx(xr.cpu().numpy(), xs, 1e-9) and approx(lb.cpu().numpy(), -l_ref, 1e-9)
+    yv, lv = nf.with_logabsdet_jacobian(flow.transform, torch.tensor(xs[:, 0], device="cuda"))  # vector input
+    np.testing.assert_allclose(yv.cpu().numpy(), ys_ref[:, 0], rtol=1e-12, atol=1e-13)
+    mu, var = rng.standard_normal(d), rng.uniform(size=d) + 0.5
+    tgt = nf.DiagGaussTarget(torch.tensor(mu, device="cuda"), torch.tensor(var, device="cuda"))
+    loss, g = nf.value_and_gradient(nf.elbo_batch, flow, tgt, cm(xs, torch.float64))
+    lr, gr = o.neg_elbo_value_and_grad(spec, th, ("diaggauss", mu, var), xs)
+    assert loss == pytest.approx(lr, rel=1e-11)
+    assert np.abs(g.cpu().numpy() - gr).max() <= 1e-10 * max(1.0, np.abs(gr).max())
+    ll = nf.loglikelihood(None, flow, ys)
+    assert ll == pytest.approx(float(np.mean(o.std_normal_logpdf(xs) - l_ref)), rel=1e-10, abs=1e-10)
+    l2, g2 = nf.value_and_gradient(nf.elbo_batch, flow, tgt, n, rng=nf.PhiloxRNG(5))  # in-library draws
+    assert np.isfinite(l2) and bool(torch.isfinite(g2).all())
+
+
+@pytest.mark.parametrize("kind,d,hd,nl,K", [("realnvp", 6, (16,), 1, 0), ("realnvp", 9, (24, 16, 8), 1, 0), ("nsf", 4, (16, 16), 1, 5),
+                                            ("nsf", 6, (64, 64), 1, 8)],
+                         ids=["realnvp_1hidden", "realnvp_3hidden", "nsf_k5", "nsf_h64"])
+def test_float32_shapes_outside_the_mfma_kernels(nf, kind, d, hd, nl, K):
+    """Float32 coupling flows with other than two hidden layers, K other than 8/10 or NSF nets wider
+    than 32 run on the general kernels (nf_generic64.hip) at the same fp32 parity bar."""
+    spec = o.FlowSpec(kind, d, nl, hd, K, 5.0) if kind == "nsf" else o.FlowSpec(kind, d, nl, hd)
+    rng = np.random.default_rng(d + 100)
+    th = (o.init_params(spec, rng) + 0.05 * rng.standard_normal(o.param_count(spec))).astype(np.float32)
+    flow = nf.Flow(kind, nf.MvNormal(d), nl, hd, K, 5.0, dtype=torch.float32, device="cuda", theta=torch.tensor(th, device="cuda"))
+    n = 130
+    xs = (rng.standard_normal((d, n)) * 1.5).astype(np.float32)
+    th64, xs64 = th.astype(np.float64), xs.astype(np.float64)
+    ys_ref, l_ref = o.flow_fwd(spec, th64, xs64)
+    ys, ladj = nf.with_logabsdet_jacobian(flow.transform, cm(xs, torch.float32))
+    assert ys.dtype == torch.float32
+    assert approx(ys.cpu().numpy(), ys_ref, 2e-5) and approx(ladj.cpu().numpy(), l_ref, 2e-5)
+    xr, lb = nf.with_logabsdet_jacobian(nf.inverse(flow.transform), ys)
+    assert approx(xr.cpu().numpy(), xs64, 2e-4) and approx(lb.cpu().numpy(), -l_ref, 2e-4)
+    mu, var = rng.standard_normal(d).astype(np.float32), (rng.uniform(size=d) + 0.5).astype(np.float32)
+    tgt = nf.DiagGaussTarget(torch.tensor(mu, device="cuda"), torch.tensor(var, device="cuda"))
+    loss, g = nf.value_and_gradient(nf.elbo_batch, flow, tgt, cm(xs, torch.float32))
+    lr, gr = o.neg_elbo_value_and_grad(spec, th64, ("diaggauss", mu.astype(np.float64), var.astype(np.float64)), xs64)
+    assert loss == pytest.approx(lr, rel=2e-5)
+    assert np.abs(g.cpu().numpy() - gr).max() <= 2e-4 * np.abs(gr).max()
