@@ -198,10 +198,13 @@ def optimize(loss_and_grad: Callable, theta0: torch.Tensor, reconstruct, *, max_
             buf = torch.cat([g, torch.tensor([ls], dtype=g.dtype, device=g.device)])
             all_reduce(buf)
             g, ls = buf[:-1], float(buf[-1])
+        # the reference records the stat and runs the callback on the parameters BEFORE the update
+        # (src/optimize.jl:88-99); the gradient norm comes out of the same kernel as the update
+        theta_before = theta.clone() if callback is not None else None
         gn = adam_update(optimiser, st, theta, g)
         stat = {"iteration": i, "loss": ls, "gradient_norm": float(gn)}
         if callback is not None:
-            new_stat = callback(i, opt_stats, reconstruct, theta)
+            new_stat = callback(i, opt_stats, reconstruct, theta_before)
             if new_stat is not None:
                 stat.update(new_stat)
         opt_stats.append(stat)
