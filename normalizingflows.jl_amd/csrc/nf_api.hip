@@ -41,15 +41,6 @@ int nf_affine_reduce_slabs(nf_ctx *, const nf_flow_desc *, const float *slab, in
 int nf_affine_bwd(nf_ctx *, const nf_flow_desc *, int k, const float *theta, float *y, float *ybar, const float *lbar,
                   float lbar_const, long N, float *slab, long slab_stride, int grid);
 
-// 16-sample-tile reverse pass (nf_coupling16.hip)
-bool nf_bwd16_supported(const nf_flow_desc *desc);
-long nf_bwd16_slab_floats(const nf_flow_desc *desc);
-int nf_bwd16_pack(nf_ctx *, const nf_flow_desc *, const float *theta);
-int nf_bwd16_reduce_slabs(nf_ctx *, const nf_flow_desc *, const float *slab, int nslab, float *g);
-int nf_bwd16_grid(nf_ctx *, long N);
-int nf_bwd16(nf_ctx *, const nf_flow_desc *, int k, float *y, float *ybar, const float *lbar, float lbar_const, long N,
-             float *slab, long stride, int grid);
-
 // RealNVP with conditioner nets streamed from L2 (nf_wide.hip): d <= 256, hidden <= 256
 bool nf_wide_supported(const nf_flow_desc *desc);
 int nf_wide_pack(nf_ctx *, const nf_flow_desc *, const float *theta);
@@ -213,7 +204,6 @@ extern "C" int nf_ctx_destroy(nf_ctx *ctx) {
   if (ctx->ws) hipFree(ctx->ws);
   if (ctx->gbuf) hipFree(ctx->gbuf);
   if (ctx->wimg) hipFree(ctx->wimg);
-  if (ctx->wimg16) hipFree(ctx->wimg16);
   if (ctx->trace) hipFree(ctx->trace);
   if (ctx->host_scratch) hipHostFree(ctx->host_scratch);
   delete ctx;
@@ -303,29 +293,17 @@ static inline bool is_nsf(const nf_flow_desc *desc) { return desc->kind == NF_KI
 static inline bool is_wide(const nf_flow_desc *desc) {
   return desc->kind == NF_KIND_REALNVP && !nf_affine_supported(desc) && nf_wide_supported(desc);
 }
-// RealNVP reverse pass: the 16-sample-tile kernel (two waves per SIMD, nf_coupling16.hip) is an
-// EXPERIMENT, off by default: it is parity-green but measured slower on MI355X (128 us vs 75 us per
-// coupling at the benchmark shape; register spills at 256 registers/wave).  NF_BWD16=1 selects it.
-static bool use_bwd16(const nf_flow_desc *desc) {
-  static const bool enabled = [] {
-    const char *e = getenv("NF_BWD16");
-    return e && e[0] == '1';
-  }();
-  return enabled && !is_nsf(desc) && nf_bwd16_supported(desc);
-}
 static int coupling_pack(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta) {
   if (is_wide(desc)) return nf_wide_pack(ctx, desc, theta);
   return is_nsf(desc) ? nf_rqs_pack(ctx, desc, theta) : nf_affine_pack(ctx, desc, theta);
 }
 static int coupling_bwd_grid(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
   if (is_wide(desc)) return 1;
-  if (use_bwd16(desc)) return nf_bwd16_grid(ctx, N);
   return is_nsf(desc) ? nf_rqs_bwd_grid(ctx, N) : nf_affine_bwd_grid(ctx, N);
 }
 // floats of reverse-pass workspace per workgroup slab (wide path: the whole stash + split-K area)
 static long coupling_slab_floats(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
   if (is_wide(desc)) return (long)nf_wide_bwd_ws_floats(ctx, desc, N);
-  if (use_bwd16(desc)) return nf_bwd16_slab_floats(desc);
   return is_nsf(desc) ? nf_rqs_slab_floats(desc) : nf_affine_slab_floats(desc);
 }
 
@@ -400,12 +378,6 @@ static int realnvp_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta
   if (is_wide(desc)) return nf_wide_bwd(ctx, desc, state, gbar, lbar, lbar_const, N, slab, g_out);
   const long stride = coupling_slab_floats(ctx, desc, N);
   const int nc = 2 * desc->nlayers;
-  if (use_bwd16(desc)) {
-    NF_TRY(nf_bwd16_pack(ctx, desc, theta));
-    for (int k = 0; k < nc; ++k)
-      NF_TRY(nf_bwd16(ctx, desc, k, state, gbar, lbar, lbar_const, N, slab, stride, grid));
-    return nf_bwd16_reduce_slabs(ctx, desc, slab, grid, g_out);
-  }
   for (int k = 0; k < nc; ++k) {  // flat order = reverse of execution order
     if (is_nsf(desc))
       NF_TRY(nf_rqs_bwd(ctx, desc, k, state, gbar, lbar, lbar_const, N, slab, stride, grid));

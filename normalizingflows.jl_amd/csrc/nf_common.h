@@ -37,8 +37,6 @@ struct nf_ctx {
   // packed (padded) LDS images of the conditioner nets, rebuilt from theta once per API call
   void *wimg = nullptr;
   size_t wimg_bytes = 0;
-  void *wimg16 = nullptr;  // same, in the row-padding-4 layout of the 16x16x4 reverse-pass kernel
-  size_t wimg16_bytes = 0;
   // optional in-kernel s_memtime trace (nf_debug_trace): 128 slots, device memory
   void *trace = nullptr;
   // device gradient buffer of nf_elbo_step (P + 2 elements), grow-only

@@ -26,11 +26,7 @@ buf = (C.c_int64 * 128)()
 lib.nf_debug_trace(ctx.ptr, 0, buf, 128)
 t = list(buf)
 t0 = t[0]
-if os.environ.get("NF_BWD16", "1") != "0":
-    names = ["start", "x2 loaded+stashed", "fwd L1-L3", "y1/g1 load + element-wise", "stash d3 + fence", "dW3", "dX3 + scale",
-             "stash d2 + dW2", "dX2 + scale", "stash d1 + dW1", "dX1 + x2bar stores"]
-else:
-    names = ["start", "x2 loaded", "fwd L1-L3 (+stash x2,a1,a2)", "element-wise", "dX3 (+stash d3)", "dW3 (+d2 scale)",
+names = ["start", "x2 loaded", "fwd L1-L3 (+stash x2,a1,a2)", "element-wise", "dX3 (+stash d3)", "dW3 (+d2 scale)",
              "dX2 (+stash d2)", "dW2 (+d1 scale)", "dX1 (+stash d1)", "dW1 (+x2bar stores)", "tail fence"]
 print("kernel: staged phaseT @", t[1] - t0, " tiles done @", t[2] - t0, " folded+slab @", t[3] - t0)
 print("        staged phaseS @", t[4] - t0, " tiles done @", t[5] - t0, " folded+slab @", t[6] - t0)
