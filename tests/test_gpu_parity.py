@@ -488,3 +488,25 @@ def test_float32_shapes_outside_the_mfma_kernels(nf, kind, d, hd, nl, K):
     lr, gr = o.neg_elbo_value_and_grad(spec, th64, ("diaggauss", mu.astype(np.float64), var.astype(np.float64)), xs64)
     assert loss == pytest.approx(lr, rel=2e-5)
     assert np.abs(g.cpu().numpy() - gr).max() <= 2e-4 * np.abs(gr).max()
+
+
+@pytest.mark.parametrize("kind", ["realnvp", "nsf"])
+def test_training_improves_the_elbo_on_the_banana_target(nf, kind):
+    """End-to-end train_flow on the demos' Banana target (example/demo_RealNVP.jl, demo_neural_spline_flow.jl
+    shape, shortened): the ELBO estimated on fresh draws rises by a wide margin and samples of the
+    trained flow land in the target's high-density region."""
+    d = 2
+    q0 = nf.MvNormal(d)
+    if kind == "realnvp":
+        flow = nf.realnvp(q0, [32, 32], 3, paramtype=torch.float32, seed=1)
+    else:
+        flow = nf.nsf(q0, [32, 32], 10, 30.0, 2, paramtype=torch.float32, seed=1)
+    tgt = nf.BananaTarget(d, 1.0, 10.0)
+    el0 = nf.elbo_batch(nf.PhiloxRNG(99), flow, tgt, 4096)
+    trained, stats, st = nf.train_flow(nf.PhiloxRNG(1), nf.elbo_batch, flow, tgt, 512, max_iters=400, optimiser=nf.Adam(2e-3))
+    el1 = nf.elbo_batch(nf.PhiloxRNG(99), trained, tgt, 4096)
+    assert np.isfinite(el1) and el1 > el0 + 5.0 and el1 > -2.5  # exact posterior would give 0; untrained is about -40
+    assert stats[-1]["iteration"] == 400 and np.isfinite(stats[-1]["loss"])
+    ys = nf.rand(trained, 2000, nf.PhiloxRNG(7))
+    lp = nf.target_logp(tgt, ys)
+    assert float(lp.mean()) > -6.0  # E_p[log p] of Banana(2, 1, 10) is about -4; an untrained flow sits far below
