@@ -180,6 +180,11 @@ int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, const nf_targe
 int nf_adam_update(nf_ctx *ctx, int32_t dtype, void *theta, const void *g, void *m, void *v,
                    int64_t P, double lr, double beta1, double beta2, double eps, int64_t t,
                    void *gnorm_out);
+/* Optimisers.Descent(lr) (vel = NULL: theta -= lr g) and Optimisers.Momentum(lr, rho)
+ * (vel = rho vel - lr g; theta += vel) -- the other rules the reference's `optimiser` keyword
+ * is commonly given (src/optimize.jl:67); gnorm_out as in nf_adam_update. */
+int nf_sgd_update(nf_ctx *ctx, int32_t dtype, void *theta, const void *g, void *vel, int64_t P,
+                  double lr, double rho, void *gnorm_out);
 /* Single-GPU convenience: nf_elbo_value_and_grad + nf_adam_update in one call; returns the
  * loss and gradient norm of the step (the stat tuple of src/optimize.jl:89). */
 int nf_elbo_step(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, void *theta,

@@ -9,7 +9,7 @@ from .flows import (BananaTarget, CrossTarget, DiagGaussTarget, FunnelTarget, Wa
                     device_specific_rand, inverse, layer, logpdf, meanfield, new_batch, nsf, planarflow, radialflow,
                     rand, realnvp, target_logp, transform, with_logabsdet_jacobian)
 from .parallel import ShardedObjective, allreduce_grad_loss, make_gpu_local_step, shard_range
-from .objectives import (Adam, AdamState, adam_update, batched_elbos, elbo, elbo_batch, loglikelihood, optimize,
+from .objectives import (Adam, AdamState, Descent, Momentum, SGDState, adam_update, setup, update, batched_elbos, elbo, elbo_batch, loglikelihood, optimize,
                          train_flow, value_and_gradient)
 
 _device_specific_rand = device_specific_rand  # the reference's (underscored) extension hook name
@@ -19,5 +19,5 @@ __all__ = [
     "planarflow", "radialflow", "realnvp", "nsf", "meanfield",
     "with_logabsdet_jacobian", "transform", "inverse", "logpdf", "rand", "layer",
     "MvNormal", "PhiloxRNG", "device_specific_rand", "_device_specific_rand",
-    "DiagGaussTarget", "BananaTarget", "FunnelTarget", "WarpedGaussTarget", "CrossTarget", "Adam", "value_and_gradient",
+    "DiagGaussTarget", "BananaTarget", "FunnelTarget", "WarpedGaussTarget", "CrossTarget", "Adam", "Descent", "Momentum", "value_and_gradient",
 ]

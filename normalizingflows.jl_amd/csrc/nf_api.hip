@@ -18,6 +18,7 @@ int nf_launch_reduce_slabs(nf_ctx *, int, const void *, int, long, void *);
 long nf_adam_nblocks(long P);
 int nf_launch_adam(nf_ctx *, int, void *, const void *, void *, void *, long, double, double, double, double, long,
                    double *);
+int nf_launch_sgd(nf_ctx *, int, void *, const void *, void *, long, double, double, double *);
 int nf_launch_fill(nf_ctx *, int, void *, long, double);
 int nf_launch_base_sample_tiled(nf_ctx *, int d, long N, uint64_t seed, uint64_t off, uint32_t stream, float *xt, float *logq);
 int nf_launch_base_logpdf_tiled(nf_ctx *, int d, long N, const float *xt, float *logq);
@@ -626,6 +627,26 @@ extern "C" int nf_adam_update(nf_ctx *ctx, int32_t dtype, void *theta, const voi
     partial = (double *)((char *)ctx->ws + ctx->ws_bytes - carve_bytes((size_t)nb * 8));
   }
   NF_TRY(nf_launch_adam(ctx, dtype, theta, g, m, v, P, lr, beta1, beta2, eps, t, partial));
+  if (gnorm_out) {
+    if (dtype == NF_DTYPE_F32) return nf_launch_finish_sum(ctx, partial, nb, 1, nullptr, (float *)gnorm_out, nullptr);
+    return nf_launch_finish_sum(ctx, partial, nb, 1, (double *)gnorm_out, nullptr, nullptr);
+  }
+  return NF_OK;
+}
+
+extern "C" int nf_sgd_update(nf_ctx *ctx, int32_t dtype, void *theta, const void *g, void *vel, int64_t P, double lr,
+                             double rho, void *gnorm_out) {
+  if (!ctx || !theta || !g || P < 0) return NF_ERR_ARG;
+  if (dtype != NF_DTYPE_F32 && dtype != NF_DTYPE_F64) return NF_ERR_ARG;
+  NF_HIP(hipSetDevice(ctx->device));
+  if (P == 0) return NF_OK;
+  double *partial = nullptr;
+  const long nb = nf_adam_nblocks(P);
+  if (gnorm_out) {
+    NF_TRY(nf_ws_reserve(ctx, carve_bytes((size_t)nb * 8)));
+    partial = (double *)((char *)ctx->ws + ctx->ws_bytes - carve_bytes((size_t)nb * 8));
+  }
+  NF_TRY(nf_launch_sgd(ctx, dtype, theta, g, vel, P, lr, rho, partial));
   if (gnorm_out) {
     if (dtype == NF_DTYPE_F32) return nf_launch_finish_sum(ctx, partial, nb, 1, nullptr, (float *)gnorm_out, nullptr);
     return nf_launch_finish_sum(ctx, partial, nb, 1, (double *)gnorm_out, nullptr, nullptr);

@@ -302,6 +302,31 @@ __global__ __launch_bounds__(EW_BLOCK) void k_adam(T *__restrict__ theta, const 
   }
 }
 
+// Optimisers.Descent (vel == nullptr): theta -= lr g.  Optimisers.Momentum: vel = rho vel - lr g,
+// theta += vel.  Same gradient-norm partials as k_adam.
+template <class T>
+__global__ __launch_bounds__(EW_BLOCK) void k_sgd(T *__restrict__ theta, const T *__restrict__ g, T *__restrict__ vel,
+                                                  long P, T lr, T rho, double *__restrict__ partial) {
+  __shared__ double sm[EW_BLOCK / 64];
+  const long p = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
+  double gg = 0.0;
+  if (p < P) {
+    const T gi = g[p];
+    if (vel) {
+      const T vi = rho * vel[p] - lr * gi;
+      vel[p] = vi;
+      theta[p] += vi;
+    } else {
+      theta[p] -= lr * gi;
+    }
+    gg = (double)gi * (double)gi;
+  }
+  if (partial) {
+    const double s = block_sum(gg, sm);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // TILED batch layout used between the coupling kernels (internal to the library):
 // samples are grouped in tiles of 32; element (feature f, sample s of tile t) lives at
@@ -585,6 +610,18 @@ int nf_launch_adam(nf_ctx *ctx, int dtype, void *theta, const void *g, void *m, 
   else
     hipLaunchKernelGGL(k_adam<double>, dim3(nblk(P, EW_BLOCK)), dim3(EW_BLOCK), 0, ctx->stream, (double *)theta,
                        (const double *)g, (double *)m, (double *)v, P, lr, b1, b2, eps, c1, c2, partial);
+  return (int)hipGetLastError();
+}
+
+int nf_launch_sgd(nf_ctx *ctx, int dtype, void *theta, const void *g, void *vel, long P, double lr, double rho,
+                  double *partial) {
+  ProfScope ps(ctx, "adam");
+  if (dtype == NF_DTYPE_F32)
+    hipLaunchKernelGGL(k_sgd<float>, dim3(nblk(P, EW_BLOCK)), dim3(EW_BLOCK), 0, ctx->stream, (float *)theta,
+                       (const float *)g, (float *)vel, P, (float)lr, (float)rho, partial);
+  else
+    hipLaunchKernelGGL(k_sgd<double>, dim3(nblk(P, EW_BLOCK)), dim3(EW_BLOCK), 0, ctx->stream, (double *)theta,
+                       (const double *)g, (double *)vel, P, lr, rho, partial);
   return (int)hipGetLastError();
 }
 

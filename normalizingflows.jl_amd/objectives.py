@@ -168,6 +168,55 @@ class AdamState:
     t: int = 0
 
 
+@dataclass
+class Descent:
+    """Optimisers.Descent(eta)"""
+
+    eta: float = 0.1
+
+
+@dataclass
+class Momentum:
+    """Optimisers.Momentum(eta, rho)"""
+
+    eta: float = 0.01
+    rho: float = 0.9
+
+
+@dataclass
+class SGDState:
+    """st of Descent (vel is None) / Momentum."""
+
+    vel: Optional[torch.Tensor]
+    t: int = 0
+
+
+def setup(opt, theta: torch.Tensor):
+    """Optimisers.setup(rule, theta)  (src/optimize.jl:80)."""
+    if isinstance(opt, Adam):
+        return AdamState(torch.zeros_like(theta), torch.zeros_like(theta), 0)
+    if isinstance(opt, Momentum):
+        return SGDState(torch.zeros_like(theta), 0)
+    if isinstance(opt, Descent):
+        return SGDState(None, 0)
+    raise TypeError(f"unsupported optimiser rule {type(opt).__name__}")
+
+
+def update(opt, st, theta: torch.Tensor, g: torch.Tensor, want_norm: bool = True):
+    """Optimisers.update!(st, theta, g) for any supported rule; returns norm(g)."""
+    if isinstance(opt, Adam):
+        return adam_update(opt, st, theta, g, want_norm)
+    from ._lib import context_for
+
+    ctx = context_for(theta.device)
+    st.t += 1
+    gn = torch.empty(1, dtype=theta.dtype, device=theta.device) if want_norm else None
+    rho = opt.rho if isinstance(opt, Momentum) else 0.0
+    check(ctx.lib.nf_sgd_update(ctx.ptr, _dtype_code(theta.dtype), _ptr(theta), _ptr(g), _ptr(st.vel), theta.numel(),
+                                opt.eta, rho, _ptr(gn)))
+    return gn
+
+
 def adam_update(opt: Adam, st: AdamState, theta: torch.Tensor, g: torch.Tensor, want_norm: bool = True):
     """Optimisers.update!(st, theta, g)  (src/optimize.jl:99); also returns norm(g) (:89)."""
     from ._lib import context_for
@@ -181,14 +230,16 @@ def adam_update(opt: Adam, st: AdamState, theta: torch.Tensor, g: torch.Tensor, 
 
 
 def optimize(loss_and_grad: Callable, theta0: torch.Tensor, reconstruct, *, max_iters: int = 10000,
-             optimiser: Adam = None, show_progress: bool = False, callback=None,
-             hasconverged=lambda i, stats, re, theta, st: False, all_reduce=None):
+             optimiser=None, show_progress: bool = False, callback=None,
+             hasconverged=lambda i, stats, re, theta, st: False, all_reduce=None, state=None):
     """optimize(adbackend, loss, theta0, re, args...; kwargs...)  (src/optimize.jl:57-108).
     `loss_and_grad(theta) -> (loss, grad)` plays the role of DI.value_and_gradient(loss, ...).
-    `all_reduce(buf)` (optional) sums [grad ; loss] over data-parallel ranks."""
+    `all_reduce(buf)` (optional) sums [grad ; loss] over data-parallel ranks.  `state` (optional): the `st`
+    returned by an earlier call, to continue training where it stopped (the reference returns `st` "for
+    potential continuation of training", src/optimize.jl:106)."""
     optimiser = optimiser or Adam()
     theta = theta0.clone()
-    st = AdamState(torch.zeros_like(theta), torch.zeros_like(theta), 0)
+    st = state if state is not None else setup(optimiser, theta)
     opt_stats = []
     converged = False
     i = 1
@@ -201,7 +252,7 @@ def optimize(loss_and_grad: Callable, theta0: torch.Tensor, reconstruct, *, max_
         # the reference records the stat and runs the callback on the parameters BEFORE the update
         # (src/optimize.jl:88-99); the gradient norm comes out of the same kernel as the update
         theta_before = theta.clone() if callback is not None else None
-        gn = adam_update(optimiser, st, theta, g)
+        gn = update(optimiser, st, theta, g)
         stat = {"iteration": i, "loss": ls, "gradient_norm": float(gn)}
         if callback is not None:
             new_stat = callback(i, opt_stats, reconstruct, theta_before)

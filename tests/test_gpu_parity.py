@@ -510,3 +510,34 @@ def test_training_improves_the_elbo_on_the_banana_target(nf, kind):
     ys = nf.rand(trained, 2000, nf.PhiloxRNG(7))
     lp = nf.target_logp(tgt, ys)
     assert float(lp.mean()) > -6.0  # E_p[log p] of Banana(2, 1, 10) is about -4; an untrained flow sits far below
+
+
+@pytest.mark.parametrize("dtn", ["float32", "float64"])
+def test_descent_and_momentum_rules_and_resume(nf, dtn):
+    """Optimisers.Descent / Optimisers.Momentum on the device, and continuing a run from the returned
+    `st` (src/optimize.jl:67,80,99,106): two runs of 5 steps equal one run of 10 (deterministic draws)."""
+    dt = tdt(dtn)
+    rng = np.random.default_rng(0)
+    th0, g = rng.standard_normal(1000), rng.standard_normal(1000)
+    for opt in (nf.Descent(0.1), nf.Momentum(0.01, 0.9)):
+        theta = torch.tensor(th0, dtype=dt, device="cuda")
+        st = nf.setup(opt, theta)
+        ref, vel = th0.copy(), np.zeros_like(th0)
+        for _ in range(3):
+            gn = nf.update(opt, st, theta, torch.tensor(g, dtype=dt, device="cuda"))
+            if isinstance(opt, nf.Momentum):
+                vel = opt.rho * vel - opt.eta * g
+                ref = ref + vel
+            else:
+                ref = ref - opt.eta * g
+            assert float(gn) == pytest.approx(np.linalg.norm(g), rel=1e-6)
+        np.testing.assert_allclose(theta.cpu().numpy(), ref, rtol=0, atol=1e-5 if dtn == "float32" else 1e-13)
+    flow = nf.planarflow(nf.MvNormal(3), 4, paramtype=dt, seed=3)
+    tgt = nf.BananaTarget(3, 1.0, 5.0)
+    kw = dict(optimiser=nf.Momentum(1e-3, 0.9))
+    f10, s10, _ = nf.train_flow(nf.PhiloxRNG(4), nf.elbo_batch, flow, tgt, 64, max_iters=10, **kw)
+    f5, s5, st5 = nf.train_flow(nf.PhiloxRNG(4), nf.elbo_batch, flow, tgt, 64, max_iters=5, **kw)
+    rng5 = nf.PhiloxRNG(4)
+    rng5.stream = 5  # the first run consumed five draw streams
+    f55, s55, _ = nf.train_flow(rng5, nf.elbo_batch, f5, tgt, 64, max_iters=5, state=st5, **kw)
+    np.testing.assert_array_equal(f55.theta.cpu().numpy(), f10.theta.cpu().numpy())
