@@ -37,10 +37,11 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dens
 # fwd 262 144 + dX 262 144 + dW 262 144 over 8 couplings; recompute is not counted)
 MACS_NET = 32 * 64 + 64 * 64 + 64 * 32
 FLOPS_BWD_PER_SAMPLE_PER_COUPLING = 2 * (2 * MACS_NET) * 2  # 2 nets x (dX + dW) x 2 flop/MAC = 65 536
+COUPLINGS_PER_LAUNCH = 2 * NLAYERS  # k_affine_bwd_all walks all 8 couplings in one launch
 FLOPS_STEP_PER_SAMPLE = 786432
 WORKLOAD_TEXT = ("reverse-KL ELBO step: RealNVP d=64, 8 affine couplings, conditioner 32-64-64-32 "
                  "(hdims [64,64]), diag-Gaussian target, Philox base draws, Adam")
-DOMINANT = (b"affine_bwd", "k_affine_bwd (one coupling reverse pass: recompute + dX + dW)")
+DOMINANT = (b"affine_bwd", "k_affine_bwd_all (reverse pass of all 8 couplings in one launch: recompute + dX + dW)")
 KERNEL_NAMES = (b"base_sample", b"pack_weights", b"affine_chain", b"target", b"affine_bwd", b"reduce_slabs", b"adam")
 
 
@@ -48,11 +49,12 @@ def select_cfg4(world: int):
     """BASELINE.json configs[3] (--workload cfg4; NOT the default bench line): RealNVP d=256, 16 couplings,
     hidden [256,256], 262 144 samples in total, sharded over the ranks (strong scaling).  Dominant kernel:
     k_wide_bwd, one launch = recompute + dX chain of ONE net (its dW GEMM is k_wide_dw)."""
-    global D, HDIMS, NLAYERS, BATCH, MACS_NET, FLOPS_BWD_PER_SAMPLE_PER_COUPLING, FLOPS_STEP_PER_SAMPLE
+    global D, HDIMS, NLAYERS, BATCH, MACS_NET, FLOPS_BWD_PER_SAMPLE_PER_COUPLING, FLOPS_STEP_PER_SAMPLE, COUPLINGS_PER_LAUNCH
     global WORKLOAD_TEXT, DOMINANT, KERNEL_NAMES
     D, HDIMS, NLAYERS, BATCH = 256, (256, 256), 8, 262144 // world
     MACS_NET = 128 * 256 + 256 * 256 + 256 * 128
     FLOPS_BWD_PER_SAMPLE_PER_COUPLING = 2 * MACS_NET  # per launch: dX of one net
+    COUPLINGS_PER_LAUNCH = 1
     FLOPS_STEP_PER_SAMPLE = 16 * 2 * 3 * 2 * MACS_NET  # 16 couplings x 2 nets x (fwd + dX + dW)
     WORKLOAD_TEXT = ("reverse-KL ELBO step: RealNVP d=256, 16 affine couplings, conditioner 128-256-256-128 "
                      "(hdims [256,256]), diag-Gaussian target, Philox base draws, Adam; 262144 samples in total")
@@ -189,8 +191,9 @@ def main():
         step(i)
     barrier()
     if not args.no_kernel_events:
-        # HIP events on the launch stream, over the timed region: every 4th launch of the dominant kernel
-        nf._lib.check(lib.nf_prof_enable(ctx.ptr, 3))
+        # HIP events on the launch stream, over the timed region, around the dominant kernel only
+        # (cfg 2: one launch per step; cfg 4: every 4th of its 32 launches per step)
+        nf._lib.check(lib.nf_prof_enable(ctx.ptr, 1 if args.workload == "cfg2" else 3))
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         step(i)
@@ -222,8 +225,9 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = n_global * args.steps / elapsed
-        achieved = FLOPS_BWD_PER_SAMPLE_PER_COUPLING * n_local / (avg_ms.value * 1e-3) / 1e12 if avg_ms.value > 0 else 0.0
-        traffic, traffic_src = (pmc_traffic("k_affine_bwd") if args.workload == "cfg2" and n_local == BATCH else (None, None))
+        flop_per_launch = FLOPS_BWD_PER_SAMPLE_PER_COUPLING * COUPLINGS_PER_LAUNCH * n_local
+        achieved = flop_per_launch / (avg_ms.value * 1e-3) / 1e12 if avg_ms.value > 0 else 0.0
+        traffic, traffic_src = (pmc_traffic("k_affine_bwd_all") if args.workload == "cfg2" and n_local == BATCH else (None, None))
         rec = {
             "metric": "elbo_samples_per_sec",
             "value": value,
@@ -257,7 +261,7 @@ def main():
                 "traffic_source": traffic_src,
                 "avg_launch_ms": avg_ms.value,
                 "launches_timed": cnt.value,
-                "algorithmic_flop_per_launch": FLOPS_BWD_PER_SAMPLE_PER_COUPLING * n_local,
+                "algorithmic_flop_per_launch": flop_per_launch,
                 "whole_step_tflops": FLOPS_STEP_PER_SAMPLE * n_local / (ms_per_step * 1e-3) / 1e12,
             },
             "kernels": kernel_ms,

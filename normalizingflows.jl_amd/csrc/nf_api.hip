@@ -41,6 +41,8 @@ long nf_affine_slab_floats(const nf_flow_desc *desc);
 int nf_affine_reduce_slabs(nf_ctx *, const nf_flow_desc *, const float *slab, int nslab, float *g);
 int nf_affine_bwd(nf_ctx *, const nf_flow_desc *, int k, const float *theta, float *y, float *ybar, const float *lbar,
                   float lbar_const, long N, float *slab, long slab_stride, int grid);
+int nf_affine_bwd_all(nf_ctx *, const nf_flow_desc *, float *y, float *ybar, const float *lbar, float lbar_const, long N,
+                      float *slab, long slab_stride, int grid);
 
 // RealNVP with conditioner nets streamed from L2 (nf_wide.hip): d <= 256, hidden <= 256
 bool nf_wide_supported(const nf_flow_desc *desc);
@@ -379,6 +381,10 @@ static int realnvp_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta
   if (is_wide(desc)) return nf_wide_bwd(ctx, desc, state, gbar, lbar, lbar_const, N, slab, g_out);
   const long stride = coupling_slab_floats(ctx, desc, N);
   const int nc = 2 * desc->nlayers;
+  if (!is_nsf(desc)) {  // LDS-resident RealNVP: every coupling in one launch
+    NF_TRY(nf_affine_bwd_all(ctx, desc, state, gbar, lbar, lbar_const, N, slab, stride, grid));
+    return nf_affine_reduce_slabs(ctx, desc, slab, grid, g_out);
+  }
   for (int k = 0; k < nc; ++k) {  // flat order = reverse of execution order
     if (is_nsf(desc))
       NF_TRY(nf_rqs_bwd(ctx, desc, k, state, gbar, lbar, lbar_const, N, slab, stride, grid));
