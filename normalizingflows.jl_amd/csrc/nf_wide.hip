@@ -896,11 +896,14 @@ bool nf_wide_supported(const nf_flow_desc *desc) {
   return wblocks32(c) <= GW::MB && wblocks32(desc->hdims[0]) <= GW::H1B && wblocks32(desc->hdims[1]) <= GW::H2B;
 }
 
-// packed images of every net: [coupling][s|t][GW::SIZE] in ctx->wimg, plus DMA slack at the end
-int nf_wide_pack(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta) {
+// Host code per padded geometry G; the entry points below pick the geometry from the flow shape.
+template <class G>
+struct WideHost {
+// packed images of every net: [coupling][s|t][G::SIZE] in ctx->wimg, plus DMA slack at the end
+static int wide_pack(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta) {
   if (!nf_wide_supported(desc)) return NF_ERR_UNSUPPORTED;
   const int nc = 2 * desc->nlayers;
-  const size_t bytes = (size_t)nc * 2 * GW::SIZE * sizeof(float) + 4096;
+  const size_t bytes = (size_t)nc * 2 * G::SIZE * sizeof(float) + 4096;
   if (bytes > ctx->wimg_bytes) {
     NF_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->wimg) NF_HIP(hipFree(ctx->wimg));
@@ -910,9 +913,9 @@ int nf_wide_pack(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta) {
     ctx->wimg_bytes = bytes;
   }
   const PackArgs p = make_pack_args(desc);
-  const long total = (long)nc * 2 * GW::SIZE;
+  const long total = (long)nc * 2 * G::SIZE;
   ProfScope ps(ctx, "pack_weights");
-  hipLaunchKernelGGL((k_pack_net_images<GW>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, p, theta,
+  hipLaunchKernelGGL((k_pack_net_images<G>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, p, theta,
                      (float *)ctx->wimg);
   return (int)hipGetLastError();
 }
@@ -920,8 +923,8 @@ int nf_wide_pack(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta) {
 static WideArgs make_wide_args(nf_ctx *ctx, const nf_flow_desc *desc, int k, long N) {
   const CouplingInfo ci = nf_coupling_info(desc, k);
   WideArgs a;
-  a.img_s = (const float *)ctx->wimg + (size_t)(2 * k) * GW::SIZE;
-  a.img_t = a.img_s + GW::SIZE;
+  a.img_s = (const float *)ctx->wimg + (size_t)(2 * k) * G::SIZE;
+  a.img_t = a.img_s + G::SIZE;
   a.trace = (long long *)ctx->trace;
   a.d = desc->d; a.c = ci.c; a.m = ci.m; a.par_t = ci.par_t; a.N = N;
   return a;
@@ -929,15 +932,15 @@ static WideArgs make_wide_args(nf_ctx *ctx, const nf_flow_desc *desc, int k, lon
 
 static long wide_groups(long N) { return ((N + NF_TILE - 1) / NF_TILE + 3) / 4; }
 
-int nf_wide_apply(nf_ctx *ctx, const nf_flow_desc *desc, int k, bool inverse, float *xt, long N, float *ladj,
+static int wide_apply(nf_ctx *ctx, const nf_flow_desc *desc, int k, bool inverse, float *xt, long N, float *ladj,
                   int accumulate) {
   if (!ctx->wimg) return NF_ERR_UNSUPPORTED;
   const WideArgs a = make_wide_args(ctx, desc, k, N);
-  const size_t lds = Wide<GW>::LDS_APPLY;
+  const size_t lds = Wide<G>::LDS_APPLY;
   static bool attr_done = false;
   if (!attr_done) {
-    NF_HIP(hipFuncSetAttribute((const void *)k_wide_apply<GW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    NF_HIP(hipFuncSetAttribute((const void *)k_wide_apply<GW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NF_HIP(hipFuncSetAttribute((const void *)k_wide_apply<G, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NF_HIP(hipFuncSetAttribute((const void *)k_wide_apply<G, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
   long grid = wide_groups(N);
@@ -946,9 +949,9 @@ int nf_wide_apply(nf_ctx *ctx, const nf_flow_desc *desc, int k, bool inverse, fl
   ProfScope ps(ctx, "wide_apply");
   const FwdStash none{};
   if (inverse)
-    hipLaunchKernelGGL((k_wide_apply<GW, true>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, xt, ladj, accumulate, none);
+    hipLaunchKernelGGL((k_wide_apply<G, true>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, xt, ladj, accumulate, none);
   else
-    hipLaunchKernelGGL((k_wide_apply<GW, false>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, xt, ladj, accumulate, none);
+    hipLaunchKernelGGL((k_wide_apply<G, false>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, xt, ladj, accumulate, none);
   return (int)hipGetLastError();
 }
 
@@ -962,7 +965,6 @@ static int wide_ksplit(nf_ctx *ctx, long ntiles, int njobs) {
 
 static int build_jobs(DwArgs *args, const float *x2src, long x2_tile_stride, int x2_extent, int x2_roff,
                       const WideStash &st) {
-  using G = GW;
   int n = 0;
   auto add_layer = [&](const float *A, long ats, int aext, int arstride, int aroff, int IB, const float *D, int OB,
                        int w_off, int w_stride, int b_off) {
@@ -993,19 +995,18 @@ static int wide_njobs() {
 }
 
 // floats of device workspace the reverse pass needs for a batch of N
-size_t nf_wide_bwd_ws_floats(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
+static size_t wide_bwd_ws_floats(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
   (void)desc;
   const long ntiles = (N + NF_TILE - 1) / NF_TILE;
-  const size_t stash = (size_t)ntiles * NF_TILE * 32 * (2 * GW::H1B + 2 * GW::H2B + GW::CB);
+  const size_t stash = (size_t)ntiles * NF_TILE * 32 * (2 * G::H1B + 2 * G::H2B + G::CB);
   const int ks = wide_ksplit(ctx, ntiles, wide_njobs());
-  return stash + (size_t)ks * GW::SIZE + 1024;
+  return stash + (size_t)ks * G::SIZE + 1024;
 }
 
 // reverse pass over the whole chain; state/gbar as in realnvp_bwd (nf_api.hip)
-int nf_wide_bwd(nf_ctx *ctx, const nf_flow_desc *desc, float *state, float *gbar, const float *lbar, float lbar_const,
+static int wide_bwd(nf_ctx *ctx, const nf_flow_desc *desc, float *state, float *gbar, const float *lbar, float lbar_const,
                 long N, float *ws, float *g_out) {
   if (!ctx->wimg) return NF_ERR_UNSUPPORTED;
-  using G = GW;
   const long ntiles = (N + NF_TILE - 1) / NF_TILE;
   const size_t per = (size_t)ntiles * NF_TILE * 32;
   WideStash st;
@@ -1074,37 +1075,37 @@ int nf_wide_bwd(nf_ctx *ctx, const nf_flow_desc *desc, float *state, float *gbar
 // ------------------------------------------------------------------------------------
 // workspace layout (floats): [forward stash: per (coupling, net) a1 | a2 | out | masks] [d1 d2 d3] [split-K slab]
 static size_t fwd_stash_floats_per_net(long ntiles) {
-  return (size_t)ntiles * ((size_t)NF_TILE * 32 * (GW::H1B + GW::H2B + GW::CB) + 16 * 64);
+  return (size_t)ntiles * ((size_t)NF_TILE * 32 * (G::H1B + G::H2B + G::CB) + 16 * 64);
 }
 static FwdStash fwd_stash_at(float *base, long ntiles, int k) {
   FwdStash fs;
   const size_t per = (size_t)ntiles * NF_TILE * 32;
   for (int net = 0; net < 2; ++net) {
     float *p = base + (size_t)(2 * k + net) * fwd_stash_floats_per_net(ntiles);
-    fs.a1[net] = p; p += per * GW::H1B;
-    fs.a2[net] = p; p += per * GW::H2B;
-    fs.out[net] = p; p += per * GW::CB;
+    fs.a1[net] = p; p += per * G::H1B;
+    fs.a2[net] = p; p += per * G::H2B;
+    fs.out[net] = p; p += per * G::CB;
     fs.mask[net] = (unsigned *)p;
   }
   return fs;
 }
 
-size_t nf_wide_train_ws_floats(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
+static size_t wide_train_ws_floats(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
   const long ntiles = (N + NF_TILE - 1) / NF_TILE;
   const size_t fwd = (size_t)2 * desc->nlayers * 2 * fwd_stash_floats_per_net(ntiles);
-  const size_t dstash = (size_t)ntiles * NF_TILE * 32 * (GW::H1B + GW::H2B + GW::CB);
+  const size_t dstash = (size_t)ntiles * NF_TILE * 32 * (G::H1B + G::H2B + G::CB);
   const int ks = wide_ksplit(ctx, ntiles, wide_njobs());
-  return fwd + dstash + (size_t)ks * GW::SIZE + 1024;
+  return fwd + dstash + (size_t)ks * G::SIZE + 1024;
 }
 
 // whole chain forward on a base draw (in place on xt), stashing for the reverse pass
-int nf_wide_train_forward(nf_ctx *ctx, const nf_flow_desc *desc, float *xt, long N, float *ladj, float *ws) {
+static int wide_train_forward(nf_ctx *ctx, const nf_flow_desc *desc, float *xt, long N, float *ladj, float *ws) {
   if (!ctx->wimg) return NF_ERR_UNSUPPORTED;
   const long ntiles = (N + NF_TILE - 1) / NF_TILE;
-  const size_t lds = Wide<GW>::LDS_APPLY;
+  const size_t lds = Wide<G>::LDS_APPLY;
   static bool attr_done = false;
   if (!attr_done) {
-    NF_HIP(hipFuncSetAttribute((const void *)k_wide_apply<GW, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NF_HIP(hipFuncSetAttribute((const void *)k_wide_apply<G, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
   long grid = wide_groups(N);
@@ -1116,16 +1117,15 @@ int nf_wide_train_forward(nf_ctx *ctx, const nf_flow_desc *desc, float *xt, long
     const WideArgs a = make_wide_args(ctx, desc, k, N);
     const FwdStash fs = fwd_stash_at(ws, ntiles, k);
     ProfScope ps(ctx, "wide_apply");
-    hipLaunchKernelGGL((k_wide_apply<GW, false, true>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, xt, ladj, s > 0 ? 1 : 0, fs);
+    hipLaunchKernelGGL((k_wide_apply<G, false, true>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, xt, ladj, s > 0 ? 1 : 0, fs);
     NF_HIP(hipGetLastError());
   }
   return NF_OK;
 }
 
-int nf_wide_train_backward(nf_ctx *ctx, const nf_flow_desc *desc, float *state, float *gbar, const float *lbar,
+static int wide_train_backward(nf_ctx *ctx, const nf_flow_desc *desc, float *state, float *gbar, const float *lbar,
                            float lbar_const, long N, float *ws, float *g_out) {
   if (!ctx->wimg) return NF_ERR_UNSUPPORTED;
-  using G = GW;
   const long ntiles = (N + NF_TILE - 1) / NF_TILE;
   const size_t per = (size_t)ntiles * NF_TILE * 32;
   const int nc = 2 * desc->nlayers;
@@ -1191,3 +1191,21 @@ int nf_wide_train_backward(nf_ctx *ctx, const nf_flow_desc *desc, float *state, 
   }
   return NF_OK;
 }
+
+};
+
+using GM = NetGeo<2, 4, 4, 2>;  // d <= 128, hidden <= 128: a quarter of GW's padded flops
+
+static bool wide_fits_mid(const nf_flow_desc *desc) {
+  const int c = (desc->d + 1) / 2;
+  return wblocks32(c) <= GM::MB && wblocks32(desc->hdims[0]) <= GM::H1B && wblocks32(desc->hdims[1]) <= GM::H2B;
+}
+#define WIDE_DISPATCH(CALL) (wide_fits_mid(desc) ? WideHost<GM>::CALL : WideHost<GW>::CALL)
+
+int nf_wide_pack(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta) { return WIDE_DISPATCH(wide_pack(ctx, desc, theta)); }
+int nf_wide_apply(nf_ctx *ctx, const nf_flow_desc *desc, int k, bool inverse, float *xt, long N, float *ladj, int accumulate) { return WIDE_DISPATCH(wide_apply(ctx, desc, k, inverse, xt, N, ladj, accumulate)); }
+size_t nf_wide_bwd_ws_floats(nf_ctx *ctx, const nf_flow_desc *desc, long N) { return WIDE_DISPATCH(wide_bwd_ws_floats(ctx, desc, N)); }
+int nf_wide_bwd(nf_ctx *ctx, const nf_flow_desc *desc, float *state, float *gbar, const float *lbar, float lbar_const, long N, float *ws, float *g_out) { return WIDE_DISPATCH(wide_bwd(ctx, desc, state, gbar, lbar, lbar_const, N, ws, g_out)); }
+size_t nf_wide_train_ws_floats(nf_ctx *ctx, const nf_flow_desc *desc, long N) { return WIDE_DISPATCH(wide_train_ws_floats(ctx, desc, N)); }
+int nf_wide_train_forward(nf_ctx *ctx, const nf_flow_desc *desc, float *xt, long N, float *ladj, float *ws) { return WIDE_DISPATCH(wide_train_forward(ctx, desc, xt, N, ladj, ws)); }
+int nf_wide_train_backward(nf_ctx *ctx, const nf_flow_desc *desc, float *state, float *gbar, const float *lbar, float lbar_const, long N, float *ws, float *g_out) { return WIDE_DISPATCH(wide_train_backward(ctx, desc, state, gbar, lbar, lbar_const, N, ws, g_out)); }

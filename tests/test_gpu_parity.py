@@ -306,8 +306,9 @@ def test_nsf_properties_cfg3_shape(nf):
     assert float((ga + gb - g).abs().max()) <= 1e-4 * float(g.abs().max())
 
 
-@pytest.mark.parametrize("d,hd,nl,n", [(256, (256, 256), 1, 200), (100, (96, 130), 1, 77), (129, (40, 256), 2, 33)],
-                         ids=["cfg4_d256_h256", "d100_h96_130", "d129_h40_256"])
+@pytest.mark.parametrize("d,hd,nl,n", [(256, (256, 256), 1, 200), (100, (96, 130), 1, 77), (129, (40, 256), 2, 33),
+                                       (120, (128, 100), 2, 150), (70, (65, 33), 1, 64)],
+                         ids=["cfg4_d256_h256", "d100_h96_130", "d129_h40_256", "mid_d120_h128_100", "mid_d70_h65_33"])
 def test_wide_realnvp_matches_oracle(nf, d, hd, nl, n):
     """RealNVP shapes whose conditioner nets do not fit in LDS (BASELINE cfg 4: d=256, h=256) run on the
     weight-streaming kernels; same parity bar as the resident path (forward, inverse, ELBO, gradient)."""
