@@ -72,7 +72,9 @@ int nf_simple_apply(nf_ctx *, const nf_flow_desc *, int layer_lo, int layer_hi, 
                     const void *x, long N, void *y, void *ladj);
 size_t nf_simple_bwd_ws_bytes(nf_ctx *, const nf_flow_desc *, long N);
 int nf_simple_bwd(nf_ctx *, const nf_flow_desc *, const void *theta, const void *x, const void *ybar, const void *lbar,
-                  double lbar_const, long N, void *xbar_out, void *gtheta_out, void *ws);
+                  double lbar_const, long N, void *xbar_out, void *gtheta_out, void *ws, bool have_stash);
+int nf_simple_apply_stash(nf_ctx *, const nf_flow_desc *, const void *theta, const void *x, long N, void *y, void *ladj,
+                          void *ws);
 
 // general coupling kernels (nf_generic64.hip): Float64, and the Float32 shapes the MFMA paths do not
 // build; one thread per sample, standard layout
@@ -289,7 +291,7 @@ static int flat_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, co
                     const void *lbar, double lbar_const, long N, void *xbar_out, void *gtheta_out, void *ws) {
   if (is_g64(desc))
     return nf_g64_bwd(ctx, desc, theta, x, ybar, lbar, lbar_const, N, xbar_out, gtheta_out, ws);
-  return nf_simple_bwd(ctx, desc, theta, x, ybar, lbar, lbar_const, N, xbar_out, gtheta_out, ws);
+  return nf_simple_bwd(ctx, desc, theta, x, ybar, lbar, lbar_const, N, xbar_out, gtheta_out, ws, false);
 }
 static inline bool is_nsf(const nf_flow_desc *desc) { return desc->kind == NF_KIND_NSF; }
 // RealNVP shapes whose nets do not fit in LDS take the weight-streaming kernels
@@ -609,9 +611,15 @@ extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, con
     } else {
       NF_TRY(nf_launch_base_sample(ctx, dt, desc->d, N, seed, sample_offset, stream_id, x0, logq));
     }
-    NF_TRY(flat_apply(ctx, desc, 0, nf_layer_count(desc), false, theta, x0, N, x, ladj));
-    NF_TRY(nf_launch_target(ctx, dt, target, desc->d, N, x, logq, ladj, nullptr, gbar, -inv, nullptr, partial, -inv));
-    NF_TRY(flat_bwd(ctx, desc, theta, x0, gbar, nullptr, -inv, N, gbar, out, sws));
+    if (is_g64(desc)) {
+      NF_TRY(flat_apply(ctx, desc, 0, nf_layer_count(desc), false, theta, x0, N, x, ladj));
+      NF_TRY(nf_launch_target(ctx, dt, target, desc->d, N, x, logq, ladj, nullptr, gbar, -inv, nullptr, partial, -inv));
+      NF_TRY(flat_bwd(ctx, desc, theta, x0, gbar, nullptr, -inv, N, gbar, out, sws));
+    } else {  // planar / radial / mean-field: the forward pass leaves the reverse pass's per-layer inputs behind
+      NF_TRY(nf_simple_apply_stash(ctx, desc, theta, x0, N, x, ladj, sws));
+      NF_TRY(nf_launch_target(ctx, dt, target, desc->d, N, x, logq, ladj, nullptr, gbar, -inv, nullptr, partial, -inv));
+      NF_TRY(nf_simple_bwd(ctx, desc, theta, x0, gbar, nullptr, -inv, N, gbar, out, sws, true));
+    }
   }
   if (cp) return NF_OK;
   if (dt == NF_DTYPE_F32)

@@ -271,142 +271,150 @@ __global__ __launch_bounds__(SB) void k_simple_apply(SimpleArgs a, const T *__re
 //   radial: z0bar[d] | alpha_bar | betahat_bar
 //   shift : abar[d]            scale: sum(ybar .* x)[d] | sum(lbar)
 template <class T, int DPL>
-__global__ __launch_bounds__(SB) void k_simple_bwd_layer(SimpleArgs a, int l, const T *__restrict__ theta,
-                                                         const T *__restrict__ zin, T *__restrict__ gbar,
-                                                         const T *__restrict__ lbar, T lbar_const,
-                                                         T *__restrict__ slab) {
+__global__ __launch_bounds__(SB) void k_simple_bwd_layers(SimpleArgs a, int nl, const T *__restrict__ theta,
+                                                          const T *__restrict__ stash, long stash_stride,
+                                                          T *__restrict__ gbar, const T *__restrict__ lbar, T lbar_const,
+                                                          T *__restrict__ slabs, long slab_stride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T *cache = (T *)smem;                 // one layer: 2d+2
   const int d = a.d, LP = 2 * d + 2;
   T *red = cache + LP;                  // [SPB][LP] block reduction buffer
-  SimpleArgs one = a;
-  one.lo = l;
-  one.hi = l + 1;
-  build_layer_cache<T>(cache, one, theta);
-  __syncthreads();
-  const int q = threadIdx.x & (LPS - 1), grp = threadIdx.x / LPS;
-  const int lk = layer_kind(a.kind, l);
-  const T *c = cache;
-  T acc0[DPL], acc1[DPL];
-  T s0 = 0, s1 = 0;
-#pragma unroll
-  for (int k = 0; k < DPL; ++k) acc0[k] = acc1[k] = 0;
+  // every layer in one launch: a thread keeps its samples from layer to layer (it re-reads the gbar it
+  // wrote), so only the block-wide parameter reduction needs the barriers
+#pragma unroll 1
+  for (int l = 0; l < nl; ++l) {  // flat order = reverse of execution order
+    const T *zin = stash + (long)(nl - 1 - l) * stash_stride;
+    T *slab = slabs + (long)l * slab_stride;
+    SimpleArgs one = a;
+    one.lo = l;
+    one.hi = l + 1;
+    build_layer_cache<T>(cache, one, theta);
+    __syncthreads();
+    const int q = threadIdx.x & (LPS - 1), grp = threadIdx.x / LPS;
+    const int lk = layer_kind(a.kind, l);
+    const T *c = cache;
+    T acc0[DPL], acc1[DPL];
+    T s0 = 0, s1 = 0;
+  #pragma unroll
+    for (int k = 0; k < DPL; ++k) acc0[k] = acc1[k] = 0;
 
-  for (long j = (long)blockIdx.x * SPB + grp; j < a.N; j += (long)gridDim.x * SPB) {
-    const bool valid = true;
-    const long jj = valid ? j : 0;
-    T z[DPL], g[DPL];
-#pragma unroll
+    for (long j = (long)blockIdx.x * SPB + grp; j < a.N; j += (long)gridDim.x * SPB) {
+      const bool valid = true;
+      const long jj = valid ? j : 0;
+      T z[DPL], g[DPL];
+  #pragma unroll
+      for (int k = 0; k < DPL; ++k) {
+        const int i = q + LPS * k;
+        const bool ok = valid && i < d;
+        z[k] = ok ? zin[jj * d + i] : (T)0;
+        g[k] = ok ? gbar[jj * d + i] : (T)0;
+      }
+      const T lb = valid ? (lbar ? lbar[jj] : lbar_const) : (T)0;
+      if (lk == LK_PLANAR) {
+        T dot = 0, ug = 0;
+  #pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+          const int i = q + LPS * k;
+          if (i < d) {
+            dot += c[i] * z[k];
+            ug += c[d + i] * g[k];
+          }
+        }
+        const T cc = c[2 * d + 1];
+        const T t = tanh(g16sum(dot) + c[2 * d]);
+        ug = g16sum(ug);
+        const T gg = (T)1 - t * t, D = (T)1 + cc * gg;
+        const T ab = ug * gg - (T)2 * lb * cc * t * gg / D;
+  #pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+          const int i = q + LPS * k;
+          if (i < d) {
+            acc0[k] += ab * z[k];  // wbar_raw
+            acc1[k] += t * g[k];   // uhat_bar
+            g[k] += c[i] * ab;     // zbar
+          }
+        }
+        if (q == 0) {
+          s0 += ab;            // bbar
+          s1 += lb * gg / D;   // cbar
+        }
+      } else if (lk == LK_RADIAL) {
+        const T alpha = c[d], bh = c[d + 1];
+        T ss = 0, yd = 0;
+  #pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+          const int i = q + LPS * k;
+          if (i < d) {
+            z[k] -= c[i];  // delta
+            ss += z[k] * z[k];
+            yd += g[k] * z[k];
+          }
+        }
+        const T r = sqrt(g16sum(ss));
+        yd = g16sum(yd);
+        const T h = (T)1 / (alpha + r);
+        const T qq = bh * h, bah2 = bh * alpha * h * h;
+        const T dL_dh = (T)(d - 1) * bh / ((T)1 + qq) + (T)2 * bh * alpha * h / ((T)1 + bah2);
+        const T dL_db = (T)(d - 1) * h / ((T)1 + qq) + alpha * h * h / ((T)1 + bah2);
+        const T dL_da = bh * h * h / ((T)1 + bah2);
+        const T hbar = bh * yd + lb * dL_dh;
+        const T rbar_over_r = r > (T)0 ? -h * h * hbar / r : (T)0;
+  #pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+          const int i = q + LPS * k;
+          if (i < d) {
+            const T db = qq * g[k] + rbar_over_r * z[k];
+            acc0[k] -= db;  // z0bar
+            g[k] += db;     // zbar
+          }
+        }
+        if (q == 0) {
+          s0 += -h * h * hbar + lb * dL_da;  // alpha_bar
+          s1 += h * yd + lb * dL_db;         // betahat_bar
+        }
+      } else if (lk == LK_SHIFT) {
+  #pragma unroll
+        for (int k = 0; k < DPL; ++k) acc0[k] += g[k];
+      } else {
+  #pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+          const int i = q + LPS * k;
+          if (i < d) {
+            acc0[k] += g[k] * z[k];
+            g[k] *= c[i];
+          }
+        }
+        if (q == 0) s0 += lb;
+      }
+      if (valid) {
+  #pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+          const int i = q + LPS * k;
+          if (i < d) gbar[j * d + i] = g[k];
+        }
+      }
+    }
+    // deterministic block reduction over the SPB sample groups
+    T *mine = red + (long)grp * LP;
+  #pragma unroll
     for (int k = 0; k < DPL; ++k) {
       const int i = q + LPS * k;
-      const bool ok = valid && i < d;
-      z[k] = ok ? zin[jj * d + i] : (T)0;
-      g[k] = ok ? gbar[jj * d + i] : (T)0;
-    }
-    const T lb = valid ? (lbar ? lbar[jj] : lbar_const) : (T)0;
-    if (lk == LK_PLANAR) {
-      T dot = 0, ug = 0;
-#pragma unroll
-      for (int k = 0; k < DPL; ++k) {
-        const int i = q + LPS * k;
-        if (i < d) {
-          dot += c[i] * z[k];
-          ug += c[d + i] * g[k];
-        }
-      }
-      const T cc = c[2 * d + 1];
-      const T t = tanh(g16sum(dot) + c[2 * d]);
-      ug = g16sum(ug);
-      const T gg = (T)1 - t * t, D = (T)1 + cc * gg;
-      const T ab = ug * gg - (T)2 * lb * cc * t * gg / D;
-#pragma unroll
-      for (int k = 0; k < DPL; ++k) {
-        const int i = q + LPS * k;
-        if (i < d) {
-          acc0[k] += ab * z[k];  // wbar_raw
-          acc1[k] += t * g[k];   // uhat_bar
-          g[k] += c[i] * ab;     // zbar
-        }
-      }
-      if (q == 0) {
-        s0 += ab;            // bbar
-        s1 += lb * gg / D;   // cbar
-      }
-    } else if (lk == LK_RADIAL) {
-      const T alpha = c[d], bh = c[d + 1];
-      T ss = 0, yd = 0;
-#pragma unroll
-      for (int k = 0; k < DPL; ++k) {
-        const int i = q + LPS * k;
-        if (i < d) {
-          z[k] -= c[i];  // delta
-          ss += z[k] * z[k];
-          yd += g[k] * z[k];
-        }
-      }
-      const T r = sqrt(g16sum(ss));
-      yd = g16sum(yd);
-      const T h = (T)1 / (alpha + r);
-      const T qq = bh * h, bah2 = bh * alpha * h * h;
-      const T dL_dh = (T)(d - 1) * bh / ((T)1 + qq) + (T)2 * bh * alpha * h / ((T)1 + bah2);
-      const T dL_db = (T)(d - 1) * h / ((T)1 + qq) + alpha * h * h / ((T)1 + bah2);
-      const T dL_da = bh * h * h / ((T)1 + bah2);
-      const T hbar = bh * yd + lb * dL_dh;
-      const T rbar_over_r = r > (T)0 ? -h * h * hbar / r : (T)0;
-#pragma unroll
-      for (int k = 0; k < DPL; ++k) {
-        const int i = q + LPS * k;
-        if (i < d) {
-          const T db = qq * g[k] + rbar_over_r * z[k];
-          acc0[k] -= db;  // z0bar
-          g[k] += db;     // zbar
-        }
-      }
-      if (q == 0) {
-        s0 += -h * h * hbar + lb * dL_da;  // alpha_bar
-        s1 += h * yd + lb * dL_db;         // betahat_bar
-      }
-    } else if (lk == LK_SHIFT) {
-#pragma unroll
-      for (int k = 0; k < DPL; ++k) acc0[k] += g[k];
-    } else {
-#pragma unroll
-      for (int k = 0; k < DPL; ++k) {
-        const int i = q + LPS * k;
-        if (i < d) {
-          acc0[k] += g[k] * z[k];
-          g[k] *= c[i];
-        }
-      }
-      if (q == 0) s0 += lb;
-    }
-    if (valid) {
-#pragma unroll
-      for (int k = 0; k < DPL; ++k) {
-        const int i = q + LPS * k;
-        if (i < d) gbar[j * d + i] = g[k];
+      if (i < d) {
+        mine[i] = acc0[k];
+        mine[d + i] = acc1[k];
       }
     }
-  }
-  // deterministic block reduction over the SPB sample groups
-  T *mine = red + (long)grp * LP;
-#pragma unroll
-  for (int k = 0; k < DPL; ++k) {
-    const int i = q + LPS * k;
-    if (i < d) {
-      mine[i] = acc0[k];
-      mine[d + i] = acc1[k];
+    if (q == 0) {
+      mine[2 * d] = s0;
+      mine[2 * d + 1] = s1;
     }
-  }
-  if (q == 0) {
-    mine[2 * d] = s0;
-    mine[2 * d + 1] = s1;
-  }
-  __syncthreads();
-  for (int s = threadIdx.x; s < LP; s += SB) {
-    T v = 0;
-    for (int gI = 0; gI < SPB; ++gI) v += red[(long)gI * LP + s];
-    slab[(long)blockIdx.x * LP + s] = v;
+    __syncthreads();
+    for (int s = threadIdx.x; s < LP; s += SB) {
+      T v = 0;
+      for (int gI = 0; gI < SPB; ++gI) v += red[(long)gI * LP + s];
+      slab[(long)blockIdx.x * LP + s] = v;
+    }
+    __syncthreads();  // cache and reduction buffer are rebuilt for the next layer
   }
 }
 
@@ -544,9 +552,22 @@ size_t nf_simple_bwd_ws_bytes(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
          carve_bytes((size_t)nl * bwd_blocks(ctx, N) * LP * es);
 }
 
+// forward pass that leaves the input of every layer in the reverse pass's workspace (same carving as
+// bwd_t), so that nf_simple_bwd(..., have_stash = true) need not recompute it
+int nf_simple_apply_stash(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *x, long N, void *y,
+                          void *ladj, void *ws) {
+  if (N <= 0) return NF_OK;
+  const int nl = desc->kind == NF_KIND_MEANFIELD ? 2 : desc->nlayers;
+  SimpleArgs a = make_sargs(desc, 0, nl, false, N);
+  Carver cv(ws);
+  if (desc->dtype == NF_DTYPE_F32) return apply_t<float>(ctx, a, theta, x, y, ladj, cv.take<float>((size_t)nl * N * desc->d));
+  return apply_t<double>(ctx, a, theta, x, y, ladj, cv.take<double>((size_t)nl * N * desc->d));
+}
+
 template <class T>
 static int bwd_t(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *x, const void *ybar,
-                 const void *lbar, double lbar_const, long N, void *xbar_out, void *gtheta_out, void *ws) {
+                 const void *lbar, double lbar_const, long N, void *xbar_out, void *gtheta_out, void *ws,
+                 bool have_stash) {
   const int nl = desc->kind == NF_KIND_MEANFIELD ? 2 : desc->nlayers;
   const int d = desc->d;
   const size_t LP = 2 * (size_t)d + 2;
@@ -557,17 +578,15 @@ static int bwd_t(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const
   T *slabs = cv.take<T>((size_t)nl * nb * LP);
   SimpleArgs a = make_sargs(desc, 0, nl, false, N);
   // forward recompute, stashing the input of every layer (execution index e <-> flat layer nl-1-e)
-  NF_TRY(apply_t<T>(ctx, a, theta, x, ytmp, nullptr, stash));
+  if (!have_stash) NF_TRY(apply_t<T>(ctx, a, theta, x, ytmp, nullptr, stash));
   if (xbar_out != ybar)
     NF_HIP(hipMemcpyAsync(xbar_out, ybar, (size_t)N * d * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
   const size_t lds = (LP + (size_t)SPB * LP) * sizeof(T);
-  for (int l = 0; l < nl; ++l) {  // flat order = reverse of execution order
-    const int e = nl - 1 - l;
+  {
     ProfScope ps(ctx, "simple_bwd");
-#define LAUNCH_BWD(DPLv)                                                                                          \
-  hipLaunchKernelGGL((k_simple_bwd_layer<T, DPLv>), dim3(nb), dim3(SB), lds, ctx->stream, a, l, (const T *)theta, \
-                     (const T *)(stash + (size_t)e * N * d), (T *)xbar_out, (const T *)lbar, (T)lbar_const,       \
-                     slabs + (size_t)l * nb * LP)
+#define LAUNCH_BWD(DPLv)                                                                                            \
+  hipLaunchKernelGGL((k_simple_bwd_layers<T, DPLv>), dim3(nb), dim3(SB), lds, ctx->stream, a, nl, (const T *)theta, \
+                     (const T *)stash, (long)N * d, (T *)xbar_out, (const T *)lbar, (T)lbar_const, slabs, (long)nb * LP)
     switch (dpl_for(d)) {
       case 1: LAUNCH_BWD(1); break;
       case 2: LAUNCH_BWD(2); break;
@@ -585,8 +604,9 @@ static int bwd_t(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const
 }
 
 int nf_simple_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *x, const void *ybar,
-                  const void *lbar, double lbar_const, long N, void *xbar_out, void *gtheta_out, void *ws) {
+                  const void *lbar, double lbar_const, long N, void *xbar_out, void *gtheta_out, void *ws,
+                  bool have_stash) {
   if (desc->dtype == NF_DTYPE_F32)
-    return bwd_t<float>(ctx, desc, theta, x, ybar, lbar, lbar_const, N, xbar_out, gtheta_out, ws);
-  return bwd_t<double>(ctx, desc, theta, x, ybar, lbar, lbar_const, N, xbar_out, gtheta_out, ws);
+    return bwd_t<float>(ctx, desc, theta, x, ybar, lbar, lbar_const, N, xbar_out, gtheta_out, ws, have_stash);
+  return bwd_t<double>(ctx, desc, theta, x, ybar, lbar, lbar_const, N, xbar_out, gtheta_out, ws, have_stash);
 }
