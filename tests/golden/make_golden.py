@@ -26,6 +26,16 @@ CASES = {
     "meanfield_d4": (o.FlowSpec("meanfield", 4, 1), 16, "diaggauss", np.float64),
     "nsf_d5_k10": (o.FlowSpec("nsf", 5, 2, (32, 32), K=10, B=5.0), 10, "diaggauss", np.float32),  # test/flow.jl:68
     "nsf_d32_k8": (o.FlowSpec("nsf", 32, 1, (32, 32), K=8, B=5.0), 40, "diaggauss", np.float32),  # cfg 3 shape
+    # Float64 coupling flows (test/flow.jl:7,72 run both element types) -> general kernels
+    "realnvp_d5_h32_f64": (o.FlowSpec("realnvp", 5, 2, (32, 32)), 10, "diaggauss", np.float64),
+    "nsf_d5_k10_f64": (o.FlowSpec("nsf", 5, 2, (32, 32), K=10, B=5.0), 10, "diaggauss", np.float64),
+    # weight-streaming kernels at a small padded shape (64-128-128-64 geometry), and an odd hidden-layer count
+    "realnvp_d70_h65_33": (o.FlowSpec("realnvp", 70, 1, (65, 33)), 33, "diaggauss", np.float32),
+    "realnvp_d9_3hidden": (o.FlowSpec("realnvp", 9, 1, (24, 16, 8)), 20, "diaggauss", np.float32),
+    # demo targets (example/targets/*.jl)
+    "planar_d5_funnel": (o.FlowSpec("planar", 5, 4), 32, "funnel", np.float64),
+    "radial_d2_cross": (o.FlowSpec("radial", 2, 4), 32, "cross", np.float32),
+    "planar_d2_warped": (o.FlowSpec("planar", 2, 4), 32, "warped", np.float64),
 }
 
 
@@ -44,9 +54,18 @@ def main():
             var = (rng.uniform(size=spec.d) + 0.5).astype(dt).astype(np.float64)
             tgt = ("diaggauss", mu, var)
             tp = np.stack([mu, var])
-        else:
+        elif tkind == "banana":
             tgt = ("banana", 1.0, 10.0)  # Banana(2, 1.0, 10.0): example/demo_planar_flow.jl:16
             tp = np.array([[1.0], [10.0]])
+        elif tkind == "funnel":
+            tgt = ("funnel", -2.0, 3.0)  # Funnel(d, mu, sigma): example/targets/neal_funnel.jl
+            tp = np.array([[-2.0], [3.0]])
+        elif tkind == "cross":
+            tgt = ("cross", 2.0, 0.15)  # Cross(): example/targets/cross.jl:29
+            tp = np.array([[2.0], [0.15]])
+        else:
+            tgt = ("warped", 1.0, 0.12)  # WarpedGauss(): example/targets/warped_gaussian.jl:37
+            tp = np.array([[1.0], [0.12]])
         ys, ladj = o.flow_fwd(spec, theta, xs)
         xr, ladj_inv = o.flow_inv(spec, theta, ys)
         elbos = o.batched_elbos(spec, theta, tgt, xs)

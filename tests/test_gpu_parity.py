@@ -57,8 +57,10 @@ def load_case(nf, path):
                                  torch.tensor(z["target_params"][1], dtype=dt, device="cuda"))
         otgt = ("diaggauss", z["target_params"][0], z["target_params"][1])
     else:
-        tgt = nf.BananaTarget(d, float(z["target_params"][0, 0]), float(z["target_params"][1, 0]))
-        otgt = ("banana", float(z["target_params"][0, 0]), float(z["target_params"][1, 0]))
+        p0, p1, tk = float(z["target_params"][0, 0]), float(z["target_params"][1, 0]), str(z["target"])
+        tgt = {"banana": lambda: nf.BananaTarget(d, p0, p1), "funnel": lambda: nf.FunnelTarget(d, p0, p1),
+               "warped": lambda: nf.WarpedGaussTarget(p0, p1), "cross": lambda: nf.CrossTarget(p0, p1)}[tk]()
+        otgt = (tk, p0, p1)
     spec = o.FlowSpec(kind, d, nl, hd, K, B)
     return z, dt, flow, tgt, spec, otgt
 
