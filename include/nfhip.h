@@ -48,6 +48,11 @@ extern "C" {
 #define NF_KIND_REALNVP 2   /* realnvp     src/flows/realnvp.jl:170-180            */
 #define NF_KIND_NSF 3       /* nsf         src/flows/neuralspline.jl:218-234       */
 #define NF_KIND_MEANFIELD 4 /* Shift o Scale, test/interface.jl:22-25              */
+#define NF_KIND_HAMILTONIAN 5 /* mean-field reference + (momentum Shift o Scale) o LeapFrog blocks on the
+                                 joint [x; rho], example/demo_hamiltonian_flow.jl:27-146: d = 2 * dims,
+                                 nlayers = blocks, K = leapfrog steps per block, score = target whose
+                                 score drives the integrator; targets passed to the ELBO entry points
+                                 describe x, the library adds log N(rho; 0, I) (logp_joint, demo :121-128) */
 
 #define NF_DTYPE_F32 0
 #define NF_DTYPE_F64 1
@@ -63,6 +68,7 @@ extern "C" {
 /* Static (non-trainable) description of a flow: the fields of the reference's
  * layer structs that Optimisers.destructure leaves out (dim, mask, K, B, hidden
  * sizes; src/flows/realnvp.jl:33-38, src/flows/neuralspline.jl:35-42). */
+struct nf_target;
 typedef struct nf_flow_desc {
   int32_t kind;                 /* NF_KIND_*                                         */
   int32_t dtype;                /* NF_DTYPE_*                                        */
@@ -73,6 +79,8 @@ typedef struct nf_flow_desc {
   int32_t hdims[NF_MAX_HIDDEN]; /* conditioner hidden widths, src/flows/utils.jl:71  */
   int32_t K;                    /* spline bins (nsf)                                 */
   float B;                      /* spline box bound (nsf)                            */
+  const struct nf_target *score; /* NF_KIND_HAMILTONIAN: the target behind LeapFrog's
+                                    score function (host pointer); NULL otherwise     */
 } nf_flow_desc;
 
 /* Built-in target log-densities (the `logp` closure of src/objectives/elbo.jl:68

@@ -6,7 +6,7 @@ importing works anywhere, computing needs a gfx950 GPU and the built library.
 """
 from ._lib import LIB_PATH, SYMBOLS, Context, NFHipError, context_for, load_library
 from .flows import (BananaTarget, CrossTarget, DiagGaussTarget, FunnelTarget, WarpedGaussTarget, Flow, MvNormal, PhiloxRNG, Transform, as_batch, base_logpdf,
-                    device_specific_rand, inverse, layer, logpdf, meanfield, new_batch, nsf, planarflow, radialflow,
+                    device_specific_rand, hamiltonianflow, inverse, layer, logpdf, meanfield, new_batch, nsf, planarflow, radialflow,
                     rand, realnvp, target_logp, transform, with_logabsdet_jacobian)
 from .parallel import ShardedObjective, allreduce_grad_loss, make_gpu_local_step, shard_range
 from .objectives import (Adam, AdamState, Descent, Momentum, SGDState, adam_update, setup, update, batched_elbos, elbo, elbo_batch, loglikelihood, optimize,
@@ -16,7 +16,7 @@ _device_specific_rand = device_specific_rand  # the reference's (underscored) ex
 
 __all__ = [
     "train_flow", "elbo", "elbo_batch", "loglikelihood", "optimize",
-    "planarflow", "radialflow", "realnvp", "nsf", "meanfield",
+    "planarflow", "radialflow", "realnvp", "nsf", "meanfield", "hamiltonianflow",
     "with_logabsdet_jacobian", "transform", "inverse", "logpdf", "rand", "layer",
     "MvNormal", "PhiloxRNG", "device_specific_rand", "_device_specific_rand",
     "DiagGaussTarget", "BananaTarget", "FunnelTarget", "WarpedGaussTarget", "CrossTarget", "Adam", "Descent", "Momentum", "value_and_gradient",

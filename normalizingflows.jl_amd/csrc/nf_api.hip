@@ -10,7 +10,7 @@ int nf_launch_base_sample(nf_ctx *, int, int, long, uint64_t, uint64_t, uint32_t
 int nf_launch_base_logpdf(nf_ctx *, int, int, long, const void *, void *);
 long nf_target_nblocks(long N);
 int nf_launch_target(nf_ctx *, int, const nf_target *, int, long, const void *, const void *, const void *, void *,
-                     void *, double, void *, double *, double);
+                     void *, double, void *, double *, double, int joint_d);
 long nf_sum2_nblocks(long N);
 int nf_launch_sum2(nf_ctx *, int, long, const void *, const void *, void *, double *, double);
 int nf_launch_finish_sum(nf_ctx *, const double *, long, int, double *, float *, double *);
@@ -85,6 +85,14 @@ size_t nf_g64_bwd_ws_bytes(const nf_flow_desc *desc, long N);
 int nf_g64_bwd(nf_ctx *, const nf_flow_desc *, const void *theta, const void *x, const void *ybar, const void *lbar,
                double lbar_const, long N, void *xbar_out, void *gtheta_out, void *ws);
 
+// Hamiltonian flow of the demos (nf_hamiltonian.hip)
+bool nf_hf_supported(const nf_flow_desc *desc);
+int nf_hf_apply(nf_ctx *, const nf_flow_desc *, int lo, int hi, bool inverse, const void *theta, const void *x, long N,
+                void *y, void *ladj);
+size_t nf_hf_bwd_ws_bytes(const nf_flow_desc *desc, long N);
+int nf_hf_bwd(nf_ctx *, const nf_flow_desc *, const void *theta, const void *x, const void *ybar, const void *lbar,
+              double lbar_const, long N, void *xbar_out, void *gtheta_out, void *ws);
+
 // ---- helpers -----------------------------------------------------------------------------
 static inline size_t esize(int dtype) { return dtype == NF_DTYPE_F64 ? 8 : 4; }
 
@@ -102,6 +110,9 @@ static int check_desc(const nf_flow_desc *d) {
       if (d->d < 2) return NF_ERR_ARG;
       if (d->dtype != NF_DTYPE_F32) return nf_g64_supported(d) ? NF_OK : NF_ERR_UNSUPPORTED;
       return (nf_affine_supported(d) || nf_wide_supported(d) || nf_g64_supported(d)) ? NF_OK : NF_ERR_UNSUPPORTED;
+    case NF_KIND_HAMILTONIAN:
+      if (d->d < 2 || (d->d & 1) || d->K < 1 || !d->score) return NF_ERR_ARG;
+      return nf_hf_supported(d) ? NF_OK : NF_ERR_UNSUPPORTED;
     case NF_KIND_NSF:
       if (d->n_hidden < 1 || d->n_hidden > NF_MAX_HIDDEN || d->d < 2 || d->K < 2) return NF_ERR_ARG;
       if (d->dtype != NF_DTYPE_F32) return nf_g64_supported(d) ? NF_OK : NF_ERR_UNSUPPORTED;
@@ -145,6 +156,7 @@ extern "C" int64_t nf_param_count(const nf_flow_desc *d) {
     case NF_KIND_PLANAR: return (int64_t)d->nlayers * (2 * d->d + 1);
     case NF_KIND_RADIAL: return (int64_t)d->nlayers * (d->d + 2);
     case NF_KIND_MEANFIELD: return 2 * (int64_t)d->d;
+    case NF_KIND_HAMILTONIAN: return 2 * (int64_t)d->d + 3 * (int64_t)(d->d / 2) * d->nlayers;
     case NF_KIND_REALNVP:
     case NF_KIND_NSF: {
       CouplingInfo last = nf_coupling_info(d, 2 * d->nlayers - 1);
@@ -160,6 +172,7 @@ extern "C" int32_t nf_layer_count(const nf_flow_desc *d) {
     case NF_KIND_PLANAR:
     case NF_KIND_RADIAL: return d->nlayers;
     case NF_KIND_MEANFIELD: return 2;
+    case NF_KIND_HAMILTONIAN: return d->nlayers + 1;  // blocks, then the reference's affine map
     case NF_KIND_REALNVP:
     case NF_KIND_NSF: return 2 * d->nlayers;
     default: return NF_ERR_ARG;
@@ -280,20 +293,26 @@ static inline bool is_g64(const nf_flow_desc *desc) {
 // standard-layout flows: planar / radial / mean-field (nf_simple.hip) and Float64 couplings
 static int flat_apply(nf_ctx *ctx, const nf_flow_desc *desc, int lo, int hi, bool inverse, const void *theta,
                       const void *x, long N, void *y, void *ladj) {
+  if (desc->kind == NF_KIND_HAMILTONIAN) return nf_hf_apply(ctx, desc, lo, hi, inverse, theta, x, N, y, ladj);
   if (is_g64(desc))
     return nf_g64_apply(ctx, desc, lo, hi, inverse, theta, x, N, y, ladj);
   return nf_simple_apply(ctx, desc, lo, hi, inverse, theta, x, N, y, ladj);
 }
 static size_t flat_bwd_ws_bytes(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
+  if (desc->kind == NF_KIND_HAMILTONIAN) return nf_hf_bwd_ws_bytes(desc, N);
   return is_g64(desc) ? nf_g64_bwd_ws_bytes(desc, N) : nf_simple_bwd_ws_bytes(ctx, desc, N);
 }
 static int flat_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *x, const void *ybar,
                     const void *lbar, double lbar_const, long N, void *xbar_out, void *gtheta_out, void *ws) {
+  if (desc->kind == NF_KIND_HAMILTONIAN)
+    return nf_hf_bwd(ctx, desc, theta, x, ybar, lbar, lbar_const, N, xbar_out, gtheta_out, ws);
   if (is_g64(desc))
     return nf_g64_bwd(ctx, desc, theta, x, ybar, lbar, lbar_const, N, xbar_out, gtheta_out, ws);
   return nf_simple_bwd(ctx, desc, theta, x, ybar, lbar, lbar_const, N, xbar_out, gtheta_out, ws, false);
 }
 static inline bool is_nsf(const nf_flow_desc *desc) { return desc->kind == NF_KIND_NSF; }
+// Hamiltonian flows: ELBO targets describe x (the first d/2 coordinates); the momenta are standard normal
+static inline int joint_dims(const nf_flow_desc *desc) { return desc->kind == NF_KIND_HAMILTONIAN ? desc->d / 2 : 0; }
 // RealNVP shapes whose nets do not fit in LDS take the weight-streaming kernels
 static inline bool is_wide(const nf_flow_desc *desc) {
   return desc->kind == NF_KIND_REALNVP && !nf_affine_supported(desc) && nf_wide_supported(desc);
@@ -430,7 +449,7 @@ extern "C" int nf_target_logp(nf_ctx *ctx, int32_t dtype, const nf_target *targe
   if (!ctx || !target || !y || d < 1 || N < 0) return NF_ERR_ARG;
   if (dtype != NF_DTYPE_F32 && dtype != NF_DTYPE_F64) return NF_ERR_ARG;
   NF_HIP(hipSetDevice(ctx->device));
-  return nf_launch_target(ctx, dtype, target, d, N, y, nullptr, nullptr, logp_out, grad_out, 1.0, nullptr, nullptr, 0.0);
+  return nf_launch_target(ctx, dtype, target, d, N, y, nullptr, nullptr, logp_out, grad_out, 1.0, nullptr, nullptr, 0.0, 0);
 }
 
 // ---- objectives ----------------------------------------------------------------------------
@@ -476,7 +495,7 @@ static int elbo_forward(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *
     }
     NF_TRY(flat_apply(ctx, desc, 0, nf_layer_count(desc), false, theta, x, N, x, ladj));
     NF_TRY(nf_launch_target(ctx, desc->dtype, target, desc->d, N, x, logq, ladj, nullptr, nullptr, 0.0, elbos_out,
-                            partial, 1.0 / (double)N));
+                            partial, 1.0 / (double)N, joint_dims(desc)));
   }
   NF_TRY(nf_launch_finish_sum(ctx, partial, nb, 0, result, nullptr, nullptr));
   return read_scalar(ctx, result, elbo_host);
@@ -611,13 +630,13 @@ extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, con
     } else {
       NF_TRY(nf_launch_base_sample(ctx, dt, desc->d, N, seed, sample_offset, stream_id, x0, logq));
     }
-    if (is_g64(desc)) {
+    if (is_g64(desc) || desc->kind == NF_KIND_HAMILTONIAN) {
       NF_TRY(flat_apply(ctx, desc, 0, nf_layer_count(desc), false, theta, x0, N, x, ladj));
-      NF_TRY(nf_launch_target(ctx, dt, target, desc->d, N, x, logq, ladj, nullptr, gbar, -inv, nullptr, partial, -inv));
+      NF_TRY(nf_launch_target(ctx, dt, target, desc->d, N, x, logq, ladj, nullptr, gbar, -inv, nullptr, partial, -inv, joint_dims(desc)));
       NF_TRY(flat_bwd(ctx, desc, theta, x0, gbar, nullptr, -inv, N, gbar, out, sws));
     } else {  // planar / radial / mean-field: the forward pass leaves the reverse pass's per-layer inputs behind
       NF_TRY(nf_simple_apply_stash(ctx, desc, theta, x0, N, x, ladj, sws));
-      NF_TRY(nf_launch_target(ctx, dt, target, desc->d, N, x, logq, ladj, nullptr, gbar, -inv, nullptr, partial, -inv));
+      NF_TRY(nf_launch_target(ctx, dt, target, desc->d, N, x, logq, ladj, nullptr, gbar, -inv, nullptr, partial, -inv, joint_dims(desc)));
       NF_TRY(nf_simple_bwd(ctx, desc, theta, x0, gbar, nullptr, -inv, N, gbar, out, sws, true));
     }
   }

@@ -175,7 +175,10 @@ __global__ __launch_bounds__(EW_BLOCK) void k_target(int kind, int d, long N, co
                                                      T var_ban, const T *__restrict__ logq, const T *__restrict__ ladj,
                                                      T *__restrict__ logp_out, T *__restrict__ grad_out, T gscale,
                                                      T *__restrict__ elbos_out, double *__restrict__ partial,
-                                                     double pscale) {
+                                                     double pscale, int dj) {
+  // dj > 0: joint density of the Hamiltonian flows -- the target describes the first dj coordinates,
+  // the remaining d - dj (momenta) are standard normal (logp_joint, example/demo_hamiltonian_flow.jl:121-128)
+  const int dt_ = dj > 0 ? dj : d;
   __shared__ double sm[EW_BLOCK / 64];
   const int q = threadIdx.x & (LPS - 1);
   const long j = (long)blockIdx.x * SPB + (threadIdx.x / LPS);
@@ -184,18 +187,23 @@ __global__ __launch_bounds__(EW_BLOCK) void k_target(int kind, int d, long N, co
   T s2 = 0;
   if (kind == NF_TARGET_FUNNEL) {  // sum_{i>=1} y_i^2 of the sample, needed by feature 0's gradient
     if (valid)
-      for (int i = q; i < d; i += LPS)
+      for (int i = q; i < dt_; i += LPS)
         if (i >= 1) s2 += y[j * d + i] * y[j * d + i];
     s2 = group16_sum(s2);
   }
   if (valid) {
     const T *yr = y + j * d;
-    const T y0 = yr[0], y1 = d > 1 ? yr[1] : (T)0;
+    const T y0 = yr[0], y1 = dt_ > 1 ? yr[1] : (T)0;
     auto run = [&](auto kc) {  // the target kind is resolved once, outside the feature loop
       constexpr int KD = decltype(kc)::value;
       for (int i = q; i < d; i += LPS) {
         T g;
-        acc += target_term<KD, T>(d, i, yr[i], y0, y1, s2, mu, var, b_ban, var_ban, g);
+        if (i < dt_) {
+          acc += target_term<KD, T>(dt_, i, yr[i], y0, y1, s2, mu, var, b_ban, var_ban, g);
+        } else {
+          g = -yr[i];
+          acc += (T)-0.5 * ((T)1.8378770664093453 + yr[i] * yr[i]);
+        }
         if (grad_out) grad_out[j * d + i] = gscale * g;
       }
     };
@@ -550,20 +558,20 @@ long nf_target_nblocks(long N) { return nblk(N, SPB); }
 
 int nf_launch_target(nf_ctx *ctx, int dtype, const nf_target *t, int d, long N, const void *y, const void *logq,
                      const void *ladj, void *logp_out, void *grad_out, double gscale, void *elbos_out, double *partial,
-                     double pscale) {
+                     double pscale, int joint_d) {
   if (N <= 0) return NF_OK;
-  NF_TRY(nf_target_check(t, d));
+  NF_TRY(nf_target_check(t, joint_d > 0 ? joint_d : d));
   ProfScope ps(ctx, "target");
   if (dtype == NF_DTYPE_F32)
     hipLaunchKernelGGL(k_target<float>, dim3(nblk(N, SPB)), dim3(EW_BLOCK), 0, ctx->stream, t->kind, d, N,
                        (const float *)y, (const float *)t->p0, (const float *)t->p1, (float)t->s0, (float)t->s1,
                        (const float *)logq, (const float *)ladj, (float *)logp_out, (float *)grad_out, (float)gscale,
-                       (float *)elbos_out, partial, pscale);
+                       (float *)elbos_out, partial, pscale, joint_d);
   else
     hipLaunchKernelGGL(k_target<double>, dim3(nblk(N, SPB)), dim3(EW_BLOCK), 0, ctx->stream, t->kind, d, N,
                        (const double *)y, (const double *)t->p0, (const double *)t->p1, (double)t->s0, (double)t->s1,
                        (const double *)logq, (const double *)ladj, (double *)logp_out, (double *)grad_out, gscale,
-                       (double *)elbos_out, partial, pscale);
+                       (double *)elbos_out, partial, pscale, joint_d);
   return (int)hipGetLastError();
 }
 

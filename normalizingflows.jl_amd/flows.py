@@ -125,8 +125,9 @@ class Flow:
     parameter vector of Optimisers.destructure(flow) (src/NormalizingFlows.jl:67)."""
 
     def __init__(self, kind: str, dist: MvNormal, nlayers: int, hdims: Sequence[int] = (), K: int = 0, B: float = 0.0,
-                 dtype=torch.float32, device="cuda", theta: Optional[torch.Tensor] = None):
+                 dtype=torch.float32, device="cuda", theta: Optional[torch.Tensor] = None, score=None):
         self.kind, self.dist, self.nlayers = kind, dist, int(nlayers)
+        self.score = score  # Hamiltonian flows: the target whose score drives LeapFrog (kept alive here)
         self.hdims, self.K, self.B = tuple(int(h) for h in hdims), int(K), float(B)
         if len(self.hdims) > _lib.NF_MAX_HIDDEN:
             raise NFHipError("at most 4 hidden layers")
@@ -140,6 +141,7 @@ class Flow:
             self.desc.hdims[i] = h
         self.desc.K = self.K
         self.desc.B = self.B
+        self.desc.score = C.addressof(score.c) if score is not None else None
         self.P = int(_lib.load_library().nf_param_count(C.byref(self.desc)))
         if self.P < 0:
             check(self.P)
@@ -158,7 +160,7 @@ class Flow:
 
     def with_theta(self, theta: torch.Tensor) -> "Flow":
         return Flow(self.kind, self.dist, self.nlayers, self.hdims, self.K, self.B, self.theta.dtype,
-                    self.theta.device, theta)
+                    self.theta.device, theta, self.score)
 
     @property
     def ctx(self):
@@ -298,6 +300,21 @@ def meanfield(q0: MvNormal, *, paramtype=torch.float64, device="cuda") -> Flow:
     flow = Flow("meanfield", q0, 1, dtype=paramtype, device=device)
     d = q0.d
     return _finish(flow, torch.cat([torch.zeros(d, dtype=torch.float64), torch.ones(d, dtype=torch.float64)]))
+
+
+def hamiltonianflow(dims: int, nblocks: int, nleapfrog: int, target, *, logeps0: float = math.log(0.05),
+                    paramtype=torch.float64, device="cuda") -> Flow:
+    """The Hamiltonian flow of example/demo_hamiltonian_flow.jl:132-146 on the joint z = [x; rho] (2*dims):
+    a mean-field Gaussian reference, then `nblocks` blocks (momentum Shift o Scale) o LeapFrog(dims, logeps0,
+    nleapfrog, score(target)).  `target` is a built-in target of dimension `dims` (diagonal Gaussian, Banana,
+    Funnel -- the ones with a closed-form Hessian-vector product); pass the same object as `logp` to
+    elbo / train_flow: the library forms logp_joint(z) = logp(x) + log N(rho; 0, I) (demo :121-128)."""
+    flow = Flow("hamiltonian", MvNormal(2 * dims), nblocks, K=nleapfrog, dtype=paramtype, device=device, score=target)
+    th = [torch.zeros(2 * dims, dtype=torch.float64), torch.ones(2 * dims, dtype=torch.float64)]
+    for _ in range(nblocks):
+        th += [torch.zeros(dims, dtype=torch.float64), torch.ones(dims, dtype=torch.float64),
+               torch.full((dims,), float(logeps0), dtype=torch.float64)]
+    return _finish(flow, torch.cat(th))
 
 
 # --------------------------------------------------------------------------------------

@@ -934,3 +934,153 @@ def base_sample(d: int, n: int, seed: int, sample_offset: int = 0, stream: int =
         out[:, :, 2 * a] = rad * np.cos(ang)
         out[:, :, 2 * a + 1] = rad * np.sin(ang)
     return out.reshape(n, ng * 4)[:, :d].T.copy().astype(dtype)
+
+
+# --------------------------------------------------------------------------
+# Hamiltonian flow (example/demo_hamiltonian_flow.jl:27-146): a mean-field Gaussian reference on the joint
+# z = [x; rho] followed by n blocks (momentum Shift o Scale) o LeapFrog(L steps, per-dimension step sizes
+# exp(log_eps), score of the target).  theta = [shift0(2D), scale0(2D), then per block: shift_rho(D),
+# scale_rho(D), log_eps(D)]: `transformed(q0, T)` destructures its dist (q0's own Shift o Scale, :135-137)
+# before its transform, and each block is ComposedFunction(outer = momentum layer, inner = LeapFrog) (:144).
+# --------------------------------------------------------------------------
+
+
+def target_hvp(target, x, v):
+    """Hessian of log p at x (columns) applied to v: what reverse-mode AD through `score` needs."""
+    kind = target[0]
+    if kind == "diaggauss":
+        return -v / target[2][:, None]
+    if kind == "banana":
+        b, s = target[1], target[2]
+        y2 = x[1] + b * x[0] ** 2 - s * b
+        out = -v.copy()
+        h11 = -1.0 / s - 2.0 * b * y2 - 4.0 * b * b * x[0] ** 2
+        h12 = -2.0 * b * x[0]
+        out[0] = h11 * v[0] + h12 * v[1]
+        out[1] = h12 * v[0] - v[1]
+        return out
+    if kind == "funnel":
+        mu, sg = target[1], target[2]
+        a = np.exp(-x[0])
+        s2 = (x[1:] ** 2).sum(axis=0)
+        out = np.empty_like(v)
+        out[0] = (-1.0 / sg**2 - 0.5 * a * s2) * v[0] + a * (x[1:] * v[1:]).sum(axis=0)
+        out[1:] = a * x[1:] * v[0] - a * v[1:]
+        return out
+    raise ValueError(f"no Hessian-vector product for target {kind!r}")
+
+
+def hflow_param_count(D: int, n: int) -> int:
+    return 4 * D + 3 * D * n
+
+
+def _hflow_views(D, n, theta):
+    sh0, sc0 = theta[: 2 * D], theta[2 * D : 4 * D]
+    blocks = []
+    off = 4 * D
+    for _ in range(n):
+        blocks.append((theta[off : off + D], theta[off + D : off + 2 * D], theta[off + 2 * D : off + 3 * D]))
+        off += 3 * D
+    return sh0, sc0, blocks
+
+
+def _leapfrog(target, eps, L, x, v, keep=None):
+    """_leapfrog of demo_hamiltonian_flow.jl:49-60 (eps is a column of per-dimension step sizes)."""
+    g = target_grad(target, x)
+    v = v + 0.5 * eps * g
+    if keep is not None:
+        keep.append((x, v, g))
+    for _ in range(L - 1):
+        x = x + eps * v
+        g = target_grad(target, x)
+        v = v + eps * g
+        if keep is not None:
+            keep.append((x, v, g))
+    xl = x + eps * v
+    gl = target_grad(target, xl)
+    vl = v + 0.5 * eps * gl
+    if keep is not None:
+        keep.append((xl, vl, gl))
+    return xl, vl
+
+
+def hflow_fwd(D, n, L, theta, target, x0, keep=None):
+    """Base draws x0 (2D x N) -> (z, ladj).  Blocks execute last-listed first (utils.jl:23-26)."""
+    sh0, sc0, blocks = _hflow_views(D, n, theta)
+    z = sh0[:, None] + sc0[:, None] * x0
+    ladj = np.full(x0.shape[1], np.log(np.abs(sc0)).sum())
+    for bi in range(n - 1, -1, -1):
+        shr, scr, leps = blocks[bi]
+        eps = np.exp(leps)[:, None]
+        tr = [] if keep is not None else None
+        x, v = _leapfrog(target, eps, L, z[:D], z[D:], tr)
+        if keep is not None:
+            keep.append((bi, z.copy(), tr, v.copy()))
+        z = np.concatenate([x, shr[:, None] + scr[:, None] * v], axis=0)
+        ladj = ladj + np.log(np.abs(scr)).sum()
+    return z, ladj
+
+
+def hflow_inv(D, n, L, theta, target, z):
+    """Inverse chain: momentum layers undone, LeapFrog run with -eps (demo :74-84); returns (x0, ladj_inv)."""
+    sh0, sc0, blocks = _hflow_views(D, n, theta)
+    ladj = np.zeros(z.shape[1])
+    for bi in range(n):
+        shr, scr, leps = blocks[bi]
+        v = (z[D:] - shr[:, None]) / scr[:, None]
+        ladj = ladj - np.log(np.abs(scr)).sum()
+        x, v = _leapfrog(target, -np.exp(leps)[:, None], L, z[:D], v)
+        z = np.concatenate([x, v], axis=0)
+    ladj = ladj - np.log(np.abs(sc0)).sum()
+    return (z - sh0[:, None]) / sc0[:, None], ladj
+
+
+def hflow_joint_logp(D, target, z):
+    """logp_joint of the demo (:121-128): log p(x) + log N(rho; 0, I)."""
+    return target_logp(target, z[:D]) + std_normal_logpdf(z[D:])
+
+
+def hflow_neg_elbo_value_and_grad(D, n, L, theta, target, x0):
+    """loss = -mean_j [logp_joint(z_j) - log N(x0_j) + ladj_j] and its gradient, hand-derived: the LeapFrog
+    reverse pass needs Hessian-vector products of log p (target_hvp)."""
+    N = x0.shape[1]
+    keep = []
+    z, ladj = hflow_fwd(D, n, L, theta, target, x0, keep)
+    loss = -np.mean(hflow_joint_logp(D, target, z) - std_normal_logpdf(x0) + ladj)
+    sh0, sc0, blocks = _hflow_views(D, n, theta)
+    grad = np.zeros_like(theta)
+    zbar = np.concatenate([target_grad(target, z[:D]), -z[D:]], axis=0) * (-1.0 / N)
+    lbar = -1.0  # d loss / d (sum_j ladj_j / N) per sample, constant terms handled per parameter below
+    off_of = lambda bi: 4 * D + 3 * D * bi  # noqa: E731
+    for bi, zin, tr, vout in keep[::-1]:  # reverse of execution order = flat order bi = 0 .. n-1
+        shr, scr, leps = blocks[bi]
+        eps = np.exp(leps)[:, None]
+        o0 = off_of(bi)
+        xbar, rbar = zbar[:D].copy(), zbar[D:].copy()
+        # momentum layer: rho' = shr + scr * v
+        grad[o0 : o0 + D] += rbar.sum(axis=1)
+        grad[o0 + D : o0 + 2 * D] += (rbar * vout).sum(axis=1) + lbar / scr
+        vbar = rbar * scr[:, None]
+        # LeapFrog reverse (states tr[s] = (x_s, v_s, g(x_s)), s = 0..L)
+        ebar = np.zeros((D, N))
+        xs_, vs_, gs_ = tr[L]
+        xbar = xbar + target_hvp(target, xs_, 0.5 * eps * vbar)
+        ebar += 0.5 * vbar * gs_
+        vprev = tr[L - 1][1]
+        ebar += xbar * vprev
+        vbar = vbar + eps * xbar
+        for s in range(L - 1, 0, -1):
+            xs_, vs_, gs_ = tr[s]
+            xbar = xbar + target_hvp(target, xs_, eps * vbar)
+            ebar += vbar * gs_
+            vprev = tr[s - 1][1]
+            ebar += xbar * vprev
+            vbar = vbar + eps * xbar
+        xs_, vs_, gs_ = tr[0]
+        xbar = xbar + target_hvp(target, xs_, 0.5 * eps * vbar)
+        ebar += 0.5 * vbar * gs_
+        grad[o0 + 2 * D : o0 + 3 * D] += (ebar * eps).sum(axis=1)
+        zbar = np.concatenate([xbar, vbar], axis=0)
+    grad[: 2 * D] += zbar.sum(axis=1)
+    grad[2 * D : 4 * D] += (zbar * x0).sum(axis=1) + lbar / sc0
+    return float(loss), grad
