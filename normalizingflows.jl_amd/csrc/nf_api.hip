@@ -38,7 +38,8 @@ int nf_affine_chain_elbo(nf_ctx *, const nf_flow_desc *, long N, uint64_t seed, 
                          const float *mu, const float *var, float *yt, float *gt, double gscale, double *partial,
                          double pscale);
 long nf_affine_slab_floats(const nf_flow_desc *desc);
-int nf_affine_reduce_slabs(nf_ctx *, const nf_flow_desc *, const float *slab, int nslab, float *g);
+int nf_affine_reduce_slabs(nf_ctx *, const nf_flow_desc *, const float *slab, int nslab, float *g,
+                           const double *lpart = nullptr, int nlpart = 0, float *lout = nullptr);
 int nf_affine_bwd(nf_ctx *, const nf_flow_desc *, int k, const float *theta, float *y, float *ybar, const float *lbar,
                   float lbar_const, long N, float *slab, long slab_stride, int grid);
 int nf_affine_bwd_all(nf_ctx *, const nf_flow_desc *, float *y, float *ybar, const float *lbar, float lbar_const, long N,
@@ -397,14 +398,16 @@ extern "C" int nf_layer_apply(nf_ctx *ctx, const nf_flow_desc *desc, int32_t lay
 
 // reverse pass over the coupling chain (tiled buffers).  `state` holds the flow OUTPUT on entry and
 // the flow INPUT on exit (invertible recompute); `gbar` holds ybar on entry and xbar on exit.
+// lpart/nlpart/lout: optional loss partials for the slab-reduction kernel to finish (resident RealNVP only)
 static int realnvp_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta, float *state, float *gbar,
-                       const float *lbar, float lbar_const, long N, float *slab, int grid, float *g_out) {
+                       const float *lbar, float lbar_const, long N, float *slab, int grid, float *g_out,
+                       const double *lpart = nullptr, int nlpart = 0, float *lout = nullptr) {
   if (is_wide(desc)) return nf_wide_bwd(ctx, desc, state, gbar, lbar, lbar_const, N, slab, g_out);
   const long stride = coupling_slab_floats(ctx, desc, N);
   const int nc = 2 * desc->nlayers;
   if (!is_nsf(desc)) {  // LDS-resident RealNVP: every coupling in one launch
     NF_TRY(nf_affine_bwd_all(ctx, desc, state, gbar, lbar, lbar_const, N, slab, stride, grid));
-    return nf_affine_reduce_slabs(ctx, desc, slab, grid, g_out);
+    return nf_affine_reduce_slabs(ctx, desc, slab, grid, g_out, lpart, nlpart, lout);
   }
   for (int k = 0; k < nc; ++k) {  // flat order = reverse of execution order
     if (is_nsf(desc))
@@ -589,8 +592,9 @@ extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, con
     NF_TRY(coupling_pack(ctx, desc, (const float *)theta));
     NF_TRY(nf_affine_chain_elbo(ctx, desc, N, seed, sample_offset, stream_id, (const float *)target->p0,
                                 (const float *)target->p1, xt, gt, -inv, partial, -inv));
-    NF_TRY(nf_launch_finish_sum(ctx, partial, nf_affine_chain_grid(ctx, N), 0, nullptr, (float *)out + P, nullptr));
-    return realnvp_bwd(ctx, desc, (const float *)theta, xt, gt, nullptr, (float)(-inv), N, (float *)slab, grid, (float *)out);
+    // the loss partials of the fused forward are finished by the slab-reduction launch
+    return realnvp_bwd(ctx, desc, (const float *)theta, xt, gt, nullptr, (float)(-inv), N, (float *)slab, grid, (float *)out,
+                       partial, (int)nf_affine_chain_grid(ctx, N), (float *)out + P);
   }
   if (wide) {
     // wide RealNVP: the forward pass keeps its activations (HBM stash), the reverse pass recomputes nothing

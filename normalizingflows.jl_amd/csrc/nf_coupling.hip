@@ -691,7 +691,8 @@ static int geo_size(const nf_flow_desc *desc) {
 // floats of one workgroup's gradient slab (image layout): [coupling][net s|t][G::SIZE]
 long nf_affine_slab_floats(const nf_flow_desc *desc) { return (long)2 * desc->nlayers * 2 * geo_size(desc); }
 
-int nf_affine_reduce_slabs(nf_ctx *ctx, const nf_flow_desc *desc, const float *slab, int nslab, float *g) {
+int nf_affine_reduce_slabs(nf_ctx *ctx, const nf_flow_desc *desc, const float *slab, int nslab, float *g,
+                           const double *lpart, int nlpart, float *lout) {
   const int size = geo_size(desc);
   if (!size) return NF_ERR_UNSUPPORTED;
   const PackArgs p = make_pack_args(desc);
@@ -699,9 +700,9 @@ int nf_affine_reduce_slabs(nf_ctx *ctx, const nf_flow_desc *desc, const float *s
   const unsigned grid = (unsigned)((total + 255) / 256);
   ProfScope ps(ctx, "reduce_slabs");
   if (size == NetGeo<1, 1, 1, 1>::SIZE)
-    hipLaunchKernelGGL((k_reduce_image_slabs<NetGeo<1, 1, 1, 1>>), dim3(grid), dim3(256), 0, ctx->stream, p, slab, nslab, total, g);
+    hipLaunchKernelGGL((k_reduce_image_slabs<NetGeo<1, 1, 1, 1>>), dim3(grid), dim3(256), 0, ctx->stream, p, slab, nslab, total, g, lpart, nlpart, lout);
   else
-    hipLaunchKernelGGL((k_reduce_image_slabs<NetGeo<1, 2, 2, 1>>), dim3(grid), dim3(256), 0, ctx->stream, p, slab, nslab, total, g);
+    hipLaunchKernelGGL((k_reduce_image_slabs<NetGeo<1, 2, 2, 1>>), dim3(grid), dim3(256), 0, ctx->stream, p, slab, nslab, total, g, lpart, nlpart, lout);
   return (int)hipGetLastError();
 }
 

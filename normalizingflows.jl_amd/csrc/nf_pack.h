@@ -31,9 +31,23 @@ __global__ __launch_bounds__(256) void k_pack_net_images(PackArgs p, const float
 }
 
 // g[theta index] = sum over workgroup slabs of the image-layout partial gradients
+// Block 0 can also finish a deterministic sum of `nlpart` double partials into *lout (the step's loss:
+// saves a separate one-block launch in the training step).
 template <class G>
 __global__ __launch_bounds__(256) void k_reduce_image_slabs(PackArgs p, const float *__restrict__ slab, int nslab,
-                                                            long slab_stride, float *__restrict__ g) {
+                                                            long slab_stride, float *__restrict__ g,
+                                                            const double *__restrict__ lpart, int nlpart,
+                                                            float *__restrict__ lout) {
+  if (lout && blockIdx.x == 0) {
+    __shared__ double sm[4];
+    double c = 0.0;
+    for (int i = threadIdx.x; i < nlpart; i += 256) c += lpart[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) *lout = (float)((sm[0] + sm[1]) + (sm[2] + sm[3]));
+  }
   const long gid = (long)blockIdx.x * 256 + threadIdx.x;
   const long total = (long)p.ncoup * 2 * G::SIZE;
   if (gid >= total) return;
