@@ -65,20 +65,22 @@ def select_cfg4(world: int):
 def pmc_traffic(kernel_substr: str):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 counter passes
     (profiles/*_pmc_summary.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this
-    same command by tools/collect_profiles.sh; rocprofv3 reports both in KiB).  The loads of this kernel
-    are 4 B/lane tile loads, for which MI355X_MICROARCH.md gives no calibrated correction factor, so the
-    counters are taken as reported.  None if no profile is committed."""
+    same command by tools/collect_profiles.sh; rocprofv3 reports both in KiB).  Correction
+    (MI355X_MICROARCH.md, HBM section): on gfx950 FETCH_SIZE counts 64 B per 128-B request, i.e. half
+    the bytes read.  Calibrated on this library's own access pattern (4 B/lane tile loads and stores):
+    k_target_tiled reads 17.3 MB and reports 8 478 KiB = 8.68 MB (factor 2.0); k_base_sample_tiled
+    writes 17.04 MB and reports WRITE_SIZE 16 640 KiB = 17.04 MB (factor 1.0) -- profiles/r1b_pmc_summary.json.
+    So traffic = 2 * FETCH_SIZE + WRITE_SIZE.  None if no profile is committed."""
     import glob
 
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
-    if not files:
-        return None, None
-    with open(files[-1]) as f:
-        summ = json.load(f)
-    for name, counters in summ.items():
-        if kernel_substr in name and "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
-            kib = counters["FETCH_SIZE"]["avg_per_launch"] + counters["WRITE_SIZE"]["avg_per_launch"]
-            return kib * 1024.0, os.path.relpath(files[-1], ROOT)
+    for path in reversed(files):
+        with open(path) as f:
+            summ = json.load(f)
+        for name, counters in summ.items():
+            if kernel_substr in name and "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
+                kib = 2.0 * counters["FETCH_SIZE"]["avg_per_launch"] + counters["WRITE_SIZE"]["avg_per_launch"]
+                return kib * 1024.0, os.path.relpath(path, ROOT)
     return None, None
 
 
@@ -257,7 +259,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                 "traffic": traffic,
-                "traffic_unit": "bytes per launch (HBM fetch + write, rocprofv3 PMC)",
+                "traffic_unit": "bytes per launch (HBM: 2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC, gfx950 correction)",
                 "traffic_source": traffic_src,
                 "avg_launch_ms": avg_ms.value,
                 "launches_timed": cnt.value,
