@@ -69,7 +69,7 @@ def pmc_traffic(kernel_substr: str):
     (MI355X_MICROARCH.md, HBM section): on gfx950 FETCH_SIZE counts 64 B per 128-B request, i.e. half
     the bytes read.  Calibrated on this library's own access pattern (4 B/lane tile loads and stores):
     k_target_tiled reads 17.3 MB and reports 8 478 KiB = 8.68 MB (factor 2.0); k_base_sample_tiled
-    writes 17.04 MB and reports WRITE_SIZE 16 640 KiB = 17.04 MB (factor 1.0) -- profiles/r1b_pmc_summary.json.
+    writes 17.04 MB and reports WRITE_SIZE 16 640 KiB = 17.04 MB (factor 1.0) -- profiles/r1c_pmc_calibration.json.
     So traffic = 2 * FETCH_SIZE + WRITE_SIZE.  None if no profile is committed."""
     import glob
 
