@@ -253,14 +253,16 @@ __global__ __launch_bounds__(512) void k_affine_chain(ChainArgs a, float *xt, fl
         // prefetch the next coupling's images (wraps to the first coupling for the next tile group)
         const bool have_next = pos + 1 < a.ncoup || more_groups;
         const int knext = coupling_at(pos + 1 < a.ncoup ? pos + 1 : 0);
-        float4 tmp[PER];
         if (have_next) {
-          const float4 *src = reinterpret_cast<const float4 *>(a.wimg + (long)knext * IMG2);
-#pragma unroll
-          for (int q = 0; q < PER; ++q) {
-            const int idx = tid + q * 512;
-            tmp[q] = idx < NV4 ? src[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
-          }
+          // LDS-DMA (buffer_load_dwordx4 ... lds) straight into the other image buffer: no staging
+          // registers, no ds_write pass; complete at the barrier below (s_waitcnt vmcnt(0))
+          typedef __attribute__((address_space(3))) void lds_void_t;
+          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wimg) + (long)knext * IMG2, 0, IMG2 * 4, 0x00020000);
+          float *dstb = lds + (buf ^ 1) * IMG2;
+          constexpr int NP = (IMG2 * 4 + 1023) / 1024;
+          for (int p = wave; p < NP; p += 8)
+            if (p * 1024 + lane * 16 < IMG2 * 4)  // the last piece is partial: its idle lanes must not write
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t *)(dstb + p * 256), 16, lane * 16, p * 1024, 0, 0);
         }
         const float *img_s = lds + buf * IMG2;
         const float *img_t = img_s + G::SIZE;
@@ -274,14 +276,6 @@ __global__ __launch_bounds__(512) void k_affine_chain(ChainArgs a, float *xt, fl
           ls = coupling_step<G, INVERSE>(img_s, img_t, E, O, l31, hi);
         }
         lsum += ls;
-        if (have_next) {
-          float4 *dst = reinterpret_cast<float4 *>(lds + (buf ^ 1) * IMG2);
-#pragma unroll
-          for (int q = 0; q < PER; ++q) {
-            const int idx = tid + q * 512;
-            if (idx < NV4) dst[idx] = tmp[q];
-          }
-        }
         __syncthreads();
         buf ^= 1;
       }
