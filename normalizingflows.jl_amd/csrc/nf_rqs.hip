@@ -467,14 +467,16 @@ __global__ __launch_bounds__(512) void k_rqs_chain(RqsChainArgs a, float *xt, fl
         const int pos = s + half;
         const bool have_next = pos + 1 < a.ncoup || more_groups;
         const int knext = coupling_at(pos + 1 < a.ncoup ? pos + 1 : 0);
-        float4 tmp[PER];
         if (have_next) {
-          const float4 *src = reinterpret_cast<const float4 *>(a.wimg + (long)knext * G::SIZE);
-#pragma unroll
-          for (int q = 0; q < PER; ++q) {
-            const int idx = tid + q * 512;
-            tmp[q] = idx < NV4 ? src[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
-          }
+          // LDS-DMA straight into the other image buffer (as in k_affine_chain); complete at the barrier below
+          typedef __attribute__((address_space(3))) void lds_void_t;
+          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wimg) + (long)knext * G::SIZE, 0, G::SIZE * 4, 0x00020000);
+          float *dstb = lds + (buf ^ 1) * G::SIZE;
+          constexpr int NP = (G::SIZE * 4 + 1023) / 1024;
+          const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+          for (int p = wave; p < NP; p += 8)
+            if (p * 1024 + lane * 16 < G::SIZE * 4)  // the last piece is partial: its idle lanes must not write
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t *)(dstb + p * 256), 16, lane * 16, p * 1024, 0, 0);
         }
         const float *img = lds + buf * G::SIZE;
         // forward: position 0 is the last flat coupling (odd index, mask 2:2:d): x1 = O
@@ -483,14 +485,6 @@ __global__ __launch_bounds__(512) void k_rqs_chain(RqsChainArgs a, float *xt, fl
             lsum += rqs_coupling_step<G, INVERSE>(img, O, E, c_even, a.B, l31, hi);
           else
             lsum += rqs_coupling_step<G, INVERSE>(img, E, O, c_odd, a.B, l31, hi);
-        }
-        if (have_next) {
-          float4 *dst = reinterpret_cast<float4 *>(lds + (buf ^ 1) * G::SIZE);
-#pragma unroll
-          for (int q = 0; q < PER; ++q) {
-            const int idx = tid + q * 512;
-            if (idx < NV4) dst[idx] = tmp[q];
-          }
         }
         __syncthreads();
         buf ^= 1;
