@@ -182,6 +182,17 @@ int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, const nf_targe
                            const void *theta, const void *xs, int64_t N_local, int64_t N_global,
                            uint64_t seed, uint64_t sample_offset, uint32_t stream_id,
                            void *out_grad_loss);
+/* Forward-KL training, `train_flow(loglikelihood, flow, ys)`: loss(theta) =
+ * -loglikelihood(rng, re(theta), ys) (src/objectives/loglikelihood.jl:26-33 inside the loss closure
+ * src/NormalizingFlows.jl:69) and its gradient (_value_and_gradient, src/optimize.jl:12-14,86) for
+ * THIS rank's N_local columns of an N_global-column data set:
+ *   out[0..P) = sum_{j in shard} d(-loglik_j / N_global)/dtheta,   out[P] = sum (-loglik_j / N_global).
+ * The chain is inverted once; its reverse pass walks the layers in forward order with the
+ * implicit-function form of each inverse (no root-find or spline inversion is differentiated).
+ * NF_ERR_UNSUPPORTED for the Hamiltonian flow. */
+int nf_loglikelihood_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta,
+                                    const void *ys, int64_t N_local, int64_t N_global,
+                                    void *out_grad_loss);
 /* Optimisers.update!(st, theta, g) for Optimisers.Adam (src/optimize.jl:99), in place on
  * theta/m/v; t = 1-based step count.  gnorm_out (device scalar, optional) receives
  * norm(g) (src/optimize.jl:89). */

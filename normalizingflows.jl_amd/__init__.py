@@ -9,13 +9,13 @@ from .flows import (BananaTarget, CrossTarget, DiagGaussTarget, FunnelTarget, Wa
                     device_specific_rand, hamiltonianflow, inverse, layer, logpdf, meanfield, new_batch, nsf, planarflow, radialflow,
                     rand, realnvp, target_logp, transform, with_logabsdet_jacobian)
 from .parallel import ShardedObjective, allreduce_grad_loss, make_gpu_local_step, shard_range
-from .objectives import (Adam, AdamState, Descent, Momentum, SGDState, adam_update, setup, update, batched_elbos, elbo, elbo_batch, loglikelihood, optimize,
+from .objectives import (Adam, AdamState, Descent, Momentum, SGDState, adam_update, setup, update, batched_elbos, elbo, elbo_batch, loglikelihood, loglikelihood_value_and_gradient, optimize,
                          train_flow, value_and_gradient)
 
 _device_specific_rand = device_specific_rand  # the reference's (underscored) extension hook name
 
 __all__ = [
-    "train_flow", "elbo", "elbo_batch", "loglikelihood", "optimize",
+    "train_flow", "elbo", "elbo_batch", "loglikelihood", "loglikelihood_value_and_gradient", "optimize",
     "planarflow", "radialflow", "realnvp", "nsf", "meanfield", "hamiltonianflow",
     "with_logabsdet_jacobian", "transform", "inverse", "logpdf", "rand", "layer",
     "MvNormal", "PhiloxRNG", "device_specific_rand", "_device_specific_rand",

@@ -73,6 +73,7 @@ SYMBOLS = {
     "nf_elbo_batch_rng": (C.c_int, [_P, _DESC, _TGT, _P, _I64, _U64, _U64, _U32, _PD]),
     "nf_loglikelihood": (C.c_int, [_P, _DESC, _P, _P, _I64, _P, _PD]),
     "nf_elbo_value_and_grad": (C.c_int, [_P, _DESC, _TGT, _P, _P, _I64, _I64, _U64, _U64, _U32, _P]),
+    "nf_loglikelihood_value_and_grad": (C.c_int, [_P, _DESC, _P, _P, _I64, _I64, _P]),
     "nf_adam_update": (C.c_int, [_P, _I32, _P, _P, _P, _P, _I64, _D, _D, _D, _D, _I64, _P]),
     "nf_sgd_update": (C.c_int, [_P, _I32, _P, _P, _P, _I64, _D, _D, _P]),
     "nf_elbo_step": (C.c_int, [_P, _DESC, _TGT, _P, _P, _P, _I64, _U64, _U32, _D, _D, _D, _D, _PD, _PD]),

@@ -73,9 +73,9 @@ int nf_simple_apply(nf_ctx *, const nf_flow_desc *, int layer_lo, int layer_hi, 
                     const void *x, long N, void *y, void *ladj);
 size_t nf_simple_bwd_ws_bytes(nf_ctx *, const nf_flow_desc *, long N);
 int nf_simple_bwd(nf_ctx *, const nf_flow_desc *, const void *theta, const void *x, const void *ybar, const void *lbar,
-                  double lbar_const, long N, void *xbar_out, void *gtheta_out, void *ws, bool have_stash);
+                  double lbar_const, long N, void *xbar_out, void *gtheta_out, void *ws, bool have_stash, bool inv = false);
 int nf_simple_apply_stash(nf_ctx *, const nf_flow_desc *, const void *theta, const void *x, long N, void *y, void *ladj,
-                          void *ws);
+                          void *ws, bool inverse = false);
 
 // general coupling kernels (nf_generic64.hip): Float64, and the Float32 shapes the MFMA paths do not
 // build; one thread per sample, standard layout
@@ -85,6 +85,10 @@ int nf_g64_apply(nf_ctx *, const nf_flow_desc *, int layer_lo, int layer_hi, boo
 size_t nf_g64_bwd_ws_bytes(const nf_flow_desc *desc, long N);
 int nf_g64_bwd(nf_ctx *, const nf_flow_desc *, const void *theta, const void *x, const void *ybar, const void *lbar,
                double lbar_const, long N, void *xbar_out, void *gtheta_out, void *ws);
+
+size_t nf_g64_bwd_inv_ws_bytes(const nf_flow_desc *desc, long N);
+int nf_g64_bwd_inv(nf_ctx *, const nf_flow_desc *, const void *theta, void *z, void *gbar, double lbar_const, long N,
+                   void *gtheta_out, void *ws);
 
 // Hamiltonian flow of the demos (nf_hamiltonian.hip)
 bool nf_hf_supported(const nf_flow_desc *desc);
@@ -419,6 +423,18 @@ static int realnvp_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta
   return nf_affine_reduce_slabs(ctx, desc, slab, grid, g_out);
 }
 
+// reverse pass of the INVERSE coupling chain on tiled buffers (forward-KL training): `state` holds
+// T^-1(data) on entry and the data on exit, `gbar` the cotangent of z; couplings in forward execution order
+static inline bool coupling_inv_bwd_tiled(const nf_flow_desc *desc) {
+  (void)desc;
+  return false;
+}
+static int coupling_inv_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta, float *state, float *gbar,
+                            float lbar_const, long N, float *slab, int grid, float *g_out) {
+  (void)ctx; (void)desc; (void)theta; (void)state; (void)gbar; (void)lbar_const; (void)N; (void)slab; (void)grid; (void)g_out;
+  return NF_ERR_UNSUPPORTED;
+}
+
 extern "C" int nf_flow_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *x, const void *y,
                            const void *ybar, const void *lbar, int64_t N, void *xbar_out, void *gtheta_out) {
   if (!ctx || !theta || !x || !y || !ybar || !lbar || !xbar_out || !gtheta_out || N < 0) return NF_ERR_ARG;
@@ -550,6 +566,71 @@ extern "C" int nf_loglikelihood(nf_ctx *ctx, const nf_flow_desc *desc, const voi
   NF_TRY(nf_launch_sum2(ctx, desc->dtype, N, logq, ladj, logliks_out, partial, 1.0 / (double)N));
   NF_TRY(nf_launch_finish_sum(ctx, partial, nb, 0, result, nullptr, nullptr));
   return read_scalar(ctx, result, ll_host);
+}
+
+// ---- forward-KL training step -----------------------------------------------------------------
+// loss = -(1/Ng) sum_j [log q0(z_j) + ladj_inv_j],  z = T^-1(ys).  One inverse pass, then the reverse pass of
+// the INVERSE chain: layers in forward execution order, each with the implicit-function form of its inverse
+// (cotangent of z: z / Ng; cotangent of every ladj_inv: -1 / Ng).  The standard-normal base density and its
+// gradient come from the diagonal-Gaussian target kernel with mu = 0, var = 1.
+extern "C" int nf_loglikelihood_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *ys,
+                                               int64_t N_local, int64_t N_global, void *out) {
+  if (!ctx || !theta || !out || N_local < 0 || N_global < 1 || (N_local > 0 && !ys)) return NF_ERR_ARG;
+  NF_TRY(check_desc(desc));
+  if (desc->kind == NF_KIND_HAMILTONIAN) return NF_ERR_UNSUPPORTED;
+  NF_HIP(hipSetDevice(ctx->device));
+  const long N = N_local;
+  const long P = nf_param_count(desc);
+  const int dt = desc->dtype;
+  const size_t es = esize(dt);
+  if (N == 0) return nf_launch_fill(ctx, dt, out, P + 1, 0.0);
+  const double inv = 1.0 / (double)N_global;
+  const bool coupling_kind = desc->kind == NF_KIND_REALNVP || desc->kind == NF_KIND_NSF;
+  const bool tiled = is_coupling(desc) && coupling_inv_bwd_tiled(desc);
+  if (coupling_kind && !tiled && !nf_g64_supported(desc)) return NF_ERR_UNSUPPORTED;
+  const long nb = tiled ? nf_target_tiled_nblocks(N) : nf_target_nblocks(N);
+  const int grid = tiled ? coupling_bwd_grid(ctx, desc, N) : 0;
+  const size_t slabf = tiled ? (size_t)grid * coupling_slab_floats(ctx, desc, N) : 0;
+  const size_t flat_ws = tiled ? 0 : coupling_kind ? nf_g64_bwd_inv_ws_bytes(desc, N) : nf_simple_bwd_ws_bytes(ctx, desc, N);
+  const size_t xe = tiled ? tiled_elems(desc, N) : (size_t)N * desc->d;
+  const size_t need = 2 * carve_bytes(xe * es) + carve_bytes((size_t)N * es) + carve_bytes((size_t)nb * 8) +
+                      carve_bytes(2 * (size_t)desc->d * es) + carve_bytes(slabf * es) + carve_bytes(flat_ws);
+  NF_TRY(nf_ws_reserve(ctx, need));
+  Carver cv(ctx->ws);
+  char *z = cv.take<char>(xe * es);
+  char *gbar = cv.take<char>(xe * es);
+  char *ladj = cv.take<char>((size_t)N * es);
+  double *partial = cv.take<double>(nb);
+  char *q0par = cv.take<char>(2 * (size_t)desc->d * es);
+  char *slab = cv.take<char>(slabf * es);
+  char *fws = cv.take<char>(flat_ws);
+  nf_target q0;
+  q0.kind = NF_TARGET_DIAGGAUSS;
+  q0.p0 = q0par;
+  q0.p1 = q0par + (size_t)desc->d * es;
+  q0.s0 = q0.s1 = 0.0;
+  NF_TRY(nf_launch_fill(ctx, dt, q0par, desc->d, 0.0));
+  NF_TRY(nf_launch_fill(ctx, dt, q0par + (size_t)desc->d * es, desc->d, 1.0));
+
+  if (tiled) {
+    float *zt = (float *)z, *gt = (float *)gbar;
+    NF_TRY(nf_launch_layout_convert(ctx, desc->d, N, (const float *)ys, zt, 1));
+    NF_TRY(coupling_chain_tiled(ctx, desc, true, (const float *)theta, zt, N, (float *)ladj, -1));
+    NF_TRY(nf_launch_target_tiled(ctx, &q0, desc->d, N, zt, nullptr, (const float *)ladj, gt, -inv, nullptr, partial, -inv));
+    NF_TRY(nf_launch_finish_sum(ctx, partial, nb, 0, nullptr, (float *)out + P, nullptr));
+    return coupling_inv_bwd(ctx, desc, (const float *)theta, zt, gt, (float)(-inv), N, (float *)slab, grid, (float *)out);
+  }
+  if (coupling_kind) {
+    NF_TRY(nf_g64_apply(ctx, desc, 0, nf_layer_count(desc), true, theta, ys, N, z, ladj));
+    NF_TRY(nf_launch_target(ctx, dt, &q0, desc->d, N, z, nullptr, ladj, nullptr, gbar, -inv, nullptr, partial, -inv, 0));
+    NF_TRY(nf_g64_bwd_inv(ctx, desc, theta, z, gbar, -inv, N, out, fws));
+  } else {
+    NF_TRY(nf_simple_apply_stash(ctx, desc, theta, ys, N, z, ladj, fws, true));
+    NF_TRY(nf_launch_target(ctx, dt, &q0, desc->d, N, z, nullptr, ladj, nullptr, gbar, -inv, nullptr, partial, -inv, 0));
+    NF_TRY(nf_simple_bwd(ctx, desc, theta, z, gbar, nullptr, -inv, N, gbar, out, fws, true, true));
+  }
+  if (dt == NF_DTYPE_F32) return nf_launch_finish_sum(ctx, partial, nb, 0, nullptr, (float *)out + P, nullptr);
+  return nf_launch_finish_sum(ctx, partial, nb, 0, (double *)out + P, nullptr, nullptr);
 }
 
 // ---- training step -------------------------------------------------------------------------

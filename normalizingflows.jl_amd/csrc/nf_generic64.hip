@@ -148,10 +148,13 @@ __device__ T g64_spline_inv(const G64Spline<T> &sp, int K, T y, T &logd) {
   logd -= g64_logderiv(s, d0, d1, xi);
   return xi * dx + sp.pX[k];
 }
-// reverse pass of g64_spline_fwd at x: (ybar, lbar) -> xbar, thbar[3K-1]
+// reverse pass of g64_spline_fwd at x: (ybar, lbar) -> xbar, thbar[3K-1].
+// inv: reverse pass of the INVERSE spline v -> x = S^-1(v), ladj_inv = -log S'(x), at its output x, with
+// (ybar, lbar) the cotangents of (x, ladj_inv); implicit-function form: vbar = (ybar - lbar dlogS'/dx) / S',
+// thbar = the forward reverse pass with cotangents (-vbar, -lbar).  Returns vbar.
 template <class T>
 __device__ T g64_spline_bwd(const G64Spline<T> &sp, const T *raw, int K, T B, T x, T ybar,
-                                 T lbar, T *thbar) {
+                                 T lbar, T *thbar, bool inv = false) {
   const int P = 3 * K - 1;
   for (int i = 0; i < P; ++i) thbar[i] = (T)0.0;
   bool inside;
@@ -165,6 +168,12 @@ __device__ T g64_spline_bwd(const G64Spline<T> &sp, const T *raw, int K, T B, T 
   const T dnd_dxi = (T)2.0 * d1 * xi + (T)2.0 * s * ((T)1.0 - (T)2.0 * xi) - (T)2.0 * d0 * om;
   const T dy_dxi = dy * (dnum_dxi * den - num * dden_dxi) / (den * den);
   const T dL_dxi = dnd_dxi / nd - (T)2.0 * dden_dxi / den;
+  T vbar = (T)0.0;
+  if (inv) {
+    vbar = (ybar - lbar * dL_dxi / dx) / (dy_dxi / dx);
+    ybar = -vbar;
+    lbar = -lbar;
+  }
   const T dden_ds = (T)1.0 - (T)2.0 * xi * om;
   const T dy_ds = dy * (xi * xi * den - num * dden_ds) / (den * den);
   const T dL_ds = (T)2.0 / s + (T)2.0 * xi * om / nd - (T)2.0 * dden_ds / den;
@@ -231,9 +240,11 @@ __global__ __launch_bounds__(G64_BLOCK) void k_g64_apply(G64Args a, int inverse,
   ladj[j] += lsum;
 }
 
-// reverse pass of one coupling at its INPUT x: gbar holds ybar on entry, xbar on exit
+// reverse pass of one coupling at its INPUT x: gbar holds ybar on entry, xbar on exit.
+// inv != 0: reverse pass of the INVERSE coupling at its OUTPUT x (same point): gbar holds the cotangent of
+// x on entry and of the inverse's input on exit, lbar is the cotangent of ladj_inv.
 template <class T>
-__global__ __launch_bounds__(G64_BLOCK) void k_g64_bwd(G64Args a, const T *__restrict__ theta,
+__global__ __launch_bounds__(G64_BLOCK) void k_g64_bwd(G64Args a, int inv, const T *__restrict__ theta,
                                                       const T *__restrict__ x, T *gbar,
                                                       const T *__restrict__ lbar, T lbar_const,
                                                       T *__restrict__ g) {
@@ -245,7 +256,21 @@ __global__ __launch_bounds__(G64_BLOCK) void k_g64_bwd(G64Args a, const T *__res
   T x2[G64_MAXC], acts[NF_MAX_HIDDEN][G64_MAXH], out[G64_MAXO], din[G64_MAXC];
   const int par_c = 1 - a.par_t;
   for (int q = 0; q < a.m; ++q) x2[q] = xr[2 * q + par_c];
-  if (a.kind == NF_KIND_REALNVP) {
+  if (a.kind == NF_KIND_REALNVP && inv) {
+    // x1 = (v1 - t) exp(-s), ladj_inv = -sum s:  v1bar = x1bar exp(-s), sbar = -x1bar x1 - lbar, tbar = -v1bar
+    g64_net_fwd(theta, a.net[0], x2, acts, out);
+    for (int p = 0; p < a.c; ++p) {
+      const T s = tanh(out[p]), x1 = xr[2 * p + a.par_t], xb = gr[2 * p + a.par_t];
+      gr[2 * p + a.par_t] = xb * exp(-s);
+      out[p] = (-xb * x1 - lb) * ((T)1.0 - s * s);
+    }
+    g64_net_bwd(theta, a.net[0], x2, acts, out, din, g);
+    for (int q = 0; q < a.m; ++q) gr[2 * q + par_c] += din[q];
+    g64_net_fwd(theta, a.net[1], x2, acts, out);
+    for (int p = 0; p < a.c; ++p) out[p] = -gr[2 * p + a.par_t];
+    g64_net_bwd(theta, a.net[1], x2, acts, out, din, g);
+    for (int q = 0; q < a.m; ++q) gr[2 * q + par_c] += din[q];
+  } else if (a.kind == NF_KIND_REALNVP) {
     // t net: y1 = x1 exp(s) + t  =>  tbar = ybar1
     g64_net_fwd(theta, a.net[1], x2, acts, out);
     for (int p = 0; p < a.c; ++p) out[p] = gr[2 * p + a.par_t];
@@ -267,7 +292,7 @@ __global__ __launch_bounds__(G64_BLOCK) void k_g64_bwd(G64Args a, const T *__res
     T thb[3 * G64_MAXK];
     for (int p = 0; p < a.c; ++p) {
       g64_build<T>(out + p * P, a.K, (T)a.B, sp);
-      const T xb = g64_spline_bwd<T>(sp, out + p * P, a.K, (T)a.B, xr[2 * p + a.par_t], gr[2 * p + a.par_t], lb, thb);
+      const T xb = g64_spline_bwd<T>(sp, out + p * P, a.K, (T)a.B, xr[2 * p + a.par_t], gr[2 * p + a.par_t], lb, thb, inv != 0);
       gr[2 * p + a.par_t] = xb;
       for (int i = 0; i < P; ++i) out[p * P + i] = thb[i];
     }
@@ -378,7 +403,7 @@ static int g64_bwd_t(nf_ctx *ctx, const nf_flow_desc *desc, const T *theta, cons
   for (int k = 0; k < nc; ++k) {  // reverse of execution order
     const G64Args a = make_g64_args(desc, k, N);
     ProfScope ps(ctx, "g64_bwd");
-    hipLaunchKernelGGL(k_g64_bwd<T>, dim3(grid), dim3(G64_BLOCK), 0, ctx->stream, a, theta, (const T *)(inputs + (size_t)k * nd), xbar_out, lbar, (T)lbar_const, gtheta_out);
+    hipLaunchKernelGGL(k_g64_bwd<T>, dim3(grid), dim3(G64_BLOCK), 0, ctx->stream, a, 0, theta, (const T *)(inputs + (size_t)k * nd), xbar_out, lbar, (T)lbar_const, gtheta_out);
     NF_HIP(hipGetLastError());
   }
   return NF_OK;
@@ -391,4 +416,43 @@ int nf_g64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const v
                              lbar_const, N, (double *)xbar_out, (double *)gtheta_out, ws);
   return g64_bwd_t<float>(ctx, desc, (const float *)theta, (const float *)x, (const float *)ybar, (const float *)lbar,
                           lbar_const, N, (float *)xbar_out, (float *)gtheta_out, ws);
+}
+
+// Reverse pass of the INVERSE chain (forward-KL training).  `z` holds T^-1(data) on entry and the data
+// again on exit; `gbar` the cotangent of z on entry; lbar_const the cotangent of every sample's
+// ladj_inv.  Couplings are walked in forward execution order: reverse pass of inverse coupling k at z,
+// then z <- coupling_k(z).  ws: N elements (scratch log-det).
+template <class T>
+static int g64_bwd_inv_t(nf_ctx *ctx, const nf_flow_desc *desc, const T *theta, T *z, T *gbar, double lbar_const, long N,
+                         T *gtheta_out, void *ws) {
+  const int nc = 2 * desc->nlayers;
+  const CouplingInfo last = nf_coupling_info(desc, nc - 1);
+  const long P = last.theta_off + last.nparams;
+  NF_HIP(hipMemsetAsync(gtheta_out, 0, (size_t)P * sizeof(T), ctx->stream));
+  if (N <= 0) return NF_OK;
+  T *scr_ladj = (T *)ws;
+  NF_HIP(hipMemsetAsync(scr_ladj, 0, (size_t)N * sizeof(T), ctx->stream));
+  const unsigned grid = (unsigned)((N + G64_BLOCK - 1) / G64_BLOCK);
+  for (int k = nc - 1; k >= 0; --k) {
+    const G64Args a = make_g64_args(desc, k, N);
+    {
+      ProfScope ps(ctx, "g64_bwd");
+      hipLaunchKernelGGL(k_g64_bwd<T>, dim3(grid), dim3(G64_BLOCK), 0, ctx->stream, a, 1, theta, (const T *)z, gbar,
+                         (const T *)nullptr, (T)lbar_const, gtheta_out);
+      NF_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_g64_apply<T>, dim3(grid), dim3(G64_BLOCK), 0, ctx->stream, a, 0, theta, (const T *)z, z, scr_ladj);
+    NF_HIP(hipGetLastError());
+  }
+  return NF_OK;
+}
+
+size_t nf_g64_bwd_inv_ws_bytes(const nf_flow_desc *, long N) { return (size_t)N * sizeof(double); }
+
+int nf_g64_bwd_inv(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, void *z, void *gbar, double lbar_const, long N,
+                   void *gtheta_out, void *ws) {
+  if (desc->dtype == NF_DTYPE_F64)
+    return g64_bwd_inv_t<double>(ctx, desc, (const double *)theta, (double *)z, (double *)gbar, lbar_const, N,
+                                 (double *)gtheta_out, ws);
+  return g64_bwd_inv_t<float>(ctx, desc, (const float *)theta, (float *)z, (float *)gbar, lbar_const, N, (float *)gtheta_out, ws);
 }

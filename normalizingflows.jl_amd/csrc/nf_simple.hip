@@ -220,8 +220,10 @@ __device__ __forceinline__ T layer_inverse(int lk, const T *c, int d, int q, T (
   return -c[d];
 }
 
-// chain-fused forward / inverse over flat layers [lo, hi).  If `stash` != nullptr the INPUT of
-// every layer (execution order index e) is written to stash[e][N][d] for the reverse pass.
+// chain-fused forward / inverse over flat layers [lo, hi).  If `stash` != nullptr the reverse pass's
+// evaluation points are left behind: forward -- the INPUT of every layer at stash[e][N][d] (execution
+// index e); inverse -- the OUTPUT of every inverse layer at stash[l][N][d] (flat index l), i.e. the
+// forward-sense input of layer l, which is where the inverse chain's reverse pass evaluates it.
 template <class T, int DPL>
 __global__ __launch_bounds__(SB) void k_simple_apply(SimpleArgs a, const T *__restrict__ theta, const T *x,
                                                      T *y, T *__restrict__ ladj, T *__restrict__ stash) {
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(SB) void k_simple_apply(SimpleArgs a, const T *__re
     T lsum = 0;
     for (int e = 0; e < nlr; ++e) {
       const int l = a.inverse ? a.lo + e : a.hi - 1 - e;
-      if (stash && valid) {
+      if (stash && valid && !a.inverse) {
 #pragma unroll
         for (int k = 0; k < DPL; ++k) {
           const int i = q + LPS * k;
@@ -253,6 +255,13 @@ __global__ __launch_bounds__(SB) void k_simple_apply(SimpleArgs a, const T *__re
       const T *c = cache + (long)(l - a.lo) * LP;
       const int lk = layer_kind(a.kind, l);
       lsum += a.inverse ? layer_inverse<T, DPL>(lk, c, d, q, z) : layer_forward<T, DPL>(lk, c, d, q, z);
+      if (stash && valid && a.inverse) {
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+          const int i = q + LPS * k;
+          if (i < d) stash[((long)l * a.N + j) * d + i] = z[k];
+        }
+      }
     }
     if (valid) {
 #pragma unroll
@@ -270,7 +279,13 @@ __global__ __launch_bounds__(SB) void k_simple_apply(SimpleArgs a, const T *__re
 //   planar: wbar_raw[d] | uhat_bar[d] | bbar | cbar
 //   radial: z0bar[d] | alpha_bar | betahat_bar
 //   shift : abar[d]            scale: sum(ybar .* x)[d] | sum(lbar)
-template <class T, int DPL>
+//
+// INV: reverse pass of the INVERSE chain (forward-KL training).  Layers are walked in forward execution
+// order; zin = the inverse layer's OUTPUT w (stash of the inverse pass), gbar in = cotangent of w, out =
+// cotangent vbar of the inverse layer's input, lbar = cotangent of ladj_inv.  Implicit-function form:
+//   vbar = J^-T (wbar - lbar grad_w ladj_fwd),  parameter sums = the forward formulas with (-vbar, -lbar);
+// J^-T is closed-form for every layer here (Sherman-Morrison for planar / radial).
+template <class T, int DPL, bool INV>
 __global__ __launch_bounds__(SB) void k_simple_bwd_layers(SimpleArgs a, int nl, const T *__restrict__ theta,
                                                           const T *__restrict__ stash, long stash_stride,
                                                           T *__restrict__ gbar, const T *__restrict__ lbar, T lbar_const,
@@ -282,8 +297,9 @@ __global__ __launch_bounds__(SB) void k_simple_bwd_layers(SimpleArgs a, int nl, 
   // every layer in one launch: a thread keeps its samples from layer to layer (it re-reads the gbar it
   // wrote), so only the block-wide parameter reduction needs the barriers
 #pragma unroll 1
-  for (int l = 0; l < nl; ++l) {  // flat order = reverse of execution order
-    const T *zin = stash + (long)(nl - 1 - l) * stash_stride;
+  for (int step = 0; step < nl; ++step) {
+    const int l = INV ? nl - 1 - step : step;  // forward chain: flat order = reverse of execution order
+    const T *zin = stash + (long)(INV ? l : nl - 1 - l) * stash_stride;
     T *slab = slabs + (long)l * slab_stride;
     SimpleArgs one = a;
     one.lo = l;
@@ -301,15 +317,16 @@ __global__ __launch_bounds__(SB) void k_simple_bwd_layers(SimpleArgs a, int nl, 
     for (long j = (long)blockIdx.x * SPB + grp; j < a.N; j += (long)gridDim.x * SPB) {
       const bool valid = true;
       const long jj = valid ? j : 0;
-      T z[DPL], g[DPL];
+      T z[DPL], g[DPL], v[DPL];
   #pragma unroll
       for (int k = 0; k < DPL; ++k) {
         const int i = q + LPS * k;
         const bool ok = valid && i < d;
         z[k] = ok ? zin[jj * d + i] : (T)0;
         g[k] = ok ? gbar[jj * d + i] : (T)0;
+        v[k] = (T)0;
       }
-      const T lb = valid ? (lbar ? lbar[jj] : lbar_const) : (T)0;
+      T lb = valid ? (lbar ? lbar[jj] : lbar_const) : (T)0;
       if (lk == LK_PLANAR) {
         T dot = 0, ug = 0;
   #pragma unroll
@@ -324,6 +341,22 @@ __global__ __launch_bounds__(SB) void k_simple_bwd_layers(SimpleArgs a, int nl, 
         const T t = tanh(g16sum(dot) + c[2 * d]);
         ug = g16sum(ug);
         const T gg = (T)1 - t * t, D = (T)1 + cc * gg;
+        if (INV) {
+          // J^T = I + gg w uhat^T, grad_z ladj = kap w, uhat^T w = cc:  vbar = g - w beta
+          const T kap = -(T)2 * cc * t * gg / D;
+          const T uap = ug - lb * kap * cc;
+          const T beta = lb * kap + gg * uap / D;
+  #pragma unroll
+          for (int k = 0; k < DPL; ++k) {
+            const int i = q + LPS * k;
+            if (i < d) {
+              v[k] = g[k] - c[i] * beta;
+              g[k] = -v[k];
+            }
+          }
+          ug = -(ug - cc * beta);
+          lb = -lb;
+        }
         const T ab = ug * gg - (T)2 * lb * cc * t * gg / D;
   #pragma unroll
         for (int k = 0; k < DPL; ++k) {
@@ -357,6 +390,23 @@ __global__ __launch_bounds__(SB) void k_simple_bwd_layers(SimpleArgs a, int nl, 
         const T dL_dh = (T)(d - 1) * bh / ((T)1 + qq) + (T)2 * bh * alpha * h / ((T)1 + bah2);
         const T dL_db = (T)(d - 1) * h / ((T)1 + qq) + alpha * h * h / ((T)1 + bah2);
         const T dL_da = bh * h * h / ((T)1 + bah2);
+        if (INV) {
+          // J = A I + Bc delta delta^T (symmetric), A + Bc r^2 = 1 + bah2, grad_z ladj = -dL_dh h^2 delta / r
+          const T A = (T)1 + qq;
+          const T e = r > (T)0 ? lb * dL_dh * h * h / r : (T)0;
+          const T dap = yd + lb * dL_dh * h * h * r;
+          const T f2 = r > (T)0 ? (-bh * h * h / r) * dap / ((T)1 + bah2) : (T)0;
+  #pragma unroll
+          for (int k = 0; k < DPL; ++k) {
+            const int i = q + LPS * k;
+            if (i < d) {
+              v[k] = (g[k] + (e - f2) * z[k]) / A;
+              g[k] = -v[k];
+            }
+          }
+          yd = -dap / ((T)1 + bah2);
+          lb = -lb;
+        }
         const T hbar = bh * yd + lb * dL_dh;
         const T rbar_over_r = r > (T)0 ? -h * h * hbar / r : (T)0;
   #pragma unroll
@@ -374,23 +424,31 @@ __global__ __launch_bounds__(SB) void k_simple_bwd_layers(SimpleArgs a, int nl, 
         }
       } else if (lk == LK_SHIFT) {
   #pragma unroll
-        for (int k = 0; k < DPL; ++k) acc0[k] += g[k];
+        for (int k = 0; k < DPL; ++k) {
+          acc0[k] += INV ? -g[k] : g[k];
+          v[k] = g[k];
+        }
       } else {
   #pragma unroll
         for (int k = 0; k < DPL; ++k) {
           const int i = q + LPS * k;
           if (i < d) {
-            acc0[k] += g[k] * z[k];
-            g[k] *= c[i];
+            if (INV) {
+              v[k] = g[k] / c[i];
+              acc0[k] -= v[k] * z[k];
+            } else {
+              acc0[k] += g[k] * z[k];
+              g[k] *= c[i];
+            }
           }
         }
-        if (q == 0) s0 += lb;
+        if (q == 0) s0 += INV ? -lb : lb;
       }
       if (valid) {
   #pragma unroll
         for (int k = 0; k < DPL; ++k) {
           const int i = q + LPS * k;
-          if (i < d) gbar[j * d + i] = g[k];
+          if (i < d) gbar[j * d + i] = INV ? v[k] : g[k];
         }
       }
     }
@@ -555,10 +613,10 @@ size_t nf_simple_bwd_ws_bytes(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
 // forward pass that leaves the input of every layer in the reverse pass's workspace (same carving as
 // bwd_t), so that nf_simple_bwd(..., have_stash = true) need not recompute it
 int nf_simple_apply_stash(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *x, long N, void *y,
-                          void *ladj, void *ws) {
+                          void *ladj, void *ws, bool inverse) {
   if (N <= 0) return NF_OK;
   const int nl = desc->kind == NF_KIND_MEANFIELD ? 2 : desc->nlayers;
-  SimpleArgs a = make_sargs(desc, 0, nl, false, N);
+  SimpleArgs a = make_sargs(desc, 0, nl, inverse, N);
   Carver cv(ws);
   if (desc->dtype == NF_DTYPE_F32) return apply_t<float>(ctx, a, theta, x, y, ladj, cv.take<float>((size_t)nl * N * desc->d));
   return apply_t<double>(ctx, a, theta, x, y, ladj, cv.take<double>((size_t)nl * N * desc->d));
@@ -567,7 +625,8 @@ int nf_simple_apply_stash(nf_ctx *ctx, const nf_flow_desc *desc, const void *the
 template <class T>
 static int bwd_t(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *x, const void *ybar,
                  const void *lbar, double lbar_const, long N, void *xbar_out, void *gtheta_out, void *ws,
-                 bool have_stash) {
+                 bool have_stash, bool inv) {
+  if (inv && !have_stash) return NF_ERR_ARG;  // the inverse chain's points come from nf_simple_apply_stash(inverse)
   const int nl = desc->kind == NF_KIND_MEANFIELD ? 2 : desc->nlayers;
   const int d = desc->d;
   const size_t LP = 2 * (size_t)d + 2;
@@ -584,9 +643,14 @@ static int bwd_t(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const
   const size_t lds = (LP + (size_t)SPB * LP) * sizeof(T);
   {
     ProfScope ps(ctx, "simple_bwd");
-#define LAUNCH_BWD(DPLv)                                                                                            \
-  hipLaunchKernelGGL((k_simple_bwd_layers<T, DPLv>), dim3(nb), dim3(SB), lds, ctx->stream, a, nl, (const T *)theta, \
+#define LAUNCH_BWD_V(DPLv, INVv)                                                                                     \
+  hipLaunchKernelGGL((k_simple_bwd_layers<T, DPLv, INVv>), dim3(nb), dim3(SB), lds, ctx->stream, a, nl, (const T *)theta, \
                      (const T *)stash, (long)N * d, (T *)xbar_out, (const T *)lbar, (T)lbar_const, slabs, (long)nb * LP)
+#define LAUNCH_BWD(DPLv)           \
+  do {                             \
+    if (inv) LAUNCH_BWD_V(DPLv, true); \
+    else LAUNCH_BWD_V(DPLv, false);    \
+  } while (0)
     switch (dpl_for(d)) {
       case 1: LAUNCH_BWD(1); break;
       case 2: LAUNCH_BWD(2); break;
@@ -596,6 +660,7 @@ static int bwd_t(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const
       default: return NF_ERR_UNSUPPORTED;
     }
 #undef LAUNCH_BWD
+#undef LAUNCH_BWD_V
     NF_HIP(hipGetLastError());
   }
   hipLaunchKernelGGL(k_simple_finalize<T>, dim3(nl), dim3(SB), LP * sizeof(T), ctx->stream, a, (const T *)theta,
@@ -605,8 +670,8 @@ static int bwd_t(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const
 
 int nf_simple_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *x, const void *ybar,
                   const void *lbar, double lbar_const, long N, void *xbar_out, void *gtheta_out, void *ws,
-                  bool have_stash) {
+                  bool have_stash, bool inv) {
   if (desc->dtype == NF_DTYPE_F32)
-    return bwd_t<float>(ctx, desc, theta, x, ybar, lbar, lbar_const, N, xbar_out, gtheta_out, ws, have_stash);
-  return bwd_t<double>(ctx, desc, theta, x, ybar, lbar, lbar_const, N, xbar_out, gtheta_out, ws, have_stash);
+    return bwd_t<float>(ctx, desc, theta, x, ybar, lbar, lbar_const, N, xbar_out, gtheta_out, ws, have_stash, inv);
+  return bwd_t<double>(ctx, desc, theta, x, ybar, lbar, lbar_const, N, xbar_out, gtheta_out, ws, have_stash, inv);
 }

@@ -99,6 +99,21 @@ def loglikelihood(rng, flow: Flow, xs: torch.Tensor) -> float:
     return val.value
 
 
+def loglikelihood_value_and_gradient(flow: Flow, xs: torch.Tensor, n_global: Optional[int] = None):
+    """(loss, grad) of loss(theta) = -loglikelihood(rng, re(theta), xs) -- what
+    `train_flow(loglikelihood, flow, xs)` differentiates (src/NormalizingFlows.jl:69 with
+    src/objectives/loglikelihood.jl:26-33; gradient by src/optimize.jl:77,86).  For a shard of a global
+    data set pass n_global and all-reduce the returned loss and grad over ranks."""
+    dt, dev = flow.theta.dtype, flow.theta.device
+    xm, _ = as_batch(xs.to(dt))
+    n = xm.shape[1]
+    ng = n if n_global is None else int(n_global)
+    out = torch.empty(flow.P + 1, dtype=dt, device=dev)
+    ctx = flow.ctx
+    check(ctx.lib.nf_loglikelihood_value_and_grad(ctx.ptr, C.byref(flow.desc), _ptr(flow.theta), _ptr(xm), n, ng, _ptr(out)))
+    return float(out[flow.P]), out[: flow.P]
+
+
 # --------------------------------------------------------------------------------------
 # gradients (the device analogue of _value_and_gradient, src/optimize.jl:12-14)
 # --------------------------------------------------------------------------------------
@@ -111,8 +126,11 @@ def value_and_gradient(vo, flow: Flow, logp, xs_or_n, rng: Optional[PhiloxRNG] =
     Returns (loss: float, grad: tensor[P]) -- for a shard of a global batch pass n_global and
     all-reduce the returned grad and loss over ranks.
     """
+    if vo is loglikelihood:
+        # forward KL: the second positional slot of the reference's loss closure is the data
+        return loglikelihood_value_and_gradient(flow, logp if xs_or_n is None else xs_or_n, n_global)
     if vo not in (elbo, elbo_batch):
-        raise NFHipError("value_and_gradient supports elbo and elbo_batch")
+        raise NFHipError("value_and_gradient supports elbo, elbo_batch and loglikelihood")
     dt, dev = flow.theta.dtype, flow.theta.device
     ctx = flow.ctx
     P = flow.P
@@ -284,7 +302,10 @@ def train_flow(*args, max_iters: int = 1000, optimiser: Adam = None, ADbackend=N
         if vo in (elbo, elbo_batch):
             logp, n = rest
             return value_and_gradient(vo, f, logp, n, rng)
-        raise NFHipError("train_flow: objective has no device gradient yet")
+        if vo is loglikelihood:  # train_flow(loglikelihood, flow, xs): forward KL on the data xs
+            (xs,) = rest
+            return loglikelihood_value_and_gradient(f, xs)
+        raise NFHipError("train_flow: objective must be elbo, elbo_batch or loglikelihood")
 
     theta, stats, st = optimize(loss_and_grad, theta_flat, re, max_iters=max_iters, optimiser=optimiser, **kwargs)
     return re(theta), stats, st

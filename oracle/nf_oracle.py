@@ -661,6 +661,25 @@ def flow_inv(spec: FlowSpec, theta, y):
     return y, ladj
 
 
+def _layer_bwd(spec, theta, li, xin, ybar, lbar, grad):
+    """Reverse pass of one layer at its input `xin`; parameter gradients are added to `grad`."""
+    gp = grad[li.offset : li.offset + li.nparams]
+    p = theta[li.offset : li.offset + li.nparams]
+    if li.kind == "planar":
+        return planar_bwd(p, xin, ybar, lbar, gp)
+    if li.kind == "radial":
+        return radial_bwd(p, xin, ybar, lbar, gp)
+    if li.kind == "affine":
+        return affine_bwd(theta, li, xin, ybar, lbar, grad)
+    if li.kind == "shift":
+        gp += ybar.sum(axis=1)
+        return ybar
+    if li.kind == "scale":
+        gp += (ybar * xin).sum(axis=1) + lbar.sum() / p
+        return ybar * p[:, None]
+    return rqs_bwd(theta, li, xin, ybar, lbar, grad, spec.K, spec.B)
+
+
 def flow_bwd(spec: FlowSpec, theta, states, ybar, lbar):
     """Reverse pass through the whole chain.  states from flow_fwd(keep=True).
     Returns (xbar, grad_theta)."""
@@ -668,24 +687,35 @@ def flow_bwd(spec: FlowSpec, theta, states, ybar, lbar):
     grad = np.zeros_like(theta)
     exec_order = list(reversed(layers))
     for i in range(len(exec_order) - 1, -1, -1):
-        li = exec_order[i]
-        xin = states[i]
-        gp = grad[li.offset : li.offset + li.nparams]
-        p = theta[li.offset : li.offset + li.nparams]
-        if li.kind == "planar":
-            ybar = planar_bwd(p, xin, ybar, lbar, gp)
-        elif li.kind == "radial":
-            ybar = radial_bwd(p, xin, ybar, lbar, gp)
-        elif li.kind == "affine":
-            ybar = affine_bwd(theta, li, xin, ybar, lbar, grad)
-        elif li.kind == "shift":
-            gp += ybar.sum(axis=1)
-        elif li.kind == "scale":
-            gp += (ybar * xin).sum(axis=1) + lbar.sum() / p
-            ybar = ybar * p[:, None]
-        else:
-            ybar = rqs_bwd(theta, li, xin, ybar, lbar, grad, spec.K, spec.B)
+        ybar = _layer_bwd(spec, theta, exec_order[i], states[i], ybar, lbar, grad)
     return ybar, grad
+
+
+def _layer_inv_bwd(spec, theta, li, w, wbar, c, grad):
+    """Reverse pass of ONE INVERSE layer  v -> w = T^-1(v),  ladj_inv = -ladj_fwd(w; theta),
+    at its output w, by the implicit-function theorem on v = T(w; theta):
+        dw/dv = J^-1,  dw/dtheta = -J^-1 dT/dtheta          (J = dT/dw).
+    With cotangents (wbar, c) of (w, ladj_inv):
+        vbar      = J^-T (wbar - c * grad_w ladj_fwd)
+        thetabar  = -(dT/dtheta)^T vbar - c * grad_theta ladj_fwd
+                  =  the FORWARD layer's reverse pass at w with cotangents (-vbar, -c).
+    J^T is assembled column by column from the forward layer's reverse pass and solved densely,
+    so this is independent of any closed-form inverse Jacobian (what the device kernels use).
+    This is what reverse-mode AD of `loglikelihood` (src/objectives/loglikelihood.jl:26-33,
+    differentiated by src/optimize.jl:77,86) evaluates.  Returns vbar."""
+    d, n = w.shape
+    scratch = np.zeros_like(theta)
+    zeros_n = np.zeros(n, dtype=w.dtype)
+    D = _layer_bwd(spec, theta, li, w, np.zeros_like(w), np.ones(n, dtype=w.dtype), scratch)
+    ap = wbar - c[None, :] * D
+    JT = np.empty((n, d, d), dtype=w.dtype)
+    for i in range(d):
+        e = np.zeros_like(w)
+        e[i] = 1.0
+        JT[:, :, i] = _layer_bwd(spec, theta, li, w, e, zeros_n, scratch).T
+    vbar = np.linalg.solve(JT, ap.T[:, :, None])[:, :, 0].T
+    _layer_bwd(spec, theta, li, w, -vbar, -c, grad)
+    return vbar
 
 
 # --------------------------------------------------------------------------
@@ -856,6 +886,25 @@ def loglikelihood(spec, theta, ys):
     logpdf(td, y) = logpdf(td.dist, x) + ladj_inv (Bijectors)."""
     xs, ladj = flow_inv(spec, theta, ys)
     return (std_normal_logpdf(xs) + ladj).mean()
+
+
+def neg_loglik_value_and_grad(spec, theta, ys, n_global=None):
+    """loss(theta) = -loglikelihood(flow, ys) and its gradient: `train_flow(loglikelihood, flow, ys)`
+    (src/NormalizingFlows.jl:69 with vo = loglikelihood; gradient by src/optimize.jl:77,86).
+    The chain is inverted once, then walked in forward execution order with _layer_inv_bwd."""
+    n = ys.shape[1]
+    ng = n if n_global is None else n_global
+    layers = layers_flat_order(spec)
+    z, ladj = flow_inv(spec, theta, ys)
+    loss = -(std_normal_logpdf(z) + ladj).sum() / ng
+    a = z / ng  # d loss / dz through -log q0(z)
+    c = np.full(n, -1.0 / ng, dtype=ys.dtype)
+    grad = np.zeros_like(theta)
+    w = z
+    for li in reversed(layers):
+        a = _layer_inv_bwd(spec, theta, li, w, a, c, grad)
+        w, _ = _layer_fwd(spec, theta, li, w)
+    return loss, grad
 
 
 def neg_elbo_value_and_grad(spec, theta, target, xs):

@@ -287,3 +287,27 @@ def test_hamiltonian_flow_oracle(tname):
         tm[i] -= 1e-6
         gn[i] = (f(tp) - f(tm)) / 2e-6
     assert np.abs(g - gn).max() <= 1e-7 * max(1.0, np.abs(gn).max())
+
+
+@pytest.mark.parametrize("kind", list(SPECS))
+def test_loglikelihood_gradient_matches_finite_differences(kind):
+    """Forward-KL training (train_flow(loglikelihood, ...)): the implicit-function reverse pass of the
+    inverse chain against central differences of -loglikelihood."""
+    spec = SPECS[kind]
+    if kind in ("planar", "radial"):
+        spec = o.FlowSpec(kind, 3, 3)
+    if kind in ("realnvp", "nsf"):
+        spec = o.FlowSpec(kind, 3, 1, (4, 4), K=4 if kind == "nsf" else 0, B=3.0 if kind == "nsf" else 0.0)
+    th = _theta(spec, 9)
+    rng = np.random.default_rng(10)
+    ys = 0.8 * rng.standard_normal((spec.d, 6))
+    loss, g = o.neg_loglik_value_and_grad(spec, th, ys)
+    assert loss == pytest.approx(-o.loglikelihood(spec, th, ys), rel=1e-12)
+    eps = 1e-6
+    gfd = np.zeros_like(th)
+    for i in range(len(th)):
+        tp, tm = th.copy(), th.copy()
+        tp[i] += eps
+        tm[i] -= eps
+        gfd[i] = (-o.loglikelihood(spec, tp, ys) + o.loglikelihood(spec, tm, ys)) / (2 * eps)
+    np.testing.assert_allclose(g, gfd, rtol=5e-5, atol=2e-7)
