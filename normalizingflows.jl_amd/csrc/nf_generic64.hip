@@ -200,7 +200,7 @@ __device__ T g64_spline_bwd(const G64Spline<T> &sp, const T *raw, int K, T B, T 
   }
   if (k >= 1) thbar[2 * K + k - 1] = d0bar * g64_sigmoid(raw[2 * K + k - 1]);
   if (k + 1 <= K - 1) thbar[2 * K + k] = d1bar * g64_sigmoid(raw[2 * K + k]);
-  return xibar / dx;
+  return inv ? vbar : xibar / dx;
 }
 
 // ---- one coupling, forward or inverse, standard layout (x[j*d + i]) ---------------------------
