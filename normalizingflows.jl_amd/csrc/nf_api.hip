@@ -43,7 +43,7 @@ int nf_affine_reduce_slabs(nf_ctx *, const nf_flow_desc *, const float *slab, in
 int nf_affine_bwd(nf_ctx *, const nf_flow_desc *, int k, const float *theta, float *y, float *ybar, const float *lbar,
                   float lbar_const, long N, float *slab, long slab_stride, int grid);
 int nf_affine_bwd_all(nf_ctx *, const nf_flow_desc *, float *y, float *ybar, const float *lbar, float lbar_const, long N,
-                      float *slab, long slab_stride, int grid);
+                      float *slab, long slab_stride, int grid, bool inv_dir = false);
 
 // RealNVP with conditioner nets streamed from L2 (nf_wide.hip): d <= 256, hidden <= 256
 bool nf_wide_supported(const nf_flow_desc *desc);
@@ -426,12 +426,16 @@ static int realnvp_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta
 // reverse pass of the INVERSE coupling chain on tiled buffers (forward-KL training): `state` holds
 // T^-1(data) on entry and the data on exit, `gbar` the cotangent of z; couplings in forward execution order
 static inline bool coupling_inv_bwd_tiled(const nf_flow_desc *desc) {
-  (void)desc;
-  return false;
+  return desc->kind == NF_KIND_REALNVP && nf_affine_supported(desc);
 }
 static int coupling_inv_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta, float *state, float *gbar,
                             float lbar_const, long N, float *slab, int grid, float *g_out) {
-  (void)ctx; (void)desc; (void)theta; (void)state; (void)gbar; (void)lbar_const; (void)N; (void)slab; (void)grid; (void)g_out;
+  (void)theta;
+  if (desc->kind == NF_KIND_REALNVP && nf_affine_supported(desc)) {
+    const long stride = coupling_slab_floats(ctx, desc, N);
+    NF_TRY(nf_affine_bwd_all(ctx, desc, state, gbar, nullptr, lbar_const, N, slab, stride, grid, true));
+    return nf_affine_reduce_slabs(ctx, desc, slab, grid, g_out);
+  }
   return NF_ERR_UNSUPPORTED;
 }
 

@@ -443,7 +443,11 @@ struct BwdLds {
   static constexpr size_t BYTES = (size_t)(G::SIZE + WAVES * SCRATCH) * sizeof(float);
 };
 
-template <class G, bool PHASE_S, bool FULL>
+// INVD: reverse pass of the INVERSE coupling (forward-KL training) at its output w: `y` holds w and is
+// advanced to coupling(w), `ybar` holds the cotangent of w and leaves that of the inverse's input.
+//   w1 = (v1 - t) exp(-s), ladj_inv = -sum s:   v1bar = w1bar exp(-s),  sbar = -(w1bar w1 + lbar),  tbar = -v1bar
+// Phase S runs first there (it needs w1bar and w1), then phase T.
+template <class G, bool PHASE_S, bool FULL, bool INVD = false>
 __device__ __forceinline__ void bwd_tile(const CouplingArgs &a, const float *__restrict__ img, float *__restrict__ sc,
                                          BwdAcc<G> &acc, float *__restrict__ y, float *__restrict__ ybar,
                                          const float *__restrict__ lbar, float lbar_const, long tile, int l31, int hi,
@@ -513,7 +517,16 @@ __device__ __forceinline__ void bwd_tile(const CouplingArgs &a, const float *__r
       const int p = b * 32 + nf_row(r, hi);
       const bool ok = (p < a.c) && valid;  // rows >= c: the loads returned 0, the stores are dropped
       const float yv = y1[b][r], gv = g1[b][r];
-      if (!PHASE_S) {
+      if (INVD && !PHASE_S) {
+        tile_store(yio, tile_soff(b, r, a.par_t), yv + d3[b][r]);  // v1 = w1 exp(s) + t
+        d3[b][r] = ok ? -gv : 0.f;                                  // T-bar = -v1bar
+      } else if (INVD) {
+        const float s = nf_tanh(d3[b][r]);
+        const float es = nf_exp(s);
+        tile_store(yio, tile_soff(b, r, a.par_t), yv * es);            // w1 exp(s)
+        tile_store(gio, tile_soff(b, r, a.par_t), nf_fdiv(gv, es));    // v1bar
+        d3[b][r] = ok ? -(gv * yv + lb) * (1.f - s * s) : 0.f;         // S-bar through tanh
+      } else if (!PHASE_S) {
         tile_store(yio, tile_soff(b, r, a.par_t), yv - d3[b][r]);  // u = x1 * exp(S)
         d3[b][r] = ok ? gv : 0.f;                                   // T-bar = ybar1
       } else {
@@ -564,7 +577,7 @@ __device__ __forceinline__ void bwd_tile(const CouplingArgs &a, const float *__r
 }
 
 // reverse pass of ONE coupling by this workgroup (both phases, fold, slab write)
-template <class G, bool FULL>
+template <class G, bool FULL, bool INVD = false>
 __device__ __forceinline__ void bwd_coupling(const CouplingArgs &a, float *__restrict__ y, float *__restrict__ ybar,
                                              const float *__restrict__ lbar, float lbar_const,
                                              float *__restrict__ slab, long slab_stride, float *lds) {
@@ -580,7 +593,8 @@ __device__ __forceinline__ void bwd_coupling(const CouplingArgs &a, float *__res
 #pragma unroll 1
   for (int phase = 0; phase < 2; ++phase) {
     long long *tr = tr0 ? tr0 + 8 + phase * 40 : nullptr;  // [8 + phase*40 + tileidx*12 + slot]
-    stage_packed<G::SIZE, 256>(img, phase == 0 ? a.img_t : a.img_s, tid);
+    const bool is_s = INVD ? phase == 0 : phase == 1;      // forward chain: T then S; inverse chain: S then T
+    stage_packed<G::SIZE, 256>(img, is_s ? a.img_s : a.img_t, tid);
     __syncthreads();
     if (tr0) tr0[1 + phase * 3] = clock64();
     BwdAcc<G> acc;
@@ -589,10 +603,10 @@ __device__ __forceinline__ void bwd_coupling(const CouplingArgs &a, float *__res
     zero_acc(acc.w3, acc.b3);
 #pragma unroll 1
     for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
-      if (phase == 0)
-        bwd_tile<G, false, FULL>(a, img, sc, acc, y, ybar, lbar, lbar_const, tile, l31, hi, tr);
+      if (!is_s)
+        bwd_tile<G, false, FULL, INVD>(a, img, sc, acc, y, ybar, lbar, lbar_const, tile, l31, hi, tr);
       else
-        bwd_tile<G, true, FULL>(a, img, sc, acc, y, ybar, lbar, lbar_const, tile, l31, hi, tr);
+        bwd_tile<G, true, FULL, INVD>(a, img, sc, acc, y, ybar, lbar, lbar_const, tile, l31, hi, tr);
       if (tr) tr += 12;
     }
     if (tr0) tr0[2 + phase * 3] = clock64();
@@ -609,7 +623,7 @@ __device__ __forceinline__ void bwd_coupling(const CouplingArgs &a, float *__res
     __syncthreads();
     {
       const float4 *c0 = reinterpret_cast<const float4 *>(lds);
-      float4 *dst = reinterpret_cast<float4 *>(slab + ((long)blockIdx.x * slab_stride + (phase == 0 ? 1 : 0) * (long)G::SIZE));
+      float4 *dst = reinterpret_cast<float4 *>(slab + ((long)blockIdx.x * slab_stride + (is_s ? 0 : 1) * (long)G::SIZE));
       constexpr int NV4 = G::SIZE / 4;
       for (int i = tid; i < NV4; i += 256) {
         const float4 p0 = c0[i], p1 = c0[i + NV4], p2 = c0[i + 2 * NV4], p3 = c0[i + 3 * NV4];
@@ -644,13 +658,14 @@ struct BwdAllArgs {
   int d, ncoup;
   long N;
 };
-template <class G, bool FULL>
+template <class G, bool FULL, bool INVD>
 __global__ __launch_bounds__(256, 1) void k_affine_bwd_all(BwdAllArgs aa, float *__restrict__ y, float *__restrict__ ybar,
                                                            const float *__restrict__ lbar, float lbar_const,
                                                            float *__restrict__ slab, long slab_stride) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
 #pragma unroll 1
-  for (int k = 0; k < aa.ncoup; ++k) {
+  for (int step = 0; step < aa.ncoup; ++step) {
+    const int k = INVD ? aa.ncoup - 1 - step : step;  // the inverse chain's reverse pass runs in execution order
     CouplingArgs a;
     a.theta = nullptr;
     a.img_s = aa.wimg + (size_t)(2 * k) * G::SIZE;
@@ -661,7 +676,7 @@ __global__ __launch_bounds__(256, 1) void k_affine_bwd_all(BwdAllArgs aa, float 
     a.c = (k & 1) ? aa.d / 2 : (aa.d + 1) / 2;
     a.m = aa.d - a.c;
     a.N = aa.N;
-    bwd_coupling<G, FULL>(a, y, ybar, lbar, lbar_const, slab + (long)k * 2 * G::SIZE, slab_stride, lds);
+    bwd_coupling<G, FULL, INVD>(a, y, ybar, lbar, lbar_const, slab + (long)k * 2 * G::SIZE, slab_stride, lds);
     // What coupling k + 1 loads are this same wave's stores of coupling k.  They are ordered by the
     // barrier at the end of bwd_coupling (s_waitcnt vmcnt(0): the stores have reached L2) and the vector
     // L1 is write-through, exactly as between the two phases inside one coupling -- no agent-scope fence:
@@ -892,25 +907,26 @@ int nf_affine_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const float *the
   return NF_ERR_UNSUPPORTED;
 }
 
-template <class G, bool FULL>
+template <class G, bool FULL, bool INVD = false>
 static int launch_bwd_all_v(nf_ctx *ctx, const BwdAllArgs &aa, float *y, float *ybar, const float *lbar, float lbar_const,
                             float *slab, long slab_stride, int grid) {
   const size_t lds = BwdLds<G>::BYTES;
   static bool attr_done = false;
   if (!attr_done) {
-    NF_HIP(hipFuncSetAttribute((const void *)k_affine_bwd_all<G, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NF_HIP(hipFuncSetAttribute((const void *)k_affine_bwd_all<G, FULL, INVD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
-  ProfScope ps(ctx, "affine_bwd");
-  hipLaunchKernelGGL((k_affine_bwd_all<G, FULL>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, aa, y, ybar, lbar,
+  ProfScope ps(ctx, INVD ? "affine_bwd_inv" : "affine_bwd");
+  hipLaunchKernelGGL((k_affine_bwd_all<G, FULL, INVD>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, aa, y, ybar, lbar,
                      lbar_const, slab, slab_stride);
   return (int)hipGetLastError();
 }
 
 // reverse pass of ALL couplings in one launch (flat order = reverse of execution order); packed images
 // must be current.  Slab layout as with nf_affine_bwd called for k = 0 .. ncoup-1.
+// inv_dir: reverse pass of the INVERSE chain instead (y: T^-1(data) -> data, couplings in execution order).
 int nf_affine_bwd_all(nf_ctx *ctx, const nf_flow_desc *desc, float *y, float *ybar, const float *lbar, float lbar_const,
-                      long N, float *slab, long slab_stride, int grid) {
+                      long N, float *slab, long slab_stride, int grid, bool inv_dir) {
   const int size = geo_size(desc);
   if (!size || !ctx->wimg || desc->n_hidden != 2) return NF_ERR_UNSUPPORTED;
   BwdAllArgs aa;
@@ -921,6 +937,12 @@ int nf_affine_bwd_all(nf_ctx *ctx, const nf_flow_desc *desc, float *y, float *yb
   aa.N = N;
   const bool h64 = size != NetGeo<1, 1, 1, 1>::SIZE;
   const bool full = desc->d == 64 && N % NF_TILE == 0;  // both partitions fill their 32-row block
+  if (inv_dir) {
+    if (h64)
+      return full ? launch_bwd_all_v<NetGeo<1, 2, 2, 1>, true, true>(ctx, aa, y, ybar, lbar, lbar_const, slab, slab_stride, grid)
+                  : launch_bwd_all_v<NetGeo<1, 2, 2, 1>, false, true>(ctx, aa, y, ybar, lbar, lbar_const, slab, slab_stride, grid);
+    return launch_bwd_all_v<NetGeo<1, 1, 1, 1>, false, true>(ctx, aa, y, ybar, lbar, lbar_const, slab, slab_stride, grid);
+  }
   if (h64)
     return full ? launch_bwd_all_v<NetGeo<1, 2, 2, 1>, true>(ctx, aa, y, ybar, lbar, lbar_const, slab, slab_stride, grid)
                 : launch_bwd_all_v<NetGeo<1, 2, 2, 1>, false>(ctx, aa, y, ybar, lbar, lbar_const, slab, slab_stride, grid);
