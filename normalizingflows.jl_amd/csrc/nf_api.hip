@@ -51,7 +51,7 @@ int nf_wide_pack(nf_ctx *, const nf_flow_desc *, const float *theta);
 int nf_wide_apply(nf_ctx *, const nf_flow_desc *, int k, bool inverse, float *xt, long N, float *ladj, int accumulate);
 size_t nf_wide_bwd_ws_floats(nf_ctx *, const nf_flow_desc *, long N);
 int nf_wide_bwd(nf_ctx *, const nf_flow_desc *, float *state, float *gbar, const float *lbar, float lbar_const, long N,
-                float *ws, float *g_out);
+                float *ws, float *g_out, bool inv_dir = false);
 size_t nf_wide_train_ws_floats(nf_ctx *, const nf_flow_desc *, long N);
 int nf_wide_train_forward(nf_ctx *, const nf_flow_desc *, float *xt, long N, float *ladj, float *ws);
 int nf_wide_train_backward(nf_ctx *, const nf_flow_desc *, float *state, float *gbar, const float *lbar,
@@ -63,7 +63,7 @@ int nf_rqs_pack(nf_ctx *, const nf_flow_desc *, const float *theta);
 int nf_rqs_chain(nf_ctx *, const nf_flow_desc *, bool inverse, float *xt, long N, float *ladj, int k_only);
 int nf_rqs_bwd_grid(nf_ctx *, long N);
 int nf_rqs_bwd(nf_ctx *, const nf_flow_desc *, int k, float *y, float *ybar, const float *lbar, float lbar_const, long N,
-               float *slab, long slab_stride, int grid);
+               float *slab, long slab_stride, int grid, bool inv_dir = false);
 long nf_rqs_slab_floats(const nf_flow_desc *desc);
 int nf_rqs_reduce_slabs(nf_ctx *, const nf_flow_desc *, const float *slab, int nslab, float *g);
 
@@ -425,16 +425,21 @@ static int realnvp_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta
 
 // reverse pass of the INVERSE coupling chain on tiled buffers (forward-KL training): `state` holds
 // T^-1(data) on entry and the data on exit, `gbar` the cotangent of z; couplings in forward execution order
-static inline bool coupling_inv_bwd_tiled(const nf_flow_desc *desc) {
-  return desc->kind == NF_KIND_REALNVP && nf_affine_supported(desc);
-}
+static inline bool coupling_inv_bwd_tiled(const nf_flow_desc *desc) { return is_coupling(desc); }
 static int coupling_inv_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta, float *state, float *gbar,
                             float lbar_const, long N, float *slab, int grid, float *g_out) {
   (void)theta;
+  if (is_wide(desc)) return nf_wide_bwd(ctx, desc, state, gbar, nullptr, lbar_const, N, slab, g_out, true);
   if (desc->kind == NF_KIND_REALNVP && nf_affine_supported(desc)) {
     const long stride = coupling_slab_floats(ctx, desc, N);
     NF_TRY(nf_affine_bwd_all(ctx, desc, state, gbar, nullptr, lbar_const, N, slab, stride, grid, true));
     return nf_affine_reduce_slabs(ctx, desc, slab, grid, g_out);
+  }
+  if (desc->kind == NF_KIND_NSF && nf_rqs_supported(desc)) {
+    const long stride = coupling_slab_floats(ctx, desc, N);
+    for (int k = 2 * desc->nlayers - 1; k >= 0; --k)  // forward execution order
+      NF_TRY(nf_rqs_bwd(ctx, desc, k, state, gbar, nullptr, lbar_const, N, slab, stride, grid, true));
+    return nf_rqs_reduce_slabs(ctx, desc, slab, grid, g_out);
   }
   return NF_ERR_UNSUPPORTED;
 }

@@ -288,8 +288,11 @@ __device__ __forceinline__ float rqs_inv_elem(const Knots<K> &kn, float y, float
   return b.inside ? xi * dx + b.xk : y;
 }
 
-// reverse pass of rqs_forward at (x in bin b, xi): ybar, lbar -> xbar and raw-parameter gradients
-template <int K>
+// reverse pass of rqs_forward at (x in bin b, xi): ybar, lbar -> xbar and raw-parameter gradients.
+// INVD: reverse pass of the INVERSE spline at its output x (same point), (ybar, lbar) = cotangents of
+// (x, ladj_inv = -log S'(x)); implicit-function form vbar = (ybar - lbar dlogS'/dx) / S', parameters =
+// the forward formulas with (-vbar, -lbar).  Returns vbar.
+template <int K, bool INVD = false>
 __device__ __forceinline__ float rqs_bwd_elem(const Knots<K> &kn, const float *raw, const Bin &b, float xi, float B,
                                               float ybar, float lbar, float *thbar) {
   const float dx = b.xk1 - b.xk, dy = b.yk1 - b.yk;
@@ -315,7 +318,13 @@ __device__ __forceinline__ float rqs_bwd_elem(const Knots<K> &kn, const float *r
   const float dL_dd1 = xi * xi * ind - 2.f * xi * om * iden;
   // every parameter cotangent is linear in (ybar, lbar): zeroing them outside the box (identity
   // branch) makes all of them vanish without per-parameter selects
-  const float yb = b.inside ? ybar : 0.f, lbr = b.inside ? lbar : 0.f;
+  float yb = b.inside ? ybar : 0.f, lbr = b.inside ? lbar : 0.f;
+  float vbar = 0.f;
+  if (INVD) {
+    vbar = b.inside ? nf_fdiv(yb - lbr * dL_dxi * idx, dy_dxi * idx) : 0.f;
+    yb = -vbar;
+    lbr = -lbr;
+  }
   const float xibar = yb * dy_dxi + lbr * dL_dxi;
   const float sbar = yb * dy_ds + lbr * dL_ds;
   const float d0bar = yb * dy_dd0 + lbr * dL_dd0;
@@ -343,7 +352,7 @@ __device__ __forceinline__ float rqs_bwd_elem(const Knots<K> &kn, const float *r
   const float g0 = d0bar * (1.f - __expf(-d0)), g1 = d1bar * (1.f - __expf(-d1));
 #pragma unroll
   for (int j = 1; j < K; ++j) thbar[2 * K + j - 1] = ((j == b.k) ? g0 : 0.f) + ((j == b.k + 1) ? g1 : 0.f);
-  return b.inside ? xibar * idx : ybar;
+  return b.inside ? (INVD ? vbar : xibar * idx) : ybar;
 }
 
 // pull the P raw parameters of local dim `ql` of a chunk out of its accumulator blocks
@@ -569,7 +578,9 @@ __device__ __forceinline__ void rqs_fold(float *__restrict__ w, float *__restric
   }
 }
 
-template <class G>
+// INVD: reverse pass of the INVERSE coupling at its output (forward-KL training): `y` holds w and is advanced
+// to coupling(w); `ybar` the cotangent of w -> that of the inverse's input; lbar the cotangent of ladj_inv.
+template <class G, bool INVD = false>
 __device__ __forceinline__ void rqs_bwd_tile(const RqsBwdArgs &a, const float *__restrict__ img, float *__restrict__ sc,
                                              RqsAcc<G> &acc, float *__restrict__ y, float *__restrict__ ybar,
                                              const float *__restrict__ lbar, float lbar_const, long tile, int l31,
@@ -659,8 +670,15 @@ __device__ __forceinline__ void rqs_bwd_tile(const RqsBwdArgs &a, const float *_
       // forward map at that point
       float dummy = 0.f, xi;
       Bin bn;
-      const float xv = rqs_inv_elem<G::K, false>(kn, yv, dummy, bn, xi);
-      const float xbar = rqs_bwd_elem<G::K>(kn, raw, bn, xi, a.B, gv, ok ? lb : 0.f, thb);  // gv, lb are 0 when !ok
+      float xv;
+      if (INVD) {  // the point is already the spline's input: locate it, and advance the state through the spline
+        bn = find_bin<G::K, false>(kn, kn.pX, yv);
+        xi = nf_fdiv(yv - bn.xk, bn.xk1 - bn.xk);
+        xv = rqs_fwd_elem<G::K, false>(kn, yv, dummy);
+      } else {
+        xv = rqs_inv_elem<G::K, false>(kn, yv, dummy, bn, xi);
+      }
+      const float xbar = rqs_bwd_elem<G::K, INVD>(kn, raw, bn, xi, a.B, gv, ok ? lb : 0.f, thb);  // gv, lb are 0 when !ok
       chunk_put<G>(out, ql, thb);
       tile_store(yio, tile_soff(q / 16, q % 16, a.par_t), xv);    // coupling input x1
       tile_store(gio, tile_soff(q / 16, q % 16, a.par_t), xbar);  // its cotangent
@@ -726,7 +744,7 @@ __device__ __forceinline__ void rqs_bwd_tile(const RqsBwdArgs &a, const float *_
 #undef RQS_STAMP
 }
 
-template <class G>
+template <class G, bool INVD>
 __global__ __launch_bounds__(256, 1) void k_rqs_bwd(RqsBwdArgs a, float *__restrict__ y, float *__restrict__ ybar,
                                                     const float *__restrict__ lbar, float lbar_const,
                                                     float *__restrict__ slab, long slab_stride) {
@@ -745,7 +763,7 @@ __global__ __launch_bounds__(256, 1) void k_rqs_bwd(RqsBwdArgs a, float *__restr
   rqs_zero(acc.w3, acc.b3);
 #pragma unroll 1
   for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4)
-    rqs_bwd_tile<G>(a, img, sc, acc, y, ybar, lbar, lbar_const, tile, l31, hi,
+    rqs_bwd_tile<G, INVD>(a, img, sc, acc, y, ybar, lbar, lbar_const, tile, l31, hi,
                     (a.trace && blockIdx.x == 0 && tid == 0 && tile == (long)wave) ? a.trace : nullptr);
   __syncthreads();  // the weight image is dead: it becomes the (deterministic, wave-ordered) fold target
 #pragma unroll 1
@@ -878,13 +896,13 @@ int nf_rqs_bwd_grid(nf_ctx *ctx, long N) {
   return (int)(grid < 1 ? 1 : grid);
 }
 
-template <class G>
+template <class G, bool INVD>
 static int launch_rqs_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, float *y, float *ybar, const float *lbar,
                           float lbar_const, long N, float *slab, long slab_stride, int grid) {
   const size_t lds = RqsLds<G>::BYTES;
   static bool attr_done = false;
   if (!attr_done) {
-    NF_HIP(hipFuncSetAttribute((const void *)k_rqs_bwd<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NF_HIP(hipFuncSetAttribute((const void *)k_rqs_bwd<G, INVD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
   const CouplingInfo ci = nf_coupling_info(desc, k);
@@ -892,16 +910,21 @@ static int launch_rqs_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, float *y
   a.img = (const float *)ctx->wimg + (size_t)k * G::SIZE;
   a.d = desc->d; a.c = ci.c; a.m = ci.m; a.par_t = ci.par_t; a.B = desc->B; a.N = N;
   a.trace = (long long *)ctx->trace;
-  ProfScope ps(ctx, "rqs_bwd");
-  hipLaunchKernelGGL((k_rqs_bwd<G>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, y, ybar, lbar, lbar_const,
+  ProfScope ps(ctx, INVD ? "rqs_bwd_inv" : "rqs_bwd");
+  hipLaunchKernelGGL((k_rqs_bwd<G, INVD>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, y, ybar, lbar, lbar_const,
                      slab + (long)k * G::SIZE, slab_stride);
   return (int)hipGetLastError();
 }
 
+// inv_dir: reverse pass of the INVERSE coupling k at its output (see rqs_bwd_tile)
 int nf_rqs_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, float *y, float *ybar, const float *lbar, float lbar_const,
-               long N, float *slab, long slab_stride, int grid) {
+               long N, float *slab, long slab_stride, int grid, bool inv_dir) {
   const int id = rqs_geo_id(desc);
   if (!id || !ctx->wimg) return NF_ERR_UNSUPPORTED;
-  if (id == 1) return launch_rqs_bwd<GeoK8>(ctx, desc, k, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid);
-  return launch_rqs_bwd<GeoK10>(ctx, desc, k, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid);
+  if (inv_dir) {
+    if (id == 1) return launch_rqs_bwd<GeoK8, true>(ctx, desc, k, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid);
+    return launch_rqs_bwd<GeoK10, true>(ctx, desc, k, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid);
+  }
+  if (id == 1) return launch_rqs_bwd<GeoK8, false>(ctx, desc, k, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid);
+  return launch_rqs_bwd<GeoK10, false>(ctx, desc, k, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid);
 }

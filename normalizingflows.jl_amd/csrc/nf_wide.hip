@@ -502,7 +502,9 @@ __device__ __forceinline__ void wide_dx_chain(wide_img_t img, float *cb, int &bu
   }
 }
 
-template <class G, bool PHASE_S>
+// INVD: reverse pass of the INVERSE coupling at its output (forward-KL training), as in nf_coupling.hip:
+// the s net runs first (v1bar = w1bar exp(-s), sbar = -(w1bar w1 + lbar)), then the t net (tbar = -v1bar).
+template <class G, bool PHASE_S, bool INVD = false>
 __global__ __launch_bounds__(256, 1) void k_wide_bwd(WideArgs a, float *__restrict__ y, float *__restrict__ ybar,
                                                      const float *__restrict__ lbar, float lbar_const, WideStash st) {
   using W = Wide<G>;
@@ -591,7 +593,18 @@ __global__ __launch_bounds__(256, 1) void k_wide_bwd(WideArgs a, float *__restri
         const int p = b * 32 + nf_row(r, hi);
         const bool ok = (p < a.c) && valid;
         const float yv = y1[b][r], gv = g1[b][r];
-        if (!PHASE_S) {
+        if (INVD && !PHASE_S) {
+          if (live) tile_store(yio, tile_soff(b, r, a.par_t), yv + d3[b][r]);  // v1 = w1 exp(s) + t
+          d3[b][r] = ok ? -gv : 0.f;
+        } else if (INVD) {
+          const float s = nf_tanh(d3[b][r]);
+          const float es = nf_exp(s);
+          if (live) {
+            tile_store(yio, tile_soff(b, r, a.par_t), yv * es);           // w1 exp(s)
+            tile_store(gio, tile_soff(b, r, a.par_t), nf_fdiv(gv, es));   // v1bar
+          }
+          d3[b][r] = ok ? -(gv * yv + lb) * (1.f - s * s) : 0.f;
+        } else if (!PHASE_S) {
           if (live) tile_store(yio, tile_soff(b, r, a.par_t), yv - d3[b][r]);  // u = x1 * exp(S)
           d3[b][r] = ok ? gv : 0.f;
         } else {
@@ -1004,8 +1017,9 @@ static size_t wide_bwd_ws_floats(nf_ctx *ctx, const nf_flow_desc *desc, long N) 
 }
 
 // reverse pass over the whole chain; state/gbar as in realnvp_bwd (nf_api.hip)
+// inv_dir: reverse pass of the INVERSE chain (state: T^-1(data) -> data; couplings in execution order, s net first)
 static int wide_bwd(nf_ctx *ctx, const nf_flow_desc *desc, float *state, float *gbar, const float *lbar, float lbar_const,
-                long N, float *ws, float *g_out) {
+                long N, float *ws, float *g_out, bool inv_dir) {
   if (!ctx->wimg) return NF_ERR_UNSUPPORTED;
   const long ntiles = (N + NF_TILE - 1) / NF_TILE;
   const size_t per = (size_t)ntiles * NF_TILE * 32;
@@ -1026,6 +1040,8 @@ static int wide_bwd(nf_ctx *ctx, const nf_flow_desc *desc, float *state, float *
   if (!attr_done) {
     NF_HIP(hipFuncSetAttribute((const void *)k_wide_bwd<G, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bwd));
     NF_HIP(hipFuncSetAttribute((const void *)k_wide_bwd<G, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bwd));
+    NF_HIP(hipFuncSetAttribute((const void *)k_wide_bwd<G, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bwd));
+    NF_HIP(hipFuncSetAttribute((const void *)k_wide_bwd<G, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bwd));
     NF_HIP(hipFuncSetAttribute((const void *)k_wide_dw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dw));
     attr_done = true;
   }
@@ -1034,13 +1050,19 @@ static int wide_bwd(nf_ctx *ctx, const nf_flow_desc *desc, float *state, float *
   if (grid < 1) grid = 1;
   const int nc = 2 * desc->nlayers;
   const int h1 = desc->hdims[0], h2 = desc->hdims[1];
-  for (int k = 0; k < nc; ++k) {  // flat order = reverse of execution order
+  for (int step = 0; step < nc; ++step) {
+    const int k = inv_dir ? nc - 1 - step : step;  // forward chain: flat order = reverse of execution order
     const WideArgs a = make_wide_args(ctx, desc, k, N);
     const CouplingInfo ci = nf_coupling_info(desc, k);
-    for (int phase = 0; phase < 2; ++phase) {  // 0: t net, 1: s net
+    for (int phase = 0; phase < 2; ++phase) {  // forward chain: t net, then s net; inverse chain: s, then t
+      const bool is_s = inv_dir ? phase == 0 : phase == 1;
       {
         ProfScope ps(ctx, "wide_bwd");
-        if (phase == 0)
+        if (inv_dir && is_s)
+          hipLaunchKernelGGL((k_wide_bwd<G, true, true>), dim3((unsigned)grid), dim3(256), lds_bwd, ctx->stream, a, state, gbar, lbar, lbar_const, st);
+        else if (inv_dir)
+          hipLaunchKernelGGL((k_wide_bwd<G, false, true>), dim3((unsigned)grid), dim3(256), lds_bwd, ctx->stream, a, state, gbar, lbar, lbar_const, st);
+        else if (!is_s)
           hipLaunchKernelGGL((k_wide_bwd<G, false>), dim3((unsigned)grid), dim3(256), lds_bwd, ctx->stream, a, state, gbar, lbar, lbar_const, st);
         else
           hipLaunchKernelGGL((k_wide_bwd<G, true>), dim3((unsigned)grid), dim3(256), lds_bwd, ctx->stream, a, state, gbar, lbar, lbar_const, st);
@@ -1057,7 +1079,7 @@ static int wide_bwd(nf_ctx *ctx, const nf_flow_desc *desc, float *state, float *
         NF_HIP(hipGetLastError());
       }
       long off = ci.theta_off;
-      if (phase == 0) off += net_param_count(ci.m, h1, h2, ci.c);  // t net follows the s net in theta
+      if (!is_s) off += net_param_count(ci.m, h1, h2, ci.c);  // t net follows the s net in theta
       const NetDims nd = make_net_dims(off, ci.m, h1, h2, ci.c);
       {
         ProfScope ps(ctx, "reduce_slabs");
@@ -1205,7 +1227,7 @@ static bool wide_fits_mid(const nf_flow_desc *desc) {
 int nf_wide_pack(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta) { return WIDE_DISPATCH(wide_pack(ctx, desc, theta)); }
 int nf_wide_apply(nf_ctx *ctx, const nf_flow_desc *desc, int k, bool inverse, float *xt, long N, float *ladj, int accumulate) { return WIDE_DISPATCH(wide_apply(ctx, desc, k, inverse, xt, N, ladj, accumulate)); }
 size_t nf_wide_bwd_ws_floats(nf_ctx *ctx, const nf_flow_desc *desc, long N) { return WIDE_DISPATCH(wide_bwd_ws_floats(ctx, desc, N)); }
-int nf_wide_bwd(nf_ctx *ctx, const nf_flow_desc *desc, float *state, float *gbar, const float *lbar, float lbar_const, long N, float *ws, float *g_out) { return WIDE_DISPATCH(wide_bwd(ctx, desc, state, gbar, lbar, lbar_const, N, ws, g_out)); }
+int nf_wide_bwd(nf_ctx *ctx, const nf_flow_desc *desc, float *state, float *gbar, const float *lbar, float lbar_const, long N, float *ws, float *g_out, bool inv_dir) { return WIDE_DISPATCH(wide_bwd(ctx, desc, state, gbar, lbar, lbar_const, N, ws, g_out, inv_dir)); }
 size_t nf_wide_train_ws_floats(nf_ctx *ctx, const nf_flow_desc *desc, long N) { return WIDE_DISPATCH(wide_train_ws_floats(ctx, desc, N)); }
 int nf_wide_train_forward(nf_ctx *ctx, const nf_flow_desc *desc, float *xt, long N, float *ladj, float *ws) { return WIDE_DISPATCH(wide_train_forward(ctx, desc, xt, N, ladj, ws)); }
 int nf_wide_train_backward(nf_ctx *ctx, const nf_flow_desc *desc, float *state, float *gbar, const float *lbar, float lbar_const, long N, float *ws, float *g_out) { return WIDE_DISPATCH(wide_train_backward(ctx, desc, state, gbar, lbar, lbar_const, N, ws, g_out)); }

@@ -610,7 +610,8 @@ def test_hamiltonian_flow_demo_trains(nf):
 FKL_CASES = [
     ("planar", 5, (), 10, 0), ("radial", 5, (), 10, 0), ("planar", 40, (), 3, 0), ("meanfield", 4, (), 1, 0),
     ("realnvp", 5, (32, 32), 2, 0), ("realnvp", 8, (16,), 1, 0), ("realnvp", 64, (64, 64), 2, 0),
-    ("realnvp", 20, (40, 24), 1, 0), ("nsf", 5, (32, 32), 2, 10), ("nsf", 32, (64, 64), 1, 8), ("nsf", 6, (24, 16, 8), 1, 8),
+    ("realnvp", 20, (40, 24), 1, 0), ("realnvp", 256, (256, 256), 1, 0), ("realnvp", 129, (40, 256), 1, 0),
+    ("realnvp", 100, (96, 130), 1, 0), ("nsf", 5, (32, 32), 2, 10), ("nsf", 32, (64, 64), 1, 8), ("nsf", 6, (24, 16, 8), 1, 8),
 ]
 
 
@@ -623,6 +624,8 @@ def test_forward_kl_value_and_gradient_matches_oracle(nf, kind, d, hd, nl, K, dt
     Jacobian solves (oracle/nf_oracle.py:_layer_inv_bwd), itself pinned by finite differences."""
     dt = tdt(dtn)
     f64 = dt == torch.float64
+    if f64 and (d > 128 or max(hd, default=0) > 128):
+        pytest.skip("Float64 couplings are built for d <= 128, hidden <= 128 (general kernels)")
     spec = o.FlowSpec(kind, d, nl, hd, K, 5.0) if kind == "nsf" else o.FlowSpec(kind, d, nl, hd)
     rng = np.random.default_rng(1000 + d)
     th = o.init_params(spec, rng)
@@ -631,7 +634,7 @@ def test_forward_kl_value_and_gradient_matches_oracle(nf, kind, d, hd, nl, K, dt
     if not f64:
         th = th.astype(np.float32).astype(np.float64)
     flow = nf.Flow(kind, nf.MvNormal(d), nl, hd, K, 5.0, dtype=dt, device="cuda", theta=torch.tensor(th, dtype=dt, device="cuda"))
-    n = 61
+    n = 61 if d <= 64 else 37  # the oracle assembles a dense Jacobian per sample and layer
     ys = rng.standard_normal((d, n)) * 1.2
     if not f64:
         ys = ys.astype(np.float32).astype(np.float64)
