@@ -68,3 +68,27 @@ def make_gpu_local_step(flow, target, seed: int):
         return out
 
     return local_step
+
+
+def make_gpu_forward_kl_local_step(flow, xs):
+    """local_step for forward-KL training (`train_flow(loglikelihood, flow, xs)`) on a data set sharded by
+    column: rank r evaluates columns [offset, offset + count) of `xs` (d x N_global, on this rank's device)
+    with nf_loglikelihood_value_and_grad; the same single all-reduce of [grad ; loss] follows."""
+    import ctypes as C
+
+    import torch
+
+    from ._lib import check
+    from .flows import _ptr, as_batch
+
+    out = torch.empty(flow.P + 1, dtype=flow.theta.dtype, device=flow.theta.device)
+    xm, _ = as_batch(xs.to(flow.theta.dtype))
+
+    def local_step(theta, offset, count, n_global, step):
+        ctx = flow.ctx
+        shard = xm[:, offset:offset + count]  # columns are contiguous in the column-major batch
+        check(ctx.lib.nf_loglikelihood_value_and_grad(ctx.ptr, C.byref(flow.desc), _ptr(theta), _ptr(shard), count,
+                                                      n_global, _ptr(out)))
+        return out
+
+    return local_step

@@ -668,3 +668,20 @@ def test_forward_kl_training_fits_a_shifted_gaussian(nf):
     th = trained.theta.cpu().numpy()
     np.testing.assert_allclose(th[:d], xs.mean(dim=1).cpu().numpy(), atol=2e-2)
     np.testing.assert_allclose(np.abs(th[d:]), xs.std(dim=1).cpu().numpy(), rtol=2e-2)
+
+
+def test_forward_kl_sharded_local_step_sums_to_the_full_gradient(nf):
+    """The data-parallel forward-KL step (parallel.make_gpu_forward_kl_local_step): the [grad ; loss] buffers of
+    the column shards of a data set add up to the single-rank result -- what the one all-reduce delivers."""
+    flow = nf.realnvp(nf.MvNormal(64), [64, 64], 2, paramtype=torch.float32, seed=4)
+    torch.manual_seed(1)
+    n = 1000
+    xs = torch.randn(64, n, device="cuda")
+    full_loss, full_g = nf.loglikelihood_value_and_gradient(flow, xs)
+    step = nf.make_gpu_forward_kl_local_step(flow, xs)
+    acc = torch.zeros(flow.P + 1, device="cuda")
+    for r in range(3):
+        off, cnt = nf.shard_range(n, r, 3)
+        acc += step(flow.theta, off, cnt, n, 0)
+    assert float(acc[-1]) == pytest.approx(full_loss, rel=1e-5)
+    assert float((acc[:-1] - full_g).abs().max()) <= 1e-4 * max(1.0, float(full_g.abs().max()))

@@ -95,3 +95,38 @@ def test_two_rank_gloo_matches_single_rank():
         np.testing.assert_allclose(res[r][0], ref_losses, rtol=1e-12)
         np.testing.assert_allclose(res[r][1], theta, rtol=1e-10, atol=1e-12)
     np.testing.assert_array_equal(res[0][1], res[1][1])  # replicas bit-identical
+
+
+# ---- forward KL: the data set (not the base draws) is what is sharded ---------------------------------
+def _fkl_data():
+    return 0.9 * np.random.default_rng(3).standard_normal((SPEC.d, N_GLOBAL))
+
+
+def _oracle_fkl_local_step(theta, offset, count, n_global, step):
+    ys = _fkl_data()[:, offset:offset + count]
+    loss, grad = o.neg_loglik_value_and_grad(SPEC, theta.numpy(), ys, n_global=n_global)
+    return torch.tensor(np.concatenate([grad, [loss]]))
+
+
+def _fkl_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nf = load_package()
+    obj = nf.ShardedObjective(_oracle_fkl_local_step, N_GLOBAL, rank, world)
+    loss, g = obj(torch.tensor(_theta0()))
+    ret[rank] = (loss, g.numpy().copy())
+    dist.destroy_process_group()
+
+
+def test_two_rank_forward_kl_matches_single_rank():
+    """train_flow(loglikelihood, ...) data-parallel: column shards of the data set, one all-reduce of
+    [grad ; loss] (same contract as nf_loglikelihood_value_and_grad with N_global)."""
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_fkl_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+        res = dict(ret)
+    lref, gref = o.neg_loglik_value_and_grad(SPEC, _theta0(), _fkl_data())
+    for r in range(world):
+        assert res[r][0] == pytest.approx(lref, rel=1e-12)
+        np.testing.assert_allclose(res[r][1], gref, rtol=1e-10, atol=1e-13)

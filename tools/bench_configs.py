@@ -7,6 +7,7 @@ cfg2b RealNVP d=64, 8 couplings, h=32 (reference default widths)       (ELBO ste
 cfg3  NSF d=32, 8 RQ-spline couplings, K=8, B=5, h=32, batch 131072    (ELBO step)
 cfg4  RealNVP d=256, 16 couplings, h=256, batch 32768 = one GPU's shard of 262144/8  (ELBO step)
 cfg5  RealNVP d=64 inverse + logdet + log q0 on 1 M samples           (loglikelihood)
+cfg5t the same data set, one forward-KL TRAINING step (value + gradient of -loglikelihood, Adam)
 """
 import argparse
 import ctypes as C
@@ -105,6 +106,36 @@ def main():
     torch.cuda.synchronize()
     el = (time.perf_counter() - t0) / 10
     res["cfg5_loglik_realnvp_d64_n1M"] = {"ms_per_call": 1e3 * el, "samples_per_s": n / el, "loglik": ll}
+    # forward-KL training step on the same data set: train_flow(loglikelihood, flow, ys)
+    ctx = nf.context_for(dev)
+    theta = flow.theta.clone()
+    m, v = torch.zeros_like(theta), torch.zeros_like(theta)
+    out = torch.zeros(flow.P + 1, dtype=theta.dtype, device=dev)
+
+    def fkl_step(i):
+        nf._lib.check(lib.nf_loglikelihood_value_and_grad(ctx.ptr, C.byref(flow.desc), vp(theta), vp(ys), n, n, vp(out)))
+        nf._lib.check(lib.nf_adam_update(ctx.ptr, 0, vp(theta), vp(out), vp(m), vp(v), flow.P, 1e-3, 0.9, 0.999, 1e-8, i + 1, None))
+
+    for i in range(3):
+        fkl_step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(3, 13):
+        fkl_step(i)
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / 10
+    lib.nf_prof_enable(ctx.ptr, 2)
+    fkl_step(13)
+    torch.cuda.synchronize()
+    kern = {}
+    for name in (b"layout_convert", b"affine_chain", b"target", b"affine_bwd_inv", b"reduce_slabs", b"adam"):
+        a, c = C.c_double(0.0), C.c_int64(0)
+        lib.nf_prof_read(ctx.ptr, name, C.byref(a), C.byref(c))
+        if c.value:
+            kern[name.decode()] = [round(1e3 * a.value, 1), c.value]
+    lib.nf_prof_enable(ctx.ptr, 0)
+    res["cfg5t_forward_kl_step_realnvp_d64_n1M"] = {"ms_per_step": 1e3 * el, "samples_per_s": n / el, "loss": float(out[flow.P]),
+                                                    "kernels_us": kern}
     for k, v in res.items():
         print(k, json.dumps(v))
 
