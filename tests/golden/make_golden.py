@@ -4,7 +4,9 @@
 The reference itself (Julia) cannot run in the build container and ships no golden vectors
 (SURVEY.md 8c), so these vectors pin the HIP path to the oracle, and the oracle is pinned by
 tests/test_oracle.py.  Each fixture holds: flow spec, theta, base draws xs, ys, ladj, per-sample
-elbos, loss = -elbo_batch, grad, and theta after one Adam(1e-3) step.
+elbos, loss = -elbo_batch, grad, theta after one Adam(1e-3) step, and the forward-KL training pair
+(fkl_loss, fkl_grad) = value and gradient of -loglikelihood(flow, fkl_xs) on the data fkl_xs = ys rounded to
+the storage dtype.
 """
 import os
 import sys
@@ -73,12 +75,15 @@ def main():
         th1 = theta.copy()
         o.adam_update(th1, grad, np.zeros_like(theta), np.zeros_like(theta), 1)
         ll = o.loglikelihood(spec, theta, ys)
+        fkl_xs = ys.astype(dt).astype(np.float64)
+        fkl_loss, fkl_grad = o.neg_loglik_value_and_grad(spec, theta, fkl_xs)
         np.savez_compressed(
             os.path.join(HERE, name + ".npz"),
             kind=spec.kind, d=spec.d, nlayers=spec.nlayers, hdims=np.array(spec.hdims, dtype=np.int64), K=spec.K,
             B=spec.B, dtype=np.dtype(dt).name, target=tkind, target_params=tp,
             theta=theta.astype(dt), xs=xs.astype(dt), ys=ys, ladj=ladj, ladj_inv=ladj_inv, elbos=elbos, loss=loss,
             grad=grad.astype(dt), theta_adam1=th1.astype(dt), loglik_of_ys=ll,
+            fkl_xs=fkl_xs.astype(dt), fkl_loss=fkl_loss, fkl_grad=fkl_grad.astype(dt),
         )
         print(f"{name}: P={theta.size} N={n} loss={loss:.6f} |g|inf={np.abs(grad).max():.3e} inv_err={np.abs(xr-xs).max():.1e}")
 

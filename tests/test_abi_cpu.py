@@ -82,6 +82,10 @@ def test_golden_fixtures_are_oracle_outputs():
         ys, ladj = o.flow_fwd(spec, th, xs)
         np.testing.assert_allclose(ys, z["ys"], rtol=1e-12, atol=1e-12)
         np.testing.assert_allclose(ladj, z["ladj"], rtol=1e-12, atol=1e-12)
+        if spec.d <= 9:  # the forward-KL pair (dense per-sample Jacobian solves: small cases only here)
+            fl, fg = o.neg_loglik_value_and_grad(spec, th, z["fkl_xs"].astype(np.float64))
+            assert fl == pytest.approx(float(z["fkl_loss"]), rel=1e-12)
+            np.testing.assert_allclose(fg, z["fkl_grad"], rtol=2e-6, atol=1e-7)  # stored in the storage dtype
 
 
 def test_product_does_not_import_oracle():

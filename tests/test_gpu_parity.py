@@ -102,6 +102,11 @@ def test_golden_forward_inverse_elbo_grad_adam(nf, path):
     gn = nf.adam_update(nf.Adam(1e-3), st, theta, g)
     assert float(gn) == pytest.approx(np.linalg.norm(gref), rel=1e-4)
     np.testing.assert_allclose(theta.cpu().numpy(), z["theta_adam1"], rtol=0, atol=(1e-12 if f64 else 2e-6))
+    # forward-KL training pair on the committed data: value and gradient of -loglikelihood
+    fl, fg = nf.loglikelihood_value_and_gradient(flow, cm(z["fkl_xs"], dt))
+    assert fl == pytest.approx(float(z["fkl_loss"]), rel=10 * rt)
+    fref = z["fkl_grad"].astype(np.float64)
+    assert np.abs(fg.cpu().numpy() - fref).max() <= (1e-9 if f64 else 2e-4) * max(1.0, np.abs(fref).max())
 
 
 @pytest.mark.parametrize("n", [1, 31, 32, 33, 257])
