@@ -56,7 +56,9 @@ __host__ __device__ inline long layer_off(int flow_kind, int d, int l) {
 }
 
 // per-layer cache in LDS, stride LP = 2d + 2:
-//   planar: w[d] | uhat[d] | b | c          (get_u_hat: test/ext/CUDA/cuda.jl:12-18)
+//   planar: w[d] | uhat[d] | b | 1 + c      (get_u_hat: test/ext/CUDA/cuda.jl:12-18; c = w'uhat = softplus(w'u) - 1.
+//           1 + c = softplus(w'u) is kept instead of c: the Jacobian factor 1 + c sech^2 = (1+c) sech^2 + tanh^2 is
+//           then a sum of non-negative terms -- no cancellation as c -> -1, where 1 + c (1 - t^2) loses every digit)
 //   radial: z0[d] | alpha | beta_hat
 //   shift : a[d]
 //   scale : a[d] | sum(log|a|)
@@ -79,7 +81,7 @@ __device__ void build_layer_cache(T *cache, const SimpleArgs &a, const T *__rest
         c[d + i] = p[d + i] + scale * p[i];
       }
       c[2 * d] = p[2 * d];
-      c[2 * d + 1] = softplus_(wu) - (T)1;
+      c[2 * d + 1] = softplus_(wu);
     } else if (lk == LK_RADIAL) {
       const T alpha = softplus_(p[0]);
       for (int i = 0; i < d; ++i) c[i] = p[2 + i];
@@ -111,7 +113,7 @@ __device__ __forceinline__ T layer_forward(int lk, const T *c, int d, int q, T (
       const int i = q + LPS * k;
       if (i < d) z[k] += c[d + i] * t;
     }
-    return log1p(c[2 * d + 1] * ((T)1 - t * t));
+    return log(c[2 * d + 1] * ((T)1 - t * t) + t * t);
   }
   if (lk == LK_RADIAL) {
     const T alpha = c[d], bh = c[d + 1];
@@ -159,7 +161,7 @@ __device__ __forceinline__ T layer_inverse(int lk, const T *c, int d, int q, T (
       const int i = q + LPS * k;
       if (i < d) dot += c[i] * z[k];
     }
-    const T wy = g16sum(dot), b = c[2 * d], cc = c[2 * d + 1];
+    const T wy = g16sum(dot), b = c[2 * d], sp = c[2 * d + 1], cc = sp - (T)1;
     T lo = wy - fabs(cc), hi = wy + fabs(cc);
     const int iters = sizeof(T) == 8 ? 64 : 40;
     for (int it = 0; it < iters; ++it) {
@@ -171,7 +173,7 @@ __device__ __forceinline__ T layer_inverse(int lk, const T *c, int d, int q, T (
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {  // Newton polish
       const T t = tanh(al + b);
-      al -= (al + cc * t - wy) / ((T)1 + cc * ((T)1 - t * t));
+      al -= (al + cc * t - wy) / (sp * ((T)1 - t * t) + t * t);
     }
     const T t = tanh(al + b);
 #pragma unroll
@@ -179,7 +181,7 @@ __device__ __forceinline__ T layer_inverse(int lk, const T *c, int d, int q, T (
       const int i = q + LPS * k;
       if (i < d) z[k] -= c[d + i] * t;
     }
-    return -log1p(cc * ((T)1 - t * t));
+    return -log(sp * ((T)1 - t * t) + t * t);
   }
   if (lk == LK_RADIAL) {
     const T alpha = c[d], bh = c[d + 1];
@@ -337,10 +339,10 @@ __global__ __launch_bounds__(SB) void k_simple_bwd_layers(SimpleArgs a, int nl, 
             ug += c[d + i] * g[k];
           }
         }
-        const T cc = c[2 * d + 1];
+        const T sp = c[2 * d + 1], cc = sp - (T)1;
         const T t = tanh(g16sum(dot) + c[2 * d]);
         ug = g16sum(ug);
-        const T gg = (T)1 - t * t, D = (T)1 + cc * gg;
+        const T gg = (T)1 - t * t, D = sp * gg + t * t;
         if (INV) {
           // J^T = I + gg w uhat^T, grad_z ladj = kap w, uhat^T w = cc:  vbar = g - w beta
           const T kap = -(T)2 * cc * t * gg / D;
