@@ -147,8 +147,16 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # NF_BENCH_ONE_DEVICE=1 (logic check of the multi-rank path on a 1-GPU box): every rank on cuda:0, gloo
+        # collectives -- RCCL refuses two ranks on one device.  Never set by the driver; numbers are meaningless.
+        one_device = os.environ.get("NF_BENCH_ONE_DEVICE") == "1"
+        if one_device:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
         local_rank = 0
