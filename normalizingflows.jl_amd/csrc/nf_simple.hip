@@ -9,6 +9,10 @@
 // features q, q+16, ...; the d-length dot products / norms are 4-step shuffle reductions
 // inside the 16-lane group.  The forward/inverse kernel is chain-fused: the state stays
 // in registers across all layers, the batch is read once and written once.
+#include <cstdint>
+#include <initializer_list>
+#include <vector>
+
 #include "nf_common.h"
 
 #define LPS 16
@@ -41,6 +45,7 @@ struct SimpleArgs {
   int nl;       // number of flat layers of the flow
   int lo, hi;   // flat layer range to apply
   int inverse;
+  int vec;      // rows may be accessed with 16-byte (8-byte for two-element chunks) vector loads / stores
   long N;
 };
 
@@ -54,8 +59,64 @@ __host__ __device__ inline long layer_off(int flow_kind, int d, int l) {
   if (flow_kind == NF_KIND_RADIAL) return (long)l * (d + 2);
   return (long)l * d;
 }
+// stride of one layer's cache / gradient slab: 2d + 2 entries, rounded to 16-byte rows
+__host__ __device__ inline int lp_of(int d) { return (2 * d + 2 + 3) & ~3; }
 
-// per-layer cache in LDS, stride LP = 2d + 2:
+// ---- row access ---------------------------------------------------------------------------------
+// Lane q of a sample's 16-lane group owns the CONTIGUOUS features [q DPL, (q+1) DPL): one dwordx4 (dwordx2)
+// per lane and row instead of DPL strided dwords -- a wave instruction then moves 1 KB of four consecutive
+// rows.  Vector access needs d % VW == 0 (every vector wholly inside or outside the row, 16-byte alignment
+// of every row); otherwise the element-wise path is taken.  Works on global and LDS pointers alike.
+template <class T, int DPL>
+struct RowVec {
+  static constexpr int VW = (DPL * (int)sizeof(T) >= 16) ? 16 / (int)sizeof(T) : DPL;
+};
+template <class T, int DPL>
+__device__ __forceinline__ void row_load(const T *row, int i0, int d, bool vec, T (&z)[DPL]) {
+  constexpr int VW = RowVec<T, DPL>::VW;
+  if constexpr (VW > 1) {
+    if (vec) {
+      typedef T V __attribute__((ext_vector_type(VW)));
+#pragma unroll
+      for (int k = 0; k < DPL; k += VW) {
+        if (i0 + k < d) {
+          const V v = *reinterpret_cast<const V *>(row + i0 + k);
+#pragma unroll
+          for (int u = 0; u < VW; ++u) z[k + u] = v[u];
+        } else {
+#pragma unroll
+          for (int u = 0; u < VW; ++u) z[k + u] = (T)0;
+        }
+      }
+      return;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < DPL; ++k) z[k] = (i0 + k < d) ? row[i0 + k] : (T)0;
+}
+template <class T, int DPL>
+__device__ __forceinline__ void row_store(T *row, int i0, int d, bool vec, const T (&z)[DPL]) {
+  constexpr int VW = RowVec<T, DPL>::VW;
+  if constexpr (VW > 1) {
+    if (vec) {
+      typedef T V __attribute__((ext_vector_type(VW)));
+#pragma unroll
+      for (int k = 0; k < DPL; k += VW)
+        if (i0 + k < d) {
+          V v;
+#pragma unroll
+          for (int u = 0; u < VW; ++u) v[u] = z[k + u];
+          *reinterpret_cast<V *>(row + i0 + k) = v;
+        }
+      return;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < DPL; ++k)
+    if (i0 + k < d) row[i0 + k] = z[k];
+}
+
+// per-layer cache in LDS, stride LP = lp_of(d):
 //   planar: w[d] | uhat[d] | b | 1 + c      (get_u_hat: test/ext/CUDA/cuda.jl:12-18; c = w'uhat = softplus(w'u) - 1.
 //           1 + c = softplus(w'u) is kept instead of c: the Jacobian factor 1 + c sech^2 = (1+c) sech^2 + tanh^2 is
 //           then a sum of non-negative terms -- no cancellation as c -> -1, where 1 + c (1 - t^2) loses every digit)
@@ -64,7 +125,7 @@ __host__ __device__ inline long layer_off(int flow_kind, int d, int l) {
 //   scale : a[d] | sum(log|a|)
 template <class T>
 __device__ void build_layer_cache(T *cache, const SimpleArgs &a, const T *__restrict__ theta) {
-  const int d = a.d, LP = 2 * d + 2;
+  const int d = a.d, LP = lp_of(d);
   for (int l = a.lo + (int)threadIdx.x; l < a.hi; l += blockDim.x) {
     T *c = cache + (long)(l - a.lo) * LP;
     const T *p = theta + layer_off(a.kind, d, l);
@@ -99,20 +160,18 @@ __device__ void build_layer_cache(T *cache, const SimpleArgs &a, const T *__rest
 }
 
 template <class T, int DPL>
-__device__ __forceinline__ T layer_forward(int lk, const T *c, int d, int q, T (&z)[DPL]) {
+__device__ __forceinline__ T layer_forward(int lk, const T *c, int d, int i0, bool vec, T (&z)[DPL]) {
+  T p0[DPL];
+  row_load<T, DPL>(c, i0, d, vec, p0);  // planar: w, radial: z0, shift / scale: a   (0 beyond d)
   if (lk == LK_PLANAR) {
     T dot = 0;
 #pragma unroll
-    for (int k = 0; k < DPL; ++k) {
-      const int i = q + LPS * k;
-      if (i < d) dot += c[i] * z[k];
-    }
+    for (int k = 0; k < DPL; ++k) dot += p0[k] * z[k];
     const T t = tanh(g16sum(dot) + c[2 * d]);
+    T uh[DPL];
+    row_load<T, DPL>(c + d, i0, d, vec, uh);
 #pragma unroll
-    for (int k = 0; k < DPL; ++k) {
-      const int i = q + LPS * k;
-      if (i < d) z[k] += c[d + i] * t;
-    }
+    for (int k = 0; k < DPL; ++k) z[k] += uh[k] * t;
     return log(c[2 * d + 1] * ((T)1 - t * t) + t * t);
   }
   if (lk == LK_RADIAL) {
@@ -120,47 +179,35 @@ __device__ __forceinline__ T layer_forward(int lk, const T *c, int d, int q, T (
     T ss = 0;
 #pragma unroll
     for (int k = 0; k < DPL; ++k) {
-      const int i = q + LPS * k;
-      if (i < d) {
-        const T dl = z[k] - c[i];
-        ss += dl * dl;
-      }
+      const T dl = (i0 + k < d) ? z[k] - p0[k] : (T)0;
+      ss += dl * dl;
     }
     const T r = sqrt(g16sum(ss));
     const T h = (T)1 / (alpha + r);
 #pragma unroll
-    for (int k = 0; k < DPL; ++k) {
-      const int i = q + LPS * k;
-      if (i < d) z[k] += bh * h * (z[k] - c[i]);
-    }
+    for (int k = 0; k < DPL; ++k)
+      if (i0 + k < d) z[k] += bh * h * (z[k] - p0[k]);
     return (T)(d - 1) * log1p(bh * h) + log1p(bh * h - bh * h * h * r);
   }
   if (lk == LK_SHIFT) {
 #pragma unroll
-    for (int k = 0; k < DPL; ++k) {
-      const int i = q + LPS * k;
-      if (i < d) z[k] += c[i];
-    }
+    for (int k = 0; k < DPL; ++k) z[k] += p0[k];
     return (T)0;
   }
 #pragma unroll
-  for (int k = 0; k < DPL; ++k) {
-    const int i = q + LPS * k;
-    if (i < d) z[k] *= c[i];
-  }
+  for (int k = 0; k < DPL; ++k) z[k] *= p0[k];
   return c[d];
 }
 
 template <class T, int DPL>
-__device__ __forceinline__ T layer_inverse(int lk, const T *c, int d, int q, T (&z)[DPL]) {
+__device__ __forceinline__ T layer_inverse(int lk, const T *c, int d, int i0, bool vec, T (&z)[DPL]) {
+  T p0[DPL];
+  row_load<T, DPL>(c, i0, d, vec, p0);
   if (lk == LK_PLANAR) {
     // solve alpha + c tanh(alpha + b) = w'y for alpha = w'z  (monotone: c > -1)
     T dot = 0;
 #pragma unroll
-    for (int k = 0; k < DPL; ++k) {
-      const int i = q + LPS * k;
-      if (i < d) dot += c[i] * z[k];
-    }
+    for (int k = 0; k < DPL; ++k) dot += p0[k] * z[k];
     const T wy = g16sum(dot), b = c[2 * d], sp = c[2 * d + 1], cc = sp - (T)1;
     T lo = wy - fabs(cc), hi = wy + fabs(cc);
     const int iters = sizeof(T) == 8 ? 64 : 40;
@@ -176,11 +223,10 @@ __device__ __forceinline__ T layer_inverse(int lk, const T *c, int d, int q, T (
       al -= (al + cc * t - wy) / (sp * ((T)1 - t * t) + t * t);
     }
     const T t = tanh(al + b);
+    T uh[DPL];
+    row_load<T, DPL>(c + d, i0, d, vec, uh);
 #pragma unroll
-    for (int k = 0; k < DPL; ++k) {
-      const int i = q + LPS * k;
-      if (i < d) z[k] -= c[d + i] * t;
-    }
+    for (int k = 0; k < DPL; ++k) z[k] -= uh[k] * t;
     return -log(sp * ((T)1 - t * t) + t * t);
   }
   if (lk == LK_RADIAL) {
@@ -188,37 +234,27 @@ __device__ __forceinline__ T layer_inverse(int lk, const T *c, int d, int q, T (
     T ss = 0;
 #pragma unroll
     for (int k = 0; k < DPL; ++k) {
-      const int i = q + LPS * k;
-      if (i < d) {
-        const T dl = z[k] - c[i];
-        ss += dl * dl;
-      }
+      const T dl = (i0 + k < d) ? z[k] - p0[k] : (T)0;
+      ss += dl * dl;
     }
     const T rho = sqrt(g16sum(ss));
     const T aa = (alpha + bh) - rho;
     const T r = (T)0.5 * (sqrt(aa * aa + (T)4 * alpha * rho) - aa);
     const T f = (alpha + r) / (alpha + bh + r);
 #pragma unroll
-    for (int k = 0; k < DPL; ++k) {
-      const int i = q + LPS * k;
-      if (i < d) z[k] = c[i] + f * (z[k] - c[i]);
-    }
+    for (int k = 0; k < DPL; ++k)
+      if (i0 + k < d) z[k] = p0[k] + f * (z[k] - p0[k]);
     const T h = (T)1 / (alpha + r);
     return -((T)(d - 1) * log1p(bh * h) + log1p(bh * h - bh * h * h * r));
   }
   if (lk == LK_SHIFT) {
 #pragma unroll
-    for (int k = 0; k < DPL; ++k) {
-      const int i = q + LPS * k;
-      if (i < d) z[k] -= c[i];
-    }
+    for (int k = 0; k < DPL; ++k) z[k] -= p0[k];
     return (T)0;
   }
 #pragma unroll
-  for (int k = 0; k < DPL; ++k) {
-    const int i = q + LPS * k;
-    if (i < d) z[k] /= c[i];
-  }
+  for (int k = 0; k < DPL; ++k)
+    if (i0 + k < d) z[k] /= p0[k];
   return -c[d];
 }
 
@@ -231,250 +267,254 @@ __global__ __launch_bounds__(SB) void k_simple_apply(SimpleArgs a, const T *__re
                                                      T *y, T *__restrict__ ladj, T *__restrict__ stash) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T *cache = (T *)smem;
-  const int d = a.d, LP = 2 * d + 2, nlr = a.hi - a.lo;
+  const int d = a.d, LP = lp_of(d), nlr = a.hi - a.lo;
+  const bool vec = a.vec != 0;
   build_layer_cache<T>(cache, a, theta);
   __syncthreads();
-  const int q = threadIdx.x & (LPS - 1);
+  const int q = threadIdx.x & (LPS - 1), i0 = q * DPL;
+  // a 16-lane group shares j, so it is converged for the shuffles
   for (long j = (long)blockIdx.x * SPB + threadIdx.x / LPS; j < a.N; j += (long)gridDim.x * SPB) {
-    const bool valid = true;  // a 16-lane group shares j, so it is converged for the shuffles
-    const long jj = valid ? j : 0;
     T z[DPL];
-#pragma unroll
-    for (int k = 0; k < DPL; ++k) {
-      const int i = q + LPS * k;
-      z[k] = (valid && i < d) ? x[jj * d + i] : (T)0;
-    }
+    row_load<T, DPL>(x + j * d, i0, d, vec, z);
     T lsum = 0;
     for (int e = 0; e < nlr; ++e) {
       const int l = a.inverse ? a.lo + e : a.hi - 1 - e;
-      if (stash && valid && !a.inverse) {
-#pragma unroll
-        for (int k = 0; k < DPL; ++k) {
-          const int i = q + LPS * k;
-          if (i < d) stash[((long)e * a.N + j) * d + i] = z[k];
-        }
-      }
+      if (stash && !a.inverse) row_store<T, DPL>(stash + ((long)e * a.N + j) * d, i0, d, vec, z);
       const T *c = cache + (long)(l - a.lo) * LP;
       const int lk = layer_kind(a.kind, l);
-      lsum += a.inverse ? layer_inverse<T, DPL>(lk, c, d, q, z) : layer_forward<T, DPL>(lk, c, d, q, z);
-      if (stash && valid && a.inverse) {
-#pragma unroll
-        for (int k = 0; k < DPL; ++k) {
-          const int i = q + LPS * k;
-          if (i < d) stash[((long)l * a.N + j) * d + i] = z[k];
-        }
-      }
+      lsum += a.inverse ? layer_inverse<T, DPL>(lk, c, d, i0, vec, z) : layer_forward<T, DPL>(lk, c, d, i0, vec, z);
+      if (stash && a.inverse) row_store<T, DPL>(stash + ((long)l * a.N + j) * d, i0, d, vec, z);
     }
-    if (valid) {
-#pragma unroll
-      for (int k = 0; k < DPL; ++k) {
-        const int i = q + LPS * k;
-        if (i < d) y[j * d + i] = z[k];
-      }
-      if (q == 0 && ladj) ladj[j] = lsum;
-    }
+    row_store<T, DPL>(y + j * d, i0, d, vec, z);
+    if (q == 0 && ladj) ladj[j] = lsum;
   }
 }
 
-// Reverse pass of ONE layer over the whole batch: zin = layer input (from the stash),
-// gbar: in = dL/d(output), out = dL/d(input).  Raw parameter sums go to slab[block][2d+2]:
-//   planar: wbar_raw[d] | uhat_bar[d] | bbar | cbar
-//   radial: z0bar[d] | alpha_bar | betahat_bar
-//   shift : abar[d]            scale: sum(ybar .* x)[d] | sum(lbar)
+// Reverse pass of ONE layer for one sample (a 16-lane group): z = layer input, g: in = dL/d(output), out =
+// dL/d(input); raw parameter sums are accumulated per lane:
+//   planar: acc0 = wbar_raw[d], acc1 = uhat_bar[d], s0 = bbar, s1 = cbar
+//   radial: acc0 = z0bar[d], s0 = alpha_bar, s1 = betahat_bar
+//   shift : acc0 = abar[d]            scale: acc0 = sum(ybar .* x)[d], s0 = sum(lbar)
 //
-// INV: reverse pass of the INVERSE chain (forward-KL training).  Layers are walked in forward execution
-// order; zin = the inverse layer's OUTPUT w (stash of the inverse pass), gbar in = cotangent of w, out =
-// cotangent vbar of the inverse layer's input, lbar = cotangent of ladj_inv.  Implicit-function form:
+// INV: reverse pass of the INVERSE layer (forward-KL training).  z = the inverse layer's OUTPUT w (stash of
+// the inverse pass), g in = cotangent of w, out = cotangent vbar of the inverse layer's input, lb = cotangent
+// of ladj_inv.  Implicit-function form:
 //   vbar = J^-T (wbar - lbar grad_w ladj_fwd),  parameter sums = the forward formulas with (-vbar, -lbar);
 // J^-T is closed-form for every layer here (Sherman-Morrison for planar / radial).
+template <class T, int DPL, bool INV>
+__device__ __forceinline__ void layer_bwd(int lk, const T *c, int d, int i0, int q, bool vec, T (&z)[DPL], T (&g)[DPL], T lb,
+                                          T (&acc0)[DPL], T (&acc1)[DPL], T &s0, T &s1) {
+  T p0[DPL], v[DPL];
+  row_load<T, DPL>(c, i0, d, vec, p0);
+#pragma unroll
+  for (int k = 0; k < DPL; ++k) v[k] = (T)0;
+  if (lk == LK_PLANAR) {
+    T uh[DPL];
+    row_load<T, DPL>(c + d, i0, d, vec, uh);
+    T dot = 0, ug = 0;
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) {
+      dot += p0[k] * z[k];
+      ug += uh[k] * g[k];
+    }
+    const T sp = c[2 * d + 1], cc = sp - (T)1;
+    const T t = tanh(g16sum(dot) + c[2 * d]);
+    ug = g16sum(ug);
+    const T gg = (T)1 - t * t, D = sp * gg + t * t;
+    if (INV) {
+      // J^T = I + gg w uhat^T, grad_z ladj = kap w, uhat^T w = cc:  vbar = g - w beta
+      const T kap = -(T)2 * cc * t * gg / D;
+      const T uap = ug - lb * kap * cc;
+      const T beta = lb * kap + gg * uap / D;
+#pragma unroll
+      for (int k = 0; k < DPL; ++k) {
+        v[k] = g[k] - p0[k] * beta;
+        g[k] = -v[k];
+      }
+      ug = -(ug - cc * beta);
+      lb = -lb;
+    }
+    const T ab = ug * gg - (T)2 * lb * cc * t * gg / D;
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) {
+      acc0[k] += ab * z[k];  // wbar_raw
+      acc1[k] += t * g[k];   // uhat_bar
+      g[k] += p0[k] * ab;    // zbar
+    }
+    if (q == 0) {
+      s0 += ab;            // bbar
+      s1 += lb * gg / D;   // cbar
+    }
+  } else if (lk == LK_RADIAL) {
+    const T alpha = c[d], bh = c[d + 1];
+    T ss = 0, yd = 0;
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) {
+      z[k] = (i0 + k < d) ? z[k] - p0[k] : (T)0;  // delta
+      ss += z[k] * z[k];
+      yd += g[k] * z[k];
+    }
+    const T r = sqrt(g16sum(ss));
+    yd = g16sum(yd);
+    const T h = (T)1 / (alpha + r);
+    const T qq = bh * h, bah2 = bh * alpha * h * h;
+    const T dL_dh = (T)(d - 1) * bh / ((T)1 + qq) + (T)2 * bh * alpha * h / ((T)1 + bah2);
+    const T dL_db = (T)(d - 1) * h / ((T)1 + qq) + alpha * h * h / ((T)1 + bah2);
+    const T dL_da = bh * h * h / ((T)1 + bah2);
+    if (INV) {
+      // J = A I + Bc delta delta^T (symmetric), A + Bc r^2 = 1 + bah2, grad_z ladj = -dL_dh h^2 delta / r
+      const T A = (T)1 + qq;
+      const T e = r > (T)0 ? lb * dL_dh * h * h / r : (T)0;
+      const T dap = yd + lb * dL_dh * h * h * r;
+      const T f2 = r > (T)0 ? (-bh * h * h / r) * dap / ((T)1 + bah2) : (T)0;
+#pragma unroll
+      for (int k = 0; k < DPL; ++k) {
+        v[k] = (g[k] + (e - f2) * z[k]) / A;
+        g[k] = -v[k];
+      }
+      yd = -dap / ((T)1 + bah2);
+      lb = -lb;
+    }
+    const T hbar = bh * yd + lb * dL_dh;
+    const T rbar_over_r = r > (T)0 ? -h * h * hbar / r : (T)0;
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) {
+      const T db = qq * g[k] + rbar_over_r * z[k];
+      acc0[k] -= db;  // z0bar
+      g[k] += db;     // zbar
+    }
+    if (q == 0) {
+      s0 += -h * h * hbar + lb * dL_da;  // alpha_bar
+      s1 += h * yd + lb * dL_db;         // betahat_bar
+    }
+  } else if (lk == LK_SHIFT) {
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) {
+      acc0[k] += INV ? -g[k] : g[k];
+      v[k] = g[k];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) {
+      if (INV) {
+        v[k] = (i0 + k < d) ? g[k] / p0[k] : (T)0;
+        acc0[k] -= v[k] * z[k];
+      } else {
+        acc0[k] += g[k] * z[k];
+        g[k] *= p0[k];
+      }
+    }
+    if (q == 0) s0 += INV ? -lb : lb;
+  }
+  if (INV) {
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) g[k] = v[k];
+  }
+}
+
+// layers per pass of the reverse kernel: as many as ~64 accumulator registers per thread allow (at most 4)
+template <class T, int DPL>
+struct BwdCfg {
+  static constexpr int RAW = 128 / (DPL * (int)sizeof(T));
+  static constexpr int LPP = RAW >= 4 ? 4 : (RAW >= 2 ? 2 : 1);
+};
+
+// Reverse pass over the whole batch, every layer in one launch.  The layers are taken LPP at a time: a
+// thread carries a sample's cotangent through the LPP layers of a pass in registers (gbar is read and written
+// once per PASS, each layer's input once), with one set of parameter accumulators per layer of the pass.
+// A thread keeps its samples from pass to pass (it re-reads the gbar it wrote), so only the block-wide
+// parameter reduction needs barriers: 4 groups of a wave by shuffles, the 4 waves through LDS, in a fixed
+// order (deterministic).  Raw parameter sums go to slabs[layer][block][LP] (layout: layer_bwd).
+// INV: the inverse chain's reverse pass -- layers in forward execution order, see layer_bwd.
 template <class T, int DPL, bool INV>
 __global__ __launch_bounds__(SB) void k_simple_bwd_layers(SimpleArgs a, int nl, const T *__restrict__ theta,
                                                           const T *__restrict__ stash, long stash_stride,
                                                           T *__restrict__ gbar, const T *__restrict__ lbar, T lbar_const,
                                                           T *__restrict__ slabs, long slab_stride) {
+  constexpr int LPP = BwdCfg<T, DPL>::LPP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  T *cache = (T *)smem;                 // one layer: 2d+2
-  const int d = a.d, LP = 2 * d + 2;
-  T *red = cache + LP;                  // [SPB][LP] block reduction buffer
-  // every layer in one launch: a thread keeps its samples from layer to layer (it re-reads the gbar it
-  // wrote), so only the block-wide parameter reduction needs the barriers
+  const int d = a.d, LP = lp_of(d);
+  const bool vec = a.vec != 0;
+  T *cache = (T *)smem;            // [LPP][LP]
+  T *red = cache + LPP * LP;       // [SB / 64][LPP * LP]
+  const int q = threadIdx.x & (LPS - 1), i0 = q * DPL, grp = threadIdx.x / LPS, wave = threadIdx.x >> 6;
 #pragma unroll 1
-  for (int step = 0; step < nl; ++step) {
-    const int l = INV ? nl - 1 - step : step;  // forward chain: flat order = reverse of execution order
-    const T *zin = stash + (long)(INV ? l : nl - 1 - l) * stash_stride;
-    T *slab = slabs + (long)l * slab_stride;
-    SimpleArgs one = a;
-    one.lo = l;
-    one.hi = l + 1;
-    build_layer_cache<T>(cache, one, theta);
+  for (int pass = 0; pass < nl; pass += LPP) {
+    const int nlp = nl - pass < LPP ? nl - pass : LPP;
+    // step s = pass + u  <->  flat layer l = INV ? nl-1-s : s   (forward chain: flat order = reverse of execution order)
+    const int lo = INV ? nl - pass - nlp : pass;
+    SimpleArgs span = a;
+    span.lo = lo;
+    span.hi = lo + nlp;
+    build_layer_cache<T>(cache, span, theta);
     __syncthreads();
-    const int q = threadIdx.x & (LPS - 1), grp = threadIdx.x / LPS;
-    const int lk = layer_kind(a.kind, l);
-    const T *c = cache;
-    T acc0[DPL], acc1[DPL];
-    T s0 = 0, s1 = 0;
-  #pragma unroll
-    for (int k = 0; k < DPL; ++k) acc0[k] = acc1[k] = 0;
-
+    T acc0[LPP][DPL], acc1[LPP][DPL], s0[LPP], s1[LPP];
+#pragma unroll
+    for (int u = 0; u < LPP; ++u) {
+      s0[u] = s1[u] = (T)0;
+#pragma unroll
+      for (int k = 0; k < DPL; ++k) acc0[u][k] = acc1[u][k] = (T)0;
+    }
     for (long j = (long)blockIdx.x * SPB + grp; j < a.N; j += (long)gridDim.x * SPB) {
-      const bool valid = true;
-      const long jj = valid ? j : 0;
-      T z[DPL], g[DPL], v[DPL];
-  #pragma unroll
+      T g[DPL];
+      row_load<T, DPL>(gbar + j * d, i0, d, vec, g);
+      const T lb = lbar ? lbar[j] : lbar_const;
+#pragma unroll
+      for (int u = 0; u < LPP; ++u) {
+        if (u < nlp) {
+          const int l = INV ? nl - 1 - (pass + u) : pass + u;
+          T z[DPL];
+          row_load<T, DPL>(stash + (long)(INV ? l : nl - 1 - l) * stash_stride + j * d, i0, d, vec, z);
+          layer_bwd<T, DPL, INV>(layer_kind(a.kind, l), cache + (long)(l - lo) * LP, d, i0, q, vec, z, g, lb, acc0[u],
+                                 acc1[u], s0[u], s1[u]);
+        }
+      }
+      row_store<T, DPL>(gbar + j * d, i0, d, vec, g);
+    }
+    // deterministic block reduction: the wave's 4 sample groups by shuffles, then the 4 waves through LDS
+#pragma unroll
+    for (int u = 0; u < LPP; ++u) {
+#pragma unroll
       for (int k = 0; k < DPL; ++k) {
-        const int i = q + LPS * k;
-        const bool ok = valid && i < d;
-        z[k] = ok ? zin[jj * d + i] : (T)0;
-        g[k] = ok ? gbar[jj * d + i] : (T)0;
-        v[k] = (T)0;
+        acc0[u][k] += __shfl_xor(acc0[u][k], 16, 64);
+        acc0[u][k] += __shfl_xor(acc0[u][k], 32, 64);
+        acc1[u][k] += __shfl_xor(acc1[u][k], 16, 64);
+        acc1[u][k] += __shfl_xor(acc1[u][k], 32, 64);
       }
-      T lb = valid ? (lbar ? lbar[jj] : lbar_const) : (T)0;
-      if (lk == LK_PLANAR) {
-        T dot = 0, ug = 0;
-  #pragma unroll
-        for (int k = 0; k < DPL; ++k) {
-          const int i = q + LPS * k;
-          if (i < d) {
-            dot += c[i] * z[k];
-            ug += c[d + i] * g[k];
-          }
-        }
-        const T sp = c[2 * d + 1], cc = sp - (T)1;
-        const T t = tanh(g16sum(dot) + c[2 * d]);
-        ug = g16sum(ug);
-        const T gg = (T)1 - t * t, D = sp * gg + t * t;
-        if (INV) {
-          // J^T = I + gg w uhat^T, grad_z ladj = kap w, uhat^T w = cc:  vbar = g - w beta
-          const T kap = -(T)2 * cc * t * gg / D;
-          const T uap = ug - lb * kap * cc;
-          const T beta = lb * kap + gg * uap / D;
-  #pragma unroll
-          for (int k = 0; k < DPL; ++k) {
-            const int i = q + LPS * k;
-            if (i < d) {
-              v[k] = g[k] - c[i] * beta;
-              g[k] = -v[k];
-            }
-          }
-          ug = -(ug - cc * beta);
-          lb = -lb;
-        }
-        const T ab = ug * gg - (T)2 * lb * cc * t * gg / D;
-  #pragma unroll
-        for (int k = 0; k < DPL; ++k) {
-          const int i = q + LPS * k;
-          if (i < d) {
-            acc0[k] += ab * z[k];  // wbar_raw
-            acc1[k] += t * g[k];   // uhat_bar
-            g[k] += c[i] * ab;     // zbar
-          }
-        }
-        if (q == 0) {
-          s0 += ab;            // bbar
-          s1 += lb * gg / D;   // cbar
-        }
-      } else if (lk == LK_RADIAL) {
-        const T alpha = c[d], bh = c[d + 1];
-        T ss = 0, yd = 0;
-  #pragma unroll
-        for (int k = 0; k < DPL; ++k) {
-          const int i = q + LPS * k;
-          if (i < d) {
-            z[k] -= c[i];  // delta
-            ss += z[k] * z[k];
-            yd += g[k] * z[k];
-          }
-        }
-        const T r = sqrt(g16sum(ss));
-        yd = g16sum(yd);
-        const T h = (T)1 / (alpha + r);
-        const T qq = bh * h, bah2 = bh * alpha * h * h;
-        const T dL_dh = (T)(d - 1) * bh / ((T)1 + qq) + (T)2 * bh * alpha * h / ((T)1 + bah2);
-        const T dL_db = (T)(d - 1) * h / ((T)1 + qq) + alpha * h * h / ((T)1 + bah2);
-        const T dL_da = bh * h * h / ((T)1 + bah2);
-        if (INV) {
-          // J = A I + Bc delta delta^T (symmetric), A + Bc r^2 = 1 + bah2, grad_z ladj = -dL_dh h^2 delta / r
-          const T A = (T)1 + qq;
-          const T e = r > (T)0 ? lb * dL_dh * h * h / r : (T)0;
-          const T dap = yd + lb * dL_dh * h * h * r;
-          const T f2 = r > (T)0 ? (-bh * h * h / r) * dap / ((T)1 + bah2) : (T)0;
-  #pragma unroll
-          for (int k = 0; k < DPL; ++k) {
-            const int i = q + LPS * k;
-            if (i < d) {
-              v[k] = (g[k] + (e - f2) * z[k]) / A;
-              g[k] = -v[k];
-            }
-          }
-          yd = -dap / ((T)1 + bah2);
-          lb = -lb;
-        }
-        const T hbar = bh * yd + lb * dL_dh;
-        const T rbar_over_r = r > (T)0 ? -h * h * hbar / r : (T)0;
-  #pragma unroll
-        for (int k = 0; k < DPL; ++k) {
-          const int i = q + LPS * k;
-          if (i < d) {
-            const T db = qq * g[k] + rbar_over_r * z[k];
-            acc0[k] -= db;  // z0bar
-            g[k] += db;     // zbar
-          }
-        }
-        if (q == 0) {
-          s0 += -h * h * hbar + lb * dL_da;  // alpha_bar
-          s1 += h * yd + lb * dL_db;         // betahat_bar
-        }
-      } else if (lk == LK_SHIFT) {
-  #pragma unroll
-        for (int k = 0; k < DPL; ++k) {
-          acc0[k] += INV ? -g[k] : g[k];
-          v[k] = g[k];
-        }
-      } else {
-  #pragma unroll
-        for (int k = 0; k < DPL; ++k) {
-          const int i = q + LPS * k;
-          if (i < d) {
-            if (INV) {
-              v[k] = g[k] / c[i];
-              acc0[k] -= v[k] * z[k];
-            } else {
-              acc0[k] += g[k] * z[k];
-              g[k] *= c[i];
-            }
-          }
-        }
-        if (q == 0) s0 += INV ? -lb : lb;
-      }
-      if (valid) {
-  #pragma unroll
-        for (int k = 0; k < DPL; ++k) {
-          const int i = q + LPS * k;
-          if (i < d) gbar[j * d + i] = INV ? v[k] : g[k];
-        }
-      }
+      s0[u] += __shfl_xor(s0[u], 16, 64);
+      s0[u] += __shfl_xor(s0[u], 32, 64);
+      s1[u] += __shfl_xor(s1[u], 16, 64);
+      s1[u] += __shfl_xor(s1[u], 32, 64);
     }
-    // deterministic block reduction over the SPB sample groups
-    T *mine = red + (long)grp * LP;
-  #pragma unroll
-    for (int k = 0; k < DPL; ++k) {
-      const int i = q + LPS * k;
-      if (i < d) {
-        mine[i] = acc0[k];
-        mine[d + i] = acc1[k];
+    if ((threadIdx.x & 63) < LPS) {
+      T *mine = red + (long)wave * LPP * LP;
+#pragma unroll
+      for (int u = 0; u < LPP; ++u) {
+#pragma unroll
+        for (int k = 0; k < DPL; ++k)
+          if (i0 + k < d) {
+            mine[u * LP + i0 + k] = acc0[u][k];
+            mine[u * LP + d + i0 + k] = acc1[u][k];
+          }
+        if (q == 0) {
+          mine[u * LP + 2 * d] = s0[u];
+          mine[u * LP + 2 * d + 1] = s1[u];
+        }
       }
-    }
-    if (q == 0) {
-      mine[2 * d] = s0;
-      mine[2 * d + 1] = s1;
     }
     __syncthreads();
-    for (int s = threadIdx.x; s < LP; s += SB) {
-      T v = 0;
-      for (int gI = 0; gI < SPB; ++gI) v += red[(long)gI * LP + s];
-      slab[(long)blockIdx.x * LP + s] = v;
+    for (int s = threadIdx.x; s < nlp * LP; s += SB) {
+      const int u = s / LP, e = s - u * LP;
+      if (e < 2 * d + 2) {
+        const int l = INV ? nl - 1 - (pass + u) : pass + u;
+        constexpr int NW = SB / 64;
+        T vsum = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) vsum += red[(long)w * LPP * LP + s];
+        slabs[(long)l * slab_stride + (long)blockIdx.x * LP + e] = vsum;
+      }
     }
-    __syncthreads();  // cache and reduction buffer are rebuilt for the next layer
+    __syncthreads();  // cache and reduction buffer are rebuilt for the next pass
   }
 }
 
@@ -485,11 +525,11 @@ __global__ __launch_bounds__(SB) void k_simple_finalize(SimpleArgs a, const T *_
                                                         const T *__restrict__ slabs, int nblk_bwd,
                                                         T *__restrict__ gtheta) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int d = a.d, LP = 2 * d + 2;
+  const int d = a.d, LP = lp_of(d);
   T *sum = (T *)smem;  // LP
   const int l = blockIdx.x;
   const T *sl = slabs + (long)l * nblk_bwd * LP;
-  for (int s = threadIdx.x; s < LP; s += SB) {
+  for (int s = threadIdx.x; s < 2 * d + 2; s += SB) {
     T v = 0;
     for (int b = 0; b < nblk_bwd; ++b) v += sl[(long)b * LP + s];
     sum[s] = v;
@@ -542,9 +582,19 @@ static inline int dpl_for(int d) {
   return dpl;
 }
 
+// vector row access: the row length must be a whole number of vectors and every base pointer aligned to one
+template <class T>
+static int vec_ok(int d, int dpl, std::initializer_list<const void *> ptrs) {
+  const int vw = (dpl * (int)sizeof(T) >= 16) ? 16 / (int)sizeof(T) : dpl;
+  if (vw <= 1 || d % vw != 0) return 0;
+  for (const void *p : ptrs)
+    if (p && ((uintptr_t)p % (vw * sizeof(T))) != 0) return 0;
+  return 1;
+}
+
 bool nf_simple_supported(const nf_flow_desc *desc) {
   if (desc->d > 256) return false;
-  const long LP = 2L * desc->d + 2;
+  const long LP = lp_of(desc->d);
   const long es = desc->dtype == NF_DTYPE_F64 ? 8 : 4;
   const int nl = desc->kind == NF_KIND_MEANFIELD ? 2 : desc->nlayers;
   return (long)nl * LP * es <= 64 * 1024;
@@ -558,25 +608,40 @@ static SimpleArgs make_sargs(const nf_flow_desc *desc, int lo, int hi, bool inve
   a.lo = lo;
   a.hi = hi;
   a.inverse = inverse ? 1 : 0;
+  a.vec = 0;
   a.N = N;
   return a;
 }
 
-static inline unsigned grid_for(nf_ctx *ctx, long N) {
+// grid of a grid-stride kernel: what the device holds at once (no second, partly filled round of workgroups)
+template <class K>
+static inline long resident_blocks(nf_ctx *ctx, K kernel, size_t lds) {
+  // the occupancy query is a driver call: remember the answer per (kernel, dynamic LDS) -- the small flows
+  // of the demos are launch-bound
+  struct Entry { const void *k; size_t lds; int per_cu; };
+  static std::vector<Entry> seen;
+  for (const Entry &e : seen)
+    if (e.k == (const void *)kernel && e.lds == lds) return (long)e.per_cu * ctx->num_cu;
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, SB, lds) != hipSuccess || per_cu < 1) per_cu = 2;
+  seen.push_back({(const void *)kernel, lds, per_cu});
+  return (long)per_cu * ctx->num_cu;
+}
+static inline unsigned grid_for(long N, long cap) {
   long g = (N + SPB - 1) / SPB;
-  const long cap = 8L * ctx->num_cu;
   if (g > cap) g = cap;
   return (unsigned)(g < 1 ? 1 : g);
 }
 
 template <class T>
-static int apply_t(nf_ctx *ctx, const SimpleArgs &a, const void *theta, const void *x, void *y, void *ladj, void *stash) {
-  const size_t lds = (size_t)(a.hi - a.lo) * (2 * a.d + 2) * sizeof(T);
-  const unsigned grid = grid_for(ctx, a.N);
+static int apply_t(nf_ctx *ctx, const SimpleArgs &a0, const void *theta, const void *x, void *y, void *ladj, void *stash) {
+  SimpleArgs a = a0;
+  a.vec = vec_ok<T>(a.d, dpl_for(a.d), {x, y, stash});
+  const size_t lds = (size_t)(a.hi - a.lo) * lp_of(a.d) * sizeof(T);
   ProfScope ps(ctx, "simple_apply");
-#define LAUNCH_APPLY(DPLv)                                                                                   \
-  hipLaunchKernelGGL((k_simple_apply<T, DPLv>), dim3(grid), dim3(SB), lds, ctx->stream, a, (const T *)theta, \
-                     (const T *)x, (T *)y, (T *)ladj, (T *)stash)
+#define LAUNCH_APPLY(DPLv)                                                                                          \
+  hipLaunchKernelGGL((k_simple_apply<T, DPLv>), dim3(grid_for(a.N, resident_blocks(ctx, k_simple_apply<T, DPLv>, lds))), \
+                     dim3(SB), lds, ctx->stream, a, (const T *)theta, (const T *)x, (T *)y, (T *)ladj, (T *)stash)
   switch (dpl_for(a.d)) {
     case 1: LAUNCH_APPLY(1); break;
     case 2: LAUNCH_APPLY(2); break;
@@ -599,7 +664,7 @@ int nf_simple_apply(nf_ctx *ctx, const nf_flow_desc *desc, int lo, int hi, bool 
 
 static inline int bwd_blocks(nf_ctx *ctx, long N) {
   long g = (N + SPB - 1) / SPB;
-  const long cap = 2L * ctx->num_cu;
+  const long cap = 4L * ctx->num_cu;  // 16 waves per CU in flight: the kernel is HBM-bound
   if (g > cap) g = cap;
   return (int)(g < 1 ? 1 : g);
 }
@@ -607,7 +672,7 @@ static inline int bwd_blocks(nf_ctx *ctx, long N) {
 size_t nf_simple_bwd_ws_bytes(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
   const size_t es = desc->dtype == NF_DTYPE_F64 ? 8 : 4;
   const int nl = desc->kind == NF_KIND_MEANFIELD ? 2 : desc->nlayers;
-  const size_t LP = 2 * (size_t)desc->d + 2;
+  const size_t LP = lp_of(desc->d);
   return carve_bytes((size_t)nl * N * desc->d * es) + carve_bytes((size_t)N * desc->d * es) +
          carve_bytes((size_t)nl * bwd_blocks(ctx, N) * LP * es);
 }
@@ -631,7 +696,7 @@ static int bwd_t(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const
   if (inv && !have_stash) return NF_ERR_ARG;  // the inverse chain's points come from nf_simple_apply_stash(inverse)
   const int nl = desc->kind == NF_KIND_MEANFIELD ? 2 : desc->nlayers;
   const int d = desc->d;
-  const size_t LP = 2 * (size_t)d + 2;
+  const size_t LP = lp_of(d);
   const int nb = bwd_blocks(ctx, N);
   Carver cv(ws);
   T *stash = cv.take<T>((size_t)nl * N * d);
@@ -642,12 +707,20 @@ static int bwd_t(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const
   if (!have_stash) NF_TRY(apply_t<T>(ctx, a, theta, x, ytmp, nullptr, stash));
   if (xbar_out != ybar)
     NF_HIP(hipMemcpyAsync(xbar_out, ybar, (size_t)N * d * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
-  const size_t lds = (LP + (size_t)SPB * LP) * sizeof(T);
+  a.vec = vec_ok<T>(d, dpl_for(d), {stash, xbar_out});
+  int nb_used = nb;
   {
     ProfScope ps(ctx, "simple_bwd");
-#define LAUNCH_BWD_V(DPLv, INVv)                                                                                     \
-  hipLaunchKernelGGL((k_simple_bwd_layers<T, DPLv, INVv>), dim3(nb), dim3(SB), lds, ctx->stream, a, nl, (const T *)theta, \
-                     (const T *)stash, (long)N * d, (T *)xbar_out, (const T *)lbar, (T)lbar_const, slabs, (long)nb * LP)
+    // LDS: the pass's layer caches + one reduction row per wave; grid: what is resident at once, at most `nb`
+#define LAUNCH_BWD_V(DPLv, INVv)                                                                                       \
+  do {                                                                                                                 \
+    const size_t ldsv = (size_t)(1 + SB / 64) * (BwdCfg<T, DPLv>::LPP) * LP * sizeof(T);                                 \
+    const long res = resident_blocks(ctx, k_simple_bwd_layers<T, DPLv, INVv>, ldsv);                                    \
+    nb_used = (int)(res < nb ? res : nb);                                                                              \
+    hipLaunchKernelGGL((k_simple_bwd_layers<T, DPLv, INVv>), dim3(nb_used), dim3(SB), ldsv, ctx->stream, a, nl,          \
+                       (const T *)theta, (const T *)stash, (long)N * d, (T *)xbar_out, (const T *)lbar, (T)lbar_const, \
+                       slabs, (long)nb_used * LP);                                                                     \
+  } while (0)
 #define LAUNCH_BWD(DPLv)           \
   do {                             \
     if (inv) LAUNCH_BWD_V(DPLv, true); \
@@ -666,7 +739,7 @@ static int bwd_t(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const
     NF_HIP(hipGetLastError());
   }
   hipLaunchKernelGGL(k_simple_finalize<T>, dim3(nl), dim3(SB), LP * sizeof(T), ctx->stream, a, (const T *)theta,
-                     (const T *)slabs, nb, (T *)gtheta_out);
+                     (const T *)slabs, nb_used, (T *)gtheta_out);
   return (int)hipGetLastError();
 }
 

@@ -1,0 +1,51 @@
+"""HBM-bound kernels at scale: ELBO step of planar / radial flows, d = 64, 10 layers, 1 M samples (fp32), with the
+bytes each kernel must move and the resulting GB/s.  usage: python tools/bench_simple.py [N]"""
+import ctypes as C
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from __graft_entry__ import load_package
+
+nf = load_package()
+lib = nf.load_library()
+dev = torch.device("cuda", 0)
+vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
+d, nl = 64, 10
+g = torch.Generator().manual_seed(1)
+tgt = nf.DiagGaussTarget(torch.randn(d, generator=g).to(dev), (torch.rand(d, generator=g) + 0.5).to(dev))
+for kind in ("planar", "radial"):
+    flow = (nf.planarflow if kind == "planar" else nf.radialflow)(nf.MvNormal(d), nl, paramtype=torch.float32, device=dev, seed=3)
+    with torch.no_grad():
+        flow.theta.mul_(0.1)
+    ctx = nf.context_for(dev)
+    out = torch.zeros(flow.P + 1, device=dev)
+
+    def step(i):
+        nf._lib.check(lib.nf_elbo_value_and_grad(ctx.ptr, C.byref(flow.desc), C.byref(tgt.c), vp(flow.theta), None, N, N, 1, 0, i, vp(out)))
+
+    for i in range(3):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(10):
+        step(3 + i)
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / 10
+    lib.nf_prof_enable(ctx.ptr, 2)
+    step(20)
+    torch.cuda.synchronize()
+    row = N * d * 4
+    need = {"base_sample": row + 4 * N, "simple_apply": row * (1 + nl + 1) + 4 * N, "target": 2 * row + 12 * N,
+            "simple_bwd": nl * 3 * row}
+    print(f"{kind} d={d} layers={nl} N={N}: {1e3 * el:.3f} ms/step = {N / el / 1e6:.1f} M samples/s, loss {float(out[-1]):.4f}")
+    for name, b in need.items():
+        a, c = C.c_double(0.0), C.c_int64(0)
+        lib.nf_prof_read(ctx.ptr, name.encode(), C.byref(a), C.byref(c))
+        if c.value:
+            print(f"   {name:13s} {1e3 * a.value:8.1f} us  {b / 1e6:8.1f} MB  -> {b / (a.value * 1e-3) / 1e12:.2f} TB/s ({b / (a.value * 1e-3) / 8e12:.0%} of 8 TB/s)")
+    lib.nf_prof_enable(ctx.ptr, 0)
