@@ -77,6 +77,12 @@ int nf_simple_bwd(nf_ctx *, const nf_flow_desc *, const void *theta, const void 
 int nf_simple_apply_stash(nf_ctx *, const nf_flow_desc *, const void *theta, const void *x, long N, void *y, void *ladj,
                           void *ws, bool inverse = false);
 
+long nf_simple_elbo_max_partials(nf_ctx *);
+int nf_simple_elbo_forward(nf_ctx *, const nf_flow_desc *, const nf_target *, const void *theta, const void *xs, long N,
+                           uint64_t seed, uint64_t off, uint32_t stream_id, void *gbar, double gscale, double *partial,
+                           double pscale, void *ws, long *npartial);
+int nf_target_check(const nf_target *t, int d);
+
 // general coupling kernels (nf_generic64.hip): Float64, and the Float32 shapes the MFMA paths do not
 // build; one thread per sample, standard layout
 bool nf_g64_supported(const nf_flow_desc *desc);
@@ -718,20 +724,27 @@ extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, con
     NF_TRY(realnvp_bwd(ctx, desc, (const float *)theta, xt, gt, nullptr, (float)(-inv), N, (float *)slab, grid,
                        (float *)out));
   } else {
+    if (!(is_g64(desc) || desc->kind == NF_KIND_HAMILTONIAN)) {
+      // planar / radial / mean-field: draws + chain + target + ELBO partial sums in one launch (the per-layer inputs
+      // stay behind for the reverse pass), then the reverse pass over all layers
+      NF_TRY(nf_target_check(target, desc->d));
+      long np = 0;
+      NF_TRY(nf_simple_elbo_forward(ctx, desc, target, theta, xs, N, seed, sample_offset, stream_id, gbar, -inv, partial, -inv,
+                                    sws, &np));
+      NF_TRY(nf_simple_bwd(ctx, desc, theta, nullptr, gbar, nullptr, -inv, N, gbar, out, sws, true));
+      if (dt == NF_DTYPE_F32) return nf_launch_finish_sum(ctx, partial, np, 0, nullptr, (float *)out + P, nullptr);
+      return nf_launch_finish_sum(ctx, partial, np, 0, (double *)out + P, nullptr, nullptr);
+    }
     if (xs) {
       NF_HIP(hipMemcpyAsync(x0, xs, (size_t)N * desc->d * es, hipMemcpyDeviceToDevice, ctx->stream));
       NF_TRY(nf_launch_base_logpdf(ctx, dt, desc->d, N, x0, logq));
     } else {
       NF_TRY(nf_launch_base_sample(ctx, dt, desc->d, N, seed, sample_offset, stream_id, x0, logq));
     }
-    if (is_g64(desc) || desc->kind == NF_KIND_HAMILTONIAN) {
+    {
       NF_TRY(flat_apply(ctx, desc, 0, nf_layer_count(desc), false, theta, x0, N, x, ladj));
       NF_TRY(nf_launch_target(ctx, dt, target, desc->d, N, x, logq, ladj, nullptr, gbar, -inv, nullptr, partial, -inv, joint_dims(desc)));
       NF_TRY(flat_bwd(ctx, desc, theta, x0, gbar, nullptr, -inv, N, gbar, out, sws));
-    } else {  // planar / radial / mean-field: the forward pass leaves the reverse pass's per-layer inputs behind
-      NF_TRY(nf_simple_apply_stash(ctx, desc, theta, x0, N, x, ladj, sws));
-      NF_TRY(nf_launch_target(ctx, dt, target, desc->d, N, x, logq, ladj, nullptr, gbar, -inv, nullptr, partial, -inv, joint_dims(desc)));
-      NF_TRY(nf_simple_bwd(ctx, desc, theta, x0, gbar, nullptr, -inv, N, gbar, out, sws, true));
     }
   }
   if (cp) return NF_OK;

@@ -13,7 +13,11 @@
 #include <initializer_list>
 #include <vector>
 
+#include <type_traits>
+
 #include "nf_common.h"
+#include "nf_philox.h"
+#include "nf_targets.h"
 
 #define LPS 16
 #define SB 256
@@ -38,6 +42,29 @@ __device__ __forceinline__ T sigmoid_(T x) {
   const T e = exp(-fabs(x));
   return x >= (T)0 ? (T)1 / ((T)1 + e) : e / ((T)1 + e);
 }
+
+// Per-sample scalar math of the layers.  Float64 keeps libm; Float32 uses the hardware transcendentals
+// (v_exp / v_log / v_rcp / v_sqrt: ~1 ulp, absolute error of tanh and log1p <= 2e-7) -- these kernels are
+// HBM-bound only as long as the 16 lanes of a sample do not spend their time in libm's fp32 expansions.
+template <class T>
+struct Fm {
+  static __device__ __forceinline__ T tanh_(T x) { return tanh(x); }
+  static __device__ __forceinline__ T log_(T x) { return log(x); }
+  static __device__ __forceinline__ T log1p_(T x) { return log1p(x); }
+  static __device__ __forceinline__ T sqrt_(T x) { return sqrt(x); }
+  static __device__ __forceinline__ T div_(T a, T b) { return a / b; }
+};
+template <>
+struct Fm<float> {
+  static __device__ __forceinline__ float tanh_(float x) {
+    const float e = __expf(2.f * x);  // inf -> 1, 0 -> -1
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+  }
+  static __device__ __forceinline__ float log_(float x) { return __logf(x); }
+  static __device__ __forceinline__ float log1p_(float x) { return __logf(1.f + x); }
+  static __device__ __forceinline__ float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
+  static __device__ __forceinline__ float div_(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+};
 
 struct SimpleArgs {
   int kind;     // NF_KIND_*
@@ -167,12 +194,12 @@ __device__ __forceinline__ T layer_forward(int lk, const T *c, int d, int i0, bo
     T dot = 0;
 #pragma unroll
     for (int k = 0; k < DPL; ++k) dot += p0[k] * z[k];
-    const T t = tanh(g16sum(dot) + c[2 * d]);
+    const T t = Fm<T>::tanh_(g16sum(dot) + c[2 * d]);
     T uh[DPL];
     row_load<T, DPL>(c + d, i0, d, vec, uh);
 #pragma unroll
     for (int k = 0; k < DPL; ++k) z[k] += uh[k] * t;
-    return log(c[2 * d + 1] * ((T)1 - t * t) + t * t);
+    return Fm<T>::log_(c[2 * d + 1] * ((T)1 - t * t) + t * t);
   }
   if (lk == LK_RADIAL) {
     const T alpha = c[d], bh = c[d + 1];
@@ -182,12 +209,12 @@ __device__ __forceinline__ T layer_forward(int lk, const T *c, int d, int i0, bo
       const T dl = (i0 + k < d) ? z[k] - p0[k] : (T)0;
       ss += dl * dl;
     }
-    const T r = sqrt(g16sum(ss));
-    const T h = (T)1 / (alpha + r);
+    const T r = Fm<T>::sqrt_(g16sum(ss));
+    const T h = Fm<T>::div_((T)1, alpha + r);
 #pragma unroll
     for (int k = 0; k < DPL; ++k)
       if (i0 + k < d) z[k] += bh * h * (z[k] - p0[k]);
-    return (T)(d - 1) * log1p(bh * h) + log1p(bh * h - bh * h * h * r);
+    return (T)(d - 1) * Fm<T>::log1p_(bh * h) + Fm<T>::log1p_(bh * h - bh * h * h * r);
   }
   if (lk == LK_SHIFT) {
 #pragma unroll
@@ -213,21 +240,21 @@ __device__ __forceinline__ T layer_inverse(int lk, const T *c, int d, int i0, bo
     const int iters = sizeof(T) == 8 ? 64 : 40;
     for (int it = 0; it < iters; ++it) {
       const T mid = (T)0.5 * (lo + hi);
-      const T f = mid + cc * tanh(mid + b) - wy;
+      const T f = mid + cc * Fm<T>::tanh_(mid + b) - wy;
       if (f > (T)0) hi = mid; else lo = mid;
     }
     T al = (T)0.5 * (lo + hi);
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {  // Newton polish
-      const T t = tanh(al + b);
-      al -= (al + cc * t - wy) / (sp * ((T)1 - t * t) + t * t);
+      const T t = Fm<T>::tanh_(al + b);
+      al -= Fm<T>::div_(al + cc * t - wy, sp * ((T)1 - t * t) + t * t);
     }
-    const T t = tanh(al + b);
+    const T t = Fm<T>::tanh_(al + b);
     T uh[DPL];
     row_load<T, DPL>(c + d, i0, d, vec, uh);
 #pragma unroll
     for (int k = 0; k < DPL; ++k) z[k] -= uh[k] * t;
-    return -log(sp * ((T)1 - t * t) + t * t);
+    return -Fm<T>::log_(sp * ((T)1 - t * t) + t * t);
   }
   if (lk == LK_RADIAL) {
     const T alpha = c[d], bh = c[d + 1];
@@ -237,15 +264,15 @@ __device__ __forceinline__ T layer_inverse(int lk, const T *c, int d, int i0, bo
       const T dl = (i0 + k < d) ? z[k] - p0[k] : (T)0;
       ss += dl * dl;
     }
-    const T rho = sqrt(g16sum(ss));
+    const T rho = Fm<T>::sqrt_(g16sum(ss));
     const T aa = (alpha + bh) - rho;
-    const T r = (T)0.5 * (sqrt(aa * aa + (T)4 * alpha * rho) - aa);
-    const T f = (alpha + r) / (alpha + bh + r);
+    const T r = (T)0.5 * (Fm<T>::sqrt_(aa * aa + (T)4 * alpha * rho) - aa);
+    const T f = Fm<T>::div_(alpha + r, alpha + bh + r);
 #pragma unroll
     for (int k = 0; k < DPL; ++k)
       if (i0 + k < d) z[k] = p0[k] + f * (z[k] - p0[k]);
-    const T h = (T)1 / (alpha + r);
-    return -((T)(d - 1) * log1p(bh * h) + log1p(bh * h - bh * h * h * r));
+    const T h = Fm<T>::div_((T)1, alpha + r);
+    return -((T)(d - 1) * Fm<T>::log1p_(bh * h) + Fm<T>::log1p_(bh * h - bh * h * h * r));
   }
   if (lk == LK_SHIFT) {
 #pragma unroll
@@ -258,13 +285,58 @@ __device__ __forceinline__ T layer_inverse(int lk, const T *c, int d, int i0, bo
   return -c[d];
 }
 
+// The ELBO forward of a training step, fused into the chain kernel (fu.on): the base draws are generated in
+// registers (Philox4x32-10 + Box-Muller, same counters as k_base_sample: (sample, feature group of 4, stream)) or
+// read from xs, log q0 and the log-det never touch memory, and the target log-density, ybar = gscale grad log p(y)
+// and the block's partial sum of pscale * elbo_j come out of the same launch.  The flow output is not written:
+// the reverse pass needs only ybar and the per-layer inputs (stash).
+struct SimpleFused {
+  int on, draw, tkind;
+  uint32_t k0, k1, stream;
+  uint64_t off;
+  const void *mu, *var;
+  double s0, s1, gscale, pscale;
+  void *gbar;       // [N][d]
+  double *partial;  // [gridDim.x]
+};
+
+template <class T, int DPL>
+__device__ __forceinline__ void draw_row(const SimpleFused &fu, long j, int i0, int d, T (&z)[DPL]) {
+  const uint64_t gj = fu.off + (uint64_t)j;
+  constexpr int NG = DPL >= 4 ? DPL / 4 : 1;
+#pragma unroll
+  for (int m = 0; m < NG; ++m) {
+    const int g = i0 / 4 + m;
+    T n4[4] = {(T)0, (T)0, (T)0, (T)0};
+    if (4 * g < d) {
+      U4 c = {(uint32_t)gj, (uint32_t)(gj >> 32), (uint32_t)g, fu.stream};
+      const U4 r = philox4x32_10(c, fu.k0, fu.k1);
+      box_muller<T>(r.x, r.y, n4[0], n4[1]);
+      box_muller<T>(r.z, r.w, n4[2], n4[3]);
+    }
+    if constexpr (DPL >= 4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) z[4 * m + e] = (i0 + 4 * m + e < d) ? n4[e] : (T)0;
+    } else {
+      const int e0 = i0 & 3;  // DPL = 1, 2: this lane's share of the group of four
+#pragma unroll
+      for (int k = 0; k < DPL; ++k) {
+        T v = n4[0];
+#pragma unroll
+        for (int e = 1; e < 4; ++e) v = (e0 + k == e) ? n4[e] : v;
+        z[k] = (i0 + k < d) ? v : (T)0;
+      }
+    }
+  }
+}
+
 // chain-fused forward / inverse over flat layers [lo, hi).  If `stash` != nullptr the reverse pass's
 // evaluation points are left behind: forward -- the INPUT of every layer at stash[e][N][d] (execution
 // index e); inverse -- the OUTPUT of every inverse layer at stash[l][N][d] (flat index l), i.e. the
 // forward-sense input of layer l, which is where the inverse chain's reverse pass evaluates it.
 template <class T, int DPL>
 __global__ __launch_bounds__(SB) void k_simple_apply(SimpleArgs a, const T *__restrict__ theta, const T *x,
-                                                     T *y, T *__restrict__ ladj, T *__restrict__ stash) {
+                                                     T *y, T *__restrict__ ladj, T *__restrict__ stash, SimpleFused fu) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T *cache = (T *)smem;
   const int d = a.d, LP = lp_of(d), nlr = a.hi - a.lo;
@@ -272,10 +344,19 @@ __global__ __launch_bounds__(SB) void k_simple_apply(SimpleArgs a, const T *__re
   build_layer_cache<T>(cache, a, theta);
   __syncthreads();
   const int q = threadIdx.x & (LPS - 1), i0 = q * DPL;
+  double contrib = 0.0;
   // a 16-lane group shares j, so it is converged for the shuffles
   for (long j = (long)blockIdx.x * SPB + threadIdx.x / LPS; j < a.N; j += (long)gridDim.x * SPB) {
     T z[DPL];
-    row_load<T, DPL>(x + j * d, i0, d, vec, z);
+    if (fu.on && fu.draw) draw_row<T, DPL>(fu, j, i0, d, z);
+    else row_load<T, DPL>(x + j * d, i0, d, vec, z);
+    T logq = 0;
+    if (fu.on) {
+      T ss = 0;
+#pragma unroll
+      for (int k = 0; k < DPL; ++k) ss += z[k] * z[k];
+      logq = (T)(-0.5 * 1.8378770664093453 * d) - (T)0.5 * g16sum(ss);
+    }
     T lsum = 0;
     for (int e = 0; e < nlr; ++e) {
       const int l = a.inverse ? a.lo + e : a.hi - 1 - e;
@@ -285,8 +366,53 @@ __global__ __launch_bounds__(SB) void k_simple_apply(SimpleArgs a, const T *__re
       lsum += a.inverse ? layer_inverse<T, DPL>(lk, c, d, i0, vec, z) : layer_forward<T, DPL>(lk, c, d, i0, vec, z);
       if (stash && a.inverse) row_store<T, DPL>(stash + ((long)l * a.N + j) * d, i0, d, vec, z);
     }
-    row_store<T, DPL>(y + j * d, i0, d, vec, z);
+    if (y) row_store<T, DPL>(y + j * d, i0, d, vec, z);
     if (q == 0 && ladj) ladj[j] = lsum;
+    if (fu.on) {
+      const T y0 = __shfl(z[0], 0, LPS);
+      const T y1 = DPL >= 2 ? __shfl(z[DPL >= 2 ? 1 : 0], 0, LPS) : __shfl(z[0], 1, LPS);
+      T s2 = 0;
+      if (fu.tkind == NF_TARGET_FUNNEL) {
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) s2 += (i0 + k >= 1) ? z[k] * z[k] : (T)0;
+        s2 = g16sum(s2);
+      }
+      T acc = 0, gr[DPL];
+      auto run = [&](auto kc) {  // the target kind is resolved once per sample, outside the feature loop
+        constexpr int KD = decltype(kc)::value;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+          T gk = 0;
+          if (i0 + k < d)
+            acc += target_term<KD, T>(d, i0 + k, z[k], y0, y1, s2, (const T *)fu.mu, (const T *)fu.var, (T)fu.s0, (T)fu.s1, gk);
+          gr[k] = (T)fu.gscale * gk;
+        }
+      };
+      switch (fu.tkind) {
+        case NF_TARGET_DIAGGAUSS: run(std::integral_constant<int, NF_TARGET_DIAGGAUSS>{}); break;
+        case NF_TARGET_BANANA: run(std::integral_constant<int, NF_TARGET_BANANA>{}); break;
+        case NF_TARGET_FUNNEL: run(std::integral_constant<int, NF_TARGET_FUNNEL>{}); break;
+        case NF_TARGET_WARPED: run(std::integral_constant<int, NF_TARGET_WARPED>{}); break;
+        default: run(std::integral_constant<int, NF_TARGET_CROSS>{}); break;
+      }
+      acc = g16sum(acc);
+      row_store<T, DPL>((T *)fu.gbar + j * d, i0, d, vec, gr);
+      if (q == 0) contrib += fu.pscale * (double)(acc - logq + lsum);
+    }
+  }
+  if (fu.on) {  // deterministic block sum of the ELBO terms
+    __shared__ double sm[SB / 64];
+    double c = contrib;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+#pragma unroll
+      for (int w = 0; w < SB / 64; ++w) t += sm[w];
+      fu.partial[blockIdx.x] = t;
+    }
   }
 }
 
@@ -318,14 +444,14 @@ __device__ __forceinline__ void layer_bwd(int lk, const T *c, int d, int i0, int
       ug += uh[k] * g[k];
     }
     const T sp = c[2 * d + 1], cc = sp - (T)1;
-    const T t = tanh(g16sum(dot) + c[2 * d]);
+    const T t = Fm<T>::tanh_(g16sum(dot) + c[2 * d]);
     ug = g16sum(ug);
-    const T gg = (T)1 - t * t, D = sp * gg + t * t;
+    const T gg = (T)1 - t * t, D = sp * gg + t * t, iD = Fm<T>::div_((T)1, D);
     if (INV) {
       // J^T = I + gg w uhat^T, grad_z ladj = kap w, uhat^T w = cc:  vbar = g - w beta
-      const T kap = -(T)2 * cc * t * gg / D;
+      const T kap = -(T)2 * cc * t * gg * iD;
       const T uap = ug - lb * kap * cc;
-      const T beta = lb * kap + gg * uap / D;
+      const T beta = lb * kap + gg * uap * iD;
 #pragma unroll
       for (int k = 0; k < DPL; ++k) {
         v[k] = g[k] - p0[k] * beta;
@@ -334,7 +460,7 @@ __device__ __forceinline__ void layer_bwd(int lk, const T *c, int d, int i0, int
       ug = -(ug - cc * beta);
       lb = -lb;
     }
-    const T ab = ug * gg - (T)2 * lb * cc * t * gg / D;
+    const T ab = ug * gg - (T)2 * lb * cc * t * gg * iD;
 #pragma unroll
     for (int k = 0; k < DPL; ++k) {
       acc0[k] += ab * z[k];  // wbar_raw
@@ -343,7 +469,7 @@ __device__ __forceinline__ void layer_bwd(int lk, const T *c, int d, int i0, int
     }
     if (q == 0) {
       s0 += ab;            // bbar
-      s1 += lb * gg / D;   // cbar
+      s1 += lb * gg * iD;  // cbar
     }
   } else if (lk == LK_RADIAL) {
     const T alpha = c[d], bh = c[d + 1];
@@ -354,29 +480,29 @@ __device__ __forceinline__ void layer_bwd(int lk, const T *c, int d, int i0, int
       ss += z[k] * z[k];
       yd += g[k] * z[k];
     }
-    const T r = sqrt(g16sum(ss));
+    const T r = Fm<T>::sqrt_(g16sum(ss));
     yd = g16sum(yd);
-    const T h = (T)1 / (alpha + r);
+    const T h = Fm<T>::div_((T)1, alpha + r);
     const T qq = bh * h, bah2 = bh * alpha * h * h;
-    const T dL_dh = (T)(d - 1) * bh / ((T)1 + qq) + (T)2 * bh * alpha * h / ((T)1 + bah2);
-    const T dL_db = (T)(d - 1) * h / ((T)1 + qq) + alpha * h * h / ((T)1 + bah2);
-    const T dL_da = bh * h * h / ((T)1 + bah2);
+    const T iq = Fm<T>::div_((T)1, (T)1 + qq), ib = Fm<T>::div_((T)1, (T)1 + bah2), ir = r > (T)0 ? Fm<T>::div_((T)1, r) : (T)0;
+    const T dL_dh = (T)(d - 1) * bh * iq + (T)2 * bh * alpha * h * ib;
+    const T dL_db = (T)(d - 1) * h * iq + alpha * h * h * ib;
+    const T dL_da = bh * h * h * ib;
     if (INV) {
       // J = A I + Bc delta delta^T (symmetric), A + Bc r^2 = 1 + bah2, grad_z ladj = -dL_dh h^2 delta / r
-      const T A = (T)1 + qq;
-      const T e = r > (T)0 ? lb * dL_dh * h * h / r : (T)0;
+      const T e = lb * dL_dh * h * h * ir;
       const T dap = yd + lb * dL_dh * h * h * r;
-      const T f2 = r > (T)0 ? (-bh * h * h / r) * dap / ((T)1 + bah2) : (T)0;
+      const T f2 = (-bh * h * h * ir) * dap * ib;
 #pragma unroll
       for (int k = 0; k < DPL; ++k) {
-        v[k] = (g[k] + (e - f2) * z[k]) / A;
+        v[k] = (g[k] + (e - f2) * z[k]) * iq;  // 1 / A, A = 1 + qq
         g[k] = -v[k];
       }
-      yd = -dap / ((T)1 + bah2);
+      yd = -dap * ib;
       lb = -lb;
     }
     const T hbar = bh * yd + lb * dL_dh;
-    const T rbar_over_r = r > (T)0 ? -h * h * hbar / r : (T)0;
+    const T rbar_over_r = -h * h * hbar * ir;
 #pragma unroll
     for (int k = 0; k < DPL; ++k) {
       const T db = qq * g[k] + rbar_over_r * z[k];
@@ -634,14 +760,21 @@ static inline unsigned grid_for(long N, long cap) {
 }
 
 template <class T>
-static int apply_t(nf_ctx *ctx, const SimpleArgs &a0, const void *theta, const void *x, void *y, void *ladj, void *stash) {
+static int apply_t(nf_ctx *ctx, const SimpleArgs &a0, const void *theta, const void *x, void *y, void *ladj, void *stash,
+                   const SimpleFused *fused = nullptr, long *nblocks_out = nullptr) {
   SimpleArgs a = a0;
-  a.vec = vec_ok<T>(a.d, dpl_for(a.d), {x, y, stash});
+  SimpleFused fu{};
+  if (fused) fu = *fused;
+  a.vec = vec_ok<T>(a.d, dpl_for(a.d), {x, y, stash, fu.gbar});
   const size_t lds = (size_t)(a.hi - a.lo) * lp_of(a.d) * sizeof(T);
   ProfScope ps(ctx, "simple_apply");
-#define LAUNCH_APPLY(DPLv)                                                                                          \
-  hipLaunchKernelGGL((k_simple_apply<T, DPLv>), dim3(grid_for(a.N, resident_blocks(ctx, k_simple_apply<T, DPLv>, lds))), \
-                     dim3(SB), lds, ctx->stream, a, (const T *)theta, (const T *)x, (T *)y, (T *)ladj, (T *)stash)
+#define LAUNCH_APPLY(DPLv)                                                                                      \
+  do {                                                                                                          \
+    const unsigned gridv = grid_for(a.N, resident_blocks(ctx, k_simple_apply<T, DPLv>, lds));                   \
+    if (nblocks_out) *nblocks_out = gridv;                                                                      \
+    hipLaunchKernelGGL((k_simple_apply<T, DPLv>), dim3(gridv), dim3(SB), lds, ctx->stream, a, (const T *)theta, \
+                       (const T *)x, (T *)y, (T *)ladj, (T *)stash, fu);                                        \
+  } while (0)
   switch (dpl_for(a.d)) {
     case 1: LAUNCH_APPLY(1); break;
     case 2: LAUNCH_APPLY(2); break;
@@ -687,6 +820,29 @@ int nf_simple_apply_stash(nf_ctx *ctx, const nf_flow_desc *desc, const void *the
   Carver cv(ws);
   if (desc->dtype == NF_DTYPE_F32) return apply_t<float>(ctx, a, theta, x, y, ladj, cv.take<float>((size_t)nl * N * desc->d));
   return apply_t<double>(ctx, a, theta, x, y, ladj, cv.take<double>((size_t)nl * N * desc->d));
+}
+
+// The training step's forward pass in ONE launch (see SimpleFused): xs == nullptr draws in-library.  Leaves the
+// per-layer inputs in `ws` (carving of bwd_t), ybar in gbar, block partials of pscale * elbo_j in partial
+// (*npartial of them; room for nf_simple_elbo_max_partials()).
+long nf_simple_elbo_max_partials(nf_ctx *ctx) { return 16L * ctx->num_cu; }
+int nf_simple_elbo_forward(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, const void *theta, const void *xs,
+                           long N, uint64_t seed, uint64_t off, uint32_t stream_id, void *gbar, double gscale, double *partial,
+                           double pscale, void *ws, long *npartial) {
+  if (N <= 0) return NF_OK;
+  const int nl = desc->kind == NF_KIND_MEANFIELD ? 2 : desc->nlayers;
+  SimpleArgs a = make_sargs(desc, 0, nl, false, N);
+  SimpleFused fu{};
+  fu.on = 1;
+  fu.draw = xs ? 0 : 1;
+  fu.tkind = target->kind;
+  fu.k0 = (uint32_t)seed; fu.k1 = (uint32_t)(seed >> 32); fu.stream = stream_id; fu.off = off;
+  fu.mu = target->p0; fu.var = target->p1; fu.s0 = target->s0; fu.s1 = target->s1;
+  fu.gscale = gscale; fu.pscale = pscale; fu.gbar = gbar; fu.partial = partial;
+  Carver cv(ws);
+  if (desc->dtype == NF_DTYPE_F32)
+    return apply_t<float>(ctx, a, theta, xs, nullptr, nullptr, cv.take<float>((size_t)nl * N * desc->d), &fu, npartial);
+  return apply_t<double>(ctx, a, theta, xs, nullptr, nullptr, cv.take<double>((size_t)nl * N * desc->d), &fu, npartial);
 }
 
 template <class T>

@@ -690,3 +690,32 @@ def test_forward_kl_sharded_local_step_sums_to_the_full_gradient(nf):
         acc += step(flow.theta, off, cnt, n, 0)
     assert float(acc[-1]) == pytest.approx(full_loss, rel=1e-5)
     assert float((acc[:-1] - full_g).abs().max()) <= 1e-4 * max(1.0, float(full_g.abs().max()))
+
+
+@pytest.mark.parametrize("kind,d", [("planar", 2), ("planar", 5), ("radial", 7), ("planar", 33), ("radial", 64), ("planar", 100), ("meanfield", 4)])
+@pytest.mark.parametrize("dtn", ["float32", "float64"])
+def test_fused_simple_training_forward_draws_match_supplied_draws(nf, kind, d, dtn):
+    """The planar / radial / mean-field training step draws its base samples inside the chain kernel (Philox counters
+    of (global sample index, feature group of four, stream)); the same step on caller-supplied draws from the same
+    RNG state, and a shard of it at a sample offset, must agree -- every lanes-per-feature layout (d = 2 ... 100)."""
+    dt = tdt(dtn)
+    f64 = dt == torch.float64
+    nl = 1 if kind == "meanfield" else 3
+    spec = o.FlowSpec(kind, d, nl)
+    rng = np.random.default_rng(d)
+    th = o.init_params(spec, rng) * (0.3 if kind != "meanfield" else 1.0) + (0.2 * rng.standard_normal(o.param_count(spec)) if kind == "meanfield" else 0.0)
+    flow = nf.Flow(kind, nf.MvNormal(d), nl, dtype=dt, device="cuda", theta=torch.tensor(th, dtype=dt, device="cuda"))
+    mu, var = rng.standard_normal(d), rng.uniform(size=d) + 0.5
+    tgt = nf.DiagGaussTarget(torch.tensor(mu, dtype=dt, device="cuda"), torch.tensor(var, dtype=dt, device="cuda"))
+    n = 77
+    r1 = nf.PhiloxRNG(11)
+    l_in, g_in = nf.value_and_gradient(nf.elbo_batch, flow, tgt, n, rng=r1)
+    r2 = nf.PhiloxRNG(11)
+    xs = nf.device_specific_rand(r2, flow.dist, n, dtype=dt)
+    l_xs, g_xs = nf.value_and_gradient(nf.elbo_batch, flow, tgt, xs)
+    tol = 1e-12 if f64 else 2e-6
+    assert l_in == pytest.approx(l_xs, rel=tol, abs=tol)
+    assert float((g_in - g_xs).abs().max()) <= tol * max(1.0, float(g_xs.abs().max()))
+    lr, gr = o.neg_elbo_value_and_grad(spec, th, ("diaggauss", mu, var), xs.cpu().numpy().astype(np.float64))
+    assert l_xs == pytest.approx(lr, rel=1e-10 if f64 else 2e-5)
+    assert np.abs(g_xs.cpu().numpy() - gr).max() <= (1e-9 if f64 else 2e-4) * max(1.0, np.abs(gr).max())

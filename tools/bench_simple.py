@@ -40,8 +40,10 @@ for kind in ("planar", "radial"):
     step(20)
     torch.cuda.synchronize()
     row = N * d * 4
-    need = {"base_sample": row + 4 * N, "simple_apply": row * (1 + nl + 1) + 4 * N, "target": 2 * row + 12 * N,
-            "simple_bwd": nl * 3 * row}
+    lpp = 4  # layers per pass of the reverse kernel (float, d = 64)
+    # fused forward: the per-layer inputs (stash) and ybar are written, nothing is read;
+    # reverse: every layer's input once, gbar read + written once per pass of `lpp` layers
+    need = {"simple_apply": row * (nl + 1), "simple_bwd": row * (nl + 2 * -(-nl // lpp))}
     print(f"{kind} d={d} layers={nl} N={N}: {1e3 * el:.3f} ms/step = {N / el / 1e6:.1f} M samples/s, loss {float(out[-1]):.4f}")
     for name, b in need.items():
         a, c = C.c_double(0.0), C.c_int64(0)
