@@ -553,7 +553,7 @@ struct BwdCfg {
 // order (deterministic).  Raw parameter sums go to slabs[layer][block][LP] (layout: layer_bwd).
 // INV: the inverse chain's reverse pass -- layers in forward execution order, see layer_bwd.
 template <class T, int DPL, bool INV>
-__global__ __launch_bounds__(SB) void k_simple_bwd_layers(SimpleArgs a, int nl, const T *__restrict__ theta,
+__global__ __launch_bounds__(SB, (DPL * (int)sizeof(T) <= 16 ? 4 : 1)) void k_simple_bwd_layers(SimpleArgs a, int nl, const T *__restrict__ theta,
                                                           const T *__restrict__ stash, long stash_stride,
                                                           T *__restrict__ gbar, const T *__restrict__ lbar, T lbar_const,
                                                           T *__restrict__ slabs, long slab_stride) {
@@ -645,19 +645,33 @@ __global__ __launch_bounds__(SB) void k_simple_bwd_layers(SimpleArgs a, int nl, 
 }
 
 // sums the per-block slabs of every layer and applies the parameter-space chain rule
-// (get_u_hat for planar, softplus re-parameterisation for radial).  One block per layer.
+// (get_u_hat for planar, softplus re-parameterisation for radial).  One block of FB threads per layer: FB / 64
+// row groups each sum every (FB/64)-th slab with 64 consecutive columns per wave (coalesced, independent loads),
+// then the row groups are added in a fixed order (deterministic).
+#define FB 512
 template <class T>
-__global__ __launch_bounds__(SB) void k_simple_finalize(SimpleArgs a, const T *__restrict__ theta,
+__global__ __launch_bounds__(FB) void k_simple_finalize(SimpleArgs a, const T *__restrict__ theta,
                                                         const T *__restrict__ slabs, int nblk_bwd,
                                                         T *__restrict__ gtheta) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int d = a.d, LP = lp_of(d);
   T *sum = (T *)smem;  // LP
+  T *red = sum + LP;   // [FB / 64][LP]
+  constexpr int RG = FB / 64;
   const int l = blockIdx.x;
   const T *sl = slabs + (long)l * nblk_bwd * LP;
-  for (int s = threadIdx.x; s < 2 * d + 2; s += SB) {
+  const int rg = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int s = lane; s < 2 * d + 2; s += 64) {
     T v = 0;
-    for (int b = 0; b < nblk_bwd; ++b) v += sl[(long)b * LP + s];
+#pragma unroll 4
+    for (int b = rg; b < nblk_bwd; b += RG) v += sl[(long)b * LP + s];
+    red[rg * LP + s] = v;
+  }
+  __syncthreads();
+  for (int s = threadIdx.x; s < 2 * d + 2; s += FB) {
+    T v = 0;
+#pragma unroll
+    for (int r = 0; r < RG; ++r) v += red[r * LP + s];
     sum[s] = v;
   }
   __syncthreads();
@@ -679,22 +693,22 @@ __global__ __launch_bounds__(SB) void k_simple_finalize(SimpleArgs a, const T *_
     const T m = (T)sc[0], ww = (T)sc[1], uw = (T)sc[2];
     const T sg = sigmoid_(m), spn = softplus_(-m) - (T)1;
     const T mbar = sum[2 * d + 1] * sg + uw * (sg - (T)1) / ww;
-    for (int i = threadIdx.x; i < d; i += SB) {
+    for (int i = threadIdx.x; i < d; i += FB) {
       const T ub = sum[d + i];
       g[i] = sum[i] + mbar * p[d + i] + spn * (ub / ww - (T)2 * uw * p[i] / (ww * ww));
       g[d + i] = ub + mbar * p[i];
     }
     if (threadIdx.x == 0) g[2 * d] = sum[2 * d];
   } else if (lk == LK_RADIAL) {
-    for (int i = threadIdx.x; i < d; i += SB) g[2 + i] = sum[i];
+    for (int i = threadIdx.x; i < d; i += FB) g[2 + i] = sum[i];
     if (threadIdx.x == 0) {
       g[0] = (sum[2 * d] - sum[2 * d + 1]) * sigmoid_(p[0]);
       g[1] = sum[2 * d + 1] * sigmoid_(p[1]);
     }
   } else if (lk == LK_SHIFT) {
-    for (int i = threadIdx.x; i < d; i += SB) g[i] = sum[i];
+    for (int i = threadIdx.x; i < d; i += FB) g[i] = sum[i];
   } else {
-    for (int i = threadIdx.x; i < d; i += SB) g[i] = sum[i] + sum[2 * d] / p[i];
+    for (int i = threadIdx.x; i < d; i += FB) g[i] = sum[i] + sum[2 * d] / p[i];
   }
 }
 
@@ -894,7 +908,8 @@ static int bwd_t(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const
 #undef LAUNCH_BWD_V
     NF_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL(k_simple_finalize<T>, dim3(nl), dim3(SB), LP * sizeof(T), ctx->stream, a, (const T *)theta,
+  ProfScope pf(ctx, "simple_finalize");
+  hipLaunchKernelGGL(k_simple_finalize<T>, dim3(nl), dim3(FB), (size_t)(1 + FB / 64) * LP * sizeof(T), ctx->stream, a, (const T *)theta,
                      (const T *)slabs, nb_used, (T *)gtheta_out);
   return (int)hipGetLastError();
 }

@@ -50,4 +50,9 @@ for kind in ("planar", "radial"):
         lib.nf_prof_read(ctx.ptr, name.encode(), C.byref(a), C.byref(c))
         if c.value:
             print(f"   {name:13s} {1e3 * a.value:8.1f} us  {b / 1e6:8.1f} MB  -> {b / (a.value * 1e-3) / 1e12:.2f} TB/s ({b / (a.value * 1e-3) / 8e12:.0%} of 8 TB/s)")
+    for name in (b"simple_finalize", b"finish_sum"):
+        a, c = C.c_double(0.0), C.c_int64(0)
+        lib.nf_prof_read(ctx.ptr, name, C.byref(a), C.byref(c))
+        if c.value:
+            print(f"   {name.decode():13s} {1e3 * a.value:8.1f} us")
     lib.nf_prof_enable(ctx.ptr, 0)
