@@ -520,6 +520,14 @@ static int elbo_forward(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *
     NF_TRY(coupling_chain_tiled(ctx, desc, false, (const float *)theta, xt, N, (float *)ladj, -1));
     NF_TRY(nf_launch_target_tiled(ctx, target, desc->d, N, xt, (const float *)logq, (const float *)ladj, nullptr, 0.0,
                                   (float *)elbos_out, partial, 1.0 / (double)N));
+  } else if (!elbos_out && !is_g64(desc) && desc->kind != NF_KIND_HAMILTONIAN) {
+    // planar / radial / mean-field, value only: draws (or xs), chain, target and ELBO sums in one launch
+    NF_TRY(nf_target_check(target, desc->d));
+    long np = 0;
+    NF_TRY(nf_simple_elbo_forward(ctx, desc, target, theta, xs, N, seed, off, stream_id, nullptr, 0.0, partial, 1.0 / (double)N,
+                                  nullptr, &np));
+    NF_TRY(nf_launch_finish_sum(ctx, partial, np, 0, result, nullptr, nullptr));
+    return read_scalar(ctx, result, elbo_host);
   } else {
     if (xs) {
       NF_HIP(hipMemcpyAsync(x, xs, (size_t)N * desc->d * es, hipMemcpyDeviceToDevice, ctx->stream));

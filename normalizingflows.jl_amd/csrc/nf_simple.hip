@@ -25,12 +25,33 @@
 
 enum { LK_PLANAR = 0, LK_RADIAL = 1, LK_SHIFT = 2, LK_SCALE = 3 };
 
+// Sum over the 16 lanes of a sample (= one DPP row), result in every lane: four DPP-modified moves / adds
+// (lane ^ 1, lane ^ 2 by quad_perm, then row_half_mirror and row_mirror) -- no LDS crossbar (ds_bpermute) and no
+// waitcnt in the per-layer dependency chain.
+__device__ __forceinline__ int dpp_quad_x1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false); }  // [1,0,3,2]
+__device__ __forceinline__ int dpp_quad_x2(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false); }  // [2,3,0,1]
+__device__ __forceinline__ int dpp_half_mirror(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false); }
+__device__ __forceinline__ int dpp_row_mirror(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false); }
+template <int STEP>
+__device__ __forceinline__ int dpp_step(int v) {
+  return STEP == 0 ? dpp_quad_x1(v) : STEP == 1 ? dpp_quad_x2(v) : STEP == 2 ? dpp_half_mirror(v) : dpp_row_mirror(v);
+}
+template <int STEP>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, dpp_step<STEP>(__builtin_bit_cast(int, v)));
+}
+template <int STEP>
+__device__ __forceinline__ double dpp_add(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const unsigned lo = (unsigned)dpp_step<STEP>((int)(unsigned)b), hi = (unsigned)dpp_step<STEP>((int)(unsigned)(b >> 32));
+  return v + __builtin_bit_cast(double, (long long)(((unsigned long long)hi << 32) | lo));
+}
 template <class T>
 __device__ __forceinline__ T g16sum(T v) {
-  v += __shfl_xor(v, 8, 16);
-  v += __shfl_xor(v, 4, 16);
-  v += __shfl_xor(v, 2, 16);
-  v += __shfl_xor(v, 1, 16);
+  v = dpp_add<0>(v);
+  v = dpp_add<1>(v);
+  v = dpp_add<2>(v);
+  v = dpp_add<3>(v);
   return v;
 }
 template <class T>
@@ -396,7 +417,7 @@ __global__ __launch_bounds__(SB) void k_simple_apply(SimpleArgs a, const T *__re
         default: run(std::integral_constant<int, NF_TARGET_CROSS>{}); break;
       }
       acc = g16sum(acc);
-      row_store<T, DPL>((T *)fu.gbar + j * d, i0, d, vec, gr);
+      if (fu.gbar) row_store<T, DPL>((T *)fu.gbar + j * d, i0, d, vec, gr);
       if (q == 0) contrib += fu.pscale * (double)(acc - logq + lsum);
     }
   }
@@ -853,10 +874,13 @@ int nf_simple_elbo_forward(nf_ctx *ctx, const nf_flow_desc *desc, const nf_targe
   fu.k0 = (uint32_t)seed; fu.k1 = (uint32_t)(seed >> 32); fu.stream = stream_id; fu.off = off;
   fu.mu = target->p0; fu.var = target->p1; fu.s0 = target->s0; fu.s1 = target->s1;
   fu.gscale = gscale; fu.pscale = pscale; fu.gbar = gbar; fu.partial = partial;
+  // ws == nullptr (ELBO value only): no per-layer inputs are kept
   Carver cv(ws);
   if (desc->dtype == NF_DTYPE_F32)
-    return apply_t<float>(ctx, a, theta, xs, nullptr, nullptr, cv.take<float>((size_t)nl * N * desc->d), &fu, npartial);
-  return apply_t<double>(ctx, a, theta, xs, nullptr, nullptr, cv.take<double>((size_t)nl * N * desc->d), &fu, npartial);
+    return apply_t<float>(ctx, a, theta, xs, nullptr, nullptr, ws ? cv.take<float>((size_t)nl * N * desc->d) : nullptr, &fu,
+                          npartial);
+  return apply_t<double>(ctx, a, theta, xs, nullptr, nullptr, ws ? cv.take<double>((size_t)nl * N * desc->d) : nullptr, &fu,
+                         npartial);
 }
 
 template <class T>
