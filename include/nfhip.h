@@ -132,6 +132,12 @@ int nf_flow_fwd(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const 
  * src/flows/neuralspline.jl:134-140; reached from loglikelihood.jl:31 via logpdf). */
 int nf_flow_inv(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *y_in,
                 int64_t N, void *x_out, void *ladj_out);
+/* rand(rng, flow, n) / _device_specific_rand(rng, flow, n)  (src/NormalizingFlows.jl:117-127; the CUDA extension's
+ * per-column version: ext/NormalizingFlowsCUDAExt.jl:61-74): N base draws -- the same Philox stream
+ * nf_base_sample_logpdf(seed, sample_offset, stream_id) produces -- pushed through the transform, batched.
+ * Planar / radial / mean-field flows do it in one launch (draws in registers); y_out is d x N. */
+int nf_flow_rand(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, int64_t N, uint64_t seed,
+                 uint64_t sample_offset, uint32_t stream_id, void *y_out);
 /* One bijector layer, `layer` in FLAT order (0 = L1, the outermost / last applied):
  * Bijectors.with_logabsdet_jacobian(layer, x)  (src/flows/realnvp.jl:77-83,
  * src/flows/neuralspline.jl:102-108).  inverse != 0 selects Inverse{layer}.

@@ -66,6 +66,7 @@ SYMBOLS = {
     "nf_base_logpdf": (C.c_int, [_P, _I32, _I32, _I64, _P, _P]),
     "nf_flow_fwd": (C.c_int, [_P, _DESC, _P, _P, _I64, _P, _P]),
     "nf_flow_inv": (C.c_int, [_P, _DESC, _P, _P, _I64, _P, _P]),
+    "nf_flow_rand": (C.c_int, [_P, _DESC, _P, _I64, _U64, _U64, _U32, _P]),
     "nf_layer_apply": (C.c_int, [_P, _DESC, _I32, _I32, _P, _P, _I64, _P, _P]),
     "nf_flow_bwd": (C.c_int, [_P, _DESC, _P, _P, _P, _P, _P, _I64, _P, _P]),
     "nf_target_logp": (C.c_int, [_P, _I32, _TGT, _I32, _I64, _P, _P, _P]),

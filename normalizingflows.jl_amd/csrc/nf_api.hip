@@ -82,6 +82,8 @@ int nf_simple_elbo_forward(nf_ctx *, const nf_flow_desc *, const nf_target *, co
                            uint64_t seed, uint64_t off, uint32_t stream_id, void *gbar, double gscale, double *partial,
                            double pscale, void *ws, long *npartial);
 int nf_target_check(const nf_target *t, int d);
+int nf_simple_rand(nf_ctx *, const nf_flow_desc *, const void *theta, long N, uint64_t seed, uint64_t off, uint32_t stream_id,
+                   void *y);
 
 // general coupling kernels (nf_generic64.hip): Float64, and the Float32 shapes the MFMA paths do not
 // build; one thread per sample, standard layout
@@ -395,6 +397,30 @@ extern "C" int nf_flow_inv(nf_ctx *ctx, const nf_flow_desc *desc, const void *th
   NF_TRY(check_desc(desc));
   NF_HIP(hipSetDevice(ctx->device));
   return apply_std(ctx, desc, true, -1, theta, y_in, N, x_out, ladj_out);
+}
+
+// rand(rng, flow, n) / _device_specific_rand(rng, flow, n): N base draws (Philox, as nf_base_sample_logpdf with the
+// same seed / offset / stream) pushed through the transform
+extern "C" int nf_flow_rand(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, int64_t N, uint64_t seed,
+                            uint64_t sample_offset, uint32_t stream_id, void *y_out) {
+  if (!ctx || !theta || !y_out || N < 0) return NF_ERR_ARG;
+  NF_TRY(check_desc(desc));
+  NF_HIP(hipSetDevice(ctx->device));
+  if (N == 0) return NF_OK;
+  if (is_coupling(desc)) {
+    NF_TRY(nf_ws_reserve(ctx, carve_bytes(tiled_elems(desc, N) * 4) + carve_bytes((size_t)N * 4)));
+    Carver cv(ctx->ws);
+    float *xt = cv.take<float>(tiled_elems(desc, N));
+    float *ladj = cv.take<float>((size_t)N);
+    NF_TRY(nf_launch_base_sample_tiled(ctx, desc->d, N, seed, sample_offset, stream_id, xt, nullptr));
+    NF_TRY(coupling_chain_tiled(ctx, desc, false, (const float *)theta, xt, N, ladj, -1));
+    return nf_launch_layout_convert(ctx, desc->d, N, xt, (float *)y_out, 0);
+  }
+  if (!is_g64(desc) && desc->kind != NF_KIND_HAMILTONIAN)
+    return nf_simple_rand(ctx, desc, theta, N, seed, sample_offset, stream_id, y_out);
+  NF_TRY(nf_ws_reserve(ctx, carve_bytes((size_t)N * esize(desc->dtype))));
+  NF_TRY(nf_launch_base_sample(ctx, desc->dtype, desc->d, N, seed, sample_offset, stream_id, y_out, nullptr));
+  return flat_apply(ctx, desc, 0, nf_layer_count(desc), false, theta, y_out, N, y_out, ctx->ws);
 }
 
 extern "C" int nf_layer_apply(nf_ctx *ctx, const nf_flow_desc *desc, int32_t layer, int32_t inverse, const void *theta,

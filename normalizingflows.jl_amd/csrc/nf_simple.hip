@@ -257,6 +257,10 @@ __device__ __forceinline__ T layer_inverse(int lk, const T *c, int d, int i0, bo
 #pragma unroll
     for (int k = 0; k < DPL; ++k) dot += p0[k] * z[k];
     const T wy = g16sum(dot), b = c[2 * d], sp = c[2 * d + 1], cc = sp - (T)1;
+    // f(al) = al + c tanh(al + b) - w'y is increasing (f' = (1+c) sech^2 + tanh^2 > 0), root in [w'y - |c|, w'y + |c|]:
+    // a fixed bisection schedule, then two Newton steps.  (A bracketed Newton with a wave-uniform early exit was
+    // tried: Newton 2-cycles that stay inside the bracket for large c > 0 need the full rtsafe step test, and with it
+    // the average iteration count in Float64 is no better than this schedule.)
     T lo = wy - fabs(cc), hi = wy + fabs(cc);
     const int iters = sizeof(T) == 8 ? 64 : 40;
     for (int it = 0; it < iters; ++it) {
@@ -369,7 +373,7 @@ __global__ __launch_bounds__(SB) void k_simple_apply(SimpleArgs a, const T *__re
   // a 16-lane group shares j, so it is converged for the shuffles
   for (long j = (long)blockIdx.x * SPB + threadIdx.x / LPS; j < a.N; j += (long)gridDim.x * SPB) {
     T z[DPL];
-    if (fu.on && fu.draw) draw_row<T, DPL>(fu, j, i0, d, z);
+    if (fu.draw) draw_row<T, DPL>(fu, j, i0, d, z);
     else row_load<T, DPL>(x + j * d, i0, d, vec, z);
     T logq = 0;
     if (fu.on) {
@@ -881,6 +885,20 @@ int nf_simple_elbo_forward(nf_ctx *ctx, const nf_flow_desc *desc, const nf_targe
                           npartial);
   return apply_t<double>(ctx, a, theta, xs, nullptr, nullptr, ws ? cv.take<double>((size_t)nl * N * desc->d) : nullptr, &fu,
                          npartial);
+}
+
+// rand(rng, flow, n): the base draws are generated in the chain kernel's registers and pushed through the
+// transform -- one launch, only the samples are written
+int nf_simple_rand(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, long N, uint64_t seed, uint64_t off,
+                   uint32_t stream_id, void *y) {
+  if (N <= 0) return NF_OK;
+  const int nl = desc->kind == NF_KIND_MEANFIELD ? 2 : desc->nlayers;
+  SimpleArgs a = make_sargs(desc, 0, nl, false, N);
+  SimpleFused fu{};
+  fu.draw = 1;
+  fu.k0 = (uint32_t)seed; fu.k1 = (uint32_t)(seed >> 32); fu.stream = stream_id; fu.off = off;
+  if (desc->dtype == NF_DTYPE_F32) return apply_t<float>(ctx, a, theta, nullptr, y, nullptr, nullptr, &fu);
+  return apply_t<double>(ctx, a, theta, nullptr, y, nullptr, nullptr, &fu);
 }
 
 template <class T>

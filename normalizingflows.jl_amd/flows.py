@@ -91,8 +91,13 @@ def device_specific_rand(rng: PhiloxRNG, dist, n: Optional[int] = None, *, devic
     `dist` is an MvNormal base or a Flow (then base draws are pushed through the transform,
     as rand(td, n) does)."""
     if isinstance(dist, Flow):
-        xs = device_specific_rand(rng, dist.dist, n, device=dist.theta.device, dtype=dist.theta.dtype)
-        return dist.transform(xs)
+        flow = dist
+        nn = 1 if n is None else int(n)
+        y = new_batch(flow.dist.d, nn, flow.theta.dtype, flow.theta.device)
+        ctx = flow.ctx
+        check(ctx.lib.nf_flow_rand(ctx.ptr, C.byref(flow.desc), _ptr(flow.theta), nn, rng.seed, rng.sample_offset,
+                                   rng.next_stream(), _ptr(y)))
+        return y[:, 0] if n is None else y
     device = torch.device(device if device is not None else "cuda")
     nn = 1 if n is None else int(n)
     x = new_batch(dist.d, nn, dtype, device)

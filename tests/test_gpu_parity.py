@@ -719,3 +719,31 @@ def test_fused_simple_training_forward_draws_match_supplied_draws(nf, kind, d, d
     lr, gr = o.neg_elbo_value_and_grad(spec, th, ("diaggauss", mu, var), xs.cpu().numpy().astype(np.float64))
     assert l_xs == pytest.approx(lr, rel=1e-10 if f64 else 2e-5)
     assert np.abs(g_xs.cpu().numpy() - gr).max() <= (1e-9 if f64 else 2e-4) * max(1.0, np.abs(gr).max())
+
+
+@pytest.mark.parametrize("maker", ["planar5", "radial64", "planar100_f64", "realnvp5", "nsf5", "realnvp5_f64", "wide"])
+def test_rand_flow_is_transform_of_base_draws(nf, maker):
+    """rand(rng, flow, n) / _device_specific_rand(rng, flow, n) (src/NormalizingFlows.jl:117-127): the batched, fused
+    sampler (nf_flow_rand) returns exactly the base draws of the same RNG state pushed through the transform."""
+    mk = {
+        "planar5": lambda: nf.planarflow(nf.MvNormal(5), 4, paramtype=torch.float32, seed=1),
+        "radial64": lambda: nf.radialflow(nf.MvNormal(64), 3, paramtype=torch.float32, seed=2),
+        "planar100_f64": lambda: nf.planarflow(nf.MvNormal(100), 2, paramtype=torch.float64, seed=3),
+        "realnvp5": lambda: nf.realnvp(nf.MvNormal(5), [32, 32], 2, paramtype=torch.float32, seed=4),
+        "nsf5": lambda: nf.nsf(nf.MvNormal(5), [32, 32], 10, 5.0, 2, paramtype=torch.float32, seed=5),
+        "realnvp5_f64": lambda: nf.realnvp(nf.MvNormal(5), [16], 1, paramtype=torch.float64, seed=6),
+        "wide": lambda: nf.realnvp(nf.MvNormal(100), [96, 130], 1, paramtype=torch.float32, seed=7),
+    }
+    flow = mk[maker]()
+    if maker.startswith("planar") or maker.startswith("radial"):
+        with torch.no_grad():
+            flow.theta.mul_(0.3)
+    n = 131
+    ys = nf.rand(flow, n, nf.PhiloxRNG(21))
+    xs = nf.device_specific_rand(nf.PhiloxRNG(21), flow.dist, n, dtype=flow.theta.dtype)
+    ref = flow.transform(xs)
+    assert ys.shape == (flow.dist.d, n) and ys.dtype == flow.theta.dtype
+    tol = 1e-13 if flow.theta.dtype == torch.float64 else 1e-6
+    assert float((ys - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
+    v = nf.rand(flow, None, nf.PhiloxRNG(22))  # a single draw is a vector
+    assert v.shape == (flow.dist.d,)

@@ -56,3 +56,27 @@ for kind in ("planar", "radial"):
         if c.value:
             print(f"   {name.decode():13s} {1e3 * a.value:8.1f} us")
     lib.nf_prof_enable(ctx.ptr, 0)
+    # density evaluation / forward-KL side: logpdf(flow, ys) on the flow's own samples, then one forward-KL training step
+    ys = nf.rand(flow, N, nf.PhiloxRNG(5))
+    torch.cuda.synchronize()
+    for name, fn in (("rand(flow, n)", lambda: nf.rand(flow, N, nf.PhiloxRNG(5))),
+                     ("loglikelihood", lambda: nf.loglikelihood(None, flow, ys)),
+                     ("forward-KL step", lambda: nf.loglikelihood_value_and_gradient(flow, ys))):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        el2 = (time.perf_counter() - t0) / 5
+        lib.nf_prof_enable(ctx.ptr, 2)
+        fn()
+        torch.cuda.synchronize()
+        parts = []
+        for kn in (b"base_sample", b"base_logpdf", b"simple_apply", b"target", b"sum2", b"simple_bwd", b"simple_finalize", b"finish_sum"):
+            a, c = C.c_double(0.0), C.c_int64(0)
+            lib.nf_prof_read(ctx.ptr, kn, C.byref(a), C.byref(c))
+            if c.value:
+                parts.append(f"{kn.decode()} {1e3 * a.value:.0f}us" + (f" x{c.value}" if c.value > 1 else ""))
+        lib.nf_prof_enable(ctx.ptr, 0)
+        print(f"   {name:16s} {1e3 * el2:8.3f} ms = {N / el2 / 1e6:7.1f} M samples/s   [{', '.join(parts)}]")
