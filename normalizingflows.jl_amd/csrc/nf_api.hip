@@ -106,6 +106,9 @@ size_t nf_hf_bwd_ws_bytes(const nf_flow_desc *desc, long N);
 int nf_hf_bwd(nf_ctx *, const nf_flow_desc *, const void *theta, const void *x, const void *ybar, const void *lbar,
               double lbar_const, long N, void *xbar_out, void *gtheta_out, void *ws);
 
+int nf_hf_bwd_inv(nf_ctx *, const nf_flow_desc *, const void *theta, const void *u, const void *gbar, double lbar_const,
+                  long N, void *gtheta_out, void *ws);
+
 // ---- helpers -----------------------------------------------------------------------------
 static inline size_t esize(int dtype) { return dtype == NF_DTYPE_F64 ? 8 : 4; }
 
@@ -626,7 +629,6 @@ extern "C" int nf_loglikelihood_value_and_grad(nf_ctx *ctx, const nf_flow_desc *
                                                int64_t N_local, int64_t N_global, void *out) {
   if (!ctx || !theta || !out || N_local < 0 || N_global < 1 || (N_local > 0 && !ys)) return NF_ERR_ARG;
   NF_TRY(check_desc(desc));
-  if (desc->kind == NF_KIND_HAMILTONIAN) return NF_ERR_UNSUPPORTED;
   NF_HIP(hipSetDevice(ctx->device));
   const long N = N_local;
   const long P = nf_param_count(desc);
@@ -635,12 +637,14 @@ extern "C" int nf_loglikelihood_value_and_grad(nf_ctx *ctx, const nf_flow_desc *
   if (N == 0) return nf_launch_fill(ctx, dt, out, P + 1, 0.0);
   const double inv = 1.0 / (double)N_global;
   const bool coupling_kind = desc->kind == NF_KIND_REALNVP || desc->kind == NF_KIND_NSF;
+  const bool hf = desc->kind == NF_KIND_HAMILTONIAN;
   const bool tiled = is_coupling(desc) && coupling_inv_bwd_tiled(desc);
   if (coupling_kind && !tiled && !nf_g64_supported(desc)) return NF_ERR_UNSUPPORTED;
   const long nb = tiled ? nf_target_tiled_nblocks(N) : nf_target_nblocks(N);
   const int grid = tiled ? coupling_bwd_grid(ctx, desc, N) : 0;
   const size_t slabf = tiled ? (size_t)grid * coupling_slab_floats(ctx, desc, N) : 0;
-  const size_t flat_ws = tiled ? 0 : coupling_kind ? nf_g64_bwd_inv_ws_bytes(desc, N) : nf_simple_bwd_ws_bytes(ctx, desc, N);
+  const size_t flat_ws = tiled ? 0 : hf ? nf_hf_bwd_ws_bytes(desc, N) : coupling_kind ? nf_g64_bwd_inv_ws_bytes(desc, N)
+                                                                                       : nf_simple_bwd_ws_bytes(ctx, desc, N);
   const size_t xe = tiled ? tiled_elems(desc, N) : (size_t)N * desc->d;
   const size_t need = 2 * carve_bytes(xe * es) + carve_bytes((size_t)N * es) + carve_bytes((size_t)nb * 8) +
                       carve_bytes(2 * (size_t)desc->d * es) + carve_bytes(slabf * es) + carve_bytes(flat_ws);
@@ -669,7 +673,11 @@ extern "C" int nf_loglikelihood_value_and_grad(nf_ctx *ctx, const nf_flow_desc *
     NF_TRY(nf_launch_finish_sum(ctx, partial, nb, 0, nullptr, (float *)out + P, nullptr));
     return coupling_inv_bwd(ctx, desc, (const float *)theta, zt, gt, (float)(-inv), N, (float *)slab, grid, (float *)out);
   }
-  if (coupling_kind) {
+  if (hf) {  // every inverse layer of the Hamiltonian flow is explicit: differentiated directly (nf_hamiltonian.hip)
+    NF_TRY(nf_hf_apply(ctx, desc, 0, nf_layer_count(desc), true, theta, ys, N, z, ladj));
+    NF_TRY(nf_launch_target(ctx, dt, &q0, desc->d, N, z, nullptr, ladj, nullptr, gbar, -inv, nullptr, partial, -inv, 0));
+    NF_TRY(nf_hf_bwd_inv(ctx, desc, theta, ys, gbar, -inv, N, out, fws));
+  } else if (coupling_kind) {
     NF_TRY(nf_g64_apply(ctx, desc, 0, nf_layer_count(desc), true, theta, ys, N, z, ladj));
     NF_TRY(nf_launch_target(ctx, dt, &q0, desc->d, N, z, nullptr, ladj, nullptr, gbar, -inv, nullptr, partial, -inv, 0));
     NF_TRY(nf_g64_bwd_inv(ctx, desc, theta, z, gbar, -inv, N, out, fws));

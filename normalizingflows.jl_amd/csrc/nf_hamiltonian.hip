@@ -138,6 +138,39 @@ __global__ __launch_bounds__(HF_BLOCK) void k_hf_apply(HfArgs a, int lo, int hi,
   ladj[j] = ls;
 }
 
+// Reverse pass of hf_leapfrog (either time direction: eps carries the sign) from its recorded states tr:
+// (xb, vb) = cotangents of (x_L, v_L) on entry, of (x_0, rho) on exit; ebar = d/d eps (per dimension).
+template <class T>
+__device__ void hf_leapfrog_bwd(const HfArgs &a, const T *eps, T *tr, T *xb, T *vb, T *ebar) {
+  const int D = a.D, L = a.L;
+  T tmp[HF_MAXD], hv[HF_MAXD];
+  auto V = [&](int s, int i) { return tr[(s * 3 + 1) * HF_MAXD + i]; };
+  auto G = [&](int s, int i) { return tr[(s * 3 + 2) * HF_MAXD + i]; };
+  // v_L = v_{L-1} + eps/2 g(x_L);  x_L = x_{L-1} + eps v_{L-1}
+  for (int i = 0; i < D; ++i) tmp[i] = eps[i] / (T)2 * vb[i];
+  hf_hvp<T>(a, &tr[(L * 3 + 0) * HF_MAXD], tmp, hv);
+  for (int i = 0; i < D; ++i) {
+    xb[i] += hv[i];
+    ebar[i] += vb[i] * G(L, i) / (T)2 + xb[i] * V(L - 1, i);
+    vb[i] += eps[i] * xb[i];
+  }
+  for (int s = L - 1; s >= 1; --s) {  // v_s = v_{s-1} + eps g(x_s);  x_s = x_{s-1} + eps v_{s-1}
+    for (int i = 0; i < D; ++i) tmp[i] = eps[i] * vb[i];
+    hf_hvp<T>(a, &tr[(s * 3 + 0) * HF_MAXD], tmp, hv);
+    for (int i = 0; i < D; ++i) {
+      xb[i] += hv[i];
+      ebar[i] += vb[i] * G(s, i) + xb[i] * V(s - 1, i);
+      vb[i] += eps[i] * xb[i];
+    }
+  }
+  for (int i = 0; i < D; ++i) tmp[i] = eps[i] / (T)2 * vb[i];  // v_0 = rho + eps/2 g(x_0)
+  hf_hvp<T>(a, &tr[0], tmp, hv);
+  for (int i = 0; i < D; ++i) {
+    xb[i] += hv[i];
+    ebar[i] += vb[i] * G(0, i) / (T)2;
+  }
+}
+
 // reverse pass of the whole chain at the flow INPUT x0: ybar -> xbar (in gbar), dL/dtheta added to g.
 // ws: [n][N][2D] inputs of every block (written here).
 template <class T>
@@ -158,7 +191,7 @@ __global__ __launch_bounds__(HF_BLOCK) void k_hf_bwd(HfArgs a, const T *__restri
     hf_leapfrog<T>(a, leps, (T)1, z, z + D, nullptr);
     for (int i = 0; i < D; ++i) z[D + i] = shr[i] + scr[i] * z[D + i];
   }
-  T zb[2 * HF_MAXD], tr[(HF_MAXL + 1) * 3 * HF_MAXD], eps[HF_MAXD], ebar[HF_MAXD], tmp[HF_MAXD], hv[HF_MAXD];
+  T zb[2 * HF_MAXD], tr[(HF_MAXL + 1) * 3 * HF_MAXD], eps[HF_MAXD], ebar[HF_MAXD];
   for (int i = 0; i < d2; ++i) zb[i] = gbar[j * d2 + i];
   for (int bi = 0; bi < n; ++bi) {  // reverse of execution order
     const long o0 = 4 * D + 3 * D * bi;
@@ -174,40 +207,68 @@ __global__ __launch_bounds__(HF_BLOCK) void k_hf_bwd(HfArgs a, const T *__restri
       atomicAdd(g + o0 + D + i, vb[i] * z[D + i] + lb / scr[i]);  // scale_rho (+ d ladj / d scale)
       vb[i] *= scr[i];
     }
-    auto X = [&](int s, int i) { return tr[(s * 3 + 0) * HF_MAXD + i]; };
-    auto V = [&](int s, int i) { return tr[(s * 3 + 1) * HF_MAXD + i]; };
-    auto G = [&](int s, int i) { return tr[(s * 3 + 2) * HF_MAXD + i]; };
-    // v_L = v_{L-1} + eps/2 g(x_L);  x_L = x_{L-1} + eps v_{L-1}
-    for (int i = 0; i < D; ++i) tmp[i] = eps[i] / (T)2 * vb[i];
-    hf_hvp<T>(a, &tr[(L * 3 + 0) * HF_MAXD], tmp, hv);
-    for (int i = 0; i < D; ++i) {
-      xb[i] += hv[i];
-      ebar[i] += vb[i] * G(L, i) / (T)2 + xb[i] * V(L - 1, i);
-      vb[i] += eps[i] * xb[i];
-    }
-    for (int s = L - 1; s >= 1; --s) {  // v_s = v_{s-1} + eps g(x_s);  x_s = x_{s-1} + eps v_{s-1}
-      for (int i = 0; i < D; ++i) tmp[i] = eps[i] * vb[i];
-      hf_hvp<T>(a, &tr[(s * 3 + 0) * HF_MAXD], tmp, hv);
-      for (int i = 0; i < D; ++i) {
-        xb[i] += hv[i];
-        ebar[i] += vb[i] * G(s, i) + xb[i] * V(s - 1, i);
-        vb[i] += eps[i] * xb[i];
-      }
-    }
-    for (int i = 0; i < D; ++i) tmp[i] = eps[i] / (T)2 * vb[i];  // v_0 = rho + eps/2 g(x_0)
-    hf_hvp<T>(a, &tr[0], tmp, hv);
-    for (int i = 0; i < D; ++i) {
-      xb[i] += hv[i];
-      ebar[i] += vb[i] * G(0, i) / (T)2;
-      atomicAdd(g + o0 + 2 * D + i, ebar[i] * eps[i]);  // d/d log_eps
-    }
-    (void)X;
+    hf_leapfrog_bwd<T>(a, eps, tr, xb, vb, ebar);
+    for (int i = 0; i < D; ++i) atomicAdd(g + o0 + 2 * D + i, ebar[i] * eps[i]);  // d/d log_eps
   }
   for (int i = 0; i < d2; ++i) {  // reference map
     const T xi = x0[j * d2 + i];
     atomicAdd(g + i, zb[i]);
     atomicAdd(g + d2 + i, zb[i] * xi + lb / sc0[i]);
     gbar[j * d2 + i] = zb[i] * sc0[i];
+  }
+}
+
+// Reverse pass of the INVERSE chain (forward-KL training, `train_flow(loglikelihood, flow, xs)`).  The inverse of
+// every layer here is explicit -- the momentum layer's affine inverse, LeapFrog with -eps (demo :74-84), the
+// reference map's affine inverse -- so it is differentiated directly: u = data, gbar in = cotangent of the base
+// point x0 = T^-1(u), lb = cotangent of ladj_inv = -sum log|scale|.  ws: [n][N][2D] inputs of every inverse block.
+template <class T>
+__global__ __launch_bounds__(HF_BLOCK) void k_hf_bwd_inv(HfArgs a, const T *__restrict__ theta, const T *__restrict__ u,
+                                                         const T *__restrict__ gbar, T lb, T *__restrict__ ws,
+                                                         T *__restrict__ g) {
+  const long j = (long)blockIdx.x * HF_BLOCK + threadIdx.x;
+  if (j >= a.N) return;
+  const int D = a.D, d2 = 2 * D, n = a.n;
+  T z[2 * HF_MAXD];
+  for (int i = 0; i < d2; ++i) z[i] = u[j * d2 + i];
+  for (int bi = 0; bi < n; ++bi) {  // inverse chain: flat blocks 0 .. n-1, then the reference map
+    T *slot = ws + ((long)bi * a.N + j) * d2;
+    for (int i = 0; i < d2; ++i) slot[i] = z[i];
+    const T *shr = theta + 4 * D + 3 * D * bi, *scr = shr + D, *leps = scr + D;
+    for (int i = 0; i < D; ++i) z[D + i] = (z[D + i] - shr[i]) / scr[i];
+    hf_leapfrog<T>(a, leps, -(T)1, z, z + D, nullptr);
+  }
+  const T *sh0 = theta, *sc0 = theta + d2;
+  T zb[2 * HF_MAXD], tr[(HF_MAXL + 1) * 3 * HF_MAXD], eps[HF_MAXD], ebar[HF_MAXD];
+  for (int i = 0; i < d2; ++i) {  // x0 = (z - sh0) / sc0
+    const T x0 = (z[i] - sh0[i]) / sc0[i];
+    const T b = gbar[j * d2 + i] / sc0[i];
+    atomicAdd(g + i, -b);
+    atomicAdd(g + d2 + i, -b * x0 - lb / sc0[i]);
+    zb[i] = b;
+  }
+  for (int bi = n - 1; bi >= 0; --bi) {
+    const long o0 = 4 * D + 3 * D * bi;
+    const T *shr = theta + o0, *scr = shr + D, *leps = scr + D;
+    const T *slot = ws + ((long)bi * a.N + j) * d2;
+    T rp[HF_MAXD];
+    for (int i = 0; i < D; ++i) {
+      z[i] = slot[i];
+      rp[i] = (slot[D + i] - shr[i]) / scr[i];  // rho' = the integrator's initial momentum
+      z[D + i] = rp[i];
+      eps[i] = -exp(leps[i]);
+      ebar[i] = 0;
+    }
+    hf_leapfrog<T>(a, leps, -(T)1, z, z + D, tr);
+    T *xb = zb, *vb = zb + D;
+    hf_leapfrog_bwd<T>(a, eps, tr, xb, vb, ebar);
+    for (int i = 0; i < D; ++i) {
+      atomicAdd(g + o0 + 2 * D + i, ebar[i] * eps[i]);  // d(-exp(log_eps)) / d log_eps = eps (signed)
+      const T b = vb[i] / scr[i];
+      atomicAdd(g + o0 + i, -b);
+      atomicAdd(g + o0 + D + i, -b * rp[i] - lb / scr[i]);
+      vb[i] = b;
+    }
   }
 }
 
@@ -263,5 +324,24 @@ int nf_hf_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const vo
   else
     hipLaunchKernelGGL(k_hf_bwd<float>, dim3(grid), dim3(HF_BLOCK), 0, ctx->stream, a, (const float *)theta,
                        (const float *)x, (float *)xbar_out, (const float *)lbar, (float)lbar_const, (float *)ws, (float *)gtheta_out);
+  return (int)hipGetLastError();
+}
+
+// forward-KL reverse pass: u = data (d x N), gbar = cotangent of T^-1(u), lbar_const = cotangent of ladj_inv
+int nf_hf_bwd_inv(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *u, const void *gbar, double lbar_const,
+                  long N, void *gtheta_out, void *ws) {
+  const size_t es = desc->dtype == NF_DTYPE_F64 ? 8 : 4;
+  const long P = 2L * desc->d + 3L * (desc->d / 2) * desc->nlayers;
+  NF_HIP(hipMemsetAsync(gtheta_out, 0, (size_t)P * es, ctx->stream));
+  if (N <= 0) return NF_OK;
+  const HfArgs a = make_hf_args(desc, N);
+  const unsigned grid = (unsigned)((N + HF_BLOCK - 1) / HF_BLOCK);
+  ProfScope ps(ctx, "hf_bwd");
+  if (desc->dtype == NF_DTYPE_F64)
+    hipLaunchKernelGGL(k_hf_bwd_inv<double>, dim3(grid), dim3(HF_BLOCK), 0, ctx->stream, a, (const double *)theta,
+                       (const double *)u, (const double *)gbar, lbar_const, (double *)ws, (double *)gtheta_out);
+  else
+    hipLaunchKernelGGL(k_hf_bwd_inv<float>, dim3(grid), dim3(HF_BLOCK), 0, ctx->stream, a, (const float *)theta,
+                       (const float *)u, (const float *)gbar, (float)lbar_const, (float *)ws, (float *)gtheta_out);
   return (int)hipGetLastError();
 }
