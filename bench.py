@@ -12,8 +12,13 @@ Workload (BASELINE.json configs[1]): RealNVP, d = 64, 8 affine couplings (= real
 fp32, diag-Gaussian target, synthetic Glorot weights.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the coupling reverse
-pass, fp32 MFMA bound); `cpu_baseline` is the CPU oracle (a numpy/BLAS port of the reference
-algorithm; the Julia reference cannot run on this box) timed on a bounded sample.
+pass, fp32 MFMA bound); `cpu_baseline` is the reference's step under torch-CPU autograd on all host
+cores at the SAME batch (oracle/nf_torch_cpu.py; the Julia reference cannot run on this box).
+
+Multi-GPU: one process per GPU.  Under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`
+the ranks come from the environment; a bare `python bench.py --gpus N` starts the N ranks itself (the parent
+never touches a GPU, a failed rank fails the run).  `n_gpus` in the output is the world size the collective
+actually ran on, and the run fails if that differs from --gpus.
 """
 from __future__ import annotations
 
@@ -21,6 +26,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -62,6 +69,27 @@ def select_cfg4(world: int):
     KERNEL_NAMES = (b"base_sample", b"pack_weights", b"wide_apply", b"target", b"wide_bwd", b"wide_dw", b"reduce_slabs", b"adam")
 
 
+def select_cfg3(world: int):
+    """BASELINE.json configs[2] (--workload cfg3): NSF d=32, 8 RQ-spline couplings, K=8, B=5, hidden [32,32], batch
+    131 072 per GPU.  Dominant kernel: the spline-coupling reverse pass (conditioner GEMM flops only:
+    fwd 212 992 flop/sample over 8 couplings, step 638 976; the spline's VALU work is not counted)."""
+    global D, HDIMS, NLAYERS, BATCH, MACS_NET, FLOPS_BWD_PER_SAMPLE_PER_COUPLING, FLOPS_STEP_PER_SAMPLE, COUPLINGS_PER_LAUNCH
+    global WORKLOAD_TEXT, DOMINANT, KERNEL_NAMES, FLOW_KIND
+    D, HDIMS, NLAYERS, BATCH = 32, (32, 32), 4, 131072
+    FLOW_KIND = "nsf"
+    MACS_NET = 16 * 32 + 32 * 32 + 32 * 368
+    FLOPS_BWD_PER_SAMPLE_PER_COUPLING = 2 * 2 * MACS_NET  # (dX + dW) x 2 flop/MAC = 53 248
+    COUPLINGS_PER_LAUNCH = None  # read from the library: launches per step of the dominant kernel
+    FLOPS_STEP_PER_SAMPLE = 638976
+    WORKLOAD_TEXT = ("reverse-KL ELBO step: NSF d=32, 8 rational-quadratic spline couplings (K=8, B=5), conditioner 16-32-32-368 "
+                     "(hdims [32,32]), diag-Gaussian target, Philox base draws, Adam")
+    DOMINANT = (b"rqs_bwd", "k_rqs_bwd (reverse pass of the spline couplings: recompute + spline reverse + dX + dW)")
+    KERNEL_NAMES = (b"base_sample", b"pack_weights", b"rqs_chain", b"target", b"rqs_bwd", b"reduce_slabs", b"adam")
+
+
+FLOW_KIND = "realnvp"
+
+
 def pmc_traffic(kernel_substr: str):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 counter passes
     (profiles/*_pmc_summary.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this
@@ -84,44 +112,51 @@ def pmc_traffic(kernel_substr: str):
     return None, None
 
 
-def cpu_baseline(seconds_budget: float = 12.0):
-    """numpy (BLAS-threaded) port of the same step on a bounded sample of the same workload."""
+def cpu_baseline(seconds_budget: float = 20.0):
+    """The reference's training step under torch-CPU autograd (MKL/oneDNN GEMMs, all host cores) at the FULL batch of
+    the GPU workload -- oracle/nf_torch_cpu.py, pinned against the oracle by tests/test_oracle.py."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import nf_oracle as orc
+    import nf_torch_cpu as tc
 
-    try:
-        from threadpoolctl import threadpool_info
+    return tc.time_training_steps(D, HDIMS, NLAYERS, BATCH, seconds_budget=seconds_budget)
 
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count() or 1])
-    except Exception:
-        threads = os.cpu_count() or 1
-    n = 16384
-    spec = orc.FlowSpec("realnvp", D, NLAYERS, HDIMS)
-    rng = np.random.default_rng(123)
-    theta = orc.init_params(spec, rng, dtype=np.float32)
-    mu = rng.standard_normal(D).astype(np.float32)
-    var = (rng.uniform(size=D) + 1e-3).astype(np.float32)
-    m, v = np.zeros_like(theta), np.zeros_like(theta)
-    reps, t_used = 0, 0.0
-    t_all0 = time.perf_counter()
-    while True:
-        t0 = time.perf_counter()
-        xs = rng.standard_normal((D, n)).astype(np.float32)  # the reference's randn-based draw
-        loss, g = orc.neg_elbo_value_and_grad(spec, theta, ("diaggauss", mu, var), xs)
-        orc.adam_update(theta, g.astype(np.float32), m, v, reps + 1)
-        gn = float(np.linalg.norm(g))
-        t_used += time.perf_counter() - t0
-        reps += 1
-        if time.perf_counter() - t_all0 > seconds_budget or reps >= 50:
-            break
-    return {
-        "value": n * reps / t_used,
-        "unit": "samples/s",
-        "cores": int(threads),
-        "kind": "port",
-        "sample": f"{reps} steps of batch {n} (same flow/target/dtype as the GPU workload), numpy float32 + BLAS, "
-                  f"{os.cpu_count()} host cpus visible",
-    }
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one per GPU) and wait.  This parent
+    process never initialises a GPU (no HIP call, no torch.cuda.is_available()); it only counts devices.  Returns the
+    exit code for the whole run: non-zero as soon as any rank fails (the others are then terminated)."""
+    one_device = os.environ.get("NF_BENCH_ONE_DEVICE") == "1"
+    have = torch.cuda.device_count()
+    if have < n and not one_device:
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
+        return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in list(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                for q in alive:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return rc
 
 
 def main():
@@ -130,17 +165,23 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=None, help="samples per GPU per step")
-    ap.add_argument("--workload", choices=("cfg2", "cfg4"), default="cfg2",
-                    help="cfg2 = the headline line (default); cfg4 = d=256 / 16 couplings / h=256, 262144 samples sharded")
+    ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg4"), default="cfg2",
+                    help="cfg2 = the headline line (default); cfg3 = NSF d=32 K=8, 131072 per GPU; "
+                         "cfg4 = d=256 / 16 couplings / h=256, 262144 samples sharded (strong scaling)")
+    ap.add_argument("--collective", choices=("torch", "nfhip"), default="torch",
+                    help="who issues the one all-reduce per step: torch.distributed's RCCL process group (default) or the "
+                         "library's own RCCL communicator (nf_allreduce_grad_loss, on the context stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket kernels with HIP events in the timed region (roofline object is then empty)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))  # the parent only supervises; ranks are fresh processes
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
     if world > 1:
@@ -162,14 +203,22 @@ def main():
         local_rank = 0
     dev = torch.device("cuda", local_rank)
 
+    if dist is not None and dist.get_world_size() != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
+    world_observed = dist.get_world_size() if dist is not None else 1
     if args.workload == "cfg4":
         select_cfg4(world)
+    elif args.workload == "cfg3":
+        select_cfg3(world)
     if args.batch is None:
         args.batch = BATCH
     nf = load_package()
     lib = nf.load_library()
     n_local, n_global = args.batch, args.batch * world
-    flow = nf.realnvp(nf.MvNormal(D), HDIMS, NLAYERS, paramtype=torch.float32, device=dev, seed=123)
+    if FLOW_KIND == "nsf":
+        flow = nf.nsf(nf.MvNormal(D), HDIMS, 8, 5.0, NLAYERS, paramtype=torch.float32, device=dev, seed=123)
+    else:
+        flow = nf.realnvp(nf.MvNormal(D), HDIMS, NLAYERS, paramtype=torch.float32, device=dev, seed=123)
     g0 = torch.Generator().manual_seed(123)
     mu = torch.randn(D, generator=g0).to(dev)
     var = (torch.rand(D, generator=g0) + 1e-3).to(dev)
@@ -183,10 +232,26 @@ def main():
     vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
     desc, tgt = C.byref(flow.desc), C.byref(target.c)
 
+    lib_comm = False
+    if dist is not None and args.collective == "nfhip" and os.environ.get("NF_BENCH_ONE_DEVICE") != "1":
+        # the library's own RCCL communicator: rank 0's unique id travels through the process group
+        idbuf = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            raw = (C.c_char * 128)()
+            nf._lib.check(lib.nf_comm_get_unique_id(raw))
+            idbuf = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
+        idbuf = idbuf.to(dev)
+        dist.broadcast(idbuf, 0)
+        raw = (C.c_char * 128).from_buffer_copy(idbuf.cpu().numpy().tobytes())
+        nf._lib.check(lib.nf_comm_init_rank(ctx.ptr, raw, world, rank))
+        lib_comm = True
+
     def step(i: int):
         nf._lib.check(lib.nf_elbo_value_and_grad(ctx.ptr, desc, tgt, vp(theta), None, n_local, n_global, 123,
                                                  rank * n_local, i, vp(out)))
-        if dist is not None:
+        if lib_comm:
+            nf._lib.check(lib.nf_allreduce_grad_loss(ctx.ptr, 0, vp(out), P + 1))
+        elif dist is not None:
             dist.all_reduce(out)  # one RCCL all-reduce of [grad ; loss] (P + 1 floats)
         nf._lib.check(lib.nf_adam_update(ctx.ptr, 0, vp(theta), vp(out), vp(m), vp(v), P, 1e-3, 0.9, 0.999, 1e-8,
                                          i + 1, vp(gnorm)))
@@ -203,12 +268,16 @@ def main():
     if not args.no_kernel_events:
         # HIP events on the launch stream, over the timed region, around the dominant kernel only
         # (cfg 2: one launch per step; cfg 4: every 4th of its 32 launches per step)
-        nf._lib.check(lib.nf_prof_enable(ctx.ptr, 1 if args.workload == "cfg2" else 3))
+        nf._lib.check(lib.nf_prof_enable(ctx.ptr, 3 if args.workload == "cfg4" else 1))
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
+    marks[0].record()
+    for k, i in enumerate(range(args.warmup, args.warmup + args.steps)):
         step(i)
+        marks[k + 1].record()  # same stream as the library's launches: per-step device time for the median
     barrier()
     elapsed = time.perf_counter() - t0
+    step_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -235,19 +304,26 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = n_global * args.steps / elapsed
-        flop_per_launch = FLOPS_BWD_PER_SAMPLE_PER_COUPLING * COUPLINGS_PER_LAUNCH * n_local
+        couplings_per_launch = COUPLINGS_PER_LAUNCH
+        if couplings_per_launch is None:  # cfg3: 8 couplings over however many launches the library used per step
+            per_step = kernel_ms.get(DOMINANT[0].decode(), {}).get("launches_per_step", 8.0)
+            couplings_per_launch = 2 * NLAYERS / max(per_step, 1.0)
+        flop_per_launch = FLOPS_BWD_PER_SAMPLE_PER_COUPLING * couplings_per_launch * n_local
         achieved = flop_per_launch / (avg_ms.value * 1e-3) / 1e12 if avg_ms.value > 0 else 0.0
-        traffic, traffic_src = (pmc_traffic("k_affine_bwd_all") if args.workload == "cfg2" and n_local == BATCH else (None, None))
+        traffic, traffic_src = (None, None)
+        if n_local == BATCH and args.workload in ("cfg2", "cfg3"):
+            traffic, traffic_src = pmc_traffic("k_affine_bwd_all" if args.workload == "cfg2" else "k_rqs_bwd")
         rec = {
             "metric": "elbo_samples_per_sec",
             "value": value,
             "unit": "samples/s",
-            "n_gpus": world,
+            "n_gpus": world_observed,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            "ms_per_step_median": step_ms[len(step_ms) // 2],
             "higher_is_better": True,
-            "scaling": "weak" if args.workload == "cfg2" else "strong",
+            "scaling": "strong" if args.workload == "cfg4" else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -256,7 +332,8 @@ def main():
                 "batch_per_gpu": n_local,
                 "global_batch": n_global,
                 "params": P,
-                "parallelism": f"dp{world} (sample-sharded, one all-reduce of P+1 floats per step)",
+                "parallelism": f"dp{world_observed} (sample-sharded, one all-reduce of P+1 floats per step"
+                               + (", issued by libnfhip's RCCL communicator)" if lib_comm else ", torch.distributed RCCL)" if dist is not None else ")"),
                 "final_loss": loss,
             },
             "roofline": {

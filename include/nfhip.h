@@ -40,7 +40,10 @@ extern "C" {
 #define NF_ERR_ARG -1          /* null pointer, negative size, bad enum            */
 #define NF_ERR_UNSUPPORTED -2  /* flow shape / dtype not built into this library   */
 #define NF_ERR_NO_DEVICE -3    /* no gfx950 device visible                         */
-#define NF_ERR_NONFINITE -4    /* reserved: loss became non-finite                 */
+#define NF_ERR_NONFINITE -4    /* loss or gradient norm became non-finite (nf_elbo_step; the reference's
+                                  tests require finite ELBOs, test/flow.jl:58-60)  */
+#define NF_ERR_NO_RCCL -5      /* librccl.so.1 could not be loaded (multi-GPU entry points only) */
+#define NF_ERR_RCCL -6         /* an RCCL call failed; nf_strerror gives RCCL's message          */
 
 /* flow kinds: the constructors of src/flows/*.jl */
 #define NF_KIND_PLANAR 0    /* planarflow  src/flows/planar_radial.jl:21-29        */
@@ -215,6 +218,28 @@ int nf_sgd_update(nf_ctx *ctx, int32_t dtype, void *theta, const void *g, void *
 int nf_elbo_step(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, void *theta,
                  void *m, void *v, int64_t N, uint64_t seed, uint32_t step, double lr,
                  double beta1, double beta2, double eps, double *loss_host, double *gnorm_host);
+
+/* ---- (e) multi-GPU: the path's one collective ----------------------------------- */
+/* The ELBO is a mean over independent draws (src/objectives/elbo.jl:68,91,96), so ranks take sample shards
+ * (nf_elbo_value_and_grad's sample_offset / N_local / N_global) and the ONLY exchange per step is an in-place SUM
+ * all-reduce of the packed [grad ; loss] buffer (P + 1 elements) -- RCCL over xGMI, enqueued on the context's
+ * stream, so it is ordered after the reverse pass and before nf_adam_update without host synchronisation.  Every
+ * rank then applies the identical Adam update: replicas stay bit-identical, no broadcast.  The reference has no
+ * multi-device code to cite; this is north_star's "single RCCL all-reduce over xGMI of the scalar ELBO and
+ * parameter gradients per step" (SURVEY.md 8e).  librccl is bound at run time (dlopen), see NF_ERR_NO_RCCL.
+ *
+ * One process (or thread) per GPU:  rank 0 calls nf_comm_get_unique_id, ships the NF_COMM_ID_BYTES bytes to the
+ * other ranks by any host channel, every rank calls nf_comm_init_rank.
+ * One process driving G contexts (the Julia form: one task, G devices): nf_comm_init_all + nf_allreduce_grad_loss_all. */
+#define NF_COMM_ID_BYTES 128
+int nf_comm_get_unique_id(void *id_out_host);
+int nf_comm_init_rank(nf_ctx *ctx, const void *id_host, int32_t nranks, int32_t rank);
+int nf_comm_init_all(nf_ctx **ctxs, int32_t ngpus);
+int nf_comm_size(nf_ctx *ctx); /* ranks of the context's communicator (1 if none) */
+/* in place: buf[0..count) <- sum over ranks; count = P + 1 for the training step */
+int nf_allreduce_grad_loss(nf_ctx *ctx, int32_t dtype, void *buf, int64_t count);
+int nf_allreduce_grad_loss_all(nf_ctx **ctxs, int32_t ngpus, int32_t dtype, void **bufs, int64_t count);
+int nf_comm_destroy(nf_ctx *ctx);
 
 /* ---- measurement support ---------------------------------------------------- */
 /* Kernel durations from HIP events recorded on the context stream around launches since the

@@ -78,6 +78,13 @@ SYMBOLS = {
     "nf_adam_update": (C.c_int, [_P, _I32, _P, _P, _P, _P, _I64, _D, _D, _D, _D, _I64, _P]),
     "nf_sgd_update": (C.c_int, [_P, _I32, _P, _P, _P, _I64, _D, _D, _P]),
     "nf_elbo_step": (C.c_int, [_P, _DESC, _TGT, _P, _P, _P, _I64, _U64, _U32, _D, _D, _D, _D, _PD, _PD]),
+    "nf_comm_get_unique_id": (C.c_int, [_P]),
+    "nf_comm_init_rank": (C.c_int, [_P, _P, _I32, _I32]),
+    "nf_comm_init_all": (C.c_int, [C.POINTER(_P), _I32]),
+    "nf_comm_size": (C.c_int, [_P]),
+    "nf_allreduce_grad_loss": (C.c_int, [_P, _I32, _P, _I64]),
+    "nf_allreduce_grad_loss_all": (C.c_int, [C.POINTER(_P), _I32, _I32, C.POINTER(_P), _I64]),
+    "nf_comm_destroy": (C.c_int, [_P]),
     "nf_prof_enable": (C.c_int, [_P, _I32]),
     "nf_prof_read": (C.c_int, [_P, C.c_char_p, _PD, C.POINTER(C.c_int64)]),
     "nf_debug_trace": (C.c_int, [_P, _I32, C.POINTER(C.c_int64), _I32]),

@@ -204,7 +204,9 @@ extern "C" const char *nf_strerror(int code) {
     case NF_ERR_ARG: return "nfhip: invalid argument";
     case NF_ERR_UNSUPPORTED: return "nfhip: flow shape/dtype not built into this library";
     case NF_ERR_NO_DEVICE: return "nfhip: no usable HIP device";
-    case NF_ERR_NONFINITE: return "nfhip: non-finite loss";
+    case NF_ERR_NONFINITE: return "nfhip: non-finite loss or gradient norm";
+    case NF_ERR_NO_RCCL: return "nfhip: librccl.so.1 could not be loaded";
+    case NF_ERR_RCCL: return nf_comm_last_error();
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "nfhip: unknown error";
   }
 }
@@ -234,6 +236,7 @@ extern "C" int nf_ctx_destroy(nf_ctx *ctx) {
   if (!ctx) return NF_ERR_ARG;
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
+  nf_comm_destroy(ctx);
   for (auto &e : ctx->prof_pool) hipEventDestroy(e);
   if (ctx->ws) hipFree(ctx->ws);
   if (ctx->gbuf) hipFree(ctx->gbuf);
@@ -262,7 +265,7 @@ int nf_ws_reserve(nf_ctx *ctx, size_t bytes) {
   if (ctx->ws) NF_HIP(hipFree(ctx->ws));
   ctx->ws = nullptr;
   ctx->ws_bytes = 0;
-  const size_t want = bytes + bytes / 8;
+  const size_t want = carve_bytes(bytes + bytes / 8);  // multiple of 256: the optimiser's scratch is carved off the tail
   NF_HIP(hipMalloc(&ctx->ws, want));
   ctx->ws_bytes = want;
   return NF_OK;

@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -48,7 +49,12 @@ struct nf_ctx {
   std::vector<hipEvent_t> prof_pool;  // pre-created events, reused
   size_t prof_pool_next = 0;
   std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof_events;
+  // RCCL communicator of this context (nf_comm.hip); null for single-GPU use
+  void *comm = nullptr;
+  int comm_size = 1, comm_rank = 0;
 };
+
+const char *nf_comm_last_error();
 
 int nf_ws_reserve(nf_ctx *ctx, size_t bytes);
 
@@ -87,6 +93,22 @@ struct ProfScope {
   }
   ~ProfScope() {
     if (b) hipEventRecord(b, ctx->stream);
+  }
+};
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize, ...) once per (launcher, device).  A process may hold contexts
+// on several devices (nf_ctx_create(device, ...)), possibly driven from several threads.
+struct AttrOnce {
+  std::mutex mu;
+  unsigned long long done = 0;
+  template <class F>
+  int run(int device, F f) {
+    std::lock_guard<std::mutex> g(mu);
+    const unsigned long long bit = 1ull << (device & 63);
+    if (done & bit) return NF_OK;
+    const int st = f();
+    if (st == NF_OK) done |= bit;
+    return st;
   }
 };
 

@@ -768,11 +768,11 @@ static int make_args(nf_ctx *ctx, const nf_flow_desc *desc, int k, const float *
 template <class G, bool INV, bool FULL>
 static int launch_apply_v(nf_ctx *ctx, const CouplingArgs &a, const float *x, float *y, float *ladj, int accumulate) {
   const size_t lds = 2 * (size_t)G::SIZE * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static AttrOnce attr_once;  // once per device: a context on another GPU needs its own
+  NF_TRY(attr_once.run(ctx->device, [&]() -> int {
     NF_HIP(hipFuncSetAttribute((const void *)k_affine_apply<G, INV, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
+    return NF_OK;
+  }));
   const long ntiles = (a.N + NF_TILE - 1) / NF_TILE;
   long grid = (ntiles + 7) / 8;
   const long cap = 2L * ctx->num_cu;
@@ -807,11 +807,11 @@ template <class G, bool FULL>
 static int launch_bwd_v(nf_ctx *ctx, const CouplingArgs &a, float *y, float *ybar, const float *lbar, float lbar_const,
                         float *slab, long slab_stride, int grid) {
   const size_t lds = BwdLds<G>::BYTES;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static AttrOnce attr_once;  // once per device: a context on another GPU needs its own
+  NF_TRY(attr_once.run(ctx->device, [&]() -> int {
     NF_HIP(hipFuncSetAttribute((const void *)k_affine_bwd<G, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
+    return NF_OK;
+  }));
   ProfScope ps(ctx, "affine_bwd");
   hipLaunchKernelGGL((k_affine_bwd<G, FULL>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, y, ybar, lbar,
                      lbar_const, slab, slab_stride);
@@ -822,13 +822,13 @@ static int launch_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, flo
                         const FusedArgs *fused = nullptr) {
   // two double-buffered (s,t) image pairs + target parameters and per-wave sums of the fused variant
   const size_t lds = (4 * (size_t)G::SIZE + 2 * 64 * G::CB + 2) * sizeof(float) + 8 * sizeof(double);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static AttrOnce attr_once;  // once per device: a context on another GPU needs its own
+  NF_TRY(attr_once.run(ctx->device, [&]() -> int {
     NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
+    return NF_OK;
+  }));
   ChainArgs a;
   a.wimg = (const float *)ctx->wimg;
   a.d = desc->d;
@@ -911,11 +911,11 @@ template <class G, bool FULL, bool INVD = false>
 static int launch_bwd_all_v(nf_ctx *ctx, const BwdAllArgs &aa, float *y, float *ybar, const float *lbar, float lbar_const,
                             float *slab, long slab_stride, int grid) {
   const size_t lds = BwdLds<G>::BYTES;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static AttrOnce attr_once;  // once per device: a context on another GPU needs its own
+  NF_TRY(attr_once.run(ctx->device, [&]() -> int {
     NF_HIP(hipFuncSetAttribute((const void *)k_affine_bwd_all<G, FULL, INVD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
+    return NF_OK;
+  }));
   ProfScope ps(ctx, INVD ? "affine_bwd_inv" : "affine_bwd");
   hipLaunchKernelGGL((k_affine_bwd_all<G, FULL, INVD>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, aa, y, ybar, lbar,
                      lbar_const, slab, slab_stride);

@@ -861,12 +861,12 @@ template <class G>
 static int launch_rqs_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, float *xt, long N, float *ladj,
                             int k_only) {
   const size_t lds = 2 * (size_t)G::SIZE * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static AttrOnce attr_once;  // once per device: a context on another GPU needs its own
+  NF_TRY(attr_once.run(ctx->device, [&]() -> int {
     NF_HIP(hipFuncSetAttribute((const void *)k_rqs_chain<G, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     NF_HIP(hipFuncSetAttribute((const void *)k_rqs_chain<G, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
+    return NF_OK;
+  }));
   RqsChainArgs a;
   a.wimg = (const float *)ctx->wimg;
   a.d = desc->d; a.ncoup = 2 * desc->nlayers; a.B = desc->B; a.N = N; a.k_only = k_only;
@@ -900,11 +900,11 @@ template <class G, bool INVD>
 static int launch_rqs_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, float *y, float *ybar, const float *lbar,
                           float lbar_const, long N, float *slab, long slab_stride, int grid) {
   const size_t lds = RqsLds<G>::BYTES;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static AttrOnce attr_once;  // once per device: a context on another GPU needs its own
+  NF_TRY(attr_once.run(ctx->device, [&]() -> int {
     NF_HIP(hipFuncSetAttribute((const void *)k_rqs_bwd<G, INVD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
+    return NF_OK;
+  }));
   const CouplingInfo ci = nf_coupling_info(desc, k);
   RqsBwdArgs a;
   a.img = (const float *)ctx->wimg + (size_t)k * G::SIZE;

@@ -783,13 +783,15 @@ template <class K>
 static inline long resident_blocks(nf_ctx *ctx, K kernel, size_t lds) {
   // the occupancy query is a driver call: remember the answer per (kernel, dynamic LDS) -- the small flows
   // of the demos are launch-bound
-  struct Entry { const void *k; size_t lds; int per_cu; };
+  struct Entry { const void *k; size_t lds; int device; int per_cu; };
   static std::vector<Entry> seen;
+  static std::mutex seen_mu;  // contexts on different devices may be driven from different threads
+  std::lock_guard<std::mutex> guard(seen_mu);
   for (const Entry &e : seen)
-    if (e.k == (const void *)kernel && e.lds == lds) return (long)e.per_cu * ctx->num_cu;
+    if (e.k == (const void *)kernel && e.lds == lds && e.device == ctx->device) return (long)e.per_cu * ctx->num_cu;
   int per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, SB, lds) != hipSuccess || per_cu < 1) per_cu = 2;
-  seen.push_back({(const void *)kernel, lds, per_cu});
+  seen.push_back({(const void *)kernel, lds, ctx->device, per_cu});
   return (long)per_cu * ctx->num_cu;
 }
 static inline unsigned grid_for(long N, long cap) {

@@ -950,12 +950,12 @@ static int wide_apply(nf_ctx *ctx, const nf_flow_desc *desc, int k, bool inverse
   if (!ctx->wimg) return NF_ERR_UNSUPPORTED;
   const WideArgs a = make_wide_args(ctx, desc, k, N);
   const size_t lds = Wide<G>::LDS_APPLY;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static AttrOnce attr_once;  // once per device: a context on another GPU needs its own
+  NF_TRY(attr_once.run(ctx->device, [&]() -> int {
     NF_HIP(hipFuncSetAttribute((const void *)k_wide_apply<G, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     NF_HIP(hipFuncSetAttribute((const void *)k_wide_apply<G, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
+    return NF_OK;
+  }));
   long grid = wide_groups(N);
   if (grid > ctx->num_cu) grid = ctx->num_cu;
   if (grid < 1) grid = 1;
@@ -1034,17 +1034,17 @@ static int wide_bwd(nf_ctx *ctx, const nf_flow_desc *desc, float *state, float *
   const int njobs = wide_njobs();
   const int ks = wide_ksplit(ctx, ntiles, njobs);
 
-  static bool attr_done = false;
+  static AttrOnce attr_once;  // once per device
   const size_t lds_bwd = Wide<G>::LDS_BWD;
   const size_t lds_dw = (size_t)2 * DW_ROWS * DW_TS * sizeof(float);
-  if (!attr_done) {
+  NF_TRY(attr_once.run(ctx->device, [&]() -> int {
     NF_HIP(hipFuncSetAttribute((const void *)k_wide_bwd<G, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bwd));
     NF_HIP(hipFuncSetAttribute((const void *)k_wide_bwd<G, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bwd));
     NF_HIP(hipFuncSetAttribute((const void *)k_wide_bwd<G, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bwd));
     NF_HIP(hipFuncSetAttribute((const void *)k_wide_bwd<G, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bwd));
     NF_HIP(hipFuncSetAttribute((const void *)k_wide_dw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dw));
-    attr_done = true;
-  }
+    return NF_OK;
+  }));
   long grid = wide_groups(N);
   if (grid > ctx->num_cu) grid = ctx->num_cu;
   if (grid < 1) grid = 1;
@@ -1125,11 +1125,11 @@ static int wide_train_forward(nf_ctx *ctx, const nf_flow_desc *desc, float *xt, 
   if (!ctx->wimg) return NF_ERR_UNSUPPORTED;
   const long ntiles = (N + NF_TILE - 1) / NF_TILE;
   const size_t lds = Wide<G>::LDS_APPLY;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static AttrOnce attr_once;  // once per device: a context on another GPU needs its own
+  NF_TRY(attr_once.run(ctx->device, [&]() -> int {
     NF_HIP(hipFuncSetAttribute((const void *)k_wide_apply<G, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
+    return NF_OK;
+  }));
   long grid = wide_groups(N);
   if (grid > ctx->num_cu) grid = ctx->num_cu;
   if (grid < 1) grid = 1;
@@ -1160,15 +1160,15 @@ static int wide_train_backward(nf_ctx *ctx, const nf_flow_desc *desc, float *sta
   float *slab = p;
   const int njobs = wide_njobs();
   const int ks = wide_ksplit(ctx, ntiles, njobs);
-  static bool attr_done = false;
+  static AttrOnce attr_once;  // once per device
   const size_t lds_bwd = (size_t)2 * Wide<G>::CHBUF * sizeof(float);
   const size_t lds_dw = (size_t)2 * DW_ROWS * DW_TS * sizeof(float);
-  if (!attr_done) {
+  NF_TRY(attr_once.run(ctx->device, [&]() -> int {
     NF_HIP(hipFuncSetAttribute((const void *)k_wide_bwd_stashed<G, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bwd));
     NF_HIP(hipFuncSetAttribute((const void *)k_wide_bwd_stashed<G, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bwd));
     NF_HIP(hipFuncSetAttribute((const void *)k_wide_dw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dw));
-    attr_done = true;
-  }
+    return NF_OK;
+  }));
   long grid = wide_groups(N);
   if (grid > ctx->num_cu) grid = ctx->num_cu;
   if (grid < 1) grid = 1;

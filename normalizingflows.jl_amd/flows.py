@@ -314,6 +314,7 @@ def hamiltonianflow(dims: int, nblocks: int, nleapfrog: int, target, *, logeps0:
     nleapfrog, score(target)).  `target` is a built-in target of dimension `dims` (diagonal Gaussian, Banana,
     Funnel -- the ones with a closed-form Hessian-vector product); pass the same object as `logp` to
     elbo / train_flow: the library forms logp_joint(z) = logp(x) + log N(rho; 0, I) (demo :121-128)."""
+    check_target(target, paramtype, device, dims)
     flow = Flow("hamiltonian", MvNormal(2 * dims), nblocks, K=nleapfrog, dtype=paramtype, device=device, score=target)
     th = [torch.zeros(2 * dims, dtype=torch.float64), torch.ones(2 * dims, dtype=torch.float64)]
     for _ in range(nblocks):
@@ -329,8 +330,23 @@ class DiagGaussTarget:
     """logp(z) = logpdf(MvNormal(mu, Diagonal(var)), z)  (test/flow.jl:43-46)."""
 
     def __init__(self, mu: torch.Tensor, var: torch.Tensor):
+        if mu.dtype != var.dtype or mu.device != var.device or mu.shape != var.shape or mu.dim() != 1:
+            raise NFHipError("DiagGaussTarget: mu and var must be vectors of one length, element type and device")
         self.mu, self.var = mu.contiguous(), var.contiguous()
         self.c = Target(_lib.NF_TARGET_DIAGGAUSS, self.mu.data_ptr(), self.var.data_ptr(), 0.0, 0.0)
+
+    def check_compatible(self, dtype, device, d=None):
+        """The C ABI passes mu / var as untyped device pointers that the kernels read in the FLOW's element type:
+        a Float32 target under a Float64 flow would be read out of bounds.  Refuse instead."""
+        if self.mu.dtype != dtype:
+            raise NFHipError(f"target parameters are {self.mu.dtype} but the flow computes in {dtype}: "
+                             "build the target in the flow's element type (the reference's logp closure would promote; "
+                             "the device kernels cannot)")
+        dv = torch.device(device)
+        if self.mu.device.type != dv.type or (dv.index is not None and self.mu.device.index is not None and dv.index != self.mu.device.index):
+            raise NFHipError(f"target parameters live on {self.mu.device}, the flow on {device}")
+        if d is not None and self.mu.numel() != d:
+            raise NFHipError(f"target has dimension {self.mu.numel()}, expected {d}")
 
     def __call__(self, ys):
         return target_logp(self, ys)
@@ -388,9 +404,16 @@ class CrossTarget:
         return target_logp(self, ys)
 
 
+def check_target(target, dtype, device=None, d=None):
+    """Element-type / device / dimension agreement between a built-in target and the flow that will read it."""
+    if isinstance(target, DiagGaussTarget):
+        target.check_compatible(dtype, device if device is not None else target.mu.device, d)
+
+
 def target_logp(target, ys: torch.Tensor, with_grad: bool = False):
     ym, vec = as_batch(ys)
     d, n = ym.shape
+    check_target(target, ym.dtype, ym.device, d)
     out = torch.empty(n, dtype=ym.dtype, device=ym.device)
     grad = new_batch(d, n, ym.dtype, ym.device) if with_grad else None
     ctx = context_for(ym.device)

@@ -13,9 +13,22 @@ import torch
 
 from ._lib import NFHipError, check
 from .flows import (BananaTarget, CrossTarget, DiagGaussTarget, FunnelTarget, WarpedGaussTarget, Flow, PhiloxRNG, _dtype_code, _ptr, as_batch, base_logpdf,
-                    device_specific_rand, new_batch, with_logabsdet_jacobian)
+                    check_target, device_specific_rand, new_batch, with_logabsdet_jacobian)
 
 _BUILTIN = (DiagGaussTarget, BananaTarget, FunnelTarget, WarpedGaussTarget, CrossTarget)
+
+
+def _target_dim(flow: Flow) -> int:
+    return flow.dist.d // 2 if flow.kind == "hamiltonian" else flow.dist.d  # Hamiltonian targets describe x of [x; rho]
+
+
+def _builtin(flow: Flow, logp) -> bool:
+    """True for a built-in device target -- after checking that its parameters match the flow's element type, device
+    and dimension (the ABI carries them as untyped pointers)."""
+    if not isinstance(logp, _BUILTIN):
+        return False
+    check_target(logp, flow.theta.dtype, flow.theta.device, _target_dim(flow))
+    return True
 
 
 def _host_double():
@@ -29,7 +42,7 @@ def batched_elbos(flow: Flow, logp, xs: torch.Tensor) -> torch.Tensor:
     """_batched_elbos(flow, logp, xs)  (src/objectives/elbo.jl:65-70)."""
     xm, _ = as_batch(xs.to(flow.theta.dtype))
     d, n = xm.shape
-    if isinstance(logp, _BUILTIN):
+    if _builtin(flow, logp):
         out = torch.empty(n, dtype=xm.dtype, device=xm.device)
         val = _host_double()
         ctx = flow.ctx
@@ -45,7 +58,7 @@ def elbo_batch(*args):
     (src/objectives/elbo.jl:89-99)."""
     rng, flow, logp, last = _split_args(args)
     if isinstance(last, int):
-        if isinstance(logp, _BUILTIN):
+        if _builtin(flow, logp):
             val = _host_double()
             ctx = flow.ctx
             check(ctx.lib.nf_elbo_batch_rng(ctx.ptr, C.byref(flow.desc), C.byref(logp.c), _ptr(flow.theta), last,
@@ -53,7 +66,7 @@ def elbo_batch(*args):
             return val.value
         last = device_specific_rand(rng, flow.dist, last, device=flow.theta.device, dtype=flow.theta.dtype)
     xm, _ = as_batch(last.to(flow.theta.dtype))
-    if isinstance(logp, _BUILTIN):
+    if _builtin(flow, logp):
         val = _host_double()
         ctx = flow.ctx
         check(ctx.lib.nf_elbo_batch(ctx.ptr, C.byref(flow.desc), C.byref(logp.c), _ptr(flow.theta), _ptr(xm),
@@ -142,7 +155,7 @@ def value_and_gradient(vo, flow: Flow, logp, xs_or_n, rng: Optional[PhiloxRNG] =
         n = xm.shape[1]
     ng = n if n_global is None else int(n_global)
     rng = rng if rng is not None else PhiloxRNG(0)
-    if isinstance(logp, _BUILTIN):
+    if _builtin(flow, logp):
         out = torch.empty(P + 1, dtype=dt, device=dev)
         check(ctx.lib.nf_elbo_value_and_grad(ctx.ptr, C.byref(flow.desc), C.byref(logp.c), _ptr(flow.theta), _ptr(xm), n,
                                              ng, rng.seed, rng.sample_offset, rng.next_stream() if xm is None else 0,

@@ -464,7 +464,7 @@ def rqs_forward(x1, pX, pY, dYdX):
     d0, d1 = _take(dYdX, k), _take(dYdX, k + 1)
     dx, dy = xk1 - xk, yk1 - yk
     s = dy / dx
-    xi = (x1 - xk) / dx
+    xi = np.where(inside, (x1 - xk) / dx, 0.5)  # lanes outside [-B, B] are the identity: keep their dummy xi in (0, 1)
     om = 1.0 - xi
     den = s + (d1 + d0 - 2.0 * s) * xi * om
     y = yk + dy * (s * xi * xi + d0 * xi * om) / den
@@ -482,7 +482,7 @@ def rqs_inverse(y1, pX, pY, dYdX):
     d0, d1 = _take(dYdX, k), _take(dYdX, k + 1)
     dx, dy = xk1 - xk, yk1 - yk
     s = dy / dx
-    yy = y1 - yk
+    yy = np.where(inside, y1 - yk, 0.5 * dy)  # outside lanes: identity, dummy in-bin value
     a = dy * (s - d0) + yy * (d1 + d0 - 2.0 * s)
     b = dy * d0 - yy * (d1 + d0 - 2.0 * s)
     c = -s * yy

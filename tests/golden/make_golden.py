@@ -28,6 +28,7 @@ CASES = {
     "meanfield_d4": (o.FlowSpec("meanfield", 4, 1), 16, "diaggauss", np.float64),
     "nsf_d5_k10": (o.FlowSpec("nsf", 5, 2, (32, 32), K=10, B=5.0), 10, "diaggauss", np.float32),  # test/flow.jl:68
     "nsf_d32_k8": (o.FlowSpec("nsf", 32, 1, (32, 32), K=8, B=5.0), 40, "diaggauss", np.float32),  # cfg 3 shape
+    "nsf_d32_k8_nl4": (o.FlowSpec("nsf", 32, 4, (32, 32), K=8, B=5.0), 40, "diaggauss", np.float32),  # cfg 3: all 8 couplings
     # Float64 coupling flows (test/flow.jl:7,72 run both element types) -> general kernels
     "realnvp_d5_h32_f64": (o.FlowSpec("realnvp", 5, 2, (32, 32)), 10, "diaggauss", np.float64),
     "nsf_d5_k10_f64": (o.FlowSpec("nsf", 5, 2, (32, 32), K=10, B=5.0), 10, "diaggauss", np.float64),
@@ -42,7 +43,10 @@ CASES = {
 
 
 def main():
+    only = sys.argv[1:]  # optional: regenerate only the named fixtures
     for name, (spec, n, tkind, dt) in CASES.items():
+        if only and name not in only:
+            continue
         rng = np.random.default_rng(abs(hash(name)) % (2**31) if False else sum(map(ord, name)))
         theta = o.init_params(spec, rng)
         if spec.kind in ("realnvp", "nsf"):

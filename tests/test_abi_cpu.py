@@ -102,3 +102,23 @@ def test_missing_library_fails_loudly(nf, monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libnfhip.so")
     with pytest.raises(nf.NFHipError):
         _lib.load_library()
+
+
+def test_target_element_type_mismatch_is_refused():
+    """the ABI carries DiagGauss mu / var as untyped pointers read in the flow's element type, so the host
+    mirror must refuse a Float32 target under a Float64 flow (an out-of-bounds read otherwise).  No GPU needed."""
+    import torch
+
+    from __graft_entry__ import load_package
+
+    nf = load_package()
+    tgt = nf.DiagGaussTarget(torch.zeros(3), torch.ones(3))  # float32, cpu
+    with pytest.raises(nf.NFHipError, match="element type|float"):
+        tgt.check_compatible(torch.float64, "cpu", 3)
+    with pytest.raises(nf.NFHipError, match="dimension"):
+        tgt.check_compatible(torch.float32, "cpu", 4)
+    with pytest.raises(nf.NFHipError, match="live on"):
+        tgt.check_compatible(torch.float32, "cuda", 3)
+    tgt.check_compatible(torch.float32, "cpu", 3)
+    with pytest.raises(nf.NFHipError):
+        nf.DiagGaussTarget(torch.zeros(3), torch.ones(3, dtype=torch.float64))

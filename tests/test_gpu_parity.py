@@ -1,13 +1,10 @@
 """GPU parity tests (`-m gpu`): the HIP path, called through the C ABI, against the CPU oracle
 and the committed golden fixtures, plus the reference's own property tests.
 
-Stated tolerances (fp32 device arithmetic vs float64 oracle):
-  per-sample y / ladj : norm-wise rtol 2e-5  (isapprox semantics, as the reference tests use)
-  ELBO / loss         : rtol 2e-5
-  gradient            : max-abs error <= 2e-4 * ||g||_inf
-  float64 paths       : rtol 1e-10
-  invertibility       : the reference's own tolerances (test/flow.jl: 1e-6 RealNVP Float64;
-                        for Float32 we use 2e-5, fp32 round-off through 4-8 couplings)
+Tolerances: tests/parity.py (BASELINE.md's: element-wise 1e-6 + 1e-5 |ref| for per-sample values, 1e-5 for the
+ELBO mean, 1e-4 ||g||_inf for gradients, the reference's own round-trip tolerances -- 1e-6 RealNVP, Float32
+included, 1e-4 NSF / planar / radial; 1e-10 for Float64 paths).  Every check records its measured error
+(gpurun_out/parity_measured.json, copied to profiles/ per round).
 """
 import glob
 import os
@@ -16,6 +13,7 @@ import numpy as np
 import pytest
 
 import nf_oracle as o
+import parity as P
 from __graft_entry__ import ROOT, load_package
 
 torch = pytest.importorskip("torch")
@@ -34,6 +32,17 @@ def approx(a, b, rtol):
     """Julia isapprox: norm(a-b) <= rtol * max(norm(a), norm(b))."""
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     return np.linalg.norm(a - b) <= rtol * max(np.linalg.norm(a), np.linalg.norm(b)) + 1e-30
+
+
+def fp32_floor(spec, th64, xs64, otgt=None):
+    """The oracle evaluated op by op in IEEE float32 on the same inputs (tests/parity.py, "the fp32 floor")."""
+    th32, xs32 = P.f32(th64, xs64)
+    y32, l32 = o.flow_fwd(spec, th32, xs32)
+    xr32, lb32 = o.flow_inv(spec, th32, y32)
+    out = {"ys": y32, "ladj": l32, "rt_x": P.relerr(xr32, xs32), "rt_l": P.relerr(lb32, -l32)}
+    if otgt is not None:
+        out["elbos"] = o.batched_elbos(spec, th32, P.f32(otgt), xs32)
+    return out
 
 
 def tdt(name):
@@ -68,8 +77,9 @@ def load_case(nf, path):
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
 def test_golden_forward_inverse_elbo_grad_adam(nf, path):
     z, dt, flow, tgt, spec, otgt = load_case(nf, path)
+    name = os.path.basename(path)[:-4]
     f64 = dt == torch.float64
-    rt = 1e-10 if f64 else 2e-5
+    yr, ya = (P.F64_RTOL, 1e-12) if f64 else (P.Y_RTOL, P.Y_ATOL)
     xs = cm(z["xs"], dt)
     try:
         ys, ladj = nf.with_logabsdet_jacobian(flow.transform, xs)
@@ -78,35 +88,44 @@ def test_golden_forward_inverse_elbo_grad_adam(nf, path):
             pytest.skip(f"{flow.kind}: {e}")
         raise
     assert ys.shape == xs.shape and ladj.shape == (xs.shape[1],) and ys.dtype == dt  # test/flow.jl:17-21
-    assert approx(ys.cpu().numpy(), z["ys"], rt)
-    assert approx(ladj.cpu().numpy(), z["ladj"], rt)
-    # inverse: x ~= inv(fwd(x)), lj_fwd ~= -lj_bwd   (test/flow.jl:26-38)
+    fl = {} if f64 else fp32_floor(spec, z["theta"], z["xs"], otgt)
+    P.elementwise(f"golden {name}: ys", ys, z["ys"], yr, ya, fl.get("ys"))
+    P.elementwise(f"golden {name}: ladj", ladj, z["ladj"], yr, ya, fl.get("ladj"))
+    # inverse: x ~= inv(fwd(x)), lj_fwd ~= -lj_bwd at the reference's tolerance (test/flow.jl:26-38,92-105,158-171,224-237)
     xr, lb = nf.with_logabsdet_jacobian(nf.inverse(flow.transform), ys)
-    inv_rt = 1e-9 if f64 else (2e-4 if flow.kind in ("nsf", "planar", "radial") else 2e-5)
-    assert approx(xr.cpu().numpy(), z["xs"], inv_rt)
-    assert approx(lb.cpu().numpy(), -z["ladj"], inv_rt)
+    inv_rt = P.F64_GRAD if f64 else P.INV_RTOL[flow.kind]
+    P.isapprox(f"golden {name}: round trip x", xr, xs, inv_rt, fl.get("rt_x"))
+    P.isapprox(f"golden {name}: lj_fwd ~ -lj_bwd", lb, -ladj, inv_rt, fl.get("rt_l"))
     # objective values
     el = nf.batched_elbos(flow, tgt, xs)
-    assert approx(el.cpu().numpy(), z["elbos"], rt)
-    assert nf.elbo_batch(flow, tgt, xs) == pytest.approx(-float(z["loss"]), rel=rt)
-    ll = nf.loglikelihood(None, flow, ys)
-    assert ll == pytest.approx(float(z["loglik_of_ys"]), rel=10 * rt, abs=10 * rt)
+    P.elementwise(f"golden {name}: elbos", el, z["elbos"], yr, ya, fl.get("elbos"))
+    lr = P.F64_RTOL if f64 else P.LOSS_RTOL
+    P.scalar(f"golden {name}: elbo_batch", nf.elbo_batch(flow, tgt, xs), -float(z["loss"]), lr)
+    P.scalar(f"golden {name}: loglikelihood", nf.loglikelihood(None, flow, ys), float(z["loglik_of_ys"]), 10 * lr, 10 * lr)
     # loss + gradient of -elbo_batch, then one Adam step
     loss, g = nf.value_and_gradient(nf.elbo_batch, flow, tgt, xs)
-    assert loss == pytest.approx(float(z["loss"]), rel=rt)
+    P.scalar(f"golden {name}: loss", loss, float(z["loss"]), lr)
     gref = z["grad"].astype(np.float64)
-    gerr = np.abs(g.cpu().numpy() - gref).max() / np.abs(gref).max()
-    assert gerr < (1e-9 if f64 else 2e-4), gerr
+    P.gradient(f"golden {name}: grad", g, gref, P.F64_GRAD if f64 else P.GRAD_RTOL)
+    # Optimisers.update! (Adam): the first step is theta - lr * g / (|g| + eps), which is discontinuous in g at 0, so
+    # the update rule is checked on the GOLDEN gradient (device arithmetic of the rule alone) ...
     theta = flow.theta.clone()
     st = nf.AdamState(torch.zeros_like(theta), torch.zeros_like(theta), 0)
-    gn = nf.adam_update(nf.Adam(1e-3), st, theta, g)
-    assert float(gn) == pytest.approx(np.linalg.norm(gref), rel=1e-4)
-    np.testing.assert_allclose(theta.cpu().numpy(), z["theta_adam1"], rtol=0, atol=(1e-12 if f64 else 2e-6))
+    gn = nf.adam_update(nf.Adam(1e-3), st, theta, torch.tensor(z["grad"], dtype=dt, device="cuda"))
+    P.scalar(f"golden {name}: |g|", float(gn), np.linalg.norm(gref), 1e-6 if f64 else 1e-5)
+    np.testing.assert_allclose(theta.cpu().numpy(), z["theta_adam1"], rtol=0, atol=(1e-12 if f64 else 2e-7))
+    # ... and on the device's own gradient away from the kink (|g| well above the gradient tolerance)
+    theta2 = flow.theta.clone()
+    st2 = nf.AdamState(torch.zeros_like(theta2), torch.zeros_like(theta2), 0)
+    gn2 = nf.adam_update(nf.Adam(1e-3), st2, theta2, g)
+    P.scalar(f"golden {name}: |g| of the device gradient", float(gn2), np.linalg.norm(gref), 1e-4)
+    big = np.abs(gref) > 1e-2 * np.abs(gref).max()
+    np.testing.assert_allclose(theta2.cpu().numpy()[big], z["theta_adam1"][big], rtol=0, atol=(1e-12 if f64 else 2e-6))
     # forward-KL training pair on the committed data: value and gradient of -loglikelihood
     fl, fg = nf.loglikelihood_value_and_gradient(flow, cm(z["fkl_xs"], dt))
-    assert fl == pytest.approx(float(z["fkl_loss"]), rel=10 * rt)
+    P.scalar(f"golden {name}: forward-KL loss", fl, float(z["fkl_loss"]), 10 * lr)
     fref = z["fkl_grad"].astype(np.float64)
-    assert np.abs(fg.cpu().numpy() - fref).max() <= (1e-9 if f64 else 2e-4) * max(1.0, np.abs(fref).max())
+    P.gradient(f"golden {name}: forward-KL grad", fg, fref, P.F64_GRAD if f64 else P.GRAD_RTOL)
 
 
 @pytest.mark.parametrize("n", [1, 31, 32, 33, 257])
@@ -121,7 +140,8 @@ def test_ragged_batches_and_vector_input(nf, n):
     xs = rng.standard_normal((7, n)).astype(np.float32)
     ys_ref, l_ref = o.flow_fwd(spec, th.astype(np.float32).astype(np.float64), xs.astype(np.float64))
     ys, ladj = nf.with_logabsdet_jacobian(flow.transform, cm(xs, torch.float32))
-    assert approx(ys.cpu().numpy(), ys_ref, 2e-5) and approx(ladj.cpu().numpy(), l_ref, 2e-5)
+    P.elementwise(f"ragged n={n}: ys", ys, ys_ref)
+    P.elementwise(f"ragged n={n}: ladj", ladj, l_ref)
     yv, lv = nf.with_logabsdet_jacobian(flow.transform, torch.tensor(xs[:, 0], device="cuda"))
     assert yv.shape == (7,) and lv.dim() == 0
     np.testing.assert_array_equal(yv.cpu().numpy(), ys[:, 0].cpu().numpy())
@@ -132,8 +152,8 @@ def test_ragged_batches_and_vector_input(nf, n):
     l_ref, g_ref = o.neg_elbo_value_and_grad(spec, th.astype(np.float32).astype(np.float64),
                                              ("diaggauss", mu.astype(np.float32).astype(np.float64), var.astype(np.float32).astype(np.float64)),
                                              xs.astype(np.float64))
-    assert loss == pytest.approx(l_ref, rel=2e-5)
-    assert np.abs(g.cpu().numpy() - g_ref).max() <= 2e-4 * np.abs(g_ref).max()
+    P.scalar(f"ragged n={n}: loss", loss, l_ref)
+    P.gradient(f"ragged n={n}: grad", g, g_ref)
 
 
 def test_per_layer_apply_matches_chain(nf):
@@ -237,8 +257,9 @@ def test_full_size_properties_cfg2(nf):
     xs = nf.device_specific_rand(nf.PhiloxRNG(123), flow.dist, n)
     ys, lf = nf.with_logabsdet_jacobian(flow.transform, xs)
     xr, lb = nf.with_logabsdet_jacobian(nf.inverse(flow.transform), ys)
-    assert float((xr - xs).norm() / xs.norm()) < 2e-5
-    assert float((lf + lb).norm() / lf.norm().clamp_min(1e-6)) < 2e-5
+    fl = fp32_floor(o.FlowSpec("realnvp", d, 4, (64, 64)), flow.theta.cpu().numpy(), xs[:, :256].cpu().numpy())
+    P.isapprox("cfg2 full size: round trip x", xr, xs, P.INV_RTOL["realnvp"], fl["rt_x"])
+    P.isapprox("cfg2 full size: lj_fwd ~ -lj_bwd", lb, -lf, P.INV_RTOL["realnvp"], fl["rt_l"])
     loss, g = nf.value_and_gradient(nf.elbo_batch, flow, tgt, xs)
     assert np.isfinite(loss) and bool(torch.isfinite(g).all())
     la, ga = nf.value_and_gradient(nf.elbo_batch, flow, tgt, xs[:, : n // 2], n_global=n)
@@ -248,6 +269,136 @@ def test_full_size_properties_cfg2(nf):
     l_rng, g_rng = nf.value_and_gradient(nf.elbo_batch, flow, tgt, n, rng=nf.PhiloxRNG(123))
     assert l_rng == pytest.approx(loss, rel=1e-6)
     assert float((g_rng - g).abs().max()) <= 1e-5 * float(g.abs().max())
+
+
+FULL_CFGS = {
+    # BASELINE.json configs[1..4] at their full depth and per-GPU size
+    "cfg2_realnvp_d64_8couplings_n65536": dict(kind="realnvp", d=64, nl=4, hd=(64, 64), K=0, B=0.0, n=65536, off=0),
+    "cfg3_nsf_d32_k8_8couplings_n131072": dict(kind="nsf", d=32, nl=4, hd=(32, 32), K=8, B=5.0, n=131072, off=0),
+    # cfg 4: rank 3's shard of the 262 144-sample batch over 8 GPUs (global samples 98 304 .. 131 071)
+    # The Glorot-initialised cfg 4 flow is chaotic (16 couplings at d = 256: |y| up to 2e3, ladj -87 .. 59; an IEEE-float32
+    # evaluation of the oracle is already 5 000x off the element-wise tolerance), so the primary cfg 4 case halves the
+    # parameters (a contraction: float32 floor 0.3x the tolerance) and the bench's own initialisation is kept as a
+    # second case, judged against the float32 floor.
+    "cfg4_realnvp_d256_16couplings_shard32768": dict(kind="realnvp", d=256, nl=8, hd=(256, 256), K=0, B=0.0, n=32768,
+                                                      off=3 * 32768, n_global=262144, damp=0.5),
+    "cfg4_bench_init_realnvp_d256_16couplings_shard32768": dict(kind="realnvp", d=256, nl=8, hd=(256, 256), K=0, B=0.0,
+                                                                 n=32768, off=3 * 32768, n_global=262144),
+}
+
+
+def _oracle_columns(d, cols, seed, off):
+    return np.concatenate([o.base_sample(d, 1, seed=seed, sample_offset=off + int(j)) for j in cols], axis=1)
+
+
+@pytest.mark.parametrize("name", list(FULL_CFGS))
+def test_full_config_against_oracle_on_sampled_columns(nf, name):
+    """The benchmark configurations at FULL depth and size (all couplings, the whole per-GPU batch), in-library Philox
+    draws.  The draws are counter-based, so any column of the full-size run can be reproduced by the oracle
+    (o.base_sample(..., sample_offset=j)): 256 sampled columns of xs / ys / ladj / per-sample ELBO terms are compared
+    element-wise, a 2048-column shard's (loss, gradient) contribution against the oracle's gradient, and the
+    full-size gradient against the sum of its shards."""
+    c = FULL_CFGS[name]
+    kind, d, nl, hd, K, B, n, off = c["kind"], c["d"], c["nl"], c["hd"], c["K"], c["B"], c["n"], c["off"]
+    ng = c.get("n_global", n)
+    if kind == "realnvp":
+        flow = nf.realnvp(nf.MvNormal(d), hd, nl, paramtype=torch.float32, seed=123)
+    else:
+        flow = nf.nsf(nf.MvNormal(d), hd, K, B, nl, paramtype=torch.float32, seed=123)
+    # trained-looking parameters: non-zero biases
+    gen = torch.Generator().manual_seed(5)
+    flow = flow.with_theta(c.get("damp", 1.0) * (flow.theta + 0.02 * torch.randn(flow.P, generator=gen).to("cuda")))
+    spec = o.FlowSpec(kind, d, nl, hd, K, B)
+    th64 = flow.theta.cpu().numpy().astype(np.float64)
+    rng = np.random.default_rng(7)
+    mu, var = rng.standard_normal(d).astype(np.float32), (rng.uniform(size=d) + 1e-3 + 0.5).astype(np.float32)
+    tgt = nf.DiagGaussTarget(torch.tensor(mu, device="cuda"), torch.tensor(var, device="cuda"))
+    otgt = ("diaggauss", mu.astype(np.float64), var.astype(np.float64))
+    seed = 123
+    cols = np.sort(rng.choice(n, 256, replace=False))
+    # (1) the in-library draws are the oracle's Philox draws
+    xs = nf.device_specific_rand(nf.PhiloxRNG(seed, sample_offset=off), flow.dist, n)
+    x_sel = xs[:, torch.tensor(cols, device="cuda")].cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(x_sel, _oracle_columns(d, cols, seed, off), rtol=0, atol=3e-6)
+    # (2) forward, log-det, per-sample ELBO terms at full size, sampled columns against the oracle
+    ys, ladj = nf.with_logabsdet_jacobian(flow.transform, xs)
+    y_ref, l_ref = o.flow_fwd(spec, th64, x_sel)
+    fl = fp32_floor(spec, th64, x_sel, otgt)
+    ci = torch.tensor(cols, device="cuda")
+    P.elementwise(f"{name}: ys (256 sampled columns of the full batch)", ys[:, ci], y_ref, floor=fl["ys"])
+    P.elementwise(f"{name}: ladj (256 sampled columns)", ladj[ci], l_ref, floor=fl["ladj"])
+    el = nf.batched_elbos(flow, tgt, xs)
+    P.elementwise(f"{name}: elbo terms (256 sampled columns)", el[ci], o.batched_elbos(spec, th64, otgt, x_sel), floor=fl["elbos"])
+    # round trip at full size, the reference's tolerance
+    xr, lb = nf.with_logabsdet_jacobian(nf.inverse(flow.transform), ys)
+    P.isapprox(f"{name}: round trip x (full batch)", xr, xs, P.INV_RTOL[kind], fl["rt_x"])
+    P.isapprox(f"{name}: lj_fwd ~ -lj_bwd (full batch)", lb, -ladj, P.INV_RTOL[kind], fl["rt_l"])
+    # (3) in-library ELBO of the whole batch == mean of the per-sample terms
+    v = nf.elbo_batch(nf.PhiloxRNG(seed, sample_offset=off), flow, tgt, n)
+    P.scalar(f"{name}: elbo_batch(rng) vs mean of terms", v, float(el.double().mean()), 1e-5)
+    # (4) a 2048-column shard of the step, in-library draws: (loss, grad) contribution vs the oracle
+    s0, ns = 4096, 2048
+    ls, gs = nf.value_and_gradient(nf.elbo_batch, flow, tgt, ns, rng=nf.PhiloxRNG(seed, sample_offset=off + s0), n_global=ng)
+    x_sh = xs[:, s0:s0 + ns].cpu().numpy().astype(np.float64)
+    lo, go = o.neg_elbo_value_and_grad(spec, th64, otgt, x_sh)
+    _, go32 = o.neg_elbo_value_and_grad(spec, P.f32(th64), P.f32(otgt), P.f32(x_sh))
+    P.scalar(f"{name}: shard loss contribution", ls, lo * ns / ng)
+    P.gradient(f"{name}: shard gradient contribution (2048 columns)", gs, go * ns / ng, floor=go32.astype(np.float64) * ns / ng)
+    # (5) the full-size step equals the sum of its shards (what the all-reduce assembles)
+    lf, gf = nf.value_and_gradient(nf.elbo_batch, flow, tgt, n, rng=nf.PhiloxRNG(seed, sample_offset=off), n_global=ng)
+    assert np.isfinite(lf) and bool(torch.isfinite(gf).all())
+    acc_l, acc_g = 0.0, torch.zeros_like(gf)
+    q = n // 4
+    for r in range(4):
+        lr_, gr_ = nf.value_and_gradient(nf.elbo_batch, flow, tgt, q, rng=nf.PhiloxRNG(seed, sample_offset=off + r * q), n_global=ng)
+        acc_l += lr_
+        acc_g += gr_
+    P.scalar(f"{name}: full loss vs sum of 4 shards", lf, acc_l, 1e-5)
+    P.gradient(f"{name}: full gradient vs sum of 4 shards", gf, acc_g, 2e-5)
+    P.scalar(f"{name}: full loss vs -mean(elbo terms)", lf, -float(el.double().sum()) / ng, 1e-5)
+
+
+def test_full_config_cfg5_loglikelihood_on_one_million_samples(nf):
+    """BASELINE cfg 5: RealNVP d=64, 8 couplings, inverse + log-det + log q0 on 1 048 576 synthetic samples
+    (ys = 2 z + 1, z Philox seed 123).  256 sampled columns against the oracle's inverse, the mean against the
+    per-sample values, and a 512-column shard of the forward-KL training gradient against the oracle."""
+    d, n = 64, 1 << 20
+    flow = nf.realnvp(nf.MvNormal(d), (64, 64), 4, paramtype=torch.float32, seed=123)
+    gen = torch.Generator().manual_seed(5)
+    flow = flow.with_theta(flow.theta + 0.02 * torch.randn(flow.P, generator=gen).to("cuda"))
+    spec = o.FlowSpec("realnvp", d, 4, (64, 64))
+    th64 = flow.theta.cpu().numpy().astype(np.float64)
+    ys = nf.device_specific_rand(nf.PhiloxRNG(123), flow.dist, n) * 2 + 1
+    rng = np.random.default_rng(9)
+    cols = np.sort(rng.choice(n, 256, replace=False))
+    ci = torch.tensor(cols, device="cuda")
+    y_sel = ys[:, ci].cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(y_sel, 2 * _oracle_columns(d, cols, 123, 0) + 1, rtol=0, atol=1e-5)
+    xr, ladj = nf.with_logabsdet_jacobian(nf.inverse(flow.transform), ys)
+    x_ref, l_ref = o.flow_inv(spec, th64, y_sel)
+    x32, l32 = o.flow_inv(spec, *P.f32(th64, y_sel))  # the fp32 floor of the inverse direction
+    P.elementwise("cfg5: x = T^-1 y (256 sampled columns of 1M)", xr[:, ci], x_ref, floor=x32)
+    P.elementwise("cfg5: ladj_inv (256 sampled columns)", ladj[ci], l_ref, floor=l32)
+    lp = nf.logpdf(flow, ys)
+    P.elementwise("cfg5: logpdf(flow, y) (256 sampled columns)", lp[ci], o.std_normal_logpdf(x_ref) + l_ref,
+                  floor=o.std_normal_logpdf(x32) + l32)
+    ll = nf.loglikelihood(None, flow, ys)
+    P.scalar("cfg5: loglikelihood vs mean of per-sample values", ll, float(lp.double().mean()), 1e-5)
+    # back through the forward direction at full size
+    yb, lf = nf.with_logabsdet_jacobian(flow.transform, xr)
+    yb32, _ = o.flow_fwd(spec, P.f32(th64), x32)
+    P.isapprox("cfg5: round trip y (1M samples)", yb, ys, P.INV_RTOL["realnvp"], P.relerr(yb32, y_sel))
+    # forward-KL training: one 512-column shard's (loss, grad) contribution vs the oracle
+    s0, ns = 777 * 512, 512
+    lsh, gsh = nf.loglikelihood_value_and_gradient(flow, ys[:, s0:s0 + ns], n_global=n)
+    y_sh = ys[:, s0:s0 + ns].cpu().numpy().astype(np.float64)
+    lo, go = o.neg_loglik_value_and_grad(spec, th64, y_sh, n_global=n)
+    _, go32 = o.neg_loglik_value_and_grad(spec, P.f32(th64), P.f32(y_sh), n_global=n)
+    P.scalar("cfg5: forward-KL shard loss contribution", lsh, lo)
+    P.gradient("cfg5: forward-KL shard gradient contribution (512 columns)", gsh, go, floor=go32)
+    lfull, gfull = nf.loglikelihood_value_and_gradient(flow, ys)
+    P.scalar("cfg5: forward-KL full loss vs -loglikelihood", lfull, -ll, 1e-5)
+    assert bool(torch.isfinite(gfull).all())
 
 
 def test_fused_elbo_step_matches_split_calls(nf):
@@ -328,24 +479,29 @@ def test_wide_realnvp_matches_oracle(nf, d, hd, nl, n):
     th64, xs64 = th.astype(np.float64), xs.astype(np.float64)
     ys_ref, l_ref = o.flow_fwd(spec, th64, xs64)
     ys, ladj = nf.with_logabsdet_jacobian(flow.transform, cm(xs, torch.float32))
-    assert approx(ys.cpu().numpy(), ys_ref, 2e-5) and approx(ladj.cpu().numpy(), l_ref, 2e-5)
+    tag = f"wide d={d} h={hd} nl={nl}"
+    fl = fp32_floor(spec, th64, xs64)
+    P.elementwise(f"{tag}: ys", ys, ys_ref, floor=fl["ys"])
+    P.elementwise(f"{tag}: ladj", ladj, l_ref, floor=fl["ladj"])
     xr, lb = nf.with_logabsdet_jacobian(nf.inverse(flow.transform), ys)
-    assert approx(xr.cpu().numpy(), xs64, 2e-5) and approx(lb.cpu().numpy(), -l_ref, 2e-5)
+    P.isapprox(f"{tag}: round trip x", xr, xs64, P.INV_RTOL["realnvp"], fl["rt_x"])
+    P.isapprox(f"{tag}: lj_fwd ~ -lj_bwd", lb, -ladj, P.INV_RTOL["realnvp"], fl["rt_l"])
     # single couplings compose to the chain
     z, tot = cm(xs, torch.float32), torch.zeros(n, device="cuda")
     for k in reversed(range(2 * nl)):
         z, lj = nf.with_logabsdet_jacobian(nf.layer(flow, k), z)
         tot = tot + lj
-    assert approx(z.cpu().numpy(), ys_ref, 2e-5) and approx(tot.cpu().numpy(), l_ref, 2e-5)
+    P.elementwise(f"{tag}: per-layer composition ys", z, ys_ref, floor=fl["ys"])
+    P.elementwise(f"{tag}: per-layer composition ladj", tot, l_ref, floor=fl["ladj"])
     mu, var = rng.standard_normal(d).astype(np.float32), (rng.uniform(size=d) + 0.5).astype(np.float32)
     tgt = nf.DiagGaussTarget(torch.tensor(mu, device="cuda"), torch.tensor(var, device="cuda"))
     loss, g = nf.value_and_gradient(nf.elbo_batch, flow, tgt, cm(xs, torch.float32))
     lr, gr = o.neg_elbo_value_and_grad(spec, th64, ("diaggauss", mu.astype(np.float64), var.astype(np.float64)), xs64)
-    assert loss == pytest.approx(lr, rel=2e-5)
-    assert np.abs(g.cpu().numpy() - gr).max() <= 2e-4 * np.abs(gr).max()
+    P.scalar(f"{tag}: loss", loss, lr)
+    P.gradient(f"{tag}: grad", g, gr)
     ll = nf.loglikelihood(None, flow, ys)
     ll_ref = float(np.mean(o.std_normal_logpdf(xs64) - l_ref))
-    assert ll == pytest.approx(ll_ref, rel=2e-4, abs=2e-4)
+    P.scalar(f"{tag}: loglikelihood", ll, ll_ref, 1e-4, 1e-4)
 
 
 def test_wide_cfg4_shard_properties(nf):
@@ -357,8 +513,8 @@ def test_wide_cfg4_shard_properties(nf):
     xs = nf.device_specific_rand(nf.PhiloxRNG(123), flow.dist, n)
     ys, lf = nf.with_logabsdet_jacobian(flow.transform, xs)
     xr, lb = nf.with_logabsdet_jacobian(nf.inverse(flow.transform), ys)
-    assert float((xr - xs).norm() / xs.norm()) < 2e-5
-    assert float((lf + lb).norm() / lf.norm().clamp_min(1e-6)) < 2e-5
+    P.isapprox("cfg4 shard: round trip x", xr, xs, P.INV_RTOL["realnvp"])
+    P.isapprox("cfg4 shard: lj_fwd ~ -lj_bwd", lb, -lf, P.INV_RTOL["realnvp"])
     tgt = nf.DiagGaussTarget(torch.randn(d, device="cuda"), torch.rand(d, device="cuda") + 0.5)
     loss, g = nf.value_and_gradient(nf.elbo_batch, flow, tgt, xs)
     assert np.isfinite(loss) and bool(torch.isfinite(g).all())
@@ -385,9 +541,11 @@ def test_synthetic_targets_logp_and_score(nf, name, dtn):
     y = (rng.standard_normal((d, 333)) * 1.2).astype(np.float32 if dtn == "float32" else np.float64)
     lp, g = nf.target_logp(tgt, cm(y, dt), with_grad=True)
     y64 = y.astype(np.float64)
-    rt = 2e-5 if dtn == "float32" else 1e-10
-    assert approx(lp.cpu().numpy(), o.target_logp(otgt, y64), rt)
-    assert approx(g.cpu().numpy(), o.target_grad(otgt, y64), rt)
+    rt = P.LOSS_RTOL if dtn == "float32" else 1e-10
+    ew = (P.Y_RTOL, P.Y_ATOL) if dtn == "float32" else (1e-10, 1e-12)
+    P.elementwise(f"target {name} {dtn}: logp", lp, o.target_logp(otgt, y64), *ew)
+    P.elementwise(f"target {name} {dtn}: score", g, o.target_grad(otgt, y64), *ew,
+                  floor=o.target_grad(otgt, y) if dtn == "float32" else None)
     # ELBO value and gradient with a planar flow (standard layout) ...
     pd = torch.float64 if dtn == "float64" else torch.float32
     flow = nf.planarflow(nf.MvNormal(d), 3, paramtype=pd, seed=2)
@@ -396,16 +554,16 @@ def test_synthetic_targets_logp_and_score(nf, name, dtn):
     th64 = flow.theta.cpu().numpy().astype(np.float64)
     loss, gr = nf.value_and_gradient(nf.elbo_batch, flow, tgt, cm(xs, dt))
     lref, gref = o.neg_elbo_value_and_grad(spec, th64, otgt, xs.astype(np.float64))
-    assert loss == pytest.approx(lref, rel=10 * rt)
-    assert np.abs(gr.cpu().numpy() - gref).max() <= (2e-4 if dtn == "float32" else 1e-9) * np.abs(gref).max()
+    P.scalar(f"target {name} {dtn}: planar loss", loss, lref, rt)
+    P.gradient(f"target {name} {dtn}: planar grad", gr, gref, P.GRAD_RTOL if dtn == "float32" else P.F64_GRAD)
     # ... and with a coupling flow (tiled layout)
     if dtn == "float32":
         fl2 = nf.realnvp(nf.MvNormal(d), [16, 16], 1, paramtype=torch.float32, seed=4)
         sp2 = o.FlowSpec("realnvp", d, 1, (16, 16))
         l2, g2 = nf.value_and_gradient(nf.elbo_batch, fl2, tgt, cm(xs, dt))
         lr2, gr2 = o.neg_elbo_value_and_grad(sp2, fl2.theta.cpu().numpy().astype(np.float64), otgt, xs.astype(np.float64))
-        assert l2 == pytest.approx(lr2, rel=2e-5)
-        assert np.abs(g2.cpu().numpy() - gr2).max() <= 2e-4 * np.abs(gr2).max()
+        P.scalar(f"target {name}: realnvp loss", l2, lr2)
+        P.gradient(f"target {name}: realnvp grad", g2, gr2)
 
 
 def test_target_argument_conventions(nf):
@@ -487,15 +645,19 @@ def test_float32_shapes_outside_the_mfma_kernels(nf, kind, d, hd, nl, K):
     ys_ref, l_ref = o.flow_fwd(spec, th64, xs64)
     ys, ladj = nf.with_logabsdet_jacobian(flow.transform, cm(xs, torch.float32))
     assert ys.dtype == torch.float32
-    assert approx(ys.cpu().numpy(), ys_ref, 2e-5) and approx(ladj.cpu().numpy(), l_ref, 2e-5)
+    tag = f"general f32 {kind} d={d} h={hd} K={K}"
+    fl = fp32_floor(spec, th64, xs64)
+    P.elementwise(f"{tag}: ys", ys, ys_ref, floor=fl["ys"])
+    P.elementwise(f"{tag}: ladj", ladj, l_ref, floor=fl["ladj"])
     xr, lb = nf.with_logabsdet_jacobian(nf.inverse(flow.transform), ys)
-    assert approx(xr.cpu().numpy(), xs64, 2e-4) and approx(lb.cpu().numpy(), -l_ref, 2e-4)
+    P.isapprox(f"{tag}: round trip x", xr, xs64, P.INV_RTOL[kind], fl["rt_x"])
+    P.isapprox(f"{tag}: lj_fwd ~ -lj_bwd", lb, -ladj, P.INV_RTOL[kind], fl["rt_l"])
     mu, var = rng.standard_normal(d).astype(np.float32), (rng.uniform(size=d) + 0.5).astype(np.float32)
     tgt = nf.DiagGaussTarget(torch.tensor(mu, device="cuda"), torch.tensor(var, device="cuda"))
     loss, g = nf.value_and_gradient(nf.elbo_batch, flow, tgt, cm(xs, torch.float32))
     lr, gr = o.neg_elbo_value_and_grad(spec, th64, ("diaggauss", mu.astype(np.float64), var.astype(np.float64)), xs64)
-    assert loss == pytest.approx(lr, rel=2e-5)
-    assert np.abs(g.cpu().numpy() - gr).max() <= 2e-4 * np.abs(gr).max()
+    P.scalar(f"{tag}: loss", loss, lr)
+    P.gradient(f"{tag}: grad", g, gr)
 
 
 @pytest.mark.parametrize("kind", ["realnvp", "nsf"])
@@ -581,17 +743,21 @@ def test_hamiltonian_flow_matches_oracle(nf, tname, dtn):
     x064 = x0.astype(np.float64)
     z_ref, l_ref = o.hflow_fwd(D, n, L, th64, otgt, x064)
     z, ladj = nf.with_logabsdet_jacobian(flow.transform, cm(x0, dt))
-    rt = 1e-11 if dtn == "float64" else 2e-5
-    assert approx(z.cpu().numpy(), z_ref, rt) and approx(ladj.cpu().numpy(), l_ref, rt)
+    rt = 1e-11 if dtn == "float64" else P.LOSS_RTOL
+    tag = f"hamiltonian {tname} {dtn}"
+    ew = (1e-10, 1e-12) if dtn == "float64" else (P.Y_RTOL, P.Y_ATOL)
+    P.elementwise(f"{tag}: z", z, z_ref, *ew)
+    P.elementwise(f"{tag}: ladj", ladj, l_ref, *ew)
     xr, lb = nf.with_logabsdet_jacobian(nf.inverse(flow.transform), z)
-    assert approx(xr.cpu().numpy(), x064, 1e-9 if dtn == "float64" else 2e-4) and approx(lb.cpu().numpy(), -l_ref, 10 * rt)
+    P.isapprox(f"{tag}: round trip x", xr, x064, 1e-9 if dtn == "float64" else P.INV_RTOL["hamiltonian"])
+    P.isapprox(f"{tag}: lj_fwd ~ -lj_bwd", lb, -l_ref, 10 * rt)
     # a single block changes the log-det only through its momentum scale
     z1, l1 = nf.with_logabsdet_jacobian(nf.layer(flow, 0), cm(x0, dt))
     assert float(l1.std()) < (1e-12 if dtn == "float64" else 1e-5)
     loss, g = nf.value_and_gradient(nf.elbo_batch, flow, tgt, cm(x0, dt))
     lr, gr = o.hflow_neg_elbo_value_and_grad(D, n, L, th64, otgt, x064)
-    assert loss == pytest.approx(lr, rel=10 * rt)
-    assert np.abs(g.cpu().numpy() - gr).max() <= (1e-9 if dtn == "float64" else 3e-4) * np.abs(gr).max()
+    P.scalar(f"{tag}: loss", loss, lr, 10 * rt)
+    P.gradient(f"{tag}: grad", g, gr, 1e-9 if dtn == "float64" else P.GRAD_RTOL)
 
 
 def test_hamiltonian_flow_demo_trains(nf):
@@ -645,10 +811,10 @@ def test_forward_kl_value_and_gradient_matches_oracle(nf, kind, d, hd, nl, K, dt
         ys = ys.astype(np.float32).astype(np.float64)
     lr, gr = o.neg_loglik_value_and_grad(spec, th, ys)
     loss, g = nf.value_and_gradient(nf.loglikelihood, flow, cm(ys, dt), None)
-    assert loss == pytest.approx(lr, rel=1e-10 if f64 else 2e-5)
+    tag = f"forward-KL {kind} d={d} h={hd} {dtn}"
+    P.scalar(f"{tag}: loss", loss, lr, 1e-10 if f64 else P.LOSS_RTOL)
     assert loss == pytest.approx(-nf.loglikelihood(None, flow, cm(ys, dt)), rel=1e-10 if f64 else 1e-5)
-    err = np.abs(g.cpu().numpy().astype(np.float64) - gr).max()
-    assert err <= (1e-9 if f64 else 2e-4) * max(1.0, np.abs(gr).max()), err
+    P.gradient(f"{tag}: grad", g, gr, P.F64_GRAD if f64 else P.GRAD_RTOL)
     # a shard of a global data set: the (loss, grad) of two halves add up
     h = n // 2
     l1, g1 = nf.loglikelihood_value_and_gradient(flow, cm(ys[:, :h], dt), n_global=n)
@@ -717,36 +883,49 @@ def test_fused_simple_training_forward_draws_match_supplied_draws(nf, kind, d, d
     assert l_in == pytest.approx(l_xs, rel=tol, abs=tol)
     assert float((g_in - g_xs).abs().max()) <= tol * max(1.0, float(g_xs.abs().max()))
     lr, gr = o.neg_elbo_value_and_grad(spec, th, ("diaggauss", mu, var), xs.cpu().numpy().astype(np.float64))
-    assert l_xs == pytest.approx(lr, rel=1e-10 if f64 else 2e-5)
-    assert np.abs(g_xs.cpu().numpy() - gr).max() <= (1e-9 if f64 else 2e-4) * max(1.0, np.abs(gr).max())
+    P.scalar(f"simple step {kind} d={d} {dtn}: loss", l_xs, lr, 1e-10 if f64 else P.LOSS_RTOL)
+    P.gradient(f"simple step {kind} d={d} {dtn}: grad", g_xs, gr, P.F64_GRAD if f64 else P.GRAD_RTOL)
 
 
-@pytest.mark.parametrize("maker", ["planar5", "radial64", "planar100_f64", "realnvp5", "nsf5", "realnvp5_f64", "wide"])
-def test_rand_flow_is_transform_of_base_draws(nf, maker):
+RAND_CASES = {
+    "planar5": ("planar", 5, 4, (), 0, 0.0, "float32"), "radial64": ("radial", 64, 3, (), 0, 0.0, "float32"),
+    "planar100_f64": ("planar", 100, 2, (), 0, 0.0, "float64"), "realnvp5": ("realnvp", 5, 2, (32, 32), 0, 0.0, "float32"),
+    "nsf5": ("nsf", 5, 2, (32, 32), 10, 5.0, "float32"), "realnvp5_f64": ("realnvp", 5, 1, (16,), 0, 0.0, "float64"),
+    "wide": ("realnvp", 100, 1, (96, 130), 0, 0.0, "float32"), "realnvp64": ("realnvp", 64, 4, (64, 64), 0, 0.0, "float32"),
+    "nsf32": ("nsf", 32, 2, (32, 32), 8, 5.0, "float32"),
+}
+
+
+@pytest.mark.parametrize("maker", list(RAND_CASES))
+def test_rand_flow_matches_oracle_transform_of_oracle_draws(nf, maker):
     """rand(rng, flow, n) / _device_specific_rand(rng, flow, n) (src/NormalizingFlows.jl:117-127): the batched, fused
-    sampler (nf_flow_rand) returns exactly the base draws of the same RNG state pushed through the transform."""
-    mk = {
-        "planar5": lambda: nf.planarflow(nf.MvNormal(5), 4, paramtype=torch.float32, seed=1),
-        "radial64": lambda: nf.radialflow(nf.MvNormal(64), 3, paramtype=torch.float32, seed=2),
-        "planar100_f64": lambda: nf.planarflow(nf.MvNormal(100), 2, paramtype=torch.float64, seed=3),
-        "realnvp5": lambda: nf.realnvp(nf.MvNormal(5), [32, 32], 2, paramtype=torch.float32, seed=4),
-        "nsf5": lambda: nf.nsf(nf.MvNormal(5), [32, 32], 10, 5.0, 2, paramtype=torch.float32, seed=5),
-        "realnvp5_f64": lambda: nf.realnvp(nf.MvNormal(5), [16], 1, paramtype=torch.float64, seed=6),
-        "wide": lambda: nf.realnvp(nf.MvNormal(100), [96, 130], 1, paramtype=torch.float32, seed=7),
-    }
-    flow = mk[maker]()
-    if maker.startswith("planar") or maker.startswith("radial"):
-        with torch.no_grad():
-            flow.theta.mul_(0.3)
-    n = 131
-    ys = nf.rand(flow, n, nf.PhiloxRNG(21))
-    xs = nf.device_specific_rand(nf.PhiloxRNG(21), flow.dist, n, dtype=flow.theta.dtype)
+    sampler (nf_flow_rand) against the ORACLE's transform of the ORACLE's Philox draws for the same (seed, offset,
+    stream) -- and, second, against the device transform of the device draws."""
+    kind, d, nl, hd, K, B, dtn = RAND_CASES[maker]
+    dt = tdt(dtn)
+    spec = o.FlowSpec(kind, d, nl, hd, K, B)
+    rng = np.random.default_rng(len(maker) + d)
+    th = o.init_params(spec, rng)
+    th = th * 0.3 if kind in ("planar", "radial") else th + 0.05 * rng.standard_normal(th.shape)
+    if dtn == "float32":
+        th = th.astype(np.float32).astype(np.float64)
+    flow = nf.Flow(kind, nf.MvNormal(d), nl, hd, K, B, dtype=dt, device="cuda", theta=torch.tensor(th, dtype=dt, device="cuda"))
+    n, off = 131, 1000
+    ys = nf.rand(flow, n, nf.PhiloxRNG(21, sample_offset=off))
+    assert ys.shape == (d, n) and ys.dtype == dt
+    x_ref = o.base_sample(d, n, seed=21, sample_offset=off, stream=0)
+    y_ref, _ = o.flow_fwd(spec, th, x_ref)
+    f64 = dtn == "float64"
+    # fp32: the device draws carry Box-Muller round-off (3e-6 abs, test_base_sampler...), which the flow amplifies like
+    # any other input perturbation; the floor here is the float32 oracle on the float32-rounded oracle draws
+    y32 = None if f64 else o.flow_fwd(spec, *P.f32(th, x_ref))[0]
+    P.elementwise(f"rand {maker}: ys vs oracle(oracle draws)", ys, y_ref, 1e-10 if f64 else 2e-5, 1e-11 if f64 else 1e-5, y32)
+    xs = nf.device_specific_rand(nf.PhiloxRNG(21, sample_offset=off), flow.dist, n, dtype=dt)
     ref = flow.transform(xs)
-    assert ys.shape == (flow.dist.d, n) and ys.dtype == flow.theta.dtype
-    tol = 1e-13 if flow.theta.dtype == torch.float64 else 1e-6
+    tol = 1e-13 if f64 else 1e-6
     assert float((ys - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
     v = nf.rand(flow, None, nf.PhiloxRNG(22))  # a single draw is a vector
-    assert v.shape == (flow.dist.d,)
+    assert v.shape == (d,)
 
 
 @pytest.mark.parametrize("tname", ["funnel", "banana", "diaggauss"])

@@ -311,3 +311,24 @@ def test_loglikelihood_gradient_matches_finite_differences(kind):
         tm[i] -= eps
         gfd[i] = (-o.loglikelihood(spec, tp, ys) + o.loglikelihood(spec, tm, ys)) / (2 * eps)
     np.testing.assert_allclose(g, gfd, rtol=5e-5, atol=2e-7)
+
+
+def test_torch_cpu_baseline_graph_matches_the_oracle():
+    """bench.py's CPU baseline (oracle/nf_torch_cpu.py: the reference's RealNVP step under torch-CPU autograd) computes
+    the same loss and gradient as the hand-derived oracle -- so the thing timed as "CPU" is the algorithm, not a lookalike."""
+    torch = pytest.importorskip("torch")
+    import nf_torch_cpu as tc
+
+    spec = o.FlowSpec("realnvp", 7, 2, (16, 12))
+    rng = np.random.default_rng(5)
+    th = o.init_params(spec, rng) + 0.1 * rng.standard_normal(o.param_count(spec))
+    xs = rng.standard_normal((7, 33))
+    mu, var = rng.standard_normal(7), rng.uniform(size=7) + 0.5
+    l_ref, g_ref = o.neg_elbo_value_and_grad(spec, th, ("diaggauss", mu, var), xs)
+    loss, g = tc.value_and_grad(spec, th, mu, var, xs)
+    assert loss == pytest.approx(l_ref, rel=1e-12)
+    np.testing.assert_allclose(g, g_ref, rtol=1e-9, atol=1e-12)
+    ys, ladj = tc.realnvp_forward(spec, torch.tensor(th), torch.tensor(xs.T.copy()))
+    y_ref, l_ref2 = o.flow_fwd(spec, th, xs)
+    np.testing.assert_allclose(ys.numpy().T, y_ref, rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(ladj.numpy(), l_ref2, rtol=1e-12, atol=1e-13)
