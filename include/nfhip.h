@@ -55,7 +55,12 @@ extern "C" {
                                  joint [x; rho], example/demo_hamiltonian_flow.jl:27-146: d = 2 * dims,
                                  nlayers = blocks, K = leapfrog steps per block, score = target whose
                                  score drives the integrator; targets passed to the ELBO entry points
-                                 describe x, the library adds log N(rho; 0, I) (logp_joint, demo :121-128) */
+                                 describe x, the library adds log N(rho; 0, I) (logp_joint, demo :121-128).
+                                 theta = [shift0(d); scale0(d); per block: shift_rho(d/2), scale_rho(d/2),
+                                 log_eps(d/2)] -- the reference distribution's affine map FIRST (destructure of
+                                 a TransformedDistribution whose `dist` is q0 = transformed(MvNormal, Shift o
+                                 Scale), demo :135-137).  nf_param_count cannot detect a permuted theta: bind
+                                 by name, see INTEGRATION.md "theta order of the Hamiltonian demo flow" */
 
 #define NF_DTYPE_F32 0
 #define NF_DTYPE_F64 1

@@ -760,6 +760,20 @@ def test_hamiltonian_flow_matches_oracle(nf, tname, dtn):
     P.gradient(f"{tag}: grad", g, gr, 1e-9 if dtn == "float64" else P.GRAD_RTOL)
 
 
+def test_hamiltonian_theta_order_reference_map_first(nf):
+    """Device counterpart of tests/test_oracle.py::test_hamiltonian_theta_order_reference_map_first: theta[0:4D] is the
+    reference distribution's Shift / Scale (include/nfhip.h documents the order; the length check cannot)."""
+    D, n, L = 2, 3, 2
+    tgt = nf.DiagGaussTarget(torch.zeros(D, dtype=torch.float64, device="cuda"), torch.ones(D, dtype=torch.float64, device="cuda"))
+    flow = nf.hamiltonianflow(D, n, L, tgt, paramtype=torch.float64)
+    th = np.concatenate([np.arange(1.0, 5.0), np.arange(2.0, 6.0)] + [np.concatenate([np.zeros(D), np.ones(D), np.full(D, -60.0)])] * n)
+    flow = flow.with_theta(torch.tensor(th, device="cuda"))
+    x0 = np.random.default_rng(0).standard_normal((2 * D, 7))
+    z, ladj = nf.with_logabsdet_jacobian(flow.transform, cm(x0, torch.float64))
+    np.testing.assert_allclose(z.cpu().numpy(), th[:4, None] + th[4:8, None] * x0, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(ladj.cpu().numpy(), np.log(th[4:8]).sum(), rtol=1e-12)
+
+
 def test_hamiltonian_flow_demo_trains(nf):
     """The demo's configuration (demo_hamiltonian_flow.jl:114-173: Funnel(2, -8, 5), 15 blocks of 3 leapfrog
     steps, log eps0 = log 0.05, Float64, 16 draws per step, Adam(3e-4), convergence check on the gradient

@@ -332,3 +332,16 @@ def test_torch_cpu_baseline_graph_matches_the_oracle():
     y_ref, l_ref2 = o.flow_fwd(spec, th, xs)
     np.testing.assert_allclose(ys.numpy().T, y_ref, rtol=1e-12, atol=1e-13)
     np.testing.assert_allclose(ladj.numpy(), l_ref2, rtol=1e-12, atol=1e-13)
+
+
+def test_hamiltonian_theta_order_reference_map_first():
+    """The documented theta order of the Hamiltonian demo flow (include/nfhip.h): the reference
+    distribution's Shift / Scale occupy theta[0:4D], the blocks follow.  With vanishing leapfrog steps and identity
+    momentum layers the flow IS that affine map -- the analogue of test/interface.jl:47-48 for this flow."""
+    D, n, L = 2, 3, 2
+    th = np.concatenate([np.arange(1.0, 5.0), np.arange(2.0, 6.0)] + [np.concatenate([np.zeros(D), np.ones(D), np.full(D, -60.0)])] * n)
+    assert th.size == o.hflow_param_count(D, n)
+    x0 = np.random.default_rng(0).standard_normal((2 * D, 7))
+    z, ladj = o.hflow_fwd(D, n, L, th, ("diaggauss", np.zeros(D), np.ones(D)), x0)
+    np.testing.assert_allclose(z, th[:4, None] + th[4:8, None] * x0, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(ladj, np.log(th[4:8]).sum(), rtol=1e-12)
