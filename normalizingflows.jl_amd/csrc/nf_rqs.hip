@@ -154,44 +154,49 @@ __device__ __forceinline__ float sigmoid_f(float x) {
   return x >= 0.f ? nf_fdiv(1.f, 1.f + e) : nf_fdiv(e, 1.f + e);
 }
 
-// Knot positions and the softmax weights behind them.  The knot DERIVATIVES are not built here: only
-// the two at the ends of the bin an element falls into are ever used (forward, inverse and reverse
-// pass alike), so find_bin selects their raw parameters and evaluates those two softplus' -- 4
-// transcendentals instead of 2(K-1), at 16 clocks each on a kernel that is VALU-bound.
+// Knot positions and the softmax weights behind them.  The knot DERIVATIVES are never built as a vector: only
+// the two at the ends of the bin an element falls into are used (forward, inverse and reverse pass alike), so
+// find_bin selects their raw parameters and evaluates those two softplus' -- 4 transcendentals instead of 2(K-1),
+// at 16 clocks each on kernels that are VALU-bound.
 template <int K>
 struct Knots {
   float pX[K + 1], pY[K + 1], smw[K], smh[K];
   const float *rawd;  // raw[2K .. 3K-2]: interior derivative parameters (registers, compile-time indexed)
-  float dd[K + 1];    // EAGER mode only: all knot derivatives (see build_knots)
+  float dd[K + 1];    // EAGER mode only (the reverse kernel): all knot derivatives, see build_knots
 };
+
+constexpr float NF_LOG2E = 1.4426950408889634f;
 
 template <int K>
 __device__ __forceinline__ void softmax_knots(const float *v, float B, float *sm, float *p) {
   float mx = v[0];
 #pragma unroll
   for (int k = 1; k < K; ++k) mx = fmaxf(mx, v[k]);
+  const float nmx = -mx * NF_LOG2E;
   float sum = 0.f;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    sm[k] = __expf(v[k] - mx);
+    sm[k] = __builtin_amdgcn_exp2f(fmaf(v[k], NF_LOG2E, nmx));  // exp(v - max): one fma + v_exp_f32
     sum += sm[k];
   }
   const float inv = nf_fdiv(1.f, sum);
+  const float twoB = 2.f * B;
   float cs = 0.f;
   p[0] = -B;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     sm[k] *= inv;
     cs += sm[k];
-    p[k + 1] = -B + 2.f * B * cs;
+    p[k + 1] = fmaf(twoB, cs, -B);
   }
 }
 
-// raw[0:K] widths, raw[K:2K] heights, raw[2K:3K-1] interior derivatives
-// LAZY (forward / inverse chain): derivatives are evaluated by find_bin.  EAGER (reverse kernel): all of
-// them here, as before -- there the lazy form lengthens the live range of the raw parameters and tips
-// hipcc's register allocation into 140 spilled registers (212 vs 168 us per launch).
-template <int K, bool LAZY>
+// raw[0:K] widths, raw[K:2K] heights, raw[2K:3K-1] interior derivatives.
+// LAZY (forward / inverse chain): the two derivatives an element needs are evaluated by find_bin.  EAGER (reverse
+// kernel): all of them here -- measured on the reverse kernel, the lazy form keeps the raw derivative parameters
+// live through the bin search and tips hipcc's allocation over the register wall (224 dW accumulators): 496 B of
+// scratch spills, 204 instead of 166 us per launch, although it executes 10 % fewer instructions.
+template <int K, bool LAZY = true>
 __device__ __forceinline__ void build_knots(const float *raw, float B, Knots<K> &kn) {
   softmax_knots<K>(raw, B, kn.smw, kn.pX);
   softmax_knots<K>(raw + K, B, kn.smh, kn.pY);
@@ -204,51 +209,56 @@ __device__ __forceinline__ void build_knots(const float *raw, float B, Knots<K> 
   }
 }
 
+// The bin an element falls into, as the bin search leaves it: the knots at both ends, the two knot derivatives,
+// and the search CONDITIONS ge[j] <=> v >= p[j] (ge[0] = true, ge[K] = false).  The knot vector is increasing,
+// so the bin index is k = #{j in 1..K-1 : ge[j]} and
+//     i <  k  <=>  ge[i + 1],        i == k  <=>  ge[i] && !ge[i + 1]
+// -- every "is this the bin / is this left of the bin" test of the reverse pass is one of these lane masks,
+// already sitting in scalar registers; no integer index is ever formed or compared.
+template <int K>
 struct Bin {
   float xk, xk1, yk, yk1, d0, d1;
-  int k;
+  bool ge[K + 1];
   bool inside;
 };
 
-// bin with p[k] <= v < p[k+1] on the knot vector `p` (pX forward, pY inverse)
-template <int K, bool LAZY>
-__device__ __forceinline__ Bin find_bin(const Knots<K> &kn, const float *p, float v) {
-  Bin b;
+// bin with p[k] <= v < p[k+1] on the knot vector `p` (pX forward, pY inverse): one ascending select chain
+template <int K, bool LAZY = true>
+__device__ __forceinline__ void find_bin(const Knots<K> &kn, const float *p, float v, Bin<K> &b) {
   b.inside = (v >= p[0]) && (v < p[K]);
-  int k = 0;
-#pragma unroll
-  for (int j = 1; j < K; ++j) k += (v >= p[j]) ? 1 : 0;
-  b.k = k;
+  b.ge[0] = true;
+  b.ge[K] = false;
   b.xk = kn.pX[0]; b.xk1 = kn.pX[1]; b.yk = kn.pY[0]; b.yk1 = kn.pY[1];
   if (LAZY) {
     float r0 = 0.f, r1 = kn.rawd[0];  // raw derivative parameters of knots k and k+1 (knot j <-> rawd[j-1])
 #pragma unroll
     for (int j = 1; j < K; ++j) {
-      const bool is = (k == j);
-      b.xk = is ? kn.pX[j] : b.xk;
-      b.xk1 = is ? kn.pX[j + 1] : b.xk1;
-      b.yk = is ? kn.pY[j] : b.yk;
-      b.yk1 = is ? kn.pY[j + 1] : b.yk1;
-      r0 = is ? kn.rawd[j - 1] : r0;
-      if (j < K - 1) r1 = is ? kn.rawd[j] : r1;
+      const bool c = v >= p[j];
+      b.ge[j] = c;
+      b.xk = c ? kn.pX[j] : b.xk;
+      b.xk1 = c ? kn.pX[j + 1] : b.xk1;
+      b.yk = c ? kn.pY[j] : b.yk;
+      b.yk1 = c ? kn.pY[j + 1] : b.yk1;
+      r0 = c ? kn.rawd[j - 1] : r0;
+      if (j < K - 1) r1 = c ? kn.rawd[j] : r1;
     }
-    b.d0 = (k == 0) ? 1.f : softplus_f(r0);  // boundary derivatives are 1
-    b.d1 = (k == K - 1) ? 1.f : softplus_f(r1);
+    b.d0 = b.ge[1] ? softplus_f(r0) : 1.f;      // k == 0: boundary derivative 1
+    b.d1 = b.ge[K - 1] ? 1.f : softplus_f(r1);  // k == K-1: boundary derivative 1
   } else {
     b.d0 = kn.dd[0];
     b.d1 = kn.dd[1];
 #pragma unroll
     for (int j = 1; j < K; ++j) {
-      const bool is = (k == j);
-      b.xk = is ? kn.pX[j] : b.xk;
-      b.xk1 = is ? kn.pX[j + 1] : b.xk1;
-      b.yk = is ? kn.pY[j] : b.yk;
-      b.yk1 = is ? kn.pY[j + 1] : b.yk1;
-      b.d0 = is ? kn.dd[j] : b.d0;
-      b.d1 = is ? kn.dd[j + 1] : b.d1;
+      const bool c = v >= p[j];
+      b.ge[j] = c;
+      b.xk = c ? kn.pX[j] : b.xk;
+      b.xk1 = c ? kn.pX[j + 1] : b.xk1;
+      b.yk = c ? kn.pY[j] : b.yk;
+      b.yk1 = c ? kn.pY[j + 1] : b.yk1;
+      b.d0 = c ? kn.dd[j] : b.d0;
+      b.d1 = c ? kn.dd[j + 1] : b.d1;
     }
   }
-  return b;
 }
 
 __device__ __forceinline__ float rq_logderiv(float s, float d0, float d1, float xi) {
@@ -258,9 +268,10 @@ __device__ __forceinline__ float rq_logderiv(float s, float d0, float d1, float 
 }
 
 // rqs_forward for one element: returns y, adds log dy/dx to logd
-template <int K, bool LAZY>
+template <int K>
 __device__ __forceinline__ float rqs_fwd_elem(const Knots<K> &kn, float x, float &logd) {
-  const Bin b = find_bin<K, LAZY>(kn, kn.pX, x);
+  Bin<K> b;
+  find_bin<K>(kn, kn.pX, x, b);
   const float dx = b.xk1 - b.xk, dy = b.yk1 - b.yk;
   const float s = nf_fdiv(dy, dx);
   const float xi = nf_fdiv(x - b.xk, dx), om = 1.f - xi;
@@ -270,10 +281,10 @@ __device__ __forceinline__ float rqs_fwd_elem(const Knots<K> &kn, float x, float
   return b.inside ? y : x;
 }
 
-// rqs_inverse for one element: returns x and the bin / xi it lies in; adds -log dy/dx to logd
-template <int K, bool LAZY>
-__device__ __forceinline__ float rqs_inv_elem(const Knots<K> &kn, float y, float &logd, Bin &b, float &xi_out) {
-  b = find_bin<K, LAZY>(kn, kn.pY, y);
+// rqs_inverse for one element: returns x and the bin / xi it lies in; adds -log dy/dx to logd when WANT_LOGD
+template <int K, bool WANT_LOGD = true, bool LAZY = true>
+__device__ __forceinline__ float rqs_inv_elem(const Knots<K> &kn, float y, float &logd, Bin<K> &b, float &xi_out) {
+  find_bin<K, LAZY>(kn, kn.pY, y, b);
   const float dx = b.xk1 - b.xk, dy = b.yk1 - b.yk;
   const float s = nf_fdiv(dy, dx);
   const float yy = y - b.yk;
@@ -284,7 +295,7 @@ __device__ __forceinline__ float rqs_inv_elem(const Knots<K> &kn, float y, float
   const float disc = fmaxf(bb * bb - 4.f * a * c, 0.f);
   const float xi = nf_fdiv(2.f * c, -bb - __builtin_amdgcn_sqrtf(disc));
   xi_out = xi;
-  logd -= b.inside ? rq_logderiv(s, b.d0, b.d1, xi) : 0.f;
+  if (WANT_LOGD) logd -= b.inside ? rq_logderiv(s, b.d0, b.d1, xi) : 0.f;
   return b.inside ? xi * dx + b.xk : y;
 }
 
@@ -293,29 +304,33 @@ __device__ __forceinline__ float rqs_inv_elem(const Knots<K> &kn, float y, float
 // (x, ladj_inv = -log S'(x)); implicit-function form vbar = (ybar - lbar dlogS'/dx) / S', parameters =
 // the forward formulas with (-vbar, -lbar).  Returns vbar.
 template <int K, bool INVD = false>
-__device__ __forceinline__ float rqs_bwd_elem(const Knots<K> &kn, const float *raw, const Bin &b, float xi, float B,
-                                              float ybar, float lbar, float *thbar) {
+__device__ __forceinline__ float rqs_bwd_elem(const Knots<K> &kn, const Bin<K> &b, float xi, float B, float ybar,
+                                              float lbar, float *thbar) {
   const float dx = b.xk1 - b.xk, dy = b.yk1 - b.yk;
   const float s = nf_fdiv(dy, dx), om = 1.f - xi;
   const float d0 = b.d0, d1 = b.d1;
   const float q = d1 + d0 - 2.f * s;
-  const float den = s + q * xi * om;
-  const float num = s * xi * xi + d0 * xi * om;
-  const float nd = d1 * xi * xi + 2.f * s * xi * om + d0 * om * om;
+  const float xo = xi * om;
+  const float den = s + q * xo;
+  const float num = s * xi * xi + d0 * xo;
+  const float nd = d1 * xi * xi + 2.f * s * xo + d0 * om * om;
   const float iden = nf_fdiv(1.f, den), ind = nf_fdiv(1.f, nd), idx = nf_fdiv(1.f, dx);
   const float iden2 = iden * iden;
-  const float dnum_dxi = 2.f * s * xi + d0 * (1.f - 2.f * xi);
-  const float dden_dxi = q * (1.f - 2.f * xi);
-  const float dnd_dxi = 2.f * d1 * xi + 2.f * s * (1.f - 2.f * xi) - 2.f * d0 * om;
-  const float dy_dxi = dy * (dnum_dxi * den - num * dden_dxi) * iden2;
+  const float t12 = 1.f - 2.f * xi;
+  const float dnum_dxi = 2.f * s * xi + d0 * t12;
+  const float dden_dxi = q * t12;
+  const float dnd_dxi = 2.f * d1 * xi + 2.f * s * t12 - 2.f * d0 * om;
+  const float dyi = dy * iden2;
+  const float dy_dxi = dyi * (dnum_dxi * den - num * dden_dxi);
   const float dL_dxi = dnd_dxi * ind - 2.f * dden_dxi * iden;
-  const float dden_ds = 1.f - 2.f * xi * om;
-  const float dy_ds = dy * (xi * xi * den - num * dden_ds) * iden2;
-  const float dL_ds = nf_fdiv(2.f, s) + 2.f * xi * om * ind - 2.f * dden_ds * iden;
-  const float dy_dd0 = dy * (xi * om * den - num * xi * om) * iden2;
-  const float dL_dd0 = om * om * ind - 2.f * xi * om * iden;
-  const float dy_dd1 = dy * (-num * xi * om) * iden2;
-  const float dL_dd1 = xi * xi * ind - 2.f * xi * om * iden;
+  const float dden_ds = 1.f - 2.f * xo;
+  const float dy_ds = dyi * (xi * xi * den - num * dden_ds);
+  const float dL_ds = nf_fdiv(2.f, s) + 2.f * xo * ind - 2.f * dden_ds * iden;
+  const float nxo = num * xo;
+  const float dy_dd0 = dyi * (xo * den - nxo);
+  const float dL_dd0 = om * om * ind - 2.f * xo * iden;
+  const float dy_dd1 = -dyi * nxo;
+  const float dL_dd1 = xi * xi * ind - 2.f * xo * iden;
   // every parameter cotangent is linear in (ybar, lbar): zeroing them outside the box (identity
   // branch) makes all of them vanish without per-parameter selects
   float yb = b.inside ? ybar : 0.f, lbr = b.inside ? lbar : 0.f;
@@ -333,25 +348,27 @@ __device__ __forceinline__ float rqs_bwd_elem(const Knots<K> &kn, const float *r
   const float dxbar = -sbar * s * idx - xibar * xi * idx;
   const float xkbar = -xibar * idx - dxbar, xk1bar = dxbar;
   const float ykbar = yb - dybar, yk1bar = dybar;
-  // knots: p[j] = -B + 2B sum_{i<j} sm_i  =>  dL/dsm_i = 2B * sum_{j>i} pbar[j]; only pbar[k], pbar[k+1] != 0
-  float dotw = 0.f, doth = 0.f;
-  float sbw[K], sbh[K];
+  // knots: p[j] = -B + 2B sum_{i<j} sm_i  =>  dL/dsm_i = 2B * (pbar[k] + pbar[k+1]) for i < k, 2B * pbar[k+1] for
+  // i == k, 0 beyond.  The softmax pullback needs dot = sum_i dL/dsm_i * sm_i, which has a closed form:
+  // sum_{i<k} sm_i = (p[k] + B) / 2B and sm_k = (p[k+1] - p[k]) / 2B, both already in hand.
+  const float twoB = 2.f * B;
+  const float aw = xkbar + xk1bar, ah = ykbar + yk1bar;
+  const float dotw = fmaf(aw, b.xk + B, xk1bar * dx);
+  const float doth = fmaf(ah, b.yk + B, yk1bar * dy);
+  const float aw2 = twoB * aw - dotw, bw2 = twoB * xk1bar - dotw;  // (dL/dsm_i - dot) for i < k, i == k; -dot beyond
+  const float ah2 = twoB * ah - doth, bh2 = twoB * yk1bar - doth;
 #pragma unroll
   for (int i = 0; i < K; ++i) {
-    sbw[i] = 2.f * B * ((i < b.k) ? (xkbar + xk1bar) : ((i == b.k) ? xk1bar : 0.f));
-    sbh[i] = 2.f * B * ((i < b.k) ? (ykbar + yk1bar) : ((i == b.k) ? yk1bar : 0.f));
-    dotw += sbw[i] * kn.smw[i];
-    doth += sbh[i] * kn.smh[i];
+    const float sw = b.ge[i + 1] ? aw2 : (b.ge[i] ? bw2 : -dotw);
+    const float sh = b.ge[i + 1] ? ah2 : (b.ge[i] ? bh2 : -doth);
+    thbar[i] = kn.smw[i] * sw;
+    thbar[K + i] = kn.smh[i] * sh;
   }
-#pragma unroll
-  for (int i = 0; i < K; ++i) {
-    thbar[i] = kn.smw[i] * (sbw[i] - dotw);
-    thbar[K + i] = kn.smh[i] * (sbh[i] - doth);
-  }
-  // d/draw softplus = sigmoid(raw) = 1 - exp(-softplus(raw)); only knots k and k+1 carry a cotangent
+  // d/draw softplus = sigmoid(raw) = 1 - exp(-softplus(raw)); only knots k and k+1 carry a cotangent:
+  // knot j is the bin's left end iff ge[j] && !ge[j+1], its right end iff ge[j-1] && !ge[j]
   const float g0 = d0bar * (1.f - __expf(-d0)), g1 = d1bar * (1.f - __expf(-d1));
 #pragma unroll
-  for (int j = 1; j < K; ++j) thbar[2 * K + j - 1] = ((j == b.k) ? g0 : 0.f) + ((j == b.k + 1) ? g1 : 0.f);
+  for (int j = 1; j < K; ++j) thbar[2 * K + j - 1] = b.ge[j + 1] ? 0.f : (b.ge[j] ? g0 : (b.ge[j - 1] ? g1 : 0.f));
   return b.inside ? (INVD ? vbar : xibar * idx) : ybar;
 }
 
@@ -413,15 +430,15 @@ __device__ __forceinline__ float rqs_coupling_step(const float *__restrict__ img
       float raw[G::P];
       chunk_get<G>(out, ql, raw);
       Knots<G::K> kn;
-      build_knots<G::K, true>(raw, B, kn);
+      build_knots<G::K>(raw, B, kn);
       const float v = x1[q / 16][q % 16];
       float logd = 0.f, res;
       if (INVERSE) {
-        Bin bn;
+        Bin<G::K> bn;
         float xi;
-        res = rqs_inv_elem<G::K, true>(kn, v, logd, bn, xi);
+        res = rqs_inv_elem<G::K>(kn, v, logd, bn, xi);
       } else {
-        res = rqs_fwd_elem<G::K, true>(kn, v, logd);
+        res = rqs_fwd_elem<G::K>(kn, v, logd);
       }
       const bool ok = p < c;  // padded dims: keep the zero, contribute nothing
       x1[q / 16][q % 16] = ok ? res : v;
@@ -578,6 +595,9 @@ __device__ __forceinline__ void rqs_fold(float *__restrict__ w, float *__restric
   }
 }
 
+#ifndef RQS_BWD_LAZY
+#define RQS_BWD_LAZY false
+#endif
 // INVD: reverse pass of the INVERSE coupling at its output (forward-KL training): `y` holds w and is advanced
 // to coupling(w); `ybar` the cotangent of w -> that of the inverse's input; lbar the cotangent of ladj_inv.
 template <class G, bool INVD = false>
@@ -663,25 +683,34 @@ __device__ __forceinline__ void rqs_bwd_tile(const RqsBwdArgs &a, const float *_
       float raw[G::P], thb[G::P];
       chunk_get<G>(out, ql, raw);
       Knots<G::K> kn;
-      build_knots<G::K, false>(raw, a.B, kn);
+      build_knots<G::K, RQS_BWD_LAZY>(raw, a.B, kn);
       const float yv = yq[ql];
       const float gv = ok ? gq[ql] : 0.f;
       // invert to the coupling input (src/flows/neuralspline.jl:134-140), then differentiate the
       // forward map at that point
       float dummy = 0.f, xi;
-      Bin bn;
+      Bin<G::K> bn;
       float xv;
       if (INVD) {  // the point is already the spline's input: locate it, and advance the state through the spline
-        bn = find_bin<G::K, false>(kn, kn.pX, yv);
-        xi = nf_fdiv(yv - bn.xk, bn.xk1 - bn.xk);
-        xv = rqs_fwd_elem<G::K, false>(kn, yv, dummy);
+        find_bin<G::K, RQS_BWD_LAZY>(kn, kn.pX, yv, bn);
+        const float dx = bn.xk1 - bn.xk, dy = bn.yk1 - bn.yk;
+        const float sl = nf_fdiv(dy, dx);
+        xi = nf_fdiv(yv - bn.xk, dx);
+        const float om = 1.f - xi;
+        const float den = sl + (bn.d1 + bn.d0 - 2.f * sl) * xi * om;
+        xv = bn.inside ? bn.yk + nf_fdiv(dy * (sl * xi * xi + bn.d0 * xi * om), den) : yv;
       } else {
-        xv = rqs_inv_elem<G::K, false>(kn, yv, dummy, bn, xi);
+        xv = rqs_inv_elem<G::K, false, RQS_BWD_LAZY>(kn, yv, dummy, bn, xi);
       }
-      const float xbar = rqs_bwd_elem<G::K, INVD>(kn, raw, bn, xi, a.B, gv, ok ? lb : 0.f, thb);  // gv, lb are 0 when !ok
+      const float xbar = rqs_bwd_elem<G::K, INVD>(kn, bn, xi, a.B, gv, ok ? lb : 0.f, thb);  // gv, lb are 0 when !ok
       chunk_put<G>(out, ql, thb);
       tile_store(yio, tile_soff(q / 16, q % 16, a.par_t), xv);    // coupling input x1
       tile_store(gio, tile_soff(q / 16, q % 16, a.par_t), xbar);  // its cotangent
+#ifndef NF_RQS_NO_ELEM_FENCE
+      // one element at a time: interleaving the two elements of a chunk doubles the live temporaries, and this kernel
+      // sits at the register wall (224 dW accumulators in AGPRs + the chunk's 48 raw outputs + knots)
+      __builtin_amdgcn_sched_barrier(0);
+#endif
     }
     // unused slots of the chunk (beyond QCH * P) carry raw outputs of zero-weight rows: clear them
 #pragma unroll
