@@ -65,6 +65,12 @@ int nf_rqs_bwd_grid(nf_ctx *, long N);
 int nf_rqs_bwd(nf_ctx *, const nf_flow_desc *, int k, float *y, float *ybar, const float *lbar, float lbar_const, long N,
                float *slab, long slab_stride, int grid, bool inv_dir = false);
 long nf_rqs_slab_floats(const nf_flow_desc *desc);
+int nf_rqs_bwd_all(nf_ctx *, const nf_flow_desc *, float *y, float *ybar, const float *lbar, float lbar_const, long N,
+                   float *slab, long slab_stride, int grid, bool inv_dir = false);
+long nf_rqs_chain_grid(nf_ctx *, long N);
+int nf_rqs_chain_elbo(nf_ctx *, const nf_flow_desc *, long N, uint64_t seed, uint64_t off, uint32_t stream,
+                      const float *mu, const float *var, float *yt, float *gt, double gscale, double *partial,
+                      double pscale);
 int nf_rqs_reduce_slabs(nf_ctx *, const nf_flow_desc *, const float *slab, int nslab, float *g);
 
 // planar / radial / mean-field flows (nf_simple.hip)
@@ -353,8 +359,22 @@ static long coupling_slab_floats(nf_ctx *ctx, const nf_flow_desc *desc, long N) 
 // The ELBO forward of a training step fuses into ONE launch (draws + chain + target + partial sums)
 // when the draws are in-library, the nets are LDS-resident and the target is the diagonal Gaussian.
 static inline bool elbo_fusable(const nf_flow_desc *desc, const nf_target *target, const void *xs) {
-  return !xs && desc->kind == NF_KIND_REALNVP && nf_affine_supported(desc) && target->kind == NF_TARGET_DIAGGAUSS &&
-         target->p0 && target->p1;
+  const bool resident = (desc->kind == NF_KIND_REALNVP && nf_affine_supported(desc)) ||
+                        (desc->kind == NF_KIND_NSF && nf_rqs_supported(desc));
+  return !xs && desc->dtype == NF_DTYPE_F32 && resident && target->kind == NF_TARGET_DIAGGAUSS && target->p0 && target->p1;
+}
+// the fused forward launch (draws + chain + target + ELBO partial sums) of the two LDS-resident coupling families
+static int fused_chain_elbo(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, long N, uint64_t seed,
+                            uint64_t off, uint32_t stream_id, float *yt, float *gt, double gscale, double *partial,
+                            double pscale) {
+  if (desc->kind == NF_KIND_NSF)
+    return nf_rqs_chain_elbo(ctx, desc, N, seed, off, stream_id, (const float *)target->p0, (const float *)target->p1, yt, gt,
+                             gscale, partial, pscale);
+  return nf_affine_chain_elbo(ctx, desc, N, seed, off, stream_id, (const float *)target->p0, (const float *)target->p1, yt, gt,
+                              gscale, partial, pscale);
+}
+static long fused_chain_grid(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
+  return desc->kind == NF_KIND_NSF ? nf_rqs_chain_grid(ctx, N) : nf_affine_chain_grid(ctx, N);
 }
 
 // all couplings (or one, if k_only >= 0) in execution order / inverse order, in place on `xt`
@@ -451,14 +471,18 @@ static int realnvp_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta
     NF_TRY(nf_affine_bwd_all(ctx, desc, state, gbar, lbar, lbar_const, N, slab, stride, grid));
     return nf_affine_reduce_slabs(ctx, desc, slab, grid, g_out, lpart, nlpart, lout);
   }
-  for (int k = 0; k < nc; ++k) {  // flat order = reverse of execution order
-    if (is_nsf(desc))
-      NF_TRY(nf_rqs_bwd(ctx, desc, k, state, gbar, lbar, lbar_const, N, slab, stride, grid));
-    else
-      NF_TRY(nf_affine_bwd(ctx, desc, k, theta, state, gbar, lbar, lbar_const, N, slab, stride, grid));
+  // Neural spline couplings: one launch per coupling.  The single-launch form exists (k_rqs_bwd_all, the structure of
+  // k_affine_bwd_all; NF_RQS_BWD_FUSED=1 selects it) but MEASURED SLOWER on this kernel, A/B on one box: 1329 us for
+  // the 8 couplings against 8 x 159.5 us = 1276 us, step 1.729 vs 1.657 ms -- the kernel sits at the register wall
+  // (256 VGPR + 256 AGPR), and the outer coupling loop costs it 40 more bytes of scratch spills per lane than the
+  // launch gaps it saves (profiles/r2_cfg3_fused_vs_split.txt).
+  static const bool fused = std::getenv("NF_RQS_BWD_FUSED") != nullptr;
+  if (!fused) {
+    for (int k = 0; k < nc; ++k) NF_TRY(nf_rqs_bwd(ctx, desc, k, state, gbar, lbar, lbar_const, N, slab, stride, grid));
+  } else {
+    NF_TRY(nf_rqs_bwd_all(ctx, desc, state, gbar, lbar, lbar_const, N, slab, stride, grid));
   }
-  if (is_nsf(desc)) return nf_rqs_reduce_slabs(ctx, desc, slab, grid, g_out);
-  return nf_affine_reduce_slabs(ctx, desc, slab, grid, g_out);
+  return nf_rqs_reduce_slabs(ctx, desc, slab, grid, g_out);
 }
 
 // reverse pass of the INVERSE coupling chain on tiled buffers (forward-KL training): `state` holds
@@ -475,7 +499,7 @@ static int coupling_inv_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const float *
   }
   if (desc->kind == NF_KIND_NSF && nf_rqs_supported(desc)) {
     const long stride = coupling_slab_floats(ctx, desc, N);
-    for (int k = 2 * desc->nlayers - 1; k >= 0; --k)  // forward execution order
+    for (int k = 2 * desc->nlayers - 1; k >= 0; --k)  // forward execution order (one launch per coupling: see realnvp_bwd)
       NF_TRY(nf_rqs_bwd(ctx, desc, k, state, gbar, nullptr, lbar_const, N, slab, stride, grid, true));
     return nf_rqs_reduce_slabs(ctx, desc, slab, grid, g_out);
   }
@@ -525,20 +549,20 @@ static int elbo_forward(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *
   const size_t es = esize(desc->dtype);
   const bool cp = is_coupling(desc);
   const long nb = cp ? nf_target_tiled_nblocks(N) : nf_target_nblocks(N);
+  const long nb_alloc = nb < ctx->num_cu ? ctx->num_cu : nb;  // the fused forward leaves one partial per workgroup
   const size_t xe = cp ? tiled_elems(desc, N) : (size_t)N * desc->d;
-  const size_t need = carve_bytes(xe * es) + 2 * carve_bytes((size_t)N * es) + carve_bytes((size_t)nb * 8) + carve_bytes(64);
+  const size_t need = carve_bytes(xe * es) + 2 * carve_bytes((size_t)N * es) + carve_bytes((size_t)nb_alloc * 8) + carve_bytes(64);
   NF_TRY(nf_ws_reserve(ctx, need));
   Carver cv(ctx->ws);
   char *x = cv.take<char>(xe * es);
   char *logq = cv.take<char>((size_t)N * es);
   char *ladj = cv.take<char>((size_t)N * es);
-  double *partial = cv.take<double>(nb);
+  double *partial = cv.take<double>(nb_alloc);
   double *result = cv.take<double>(8);
   if (cp && !elbos_out && elbo_fusable(desc, target, xs)) {
     NF_TRY(coupling_pack(ctx, desc, (const float *)theta));
-    NF_TRY(nf_affine_chain_elbo(ctx, desc, N, seed, off, stream_id, (const float *)target->p0, (const float *)target->p1,
-                                (float *)x, nullptr, 0.0, partial, 1.0 / (double)N));
-    NF_TRY(nf_launch_finish_sum(ctx, partial, nf_affine_chain_grid(ctx, N), 0, result, nullptr, nullptr));
+    NF_TRY(fused_chain_elbo(ctx, desc, target, N, seed, off, stream_id, (float *)x, nullptr, 0.0, partial, 1.0 / (double)N));
+    NF_TRY(nf_launch_finish_sum(ctx, partial, fused_chain_grid(ctx, desc, N), 0, result, nullptr, nullptr));
     return read_scalar(ctx, result, elbo_host);
   }
   if (cp) {
@@ -708,12 +732,13 @@ extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, con
   const double inv = 1.0 / (double)N_global;
   const bool cp = is_coupling(desc);
   const long nb = cp ? nf_target_tiled_nblocks(N) : nf_target_nblocks(N);
+  const long nb_alloc = nb < ctx->num_cu ? ctx->num_cu : nb;  // the fused forward leaves one partial per workgroup
   const int grid = cp ? coupling_bwd_grid(ctx, desc, N) : 0;
   const size_t simple_ws = cp ? 0 : flat_bwd_ws_bytes(ctx, desc, N);
   const bool wide = cp && is_wide(desc);
   const size_t slabf = wide ? nf_wide_train_ws_floats(ctx, desc, N) : cp ? (size_t)grid * coupling_slab_floats(ctx, desc, N) : 0;
   const size_t xe = cp ? tiled_elems(desc, N) : (size_t)N * desc->d;
-  const size_t need = 3 * carve_bytes(xe * es) + 2 * carve_bytes((size_t)N * es) + carve_bytes((size_t)nb * 8) +
+  const size_t need = 3 * carve_bytes(xe * es) + 2 * carve_bytes((size_t)N * es) + carve_bytes((size_t)nb_alloc * 8) +
                       carve_bytes(64) + carve_bytes(slabf * es) + carve_bytes(simple_ws);
   NF_TRY(nf_ws_reserve(ctx, need));
   Carver cv(ctx->ws);
@@ -722,7 +747,7 @@ extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, con
   char *x0 = cv.take<char>(xe * es);  // flow input kept for the non-invertible (planar/radial) recompute
   char *logq = cv.take<char>((size_t)N * es);
   char *ladj = cv.take<char>((size_t)N * es);
-  double *partial = cv.take<double>(nb);
+  double *partial = cv.take<double>(nb_alloc);
   double *result = cv.take<double>(8);
   (void)result;
   char *slab = cv.take<char>(slabf * es);
@@ -731,8 +756,11 @@ extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, con
   if (cp && elbo_fusable(desc, target, xs)) {
     float *xt = (float *)x, *gt = (float *)gbar;
     NF_TRY(coupling_pack(ctx, desc, (const float *)theta));
-    NF_TRY(nf_affine_chain_elbo(ctx, desc, N, seed, sample_offset, stream_id, (const float *)target->p0,
-                                (const float *)target->p1, xt, gt, -inv, partial, -inv));
+    NF_TRY(fused_chain_elbo(ctx, desc, target, N, seed, sample_offset, stream_id, xt, gt, -inv, partial, -inv));
+    if (is_nsf(desc)) {
+      NF_TRY(nf_launch_finish_sum(ctx, partial, fused_chain_grid(ctx, desc, N), 0, nullptr, (float *)out + P, nullptr));
+      return realnvp_bwd(ctx, desc, (const float *)theta, xt, gt, nullptr, (float)(-inv), N, (float *)slab, grid, (float *)out);
+    }
     // the loss partials of the fused forward are finished by the slab-reduction launch
     return realnvp_bwd(ctx, desc, (const float *)theta, xt, gt, nullptr, (float)(-inv), N, (float *)slab, grid, (float *)out,
                        partial, (int)nf_affine_chain_grid(ctx, N), (float *)out + P);

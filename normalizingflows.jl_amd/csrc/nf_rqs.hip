@@ -21,6 +21,7 @@
 // reverse pass) then runs entirely in registers, one (dim, sample) per lane at a time.
 #include "nf_common.h"
 #include "nf_mfma.h"
+#include "nf_philox.h"
 
 template <int MB_, int H1B_, int H2B_, int K_, int NCH_, int QCH_ = 2>
 struct RqsGeo {
@@ -448,8 +449,23 @@ __device__ __forceinline__ float rqs_coupling_step(const float *__restrict__ img
   return lsum;
 }
 
-template <class G, bool INVERSE>
-__global__ __launch_bounds__(512) void k_rqs_chain(RqsChainArgs a, float *xt, float *__restrict__ ladj) {
+// FUSED (forward only): the ELBO forward of the training step in the same launch, as k_affine_chain<.., FUSED> does
+// (nf_coupling.hip): the tile's base draws are generated in registers (Philox4x32-10 + Box-Muller, the counters of
+// k_base_sample_tiled), log q0 and the accumulated log|det J| never touch memory, and after the last coupling the
+// diagonal-Gaussian target, ybar = gscale * grad log p(y) and the workgroup's partial sum of pscale * elbo_j come out
+// of the registers (src/objectives/elbo.jl:65-70,93-97).
+struct RqsFusedArgs {
+  uint32_t k0, k1, stream;
+  uint64_t off;           // global index of this shard's first sample
+  const float *mu, *var;  // diagonal-Gaussian target (test/flow.jl:43-46)
+  float *gt;              // ybar out (tiled), or nullptr
+  float gscale;
+  double *partial;        // [gridDim.x] out
+  double pscale;
+};
+
+template <class G, bool INVERSE, bool FUSED = false>
+__global__ __launch_bounds__(512) void k_rqs_chain(RqsChainArgs a, float *xt, float *__restrict__ ladj, RqsFusedArgs fa) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NV4 = G::SIZE / 4;
   constexpr int PER = (NV4 + 511) / 512;
@@ -464,6 +480,22 @@ __global__ __launch_bounds__(512) void k_rqs_chain(RqsChainArgs a, float *xt, fl
     float4 *dst = reinterpret_cast<float4 *>(lds);
     for (int i = tid; i < NV4; i += 512) dst[i] = src[i];
   }
+  // FUSED: target parameters by feature, zero padded: tmu[f], tiv[f] = 1/var[f]; tc0 = d log 2pi + sum log var
+  constexpr int TP = 64 * G::CB;
+  float *tmu = lds + 2 * G::SIZE, *tiv = tmu + TP, *tc0 = tiv + TP;
+  double *wsum = reinterpret_cast<double *>(tc0 + 2);  // [8] per-wave partial sums (G::SIZE and TP are even)
+  if (FUSED) {
+    for (int i = tid; i < TP; i += 512) {
+      tmu[i] = i < a.d ? fa.mu[i] : 0.f;
+      tiv[i] = i < a.d ? 1.f / fa.var[i] : 0.f;
+    }
+    if (tid == 0) {
+      float c = 1.8378770664093453f * (float)a.d;
+      for (int i = 0; i < a.d; ++i) c += logf(fa.var[i]);
+      tc0[0] = c;
+    }
+  }
+  double wg_total = 0.0;
   __syncthreads();
   const int c_odd = (a.d + 1) / 2, c_even = a.d / 2;  // mask 1:2:d / 2:2:d
   int buf = 0;
@@ -475,15 +507,45 @@ __global__ __launch_bounds__(512) void k_rqs_chain(RqsChainArgs a, float *xt, fl
     const bool valid = live && j < a.N;
     const TileIO io = make_tile_io(xt, tl, a.d, l31, hi);
     f32x16 E[G::CB], O[G::MB];
+    float zz = 0.f;  // FUSED: this lane's share of ||x||^2
+    if (!FUSED) {
 #pragma unroll
-    for (int b = 0; b < G::CB; ++b)
+      for (int b = 0; b < G::CB; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = tile_load(io, tile_soff(b, r, 0));
-        const float o = tile_load(io, tile_soff(b, r, 1));
-        E[b][r] = valid ? e : 0.f;
-        O[b][r] = valid ? o : 0.f;
-      }
+        for (int r = 0; r < 16; ++r) {
+          const float e = tile_load(io, tile_soff(b, r, 0));
+          const float o = tile_load(io, tile_soff(b, r, 1));
+          E[b][r] = valid ? e : 0.f;
+          O[b][r] = valid ? o : 0.f;
+        }
+    } else {
+      // registers (b, 4q..4q+3) of E and O are features base..base+7, base = 64b + 16q + 8hi:
+      // Philox groups base/4 (-> E0 O0 E1 O1) and base/4 + 1 (-> E2 O2 E3 O3)
+      const uint64_t gj = fa.off + (uint64_t)j;
+#pragma unroll
+      for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int base = 64 * b + 16 * q + 8 * hi;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int g = base / 4 + h;
+            U4 c = {(uint32_t)gj, (uint32_t)(gj >> 32), (uint32_t)g, fa.stream};
+            const U4 rr = philox4x32_10(c, fa.k0, fa.k1);
+            float z[4];
+            box_muller<float>(rr.x, rr.y, z[0], z[1]);
+            box_muller<float>(rr.z, rr.w, z[2], z[3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const bool in = (4 * g + e < a.d) && valid;  // features >= d and padding samples stay 0
+              const float v = in ? z[e] : 0.f;
+              zz += v * v;
+              if (e & 1) O[b][4 * q + 2 * h + (e >> 1)] = v;
+              else E[b][4 * q + 2 * h + (e >> 1)] = v;
+            }
+          }
+        }
+    }
     float lsum = 0.f;
     const bool more_groups = grp + gridDim.x < ngroups;
 #pragma unroll 1
@@ -525,9 +587,48 @@ __global__ __launch_bounds__(512) void k_rqs_chain(RqsChainArgs a, float *xt, fl
           tile_store(io, tile_soff(b, r, 1), O[b][r]);
         }
       lsum += __shfl_xor(lsum, 32);
-      if (hi == 0 && valid) ladj[j] = lsum;  // inverse: rqs_inv_elem already accumulates -log dy/dx
+      if (!FUSED) {
+        if (hi == 0 && valid) ladj[j] = lsum;  // inverse: rqs_inv_elem already accumulates -log dy/dx
+      }
+    }
+    if (FUSED) {
+      // elbo_j = log p(y_j) - log q0(x_j) + ladj_j ;  ybar = gscale * grad log p(y)
+      const TileIO gio = make_tile_io(fa.gt ? fa.gt : xt, tl, a.d, l31, hi);
+      float t = 0.f;
+#pragma unroll
+      for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int fe = 2 * (b * 32 + nf_row(r, hi));
+          const float re = E[b][r] - tmu[fe], ro = O[b][r] - tmu[fe + 1];
+          const float ge = re * tiv[fe], go = ro * tiv[fe + 1];
+          t += re * ge + ro * go;
+          if (fa.gt && live) {
+            tile_store(gio, tile_soff(b, r, 0), valid ? -fa.gscale * ge : 0.f);
+            tile_store(gio, tile_soff(b, r, 1), valid ? -fa.gscale * go : 0.f);
+          }
+        }
+      t += __shfl_xor(t, 32);
+      zz += __shfl_xor(zz, 32);
+      double contrib = 0.0;
+      if (hi == 0 && valid) {
+        const float logq = (float)(-0.5 * 1.8378770664093453 * a.d) - 0.5f * zz;
+        const float e = -0.5f * (tc0[0] + t) - logq + lsum;
+        contrib = fa.pscale * (double)e;
+      }
+#pragma unroll
+      for (int sft = 16; sft >= 1; sft >>= 1) contrib += __shfl_xor(contrib, sft);  // lanes 0..31 carry the terms
+      if (lane == 0) wsum[wave] = contrib;
+      __syncthreads();
+      if (tid == 0) {
+        double sgrp = 0.0;
+        for (int w = 0; w < 8; ++w) sgrp += wsum[w];
+        wg_total += sgrp;
+      }
+      __syncthreads();
     }
   }
+  if (FUSED && tid == 0) fa.partial[blockIdx.x] = wg_total;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -773,11 +874,12 @@ __device__ __forceinline__ void rqs_bwd_tile(const RqsBwdArgs &a, const float *_
 #undef RQS_STAMP
 }
 
+// reverse pass of ONE coupling by this workgroup: stage the image, walk this workgroup's tiles, fold the four waves'
+// accumulators (deterministic, wave-ordered) and write the workgroup's slab
 template <class G, bool INVD>
-__global__ __launch_bounds__(256, 1) void k_rqs_bwd(RqsBwdArgs a, float *__restrict__ y, float *__restrict__ ybar,
-                                                    const float *__restrict__ lbar, float lbar_const,
-                                                    float *__restrict__ slab, long slab_stride) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+__device__ __forceinline__ void rqs_bwd_coupling(const RqsBwdArgs &a, float *__restrict__ y, float *__restrict__ ybar,
+                                                 const float *__restrict__ lbar, float lbar_const,
+                                                 float *__restrict__ slab, long slab_stride, float *lds) {
   float *img = lds;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -808,6 +910,48 @@ __global__ __launch_bounds__(256, 1) void k_rqs_bwd(RqsBwdArgs a, float *__restr
     const float4 *c0 = reinterpret_cast<const float4 *>(img);
     float4 *dst = reinterpret_cast<float4 *>(slab + (long)blockIdx.x * slab_stride);
     for (int i = tid; i < G::SIZE / 4; i += 256) dst[i] = c0[i];
+  }
+  __syncthreads();  // the image region is restaged by the next coupling
+}
+
+template <class G, bool INVD>
+__global__ __launch_bounds__(256, 1) void k_rqs_bwd(RqsBwdArgs a, float *__restrict__ y, float *__restrict__ ybar,
+                                                    const float *__restrict__ lbar, float lbar_const,
+                                                    float *__restrict__ slab, long slab_stride) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  rqs_bwd_coupling<G, INVD>(a, y, ybar, lbar, lbar_const, slab, slab_stride, lds);
+}
+
+// The whole chain's reverse pass in ONE launch (the structure of k_affine_bwd_all, nf_coupling.hip): a wave's tiles
+// never change hands and coupling k + 1 only reads what the same wave wrote for coupling k (y <- x, ybar <- xbar),
+// so each workgroup walks the couplings on its own -- seven launch gaps and ramp-up / tail phases less per step.
+struct RqsBwdAllArgs {
+  const float *wimg;  // [coupling][G::SIZE]
+  long long *trace;
+  int d, ncoup;
+  float B;
+  long N;
+};
+template <class G, bool INVD>
+__global__ __launch_bounds__(256, 1) void k_rqs_bwd_all(RqsBwdAllArgs aa, float *__restrict__ y, float *__restrict__ ybar,
+                                                        const float *__restrict__ lbar, float lbar_const,
+                                                        float *__restrict__ slab, long slab_stride) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+#pragma unroll 1
+  for (int step = 0; step < aa.ncoup; ++step) {
+    const int k = INVD ? aa.ncoup - 1 - step : step;  // the inverse chain's reverse pass runs in execution order
+    RqsBwdArgs a;
+    a.img = aa.wimg + (size_t)k * G::SIZE;
+    a.d = aa.d;
+    a.par_t = k & 1;
+    a.c = (k & 1) ? aa.d / 2 : (aa.d + 1) / 2;
+    a.m = aa.d - a.c;
+    a.B = aa.B;
+    a.N = aa.N;
+    a.trace = k == 0 ? aa.trace : nullptr;
+    // coupling k + 1 loads this same wave's stores of coupling k: ordered by the barrier that ends
+    // rqs_bwd_coupling (s_waitcnt vmcnt(0)), the vector L1 is write-through -- as in k_affine_bwd_all
+    rqs_bwd_coupling<G, INVD>(a, y, ybar, lbar, lbar_const, slab + (long)k * G::SIZE, slab_stride, lds);
   }
 }
 
@@ -888,12 +1032,14 @@ int nf_rqs_reduce_slabs(nf_ctx *ctx, const nf_flow_desc *desc, const float *slab
 
 template <class G>
 static int launch_rqs_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, float *xt, long N, float *ladj,
-                            int k_only) {
-  const size_t lds = 2 * (size_t)G::SIZE * sizeof(float);
+                            int k_only, const RqsFusedArgs *fused = nullptr) {
+  // two double-buffered images + target parameters and per-wave sums of the fused variant
+  const size_t lds = (2 * (size_t)G::SIZE + 2 * 64 * G::CB + 2) * sizeof(float) + 8 * sizeof(double);
   static AttrOnce attr_once;  // once per device: a context on another GPU needs its own
   NF_TRY(attr_once.run(ctx->device, [&]() -> int {
     NF_HIP(hipFuncSetAttribute((const void *)k_rqs_chain<G, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     NF_HIP(hipFuncSetAttribute((const void *)k_rqs_chain<G, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NF_HIP(hipFuncSetAttribute((const void *)k_rqs_chain<G, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return NF_OK;
   }));
   RqsChainArgs a;
@@ -903,11 +1049,35 @@ static int launch_rqs_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse,
   long grid = ngroups < ctx->num_cu ? ngroups : ctx->num_cu;
   if (grid < 1) grid = 1;
   ProfScope ps(ctx, "rqs_chain");
-  if (inverse)
-    hipLaunchKernelGGL((k_rqs_chain<G, true>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj);
+  RqsFusedArgs none{};
+  if (fused)
+    hipLaunchKernelGGL((k_rqs_chain<G, false, true>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, *fused);
+  else if (inverse)
+    hipLaunchKernelGGL((k_rqs_chain<G, true>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, none);
   else
-    hipLaunchKernelGGL((k_rqs_chain<G, false>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj);
+    hipLaunchKernelGGL((k_rqs_chain<G, false>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, none);
   return (int)hipGetLastError();
+}
+
+long nf_rqs_chain_grid(nf_ctx *ctx, long N) {
+  const long ngroups = ((N + NF_TILE - 1) / NF_TILE + 7) / 8;
+  const long grid = ngroups < ctx->num_cu ? ngroups : ctx->num_cu;
+  return grid < 1 ? 1 : grid;
+}
+
+// base draws + whole chain forward + diagonal-Gaussian target + ELBO partial sums in one launch (packed images must
+// be current).  yt <- flow output (tiled), gt <- gscale * grad log p(y) (or null), partial[nf_rqs_chain_grid] <- sums
+// of pscale * elbo_j.
+int nf_rqs_chain_elbo(nf_ctx *ctx, const nf_flow_desc *desc, long N, uint64_t seed, uint64_t off, uint32_t stream,
+                      const float *mu, const float *var, float *yt, float *gt, double gscale, double *partial,
+                      double pscale) {
+  const int id = rqs_geo_id(desc);
+  if (!id || !ctx->wimg) return NF_ERR_UNSUPPORTED;
+  RqsFusedArgs fa;
+  fa.k0 = (uint32_t)seed; fa.k1 = (uint32_t)(seed >> 32); fa.stream = stream; fa.off = off;
+  fa.mu = mu; fa.var = var; fa.gt = gt; fa.gscale = (float)gscale; fa.partial = partial; fa.pscale = pscale;
+  if (id == 1) return launch_rqs_chain<GeoK8>(ctx, desc, false, yt, N, nullptr, -1, &fa);
+  return launch_rqs_chain<GeoK10>(ctx, desc, false, yt, N, nullptr, -1, &fa);
 }
 
 // whole chain (k_only < 0) or a single coupling (flat index k_only), in place on the tiled buffer
@@ -956,4 +1126,36 @@ int nf_rqs_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, float *y, float *yb
   }
   if (id == 1) return launch_rqs_bwd<GeoK8, false>(ctx, desc, k, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid);
   return launch_rqs_bwd<GeoK10, false>(ctx, desc, k, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid);
+}
+
+template <class G, bool INVD>
+static int launch_rqs_bwd_all(nf_ctx *ctx, const nf_flow_desc *desc, float *y, float *ybar, const float *lbar,
+                              float lbar_const, long N, float *slab, long slab_stride, int grid) {
+  const size_t lds = RqsLds<G>::BYTES;
+  static AttrOnce attr_once;  // once per device
+  NF_TRY(attr_once.run(ctx->device, [&]() -> int {
+    NF_HIP(hipFuncSetAttribute((const void *)k_rqs_bwd_all<G, INVD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return NF_OK;
+  }));
+  RqsBwdAllArgs aa;
+  aa.wimg = (const float *)ctx->wimg;
+  aa.trace = (long long *)ctx->trace;
+  aa.d = desc->d; aa.ncoup = 2 * desc->nlayers; aa.B = desc->B; aa.N = N;
+  ProfScope ps(ctx, INVD ? "rqs_bwd_inv" : "rqs_bwd");
+  hipLaunchKernelGGL((k_rqs_bwd_all<G, INVD>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, aa, y, ybar, lbar,
+                     lbar_const, slab, slab_stride);
+  return (int)hipGetLastError();
+}
+
+// every coupling of the chain in one launch (flat order; inv_dir: forward execution order, see rqs_bwd_tile)
+int nf_rqs_bwd_all(nf_ctx *ctx, const nf_flow_desc *desc, float *y, float *ybar, const float *lbar, float lbar_const,
+                   long N, float *slab, long slab_stride, int grid, bool inv_dir) {
+  const int id = rqs_geo_id(desc);
+  if (!id || !ctx->wimg) return NF_ERR_UNSUPPORTED;
+  if (inv_dir) {
+    if (id == 1) return launch_rqs_bwd_all<GeoK8, true>(ctx, desc, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid);
+    return launch_rqs_bwd_all<GeoK10, true>(ctx, desc, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid);
+  }
+  if (id == 1) return launch_rqs_bwd_all<GeoK8, false>(ctx, desc, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid);
+  return launch_rqs_bwd_all<GeoK10, false>(ctx, desc, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid);
 }
