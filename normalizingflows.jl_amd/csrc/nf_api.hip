@@ -88,6 +88,11 @@ int nf_simple_elbo_forward(nf_ctx *, const nf_flow_desc *, const nf_target *, co
                            uint64_t seed, uint64_t off, uint32_t stream_id, void *gbar, double gscale, double *partial,
                            double pscale, void *ws, long *npartial);
 int nf_target_check(const nf_target *t, int d);
+bool nf_simple_step_supported(const nf_flow_desc *desc);
+size_t nf_simple_step_ws_bytes(nf_ctx *, const nf_flow_desc *, long N);
+int nf_simple_elbo_step(nf_ctx *, const nf_flow_desc *, const nf_target *, const void *theta, const void *xs, long N,
+                        uint64_t seed, uint64_t off, uint32_t stream_id, double gscale, double lbar_const, double *partial,
+                        double pscale, void *ws, void *gtheta_out, long *npartial);
 int nf_simple_rand(nf_ctx *, const nf_flow_desc *, const void *theta, long N, uint64_t seed, uint64_t off, uint32_t stream_id,
                    void *y);
 
@@ -734,10 +739,14 @@ extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, con
   const long nb = cp ? nf_target_tiled_nblocks(N) : nf_target_nblocks(N);
   const long nb_alloc = nb < ctx->num_cu ? ctx->num_cu : nb;  // the fused forward leaves one partial per workgroup
   const int grid = cp ? coupling_bwd_grid(ctx, desc, N) : 0;
-  const size_t simple_ws = cp ? 0 : flat_bwd_ws_bytes(ctx, desc, N);
+  const bool simple_kind = !cp && !is_g64(desc) && desc->kind != NF_KIND_HAMILTONIAN;
+  // planar / radial / mean-field within the register budget: the whole step in one launch, nothing stashed
+  static const bool no_step = std::getenv("NF_SIMPLE_STASH") != nullptr;  // A/B switch: the two-kernel stash path
+  const bool simple_step = simple_kind && !no_step && nf_simple_step_supported(desc);
+  const size_t simple_ws = cp ? 0 : simple_step ? nf_simple_step_ws_bytes(ctx, desc, N) : flat_bwd_ws_bytes(ctx, desc, N);
   const bool wide = cp && is_wide(desc);
   const size_t slabf = wide ? nf_wide_train_ws_floats(ctx, desc, N) : cp ? (size_t)grid * coupling_slab_floats(ctx, desc, N) : 0;
-  const size_t xe = cp ? tiled_elems(desc, N) : (size_t)N * desc->d;
+  const size_t xe = cp ? tiled_elems(desc, N) : simple_step ? 0 : (size_t)N * desc->d;
   const size_t need = 3 * carve_bytes(xe * es) + 2 * carve_bytes((size_t)N * es) + carve_bytes((size_t)nb_alloc * 8) +
                       carve_bytes(64) + carve_bytes(slabf * es) + carve_bytes(simple_ws);
   NF_TRY(nf_ws_reserve(ctx, need));
@@ -797,9 +806,19 @@ extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, con
     NF_TRY(realnvp_bwd(ctx, desc, (const float *)theta, xt, gt, nullptr, (float)(-inv), N, (float *)slab, grid,
                        (float *)out));
   } else {
-    if (!(is_g64(desc) || desc->kind == NF_KIND_HAMILTONIAN)) {
-      // planar / radial / mean-field: draws + chain + target + ELBO partial sums in one launch (the per-layer inputs
-      // stay behind for the reverse pass), then the reverse pass over all layers
+    if (simple_step) {
+      // planar / radial / mean-field: draws (or xs), chain, target, ELBO sums AND the reverse pass in one launch;
+      // every layer input stays in registers, only the parameter slabs are written (k_simple_step)
+      NF_TRY(nf_target_check(target, desc->d));
+      long np = 0;
+      NF_TRY(nf_simple_elbo_step(ctx, desc, target, theta, xs, N, seed, sample_offset, stream_id, -inv, -inv, partial, -inv, sws,
+                                 out, &np));
+      if (dt == NF_DTYPE_F32) return nf_launch_finish_sum(ctx, partial, np, 0, nullptr, (float *)out + P, nullptr);
+      return nf_launch_finish_sum(ctx, partial, np, 0, (double *)out + P, nullptr, nullptr);
+    }
+    if (simple_kind) {
+      // flows beyond the register budget of k_simple_step: draws + chain + target + ELBO partial sums in one launch
+      // (the per-layer inputs stay behind for the reverse pass), then the reverse pass over all layers
       NF_TRY(nf_target_check(target, desc->d));
       long np = 0;
       NF_TRY(nf_simple_elbo_forward(ctx, desc, target, theta, xs, N, seed, sample_offset, stream_id, gbar, -inv, partial, -inv,

@@ -669,6 +669,161 @@ __global__ __launch_bounds__(SB, (DPL * (int)sizeof(T) <= 16 ? 4 : 1)) void k_si
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The whole reverse-KL training step of a planar / radial / mean-field flow in ONE launch, with no activation ever
+// written to memory (src/objectives/elbo.jl:65-97 under _value_and_gradient, src/optimize.jl:86).
+//
+// k_simple_apply + k_simple_bwd_layers move 11 + 16 rows of d elements per sample through HBM (the per-layer input
+// stash and ybar): 7.1 KB per sample at d = 64 against 516 B of algorithmic traffic.  But the draws are counter-based
+// and a sample's state is DPL registers per lane, so a 16-lane group can keep the input of EVERY layer in registers
+// (NL * DPL of them), evaluate the target, and walk straight back: the only global traffic left is the parameter
+// slabs.  The kernel is then bound by VALU / transcendental issue, not by HBM.
+//
+// Register budget: NL * DPL stash + NL * (2 DPL + 2) parameter accumulators per thread.  NLMAX bounds the unrolled
+// layer loops (l is a compile-time constant in every access; layers l >= nl are skipped by a wave-uniform guard);
+// flows with more layers, or wider than the budget, take the stash path above.
+// NLMAX: unroll bound of the layer loops, one of {2, 4, 8, 12, 16} (the smallest that holds the flow's layers: unused
+// slots still cost their accumulator registers); NLMAX * DPL stash elements must fit the budget of 64 (Float32) /
+// 32 (Float64) per thread.
+template <class T, int DPL, int KIND, int NLMAX>
+__global__ __launch_bounds__(SB, 2) void k_simple_step(SimpleArgs a, const T *__restrict__ theta, const T *__restrict__ xs,
+                                                    SimpleFused fu, T lbar_const, T *__restrict__ slabs, long slab_stride) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int d = a.d, LP = lp_of(d), nl = a.nl;
+  const bool vec = a.vec != 0;
+  T *cache = (T *)smem;            // [nl][LP]
+  T *red = cache + (long)nl * LP;  // [SB / 64][nl * LP]
+  build_layer_cache<T>(cache, a, theta);
+  __syncthreads();
+  const int q = threadIdx.x & (LPS - 1), i0 = q * DPL, wave = threadIdx.x >> 6;
+  T acc0[NLMAX][DPL], acc1[NLMAX][DPL], s0[NLMAX], s1[NLMAX];
+#pragma unroll
+  for (int l = 0; l < NLMAX; ++l) {
+    s0[l] = s1[l] = (T)0;
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) acc0[l][k] = acc1[l][k] = (T)0;
+  }
+  double contrib = 0.0;
+  for (long j = (long)blockIdx.x * SPB + threadIdx.x / LPS; j < a.N; j += (long)gridDim.x * SPB) {
+    // The layer caches are loop-invariant LDS data; with the layer loops unrolled hipcc would hoist every row of every
+    // layer out of the sample loop (2 * DPL registers per layer) and spill.  The clobber keeps the reads inside.
+    asm volatile("" ::: "memory");
+    T z[DPL];
+    if (fu.draw) draw_row<T, DPL>(fu, j, i0, d, z);
+    else row_load<T, DPL>(xs + j * d, i0, d, vec, z);
+    T ss = 0;
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) ss += z[k] * z[k];
+    const T logq = (T)(-0.5 * 1.8378770664093453 * d) - (T)0.5 * g16sum(ss);
+    // forward: layers execute last-listed first (src/flows/utils.jl:23-26); zs[l] = input of flat layer l
+    T zs[NLMAX][DPL];
+    T lsum = 0;
+#pragma unroll
+    for (int l = NLMAX - 1; l >= 0; --l) {
+      if (l < nl) {
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) zs[l][k] = z[k];
+        lsum += layer_forward<T, DPL>(layer_kind(KIND, l), cache + (long)l * LP, d, i0, vec, z);
+      }
+    }
+    // target log-density, ybar = gscale * grad log p(y), ELBO term
+    T g[DPL];
+    {
+      const T y0 = __shfl(z[0], 0, LPS);
+      const T y1 = DPL >= 2 ? __shfl(z[DPL >= 2 ? 1 : 0], 0, LPS) : __shfl(z[0], 1, LPS);
+      T s2 = 0;
+      if (fu.tkind == NF_TARGET_FUNNEL) {
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) s2 += (i0 + k >= 1) ? z[k] * z[k] : (T)0;
+        s2 = g16sum(s2);
+      }
+      T acc = 0;
+      auto run = [&](auto kc) {
+        constexpr int KD = decltype(kc)::value;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+          T gk = 0;
+          if (i0 + k < d)
+            acc += target_term<KD, T>(d, i0 + k, z[k], y0, y1, s2, (const T *)fu.mu, (const T *)fu.var, (T)fu.s0, (T)fu.s1, gk);
+          g[k] = (T)fu.gscale * gk;
+        }
+      };
+      switch (fu.tkind) {
+        case NF_TARGET_DIAGGAUSS: run(std::integral_constant<int, NF_TARGET_DIAGGAUSS>{}); break;
+        case NF_TARGET_BANANA: run(std::integral_constant<int, NF_TARGET_BANANA>{}); break;
+        case NF_TARGET_FUNNEL: run(std::integral_constant<int, NF_TARGET_FUNNEL>{}); break;
+        case NF_TARGET_WARPED: run(std::integral_constant<int, NF_TARGET_WARPED>{}); break;
+        default: run(std::integral_constant<int, NF_TARGET_CROSS>{}); break;
+      }
+      acc = g16sum(acc);
+      if (q == 0) contrib += fu.pscale * (double)(acc - logq + lsum);
+    }
+    // reverse: flat order = reverse of execution order; the cotangent never leaves the registers
+#pragma unroll
+    for (int l = 0; l < NLMAX; ++l) {
+      if (l < nl)
+        layer_bwd<T, DPL, false>(layer_kind(KIND, l), cache + (long)l * LP, d, i0, q, vec, zs[l], g, lbar_const, acc0[l],
+                                 acc1[l], s0[l], s1[l]);
+    }
+  }
+  // deterministic block reduction of the parameter sums: the wave's 4 sample groups by shuffles, then the 4 waves
+  // through LDS in a fixed order; raw sums go to slabs[layer][block][LP] (layout: layer_bwd), as k_simple_bwd_layers
+#pragma unroll
+  for (int l = 0; l < NLMAX; ++l) {
+    if (l < nl) {
+#pragma unroll
+      for (int k = 0; k < DPL; ++k) {
+        acc0[l][k] += __shfl_xor(acc0[l][k], 16, 64);
+        acc0[l][k] += __shfl_xor(acc0[l][k], 32, 64);
+        acc1[l][k] += __shfl_xor(acc1[l][k], 16, 64);
+        acc1[l][k] += __shfl_xor(acc1[l][k], 32, 64);
+      }
+      s0[l] += __shfl_xor(s0[l], 16, 64);
+      s0[l] += __shfl_xor(s0[l], 32, 64);
+      s1[l] += __shfl_xor(s1[l], 16, 64);
+      s1[l] += __shfl_xor(s1[l], 32, 64);
+      if ((threadIdx.x & 63) < LPS) {
+        T *mine = red + ((long)wave * nl + l) * LP;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k)
+          if (i0 + k < d) {
+            mine[i0 + k] = acc0[l][k];
+            mine[d + i0 + k] = acc1[l][k];
+          }
+        if (q == 0) {
+          mine[2 * d] = s0[l];
+          mine[2 * d + 1] = s1[l];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int s = threadIdx.x; s < nl * LP; s += SB) {
+    const int l = s / LP, e = s - l * LP;
+    if (e < 2 * d + 2) {
+      constexpr int NW = SB / 64;
+      T vsum = 0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) vsum += red[(long)w * nl * LP + s];
+      slabs[(long)l * slab_stride + (long)blockIdx.x * LP + e] = vsum;
+    }
+  }
+  {  // deterministic block sum of the ELBO terms
+    __shared__ double sm[SB / 64];
+    double c = contrib;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+#pragma unroll
+      for (int w = 0; w < SB / 64; ++w) t += sm[w];
+      fu.partial[blockIdx.x] = t;
+    }
+  }
+}
+
 // sums the per-block slabs of every layer and applies the parameter-space chain rule
 // (get_u_hat for planar, softplus re-parameterisation for radial).  One block of FB threads per layer: FB / 64
 // row groups each sum every (FB/64)-th slab with 64 consecutive columns per wave (coalesced, independent loads),
@@ -964,4 +1119,128 @@ int nf_simple_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, cons
   if (desc->dtype == NF_DTYPE_F32)
     return bwd_t<float>(ctx, desc, theta, x, ybar, lbar, lbar_const, N, xbar_out, gtheta_out, ws, have_stash, inv);
   return bwd_t<double>(ctx, desc, theta, x, ybar, lbar, lbar_const, N, xbar_out, gtheta_out, ws, have_stash, inv);
+}
+
+// ---- the stash-free training step (k_simple_step) ----------------------------------------------------------------
+template <class T, int DPL, int KIND, int NLMAX>
+static int step_launch(nf_ctx *ctx, SimpleArgs a, const void *theta, const void *xs, const SimpleFused &fu, double lbar_const,
+                       T *slabs, int *nb_out) {
+  const size_t LP = lp_of(a.d);
+  const size_t lds = (size_t)(1 + SB / 64) * a.nl * LP * sizeof(T);
+  static AttrOnce attr_once;  // once per device
+  NF_TRY(attr_once.run(ctx->device, [&]() -> int {
+    NF_HIP(hipFuncSetAttribute((const void *)k_simple_step<T, DPL, KIND, NLMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    return NF_OK;
+  }));
+  long nb = (a.N + SPB - 1) / SPB;
+  const long res = resident_blocks(ctx, k_simple_step<T, DPL, KIND, NLMAX>, lds);
+  if (nb > res) nb = res;
+  if (nb < 1) nb = 1;
+  *nb_out = (int)nb;
+  ProfScope ps(ctx, "simple_step");
+  hipLaunchKernelGGL((k_simple_step<T, DPL, KIND, NLMAX>), dim3((unsigned)nb), dim3(SB), lds, ctx->stream, a, (const T *)theta,
+                     (const T *)xs, fu, (T)lbar_const, slabs, (long)nb * (long)LP);
+  return (int)hipGetLastError();
+}
+
+// smallest unroll bound that holds nl layers
+static inline int step_bound(int nl) { return nl <= 2 ? 2 : nl <= 4 ? 4 : nl <= 8 ? 8 : nl <= 12 ? 12 : 16; }
+
+template <class T, int DPL, int KIND>
+static int step_dpl(nf_ctx *ctx, const SimpleArgs &a, const void *theta, const void *xs, const SimpleFused &fu,
+                    double lbar_const, T *slabs, int *nb_out) {
+  constexpr int BUDGET = (sizeof(T) == 4 ? 64 : 32) / DPL;  // layers whose inputs fit the stash registers
+  const int nb = step_bound(a.nl);
+  if constexpr (KIND == NF_KIND_MEANFIELD) return step_launch<T, DPL, KIND, 2>(ctx, a, theta, xs, fu, lbar_const, slabs, nb_out);
+  if constexpr (BUDGET >= 2)
+    if (nb == 2) return step_launch<T, DPL, KIND, 2>(ctx, a, theta, xs, fu, lbar_const, slabs, nb_out);
+  if constexpr (BUDGET >= 4)
+    if (nb == 4) return step_launch<T, DPL, KIND, 4>(ctx, a, theta, xs, fu, lbar_const, slabs, nb_out);
+  if constexpr (BUDGET >= 8)
+    if (nb == 8) return step_launch<T, DPL, KIND, 8>(ctx, a, theta, xs, fu, lbar_const, slabs, nb_out);
+  if constexpr (BUDGET >= 12)
+    if (nb == 12) return step_launch<T, DPL, KIND, 12>(ctx, a, theta, xs, fu, lbar_const, slabs, nb_out);
+  if constexpr (BUDGET >= 16)
+    if (nb == 16) return step_launch<T, DPL, KIND, 16>(ctx, a, theta, xs, fu, lbar_const, slabs, nb_out);
+  return NF_ERR_UNSUPPORTED;
+}
+
+template <class T, int KIND>
+static int step_kind(nf_ctx *ctx, const SimpleArgs &a, const void *theta, const void *xs, const SimpleFused &fu,
+                     double lbar_const, T *slabs, int *nb_out) {
+  switch (dpl_for(a.d)) {
+    case 1: return step_dpl<T, 1, KIND>(ctx, a, theta, xs, fu, lbar_const, slabs, nb_out);
+    case 2: return step_dpl<T, 2, KIND>(ctx, a, theta, xs, fu, lbar_const, slabs, nb_out);
+    case 4: return step_dpl<T, 4, KIND>(ctx, a, theta, xs, fu, lbar_const, slabs, nb_out);
+    case 8: return step_dpl<T, 8, KIND>(ctx, a, theta, xs, fu, lbar_const, slabs, nb_out);
+    case 16: return step_dpl<T, 16, KIND>(ctx, a, theta, xs, fu, lbar_const, slabs, nb_out);
+    default: return NF_ERR_UNSUPPORTED;
+  }
+}
+
+static int step_nlmax(const nf_flow_desc *desc) {
+  if (desc->kind == NF_KIND_MEANFIELD) return 2;
+  const int budget = (desc->dtype == NF_DTYPE_F64 ? 32 : 64) / dpl_for(desc->d);
+  return budget >= 16 ? 16 : budget >= 12 ? 12 : budget >= 8 ? 8 : budget >= 4 ? 4 : budget >= 2 ? 2 : 0;
+}
+
+// flows whose every layer input fits the register budget of k_simple_step and whose caches + reduction rows fit LDS
+bool nf_simple_step_supported(const nf_flow_desc *desc) {
+  if (!nf_simple_supported(desc) || dpl_for(desc->d) > 16) return false;
+  const int nl = desc->kind == NF_KIND_MEANFIELD ? 2 : desc->nlayers;
+  const size_t es = desc->dtype == NF_DTYPE_F64 ? 8 : 4;
+  if (nl > step_nlmax(desc)) return false;
+  return (size_t)(1 + SB / 64) * nl * lp_of(desc->d) * es <= 144 * 1024;
+}
+
+size_t nf_simple_step_ws_bytes(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
+  const size_t es = desc->dtype == NF_DTYPE_F64 ? 8 : 4;
+  const int nl = desc->kind == NF_KIND_MEANFIELD ? 2 : desc->nlayers;
+  long nb = (N + SPB - 1) / SPB;
+  const long cap = 16L * ctx->num_cu;  // upper bound of the resident-block count
+  if (nb > cap) nb = cap;
+  return carve_bytes((size_t)nl * nb * lp_of(desc->d) * es);
+}
+
+// loss partials (pscale * elbo_j, *npartial block sums in `partial`) and the gradient of the step in two launches:
+// k_simple_step (draws or xs, chain, target, reverse pass, slabs) and k_simple_finalize.  gscale / lbar_const are the
+// cotangents: -1 / N_global for loss = -elbo_batch.
+template <class T>
+static int step_t(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, const void *theta, const void *xs, long N,
+                  uint64_t seed, uint64_t off, uint32_t stream_id, double gscale, double lbar_const, double *partial,
+                  double pscale, void *ws, void *gtheta_out, long *npartial) {
+  const int nl = desc->kind == NF_KIND_MEANFIELD ? 2 : desc->nlayers;
+  SimpleArgs a = make_sargs(desc, 0, nl, false, N);
+  a.vec = vec_ok<T>(a.d, dpl_for(a.d), {xs});
+  SimpleFused fu{};
+  fu.on = 1;
+  fu.draw = xs ? 0 : 1;
+  fu.tkind = target->kind;
+  fu.k0 = (uint32_t)seed; fu.k1 = (uint32_t)(seed >> 32); fu.stream = stream_id; fu.off = off;
+  fu.mu = target->p0; fu.var = target->p1; fu.s0 = target->s0; fu.s1 = target->s1;
+  fu.gscale = gscale; fu.pscale = pscale; fu.gbar = nullptr; fu.partial = partial;
+  T *slabs = (T *)ws;
+  int nb = 0;
+  int st;
+  if (desc->kind == NF_KIND_PLANAR) st = step_kind<T, NF_KIND_PLANAR>(ctx, a, theta, xs, fu, lbar_const, slabs, &nb);
+  else if (desc->kind == NF_KIND_RADIAL) st = step_kind<T, NF_KIND_RADIAL>(ctx, a, theta, xs, fu, lbar_const, slabs, &nb);
+  else st = step_kind<T, NF_KIND_MEANFIELD>(ctx, a, theta, xs, fu, lbar_const, slabs, &nb);
+  NF_TRY(st);
+  *npartial = nb;
+  const size_t LP = lp_of(a.d);
+  ProfScope pf(ctx, "simple_finalize");
+  hipLaunchKernelGGL(k_simple_finalize<T>, dim3(nl), dim3(FB), (size_t)(1 + FB / 64) * LP * sizeof(T), ctx->stream, a,
+                     (const T *)theta, (const T *)slabs, nb, (T *)gtheta_out);
+  return (int)hipGetLastError();
+}
+
+int nf_simple_elbo_step(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, const void *theta, const void *xs,
+                        long N, uint64_t seed, uint64_t off, uint32_t stream_id, double gscale, double lbar_const,
+                        double *partial, double pscale, void *ws, void *gtheta_out, long *npartial) {
+  if (N <= 0) return NF_OK;
+  if (desc->dtype == NF_DTYPE_F32)
+    return step_t<float>(ctx, desc, target, theta, xs, N, seed, off, stream_id, gscale, lbar_const, partial, pscale, ws,
+                         gtheta_out, npartial);
+  return step_t<double>(ctx, desc, target, theta, xs, N, seed, off, stream_id, gscale, lbar_const, partial, pscale, ws,
+                        gtheta_out, npartial);
 }
