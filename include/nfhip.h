@@ -42,6 +42,7 @@ extern "C" {
 #define NF_ERR_NO_DEVICE -3    /* no gfx950 device visible                         */
 #define NF_ERR_NONFINITE -4    /* loss or gradient norm became non-finite (nf_elbo_step; the reference's
                                   tests require finite ELBOs, test/flow.jl:58-60)  */
+#define NF_ERR_WORKSPACE -7    /* the caller-provided arena (nf_ctx_set_arena) is too small         */
 #define NF_ERR_NO_RCCL -5      /* librccl.so.1 could not be loaded (multi-GPU entry points only) */
 #define NF_ERR_RCCL -6         /* an RCCL call failed; nf_strerror gives RCCL's message          */
 
@@ -112,6 +113,15 @@ int nf_ctx_create(int device, void *hip_stream, nf_ctx **out);
 int nf_ctx_destroy(nf_ctx *ctx);
 int nf_ctx_set_stream(nf_ctx *ctx, void *hip_stream);
 int nf_ctx_synchronize(nf_ctx *ctx);
+/* Memory.  By default a context owns a grow-only arena: the first call of a larger shape allocates (and synchronises
+ * the stream once), steady-state steps never do.  For callers that want NO allocation or synchronisation inside the
+ * compute entry points (hipGraph capture, a Julia GC-managed ROCArray as backing store):
+ *   bytes = nf_workspace_bytes(ctx, desc, N_max);  nf_ctx_set_arena(ctx, device_ptr, bytes);   (device_ptr 256-byte aligned)
+ * after which every entry point with this flow and N <= N_max works inside the arena and a larger request returns
+ * NF_ERR_WORKSPACE.  nf_ctx_set_arena(ctx, NULL, 0) returns to the owned mode.  ("the library allocates
+ * nothing persistent except the ctx; arena sized by nf_workspace_bytes".) */
+int64_t nf_workspace_bytes(nf_ctx *ctx, const nf_flow_desc *desc, int64_t N);
+int nf_ctx_set_arena(nf_ctx *ctx, void *arena_device, size_t bytes);
 
 /* ---- layout -------------------------------------------------------------- */
 /* length(first(Optimisers.destructure(flow)))  (src/NormalizingFlows.jl:67) */

@@ -1,6 +1,7 @@
 // nf_api.hip -- extern "C" entry points of libnfhip.so (see include/nfhip.h for the
 // reference interface each one stands behind).  Host-side orchestration only: every
 // arithmetic operation happens in a gfx950 kernel; there is no CPU fallback.
+#include <cmath>
 #include <cstdlib>
 
 #include "nf_common.h"
@@ -216,6 +217,7 @@ extern "C" const char *nf_strerror(int code) {
     case NF_ERR_UNSUPPORTED: return "nfhip: flow shape/dtype not built into this library";
     case NF_ERR_NO_DEVICE: return "nfhip: no usable HIP device";
     case NF_ERR_NONFINITE: return "nfhip: non-finite loss or gradient norm";
+    case NF_ERR_WORKSPACE: return "nfhip: the caller-provided arena is too small (size it with nf_workspace_bytes)";
     case NF_ERR_NO_RCCL: return "nfhip: librccl.so.1 could not be loaded";
     case NF_ERR_RCCL: return nf_comm_last_error();
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "nfhip: unknown error";
@@ -249,9 +251,11 @@ extern "C" int nf_ctx_destroy(nf_ctx *ctx) {
   hipStreamSynchronize(ctx->stream);
   nf_comm_destroy(ctx);
   for (auto &e : ctx->prof_pool) hipEventDestroy(e);
-  if (ctx->ws) hipFree(ctx->ws);
-  if (ctx->gbuf) hipFree(ctx->gbuf);
-  if (ctx->wimg) hipFree(ctx->wimg);
+  if (!ctx->arena) {  // arena mode: ws / wimg / gbuf are the caller's memory
+    if (ctx->ws) hipFree(ctx->ws);
+    if (ctx->gbuf) hipFree(ctx->gbuf);
+    if (ctx->wimg) hipFree(ctx->wimg);
+  }
   if (ctx->trace) hipFree(ctx->trace);
   if (ctx->host_scratch) hipHostFree(ctx->host_scratch);
   delete ctx;
@@ -270,7 +274,18 @@ extern "C" int nf_ctx_synchronize(nf_ctx *ctx) {
   return NF_OK;
 }
 
+// ---- workspace ------------------------------------------------------------------------------------
+// Default: grow-only device arena (the first call of a larger shape allocates and synchronises once, steady-state
+// steps never do).  With a caller-provided arena (nf_ctx_set_arena, sized by nf_workspace_bytes) no compute entry
+// point allocates, frees or synchronises for memory at all: requests beyond the arena fail with NF_ERR_WORKSPACE.
 int nf_ws_reserve(nf_ctx *ctx, size_t bytes) {
+  if (ctx->arena) {
+    const size_t avail = ctx->arena_bytes - ctx->arena_tail;
+    if (bytes > avail) return NF_ERR_WORKSPACE;
+    ctx->ws = ctx->arena;
+    ctx->ws_bytes = avail;
+    return NF_OK;
+  }
   if (bytes <= ctx->ws_bytes) return NF_OK;
   NF_HIP(hipStreamSynchronize(ctx->stream));
   if (ctx->ws) NF_HIP(hipFree(ctx->ws));
@@ -279,6 +294,67 @@ int nf_ws_reserve(nf_ctx *ctx, size_t bytes) {
   const size_t want = carve_bytes(bytes + bytes / 8);  // multiple of 256: the optimiser's scratch is carved off the tail
   NF_HIP(hipMalloc(&ctx->ws, want));
   ctx->ws_bytes = want;
+  return NF_OK;
+}
+
+// carve `bytes` off the tail of the caller's arena (arena mode only)
+static int arena_tail_take(nf_ctx *ctx, size_t bytes, void **out) {
+  const size_t b = carve_bytes(bytes);
+  if (ctx->arena_tail + b > ctx->arena_bytes) return NF_ERR_WORKSPACE;
+  ctx->arena_tail += b;
+  *out = (char *)ctx->arena + (ctx->arena_bytes - ctx->arena_tail);
+  ctx->ws = ctx->arena;
+  ctx->ws_bytes = ctx->arena_bytes - ctx->arena_tail;
+  return NF_OK;
+}
+
+int nf_wimg_reserve(nf_ctx *ctx, size_t bytes) {
+  if (bytes <= ctx->wimg_bytes) return NF_OK;
+  if (ctx->arena) {
+    NF_TRY(arena_tail_take(ctx, bytes, &ctx->wimg));
+    ctx->wimg_bytes = carve_bytes(bytes);
+    return NF_OK;
+  }
+  NF_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->wimg) NF_HIP(hipFree(ctx->wimg));
+  ctx->wimg = nullptr;
+  ctx->wimg_bytes = 0;
+  NF_HIP(hipMalloc(&ctx->wimg, bytes));
+  ctx->wimg_bytes = bytes;
+  return NF_OK;
+}
+
+static int gbuf_reserve(nf_ctx *ctx, size_t bytes) {
+  if (bytes <= ctx->gbuf_bytes) return NF_OK;
+  if (ctx->arena) {
+    NF_TRY(arena_tail_take(ctx, bytes, &ctx->gbuf));
+    ctx->gbuf_bytes = carve_bytes(bytes);
+    return NF_OK;
+  }
+  NF_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->gbuf) NF_HIP(hipFree(ctx->gbuf));
+  ctx->gbuf = nullptr;
+  ctx->gbuf_bytes = 0;
+  NF_HIP(hipMalloc(&ctx->gbuf, bytes));
+  ctx->gbuf_bytes = bytes;
+  return NF_OK;
+}
+
+extern "C" int nf_ctx_set_arena(nf_ctx *ctx, void *arena, size_t bytes) {
+  if (!ctx || (arena && bytes < 4096) || ((uintptr_t)arena & 255)) return NF_ERR_ARG;
+  NF_HIP(hipSetDevice(ctx->device));
+  NF_HIP(hipStreamSynchronize(ctx->stream));
+  // drop whatever the context owns or had carved: the next calls re-establish their buffers in the new mode
+  if (!ctx->arena) {
+    if (ctx->ws) NF_HIP(hipFree(ctx->ws));
+    if (ctx->wimg) NF_HIP(hipFree(ctx->wimg));
+    if (ctx->gbuf) NF_HIP(hipFree(ctx->gbuf));
+  }
+  ctx->ws = ctx->wimg = ctx->gbuf = nullptr;
+  ctx->ws_bytes = ctx->wimg_bytes = ctx->gbuf_bytes = 0;
+  ctx->arena = arena;
+  ctx->arena_bytes = arena ? (bytes / 256) * 256 : 0;
+  ctx->arena_tail = 0;
   return NF_OK;
 }
 
@@ -895,14 +971,7 @@ extern "C" int nf_elbo_step(nf_ctx *ctx, const nf_flow_desc *desc, const nf_targ
   const long P = nf_param_count(desc);
   const size_t es = esize(desc->dtype);
   const size_t gneed = (size_t)(P + 2) * es;
-  if (gneed > ctx->gbuf_bytes) {
-    NF_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->gbuf) NF_HIP(hipFree(ctx->gbuf));
-    ctx->gbuf = nullptr;
-    ctx->gbuf_bytes = 0;
-    NF_HIP(hipMalloc(&ctx->gbuf, gneed));
-    ctx->gbuf_bytes = gneed;
-  }
+  NF_TRY(gbuf_reserve(ctx, gneed));
   void *gbuf = ctx->gbuf;
   NF_TRY(nf_elbo_value_and_grad(ctx, desc, target, theta, nullptr, N, N, seed, 0, step, gbuf));
   char *gnorm_dev = (char *)gbuf + (size_t)(P + 1) * es;
@@ -921,8 +990,78 @@ extern "C" int nf_elbo_step(nf_ctx *ctx, const nf_flow_desc *desc, const nf_targ
     }
     if (loss_host) *loss_host = l;
     if (gnorm_host) *gnorm_host = gnv;
+    // the reference's tests require finite ELBOs (test/flow.jl:58-60); theta has already been updated with the
+    // non-finite gradient, as Optimisers.update! would have done -- the caller decides whether to stop
+    if (!std::isfinite(l) || !std::isfinite(gnv)) return NF_ERR_NONFINITE;
   }
   return NF_OK;
+}
+
+// ---- arena sizing ------------------------------------------------------------------------------
+// Upper bound, over EVERY compute entry point called with this flow and up to N samples, of the device memory the
+// context needs: the intermediates arena (the per-entry-point `need` formulas above, restated here -- the arena-mode
+// GPU test runs every entry point against exactly this bound, so a formula that drifts fails loudly with
+// NF_ERR_WORKSPACE), the optimiser's norm partials, the packed weight images and the nf_elbo_step buffer.
+size_t nf_affine_wimg_bytes(const nf_flow_desc *desc);
+size_t nf_rqs_wimg_bytes(const nf_flow_desc *desc);
+size_t nf_wide_wimg_bytes(nf_ctx *, const nf_flow_desc *desc);
+
+extern "C" int64_t nf_workspace_bytes(nf_ctx *ctx, const nf_flow_desc *desc, int64_t N) {
+  if (!ctx || N < 0) return NF_ERR_ARG;
+  const int st = check_desc(desc);
+  if (st != NF_OK) return st;
+  if (N == 0) N = 1;
+  const size_t es = esize(desc->dtype);
+  const bool cp = is_coupling(desc);
+  const long P = nf_param_count(desc);
+  const size_t te = cp ? tiled_elems(desc, N) : 0;
+  const size_t xe = cp ? te : (size_t)N * desc->d;
+  const size_t cn = carve_bytes((size_t)N * es);
+  size_t need = 0;
+  auto upd = [&](size_t v) { if (v > need) need = v; };
+  // nf_flow_fwd / inv / layer_apply, nf_flow_rand
+  upd(cp ? carve_bytes(te * 4) + carve_bytes((size_t)N * 4) : cn);
+  // nf_flow_bwd
+  const int grid = cp ? coupling_bwd_grid(ctx, desc, N) : 0;
+  const size_t slab_pull = cp ? (size_t)grid * coupling_slab_floats(ctx, desc, N) : 0;
+  upd(cp ? 2 * carve_bytes(te * 4) + carve_bytes(slab_pull * 4) : flat_bwd_ws_bytes(ctx, desc, N));
+  // nf_elbo_batch(_rng), nf_loglikelihood
+  const long nbt = cp ? nf_target_tiled_nblocks(N) : nf_target_nblocks(N);
+  const long nb_alloc = nbt < ctx->num_cu ? ctx->num_cu : nbt;
+  upd(carve_bytes(xe * es) + 2 * cn + carve_bytes((size_t)nb_alloc * 8) + carve_bytes(64));
+  upd(carve_bytes(xe * es) + 2 * cn + carve_bytes((size_t)nf_sum2_nblocks(N) * 8) + carve_bytes(64));
+  // nf_loglikelihood_value_and_grad
+  {
+    const bool coupling_kind = desc->kind == NF_KIND_REALNVP || desc->kind == NF_KIND_NSF;
+    const bool hf = desc->kind == NF_KIND_HAMILTONIAN;
+    const bool tiled = cp && coupling_inv_bwd_tiled(desc);
+    if (!(coupling_kind && !tiled && !nf_g64_supported(desc))) {
+      const size_t slabf = tiled ? slab_pull : 0;
+      const size_t flat_ws = tiled ? 0 : hf ? nf_hf_bwd_ws_bytes(desc, N) : coupling_kind ? nf_g64_bwd_inv_ws_bytes(desc, N)
+                                                                                       : nf_simple_bwd_ws_bytes(ctx, desc, N);
+      upd(2 * carve_bytes(xe * es) + cn + carve_bytes((size_t)nbt * 8) + carve_bytes(2 * (size_t)desc->d * es) +
+          carve_bytes(slabf * es) + carve_bytes(flat_ws));
+    }
+  }
+  // nf_elbo_value_and_grad / nf_elbo_step (both the stash-free and the stash form of the simple flows)
+  {
+    const bool wide = cp && is_wide(desc);
+    const size_t slabf = wide ? nf_wide_train_ws_floats(ctx, desc, N) : slab_pull;
+    size_t simple_ws = cp ? 0 : flat_bwd_ws_bytes(ctx, desc, N);
+    if (!cp && !is_g64(desc) && desc->kind != NF_KIND_HAMILTONIAN && nf_simple_step_supported(desc)) {
+      const size_t sw = nf_simple_step_ws_bytes(ctx, desc, N);
+      if (sw > simple_ws) simple_ws = sw;
+    }
+    upd(3 * carve_bytes(xe * es) + 2 * cn + carve_bytes((size_t)nb_alloc * 8) + carve_bytes(64) + carve_bytes(slabf * es) +
+        carve_bytes(simple_ws));
+  }
+  // nf_adam_update / nf_sgd_update: gradient-norm partials at the tail of the intermediates arena
+  need += carve_bytes((size_t)nf_adam_nblocks(P) * 8);
+  // packed weight images, nf_elbo_step's [grad ; loss ; norm] buffer
+  size_t wimg = 0;
+  if (cp) wimg = is_wide(desc) ? nf_wide_wimg_bytes(ctx, desc) : is_nsf(desc) ? nf_rqs_wimg_bytes(desc) : nf_affine_wimg_bytes(desc);
+  need += carve_bytes(wimg) + carve_bytes((size_t)(P + 2) * es) + 4096;
+  return (int64_t)need;
 }
 
 // ---- measurement support -------------------------------------------------------------------

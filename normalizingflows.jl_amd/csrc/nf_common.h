@@ -49,6 +49,10 @@ struct nf_ctx {
   std::vector<hipEvent_t> prof_pool;  // pre-created events, reused
   size_t prof_pool_next = 0;
   std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof_events;
+  // caller-provided arena (nf_ctx_set_arena): when set, NOTHING is allocated or freed by compute entry points; the
+  // intermediates arena `ws` is its front, packed weight images and the nf_elbo_step buffer are carved off its tail
+  void *arena = nullptr;
+  size_t arena_bytes = 0, arena_tail = 0;
   // RCCL communicator of this context (nf_comm.hip); null for single-GPU use
   void *comm = nullptr;
   int comm_size = 1, comm_rank = 0;
@@ -57,6 +61,8 @@ struct nf_ctx {
 const char *nf_comm_last_error();
 
 int nf_ws_reserve(nf_ctx *ctx, size_t bytes);
+// packed weight images (ctx->wimg) of at least `bytes`: grow-only allocation, or a tail carve of the caller's arena
+int nf_wimg_reserve(nf_ctx *ctx, size_t bytes);
 
 // carve helper over the arena: returns 256-byte aligned sub-buffers
 struct Carver {

@@ -716,20 +716,15 @@ int nf_affine_reduce_slabs(nf_ctx *ctx, const nf_flow_desc *desc, const float *s
 }
 
 // packs every net of the flow into ctx->wimg (grow-only) -- call once per API entry
+size_t nf_affine_wimg_bytes(const nf_flow_desc *desc) { return (size_t)2 * desc->nlayers * 2 * geo_size(desc) * sizeof(float); }
+
 int nf_affine_pack(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta) {
   if (desc->n_hidden != 2) return NF_ERR_UNSUPPORTED;
   const int size = geo_size(desc);
   if (!size) return NF_ERR_UNSUPPORTED;
   const int nc = 2 * desc->nlayers;
   const size_t bytes = (size_t)nc * 2 * size * sizeof(float);
-  if (bytes > ctx->wimg_bytes) {
-    NF_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->wimg) NF_HIP(hipFree(ctx->wimg));
-    ctx->wimg = nullptr;
-    ctx->wimg_bytes = 0;
-    NF_HIP(hipMalloc(&ctx->wimg, bytes));
-    ctx->wimg_bytes = bytes;
-  }
+  NF_TRY(nf_wimg_reserve(ctx, bytes));
   const PackArgs p = make_pack_args(desc);
   const long total = (long)nc * 2 * size;
   const unsigned grid = (unsigned)((total + 255) / 256);

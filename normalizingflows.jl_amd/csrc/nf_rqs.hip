@@ -991,20 +991,15 @@ static RqsPackArgs rqs_pack_args(const nf_flow_desc *desc) {
 
 long nf_rqs_slab_floats(const nf_flow_desc *desc) { return (long)2 * desc->nlayers * rqs_geo_size(desc); }
 
+size_t nf_rqs_wimg_bytes(const nf_flow_desc *desc) { return (size_t)2 * desc->nlayers * rqs_geo_size(desc) * sizeof(float); }
+
 int nf_rqs_pack(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta) {
   const int id = rqs_geo_id(desc);
   if (!id) return NF_ERR_UNSUPPORTED;
   const int size = rqs_geo_size(desc);
   const int nc = 2 * desc->nlayers;
   const size_t bytes = (size_t)nc * size * sizeof(float);
-  if (bytes > ctx->wimg_bytes) {
-    NF_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->wimg) NF_HIP(hipFree(ctx->wimg));
-    ctx->wimg = nullptr;
-    ctx->wimg_bytes = 0;
-    NF_HIP(hipMalloc(&ctx->wimg, bytes));
-    ctx->wimg_bytes = bytes;
-  }
+  NF_TRY(nf_wimg_reserve(ctx, bytes));
   const RqsPackArgs p = rqs_pack_args(desc);
   const long total = (long)nc * size;
   const unsigned grid = (unsigned)((total + 255) / 256);

@@ -682,7 +682,7 @@ __global__ __launch_bounds__(SB, (DPL * (int)sizeof(T) <= 16 ? 4 : 1)) void k_si
 // Register budget: NL * DPL stash + NL * (2 DPL + 2) parameter accumulators per thread.  NLMAX bounds the unrolled
 // layer loops (l is a compile-time constant in every access; layers l >= nl are skipped by a wave-uniform guard);
 // flows with more layers, or wider than the budget, take the stash path above.
-// NLMAX: unroll bound of the layer loops, one of {2, 4, 8, 12, 16} (the smallest that holds the flow's layers: unused
+// NLMAX: unroll bound of the layer loops, 4 or 12 (the smaller that holds the flow's layers; 2 for mean-field: unused
 // slots still cost their accumulator registers); NLMAX * DPL stash elements must fit the budget of 64 (Float32) /
 // 32 (Float64) per thread.
 template <class T, int DPL, int KIND, int NLMAX>
@@ -1144,7 +1144,7 @@ static int step_launch(nf_ctx *ctx, SimpleArgs a, const void *theta, const void 
 }
 
 // smallest unroll bound that holds nl layers
-static inline int step_bound(int nl) { return nl <= 2 ? 2 : nl <= 4 ? 4 : nl <= 8 ? 8 : nl <= 12 ? 12 : 16; }
+static inline int step_bound(int nl) { return nl <= 4 ? 4 : 12; }  // two unroll bounds keep the instantiation count (and the build time) down
 
 template <class T, int DPL, int KIND>
 static int step_dpl(nf_ctx *ctx, const SimpleArgs &a, const void *theta, const void *xs, const SimpleFused &fu,
@@ -1152,16 +1152,10 @@ static int step_dpl(nf_ctx *ctx, const SimpleArgs &a, const void *theta, const v
   constexpr int BUDGET = (sizeof(T) == 4 ? 64 : 32) / DPL;  // layers whose inputs fit the stash registers
   const int nb = step_bound(a.nl);
   if constexpr (KIND == NF_KIND_MEANFIELD) return step_launch<T, DPL, KIND, 2>(ctx, a, theta, xs, fu, lbar_const, slabs, nb_out);
-  if constexpr (BUDGET >= 2)
-    if (nb == 2) return step_launch<T, DPL, KIND, 2>(ctx, a, theta, xs, fu, lbar_const, slabs, nb_out);
   if constexpr (BUDGET >= 4)
     if (nb == 4) return step_launch<T, DPL, KIND, 4>(ctx, a, theta, xs, fu, lbar_const, slabs, nb_out);
-  if constexpr (BUDGET >= 8)
-    if (nb == 8) return step_launch<T, DPL, KIND, 8>(ctx, a, theta, xs, fu, lbar_const, slabs, nb_out);
   if constexpr (BUDGET >= 12)
     if (nb == 12) return step_launch<T, DPL, KIND, 12>(ctx, a, theta, xs, fu, lbar_const, slabs, nb_out);
-  if constexpr (BUDGET >= 16)
-    if (nb == 16) return step_launch<T, DPL, KIND, 16>(ctx, a, theta, xs, fu, lbar_const, slabs, nb_out);
   return NF_ERR_UNSUPPORTED;
 }
 
@@ -1181,7 +1175,7 @@ static int step_kind(nf_ctx *ctx, const SimpleArgs &a, const void *theta, const 
 static int step_nlmax(const nf_flow_desc *desc) {
   if (desc->kind == NF_KIND_MEANFIELD) return 2;
   const int budget = (desc->dtype == NF_DTYPE_F64 ? 32 : 64) / dpl_for(desc->d);
-  return budget >= 16 ? 16 : budget >= 12 ? 12 : budget >= 8 ? 8 : budget >= 4 ? 4 : budget >= 2 ? 2 : 0;
+  return budget >= 12 ? 12 : budget >= 4 ? 4 : 0;
 }
 
 // flows whose every layer input fits the register budget of k_simple_step and whose caches + reduction rows fit LDS

@@ -913,18 +913,13 @@ bool nf_wide_supported(const nf_flow_desc *desc) {
 template <class G>
 struct WideHost {
 // packed images of every net: [coupling][s|t][G::SIZE] in ctx->wimg, plus DMA slack at the end
+static size_t wide_wimg_bytes(nf_ctx *, const nf_flow_desc *desc) { return (size_t)2 * desc->nlayers * 2 * G::SIZE * sizeof(float) + 4096; }
+
 static int wide_pack(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta) {
   if (!nf_wide_supported(desc)) return NF_ERR_UNSUPPORTED;
   const int nc = 2 * desc->nlayers;
   const size_t bytes = (size_t)nc * 2 * G::SIZE * sizeof(float) + 4096;
-  if (bytes > ctx->wimg_bytes) {
-    NF_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->wimg) NF_HIP(hipFree(ctx->wimg));
-    ctx->wimg = nullptr;
-    ctx->wimg_bytes = 0;
-    NF_HIP(hipMalloc(&ctx->wimg, bytes));
-    ctx->wimg_bytes = bytes;
-  }
+  NF_TRY(nf_wimg_reserve(ctx, bytes));
   const PackArgs p = make_pack_args(desc);
   const long total = (long)nc * 2 * G::SIZE;
   ProfScope ps(ctx, "pack_weights");
@@ -1225,6 +1220,7 @@ static bool wide_fits_mid(const nf_flow_desc *desc) {
 #define WIDE_DISPATCH(CALL) (wide_fits_mid(desc) ? WideHost<GM>::CALL : WideHost<GW>::CALL)
 
 int nf_wide_pack(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta) { return WIDE_DISPATCH(wide_pack(ctx, desc, theta)); }
+size_t nf_wide_wimg_bytes(nf_ctx *ctx, const nf_flow_desc *desc) { return WIDE_DISPATCH(wide_wimg_bytes(ctx, desc)); }
 int nf_wide_apply(nf_ctx *ctx, const nf_flow_desc *desc, int k, bool inverse, float *xt, long N, float *ladj, int accumulate) { return WIDE_DISPATCH(wide_apply(ctx, desc, k, inverse, xt, N, ladj, accumulate)); }
 size_t nf_wide_bwd_ws_floats(nf_ctx *ctx, const nf_flow_desc *desc, long N) { return WIDE_DISPATCH(wide_bwd_ws_floats(ctx, desc, N)); }
 int nf_wide_bwd(nf_ctx *ctx, const nf_flow_desc *desc, float *state, float *gbar, const float *lbar, float lbar_const, long N, float *ws, float *g_out, bool inv_dir) { return WIDE_DISPATCH(wide_bwd(ctx, desc, state, gbar, lbar, lbar_const, N, ws, g_out, inv_dir)); }

@@ -79,3 +79,106 @@ def test_library_rccl_entry_points_world_size_one():
         assert torch.equal(buf, ref)
     finally:
         ctx.close()
+
+
+ARENA_FLOWS = {
+    "realnvp_resident": lambda nf: nf.realnvp(nf.MvNormal(8), [32, 32], 2, paramtype=torch.float32, seed=1),
+    "realnvp_wide": lambda nf: nf.realnvp(nf.MvNormal(100), [96, 130], 1, paramtype=torch.float32, seed=2),
+    "realnvp_f64": lambda nf: nf.realnvp(nf.MvNormal(5), [16], 1, paramtype=torch.float64, seed=3),
+    "nsf_mfma": lambda nf: nf.nsf(nf.MvNormal(5), [32, 32], 10, 5.0, 2, paramtype=torch.float32, seed=4),
+    "nsf_general": lambda nf: nf.nsf(nf.MvNormal(6), [24, 16, 8], 8, 5.0, 1, paramtype=torch.float32, seed=5),
+    "planar": lambda nf: nf.planarflow(nf.MvNormal(5), 10, paramtype=torch.float32, seed=6),
+    "planar_many_layers": lambda nf: nf.planarflow(nf.MvNormal(40), 20, paramtype=torch.float32, seed=6),  # beyond k_simple_step
+    "radial_f64": lambda nf: nf.radialflow(nf.MvNormal(7), 4, paramtype=torch.float64, seed=7),
+    "meanfield": lambda nf: nf.meanfield(nf.MvNormal(4), paramtype=torch.float32),
+}
+
+
+@pytest.mark.parametrize("name", list(ARENA_FLOWS))
+def test_caller_provided_arena_covers_every_entry_point(name):
+    """nf_workspace_bytes + nf_ctx_set_arena ("allocates nothing persistent except the ctx; arena sized by
+    nf_workspace_bytes"): with the arena set, every compute entry point runs inside it -- same results as the owned
+    mode -- and an arena that is too small is refused with NF_ERR_WORKSPACE instead of allocating."""
+    nf = load_package()
+    lib = nf.load_library()
+    flow = ARENA_FLOWS[name](nf)
+    if name.startswith("planar") or name.startswith("radial"):
+        flow = flow.with_theta(flow.theta * 0.3)
+    dt, d, n = flow.theta.dtype, flow.dist.d, 333
+    ctx = flow.ctx
+    tgt = nf.DiagGaussTarget(torch.randn(d, dtype=dt, device="cuda"), torch.rand(d, dtype=dt, device="cuda") + 0.5)
+
+    def run_everything():
+        out = {}
+        xs = nf.device_specific_rand(nf.PhiloxRNG(3), flow.dist, n, dtype=dt)
+        ys, ladj = nf.with_logabsdet_jacobian(flow.transform, xs)
+        xr, lb = nf.with_logabsdet_jacobian(nf.inverse(flow.transform), ys)
+        y1, l1 = nf.with_logabsdet_jacobian(nf.layer(flow, 0), xs)
+        out["fwd"], out["inv"], out["layer"] = ys, xr, y1
+        out["rand"] = nf.rand(flow, n, nf.PhiloxRNG(4))
+        out["elbo_xs"] = torch.tensor(nf.elbo_batch(flow, tgt, xs))
+        out["elbo_rng"] = torch.tensor(nf.elbo_batch(nf.PhiloxRNG(5), flow, tgt, n))
+        out["elbos"] = nf.batched_elbos(flow, tgt, xs)
+        out["loglik"] = torch.tensor(nf.loglikelihood(None, flow, ys))
+        l, g = nf.value_and_gradient(nf.elbo_batch, flow, tgt, n, rng=nf.PhiloxRNG(6))
+        out["step_rng"] = torch.cat([g, torch.tensor([l], dtype=dt, device="cuda")])
+        l, g = nf.value_and_gradient(nf.elbo_batch, flow, tgt, xs)
+        out["step_xs"] = torch.cat([g, torch.tensor([l], dtype=dt, device="cuda")])
+        l, g = nf.value_and_gradient(nf.elbo_batch, flow, lambda y: -(y * y).sum(0), xs)  # generic closure: nf_flow_bwd
+        out["pullback"] = g
+        l, g = nf.loglikelihood_value_and_gradient(flow, ys)
+        out["fkl"] = torch.cat([g, torch.tensor([l], dtype=dt, device="cuda")])
+        th = flow.theta.clone()
+        st = nf.setup(nf.Adam(1e-3), th)
+        out["gnorm"] = nf.adam_update(nf.Adam(1e-3), st, th, g).clone()
+        out["adam"] = th
+        th2, m2, v2 = flow.theta.clone(), torch.zeros_like(flow.theta), torch.zeros_like(flow.theta)
+        loss, gn = C.c_double(0), C.c_double(0)
+        nf._lib.check(lib.nf_elbo_step(ctx.ptr, C.byref(flow.desc), C.byref(tgt.c), C.c_void_p(th2.data_ptr()), C.c_void_p(m2.data_ptr()),
+                                       C.c_void_p(v2.data_ptr()), n, 9, 0, 1e-3, 0.9, 0.999, 1e-8, C.byref(loss), C.byref(gn)))
+        out["elbo_step"] = th2
+        torch.cuda.synchronize()
+        return {k: v.detach().clone() for k, v in out.items()}
+
+    ref = run_everything()
+    need = int(lib.nf_workspace_bytes(ctx.ptr, C.byref(flow.desc), n))
+    assert need > 0
+    arena = torch.empty(need + 256, dtype=torch.uint8, device="cuda")
+    base = (arena.data_ptr() + 255) // 256 * 256
+    try:
+        nf._lib.check(lib.nf_ctx_set_arena(ctx.ptr, C.c_void_p(base), need))
+        got = run_everything()
+        # the general one-thread-per-sample kernels (Float64 / odd shapes) sum parameter gradients with atomics: equal up
+        # to summation order; every other path is deterministic and must reproduce bit for bit
+        atomic = flow.kind in ("realnvp", "nsf") and name in ("realnvp_f64", "nsf_general")
+
+        def same(a, b):
+            return torch.allclose(a, b, rtol=1e-5 if dt == torch.float32 else 1e-12, atol=1e-6 if dt == torch.float32 else 1e-13) if atomic else torch.equal(a, b)
+
+        for k in ref:
+            assert same(ref[k], got[k]), (name, k)
+        # an arena that is too small is refused, never silently replaced by an allocation
+        nf._lib.check(lib.nf_ctx_set_arena(ctx.ptr, C.c_void_p(base), 4096))
+        with pytest.raises(nf.NFHipError, match="arena is too small"):
+            nf.value_and_gradient(nf.elbo_batch, flow, tgt, 4096, rng=nf.PhiloxRNG(6))
+    finally:
+        nf._lib.check(lib.nf_ctx_set_arena(ctx.ptr, None, 0))  # back to the owned, grow-only mode
+    again = run_everything()
+    for k in ref:
+        assert same(ref[k], again[k]), (name, k, "after leaving arena mode")
+
+
+def test_elbo_step_reports_non_finite_loss():
+    """NF_ERR_NONFINITE: the reference's tests require finite ELBOs (test/flow.jl:58-60); the fused step says so."""
+    nf = load_package()
+    lib = nf.load_library()
+    flow = nf.realnvp(nf.MvNormal(6), [16, 16], 1, paramtype=torch.float32, seed=1)
+    tgt = nf.DiagGaussTarget(torch.zeros(6, device="cuda"), torch.ones(6, device="cuda"))
+    th = flow.theta.clone()
+    th[3] = float("nan")
+    m, v = torch.zeros_like(th), torch.zeros_like(th)
+    loss, gn = C.c_double(0), C.c_double(0)
+    code = lib.nf_elbo_step(flow.ctx.ptr, C.byref(flow.desc), C.byref(tgt.c), C.c_void_p(th.data_ptr()), C.c_void_p(m.data_ptr()),
+                            C.c_void_p(v.data_ptr()), 256, 1, 0, 1e-3, 0.9, 0.999, 1e-8, C.byref(loss), C.byref(gn))
+    assert code == -4 and b"non-finite" in lib.nf_strerror(code)
+    assert not (np.isfinite(loss.value) and np.isfinite(gn.value))  # here the clamp inside tanh keeps the loss finite, the gradient is NaN
