@@ -32,6 +32,13 @@ struct NFDesc
     K::Int32
     B::Float32
     score::Ptr{Cvoid}   # NF_KIND_HAMILTONIAN: pointer to the NFTarget behind LeapFrog's score, else C_NULL
+    base::Ptr{Cvoid}    # pointer to an NFBase for a general MvNormal(mu, Sigma) q0, C_NULL = MvNormal(zeros, I)
+end
+struct NFBase            # nf_base: kind 1 = Diagonal(sigma^2) (scale = sigma), 2 = dense (scale = L, column-major)
+    kind::Int32
+    mu::Ptr{Cvoid}
+    scale::Ptr{Cvoid}
+    logdet::Float64
 end
 struct NFTarget
     kind::Int32
@@ -108,19 +115,19 @@ function desc_of(flow::Bijectors.TransformedDistribution)
     L1 = first(Ls)
     nohid = ntuple(_ -> Int32(0), 4)
     if all(l -> l isa Bijectors.PlanarLayer, Ls)
-        return NFDesc(NF_KIND_PLANAR, dtype_code(T), d, Int32(length(Ls)), 0, nohid, 0, 0.0f0, C_NULL)
+        return NFDesc(NF_KIND_PLANAR, dtype_code(T), d, Int32(length(Ls)), 0, nohid, 0, 0.0f0, C_NULL, C_NULL)
     elseif all(l -> l isa Bijectors.RadialLayer, Ls)
-        return NFDesc(NF_KIND_RADIAL, dtype_code(T), d, Int32(length(Ls)), 0, nohid, 0, 0.0f0, C_NULL)
+        return NFDesc(NF_KIND_RADIAL, dtype_code(T), d, Int32(length(Ls)), 0, nohid, 0, 0.0f0, C_NULL, C_NULL)
     elseif length(Ls) == 2 && Ls[1] isa Bijectors.Shift && Ls[2] isa Bijectors.Scale
-        return NFDesc(NF_KIND_MEANFIELD, dtype_code(T), d, Int32(1), 0, nohid, 0, 0.0f0, C_NULL)
+        return NFDesc(NF_KIND_MEANFIELD, dtype_code(T), d, Int32(1), 0, nohid, 0, 0.0f0, C_NULL, C_NULL)
     elseif all(l -> l isa AffineCoupling, Ls)
         iseven(length(Ls)) || error("nfhip: realnvp flows are built from RealNVP_layer pairs (src/flows/realnvp.jl:132-145)")
         h = hidden_dims(L1.s)
-        return NFDesc(NF_KIND_REALNVP, dtype_code(T), d, Int32(length(Ls) ÷ 2), Int32(length(h)), pad4(h), 0, 0.0f0, C_NULL)
+        return NFDesc(NF_KIND_REALNVP, dtype_code(T), d, Int32(length(Ls) ÷ 2), Int32(length(h)), pad4(h), 0, 0.0f0, C_NULL, C_NULL)
     elseif all(l -> l isa NeuralSplineCoupling, Ls)
         iseven(length(Ls)) || error("nfhip: nsf flows are built from NSF_layer pairs (src/flows/neuralspline.jl:169-184)")
         h = hidden_dims(L1.nn)
-        return NFDesc(NF_KIND_NSF, dtype_code(T), d, Int32(length(Ls) ÷ 2), Int32(length(h)), pad4(h), Int32(L1.K), Float32(L1.B), C_NULL)
+        return NFDesc(NF_KIND_NSF, dtype_code(T), d, Int32(length(Ls) ÷ 2), Int32(length(h)), pad4(h), Int32(L1.K), Float32(L1.B), C_NULL, C_NULL)
     end
     return error("nfhip: flow is not one of planarflow / radialflow / realnvp / nsf / Shift∘Scale; use the per-layer methods")
 end
@@ -210,13 +217,33 @@ struct NFHipTransform{V<:ROCVector,R} <: Bijectors.Bijector
     desc::NFDesc
     re::R            # Optimisers restructure: re(θ) gives back the reference-side flow
     inverted::Bool
+    keep::Any        # roots what desc points into (the NFBase Ref and its device arrays), or nothing
 end
-Bijectors.inverse(t::NFHipTransform) = NFHipTransform(t.θ, t.desc, t.re, !t.inverted)
+Bijectors.inverse(t::NFHipTransform) = NFHipTransform(t.θ, t.desc, t.re, !t.inverted, t.keep)
+
+# a general MvNormal(μ, Σ) q0 as an nf_base: Σ = L L', scale = σ (diagonal) or L (dense, column-major as Julia stores it)
+function base_of(q0::Distributions.MvNormal, ::Type{T}) where {T}
+    is_standard_normal(q0) && return C_NULL, nothing
+    μ = ROCVector{T}(q0.μ)
+    if q0.Σ isa Union{Distributions.PDMats.ScalMat,Distributions.PDMats.PDiagMat}
+        σ = ROCVector{T}(sqrt.(LinearAlgebra.diag(q0.Σ)))
+        ref = Ref(NFBase(Int32(1), devptr(μ), devptr(σ), Float64(sum(log, Array(σ)))))
+        return Base.unsafe_convert(Ptr{Cvoid}, ref), (ref, μ, σ)
+    end
+    Lh = Matrix{T}(LinearAlgebra.cholesky(Matrix(q0.Σ)).L)
+    L = ROCMatrix{T}(Lh)
+    ref = Ref(NFBase(Int32(2), devptr(μ), devptr(L), Float64(sum(log, LinearAlgebra.diag(Lh)))))
+    return Base.unsafe_convert(Ptr{Cvoid}, ref), (ref, μ, L)
+end
+
+with_base(d::NFDesc, base::Ptr{Cvoid}) =
+    NFDesc(d.kind, d.dtype, d.d, d.nlayers, d.n_hidden, d.hdims, d.K, d.B, d.score, base)
 
 "nfhip(flow): the same flow with parameters on the device and a library-backed transform"
 function nfhip(flow::Bijectors.TransformedDistribution)
     θ, re, desc = theta_of(flow)
-    return Bijectors.transformed(flow.dist, NFHipTransform(θ, desc, re, false))
+    bptr, keep = base_of(flow.dist, eltype(θ))
+    return Bijectors.transformed(flow.dist, NFHipTransform(θ, with_base(desc, bptr), re, false, keep))
 end
 
 function apply(t::NFHipTransform, x::ROCMatrix{T}) where {T}
@@ -356,7 +383,7 @@ function NormalizingFlows.train_flow(rng::NFHipRNG, vo, flow::Bijectors.Transfor
     dflow = flow isa DeviceFlow ? flow : nfhip(flow)
     t = dflow.transform
     θ = copy(t.θ)
-    re_dev = th -> Bijectors.transformed(dflow.dist, NFHipTransform(th, t.desc, t.re, false))   # current_desc(): t.desc, static
+    re_dev = th -> Bijectors.transformed(dflow.dist, NFHipTransform(th, t.desc, t.re, false, t.keep))   # t.desc is static
     loss(th, rng_, args_...) = -vo(rng_, re_dev(th), args_...)
     nloc = vo === NormalizingFlows.loglikelihood ? size(args[1], 2) : args[2]
     ad = AutoNFHip(vo, t.desc, args, n_global > 0 ? n_global : nloc, allreduce)

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NF_ABI_VERSION 1
+#define NF_ABI_VERSION 2
 
 /* status codes (< 0: library errors; > 0: hipError_t) */
 #define NF_OK 0
@@ -74,6 +74,23 @@ extern "C" {
 
 #define NF_MAX_HIDDEN 4
 
+/* Base distribution q0 of a flow (the `dist` of the TransformedDistribution).  Every reference configuration uses
+ * MvNormal(zeros(d), I) (test/flow.jl:9, demo_planar_flow.jl:24) -- that is base == NULL, and the only form the fused
+ * kernels draw in registers.  General MvNormal(mu, Sigma) bases (what _device_specific_rand(rng, ::MvNormal, n) and
+ * logpdf(flow.dist, xs) accept: src/NormalizingFlows.jl:109-115, ext/NormalizingFlowsCUDAExt.jl:43-48,
+ * test/ext/CUDA/cuda.jl:33-45) are drawn as x = mu + L eps and enter the objectives through an exact per-sample
+ * correction of log q0; q0 is a leaf of destructure (@leaf MvNormal), so it carries no trainable parameter. */
+#define NF_BASE_STANDARD 0 /* MvNormal(zeros(d), I)                                                    */
+#define NF_BASE_DIAG 1     /* MvNormal(mu, Diagonal(sigma.^2)): scale = sigma[d]  (device)              */
+#define NF_BASE_DENSE 2    /* MvNormal(mu, Sigma), Sigma = L L': scale = L, d x d lower triangular,
+                              column-major (device)                                                     */
+typedef struct nf_base {
+  int32_t kind;      /* NF_BASE_*                                     */
+  const void *mu;    /* [d], device, the flow's element type          */
+  const void *scale; /* see NF_BASE_*                                 */
+  double logdet;     /* log|det L| = sum(log(diag(L))) / sum(log(sigma)) */
+} nf_base;
+
 /* Static (non-trainable) description of a flow: the fields of the reference's
  * layer structs that Optimisers.destructure leaves out (dim, mask, K, B, hidden
  * sizes; src/flows/realnvp.jl:33-38, src/flows/neuralspline.jl:35-42). */
@@ -90,6 +107,7 @@ typedef struct nf_flow_desc {
   float B;                      /* spline box bound (nsf)                            */
   const struct nf_target *score; /* NF_KIND_HAMILTONIAN: the target behind LeapFrog's
                                     score function (host pointer); NULL otherwise     */
+  const struct nf_base *base;    /* q0 (host pointer); NULL = MvNormal(zeros(d), I)  */
 } nf_flow_desc;
 
 /* Built-in target log-densities (the `logp` closure of src/objectives/elbo.jl:68
@@ -139,6 +157,12 @@ int nf_base_sample_logpdf(nf_ctx *ctx, int32_t dtype, int32_t d, int64_t N, uint
                           uint64_t sample_offset, uint32_t stream_id, void *x_out, void *logq_out);
 /* logpdf(MvNormal(zeros(d), I), xs) for caller-supplied xs */
 int nf_base_logpdf(nf_ctx *ctx, int32_t dtype, int32_t d, int64_t N, const void *x, void *logq_out);
+/* The same two for a general MvNormal(mu, Sigma) base (base == NULL or NF_BASE_STANDARD: identical to the above):
+ * x = mu + L eps with the eps of nf_base_sample_logpdf(seed, sample_offset, stream_id), and its log-density. */
+int nf_base_rand(nf_ctx *ctx, int32_t dtype, const nf_base *base, int32_t d, int64_t N, uint64_t seed,
+                 uint64_t sample_offset, uint32_t stream_id, void *x_out, void *logq_out);
+int nf_base_logpdf_general(nf_ctx *ctx, int32_t dtype, const nf_base *base, int32_t d, int64_t N, const void *x,
+                           void *logq_out);
 
 /* ---- a6, a7, a10, a12, a13: transforms ----------------------------------- */
 /* Bijectors.with_logabsdet_jacobian(flow.transform, xs)  (src/objectives/elbo.jl:67):

@@ -34,7 +34,17 @@ class FlowDesc(C.Structure):
         ("K", C.c_int32),
         ("B", C.c_float),
         ("score", C.c_void_p),  # const nf_target * (Hamiltonian flows), else NULL
+        ("base", C.c_void_p),  # const nf_base * (general MvNormal(mu, Sigma) base), NULL = MvNormal(zeros, I)
     ]
+
+
+class Base(C.Structure):
+    """nf_base"""
+
+    _fields_ = [("kind", C.c_int32), ("mu", C.c_void_p), ("scale", C.c_void_p), ("logdet", C.c_double)]
+
+
+NF_BASE_STANDARD, NF_BASE_DIAG, NF_BASE_DENSE = 0, 1, 2
 
 
 class Target(C.Structure):
@@ -51,7 +61,7 @@ class Target(C.Structure):
 
 # every symbol include/nfhip.h declares: name -> (restype, argtypes)
 _P, _I32, _I64, _U64, _U32, _D = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_uint32, C.c_double
-_DESC, _TGT = C.POINTER(FlowDesc), C.POINTER(Target)
+_DESC, _TGT, _BASE = C.POINTER(FlowDesc), C.POINTER(Target), C.POINTER(Base)
 _PD = C.POINTER(C.c_double)
 SYMBOLS = {
     "nf_abi_version": (C.c_int, []),
@@ -66,6 +76,8 @@ SYMBOLS = {
     "nf_layer_count": (_I32, [_DESC]),
     "nf_base_sample_logpdf": (C.c_int, [_P, _I32, _I32, _I64, _U64, _U64, _U32, _P, _P]),
     "nf_base_logpdf": (C.c_int, [_P, _I32, _I32, _I64, _P, _P]),
+    "nf_base_rand": (C.c_int, [_P, _I32, _BASE, _I32, _I64, _U64, _U64, _U32, _P, _P]),
+    "nf_base_logpdf_general": (C.c_int, [_P, _I32, _BASE, _I32, _I64, _P, _P]),
     "nf_flow_fwd": (C.c_int, [_P, _DESC, _P, _P, _I64, _P, _P]),
     "nf_flow_inv": (C.c_int, [_P, _DESC, _P, _P, _I64, _P, _P]),
     "nf_flow_rand": (C.c_int, [_P, _DESC, _P, _I64, _U64, _U64, _U32, _P]),
@@ -110,7 +122,7 @@ def load_library():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.nf_abi_version() != 1:
+    if lib.nf_abi_version() != 2:
         raise NFHipError("libnfhip.so ABI version mismatch")
     _lib = lib
     return lib

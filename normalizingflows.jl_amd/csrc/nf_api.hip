@@ -9,6 +9,9 @@
 // ---- kernels' host launchers (other translation units) ---------------------------------
 int nf_launch_base_sample(nf_ctx *, int, int, long, uint64_t, uint64_t, uint32_t, void *, void *);
 int nf_launch_base_logpdf(nf_ctx *, int, int, long, const void *, void *);
+int nf_launch_base_unwhiten(nf_ctx *, int dtype, int kind, int d, long N, const void *mu, const void *scale, void *x);
+int nf_launch_base_general_logpdf(nf_ctx *, int dtype, int kind, int d, long N, const void *mu, const void *scale, double logdet,
+                                  const void *x, void *logq_out, void *corr_out, void *zbuf);
 long nf_target_nblocks(long N);
 int nf_launch_target(nf_ctx *, int, const nf_target *, int, long, const void *, const void *, const void *, void *,
                      void *, double, void *, double *, double, int joint_d);
@@ -122,11 +125,24 @@ int nf_hf_bwd_inv(nf_ctx *, const nf_flow_desc *, const void *theta, const void 
                   long N, void *gtheta_out, void *ws);
 
 // ---- helpers -----------------------------------------------------------------------------
+static size_t ws_need_bound(nf_ctx *ctx, const nf_flow_desc *desc, long N);
+static size_t base_extra_bytes(const nf_flow_desc *desc, long N);
 static inline size_t esize(int dtype) { return dtype == NF_DTYPE_F64 ? 8 : 4; }
+
+// general MvNormal(mu, Sigma) base of a flow, or nullptr for the standard normal
+static inline const nf_base *flow_base(const nf_flow_desc *d) {
+  return (d->base && d->base->kind != NF_BASE_STANDARD) ? d->base : nullptr;
+}
+static int check_base(const nf_base *b) {
+  if (!b || b->kind == NF_BASE_STANDARD) return NF_OK;
+  if (b->kind != NF_BASE_DIAG && b->kind != NF_BASE_DENSE) return NF_ERR_ARG;
+  return (b->mu && b->scale) ? NF_OK : NF_ERR_ARG;
+}
 
 static int check_desc(const nf_flow_desc *d) {
   if (!d) return NF_ERR_ARG;
   if (d->d < 1 || d->nlayers < 1) return NF_ERR_ARG;
+  NF_TRY(check_base(d->base));
   if (d->dtype != NF_DTYPE_F32 && d->dtype != NF_DTYPE_F64) return NF_ERR_ARG;
   switch (d->kind) {
     case NF_KIND_PLANAR:
@@ -279,6 +295,8 @@ extern "C" int nf_ctx_synchronize(nf_ctx *ctx) {
 // steps never do).  With a caller-provided arena (nf_ctx_set_arena, sized by nf_workspace_bytes) no compute entry
 // point allocates, frees or synchronises for memory at all: requests beyond the arena fail with NF_ERR_WORKSPACE.
 int nf_ws_reserve(nf_ctx *ctx, size_t bytes) {
+  // an outer entry point (general-base wrappers) keeps its own buffers behind the first ws_guard bytes
+  if (ctx->ws_guard && bytes > ctx->ws_guard) return NF_ERR_WORKSPACE;
   if (ctx->arena) {
     const size_t avail = ctx->arena_bytes - ctx->arena_tail;
     if (bytes > avail) return NF_ERR_WORKSPACE;
@@ -364,6 +382,51 @@ static int read_scalar(nf_ctx *ctx, const double *dev, double *host) {
   *host = ctx->host_scratch[0];
   return NF_OK;
 }
+
+// buffers and helpers of the general-base wrappers (defined with the objectives below)
+struct BaseBufs {
+  char *x, *corr, *tmp, *z;
+  double *partial, *result;
+  long nb;
+};
+static int base_bufs(nf_ctx *ctx, const nf_flow_desc *desc, const nf_flow_desc *inner, long N, BaseBufs *bb) {
+  const nf_base *b = flow_base(desc);
+  const size_t es = esize(desc->dtype);
+  const size_t in_need = ws_need_bound(ctx, inner, N);
+  ctx->ws_guard = 0;
+  NF_TRY(nf_ws_reserve(ctx, in_need + base_extra_bytes(desc, N)));
+  Carver cv((char *)ctx->ws + in_need);
+  bb->x = cv.take<char>((size_t)N * desc->d * es);
+  bb->z = b->kind == NF_BASE_DENSE ? cv.take<char>((size_t)N * desc->d * es) : nullptr;
+  bb->corr = cv.take<char>((size_t)N * es);
+  bb->tmp = cv.take<char>((size_t)N * es);
+  bb->nb = nf_sum2_nblocks(N);
+  bb->partial = cv.take<double>(bb->nb);
+  bb->result = cv.take<double>(8);
+  ctx->ws_guard = in_need;  // the inner entry point must stay in front of these buffers
+  return NF_OK;
+}
+struct GuardReset {  // clears the guard on every exit path
+  nf_ctx *ctx;
+  ~GuardReset() { ctx->ws_guard = 0; }
+};
+
+static int base_draw(nf_ctx *ctx, const nf_flow_desc *desc, long N, uint64_t seed, uint64_t off, uint32_t stream_id, void *x,
+                     void *logq_eps) {
+  const nf_base *b = flow_base(desc);
+  NF_TRY(nf_launch_base_sample(ctx, desc->dtype, desc->d, N, seed, off, stream_id, x, logq_eps));
+  return nf_launch_base_unwhiten(ctx, desc->dtype, b->kind, desc->d, N, b->mu, b->scale, x);
+}
+
+
+static int elbo_forward_general_base(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, const void *theta,
+                                     const void *xs, long N, uint64_t seed, uint64_t off, uint32_t stream_id,
+                                     void *elbos_out, double *elbo_host);
+static int loglikelihood_general_base(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *ys, long N,
+                                      void *logliks_out, double *ll_host);
+static int value_and_grad_general_base(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, const void *theta,
+                                       const void *xs, int64_t N_local, int64_t N_global, uint64_t seed, uint64_t sample_offset,
+                                       uint32_t stream_id, void *out);
 
 // ---- base distribution ---------------------------------------------------------------------
 extern "C" int nf_base_sample_logpdf(nf_ctx *ctx, int32_t dtype, int32_t d, int64_t N, uint64_t seed,
@@ -514,6 +577,15 @@ extern "C" int nf_flow_rand(nf_ctx *ctx, const nf_flow_desc *desc, const void *t
   NF_TRY(check_desc(desc));
   NF_HIP(hipSetDevice(ctx->device));
   if (N == 0) return NF_OK;
+  if (flow_base(desc)) {  // x = mu + L eps into y_out, then the transform in place (log-det into scratch)
+    nf_flow_desc inner = *desc;
+    inner.base = nullptr;
+    BaseBufs bb;
+    NF_TRY(base_bufs(ctx, desc, &inner, N, &bb));
+    GuardReset gr{ctx};
+    NF_TRY(base_draw(ctx, desc, N, seed, sample_offset, stream_id, y_out, nullptr));
+    return apply_std(ctx, &inner, false, -1, theta, y_out, N, y_out, bb.tmp);
+  }
   if (is_coupling(desc)) {
     NF_TRY(nf_ws_reserve(ctx, carve_bytes(tiled_elems(desc, N) * 4) + carve_bytes((size_t)N * 4)));
     Carver cv(ctx->ws);
@@ -685,6 +757,7 @@ extern "C" int nf_elbo_batch(nf_ctx *ctx, const nf_flow_desc *desc, const nf_tar
   if (!ctx || !target || !theta || !xs || !elbo_host || N < 1) return NF_ERR_ARG;
   NF_TRY(check_desc(desc));
   NF_HIP(hipSetDevice(ctx->device));
+  if (flow_base(desc)) return elbo_forward_general_base(ctx, desc, target, theta, xs, N, 0, 0, 0, elbos_out, elbo_host);
   return elbo_forward(ctx, desc, target, theta, xs, N, 0, 0, 0, elbos_out, elbo_host);
 }
 
@@ -694,6 +767,8 @@ extern "C" int nf_elbo_batch_rng(nf_ctx *ctx, const nf_flow_desc *desc, const nf
   if (!ctx || !target || !theta || !elbo_host || N < 1) return NF_ERR_ARG;
   NF_TRY(check_desc(desc));
   NF_HIP(hipSetDevice(ctx->device));
+  if (flow_base(desc))
+    return elbo_forward_general_base(ctx, desc, target, theta, nullptr, N, seed, sample_offset, stream_id, nullptr, elbo_host);
   return elbo_forward(ctx, desc, target, theta, nullptr, N, seed, sample_offset, stream_id, nullptr, elbo_host);
 }
 
@@ -702,6 +777,7 @@ extern "C" int nf_loglikelihood(nf_ctx *ctx, const nf_flow_desc *desc, const voi
   if (!ctx || !theta || !ys || !ll_host || N < 1) return NF_ERR_ARG;
   NF_TRY(check_desc(desc));
   NF_HIP(hipSetDevice(ctx->device));
+  if (flow_base(desc)) return loglikelihood_general_base(ctx, desc, theta, ys, N, logliks_out, ll_host);
   const size_t es = esize(desc->dtype);
   const bool cp = is_coupling(desc);
   const long nb = nf_sum2_nblocks(N);
@@ -738,6 +814,7 @@ extern "C" int nf_loglikelihood_value_and_grad(nf_ctx *ctx, const nf_flow_desc *
   if (!ctx || !theta || !out || N_local < 0 || N_global < 1 || (N_local > 0 && !ys)) return NF_ERR_ARG;
   NF_TRY(check_desc(desc));
   NF_HIP(hipSetDevice(ctx->device));
+  if (flow_base(desc)) return NF_ERR_UNSUPPORTED;  // forward-KL training is built for the standard-normal base only
   const long N = N_local;
   const long P = nf_param_count(desc);
   const int dt = desc->dtype;
@@ -798,6 +875,121 @@ extern "C" int nf_loglikelihood_value_and_grad(nf_ctx *ctx, const nf_flow_desc *
   return nf_launch_finish_sum(ctx, partial, nb, 0, (double *)out + P, nullptr, nullptr);
 }
 
+
+// ---- general MvNormal(mu, Sigma) bases -----------------------------------------------------------
+// q0 carries no trainable parameter (@leaf MvNormal), so a general base only changes (i) where the draws come from,
+// x = mu + L eps, and (ii) log q0(x).  The wrappers below produce x in a buffer of their own, run the standard-normal
+// entry point on it as caller-supplied xs (every fused / MFMA kernel untouched), and add the exact per-sample
+// correction  log N(x; 0, I) - log q0(x)  to the ELBO terms; gradients with respect to theta are unaffected.
+static int elbo_forward(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, const void *theta,
+                        const void *xs, long N, uint64_t seed, uint64_t off, uint32_t stream_id, void *elbos_out,
+                        double *elbo_host);
+extern "C" int nf_base_logpdf_general(nf_ctx *ctx, int32_t dtype, const nf_base *base, int32_t d, int64_t N, const void *x,
+                                      void *logq_out);
+
+static int elbo_forward_general_base(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, const void *theta,
+                                     const void *xs, long N, uint64_t seed, uint64_t off, uint32_t stream_id,
+                                     void *elbos_out, double *elbo_host) {
+  const nf_base *b = flow_base(desc);
+  nf_flow_desc inner = *desc;
+  inner.base = nullptr;
+  BaseBufs bb;
+  NF_TRY(base_bufs(ctx, desc, &inner, N, &bb));
+  GuardReset gr{ctx};
+  const void *x = xs;
+  if (!xs) {
+    NF_TRY(base_draw(ctx, desc, N, seed, off, stream_id, bb.x, nullptr));
+    x = bb.x;
+  }
+  NF_TRY(nf_launch_base_general_logpdf(ctx, desc->dtype, b->kind, desc->d, N, b->mu, b->scale, b->logdet, x, nullptr, bb.corr, bb.z));
+  double v = 0.0;
+  NF_TRY(elbo_forward(ctx, &inner, target, theta, x, N, 0, 0, 0, elbos_out, &v));
+  // per-sample terms and the mean: add the correction
+  NF_TRY(nf_launch_sum2(ctx, desc->dtype, N, bb.corr, elbos_out, elbos_out, bb.partial, 1.0 / (double)N));
+  if (elbos_out) {  // sum2 accumulated corr + elbos into the partials: the mean of the corrected terms
+    NF_TRY(nf_launch_finish_sum(ctx, bb.partial, bb.nb, 0, bb.result, nullptr, nullptr));
+    return read_scalar(ctx, bb.result, elbo_host);
+  }
+  NF_TRY(nf_launch_finish_sum(ctx, bb.partial, bb.nb, 0, bb.result, nullptr, nullptr));
+  double c = 0.0;
+  NF_TRY(read_scalar(ctx, bb.result, &c));
+  *elbo_host = v + c;
+  return NF_OK;
+}
+
+static int value_and_grad_general_base(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, const void *theta,
+                                       const void *xs, int64_t N_local, int64_t N_global, uint64_t seed, uint64_t sample_offset,
+                                       uint32_t stream_id, void *out) {
+  const nf_base *b = flow_base(desc);
+  const long N = N_local;
+  const long P = nf_param_count(desc);
+  if (N == 0) return nf_launch_fill(ctx, desc->dtype, out, P + 1, 0.0);
+  nf_flow_desc inner = *desc;
+  inner.base = nullptr;
+  BaseBufs bb;
+  NF_TRY(base_bufs(ctx, desc, &inner, N, &bb));
+  GuardReset gr{ctx};
+  const void *x = xs;
+  if (!xs) {
+    NF_TRY(base_draw(ctx, desc, N, seed, sample_offset, stream_id, bb.x, nullptr));
+    x = bb.x;
+  }
+  NF_TRY(nf_launch_base_general_logpdf(ctx, desc->dtype, b->kind, desc->d, N, b->mu, b->scale, b->logdet, x, nullptr, bb.corr, bb.z));
+  NF_TRY(nf_elbo_value_and_grad(ctx, &inner, target, theta, x, N_local, N_global, 0, 0, 0, out));
+  // loss += sum_j -(corr_j) / N_global
+  const size_t es = esize(desc->dtype);
+  NF_TRY(nf_launch_sum2(ctx, desc->dtype, N, bb.corr, nullptr, nullptr, bb.partial, -1.0 / (double)N_global));
+  if (desc->dtype == NF_DTYPE_F32) NF_TRY(nf_launch_finish_sum(ctx, bb.partial, bb.nb, 0, nullptr, (float *)bb.tmp, nullptr));
+  else NF_TRY(nf_launch_finish_sum(ctx, bb.partial, bb.nb, 0, (double *)bb.tmp, nullptr, nullptr));
+  char *lossp = (char *)out + (size_t)P * es;
+  return nf_launch_sum2(ctx, desc->dtype, 1, lossp, bb.tmp, lossp, bb.partial, 0.0);
+}
+
+static int loglikelihood_general_base(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *ys, long N,
+                                      void *logliks_out, double *ll_host) {
+  const nf_base *b = flow_base(desc);
+  nf_flow_desc inner = *desc;
+  inner.base = nullptr;
+  BaseBufs bb;
+  NF_TRY(base_bufs(ctx, desc, &inner, N, &bb));
+  GuardReset gr{ctx};
+  // z = T^-1 y and ladj_inv with the public inverse, then log q0(z) with the general density
+  NF_TRY(nf_flow_inv(ctx, &inner, theta, ys, N, bb.x, bb.tmp));
+  NF_TRY(nf_launch_base_general_logpdf(ctx, desc->dtype, b->kind, desc->d, N, b->mu, b->scale, b->logdet, bb.x, bb.corr, nullptr, bb.z));
+  NF_TRY(nf_launch_sum2(ctx, desc->dtype, N, bb.corr, bb.tmp, logliks_out, bb.partial, 1.0 / (double)N));
+  NF_TRY(nf_launch_finish_sum(ctx, bb.partial, bb.nb, 0, bb.result, nullptr, nullptr));
+  return read_scalar(ctx, bb.result, ll_host);
+}
+
+extern "C" int nf_base_rand(nf_ctx *ctx, int32_t dtype, const nf_base *base, int32_t d, int64_t N, uint64_t seed,
+                            uint64_t sample_offset, uint32_t stream_id, void *x_out, void *logq_out) {
+  if (!ctx || !x_out || d < 1 || N < 0) return NF_ERR_ARG;
+  if (dtype != NF_DTYPE_F32 && dtype != NF_DTYPE_F64) return NF_ERR_ARG;
+  NF_TRY(check_base(base));
+  NF_HIP(hipSetDevice(ctx->device));
+  if (!base || base->kind == NF_BASE_STANDARD)
+    return nf_launch_base_sample(ctx, dtype, d, N, seed, sample_offset, stream_id, x_out, logq_out);
+  NF_TRY(nf_launch_base_sample(ctx, dtype, d, N, seed, sample_offset, stream_id, x_out, nullptr));
+  NF_TRY(nf_launch_base_unwhiten(ctx, dtype, base->kind, d, N, base->mu, base->scale, x_out));
+  if (!logq_out) return NF_OK;
+  return nf_base_logpdf_general(ctx, dtype, base, d, N, x_out, logq_out);
+}
+
+extern "C" int nf_base_logpdf_general(nf_ctx *ctx, int32_t dtype, const nf_base *base, int32_t d, int64_t N, const void *x,
+                                      void *logq_out) {
+  if (!ctx || !x || !logq_out || d < 1 || N < 0) return NF_ERR_ARG;
+  if (dtype != NF_DTYPE_F32 && dtype != NF_DTYPE_F64) return NF_ERR_ARG;
+  NF_TRY(check_base(base));
+  NF_HIP(hipSetDevice(ctx->device));
+  if (!base || base->kind == NF_BASE_STANDARD) return nf_launch_base_logpdf(ctx, dtype, d, N, x, logq_out);
+  void *zbuf = nullptr;
+  if (base->kind == NF_BASE_DENSE) {
+    NF_TRY(nf_ws_reserve(ctx, carve_bytes((size_t)N * d * esize(dtype))));
+    zbuf = ctx->ws;
+  }
+  return nf_launch_base_general_logpdf(ctx, dtype, base->kind, d, N, base->mu, base->scale, base->logdet, x, logq_out, nullptr, zbuf);
+}
+
 // ---- training step -------------------------------------------------------------------------
 extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target,
                                       const void *theta, const void *xs, int64_t N_local, int64_t N_global,
@@ -805,6 +997,8 @@ extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, con
   if (!ctx || !target || !theta || !out || N_local < 0 || N_global < 1) return NF_ERR_ARG;
   NF_TRY(check_desc(desc));
   NF_HIP(hipSetDevice(ctx->device));
+  if (flow_base(desc))
+    return value_and_grad_general_base(ctx, desc, target, theta, xs, N_local, N_global, seed, sample_offset, stream_id, out);
   const long N = N_local;
   const long P = nf_param_count(desc);
   const int dt = desc->dtype;
@@ -1006,11 +1200,8 @@ size_t nf_affine_wimg_bytes(const nf_flow_desc *desc);
 size_t nf_rqs_wimg_bytes(const nf_flow_desc *desc);
 size_t nf_wide_wimg_bytes(nf_ctx *, const nf_flow_desc *desc);
 
-extern "C" int64_t nf_workspace_bytes(nf_ctx *ctx, const nf_flow_desc *desc, int64_t N) {
-  if (!ctx || N < 0) return NF_ERR_ARG;
-  const int st = check_desc(desc);
-  if (st != NF_OK) return st;
-  if (N == 0) N = 1;
+// intermediates only (what nf_ws_reserve is asked for), standard-normal base
+static size_t ws_need_bound(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
   const size_t es = esize(desc->dtype);
   const bool cp = is_coupling(desc);
   const long P = nf_param_count(desc);
@@ -1055,6 +1246,29 @@ extern "C" int64_t nf_workspace_bytes(nf_ctx *ctx, const nf_flow_desc *desc, int
     upd(3 * carve_bytes(xe * es) + 2 * cn + carve_bytes((size_t)nb_alloc * 8) + carve_bytes(64) + carve_bytes(slabf * es) +
         carve_bytes(simple_ws));
   }
+  return need;
+}
+
+// what the general-base wrappers keep behind the inner entry point's intermediates: x (N x d), the per-sample
+// correction, the substitution scratch of a dense base, block partials and a result slot
+static size_t base_extra_bytes(const nf_flow_desc *desc, long N) {
+  const nf_base *b = flow_base(desc);
+  if (!b) return 0;
+  const size_t es = esize(desc->dtype);
+  const size_t xb = carve_bytes((size_t)N * desc->d * es);
+  return xb + (b->kind == NF_BASE_DENSE ? xb : 0) + 2 * carve_bytes((size_t)N * es) +
+         carve_bytes((size_t)nf_sum2_nblocks(N) * 8) + carve_bytes(64);
+}
+
+extern "C" int64_t nf_workspace_bytes(nf_ctx *ctx, const nf_flow_desc *desc, int64_t N) {
+  if (!ctx || N < 0) return NF_ERR_ARG;
+  const int st = check_desc(desc);
+  if (st != NF_OK) return st;
+  if (N == 0) N = 1;
+  const size_t es = esize(desc->dtype);
+  const bool cp = is_coupling(desc);
+  const long P = nf_param_count(desc);
+  size_t need = ws_need_bound(ctx, desc, N) + base_extra_bytes(desc, N);
   // nf_adam_update / nf_sgd_update: gradient-norm partials at the tail of the intermediates arena
   need += carve_bytes((size_t)nf_adam_nblocks(P) * 8);
   // packed weight images, nf_elbo_step's [grad ; loss ; norm] buffer

@@ -53,6 +53,9 @@ struct nf_ctx {
   // intermediates arena `ws` is its front, packed weight images and the nf_elbo_step buffer are carved off its tail
   void *arena = nullptr;
   size_t arena_bytes = 0, arena_tail = 0;
+  // > 0 while a wrapper entry point has buffers of its own behind the first ws_guard bytes of `ws`: inner requests
+  // beyond the guard fail instead of overlapping them
+  size_t ws_guard = 0;
   // RCCL communicator of this context (nf_comm.hip); null for single-GPU use
   void *comm = nullptr;
   int comm_size = 1, comm_rank = 0;

@@ -88,6 +88,95 @@ __global__ __launch_bounds__(EW_BLOCK) void k_base_logpdf(int d, long N, const T
 }
 
 // ---------------------------------------------------------------------------------------
+// general MvNormal(mu, Sigma) base distributions
+// ---------------------------------------------------------------------------------------
+// _device_specific_rand(rng, ::MvNormal, n) draws x = mu + L eps with Sigma = L L' ("unwhiten", Distributions'
+// _rand!; the device version is ext/NormalizingFlowsCUDAExt.jl:43-48; a dense Sigma is what test/ext/CUDA/cuda.jl:33-45
+// exercises), and logpdf(flow.dist, xs) (src/objectives/elbo.jl:6,68) is
+//   -d/2 log 2pi - log|det L| - 1/2 ||L^-1 (x - mu)||^2.
+// kind 1: Sigma = Diagonal(sigma^2), scale = sigma[d];  kind 2: dense, scale = L, d x d lower triangular, column-major.
+// One thread per sample for the dense case (a d^2 / 2 triangular product / substitution per sample; d <= 256 here and
+// the base is a cold path next to the flow), in place: eps -> x.
+template <class T>
+__global__ __launch_bounds__(EW_BLOCK) void k_base_unwhiten(int kind, int d, long N, const T *__restrict__ mu,
+                                                            const T *__restrict__ scale, T *__restrict__ x) {
+  const long j = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
+  if (j >= N) return;
+  T *r = x + j * d;
+  if (kind == NF_BASE_DIAG) {
+    for (int i = 0; i < d; ++i) r[i] = mu[i] + scale[i] * r[i];
+  } else {
+    // x_i = mu_i + sum_{k <= i} L[i][k] eps_k: rows from the bottom up, so eps is still intact where it is read
+    for (int i = d - 1; i >= 0; --i) {
+      T acc = mu[i];
+      for (int k = 0; k <= i; ++k) acc += scale[(long)k * d + i] * r[k];
+      r[i] = acc;
+    }
+  }
+}
+
+// logq_out[j] (optional) = logpdf(base, x_j);  corr_out[j] (optional) = logpdf(MvNormal(0, I), x_j) - logpdf(base, x_j):
+// what must be ADDED to an ELBO term that was assembled with the standard-normal log q0.
+template <class T>
+__global__ __launch_bounds__(EW_BLOCK) void k_base_general_logpdf(int kind, int d, long N, const T *__restrict__ mu,
+                                                                  const T *__restrict__ scale, T logdet,
+                                                                  const T *__restrict__ x, T *__restrict__ logq_out,
+                                                                  T *__restrict__ corr_out, T *__restrict__ zbuf) {
+  const long j = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
+  if (j >= N) return;
+  const T *r = x + j * d;
+  T ss = 0, s0 = 0;
+  if (kind == NF_BASE_DIAG) {
+    for (int i = 0; i < d; ++i) {
+      const T z = (r[i] - mu[i]) / scale[i];
+      ss += z * z;
+      s0 += r[i] * r[i];
+    }
+  } else {
+    T *z = zbuf + j * d;  // forward substitution L z = x - mu
+    for (int i = 0; i < d; ++i) {
+      T acc = r[i] - mu[i];
+      for (int k = 0; k < i; ++k) acc -= scale[(long)k * d + i] * z[k];
+      const T zi = acc / scale[(long)i * d + i];
+      z[i] = zi;
+      ss += zi * zi;
+      s0 += r[i] * r[i];
+    }
+  }
+  const T c0 = (T)(-0.5 * 1.8378770664093453 * d);
+  const T lq = c0 - logdet - (T)0.5 * ss;
+  if (logq_out) logq_out[j] = lq;
+  if (corr_out) corr_out[j] = (c0 - (T)0.5 * s0) - lq;
+}
+
+int nf_launch_base_unwhiten(nf_ctx *ctx, int dtype, int kind, int d, long N, const void *mu, const void *scale, void *x) {
+  if (N <= 0) return NF_OK;
+  const unsigned grid = (unsigned)((N + EW_BLOCK - 1) / EW_BLOCK);
+  ProfScope ps(ctx, "base_unwhiten");
+  if (dtype == NF_DTYPE_F32)
+    hipLaunchKernelGGL(k_base_unwhiten<float>, dim3(grid), dim3(EW_BLOCK), 0, ctx->stream, kind, d, N, (const float *)mu,
+                       (const float *)scale, (float *)x);
+  else
+    hipLaunchKernelGGL(k_base_unwhiten<double>, dim3(grid), dim3(EW_BLOCK), 0, ctx->stream, kind, d, N, (const double *)mu,
+                       (const double *)scale, (double *)x);
+  return (int)hipGetLastError();
+}
+
+int nf_launch_base_general_logpdf(nf_ctx *ctx, int dtype, int kind, int d, long N, const void *mu, const void *scale,
+                                  double logdet, const void *x, void *logq_out, void *corr_out, void *zbuf) {
+  if (N <= 0) return NF_OK;
+  const unsigned grid = (unsigned)((N + EW_BLOCK - 1) / EW_BLOCK);
+  ProfScope ps(ctx, "base_logpdf");
+  if (dtype == NF_DTYPE_F32)
+    hipLaunchKernelGGL(k_base_general_logpdf<float>, dim3(grid), dim3(EW_BLOCK), 0, ctx->stream, kind, d, N, (const float *)mu,
+                       (const float *)scale, (float)logdet, (const float *)x, (float *)logq_out, (float *)corr_out, (float *)zbuf);
+  else
+    hipLaunchKernelGGL(k_base_general_logpdf<double>, dim3(grid), dim3(EW_BLOCK), 0, ctx->stream, kind, d, N, (const double *)mu,
+                       (const double *)scale, logdet, (const double *)x, (double *)logq_out, (double *)corr_out, (double *)zbuf);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
 // targets + ELBO assembly
 // ---------------------------------------------------------------------------------------
 // target_term<kind, T> and target_needs_d2: nf_targets.h (shared with the fused forward of nf_simple.hip)

@@ -24,7 +24,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import FlowDesc, NFHipError, Target, check, context_for
+from ._lib import Base, FlowDesc, NFHipError, Target, check, context_for
 
 
 def _dtype_code(dt: torch.dtype) -> int:
@@ -59,12 +59,44 @@ def _ptr(t: Optional[torch.Tensor]):
 # --------------------------------------------------------------------------------------
 # base distribution and RNG seam
 # --------------------------------------------------------------------------------------
-@dataclass(frozen=True)
 class MvNormal:
-    """MvNormal(zeros(T, d), I) -- the base distribution of every reference flow config
-    (test/flow.jl:9, example/demo_planar_flow.jl:24)."""
+    """Distributions.MvNormal as the reference uses it for q0.
 
-    d: int
+    MvNormal(d)            -> MvNormal(zeros(T, d), I): the base of every reference flow config (test/flow.jl:9,
+                              example/demo_planar_flow.jl:24); the form the fused kernels draw in registers.
+    MvNormal(mu, Sigma)    -> general base: Sigma a vector of VARIANCES (Diagonal(Sigma)) or a d x d covariance matrix
+                              (Cholesky-factored here, once, on the host side of the boundary).  Draws are mu + L eps
+                              (`unwhiten`, ext/NormalizingFlowsCUDAExt.jl:43-48; dense Sigma: test/ext/CUDA/cuda.jl:33-45).
+    q0 is a leaf of destructure (@leaf MvNormal): none of this is trainable."""
+
+    def __init__(self, mu_or_d, cov: Optional[torch.Tensor] = None):
+        if cov is None and not torch.is_tensor(mu_or_d):
+            self.d, self.mu, self.scale, self.c = int(mu_or_d), None, None, None
+            return
+        mu = mu_or_d
+        if cov is None:
+            raise NFHipError("MvNormal(mu, Sigma): give the covariance (a vector of variances or a matrix)")
+        if mu.dim() != 1 or cov.shape[0] != mu.numel() or cov.dtype != mu.dtype or cov.device != mu.device:
+            raise NFHipError("MvNormal(mu, Sigma): mu (d,), Sigma (d,) or (d, d), one element type and device")
+        self.d = mu.numel()
+        self.mu = mu.contiguous()
+        if cov.dim() == 1:
+            if not bool((cov > 0).all()):
+                raise NFHipError("MvNormal: variances must be positive")
+            self.scale = cov.sqrt().contiguous()
+            kind, logdet = _lib.NF_BASE_DIAG, float(self.scale.double().log().sum())
+        else:
+            L = torch.linalg.cholesky(cov)  # raises for a matrix that is not positive definite, as PDMats does
+            self.scale = L.t().contiguous()  # column-major lower triangle: element (i, k) at [k * d + i]
+            kind, logdet = _lib.NF_BASE_DENSE, float(torch.diagonal(L).double().log().sum())
+        self.c = Base(kind, self.mu.data_ptr(), self.scale.data_ptr(), logdet)
+
+    @property
+    def standard(self) -> bool:
+        return self.c is None
+
+    def base_ptr(self):
+        return None if self.c is None else C.byref(self.c)
 
     def __len__(self):
         return self.d
@@ -98,15 +130,14 @@ def device_specific_rand(rng: PhiloxRNG, dist, n: Optional[int] = None, *, devic
         check(ctx.lib.nf_flow_rand(ctx.ptr, C.byref(flow.desc), _ptr(flow.theta), nn, rng.seed, rng.sample_offset,
                                    rng.next_stream(), _ptr(y)))
         return y[:, 0] if n is None else y
+    if not dist.standard:
+        device, dtype = dist.mu.device, dist.mu.dtype
     device = torch.device(device if device is not None else "cuda")
     nn = 1 if n is None else int(n)
     x = new_batch(dist.d, nn, dtype, device)
     ctx = context_for(device)
-    check(
-        ctx.lib.nf_base_sample_logpdf(
-            ctx.ptr, _dtype_code(dtype), dist.d, nn, rng.seed, rng.sample_offset, rng.next_stream(), _ptr(x), _ptr(None)
-        )
-    )
+    check(ctx.lib.nf_base_rand(ctx.ptr, _dtype_code(dtype), dist.base_ptr(), dist.d, nn, rng.seed, rng.sample_offset,
+                               rng.next_stream(), _ptr(x), _ptr(None)))
     return x[:, 0] if n is None else x
 
 
@@ -147,6 +178,10 @@ class Flow:
         self.desc.K = self.K
         self.desc.B = self.B
         self.desc.score = C.addressof(score.c) if score is not None else None
+        if not dist.standard:
+            if dist.mu.dtype != dtype:
+                raise NFHipError(f"base distribution is {dist.mu.dtype}, flow parameters are {dtype}")
+            self.desc.base = C.addressof(dist.c)  # kept alive by self.dist
         self.P = int(_lib.load_library().nf_param_count(C.byref(self.desc)))
         if self.P < 0:
             check(self.P)
@@ -211,12 +246,16 @@ def transform(t: Transform, x: torch.Tensor):
 
 
 def base_logpdf(dist: MvNormal, xs: torch.Tensor):
-    """logpdf(MvNormal(zeros, I), xs) per column"""
+    """logpdf(q0, xs) per column (MvNormal(zeros, I) or a general MvNormal(mu, Sigma))"""
     xm, vec = as_batch(xs)
     d, n = xm.shape
+    if d != dist.d:
+        raise NFHipError(f"dimension mismatch: distribution has d={dist.d}, input has {d}")
+    if not dist.standard and dist.mu.dtype != xm.dtype:
+        raise NFHipError(f"base distribution is {dist.mu.dtype}, input is {xm.dtype}")
     out = torch.empty(n, dtype=xm.dtype, device=xm.device)
     ctx = context_for(xm.device)
-    check(ctx.lib.nf_base_logpdf(ctx.ptr, _dtype_code(xm.dtype), d, n, _ptr(xm), _ptr(out)))
+    check(ctx.lib.nf_base_logpdf_general(ctx.ptr, _dtype_code(xm.dtype), dist.base_ptr(), d, n, _ptr(xm), _ptr(out)))
     return out[0] if vec else out
 
 
@@ -225,8 +264,15 @@ def logpdf(flow, ys: torch.Tensor):
     src/objectives/loglikelihood.jl:23,31 and test/flow.jl:15)."""
     if isinstance(flow, MvNormal):
         return base_logpdf(flow, ys)
-    xs, ladj = with_logabsdet_jacobian(inverse(flow.transform), ys)
-    return base_logpdf(flow.dist, xs) + ladj
+    ym, vec = as_batch(ys.to(flow.theta.dtype))
+    d, n = ym.shape
+    if d != flow.dist.d:
+        raise NFHipError(f"dimension mismatch: flow has d={flow.dist.d}, input has {d}")
+    out = torch.empty(n, dtype=ym.dtype, device=ym.device)
+    val = C.c_double(0.0)
+    ctx = flow.ctx
+    check(ctx.lib.nf_loglikelihood(ctx.ptr, C.byref(flow.desc), _ptr(flow.theta), _ptr(ym), n, _ptr(out), C.byref(val)))
+    return out[0] if vec else out
 
 
 def rand(flow, n: Optional[int] = None, rng: Optional[PhiloxRNG] = None):

@@ -986,6 +986,52 @@ def base_sample(d: int, n: int, seed: int, sample_offset: int = 0, stream: int =
 
 
 # --------------------------------------------------------------------------
+# General MvNormal(mu, Sigma) base distributions: _device_specific_rand(rng, ::MvNormal, n) draws mu + L eps
+# (Distributions' unwhiten; device version ext/NormalizingFlowsCUDAExt.jl:43-48, dense Sigma exercised by
+# test/ext/CUDA/cuda.jl:33-45) and logpdf(flow.dist, xs) enters the ELBO at src/objectives/elbo.jl:6,68.
+# base = None (standard normal) | ("diag", mu, sigma) | ("dense", mu, L) with Sigma = L L'.
+# --------------------------------------------------------------------------
+
+
+def base_unwhiten(base, eps):
+    if base is None:
+        return eps
+    kind, mu, sc = base
+    return mu[:, None] + (sc[:, None] * eps if kind == "diag" else sc @ eps)
+
+
+def base_logpdf(base, x):
+    """logpdf(MvNormal(mu, Sigma), x) per column (Distributions: -(d log 2pi + logdet Sigma)/2 - sqmahal/2)."""
+    if base is None:
+        return std_normal_logpdf(x)
+    kind, mu, sc = base
+    r = x - mu[:, None]
+    if kind == "diag":
+        z, logdet = r / sc[:, None], np.log(sc).sum()
+    else:
+        import scipy.linalg
+
+        z, logdet = scipy.linalg.solve_triangular(sc, r, lower=True), np.log(np.diag(sc)).sum()
+    return -0.5 * x.shape[0] * LOG2PI - logdet - 0.5 * (z * z).sum(axis=0)
+
+
+def batched_elbos_base(spec, theta, target, xs, base):
+    ys, ladj = flow_fwd(spec, theta, xs)
+    return target_logp(target, ys) - base_logpdf(base, xs) + ladj
+
+
+def neg_elbo_value_and_grad_base(spec, theta, target, xs, base):
+    """-elbo_batch with a general base: q0 is not trainable, so only the value's log q0 term differs."""
+    loss, grad = neg_elbo_value_and_grad(spec, theta, target, xs)
+    return loss + (base_logpdf(base, xs) - std_normal_logpdf(xs)).mean(), grad
+
+
+def loglikelihood_base(spec, theta, ys, base):
+    xs, ladj = flow_inv(spec, theta, ys)
+    return (base_logpdf(base, xs) + ladj).mean()
+
+
+# --------------------------------------------------------------------------
 # Hamiltonian flow (example/demo_hamiltonian_flow.jl:27-146): a mean-field Gaussian reference on the joint
 # z = [x; rho] followed by n blocks (momentum Shift o Scale) o LeapFrog(L steps, per-dimension step sizes
 # exp(log_eps), score of the target).  theta = [shift0(2D), scale0(2D), then per block: shift_rho(D),

@@ -901,6 +901,75 @@ def test_fused_simple_training_forward_draws_match_supplied_draws(nf, kind, d, d
     P.gradient(f"simple step {kind} d={d} {dtn}: grad", g_xs, gr, P.F64_GRAD if f64 else P.GRAD_RTOL)
 
 
+@pytest.mark.parametrize("bkind", ["diag", "dense"])
+@pytest.mark.parametrize("maker", ["realnvp_resident", "nsf_mfma", "planar", "realnvp_f64", "wide"])
+def test_general_mvnormal_base(nf, bkind, maker):
+    """q0 = MvNormal(mu, Sigma), diagonal and dense (src/NormalizingFlows.jl:109-115, ext/NormalizingFlowsCUDAExt.jl:43-48,
+    test/ext/CUDA/cuda.jl:33-45): draws are mu + L eps of the Philox eps, logpdf(q0, xs) is the multivariate normal's, and
+    rand(flow), elbo_batch (xs and rng forms), per-sample terms, the training step's (loss, grad) and loglikelihood all
+    agree with the oracle evaluated with the same base."""
+    mk = {
+        "realnvp_resident": ("realnvp", 6, 2, (32, 32), 0, 0.0, "float32"), "nsf_mfma": ("nsf", 5, 2, (32, 32), 10, 5.0, "float32"),
+        "planar": ("planar", 5, 6, (), 0, 0.0, "float32"), "realnvp_f64": ("realnvp", 5, 1, (16,), 0, 0.0, "float64"),
+        "wide": ("realnvp", 70, 1, (65, 33), 0, 0.0, "float32"),
+    }
+    kind, d, nl, hd, K, B, dtn = mk[maker]
+    dt = tdt(dtn)
+    f64 = dtn == "float64"
+    npdt = np.float64 if f64 else np.float32
+    rng = np.random.default_rng(d + len(bkind))
+    mu = rng.standard_normal(d).astype(npdt)
+    if bkind == "diag":
+        var = (rng.uniform(size=d) + 0.3).astype(npdt)
+        q0 = nf.MvNormal(torch.tensor(mu, device="cuda"), torch.tensor(var, device="cuda"))
+        obase = ("diag", mu.astype(np.float64), np.sqrt(var.astype(np.float64)))
+    else:
+        A = rng.standard_normal((d, d)) / np.sqrt(d)
+        Sigma = (A @ A.T + 0.5 * np.eye(d)).astype(npdt)
+        q0 = nf.MvNormal(torch.tensor(mu, device="cuda"), torch.tensor(Sigma, device="cuda"))
+        obase = ("dense", mu.astype(np.float64), np.linalg.cholesky(Sigma.astype(np.float64)))
+    spec = o.FlowSpec(kind, d, nl, hd, K, B)
+    th = o.init_params(spec, rng)
+    th = th * 0.3 if kind == "planar" else th + 0.05 * rng.standard_normal(th.shape)
+    th = th.astype(npdt).astype(np.float64)
+    flow = nf.Flow(kind, q0, nl, hd, K, B, dtype=dt, device="cuda", theta=torch.tensor(th, dtype=dt, device="cuda"))
+    tmu, tvar = rng.standard_normal(d).astype(npdt), (rng.uniform(size=d) + 0.5).astype(npdt)
+    tgt = nf.DiagGaussTarget(torch.tensor(tmu, device="cuda"), torch.tensor(tvar, device="cuda"))
+    otgt = ("diaggauss", tmu.astype(np.float64), tvar.astype(np.float64))
+    n, tag = 150, f"base {bkind} {maker}"
+    ew = (1e-10, 1e-11) if f64 else (2e-5, 2e-5)
+    # draws and density of q0 itself
+    xs = nf.device_specific_rand(nf.PhiloxRNG(13), q0, n)
+    assert xs.shape == (d, n) and xs.dtype == dt
+    x_ref = o.base_unwhiten(obase, o.base_sample(d, n, seed=13))
+    P.elementwise(f"{tag}: draws mu + L eps", xs, x_ref, *ew)
+    xs64 = xs.cpu().numpy().astype(np.float64)
+    P.elementwise(f"{tag}: logpdf(q0, xs)", nf.logpdf(q0, xs), o.base_logpdf(obase, xs64), *ew)
+    # rand(flow, n): base draws pushed through the transform
+    ys = nf.rand(flow, n, nf.PhiloxRNG(13))
+    y_ref, l_ref = o.flow_fwd(spec, th, xs64)
+    P.elementwise(f"{tag}: rand(flow)", ys, y_ref, *ew)
+    # objectives
+    el = nf.batched_elbos(flow, tgt, xs)
+    el_ref = o.batched_elbos_base(spec, th, otgt, xs64, obase)
+    P.elementwise(f"{tag}: elbo terms", el, el_ref, *ew)
+    lr = 1e-10 if f64 else P.LOSS_RTOL
+    P.scalar(f"{tag}: elbo_batch(xs)", nf.elbo_batch(flow, tgt, xs), el_ref.mean(), lr, lr)
+    P.scalar(f"{tag}: elbo_batch(rng)", nf.elbo_batch(nf.PhiloxRNG(13), flow, tgt, n), el_ref.mean(), lr, lr)
+    loss, g = nf.value_and_gradient(nf.elbo_batch, flow, tgt, n, rng=nf.PhiloxRNG(13))
+    lo, go = o.neg_elbo_value_and_grad_base(spec, th, otgt, xs64, obase)
+    P.scalar(f"{tag}: step loss (rng)", loss, lo, lr, lr)
+    P.gradient(f"{tag}: step grad (rng)", g, go, P.F64_GRAD if f64 else P.GRAD_RTOL)
+    loss2, g2 = nf.value_and_gradient(nf.elbo_batch, flow, tgt, xs)
+    P.scalar(f"{tag}: step loss (xs)", loss2, lo, lr, lr)
+    P.gradient(f"{tag}: step grad (xs)", g2, go, P.F64_GRAD if f64 else P.GRAD_RTOL)
+    ll = nf.loglikelihood(None, flow, ys)
+    P.scalar(f"{tag}: loglikelihood", ll, o.loglikelihood_base(spec, th, ys.cpu().numpy().astype(np.float64), obase), 10 * lr, 10 * lr)
+    P.elementwise(f"{tag}: logpdf(flow, ys)", nf.logpdf(flow, ys), o.base_logpdf(obase, xs64) - l_ref, 10 * ew[0], 10 * ew[1])
+    with pytest.raises(nf.NFHipError, match="not built"):
+        nf.loglikelihood_value_and_gradient(flow, ys)  # forward-KL training: standard-normal base only
+
+
 RAND_CASES = {
     "planar5": ("planar", 5, 4, (), 0, 0.0, "float32"), "radial64": ("radial", 64, 3, (), 0, 0.0, "float32"),
     "planar100_f64": ("planar", 100, 2, (), 0, 0.0, "float64"), "realnvp5": ("realnvp", 5, 2, (32, 32), 0, 0.0, "float32"),

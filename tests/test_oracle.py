@@ -345,3 +345,24 @@ def test_hamiltonian_theta_order_reference_map_first():
     z, ladj = o.hflow_fwd(D, n, L, th, ("diaggauss", np.zeros(D), np.ones(D)), x0)
     np.testing.assert_allclose(z, th[:4, None] + th[4:8, None] * x0, rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(ladj, np.log(th[4:8]).sum(), rtol=1e-12)
+
+
+def test_general_base_density_is_the_multivariate_normal():
+    """The oracle's general-base log-density against scipy's multivariate normal, and draws mu + L eps having the
+    stated mean / covariance (the statistical check of test/ext/CUDA/cuda.jl:33-45, on the oracle)."""
+    import scipy.stats
+
+    rng = np.random.default_rng(0)
+    d = 4
+    A = rng.standard_normal((d, d))
+    Sigma = A @ A.T + 0.5 * np.eye(d)
+    mu = rng.standard_normal(d)
+    L = np.linalg.cholesky(Sigma)
+    x = rng.standard_normal((d, 50)) * 2
+    np.testing.assert_allclose(o.base_logpdf(("dense", mu, L), x), scipy.stats.multivariate_normal(mu, Sigma).logpdf(x.T), rtol=1e-12)
+    sig = np.sqrt(np.diag(Sigma))
+    np.testing.assert_allclose(o.base_logpdf(("diag", mu, sig), x), scipy.stats.multivariate_normal(mu, np.diag(sig**2)).logpdf(x.T), rtol=1e-12)
+    np.testing.assert_allclose(o.base_logpdf(None, x), scipy.stats.multivariate_normal(np.zeros(d), np.eye(d)).logpdf(x.T), rtol=1e-12)
+    eps = o.base_sample(d, 200000, seed=3)
+    xs = o.base_unwhiten(("dense", mu, L), eps)
+    assert np.abs(xs.mean(axis=1) - mu).max() < 0.02 and np.abs(np.cov(xs) - Sigma).max() < 0.05
