@@ -33,6 +33,8 @@ struct NFDesc
     B::Float32
     score::Ptr{Cvoid}   # NF_KIND_HAMILTONIAN: pointer to the NFTarget behind LeapFrog's score, else C_NULL
     base::Ptr{Cvoid}    # pointer to an NFBase for a general MvNormal(mu, Sigma) q0, C_NULL = MvNormal(zeros, I)
+    nsegments::Int32    # NF_KIND_COMPOSITE: mixed bijector families, see segments_of
+    segments::Ptr{Cvoid}
 end
 struct NFBase            # nf_base: kind 1 = Diagonal(sigma^2) (scale = sigma), 2 = dense (scale = L, column-major)
     kind::Int32
@@ -115,21 +117,45 @@ function desc_of(flow::Bijectors.TransformedDistribution)
     L1 = first(Ls)
     nohid = ntuple(_ -> Int32(0), 4)
     if all(l -> l isa Bijectors.PlanarLayer, Ls)
-        return NFDesc(NF_KIND_PLANAR, dtype_code(T), d, Int32(length(Ls)), 0, nohid, 0, 0.0f0, C_NULL, C_NULL)
+        return NFDesc(NF_KIND_PLANAR, dtype_code(T), d, Int32(length(Ls)), 0, nohid, 0, 0.0f0, C_NULL, C_NULL, Int32(0), C_NULL)
     elseif all(l -> l isa Bijectors.RadialLayer, Ls)
-        return NFDesc(NF_KIND_RADIAL, dtype_code(T), d, Int32(length(Ls)), 0, nohid, 0, 0.0f0, C_NULL, C_NULL)
+        return NFDesc(NF_KIND_RADIAL, dtype_code(T), d, Int32(length(Ls)), 0, nohid, 0, 0.0f0, C_NULL, C_NULL, Int32(0), C_NULL)
     elseif length(Ls) == 2 && Ls[1] isa Bijectors.Shift && Ls[2] isa Bijectors.Scale
-        return NFDesc(NF_KIND_MEANFIELD, dtype_code(T), d, Int32(1), 0, nohid, 0, 0.0f0, C_NULL, C_NULL)
+        return NFDesc(NF_KIND_MEANFIELD, dtype_code(T), d, Int32(1), 0, nohid, 0, 0.0f0, C_NULL, C_NULL, Int32(0), C_NULL)
     elseif all(l -> l isa AffineCoupling, Ls)
         iseven(length(Ls)) || error("nfhip: realnvp flows are built from RealNVP_layer pairs (src/flows/realnvp.jl:132-145)")
         h = hidden_dims(L1.s)
-        return NFDesc(NF_KIND_REALNVP, dtype_code(T), d, Int32(length(Ls) ÷ 2), Int32(length(h)), pad4(h), 0, 0.0f0, C_NULL, C_NULL)
+        return NFDesc(NF_KIND_REALNVP, dtype_code(T), d, Int32(length(Ls) ÷ 2), Int32(length(h)), pad4(h), 0, 0.0f0, C_NULL, C_NULL, Int32(0), C_NULL)
     elseif all(l -> l isa NeuralSplineCoupling, Ls)
         iseven(length(Ls)) || error("nfhip: nsf flows are built from NSF_layer pairs (src/flows/neuralspline.jl:169-184)")
         h = hidden_dims(L1.nn)
-        return NFDesc(NF_KIND_NSF, dtype_code(T), d, Int32(length(Ls) ÷ 2), Int32(length(h)), pad4(h), Int32(L1.K), Float32(L1.B), C_NULL, C_NULL)
+        return NFDesc(NF_KIND_NSF, dtype_code(T), d, Int32(length(Ls) ÷ 2), Int32(length(h)), pad4(h), Int32(L1.K), Float32(L1.B), C_NULL, C_NULL, Int32(0), C_NULL)
     end
-    return error("nfhip: flow is not one of planarflow / radialflow / realnvp / nsf / Shift∘Scale; use the per-layer methods")
+    return composite_desc(Ls, T, d)   # mixed families: create_flow((L1, …, Ln), q0), src/flows/utils.jl:23-26
+end
+
+# Mixed bijector families: maximal runs of one family become the segments of an NF_KIND_COMPOSITE descriptor (flat
+# order, first = outermost).  The segment array must outlive the descriptor: SEGMENT_ROOTS keeps it (descriptors are
+# tiny and flows are few; a finaliser-free global is the simplest correct owner).
+const NF_KIND_COMPOSITE = Int32(6)
+const SEGMENT_ROOTS = Vector{NFDesc}[]
+family(l) = l isa Bijectors.PlanarLayer ? :planar : l isa Bijectors.RadialLayer ? :radial : l isa AffineCoupling ? :realnvp :
+            l isa NeuralSplineCoupling ? :nsf : error("nfhip: no device kernels for a $(typeof(l)) layer")
+function composite_desc(Ls, ::Type{T}, d::Int32) where {T}
+    segs = NFDesc[]
+    i = 1
+    while i <= length(Ls)
+        j = i
+        while j < length(Ls) && family(Ls[j + 1]) == family(Ls[i]); j += 1; end
+        run = Ls[i:j]
+        fake = Bijectors.transformed(Distributions.MvNormal(zeros(T, d), LinearAlgebra.I), reduce(∘, run))
+        push!(segs, desc_of(fake))          # a single-family run: one of the branches above
+        i = j + 1
+    end
+    push!(SEGMENT_ROOTS, segs)
+    nohid = ntuple(_ -> Int32(0), 4)
+    return NFDesc(NF_KIND_COMPOSITE, dtype_code(T), d, Int32(1), 0, nohid, 0, 0.0f0, C_NULL, C_NULL,
+                  Int32(length(segs)), Ptr{Cvoid}(pointer(segs)))
 end
 
 # theta: Optimisers.destructure(flow) as is, on the device (src/NormalizingFlows.jl:67)
@@ -237,7 +263,7 @@ function base_of(q0::Distributions.MvNormal, ::Type{T}) where {T}
 end
 
 with_base(d::NFDesc, base::Ptr{Cvoid}) =
-    NFDesc(d.kind, d.dtype, d.d, d.nlayers, d.n_hidden, d.hdims, d.K, d.B, d.score, base)
+    NFDesc(d.kind, d.dtype, d.d, d.nlayers, d.n_hidden, d.hdims, d.K, d.B, d.score, base, d.nsegments, d.segments)
 
 "nfhip(flow): the same flow with parameters on the device and a library-backed transform"
 function nfhip(flow::Bijectors.TransformedDistribution)

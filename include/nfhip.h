@@ -63,6 +63,14 @@ extern "C" {
                                  Scale), demo :135-137).  nf_param_count cannot detect a permuted theta: bind
                                  by name, see INTEGRATION.md "theta order of the Hamiltonian demo flow" */
 
+#define NF_KIND_COMPOSITE 6 /* create_flow((L1, ..., Ln), q0) with MIXED bijector families (src/flows/utils.jl:23-26:
+                               any list of bijectors composes).  `segments` lists the maximal runs of one family in FLAT
+                               order (segment 0 = outermost = applied last), each a descriptor of one of the kinds above
+                               with the same d / dtype; theta = the segments' thetas concatenated in that order, which is
+                               the order Optimisers.destructure walks the composition.  Forward, inverse, per-layer
+                               application, rand, elbo / elbo_batch, the training step and loglikelihood are built
+                               (the reverse pass chains the segments' own reverse passes); forward-KL training is not. */
+
 #define NF_DTYPE_F32 0
 #define NF_DTYPE_F64 1
 
@@ -95,6 +103,7 @@ typedef struct nf_base {
  * layer structs that Optimisers.destructure leaves out (dim, mask, K, B, hidden
  * sizes; src/flows/realnvp.jl:33-38, src/flows/neuralspline.jl:35-42). */
 struct nf_target;
+struct nf_base;
 typedef struct nf_flow_desc {
   int32_t kind;                 /* NF_KIND_*                                         */
   int32_t dtype;                /* NF_DTYPE_*                                        */
@@ -108,6 +117,8 @@ typedef struct nf_flow_desc {
   const struct nf_target *score; /* NF_KIND_HAMILTONIAN: the target behind LeapFrog's
                                     score function (host pointer); NULL otherwise     */
   const struct nf_base *base;    /* q0 (host pointer); NULL = MvNormal(zeros(d), I)  */
+  int32_t nsegments;             /* NF_KIND_COMPOSITE: number of segments, else 0    */
+  const struct nf_flow_desc *segments; /* NF_KIND_COMPOSITE: host array [nsegments]  */
 } nf_flow_desc;
 
 /* Built-in target log-densities (the `logp` closure of src/objectives/elbo.jl:68

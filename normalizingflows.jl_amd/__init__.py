@@ -5,7 +5,7 @@ docs/src/api.md) over the C ABI of libnfhip.so (include/nfhip.h).  There is no C
 importing works anywhere, computing needs a gfx950 GPU and the built library.
 """
 from ._lib import LIB_PATH, SYMBOLS, Context, NFHipError, context_for, load_library
-from .flows import (BananaTarget, CrossTarget, DiagGaussTarget, FunnelTarget, WarpedGaussTarget, Flow, MvNormal, PhiloxRNG, Transform, as_batch, base_logpdf,
+from .flows import (BananaTarget, CompositeFlow, CrossTarget, DiagGaussTarget, FunnelTarget, WarpedGaussTarget, Flow, MvNormal, create_flow, PhiloxRNG, Transform, as_batch, base_logpdf,
                     device_specific_rand, hamiltonianflow, inverse, layer, logpdf, meanfield, new_batch, nsf, planarflow, radialflow,
                     rand, realnvp, target_logp, transform, with_logabsdet_jacobian)
 from .parallel import ShardedObjective, allreduce_grad_loss, make_gpu_forward_kl_local_step, make_gpu_local_step, shard_range
@@ -16,7 +16,7 @@ _device_specific_rand = device_specific_rand  # the reference's (underscored) ex
 
 __all__ = [
     "train_flow", "elbo", "elbo_batch", "loglikelihood", "loglikelihood_value_and_gradient", "optimize",
-    "planarflow", "radialflow", "realnvp", "nsf", "meanfield", "hamiltonianflow",
+    "planarflow", "radialflow", "realnvp", "nsf", "meanfield", "hamiltonianflow", "create_flow",
     "with_logabsdet_jacobian", "transform", "inverse", "logpdf", "rand", "layer",
     "MvNormal", "PhiloxRNG", "device_specific_rand", "_device_specific_rand",
     "DiagGaussTarget", "BananaTarget", "FunnelTarget", "WarpedGaussTarget", "CrossTarget", "Adam", "Descent", "Momentum", "value_and_gradient",

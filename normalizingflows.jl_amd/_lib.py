@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnfhip.so")
 
-NF_KIND = {"planar": 0, "radial": 1, "realnvp": 2, "nsf": 3, "meanfield": 4, "hamiltonian": 5}
+NF_KIND = {"planar": 0, "radial": 1, "realnvp": 2, "nsf": 3, "meanfield": 4, "hamiltonian": 5, "composite": 6}
 NF_DTYPE_F32, NF_DTYPE_F64 = 0, 1
 NF_TARGET_DIAGGAUSS, NF_TARGET_BANANA, NF_TARGET_FUNNEL, NF_TARGET_WARPED, NF_TARGET_CROSS = 0, 1, 2, 3, 4
 NF_MAX_HIDDEN = 4
@@ -35,6 +35,8 @@ class FlowDesc(C.Structure):
         ("B", C.c_float),
         ("score", C.c_void_p),  # const nf_target * (Hamiltonian flows), else NULL
         ("base", C.c_void_p),  # const nf_base * (general MvNormal(mu, Sigma) base), NULL = MvNormal(zeros, I)
+        ("nsegments", C.c_int32),  # NF_KIND_COMPOSITE
+        ("segments", C.c_void_p),  # const nf_flow_desc * [nsegments]
     ]
 
 

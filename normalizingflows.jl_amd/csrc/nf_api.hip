@@ -139,10 +139,26 @@ static int check_base(const nf_base *b) {
   return (b->mu && b->scale) ? NF_OK : NF_ERR_ARG;
 }
 
+static inline bool is_composite(const nf_flow_desc *d) { return d->kind == NF_KIND_COMPOSITE; }
+static int check_desc(const nf_flow_desc *d);
+static int check_composite(const nf_flow_desc *d) {
+  if (d->nsegments < 1 || d->nsegments > 64 || !d->segments) return NF_ERR_ARG;
+  for (int s = 0; s < d->nsegments; ++s) {
+    const nf_flow_desc *g = &d->segments[s];
+    if (g->kind == NF_KIND_COMPOSITE || g->kind == NF_KIND_HAMILTONIAN) return NF_ERR_ARG;
+    if (g->d != d->d || g->dtype != d->dtype || g->base) return NF_ERR_ARG;  // q0 belongs to the composition
+    NF_TRY(check_desc(g));
+  }
+  return NF_OK;
+}
+
 static int check_desc(const nf_flow_desc *d) {
   if (!d) return NF_ERR_ARG;
-  if (d->d < 1 || d->nlayers < 1) return NF_ERR_ARG;
+  if (d->d < 1) return NF_ERR_ARG;
+  if (d->dtype != NF_DTYPE_F32 && d->dtype != NF_DTYPE_F64) return NF_ERR_ARG;
   NF_TRY(check_base(d->base));
+  if (d->kind == NF_KIND_COMPOSITE) return check_composite(d);
+  if (d->nlayers < 1) return NF_ERR_ARG;
   if (d->dtype != NF_DTYPE_F32 && d->dtype != NF_DTYPE_F64) return NF_ERR_ARG;
   switch (d->kind) {
     case NF_KIND_PLANAR:
@@ -196,6 +212,17 @@ CouplingInfo nf_coupling_info(const nf_flow_desc *desc, int k) {
 
 extern "C" int64_t nf_param_count(const nf_flow_desc *d) {
   if (!d) return NF_ERR_ARG;
+  if (d->kind == NF_KIND_COMPOSITE) {
+    if (d->nsegments < 1 || !d->segments) return NF_ERR_ARG;
+    int64_t tot = 0;
+    for (int s = 0; s < d->nsegments; ++s) {
+      if (d->segments[s].kind == NF_KIND_COMPOSITE) return NF_ERR_ARG;
+      const int64_t p = nf_param_count(&d->segments[s]);
+      if (p < 0) return p;
+      tot += p;
+    }
+    return tot;
+  }
   switch (d->kind) {
     case NF_KIND_PLANAR: return (int64_t)d->nlayers * (2 * d->d + 1);
     case NF_KIND_RADIAL: return (int64_t)d->nlayers * (d->d + 2);
@@ -212,6 +239,17 @@ extern "C" int64_t nf_param_count(const nf_flow_desc *d) {
 
 extern "C" int32_t nf_layer_count(const nf_flow_desc *d) {
   if (!d) return NF_ERR_ARG;
+  if (d->kind == NF_KIND_COMPOSITE) {
+    if (d->nsegments < 1 || !d->segments) return NF_ERR_ARG;
+    int32_t tot = 0;
+    for (int s = 0; s < d->nsegments; ++s) {
+      if (d->segments[s].kind == NF_KIND_COMPOSITE) return NF_ERR_ARG;
+      const int32_t c = nf_layer_count(&d->segments[s]);
+      if (c < 0) return c;
+      tot += c;
+    }
+    return tot;
+  }
   switch (d->kind) {
     case NF_KIND_PLANAR:
     case NF_KIND_RADIAL: return d->nlayers;
@@ -393,7 +431,6 @@ static int base_bufs(nf_ctx *ctx, const nf_flow_desc *desc, const nf_flow_desc *
   const nf_base *b = flow_base(desc);
   const size_t es = esize(desc->dtype);
   const size_t in_need = ws_need_bound(ctx, inner, N);
-  ctx->ws_guard = 0;
   NF_TRY(nf_ws_reserve(ctx, in_need + base_extra_bytes(desc, N)));
   Carver cv((char *)ctx->ws + in_need);
   bb->x = cv.take<char>((size_t)N * desc->d * es);
@@ -406,9 +443,10 @@ static int base_bufs(nf_ctx *ctx, const nf_flow_desc *desc, const nf_flow_desc *
   ctx->ws_guard = in_need;  // the inner entry point must stay in front of these buffers
   return NF_OK;
 }
-struct GuardReset {  // clears the guard on every exit path
+struct GuardReset {  // puts the enclosing wrapper's guard (or none) back on every exit path
   nf_ctx *ctx;
-  ~GuardReset() { ctx->ws_guard = 0; }
+  size_t prev;
+  ~GuardReset() { ctx->ws_guard = prev; }
 };
 
 static int base_draw(nf_ctx *ctx, const nf_flow_desc *desc, long N, uint64_t seed, uint64_t off, uint32_t stream_id, void *x,
@@ -419,11 +457,24 @@ static int base_draw(nf_ctx *ctx, const nf_flow_desc *desc, long N, uint64_t see
 }
 
 
+struct CompBufs {
+  char *xin[64];  // input of segment s
+  char *y, *gbar, *logq, *ladj, *tmp, *lbar, *spare;
+  double *partial_t, *partial_s, *result;
+};
+static int composite_bufs(nf_ctx *ctx, const nf_flow_desc *desc, long N, CompBufs *cb);
+static int composite_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, const void *theta, const void *x_in, long N,
+                           void *y_out, void *ladj, CompBufs &cb, char **stash_inputs);
 static int elbo_forward_general_base(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, const void *theta,
                                      const void *xs, long N, uint64_t seed, uint64_t off, uint32_t stream_id,
                                      void *elbos_out, double *elbo_host);
 static int loglikelihood_general_base(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *ys, long N,
                                       void *logliks_out, double *ll_host);
+static int loglikelihood_composite(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *ys, long N,
+                                   void *logliks_out, double *ll_host);
+static int value_and_grad_composite(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, const void *theta,
+                                    const void *xs, int64_t N_local, int64_t N_global, uint64_t seed, uint64_t sample_offset,
+                                    uint32_t stream_id, void *out);
 static int value_and_grad_general_base(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, const void *theta,
                                        const void *xs, int64_t N_local, int64_t N_global, uint64_t seed, uint64_t sample_offset,
                                        uint32_t stream_id, void *out);
@@ -537,10 +588,14 @@ static int coupling_chain_tiled(nf_ctx *ctx, const nf_flow_desc *desc, bool inve
   return nf_affine_chain(ctx, desc, inverse, xt, N, ladj);
 }
 
+static int composite_apply(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, int layer, const void *theta,
+                           const void *x_in, long N, void *y_out, void *ladj);
+
 // standard-layout in/out wrapper used by nf_flow_fwd / nf_flow_inv / nf_layer_apply
 static int apply_std(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, int layer, const void *theta,
                      const void *x_in, long N, void *y_out, void *ladj) {
   if (N == 0) return NF_OK;
+  if (is_composite(desc)) return composite_apply(ctx, desc, inverse, layer, theta, x_in, N, y_out, ladj);
   if (is_coupling(desc)) {
     NF_TRY(nf_ws_reserve(ctx, carve_bytes(tiled_elems(desc, N) * 4)));
     float *xt = (float *)ctx->ws;
@@ -581,10 +636,19 @@ extern "C" int nf_flow_rand(nf_ctx *ctx, const nf_flow_desc *desc, const void *t
     nf_flow_desc inner = *desc;
     inner.base = nullptr;
     BaseBufs bb;
+    const size_t prev_guard = ctx->ws_guard;
     NF_TRY(base_bufs(ctx, desc, &inner, N, &bb));
-    GuardReset gr{ctx};
+    GuardReset gr{ctx, prev_guard};
     NF_TRY(base_draw(ctx, desc, N, seed, sample_offset, stream_id, y_out, nullptr));
     return apply_std(ctx, &inner, false, -1, theta, y_out, N, y_out, bb.tmp);
+  }
+  if (is_composite(desc)) {  // draws into y_out, then the chain in place
+    CompBufs cb;
+    const size_t prev_guard = ctx->ws_guard;
+    NF_TRY(composite_bufs(ctx, desc, N, &cb));
+    GuardReset gr{ctx, prev_guard};
+    NF_TRY(nf_launch_base_sample(ctx, desc->dtype, desc->d, N, seed, sample_offset, stream_id, y_out, nullptr));
+    return composite_chain(ctx, desc, false, theta, y_out, N, y_out, cb.ladj, cb, nullptr);
   }
   if (is_coupling(desc)) {
     NF_TRY(nf_ws_reserve(ctx, carve_bytes(tiled_elems(desc, N) * 4) + carve_bytes((size_t)N * 4)));
@@ -666,6 +730,7 @@ extern "C" int nf_flow_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const void *th
   NF_HIP(hipSetDevice(ctx->device));
   const long P = nf_param_count(desc);
   if (N == 0) return nf_launch_fill(ctx, desc->dtype, gtheta_out, P, 0.0);
+  if (is_composite(desc)) return NF_ERR_UNSUPPORTED;  // pull back segment by segment (each is a flow of its own)
   if (is_coupling(desc)) {
     const int grid = coupling_bwd_grid(ctx, desc, N);
     const size_t te = tiled_elems(desc, N);
@@ -696,9 +761,13 @@ extern "C" int nf_target_logp(nf_ctx *ctx, int32_t dtype, const nf_target *targe
 }
 
 // ---- objectives ----------------------------------------------------------------------------
+static int elbo_forward_composite(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, const void *theta,
+                                  const void *xs, long N, uint64_t seed, uint64_t off, uint32_t stream_id, void *elbos_out,
+                                  double *elbo_host);
 static int elbo_forward(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, const void *theta,
                         const void *xs, long N, uint64_t seed, uint64_t off, uint32_t stream_id, void *elbos_out,
                         double *elbo_host) {
+  if (is_composite(desc)) return elbo_forward_composite(ctx, desc, target, theta, xs, N, seed, off, stream_id, elbos_out, elbo_host);
   const size_t es = esize(desc->dtype);
   const bool cp = is_coupling(desc);
   const long nb = cp ? nf_target_tiled_nblocks(N) : nf_target_nblocks(N);
@@ -778,6 +847,7 @@ extern "C" int nf_loglikelihood(nf_ctx *ctx, const nf_flow_desc *desc, const voi
   NF_TRY(check_desc(desc));
   NF_HIP(hipSetDevice(ctx->device));
   if (flow_base(desc)) return loglikelihood_general_base(ctx, desc, theta, ys, N, logliks_out, ll_host);
+  if (is_composite(desc)) return loglikelihood_composite(ctx, desc, theta, ys, N, logliks_out, ll_host);
   const size_t es = esize(desc->dtype);
   const bool cp = is_coupling(desc);
   const long nb = nf_sum2_nblocks(N);
@@ -815,6 +885,7 @@ extern "C" int nf_loglikelihood_value_and_grad(nf_ctx *ctx, const nf_flow_desc *
   NF_TRY(check_desc(desc));
   NF_HIP(hipSetDevice(ctx->device));
   if (flow_base(desc)) return NF_ERR_UNSUPPORTED;  // forward-KL training is built for the standard-normal base only
+  if (is_composite(desc)) return NF_ERR_UNSUPPORTED;  // ... and for single-family flows
   const long N = N_local;
   const long P = nf_param_count(desc);
   const int dt = desc->dtype;
@@ -876,6 +947,165 @@ extern "C" int nf_loglikelihood_value_and_grad(nf_ctx *ctx, const nf_flow_desc *
 }
 
 
+// ---- heterogeneous compositions: create_flow((L1, ..., Ln), q0) with mixed families ---------------------
+// (src/flows/utils.jl:23-26.)  A composite is a list of homogeneous segments in flat order; every operation chains
+// the segments' own kernels through standard-layout buffers that live behind the segments' intermediates (ws_guard).
+static size_t composite_inner_need(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
+  size_t m = 0;
+  for (int s = 0; s < desc->nsegments; ++s) {
+    const size_t v = ws_need_bound(ctx, &desc->segments[s], N);
+    if (v > m) m = v;
+  }
+  return m;
+}
+static size_t composite_extra_bytes(const nf_flow_desc *desc, long N) {
+  const size_t es = esize(desc->dtype);
+  return (size_t)(desc->nsegments + 2) * carve_bytes((size_t)N * desc->d * es) + 5 * carve_bytes((size_t)N * es) +
+         carve_bytes((size_t)nf_target_nblocks(N) * 8) + carve_bytes((size_t)nf_sum2_nblocks(N) * 8) + carve_bytes(64);
+}
+static long seg_theta_off(const nf_flow_desc *desc, int s) {
+  long off = 0;
+  for (int t = 0; t < s; ++t) off += nf_param_count(&desc->segments[t]);
+  return off;
+}
+static int composite_bufs(nf_ctx *ctx, const nf_flow_desc *desc, long N, CompBufs *cb) {
+  const size_t es = esize(desc->dtype);
+  const size_t in_need = composite_inner_need(ctx, desc, N);
+  NF_TRY(nf_ws_reserve(ctx, in_need + composite_extra_bytes(desc, N)));
+  Carver cv((char *)ctx->ws + in_need);
+  for (int s = 0; s < desc->nsegments; ++s) cb->xin[s] = cv.take<char>((size_t)N * desc->d * es);
+  cb->y = cv.take<char>((size_t)N * desc->d * es);
+  cb->gbar = cv.take<char>((size_t)N * desc->d * es);
+  cb->logq = cv.take<char>((size_t)N * es);
+  cb->ladj = cv.take<char>((size_t)N * es);
+  cb->tmp = cv.take<char>((size_t)N * es);
+  cb->lbar = cv.take<char>((size_t)N * es);
+  cb->spare = cv.take<char>((size_t)N * es);
+  cb->partial_t = cv.take<double>(nf_target_nblocks(N));
+  cb->partial_s = cv.take<double>(nf_sum2_nblocks(N));
+  cb->result = cv.take<double>(8);
+  ctx->ws_guard = in_need;
+  return NF_OK;
+}
+
+// forward: the LAST segment is applied first; inverse: the first.  layer >= 0: one bijector, flat index over the segments.
+// ladj is overwritten.  x_in may alias y_out.
+static int composite_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, const void *theta, const void *x_in, long N,
+                           void *y_out, void *ladj, CompBufs &cb, char **stash_inputs) {
+  const size_t es = esize(desc->dtype);
+  const int ns = desc->nsegments;
+  const void *cur = x_in;
+  for (int i = 0; i < ns; ++i) {
+    const int sidx = inverse ? i : ns - 1 - i;
+    const nf_flow_desc *g = &desc->segments[sidx];
+    const char *th = (const char *)theta + (size_t)seg_theta_off(desc, sidx) * es;
+    void *dst = y_out;
+    if (stash_inputs) {  // forward with the segment inputs kept: input of segment s in xin[s], output into the next input
+      if (cur != stash_inputs[sidx])
+        NF_HIP(hipMemcpyAsync(stash_inputs[sidx], cur, (size_t)N * desc->d * es, hipMemcpyDeviceToDevice, ctx->stream));
+      cur = stash_inputs[sidx];
+      dst = i + 1 < ns ? (void *)stash_inputs[inverse ? sidx + 1 : sidx - 1] : y_out;
+    }
+    NF_TRY(apply_std(ctx, g, inverse, -1, th, cur, N, dst, i == 0 ? ladj : (void *)cb.tmp));
+    if (i > 0) NF_TRY(nf_launch_sum2(ctx, desc->dtype, N, ladj, cb.tmp, ladj, cb.partial_s, 0.0));
+    cur = dst;
+  }
+  return NF_OK;
+}
+
+static int composite_apply(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, int layer, const void *theta,
+                           const void *x_in, long N, void *y_out, void *ladj) {
+  const size_t es = esize(desc->dtype);
+  if (layer >= 0) {  // a single bijector: find its segment
+    int base_l = 0;
+    for (int s = 0; s < desc->nsegments; ++s) {
+      const int c = nf_layer_count(&desc->segments[s]);
+      if (layer < base_l + c)
+        return apply_std(ctx, &desc->segments[s], inverse, layer - base_l, (const char *)theta + (size_t)seg_theta_off(desc, s) * es,
+                         x_in, N, y_out, ladj);
+      base_l += c;
+    }
+    return NF_ERR_ARG;
+  }
+  CompBufs cb;
+  const size_t prev_guard = ctx->ws_guard;
+  NF_TRY(composite_bufs(ctx, desc, N, &cb));
+  GuardReset gr{ctx, prev_guard};
+  return composite_chain(ctx, desc, inverse, theta, x_in, N, y_out, ladj, cb, nullptr);
+}
+
+static int elbo_forward_composite(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, const void *theta,
+                                  const void *xs, long N, uint64_t seed, uint64_t off, uint32_t stream_id, void *elbos_out,
+                                  double *elbo_host) {
+  const size_t es = esize(desc->dtype);
+  CompBufs cb;
+  const size_t prev_guard = ctx->ws_guard;
+  NF_TRY(composite_bufs(ctx, desc, N, &cb));
+  GuardReset gr{ctx, prev_guard};
+  if (xs) {
+    NF_HIP(hipMemcpyAsync(cb.y, xs, (size_t)N * desc->d * es, hipMemcpyDeviceToDevice, ctx->stream));
+    NF_TRY(nf_launch_base_logpdf(ctx, desc->dtype, desc->d, N, cb.y, cb.logq));
+  } else {
+    NF_TRY(nf_launch_base_sample(ctx, desc->dtype, desc->d, N, seed, off, stream_id, cb.y, cb.logq));
+  }
+  NF_TRY(composite_chain(ctx, desc, false, theta, cb.y, N, cb.y, cb.ladj, cb, nullptr));
+  NF_TRY(nf_launch_target(ctx, desc->dtype, target, desc->d, N, cb.y, cb.logq, cb.ladj, nullptr, nullptr, 0.0, elbos_out,
+                          cb.partial_t, 1.0 / (double)N, 0));
+  NF_TRY(nf_launch_finish_sum(ctx, cb.partial_t, nf_target_nblocks(N), 0, cb.result, nullptr, nullptr));
+  return read_scalar(ctx, cb.result, elbo_host);
+}
+
+static int value_and_grad_composite(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, const void *theta,
+                                    const void *xs, int64_t N_local, int64_t N_global, uint64_t seed, uint64_t sample_offset,
+                                    uint32_t stream_id, void *out) {
+  const long N = N_local;
+  const long P = nf_param_count(desc);
+  const int dt = desc->dtype;
+  const size_t es = esize(dt);
+  if (N == 0) return nf_launch_fill(ctx, dt, out, P + 1, 0.0);
+  const double inv = 1.0 / (double)N_global;
+  const int ns = desc->nsegments;
+  CompBufs cb;
+  const size_t prev_guard = ctx->ws_guard;
+  NF_TRY(composite_bufs(ctx, desc, N, &cb));
+  GuardReset gr{ctx, prev_guard};
+  char *x0 = cb.xin[ns - 1];  // the input of the first-applied segment is the base draw
+  if (xs) {
+    NF_HIP(hipMemcpyAsync(x0, xs, (size_t)N * desc->d * es, hipMemcpyDeviceToDevice, ctx->stream));
+    NF_TRY(nf_launch_base_logpdf(ctx, dt, desc->d, N, x0, cb.logq));
+  } else {
+    NF_TRY(nf_launch_base_sample(ctx, dt, desc->d, N, seed, sample_offset, stream_id, x0, cb.logq));
+  }
+  NF_TRY(composite_chain(ctx, desc, false, theta, x0, N, cb.y, cb.ladj, cb, cb.xin));
+  // gbar = d(-elbo/Ng)/dy, loss partials; then the segments' reverse passes, last applied first
+  NF_TRY(nf_launch_target(ctx, dt, target, desc->d, N, cb.y, cb.logq, cb.ladj, nullptr, cb.gbar, -inv, nullptr, cb.partial_t,
+                          -inv, 0));
+  if (dt == NF_DTYPE_F32) NF_TRY(nf_launch_finish_sum(ctx, cb.partial_t, nf_target_nblocks(N), 0, nullptr, (float *)out + P, nullptr));
+  else NF_TRY(nf_launch_finish_sum(ctx, cb.partial_t, nf_target_nblocks(N), 0, (double *)out + P, nullptr, nullptr));
+  NF_TRY(nf_launch_fill(ctx, dt, cb.lbar, N, -inv));
+  for (int s = 0; s < ns; ++s) {
+    const nf_flow_desc *g = &desc->segments[s];
+    const long off = seg_theta_off(desc, s);
+    const void *yseg = s == 0 ? (const void *)cb.y : (const void *)cb.xin[s - 1];
+    NF_TRY(nf_flow_bwd(ctx, g, (const char *)theta + (size_t)off * es, cb.xin[s], yseg, cb.gbar, cb.lbar, N, cb.gbar,
+                       (char *)out + (size_t)off * es));
+  }
+  return NF_OK;
+}
+
+static int loglikelihood_composite(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *ys, long N,
+                                   void *logliks_out, double *ll_host) {
+  CompBufs cb;
+  const size_t prev_guard = ctx->ws_guard;
+  NF_TRY(composite_bufs(ctx, desc, N, &cb));
+  GuardReset gr{ctx, prev_guard};
+  NF_TRY(composite_chain(ctx, desc, true, theta, ys, N, cb.y, cb.ladj, cb, nullptr));
+  NF_TRY(nf_launch_base_logpdf(ctx, desc->dtype, desc->d, N, cb.y, cb.logq));
+  NF_TRY(nf_launch_sum2(ctx, desc->dtype, N, cb.logq, cb.ladj, logliks_out, cb.partial_s, 1.0 / (double)N));
+  NF_TRY(nf_launch_finish_sum(ctx, cb.partial_s, nf_sum2_nblocks(N), 0, cb.result, nullptr, nullptr));
+  return read_scalar(ctx, cb.result, ll_host);
+}
+
 // ---- general MvNormal(mu, Sigma) bases -----------------------------------------------------------
 // q0 carries no trainable parameter (@leaf MvNormal), so a general base only changes (i) where the draws come from,
 // x = mu + L eps, and (ii) log q0(x).  The wrappers below produce x in a buffer of their own, run the standard-normal
@@ -894,8 +1124,9 @@ static int elbo_forward_general_base(nf_ctx *ctx, const nf_flow_desc *desc, cons
   nf_flow_desc inner = *desc;
   inner.base = nullptr;
   BaseBufs bb;
+  const size_t prev_guard = ctx->ws_guard;
   NF_TRY(base_bufs(ctx, desc, &inner, N, &bb));
-  GuardReset gr{ctx};
+  GuardReset gr{ctx, prev_guard};
   const void *x = xs;
   if (!xs) {
     NF_TRY(base_draw(ctx, desc, N, seed, off, stream_id, bb.x, nullptr));
@@ -927,8 +1158,9 @@ static int value_and_grad_general_base(nf_ctx *ctx, const nf_flow_desc *desc, co
   nf_flow_desc inner = *desc;
   inner.base = nullptr;
   BaseBufs bb;
+  const size_t prev_guard = ctx->ws_guard;
   NF_TRY(base_bufs(ctx, desc, &inner, N, &bb));
-  GuardReset gr{ctx};
+  GuardReset gr{ctx, prev_guard};
   const void *x = xs;
   if (!xs) {
     NF_TRY(base_draw(ctx, desc, N, seed, sample_offset, stream_id, bb.x, nullptr));
@@ -951,8 +1183,9 @@ static int loglikelihood_general_base(nf_ctx *ctx, const nf_flow_desc *desc, con
   nf_flow_desc inner = *desc;
   inner.base = nullptr;
   BaseBufs bb;
+  const size_t prev_guard = ctx->ws_guard;
   NF_TRY(base_bufs(ctx, desc, &inner, N, &bb));
-  GuardReset gr{ctx};
+  GuardReset gr{ctx, prev_guard};
   // z = T^-1 y and ladj_inv with the public inverse, then log q0(z) with the general density
   NF_TRY(nf_flow_inv(ctx, &inner, theta, ys, N, bb.x, bb.tmp));
   NF_TRY(nf_launch_base_general_logpdf(ctx, desc->dtype, b->kind, desc->d, N, b->mu, b->scale, b->logdet, bb.x, bb.corr, nullptr, bb.z));
@@ -999,6 +1232,8 @@ extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, con
   NF_HIP(hipSetDevice(ctx->device));
   if (flow_base(desc))
     return value_and_grad_general_base(ctx, desc, target, theta, xs, N_local, N_global, seed, sample_offset, stream_id, out);
+  if (is_composite(desc))
+    return value_and_grad_composite(ctx, desc, target, theta, xs, N_local, N_global, seed, sample_offset, stream_id, out);
   const long N = N_local;
   const long P = nf_param_count(desc);
   const int dt = desc->dtype;
@@ -1201,7 +1436,10 @@ size_t nf_rqs_wimg_bytes(const nf_flow_desc *desc);
 size_t nf_wide_wimg_bytes(nf_ctx *, const nf_flow_desc *desc);
 
 // intermediates only (what nf_ws_reserve is asked for), standard-normal base
+static size_t composite_inner_need(nf_ctx *ctx, const nf_flow_desc *desc, long N);
+static size_t composite_extra_bytes(const nf_flow_desc *desc, long N);
 static size_t ws_need_bound(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
+  if (is_composite(desc)) return composite_inner_need(ctx, desc, N) + composite_extra_bytes(desc, N);
   const size_t es = esize(desc->dtype);
   const bool cp = is_coupling(desc);
   const long P = nf_param_count(desc);
@@ -1273,7 +1511,17 @@ extern "C" int64_t nf_workspace_bytes(nf_ctx *ctx, const nf_flow_desc *desc, int
   need += carve_bytes((size_t)nf_adam_nblocks(P) * 8);
   // packed weight images, nf_elbo_step's [grad ; loss ; norm] buffer
   size_t wimg = 0;
-  if (cp) wimg = is_wide(desc) ? nf_wide_wimg_bytes(ctx, desc) : is_nsf(desc) ? nf_rqs_wimg_bytes(desc) : nf_affine_wimg_bytes(desc);
+  auto wimg_of = [&](const nf_flow_desc *g) -> size_t {
+    if (!is_coupling(g)) return 0;
+    return is_wide(g) ? nf_wide_wimg_bytes(ctx, g) : is_nsf(g) ? nf_rqs_wimg_bytes(g) : nf_affine_wimg_bytes(g);
+  };
+  if (is_composite(desc)) {
+    for (int sgi = 0; sgi < desc->nsegments; ++sgi) {
+      wimg += carve_bytes(wimg_of(&desc->segments[sgi]));  // grow-only tail carves: a later, larger segment carves again
+    }
+  } else if (cp) {
+    wimg = wimg_of(desc);
+  }
   need += carve_bytes(wimg) + carve_bytes((size_t)(P + 2) * es) + 4096;
   return (int64_t)need;
 }

@@ -207,6 +207,59 @@ class Flow:
         return context_for(self.theta.device)
 
 
+class CompositeFlow(Flow):
+    """create_flow((L1, ..., Ln), q0) with bijectors of different families (src/flows/utils.jl:23-26: any list of
+    bijectors composes).  `segments` are single-family flows in flat order (the first is the outermost = applied
+    last); theta is their thetas concatenated -- the order Optimisers.destructure walks the composition."""
+
+    def __init__(self, segments: Sequence[Flow], dist: MvNormal, theta: Optional[torch.Tensor] = None):
+        if not segments:
+            raise NFHipError("create_flow: empty layer list")
+        dt, dev = segments[0].theta.dtype, segments[0].theta.device
+        for f in segments:
+            if isinstance(f, CompositeFlow) or f.kind == "hamiltonian":
+                raise NFHipError("create_flow: segments must be single-family flows")
+            if f.dist.d != dist.d or f.theta.dtype != dt or f.theta.device != dev:
+                raise NFHipError("create_flow: every layer must share the dimension, element type and device")
+        self.kind, self.dist, self.nlayers = "composite", dist, 1
+        self.hdims, self.K, self.B, self.score = (), 0, 0.0, None
+        self.segments = list(segments)
+        self._seg_descs = (FlowDesc * len(segments))()
+        for i, f in enumerate(segments):
+            C.memmove(C.addressof(self._seg_descs[i]), C.addressof(f.desc), C.sizeof(FlowDesc))
+            self._seg_descs[i].base = None  # q0 belongs to the composition
+        self.desc = FlowDesc()
+        self.desc.kind = _lib.NF_KIND["composite"]
+        self.desc.dtype = _dtype_code(dt)
+        self.desc.d = dist.d
+        self.desc.nlayers = 1
+        self.desc.nsegments = len(segments)
+        self.desc.segments = C.addressof(self._seg_descs)
+        if not dist.standard:
+            if dist.mu.dtype != dt:
+                raise NFHipError(f"base distribution is {dist.mu.dtype}, flow parameters are {dt}")
+            self.desc.base = C.addressof(dist.c)
+        self.P = int(_lib.load_library().nf_param_count(C.byref(self.desc)))
+        if self.P < 0:
+            check(self.P)
+        self.theta = theta if theta is not None else torch.cat([f.theta for f in segments])
+        if self.theta.numel() != self.P:
+            raise NFHipError(f"theta has {self.theta.numel()} entries, flow has {self.P} parameters")
+        self.transform = Transform(self)
+
+    def with_theta(self, theta: torch.Tensor) -> "CompositeFlow":
+        return CompositeFlow(self.segments, self.dist, theta)
+
+
+def create_flow(Ls: Sequence[Flow], q0: MvNormal) -> Flow:
+    """create_flow(Ls, q0) = transformed(q0, reduce(o, Ls))  (src/flows/utils.jl:23-26).  `Ls` are flows built by the
+    constructors below (each contributes its transform); one element returns that flow on q0, several compose."""
+    Ls = list(Ls)
+    if len(Ls) == 1 and not isinstance(Ls[0], CompositeFlow) and Ls[0].dist is q0:
+        return Ls[0]
+    return CompositeFlow(Ls, q0)
+
+
 def inverse(t: Transform) -> Transform:
     """Bijectors.inverse"""
     return Transform(t.flow, not t.inverted, t.layer)

@@ -986,6 +986,57 @@ def base_sample(d: int, n: int, seed: int, sample_offset: int = 0, stream: int =
 
 
 # --------------------------------------------------------------------------
+# Heterogeneous compositions: create_flow((L1, ..., Ln), q0) = transformed(q0, reduce(o, Ls)) for ANY list of
+# bijectors (src/flows/utils.jl:23-26).  `specs` are single-family FlowSpecs in flat order (first = outermost =
+# applied last); theta is their parameter vectors concatenated (the order destructure walks the composition).
+# --------------------------------------------------------------------------
+
+
+def _comp_slices(specs):
+    offs, o_ = [], 0
+    for sp in specs:
+        offs.append((o_, o_ + param_count(sp)))
+        o_ += param_count(sp)
+    return offs
+
+
+def comp_fwd(specs, theta, x, keep=False):
+    sl = _comp_slices(specs)
+    ladj = np.zeros(x.shape[1], dtype=x.dtype)
+    inputs = [None] * len(specs)
+    for s in range(len(specs) - 1, -1, -1):
+        inputs[s] = x
+        x, l = flow_fwd(specs[s], theta[sl[s][0] : sl[s][1]], x)
+        ladj = ladj + l
+    return (x, ladj, inputs) if keep else (x, ladj)
+
+
+def comp_inv(specs, theta, y):
+    sl = _comp_slices(specs)
+    ladj = np.zeros(y.shape[1], dtype=y.dtype)
+    for s in range(len(specs)):
+        y, l = flow_inv(specs[s], theta[sl[s][0] : sl[s][1]], y)
+        ladj = ladj + l
+    return y, ladj
+
+
+def comp_neg_elbo_value_and_grad(specs, theta, target, xs):
+    n = xs.shape[1]
+    sl = _comp_slices(specs)
+    ys, ladj, inputs = comp_fwd(specs, theta, xs, keep=True)
+    loss = -(target_logp(target, ys) - std_normal_logpdf(xs) + ladj).mean()
+    gbar = (-target_grad(target, ys) / n).astype(xs.dtype)
+    lbar = np.full(n, -1.0 / n, dtype=xs.dtype)
+    grad = np.zeros_like(theta)
+    for s in range(len(specs)):
+        th = theta[sl[s][0] : sl[s][1]]
+        _, _, states = flow_fwd(specs[s], th, inputs[s], keep=True)
+        gbar, g = flow_bwd(specs[s], th, states, gbar, lbar)
+        grad[sl[s][0] : sl[s][1]] = g
+    return loss, grad
+
+
+# --------------------------------------------------------------------------
 # General MvNormal(mu, Sigma) base distributions: _device_specific_rand(rng, ::MvNormal, n) draws mu + L eps
 # (Distributions' unwhiten; device version ext/NormalizingFlowsCUDAExt.jl:43-48, dense Sigma exercised by
 # test/ext/CUDA/cuda.jl:33-45) and logpdf(flow.dist, xs) enters the ELBO at src/objectives/elbo.jl:6,68.

@@ -91,6 +91,10 @@ ARENA_FLOWS = {
     "planar_many_layers": lambda nf: nf.planarflow(nf.MvNormal(40), 20, paramtype=torch.float32, seed=6),  # beyond k_simple_step
     "radial_f64": lambda nf: nf.radialflow(nf.MvNormal(7), 4, paramtype=torch.float64, seed=7),
     "meanfield": lambda nf: nf.meanfield(nf.MvNormal(4), paramtype=torch.float32),
+    "composite_general_base": lambda nf: nf.create_flow(
+        [nf.radialflow(nf.MvNormal(6), 2, paramtype=torch.float32, seed=1), nf.realnvp(nf.MvNormal(6), [16, 16], 1, paramtype=torch.float32, seed=2),
+         nf.planarflow(nf.MvNormal(6), 2, paramtype=torch.float32, seed=3)],
+        nf.MvNormal(torch.randn(6, device="cuda"), torch.rand(6, device="cuda") + 0.5)),
 }
 
 
@@ -102,7 +106,7 @@ def test_caller_provided_arena_covers_every_entry_point(name):
     nf = load_package()
     lib = nf.load_library()
     flow = ARENA_FLOWS[name](nf)
-    if name.startswith("planar") or name.startswith("radial"):
+    if name.startswith("planar") or name.startswith("radial") or name.startswith("composite"):
         flow = flow.with_theta(flow.theta * 0.3)
     dt, d, n = flow.theta.dtype, flow.dist.d, 333
     ctx = flow.ctx
@@ -110,7 +114,7 @@ def test_caller_provided_arena_covers_every_entry_point(name):
 
     def run_everything():
         out = {}
-        xs = nf.device_specific_rand(nf.PhiloxRNG(3), flow.dist, n, dtype=dt)
+        xs = nf.device_specific_rand(nf.PhiloxRNG(3), flow.dist, n, dtype=dt, device="cuda")
         ys, ladj = nf.with_logabsdet_jacobian(flow.transform, xs)
         xr, lb = nf.with_logabsdet_jacobian(nf.inverse(flow.transform), ys)
         y1, l1 = nf.with_logabsdet_jacobian(nf.layer(flow, 0), xs)
@@ -124,10 +128,11 @@ def test_caller_provided_arena_covers_every_entry_point(name):
         out["step_rng"] = torch.cat([g, torch.tensor([l], dtype=dt, device="cuda")])
         l, g = nf.value_and_gradient(nf.elbo_batch, flow, tgt, xs)
         out["step_xs"] = torch.cat([g, torch.tensor([l], dtype=dt, device="cuda")])
-        l, g = nf.value_and_gradient(nf.elbo_batch, flow, lambda y: -(y * y).sum(0), xs)  # generic closure: nf_flow_bwd
-        out["pullback"] = g
-        l, g = nf.loglikelihood_value_and_gradient(flow, ys)
-        out["fkl"] = torch.cat([g, torch.tensor([l], dtype=dt, device="cuda")])
+        if flow.kind != "composite":  # pullback of a whole composite and forward-KL training of one are not built
+            l, g = nf.value_and_gradient(nf.elbo_batch, flow, lambda y: -(y * y).sum(0), xs)  # generic closure: nf_flow_bwd
+            out["pullback"] = g
+            l, g = nf.loglikelihood_value_and_gradient(flow, ys)
+            out["fkl"] = torch.cat([g, torch.tensor([l], dtype=dt, device="cuda")])
         th = flow.theta.clone()
         st = nf.setup(nf.Adam(1e-3), th)
         out["gnorm"] = nf.adam_update(nf.Adam(1e-3), st, th, g).clone()

@@ -970,6 +970,80 @@ def test_general_mvnormal_base(nf, bkind, maker):
         nf.loglikelihood_value_and_gradient(flow, ys)  # forward-KL training: standard-normal base only
 
 
+@pytest.mark.parametrize("dtn", ["float32", "float64"])
+@pytest.mark.parametrize("general_base", [False, True])
+def test_heterogeneous_create_flow(nf, dtn, general_base):
+    """create_flow((L1, ..., Ln), q0) with bijectors of different families (src/flows/utils.jl:23-26): radial layers over
+    a RealNVP block over an NSF block over planar layers.  Forward / inverse / per-layer application / rand / ELBO /
+    the training step's (loss, grad) / loglikelihood against the oracle's composition; theta is the segments' thetas in
+    flat order."""
+    dt, f64 = tdt(dtn), dtn == "float64"
+    npdt = np.float64 if f64 else np.float32
+    d = 6
+    specs = [o.FlowSpec("radial", d, 2), o.FlowSpec("realnvp", d, 1, (16, 16)), o.FlowSpec("nsf", d, 1, (16, 16), 8, 4.0),
+             o.FlowSpec("planar", d, 3)]
+    rng = np.random.default_rng(21)
+    ths = []
+    for sp in specs:
+        t = o.init_params(sp, rng)
+        t = t * 0.4 if sp.kind in ("planar", "radial") else t + 0.05 * rng.standard_normal(t.shape)
+        ths.append(t.astype(npdt).astype(np.float64))
+    th = np.concatenate(ths)
+    if general_base:
+        mu0 = rng.standard_normal(d).astype(npdt)
+        var0 = (rng.uniform(size=d) + 0.4).astype(npdt)
+        q0 = nf.MvNormal(torch.tensor(mu0, device="cuda"), torch.tensor(var0, device="cuda"))
+        obase = ("diag", mu0.astype(np.float64), np.sqrt(var0.astype(np.float64)))
+    else:
+        q0, obase = nf.MvNormal(d), None
+    segs = [nf.Flow(sp.kind, nf.MvNormal(d), sp.nlayers, sp.hdims, sp.K, sp.B, dtype=dt, device="cuda",
+                    theta=torch.tensor(t, dtype=dt, device="cuda")) for sp, t in zip(specs, ths)]
+    flow = nf.create_flow(segs, q0)
+    assert flow.P == th.size and flow.kind == "composite"
+    np.testing.assert_array_equal(flow.theta.cpu().numpy().astype(np.float64), th)
+    n, tag = 120, f"composite {dtn} base={'diag' if general_base else 'std'}"
+    ew = (1e-10, 1e-11) if f64 else (2e-5, 2e-5)
+    xs = nf.device_specific_rand(nf.PhiloxRNG(31), q0, n, dtype=dt)
+    xs64 = xs.cpu().numpy().astype(np.float64)
+    ys, ladj = nf.with_logabsdet_jacobian(flow.transform, xs)
+    y_ref, l_ref = o.comp_fwd(specs, th, xs64)
+    P.elementwise(f"{tag}: ys", ys, y_ref, *ew)
+    P.elementwise(f"{tag}: ladj", ladj, l_ref, *ew)
+    xr, lb = nf.with_logabsdet_jacobian(nf.inverse(flow.transform), ys)
+    P.isapprox(f"{tag}: round trip x", xr, xs, 1e-9 if f64 else 1e-4)
+    P.isapprox(f"{tag}: lj_fwd ~ -lj_bwd", lb, -ladj, 1e-9 if f64 else 1e-4)
+    # single bijectors, flat index over the segments, compose to the chain
+    z, tot = xs, torch.zeros(n, dtype=dt, device="cuda")
+    nlay = 2 + 2 + 2 + 3
+    for k in reversed(range(nlay)):
+        z, lj = nf.with_logabsdet_jacobian(nf.layer(flow, k), z)
+        tot = tot + lj
+    P.elementwise(f"{tag}: per-layer composition ys", z, y_ref, *ew)
+    P.elementwise(f"{tag}: per-layer composition ladj", tot, l_ref, *ew)
+    P.elementwise(f"{tag}: rand(flow)", nf.rand(flow, n, nf.PhiloxRNG(31)), y_ref, *ew)
+    tmu, tvar = rng.standard_normal(d).astype(npdt), (rng.uniform(size=d) + 0.5).astype(npdt)
+    tgt = nf.DiagGaussTarget(torch.tensor(tmu, device="cuda"), torch.tensor(tvar, device="cuda"))
+    otgt = ("diaggauss", tmu.astype(np.float64), tvar.astype(np.float64))
+    lo, go = o.comp_neg_elbo_value_and_grad(specs, th, otgt, xs64)
+    corr = (o.base_logpdf(obase, xs64) - o.std_normal_logpdf(xs64)).mean()
+    lr = 1e-10 if f64 else P.LOSS_RTOL
+    P.scalar(f"{tag}: elbo_batch(xs)", nf.elbo_batch(flow, tgt, xs), -(lo + corr), lr, lr)
+    P.scalar(f"{tag}: elbo_batch(rng)", nf.elbo_batch(nf.PhiloxRNG(31), flow, tgt, n), -(lo + corr), lr, lr)
+    el = nf.batched_elbos(flow, tgt, xs)
+    P.scalar(f"{tag}: mean of elbo terms", float(el.double().mean()), -(lo + corr), lr, lr)
+    for form, arg in (("rng", n), ("xs", xs)):
+        loss, g = nf.value_and_gradient(nf.elbo_batch, flow, tgt, arg, rng=nf.PhiloxRNG(31))
+        P.scalar(f"{tag}: step loss ({form})", loss, lo + corr, lr, lr)
+        P.gradient(f"{tag}: step grad ({form})", g, go, P.F64_GRAD if f64 else P.GRAD_RTOL)
+    zi, li = o.comp_inv(specs, th, ys.cpu().numpy().astype(np.float64))
+    P.scalar(f"{tag}: loglikelihood", nf.loglikelihood(None, flow, ys), (o.base_logpdf(obase, zi) + li).mean(), 10 * lr, 10 * lr)
+    # training runs through the composite like through any flow
+    trained, stats, st = nf.train_flow(nf.PhiloxRNG(1), nf.elbo_batch, flow, tgt, 256, max_iters=5, optimiser=nf.Adam(1e-3))
+    assert isinstance(trained, nf.CompositeFlow) and np.isfinite(stats[-1]["loss"]) and st.t == 5
+    with pytest.raises(nf.NFHipError, match="not built"):
+        nf.loglikelihood_value_and_gradient(flow, ys)
+
+
 RAND_CASES = {
     "planar5": ("planar", 5, 4, (), 0, 0.0, "float32"), "radial64": ("radial", 64, 3, (), 0, 0.0, "float32"),
     "planar100_f64": ("planar", 100, 2, (), 0, 0.0, "float64"), "realnvp5": ("realnvp", 5, 2, (32, 32), 0, 0.0, "float32"),
