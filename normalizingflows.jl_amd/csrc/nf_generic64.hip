@@ -15,9 +15,11 @@
 // src/flows/utils.jl:71-100; MonotonicSplines 0.3.3 as restated in oracle/nf_oracle.py.
 #include "nf_common.h"
 
-#define G64_MAXH 128   // widest hidden layer
-#define G64_MAXO 512   // widest output layer ((3K-1)*c for splines)
-#define G64_MAXC 64    // transformed / conditioner dims per coupling
+// Two size classes (per-thread scratch arrays are sized at compile time): SMALL keeps the shapes such flows are
+// normally used at cheap, LARGE takes the general kernels to the d <= 256 / hidden <= 256 envelope of the MFMA paths
+// (Float64 RealNVP at the cfg 4 geometry, test/flow.jl's Float64 runs at any width the fp32 kernels take).
+struct G64Small { static constexpr int MAXH = 128, MAXO = 512, MAXC = 64; };    // widest hidden / output layer, dims per coupling
+struct G64Large { static constexpr int MAXH = 256, MAXO = 1024, MAXC = 128; };
 #define G64_MAXK 16
 #define G64_BLOCK 64
 
@@ -38,9 +40,9 @@ template <class T>
 __device__ __forceinline__ T g64_lrelu(T z) { return z > (T)0.0 ? z : (T)0.01 * z; }
 
 // forward through one MLP; hidden post-activations are kept in acts[layer][.]
-template <class T>
+template <class T, class SZ>
 __device__ void g64_net_fwd(const T *__restrict__ th, const G64Net &n, const T *in,
-                            T (*acts)[G64_MAXH], T *out) {
+                            T (*acts)[SZ::MAXH], T *out) {
   const T *cur = in;
   for (int l = 0; l < n.nl; ++l) {
     const int nin = n.dims[l], nout = n.dims[l + 1];
@@ -57,10 +59,10 @@ __device__ void g64_net_fwd(const T *__restrict__ th, const G64Net &n, const T *
 
 // reverse pass of g64_net_fwd: delta (cotangent of the output, overwritten) -> din; parameter
 // gradients are added atomically to g
-template <class T>
+template <class T, class SZ>
 __device__ void g64_net_bwd(const T *__restrict__ th, const G64Net &n, const T *in,
-                            T (*acts)[G64_MAXH], T *delta, T *din, T *__restrict__ g) {
-  T tmp[G64_MAXH];
+                            T (*acts)[SZ::MAXH], T *delta, T *din, T *__restrict__ g) {
+  T tmp[SZ::MAXH];
   for (int l = n.nl - 1; l >= 0; --l) {
     const int nin = n.dims[l], nout = n.dims[l + 1];
     const T *W = th + n.w[l];
@@ -204,29 +206,29 @@ __device__ T g64_spline_bwd(const G64Spline<T> &sp, const T *raw, int K, T B, T 
 }
 
 // ---- one coupling, forward or inverse, standard layout (x[j*d + i]) ---------------------------
-template <class T>
+template <class T, class SZ>
 __global__ __launch_bounds__(G64_BLOCK) void k_g64_apply(G64Args a, int inverse, const T *__restrict__ theta,
                                                         const T *x, T *y, T *__restrict__ ladj) {
   const long j = (long)blockIdx.x * G64_BLOCK + threadIdx.x;
   if (j >= a.N) return;
   const T *xr = x + j * a.d;
   T *yr = y + j * a.d;
-  T x2[G64_MAXC], acts[NF_MAX_HIDDEN][G64_MAXH], out[G64_MAXO];
+  T x2[SZ::MAXC], acts[NF_MAX_HIDDEN][SZ::MAXH], out[SZ::MAXO];
   const int par_c = 1 - a.par_t;
   for (int q = 0; q < a.m; ++q) x2[q] = xr[2 * q + par_c];
   T lsum = (T)0.0;
   if (a.kind == NF_KIND_REALNVP) {
-    T s[G64_MAXC];
-    g64_net_fwd(theta, a.net[0], x2, acts, out);
+    T s[SZ::MAXC];
+    g64_net_fwd<T, SZ>(theta, a.net[0], x2, acts, out);
     for (int p = 0; p < a.c; ++p) s[p] = tanh(out[p]);
-    g64_net_fwd(theta, a.net[1], x2, acts, out);  // out = t
+    g64_net_fwd<T, SZ>(theta, a.net[1], x2, acts, out);  // out = t
     for (int p = 0; p < a.c; ++p) {
       const T v = xr[2 * p + a.par_t];
       yr[2 * p + a.par_t] = inverse ? (v - out[p]) * exp(-s[p]) : v * exp(s[p]) + out[p];
       lsum += inverse ? -s[p] : s[p];
     }
   } else {
-    g64_net_fwd(theta, a.net[0], x2, acts, out);
+    g64_net_fwd<T, SZ>(theta, a.net[0], x2, acts, out);
     const int P = 3 * a.K - 1;
     G64Spline<T> sp;
     for (int p = 0; p < a.c; ++p) {
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(G64_BLOCK) void k_g64_apply(G64Args a, int inverse,
 // reverse pass of one coupling at its INPUT x: gbar holds ybar on entry, xbar on exit.
 // inv != 0: reverse pass of the INVERSE coupling at its OUTPUT x (same point): gbar holds the cotangent of
 // x on entry and of the inverse's input on exit, lbar is the cotangent of ladj_inv.
-template <class T>
+template <class T, class SZ>
 __global__ __launch_bounds__(G64_BLOCK) void k_g64_bwd(G64Args a, int inv, const T *__restrict__ theta,
                                                       const T *__restrict__ x, T *gbar,
                                                       const T *__restrict__ lbar, T lbar_const,
@@ -253,40 +255,40 @@ __global__ __launch_bounds__(G64_BLOCK) void k_g64_bwd(G64Args a, int inv, const
   const T *xr = x + j * a.d;
   T *gr = gbar + j * a.d;
   const T lb = lbar ? lbar[j] : lbar_const;
-  T x2[G64_MAXC], acts[NF_MAX_HIDDEN][G64_MAXH], out[G64_MAXO], din[G64_MAXC];
+  T x2[SZ::MAXC], acts[NF_MAX_HIDDEN][SZ::MAXH], out[SZ::MAXO], din[SZ::MAXC];
   const int par_c = 1 - a.par_t;
   for (int q = 0; q < a.m; ++q) x2[q] = xr[2 * q + par_c];
   if (a.kind == NF_KIND_REALNVP && inv) {
     // x1 = (v1 - t) exp(-s), ladj_inv = -sum s:  v1bar = x1bar exp(-s), sbar = -x1bar x1 - lbar, tbar = -v1bar
-    g64_net_fwd(theta, a.net[0], x2, acts, out);
+    g64_net_fwd<T, SZ>(theta, a.net[0], x2, acts, out);
     for (int p = 0; p < a.c; ++p) {
       const T s = tanh(out[p]), x1 = xr[2 * p + a.par_t], xb = gr[2 * p + a.par_t];
       gr[2 * p + a.par_t] = xb * exp(-s);
       out[p] = (-xb * x1 - lb) * ((T)1.0 - s * s);
     }
-    g64_net_bwd(theta, a.net[0], x2, acts, out, din, g);
+    g64_net_bwd<T, SZ>(theta, a.net[0], x2, acts, out, din, g);
     for (int q = 0; q < a.m; ++q) gr[2 * q + par_c] += din[q];
-    g64_net_fwd(theta, a.net[1], x2, acts, out);
+    g64_net_fwd<T, SZ>(theta, a.net[1], x2, acts, out);
     for (int p = 0; p < a.c; ++p) out[p] = -gr[2 * p + a.par_t];
-    g64_net_bwd(theta, a.net[1], x2, acts, out, din, g);
+    g64_net_bwd<T, SZ>(theta, a.net[1], x2, acts, out, din, g);
     for (int q = 0; q < a.m; ++q) gr[2 * q + par_c] += din[q];
   } else if (a.kind == NF_KIND_REALNVP) {
     // t net: y1 = x1 exp(s) + t  =>  tbar = ybar1
-    g64_net_fwd(theta, a.net[1], x2, acts, out);
+    g64_net_fwd<T, SZ>(theta, a.net[1], x2, acts, out);
     for (int p = 0; p < a.c; ++p) out[p] = gr[2 * p + a.par_t];
-    g64_net_bwd(theta, a.net[1], x2, acts, out, din, g);
+    g64_net_bwd<T, SZ>(theta, a.net[1], x2, acts, out, din, g);
     for (int q = 0; q < a.m; ++q) gr[2 * q + par_c] += din[q];
     // s net: sbar = ybar1 x1 exp(s) + lbar, through tanh
-    g64_net_fwd(theta, a.net[0], x2, acts, out);
+    g64_net_fwd<T, SZ>(theta, a.net[0], x2, acts, out);
     for (int p = 0; p < a.c; ++p) {
       const T s = tanh(out[p]), es = exp(s), x1 = xr[2 * p + a.par_t], yb = gr[2 * p + a.par_t];
       gr[2 * p + a.par_t] = yb * es;
       out[p] = (yb * x1 * es + lb) * ((T)1.0 - s * s);
     }
-    g64_net_bwd(theta, a.net[0], x2, acts, out, din, g);
+    g64_net_bwd<T, SZ>(theta, a.net[0], x2, acts, out, din, g);
     for (int q = 0; q < a.m; ++q) gr[2 * q + par_c] += din[q];
   } else {
-    g64_net_fwd(theta, a.net[0], x2, acts, out);
+    g64_net_fwd<T, SZ>(theta, a.net[0], x2, acts, out);
     const int P = 3 * a.K - 1;
     G64Spline<T> sp;
     T thb[3 * G64_MAXK];
@@ -296,25 +298,30 @@ __global__ __launch_bounds__(G64_BLOCK) void k_g64_bwd(G64Args a, int inv, const
       gr[2 * p + a.par_t] = xb;
       for (int i = 0; i < P; ++i) out[p * P + i] = thb[i];
     }
-    g64_net_bwd(theta, a.net[0], x2, acts, out, din, g);
+    g64_net_bwd<T, SZ>(theta, a.net[0], x2, acts, out, din, g);
     for (int q = 0; q < a.m; ++q) gr[2 * q + par_c] += din[q];
   }
 }
 
 // ---- host side --------------------------------------------------------------------------------
+template <class SZ>
+static bool g64_fits(const nf_flow_desc *desc) {
+  for (int i = 0; i < desc->n_hidden; ++i)
+    if (desc->hdims[i] < 1 || desc->hdims[i] > SZ::MAXH) return false;
+  const int c = (desc->d + 1) / 2;
+  if (c > SZ::MAXC) return false;
+  if (desc->kind == NF_KIND_NSF) {
+    if (desc->K < 2 || desc->K > G64_MAXK || !(desc->B > 0.f)) return false;
+    if ((3 * desc->K - 1) * c > SZ::MAXO) return false;
+  }
+  return true;
+}
+
 bool nf_g64_supported(const nf_flow_desc *desc) {
   if (desc->dtype != NF_DTYPE_F64 && desc->dtype != NF_DTYPE_F32) return false;
   if (desc->kind != NF_KIND_REALNVP && desc->kind != NF_KIND_NSF) return false;
   if (desc->n_hidden < 1 || desc->n_hidden > NF_MAX_HIDDEN || desc->d < 2) return false;
-  for (int i = 0; i < desc->n_hidden; ++i)
-    if (desc->hdims[i] < 1 || desc->hdims[i] > G64_MAXH) return false;
-  const int c = (desc->d + 1) / 2;
-  if (c > G64_MAXC) return false;
-  if (desc->kind == NF_KIND_NSF) {
-    if (desc->K < 2 || desc->K > G64_MAXK || !(desc->B > 0.f)) return false;
-    if ((3 * desc->K - 1) * c > G64_MAXO) return false;
-  }
-  return true;
+  return g64_fits<G64Large>(desc);
 }
 
 static long fill_net(G64Net *n, long off, int nin, const nf_flow_desc *desc, int nout) {
@@ -345,6 +352,24 @@ static G64Args make_g64_args(const nf_flow_desc *desc, int k, long N) {
   return a;
 }
 
+// launches of the two kernels in the size class the flow fits
+template <class T>
+static void g64_launch_apply(nf_ctx *ctx, const nf_flow_desc *desc, unsigned grid, const G64Args &a, int inverse, const T *theta,
+                             const T *x, T *y, T *ladj) {
+  if (g64_fits<G64Small>(desc))
+    hipLaunchKernelGGL((k_g64_apply<T, G64Small>), dim3(grid), dim3(G64_BLOCK), 0, ctx->stream, a, inverse, theta, x, y, ladj);
+  else
+    hipLaunchKernelGGL((k_g64_apply<T, G64Large>), dim3(grid), dim3(G64_BLOCK), 0, ctx->stream, a, inverse, theta, x, y, ladj);
+}
+template <class T>
+static void g64_launch_bwd(nf_ctx *ctx, const nf_flow_desc *desc, unsigned grid, const G64Args &a, int inv, const T *theta,
+                           const T *x, T *gbar, const T *lbar, T lbar_const, T *g) {
+  if (g64_fits<G64Small>(desc))
+    hipLaunchKernelGGL((k_g64_bwd<T, G64Small>), dim3(grid), dim3(G64_BLOCK), 0, ctx->stream, a, inv, theta, x, gbar, lbar, lbar_const, g);
+  else
+    hipLaunchKernelGGL((k_g64_bwd<T, G64Large>), dim3(grid), dim3(G64_BLOCK), 0, ctx->stream, a, inv, theta, x, gbar, lbar, lbar_const, g);
+}
+
 // couplings [layer_lo, layer_hi) in flat order (forward: applied last-listed first); y may alias x
 int nf_g64_apply(nf_ctx *ctx, const nf_flow_desc *desc, int layer_lo, int layer_hi, bool inverse, const void *theta,
                  const void *x, long N, void *y, void *ladj) {
@@ -359,9 +384,9 @@ int nf_g64_apply(nf_ctx *ctx, const nf_flow_desc *desc, int layer_lo, int layer_
     const G64Args a = make_g64_args(desc, k, N);
     ProfScope ps(ctx, "g64_apply");
     if (f64)
-      hipLaunchKernelGGL(k_g64_apply<double>, dim3(grid), dim3(G64_BLOCK), 0, ctx->stream, a, inverse ? 1 : 0, (const double *)theta, (const double *)y, (double *)y, (double *)ladj);
+      g64_launch_apply<double>(ctx, desc, grid, a, inverse ? 1 : 0, (const double *)theta, (const double *)y, (double *)y, (double *)ladj);
     else
-      hipLaunchKernelGGL(k_g64_apply<float>, dim3(grid), dim3(G64_BLOCK), 0, ctx->stream, a, inverse ? 1 : 0, (const float *)theta, (const float *)y, (float *)y, (float *)ladj);
+      g64_launch_apply<float>(ctx, desc, grid, a, inverse ? 1 : 0, (const float *)theta, (const float *)y, (float *)y, (float *)ladj);
     NF_HIP(hipGetLastError());
   }
   return NF_OK;
@@ -394,7 +419,7 @@ static int g64_bwd_t(nf_ctx *ctx, const nf_flow_desc *desc, const T *theta, cons
     if (k > 0) {
       T *next = inputs + (size_t)(k - 1) * nd;
       const G64Args a = make_g64_args(desc, k, N);
-      hipLaunchKernelGGL(k_g64_apply<T>, dim3(grid), dim3(G64_BLOCK), 0, ctx->stream, a, 0, theta, (const T *)slot, next, scr_ladj);
+      g64_launch_apply<T>(ctx, desc, grid, a, 0, theta, (const T *)slot, next, scr_ladj);
       NF_HIP(hipGetLastError());
       cur = next;
     }
@@ -403,7 +428,7 @@ static int g64_bwd_t(nf_ctx *ctx, const nf_flow_desc *desc, const T *theta, cons
   for (int k = 0; k < nc; ++k) {  // reverse of execution order
     const G64Args a = make_g64_args(desc, k, N);
     ProfScope ps(ctx, "g64_bwd");
-    hipLaunchKernelGGL(k_g64_bwd<T>, dim3(grid), dim3(G64_BLOCK), 0, ctx->stream, a, 0, theta, (const T *)(inputs + (size_t)k * nd), xbar_out, lbar, (T)lbar_const, gtheta_out);
+    g64_launch_bwd<T>(ctx, desc, grid, a, 0, theta, (const T *)(inputs + (size_t)k * nd), xbar_out, lbar, (T)lbar_const, gtheta_out);
     NF_HIP(hipGetLastError());
   }
   return NF_OK;
@@ -437,11 +462,10 @@ static int g64_bwd_inv_t(nf_ctx *ctx, const nf_flow_desc *desc, const T *theta, 
     const G64Args a = make_g64_args(desc, k, N);
     {
       ProfScope ps(ctx, "g64_bwd");
-      hipLaunchKernelGGL(k_g64_bwd<T>, dim3(grid), dim3(G64_BLOCK), 0, ctx->stream, a, 1, theta, (const T *)z, gbar,
-                         (const T *)nullptr, (T)lbar_const, gtheta_out);
+      g64_launch_bwd<T>(ctx, desc, grid, a, 1, theta, (const T *)z, gbar, (const T *)nullptr, (T)lbar_const, gtheta_out);
       NF_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_g64_apply<T>, dim3(grid), dim3(G64_BLOCK), 0, ctx->stream, a, 0, theta, (const T *)z, z, scr_ladj);
+    g64_launch_apply<T>(ctx, desc, grid, a, 0, theta, (const T *)z, z, scr_ladj);
     NF_HIP(hipGetLastError());
   }
   return NF_OK;
