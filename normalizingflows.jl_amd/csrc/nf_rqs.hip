@@ -19,6 +19,8 @@
 //   slot / 16, register slot % 16.
 // The spline (softmax / cumsum / bin search / rational quadratic, and its hand-derived
 // reverse pass) then runs entirely in registers, one (dim, sample) per lane at a time.
+#include <cstdlib>
+
 #include "nf_common.h"
 #include "nf_mfma.h"
 #include "nf_philox.h"
@@ -699,6 +701,9 @@ __device__ __forceinline__ void rqs_fold(float *__restrict__ w, float *__restric
 #ifndef RQS_BWD_LAZY
 #define RQS_BWD_LAZY false
 #endif
+#ifndef RQS_COOP_LAZY
+#define RQS_COOP_LAZY true  // the cooperative kernel has the registers for the lazy knot derivatives
+#endif
 // INVD: reverse pass of the INVERSE coupling at its output (forward-KL training): `y` holds w and is advanced
 // to coupling(w); `ybar` the cotangent of w -> that of the inverse's input; lbar the cotangent of ladj_inv.
 template <class G, bool INVD = false>
@@ -956,20 +961,289 @@ __global__ __launch_bounds__(256, 1) void k_rqs_bwd_all(RqsBwdAllArgs aa, float 
 }
 
 // ---------------------------------------------------------------------------------------
+// reverse pass of one coupling, COOPERATIVE form (geometries with NCH == 4 chunks)
+// ---------------------------------------------------------------------------------------
+// k_rqs_bwd keeps the dW^T accumulators of the whole output layer in every wave: H2B x OB3 blocks = 192 (K = 8) or
+// 256 (K = 10, d = 32) registers, on top of the chunk's raw outputs and the spline's working set -- the kernel sits at
+// the register wall (256 VGPR + 256 AGPR + scratch spills; 1 400 of its 9 800 instructions per tile are AGPR <-> VGPR
+// moves), and the K = 10 / d = 32 shape (the reference's default nsf(q0) on d > 16, neuralspline.jl:232-234) does not
+// fit at all.  Here the four waves of a workgroup split the OUTPUT COLUMNS instead of the tiles:
+//   home phase   wave w recomputes layers 1-2 of its own tile (a1, a2 and their sign masks) and leaves x2, a1, a2 as
+//                [feature][sample] tiles in its LDS scratch;
+//   chunk phase  wave w owns chunk w of the output layer for ALL FOUR tiles of the group: reads tile t's a2 from wave
+//                t's scratch, evaluates its chunk of the output layer, runs the spline and its reverse pass for the
+//                chunk's dims, its part of dX3 (a partial d2, handed to the home wave through an LDS slot) and its
+//                columns of dW3^T -- OBC accumulator blocks instead of OB3;
+//   home phase   wave w sums the four partial d2 of its tile (fixed order: deterministic) and finishes layers 2 and 1.
+// Same MFMA count as k_rqs_bwd, 80-96 accumulator registers per wave instead of 224-288, 9 workgroup barriers per 4 tiles.
+template <class G>
+struct RqsCoopLds {
+  static_assert(G::NCH == 4, "one chunk per wave");
+  static constexpr int OFF_X = 0;
+  static constexpr int OFF_A1 = OFF_X + G::MB * 32 * NF_TS;
+  static constexpr int OFF_A2 = OFF_A1 + G::H1B * 32 * NF_TS;
+  static constexpr int OFF_D = OFF_A2 + G::H2B * 32 * NF_TS;
+  static constexpr int DBLK = (G::H1B > G::H2B ? G::H1B : G::H2B);  // delta tile: one block for dW3, a whole hidden layer for dW2 / dW1
+  static constexpr int SCRATCH = OFF_D + DBLK * 32 * NF_TS;
+  static constexpr int SLOT = G::H2B * 16 * 64;  // one partial d2 in register-dump order
+  static constexpr size_t BYTES = (size_t)(G::SIZE + 4 * SCRATCH + 4 * SLOT) * sizeof(float);
+};
+
+template <class G>
+struct RqsCoopAcc {
+  f32x16 w1[G::MB][G::H1B];
+  f32x16 w2[G::H1B][G::H2B];
+  f32x16 w3[G::H2B][G::OBC];  // this wave's chunk of the output layer
+  float b1[G::H1B], b2[G::H2B], b3[G::OBC];
+};
+
+template <class G, bool INVD>
+__device__ __forceinline__ void rqs_bwd_coop_coupling(const RqsBwdArgs &a, float *__restrict__ y, float *__restrict__ ybar,
+                                                      const float *__restrict__ lbar, float lbar_const,
+                                                      float *__restrict__ slab, long slab_stride, float *lds) {
+  using L = RqsCoopLds<G>;
+  float *img = lds;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  float *sc_all = lds + G::SIZE;
+  float *sc = sc_all + wave * L::SCRATCH;          // this wave's tiles
+  float *slots = sc_all + 4 * L::SCRATCH;          // [4][SLOT]
+  float *sd = sc + L::OFF_D;
+  const long ntiles = (a.N + NF_TILE - 1) / NF_TILE;
+  const long ngroups = (ntiles + 3) / 4;
+  const int par_c = 1 - a.par_t;
+  const int ch = wave;                              // the chunk this wave owns
+  stage_packed<G::SIZE, 256>(img, a.img, tid);
+  __syncthreads();
+  RqsCoopAcc<G> acc;
+  rqs_zero(acc.w1, acc.b1);
+  rqs_zero(acc.w2, acc.b2);
+  rqs_zero(acc.w3, acc.b3);
+#pragma unroll 1
+  for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    // ---------------- home phase: layers 1-2 of this wave's own tile ----------------
+    const long tile = grp * 4 + wave;
+    const bool live = tile < ntiles;               // wave-uniform; every barrier below is reached by all waves
+    const long tl = live ? tile : 0;
+    const long j = tl * NF_TILE + l31;
+    const bool valid = live && j < a.N;
+    const TileIO yio = make_tile_io(y, tl, a.d, l31, hi);
+    const TileIO gio = make_tile_io(ybar, tl, a.d, l31, hi);
+    unsigned m1[G::H1B], m2[G::H2B];
+    if (live) {
+      f32x16 xb[G::MB];
+#pragma unroll
+      for (int b = 0; b < G::MB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = tile_load(yio, tile_soff(b, r, par_c));
+          xb[b][r] = valid ? v : 0.f;
+        }
+      tile_to_scratch<G::MB>(sc + L::OFF_X, xb, l31, hi);
+      f32x16 a1[G::H1B];
+      dense_fwd<G::MB, G::H1B>(img + G::W1, img + G::B1, xb, a1, l31, hi);
+#pragma unroll
+      for (int b = 0; b < G::H1B; ++b) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a1[b][r] = nf_lrelu(a1[b][r]);
+        m1[b] = nf_sign_mask16(a1[b]);
+      }
+      tile_to_scratch<G::H1B>(sc + L::OFF_A1, a1, l31, hi);
+      f32x16 a2[G::H2B];
+      dense_fwd<G::H1B, G::H2B>(img + G::W2, img + G::B2, a1, a2, l31, hi);
+#pragma unroll
+      for (int b = 0; b < G::H2B; ++b) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a2[b][r] = nf_lrelu(a2[b][r]);
+        m2[b] = nf_sign_mask16(a2[b]);
+      }
+      tile_to_scratch<G::H2B>(sc + L::OFF_A2, a2, l31, hi);
+    }
+    __syncthreads();  // B0: every home tile's a2 is in LDS
+
+    // ---------------- chunk phase: this wave's chunk of the output layer, for each tile of the group ----------------
+    f32x16 d2[G::H2B];  // the home tile's summed cotangent of a2 (filled when t == wave)
+#pragma unroll
+    for (int b = 0; b < G::H2B; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) d2[b][r] = 0.f;
+#pragma unroll 1
+    for (int t = 0; t < 4; ++t) {
+      const long tt = grp * 4 + t;
+      const bool tlive = tt < ntiles;  // uniform over the workgroup
+      if (tlive) {
+        const float *sct = sc_all + t * L::SCRATCH;  // wave t's tiles
+        const long jt = tt * NF_TILE + l31;
+        const bool tvalid = jt < a.N;
+        const TileIO yt = make_tile_io(y, tt, a.d, l31, hi);
+        const TileIO gt = make_tile_io(ybar, tt, a.d, l31, hi);
+        const float lb = tvalid ? (lbar ? lbar[jt] : lbar_const) : 0.f;
+        float yq[G::QCH], gq[G::QCH];
+#pragma unroll
+        for (int ql = 0; ql < G::QCH; ++ql) {
+          const int q = ch * G::QCH + ql;
+          yq[ql] = tile_load(yt, tile_soff(q / 16, q % 16, a.par_t));
+          gq[ql] = tile_load(gt, tile_soff(q / 16, q % 16, a.par_t));
+        }
+        f32x16 out[G::OBC];
+        {
+          f32x16 a2c[G::H2B];  // tile t's a2 back in the accumulator layout (B operand of the output layer)
+#pragma unroll
+          for (int b = 0; b < G::H2B; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a2c[b][r] = sct[L::OFF_A2 + (b * 32 + nf_row(r, hi)) * NF_TS + l31];
+          dense_fwd<G::H2B, G::OBC, G::S3>(img + G::W3 + ch * G::OBC * 32, img + G::B3 + ch * G::OBC * 32, a2c, out, l31, hi);
+        }
+#pragma unroll
+        for (int ql = 0; ql < G::QCH; ++ql) {
+          const int q = ch * G::QCH + ql;
+          const int p = (q & 3) + 8 * (q >> 2) + 4 * hi;
+          const bool ok = tvalid && p < a.c;
+          float raw[G::P], thb[G::P];
+          chunk_get<G>(out, ql, raw);
+          Knots<G::K> kn;
+          build_knots<G::K, RQS_COOP_LAZY>(raw, a.B, kn);
+          const float yv = yq[ql];
+          const float gv = ok ? gq[ql] : 0.f;
+          float dummy = 0.f, xi;
+          Bin<G::K> bn;
+          float xv;
+          if (INVD) {
+            find_bin<G::K, RQS_COOP_LAZY>(kn, kn.pX, yv, bn);
+            const float dx = bn.xk1 - bn.xk, dy = bn.yk1 - bn.yk;
+            const float sl = nf_fdiv(dy, dx);
+            xi = nf_fdiv(yv - bn.xk, dx);
+            const float om = 1.f - xi;
+            const float den = sl + (bn.d1 + bn.d0 - 2.f * sl) * xi * om;
+            xv = bn.inside ? bn.yk + nf_fdiv(dy * (sl * xi * xi + bn.d0 * xi * om), den) : yv;
+          } else {
+            xv = rqs_inv_elem<G::K, false, RQS_COOP_LAZY>(kn, yv, dummy, bn, xi);
+          }
+          const float xbar = rqs_bwd_elem<G::K, INVD>(kn, bn, xi, a.B, gv, ok ? lb : 0.f, thb);
+          chunk_put<G>(out, ql, thb);
+          tile_store(yt, tile_soff(q / 16, q % 16, a.par_t), xv);
+          tile_store(gt, tile_soff(q / 16, q % 16, a.par_t), xbar);
+        }
+#pragma unroll
+        for (int slot = G::QCH * G::P; slot < G::OBC * 16; ++slot) out[slot / 16][slot % 16] = 0.f;
+        // this chunk's share of dX3 -> the home wave's slot
+        {
+          f32x16 d2p[G::H2B];
+          dense_bwd_x<G::H2B, G::OBC, G::S3>(img + G::W3 + ch * G::OBC * 32, out, d2p, l31, hi);
+          float *mys = slots + wave * L::SLOT;
+#pragma unroll
+          for (int b = 0; b < G::H2B; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mys[(b * 16 + r) * 64 + lane] = d2p[b][r];
+        }
+        // this chunk's columns of dW3^T: one block of delta at a time through the wave's own transpose tile
+#pragma unroll
+        for (int pc = 0; pc < G::OBC; ++pc) {
+          f32x16 one[1] = {out[pc]};
+          tile_to_scratch<1>(sd, one, l31, hi);
+          wave_lds_fence();
+          dw_accumulate_at<G::H2B, 1, G::OBC>(sct + L::OFF_A2, sd, acc.w3, acc.b3, pc, l31, hi);
+          wave_lds_fence();
+        }
+      }
+      __syncthreads();  // B1: the four partial d2 of tile t are in the slots
+      if (tlive && t == wave) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w)  // fixed order: deterministic
+#pragma unroll
+          for (int b = 0; b < G::H2B; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d2[b][r] += slots[w * L::SLOT + (b * 16 + r) * 64 + lane];
+      }
+      __syncthreads();  // B2: slots free for tile t + 1
+    }
+
+    // ---------------- home phase: layers 2 and 1 of this wave's own tile ----------------
+    if (live) {
+#pragma unroll
+      for (int b = 0; b < G::H2B; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d2[b][r] *= nf_mask_slope(m2[b], r);
+      tile_to_scratch<G::H2B>(sd, d2, l31, hi);
+      wave_lds_fence();
+      dw_accumulate<G::H1B, G::H2B>(sc + L::OFF_A1, sd, acc.w2, acc.b2, l31, hi);
+      f32x16 d1[G::H1B];
+      dense_bwd_x<G::H1B, G::H2B>(img + G::W2, d2, d1, l31, hi);
+#pragma unroll
+      for (int b = 0; b < G::H1B; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d1[b][r] *= nf_mask_slope(m1[b], r);
+      wave_lds_fence();
+      tile_to_scratch<G::H1B>(sd, d1, l31, hi);
+      wave_lds_fence();
+      dw_accumulate<G::MB, G::H1B>(sc + L::OFF_X, sd, acc.w1, acc.b1, l31, hi);
+      f32x16 g2[G::MB], gold[G::MB];
+#pragma unroll
+      for (int b = 0; b < G::MB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gold[b][r] = tile_load(gio, tile_soff(b, r, par_c));
+      dense_bwd_x<G::MB, G::H1B>(img + G::W1, d1, g2, l31, hi);
+      wave_lds_fence();
+#pragma unroll
+      for (int b = 0; b < G::MB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tile_store(gio, tile_soff(b, r, par_c), gold[b][r] + g2[b][r]);
+    }
+    // no barrier here: the next group's home phase writes only this wave's own tiles, which the other waves stopped
+    // reading at the last B2, and B0 orders those writes before anybody reads them
+  }
+  __syncthreads();  // the weight image is dead: it becomes the fold target
+  // layers 1 and 2: four partial sums (one per wave), added in wave order; output layer: each wave owns its columns
+#pragma unroll 1
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+      rqs_fold<G::MB, G::H1B, G::S1>(img + G::W1, img + G::B1, acc.w1, acc.b1, w == 0, l31, hi);
+      rqs_fold<G::H1B, G::H2B, G::S2>(img + G::W2, img + G::B2, acc.w2, acc.b2, w == 0, l31, hi);
+    }
+    __syncthreads();
+  }
+  rqs_fold<G::H2B, G::OBC, G::S3>(img + G::W3 + ch * G::OBC * 32, img + G::B3 + ch * G::OBC * 32, acc.w3, acc.b3, true, l31, hi);
+  __syncthreads();
+  {
+    const float4 *c0 = reinterpret_cast<const float4 *>(img);
+    float4 *dst = reinterpret_cast<float4 *>(slab + (long)blockIdx.x * slab_stride);
+    for (int i = tid; i < G::SIZE / 4; i += 256) dst[i] = c0[i];
+  }
+  __syncthreads();
+}
+
+template <class G, bool INVD>
+__global__ __launch_bounds__(256, 1) void k_rqs_bwd_coop(RqsBwdArgs a, float *__restrict__ y, float *__restrict__ ybar,
+                                                         const float *__restrict__ lbar, float lbar_const,
+                                                         float *__restrict__ slab, long slab_stride) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  rqs_bwd_coop_coupling<G, INVD>(a, y, ybar, lbar, lbar_const, slab, slab_stride, lds);
+}
+
+// ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
 using GeoK8 = RqsGeo<1, 1, 1, 8, 4>;    // d <= 32, hidden <= 32, K = 8   (cfg 3)
 using GeoK10 = RqsGeo<1, 1, 1, 10, 2>;  // d <= 16, hidden <= 32, K = 10  (test/flow.jl:65-78)
+using GeoK10L = RqsGeo<1, 1, 1, 10, 4>; // d <= 32, hidden <= 32, K = 10: the reference's default nsf(q0) widths and K
+                                        // (neuralspline.jl:232-234) up to d = 32; reverse pass only in the cooperative form
 
 static inline int b32(int n) { return (n + 31) / 32; }
 
-// 1 -> GeoK8, 2 -> GeoK10, 0 -> unsupported
+// 1 -> GeoK8, 2 -> GeoK10, 3 -> GeoK10L, 0 -> unsupported
+#define RQS_DISPATCH(ID, CALL) ((ID) == 1 ? CALL(GeoK8) : (ID) == 2 ? CALL(GeoK10) : CALL(GeoK10L))
+#define RQS_DISPATCH_STMT(ID, CALL) \
+  do {                              \
+    if ((ID) == 1) { CALL(GeoK8); } else if ((ID) == 2) { CALL(GeoK10); } else { CALL(GeoK10L); } \
+  } while (0)
 static int rqs_geo_id(const nf_flow_desc *desc) {
   if (desc->n_hidden != 2) return 0;
   const int cmax = (desc->d + 1) / 2;
   if (b32(desc->hdims[0]) != 1 || b32(desc->hdims[1]) != 1 || b32(cmax) != 1) return 0;
   if (desc->K == 8 && cmax <= GeoK8::CMAX) return 1;
   if (desc->K == 10 && cmax <= GeoK10::CMAX) return 2;
+  if (desc->K == 10 && cmax <= GeoK10L::CMAX) return 3;
   return 0;
 }
 
@@ -977,7 +1251,7 @@ bool nf_rqs_supported(const nf_flow_desc *desc) { return desc->d >= 2 && desc->B
 
 static int rqs_geo_size(const nf_flow_desc *desc) {
   const int id = rqs_geo_id(desc);
-  return id == 1 ? GeoK8::SIZE : (id == 2 ? GeoK10::SIZE : 0);
+  return id == 1 ? GeoK8::SIZE : id == 2 ? GeoK10::SIZE : id == 3 ? GeoK10L::SIZE : 0;
 }
 
 static RqsPackArgs rqs_pack_args(const nf_flow_desc *desc) {
@@ -1004,10 +1278,9 @@ int nf_rqs_pack(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta) {
   const long total = (long)nc * size;
   const unsigned grid = (unsigned)((total + 255) / 256);
   ProfScope ps(ctx, "pack_weights");
-  if (id == 1)
-    hipLaunchKernelGGL((k_rqs_pack<GeoK8>), dim3(grid), dim3(256), 0, ctx->stream, p, theta, (float *)ctx->wimg);
-  else
-    hipLaunchKernelGGL((k_rqs_pack<GeoK10>), dim3(grid), dim3(256), 0, ctx->stream, p, theta, (float *)ctx->wimg);
+#define RQS_CALL(G) hipLaunchKernelGGL((k_rqs_pack<G>), dim3(grid), dim3(256), 0, ctx->stream, p, theta, (float *)ctx->wimg)
+  RQS_DISPATCH_STMT(id, RQS_CALL);
+#undef RQS_CALL
   return (int)hipGetLastError();
 }
 
@@ -1018,10 +1291,9 @@ int nf_rqs_reduce_slabs(nf_ctx *ctx, const nf_flow_desc *desc, const float *slab
   const long total = (long)p.ncoup * rqs_geo_size(desc);
   const unsigned grid = (unsigned)((total + 255) / 256);
   ProfScope ps(ctx, "reduce_slabs");
-  if (id == 1)
-    hipLaunchKernelGGL((k_rqs_reduce_slabs<GeoK8>), dim3(grid), dim3(256), 0, ctx->stream, p, slab, nslab, total, g);
-  else
-    hipLaunchKernelGGL((k_rqs_reduce_slabs<GeoK10>), dim3(grid), dim3(256), 0, ctx->stream, p, slab, nslab, total, g);
+#define RQS_CALL(G) hipLaunchKernelGGL((k_rqs_reduce_slabs<G>), dim3(grid), dim3(256), 0, ctx->stream, p, slab, nslab, total, g)
+  RQS_DISPATCH_STMT(id, RQS_CALL);
+#undef RQS_CALL
   return (int)hipGetLastError();
 }
 
@@ -1071,16 +1343,18 @@ int nf_rqs_chain_elbo(nf_ctx *ctx, const nf_flow_desc *desc, long N, uint64_t se
   RqsFusedArgs fa;
   fa.k0 = (uint32_t)seed; fa.k1 = (uint32_t)(seed >> 32); fa.stream = stream; fa.off = off;
   fa.mu = mu; fa.var = var; fa.gt = gt; fa.gscale = (float)gscale; fa.partial = partial; fa.pscale = pscale;
-  if (id == 1) return launch_rqs_chain<GeoK8>(ctx, desc, false, yt, N, nullptr, -1, &fa);
-  return launch_rqs_chain<GeoK10>(ctx, desc, false, yt, N, nullptr, -1, &fa);
+#define RQS_CALL(G) launch_rqs_chain<G>(ctx, desc, false, yt, N, nullptr, -1, &fa)
+  return RQS_DISPATCH(id, RQS_CALL);
+#undef RQS_CALL
 }
 
 // whole chain (k_only < 0) or a single coupling (flat index k_only), in place on the tiled buffer
 int nf_rqs_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, float *xt, long N, float *ladj, int k_only) {
   const int id = rqs_geo_id(desc);
   if (!id || !ctx->wimg) return NF_ERR_UNSUPPORTED;
-  if (id == 1) return launch_rqs_chain<GeoK8>(ctx, desc, inverse, xt, N, ladj, k_only);
-  return launch_rqs_chain<GeoK10>(ctx, desc, inverse, xt, N, ladj, k_only);
+#define RQS_CALL(G) launch_rqs_chain<G>(ctx, desc, inverse, xt, N, ladj, k_only)
+  return RQS_DISPATCH(id, RQS_CALL);
+#undef RQS_CALL
 }
 
 int nf_rqs_bwd_grid(nf_ctx *ctx, long N) {
@@ -1091,8 +1365,35 @@ int nf_rqs_bwd_grid(nf_ctx *ctx, long N) {
 }
 
 template <class G, bool INVD>
+static int launch_rqs_bwd_coop(nf_ctx *ctx, const nf_flow_desc *desc, int k, float *y, float *ybar, const float *lbar,
+                               float lbar_const, long N, float *slab, long slab_stride, int grid) {
+  const size_t lds = RqsCoopLds<G>::BYTES;
+  static AttrOnce attr_once;  // once per device
+  NF_TRY(attr_once.run(ctx->device, [&]() -> int {
+    NF_HIP(hipFuncSetAttribute((const void *)k_rqs_bwd_coop<G, INVD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return NF_OK;
+  }));
+  const CouplingInfo ci = nf_coupling_info(desc, k);
+  RqsBwdArgs a;
+  a.img = (const float *)ctx->wimg + (size_t)k * G::SIZE;
+  a.d = desc->d; a.c = ci.c; a.m = ci.m; a.par_t = ci.par_t; a.B = desc->B; a.N = N;
+  a.trace = nullptr;
+  ProfScope ps(ctx, INVD ? "rqs_bwd_inv" : "rqs_bwd");
+  hipLaunchKernelGGL((k_rqs_bwd_coop<G, INVD>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, y, ybar, lbar, lbar_const,
+                     slab + (long)k * G::SIZE, slab_stride);
+  return (int)hipGetLastError();
+}
+
+template <class G, bool INVD>
 static int launch_rqs_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, float *y, float *ybar, const float *lbar,
                           float lbar_const, long N, float *slab, long slab_stride, int grid) {
+  if constexpr (G::NCH == 4) {
+    static const bool old_form = std::getenv("NF_RQS_BWD_PERWAVE") != nullptr;  // A/B switch: the per-wave-tile kernel
+    if (!old_form || G::OB3 > 12) return launch_rqs_bwd_coop<G, INVD>(ctx, desc, k, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid);
+  }
+  if constexpr (G::OB3 > 12) {  // the per-wave-tile kernel would need more accumulators than there are registers
+    return NF_ERR_UNSUPPORTED;
+  } else {
   const size_t lds = RqsLds<G>::BYTES;
   static AttrOnce attr_once;  // once per device: a context on another GPU needs its own
   NF_TRY(attr_once.run(ctx->device, [&]() -> int {
@@ -1108,6 +1409,7 @@ static int launch_rqs_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, float *y
   hipLaunchKernelGGL((k_rqs_bwd<G, INVD>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, y, ybar, lbar, lbar_const,
                      slab + (long)k * G::SIZE, slab_stride);
   return (int)hipGetLastError();
+  }
 }
 
 // inv_dir: reverse pass of the INVERSE coupling k at its output (see rqs_bwd_tile)
@@ -1115,12 +1417,12 @@ int nf_rqs_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, float *y, float *yb
                long N, float *slab, long slab_stride, int grid, bool inv_dir) {
   const int id = rqs_geo_id(desc);
   if (!id || !ctx->wimg) return NF_ERR_UNSUPPORTED;
-  if (inv_dir) {
-    if (id == 1) return launch_rqs_bwd<GeoK8, true>(ctx, desc, k, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid);
-    return launch_rqs_bwd<GeoK10, true>(ctx, desc, k, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid);
-  }
-  if (id == 1) return launch_rqs_bwd<GeoK8, false>(ctx, desc, k, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid);
-  return launch_rqs_bwd<GeoK10, false>(ctx, desc, k, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid);
+#define RQS_CALL(G) launch_rqs_bwd<G, true>(ctx, desc, k, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid)
+  if (inv_dir) return RQS_DISPATCH(id, RQS_CALL);
+#undef RQS_CALL
+#define RQS_CALL(G) launch_rqs_bwd<G, false>(ctx, desc, k, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid)
+  return RQS_DISPATCH(id, RQS_CALL);
+#undef RQS_CALL
 }
 
 template <class G, bool INVD>
@@ -1147,6 +1449,7 @@ int nf_rqs_bwd_all(nf_ctx *ctx, const nf_flow_desc *desc, float *y, float *ybar,
                    long N, float *slab, long slab_stride, int grid, bool inv_dir) {
   const int id = rqs_geo_id(desc);
   if (!id || !ctx->wimg) return NF_ERR_UNSUPPORTED;
+  if (id == 3) return NF_ERR_UNSUPPORTED;  // GeoK10L: cooperative per-coupling launches only
   if (inv_dir) {
     if (id == 1) return launch_rqs_bwd_all<GeoK8, true>(ctx, desc, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid);
     return launch_rqs_bwd_all<GeoK10, true>(ctx, desc, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid);

@@ -467,6 +467,51 @@ def test_nsf_properties_cfg3_shape(nf):
     assert float((ga + gb - g).abs().max()) <= 1e-4 * float(g.abs().max())
 
 
+@pytest.mark.parametrize("d,nl,n", [(32, 2, 77), (20, 1, 64), (17, 1, 33), (31, 1, 50)], ids=["d32", "d20", "d17", "d31_odd"])
+def test_nsf_reference_default_k10_up_to_d32(nf, d, nl, n):
+    """The reference's default nsf(q0): hdims [32, 32], K = 10 (src/flows/neuralspline.jl:232-234).  Up to d = 16 this
+    ran on the MFMA kernels already; 16 < d <= 32 needs 16 output blocks, which only the cooperative reverse kernel can
+    hold (k_rqs_bwd_coop: the four waves split the output columns).  Forward, inverse, ELBO, gradient, forward-KL pair
+    against the oracle."""
+    spec = o.FlowSpec("nsf", d, nl, (32, 32), 10, 5.0)
+    rng = np.random.default_rng(d)
+    th = (o.init_params(spec, rng) + 0.05 * rng.standard_normal(o.param_count(spec))).astype(np.float32)
+    flow = nf.Flow("nsf", nf.MvNormal(d), nl, (32, 32), 10, 5.0, dtype=torch.float32, device="cuda", theta=torch.tensor(th, device="cuda"))
+    xs = (rng.standard_normal((d, n)) * 1.5).astype(np.float32)
+    th64, xs64 = th.astype(np.float64), xs.astype(np.float64)
+    ys_ref, l_ref = o.flow_fwd(spec, th64, xs64)
+    ys, ladj = nf.with_logabsdet_jacobian(flow.transform, cm(xs, torch.float32))
+    tag = f"nsf K=10 d={d}"
+    fl = fp32_floor(spec, th64, xs64)
+    P.elementwise(f"{tag}: ys", ys, ys_ref, floor=fl["ys"])
+    P.elementwise(f"{tag}: ladj", ladj, l_ref, floor=fl["ladj"])
+    xr, lb = nf.with_logabsdet_jacobian(nf.inverse(flow.transform), ys)
+    P.isapprox(f"{tag}: round trip x", xr, xs64, P.INV_RTOL["nsf"], fl["rt_x"])
+    P.isapprox(f"{tag}: lj_fwd ~ -lj_bwd", lb, -ladj, P.INV_RTOL["nsf"], fl["rt_l"])
+    mu, var = rng.standard_normal(d).astype(np.float32), (rng.uniform(size=d) + 0.5).astype(np.float32)
+    tgt = nf.DiagGaussTarget(torch.tensor(mu, device="cuda"), torch.tensor(var, device="cuda"))
+    otgt = ("diaggauss", mu.astype(np.float64), var.astype(np.float64))
+    loss, g = nf.value_and_gradient(nf.elbo_batch, flow, tgt, cm(xs, torch.float32))
+    lr, gr = o.neg_elbo_value_and_grad(spec, th64, otgt, xs64)
+    P.scalar(f"{tag}: loss", loss, lr)
+    P.gradient(f"{tag}: grad", g, gr)
+    # in-library draws (fused forward) and the forward-KL pair
+    l2, g2 = nf.value_and_gradient(nf.elbo_batch, flow, tgt, n, rng=nf.PhiloxRNG(3))
+    x2 = nf.device_specific_rand(nf.PhiloxRNG(3), flow.dist, n).cpu().numpy().astype(np.float64)
+    lr2, gr2 = o.neg_elbo_value_and_grad(spec, th64, otgt, x2)
+    P.scalar(f"{tag}: loss (rng)", l2, lr2)
+    P.gradient(f"{tag}: grad (rng)", g2, gr2)
+    # forward-KL pair on data from the flow's bulk (0.7 sigma draws): the gradient through narrow outer bins is
+    # ill-conditioned in fp32 (float32-oracle floor 2e-3 of |g|inf on the 1.5 sigma data above, 5e-6 here)
+    ys2 = nf.with_logabsdet_jacobian(flow.transform, cm((xs * (0.7 / 1.5)).astype(np.float32), torch.float32))[0]
+    ysd = ys2.cpu().numpy().astype(np.float64)
+    fl_, fg_ = nf.loglikelihood_value_and_gradient(flow, ys2)
+    flr, fgr = o.neg_loglik_value_and_grad(spec, th64, ysd)
+    _, fg32 = o.neg_loglik_value_and_grad(spec, P.f32(th64), P.f32(ysd))
+    P.scalar(f"{tag}: forward-KL loss", fl_, flr, 10 * P.LOSS_RTOL)
+    P.gradient(f"{tag}: forward-KL grad", fg_, fgr, floor=fg32)
+
+
 @pytest.mark.parametrize("d,hd,nl,n", [(256, (256, 256), 1, 200), (100, (96, 130), 1, 77), (129, (40, 256), 2, 33),
                                        (120, (128, 100), 2, 150), (70, (65, 33), 1, 64)],
                          ids=["cfg4_d256_h256", "d100_h96_130", "d129_h40_256", "mid_d120_h128_100", "mid_d70_h65_33"])
