@@ -1,24 +1,38 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun): the default bench line, rocprofv3 kernel-trace statistics of the
-# same command, HBM-traffic counters (separate --pmc passes) and the cfg-4 workload.  Everything
-# lands in gpurun_out/<tag>/; the summaries worth keeping are copied to profiles/ by hand.
+# Runs on the GPU box (gpurun): the default bench line, rocprofv3 kernel-trace statistics of the same command, the
+# HBM-traffic / MFMA counter passes (separate --pmc runs, program directly after `--`), the cfg-3 and cfg-4 workloads
+# and the non-headline configurations.  Everything lands in gpurun_out/<tag>/; tools/publish_profiles.py copies the
+# summaries worth keeping to profiles/<tag>_*.
 # usage: bash tools/collect_profiles.sh <tag>
-TAG=${1:-r1}
+TAG=${1:-r2}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 python3 bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
+python3 bench.py --workload cfg3 --steps 50 --no-cpu-baseline > "$OUT/bench_cfg3.json" 2>> "$OUT/bench_default.err"
 python3 bench.py --workload cfg4 --steps 5 --warmup 2 > "$OUT/bench_cfg4_1gpu_262144.json" 2>> "$OUT/bench_default.err"
 python3 bench.py --workload cfg4 --batch 32768 --steps 10 --warmup 3 > "$OUT/bench_cfg4_shard_32768.json" 2>> "$OUT/bench_default.err"
-python3 tools/bench_configs.py --steps 20 > "$OUT/configs.txt" 2>&1
+python3 tools/bench_configs.py --steps 30 > "$OUT/configs.txt" 2>&1
+python3 tools/bench_simple.py > "$OUT/simple.txt" 2>&1
 rocprofv3 --kernel-trace --stats -d "$OUT/kt_cfg2" -o cfg2 --output-format csv -- python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-kernel-events > "$OUT/kt_cfg2.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$OUT/kt_cfg3" -o cfg3 --output-format csv -- python3 bench.py --workload cfg3 --steps 30 --warmup 5 --no-cpu-baseline --no-kernel-events > "$OUT/kt_cfg3.log" 2>&1
 rocprofv3 --kernel-trace --stats -d "$OUT/kt_cfg4" -o cfg4 --output-format csv -- python3 bench.py --workload cfg4 --batch 32768 --steps 5 --warmup 2 --no-kernel-events > "$OUT/kt_cfg4.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$OUT/kt_cfg1" -o cfg1 --output-format csv -- python3 tools/bench_configs.py --only cfg1 --steps 100 > "$OUT/kt_cfg1.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$OUT/kt_cfg5" -o cfg5 --output-format csv -- python3 tools/bench_configs.py --only cfg5 --steps 10 > "$OUT/kt_cfg5.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$OUT/kt_simple" -o simple --output-format csv -- python3 tools/bench_simple.py > "$OUT/kt_simple.log" 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C -d "$OUT/pmc_$C" -o pmc --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_$C.log" 2>&1
+  rocprofv3 --pmc $C -d "$OUT/pmc_cfg2_$C" -o pmc --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_cfg2_$C.log" 2>&1
+  rocprofv3 --pmc $C -d "$OUT/pmc_cfg3_$C" -o pmc --output-format csv -- python3 bench.py --workload cfg3 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_cfg3_$C.log" 2>&1
+  rocprofv3 --pmc $C -d "$OUT/pmc_simple_$C" -o pmc --output-format csv -- python3 tools/bench_simple.py 262144 > "$OUT/pmc_simple_$C.log" 2>&1
 done
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 -d "$OUT/pmc_mfma" -o pmc --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_mfma.log" 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 -d "$OUT/pmc_mfma_cfg4" -o pmc --output-format csv -- python3 bench.py --workload cfg4 --batch 32768 --steps 3 --warmup 1 --no-kernel-events > "$OUT/pmc_mfma_cfg4.log" 2>&1
-find "$OUT" -name "*.csv" | head -50
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 -d "$OUT/pmc_cfg2_mfma" -o pmc --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_cfg2_mfma.log" 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 -d "$OUT/pmc_cfg3_mfma" -o pmc --output-format csv -- python3 bench.py --workload cfg3 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_cfg3_mfma.log" 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU -d "$OUT/pmc_cfg3_valu" -o pmc --output-format csv -- python3 bench.py --workload cfg3 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_cfg3_valu.log" 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 -d "$OUT/pmc_cfg4_mfma" -o pmc --output-format csv -- python3 bench.py --workload cfg4 --batch 32768 --steps 3 --warmup 1 --no-kernel-events > "$OUT/pmc_cfg4_mfma.log" 2>&1
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C -d "$OUT/pmc_cfg4_$C" -o pmc --output-format csv -- python3 bench.py --workload cfg4 --batch 32768 --steps 3 --warmup 1 --no-kernel-events > "$OUT/pmc_cfg4_$C.log" 2>&1
+done
 # keep the merge-back small: per-dispatch traces can be large
-find "$OUT" -name "*kernel_trace.csv" -size +8M -delete
+find "$OUT" -name "*kernel_trace.csv" -size +4M -delete
+find "$OUT" -name "*.csv" | head -60
 du -sh "$OUT"
