@@ -53,11 +53,8 @@ __global__ __launch_bounds__(EW_BLOCK) void k_base_sample(int d, long N, uint32_
   if (valid) {
     const uint64_t gj = off + (uint64_t)j;
     for (int g = q; g < ng; g += LPS) {
-      U4 c = {(uint32_t)gj, (uint32_t)(gj >> 32), (uint32_t)g, stream};
-      const U4 r = philox4x32_10(c, k0, k1);
       T z[4];
-      box_muller<T>(r.x, r.y, z[0], z[1]);
-      box_muller<T>(r.z, r.w, z[2], z[3]);
+      philox_normals4<T>(gj, (uint32_t)g, stream, k0, k1, z);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int i = 4 * g + e;

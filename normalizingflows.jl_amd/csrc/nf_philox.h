@@ -41,13 +41,40 @@ __device__ __forceinline__ void box_muller<float>(uint32_t a, uint32_t b, float 
   z0 = rad * __builtin_amdgcn_cosf(u1);
   z1 = rad * __builtin_amdgcn_sinf(u1);
 }
-template <>
-__device__ __forceinline__ void box_muller<double>(uint32_t a, uint32_t b, double &z0, double &z1) {
-  const double u0 = ((double)(a >> 9) + 0.5) * 1.1920928955078125e-07;
-  const double u1 = ((double)(b >> 9) + 0.5) * 1.1920928955078125e-07;
+// Float64 draws: 53-bit uniforms (both 32-bit words of a pair), libm log / sincospi -- 2^53 distinct radii and angles
+// and a tail out to |z| = 8.6, where the 23-bit fp32 stream stops at 5.77 (tail-sensitive Float64 ELBOs such
+// as Funnel's).  One Philox call therefore yields TWO normals in Float64 (four in Float32).
+__device__ __forceinline__ void box_muller_f64(uint32_t a_hi, uint32_t a_lo, uint32_t b_hi, uint32_t b_lo, double &z0, double &z1) {
+  const uint64_t ua = ((uint64_t)a_hi << 21) | (uint64_t)(a_lo >> 11);  // 53 bits
+  const uint64_t ub = ((uint64_t)b_hi << 21) | (uint64_t)(b_lo >> 11);
+  const double u0 = ((double)ua + 0.5) * 1.1102230246251565e-16;  // 2^-53
+  const double u1 = ((double)ub + 0.5) * 1.1102230246251565e-16;
   const double rad = sqrt(-2.0 * log(u0));
   double s, c;
   sincospi(2.0 * u1, &s, &c);
   z0 = rad * c;
   z1 = rad * s;
+}
+
+// The four standard normals of feature group g (features 4g .. 4g+3) of global sample gj.
+//   Float32: one call, counter (gj_lo, gj_hi, g, stream): words (x, y) -> features 4g, 4g+1; (z, w) -> 4g+2, 4g+3.
+//   Float64: two calls, counters (.., g, stream) -> 4g, 4g+1 and (.., g | 2^31, stream) -> 4g+2, 4g+3, each
+//            using (x, y) and (z, w) as the high / low words of its two 53-bit uniforms.
+// Specification mirrored in oracle/nf_oracle.py:base_sample.
+template <class T>
+__device__ __forceinline__ void philox_normals4(uint64_t gj, uint32_t g, uint32_t stream, uint32_t k0, uint32_t k1, T (&z)[4]);
+template <>
+__device__ __forceinline__ void philox_normals4<float>(uint64_t gj, uint32_t g, uint32_t stream, uint32_t k0, uint32_t k1, float (&z)[4]) {
+  const U4 c = {(uint32_t)gj, (uint32_t)(gj >> 32), g, stream};
+  const U4 r = philox4x32_10(c, k0, k1);
+  box_muller<float>(r.x, r.y, z[0], z[1]);
+  box_muller<float>(r.z, r.w, z[2], z[3]);
+}
+template <>
+__device__ __forceinline__ void philox_normals4<double>(uint64_t gj, uint32_t g, uint32_t stream, uint32_t k0, uint32_t k1, double (&z)[4]) {
+  const U4 ca = {(uint32_t)gj, (uint32_t)(gj >> 32), g, stream};
+  const U4 cb = {(uint32_t)gj, (uint32_t)(gj >> 32), g | 0x80000000u, stream};
+  const U4 ra = philox4x32_10(ca, k0, k1), rb = philox4x32_10(cb, k0, k1);
+  box_muller_f64(ra.x, ra.y, ra.z, ra.w, z[0], z[1]);
+  box_muller_f64(rb.x, rb.y, rb.z, rb.w, z[2], z[3]);
 }

@@ -333,12 +333,7 @@ __device__ __forceinline__ void draw_row(const SimpleFused &fu, long j, int i0, 
   for (int m = 0; m < NG; ++m) {
     const int g = i0 / 4 + m;
     T n4[4] = {(T)0, (T)0, (T)0, (T)0};
-    if (4 * g < d) {
-      U4 c = {(uint32_t)gj, (uint32_t)(gj >> 32), (uint32_t)g, fu.stream};
-      const U4 r = philox4x32_10(c, fu.k0, fu.k1);
-      box_muller<T>(r.x, r.y, n4[0], n4[1]);
-      box_muller<T>(r.z, r.w, n4[2], n4[3]);
-    }
+    if (4 * g < d) philox_normals4<T>(gj, (uint32_t)g, fu.stream, fu.k0, fu.k1, n4);
     if constexpr (DPL >= 4) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) z[4 * m + e] = (i0 + 4 * m + e < d) ? n4[e] : (T)0;

@@ -957,31 +957,45 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
     return c0, c1, c2, c3
 
 
-def base_sample(d: int, n: int, seed: int, sample_offset: int = 0, stream: int = 0, dtype=np.float64):
+def base_sample(d: int, n: int, seed: int, sample_offset: int = 0, stream: int = 0, dtype=np.float64, precision: str = "f32"):
     """x ~ N(0, I) of shape (d, n).  Features are generated four at a time:
-    counter = (global_sample_lo, global_sample_hi, feature_group, stream),
-    key = (seed_lo, seed_hi); u = ((r >> 9) + 0.5) * 2^-23 (exactly representable in
-    fp32, so the fp32 and fp64 device paths see identical uniforms); Box-Muller on
-    (u0,u1) -> features 4g, 4g+1 and (u2,u3) -> 4g+2, 4g+3.  The global sample
-    index makes the batch invariant to how it is sharded over GPUs."""
+    counter = (global_sample_lo, global_sample_hi, feature_group, stream), key = (seed_lo, seed_hi).
+      precision "f32" (the Float32 device stream; the default, also as float64 reference values of it):
+        u = ((r >> 9) + 0.5) * 2^-23 (exactly representable in fp32); Box-Muller on (u0,u1) -> features 4g, 4g+1 and
+        (u2,u3) -> 4g+2, 4g+3.
+      precision "f64" (the Float64 device stream): 53-bit uniforms u = ((hi << 21 | lo >> 11) + 0.5) * 2^-53 from word
+        pairs (r0,r1), (r2,r3); the call with counter word 2 = g gives features 4g, 4g+1, the call with g | 2^31 gives
+        4g+2, 4g+3.
+    The global sample index makes the batch invariant to how it is sharded over GPUs."""
     ng = (d + 3) // 4
     j = np.arange(n, dtype=np.uint64) + np.uint64(sample_offset)
     jj, gg = np.meshgrid(j, np.arange(ng, dtype=np.uint32), indexing="ij")
-    r = philox4x32_10(
-        (jj & np.uint64(0xFFFFFFFF)).astype(np.uint32),
-        (jj >> np.uint64(32)).astype(np.uint32),
-        gg,
-        np.full(jj.shape, stream, dtype=np.uint32),
-        np.uint32(seed & 0xFFFFFFFF),
-        np.uint32((seed >> 32) & 0xFFFFFFFF),
-    )
-    u = [((ri >> np.uint32(9)).astype(np.float64) + 0.5) * (2.0**-23) for ri in r]
+    c0 = (jj & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    c1 = (jj >> np.uint64(32)).astype(np.uint32)
+    c3 = np.full(jj.shape, stream, dtype=np.uint32)
+    k0, k1 = np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF)
     out = np.empty((n, ng, 4), dtype=np.float64)
-    for a in (0, 1):
-        rad = np.sqrt(-2.0 * np.log(u[2 * a]))
-        ang = 2.0 * np.pi * u[2 * a + 1]
-        out[:, :, 2 * a] = rad * np.cos(ang)
-        out[:, :, 2 * a + 1] = rad * np.sin(ang)
+    if precision == "f32":
+        r = philox4x32_10(c0, c1, gg, c3, k0, k1)
+        u = [((ri >> np.uint32(9)).astype(np.float64) + 0.5) * (2.0**-23) for ri in r]
+        for a in (0, 1):
+            rad = np.sqrt(-2.0 * np.log(u[2 * a]))
+            ang = 2.0 * np.pi * u[2 * a + 1]
+            out[:, :, 2 * a] = rad * np.cos(ang)
+            out[:, :, 2 * a + 1] = rad * np.sin(ang)
+    elif precision == "f64":
+        for a, word2 in ((0, gg), (1, gg | np.uint32(0x80000000))):
+            r = philox4x32_10(c0, c1, word2, c3, k0, k1)
+            u = []
+            for hi, lo in ((r[0], r[1]), (r[2], r[3])):
+                bits = (hi.astype(np.uint64) << np.uint64(21)) | (lo.astype(np.uint64) >> np.uint64(11))
+                u.append((bits.astype(np.float64) + 0.5) * (2.0**-53))
+            rad = np.sqrt(-2.0 * np.log(u[0]))
+            ang = 2.0 * np.pi * u[1]
+            out[:, :, 2 * a] = rad * np.cos(ang)
+            out[:, :, 2 * a + 1] = rad * np.sin(ang)
+    else:
+        raise ValueError(precision)
     return out.reshape(n, ng * 4)[:, :d].T.copy().astype(dtype)
 
 

@@ -179,10 +179,17 @@ def test_base_sampler_matches_spec_and_is_shard_invariant(nf):
     r2 = nf.PhiloxRNG(123, sample_offset=600)
     xb = nf.device_specific_rand(r2, nf.MvNormal(d), 400).cpu().numpy()
     np.testing.assert_array_equal(xb, x[:, 600:])
+    # Float64 draws have their own stream: 53-bit uniforms, two normals per Philox call (oracle precision="f64")
     x64 = nf.device_specific_rand(nf.PhiloxRNG(123), nf.MvNormal(d), n, dtype=torch.float64).cpu().numpy()
-    np.testing.assert_allclose(x64, ref, rtol=0, atol=1e-13)
+    ref64 = o.base_sample(d, n, seed=123, precision="f64")
+    np.testing.assert_allclose(x64, ref64, rtol=0, atol=1e-13)
+    assert np.abs(ref64 - ref).max() > 1e-3  # ... it is a different stream, not the fp32 one widened
+    x64b = nf.device_specific_rand(nf.PhiloxRNG(123, sample_offset=600), nf.MvNormal(d), 400, dtype=torch.float64).cpu().numpy()
+    np.testing.assert_array_equal(x64b, x64[:, 600:])
     lq = nf.logpdf(nf.MvNormal(d), torch.tensor(x64.T.copy(), device="cuda").t()).cpu().numpy()
-    np.testing.assert_allclose(lq, o.std_normal_logpdf(ref), rtol=1e-12)
+    np.testing.assert_allclose(lq, o.std_normal_logpdf(ref64), rtol=1e-12)
+    big64 = nf.device_specific_rand(nf.PhiloxRNG(7), nf.MvNormal(64), 65536, dtype=torch.float64)
+    assert abs(float(big64.mean())) < 2e-3 and abs(float(big64.var()) - 1.0) < 5e-3 and float(big64.abs().max()) > 4.5
     big = nf.device_specific_rand(nf.PhiloxRNG(7), nf.MvNormal(64), 65536)
     assert abs(float(big.mean())) < 2e-3 and abs(float(big.var()) - 1.0) < 5e-3
 
@@ -987,7 +994,7 @@ def test_general_mvnormal_base(nf, bkind, maker):
     # draws and density of q0 itself
     xs = nf.device_specific_rand(nf.PhiloxRNG(13), q0, n)
     assert xs.shape == (d, n) and xs.dtype == dt
-    x_ref = o.base_unwhiten(obase, o.base_sample(d, n, seed=13))
+    x_ref = o.base_unwhiten(obase, o.base_sample(d, n, seed=13, precision="f64" if f64 else "f32"))
     P.elementwise(f"{tag}: draws mu + L eps", xs, x_ref, *ew)
     xs64 = xs.cpu().numpy().astype(np.float64)
     P.elementwise(f"{tag}: logpdf(q0, xs)", nf.logpdf(q0, xs), o.base_logpdf(obase, xs64), *ew)
@@ -1116,7 +1123,7 @@ def test_rand_flow_matches_oracle_transform_of_oracle_draws(nf, maker):
     n, off = 131, 1000
     ys = nf.rand(flow, n, nf.PhiloxRNG(21, sample_offset=off))
     assert ys.shape == (d, n) and ys.dtype == dt
-    x_ref = o.base_sample(d, n, seed=21, sample_offset=off, stream=0)
+    x_ref = o.base_sample(d, n, seed=21, sample_offset=off, stream=0, precision="f64" if dtn == "float64" else "f32")
     y_ref, _ = o.flow_fwd(spec, th, x_ref)
     f64 = dtn == "float64"
     # fp32: the device draws carry Box-Muller round-off (3e-6 abs, test_base_sampler...), which the flow amplifies like

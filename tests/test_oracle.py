@@ -388,3 +388,17 @@ def test_composite_flow_gradient_matches_finite_differences():
     xr, lb = o.comp_inv(specs, th, ys)
     np.testing.assert_allclose(xr, xs, rtol=1e-6, atol=1e-8)
     np.testing.assert_allclose(lf, -lb, rtol=1e-6, atol=1e-8)
+
+
+def test_float64_base_stream_has_53_bit_uniforms_and_reaches_the_tails():
+    """The Float64 draw stream (oracle precision="f64", mirrored by philox_normals4<double> on the device): standard
+    normal moments, shard invariance, and tails beyond the |z| <= 5.77 cap of the 23-bit Float32 stream."""
+    x = o.base_sample(8, 200000, seed=5, precision="f64")
+    assert abs(x.mean()) < 5e-3 and abs(x.var() - 1.0) < 1e-2
+    b = o.base_sample(8, 100, seed=5, sample_offset=199900, precision="f64")
+    np.testing.assert_array_equal(b, x[:, 199900:])
+    x32 = o.base_sample(8, 200000, seed=5)
+    # the 23-bit stream cannot exceed sqrt(-2 log 2^-24); the 53-bit one can (not necessarily within 1.6 M draws, but its cap is 8.6)
+    assert np.abs(x32).max() <= np.sqrt(-2.0 * np.log(2.0**-24)) + 1e-9
+    u_min_53 = 0.5 * 2.0**-53
+    assert np.sqrt(-2.0 * np.log(u_min_53)) > 8.5
