@@ -402,3 +402,25 @@ def test_float64_base_stream_has_53_bit_uniforms_and_reaches_the_tails():
     assert np.abs(x32).max() <= np.sqrt(-2.0 * np.log(2.0**-24)) + 1e-9
     u_min_53 = 0.5 * 2.0**-53
     assert np.sqrt(-2.0 * np.log(u_min_53)) > 8.5
+
+
+def test_cpp_openmp_baseline_matches_the_oracle():
+    """bench.py's second CPU baseline (oracle/nf_cpu_step.cpp, built at run time): loss and gradient of the RealNVP step
+    on supplied draws against the numpy oracle (fp32 arithmetic with -ffast-math, so fp32-level agreement), odd d."""
+    import nf_cpu_omp as co
+
+    if co.load() is None:
+        pytest.skip("no C++ compiler on this host")
+    for d, hd, nl in ((7, (16, 12), 2), (64, (64, 64), 1)):
+        spec = o.FlowSpec("realnvp", d, nl, hd)
+        rng = np.random.default_rng(d)
+        th = (o.init_params(spec, rng) + 0.05 * rng.standard_normal(o.param_count(spec))).astype(np.float32)
+        xs = rng.standard_normal((d, 128)).astype(np.float32)
+        mu, var = rng.standard_normal(d).astype(np.float32), (rng.uniform(size=d) + 0.5).astype(np.float32)
+        l_ref, g_ref = o.neg_elbo_value_and_grad(spec, th.astype(np.float64), ("diaggauss", mu.astype(np.float64), var.astype(np.float64)),
+                                                 xs.astype(np.float64))
+        loss, g = co.value_and_grad(d, hd, nl, th, mu, var, xs, nthreads=3)
+        assert loss == pytest.approx(l_ref, rel=2e-5)
+        assert np.abs(g - g_ref).max() <= 2e-4 * np.abs(g_ref).max()
+    r = co.time_training_steps(8, (16, 16), 1, 256, threads=2, seconds_budget=0.2, max_steps=3)
+    assert r["value"] > 0 and np.isfinite(r["loss"])
