@@ -85,7 +85,7 @@ for case in range(ncases):
         nl = int(rng.integers(1, 3))
     elif kind == "nsf":
         K = int(rng.choice([8, 10, 5]))
-        d = int(rng.integers(2, 33 if K == 8 else 17))
+        d = int(rng.integers(2, 33 if K in (8, 10) else 17))
         hd = (int(rng.integers(1, 33)), int(rng.integers(1, 33)))
         nl = int(rng.integers(1, 3))
     else:
