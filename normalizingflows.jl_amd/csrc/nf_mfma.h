@@ -56,7 +56,17 @@ __device__ __forceinline__ unsigned nf_sign_mask16(const f32x16 &v) {
   asm volatile("" : "+v"(bits));
   return bits;
 }
-__device__ __forceinline__ float nf_mask_slope(unsigned mask, int r) { return ((mask >> (15 - r)) & 1u) ? 0.01f : 1.f; }
+// slope of element r from the packed mask: sign-extend its bit (v_bfe_i32 -> 0 / -1) and blend the two constants'
+// bit patterns with it (v_bfi_b32): two instructions, no VCC round trip (the select form costs v_and + v_cmp + s_nop +
+// v_cndmask per element)
+__device__ __forceinline__ float nf_mask_slope(unsigned mask, int r) {
+#ifdef NF_SLOPE_SELECT  // the round-1 form, kept for A/B measurements
+  return ((mask >> (15 - r)) & 1u) ? 0.01f : 1.f;
+#else
+  const unsigned t = (unsigned)__builtin_amdgcn_sbfe((int)mask, 15 - r, 1);
+  return __builtin_bit_cast(float, (t & 0x3C23D70Au) | (~t & 0x3F800000u));
+#endif
+}
 __device__ __forceinline__ float nf_exp(float x) { return __expf(x); }
 
 // LDS image of one Dense layer: W[i][o] at w[i * S + o], S = 32*OB + 1 (odd stride so
