@@ -248,7 +248,9 @@ int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, const nf_targe
  *   out[0..P) = sum_{j in shard} d(-loglik_j / N_global)/dtheta,   out[P] = sum (-loglik_j / N_global).
  * The chain is inverted once; its reverse pass walks the layers in forward order with the
  * implicit-function form of each inverse (no root-find or spline inversion is differentiated); the
- * Hamiltonian flow's inverse layers are explicit (LeapFrog with -eps) and are differentiated directly. */
+ * Hamiltonian flow's inverse layers are explicit (LeapFrog with -eps) and are differentiated directly.
+ * A general desc->base seeds the reverse pass with that base's score -Sigma^-1 (z - mu); a composite is
+ * inverted and differentiated segment by segment. */
 int nf_loglikelihood_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta,
                                     const void *ys, int64_t N_local, int64_t N_global,
                                     void *out_grad_loss);

@@ -12,6 +12,8 @@ int nf_launch_base_logpdf(nf_ctx *, int, int, long, const void *, void *);
 int nf_launch_base_unwhiten(nf_ctx *, int dtype, int kind, int d, long N, const void *mu, const void *scale, void *x);
 int nf_launch_base_general_logpdf(nf_ctx *, int dtype, int kind, int d, long N, const void *mu, const void *scale, double logdet,
                                   const void *x, void *logq_out, void *corr_out, void *zbuf);
+int nf_launch_base_general_score(nf_ctx *, int dtype, int kind, int d, long N, const void *mu, const void *scale, double logdet,
+                                 const void *x, void *logq_out, void *score_out, double gscale, void *zbuf);
 long nf_target_nblocks(long N);
 int nf_launch_target(nf_ctx *, int, const nf_target *, int, long, const void *, const void *, const void *, void *,
                      void *, double, void *, double *, double, int joint_d);
@@ -478,6 +480,9 @@ static int value_and_grad_composite(nf_ctx *ctx, const nf_flow_desc *desc, const
 static int value_and_grad_general_base(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, const void *theta,
                                        const void *xs, int64_t N_local, int64_t N_global, uint64_t seed, uint64_t sample_offset,
                                        uint32_t stream_id, void *out);
+static int fkl_general(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *ys, int64_t N_local,
+                       int64_t N_global, void *out);
+static size_t fkl_general_need(nf_ctx *ctx, const nf_flow_desc *desc, long N);
 
 // ---- base distribution ---------------------------------------------------------------------
 extern "C" int nf_base_sample_logpdf(nf_ctx *ctx, int32_t dtype, int32_t d, int64_t N, uint64_t seed,
@@ -884,8 +889,8 @@ extern "C" int nf_loglikelihood_value_and_grad(nf_ctx *ctx, const nf_flow_desc *
   if (!ctx || !theta || !out || N_local < 0 || N_global < 1 || (N_local > 0 && !ys)) return NF_ERR_ARG;
   NF_TRY(check_desc(desc));
   NF_HIP(hipSetDevice(ctx->device));
-  if (flow_base(desc)) return NF_ERR_UNSUPPORTED;  // forward-KL training is built for the standard-normal base only
-  if (is_composite(desc)) return NF_ERR_UNSUPPORTED;  // ... and for single-family flows
+  // general bases and heterogeneous compositions: segment by segment in the standard layout (fkl_general below)
+  if (flow_base(desc) || is_composite(desc)) return fkl_general(ctx, desc, theta, ys, N_local, N_global, out);
   const long N = N_local;
   const long P = nf_param_count(desc);
   const int dt = desc->dtype;
@@ -946,6 +951,146 @@ extern "C" int nf_loglikelihood_value_and_grad(nf_ctx *ctx, const nf_flow_desc *
   return nf_launch_finish_sum(ctx, partial, nb, 0, (double *)out + P, nullptr, nullptr);
 }
 
+
+// ---- forward-KL for general bases and heterogeneous compositions --------------------------------------------
+// The same computation as above, assembled from per-segment pieces in the standard layout: z_0 = ys,
+// z_{s+1} = T_s^-1(z_s) with every z kept; the seed is the base's own score, -Sigma^-1 (z - mu) (k_base_general_score;
+// the standard normal goes through the diagonal-Gaussian target kernel as above); then the reverse pass of each
+// segment's inverse, last segment first.  A single-family flow over a general base is the one-segment case.
+
+static size_t composite_inner_need(nf_ctx *ctx, const nf_flow_desc *desc, long N);
+static long seg_theta_off(const nf_flow_desc *desc, int s);
+
+// reverse pass of ONE homogeneous segment's inverse: yin = the segment's inverse input, zout = its inverse output
+// (clobbered), gbar = cotangent of zout on entry, of yin on exit; gtheta_out = the segment's parameter gradient.
+// Intermediates come from the front of the context workspace.
+static int inv_bwd_std(nf_ctx *ctx, const nf_flow_desc *g, const void *theta, const void *yin, void *zout, void *gbar,
+                       double lbar_const, long N, void *gtheta_out) {
+  const size_t es = esize(g->dtype);
+  if (is_coupling(g)) {
+    const int grid = coupling_bwd_grid(ctx, g, N);
+    const size_t te = tiled_elems(g, N);
+    const size_t slabf = (size_t)grid * coupling_slab_floats(ctx, g, N);
+    NF_TRY(nf_ws_reserve(ctx, 2 * carve_bytes(te * 4) + carve_bytes(slabf * 4)));
+    Carver cv(ctx->ws);
+    float *state = cv.take<float>(te);
+    float *gt = cv.take<float>(te);
+    float *slab = cv.take<float>(slabf);
+    NF_TRY(coupling_pack(ctx, g, (const float *)theta));
+    NF_TRY(nf_launch_layout_convert(ctx, g->d, N, (const float *)zout, state, 1));
+    NF_TRY(nf_launch_layout_convert(ctx, g->d, N, (const float *)gbar, gt, 1));
+    NF_TRY(coupling_inv_bwd(ctx, g, (const float *)theta, state, gt, (float)lbar_const, N, slab, grid, (float *)gtheta_out));
+    return nf_launch_layout_convert(ctx, g->d, N, gt, (float *)gbar, 0);
+  }
+  if (g->kind == NF_KIND_HAMILTONIAN) {  // single-segment only (check_composite): the data cotangent is not needed
+    NF_TRY(nf_ws_reserve(ctx, nf_hf_bwd_ws_bytes(g, N)));
+    return nf_hf_bwd_inv(ctx, g, theta, yin, gbar, lbar_const, N, gtheta_out, ctx->ws);
+  }
+  if (is_g64(g)) {
+    NF_TRY(nf_ws_reserve(ctx, nf_g64_bwd_inv_ws_bytes(g, N)));
+    return nf_g64_bwd_inv(ctx, g, theta, zout, gbar, lbar_const, N, gtheta_out, ctx->ws);
+  }
+  // planar / radial / mean-field: the inverse again with every layer's point stashed (the same z), then the reverse pass
+  const size_t sw = nf_simple_bwd_ws_bytes(ctx, g, N);
+  NF_TRY(nf_ws_reserve(ctx, carve_bytes(sw) + carve_bytes((size_t)N * es)));
+  char *scr_ladj = (char *)ctx->ws + carve_bytes(sw);
+  NF_TRY(nf_simple_apply_stash(ctx, g, theta, yin, N, zout, scr_ladj, ctx->ws, true));
+  return nf_simple_bwd(ctx, g, theta, zout, gbar, nullptr, lbar_const, N, gbar, gtheta_out, ctx->ws, true, true);
+}
+
+static inline long fkl_general_nb(long N) {
+  const long a = nf_target_nblocks(N), b = nf_sum2_nblocks(N);
+  return a > b ? a : b;
+}
+static size_t fkl_general_extra(const nf_flow_desc *desc, long N) {
+  const size_t es = esize(desc->dtype);
+  const nf_base *b = flow_base(desc);
+  const int ns = is_composite(desc) ? desc->nsegments : 1;
+  const size_t xb = carve_bytes((size_t)N * desc->d * es), cn = carve_bytes((size_t)N * es);
+  return (size_t)(ns + 1 + (b && b->kind == NF_BASE_DENSE ? 1 : 0)) * xb + 3 * cn + carve_bytes((size_t)fkl_general_nb(N) * 8) +
+         carve_bytes(2 * (size_t)desc->d * es);
+}
+static size_t fkl_general_inner(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
+  if (is_composite(desc)) return composite_inner_need(ctx, desc, N);
+  nf_flow_desc inner = *desc;
+  inner.base = nullptr;
+  return ws_need_bound(ctx, &inner, N);
+}
+static size_t fkl_general_need(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
+  return fkl_general_inner(ctx, desc, N) + fkl_general_extra(desc, N);
+}
+
+static int fkl_general(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *ys, int64_t N_local,
+                       int64_t N_global, void *out) {
+  const long N = N_local;
+  const long P = nf_param_count(desc);
+  const int dt = desc->dtype;
+  const size_t es = esize(dt);
+  if (N == 0) return nf_launch_fill(ctx, dt, out, P + 1, 0.0);
+  const double inv = 1.0 / (double)N_global;
+  const nf_base *b = flow_base(desc);
+  nf_flow_desc single = *desc;
+  single.base = nullptr;
+  const bool comp = is_composite(desc);
+  const nf_flow_desc *segs = comp ? desc->segments : &single;
+  const int ns = comp ? desc->nsegments : 1;
+  if (!comp) {  // the shapes the single-family entry point refuses
+    const bool coupling_kind = single.kind == NF_KIND_REALNVP || single.kind == NF_KIND_NSF;
+    if (coupling_kind && !is_coupling(&single) && !nf_g64_supported(&single)) return NF_ERR_UNSUPPORTED;
+  }
+  const size_t in_need = fkl_general_inner(ctx, desc, N);
+  const size_t prev_guard = ctx->ws_guard;
+  NF_TRY(nf_ws_reserve(ctx, in_need + fkl_general_extra(desc, N)));
+  GuardReset gr{ctx, prev_guard};
+  Carver cv((char *)ctx->ws + in_need);
+  const size_t xe = (size_t)N * desc->d;
+  char *z[65];
+  for (int s = 1; s <= ns; ++s) z[s] = cv.take<char>(xe * es);
+  char *gbar = cv.take<char>(xe * es);
+  char *zbuf = (b && b->kind == NF_BASE_DENSE) ? cv.take<char>(xe * es) : nullptr;
+  char *ladj = cv.take<char>((size_t)N * es);
+  char *tmp = cv.take<char>((size_t)N * es);
+  char *logq = cv.take<char>((size_t)N * es);
+  double *partial = cv.take<double>(fkl_general_nb(N));
+  char *q0par = cv.take<char>(2 * (size_t)desc->d * es);
+  ctx->ws_guard = in_need;  // the segments' own intermediates stay in front of these buffers
+
+  auto seg_theta = [&](int s) -> const char * {
+    return comp ? (const char *)theta + (size_t)seg_theta_off(desc, s) * es : (const char *)theta;
+  };
+  // the inverse chain, every segment output kept
+  for (int s = 0; s < ns; ++s) {
+    const void *in = s == 0 ? ys : (const void *)z[s];
+    NF_TRY(apply_std(ctx, &segs[s], true, -1, seg_theta(s), in, N, z[s + 1], s == 0 ? ladj : tmp));
+    if (s > 0) NF_TRY(nf_launch_sum2(ctx, dt, N, ladj, tmp, ladj, partial, 0.0));
+  }
+  // loss partials and the seed  gbar = -(1/Ng) dlog q0/dz
+  long nbl;
+  if (b) {
+    NF_TRY(nf_launch_base_general_score(ctx, dt, b->kind, desc->d, N, b->mu, b->scale, b->logdet, z[ns], logq, gbar, -inv, zbuf));
+    NF_TRY(nf_launch_sum2(ctx, dt, N, logq, ladj, nullptr, partial, -inv));
+    nbl = nf_sum2_nblocks(N);
+  } else {
+    nf_target q0;
+    q0.kind = NF_TARGET_DIAGGAUSS;
+    q0.p0 = q0par;
+    q0.p1 = q0par + (size_t)desc->d * es;
+    q0.s0 = q0.s1 = 0.0;
+    NF_TRY(nf_launch_fill(ctx, dt, q0par, desc->d, 0.0));
+    NF_TRY(nf_launch_fill(ctx, dt, q0par + (size_t)desc->d * es, desc->d, 1.0));
+    NF_TRY(nf_launch_target(ctx, dt, &q0, desc->d, N, z[ns], nullptr, ladj, nullptr, gbar, -inv, nullptr, partial, -inv, 0));
+    nbl = nf_target_nblocks(N);
+  }
+  if (dt == NF_DTYPE_F32) NF_TRY(nf_launch_finish_sum(ctx, partial, nbl, 0, nullptr, (float *)out + P, nullptr));
+  else NF_TRY(nf_launch_finish_sum(ctx, partial, nbl, 0, (double *)out + P, nullptr, nullptr));
+  // the reverse pass of the inverse chain, last segment first
+  for (int s = ns - 1; s >= 0; --s) {
+    const void *in = s == 0 ? ys : (const void *)z[s];
+    const long off = comp ? seg_theta_off(desc, s) : 0;
+    NF_TRY(inv_bwd_std(ctx, &segs[s], seg_theta(s), in, z[s + 1], gbar, -inv, N, (char *)out + (size_t)off * es));
+  }
+  return NF_OK;
+}
 
 // ---- heterogeneous compositions: create_flow((L1, ..., Ln), q0) with mixed families ---------------------
 // (src/flows/utils.jl:23-26.)  A composite is a list of homogeneous segments in flat order; every operation chains
@@ -1507,6 +1652,10 @@ extern "C" int64_t nf_workspace_bytes(nf_ctx *ctx, const nf_flow_desc *desc, int
   const bool cp = is_coupling(desc);
   const long P = nf_param_count(desc);
   size_t need = ws_need_bound(ctx, desc, N) + base_extra_bytes(desc, N);
+  if (flow_base(desc) || is_composite(desc)) {  // nf_loglikelihood_value_and_grad's segment-wise form
+    const size_t f = fkl_general_need(ctx, desc, N);
+    if (f > need) need = f;
+  }
   // nf_adam_update / nf_sgd_update: gradient-norm partials at the tail of the intermediates arena
   need += carve_bytes((size_t)nf_adam_nblocks(P) * 8);
   // packed weight images, nf_elbo_step's [grad ; loss ; norm] buffer

@@ -146,6 +146,45 @@ __global__ __launch_bounds__(EW_BLOCK) void k_base_general_logpdf(int kind, int 
   if (corr_out) corr_out[j] = (c0 - (T)0.5 * s0) - lq;
 }
 
+// logq_out[j] = logpdf(base, x_j) and score_out[j] = gscale * d logpdf(base, x_j) / dx = -gscale * Sigma^-1 (x_j - mu):
+// the seed of the forward-KL reverse pass for a general base (src/objectives/loglikelihood.jl:27-36 with flow.dist a
+// general MvNormal).  Dense: L z = x - mu forwards, then L' w = z backwards, both in the sample's row of zbuf.
+template <class T>
+__global__ __launch_bounds__(EW_BLOCK) void k_base_general_score(int kind, int d, long N, const T *__restrict__ mu,
+                                                                 const T *__restrict__ scale, T logdet,
+                                                                 const T *__restrict__ x, T *__restrict__ logq_out,
+                                                                 T *__restrict__ score_out, T gscale, T *__restrict__ zbuf) {
+  const long j = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
+  if (j >= N) return;
+  const T *r = x + j * d;
+  T *g = score_out + j * d;
+  T ss = 0;
+  if (kind == NF_BASE_DIAG) {
+    for (int i = 0; i < d; ++i) {
+      const T z = (r[i] - mu[i]) / scale[i];
+      ss += z * z;
+      g[i] = -gscale * z / scale[i];
+    }
+  } else {
+    T *z = zbuf + j * d;
+    for (int i = 0; i < d; ++i) {
+      T acc = r[i] - mu[i];
+      for (int k = 0; k < i; ++k) acc -= scale[(long)k * d + i] * z[k];
+      const T zi = acc / scale[(long)i * d + i];
+      z[i] = zi;
+      ss += zi * zi;
+    }
+    for (int i = d - 1; i >= 0; --i) {  // (L')[i][k] = L[k][i], k > i: column i of L below the diagonal
+      T acc = z[i];
+      for (int k = i + 1; k < d; ++k) acc -= scale[(long)i * d + k] * z[k];
+      const T wi = acc / scale[(long)i * d + i];
+      z[i] = wi;
+      g[i] = -gscale * wi;
+    }
+  }
+  if (logq_out) logq_out[j] = (T)(-0.5 * 1.8378770664093453 * d) - logdet - (T)0.5 * ss;
+}
+
 int nf_launch_base_unwhiten(nf_ctx *ctx, int dtype, int kind, int d, long N, const void *mu, const void *scale, void *x) {
   if (N <= 0) return NF_OK;
   const unsigned grid = (unsigned)((N + EW_BLOCK - 1) / EW_BLOCK);
@@ -170,6 +209,22 @@ int nf_launch_base_general_logpdf(nf_ctx *ctx, int dtype, int kind, int d, long 
   else
     hipLaunchKernelGGL(k_base_general_logpdf<double>, dim3(grid), dim3(EW_BLOCK), 0, ctx->stream, kind, d, N, (const double *)mu,
                        (const double *)scale, logdet, (const double *)x, (double *)logq_out, (double *)corr_out, (double *)zbuf);
+  return (int)hipGetLastError();
+}
+
+int nf_launch_base_general_score(nf_ctx *ctx, int dtype, int kind, int d, long N, const void *mu, const void *scale,
+                                 double logdet, const void *x, void *logq_out, void *score_out, double gscale, void *zbuf) {
+  if (N <= 0) return NF_OK;
+  const unsigned grid = (unsigned)((N + EW_BLOCK - 1) / EW_BLOCK);
+  ProfScope ps(ctx, "base_score");
+  if (dtype == NF_DTYPE_F32)
+    hipLaunchKernelGGL(k_base_general_score<float>, dim3(grid), dim3(EW_BLOCK), 0, ctx->stream, kind, d, N, (const float *)mu,
+                       (const float *)scale, (float)logdet, (const float *)x, (float *)logq_out, (float *)score_out,
+                       (float)gscale, (float *)zbuf);
+  else
+    hipLaunchKernelGGL(k_base_general_score<double>, dim3(grid), dim3(EW_BLOCK), 0, ctx->stream, kind, d, N, (const double *)mu,
+                       (const double *)scale, logdet, (const double *)x, (double *)logq_out, (double *)score_out, gscale,
+                       (double *)zbuf);
   return (int)hipGetLastError();
 }
 

@@ -1096,6 +1096,48 @@ def loglikelihood_base(spec, theta, ys, base):
     return (base_logpdf(base, xs) + ladj).mean()
 
 
+def base_score(base, x):
+    """d logpdf(base, x) / dx per column: -Sigma^-1 (x - mu)."""
+    if base is None:
+        return -x
+    kind, mu, sc = base
+    r = x - mu[:, None]
+    if kind == "diag":
+        return -r / (sc * sc)[:, None]
+    import scipy.linalg
+
+    z = scipy.linalg.solve_triangular(sc, r, lower=True)
+    return -scipy.linalg.solve_triangular(sc.T, z, lower=False)
+
+
+def comp_neg_loglik_value_and_grad(specs, theta, ys, base=None, n_global=None):
+    """-loglikelihood(flow, ys) and its gradient (src/objectives/loglikelihood.jl:26-33 through src/optimize.jl:77,86)
+    for a composition of homogeneous segments (one segment: a single-family flow) over any MvNormal base:
+    the segments are inverted first to last, log q0 is the base's own density, and the reverse pass walks the
+    inverse chain backwards -- last segment first, each one's layers in forward execution order."""
+    n = ys.shape[1]
+    ng = n if n_global is None else n_global
+    sl = _comp_slices(specs)
+    outs, w, ladj = [], ys, np.zeros(n, dtype=ys.dtype)
+    for s in range(len(specs)):
+        w, l = flow_inv(specs[s], theta[sl[s][0] : sl[s][1]], w)
+        outs.append(w)
+        ladj = ladj + l
+    loss = -(base_logpdf(base, w) + ladj).sum() / ng
+    a = (-base_score(base, w) / ng).astype(ys.dtype)
+    c = np.full(n, -1.0 / ng, dtype=ys.dtype)
+    grad = np.zeros_like(theta)
+    for s in range(len(specs) - 1, -1, -1):
+        th = theta[sl[s][0] : sl[s][1]]
+        g = np.zeros_like(th)
+        w = outs[s]
+        for li in reversed(layers_flat_order(specs[s])):
+            a = _layer_inv_bwd(specs[s], th, li, w, a, c, g)
+            w, _ = _layer_fwd(specs[s], th, li, w)
+        grad[sl[s][0] : sl[s][1]] = g
+    return loss, grad
+
+
 # --------------------------------------------------------------------------
 # Hamiltonian flow (example/demo_hamiltonian_flow.jl:27-146): a mean-field Gaussian reference on the joint
 # z = [x; rho] followed by n blocks (momentum Shift o Scale) o LeapFrog(L steps, per-dimension step sizes

@@ -1019,8 +1019,27 @@ def test_general_mvnormal_base(nf, bkind, maker):
     ll = nf.loglikelihood(None, flow, ys)
     P.scalar(f"{tag}: loglikelihood", ll, o.loglikelihood_base(spec, th, ys.cpu().numpy().astype(np.float64), obase), 10 * lr, 10 * lr)
     P.elementwise(f"{tag}: logpdf(flow, ys)", nf.logpdf(flow, ys), o.base_logpdf(obase, xs64) - l_ref, 10 * ew[0], 10 * ew[1])
-    with pytest.raises(nf.NFHipError, match="not built"):
-        nf.loglikelihood_value_and_gradient(flow, ys)  # forward-KL training: standard-normal base only
+    # forward-KL training over the general base: train_flow(loglikelihood, flow, ys), a shard of it too
+    ys64 = ys.cpu().numpy().astype(np.float64)
+    if kind == "nsf" and not f64:
+        # A spline's parameter gradient jumps where a point crosses a knot; a data point within float32 rounding of one
+        # is assigned either bin by float32 arithmetic (the float32 ORACLE differs from the float64 one by 2.4e-4 |g|inf
+        # on one such sample here).  Those knife-edge samples are left out of the gradient comparison.
+        gs = np.abs(o.comp_neg_loglik_value_and_grad([spec], th, ys64, obase)[1]).max()
+        keep = [j for j in range(n) if np.abs(
+            o.comp_neg_loglik_value_and_grad([spec], th, ys64[:, j:j + 1], obase, n)[1] -
+            o.comp_neg_loglik_value_and_grad([spec], *P.f32(th, ys64[:, j:j + 1]), P.f32(obase), n)[1]).max() <= 1e-5 * gs]
+        assert len(keep) >= n - 5
+        ys, ys64, n = ys[:, keep].contiguous(), ys64[:, keep], len(keep)
+    lf, gf = nf.loglikelihood_value_and_gradient(flow, ys)
+    lfo, gfo = o.comp_neg_loglik_value_and_grad([spec], th, ys64, obase)
+    fl = None if f64 else o.comp_neg_loglik_value_and_grad([spec], *P.f32(th, ys64), P.f32(obase))
+    P.scalar(f"{tag}: forward-KL loss", lf, lfo, 10 * lr, 10 * lr)
+    P.gradient(f"{tag}: forward-KL grad", gf, gfo, P.F64_GRAD if f64 else P.GRAD_RTOL, None if f64 else fl[1])
+    la, ga = nf.loglikelihood_value_and_gradient(flow, ys[:, :70], n_global=n)
+    lb_, gb = nf.loglikelihood_value_and_gradient(flow, ys[:, 70:], n_global=n)
+    P.scalar(f"{tag}: forward-KL loss, two shards", la + lb_, lfo, 10 * lr, 10 * lr)
+    P.gradient(f"{tag}: forward-KL grad, two shards", ga + gb, gfo, P.F64_GRAD if f64 else P.GRAD_RTOL, None if f64 else fl[1])
 
 
 @pytest.mark.parametrize("dtn", ["float32", "float64"])
@@ -1093,8 +1112,15 @@ def test_heterogeneous_create_flow(nf, dtn, general_base):
     # training runs through the composite like through any flow
     trained, stats, st = nf.train_flow(nf.PhiloxRNG(1), nf.elbo_batch, flow, tgt, 256, max_iters=5, optimiser=nf.Adam(1e-3))
     assert isinstance(trained, nf.CompositeFlow) and np.isfinite(stats[-1]["loss"]) and st.t == 5
-    with pytest.raises(nf.NFHipError, match="not built"):
-        nf.loglikelihood_value_and_gradient(flow, ys)
+    # forward-KL training through the composition (and over the general base)
+    ys64 = ys.cpu().numpy().astype(np.float64)
+    lf, gf = nf.loglikelihood_value_and_gradient(flow, ys)
+    lfo, gfo = o.comp_neg_loglik_value_and_grad(specs, th, ys64, obase)
+    fl = None if f64 else o.comp_neg_loglik_value_and_grad(specs, *P.f32(th, ys64), P.f32(obase) if obase else None)
+    P.scalar(f"{tag}: forward-KL loss", lf, lfo, 10 * lr, 10 * lr)
+    P.gradient(f"{tag}: forward-KL grad", gf, gfo, P.F64_GRAD if f64 else P.GRAD_RTOL, None if f64 else fl[1])
+    trained, stats, st = nf.train_flow(nf.loglikelihood, flow, ys, max_iters=5, optimiser=nf.Adam(1e-3))
+    assert isinstance(trained, nf.CompositeFlow) and stats[-1]["loss"] < stats[0]["loss"] and st.t == 5
 
 
 RAND_CASES = {
