@@ -68,8 +68,8 @@ extern "C" {
                                order (segment 0 = outermost = applied last), each a descriptor of one of the kinds above
                                with the same d / dtype; theta = the segments' thetas concatenated in that order, which is
                                the order Optimisers.destructure walks the composition.  Forward, inverse, per-layer
-                               application, rand, elbo / elbo_batch, the training step and loglikelihood are built
-                               (the reverse pass chains the segments' own reverse passes); forward-KL training is not. */
+                               application, rand, elbo / elbo_batch, the training step, loglikelihood, forward-KL
+                               training and nf_flow_bwd are all built (reverse passes chain the segments' own). */
 
 #define NF_DTYPE_F32 0
 #define NF_DTYPE_F64 1

@@ -480,6 +480,8 @@ static int value_and_grad_composite(nf_ctx *ctx, const nf_flow_desc *desc, const
 static int value_and_grad_general_base(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, const void *theta,
                                        const void *xs, int64_t N_local, int64_t N_global, uint64_t seed, uint64_t sample_offset,
                                        uint32_t stream_id, void *out);
+static int flow_bwd_composite(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *x, const void *ybar,
+                              const void *lbar, long N, void *xbar_out, void *gtheta_out);
 static int fkl_general(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *ys, int64_t N_local,
                        int64_t N_global, void *out);
 static size_t fkl_general_need(nf_ctx *ctx, const nf_flow_desc *desc, long N);
@@ -735,7 +737,7 @@ extern "C" int nf_flow_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const void *th
   NF_HIP(hipSetDevice(ctx->device));
   const long P = nf_param_count(desc);
   if (N == 0) return nf_launch_fill(ctx, desc->dtype, gtheta_out, P, 0.0);
-  if (is_composite(desc)) return NF_ERR_UNSUPPORTED;  // pull back segment by segment (each is a flow of its own)
+  if (is_composite(desc)) return flow_bwd_composite(ctx, desc, theta, x, ybar, lbar, N, xbar_out, gtheta_out);
   if (is_coupling(desc)) {
     const int grid = coupling_bwd_grid(ctx, desc, N);
     const size_t te = tiled_elems(desc, N);
@@ -1234,6 +1236,30 @@ static int value_and_grad_composite(nf_ctx *ctx, const nf_flow_desc *desc, const
     const void *yseg = s == 0 ? (const void *)cb.y : (const void *)cb.xin[s - 1];
     NF_TRY(nf_flow_bwd(ctx, g, (const char *)theta + (size_t)off * es, cb.xin[s], yseg, cb.gbar, cb.lbar, N, cb.gbar,
                        (char *)out + (size_t)off * es));
+  }
+  return NF_OK;
+}
+
+// nf_flow_bwd of a composition: the forward chain again with every segment's input kept, then the segments' own
+// pullbacks, last applied first (the cotangent of every segment's log-det is the caller's lbar)
+static int flow_bwd_composite(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *x, const void *ybar,
+                              const void *lbar, long N, void *xbar_out, void *gtheta_out) {
+  const size_t es = esize(desc->dtype);
+  const int ns = desc->nsegments;
+  CompBufs cb;
+  const size_t prev_guard = ctx->ws_guard;
+  NF_TRY(composite_bufs(ctx, desc, N, &cb));
+  GuardReset gr{ctx, prev_guard};
+  char *x0 = cb.xin[ns - 1];
+  NF_HIP(hipMemcpyAsync(x0, x, (size_t)N * desc->d * es, hipMemcpyDeviceToDevice, ctx->stream));
+  NF_TRY(composite_chain(ctx, desc, false, theta, x0, N, cb.y, cb.ladj, cb, cb.xin));
+  if (xbar_out != ybar)
+    NF_HIP(hipMemcpyAsync(xbar_out, ybar, (size_t)N * desc->d * es, hipMemcpyDeviceToDevice, ctx->stream));
+  for (int s = 0; s < ns; ++s) {
+    const long off = seg_theta_off(desc, s);
+    const void *yseg = s == 0 ? (const void *)cb.y : (const void *)cb.xin[s - 1];
+    NF_TRY(nf_flow_bwd(ctx, &desc->segments[s], (const char *)theta + (size_t)off * es, cb.xin[s], yseg, xbar_out, lbar, N,
+                       xbar_out, (char *)gtheta_out + (size_t)off * es));
   }
   return NF_OK;
 }

@@ -128,9 +128,8 @@ def test_caller_provided_arena_covers_every_entry_point(name):
         out["step_rng"] = torch.cat([g, torch.tensor([l], dtype=dt, device="cuda")])
         l, g = nf.value_and_gradient(nf.elbo_batch, flow, tgt, xs)
         out["step_xs"] = torch.cat([g, torch.tensor([l], dtype=dt, device="cuda")])
-        if flow.kind != "composite":  # the pullback of a whole composite goes segment by segment (nf_flow_bwd per segment)
-            l, g = nf.value_and_gradient(nf.elbo_batch, flow, lambda y: -(y * y).sum(0), xs)  # generic closure: nf_flow_bwd
-            out["pullback"] = g
+        l, g = nf.value_and_gradient(nf.elbo_batch, flow, lambda y: -(y * y).sum(0), xs)  # generic closure: nf_flow_bwd
+        out["pullback"] = g
         l, g = nf.loglikelihood_value_and_gradient(flow, ys)
         out["fkl"] = torch.cat([g, torch.tensor([l], dtype=dt, device="cuda")])
         th = flow.theta.clone()

@@ -1112,6 +1112,12 @@ def test_heterogeneous_create_flow(nf, dtn, general_base):
     # training runs through the composite like through any flow
     trained, stats, st = nf.train_flow(nf.PhiloxRNG(1), nf.elbo_batch, flow, tgt, 256, max_iters=5, optimiser=nf.Adam(1e-3))
     assert isinstance(trained, nf.CompositeFlow) and np.isfinite(stats[-1]["loss"]) and st.t == 5
+    # a generic logp closure: library forward, the closure's torch gradient, nf_flow_bwd through the whole composition
+    tm, tv = torch.tensor(tmu, device="cuda"), torch.tensor(tvar, device="cuda")
+    lc, gc = nf.value_and_gradient(nf.elbo_batch, flow, lambda y: (-0.5 * (y - tm[:, None]) ** 2 / tv[:, None]).sum(0) -
+                                   0.5 * torch.log(2 * np.pi * tv).sum(), xs)
+    P.scalar(f"{tag}: closure step loss", lc, lo + corr, lr, lr)
+    P.gradient(f"{tag}: closure step grad (nf_flow_bwd)", gc, go, P.F64_GRAD if f64 else P.GRAD_RTOL)
     # forward-KL training through the composition (and over the general base)
     ys64 = ys.cpu().numpy().astype(np.float64)
     lf, gf = nf.loglikelihood_value_and_gradient(flow, ys)
