@@ -210,13 +210,10 @@ function NormalizingFlows._device_specific_rand(rng::NFHipRNG, s::Distributions.
     T = float(eltype(s))
     d = length(s)
     x = ROCMatrix{T}(undef, d, n)
-    check(ccall((:nf_base_sample_logpdf, libnfhip), Cint,
-                (Ptr{Cvoid}, Int32, Int32, Int64, UInt64, UInt64, UInt32, Ptr{Cvoid}, Ptr{Cvoid}),
-                context(), dtype_code(T), d, n, rng.seed, rng.offset, next_stream!(rng), devptr(x), C_NULL))
-    if !is_standard_normal(s)      # general MvNormal: μ + L ε, as ext/NormalizingFlowsCUDAExt.jl:43-48 does
-        Distributions.unwhiten!(s.Σ, x)
-        x .+= ROCVector{T}(s.μ)
-    end
+    bptr, keep = base_of(s, T)     # general MvNormal: μ + L ε on the device, as ext/NormalizingFlowsCUDAExt.jl:43-48 does
+    GC.@preserve keep check(ccall((:nf_base_rand, libnfhip), Cint,
+                (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Int32, Int64, UInt64, UInt64, UInt32, Ptr{Cvoid}, Ptr{Cvoid}),
+                context(), dtype_code(T), bptr, d, n, rng.seed, rng.offset, next_stream!(rng), devptr(x), C_NULL))
     return x
 end
 NormalizingFlows._device_specific_rand(rng::NFHipRNG, s::Distributions.MvNormal) = vec(NormalizingFlows._device_specific_rand(rng, s, 1))
@@ -314,12 +311,13 @@ function ChainRulesCore.rrule(::typeof(Bijectors.with_logabsdet_jacobian), t::NF
     return (y, ladj), pullback
 end
 
-# logpdf(MvNormal(zeros, I), xs) on the device (src/objectives/elbo.jl:6,68)
+# logpdf(q0, xs) on the device for the standard normal and for a general MvNormal(μ, Σ) (src/objectives/elbo.jl:6,68)
 function Distributions.logpdf(s::Distributions.MvNormal, xs::ROCMatrix{T}) where {T}
-    is_standard_normal(s) || error("nfhip: device logpdf is built for the standard-normal base of the reference configs")
     out = ROCVector{T}(undef, size(xs, 2))
-    check(ccall((:nf_base_logpdf, libnfhip), Cint, (Ptr{Cvoid}, Int32, Int32, Int64, Ptr{Cvoid}, Ptr{Cvoid}),
-                context(), dtype_code(T), size(xs, 1), size(xs, 2), devptr(xs), devptr(out)))
+    bptr, keep = base_of(s, T)
+    GC.@preserve keep check(ccall((:nf_base_logpdf_general, libnfhip), Cint,
+                (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Int32, Int64, Ptr{Cvoid}, Ptr{Cvoid}),
+                context(), dtype_code(T), bptr, size(xs, 1), size(xs, 2), devptr(xs), devptr(out)))
     return out
 end
 
