@@ -42,7 +42,10 @@ int nf_affine_chain(nf_ctx *, const nf_flow_desc *, bool inverse, float *xt, lon
 long nf_affine_chain_grid(nf_ctx *, long N);
 int nf_affine_chain_elbo(nf_ctx *, const nf_flow_desc *, long N, uint64_t seed, uint64_t off, uint32_t stream,
                          const float *mu, const float *var, float *yt, float *gt, double gscale, double *partial,
-                         double pscale);
+                         double pscale, float *stash = nullptr);
+size_t nf_affine_stash_floats(const nf_flow_desc *desc, long N);
+int nf_affine_bwd_stashed(nf_ctx *, const nf_flow_desc *, float *stash, float *ybar, const float *lbar, float lbar_const, long N,
+                          float *slab, long slab_stride, int grid);
 long nf_affine_slab_floats(const nf_flow_desc *desc);
 int nf_affine_reduce_slabs(nf_ctx *, const nf_flow_desc *, const float *slab, int nslab, float *g,
                            const double *lpart = nullptr, int nlpart = 0, float *lout = nullptr);
@@ -568,12 +571,26 @@ static inline bool elbo_fusable(const nf_flow_desc *desc, const nf_target *targe
 // the fused forward launch (draws + chain + target + ELBO partial sums) of the two LDS-resident coupling families
 static int fused_chain_elbo(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, long N, uint64_t seed,
                             uint64_t off, uint32_t stream_id, float *yt, float *gt, double gscale, double *partial,
-                            double pscale) {
+                            double pscale, float *stash = nullptr) {
   if (desc->kind == NF_KIND_NSF)
     return nf_rqs_chain_elbo(ctx, desc, N, seed, off, stream_id, (const float *)target->p0, (const float *)target->p1, yt, gt,
                              gscale, partial, pscale);
   return nf_affine_chain_elbo(ctx, desc, N, seed, off, stream_id, (const float *)target->p0, (const float *)target->p1, yt, gt,
-                              gscale, partial, pscale);
+                              gscale, partial, pscale, stash);
+}
+// The LDS-resident RealNVP training step keeps the forward's activations for the reverse pass (nf_coupling.hip,
+// "activation stash") while they fit the budget: 46 KiB per 32-sample tile and coupling at d = 64 / hidden 64.  NF_AFFINE_STASH_MAX_MB (default 4096) bounds it; beyond, or with
+// NF_AFFINE_NO_STASH set (A/B measurements), the reverse pass recomputes them (k_affine_bwd_all).
+static size_t affine_stash_bytes(const nf_flow_desc *desc, long N) {
+  if (desc->kind != NF_KIND_REALNVP || desc->dtype != NF_DTYPE_F32 || !nf_affine_supported(desc)) return 0;
+  static const bool off = std::getenv("NF_AFFINE_NO_STASH") != nullptr;
+  if (off) return 0;
+  static const size_t cap = [] {
+    const char *e = std::getenv("NF_AFFINE_STASH_MAX_MB");
+    return (size_t)(e ? std::atol(e) : 4096) << 20;
+  }();
+  const size_t b = nf_affine_stash_floats(desc, N) * sizeof(float);
+  return b <= cap ? b : 0;
 }
 static long fused_chain_grid(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
   return desc->kind == NF_KIND_NSF ? nf_rqs_chain_grid(ctx, N) : nf_affine_chain_grid(ctx, N);
@@ -1423,8 +1440,9 @@ extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, con
   const bool wide = cp && is_wide(desc);
   const size_t slabf = wide ? nf_wide_train_ws_floats(ctx, desc, N) : cp ? (size_t)grid * coupling_slab_floats(ctx, desc, N) : 0;
   const size_t xe = cp ? tiled_elems(desc, N) : simple_step ? 0 : (size_t)N * desc->d;
+  const size_t stash_b = (cp && elbo_fusable(desc, target, xs)) ? affine_stash_bytes(desc, N) : 0;
   const size_t need = 3 * carve_bytes(xe * es) + 2 * carve_bytes((size_t)N * es) + carve_bytes((size_t)nb_alloc * 8) +
-                      carve_bytes(64) + carve_bytes(slabf * es) + carve_bytes(simple_ws);
+                      carve_bytes(64) + carve_bytes(slabf * es) + carve_bytes(simple_ws) + carve_bytes(stash_b);
   NF_TRY(nf_ws_reserve(ctx, need));
   Carver cv(ctx->ws);
   char *x = cv.take<char>(xe * es);
@@ -1437,11 +1455,18 @@ extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, con
   (void)result;
   char *slab = cv.take<char>(slabf * es);
   char *sws = cv.take<char>(simple_ws);
+  float *stash = stash_b ? cv.take<float>(stash_b / 4) : nullptr;
 
   if (cp && elbo_fusable(desc, target, xs)) {
     float *xt = (float *)x, *gt = (float *)gbar;
     NF_TRY(coupling_pack(ctx, desc, (const float *)theta));
-    NF_TRY(fused_chain_elbo(ctx, desc, target, N, seed, sample_offset, stream_id, xt, gt, -inv, partial, -inv));
+    NF_TRY(fused_chain_elbo(ctx, desc, target, N, seed, sample_offset, stream_id, xt, gt, -inv, partial, -inv, stash));
+    if (stash) {  // reverse pass from the stash: no recompute, the state is not touched
+      NF_TRY(nf_affine_bwd_stashed(ctx, desc, stash, gt, nullptr, (float)(-inv), N, (float *)slab,
+                                   coupling_slab_floats(ctx, desc, N), grid));
+      return nf_affine_reduce_slabs(ctx, desc, (const float *)slab, grid, (float *)out, partial, (int)nf_affine_chain_grid(ctx, N),
+                                    (float *)out + P);
+    }
     if (is_nsf(desc)) {
       NF_TRY(nf_launch_finish_sum(ctx, partial, fused_chain_grid(ctx, desc, N), 0, nullptr, (float *)out + P, nullptr));
       return realnvp_bwd(ctx, desc, (const float *)theta, xt, gt, nullptr, (float)(-inv), N, (float *)slab, grid, (float *)out);
@@ -1653,7 +1678,7 @@ static size_t ws_need_bound(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
       if (sw > simple_ws) simple_ws = sw;
     }
     upd(3 * carve_bytes(xe * es) + 2 * cn + carve_bytes((size_t)nb_alloc * 8) + carve_bytes(64) + carve_bytes(slabf * es) +
-        carve_bytes(simple_ws));
+        carve_bytes(simple_ws) + carve_bytes(cp ? affine_stash_bytes(desc, N) : 0));
   }
   return need;
 }

@@ -141,6 +141,120 @@ __device__ __forceinline__ float coupling_step(const float *__restrict__ img_s, 
   return lsum;
 }
 
+// ---- activation stash of the training step (forward writes, reverse pass reads) ---------------------------
+// The reverse pass needs, per (tile, coupling): the conditioner input x2, both nets' hidden activations a1 / a2 and
+// their leaky-ReLU sign masks, s = tanh(.) and u = x1 exp(s).  Recomputing them (k_affine_bwd_all) costs a third of
+// that kernel's MFMAs plus the activations' LDS transposes; with STASH the fused forward writes them once, in the
+// layouts the reverse pass consumes directly:
+//   "T layout" (x2, a1, a2 -- the dW operands): [feature 32][sample parity 2][16] per 32-feature block, so the lane
+//     that owns feature f in the dW GEMM reads its 16 k-steps (samples 2t + parity) as four 16-byte loads;
+//   "lane layout" (s, u, masks -- element-wise operands in the MFMA C layout): [lane 64][16] per block.
+// 46 KiB per (tile, coupling) for d = 64 / hidden 64: 772 MB per step at cfg 2, written once and read once.
+template <class G>
+struct StashGeo {
+  static constexpr int XT = 0;
+  static constexpr int SV = XT + G::MB * 1024;
+  static constexpr int UV = SV + G::CB * 1024;
+  static constexpr int NET0 = UV + G::CB * 1024;  // net 0 = s, net 1 = t
+  static constexpr int A1 = 0, A2 = G::H1B * 1024, MSK = A2 + G::H2B * 1024, NETSZ = MSK + 256;
+  static constexpr int SIZE = NET0 + 2 * NETSZ;  // floats per (tile, coupling), a multiple of 4
+};
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct StashIO {
+  __amdgpu_buffer_rsrc_t rs;
+  int vT, vL;  // per-lane byte offsets: T-layout element stores (C-layout lane), lane-layout rows
+};
+// live = false: a descriptor of extent 0, every store is dropped (idle waves of the last tile group)
+__device__ __forceinline__ StashIO make_stash_io(float *stash, long slot, int size, bool live, int l31, int hi) {
+  StashIO st;
+  st.rs = __builtin_amdgcn_make_buffer_rsrc(stash + slot * size, 0, live ? size * 4 : 0, 0x00020000);
+  st.vT = ((4 * hi) * 32 + (l31 & 1) * 16 + (l31 >> 1)) * 4;
+  st.vL = (hi * 32 + l31) * 64;
+  return st;
+}
+// element e (= block * 16 + reg) of a C-layout array into its T-layout slot
+template <int NB>
+__device__ __forceinline__ void stash_put_T(const StashIO &st, int base, const f32x16 (&v)[NB], int e) {
+  if (e < NB * 16) {
+    const int r = e & 15;
+    const float val = v[e >> 4][r];  // (bit_cast straight on a vector element reads element 0 under hipcc 7.2)
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), st.rs, st.vT,
+                                          (base + ((e >> 4) * 32 + (r & 3) + 8 * (r >> 2)) * 32) * 4, 0);
+  }
+}
+template <int NB>
+__device__ __forceinline__ void stash_put_lane(const StashIO &st, int base, const f32x16 (&v)[NB]) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      u32x4 w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float val = v[b][4 * q + e];
+        w[e] = __builtin_bit_cast(unsigned, val);
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(w, st.rs, st.vL, (base + b * 1024) * 4 + q * 16, 0);
+    }
+}
+
+template <class G, bool STORE_X>
+__device__ __forceinline__ void net_forward_stash(const float *__restrict__ img, const f32x16 (&x)[G::MB], f32x16 (&out)[G::CB],
+                                                  int l31, int hi, const StashIO &st, int nbase) {
+  using SG = StashGeo<G>;
+  f32x16 a1[G::H1B], a2[G::H2B];
+  unsigned m1[2] = {0u, 0u}, m2[2] = {0u, 0u};
+  if (STORE_X)
+    dense_fwd<G::MB, G::H1B>(img + G::W1, img + G::B1, x, a1, l31, hi, [&](int e) { stash_put_T<G::MB>(st, SG::XT, x, e); });
+  else
+    dense_fwd<G::MB, G::H1B>(img + G::W1, img + G::B1, x, a1, l31, hi);
+#pragma unroll
+  for (int b = 0; b < G::H1B; ++b) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a1[b][r] = nf_lrelu(a1[b][r]);
+    m1[b] = nf_sign_mask16(a1[b]);
+  }
+  dense_fwd<G::H1B, G::H2B>(img + G::W2, img + G::B2, a1, a2, l31, hi,
+                            [&](int e) { stash_put_T<G::H1B>(st, nbase + SG::A1, a1, e); });
+#pragma unroll
+  for (int b = 0; b < G::H2B; ++b) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a2[b][r] = nf_lrelu(a2[b][r]);
+    m2[b] = nf_sign_mask16(a2[b]);
+  }
+  dense_fwd<G::H2B, G::CB>(img + G::W3, img + G::B3, a2, out, l31, hi,
+                           [&](int e) { stash_put_T<G::H2B>(st, nbase + SG::A2, a2, e); });
+  const u32x4 mk = {m1[0], m1[1], m2[0], m2[1]};
+  __builtin_amdgcn_raw_buffer_store_b128(mk, st.rs, (hi * 32 + l31) * 16, (nbase + SG::MSK) * 4, 0);
+}
+
+// forward coupling of the training step: as coupling_step<G, false>, leaving the reverse pass's operands behind
+template <class G>
+__device__ __forceinline__ float coupling_step_stash(const float *__restrict__ img_s, const float *__restrict__ img_t,
+                                                     f32x16 (&x1)[G::CB], const f32x16 (&xb)[G::MB], int l31, int hi,
+                                                     const StashIO &st) {
+  using SG = StashGeo<G>;
+  static_assert(G::H1B <= 2 && G::H2B <= 2, "mask words");
+  f32x16 S[G::CB], T[G::CB];
+  net_forward_stash<G, true>(img_s, xb, S, l31, hi, st, SG::NET0);
+  net_forward_stash<G, false>(img_t, xb, T, l31, hi, st, SG::NET0 + SG::NETSZ);
+  float lsum = 0.f;
+#pragma unroll
+  for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float s = nf_tanh(S[b][r]);
+      const float u = x1[b][r] * nf_exp(s);
+      x1[b][r] = u + T[b][r];
+      S[b][r] = s;
+      T[b][r] = u;
+      lsum += s;
+    }
+  stash_put_lane<G::CB>(st, SG::SV, S);
+  stash_put_lane<G::CB>(st, SG::UV, T);
+  return lsum;
+}
+
 // FUSED (forward only): the ELBO forward of the training step in the same launch -- the tile's base
 // draws are generated in registers (Philox4x32-10 + Box-Muller, same counters as k_base_sample_tiled:
 // (sample lo, sample hi, feature group, stream)), log q0 and log|det J| never touch memory, and after
@@ -154,10 +268,12 @@ struct FusedArgs {
   float gscale;
   double *partial;        // [gridDim.x] out
   double pscale;
+  float *stash;           // STASH: [tile][coupling][StashGeo<G>::SIZE] out
 };
 
-template <class G, bool INVERSE, bool FUSED = false>
+template <class G, bool INVERSE, bool FUSED = false, bool STASH = false>
 __global__ __launch_bounds__(512) void k_affine_chain(ChainArgs a, float *xt, float *__restrict__ ladj, FusedArgs fa) {
+  static_assert(!STASH || (FUSED && !INVERSE), "the stash belongs to the training step's forward");
   static_assert(G::MB == G::CB, "parity blocks must have equal padded size");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int IMG2 = 2 * G::SIZE;  // s and t images of one coupling are adjacent in wimg
@@ -269,7 +385,11 @@ __global__ __launch_bounds__(512) void k_affine_chain(ChainArgs a, float *xt, fl
         // forward order: position 0 is the last flat coupling (odd index => mask 2:2:d => x1 = O)
         const bool x1_is_O = (coupling_at(pos) & 1) != 0;  // compile-time per (INVERSE, half) when ncoup is even
         float ls;
-        if (INVERSE ? (half == 1) : (half == 0)) {
+        if (STASH) {
+          const StashIO st = make_stash_io(fa.stash, tl * a.ncoup + coupling_at(pos), StashGeo<G>::SIZE, live, l31, hi);
+          if (half == 0) ls = coupling_step_stash<G>(img_s, img_t, O, E, l31, hi, st);
+          else ls = coupling_step_stash<G>(img_s, img_t, E, O, l31, hi, st);
+        } else if (INVERSE ? (half == 1) : (half == 0)) {
           (void)x1_is_O;
           ls = coupling_step<G, INVERSE>(img_s, img_t, O, E, l31, hi);
         } else {
@@ -685,6 +805,238 @@ __global__ __launch_bounds__(256, 1) void k_affine_bwd_all(BwdAllArgs aa, float 
 }
 
 // ------------------------------------------------------------------------------------
+// reverse pass of the training step from the forward's stash: no recompute
+// ------------------------------------------------------------------------------------
+// Same mathematics and phase structure as bwd_tile / k_affine_bwd_all (phase T then phase S per coupling, one net in
+// LDS, its dW accumulators in registers), but x2 / a1 / a2 arrive from the stash already in the dW operand layout
+// (registers, no LDS transpose), s / u / masks arrive in the C layout, and nothing of the forward is recomputed:
+// per tile-phase 256 MFMAs instead of 384, the flow state `y` is neither read nor written (it stays the flow output).
+template <int NB>
+__device__ __forceinline__ void stash_get_T(const StashIO &st, int base, int voff, float (&at)[NB][16]) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(st.rs, voff, (base + b * 1024) * 4 + q * 16, 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned bits = w[e];
+        at[b][4 * q + e] = __builtin_bit_cast(float, bits);
+      }
+    }
+}
+template <int NB>
+__device__ __forceinline__ void stash_get_lane(const StashIO &st, int base, f32x16 (&v)[NB]) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(st.rs, st.vL, (base + b * 1024) * 4 + q * 16, 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned bits = w[e];
+        v[b][4 * q + e] = __builtin_bit_cast(float, bits);
+      }
+    }
+}
+
+// dW^T accumulation with the activation operand in registers: at[ib][t] = a[feature ib*32 + l31][sample 2t + hi]
+template <int IB, int OB, class SJ = NoSideJob>
+__device__ __forceinline__ void dw_accumulate_reg(const float (&at)[IB][16], const float *__restrict__ sd,
+                                                  f32x16 (&acc)[IB][OB], float (&bsum)[OB], int l31, int hi, SJ sj = SJ()) {
+  constexpr int TG = 2, NG = 16 / TG;
+  const float *pd = sd + l31 * NF_TS + hi;
+  float dn[TG][OB], dc[TG][OB];
+#pragma unroll
+  for (int u = 0; u < TG; ++u)
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob) dn[u][ob] = pd[ob * 32 * NF_TS + 2 * u];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+#pragma unroll
+    for (int u = 0; u < TG; ++u)
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob) dc[u][ob] = dn[u][ob];
+    if (g + 1 < NG) {
+#pragma unroll
+      for (int u = 0; u < TG; ++u)
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob) dn[u][ob] = pd[ob * 32 * NF_TS + 2 * ((g + 1) * TG + u)];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < TG; ++u) {
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob) bsum[ob] += dc[u][ob];
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob) {
+          acc[ib][ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(at[ib][g * TG + u], dc[u][ob], acc[ib][ob], 0, 0, 0);
+          sj(((g * TG + u) * IB + ib) * OB + ob);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <class G>
+struct BwdStashLds {
+  static constexpr int DROWS = BwdLds<G>::DROWS;
+  static constexpr int SCRATCH = DROWS * 32 * NF_TS;  // one delta tile per wave
+  static constexpr int WAVES = 4;
+  static constexpr int FLOATS = (G::SIZE + WAVES * SCRATCH) > WAVES * G::SIZE ? (G::SIZE + WAVES * SCRATCH) : WAVES * G::SIZE;
+  static constexpr size_t BYTES = (size_t)FLOATS * sizeof(float);  // the fold at the end of a phase needs 4 images
+};
+
+template <class G, bool PHASE_S, bool FULL>
+__device__ __forceinline__ void bwd_tile_stashed(const CouplingArgs &a, const float *__restrict__ img, float *__restrict__ sd,
+                                                 BwdAcc<G> &acc, float *stash, int k, int ncoup, float *__restrict__ ybar,
+                                                 const float *__restrict__ lbar, float lbar_const, long tile, int l31,
+                                                 int hi) {
+  using SG = StashGeo<G>;
+  const long j = tile * NF_TILE + l31;
+  const bool valid = FULL ? true : j < a.N;
+  const int par_c = 1 - a.par_t;
+  const TileIO gio = make_tile_io(ybar, tile, a.d, l31, hi);
+  const StashIO st = make_stash_io(stash, tile * ncoup + k, SG::SIZE, true, l31, hi);
+  constexpr int nbase = SG::NET0 + (PHASE_S ? 0 : SG::NETSZ);
+  const int vT = (l31 * 32 + hi * 16) * 4;  // this lane's feature row and sample parity in a T-layout block
+
+  // loads in the order of first use
+  f32x16 g1[G::CB], sv[G::CB], uv[G::CB];
+#pragma unroll
+  for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g1[b][r] = tile_load(gio, tile_soff(b, r, a.par_t));
+  if (PHASE_S) {
+    stash_get_lane<G::CB>(st, SG::SV, sv);
+    stash_get_lane<G::CB>(st, SG::UV, uv);
+  }
+  const u32x4 mk = __builtin_amdgcn_raw_buffer_load_b128(st.rs, (hi * 32 + l31) * 16, (nbase + SG::MSK) * 4, 0);
+  float a2t[G::H2B][16];
+  stash_get_T<G::H2B>(st, nbase + SG::A2, vT, a2t);
+
+  const float lb = valid ? (lbar ? lbar[FULL ? j : (j < a.N ? j : 0)] : lbar_const) : 0.f;
+  f32x16 d3[G::CB];
+#pragma unroll
+  for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int p = b * 32 + nf_row(r, hi);
+      const bool ok = (p < a.c) && valid;
+      const float gv = g1[b][r];
+      if (!PHASE_S) {
+        d3[b][r] = ok ? gv : 0.f;  // T-bar = ybar1
+      } else {
+        const float s = sv[b][r];
+        tile_store(gio, tile_soff(b, r, a.par_t), gv * nf_exp(s));  // x1bar
+        d3[b][r] = ok ? (gv * uv[b][r] + lb) * (1.f - s * s) : 0.f;  // S-bar through tanh
+      }
+    }
+  const unsigned mk0 = mk[0], mk1 = mk[1], mk2 = mk[2], mk3 = mk[3];
+  const unsigned m1[2] = {mk0, mk1}, m2[2] = {mk2, mk3};
+
+  // ---- layer 3
+  f32x16 d2[G::H2B];
+  dense_bwd_x<G::H2B, G::CB>(img + G::W3, d3, d2, l31, hi, [&](int e) { scratch_put<G::CB>(sd, d3, e, l31, hi); });
+  float a1t[G::H1B][16];
+  stash_get_T<G::H1B>(st, nbase + SG::A1, vT, a1t);
+  wave_lds_fence();
+  dw_accumulate_reg<G::H2B, G::CB>(a2t, sd, acc.w3, acc.b3, l31, hi, [&](int e) {
+    if (e < G::H2B * 16) d2[e >> 4][e & 15] *= lrelu_slope(m2[e >> 4], e & 15);
+  });
+  wave_lds_fence();
+  // ---- layer 2
+  f32x16 d1[G::H1B];
+  dense_bwd_x<G::H1B, G::H2B>(img + G::W2, d2, d1, l31, hi, [&](int e) { scratch_put<G::H2B>(sd, d2, e, l31, hi); });
+  float x2t[G::MB][16];
+  stash_get_T<G::MB>(st, SG::XT, vT, x2t);
+  wave_lds_fence();
+  dw_accumulate_reg<G::H1B, G::H2B>(a1t, sd, acc.w2, acc.b2, l31, hi, [&](int e) {
+    if (e < G::H1B * 16) d1[e >> 4][e & 15] *= lrelu_slope(m1[e >> 4], e & 15);
+  });
+  wave_lds_fence();
+  // ---- layer 1: x2bar accumulates ybar2 + W1t^T d1t (phase T) + W1s^T d1s (phase S)
+  f32x16 g2[G::MB], gold[G::MB];
+#pragma unroll
+  for (int b = 0; b < G::MB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gold[b][r] = tile_load(gio, tile_soff(b, r, par_c));
+  dense_bwd_x<G::MB, G::H1B>(img + G::W1, d1, g2, l31, hi, [&](int e) { scratch_put<G::H1B>(sd, d1, e, l31, hi); });
+  wave_lds_fence();
+  dw_accumulate_reg<G::MB, G::H1B>(x2t, sd, acc.w1, acc.b1, l31, hi, [&](int e) {
+    if (e < G::MB * 16) tile_store(gio, tile_soff(e >> 4, e & 15, par_c), gold[e >> 4][e & 15] + g2[e >> 4][e & 15]);
+  });
+  wave_lds_fence();
+}
+
+template <class G, bool FULL>
+__global__ __launch_bounds__(256, 1) void k_affine_bwd_stashed(BwdAllArgs aa, float *stash, float *__restrict__ ybar,
+                                                               const float *__restrict__ lbar, float lbar_const,
+                                                               float *__restrict__ slab, long slab_stride) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *img = lds;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  float *sd = lds + G::SIZE + wave * BwdStashLds<G>::SCRATCH;
+  const long ntiles = (aa.N + NF_TILE - 1) / NF_TILE;
+#pragma unroll 1
+  for (int k = 0; k < aa.ncoup; ++k) {
+    CouplingArgs a;
+    a.theta = nullptr;
+    a.img_s = aa.wimg + (size_t)(2 * k) * G::SIZE;
+    a.img_t = a.img_s + G::SIZE;
+    a.trace = nullptr;
+    a.d = aa.d;
+    a.par_t = k & 1;
+    a.c = (k & 1) ? aa.d / 2 : (aa.d + 1) / 2;
+    a.m = aa.d - a.c;
+    a.N = aa.N;
+    float *kslab = slab + (long)k * 2 * G::SIZE;
+#pragma unroll 1
+    for (int phase = 0; phase < 2; ++phase) {
+      const bool is_s = phase == 1;
+      stage_packed<G::SIZE, 256>(img, is_s ? a.img_s : a.img_t, tid);
+      __syncthreads();
+      BwdAcc<G> acc;
+      zero_acc(acc.w1, acc.b1);
+      zero_acc(acc.w2, acc.b2);
+      zero_acc(acc.w3, acc.b3);
+#pragma unroll 1
+      for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+        if (!is_s) bwd_tile_stashed<G, false, FULL>(a, img, sd, acc, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, l31, hi);
+        else bwd_tile_stashed<G, true, FULL>(a, img, sd, acc, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, l31, hi);
+      }
+      __syncthreads();  // every wave is done with the weight image and its scratch
+      {
+        float *mine = lds + wave * G::SIZE;
+        fold_acc(mine + G::W1, mine + G::B1, acc.w1, acc.b1, true, l31, hi);
+        fold_acc(mine + G::W2, mine + G::B2, acc.w2, acc.b2, true, l31, hi);
+        fold_acc(mine + G::W3, mine + G::B3, acc.w3, acc.b3, true, l31, hi);
+      }
+      __syncthreads();
+      {
+        const float4 *c0 = reinterpret_cast<const float4 *>(lds);
+        float4 *dst = reinterpret_cast<float4 *>(kslab + ((long)blockIdx.x * slab_stride + (is_s ? 0 : 1) * (long)G::SIZE));
+        constexpr int NV4 = G::SIZE / 4;
+        for (int i = tid; i < NV4; i += 256) {
+          const float4 p0 = c0[i], p1 = c0[i + NV4], p2 = c0[i + 2 * NV4], p3 = c0[i + 3 * NV4];
+          float4 r;
+          r.x = (p0.x + p1.x) + (p2.x + p3.x);
+          r.y = (p0.y + p1.y) + (p2.y + p3.y);
+          r.z = (p0.z + p1.z) + (p2.z + p3.z);
+          r.w = (p0.w + p1.w) + (p2.w + p3.w);
+          dst[i] = r;
+        }
+      }
+      __syncthreads();  // image is restaged next phase; ybar stores of this phase are read by the next (same wave)
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------
 static inline int blocks32(int n) { return (n + 31) / 32; }
@@ -822,6 +1174,7 @@ static int launch_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, flo
     NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return NF_OK;
   }));
   ChainArgs a;
@@ -834,7 +1187,9 @@ static int launch_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, flo
   if (grid < 1) grid = 1;
   ProfScope ps(ctx, "affine_chain");
   FusedArgs none{};
-  if (fused)
+  if (fused && fused->stash)
+    hipLaunchKernelGGL((k_affine_chain<G, false, true, true>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, *fused);
+  else if (fused)
     hipLaunchKernelGGL((k_affine_chain<G, false, true>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, *fused);
   else if (inverse)
     hipLaunchKernelGGL((k_affine_chain<G, true>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, none);
@@ -855,10 +1210,11 @@ long nf_affine_chain_grid(nf_ctx *ctx, long N) {
 // partial[nf_affine_chain_grid] <- sums of pscale * elbo_j.
 int nf_affine_chain_elbo(nf_ctx *ctx, const nf_flow_desc *desc, long N, uint64_t seed, uint64_t off, uint32_t stream,
                          const float *mu, const float *var, float *yt, float *gt, double gscale, double *partial,
-                         double pscale) {
+                         double pscale, float *stash) {
   const int size = geo_size(desc);
   if (!size || !ctx->wimg) return NF_ERR_UNSUPPORTED;
   FusedArgs fa;
+  fa.stash = stash;
   fa.k0 = (uint32_t)seed; fa.k1 = (uint32_t)(seed >> 32); fa.stream = stream; fa.off = off;
   fa.mu = mu; fa.var = var; fa.gt = gt; fa.gscale = (float)gscale; fa.partial = partial; fa.pscale = pscale;
   if (size == NetGeo<1, 1, 1, 1>::SIZE) return launch_chain<NetGeo<1, 1, 1, 1>>(ctx, desc, false, yt, N, nullptr, &fa);
@@ -943,6 +1299,50 @@ int nf_affine_bwd_all(nf_ctx *ctx, const nf_flow_desc *desc, float *y, float *yb
                 : launch_bwd_all_v<NetGeo<1, 2, 2, 1>, false>(ctx, aa, y, ybar, lbar, lbar_const, slab, slab_stride, grid);
   return full ? launch_bwd_all_v<NetGeo<1, 1, 1, 1>, true>(ctx, aa, y, ybar, lbar, lbar_const, slab, slab_stride, grid)
               : launch_bwd_all_v<NetGeo<1, 1, 1, 1>, false>(ctx, aa, y, ybar, lbar, lbar_const, slab, slab_stride, grid);
+}
+
+// floats of the training step's activation stash (0: shape without a stash kernel)
+size_t nf_affine_stash_floats(const nf_flow_desc *desc, long N) {
+  const int size = geo_size(desc);
+  if (!size || desc->n_hidden != 2) return 0;
+  const size_t ntiles = (size_t)((N + NF_TILE - 1) / NF_TILE);
+  const size_t per = size == NetGeo<1, 1, 1, 1>::SIZE ? StashGeo<NetGeo<1, 1, 1, 1>>::SIZE : StashGeo<NetGeo<1, 2, 2, 1>>::SIZE;
+  return ntiles * (size_t)(2 * desc->nlayers) * per;
+}
+
+template <class G, bool FULL>
+static int launch_bwd_stashed_v(nf_ctx *ctx, const BwdAllArgs &aa, float *stash, float *ybar, const float *lbar, float lbar_const,
+                                float *slab, long slab_stride, int grid) {
+  const size_t lds = BwdStashLds<G>::BYTES;
+  static AttrOnce attr_once;  // once per device
+  NF_TRY(attr_once.run(ctx->device, [&]() -> int {
+    NF_HIP(hipFuncSetAttribute((const void *)k_affine_bwd_stashed<G, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return NF_OK;
+  }));
+  ProfScope ps(ctx, "affine_bwd");
+  hipLaunchKernelGGL((k_affine_bwd_stashed<G, FULL>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, aa, stash, ybar, lbar,
+                     lbar_const, slab, slab_stride);
+  return (int)hipGetLastError();
+}
+
+// reverse pass of all couplings from the stash nf_affine_chain_elbo(..., stash) left (same slab layout as
+// nf_affine_bwd_all; ybar: cotangent of the flow output on entry, of the flow input on exit)
+int nf_affine_bwd_stashed(nf_ctx *ctx, const nf_flow_desc *desc, float *stash, float *ybar, const float *lbar, float lbar_const,
+                          long N, float *slab, long slab_stride, int grid) {
+  const int size = geo_size(desc);
+  if (!size || !ctx->wimg || desc->n_hidden != 2 || !stash) return NF_ERR_UNSUPPORTED;
+  BwdAllArgs aa;
+  aa.wimg = (const float *)ctx->wimg;
+  aa.trace = nullptr;
+  aa.d = desc->d;
+  aa.ncoup = 2 * desc->nlayers;
+  aa.N = N;
+  const bool h64 = size != NetGeo<1, 1, 1, 1>::SIZE;
+  const bool full = desc->d == 64 && N % NF_TILE == 0;
+  if (h64)
+    return full ? launch_bwd_stashed_v<NetGeo<1, 2, 2, 1>, true>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid)
+                : launch_bwd_stashed_v<NetGeo<1, 2, 2, 1>, false>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid);
+  return launch_bwd_stashed_v<NetGeo<1, 1, 1, 1>, false>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid);
 }
 
 bool nf_affine_supported(const nf_flow_desc *desc) {
