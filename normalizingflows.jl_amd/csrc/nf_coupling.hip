@@ -889,11 +889,26 @@ struct BwdStashLds {
   static constexpr size_t BYTES = (size_t)FLOATS * sizeof(float);  // the fold at the end of a phase needs 4 images
 };
 
+// s and u of a phase-S tile are loaded one tile ahead, into the same registers, while the previous tile runs its last
+// two GEMMs: every wave of the chip asks for its tile's operands at the same moment (25 MB at once), and without the
+// head start the element-wise stage waits 3.5-6.7 k cycles for them (tools/trace_bwd_stashed.py).
+template <class G>
+struct StashFirst {
+  f32x16 sv[G::CB], uv[G::CB];
+};
+template <class G>
+__device__ __forceinline__ void stash_issue_first(StashFirst<G> &f, float *stash, int k, int ncoup, long tile, int l31, int hi) {
+  using SG = StashGeo<G>;
+  const StashIO st = make_stash_io(stash, tile * ncoup + k, SG::SIZE, true, l31, hi);
+  stash_get_lane<G::CB>(st, SG::SV, f.sv);
+  stash_get_lane<G::CB>(st, SG::UV, f.uv);
+}
+
 template <class G, bool PHASE_S, bool FULL>
 __device__ __forceinline__ void bwd_tile_stashed(const CouplingArgs &a, const float *__restrict__ img, float *__restrict__ sd,
-                                                 BwdAcc<G> &acc, float *stash, int k, int ncoup, float *__restrict__ ybar,
-                                                 const float *__restrict__ lbar, float lbar_const, long tile, int l31,
-                                                 int hi) {
+                                                 BwdAcc<G> &acc, StashFirst<G> &f, float *stash, int k, int ncoup,
+                                                 float *__restrict__ ybar, const float *__restrict__ lbar, float lbar_const,
+                                                 long tile, long next_tile, int l31, int hi) {
   using SG = StashGeo<G>;
   const long j = tile * NF_TILE + l31;
   const bool valid = FULL ? true : j < a.N;
@@ -904,15 +919,11 @@ __device__ __forceinline__ void bwd_tile_stashed(const CouplingArgs &a, const fl
   const int vT = (l31 * 32 + hi * 16) * 4;  // this lane's feature row and sample parity in a T-layout block
 
   // loads in the order of first use
-  f32x16 g1[G::CB], sv[G::CB], uv[G::CB];
+  f32x16 g1[G::CB];
 #pragma unroll
   for (int b = 0; b < G::CB; ++b)
 #pragma unroll
     for (int r = 0; r < 16; ++r) g1[b][r] = tile_load(gio, tile_soff(b, r, a.par_t));
-  if (PHASE_S) {
-    stash_get_lane<G::CB>(st, SG::SV, sv);
-    stash_get_lane<G::CB>(st, SG::UV, uv);
-  }
   const u32x4 mk = __builtin_amdgcn_raw_buffer_load_b128(st.rs, (hi * 32 + l31) * 16, (nbase + SG::MSK) * 4, 0);
   float a2t[G::H2B][16];
   stash_get_T<G::H2B>(st, nbase + SG::A2, vT, a2t);
@@ -929,9 +940,9 @@ __device__ __forceinline__ void bwd_tile_stashed(const CouplingArgs &a, const fl
       if (!PHASE_S) {
         d3[b][r] = ok ? gv : 0.f;  // T-bar = ybar1
       } else {
-        const float s = sv[b][r];
+        const float s = f.sv[b][r];
         tile_store(gio, tile_soff(b, r, a.par_t), gv * nf_exp(s));  // x1bar
-        d3[b][r] = ok ? (gv * uv[b][r] + lb) * (1.f - s * s) : 0.f;  // S-bar through tanh
+        d3[b][r] = ok ? (gv * f.uv[b][r] + lb) * (1.f - s * s) : 0.f;  // S-bar through tanh
       }
     }
   const unsigned mk0 = mk[0], mk1 = mk[1], mk2 = mk[2], mk3 = mk[3];
@@ -963,6 +974,7 @@ __device__ __forceinline__ void bwd_tile_stashed(const CouplingArgs &a, const fl
   for (int b = 0; b < G::MB; ++b)
 #pragma unroll
     for (int r = 0; r < 16; ++r) gold[b][r] = tile_load(gio, tile_soff(b, r, par_c));
+  if (PHASE_S && next_tile >= 0) stash_issue_first<G>(f, stash, k, ncoup, next_tile, l31, hi);
   dense_bwd_x<G::MB, G::H1B>(img + G::W1, d1, g2, l31, hi, [&](int e) { scratch_put<G::H1B>(sd, d1, e, l31, hi); });
   wave_lds_fence();
   dw_accumulate_reg<G::MB, G::H1B>(x2t, sd, acc.w1, acc.b1, l31, hi, [&](int e) {
@@ -982,6 +994,8 @@ __global__ __launch_bounds__(256, 1) void k_affine_bwd_stashed(BwdAllArgs aa, fl
   const int l31 = lane & 31, hi = lane >> 5;
   float *sd = lds + G::SIZE + wave * BwdStashLds<G>::SCRATCH;
   const long ntiles = (aa.N + NF_TILE - 1) / NF_TILE;
+  const long tile0 = (long)blockIdx.x * 4 + wave, tstride = (long)gridDim.x * 4;
+  StashFirst<G> f;
 #pragma unroll 1
   for (int k = 0; k < aa.ncoup; ++k) {
     CouplingArgs a;
@@ -1005,11 +1019,14 @@ __global__ __launch_bounds__(256, 1) void k_affine_bwd_stashed(BwdAllArgs aa, fl
       zero_acc(acc.w2, acc.b2);
       zero_acc(acc.w3, acc.b3);
 #pragma unroll 1
-      for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
-        if (!is_s) bwd_tile_stashed<G, false, FULL>(a, img, sd, acc, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, l31, hi);
-        else bwd_tile_stashed<G, true, FULL>(a, img, sd, acc, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, l31, hi);
+      for (long tile = tile0; tile < ntiles; tile += tstride) {
+        const long nt = tile + tstride < ntiles ? tile + tstride : -1;
+        if (!is_s) bwd_tile_stashed<G, false, FULL>(a, img, sd, acc, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, l31, hi);
+        else bwd_tile_stashed<G, true, FULL>(a, img, sd, acc, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, l31, hi);
       }
       __syncthreads();  // every wave is done with the weight image and its scratch
+      // s and u of phase S's first tile fly behind the fold, the slab write and the staging of the s-net image
+      if (!is_s && tile0 < ntiles) stash_issue_first<G>(f, stash, k, aa.ncoup, tile0, l31, hi);
       {
         float *mine = lds + wave * G::SIZE;
         fold_acc(mine + G::W1, mine + G::B1, acc.w1, acc.b1, true, l31, hi);
