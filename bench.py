@@ -44,11 +44,14 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dens
 # fwd 262 144 + dX 262 144 + dW 262 144 over 8 couplings; recompute is not counted)
 MACS_NET = 32 * 64 + 64 * 64 + 64 * 32
 FLOPS_BWD_PER_SAMPLE_PER_COUPLING = 2 * (2 * MACS_NET) * 2  # 2 nets x (dX + dW) x 2 flop/MAC = 65 536
-COUPLINGS_PER_LAUNCH = 2 * NLAYERS  # k_affine_bwd_all walks all 8 couplings in one launch
+COUPLINGS_PER_LAUNCH = 2 * NLAYERS  # the reverse kernel walks all 8 couplings in one launch
 FLOPS_STEP_PER_SAMPLE = 786432
 WORKLOAD_TEXT = ("reverse-KL ELBO step: RealNVP d=64, 8 affine couplings, conditioner 32-64-64-32 "
                  "(hdims [64,64]), diag-Gaussian target, Philox base draws, Adam")
-DOMINANT = (b"affine_bwd", "k_affine_bwd_all (reverse pass of all 8 couplings in one launch: recompute + dX + dW)")
+STASHED = not os.environ.get("NF_AFFINE_NO_STASH")  # the library's A/B switch back to the recompute kernel
+DOMINANT = (b"affine_bwd", "k_affine_bwd_stashed (reverse pass of all 8 couplings in one launch from the forward's activation "
+                           "stash: dX + dW, nothing recomputed)" if STASHED else
+            "k_affine_bwd_all (reverse pass of all 8 couplings in one launch: recompute + dX + dW)")
 KERNEL_NAMES = (b"base_sample", b"pack_weights", b"affine_chain", b"target", b"affine_bwd", b"reduce_slabs", b"adam")
 
 
@@ -335,7 +338,7 @@ def main():
         achieved = flop_per_launch / (avg_ms.value * 1e-3) / 1e12 if avg_ms.value > 0 else 0.0
         traffic, traffic_src = (None, None)
         if n_local == BATCH and args.workload in ("cfg2", "cfg3"):
-            traffic, traffic_src = pmc_traffic("k_affine_bwd_all" if args.workload == "cfg2" else "k_rqs_bwd")
+            traffic, traffic_src = pmc_traffic(("k_affine_bwd_stashed" if STASHED else "k_affine_bwd_all") if args.workload == "cfg2" else "k_rqs_bwd")
         rec = {
             "metric": "elbo_samples_per_sec",
             "value": value,

@@ -275,7 +275,10 @@ def test_full_size_properties_cfg2(nf):
     assert float((ga + gb - g).abs().max()) <= 1e-4 * float(g.abs().max())
     l_rng, g_rng = nf.value_and_gradient(nf.elbo_batch, flow, tgt, n, rng=nf.PhiloxRNG(123))
     assert l_rng == pytest.approx(loss, rel=1e-6)
-    assert float((g_rng - g).abs().max()) <= 1e-5 * float(g.abs().max())
+    # in-library draws take the stashed reverse pass (exact forward activations), supplied draws the recompute kernel
+    # (x reconstructed by inverting each coupling in float32): two float32 evaluations of the same gradient
+    assert float((g_rng - g).abs().max()) <= P.GRAD_RTOL * float(g.abs().max())
+    P.record("cfg2 full size: stashed vs recompute reverse pass [max abs diff / |g|inf]", float((g_rng - g).abs().max()) / float(g.abs().max()))
 
 
 FULL_CFGS = {
