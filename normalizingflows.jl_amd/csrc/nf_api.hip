@@ -38,7 +38,7 @@ int nf_affine_apply(nf_ctx *, const nf_flow_desc *, int k, bool inverse, const f
                     float *y, float *ladj, int accumulate);
 int nf_affine_bwd_grid(nf_ctx *, long N);
 int nf_affine_pack(nf_ctx *, const nf_flow_desc *, const float *theta);
-int nf_affine_chain(nf_ctx *, const nf_flow_desc *, bool inverse, float *xt, long N, float *ladj);
+int nf_affine_chain(nf_ctx *, const nf_flow_desc *, bool inverse, float *xt, long N, float *ladj, float *stash = nullptr);
 long nf_affine_chain_grid(nf_ctx *, long N);
 int nf_affine_chain_elbo(nf_ctx *, const nf_flow_desc *, long N, uint64_t seed, uint64_t off, uint32_t stream,
                          const float *mu, const float *var, float *yt, float *gt, double gscale, double *partial,
@@ -1440,7 +1440,7 @@ extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, con
   const bool wide = cp && is_wide(desc);
   const size_t slabf = wide ? nf_wide_train_ws_floats(ctx, desc, N) : cp ? (size_t)grid * coupling_slab_floats(ctx, desc, N) : 0;
   const size_t xe = cp ? tiled_elems(desc, N) : simple_step ? 0 : (size_t)N * desc->d;
-  const size_t stash_b = (cp && elbo_fusable(desc, target, xs)) ? affine_stash_bytes(desc, N) : 0;
+  const size_t stash_b = cp ? affine_stash_bytes(desc, N) : 0;  // 0 unless the flow is an LDS-resident RealNVP
   const size_t need = 3 * carve_bytes(xe * es) + 2 * carve_bytes((size_t)N * es) + carve_bytes((size_t)nb_alloc * 8) +
                       carve_bytes(64) + carve_bytes(slabf * es) + carve_bytes(simple_ws) + carve_bytes(stash_b);
   NF_TRY(nf_ws_reserve(ctx, need));
@@ -1499,11 +1499,21 @@ extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, con
     } else {
       NF_TRY(nf_launch_base_sample_tiled(ctx, desc->d, N, seed, sample_offset, stream_id, xt, (float *)logq));
     }
-    NF_TRY(coupling_chain_tiled(ctx, desc, false, (const float *)theta, xt, N, (float *)ladj, -1));
+    if (stash) {  // LDS-resident RealNVP: the plain forward chain leaves the stash, too
+      NF_TRY(coupling_pack(ctx, desc, (const float *)theta));
+      NF_TRY(nf_affine_chain(ctx, desc, false, xt, N, (float *)ladj, stash));
+    } else {
+      NF_TRY(coupling_chain_tiled(ctx, desc, false, (const float *)theta, xt, N, (float *)ladj, -1));
+    }
     // gt = d(-elbo/Ng)/dy = -(1/Ng) grad logp(y);  partial sums of -elbo_j/Ng
     NF_TRY(nf_launch_target_tiled(ctx, target, desc->d, N, xt, (const float *)logq, (const float *)ladj, gt, -inv,
                                   nullptr, partial, -inv));
     NF_TRY(nf_launch_finish_sum(ctx, partial, nb, 0, nullptr, (float *)out + P, nullptr));
+    if (stash) {
+      NF_TRY(nf_affine_bwd_stashed(ctx, desc, stash, gt, nullptr, (float)(-inv), N, (float *)slab,
+                                   coupling_slab_floats(ctx, desc, N), grid));
+      return nf_affine_reduce_slabs(ctx, desc, (const float *)slab, grid, (float *)out);
+    }
     NF_TRY(realnvp_bwd(ctx, desc, (const float *)theta, xt, gt, nullptr, (float)(-inv), N, (float *)slab, grid,
                        (float *)out));
   } else {

@@ -273,7 +273,7 @@ struct FusedArgs {
 
 template <class G, bool INVERSE, bool FUSED = false, bool STASH = false>
 __global__ __launch_bounds__(512) void k_affine_chain(ChainArgs a, float *xt, float *__restrict__ ladj, FusedArgs fa) {
-  static_assert(!STASH || (FUSED && !INVERSE), "the stash belongs to the training step's forward");
+  static_assert(!STASH || !INVERSE, "the stash belongs to the training step's forward");
   static_assert(G::MB == G::CB, "parity blocks must have equal padded size");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int IMG2 = 2 * G::SIZE;  // s and t images of one coupling are adjacent in wimg
@@ -1183,7 +1183,7 @@ static int launch_bwd_v(nf_ctx *ctx, const CouplingArgs &a, float *y, float *yba
 }
 template <class G>
 static int launch_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, float *xt, long N, float *ladj,
-                        const FusedArgs *fused = nullptr) {
+                        const FusedArgs *fused = nullptr, float *stash_plain = nullptr) {
   // two double-buffered (s,t) image pairs + target parameters and per-wave sums of the fused variant
   const size_t lds = (4 * (size_t)G::SIZE + 2 * 64 * G::CB + 2) * sizeof(float) + 8 * sizeof(double);
   static AttrOnce attr_once;  // once per device: a context on another GPU needs its own
@@ -1192,6 +1192,7 @@ static int launch_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, flo
     NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return NF_OK;
   }));
   ChainArgs a;
@@ -1210,6 +1211,10 @@ static int launch_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, flo
     hipLaunchKernelGGL((k_affine_chain<G, false, true>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, *fused);
   else if (inverse)
     hipLaunchKernelGGL((k_affine_chain<G, true>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, none);
+  else if (stash_plain) {  // caller-supplied draws: the plain forward chain, leaving the stash behind
+    none.stash = stash_plain;
+    hipLaunchKernelGGL((k_affine_chain<G, false, false, true>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, none);
+  }
   else
     hipLaunchKernelGGL((k_affine_chain<G, false>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, none);
   return (int)hipGetLastError();
@@ -1239,11 +1244,11 @@ int nf_affine_chain_elbo(nf_ctx *ctx, const nf_flow_desc *desc, long N, uint64_t
 }
 
 // whole chain in one launch, in place on the tiled buffer (packed images must be current)
-int nf_affine_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, float *xt, long N, float *ladj) {
+int nf_affine_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, float *xt, long N, float *ladj, float *stash) {
   const int size = geo_size(desc);
-  if (!size || !ctx->wimg) return NF_ERR_UNSUPPORTED;
-  if (size == NetGeo<1, 1, 1, 1>::SIZE) return launch_chain<NetGeo<1, 1, 1, 1>>(ctx, desc, inverse, xt, N, ladj);
-  return launch_chain<NetGeo<1, 2, 2, 1>>(ctx, desc, inverse, xt, N, ladj);
+  if (!size || !ctx->wimg || (stash && inverse)) return NF_ERR_UNSUPPORTED;
+  if (size == NetGeo<1, 1, 1, 1>::SIZE) return launch_chain<NetGeo<1, 1, 1, 1>>(ctx, desc, inverse, xt, N, ladj, nullptr, stash);
+  return launch_chain<NetGeo<1, 2, 2, 1>>(ctx, desc, inverse, xt, N, ladj, nullptr, stash);
 }
 
 template <class G>
