@@ -92,10 +92,23 @@ for case in range(ncases):
         zi, li = o.comp_inv(specs, th, ys.cpu().numpy().astype(np.float64))
         llr = (o.base_logpdf(obase, zi) + li).mean()
         e_ll = abs(nf.loglikelihood(None, flow, ys) - llr) / max(abs(llr), 1e-30)
+        # forward-KL training (and the closure pullback, nf_flow_bwd through the composition) on well-conditioned data
+        ysd = (0.7 * xs).contiguous()
+        ysd64 = ysd.cpu().numpy().astype(np.float64)
+        lf, gf = nf.loglikelihood_value_and_gradient(flow, ysd)
+        lfo, gfo = o.comp_neg_loglik_value_and_grad(specs, th, ysd64, obase)
+        e_fl = abs(lf - lfo) / max(abs(lfo), 1e-30)
+        e_fg = np.abs(gf.cpu().numpy() - gfo).max() / max(np.abs(gfo).max(), 1e-30)
+        tm, tv = torch.tensor(tmu, device="cuda"), torch.tensor(tvar, device="cuda")
+        lc, gc = nf.value_and_gradient(nf.elbo_batch, flow, lambda y: (-0.5 * (y - tm[:, None]) ** 2 / tv[:, None]).sum(0) -
+                                       0.5 * torch.log(2 * np.pi * tv).sum(), xs)
+        e_cg = np.abs(gc.cpu().numpy() - go).max() / max(np.abs(go).max(), 1e-30)
         has_planar = any(s.kind == "planar" for s in specs)
         ty, tg, ti = (1e-10, 1e-8, 1e-6) if f64 else (5e-5, 5e-4, 2e-2 if has_planar else 1e-3)
         ok = e_y < ty and e_l < 10 * ty and e_v < 20 * ty and e_loss < 20 * ty and e_g < tg and e_inv < ti and e_ll < (100 * ty if not f64 else 1e-8)
-        print(("ok   " if ok else "FAIL ") + tag + f" n={n}  y {e_y:.1e} ladj {e_l:.1e} inv {e_inv:.1e} elbo(rng) {e_v:.1e} loss {e_loss:.1e} grad {e_g:.1e} loglik {e_ll:.1e}")
+        ok = ok and e_fl < 100 * ty and e_fg < 4 * tg and e_cg < tg
+        print(("ok   " if ok else "FAIL ") + tag + f" n={n}  y {e_y:.1e} ladj {e_l:.1e} inv {e_inv:.1e} elbo(rng) {e_v:.1e} loss {e_loss:.1e} grad {e_g:.1e} loglik {e_ll:.1e}"
+              f" fkl {e_fl:.1e} fklgrad {e_fg:.1e} closure-grad {e_cg:.1e}")
         bad += 0 if ok else 1
     except nf.NFHipError as e:
         print("skip " + tag + f"  ({e})")
