@@ -151,6 +151,13 @@ int nf_ctx_synchronize(nf_ctx *ctx);
  * nothing persistent except the ctx; arena sized by nf_workspace_bytes".) */
 int64_t nf_workspace_bytes(nf_ctx *ctx, const nf_flow_desc *desc, int64_t N);
 int nf_ctx_set_arena(nf_ctx *ctx, void *arena_device, size_t bytes);
+/* The training step of the LDS-resident RealNVP path keeps the forward's activations for the reverse pass (an
+ * "activation stash": 46 KiB per 32-sample tile and coupling at d = 64 / hidden 64, i.e. 772 MB at BASELINE cfg 2) --
+ * the Zygote tape of src/optimize.jl:12-14 in kernel form -- while it fits max_bytes; beyond, the reverse pass
+ * recomputes them from the flow output (invertible recompute, slower, no extra memory).  0 disables the stash,
+ * a negative value restores the default (4 GiB, or the environment's NF_AFFINE_STASH_MAX_MB / NF_AFFINE_NO_STASH).
+ * nf_workspace_bytes reflects the setting. */
+int nf_ctx_set_stash_budget(nf_ctx *ctx, int64_t max_bytes);
 
 /* ---- layout -------------------------------------------------------------- */
 /* length(first(Optimisers.destructure(flow)))  (src/NormalizingFlows.jl:67) */

@@ -74,6 +74,7 @@ SYMBOLS = {
     "nf_ctx_synchronize": (C.c_int, [_P]),
     "nf_workspace_bytes": (_I64, [_P, _DESC, _I64]),
     "nf_ctx_set_arena": (C.c_int, [_P, _P, C.c_size_t]),
+    "nf_ctx_set_stash_budget": (C.c_int, [_P, C.c_int64]),
     "nf_param_count": (_I64, [_DESC]),
     "nf_layer_count": (_I32, [_DESC]),
     "nf_base_sample_logpdf": (C.c_int, [_P, _I32, _I32, _I64, _U64, _U64, _U32, _P, _P]),

@@ -581,16 +581,21 @@ static int fused_chain_elbo(nf_ctx *ctx, const nf_flow_desc *desc, const nf_targ
 // The LDS-resident RealNVP training step keeps the forward's activations for the reverse pass (nf_coupling.hip,
 // "activation stash") while they fit the budget: 46 KiB per 32-sample tile and coupling at d = 64 / hidden 64.  NF_AFFINE_STASH_MAX_MB (default 4096) bounds it; beyond, or with
 // NF_AFFINE_NO_STASH set (A/B measurements), the reverse pass recomputes them (k_affine_bwd_all).
-static size_t affine_stash_bytes(const nf_flow_desc *desc, long N) {
+static size_t affine_stash_bytes(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
   if (desc->kind != NF_KIND_REALNVP || desc->dtype != NF_DTYPE_F32 || !nf_affine_supported(desc)) return 0;
   static const bool off = std::getenv("NF_AFFINE_NO_STASH") != nullptr;
-  if (off) return 0;
-  static const size_t cap = [] {
+  static const size_t env_cap = [] {
     const char *e = std::getenv("NF_AFFINE_STASH_MAX_MB");
     return (size_t)(e ? std::atol(e) : 4096) << 20;
   }();
+  const size_t cap = ctx->stash_budget >= 0 ? (size_t)ctx->stash_budget : (off ? 0 : env_cap);
   const size_t b = nf_affine_stash_floats(desc, N) * sizeof(float);
   return b <= cap ? b : 0;
+}
+extern "C" int nf_ctx_set_stash_budget(nf_ctx *ctx, int64_t max_bytes) {
+  if (!ctx) return NF_ERR_ARG;
+  ctx->stash_budget = max_bytes < 0 ? -1 : max_bytes;
+  return NF_OK;
 }
 static long fused_chain_grid(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
   return desc->kind == NF_KIND_NSF ? nf_rqs_chain_grid(ctx, N) : nf_affine_chain_grid(ctx, N);
@@ -1440,7 +1445,7 @@ extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, con
   const bool wide = cp && is_wide(desc);
   const size_t slabf = wide ? nf_wide_train_ws_floats(ctx, desc, N) : cp ? (size_t)grid * coupling_slab_floats(ctx, desc, N) : 0;
   const size_t xe = cp ? tiled_elems(desc, N) : simple_step ? 0 : (size_t)N * desc->d;
-  const size_t stash_b = cp ? affine_stash_bytes(desc, N) : 0;  // 0 unless the flow is an LDS-resident RealNVP
+  const size_t stash_b = cp ? affine_stash_bytes(ctx, desc, N) : 0;  // 0 unless the flow is an LDS-resident RealNVP
   const size_t need = 3 * carve_bytes(xe * es) + 2 * carve_bytes((size_t)N * es) + carve_bytes((size_t)nb_alloc * 8) +
                       carve_bytes(64) + carve_bytes(slabf * es) + carve_bytes(simple_ws) + carve_bytes(stash_b);
   NF_TRY(nf_ws_reserve(ctx, need));
@@ -1688,7 +1693,7 @@ static size_t ws_need_bound(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
       if (sw > simple_ws) simple_ws = sw;
     }
     upd(3 * carve_bytes(xe * es) + 2 * cn + carve_bytes((size_t)nb_alloc * 8) + carve_bytes(64) + carve_bytes(slabf * es) +
-        carve_bytes(simple_ws) + carve_bytes(cp ? affine_stash_bytes(desc, N) : 0));
+        carve_bytes(simple_ws) + carve_bytes(cp ? affine_stash_bytes(ctx, desc, N) : 0));
   }
   return need;
 }

@@ -56,6 +56,9 @@ struct nf_ctx {
   // > 0 while a wrapper entry point has buffers of its own behind the first ws_guard bytes of `ws`: inner requests
   // beyond the guard fail instead of overlapping them
   size_t ws_guard = 0;
+  // activation-stash budget of the LDS-resident RealNVP training step (nf_ctx_set_stash_budget); -1: the default
+  // (NF_AFFINE_STASH_MAX_MB or 4 GiB; 0 with NF_AFFINE_NO_STASH)
+  long long stash_budget = -1;
   // RCCL communicator of this context (nf_comm.hip); null for single-GPU use
   void *comm = nullptr;
   int comm_size = 1, comm_rank = 0;

@@ -1138,6 +1138,76 @@ def test_heterogeneous_create_flow(nf, dtn, general_base):
     assert isinstance(trained, nf.CompositeFlow) and stats[-1]["loss"] < stats[0]["loss"] and st.t == 5
 
 
+def fp32_recompute_floor(spec, th64, otgt, xs64):
+    """The float32 oracle's gradient with every layer input RECONSTRUCTED by inverting the chain from its output in
+    float32 -- what an invertible-recompute reverse pass (k_affine_bwd_all) differentiates.  Its distance from the float64
+    gradient grows with depth like the float32 round-trip error of the flow; the stashed pass does not have that term."""
+    th32, xs32 = P.f32(th64, xs64)
+    t32 = P.f32(otgt)
+    n = xs32.shape[1]
+    y32, _ = o.flow_fwd(spec, th32, xs32)
+    order = list(reversed(o.layers_flat_order(spec)))
+    rec, cur = [None] * (len(order) + 1), y32
+    rec[len(order)] = y32
+    for i in range(len(order) - 1, -1, -1):
+        cur, _ = o._layer_inv(spec, th32, order[i], cur)
+        rec[i] = cur
+    ybar = (-o.target_grad(t32, y32) / n).astype(np.float32)
+    lbar = np.full(n, -1.0 / n, dtype=np.float32)
+    return o.flow_bwd(spec, th32, rec, ybar, lbar)[1]
+
+
+@pytest.mark.parametrize("shape", ["d64_h64", "d20_h32", "d63_h40x64"])
+def test_realnvp_step_stash_and_recompute_reverse_passes_against_oracle(nf, shape):
+    """The LDS-resident RealNVP training step has two reverse passes: from the forward's activation stash
+    (k_affine_bwd_stashed, the default) and with invertible recompute (k_affine_bwd_all; nf_ctx_set_stash_budget(0), also
+    what nf_flow_bwd and memory-constrained callers get).  Both, on in-library and on supplied draws, against the oracle's
+    loss and gradient (src/optimize.jl:12-14 on src/objectives/elbo.jl:93-97), non-multiples of the 32-sample tile included;
+    the workspace query follows the budget."""
+    import ctypes as C
+    d, hd, nl, n = {"d64_h64": (64, (64, 64), 4, 2048 + 17), "d20_h32": (20, (32, 32), 2, 333), "d63_h40x64": (63, (40, 64), 2, 1024)}[shape]
+    flow = nf.realnvp(nf.MvNormal(d), hd, nl, paramtype=torch.float32, seed=11)
+    gen = torch.Generator().manual_seed(3)
+    flow = flow.with_theta(flow.theta + 0.03 * torch.randn(flow.P, generator=gen).to("cuda"))
+    rng = np.random.default_rng(d)
+    mu, var = rng.standard_normal(d).astype(np.float32), (rng.uniform(size=d) + 0.5).astype(np.float32)
+    tgt = nf.DiagGaussTarget(torch.tensor(mu, device="cuda"), torch.tensor(var, device="cuda"))
+    spec = o.FlowSpec("realnvp", d, nl, hd)
+    th64 = flow.theta.cpu().numpy().astype(np.float64)
+    xs = nf.device_specific_rand(nf.PhiloxRNG(21), flow.dist, n)
+    xs64 = xs.cpu().numpy().astype(np.float64)
+    otgt = ("diaggauss", mu.astype(np.float64), var.astype(np.float64))
+    lo, go = o.neg_elbo_value_and_grad(spec, th64, otgt, xs64)
+    _, g32 = o.neg_elbo_value_and_grad(spec, P.f32(th64), P.f32(otgt), P.f32(xs64))
+    g32_rec = fp32_recompute_floor(spec, th64, otgt, xs64)
+    lib, ctx = nf.load_library(), flow.ctx
+    need = {}
+    try:
+        for mode, budget in (("stash", -1), ("recompute", 0)):
+            nf._lib.check(lib.nf_ctx_set_stash_budget(ctx.ptr, budget))
+            need[mode] = int(lib.nf_workspace_bytes(ctx.ptr, C.byref(flow.desc), n))
+            for form, arg in (("rng", n), ("xs", xs)):
+                loss, g = nf.value_and_gradient(nf.elbo_batch, flow, tgt, arg, rng=nf.PhiloxRNG(21))
+                P.scalar(f"realnvp {shape} {mode} ({form}): step loss", loss, lo)
+                if mode == "stash":
+                    P.gradient(f"realnvp {shape} {mode} ({form}): step grad", g, go, floor=g32)
+                else:
+                    # Invertible recompute re-derives every hidden activation from a float32 reconstruction of the layer
+                    # input (error 2e-5 ... 9e-5 here); a unit within that distance of its leaky-ReLU kink takes the other
+                    # slope, a discrete change of about |delta a| / n per (sample, unit).  The float64 oracle with its
+                    # states perturbed by 1e-6 shows the same 3e-3 |g|inf jumps in the first-applied couplings (DESIGN 5).
+                    # Bound: the larger of the tolerance, the float32 reconstruct-by-inversion oracle's own error, 2e-3.
+                    gnp, ref = g.cpu().numpy().astype(np.float64), go
+                    err = float(np.abs(gnp - ref).max() / np.abs(ref).max())
+                    frec = float(np.abs(g32_rec - ref).max() / np.abs(ref).max())
+                    P.record(f"realnvp {shape} {mode} ({form}): step grad [max abs err / |g|inf]", err)
+                    P.record(f"realnvp {shape} {mode} ({form}): step grad [fp32 reconstruct-by-inversion oracle, max abs err / |g|inf]", frec)
+                    assert err <= max(P.GRAD_RTOL, P.CFLOOR * frec, 2e-3), (shape, form, err, frec)
+    finally:
+        nf._lib.check(lib.nf_ctx_set_stash_budget(ctx.ptr, -1))
+    assert need["stash"] > need["recompute"] > 0
+
+
 RAND_CASES = {
     "planar5": ("planar", 5, 4, (), 0, 0.0, "float32"), "radial64": ("radial", 64, 3, (), 0, 0.0, "float32"),
     "planar100_f64": ("planar", 100, 2, (), 0, 0.0, "float64"), "realnvp5": ("realnvp", 5, 2, (32, 32), 0, 0.0, "float32"),
