@@ -153,10 +153,13 @@ int64_t nf_workspace_bytes(nf_ctx *ctx, const nf_flow_desc *desc, int64_t N);
 int nf_ctx_set_arena(nf_ctx *ctx, void *arena_device, size_t bytes);
 /* The training step of the LDS-resident RealNVP path keeps the forward's activations for the reverse pass (an
  * "activation stash": 46 KiB per 32-sample tile and coupling at d = 64 / hidden 64, i.e. 772 MB at BASELINE cfg 2) --
- * the Zygote tape of src/optimize.jl:12-14 in kernel form -- while it fits max_bytes; beyond, the reverse pass
- * recomputes them from the flow output (invertible recompute, slower, no extra memory).  0 disables the stash,
- * a negative value restores the default (4 GiB, or the environment's NF_AFFINE_STASH_MAX_MB / NF_AFFINE_NO_STASH).
- * nf_workspace_bytes reflects the setting. */
+ * the Zygote tape of src/optimize.jl:12-14 in kernel form.  max_bytes bounds the buffer: a batch whose stash is larger
+ * runs chunk by chunk through it (forward + reverse pass per chunk, all chunks' gradient slabs reduced together; same
+ * result up to float32 summation order).  nf_elbo_value_and_grad / nf_elbo_step and nf_loglikelihood_value_and_grad
+ * (the inverse chain stashes for ITS reverse pass) use it.  0 disables the stash: the reverse pass then recomputes the
+ * activations from the flow output (invertible recompute: slower, no extra memory, and every leaky-ReLU slope is decided
+ * again on a float32 reconstruction of the layer input -- DESIGN.md section 5).  A negative value restores the default
+ * (4 GiB, or the environment's NF_AFFINE_STASH_MAX_MB / NF_AFFINE_NO_STASH).  nf_workspace_bytes reflects the setting. */
 int nf_ctx_set_stash_budget(nf_ctx *ctx, int64_t max_bytes);
 
 /* ---- layout -------------------------------------------------------------- */

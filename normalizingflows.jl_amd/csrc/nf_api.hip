@@ -45,7 +45,7 @@ int nf_affine_chain_elbo(nf_ctx *, const nf_flow_desc *, long N, uint64_t seed, 
                          double pscale, float *stash = nullptr);
 size_t nf_affine_stash_floats(const nf_flow_desc *desc, long N);
 int nf_affine_bwd_stashed(nf_ctx *, const nf_flow_desc *, float *stash, float *ybar, const float *lbar, float lbar_const, long N,
-                          float *slab, long slab_stride, int grid);
+                          float *slab, long slab_stride, int grid, bool inv_dir = false);
 long nf_affine_slab_floats(const nf_flow_desc *desc);
 int nf_affine_reduce_slabs(nf_ctx *, const nf_flow_desc *, const float *slab, int nslab, float *g,
                            const double *lpart = nullptr, int nlpart = 0, float *lout = nullptr);
@@ -581,6 +581,7 @@ static int fused_chain_elbo(nf_ctx *ctx, const nf_flow_desc *desc, const nf_targ
 // The LDS-resident RealNVP training step keeps the forward's activations for the reverse pass (nf_coupling.hip,
 // "activation stash") while they fit the budget: 46 KiB per 32-sample tile and coupling at d = 64 / hidden 64.  NF_AFFINE_STASH_MAX_MB (default 4096) bounds it; beyond, or with
 // NF_AFFINE_NO_STASH set (A/B measurements), the reverse pass recomputes them (k_affine_bwd_all).
+#define NF_STASH_TILE 32
 static size_t affine_stash_bytes(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
   if (desc->kind != NF_KIND_REALNVP || desc->dtype != NF_DTYPE_F32 || !nf_affine_supported(desc)) return 0;
   static const bool off = std::getenv("NF_AFFINE_NO_STASH") != nullptr;
@@ -591,6 +592,21 @@ static size_t affine_stash_bytes(nf_ctx *ctx, const nf_flow_desc *desc, long N) 
   const size_t cap = ctx->stash_budget >= 0 ? (size_t)ctx->stash_budget : (off ? 0 : env_cap);
   const size_t b = nf_affine_stash_floats(desc, N) * sizeof(float);
   return b <= cap ? b : 0;
+}
+// Batches whose stash exceeds the budget run the step in CHUNKS of samples (forward + reverse pass per chunk through one
+// stash-sized buffer, every chunk's gradient slabs reduced together at the end): chunk size in samples, a multiple of
+// 1024 tiles so that every chunk fills the chip evenly; N itself if one chunk does; 0 if the stash is off.
+static long affine_stash_chunk(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
+  if (affine_stash_bytes(ctx, desc, N)) return N;
+  // largest multiple of `unit` tiles whose stash passes the budget test (unit: 1024 tiles = 4 per wave of the chip, or
+  // one workgroup's 4 tiles under a very small budget)
+  const long unit = affine_stash_bytes(ctx, desc, 1024L * NF_STASH_TILE) ? 1024 : 4;
+  long lo = 0, hi = (N / NF_STASH_TILE) / unit + 1;
+  while (lo + 1 < hi) {
+    const long mid = (lo + hi) / 2;
+    if (affine_stash_bytes(ctx, desc, mid * unit * NF_STASH_TILE)) lo = mid; else hi = mid;
+  }
+  return lo * unit * NF_STASH_TILE;
 }
 extern "C" int nf_ctx_set_stash_budget(nf_ctx *ctx, int64_t max_bytes) {
   if (!ctx) return NF_ERR_ARG;
@@ -931,8 +947,13 @@ extern "C" int nf_loglikelihood_value_and_grad(nf_ctx *ctx, const nf_flow_desc *
   const size_t flat_ws = tiled ? 0 : hf ? nf_hf_bwd_ws_bytes(desc, N) : coupling_kind ? nf_g64_bwd_inv_ws_bytes(desc, N)
                                                                                        : nf_simple_bwd_ws_bytes(ctx, desc, N);
   const size_t xe = tiled ? tiled_elems(desc, N) : (size_t)N * desc->d;
+  // LDS-resident RealNVP: activation stash of the inverse chain, the batch in chunks beyond the budget
+  const long stash_nc = tiled ? affine_stash_chunk(ctx, desc, N) : 0;
+  const int stash_nch = stash_nc ? (int)((N + stash_nc - 1) / stash_nc) : 0;
+  const size_t stash_b = stash_nc ? affine_stash_bytes(ctx, desc, stash_nc) : 0;
+  const size_t slabf_all = slabf * (stash_nch > 1 ? stash_nch : 1);
   const size_t need = 2 * carve_bytes(xe * es) + carve_bytes((size_t)N * es) + carve_bytes((size_t)nb * 8) +
-                      carve_bytes(2 * (size_t)desc->d * es) + carve_bytes(slabf * es) + carve_bytes(flat_ws);
+                      carve_bytes(2 * (size_t)desc->d * es) + carve_bytes(slabf_all * es) + carve_bytes(flat_ws) + carve_bytes(stash_b);
   NF_TRY(nf_ws_reserve(ctx, need));
   Carver cv(ctx->ws);
   char *z = cv.take<char>(xe * es);
@@ -940,8 +961,9 @@ extern "C" int nf_loglikelihood_value_and_grad(nf_ctx *ctx, const nf_flow_desc *
   char *ladj = cv.take<char>((size_t)N * es);
   double *partial = cv.take<double>(nb);
   char *q0par = cv.take<char>(2 * (size_t)desc->d * es);
-  char *slab = cv.take<char>(slabf * es);
+  char *slab = cv.take<char>(slabf_all * es);
   char *fws = cv.take<char>(flat_ws);
+  float *stash = stash_b ? cv.take<float>(stash_b / 4) : nullptr;
   nf_target q0;
   q0.kind = NF_TARGET_DIAGGAUSS;
   q0.p0 = q0par;
@@ -953,6 +975,24 @@ extern "C" int nf_loglikelihood_value_and_grad(nf_ctx *ctx, const nf_flow_desc *
   if (tiled) {
     float *zt = (float *)z, *gt = (float *)gbar;
     NF_TRY(nf_launch_layout_convert(ctx, desc->d, N, (const float *)ys, zt, 1));
+    if (stash) {  // the inverse chain leaves the operands of its own reverse pass (nf_coupling.hip, "activation stash")
+      NF_TRY(coupling_pack(ctx, desc, (const float *)theta));
+      const long stride = coupling_slab_floats(ctx, desc, N);
+      long nslab = 0, npart = 0;
+      for (long o = 0; o < N; o += stash_nc) {
+        const long nc = N - o < stash_nc ? N - o : stash_nc;
+        const int gc = coupling_bwd_grid(ctx, desc, nc);
+        NF_TRY(nf_affine_chain(ctx, desc, true, zt + o * desc->d, nc, (float *)ladj + o, stash));
+        NF_TRY(nf_launch_target_tiled(ctx, &q0, desc->d, nc, zt + o * desc->d, nullptr, (const float *)ladj + o, gt + o * desc->d, -inv,
+                                      nullptr, partial + npart, -inv));
+        NF_TRY(nf_affine_bwd_stashed(ctx, desc, stash, gt + o * desc->d, nullptr, (float)(-inv), nc, (float *)slab + nslab * stride,
+                                     stride, gc, true));
+        nslab += gc;
+        npart += nf_target_tiled_nblocks(nc);
+      }
+      NF_TRY(nf_launch_finish_sum(ctx, partial, npart, 0, nullptr, (float *)out + P, nullptr));
+      return nf_affine_reduce_slabs(ctx, desc, (const float *)slab, (int)nslab, (float *)out);
+    }
     NF_TRY(coupling_chain_tiled(ctx, desc, true, (const float *)theta, zt, N, (float *)ladj, -1));
     NF_TRY(nf_launch_target_tiled(ctx, &q0, desc->d, N, zt, nullptr, (const float *)ladj, gt, -inv, nullptr, partial, -inv));
     NF_TRY(nf_launch_finish_sum(ctx, partial, nb, 0, nullptr, (float *)out + P, nullptr));
@@ -1442,10 +1482,17 @@ extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, con
   static const bool no_step = std::getenv("NF_SIMPLE_STASH") != nullptr;  // A/B switch: the two-kernel stash path
   const bool simple_step = simple_kind && !no_step && nf_simple_step_supported(desc);
   const size_t simple_ws = cp ? 0 : simple_step ? nf_simple_step_ws_bytes(ctx, desc, N) : flat_bwd_ws_bytes(ctx, desc, N);
+  // LDS-resident RealNVP: activation stash for the reverse pass, the batch in chunks if it exceeds the budget (in-library
+  // draws; caller-supplied draws take one chunk or the recompute kernel)
+  const bool fusable = cp && elbo_fusable(desc, target, xs);
+  long stash_nc = cp ? affine_stash_chunk(ctx, desc, N) : 0;
+  if (stash_nc < N && !fusable) stash_nc = 0;
+  const int stash_nch = stash_nc ? (int)((N + stash_nc - 1) / stash_nc) : 0;
+  const size_t stash_b = stash_nc ? affine_stash_bytes(ctx, desc, stash_nc) : 0;
   const bool wide = cp && is_wide(desc);
-  const size_t slabf = wide ? nf_wide_train_ws_floats(ctx, desc, N) : cp ? (size_t)grid * coupling_slab_floats(ctx, desc, N) : 0;
+  const size_t slabf = wide ? nf_wide_train_ws_floats(ctx, desc, N)
+                            : cp ? (size_t)grid * coupling_slab_floats(ctx, desc, N) * (stash_nch > 1 ? stash_nch : 1) : 0;
   const size_t xe = cp ? tiled_elems(desc, N) : simple_step ? 0 : (size_t)N * desc->d;
-  const size_t stash_b = cp ? affine_stash_bytes(ctx, desc, N) : 0;  // 0 unless the flow is an LDS-resident RealNVP
   const size_t need = 3 * carve_bytes(xe * es) + 2 * carve_bytes((size_t)N * es) + carve_bytes((size_t)nb_alloc * 8) +
                       carve_bytes(64) + carve_bytes(slabf * es) + carve_bytes(simple_ws) + carve_bytes(stash_b);
   NF_TRY(nf_ws_reserve(ctx, need));
@@ -1462,16 +1509,25 @@ extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, con
   char *sws = cv.take<char>(simple_ws);
   float *stash = stash_b ? cv.take<float>(stash_b / 4) : nullptr;
 
-  if (cp && elbo_fusable(desc, target, xs)) {
+  if (fusable) {
     float *xt = (float *)x, *gt = (float *)gbar;
     NF_TRY(coupling_pack(ctx, desc, (const float *)theta));
-    NF_TRY(fused_chain_elbo(ctx, desc, target, N, seed, sample_offset, stream_id, xt, gt, -inv, partial, -inv, stash));
-    if (stash) {  // reverse pass from the stash: no recompute, the state is not touched
-      NF_TRY(nf_affine_bwd_stashed(ctx, desc, stash, gt, nullptr, (float)(-inv), N, (float *)slab,
-                                   coupling_slab_floats(ctx, desc, N), grid));
-      return nf_affine_reduce_slabs(ctx, desc, (const float *)slab, grid, (float *)out, partial, (int)nf_affine_chain_grid(ctx, N),
-                                    (float *)out + P);
+    if (stash) {  // forward with stash + reverse pass from it, chunk by chunk: no recompute, the state is not touched
+      const long stride = coupling_slab_floats(ctx, desc, N);
+      long nslab = 0, npart = 0;
+      for (long o = 0; o < N; o += stash_nc) {
+        const long nc = N - o < stash_nc ? N - o : stash_nc;
+        const int gc = coupling_bwd_grid(ctx, desc, nc);
+        NF_TRY(fused_chain_elbo(ctx, desc, target, nc, seed, sample_offset + (uint64_t)o, stream_id, xt + o * desc->d,
+                                gt + o * desc->d, -inv, partial + npart, -inv, stash));
+        NF_TRY(nf_affine_bwd_stashed(ctx, desc, stash, gt + o * desc->d, nullptr, (float)(-inv), nc,
+                                     (float *)slab + nslab * stride, stride, gc));
+        nslab += gc;
+        npart += nf_affine_chain_grid(ctx, nc);
+      }
+      return nf_affine_reduce_slabs(ctx, desc, (const float *)slab, (int)nslab, (float *)out, partial, (int)npart, (float *)out + P);
     }
+    NF_TRY(fused_chain_elbo(ctx, desc, target, N, seed, sample_offset, stream_id, xt, gt, -inv, partial, -inv));
     if (is_nsf(desc)) {
       NF_TRY(nf_launch_finish_sum(ctx, partial, fused_chain_grid(ctx, desc, N), 0, nullptr, (float *)out + P, nullptr));
       return realnvp_bwd(ctx, desc, (const float *)theta, xt, gt, nullptr, (float)(-inv), N, (float *)slab, grid, (float *)out);
@@ -1679,8 +1735,10 @@ static size_t ws_need_bound(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
       const size_t slabf = tiled ? slab_pull : 0;
       const size_t flat_ws = tiled ? 0 : hf ? nf_hf_bwd_ws_bytes(desc, N) : coupling_kind ? nf_g64_bwd_inv_ws_bytes(desc, N)
                                                                                        : nf_simple_bwd_ws_bytes(ctx, desc, N);
+      const long snc = tiled ? affine_stash_chunk(ctx, desc, N) : 0;
+      const size_t nch = snc ? (size_t)((N + snc - 1) / snc) : 1;
       upd(2 * carve_bytes(xe * es) + cn + carve_bytes((size_t)nbt * 8) + carve_bytes(2 * (size_t)desc->d * es) +
-          carve_bytes(slabf * es) + carve_bytes(flat_ws));
+          carve_bytes(slabf * nch * es) + carve_bytes(flat_ws) + carve_bytes(snc ? affine_stash_bytes(ctx, desc, snc) : 0));
     }
   }
   // nf_elbo_value_and_grad / nf_elbo_step (both the stash-free and the stash form of the simple flows)
@@ -1692,8 +1750,10 @@ static size_t ws_need_bound(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
       const size_t sw = nf_simple_step_ws_bytes(ctx, desc, N);
       if (sw > simple_ws) simple_ws = sw;
     }
-    upd(3 * carve_bytes(xe * es) + 2 * cn + carve_bytes((size_t)nb_alloc * 8) + carve_bytes(64) + carve_bytes(slabf * es) +
-        carve_bytes(simple_ws) + carve_bytes(cp ? affine_stash_bytes(ctx, desc, N) : 0));
+    const long snc = cp ? affine_stash_chunk(ctx, desc, N) : 0;
+    const size_t nch = snc ? (size_t)((N + snc - 1) / snc) : 1;
+    upd(3 * carve_bytes(xe * es) + 2 * cn + carve_bytes((size_t)nb_alloc * 8) + carve_bytes(64) +
+        carve_bytes(slabf * (wide ? 1 : nch) * es) + carve_bytes(simple_ws) + carve_bytes(snc ? affine_stash_bytes(ctx, desc, snc) : 0));
   }
   return need;
 }

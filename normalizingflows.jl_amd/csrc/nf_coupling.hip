@@ -229,7 +229,9 @@ __device__ __forceinline__ void net_forward_stash(const float *__restrict__ img,
 }
 
 // forward coupling of the training step: as coupling_step<G, false>, leaving the reverse pass's operands behind
-template <class G>
+// INVERSE (forward-KL training: the chain runs data -> base): w1 = (v1 - t) exp(-s); the UV slot then holds w1, which is
+// what the reverse pass of the inverse coupling needs next to s (bwd_tile's INVD algebra)
+template <class G, bool INVERSE = false>
 __device__ __forceinline__ float coupling_step_stash(const float *__restrict__ img_s, const float *__restrict__ img_t,
                                                      f32x16 (&x1)[G::CB], const f32x16 (&xb)[G::MB], int l31, int hi,
                                                      const StashIO &st) {
@@ -244,10 +246,16 @@ __device__ __forceinline__ float coupling_step_stash(const float *__restrict__ i
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float s = nf_tanh(S[b][r]);
-      const float u = x1[b][r] * nf_exp(s);
-      x1[b][r] = u + T[b][r];
+      if (INVERSE) {
+        const float w = nf_fdiv(x1[b][r] - T[b][r], nf_exp(s));
+        x1[b][r] = w;
+        T[b][r] = w;
+      } else {
+        const float u = x1[b][r] * nf_exp(s);
+        x1[b][r] = u + T[b][r];
+        T[b][r] = u;
+      }
       S[b][r] = s;
-      T[b][r] = u;
       lsum += s;
     }
   stash_put_lane<G::CB>(st, SG::SV, S);
@@ -273,7 +281,7 @@ struct FusedArgs {
 
 template <class G, bool INVERSE, bool FUSED = false, bool STASH = false>
 __global__ __launch_bounds__(512) void k_affine_chain(ChainArgs a, float *xt, float *__restrict__ ladj, FusedArgs fa) {
-  static_assert(!STASH || !INVERSE, "the stash belongs to the training step's forward");
+  static_assert(!STASH || !FUSED || !INVERSE, "the fused ELBO forward runs base -> data");
   static_assert(G::MB == G::CB, "parity blocks must have equal padded size");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int IMG2 = 2 * G::SIZE;  // s and t images of one coupling are adjacent in wimg
@@ -387,8 +395,8 @@ __global__ __launch_bounds__(512) void k_affine_chain(ChainArgs a, float *xt, fl
         float ls;
         if (STASH) {
           const StashIO st = make_stash_io(fa.stash, tl * a.ncoup + coupling_at(pos), StashGeo<G>::SIZE, live, l31, hi);
-          if (half == 0) ls = coupling_step_stash<G>(img_s, img_t, O, E, l31, hi, st);
-          else ls = coupling_step_stash<G>(img_s, img_t, E, O, l31, hi, st);
+          if (INVERSE ? (half == 1) : (half == 0)) ls = coupling_step_stash<G, INVERSE>(img_s, img_t, O, E, l31, hi, st);
+          else ls = coupling_step_stash<G, INVERSE>(img_s, img_t, E, O, l31, hi, st);
         } else if (INVERSE ? (half == 1) : (half == 0)) {
           (void)x1_is_O;
           ls = coupling_step<G, INVERSE>(img_s, img_t, O, E, l31, hi);
@@ -904,7 +912,9 @@ __device__ __forceinline__ void stash_issue_first(StashFirst<G> &f, float *stash
   stash_get_lane<G::CB>(st, SG::UV, f.uv);
 }
 
-template <class G, bool PHASE_S, bool FULL>
+// INVD: reverse pass of the INVERSE coupling (forward-KL training; algebra as in bwd_tile): the UV slot holds w1, phase S
+// runs first (it needs w1bar and w1 and leaves v1bar = w1bar exp(-s) behind), phase T seeds with -v1bar.
+template <class G, bool PHASE_S, bool FULL, bool INVD = false>
 __device__ __forceinline__ void bwd_tile_stashed(const CouplingArgs &a, const float *__restrict__ img, float *__restrict__ sd,
                                                  BwdAcc<G> &acc, StashFirst<G> &f, float *stash, int k, int ncoup,
                                                  float *__restrict__ ybar, const float *__restrict__ lbar, float lbar_const,
@@ -938,7 +948,11 @@ __device__ __forceinline__ void bwd_tile_stashed(const CouplingArgs &a, const fl
       const bool ok = (p < a.c) && valid;
       const float gv = g1[b][r];
       if (!PHASE_S) {
-        d3[b][r] = ok ? gv : 0.f;  // T-bar = ybar1
+        d3[b][r] = ok ? (INVD ? -gv : gv) : 0.f;  // T-bar = ybar1 (inverse: -v1bar)
+      } else if (INVD) {
+        const float s = f.sv[b][r];
+        tile_store(gio, tile_soff(b, r, a.par_t), nf_fdiv(gv, nf_exp(s)));  // v1bar
+        d3[b][r] = ok ? -(gv * f.uv[b][r] + lb) * (1.f - s * s) : 0.f;     // S-bar through tanh (uv = w1)
       } else {
         const float s = f.sv[b][r];
         tile_store(gio, tile_soff(b, r, a.par_t), gv * nf_exp(s));  // x1bar
@@ -983,7 +997,7 @@ __device__ __forceinline__ void bwd_tile_stashed(const CouplingArgs &a, const fl
   wave_lds_fence();
 }
 
-template <class G, bool FULL>
+template <class G, bool FULL, bool INVD = false>
 __global__ __launch_bounds__(256, 1) void k_affine_bwd_stashed(BwdAllArgs aa, float *stash, float *__restrict__ ybar,
                                                                const float *__restrict__ lbar, float lbar_const,
                                                                float *__restrict__ slab, long slab_stride) {
@@ -996,8 +1010,10 @@ __global__ __launch_bounds__(256, 1) void k_affine_bwd_stashed(BwdAllArgs aa, fl
   const long ntiles = (aa.N + NF_TILE - 1) / NF_TILE;
   const long tile0 = (long)blockIdx.x * 4 + wave, tstride = (long)gridDim.x * 4;
   StashFirst<G> f;
+  if (INVD && tile0 < ntiles) stash_issue_first<G>(f, stash, aa.ncoup - 1, aa.ncoup, tile0, l31, hi);  // S runs first
 #pragma unroll 1
-  for (int k = 0; k < aa.ncoup; ++k) {
+  for (int step = 0; step < aa.ncoup; ++step) {
+    const int k = INVD ? aa.ncoup - 1 - step : step;  // the inverse chain's reverse pass runs in execution order
     CouplingArgs a;
     a.theta = nullptr;
     a.img_s = aa.wimg + (size_t)(2 * k) * G::SIZE;
@@ -1011,7 +1027,7 @@ __global__ __launch_bounds__(256, 1) void k_affine_bwd_stashed(BwdAllArgs aa, fl
     float *kslab = slab + (long)k * 2 * G::SIZE;
 #pragma unroll 1
     for (int phase = 0; phase < 2; ++phase) {
-      const bool is_s = phase == 1;
+      const bool is_s = INVD ? phase == 0 : phase == 1;
       stage_packed<G::SIZE, 256>(img, is_s ? a.img_s : a.img_t, tid);
       __syncthreads();
       BwdAcc<G> acc;
@@ -1021,12 +1037,15 @@ __global__ __launch_bounds__(256, 1) void k_affine_bwd_stashed(BwdAllArgs aa, fl
 #pragma unroll 1
       for (long tile = tile0; tile < ntiles; tile += tstride) {
         const long nt = tile + tstride < ntiles ? tile + tstride : -1;
-        if (!is_s) bwd_tile_stashed<G, false, FULL>(a, img, sd, acc, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, l31, hi);
-        else bwd_tile_stashed<G, true, FULL>(a, img, sd, acc, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, l31, hi);
+        if (!is_s) bwd_tile_stashed<G, false, FULL, INVD>(a, img, sd, acc, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, l31, hi);
+        else bwd_tile_stashed<G, true, FULL, INVD>(a, img, sd, acc, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, l31, hi);
       }
       __syncthreads();  // every wave is done with the weight image and its scratch
-      // s and u of phase S's first tile fly behind the fold, the slab write and the staging of the s-net image
-      if (!is_s && tile0 < ntiles) stash_issue_first<G>(f, stash, k, aa.ncoup, tile0, l31, hi);
+      // s and u of the next phase-S's first tile fly behind the fold, the slab write and the staging of the next image
+      if (tile0 < ntiles) {
+        if (!INVD && !is_s) stash_issue_first<G>(f, stash, k, aa.ncoup, tile0, l31, hi);
+        if (INVD && !is_s && step + 1 < aa.ncoup) stash_issue_first<G>(f, stash, k - 1, aa.ncoup, tile0, l31, hi);
+      }
       {
         float *mine = lds + wave * G::SIZE;
         fold_acc(mine + G::W1, mine + G::B1, acc.w1, acc.b1, true, l31, hi);
@@ -1193,6 +1212,7 @@ static int launch_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, flo
     NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return NF_OK;
   }));
   ChainArgs a;
@@ -1209,7 +1229,10 @@ static int launch_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, flo
     hipLaunchKernelGGL((k_affine_chain<G, false, true, true>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, *fused);
   else if (fused)
     hipLaunchKernelGGL((k_affine_chain<G, false, true>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, *fused);
-  else if (inverse)
+  else if (inverse && stash_plain) {  // forward-KL training: the inverse chain leaves the stash of ITS reverse pass
+    none.stash = stash_plain;
+    hipLaunchKernelGGL((k_affine_chain<G, true, false, true>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, none);
+  } else if (inverse)
     hipLaunchKernelGGL((k_affine_chain<G, true>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, none);
   else if (stash_plain) {  // caller-supplied draws: the plain forward chain, leaving the stash behind
     none.stash = stash_plain;
@@ -1246,7 +1269,7 @@ int nf_affine_chain_elbo(nf_ctx *ctx, const nf_flow_desc *desc, long N, uint64_t
 // whole chain in one launch, in place on the tiled buffer (packed images must be current)
 int nf_affine_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, float *xt, long N, float *ladj, float *stash) {
   const int size = geo_size(desc);
-  if (!size || !ctx->wimg || (stash && inverse)) return NF_ERR_UNSUPPORTED;
+  if (!size || !ctx->wimg) return NF_ERR_UNSUPPORTED;
   if (size == NetGeo<1, 1, 1, 1>::SIZE) return launch_chain<NetGeo<1, 1, 1, 1>>(ctx, desc, inverse, xt, N, ladj, nullptr, stash);
   return launch_chain<NetGeo<1, 2, 2, 1>>(ctx, desc, inverse, xt, N, ladj, nullptr, stash);
 }
@@ -1332,17 +1355,17 @@ size_t nf_affine_stash_floats(const nf_flow_desc *desc, long N) {
   return ntiles * (size_t)(2 * desc->nlayers) * per;
 }
 
-template <class G, bool FULL>
+template <class G, bool FULL, bool INVD = false>
 static int launch_bwd_stashed_v(nf_ctx *ctx, const BwdAllArgs &aa, float *stash, float *ybar, const float *lbar, float lbar_const,
                                 float *slab, long slab_stride, int grid) {
   const size_t lds = BwdStashLds<G>::BYTES;
   static AttrOnce attr_once;  // once per device
   NF_TRY(attr_once.run(ctx->device, [&]() -> int {
-    NF_HIP(hipFuncSetAttribute((const void *)k_affine_bwd_stashed<G, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NF_HIP(hipFuncSetAttribute((const void *)k_affine_bwd_stashed<G, FULL, INVD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return NF_OK;
   }));
-  ProfScope ps(ctx, "affine_bwd");
-  hipLaunchKernelGGL((k_affine_bwd_stashed<G, FULL>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, aa, stash, ybar, lbar,
+  ProfScope ps(ctx, INVD ? "affine_bwd_inv" : "affine_bwd");
+  hipLaunchKernelGGL((k_affine_bwd_stashed<G, FULL, INVD>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, aa, stash, ybar, lbar,
                      lbar_const, slab, slab_stride);
   return (int)hipGetLastError();
 }
@@ -1350,7 +1373,7 @@ static int launch_bwd_stashed_v(nf_ctx *ctx, const BwdAllArgs &aa, float *stash,
 // reverse pass of all couplings from the stash nf_affine_chain_elbo(..., stash) left (same slab layout as
 // nf_affine_bwd_all; ybar: cotangent of the flow output on entry, of the flow input on exit)
 int nf_affine_bwd_stashed(nf_ctx *ctx, const nf_flow_desc *desc, float *stash, float *ybar, const float *lbar, float lbar_const,
-                          long N, float *slab, long slab_stride, int grid) {
+                          long N, float *slab, long slab_stride, int grid, bool inv_dir) {
   const int size = geo_size(desc);
   if (!size || !ctx->wimg || desc->n_hidden != 2 || !stash) return NF_ERR_UNSUPPORTED;
   BwdAllArgs aa;
@@ -1361,6 +1384,12 @@ int nf_affine_bwd_stashed(nf_ctx *ctx, const nf_flow_desc *desc, float *stash, f
   aa.N = N;
   const bool h64 = size != NetGeo<1, 1, 1, 1>::SIZE;
   const bool full = desc->d == 64 && N % NF_TILE == 0;
+  if (inv_dir) {  // forward-KL training: the stash of the inverse chain (nf_affine_chain(inverse, stash))
+    if (h64)
+      return full ? launch_bwd_stashed_v<NetGeo<1, 2, 2, 1>, true, true>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid)
+                  : launch_bwd_stashed_v<NetGeo<1, 2, 2, 1>, false, true>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid);
+    return launch_bwd_stashed_v<NetGeo<1, 1, 1, 1>, false, true>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid);
+  }
   if (h64)
     return full ? launch_bwd_stashed_v<NetGeo<1, 2, 2, 1>, true>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid)
                 : launch_bwd_stashed_v<NetGeo<1, 2, 2, 1>, false>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid);

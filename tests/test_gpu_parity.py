@@ -1208,6 +1208,44 @@ def test_realnvp_step_stash_and_recompute_reverse_passes_against_oracle(nf, shap
     assert need["stash"] > need["recompute"] > 0
 
 
+def test_realnvp_stash_in_chunks_equals_one_chunk(nf):
+    """A batch whose activation stash exceeds the budget runs chunk by chunk through one stash buffer (ELBO step with
+    in-library draws, forward-KL step): same loss and gradient as the single-chunk run up to float32 summation order, and
+    both against the oracle.  The budget here (1.5 MB = 32 tiles' worth, a few workgroups) forces 5 chunks."""
+    import ctypes as C
+    d, hd, nl, n = 64, (64, 64), 2, 4 * 32 * 9 + 11
+    flow = nf.realnvp(nf.MvNormal(d), hd, nl, paramtype=torch.float32, seed=5)
+    rng = np.random.default_rng(2)
+    mu, var = rng.standard_normal(d).astype(np.float32), (rng.uniform(size=d) + 0.5).astype(np.float32)
+    tgt = nf.DiagGaussTarget(torch.tensor(mu, device="cuda"), torch.tensor(var, device="cuda"))
+    spec = o.FlowSpec("realnvp", d, nl, hd)
+    th64 = flow.theta.cpu().numpy().astype(np.float64)
+    xs64 = nf.device_specific_rand(nf.PhiloxRNG(8), flow.dist, n).cpu().numpy().astype(np.float64)
+    lo, go = o.neg_elbo_value_and_grad(spec, th64, ("diaggauss", mu.astype(np.float64), var.astype(np.float64)), xs64)
+    ys = (nf.device_specific_rand(nf.PhiloxRNG(9), flow.dist, n) * 0.7).contiguous()
+    lfo, gfo = o.neg_loglik_value_and_grad(spec, th64, ys.cpu().numpy().astype(np.float64))
+    lib, ctx = nf.load_library(), flow.ctx
+    per_tile = 46 * 1024 * 2 * nl  # bytes of stash per 32-sample tile at this shape (nf_coupling.hip StashGeo)
+    res = {}
+    try:
+        for mode, budget in (("one chunk", -1), ("chunks", 8 * per_tile + 4096)):
+            nf._lib.check(lib.nf_ctx_set_stash_budget(ctx.ptr, budget))
+            assert int(lib.nf_workspace_bytes(ctx.ptr, C.byref(flow.desc), n)) > 0
+            l, g = nf.value_and_gradient(nf.elbo_batch, flow, tgt, n, rng=nf.PhiloxRNG(8))
+            lf, gf = nf.loglikelihood_value_and_gradient(flow, ys)
+            res[mode] = (l, g.clone(), lf, gf.clone())
+            P.scalar(f"stash {mode}: ELBO step loss", l, lo)
+            P.gradient(f"stash {mode}: ELBO step grad", g, go)
+            P.scalar(f"stash {mode}: forward-KL loss", lf, lfo)
+            P.gradient(f"stash {mode}: forward-KL grad", gf, gfo)
+    finally:
+        nf._lib.check(lib.nf_ctx_set_stash_budget(ctx.ptr, -1))
+    a, b = res["one chunk"], res["chunks"]
+    assert a[0] == pytest.approx(b[0], rel=1e-6) and a[2] == pytest.approx(b[2], rel=1e-6)
+    assert float((a[1] - b[1]).abs().max()) <= 2e-6 * float(a[1].abs().max())
+    assert float((a[3] - b[3]).abs().max()) <= 2e-6 * float(a[3].abs().max())
+
+
 RAND_CASES = {
     "planar5": ("planar", 5, 4, (), 0, 0.0, "float32"), "radial64": ("radial", 64, 3, (), 0, 0.0, "float32"),
     "planar100_f64": ("planar", 100, 2, (), 0, 0.0, "float64"), "realnvp5": ("realnvp", 5, 2, (32, 32), 0, 0.0, "float32"),
