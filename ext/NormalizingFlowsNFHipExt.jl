@@ -79,6 +79,16 @@ function context()
     return ctx
 end
 
+"""
+    stash_budget!(bytes)
+
+Bound (bytes ≥ 0; 0 = off) or reset (negative) the activation stash of the RealNVP training steps on the current device:
+what Zygote's tape is to `src/optimize.jl:12-14`, kept by the forward kernels for the reverse pass.  Larger batches run in
+chunks through the buffer; with 0 the reverse pass recomputes (slower, no extra memory).
+"""
+stash_budget!(bytes::Integer) =
+    check(ccall((:nf_ctx_set_stash_budget, libnfhip), Cint, (Ptr{Cvoid}, Int64), context(), Int64(bytes)))
+
 devptr(A::ROCArray) = Ptr{Cvoid}(UInt(pointer(A)))
 devptr(::Nothing) = C_NULL
 
