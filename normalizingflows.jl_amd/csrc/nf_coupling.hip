@@ -918,7 +918,8 @@ template <class G, bool PHASE_S, bool FULL, bool INVD = false>
 __device__ __forceinline__ void bwd_tile_stashed(const CouplingArgs &a, const float *__restrict__ img, float *__restrict__ sd,
                                                  BwdAcc<G> &acc, StashFirst<G> &f, float *stash, int k, int ncoup,
                                                  float *__restrict__ ybar, const float *__restrict__ lbar, float lbar_const,
-                                                 long tile, long next_tile, int l31, int hi) {
+                                                 long tile, long next_tile, int l31, int hi, long long *tr = nullptr) {
+  NF_TS_STAMP(0);
   using SG = StashGeo<G>;
   const long j = tile * NF_TILE + l31;
   const bool valid = FULL ? true : j < a.N;
@@ -938,6 +939,7 @@ __device__ __forceinline__ void bwd_tile_stashed(const CouplingArgs &a, const fl
   float a2t[G::H2B][16];
   stash_get_T<G::H2B>(st, nbase + SG::A2, vT, a2t);
 
+  NF_TS_STAMP(1);
   const float lb = valid ? (lbar ? lbar[FULL ? j : (j < a.N ? j : 0)] : lbar_const) : 0.f;
   f32x16 d3[G::CB];
 #pragma unroll
@@ -962,25 +964,30 @@ __device__ __forceinline__ void bwd_tile_stashed(const CouplingArgs &a, const fl
   const unsigned mk0 = mk[0], mk1 = mk[1], mk2 = mk[2], mk3 = mk[3];
   const unsigned m1[2] = {mk0, mk1}, m2[2] = {mk2, mk3};
 
+  NF_TS_STAMP(2);
   // ---- layer 3
   f32x16 d2[G::H2B];
   dense_bwd_x<G::H2B, G::CB>(img + G::W3, d3, d2, l31, hi, [&](int e) { scratch_put<G::CB>(sd, d3, e, l31, hi); });
   float a1t[G::H1B][16];
   stash_get_T<G::H1B>(st, nbase + SG::A1, vT, a1t);
+  NF_TS_STAMP(3);
   wave_lds_fence();
   dw_accumulate_reg<G::H2B, G::CB>(a2t, sd, acc.w3, acc.b3, l31, hi, [&](int e) {
     if (e < G::H2B * 16) d2[e >> 4][e & 15] *= lrelu_slope(m2[e >> 4], e & 15);
   });
+  NF_TS_STAMP(4);
   wave_lds_fence();
   // ---- layer 2
   f32x16 d1[G::H1B];
   dense_bwd_x<G::H1B, G::H2B>(img + G::W2, d2, d1, l31, hi, [&](int e) { scratch_put<G::H2B>(sd, d2, e, l31, hi); });
   float x2t[G::MB][16];
   stash_get_T<G::MB>(st, SG::XT, vT, x2t);
+  NF_TS_STAMP(5);
   wave_lds_fence();
   dw_accumulate_reg<G::H1B, G::H2B>(a1t, sd, acc.w2, acc.b2, l31, hi, [&](int e) {
     if (e < G::H1B * 16) d1[e >> 4][e & 15] *= lrelu_slope(m1[e >> 4], e & 15);
   });
+  NF_TS_STAMP(6);
   wave_lds_fence();
   // ---- layer 1: x2bar accumulates ybar2 + W1t^T d1t (phase T) + W1s^T d1s (phase S)
   f32x16 g2[G::MB], gold[G::MB];
@@ -990,11 +997,13 @@ __device__ __forceinline__ void bwd_tile_stashed(const CouplingArgs &a, const fl
     for (int r = 0; r < 16; ++r) gold[b][r] = tile_load(gio, tile_soff(b, r, par_c));
   if (PHASE_S && next_tile >= 0) stash_issue_first<G>(f, stash, k, ncoup, next_tile, l31, hi);
   dense_bwd_x<G::MB, G::H1B>(img + G::W1, d1, g2, l31, hi, [&](int e) { scratch_put<G::H1B>(sd, d1, e, l31, hi); });
+  NF_TS_STAMP(7);
   wave_lds_fence();
   dw_accumulate_reg<G::MB, G::H1B>(x2t, sd, acc.w1, acc.b1, l31, hi, [&](int e) {
     if (e < G::MB * 16) tile_store(gio, tile_soff(e >> 4, e & 15, par_c), gold[e >> 4][e & 15] + g2[e >> 4][e & 15]);
   });
   wave_lds_fence();
+  NF_TS_STAMP(8);
 }
 
 template <class G, bool FULL, bool INVD = false>
@@ -1010,6 +1019,16 @@ __global__ __launch_bounds__(256, 1) void k_affine_bwd_stashed(BwdAllArgs aa, fl
   const long ntiles = (aa.N + NF_TILE - 1) / NF_TILE;
   const long tile0 = (long)blockIdx.x * 4 + wave, tstride = (long)gridDim.x * 4;
   StashFirst<G> f;
+  // clock stamps of block 0 / thread 0 for tools/trace_bwd_stashed.py (first coupling processed): [0] start;
+  // per phase p: [1+4p] image staged, [2+4p] tiles done, [3+4p] every wave done, [4+4p] folded + slab written;
+  // [32 + 24p + 12i + 0..8]: stages of tile i (< 2) of phase p
+#ifdef NF_KERNEL_TRACE
+  long long *tr0 = (aa.trace && blockIdx.x == 0 && tid == 0) ? aa.trace : nullptr;
+  if (tr0) tr0[0] = clock64();
+#define NF_ST_STAMP(slot) do { if (tr0 && step == 0) { __builtin_amdgcn_sched_barrier(0); tr0[slot] = clock64(); } } while (0)
+#else
+#define NF_ST_STAMP(slot) do { } while (0)
+#endif
   if (INVD && tile0 < ntiles) stash_issue_first<G>(f, stash, aa.ncoup - 1, aa.ncoup, tile0, l31, hi);  // S runs first
 #pragma unroll 1
   for (int step = 0; step < aa.ncoup; ++step) {
@@ -1034,13 +1053,22 @@ __global__ __launch_bounds__(256, 1) void k_affine_bwd_stashed(BwdAllArgs aa, fl
       zero_acc(acc.w1, acc.b1);
       zero_acc(acc.w2, acc.b2);
       zero_acc(acc.w3, acc.b3);
+      NF_ST_STAMP(1 + phase * 4);
 #pragma unroll 1
       for (long tile = tile0; tile < ntiles; tile += tstride) {
         const long nt = tile + tstride < ntiles ? tile + tstride : -1;
-        if (!is_s) bwd_tile_stashed<G, false, FULL, INVD>(a, img, sd, acc, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, l31, hi);
-        else bwd_tile_stashed<G, true, FULL, INVD>(a, img, sd, acc, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, l31, hi);
+#ifdef NF_KERNEL_TRACE
+        const long ti = (tile - tile0) / tstride;
+        long long *tr = (tr0 && step == 0 && ti < 2) ? tr0 + 32 + phase * 24 + ti * 12 : nullptr;
+#else
+        long long *tr = nullptr;
+#endif
+        if (!is_s) bwd_tile_stashed<G, false, FULL, INVD>(a, img, sd, acc, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, l31, hi, tr);
+        else bwd_tile_stashed<G, true, FULL, INVD>(a, img, sd, acc, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, l31, hi, tr);
       }
+      NF_ST_STAMP(2 + phase * 4);
       __syncthreads();  // every wave is done with the weight image and its scratch
+      NF_ST_STAMP(3 + phase * 4);
       // s and u of the next phase-S's first tile fly behind the fold, the slab write and the staging of the next image
       if (tile0 < ntiles) {
         if (!INVD && !is_s) stash_issue_first<G>(f, stash, k, aa.ncoup, tile0, l31, hi);
@@ -1068,6 +1096,7 @@ __global__ __launch_bounds__(256, 1) void k_affine_bwd_stashed(BwdAllArgs aa, fl
         }
       }
       __syncthreads();  // image is restaged next phase; ybar stores of this phase are read by the next (same wave)
+      NF_ST_STAMP(4 + phase * 4);
     }
   }
 }
@@ -1378,7 +1407,7 @@ int nf_affine_bwd_stashed(nf_ctx *ctx, const nf_flow_desc *desc, float *stash, f
   if (!size || !ctx->wimg || desc->n_hidden != 2 || !stash) return NF_ERR_UNSUPPORTED;
   BwdAllArgs aa;
   aa.wimg = (const float *)ctx->wimg;
-  aa.trace = nullptr;
+  aa.trace = (long long *)ctx->trace;
   aa.d = desc->d;
   aa.ncoup = 2 * desc->nlayers;
   aa.N = N;

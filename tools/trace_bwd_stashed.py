@@ -30,13 +30,8 @@ for ph in range(2):
     b = 1 + ph * 4
     prev = t0 if ph == 0 else t[4]
     print(f"phase {'TS'[ph]}: stage+zero {t[b]-prev}  tiles {t[b+1]-t[b]}  wait-for-others {t[b+2]-t[b+1]}  fold+slab {t[b+3]-t[b+2]}")
-    tl = [x for x in t[16 + ph * 8: 24 + ph * 8] if x]
-    last = t[b]
-    for i, x in enumerate(tl):
-        print(f"    tile {i}: {x-last}")
-        last = x
-names = ["loads issued", "element-wise", "dX3 (+stash d3, a1 loads)", "dW3 (+d2 scale)", "dX2 (+stash d2, x2 loads)", "dW2 (+d1 scale)",
-         "dX1 (+stash d1)", "dW1 (+x2bar stores)"]
+names = ["loads issued", "element-wise (waits for its operands)", "dX3 (+stash d3, a1 loads)", "dW3 (+d2 scale)", "dX2 (+stash d2, x2 loads)",
+         "dW2 (+d1 scale)", "dX1 (+stash d1, next tile's s / u loads)", "dW1 (+x2bar stores)"]
 for ph in range(2):
     for ti in range(2):
         st = t[32 + ph * 24 + ti * 12: 32 + ph * 24 + ti * 12 + 9]
@@ -44,5 +39,5 @@ for ph in range(2):
             continue
         print(f"phase {'TS'[ph]} tile {ti}:")
         for i in range(1, 9):
-            print(f"   {names[i-1]:28s} +{st[i]-st[i-1]:6d}")
+            print(f"   {names[i-1]:44s} +{st[i]-st[i-1]:6d}")
 print("coupling 0 total", t[8] - t0, "ticks")
