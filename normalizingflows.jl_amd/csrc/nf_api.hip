@@ -1709,7 +1709,6 @@ static size_t ws_need_bound(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
   if (is_composite(desc)) return composite_inner_need(ctx, desc, N) + composite_extra_bytes(desc, N);
   const size_t es = esize(desc->dtype);
   const bool cp = is_coupling(desc);
-  const long P = nf_param_count(desc);
   const size_t te = cp ? tiled_elems(desc, N) : 0;
   const size_t xe = cp ? te : (size_t)N * desc->d;
   const size_t cn = carve_bytes((size_t)N * es);

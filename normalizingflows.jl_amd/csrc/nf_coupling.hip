@@ -286,7 +286,6 @@ __global__ __launch_bounds__(512) void k_affine_chain(ChainArgs a, float *xt, fl
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int IMG2 = 2 * G::SIZE;  // s and t images of one coupling are adjacent in wimg
   constexpr int NV4 = IMG2 / 4;
-  constexpr int PER = (NV4 + 511) / 512;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(HF_BLOCK) void k_hf_bwd(HfArgs a, const T *__restri
                                                      T *__restrict__ ws, T *__restrict__ g) {
   const long j = (long)blockIdx.x * HF_BLOCK + threadIdx.x;
   if (j >= a.N) return;
-  const int D = a.D, d2 = 2 * D, n = a.n, L = a.L;
+  const int D = a.D, d2 = 2 * D, n = a.n;
   const T lb = lbar ? lbar[j] : lbar_const;
   T z[2 * HF_MAXD];
   const T *sh0 = theta, *sc0 = theta + d2;

@@ -470,7 +470,6 @@ template <class G, bool INVERSE, bool FUSED = false>
 __global__ __launch_bounds__(512) void k_rqs_chain(RqsChainArgs a, float *xt, float *__restrict__ ladj, RqsFusedArgs fa) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NV4 = G::SIZE / 4;
-  constexpr int PER = (NV4 + 511) / 512;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
