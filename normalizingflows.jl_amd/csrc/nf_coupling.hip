@@ -1122,12 +1122,12 @@ int nf_affine_reduce_slabs(nf_ctx *ctx, const nf_flow_desc *desc, const float *s
   if (!size) return NF_ERR_UNSUPPORTED;
   const PackArgs p = make_pack_args(desc);
   const long total = (long)p.ncoup * 2 * size;
-  const unsigned grid = (unsigned)((total + 255) / 256);
+  const unsigned grid = (unsigned)((total + 63) / 64);  // 64 elements per block (k_reduce_image_slabs)
   ProfScope ps(ctx, "reduce_slabs");
   if (size == NetGeo<1, 1, 1, 1>::SIZE)
-    hipLaunchKernelGGL((k_reduce_image_slabs<NetGeo<1, 1, 1, 1>>), dim3(grid), dim3(256), 0, ctx->stream, p, slab, nslab, total, g, lpart, nlpart, lout);
+    hipLaunchKernelGGL((k_reduce_image_slabs<NetGeo<1, 1, 1, 1>>), dim3(grid), dim3(64 * NF_REDUCE_WAVES), 0, ctx->stream, p, slab, nslab, total, g, lpart, nlpart, lout);
   else
-    hipLaunchKernelGGL((k_reduce_image_slabs<NetGeo<1, 2, 2, 1>>), dim3(grid), dim3(256), 0, ctx->stream, p, slab, nslab, total, g, lpart, nlpart, lout);
+    hipLaunchKernelGGL((k_reduce_image_slabs<NetGeo<1, 2, 2, 1>>), dim3(grid), dim3(64 * NF_REDUCE_WAVES), 0, ctx->stream, p, slab, nslab, total, g, lpart, nlpart, lout);
   return (int)hipGetLastError();
 }
 

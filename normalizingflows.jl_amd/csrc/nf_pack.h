@@ -33,42 +33,64 @@ __global__ __launch_bounds__(256) void k_pack_net_images(PackArgs p, const float
 // g[theta index] = sum over workgroup slabs of the image-layout partial gradients
 // Block 0 can also finish a deterministic sum of `nlpart` double partials into *lout (the step's loss:
 // saves a separate one-block launch in the training step).
+#ifndef NF_REDUCE_WAVES
+#define NF_REDUCE_WAVES 4
+#endif
 template <class G>
-__global__ __launch_bounds__(256) void k_reduce_image_slabs(PackArgs p, const float *__restrict__ slab, int nslab,
+__global__ __launch_bounds__(64 * NF_REDUCE_WAVES) void k_reduce_image_slabs(PackArgs p, const float *__restrict__ slab, int nslab,
                                                             long slab_stride, float *__restrict__ g,
                                                             const double *__restrict__ lpart, int nlpart,
                                                             float *__restrict__ lout) {
   if (lout && blockIdx.x == 0) {
-    __shared__ double sm[4];
+    __shared__ double sm[NF_REDUCE_WAVES];
     double c = 0.0;
-    for (int i = threadIdx.x; i < nlpart; i += 256) c += lpart[i];
+    for (int i = threadIdx.x; i < nlpart; i += 64 * NF_REDUCE_WAVES) c += lpart[i];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = c;
     __syncthreads();
-    if (threadIdx.x == 0) *lout = (float)((sm[0] + sm[1]) + (sm[2] + sm[3]));
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+      for (int w = 0; w < NF_REDUCE_WAVES; ++w) t += sm[w];
+      *lout = (float)t;
+    }
   }
-  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  // 64 image elements per block, the slabs split over the block's waves (a streaming kernel of 139 MB at cfg 2:
+  // with one element per thread over all slabs only ~8 waves per CU were in flight and it ran at 3.4 TB/s)
+  __shared__ float part[NF_REDUCE_WAVES][64];
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const long gid = (long)blockIdx.x * 64 + lane;
   const long total = (long)p.ncoup * 2 * G::SIZE;
-  if (gid >= total) return;
-  const int img = (int)(gid / G::SIZE), e = (int)(gid - (long)img * G::SIZE);
-  const int k = img >> 1, net = img & 1;
-  const int c = (k & 1) ? p.d / 2 : (p.d + 1) / 2, m = p.d - c;
-  long off = (long)(k >> 1) * p.pair_params + ((k & 1) ? p.odd_params : 0);
-  if (net) off += net_param_count(m, p.h1, p.h2, c);
-  const NetDims nd = make_net_dims(off, m, p.h1, p.h2, c);
-  const long ti = e < G::B3 + 32 * G::CB ? image_theta_index<G>(nd, e) : -1;
-  if (ti < 0) return;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int s = 0;
-  for (; s + 3 < nslab; s += 4) {
-    a0 += slab[(long)s * slab_stride + gid];
-    a1 += slab[(long)(s + 1) * slab_stride + gid];
-    a2 += slab[(long)(s + 2) * slab_stride + gid];
-    a3 += slab[(long)(s + 3) * slab_stride + gid];
+  long ti = -1;
+  if (gid < total) {
+    const int img = (int)(gid / G::SIZE), e = (int)(gid - (long)img * G::SIZE);
+    const int k = img >> 1, net = img & 1;
+    const int c = (k & 1) ? p.d / 2 : (p.d + 1) / 2, m = p.d - c;
+    long off = (long)(k >> 1) * p.pair_params + ((k & 1) ? p.odd_params : 0);
+    if (net) off += net_param_count(m, p.h1, p.h2, c);
+    const NetDims nd = make_net_dims(off, m, p.h1, p.h2, c);
+    ti = e < G::B3 + 32 * G::CB ? image_theta_index<G>(nd, e) : -1;
   }
-  for (; s < nslab; ++s) a0 += slab[(long)s * slab_stride + gid];
-  g[ti] = (a0 + a1) + (a2 + a3);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (ti >= 0) {  // wave q sums slabs q, q + W, q + 2 W, ...
+    constexpr int W = NF_REDUCE_WAVES;
+    int s = q;
+    for (; s + 3 * W < nslab; s += 4 * W) {
+      a0 += slab[(long)s * slab_stride + gid];
+      a1 += slab[(long)(s + W) * slab_stride + gid];
+      a2 += slab[(long)(s + 2 * W) * slab_stride + gid];
+      a3 += slab[(long)(s + 3 * W) * slab_stride + gid];
+    }
+    for (; s < nslab; s += W) a0 += slab[(long)s * slab_stride + gid];
+  }
+  part[q][lane] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (q == 0 && ti >= 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NF_REDUCE_WAVES; ++w) t += part[w][lane];
+    g[ti] = t;
+  }
 }
 
 static inline PackArgs make_pack_args(const nf_flow_desc *desc) {
