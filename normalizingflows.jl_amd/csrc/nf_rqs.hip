@@ -129,22 +129,33 @@ __global__ __launch_bounds__(256) void k_rqs_pack(RqsPackArgs p, const float *__
   out[gid] = ti >= 0 ? theta[ti] : 0.f;
 }
 
+// 64 image elements per block, the slabs split over the block's four waves (an HBM stream of ~120 MB at cfg 3: with
+// one element per thread over all slabs too few waves were in flight -- see k_reduce_image_slabs, nf_pack.h)
 template <class G>
 __global__ __launch_bounds__(256) void k_rqs_reduce_slabs(RqsPackArgs p, const float *__restrict__ slab, int nslab,
                                                           long slab_stride, float *__restrict__ g) {
-  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= (long)p.ncoup * G::SIZE) return;
-  const int k = (int)(gid / G::SIZE), e = (int)(gid - (long)k * G::SIZE);
-  const long ti = rqs_image_theta_index<G>(rqs_dims_of<G>(p, k), e);
-  if (ti < 0) return;
-  float a0 = 0.f, a1 = 0.f;
-  int s = 0;
-  for (; s + 1 < nslab; s += 2) {
-    a0 += slab[(long)s * slab_stride + gid];
-    a1 += slab[(long)(s + 1) * slab_stride + gid];
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const long gid = (long)blockIdx.x * 64 + lane;
+  long ti = -1;
+  if (gid < (long)p.ncoup * G::SIZE) {
+    const int k = (int)(gid / G::SIZE), e = (int)(gid - (long)k * G::SIZE);
+    ti = rqs_image_theta_index<G>(rqs_dims_of<G>(p, k), e);
   }
-  if (s < nslab) a0 += slab[(long)s * slab_stride + gid];
-  g[ti] = a0 + a1;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (ti >= 0) {  // wave q sums slabs q, q + 4, q + 8, ...
+    int s = q;
+    for (; s + 12 < nslab; s += 16) {
+      a0 += slab[(long)s * slab_stride + gid];
+      a1 += slab[(long)(s + 4) * slab_stride + gid];
+      a2 += slab[(long)(s + 8) * slab_stride + gid];
+      a3 += slab[(long)(s + 12) * slab_stride + gid];
+    }
+    for (; s < nslab; s += 4) a0 += slab[(long)s * slab_stride + gid];
+  }
+  part[q][lane] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (q == 0 && ti >= 0) g[ti] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1288,7 +1299,7 @@ int nf_rqs_reduce_slabs(nf_ctx *ctx, const nf_flow_desc *desc, const float *slab
   if (!id) return NF_ERR_UNSUPPORTED;
   const RqsPackArgs p = rqs_pack_args(desc);
   const long total = (long)p.ncoup * rqs_geo_size(desc);
-  const unsigned grid = (unsigned)((total + 255) / 256);
+  const unsigned grid = (unsigned)((total + 63) / 64);  // 64 elements per block
   ProfScope ps(ctx, "reduce_slabs");
 #define RQS_CALL(G) hipLaunchKernelGGL((k_rqs_reduce_slabs<G>), dim3(grid), dim3(256), 0, ctx->stream, p, slab, nslab, total, g)
   RQS_DISPATCH_STMT(id, RQS_CALL);
