@@ -158,8 +158,10 @@ int nf_ctx_set_arena(nf_ctx *ctx, void *arena_device, size_t bytes);
  * result up to float32 summation order).  nf_elbo_value_and_grad / nf_elbo_step and nf_loglikelihood_value_and_grad
  * (the inverse chain stashes for ITS reverse pass) use it.  0 disables the stash: the reverse pass then recomputes the
  * activations from the flow output (invertible recompute: slower, no extra memory, and every leaky-ReLU slope is decided
- * again on a float32 reconstruction of the layer input -- DESIGN.md section 5).  A negative value restores the default
- * (4 GiB, or the environment's NF_AFFINE_STASH_MAX_MB / NF_AFFINE_NO_STASH).  nf_workspace_bytes reflects the setting. */
+ * again on a float32 reconstruction of the layer input -- DESIGN.md section 5).  A negative value restores the default:
+ * 4 GiB (or the environment's NF_AFFINE_STASH_MAX_MB / NF_AFFINE_NO_STASH) for conditioner nets wider than 32, where the
+ * stash is the faster reverse pass, and no stash for the narrower ones, whose recompute is cheaper than the HBM round
+ * trip (an explicit budget enables it there too).  nf_workspace_bytes reflects the setting. */
 int nf_ctx_set_stash_budget(nf_ctx *ctx, int64_t max_bytes);
 
 /* ---- layout -------------------------------------------------------------- */

@@ -44,6 +44,7 @@ int nf_affine_chain_elbo(nf_ctx *, const nf_flow_desc *, long N, uint64_t seed, 
                          const float *mu, const float *var, float *yt, float *gt, double gscale, double *partial,
                          double pscale, float *stash = nullptr);
 size_t nf_affine_stash_floats(const nf_flow_desc *desc, long N);
+bool nf_affine_stash_pays(const nf_flow_desc *desc);
 int nf_affine_bwd_stashed(nf_ctx *, const nf_flow_desc *, float *stash, float *ybar, const float *lbar, float lbar_const, long N,
                           float *slab, long slab_stride, int grid, bool inv_dir = false);
 long nf_affine_slab_floats(const nf_flow_desc *desc);
@@ -589,7 +590,8 @@ static size_t affine_stash_bytes(nf_ctx *ctx, const nf_flow_desc *desc, long N) 
     const char *e = std::getenv("NF_AFFINE_STASH_MAX_MB");
     return (size_t)(e ? std::atol(e) : 4096) << 20;
   }();
-  const size_t cap = ctx->stash_budget >= 0 ? (size_t)ctx->stash_budget : (off ? 0 : env_cap);
+  // default policy: only where the stash is the faster reverse pass; an explicit budget enables it for every resident shape
+  const size_t cap = ctx->stash_budget >= 0 ? (size_t)ctx->stash_budget : ((off || !nf_affine_stash_pays(desc)) ? 0 : env_cap);
   const size_t b = nf_affine_stash_floats(desc, N) * sizeof(float);
   return b <= cap ? b : 0;
 }

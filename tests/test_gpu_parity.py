@@ -1183,7 +1183,7 @@ def test_realnvp_step_stash_and_recompute_reverse_passes_against_oracle(nf, shap
     lib, ctx = nf.load_library(), flow.ctx
     need = {}
     try:
-        for mode, budget in (("stash", -1), ("recompute", 0)):
+        for mode, budget in (("stash", 1 << 32), ("recompute", 0)):  # explicit budget: narrow nets do not stash by default
             nf._lib.check(lib.nf_ctx_set_stash_budget(ctx.ptr, budget))
             need[mode] = int(lib.nf_workspace_bytes(ctx.ptr, C.byref(flow.desc), n))
             for form, arg in (("rng", n), ("xs", xs)):
