@@ -302,19 +302,31 @@ Bijectors.transform(t::NFHipTransform, x::ROCVecOrMat) = first(Bijectors.with_lo
 (t::NFHipTransform)(x::ROCVecOrMat) = Bijectors.transform(t, x)
 
 # reverse-mode rule: the mechanism MonotonicSplines uses for its kernels (test/ad.jl:126-127), so AutoZygote works
-# for an ARBITRARY logp closure: library forward, closure's own pullback, library pullback (nf_flow_bwd).
+# for an ARBITRARY logp closure: library forward that keeps its tape (nf_flow_fwd_keep), the closure's own pullback,
+# library pullback from that tape (nf_flow_bwd_kept).  The tape is a ROCArray owned by the pullback closure -- the
+# device form of the Zygote tape the reference differentiates (src/optimize.jl:12-14 on src/objectives/elbo.jl:65-70);
+# the pullback leaves it intact, so calling it twice (jacobians) is fine.
 function ChainRulesCore.rrule(::typeof(Bijectors.with_logabsdet_jacobian), t::NFHipTransform, x::ROCMatrix{T}) where {T}
     t.inverted && error("nfhip: the pullback of the inverse chain is exposed through loglikelihood training (AutoNFHip)")
-    y, ladj = apply(t, x)
+    d, N = size(x)
+    d == t.desc.d || throw(DimensionMismatch("flow has d=$(t.desc.d), input has $d"))
+    nbytes = ccall((:nf_tape_bytes, libnfhip), Int64, (Ptr{Cvoid}, Ref{NFDesc}, Int64), context(), t.desc, N)
+    nbytes < 0 && check(Cint(nbytes))
+    tape = ROCVector{UInt8}(undef, nbytes)                       # AMDGPU.jl allocations are 256-byte aligned
+    y = similar(x)
+    ladj = ROCVector{T}(undef, N)
+    check(ccall((:nf_flow_fwd_keep, libnfhip), Cint,
+                (Ptr{Cvoid}, Ref{NFDesc}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t),
+                context(), t.desc, devptr(t.θ), devptr(x), N, devptr(y), devptr(ladj), devptr(tape), nbytes))
     function pullback(Δ)
         ȳ, l̄ = ChainRulesCore.unthunk(Δ[1]), ChainRulesCore.unthunk(Δ[2])
         ȳ = ȳ isa ChainRulesCore.AbstractZero ? AMDGPU.zeros(T, size(y)) : ROCMatrix{T}(ȳ)
         l̄ = l̄ isa ChainRulesCore.AbstractZero ? AMDGPU.zeros(T, length(ladj)) : ROCVector{T}(l̄)
         x̄ = similar(x)
         ḡ = similar(t.θ)
-        check(ccall((:nf_flow_bwd, libnfhip), Cint,
-                    (Ptr{Cvoid}, Ref{NFDesc}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}),
-                    context(), t.desc, devptr(t.θ), devptr(x), devptr(y), devptr(ȳ), devptr(l̄), size(x, 2), devptr(x̄), devptr(ḡ)))
+        check(ccall((:nf_flow_bwd_kept, libnfhip), Cint,
+                    (Ptr{Cvoid}, Ref{NFDesc}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}),
+                    context(), t.desc, devptr(t.θ), devptr(tape), nbytes, devptr(ȳ), devptr(l̄), N, devptr(x̄), devptr(ḡ)))
         t̄ = ChainRulesCore.Tangent{typeof(t)}(; θ=ḡ)     # tangent_of: the only differentiable field is θ
         return ChainRulesCore.NoTangent(), t̄, x̄
     end

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NF_ABI_VERSION 2
+#define NF_ABI_VERSION 3
 
 /* status codes (< 0: library errors; > 0: hipError_t) */
 #define NF_OK 0
@@ -157,11 +157,10 @@ int nf_ctx_set_arena(nf_ctx *ctx, void *arena_device, size_t bytes);
  * runs chunk by chunk through it (forward + reverse pass per chunk, all chunks' gradient slabs reduced together; same
  * result up to float32 summation order).  nf_elbo_value_and_grad / nf_elbo_step and nf_loglikelihood_value_and_grad
  * (the inverse chain stashes for ITS reverse pass) use it.  0 disables the stash: the reverse pass then recomputes the
- * activations from the flow output (invertible recompute: slower, no extra memory, and every leaky-ReLU slope is decided
- * again on a float32 reconstruction of the layer input -- DESIGN.md section 5).  A negative value restores the default:
- * 4 GiB (or the environment's NF_AFFINE_STASH_MAX_MB / NF_AFFINE_NO_STASH) for conditioner nets wider than 32, where the
- * stash is the faster reverse pass, and no stash for the narrower ones, whose recompute is cheaper than the HBM round
- * trip (an explicit budget enables it there too).  nf_workspace_bytes reflects the setting. */
+ * activations from the flow output (invertible recompute: no extra memory, but every leaky-ReLU slope is decided
+ * again on a float32 reconstruction of the layer input -- DESIGN.md section 5; an explicit opt-in, never the default).
+ * A negative value restores the default: 4 GiB (or the environment's NF_AFFINE_STASH_MAX_MB / NF_AFFINE_NO_STASH) for
+ * every LDS-resident shape.  nf_workspace_bytes and nf_tape_bytes reflect the setting. */
 int nf_ctx_set_stash_budget(nf_ctx *ctx, int64_t max_bytes);
 
 /* ---- layout -------------------------------------------------------------- */
@@ -210,8 +209,28 @@ int nf_flow_rand(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, int64
 int nf_layer_apply(nf_ctx *ctx, const nf_flow_desc *desc, int32_t layer, int32_t inverse,
                    const void *theta, const void *x_in, int64_t N, void *y_out, void *ladj_out);
 
-/* Pullback of nf_flow_fwd (what a ChainRules rrule for with_logabsdet_jacobian
- * needs; the mechanism MonotonicSplines uses, test/ad.jl:126-127).
+/* Forward pass that keeps its tape, and the pullback from that tape: the two halves of a ChainRules
+ * rrule for with_logabsdet_jacobian(flow.transform, xs) (the mechanism MonotonicSplines uses, test/ad.jl:126-127;
+ * the reference's default path is Zygote differentiating the forward's own tape: src/optimize.jl:12-14 on
+ * src/objectives/elbo.jl:65-70).  An arbitrary `logp` closure trains through this pair:
+ *   tape = device buffer of nf_tape_bytes(ctx, desc, N) bytes, 256-byte aligned, owned by the caller (the rrule's closure)
+ *   nf_flow_fwd_keep(..., x, N, y, ladj, tape, bytes)       y, ladj as nf_flow_fwd; the tape holds the forward's
+ *                                                            activations in the layouts the reverse kernels consume
+ *   ybar = d loss / d y from the caller's AD of logp, lbar = d loss / d ladj
+ *   nf_flow_bwd_kept(..., tape, bytes, ybar, lbar, N, xbar, gtheta)
+ * The pullback differentiates the forward's OWN activations and leaky-ReLU slopes (nothing is re-derived by inverting
+ * the flow in float32), leaves the tape intact (it may be called again) and costs what the built-in training step's
+ * reverse pass costs.  nf_tape_bytes depends on the context's nf_ctx_set_stash_budget setting (0 = keep only the flow
+ * output and recompute by inversion): both calls must run under the setting the size was queried with.
+ * y_out may alias x_in; xbar_out may alias ybar; gtheta_out[P] is overwritten. */
+int64_t nf_tape_bytes(nf_ctx *ctx, const nf_flow_desc *desc, int64_t N);
+int nf_flow_fwd_keep(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *x_in, int64_t N,
+                     void *y_out, void *ladj_out, void *tape, size_t tape_bytes);
+int nf_flow_bwd_kept(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *tape, size_t tape_bytes,
+                     const void *ybar, const void *lbar, int64_t N, void *xbar_out, void *gtheta_out);
+
+/* Pullback of nf_flow_fwd for callers that kept only x: runs the forward again FROM x with the tape in the context
+ * workspace, then pulls it back (y is part of the rrule's signature and is not read; no float32 inversion).
  * Inputs: x (flow input), y (flow output), ybar[d*N], lbar[N] (cotangent of ladj).
  * Outputs: xbar_out[d*N] (may alias ybar), gtheta_out[P] (overwritten). */
 int nf_flow_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *x,

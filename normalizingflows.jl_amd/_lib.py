@@ -86,6 +86,9 @@ SYMBOLS = {
     "nf_flow_rand": (C.c_int, [_P, _DESC, _P, _I64, _U64, _U64, _U32, _P]),
     "nf_layer_apply": (C.c_int, [_P, _DESC, _I32, _I32, _P, _P, _I64, _P, _P]),
     "nf_flow_bwd": (C.c_int, [_P, _DESC, _P, _P, _P, _P, _P, _I64, _P, _P]),
+    "nf_tape_bytes": (_I64, [_P, _DESC, _I64]),
+    "nf_flow_fwd_keep": (C.c_int, [_P, _DESC, _P, _P, _I64, _P, _P, _P, C.c_size_t]),
+    "nf_flow_bwd_kept": (C.c_int, [_P, _DESC, _P, _P, C.c_size_t, _P, _P, _I64, _P, _P]),
     "nf_target_logp": (C.c_int, [_P, _I32, _TGT, _I32, _I64, _P, _P, _P]),
     "nf_elbo_batch": (C.c_int, [_P, _DESC, _TGT, _P, _P, _I64, _P, _PD]),
     "nf_elbo_batch_rng": (C.c_int, [_P, _DESC, _TGT, _P, _I64, _U64, _U64, _U32, _PD]),
@@ -125,7 +128,7 @@ def load_library():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.nf_abi_version() != 2:
+    if lib.nf_abi_version() != 3:
         raise NFHipError("libnfhip.so ABI version mismatch")
     _lib = lib
     return lib

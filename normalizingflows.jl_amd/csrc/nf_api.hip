@@ -65,7 +65,9 @@ int nf_wide_bwd(nf_ctx *, const nf_flow_desc *, float *state, float *gbar, const
 size_t nf_wide_train_ws_floats(nf_ctx *, const nf_flow_desc *, long N);
 int nf_wide_train_forward(nf_ctx *, const nf_flow_desc *, float *xt, long N, float *ladj, float *ws);
 int nf_wide_train_backward(nf_ctx *, const nf_flow_desc *, float *state, float *gbar, const float *lbar,
-                           float lbar_const, long N, float *ws, float *g_out);
+                           float lbar_const, long N, float *ws, float *g_out, float *scratch = nullptr);
+size_t nf_wide_fwd_stash_floats(nf_ctx *, const nf_flow_desc *, long N);
+size_t nf_wide_train_scratch_floats(nf_ctx *, const nf_flow_desc *, long N);
 
 // neural spline couplings (nf_rqs.hip)
 bool nf_rqs_supported(const nf_flow_desc *desc);
@@ -132,6 +134,8 @@ int nf_hf_bwd_inv(nf_ctx *, const nf_flow_desc *, const void *theta, const void 
 
 // ---- helpers -----------------------------------------------------------------------------
 static size_t ws_need_bound(nf_ctx *ctx, const nf_flow_desc *desc, long N);
+static size_t flow_bwd_need(nf_ctx *ctx, const nf_flow_desc *desc, long N);
+static size_t vg_composite_need(nf_ctx *ctx, const nf_flow_desc *desc, long N);
 static size_t base_extra_bytes(const nf_flow_desc *desc, long N);
 static inline size_t esize(int dtype) { return dtype == NF_DTYPE_F64 ? 8 : 4; }
 
@@ -344,6 +348,9 @@ int nf_ws_reserve(nf_ctx *ctx, size_t bytes) {
   if (ctx->arena) {
     const size_t avail = ctx->arena_bytes - ctx->arena_tail;
     if (bytes > avail) return NF_ERR_WORKSPACE;
+    // front high-water mark of the running entry point: a later tail carve (weight images, nf_elbo_step's buffer)
+    // must not reach into it.  Inside a wrapper (guard set) the outer request stays the mark.
+    ctx->arena_front = (ctx->ws_guard && ctx->arena_front > bytes) ? ctx->arena_front : bytes;
     ctx->ws = ctx->arena;
     ctx->ws_bytes = avail;
     return NF_OK;
@@ -363,6 +370,9 @@ int nf_ws_reserve(nf_ctx *ctx, size_t bytes) {
 static int arena_tail_take(nf_ctx *ctx, size_t bytes, void **out) {
   const size_t b = carve_bytes(bytes);
   if (ctx->arena_tail + b > ctx->arena_bytes) return NF_ERR_WORKSPACE;
+  // the running entry point has carved [0, arena_front) off the front already (nf_ws_reserve came first): a tail that
+  // reaches into it would silently overlap live intermediates
+  if (ctx->arena_bytes - ctx->arena_tail - b < ctx->arena_front) return NF_ERR_WORKSPACE;
   ctx->arena_tail += b;
   *out = (char *)ctx->arena + (ctx->arena_bytes - ctx->arena_tail);
   ctx->ws = ctx->arena;
@@ -417,6 +427,7 @@ extern "C" int nf_ctx_set_arena(nf_ctx *ctx, void *arena, size_t bytes) {
   ctx->arena = arena;
   ctx->arena_bytes = arena ? (bytes / 256) * 256 : 0;
   ctx->arena_tail = 0;
+  ctx->arena_front = 0;
   return NF_OK;
 }
 
@@ -464,13 +475,12 @@ static int base_draw(nf_ctx *ctx, const nf_flow_desc *desc, long N, uint64_t see
 
 
 struct CompBufs {
-  char *xin[64];  // input of segment s
   char *y, *gbar, *logq, *ladj, *tmp, *lbar, *spare;
   double *partial_t, *partial_s, *result;
 };
 static int composite_bufs(nf_ctx *ctx, const nf_flow_desc *desc, long N, CompBufs *cb);
 static int composite_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, const void *theta, const void *x_in, long N,
-                           void *y_out, void *ladj, CompBufs &cb, char **stash_inputs);
+                           void *y_out, void *ladj, CompBufs &cb);
 static int elbo_forward_general_base(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, const void *theta,
                                      const void *xs, long N, uint64_t seed, uint64_t off, uint32_t stream_id,
                                      void *elbos_out, double *elbo_host);
@@ -484,8 +494,6 @@ static int value_and_grad_composite(nf_ctx *ctx, const nf_flow_desc *desc, const
 static int value_and_grad_general_base(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, const void *theta,
                                        const void *xs, int64_t N_local, int64_t N_global, uint64_t seed, uint64_t sample_offset,
                                        uint32_t stream_id, void *out);
-static int flow_bwd_composite(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *x, const void *ybar,
-                              const void *lbar, long N, void *xbar_out, void *gtheta_out);
 static int fkl_general(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *ys, int64_t N_local,
                        int64_t N_global, void *out);
 static size_t fkl_general_need(nf_ctx *ctx, const nf_flow_desc *desc, long N);
@@ -583,15 +591,19 @@ static int fused_chain_elbo(nf_ctx *ctx, const nf_flow_desc *desc, const nf_targ
 // "activation stash") while they fit the budget: 46 KiB per 32-sample tile and coupling at d = 64 / hidden 64.  NF_AFFINE_STASH_MAX_MB (default 4096) bounds it; beyond, or with
 // NF_AFFINE_NO_STASH set (A/B measurements), the reverse pass recomputes them (k_affine_bwd_all).
 #define NF_STASH_TILE 32
+static inline bool affine_stash_off(nf_ctx *ctx);
 static size_t affine_stash_bytes(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
   if (desc->kind != NF_KIND_REALNVP || desc->dtype != NF_DTYPE_F32 || !nf_affine_supported(desc)) return 0;
-  static const bool off = std::getenv("NF_AFFINE_NO_STASH") != nullptr;
   static const size_t env_cap = [] {
     const char *e = std::getenv("NF_AFFINE_STASH_MAX_MB");
     return (size_t)(e ? std::atol(e) : 4096) << 20;
   }();
-  // default policy: only where the stash is the faster reverse pass; an explicit budget enables it for every resident shape
-  const size_t cap = ctx->stash_budget >= 0 ? (size_t)ctx->stash_budget : ((off || !nf_affine_stash_pays(desc)) ? 0 : env_cap);
+  // default policy (round 3): every LDS-resident shape keeps the forward's activations -- the reverse pass then
+  // differentiates the forward's own tape, as the reference's AD does.  The invertible-recompute kernel is the explicit
+  // nf_ctx_set_stash_budget(0) mode only (for hidden width 32 it is 3 % faster, and it re-decides leaky-ReLU slopes on a
+  // float32 reconstruction: DESIGN.md section 5).
+  if (affine_stash_off(ctx)) return 0;
+  const size_t cap = ctx->stash_budget > 0 ? (size_t)ctx->stash_budget : env_cap;
   const size_t b = nf_affine_stash_floats(desc, N) * sizeof(float);
   return b <= cap ? b : 0;
 }
@@ -609,6 +621,13 @@ static long affine_stash_chunk(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
     if (affine_stash_bytes(ctx, desc, mid * unit * NF_STASH_TILE)) lo = mid; else hi = mid;
   }
   return lo * unit * NF_STASH_TILE;
+}
+// floats of gradient slabs a chunked step writes: every chunk's workgroups leave one slab each
+static int coupling_bwd_grid(nf_ctx *ctx, const nf_flow_desc *desc, long N);
+static size_t chunked_slab_floats(nf_ctx *ctx, const nf_flow_desc *desc, long N, long chunk, long stride) {
+  if (!chunk || chunk >= N) return (size_t)coupling_bwd_grid(ctx, desc, N) * stride;
+  const long full = N / chunk, rem = N - full * chunk;
+  return ((size_t)full * coupling_bwd_grid(ctx, desc, chunk) + (rem ? coupling_bwd_grid(ctx, desc, rem) : 0)) * stride;
 }
 extern "C" int nf_ctx_set_stash_budget(nf_ctx *ctx, int64_t max_bytes) {
   if (!ctx) return NF_ERR_ARG;
@@ -695,7 +714,7 @@ extern "C" int nf_flow_rand(nf_ctx *ctx, const nf_flow_desc *desc, const void *t
     NF_TRY(composite_bufs(ctx, desc, N, &cb));
     GuardReset gr{ctx, prev_guard};
     NF_TRY(nf_launch_base_sample(ctx, desc->dtype, desc->d, N, seed, sample_offset, stream_id, y_out, nullptr));
-    return composite_chain(ctx, desc, false, theta, y_out, N, y_out, cb.ladj, cb, nullptr);
+    return composite_chain(ctx, desc, false, theta, y_out, N, y_out, cb.ladj, cb);
   }
   if (is_coupling(desc)) {
     NF_TRY(nf_ws_reserve(ctx, carve_bytes(tiled_elems(desc, N) * 4) + carve_bytes((size_t)N * 4)));
@@ -770,6 +789,223 @@ static int coupling_inv_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const float *
   return NF_ERR_UNSUPPORTED;
 }
 
+static long seg_theta_off(const nf_flow_desc *desc, int s);
+// ---- the tape: what a forward pass keeps for its pullback -------------------------------------------------------
+// The reference differentiates the forward's own tape (Zygote on src/objectives/elbo.jl:65-70 under
+// src/optimize.jl:12-14; MonotonicSplines' rrules, test/ad.jl:126-127).  nf_flow_fwd_keep writes that tape into
+// caller-owned memory and nf_flow_bwd_kept consumes it, so the pullback uses the forward's own activations and
+// leaky-ReLU slopes -- nothing is re-derived by inverting the flow in float32.  Per family:
+//   LDS-resident RealNVP        the activation stash of the training step (k_affine_chain<STASH> -> k_affine_bwd_stashed);
+//                               with nf_ctx_set_stash_budget(0): the tiled flow output (invertible recompute, explicit opt-in)
+//   weight-streaming RealNVP    k_wide_apply's forward stash + the tiled flow output (k_wide_bwd_stashed, k_wide_dw)
+//   neural spline couplings     the tiled flow output (the reverse kernel recomputes from it)
+//   planar / radial / mean-field / Float64 couplings / Hamiltonian: the flow input (their reverse pass re-runs the
+//                               forward from x in the element type -- the same arithmetic, hence the same activations)
+//   compositions                the segments' tapes, concatenated in flat order
+// The tape's size and content are a function of (context settings, desc, N) only: both calls must see the same.
+enum TapeKind { TAPE_X, TAPE_AFFINE_STASH, TAPE_TILED_Y, TAPE_WIDE };
+static inline bool affine_stash_off(nf_ctx *ctx) {
+  static const bool env_off = std::getenv("NF_AFFINE_NO_STASH") != nullptr;
+  return ctx->stash_budget == 0 || (ctx->stash_budget < 0 && env_off);
+}
+static TapeKind tape_kind(nf_ctx *ctx, const nf_flow_desc *g) {
+  if (!is_coupling(g)) return TAPE_X;
+  if (is_wide(g)) return TAPE_WIDE;
+  if (is_nsf(g)) return TAPE_TILED_Y;
+  return affine_stash_off(ctx) ? TAPE_TILED_Y : TAPE_AFFINE_STASH;
+}
+static size_t tape_seg_bytes(nf_ctx *ctx, const nf_flow_desc *g, long N) {
+  switch (tape_kind(ctx, g)) {
+    case TAPE_X: return carve_bytes((size_t)N * g->d * esize(g->dtype));
+    case TAPE_AFFINE_STASH: return carve_bytes(nf_affine_stash_floats(g, N) * 4);
+    case TAPE_TILED_Y: return carve_bytes(tiled_elems(g, N) * 4);
+    case TAPE_WIDE: return carve_bytes(nf_wide_fwd_stash_floats(ctx, g, N) * 4) + carve_bytes(tiled_elems(g, N) * 4);
+  }
+  return 0;
+}
+static size_t tape_bytes_of(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
+  if (!is_composite(desc)) return tape_seg_bytes(ctx, desc, N);
+  size_t tot = 0;
+  for (int s = 0; s < desc->nsegments; ++s) tot += tape_seg_bytes(ctx, &desc->segments[s], N);
+  return tot;
+}
+// intermediates (front of the context workspace) of the two passes
+static size_t tape_fwd_need_seg(nf_ctx *, const nf_flow_desc *g, long N) {
+  return is_coupling(g) ? carve_bytes(tiled_elems(g, N) * 4) : 0;
+}
+static size_t tape_bwd_need_seg(nf_ctx *ctx, const nf_flow_desc *g, long N) {
+  const size_t tb = is_coupling(g) ? carve_bytes(tiled_elems(g, N) * 4) : 0;
+  switch (tape_kind(ctx, g)) {
+    case TAPE_X: return flat_bwd_ws_bytes(ctx, g, N);
+    case TAPE_AFFINE_STASH: return tb + carve_bytes((size_t)coupling_bwd_grid(ctx, g, N) * coupling_slab_floats(ctx, g, N) * 4);
+    case TAPE_TILED_Y: return 2 * tb + carve_bytes((size_t)coupling_bwd_grid(ctx, g, N) * coupling_slab_floats(ctx, g, N) * 4);
+    case TAPE_WIDE: return 2 * tb + carve_bytes(nf_wide_train_scratch_floats(ctx, g, N) * 4);
+  }
+  return 0;
+}
+// a composition keeps a log-det scratch vector and the block partials nf_launch_sum2 insists on behind its segments' needs
+static size_t tape_comp_extra(const nf_flow_desc *desc, long N) {
+  return carve_bytes((size_t)N * esize(desc->dtype)) + carve_bytes((size_t)nf_sum2_nblocks(N) * 8);
+}
+static size_t tape_need(nf_ctx *ctx, const nf_flow_desc *desc, long N, bool bwd) {
+  if (!is_composite(desc)) return bwd ? tape_bwd_need_seg(ctx, desc, N) : tape_fwd_need_seg(ctx, desc, N);
+  size_t m = 0;
+  for (int s = 0; s < desc->nsegments; ++s) {
+    const nf_flow_desc *g = &desc->segments[s];
+    const size_t v = bwd ? tape_bwd_need_seg(ctx, g, N) : tape_fwd_need_seg(ctx, g, N);
+    if (v > m) m = v;
+  }
+  return m + (bwd ? 0 : tape_comp_extra(desc, N));
+}
+
+// forward of ONE homogeneous segment, leaving its tape; y_out may alias x_in
+static int tape_fwd_seg(nf_ctx *ctx, const nf_flow_desc *g, const void *theta, const void *x_in, long N, void *y_out, void *ladj,
+                        void *tape) {
+  const TapeKind tk = tape_kind(ctx, g);
+  if (tk == TAPE_X) {
+    NF_HIP(hipMemcpyAsync(tape, x_in, (size_t)N * g->d * esize(g->dtype), hipMemcpyDeviceToDevice, ctx->stream));
+    return flat_apply(ctx, g, 0, nf_layer_count(g), false, theta, x_in, N, y_out, ladj);
+  }
+  const size_t te = tiled_elems(g, N);
+  NF_TRY(nf_ws_reserve(ctx, carve_bytes(te * 4)));
+  float *xt = (float *)ctx->ws;
+  NF_TRY(nf_launch_layout_convert(ctx, g->d, N, (const float *)x_in, xt, 1));
+  NF_TRY(coupling_pack(ctx, g, (const float *)theta));
+  if (tk == TAPE_AFFINE_STASH) {
+    NF_TRY(nf_affine_chain(ctx, g, false, xt, N, (float *)ladj, (float *)tape));
+  } else if (tk == TAPE_WIDE) {
+    NF_TRY(nf_wide_train_forward(ctx, g, xt, N, (float *)ladj, (float *)tape));
+    char *ty = (char *)tape + carve_bytes(nf_wide_fwd_stash_floats(ctx, g, N) * 4);
+    NF_HIP(hipMemcpyAsync(ty, xt, te * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  } else {
+    NF_TRY(coupling_chain_tiled(ctx, g, false, (const float *)theta, xt, N, (float *)ladj, -1));
+    NF_HIP(hipMemcpyAsync(tape, xt, te * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  return nf_launch_layout_convert(ctx, g->d, N, xt, (float *)y_out, 0);
+}
+
+// pullback of ONE homogeneous segment from its tape; xbar_out may alias ybar.  lbar == nullptr: every sample's
+// log-det cotangent is lbar_const.  The tape is left intact (a pullback may be called more than once).
+static int tape_bwd_seg(nf_ctx *ctx, const nf_flow_desc *g, const void *theta, const void *tape, const void *ybar,
+                        const void *lbar, double lbar_const, long N, void *xbar_out, void *gtheta_out) {
+  const TapeKind tk = tape_kind(ctx, g);
+  if (tk == TAPE_X) {
+    NF_TRY(nf_ws_reserve(ctx, flat_bwd_ws_bytes(ctx, g, N)));
+    return flat_bwd(ctx, g, theta, tape, ybar, lbar, lbar_const, N, xbar_out, gtheta_out, ctx->ws);
+  }
+  const size_t te = tiled_elems(g, N);
+  NF_TRY(nf_ws_reserve(ctx, tape_bwd_need_seg(ctx, g, N)));
+  Carver cv(ctx->ws);
+  float *gt = cv.take<float>(te);
+  NF_TRY(coupling_pack(ctx, g, (const float *)theta));
+  NF_TRY(nf_launch_layout_convert(ctx, g->d, N, (const float *)ybar, gt, 1));
+  if (tk == TAPE_AFFINE_STASH) {
+    const int grid = coupling_bwd_grid(ctx, g, N);
+    const long stride = coupling_slab_floats(ctx, g, N);
+    float *slab = cv.take<float>((size_t)grid * stride);
+    NF_TRY(nf_affine_bwd_stashed(ctx, g, (float *)const_cast<void *>(tape), gt, (const float *)lbar, (float)lbar_const, N, slab,
+                                 stride, grid));
+    NF_TRY(nf_affine_reduce_slabs(ctx, g, slab, grid, (float *)gtheta_out));
+  } else if (tk == TAPE_WIDE) {
+    float *state = cv.take<float>(te);
+    float *scratch = cv.take<float>(nf_wide_train_scratch_floats(ctx, g, N));
+    const char *ty = (const char *)tape + carve_bytes(nf_wide_fwd_stash_floats(ctx, g, N) * 4);
+    NF_HIP(hipMemcpyAsync(state, ty, te * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    NF_TRY(nf_wide_train_backward(ctx, g, state, gt, (const float *)lbar, (float)lbar_const, N,
+                                  (float *)const_cast<void *>(tape), (float *)gtheta_out, scratch));
+  } else {
+    float *state = cv.take<float>(te);
+    const int grid = coupling_bwd_grid(ctx, g, N);
+    float *slab = cv.take<float>((size_t)grid * coupling_slab_floats(ctx, g, N));
+    NF_HIP(hipMemcpyAsync(state, tape, te * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    NF_TRY(realnvp_bwd(ctx, g, (const float *)theta, state, gt, (const float *)lbar, (float)lbar_const, N, slab, grid,
+                       (float *)gtheta_out));
+  }
+  return nf_launch_layout_convert(ctx, g->d, N, gt, (float *)xbar_out, 0);
+}
+
+// whole flow (a composition chains its segments through y_out in place; the LAST segment is applied first)
+static int tape_fwd(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *x_in, long N, void *y_out,
+                    void *ladj, void *tape) {
+  if (!is_composite(desc)) return tape_fwd_seg(ctx, desc, theta, x_in, N, y_out, ladj, tape);
+  const size_t es = esize(desc->dtype);
+  const int ns = desc->nsegments;
+  size_t in_need = 0, toff[65];
+  toff[0] = 0;
+  for (int s = 0; s < ns; ++s) {
+    const size_t v = tape_fwd_need_seg(ctx, &desc->segments[s], N);
+    if (v > in_need) in_need = v;
+    toff[s + 1] = toff[s] + tape_seg_bytes(ctx, &desc->segments[s], N);
+  }
+  const size_t prev_guard = ctx->ws_guard;
+  NF_TRY(nf_ws_reserve(ctx, in_need + tape_comp_extra(desc, N)));
+  GuardReset gr{ctx, prev_guard};
+  Carver cv((char *)ctx->ws + in_need);
+  char *tmp = cv.take<char>((size_t)N * es);
+  double *partial = cv.take<double>(nf_sum2_nblocks(N));
+  if (in_need) ctx->ws_guard = in_need;
+  const void *cur = x_in;
+  for (int i = 0; i < ns; ++i) {
+    const int s = ns - 1 - i;
+    const char *th = (const char *)theta + (size_t)seg_theta_off(desc, s) * es;
+    NF_TRY(tape_fwd_seg(ctx, &desc->segments[s], th, cur, N, y_out, i == 0 ? ladj : (void *)tmp, (char *)tape + toff[s]));
+    if (i > 0) NF_TRY(nf_launch_sum2(ctx, desc->dtype, N, ladj, tmp, ladj, partial, 0.0));
+    cur = y_out;
+  }
+  return NF_OK;
+}
+
+static int tape_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *tape, const void *ybar,
+                    const void *lbar, double lbar_const, long N, void *xbar_out, void *gtheta_out) {
+  if (!is_composite(desc)) return tape_bwd_seg(ctx, desc, theta, tape, ybar, lbar, lbar_const, N, xbar_out, gtheta_out);
+  const size_t es = esize(desc->dtype);
+  size_t toff = 0;
+  const void *cur = ybar;
+  for (int s = 0; s < desc->nsegments; ++s) {  // flat order = last applied first
+    const nf_flow_desc *g = &desc->segments[s];
+    const size_t off = (size_t)seg_theta_off(desc, s) * es;
+    NF_TRY(tape_bwd_seg(ctx, g, (const char *)theta + off, (const char *)tape + toff, cur, lbar, lbar_const, N, xbar_out,
+                        (char *)gtheta_out + off));
+    toff += tape_seg_bytes(ctx, g, N);
+    cur = xbar_out;
+  }
+  return NF_OK;
+}
+
+extern "C" int64_t nf_tape_bytes(nf_ctx *ctx, const nf_flow_desc *desc, int64_t N) {
+  if (!ctx || N < 0) return NF_ERR_ARG;
+  const int st = check_desc(desc);
+  if (st != NF_OK) return st;
+  return (int64_t)tape_bytes_of(ctx, desc, N > 0 ? N : 1);
+}
+
+extern "C" int nf_flow_fwd_keep(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *x_in, int64_t N,
+                                void *y_out, void *ladj_out, void *tape, size_t tape_bytes) {
+  if (!ctx || !theta || !x_in || !y_out || !ladj_out || !tape || N < 0 || ((uintptr_t)tape & 255)) return NF_ERR_ARG;
+  NF_TRY(check_desc(desc));
+  NF_HIP(hipSetDevice(ctx->device));
+  if (N == 0) return NF_OK;
+  if (tape_bytes < tape_bytes_of(ctx, desc, N)) return NF_ERR_WORKSPACE;
+  return tape_fwd(ctx, desc, theta, x_in, N, y_out, ladj_out, tape);
+}
+
+extern "C" int nf_flow_bwd_kept(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *tape, size_t tape_bytes,
+                                const void *ybar, const void *lbar, int64_t N, void *xbar_out, void *gtheta_out) {
+  if (!ctx || !theta || !tape || !ybar || !lbar || !xbar_out || !gtheta_out || N < 0 || ((uintptr_t)tape & 255)) return NF_ERR_ARG;
+  NF_TRY(check_desc(desc));
+  NF_HIP(hipSetDevice(ctx->device));
+  if (N == 0) return nf_launch_fill(ctx, desc->dtype, gtheta_out, nf_param_count(desc), 0.0);
+  if (tape_bytes < tape_bytes_of(ctx, desc, N)) return NF_ERR_WORKSPACE;
+  return tape_bwd(ctx, desc, theta, tape, ybar, lbar, 0.0, N, xbar_out, gtheta_out);
+}
+
+// The pullback for callers that kept only x: the forward is run again FROM x with its tape in the context workspace
+// (not reconstructed from y -- y is accepted for the signature of the rrule and not read), then the tape is pulled back.
+static size_t flow_bwd_need(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
+  const size_t a = tape_need(ctx, desc, N, false), b = tape_need(ctx, desc, N, true);
+  return (a > b ? a : b) + tape_bytes_of(ctx, desc, N) + carve_bytes((size_t)N * desc->d * esize(desc->dtype)) +
+         carve_bytes((size_t)N * esize(desc->dtype));
+}
 extern "C" int nf_flow_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *x, const void *y,
                            const void *ybar, const void *lbar, int64_t N, void *xbar_out, void *gtheta_out) {
   if (!ctx || !theta || !x || !y || !ybar || !lbar || !xbar_out || !gtheta_out || N < 0) return NF_ERR_ARG;
@@ -777,25 +1013,19 @@ extern "C" int nf_flow_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const void *th
   NF_HIP(hipSetDevice(ctx->device));
   const long P = nf_param_count(desc);
   if (N == 0) return nf_launch_fill(ctx, desc->dtype, gtheta_out, P, 0.0);
-  if (is_composite(desc)) return flow_bwd_composite(ctx, desc, theta, x, ybar, lbar, N, xbar_out, gtheta_out);
-  if (is_coupling(desc)) {
-    const int grid = coupling_bwd_grid(ctx, desc, N);
-    const size_t te = tiled_elems(desc, N);
-    const size_t slabf = (size_t)grid * coupling_slab_floats(ctx, desc, N);
-    NF_TRY(nf_ws_reserve(ctx, 2 * carve_bytes(te * 4) + carve_bytes(slabf * 4)));
-    Carver cv(ctx->ws);
-    float *state = cv.take<float>(te);
-    float *gt = cv.take<float>(te);
-    float *slab = cv.take<float>(slabf);
-    NF_TRY(coupling_pack(ctx, desc, (const float *)theta));
-    NF_TRY(nf_launch_layout_convert(ctx, desc->d, N, (const float *)y, state, 1));
-    NF_TRY(nf_launch_layout_convert(ctx, desc->d, N, (const float *)ybar, gt, 1));
-    NF_TRY(realnvp_bwd(ctx, desc, (const float *)theta, state, gt, (const float *)lbar, 0.f, N, slab, grid,
-                       (float *)gtheta_out));
-    return nf_launch_layout_convert(ctx, desc->d, N, gt, (float *)xbar_out, 0);
-  }
-  NF_TRY(nf_ws_reserve(ctx, flat_bwd_ws_bytes(ctx, desc, N)));
-  return flat_bwd(ctx, desc, theta, x, ybar, lbar, 0.0, N, xbar_out, gtheta_out, ctx->ws);
+  const size_t es = esize(desc->dtype);
+  const size_t a = tape_need(ctx, desc, N, false), b = tape_need(ctx, desc, N, true);
+  const size_t in_need = a > b ? a : b;
+  const size_t prev_guard = ctx->ws_guard;
+  NF_TRY(nf_ws_reserve(ctx, flow_bwd_need(ctx, desc, N)));
+  GuardReset gr{ctx, prev_guard};
+  Carver cv((char *)ctx->ws + in_need);
+  char *tape = cv.take<char>(tape_bytes_of(ctx, desc, N));
+  char *yscr = cv.take<char>((size_t)N * desc->d * es);
+  char *lscr = cv.take<char>((size_t)N * es);
+  if (in_need) ctx->ws_guard = in_need;
+  NF_TRY(tape_fwd(ctx, desc, theta, x, N, yscr, lscr, tape));
+  return tape_bwd(ctx, desc, theta, tape, ybar, lbar, 0.0, N, xbar_out, gtheta_out);
 }
 
 // ---- targets -------------------------------------------------------------------------------
@@ -953,7 +1183,8 @@ extern "C" int nf_loglikelihood_value_and_grad(nf_ctx *ctx, const nf_flow_desc *
   const long stash_nc = tiled ? affine_stash_chunk(ctx, desc, N) : 0;
   const int stash_nch = stash_nc ? (int)((N + stash_nc - 1) / stash_nc) : 0;
   const size_t stash_b = stash_nc ? affine_stash_bytes(ctx, desc, stash_nc) : 0;
-  const size_t slabf_all = slabf * (stash_nch > 1 ? stash_nch : 1);
+  const size_t slabf_all = tiled ? chunked_slab_floats(ctx, desc, N, stash_nc, coupling_slab_floats(ctx, desc, N)) : 0;
+  (void)slabf; (void)stash_nch;
   const size_t need = 2 * carve_bytes(xe * es) + carve_bytes((size_t)N * es) + carve_bytes((size_t)nb * 8) +
                       carve_bytes(2 * (size_t)desc->d * es) + carve_bytes(slabf_all * es) + carve_bytes(flat_ws) + carve_bytes(stash_b);
   NF_TRY(nf_ws_reserve(ctx, need));
@@ -1171,7 +1402,7 @@ static size_t composite_inner_need(nf_ctx *ctx, const nf_flow_desc *desc, long N
 }
 static size_t composite_extra_bytes(const nf_flow_desc *desc, long N) {
   const size_t es = esize(desc->dtype);
-  return (size_t)(desc->nsegments + 2) * carve_bytes((size_t)N * desc->d * es) + 5 * carve_bytes((size_t)N * es) +
+  return 2 * carve_bytes((size_t)N * desc->d * es) + 5 * carve_bytes((size_t)N * es) +
          carve_bytes((size_t)nf_target_nblocks(N) * 8) + carve_bytes((size_t)nf_sum2_nblocks(N) * 8) + carve_bytes(64);
 }
 static long seg_theta_off(const nf_flow_desc *desc, int s) {
@@ -1184,7 +1415,6 @@ static int composite_bufs(nf_ctx *ctx, const nf_flow_desc *desc, long N, CompBuf
   const size_t in_need = composite_inner_need(ctx, desc, N);
   NF_TRY(nf_ws_reserve(ctx, in_need + composite_extra_bytes(desc, N)));
   Carver cv((char *)ctx->ws + in_need);
-  for (int s = 0; s < desc->nsegments; ++s) cb->xin[s] = cv.take<char>((size_t)N * desc->d * es);
   cb->y = cv.take<char>((size_t)N * desc->d * es);
   cb->gbar = cv.take<char>((size_t)N * desc->d * es);
   cb->logq = cv.take<char>((size_t)N * es);
@@ -1202,7 +1432,7 @@ static int composite_bufs(nf_ctx *ctx, const nf_flow_desc *desc, long N, CompBuf
 // forward: the LAST segment is applied first; inverse: the first.  layer >= 0: one bijector, flat index over the segments.
 // ladj is overwritten.  x_in may alias y_out.
 static int composite_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, const void *theta, const void *x_in, long N,
-                           void *y_out, void *ladj, CompBufs &cb, char **stash_inputs) {
+                           void *y_out, void *ladj, CompBufs &cb) {
   const size_t es = esize(desc->dtype);
   const int ns = desc->nsegments;
   const void *cur = x_in;
@@ -1211,12 +1441,6 @@ static int composite_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, 
     const nf_flow_desc *g = &desc->segments[sidx];
     const char *th = (const char *)theta + (size_t)seg_theta_off(desc, sidx) * es;
     void *dst = y_out;
-    if (stash_inputs) {  // forward with the segment inputs kept: input of segment s in xin[s], output into the next input
-      if (cur != stash_inputs[sidx])
-        NF_HIP(hipMemcpyAsync(stash_inputs[sidx], cur, (size_t)N * desc->d * es, hipMemcpyDeviceToDevice, ctx->stream));
-      cur = stash_inputs[sidx];
-      dst = i + 1 < ns ? (void *)stash_inputs[inverse ? sidx + 1 : sidx - 1] : y_out;
-    }
     NF_TRY(apply_std(ctx, g, inverse, -1, th, cur, N, dst, i == 0 ? ladj : (void *)cb.tmp));
     if (i > 0) NF_TRY(nf_launch_sum2(ctx, desc->dtype, N, ladj, cb.tmp, ladj, cb.partial_s, 0.0));
     cur = dst;
@@ -1242,7 +1466,7 @@ static int composite_apply(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, 
   const size_t prev_guard = ctx->ws_guard;
   NF_TRY(composite_bufs(ctx, desc, N, &cb));
   GuardReset gr{ctx, prev_guard};
-  return composite_chain(ctx, desc, inverse, theta, x_in, N, y_out, ladj, cb, nullptr);
+  return composite_chain(ctx, desc, inverse, theta, x_in, N, y_out, ladj, cb);
 }
 
 static int elbo_forward_composite(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, const void *theta,
@@ -1259,13 +1483,24 @@ static int elbo_forward_composite(nf_ctx *ctx, const nf_flow_desc *desc, const n
   } else {
     NF_TRY(nf_launch_base_sample(ctx, desc->dtype, desc->d, N, seed, off, stream_id, cb.y, cb.logq));
   }
-  NF_TRY(composite_chain(ctx, desc, false, theta, cb.y, N, cb.y, cb.ladj, cb, nullptr));
+  NF_TRY(composite_chain(ctx, desc, false, theta, cb.y, N, cb.y, cb.ladj, cb));
   NF_TRY(nf_launch_target(ctx, desc->dtype, target, desc->d, N, cb.y, cb.logq, cb.ladj, nullptr, nullptr, 0.0, elbos_out,
                           cb.partial_t, 1.0 / (double)N, 0));
   NF_TRY(nf_launch_finish_sum(ctx, cb.partial_t, nf_target_nblocks(N), 0, cb.result, nullptr, nullptr));
   return read_scalar(ctx, cb.result, elbo_host);
 }
 
+// training step of a composition: forward with every segment's tape kept (behind the segments' intermediates), target
+// and seed, then the segments' pullbacks from their tapes, last applied first
+static size_t vg_composite_extra(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
+  const size_t es = esize(desc->dtype);
+  return tape_bytes_of(ctx, desc, N) + 2 * carve_bytes((size_t)N * desc->d * es) + 2 * carve_bytes((size_t)N * es) +
+         carve_bytes((size_t)nf_target_nblocks(N) * 8);
+}
+static size_t vg_composite_need(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
+  const size_t a = tape_need(ctx, desc, N, false), b = tape_need(ctx, desc, N, true);
+  return (a > b ? a : b) + vg_composite_extra(ctx, desc, N);
+}
 static int value_and_grad_composite(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, const void *theta,
                                     const void *xs, int64_t N_local, int64_t N_global, uint64_t seed, uint64_t sample_offset,
                                     uint32_t stream_id, void *out) {
@@ -1275,57 +1510,31 @@ static int value_and_grad_composite(nf_ctx *ctx, const nf_flow_desc *desc, const
   const size_t es = esize(dt);
   if (N == 0) return nf_launch_fill(ctx, dt, out, P + 1, 0.0);
   const double inv = 1.0 / (double)N_global;
-  const int ns = desc->nsegments;
-  CompBufs cb;
+  const size_t a = tape_need(ctx, desc, N, false), b = tape_need(ctx, desc, N, true);
+  const size_t in_need = a > b ? a : b;
   const size_t prev_guard = ctx->ws_guard;
-  NF_TRY(composite_bufs(ctx, desc, N, &cb));
+  NF_TRY(nf_ws_reserve(ctx, in_need + vg_composite_extra(ctx, desc, N)));
   GuardReset gr{ctx, prev_guard};
-  char *x0 = cb.xin[ns - 1];  // the input of the first-applied segment is the base draw
+  Carver cv((char *)ctx->ws + in_need);
+  char *y = cv.take<char>((size_t)N * desc->d * es);
+  char *gbar = cv.take<char>((size_t)N * desc->d * es);
+  char *logq = cv.take<char>((size_t)N * es);
+  char *ladj = cv.take<char>((size_t)N * es);
+  double *partial = cv.take<double>(nf_target_nblocks(N));
+  char *tape = cv.take<char>(tape_bytes_of(ctx, desc, N));
+  if (in_need) ctx->ws_guard = in_need;
   if (xs) {
-    NF_HIP(hipMemcpyAsync(x0, xs, (size_t)N * desc->d * es, hipMemcpyDeviceToDevice, ctx->stream));
-    NF_TRY(nf_launch_base_logpdf(ctx, dt, desc->d, N, x0, cb.logq));
+    NF_HIP(hipMemcpyAsync(y, xs, (size_t)N * desc->d * es, hipMemcpyDeviceToDevice, ctx->stream));
+    NF_TRY(nf_launch_base_logpdf(ctx, dt, desc->d, N, y, logq));
   } else {
-    NF_TRY(nf_launch_base_sample(ctx, dt, desc->d, N, seed, sample_offset, stream_id, x0, cb.logq));
+    NF_TRY(nf_launch_base_sample(ctx, dt, desc->d, N, seed, sample_offset, stream_id, y, logq));
   }
-  NF_TRY(composite_chain(ctx, desc, false, theta, x0, N, cb.y, cb.ladj, cb, cb.xin));
-  // gbar = d(-elbo/Ng)/dy, loss partials; then the segments' reverse passes, last applied first
-  NF_TRY(nf_launch_target(ctx, dt, target, desc->d, N, cb.y, cb.logq, cb.ladj, nullptr, cb.gbar, -inv, nullptr, cb.partial_t,
-                          -inv, 0));
-  if (dt == NF_DTYPE_F32) NF_TRY(nf_launch_finish_sum(ctx, cb.partial_t, nf_target_nblocks(N), 0, nullptr, (float *)out + P, nullptr));
-  else NF_TRY(nf_launch_finish_sum(ctx, cb.partial_t, nf_target_nblocks(N), 0, (double *)out + P, nullptr, nullptr));
-  NF_TRY(nf_launch_fill(ctx, dt, cb.lbar, N, -inv));
-  for (int s = 0; s < ns; ++s) {
-    const nf_flow_desc *g = &desc->segments[s];
-    const long off = seg_theta_off(desc, s);
-    const void *yseg = s == 0 ? (const void *)cb.y : (const void *)cb.xin[s - 1];
-    NF_TRY(nf_flow_bwd(ctx, g, (const char *)theta + (size_t)off * es, cb.xin[s], yseg, cb.gbar, cb.lbar, N, cb.gbar,
-                       (char *)out + (size_t)off * es));
-  }
-  return NF_OK;
-}
-
-// nf_flow_bwd of a composition: the forward chain again with every segment's input kept, then the segments' own
-// pullbacks, last applied first (the cotangent of every segment's log-det is the caller's lbar)
-static int flow_bwd_composite(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *x, const void *ybar,
-                              const void *lbar, long N, void *xbar_out, void *gtheta_out) {
-  const size_t es = esize(desc->dtype);
-  const int ns = desc->nsegments;
-  CompBufs cb;
-  const size_t prev_guard = ctx->ws_guard;
-  NF_TRY(composite_bufs(ctx, desc, N, &cb));
-  GuardReset gr{ctx, prev_guard};
-  char *x0 = cb.xin[ns - 1];
-  NF_HIP(hipMemcpyAsync(x0, x, (size_t)N * desc->d * es, hipMemcpyDeviceToDevice, ctx->stream));
-  NF_TRY(composite_chain(ctx, desc, false, theta, x0, N, cb.y, cb.ladj, cb, cb.xin));
-  if (xbar_out != ybar)
-    NF_HIP(hipMemcpyAsync(xbar_out, ybar, (size_t)N * desc->d * es, hipMemcpyDeviceToDevice, ctx->stream));
-  for (int s = 0; s < ns; ++s) {
-    const long off = seg_theta_off(desc, s);
-    const void *yseg = s == 0 ? (const void *)cb.y : (const void *)cb.xin[s - 1];
-    NF_TRY(nf_flow_bwd(ctx, &desc->segments[s], (const char *)theta + (size_t)off * es, cb.xin[s], yseg, xbar_out, lbar, N,
-                       xbar_out, (char *)gtheta_out + (size_t)off * es));
-  }
-  return NF_OK;
+  NF_TRY(tape_fwd(ctx, desc, theta, y, N, y, ladj, tape));
+  // gbar = d(-elbo/Ng)/dy, loss partials
+  NF_TRY(nf_launch_target(ctx, dt, target, desc->d, N, y, logq, ladj, nullptr, gbar, -inv, nullptr, partial, -inv, 0));
+  if (dt == NF_DTYPE_F32) NF_TRY(nf_launch_finish_sum(ctx, partial, nf_target_nblocks(N), 0, nullptr, (float *)out + P, nullptr));
+  else NF_TRY(nf_launch_finish_sum(ctx, partial, nf_target_nblocks(N), 0, (double *)out + P, nullptr, nullptr));
+  return tape_bwd(ctx, desc, theta, tape, gbar, nullptr, -inv, N, gbar, out);
 }
 
 static int loglikelihood_composite(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *ys, long N,
@@ -1334,7 +1543,7 @@ static int loglikelihood_composite(nf_ctx *ctx, const nf_flow_desc *desc, const 
   const size_t prev_guard = ctx->ws_guard;
   NF_TRY(composite_bufs(ctx, desc, N, &cb));
   GuardReset gr{ctx, prev_guard};
-  NF_TRY(composite_chain(ctx, desc, true, theta, ys, N, cb.y, cb.ladj, cb, nullptr));
+  NF_TRY(composite_chain(ctx, desc, true, theta, ys, N, cb.y, cb.ladj, cb));
   NF_TRY(nf_launch_base_logpdf(ctx, desc->dtype, desc->d, N, cb.y, cb.logq));
   NF_TRY(nf_launch_sum2(ctx, desc->dtype, N, cb.logq, cb.ladj, logliks_out, cb.partial_s, 1.0 / (double)N));
   NF_TRY(nf_launch_finish_sum(ctx, cb.partial_s, nf_sum2_nblocks(N), 0, cb.result, nullptr, nullptr));
@@ -1487,13 +1696,13 @@ extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, con
   // LDS-resident RealNVP: activation stash for the reverse pass, the batch in chunks if it exceeds the budget (in-library
   // draws; caller-supplied draws take one chunk or the recompute kernel)
   const bool fusable = cp && elbo_fusable(desc, target, xs);
-  long stash_nc = cp ? affine_stash_chunk(ctx, desc, N) : 0;
-  if (stash_nc < N && !fusable) stash_nc = 0;
+  const long stash_nc = cp ? affine_stash_chunk(ctx, desc, N) : 0;
   const int stash_nch = stash_nc ? (int)((N + stash_nc - 1) / stash_nc) : 0;
   const size_t stash_b = stash_nc ? affine_stash_bytes(ctx, desc, stash_nc) : 0;
   const bool wide = cp && is_wide(desc);
+  (void)stash_nch;
   const size_t slabf = wide ? nf_wide_train_ws_floats(ctx, desc, N)
-                            : cp ? (size_t)grid * coupling_slab_floats(ctx, desc, N) * (stash_nch > 1 ? stash_nch : 1) : 0;
+                            : cp ? chunked_slab_floats(ctx, desc, N, stash_nc, coupling_slab_floats(ctx, desc, N)) : 0;
   const size_t xe = cp ? tiled_elems(desc, N) : simple_step ? 0 : (size_t)N * desc->d;
   const size_t need = 3 * carve_bytes(xe * es) + 2 * carve_bytes((size_t)N * es) + carve_bytes((size_t)nb_alloc * 8) +
                       carve_bytes(64) + carve_bytes(slabf * es) + carve_bytes(simple_ws) + carve_bytes(stash_b);
@@ -1562,21 +1771,32 @@ extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, con
     } else {
       NF_TRY(nf_launch_base_sample_tiled(ctx, desc->d, N, seed, sample_offset, stream_id, xt, (float *)logq));
     }
-    if (stash) {  // LDS-resident RealNVP: the plain forward chain leaves the stash, too
+    if (stash) {
+      // LDS-resident RealNVP with caller-supplied draws or a target other than the diagonal Gaussian: the plain forward
+      // chain leaves the stash, too -- chunk by chunk through the stash buffer like the fused form above
       NF_TRY(coupling_pack(ctx, desc, (const float *)theta));
-      NF_TRY(nf_affine_chain(ctx, desc, false, xt, N, (float *)ladj, stash));
-    } else {
-      NF_TRY(coupling_chain_tiled(ctx, desc, false, (const float *)theta, xt, N, (float *)ladj, -1));
+      const long stride = coupling_slab_floats(ctx, desc, N);
+      long nslab = 0, npart = 0;
+      for (long o = 0; o < N; o += stash_nc) {
+        const long nc = N - o < stash_nc ? N - o : stash_nc;
+        const int gc = coupling_bwd_grid(ctx, desc, nc);
+        NF_TRY(nf_affine_chain(ctx, desc, false, xt + o * desc->d, nc, (float *)ladj + o, stash));
+        // gt = d(-elbo/Ng)/dy = -(1/Ng) grad logp(y);  partial sums of -elbo_j/Ng
+        NF_TRY(nf_launch_target_tiled(ctx, target, desc->d, nc, xt + o * desc->d, (const float *)logq + o, (const float *)ladj + o,
+                                      gt + o * desc->d, -inv, nullptr, partial + npart, -inv));
+        NF_TRY(nf_affine_bwd_stashed(ctx, desc, stash, gt + o * desc->d, nullptr, (float)(-inv), nc,
+                                     (float *)slab + nslab * stride, stride, gc));
+        nslab += gc;
+        npart += nf_target_tiled_nblocks(nc);
+      }
+      NF_TRY(nf_launch_finish_sum(ctx, partial, npart, 0, nullptr, (float *)out + P, nullptr));
+      return nf_affine_reduce_slabs(ctx, desc, (const float *)slab, (int)nslab, (float *)out);
     }
+    NF_TRY(coupling_chain_tiled(ctx, desc, false, (const float *)theta, xt, N, (float *)ladj, -1));
     // gt = d(-elbo/Ng)/dy = -(1/Ng) grad logp(y);  partial sums of -elbo_j/Ng
     NF_TRY(nf_launch_target_tiled(ctx, target, desc->d, N, xt, (const float *)logq, (const float *)ladj, gt, -inv,
                                   nullptr, partial, -inv));
     NF_TRY(nf_launch_finish_sum(ctx, partial, nb, 0, nullptr, (float *)out + P, nullptr));
-    if (stash) {
-      NF_TRY(nf_affine_bwd_stashed(ctx, desc, stash, gt, nullptr, (float)(-inv), N, (float *)slab,
-                                   coupling_slab_floats(ctx, desc, N), grid));
-      return nf_affine_reduce_slabs(ctx, desc, (const float *)slab, grid, (float *)out);
-    }
     NF_TRY(realnvp_bwd(ctx, desc, (const float *)theta, xt, gt, nullptr, (float)(-inv), N, (float *)slab, grid,
                        (float *)out));
   } else {
@@ -1708,7 +1928,13 @@ size_t nf_wide_wimg_bytes(nf_ctx *, const nf_flow_desc *desc);
 static size_t composite_inner_need(nf_ctx *ctx, const nf_flow_desc *desc, long N);
 static size_t composite_extra_bytes(const nf_flow_desc *desc, long N);
 static size_t ws_need_bound(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
-  if (is_composite(desc)) return composite_inner_need(ctx, desc, N) + composite_extra_bytes(desc, N);
+  if (is_composite(desc)) {
+    size_t need = composite_inner_need(ctx, desc, N) + composite_extra_bytes(desc, N);
+    const size_t v = vg_composite_need(ctx, desc, N), f = flow_bwd_need(ctx, desc, N);
+    if (v > need) need = v;
+    if (f > need) need = f;
+    return need;
+  }
   const size_t es = esize(desc->dtype);
   const bool cp = is_coupling(desc);
   const size_t te = cp ? tiled_elems(desc, N) : 0;
@@ -1718,10 +1944,10 @@ static size_t ws_need_bound(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
   auto upd = [&](size_t v) { if (v > need) need = v; };
   // nf_flow_fwd / inv / layer_apply, nf_flow_rand
   upd(cp ? carve_bytes(te * 4) + carve_bytes((size_t)N * 4) : cn);
-  // nf_flow_bwd
+  // nf_flow_bwd (its own forward + tape), nf_flow_fwd_keep / nf_flow_bwd_kept (tape in the caller's memory)
   const int grid = cp ? coupling_bwd_grid(ctx, desc, N) : 0;
   const size_t slab_pull = cp ? (size_t)grid * coupling_slab_floats(ctx, desc, N) : 0;
-  upd(cp ? 2 * carve_bytes(te * 4) + carve_bytes(slab_pull * 4) : flat_bwd_ws_bytes(ctx, desc, N));
+  upd(flow_bwd_need(ctx, desc, N));
   // nf_elbo_batch(_rng), nf_loglikelihood
   const long nbt = cp ? nf_target_tiled_nblocks(N) : nf_target_nblocks(N);
   const long nb_alloc = nbt < ctx->num_cu ? ctx->num_cu : nbt;
@@ -1733,28 +1959,27 @@ static size_t ws_need_bound(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
     const bool hf = desc->kind == NF_KIND_HAMILTONIAN;
     const bool tiled = cp && coupling_inv_bwd_tiled(desc);
     if (!(coupling_kind && !tiled && !nf_g64_supported(desc))) {
-      const size_t slabf = tiled ? slab_pull : 0;
+      const long snc = tiled ? affine_stash_chunk(ctx, desc, N) : 0;
+      const size_t slabf = tiled ? chunked_slab_floats(ctx, desc, N, snc, coupling_slab_floats(ctx, desc, N)) : 0;
       const size_t flat_ws = tiled ? 0 : hf ? nf_hf_bwd_ws_bytes(desc, N) : coupling_kind ? nf_g64_bwd_inv_ws_bytes(desc, N)
                                                                                        : nf_simple_bwd_ws_bytes(ctx, desc, N);
-      const long snc = tiled ? affine_stash_chunk(ctx, desc, N) : 0;
-      const size_t nch = snc ? (size_t)((N + snc - 1) / snc) : 1;
       upd(2 * carve_bytes(xe * es) + cn + carve_bytes((size_t)nbt * 8) + carve_bytes(2 * (size_t)desc->d * es) +
-          carve_bytes(slabf * nch * es) + carve_bytes(flat_ws) + carve_bytes(snc ? affine_stash_bytes(ctx, desc, snc) : 0));
+          carve_bytes(slabf * es) + carve_bytes(flat_ws) + carve_bytes(snc ? affine_stash_bytes(ctx, desc, snc) : 0));
     }
   }
   // nf_elbo_value_and_grad / nf_elbo_step (both the stash-free and the stash form of the simple flows)
   {
     const bool wide = cp && is_wide(desc);
-    const size_t slabf = wide ? nf_wide_train_ws_floats(ctx, desc, N) : slab_pull;
+    const long snc = cp ? affine_stash_chunk(ctx, desc, N) : 0;
+    const size_t slabf = wide ? nf_wide_train_ws_floats(ctx, desc, N)
+                              : cp ? chunked_slab_floats(ctx, desc, N, snc, coupling_slab_floats(ctx, desc, N)) : 0;
     size_t simple_ws = cp ? 0 : flat_bwd_ws_bytes(ctx, desc, N);
     if (!cp && !is_g64(desc) && desc->kind != NF_KIND_HAMILTONIAN && nf_simple_step_supported(desc)) {
       const size_t sw = nf_simple_step_ws_bytes(ctx, desc, N);
       if (sw > simple_ws) simple_ws = sw;
     }
-    const long snc = cp ? affine_stash_chunk(ctx, desc, N) : 0;
-    const size_t nch = snc ? (size_t)((N + snc - 1) / snc) : 1;
     upd(3 * carve_bytes(xe * es) + 2 * cn + carve_bytes((size_t)nb_alloc * 8) + carve_bytes(64) +
-        carve_bytes(slabf * (wide ? 1 : nch) * es) + carve_bytes(simple_ws) + carve_bytes(snc ? affine_stash_bytes(ctx, desc, snc) : 0));
+        carve_bytes(slabf * es) + carve_bytes(simple_ws) + carve_bytes(snc ? affine_stash_bytes(ctx, desc, snc) : 0));
   }
   return need;
 }

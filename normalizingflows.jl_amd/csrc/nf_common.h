@@ -53,6 +53,7 @@ struct nf_ctx {
   // intermediates arena `ws` is its front, packed weight images and the nf_elbo_step buffer are carved off its tail
   void *arena = nullptr;
   size_t arena_bytes = 0, arena_tail = 0;
+  size_t arena_front = 0;  // bytes the running entry point asked for at the front (nf_ws_reserve): tail carves stay behind it
   // > 0 while a wrapper entry point has buffers of its own behind the first ws_guard bytes of `ws`: inner requests
   // beyond the guard fail instead of overlapping them
   size_t ws_guard = 0;

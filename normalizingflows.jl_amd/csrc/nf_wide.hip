@@ -1140,13 +1140,24 @@ static int wide_train_forward(nf_ctx *ctx, const nf_flow_desc *desc, float *xt, 
   return NF_OK;
 }
 
+// floats of the forward stash alone / of the reverse pass's own scratch (delta stash + split-K slabs): the two parts of
+// wide_train_ws_floats, for callers that keep the stash elsewhere (the tape of nf_flow_fwd_keep)
+static size_t wide_fwd_stash_floats(nf_ctx *, const nf_flow_desc *desc, long N) {
+  const long ntiles = (N + NF_TILE - 1) / NF_TILE;
+  return (size_t)2 * desc->nlayers * 2 * fwd_stash_floats_per_net(ntiles);
+}
+static size_t wide_train_scratch_floats(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
+  return wide_train_ws_floats(ctx, desc, N) - wide_fwd_stash_floats(ctx, desc, N);
+}
+
+// scratch == nullptr: the reverse pass's scratch follows the forward stash inside ws (the training step's layout)
 static int wide_train_backward(nf_ctx *ctx, const nf_flow_desc *desc, float *state, float *gbar, const float *lbar,
-                           float lbar_const, long N, float *ws, float *g_out) {
+                           float lbar_const, long N, float *ws, float *g_out, float *scratch) {
   if (!ctx->wimg) return NF_ERR_UNSUPPORTED;
   const long ntiles = (N + NF_TILE - 1) / NF_TILE;
   const size_t per = (size_t)ntiles * NF_TILE * 32;
   const int nc = 2 * desc->nlayers;
-  float *p = ws + (size_t)nc * 2 * fwd_stash_floats_per_net(ntiles);
+  float *p = scratch ? scratch : ws + (size_t)nc * 2 * fwd_stash_floats_per_net(ntiles);
   WideStash st;
   st.a1 = nullptr; st.a2 = nullptr;
   st.d1 = p; p += per * G::H1B;
@@ -1226,4 +1237,6 @@ size_t nf_wide_bwd_ws_floats(nf_ctx *ctx, const nf_flow_desc *desc, long N) { re
 int nf_wide_bwd(nf_ctx *ctx, const nf_flow_desc *desc, float *state, float *gbar, const float *lbar, float lbar_const, long N, float *ws, float *g_out, bool inv_dir) { return WIDE_DISPATCH(wide_bwd(ctx, desc, state, gbar, lbar, lbar_const, N, ws, g_out, inv_dir)); }
 size_t nf_wide_train_ws_floats(nf_ctx *ctx, const nf_flow_desc *desc, long N) { return WIDE_DISPATCH(wide_train_ws_floats(ctx, desc, N)); }
 int nf_wide_train_forward(nf_ctx *ctx, const nf_flow_desc *desc, float *xt, long N, float *ladj, float *ws) { return WIDE_DISPATCH(wide_train_forward(ctx, desc, xt, N, ladj, ws)); }
-int nf_wide_train_backward(nf_ctx *ctx, const nf_flow_desc *desc, float *state, float *gbar, const float *lbar, float lbar_const, long N, float *ws, float *g_out) { return WIDE_DISPATCH(wide_train_backward(ctx, desc, state, gbar, lbar, lbar_const, N, ws, g_out)); }
+int nf_wide_train_backward(nf_ctx *ctx, const nf_flow_desc *desc, float *state, float *gbar, const float *lbar, float lbar_const, long N, float *ws, float *g_out, float *scratch) { return WIDE_DISPATCH(wide_train_backward(ctx, desc, state, gbar, lbar, lbar_const, N, ws, g_out, scratch)); }
+size_t nf_wide_fwd_stash_floats(nf_ctx *ctx, const nf_flow_desc *desc, long N) { return WIDE_DISPATCH(wide_fwd_stash_floats(ctx, desc, N)); }
+size_t nf_wide_train_scratch_floats(nf_ctx *ctx, const nf_flow_desc *desc, long N) { return WIDE_DISPATCH(wide_train_scratch_floats(ctx, desc, N)); }

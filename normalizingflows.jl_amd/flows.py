@@ -293,6 +293,47 @@ def with_logabsdet_jacobian(t: Transform, x: torch.Tensor):
     return y, ladj
 
 
+def rrule_with_logabsdet_jacobian(t: Transform, x: torch.Tensor):
+    """ChainRulesCore.rrule(with_logabsdet_jacobian, t, x) -> ((y, logabsdetjac), pullback): the forward keeps its tape in
+    a device buffer owned by the returned closure (nf_flow_fwd_keep), `pullback(ybar, lbar) -> (xbar, gtheta)` consumes it
+    (nf_flow_bwd_kept).  This is what lets an arbitrary `logp` closure train through the library: the user's AD supplies
+    ybar, the tape supplies the forward's own activations (the reference: Zygote on the forward's tape,
+    src/optimize.jl:12-14; the rrule mechanism MonotonicSplines uses, test/ad.jl:126-127).  Whole forward transforms
+    only (no Inverse, no single layer)."""
+    flow = t.flow
+    if t.inverted or t.layer is not None:
+        raise NFHipError("rrule_with_logabsdet_jacobian: whole forward transform only")
+    xm, vec = as_batch(x.to(flow.theta.dtype))
+    d, n = xm.shape
+    if d != flow.dist.d:
+        raise NFHipError(f"dimension mismatch: flow has d={flow.dist.d}, input has {d}")
+    dt, dev = xm.dtype, xm.device
+    ctx = flow.ctx
+    nbytes = int(ctx.lib.nf_tape_bytes(ctx.ptr, C.byref(flow.desc), n))
+    if nbytes < 0:
+        check(nbytes)
+    tape = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)  # torch allocations are 512-byte aligned
+    y = new_batch(d, n, dt, dev)
+    ladj = torch.empty(n, dtype=dt, device=dev)
+    theta = flow.theta
+    check(ctx.lib.nf_flow_fwd_keep(ctx.ptr, C.byref(flow.desc), _ptr(theta), _ptr(xm), n, _ptr(y), _ptr(ladj), _ptr(tape),
+                                   nbytes))
+
+    def pullback(ybar: torch.Tensor, lbar: torch.Tensor):
+        yb, _ = as_batch(ybar.to(dt))
+        lb = lbar.to(dt).reshape(-1).contiguous()
+        xbar = new_batch(d, n, dt, dev)
+        g = torch.empty(flow.P, dtype=dt, device=dev)
+        c = flow.ctx
+        check(c.lib.nf_flow_bwd_kept(c.ptr, C.byref(flow.desc), _ptr(theta), _ptr(tape), nbytes, _ptr(yb), _ptr(lb), n,
+                                     _ptr(xbar), _ptr(g)))
+        return (xbar[:, 0] if vec else xbar), g
+
+    if vec:
+        return (y[:, 0], ladj[0]), pullback
+    return (y, ladj), pullback
+
+
 def transform(t: Transform, x: torch.Tensor):
     """Bijectors.transform(t, x)"""
     return with_logabsdet_jacobian(t, x)[0]

@@ -13,7 +13,7 @@ import torch
 
 from ._lib import NFHipError, check
 from .flows import (BananaTarget, CrossTarget, DiagGaussTarget, FunnelTarget, WarpedGaussTarget, Flow, PhiloxRNG, _dtype_code, _ptr, as_batch, base_logpdf,
-                    check_target, device_specific_rand, new_batch, with_logabsdet_jacobian)
+                    check_target, device_specific_rand, new_batch, rrule_with_logabsdet_jacobian, with_logabsdet_jacobian)
 
 _BUILTIN = (DiagGaussTarget, BananaTarget, FunnelTarget, WarpedGaussTarget, CrossTarget)
 
@@ -134,8 +134,9 @@ def value_and_gradient(vo, flow: Flow, logp, xs_or_n, rng: Optional[PhiloxRNG] =
     """(loss, grad) of loss(theta) = -vo(rng, re(theta), logp, ...) (src/NormalizingFlows.jl:69).
 
     Built-in targets run the whole step inside the library (nf_elbo_value_and_grad).  An
-    arbitrary `logp` callable takes the split path: library forward, the callable's own
-    torch-autograd gradient w.r.t. ys, library pullback (nf_flow_bwd).
+    arbitrary `logp` callable takes the split path: library forward that keeps its tape
+    (nf_flow_fwd_keep), the callable's own torch-autograd gradient w.r.t. ys, library pullback
+    from that tape (nf_flow_bwd_kept) -- the same reverse kernels as the built-in step.
     Returns (loss: float, grad: tensor[P]) -- for a shard of a global batch pass n_global and
     all-reduce the returned grad and loss over ranks.
     """
@@ -164,17 +165,13 @@ def value_and_gradient(vo, flow: Flow, logp, xs_or_n, rng: Optional[PhiloxRNG] =
     # generic closure
     if xm is None:
         xm = device_specific_rand(rng, flow.dist, n, device=dev, dtype=dt)
-    ys, ladj = with_logabsdet_jacobian(flow.transform, xm)
-    yreq = ys.detach().clone().requires_grad_(True)
+    (ys, ladj), pullback = rrule_with_logabsdet_jacobian(flow.transform, xm)
+    yreq = ys.detach().requires_grad_(True)
     lp = logp(yreq)
     (glp,) = torch.autograd.grad(lp.sum(), yreq)
     elbos = lp.detach() - base_logpdf(flow.dist, xm) + ladj
-    ybar, _ = as_batch((-glp / ng).to(dt))
     lbar = torch.full((n,), -1.0 / ng, dtype=dt, device=dev)
-    xbar = new_batch(xm.shape[0], n, dt, dev)
-    g = torch.empty(P, dtype=dt, device=dev)
-    check(ctx.lib.nf_flow_bwd(ctx.ptr, C.byref(flow.desc), _ptr(flow.theta), _ptr(xm), _ptr(ys), _ptr(ybar), _ptr(lbar),
-                              n, _ptr(xbar), _ptr(g)))
+    _, g = pullback(-glp / ng, lbar)
     return float(-elbos.double().sum() / ng), g
 
 

@@ -1,0 +1,262 @@
+"""GPU parity tests of the forward-with-tape / pullback pair (nf_flow_fwd_keep, nf_flow_bwd_kept, nf_tape_bytes) and of
+everything that now runs on it: nf_flow_bwd, generic `logp` closures, heterogeneous compositions.
+
+Reference behaviour: Zygote differentiates the forward's own tape (src/optimize.jl:12-14 on
+src/objectives/elbo.jl:65-70); MonotonicSplines' rrules are the same mechanism (test/ad.jl:126-127).  So the pullback
+must meet the PLAIN gradient tolerance (1e-4 |g|inf, or 3 x the IEEE-float32 oracle where that is larger) -- the
+invertible-recompute allowance of round 2 (2e-3) does not apply to any default path any more.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import nf_oracle as o
+import parity as P
+from __graft_entry__ import load_package
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nf():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return load_package()
+
+
+def cm(a, dt, dev="cuda"):
+    return torch.tensor(np.ascontiguousarray(a.T), dtype=dt, device=dev).t()
+
+
+CASES = {
+    # name: (kind, d, nlayers, hdims, K, B, n, dtype)
+    "realnvp_d64_h64": ("realnvp", 64, 4, (64, 64), 0, 0.0, 2048 + 17, "f32"),   # cfg 2 shape: activation stash
+    "realnvp_d20_h32": ("realnvp", 20, 2, (32, 32), 0, 0.0, 333, "f32"),         # narrow nets: stash is the default now
+    "realnvp_d63_h40x64": ("realnvp", 63, 2, (40, 64), 0, 0.0, 1024, "f32"),
+    "realnvp_wide_d200_h256": ("realnvp", 200, 1, (256, 256), 0, 0.0, 300, "f32"),  # weight-streaming kernels
+    "realnvp_wide_d100_h128": ("realnvp", 100, 2, (128, 96), 0, 0.0, 257, "f32"),
+    "nsf_d32_k8": ("nsf", 32, 2, (32, 32), 8, 5.0, 515, "f32"),
+    "nsf_d5_k10": ("nsf", 5, 2, (32, 32), 10, 5.0, 100, "f32"),
+    "planar_d64": ("planar", 64, 10, (), 0, 0.0, 1000, "f32"),
+    "radial_d5": ("radial", 5, 10, (), 0, 0.0, 257, "f32"),
+    "realnvp_f64_d5": ("realnvp", 5, 2, (32, 32), 0, 0.0, 97, "f64"),             # general kernels
+    "nsf_f64_d6_3hidden": ("nsf", 6, 1, (24, 16, 8), 8, 5.0, 97, "f64"),
+}
+
+
+def make(nf, case, seed=5):
+    kind, d, nl, hd, K, B, n, dts = CASES[case]
+    dt = torch.float32 if dts == "f32" else torch.float64
+    spec = o.FlowSpec(kind, d, nl, hd, K, B) if kind == "nsf" else o.FlowSpec(kind, d, nl, hd)
+    rng = np.random.default_rng(seed + d)
+    th = o.init_params(spec, rng) + 0.03 * rng.standard_normal(o.param_count(spec))
+    if kind in ("planar", "radial"):
+        th = 0.5 * th
+    th = th.astype(np.float32).astype(np.float64) if dts == "f32" else th
+    flow = nf.Flow(kind, nf.MvNormal(d), nl, hd, K, B, dtype=dt, device="cuda", theta=torch.tensor(th, dtype=dt, device="cuda"))
+    xs = rng.standard_normal((d, n))
+    xs = xs.astype(np.float32).astype(np.float64) if dts == "f32" else xs
+    ybar = rng.standard_normal((d, n)) / n
+    lbar = rng.standard_normal(n) / n
+    if dts == "f32":
+        ybar, lbar = ybar.astype(np.float32).astype(np.float64), lbar.astype(np.float32).astype(np.float64)
+    return spec, th, flow, dt, xs, ybar, lbar
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_forward_keep_and_pullback_against_oracle(nf, case):
+    """rrule(with_logabsdet_jacobian): forward values equal nf_flow_fwd's, the pullback (xbar, gtheta) for a random
+    cotangent (ybar, lbar) matches the oracle's reverse pass at the plain tolerance, a second call of the pullback gives
+    the same bits (the tape is left intact), and the legacy nf_flow_bwd (x only) gives the same gradient."""
+    spec, th, flow, dt, xs, ybar, lbar = make(nf, case)
+    f64 = dt == torch.float64
+    x_t, yb_t, lb_t = cm(xs, dt), cm(ybar, dt), torch.tensor(lbar, dtype=dt, device="cuda")
+    (y, ladj), pullback = nf.flows.rrule_with_logabsdet_jacobian(flow.transform, x_t)
+    y0, l0 = nf.with_logabsdet_jacobian(flow.transform, x_t)
+    # (the stash-writing chain kernel may contract x1 * exp(s) + t differently from the plain one: last-bit differences)
+    assert float((y - y0).abs().max()) <= 2e-6 * max(1.0, float(y0.abs().max())), "keep-forward and plain forward disagree"
+    assert float((ladj - l0).abs().max()) <= 2e-6 * max(1.0, float(l0.abs().max()))
+    y_ref, l_ref, states = o.flow_fwd(spec, th, xs, keep=True)
+    xbar_ref, g_ref = o.flow_bwd(spec, th, states, ybar, lbar)
+    fl = None
+    if not f64:
+        th32, xs32, yb32, lb32 = P.f32(th, xs, ybar, lbar)
+        _, _, st32 = o.flow_fwd(spec, th32, xs32, keep=True)
+        fl = o.flow_bwd(spec, th32, st32, yb32, lb32)
+    xbar, g = pullback(yb_t, lb_t)
+    tol = P.F64_GRAD if f64 else P.GRAD_RTOL
+    P.gradient(f"tape {case}: pullback gtheta", g, g_ref, tol, None if f64 else fl[1])
+    P.gradient(f"tape {case}: pullback xbar", xbar, xbar_ref, tol, None if f64 else fl[0])
+    xbar2, g2 = pullback(yb_t, lb_t)
+    assert torch.equal(g, g2) and torch.equal(xbar, xbar2), "second pullback differs: the tape was modified"
+    # nf_flow_bwd: same signature as round 2, now forward-from-x + tape instead of inversion-from-y
+    lib, ctx = nf.load_library(), flow.ctx
+    xb3 = nf.new_batch(xs.shape[0], xs.shape[1], dt, "cuda")
+    g3 = torch.empty(flow.P, dtype=dt, device="cuda")
+    nf._lib.check(lib.nf_flow_bwd(ctx.ptr, C.byref(flow.desc), flow.theta.data_ptr(), x_t.data_ptr(), y.data_ptr(), yb_t.data_ptr(),
+                                  lb_t.data_ptr(), xs.shape[1], xb3.data_ptr(), g3.data_ptr()))
+    P.gradient(f"tape {case}: nf_flow_bwd gtheta", g3, g_ref, tol, None if f64 else fl[1])
+    P.gradient(f"tape {case}: nf_flow_bwd xbar", xb3, xbar_ref, tol, None if f64 else fl[0])
+
+
+def test_tape_size_follows_the_stash_setting_and_short_tapes_are_refused(nf):
+    spec, th, flow, dt, xs, ybar, lbar = make(nf, "realnvp_d64_h64")
+    lib, ctx = nf.load_library(), flow.ctx
+    n = xs.shape[1]
+    nb = int(lib.nf_tape_bytes(ctx.ptr, C.byref(flow.desc), n))
+    ntiles = (n + 31) // 32
+    assert nb >= ntiles * 8 * 46 * 1024  # 46 KiB per (tile, coupling) at d = 64 / hidden 64 (nf_coupling.hip StashGeo)
+    try:
+        nf._lib.check(lib.nf_ctx_set_stash_budget(ctx.ptr, 0))
+        nb0 = int(lib.nf_tape_bytes(ctx.ptr, C.byref(flow.desc), n))
+        assert 0 < nb0 <= ntiles * 32 * 64 * 4 + 256  # the tiled flow output only
+        # the explicit recompute mode still works through the same pair
+        (y, ladj), pullback = nf.flows.rrule_with_logabsdet_jacobian(flow.transform, cm(xs, dt))
+        _, g = pullback(cm(ybar, dt), torch.tensor(lbar, dtype=dt, device="cuda"))
+        _, _, states = o.flow_fwd(spec, th, xs, keep=True)
+        _, g_ref = o.flow_bwd(spec, th, states, ybar, lbar)
+        err = float(np.abs(g.cpu().numpy() - g_ref).max() / np.abs(g_ref).max())
+        P.record("tape realnvp_d64_h64 stash_budget(0) (explicit recompute): pullback gtheta [max abs err / |g|inf]", err)
+        assert err < 5e-3
+    finally:
+        nf._lib.check(lib.nf_ctx_set_stash_budget(ctx.ptr, -1))
+    x_t = cm(xs, dt)
+    y = nf.new_batch(64, n, dt, "cuda")
+    ladj = torch.empty(n, dtype=dt, device="cuda")
+    tape = torch.empty(nb // 4 - 64, dtype=torch.float32, device="cuda")
+    st = lib.nf_flow_fwd_keep(ctx.ptr, C.byref(flow.desc), flow.theta.data_ptr(), x_t.data_ptr(), n, y.data_ptr(), ladj.data_ptr(),
+                              tape.data_ptr(), tape.numel() * 4)
+    assert st == -7  # NF_ERR_WORKSPACE
+
+
+@pytest.mark.parametrize("case", ["realnvp_d64_h64", "realnvp_d20_h32", "realnvp_wide_d200_h256", "nsf_d32_k8", "planar_d64"])
+def test_generic_closure_step_equals_builtin_target_step(nf, case):
+    """A `logp` closure written in torch (the path every real user target takes) against the built-in diagonal-Gaussian
+    target: same loss, gradients within the plain tolerance of the ORACLE (both of them), caller-supplied and in-library
+    draws."""
+    spec, th, flow, dt, xs, _, _ = make(nf, case)
+    d, n = xs.shape
+    rng = np.random.default_rng(1)
+    mu, var = rng.standard_normal(d).astype(np.float32), (rng.uniform(size=d) + 0.5).astype(np.float32)
+    mu_t, var_t = torch.tensor(mu, device="cuda"), torch.tensor(var, device="cuda")
+    tgt = nf.DiagGaussTarget(mu_t, var_t)
+
+    def logp(ys):
+        return (-0.5 * (np.log(2 * np.pi) + var_t.log())[:, None] - 0.5 * (ys - mu_t[:, None]) ** 2 / var_t[:, None]).sum(0)
+
+    otgt = ("diaggauss", mu.astype(np.float64), var.astype(np.float64))
+    lo, go = o.neg_elbo_value_and_grad(spec, th, otgt, xs)
+    _, g32 = o.neg_elbo_value_and_grad(spec, P.f32(th), P.f32(otgt), P.f32(xs))
+    x_t = cm(xs, dt)
+    lb, gb = nf.value_and_gradient(nf.elbo_batch, flow, tgt, x_t)
+    lc, gc = nf.value_and_gradient(nf.elbo_batch, flow, logp, x_t)
+    P.scalar(f"closure {case}: loss (built-in)", lb, lo)
+    P.scalar(f"closure {case}: loss (closure)", lc, lo, 2e-5)
+    P.gradient(f"closure {case}: grad (built-in)", gb, go, floor=g32)
+    P.gradient(f"closure {case}: grad (closure)", gc, go, floor=g32)
+    l2, g2 = nf.value_and_gradient(nf.elbo_batch, flow, logp, n, rng=nf.PhiloxRNG(3))
+    l3, g3 = nf.value_and_gradient(nf.elbo_batch, flow, tgt, n, rng=nf.PhiloxRNG(3))
+    assert l2 == pytest.approx(l3, rel=2e-5)
+    assert float((g2 - g3).abs().max()) <= P.GRAD_RTOL * float(g3.abs().max())
+
+
+def test_composite_pullback_and_step_through_segment_tapes(nf):
+    """create_flow((planar, realnvp d=64 resident, radial), q0): the composition's tape is the segments' tapes; the
+    training step and the closure step agree with the oracle."""
+    d, n = 64, 777
+    rng = np.random.default_rng(4)
+    specs = [o.FlowSpec("planar", d, 3, ()), o.FlowSpec("realnvp", d, 2, (64, 64)), o.FlowSpec("radial", d, 2, ())]
+    ths = []
+    for sp in specs:
+        t = o.init_params(sp, rng)
+        if sp.kind != "realnvp":
+            t = 0.3 * t
+        ths.append(t.astype(np.float32).astype(np.float64))
+    th = np.concatenate(ths)
+    q0 = nf.MvNormal(d)
+    segs = [nf.Flow(sp.kind, q0, sp.nlayers, sp.hdims, dtype=torch.float32, device="cuda",
+                    theta=torch.tensor(t, dtype=torch.float32, device="cuda")) for sp, t in zip(specs, ths)]
+    flow = nf.create_flow(segs, q0)
+    xs = rng.standard_normal((d, n)).astype(np.float32).astype(np.float64)
+    mu, var = rng.standard_normal(d).astype(np.float32), (rng.uniform(size=d) + 0.5).astype(np.float32)
+    mu_t, var_t = torch.tensor(mu, device="cuda"), torch.tensor(var, device="cuda")
+    tgt = nf.DiagGaussTarget(mu_t, var_t)
+    otgt = ("diaggauss", mu.astype(np.float64), var.astype(np.float64))
+    lo, go = o.comp_neg_elbo_value_and_grad(specs, th, otgt, xs)
+    _, g32 = o.comp_neg_elbo_value_and_grad(specs, P.f32(th), P.f32(otgt), P.f32(xs))
+    x_t = cm(xs, torch.float32)
+    l1, g1 = nf.value_and_gradient(nf.elbo_batch, flow, tgt, x_t)
+    P.scalar("tape composite: step loss", l1, lo)
+    P.gradient("tape composite: step grad", g1, go, floor=g32)
+    l2, g2 = nf.value_and_gradient(nf.elbo_batch, flow, lambda y: (-0.5 * (np.log(2 * np.pi) + var_t.log())[:, None] -
+                                                                   0.5 * (y - mu_t[:, None]) ** 2 / var_t[:, None]).sum(0), x_t)
+    P.scalar("tape composite: closure loss", l2, lo, 2e-5)
+    P.gradient("tape composite: closure grad", g2, go, floor=g32)
+
+
+def test_supplied_draws_run_in_chunks_under_a_small_budget(nf):
+    """elbo_batch(flow, logp, xs) with a stash budget smaller than the batch's stash: the caller-supplied-draws form runs
+    chunk by chunk too (round 2 fell back to the recompute kernel there) and equals the one-chunk result."""
+    spec, th, flow, dt, xs, _, _ = make(nf, "realnvp_d64_h64")
+    d, n = xs.shape
+    rng = np.random.default_rng(2)
+    mu, var = rng.standard_normal(d).astype(np.float32), (rng.uniform(size=d) + 0.5).astype(np.float32)
+    tgt = nf.DiagGaussTarget(torch.tensor(mu, device="cuda"), torch.tensor(var, device="cuda"))
+    banana = nf.BananaTarget(d, 1.0, 10.0)
+    lib, ctx = nf.load_library(), flow.ctx
+    x_t = cm(xs, dt)
+    res = {}
+    try:
+        for mode, budget in (("one", 1 << 32), ("chunks", 16 * 46 * 1024 * 8)):  # 16 tiles' worth -> 5 chunks of 2065 samples
+            nf._lib.check(lib.nf_ctx_set_stash_budget(ctx.ptr, budget))
+            res[mode] = [nf.value_and_gradient(nf.elbo_batch, flow, t, x_t) for t in (tgt, banana)]
+    finally:
+        nf._lib.check(lib.nf_ctx_set_stash_budget(ctx.ptr, -1))
+    otgt = ("diaggauss", mu.astype(np.float64), var.astype(np.float64))
+    lo, go = o.neg_elbo_value_and_grad(spec, th, otgt, xs)
+    _, g32 = o.neg_elbo_value_and_grad(spec, P.f32(th), P.f32(otgt), P.f32(xs))
+    P.scalar("supplied draws in chunks: loss", res["chunks"][0][0], lo)
+    P.gradient("supplied draws in chunks: grad", res["chunks"][0][1], go, floor=g32)
+    for (l1, g1), (l2, g2) in zip(res["one"], res["chunks"]):
+        assert l1 == pytest.approx(l2, rel=1e-6)
+        assert float((g1 - g2).abs().max()) <= 1e-5 * float(g1.abs().max())
+
+
+def test_arena_barely_larger_than_the_intermediates_is_refused_not_overlapped(nf):
+    """with an arena that holds an entry point's front intermediates but not the tail carves
+    (packed weight images, nf_elbo_step's buffer) on top, the call must fail with NF_ERR_WORKSPACE -- round 2 carved the
+    tail INTO the live front and corrupted results silently."""
+    spec, th, flow, dt, xs, _, _ = make(nf, "realnvp_d64_h64")
+    d, n = xs.shape
+    lib = nf.load_library()
+    ctx = nf.Context(0, torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(2)
+    tgt = nf.DiagGaussTarget(torch.tensor(rng.standard_normal(d), dtype=dt, device="cuda"),
+                             torch.tensor(rng.uniform(size=d) + 0.5, dtype=dt, device="cuda"))
+    full = int(lib.nf_workspace_bytes(ctx.ptr, C.byref(flow.desc), n))
+    wimg = 8 * 2 * 4 * 8512  # >= the packed images of this flow; exact size is the library's business
+    out = torch.empty(flow.P + 1, dtype=dt, device="cuda")
+
+    def step(arena_bytes):
+        arena = torch.empty(arena_bytes // 4, dtype=torch.float32, device="cuda")
+        nf._lib.check(lib.nf_ctx_set_arena(ctx.ptr, arena.data_ptr(), arena_bytes))
+        st = lib.nf_elbo_value_and_grad(ctx.ptr, C.byref(flow.desc), C.byref(tgt.c), flow.theta.data_ptr(), None, n, n, 7, 0, 0,
+                                        out.data_ptr())
+        torch.cuda.synchronize()
+        nf._lib.check(lib.nf_ctx_set_arena(ctx.ptr, None, 0))
+        return st, out.clone()
+
+    st_ok, ref = step(full)
+    assert st_ok == 0
+    # shrink until the call is refused; every accepted size must give the reference result bit for bit
+    refused = False
+    for cut in range(1, 64):
+        st, got = step(full - cut * (wimg // 16))
+        if st != 0:
+            assert st == -7
+            refused = True
+            break
+        assert torch.equal(got, ref), f"arena of {full - cut * (wimg // 16)} bytes accepted but the result changed"
+    assert refused
+    ctx.close()
