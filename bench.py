@@ -185,6 +185,219 @@ def launch_ranks(n: int) -> int:
     return rc
 
 
+def run_once(args, world, world_observed, rank, dev, dist, damp, state):
+    """One timed run of the selected workload; rank 0 prints one JSON line.  `state` carries the library communicator
+    from one run to the next (cfg 4 prints two lines: bench initialisation and the damped one the parity tests judge)."""
+    nf = load_package()
+    lib = nf.load_library()
+    n_local, n_global = args.batch, args.batch * world
+    if FLOW_KIND == "nsf":
+        flow = nf.nsf(nf.MvNormal(D), HDIMS, 8, 5.0, NLAYERS, paramtype=torch.float32, device=dev, seed=123)
+    else:
+        flow = nf.realnvp(nf.MvNormal(D), HDIMS, NLAYERS, paramtype=torch.float32, device=dev, seed=123)
+    g0 = torch.Generator().manual_seed(123)
+    mu = torch.randn(D, generator=g0).to(dev)
+    var = (torch.rand(D, generator=g0) + 1e-3).to(dev)
+    target = nf.DiagGaussTarget(mu, var)
+    ctx = nf.context_for(dev)
+    P = flow.P
+    theta = flow.theta.clone()
+    m, v = torch.zeros_like(theta), torch.zeros_like(theta)
+    out = torch.zeros(P + 1, dtype=torch.float32, device=dev)
+    gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+    vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    desc, tgt = C.byref(flow.desc), C.byref(target.c)
+
+    if damp is not None:
+        theta.mul_(damp)
+    lib_comm = state.get("lib_comm", False)
+    if dist is not None and args.collective == "nfhip" and os.environ.get("NF_BENCH_ONE_DEVICE") != "1" and not lib_comm:
+        # the library's own RCCL communicator: rank 0's unique id travels through the process group
+        idbuf = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            raw = (C.c_char * 128)()
+            nf._lib.check(lib.nf_comm_get_unique_id(raw))
+            idbuf = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
+        idbuf = idbuf.to(dev)
+        dist.broadcast(idbuf, 0)
+        raw = (C.c_char * 128).from_buffer_copy(idbuf.cpu().numpy().tobytes())
+        nf._lib.check(lib.nf_comm_init_rank(ctx.ptr, raw, world, rank))
+        lib_comm = True
+        state["lib_comm"] = True
+    comm_size = int(lib.nf_comm_size(ctx.ptr))
+    if lib_comm and comm_size != world:
+        raise SystemExit(f"library communicator has {comm_size} ranks, the process group {world}")
+    # nf_elbo_step runs the whole iteration inside the library (for cfg 2 as three launches; with a communicator on the
+    # context the all-reduce is the library's own).  The torch collective and --split-calls keep the separate calls.
+    fused_step = not args.split_calls and (dist is None or lib_comm)
+    use_graph = args.graph and dist is None and args.workload == "cfg2" and fused_step
+    step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
+    stat_dev = torch.zeros(2, dtype=torch.float32, device=dev)
+
+    def step(i: int):
+        if fused_step:
+            nf._lib.check(lib.nf_elbo_step(ctx.ptr, desc, tgt, vp(theta), vp(m), vp(v), n_local, 123, i, 1e-3, 0.9, 0.999, 1e-8,
+                                           None, None))
+            return
+        nf._lib.check(lib.nf_elbo_value_and_grad(ctx.ptr, desc, tgt, vp(theta), None, n_local, n_global, 123,
+                                                 rank * n_local, i, vp(out)))
+        if lib_comm:
+            nf._lib.check(lib.nf_allreduce_grad_loss(ctx.ptr, 0, vp(out), P + 1))
+        elif dist is not None:
+            dist.all_reduce(out)  # one RCCL all-reduce of [grad ; loss] (P + 1 floats)
+        nf._lib.check(lib.nf_adam_update(ctx.ptr, 0, vp(theta), vp(out), vp(m), vp(v), P, 1e-3, 0.9, 0.999, 1e-8,
+                                         i + 1, vp(gnorm)))
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    graph = None
+    if use_graph:
+        # warm-up eagerly through the device-counter form (sizes the workspace, sets kernel attributes, packs the weights),
+        # then capture ONE step and replay it: every launch argument is constant from step to step
+        side = torch.cuda.Stream(dev)
+        gctx = nf.Context(dev.index or 0, side.cuda_stream)
+
+        def enqueue():
+            nf._lib.check(lib.nf_elbo_step_enqueue(gctx.ptr, desc, tgt, vp(theta), vp(m), vp(v), n_local, 123, vp(step_counter),
+                                                   1e-3, 0.9, 0.999, 1e-8, vp(stat_dev)))
+
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for i in range(args.warmup):
+                enqueue()
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            enqueue()
+        _eager_step = step
+
+        def step(i: int):  # noqa: F811
+            graph.replay()
+    else:
+        for i in range(args.warmup):
+            step(i)
+    barrier()
+    if not args.no_kernel_events and not use_graph:
+        # HIP events on the launch stream, over the timed region, around the dominant kernel only
+        # (cfg 2: one launch per step; cfg 4: every 4th of its 32 launches per step)
+        nf._lib.check(lib.nf_prof_enable(ctx.ptr, 3 if args.workload == "cfg4" else 1))
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t0 = time.perf_counter()
+    marks[0].record()
+    for k, i in enumerate(range(args.warmup, args.warmup + args.steps)):
+        step(i)
+        marks[k + 1].record()  # same stream as the library's launches: per-step device time for the median
+    barrier()
+    elapsed = time.perf_counter() - t0
+    step_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    if use_graph:
+        loss, gnorm_v = float(stat_dev[0]), float(stat_dev[1])
+        step = _eager_step  # the per-kernel breakdown below runs eagerly
+        lib.nf_ctx_weights_changed(ctx.ptr)
+    elif fused_step:
+        # one more (untimed) step that reads the stat tuple back: loss and norm(g) of the trained state
+        lh, gh = C.c_double(0.0), C.c_double(0.0)
+        nf._lib.check(lib.nf_elbo_step(ctx.ptr, desc, tgt, vp(theta), vp(m), vp(v), n_local, 123, args.warmup + args.steps, 1e-3, 0.9,
+                                       0.999, 1e-8, C.byref(lh), C.byref(gh)))
+        loss, gnorm_v = lh.value, gh.value
+    else:
+        loss, gnorm_v = float(out[P]), float(gnorm)
+    assert np.isfinite(loss) and np.isfinite(gnorm_v), "non-finite loss / gradient norm"
+
+    avg_ms, cnt = C.c_double(0.0), C.c_int64(0)
+    nf._lib.check(lib.nf_prof_read(ctx.ptr, DOMINANT[0], C.byref(avg_ms), C.byref(cnt)))
+    # per-kernel breakdown: a few extra, UNTIMED steps with every kernel bracketed
+    kernel_ms = {}
+    nbreak = 5
+    nf._lib.check(lib.nf_prof_enable(ctx.ptr, 2))
+    for i in range(nbreak):
+        step(args.warmup + args.steps + 1 + i)
+    torch.cuda.synchronize(dev)
+    for name in KERNEL_NAMES:
+        a, c = C.c_double(0.0), C.c_int64(0)
+        lib.nf_prof_read(ctx.ptr, name, C.byref(a), C.byref(c))
+        if c.value:  # kernels fused away in this configuration are not listed
+            kernel_ms[name.decode()] = {"avg_ms": round(a.value, 5), "launches_per_step": c.value / nbreak}
+    nf._lib.check(lib.nf_prof_enable(ctx.ptr, 0))
+    events_in_timed_region = cnt.value > 0
+    if not events_in_timed_region and DOMINANT[0].decode() in kernel_ms:
+        # graph replay (no event brackets inside a captured graph) or --no-kernel-events: the dominant kernel's duration
+        # comes from the bracketed, untimed steps after the timed region
+        avg_ms = C.c_double(kernel_ms[DOMINANT[0].decode()]["avg_ms"])
+        cnt = C.c_int64(int(kernel_ms[DOMINANT[0].decode()]["launches_per_step"] * nbreak))
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = n_global * args.steps / elapsed
+        couplings_per_launch = COUPLINGS_PER_LAUNCH
+        if couplings_per_launch is None:  # cfg3: 8 couplings over however many launches the library used per step
+            per_step = kernel_ms.get(DOMINANT[0].decode(), {}).get("launches_per_step", 8.0)
+            couplings_per_launch = 2 * NLAYERS / max(per_step, 1.0)
+        flop_per_launch = FLOPS_BWD_PER_SAMPLE_PER_COUPLING * couplings_per_launch * n_local
+        achieved = flop_per_launch / (avg_ms.value * 1e-3) / 1e12 if avg_ms.value > 0 else 0.0
+        traffic, traffic_src = (None, None)
+        if n_local == BATCH and args.workload in ("cfg2", "cfg3"):
+            traffic, traffic_src = pmc_traffic(("k_affine_bwd_stashed" if STASHED else "k_affine_bwd_all") if args.workload == "cfg2" else "k_rqs_bwd")
+        rec = {
+            "metric": "elbo_samples_per_sec",
+            "value": value,
+            "unit": "samples/s",
+            "n_gpus": world_observed,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "ms_per_step_median": step_ms[len(step_ms) // 2],
+            "higher_is_better": True,
+            "scaling": "strong" if args.workload == "cfg4" else "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": WORKLOAD_TEXT,
+                "batch_per_gpu": n_local,
+                "global_batch": n_global,
+                "params": P,
+                "parallelism": f"dp{world_observed} (sample-sharded, one all-reduce of P+1 floats per step"
+                               + (", issued by libnfhip's RCCL communicator)" if lib_comm else ", torch.distributed RCCL)" if dist is not None else ")"),
+                "nf_comm_size": comm_size,
+                "step_form": ("hipGraph replay of nf_elbo_step_enqueue" if use_graph else "nf_elbo_step (whole iteration inside the library)"
+                              if fused_step else "nf_elbo_value_and_grad + nf_adam_update (split calls)"),
+                "init": "Glorot-uniform weights, zero biases (Flux default)" + (f", theta scaled by {damp}" if damp is not None else ""),
+                "final_loss": loss,
+                "final_gradient_norm": gnorm_v,
+            },
+            "roofline": {
+                "kernel": DOMINANT[1],
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                "traffic": traffic,
+                "traffic_unit": "bytes per launch (HBM: 2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC, gfx950 correction)",
+                "traffic_source": traffic_src,
+                "avg_launch_ms": avg_ms.value,
+                "launches_timed": cnt.value,
+                "timed_inside_the_timed_region": events_in_timed_region,
+                "algorithmic_flop_per_launch": flop_per_launch,
+                "whole_step_tflops": FLOPS_STEP_PER_SAMPLE * n_local / (ms_per_step * 1e-3) / 1e12,
+            },
+            "kernels": kernel_ms,
+        }
+        if world == 1 and not args.no_cpu_baseline and args.workload == "cfg2":
+            rec["cpu_baseline"] = cpu_baseline()
+            rec["gpu_over_cpu"] = value / rec["cpu_baseline"]["value"]
+        print(json.dumps(rec))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -194,9 +407,17 @@ def main():
     ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg4"), default="cfg2",
                     help="cfg2 = the headline line (default); cfg3 = NSF d=32 K=8, 131072 per GPU; "
                          "cfg4 = d=256 / 16 couplings / h=256, 262144 samples sharded (strong scaling)")
-    ap.add_argument("--collective", choices=("torch", "nfhip"), default="torch",
-                    help="who issues the one all-reduce per step: torch.distributed's RCCL process group (default) or the "
-                         "library's own RCCL communicator (nf_allreduce_grad_loss, on the context stream)")
+    ap.add_argument("--collective", choices=("torch", "nfhip"), default="nfhip",
+                    help="who issues the one all-reduce per step: the library's own RCCL communicator (nf_allreduce_grad_loss on "
+                         "the context stream, inside nf_elbo_step; default) or torch.distributed's RCCL process group")
+    ap.add_argument("--split-calls", action="store_true",
+                    help="time nf_elbo_value_and_grad + nf_adam_update (six launches per cfg-2 step) instead of nf_elbo_step "
+                         "(three: fused forward, reverse pass, fused epilogue)")
+    ap.add_argument("--graph", action="store_true",
+                    help="1 GPU, cfg2: capture nf_elbo_step_enqueue into a hipGraph once and time K replays")
+    ap.add_argument("--damp", type=float, default=None,
+                    help="scale the Glorot-initialised theta (cfg4: 0.5 is the contraction the parity tests judge; default: both "
+                         "initialisations, two JSON lines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket kernels with HIP events in the timed region (roofline object is then empty)")
@@ -238,151 +459,10 @@ def main():
         select_cfg3(world)
     if args.batch is None:
         args.batch = BATCH
-    nf = load_package()
-    lib = nf.load_library()
-    n_local, n_global = args.batch, args.batch * world
-    if FLOW_KIND == "nsf":
-        flow = nf.nsf(nf.MvNormal(D), HDIMS, 8, 5.0, NLAYERS, paramtype=torch.float32, device=dev, seed=123)
-    else:
-        flow = nf.realnvp(nf.MvNormal(D), HDIMS, NLAYERS, paramtype=torch.float32, device=dev, seed=123)
-    g0 = torch.Generator().manual_seed(123)
-    mu = torch.randn(D, generator=g0).to(dev)
-    var = (torch.rand(D, generator=g0) + 1e-3).to(dev)
-    target = nf.DiagGaussTarget(mu, var)
-    ctx = nf.context_for(dev)
-    P = flow.P
-    theta = flow.theta.clone()
-    m, v = torch.zeros_like(theta), torch.zeros_like(theta)
-    out = torch.zeros(P + 1, dtype=torch.float32, device=dev)
-    gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
-    vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-    desc, tgt = C.byref(flow.desc), C.byref(target.c)
-
-    lib_comm = False
-    if dist is not None and args.collective == "nfhip" and os.environ.get("NF_BENCH_ONE_DEVICE") != "1":
-        # the library's own RCCL communicator: rank 0's unique id travels through the process group
-        idbuf = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            raw = (C.c_char * 128)()
-            nf._lib.check(lib.nf_comm_get_unique_id(raw))
-            idbuf = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
-        idbuf = idbuf.to(dev)
-        dist.broadcast(idbuf, 0)
-        raw = (C.c_char * 128).from_buffer_copy(idbuf.cpu().numpy().tobytes())
-        nf._lib.check(lib.nf_comm_init_rank(ctx.ptr, raw, world, rank))
-        lib_comm = True
-
-    def step(i: int):
-        nf._lib.check(lib.nf_elbo_value_and_grad(ctx.ptr, desc, tgt, vp(theta), None, n_local, n_global, 123,
-                                                 rank * n_local, i, vp(out)))
-        if lib_comm:
-            nf._lib.check(lib.nf_allreduce_grad_loss(ctx.ptr, 0, vp(out), P + 1))
-        elif dist is not None:
-            dist.all_reduce(out)  # one RCCL all-reduce of [grad ; loss] (P + 1 floats)
-        nf._lib.check(lib.nf_adam_update(ctx.ptr, 0, vp(theta), vp(out), vp(m), vp(v), P, 1e-3, 0.9, 0.999, 1e-8,
-                                         i + 1, vp(gnorm)))
-
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    if not args.no_kernel_events:
-        # HIP events on the launch stream, over the timed region, around the dominant kernel only
-        # (cfg 2: one launch per step; cfg 4: every 4th of its 32 launches per step)
-        nf._lib.check(lib.nf_prof_enable(ctx.ptr, 3 if args.workload == "cfg4" else 1))
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    t0 = time.perf_counter()
-    marks[0].record()
-    for k, i in enumerate(range(args.warmup, args.warmup + args.steps)):
-        step(i)
-        marks[k + 1].record()  # same stream as the library's launches: per-step device time for the median
-    barrier()
-    elapsed = time.perf_counter() - t0
-    step_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-    loss = float(out[P])
-    assert np.isfinite(loss) and np.isfinite(float(gnorm)), "non-finite loss / gradient norm"
-
-    avg_ms, cnt = C.c_double(0.0), C.c_int64(0)
-    nf._lib.check(lib.nf_prof_read(ctx.ptr, DOMINANT[0], C.byref(avg_ms), C.byref(cnt)))
-    # per-kernel breakdown: a few extra, UNTIMED steps with every kernel bracketed
-    kernel_ms = {}
-    nbreak = 5
-    nf._lib.check(lib.nf_prof_enable(ctx.ptr, 2))
-    for i in range(nbreak):
-        step(args.warmup + args.steps + i)
-    torch.cuda.synchronize(dev)
-    for name in KERNEL_NAMES:
-        a, c = C.c_double(0.0), C.c_int64(0)
-        lib.nf_prof_read(ctx.ptr, name, C.byref(a), C.byref(c))
-        if c.value:  # kernels fused away in this configuration are not listed
-            kernel_ms[name.decode()] = {"avg_ms": round(a.value, 5), "launches_per_step": c.value / nbreak}
-    nf._lib.check(lib.nf_prof_enable(ctx.ptr, 0))
-
-    if rank == 0:
-        ms_per_step = 1e3 * elapsed / args.steps
-        value = n_global * args.steps / elapsed
-        couplings_per_launch = COUPLINGS_PER_LAUNCH
-        if couplings_per_launch is None:  # cfg3: 8 couplings over however many launches the library used per step
-            per_step = kernel_ms.get(DOMINANT[0].decode(), {}).get("launches_per_step", 8.0)
-            couplings_per_launch = 2 * NLAYERS / max(per_step, 1.0)
-        flop_per_launch = FLOPS_BWD_PER_SAMPLE_PER_COUPLING * couplings_per_launch * n_local
-        achieved = flop_per_launch / (avg_ms.value * 1e-3) / 1e12 if avg_ms.value > 0 else 0.0
-        traffic, traffic_src = (None, None)
-        if n_local == BATCH and args.workload in ("cfg2", "cfg3"):
-            traffic, traffic_src = pmc_traffic(("k_affine_bwd_stashed" if STASHED else "k_affine_bwd_all") if args.workload == "cfg2" else "k_rqs_bwd")
-        rec = {
-            "metric": "elbo_samples_per_sec",
-            "value": value,
-            "unit": "samples/s",
-            "n_gpus": world_observed,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
-            "ms_per_step_median": step_ms[len(step_ms) // 2],
-            "higher_is_better": True,
-            "scaling": "strong" if args.workload == "cfg4" else "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {
-                "workload": WORKLOAD_TEXT,
-                "batch_per_gpu": n_local,
-                "global_batch": n_global,
-                "params": P,
-                "parallelism": f"dp{world_observed} (sample-sharded, one all-reduce of P+1 floats per step"
-                               + (", issued by libnfhip's RCCL communicator)" if lib_comm else ", torch.distributed RCCL)" if dist is not None else ")"),
-                "final_loss": loss,
-            },
-            "roofline": {
-                "kernel": DOMINANT[1],
-                "bound": "mfma",
-                "achieved": achieved,
-                "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                "traffic": traffic,
-                "traffic_unit": "bytes per launch (HBM: 2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC, gfx950 correction)",
-                "traffic_source": traffic_src,
-                "avg_launch_ms": avg_ms.value,
-                "launches_timed": cnt.value,
-                "algorithmic_flop_per_launch": flop_per_launch,
-                "whole_step_tflops": FLOPS_STEP_PER_SAMPLE * n_local / (ms_per_step * 1e-3) / 1e12,
-            },
-            "kernels": kernel_ms,
-        }
-        if world == 1 and not args.no_cpu_baseline and args.workload == "cfg2":
-            rec["cpu_baseline"] = cpu_baseline()
-            rec["gpu_over_cpu"] = value / rec["cpu_baseline"]["value"]
-        print(json.dumps(rec))
+    damps = [args.damp] if args.damp is not None else ([None, 0.5] if args.workload == "cfg4" else [None])
+    state = {}
+    for damp in damps:
+        run_once(args, world, world_observed, rank, dev, dist, damp, state)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

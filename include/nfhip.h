@@ -296,11 +296,31 @@ int nf_adam_update(nf_ctx *ctx, int32_t dtype, void *theta, const void *g, void 
  * is commonly given (src/optimize.jl:67); gnorm_out as in nf_adam_update. */
 int nf_sgd_update(nf_ctx *ctx, int32_t dtype, void *theta, const void *g, void *vel, int64_t P,
                   double lr, double rho, void *gnorm_out);
-/* Single-GPU convenience: nf_elbo_value_and_grad + nf_adam_update in one call; returns the
- * loss and gradient norm of the step (the stat tuple of src/optimize.jl:89). */
+/* One whole iteration of the reference's training loop (src/optimize.jl:85-99: value and gradient of
+ * -elbo_batch(rng, re(theta), logp, n), Optimisers.update! with Adam, norm(g)) in one call; loss_host / gnorm_host
+ * (optional) receive the stat tuple of src/optimize.jl:89 -- asking for them synchronises the stream, passing NULL for
+ * both keeps the call asynchronous ([loss ; norm] of the last step stay readable through a later call that asks).
+ * Philox stream id = `step`, Adam's t = step + 1.  With a communicator on the context (nf_comm_init_rank /
+ * nf_comm_init_all) this is the data-parallel step: N is THIS rank's batch, the rank draws samples
+ * [rank * N, (rank + 1) * N) of a global batch of N * nranks, and the one all-reduce of [grad ; loss] happens inside.
+ * LDS-resident RealNVP flows with a diagonal-Gaussian target (BASELINE cfg 2) run as three launches -- fused forward,
+ * reverse pass, fused epilogue (slab sum, loss, Adam, norm, and the packed weight images of the UPDATED theta for the
+ * next step).  Contract of that cache: between consecutive nf_elbo_step calls on one context with the same theta
+ * pointer, theta is modified by nobody else; a caller that edits theta in place (clipping, re-initialisation) calls
+ * nf_ctx_weights_changed(ctx) first.  Any other library call that packs weights drops the cache by itself. */
 int nf_elbo_step(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, void *theta,
                  void *m, void *v, int64_t N, uint64_t seed, uint32_t step, double lr,
                  double beta1, double beta2, double eps, double *loss_host, double *gnorm_host);
+int nf_ctx_weights_changed(nf_ctx *ctx);
+/* The same step with NO per-step host values, for hipGraph capture and replay: *step_device (uint32, device memory,
+ * caller-owned, initialised to the first step index) supplies the Philox stream id and Adam's t - 1 and is incremented
+ * by the step; out_loss_gnorm_device (optional, 2 elements of the flow's type) receives [loss ; norm(g)].  After one
+ * warm-up call (workspace sizing and kernel attributes are not capturable; use nf_ctx_set_arena or the warm-up's
+ * grow-only allocation), capture a call between hipStreamBeginCapture / hipStreamEndCapture on the context's stream
+ * and replay the graph.  NF_ERR_UNSUPPORTED for flows without the three-launch form. */
+int nf_elbo_step_enqueue(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, void *theta, void *m, void *v,
+                         int64_t N, uint64_t seed, uint32_t *step_device, double lr, double beta1, double beta2,
+                         double eps, void *out_loss_gnorm_device);
 
 /* ---- (e) multi-GPU: the path's one collective ----------------------------------- */
 /* The ELBO is a mean over independent draws (src/objectives/elbo.jl:68,91,96), so ranks take sample shards

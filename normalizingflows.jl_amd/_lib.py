@@ -98,6 +98,8 @@ SYMBOLS = {
     "nf_adam_update": (C.c_int, [_P, _I32, _P, _P, _P, _P, _I64, _D, _D, _D, _D, _I64, _P]),
     "nf_sgd_update": (C.c_int, [_P, _I32, _P, _P, _P, _I64, _D, _D, _P]),
     "nf_elbo_step": (C.c_int, [_P, _DESC, _TGT, _P, _P, _P, _I64, _U64, _U32, _D, _D, _D, _D, _PD, _PD]),
+    "nf_ctx_weights_changed": (C.c_int, [_P]),
+    "nf_elbo_step_enqueue": (C.c_int, [_P, _DESC, _TGT, _P, _P, _P, _I64, _U64, _P, _D, _D, _D, _D, _P]),
     "nf_comm_get_unique_id": (C.c_int, [_P]),
     "nf_comm_init_rank": (C.c_int, [_P, _P, _I32, _I32]),
     "nf_comm_init_all": (C.c_int, [C.POINTER(_P), _I32]),

@@ -42,7 +42,11 @@ int nf_affine_chain(nf_ctx *, const nf_flow_desc *, bool inverse, float *xt, lon
 long nf_affine_chain_grid(nf_ctx *, long N);
 int nf_affine_chain_elbo(nf_ctx *, const nf_flow_desc *, long N, uint64_t seed, uint64_t off, uint32_t stream,
                          const float *mu, const float *var, float *yt, float *gt, double gscale, double *partial,
-                         double pscale, float *stash = nullptr);
+                         double pscale, float *stash = nullptr, const uint32_t *stream_ptr = nullptr);
+long nf_affine_epilogue_blocks(const nf_flow_desc *desc);
+int nf_affine_epilogue(nf_ctx *, const nf_flow_desc *, int mode, const float *slab, int nslab, float *g, const double *lpart,
+                       int nlpart, float *theta, float *m, float *v, double lr, double b1, double b2, double eps, unsigned t_val,
+                       unsigned *t_ptr, double *gpart, unsigned *counter);
 size_t nf_affine_stash_floats(const nf_flow_desc *desc, long N);
 bool nf_affine_stash_pays(const nf_flow_desc *desc);
 int nf_affine_bwd_stashed(nf_ctx *, const nf_flow_desc *, float *stash, float *ybar, const float *lbar, float lbar_const, long N,
@@ -135,6 +139,7 @@ int nf_hf_bwd_inv(nf_ctx *, const nf_flow_desc *, const void *theta, const void 
 // ---- helpers -----------------------------------------------------------------------------
 static size_t ws_need_bound(nf_ctx *ctx, const nf_flow_desc *desc, long N);
 static size_t flow_bwd_need(nf_ctx *ctx, const nf_flow_desc *desc, long N);
+static size_t step_fused_need(nf_ctx *ctx, const nf_flow_desc *desc, long N);
 static size_t vg_composite_need(nf_ctx *ctx, const nf_flow_desc *desc, long N);
 static size_t base_extra_bytes(const nf_flow_desc *desc, long N);
 static inline size_t esize(int dtype) { return dtype == NF_DTYPE_F64 ? 8 : 4; }
@@ -391,24 +396,31 @@ int nf_wimg_reserve(nf_ctx *ctx, size_t bytes) {
   if (ctx->wimg) NF_HIP(hipFree(ctx->wimg));
   ctx->wimg = nullptr;
   ctx->wimg_bytes = 0;
+  ctx->wimg_owner = nullptr;
   NF_HIP(hipMalloc(&ctx->wimg, bytes));
   ctx->wimg_bytes = bytes;
   return NF_OK;
 }
 
+// nf_elbo_step's device buffer: [grad (P) ; loss ; gradient norm] in the flow's element type, then (256-byte aligned) the
+// fused epilogue's completion counter and the device-resident step counter of the graph-replay form.  Zeroed when
+// (re)established: the completion counter must start at 0.
+static inline size_t gbuf_state_off(long P, size_t es) { return carve_bytes((size_t)(P + 2) * es); }
+static inline size_t gbuf_need(long P, size_t es) { return gbuf_state_off(P, es) + 256; }
 static int gbuf_reserve(nf_ctx *ctx, size_t bytes) {
   if (bytes <= ctx->gbuf_bytes) return NF_OK;
   if (ctx->arena) {
     NF_TRY(arena_tail_take(ctx, bytes, &ctx->gbuf));
     ctx->gbuf_bytes = carve_bytes(bytes);
-    return NF_OK;
+  } else {
+    NF_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->gbuf) NF_HIP(hipFree(ctx->gbuf));
+    ctx->gbuf = nullptr;
+    ctx->gbuf_bytes = 0;
+    NF_HIP(hipMalloc(&ctx->gbuf, bytes));
+    ctx->gbuf_bytes = bytes;
   }
-  NF_HIP(hipStreamSynchronize(ctx->stream));
-  if (ctx->gbuf) NF_HIP(hipFree(ctx->gbuf));
-  ctx->gbuf = nullptr;
-  ctx->gbuf_bytes = 0;
-  NF_HIP(hipMalloc(&ctx->gbuf, bytes));
-  ctx->gbuf_bytes = bytes;
+  NF_HIP(hipMemsetAsync(ctx->gbuf, 0, ctx->gbuf_bytes, ctx->stream));
   return NF_OK;
 }
 
@@ -428,6 +440,7 @@ extern "C" int nf_ctx_set_arena(nf_ctx *ctx, void *arena, size_t bytes) {
   ctx->arena_bytes = arena ? (bytes / 256) * 256 : 0;
   ctx->arena_tail = 0;
   ctx->arena_front = 0;
+  ctx->wimg_owner = nullptr;
   return NF_OK;
 }
 
@@ -557,6 +570,7 @@ static inline bool is_wide(const nf_flow_desc *desc) {
   return desc->kind == NF_KIND_REALNVP && !nf_affine_supported(desc) && nf_wide_supported(desc);
 }
 static int coupling_pack(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta) {
+  ctx->wimg_owner = nullptr;  // whatever nf_elbo_step had cached is overwritten
   if (is_wide(desc)) return nf_wide_pack(ctx, desc, theta);
   return is_nsf(desc) ? nf_rqs_pack(ctx, desc, theta) : nf_affine_pack(ctx, desc, theta);
 }
@@ -1880,38 +1894,158 @@ extern "C" int nf_sgd_update(nf_ctx *ctx, int32_t dtype, void *theta, const void
   return NF_OK;
 }
 
+// ---- the fused training step of the LDS-resident RealNVP path -----------------------------------------------------
+// nf_elbo_step for cfg-2-like flows is THREE launches: k_affine_chain<FUSED, STASH> (draws + chain + target + ELBO sums,
+// leaving the activation stash), k_affine_bwd_stashed (reverse pass of every coupling) and k_affine_epilogue (slab sum ->
+// gradient, loss, Adam, ||g||, packed weight images of the UPDATED theta).  The packed images therefore survive from one
+// step to the next: no k_pack_net_images, no separate slab-reduction / Adam / norm launches.  With a communicator on the
+// context (nf_comm_init_*) the step is the data-parallel one: this rank draws samples [rank N, (rank + 1) N) of a global
+// batch of N * nranks, the epilogue splits around ONE all-reduce of [grad ; loss] (P + 1 floats).
+// step_ptr != nullptr: the Philox stream id and Adam's step count come from that device counter, which the epilogue
+// increments -- every launch argument is then the same from step to step, so one call can be captured into a hipGraph
+// and replayed (nf_elbo_step_enqueue).
+static inline unsigned long long flow_sig(const nf_flow_desc *d) {
+  return ((unsigned long long)d->d << 40) ^ ((unsigned long long)d->nlayers << 24) ^ ((unsigned long long)d->hdims[0] << 12) ^
+         (unsigned long long)d->hdims[1] ^ (1ull << 63);
+}
+static bool step_fusable(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, long N) {
+  static const bool off = std::getenv("NF_STEP_UNFUSED") != nullptr;  // A/B switch: the six-launch form
+  if (off || flow_base(desc) || is_composite(desc) || desc->dtype != NF_DTYPE_F32) return false;
+  if (!(desc->kind == NF_KIND_REALNVP && nf_affine_supported(desc))) return false;
+  if (!elbo_fusable(desc, target, nullptr)) return false;
+  return affine_stash_chunk(ctx, desc, N) > 0;
+}
+static size_t step_fused_need(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
+  const size_t te = tiled_elems(desc, N);
+  const long nb = nf_target_tiled_nblocks(N);
+  const long nb_alloc = nb < ctx->num_cu ? ctx->num_cu : nb;
+  const long snc = affine_stash_chunk(ctx, desc, N);
+  return 2 * carve_bytes(te * 4) + carve_bytes((size_t)nb_alloc * 8) +
+         carve_bytes(chunked_slab_floats(ctx, desc, N, snc, coupling_slab_floats(ctx, desc, N)) * 4) +
+         carve_bytes(snc ? affine_stash_bytes(ctx, desc, snc) : 0) + carve_bytes((size_t)nf_affine_epilogue_blocks(desc) * 8);
+}
+static int elbo_step_fused(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, float *theta, float *m, float *v,
+                           long N, uint64_t seed, uint32_t step_val, uint32_t *step_ptr, double lr, double beta1, double beta2,
+                           double eps) {
+  const long P = nf_param_count(desc);
+  const int world = ctx->comm ? ctx->comm_size : 1;
+  const long Ng = N * world;
+  const uint64_t off0 = (uint64_t)(ctx->comm ? ctx->comm_rank : 0) * (uint64_t)N;
+  const double inv = 1.0 / (double)Ng;
+  const size_t te = tiled_elems(desc, N);
+  const long nb = nf_target_tiled_nblocks(N);
+  const long nb_alloc = nb < ctx->num_cu ? ctx->num_cu : nb;
+  const long stash_nc = affine_stash_chunk(ctx, desc, N);
+  const long stride = coupling_slab_floats(ctx, desc, N);
+  const size_t slabf = chunked_slab_floats(ctx, desc, N, stash_nc, stride);
+  const size_t stash_b = affine_stash_bytes(ctx, desc, stash_nc);
+  const long eblocks = nf_affine_epilogue_blocks(desc);
+  NF_TRY(nf_ws_reserve(ctx, step_fused_need(ctx, desc, N)));
+  Carver cv(ctx->ws);
+  float *xt = cv.take<float>(te);
+  float *gt = cv.take<float>(te);
+  double *partial = cv.take<double>(nb_alloc);
+  float *slab = cv.take<float>(slabf);
+  float *stash = cv.take<float>(stash_b / 4);
+  double *gpart = cv.take<double>(eblocks);
+  float *gbuf = (float *)ctx->gbuf;
+  unsigned *counter = (unsigned *)((char *)ctx->gbuf + gbuf_state_off(P, 4));
+  // packed images: those the previous step's epilogue left, or a fresh pack
+  if (!(ctx->wimg && ctx->wimg_owner == (const void *)theta && ctx->wimg_sig == flow_sig(desc))) {
+    NF_TRY(coupling_pack(ctx, desc, theta));
+  }
+  long nslab = 0, npart = 0;
+  for (long o = 0; o < N; o += stash_nc) {
+    const long nc = N - o < stash_nc ? N - o : stash_nc;
+    const int gc = coupling_bwd_grid(ctx, desc, nc);
+    NF_TRY(nf_affine_chain_elbo(ctx, desc, nc, seed, off0 + (uint64_t)o, step_val, (const float *)target->p0, (const float *)target->p1,
+                                xt + o * desc->d, gt + o * desc->d, -inv, partial + npart, -inv, stash, step_ptr));
+    NF_TRY(nf_affine_bwd_stashed(ctx, desc, stash, gt + o * desc->d, nullptr, (float)(-inv), nc, slab + nslab * stride, stride, gc));
+    nslab += gc;
+    npart += nf_affine_chain_grid(ctx, nc);
+  }
+  if (world == 1) {
+    NF_TRY(nf_affine_epilogue(ctx, desc, 3, slab, (int)nslab, gbuf, partial, (int)npart, theta, m, v, lr, beta1, beta2, eps, step_val,
+                              step_ptr, gpart, counter));
+  } else {
+    NF_TRY(nf_affine_epilogue(ctx, desc, 1, slab, (int)nslab, gbuf, partial, (int)npart, nullptr, nullptr, nullptr, lr, beta1, beta2,
+                              eps, step_val, nullptr, gpart, counter));
+    NF_TRY(nf_allreduce_grad_loss(ctx, NF_DTYPE_F32, gbuf, P + 1));
+    NF_TRY(nf_affine_epilogue(ctx, desc, 2, nullptr, 0, gbuf, nullptr, 0, theta, m, v, lr, beta1, beta2, eps, step_val, step_ptr,
+                              gpart, counter));
+  }
+  ctx->wimg_owner = theta;
+  ctx->wimg_sig = flow_sig(desc);
+  return NF_OK;
+}
+
+extern "C" int nf_ctx_weights_changed(nf_ctx *ctx) {
+  if (!ctx) return NF_ERR_ARG;
+  ctx->wimg_owner = nullptr;
+  return NF_OK;
+}
+
+static int step_readback(nf_ctx *ctx, const nf_flow_desc *desc, long P, double *loss_host, double *gnorm_host) {
+  const size_t es = esize(desc->dtype);
+  NF_HIP(hipMemcpyAsync(ctx->host_scratch, (char *)ctx->gbuf + (size_t)P * es, 2 * es, hipMemcpyDeviceToHost, ctx->stream));
+  NF_HIP(hipStreamSynchronize(ctx->stream));
+  double l, gnv;
+  if (desc->dtype == NF_DTYPE_F32) {
+    l = ((float *)ctx->host_scratch)[0];
+    gnv = ((float *)ctx->host_scratch)[1];
+  } else {
+    l = ctx->host_scratch[0];
+    gnv = ctx->host_scratch[1];
+  }
+  if (loss_host) *loss_host = l;
+  if (gnorm_host) *gnorm_host = gnv;
+  // the reference's tests require finite ELBOs (test/flow.jl:58-60); theta has already been updated with the
+  // non-finite gradient, as Optimisers.update! would have done -- the caller decides whether to stop
+  if (!std::isfinite(l) || !std::isfinite(gnv)) return NF_ERR_NONFINITE;
+  return NF_OK;
+}
+
 extern "C" int nf_elbo_step(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, void *theta, void *m,
                             void *v, int64_t N, uint64_t seed, uint32_t step, double lr, double beta1, double beta2,
                             double eps, double *loss_host, double *gnorm_host) {
-  if (!ctx || !theta || !m || !v || N < 1) return NF_ERR_ARG;
+  if (!ctx || !target || !theta || !m || !v || N < 1) return NF_ERR_ARG;
   NF_TRY(check_desc(desc));
   NF_HIP(hipSetDevice(ctx->device));
   const long P = nf_param_count(desc);
   const size_t es = esize(desc->dtype);
-  const size_t gneed = (size_t)(P + 2) * es;
-  NF_TRY(gbuf_reserve(ctx, gneed));
+  NF_TRY(gbuf_reserve(ctx, gbuf_need(P, es)));
   void *gbuf = ctx->gbuf;
-  NF_TRY(nf_elbo_value_and_grad(ctx, desc, target, theta, nullptr, N, N, seed, 0, step, gbuf));
-  char *gnorm_dev = (char *)gbuf + (size_t)(P + 1) * es;
-  NF_TRY(nf_adam_update(ctx, desc->dtype, theta, gbuf, m, v, P, lr, beta1, beta2, eps, (int64_t)step + 1,
-                        (loss_host || gnorm_host) ? gnorm_dev : nullptr));
-  if (loss_host || gnorm_host) {
-    NF_HIP(hipMemcpyAsync(ctx->host_scratch, (char *)gbuf + (size_t)P * es, 2 * es, hipMemcpyDeviceToHost, ctx->stream));
-    NF_HIP(hipStreamSynchronize(ctx->stream));
-    double l, gnv;
-    if (desc->dtype == NF_DTYPE_F32) {
-      l = ((float *)ctx->host_scratch)[0];
-      gnv = ((float *)ctx->host_scratch)[1];
-    } else {
-      l = ctx->host_scratch[0];
-      gnv = ctx->host_scratch[1];
-    }
-    if (loss_host) *loss_host = l;
-    if (gnorm_host) *gnorm_host = gnv;
-    // the reference's tests require finite ELBOs (test/flow.jl:58-60); theta has already been updated with the
-    // non-finite gradient, as Optimisers.update! would have done -- the caller decides whether to stop
-    if (!std::isfinite(l) || !std::isfinite(gnv)) return NF_ERR_NONFINITE;
+  if (step_fusable(ctx, desc, target, N)) {
+    NF_TRY(elbo_step_fused(ctx, desc, target, (float *)theta, (float *)m, (float *)v, N, seed, step, nullptr, lr, beta1, beta2, eps));
+  } else {
+    const int world = ctx->comm ? ctx->comm_size : 1;
+    const uint64_t off = (uint64_t)(ctx->comm ? ctx->comm_rank : 0) * (uint64_t)N;
+    NF_TRY(nf_elbo_value_and_grad(ctx, desc, target, theta, nullptr, N, N * world, seed, off, step, gbuf));
+    if (world > 1) NF_TRY(nf_allreduce_grad_loss(ctx, desc->dtype, gbuf, P + 1));
+    char *gnorm_dev = (char *)gbuf + (size_t)(P + 1) * es;
+    NF_TRY(nf_adam_update(ctx, desc->dtype, theta, gbuf, m, v, P, lr, beta1, beta2, eps, (int64_t)step + 1, gnorm_dev));
   }
+  if (loss_host || gnorm_host) return step_readback(ctx, desc, P, loss_host, gnorm_host);
+  return NF_OK;
+}
+
+// The graph-capturable form: no host-side value changes from step to step.  *step_device (a uint32 in device memory,
+// owned by the caller, initialised to the first step index) is read as the Philox stream id and as Adam's t - 1 and
+// is incremented by the step itself; loss and ||g|| stay on the device (out_loss_gnorm_device[2], optional copy of the
+// step's [loss ; norm]).  Capture ONE call between hipStreamBeginCapture / EndCapture on the context's stream after a
+// warm-up call (the warm-up sizes the workspace and sets kernel attributes -- neither is capturable), then replay.
+extern "C" int nf_elbo_step_enqueue(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, void *theta, void *m, void *v,
+                                    int64_t N, uint64_t seed, uint32_t *step_device, double lr, double beta1, double beta2,
+                                    double eps, void *out_loss_gnorm_device) {
+  if (!ctx || !target || !theta || !m || !v || !step_device || N < 1) return NF_ERR_ARG;
+  NF_TRY(check_desc(desc));
+  NF_HIP(hipSetDevice(ctx->device));
+  const long P = nf_param_count(desc);
+  if (!step_fusable(ctx, desc, target, N)) return NF_ERR_UNSUPPORTED;
+  NF_TRY(gbuf_reserve(ctx, gbuf_need(P, 4)));
+  NF_TRY(elbo_step_fused(ctx, desc, target, (float *)theta, (float *)m, (float *)v, N, seed, 0, step_device, lr, beta1, beta2, eps));
+  if (out_loss_gnorm_device)
+    NF_HIP(hipMemcpyAsync(out_loss_gnorm_device, (char *)ctx->gbuf + (size_t)P * 4, 8, hipMemcpyDeviceToDevice, ctx->stream));
   return NF_OK;
 }
 
@@ -2008,6 +2142,12 @@ extern "C" int64_t nf_workspace_bytes(nf_ctx *ctx, const nf_flow_desc *desc, int
     const size_t f = fkl_general_need(ctx, desc, N);
     if (f > need) need = f;
   }
+  // nf_elbo_step's three-launch form
+  if (desc->kind == NF_KIND_REALNVP && desc->dtype == NF_DTYPE_F32 && !is_composite(desc) && nf_affine_supported(desc) &&
+      affine_stash_chunk(ctx, desc, N) > 0) {
+    const size_t f = step_fused_need(ctx, desc, N);
+    if (f > need) need = f;
+  }
   // nf_adam_update / nf_sgd_update: gradient-norm partials at the tail of the intermediates arena
   need += carve_bytes((size_t)nf_adam_nblocks(P) * 8);
   // packed weight images, nf_elbo_step's [grad ; loss ; norm] buffer
@@ -2023,7 +2163,7 @@ extern "C" int64_t nf_workspace_bytes(nf_ctx *ctx, const nf_flow_desc *desc, int
   } else if (cp) {
     wimg = wimg_of(desc);
   }
-  need += carve_bytes(wimg) + carve_bytes((size_t)(P + 2) * es) + 4096;
+  need += carve_bytes(wimg) + carve_bytes(gbuf_need(P, es)) + 4096;
   return (int64_t)need;
 }
 

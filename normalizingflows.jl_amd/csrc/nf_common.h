@@ -60,6 +60,10 @@ struct nf_ctx {
   // activation-stash budget of the LDS-resident RealNVP training step (nf_ctx_set_stash_budget); -1: the default
   // (NF_AFFINE_STASH_MAX_MB or 4 GiB; 0 with NF_AFFINE_NO_STASH)
   long long stash_budget = -1;
+  // nf_elbo_step keeps the packed images of the theta ITS epilogue wrote: valid while wimg_owner == that theta pointer
+  // and wimg_sig == the flow's signature; every other pack, a reallocation of wimg and nf_ctx_weights_changed reset it
+  const void *wimg_owner = nullptr;
+  unsigned long long wimg_sig = 0;
   // RCCL communicator of this context (nf_comm.hip); null for single-GPU use
   void *comm = nullptr;
   int comm_size = 1, comm_rank = 0;

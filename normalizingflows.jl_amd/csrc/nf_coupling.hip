@@ -270,6 +270,7 @@ __device__ __forceinline__ float coupling_step_stash(const float *__restrict__ i
 // partial sum of pscale * elbo_j are computed from the registers (src/objectives/elbo.jl:65-70,93-97).
 struct FusedArgs {
   uint32_t k0, k1, stream;
+  const uint32_t *stream_ptr;  // non-null: the Philox stream id is read from device memory (hipGraph replay of the step)
   uint64_t off;           // global index of this shard's first sample
   const float *mu, *var;  // diagonal-Gaussian target (test/flow.jl:43-46)
   float *gt;              // ybar out (tiled), or nullptr
@@ -342,6 +343,7 @@ __global__ __launch_bounds__(512) void k_affine_chain(ChainArgs a, float *xt, fl
       // registers (b, 4q..4q+3) of E and O are features base..base+7, base = 64b + 16q + 8hi:
       // Philox groups base/4 (-> E0 O0 E1 O1) and base/4 + 1 (-> E2 O2 E3 O3)
       const uint64_t gj = fa.off + (uint64_t)j;
+      const uint32_t pstream = fa.stream_ptr ? __builtin_amdgcn_readfirstlane(*fa.stream_ptr) : fa.stream;
 #pragma unroll
       for (int b = 0; b < G::CB; ++b)
 #pragma unroll
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(512) void k_affine_chain(ChainArgs a, float *xt, fl
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             const int g = base / 4 + h;
-            U4 c = {(uint32_t)gj, (uint32_t)(gj >> 32), (uint32_t)g, fa.stream};
+            U4 c = {(uint32_t)gj, (uint32_t)(gj >> 32), (uint32_t)g, pstream};
             const U4 rr = philox4x32_10(c, fa.k0, fa.k1);
             float z[4];
             box_muller<float>(rr.x, rr.y, z[0], z[1]);
@@ -1104,6 +1106,8 @@ __global__ __launch_bounds__(256, 1) void k_affine_bwd_stashed(BwdAllArgs aa, fl
 // host-side dispatch
 // ------------------------------------------------------------------------------------
 static inline int blocks32(int n) { return (n + 31) / 32; }
+#define NF_GEO_H32 NetGeo<1, 1, 1, 1>
+#define NF_GEO_H64 NetGeo<1, 2, 2, 1>
 
 static int geo_size(const nf_flow_desc *desc) {
   const int c = (desc->d + 1) / 2;
@@ -1128,6 +1132,36 @@ int nf_affine_reduce_slabs(nf_ctx *ctx, const nf_flow_desc *desc, const float *s
     hipLaunchKernelGGL((k_reduce_image_slabs<NetGeo<1, 1, 1, 1>>), dim3(grid), dim3(64 * NF_REDUCE_WAVES), 0, ctx->stream, p, slab, nslab, total, g, lpart, nlpart, lout);
   else
     hipLaunchKernelGGL((k_reduce_image_slabs<NetGeo<1, 2, 2, 1>>), dim3(grid), dim3(64 * NF_REDUCE_WAVES), 0, ctx->stream, p, slab, nslab, total, g, lpart, nlpart, lout);
+  return (int)hipGetLastError();
+}
+
+// the fused epilogue of nf_elbo_step (nf_pack.h: k_affine_epilogue).  mode: 1 = slabs -> gradient + loss only (multi-GPU,
+// before the all-reduce), 2 = Adam + ||g|| + packed images from a finished gradient (after it), 3 = both (single GPU).
+long nf_affine_epilogue_blocks(const nf_flow_desc *desc) { return ((long)2 * desc->nlayers * 2 * geo_size(desc) + 63) / 64; }
+int nf_affine_epilogue(nf_ctx *ctx, const nf_flow_desc *desc, int mode, const float *slab, int nslab, float *g,
+                       const double *lpart, int nlpart, float *theta, float *m, float *v, double lr, double b1, double b2,
+                       double eps, unsigned t_val, unsigned *t_ptr, double *gpart, unsigned *counter) {
+  const int size = geo_size(desc);
+  if (!size || !ctx->wimg) return NF_ERR_UNSUPPORTED;
+  const PackArgs p = make_pack_args(desc);
+  EpiArgs a;
+  a.slab = slab; a.nslab = nslab; a.slab_stride = (long)p.ncoup * 2 * size;
+  a.g = g; a.P = nf_param_count(desc);
+  a.lpart = lpart; a.nlpart = nlpart;
+  a.theta = theta; a.m = m; a.v = v; a.wimg = (float *)ctx->wimg;
+  a.lr = (float)lr; a.b1 = (float)b1; a.b2 = (float)b2; a.eps = (float)eps; a.b1d = b1; a.b2d = b2;
+  a.t_val = t_val; a.t_ptr = t_ptr; a.gpart = gpart; a.counter = counter;
+  const unsigned grid = (unsigned)nf_affine_epilogue_blocks(desc);
+  ProfScope ps(ctx, mode == 2 ? "adam" : "reduce_slabs");
+  const bool h64 = size != NetGeo<1, 1, 1, 1>::SIZE;
+#define NF_EPI(GEO)                                                                                                          \
+  do {                                                                                                                       \
+    if (mode == 3) hipLaunchKernelGGL((k_affine_epilogue<GEO, true, true, NF_REDUCE_WAVES>), dim3(grid), dim3(64 * NF_REDUCE_WAVES), 0, ctx->stream, p, a); \
+    else if (mode == 1) hipLaunchKernelGGL((k_affine_epilogue<GEO, true, false, NF_REDUCE_WAVES>), dim3(grid), dim3(64 * NF_REDUCE_WAVES), 0, ctx->stream, p, a); \
+    else hipLaunchKernelGGL((k_affine_epilogue<GEO, false, true, 1>), dim3(grid), dim3(64), 0, ctx->stream, p, a);             \
+  } while (0)
+  if (h64) NF_EPI(NF_GEO_H64); else NF_EPI(NF_GEO_H32);
+#undef NF_EPI
   return (int)hipGetLastError();
 }
 
@@ -1283,11 +1317,12 @@ long nf_affine_chain_grid(nf_ctx *ctx, long N) {
 // partial[nf_affine_chain_grid] <- sums of pscale * elbo_j.
 int nf_affine_chain_elbo(nf_ctx *ctx, const nf_flow_desc *desc, long N, uint64_t seed, uint64_t off, uint32_t stream,
                          const float *mu, const float *var, float *yt, float *gt, double gscale, double *partial,
-                         double pscale, float *stash) {
+                         double pscale, float *stash, const uint32_t *stream_ptr) {
   const int size = geo_size(desc);
   if (!size || !ctx->wimg) return NF_ERR_UNSUPPORTED;
   FusedArgs fa;
   fa.stash = stash;
+  fa.stream_ptr = stream_ptr;
   fa.k0 = (uint32_t)seed; fa.k1 = (uint32_t)(seed >> 32); fa.stream = stream; fa.off = off;
   fa.mu = mu; fa.var = var; fa.gt = gt; fa.gscale = (float)gscale; fa.partial = partial; fa.pscale = pscale;
   if (size == NetGeo<1, 1, 1, 1>::SIZE) return launch_chain<NetGeo<1, 1, 1, 1>>(ctx, desc, false, yt, N, nullptr, &fa);

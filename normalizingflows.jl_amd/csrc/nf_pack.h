@@ -93,6 +93,127 @@ __global__ __launch_bounds__(64 * NF_REDUCE_WAVES) void k_reduce_image_slabs(Pac
   }
 }
 
+// ------------------------------------------------------------------------------------
+// fused epilogue of the LDS-resident RealNVP training step (nf_elbo_step)
+// ------------------------------------------------------------------------------------
+// One launch does what k_reduce_image_slabs + k_adam + k_finish_sum + the NEXT step's k_pack_net_images did in four:
+// every thread owns one element of the padded weight images, and the slab sum, the gradient, Adam
+// (Optimisers.update!, src/optimize.jl:99), the gradient-norm partial (src/optimize.jl:89) and the packed image of the
+// UPDATED theta are all element-wise in that index.  ||g|| is finished by the last block to arrive (completion
+// counter; partials summed in block order, so the result does not depend on which block that is).
+//   REDUCE: g <- sum of slabs (else g is read: the multi-GPU form, after the all-reduce of [grad ; loss])
+//   ADAM:   theta / m / v / wimg updated, g[P + 1] <- ||g||
+// Adam's step count t = step + 1 comes from a.t_val or, for hipGraph replay, from the device counter a.t_ptr, which
+// the last block increments.
+struct EpiArgs {
+  const float *slab;
+  int nslab;
+  long slab_stride;
+  float *g;             // [P + 2]: gradient, loss, gradient norm
+  long P;
+  const double *lpart;  // loss partials of the forward launch (REDUCE), finished into g[P]
+  int nlpart;
+  float *theta, *m, *v, *wimg;
+  float lr, b1, b2, eps;
+  double b1d, b2d;
+  unsigned t_val;
+  unsigned *t_ptr;
+  double *gpart;        // [gridDim.x]
+  unsigned *counter;    // zero on entry; reset by the last block
+};
+
+template <class G, bool REDUCE, bool ADAM, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_affine_epilogue(PackArgs p, EpiArgs a) {
+  if (REDUCE && a.lpart && blockIdx.x == 0) {
+    __shared__ double sm[WAVES];
+    double c = 0.0;
+    for (int i = threadIdx.x; i < a.nlpart; i += 64 * WAVES) c += a.lpart[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+      for (int w = 0; w < WAVES; ++w) t += sm[w];
+      a.g[a.P] = (float)t;
+    }
+  }
+  __shared__ float part[WAVES][64];
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const long gid = (long)blockIdx.x * 64 + lane;
+  const long total = (long)p.ncoup * 2 * G::SIZE;
+  long ti = -1;
+  if (gid < total) {
+    const int img = (int)(gid / G::SIZE), e = (int)(gid - (long)img * G::SIZE);
+    const int k = img >> 1, net = img & 1;
+    const int c = (k & 1) ? p.d / 2 : (p.d + 1) / 2, m = p.d - c;
+    long off = (long)(k >> 1) * p.pair_params + ((k & 1) ? p.odd_params : 0);
+    if (net) off += net_param_count(m, p.h1, p.h2, c);
+    const NetDims nd = make_net_dims(off, m, p.h1, p.h2, c);
+    ti = e < G::B3 + 32 * G::CB ? image_theta_index<G>(nd, e) : -1;
+  }
+  float gsum = 0.f;
+  if (REDUCE) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (ti >= 0) {  // wave q sums slabs q, q + W, q + 2 W, ... (the order of k_reduce_image_slabs)
+      constexpr int W = WAVES;
+      int s = q;
+      for (; s + 3 * W < a.nslab; s += 4 * W) {
+        a0 += a.slab[(long)s * a.slab_stride + gid];
+        a1 += a.slab[(long)(s + W) * a.slab_stride + gid];
+        a2 += a.slab[(long)(s + 2 * W) * a.slab_stride + gid];
+        a3 += a.slab[(long)(s + 3 * W) * a.slab_stride + gid];
+      }
+      for (; s < a.nslab; s += W) a0 += a.slab[(long)s * a.slab_stride + gid];
+    }
+    part[q][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (q == 0) {
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) gsum += part[w][lane];
+    }
+  } else if (q == 0 && ti >= 0) {
+    gsum = a.g[ti];
+  }
+  if (q != 0) return;
+  double gg = 0.0;
+  if (ti >= 0) {
+    if (REDUCE) a.g[ti] = gsum;
+    if (ADAM) {
+      const unsigned t = (a.t_ptr ? *a.t_ptr : a.t_val) + 1u;
+      const float c1 = (float)(1.0 - pow(a.b1d, (double)t)), c2 = (float)(1.0 - pow(a.b2d, (double)t));
+      const float mi = a.b1 * a.m[ti] + (1.f - a.b1) * gsum;
+      const float vi = a.b2 * a.v[ti] + (1.f - a.b2) * gsum * gsum;
+      a.m[ti] = mi;
+      a.v[ti] = vi;
+      const float th = a.theta[ti] - a.lr * (mi / c1) / (sqrtf(vi / c2) + a.eps);
+      a.theta[ti] = th;
+      a.wimg[gid] = th;  // padding elements of the image stay zero from the first pack
+      gg = (double)gsum * (double)gsum;
+    }
+  }
+  if (!ADAM) return;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) gg += __shfl_xor(gg, o, 64);
+  unsigned done = 0;
+  if (lane == 0) {
+    __hip_atomic_store(&a.gpart[blockIdx.x], gg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    done = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  done = __shfl(done, 0, 64);
+  if (done == gridDim.x - 1) {  // the last block to arrive: lane l sums partials l, l + 64, ... (fixed order), then the wave
+    double tot = 0.0;
+    for (unsigned b = lane; b < gridDim.x; b += 64) tot += __hip_atomic_load(&a.gpart[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+    if (lane == 0) {
+      a.g[a.P + 1] = (float)sqrt(tot);
+      __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a.t_ptr) *a.t_ptr = *a.t_ptr + 1u;
+    }
+  }
+}
+
 static inline PackArgs make_pack_args(const nf_flow_desc *desc) {
   PackArgs p;
   p.d = desc->d; p.h1 = desc->hdims[0]; p.h2 = desc->hdims[1]; p.ncoup = 2 * desc->nlayers;

@@ -260,3 +260,98 @@ def test_arena_barely_larger_than_the_intermediates_is_refused_not_overlapped(nf
         assert torch.equal(got, ref), f"arena of {full - cut * (wimg // 16)} bytes accepted but the result changed"
     assert refused
     ctx.close()
+
+
+def _split_reference_steps(nf, flow, tgt, n, seed, nsteps, ctx):
+    """nsteps of nf_elbo_value_and_grad + nf_adam_update (the six-launch form) on a private context."""
+    lib = nf.load_library()
+    vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    th, m, v = flow.theta.clone(), torch.zeros_like(flow.theta), torch.zeros_like(flow.theta)
+    out, gn = torch.empty(flow.P + 1, device="cuda"), torch.empty(1, device="cuda")
+    stats = []
+    for step in range(nsteps):
+        nf._lib.check(lib.nf_elbo_value_and_grad(ctx.ptr, C.byref(flow.desc), C.byref(tgt.c), vp(th), None, n, n, seed, 0, step, vp(out)))
+        nf._lib.check(lib.nf_adam_update(ctx.ptr, 0, vp(th), vp(out), vp(m), vp(v), flow.P, 1e-3, 0.9, 0.999, 1e-8, step + 1, vp(gn)))
+        stats.append((float(out[flow.P]), float(gn)))
+    return th, m, v, stats
+
+
+@pytest.mark.parametrize("shape", ["d64_h64", "d20_h32"])
+def test_three_launch_step_equals_split_calls_over_consecutive_steps(nf, shape):
+    """nf_elbo_step on an LDS-resident RealNVP flow = fused forward + reverse pass + fused epilogue, the packed weight
+    images carried from step to step.  Five consecutive steps (so steps 2..5 run on images written by the previous
+    epilogue, never re-packed) against nf_elbo_value_and_grad + nf_adam_update on another context: theta, m, v bit for
+    bit, loss and norm(g) to float rounding.  Then nf_ctx_weights_changed after an in-place edit of theta."""
+    d, hd, nl, n = {"d64_h64": (64, (64, 64), 4, 4096 + 5), "d20_h32": (20, (32, 32), 2, 777)}[shape]
+    flow = nf.realnvp(nf.MvNormal(d), hd, nl, paramtype=torch.float32, seed=3)
+    rng = np.random.default_rng(0)
+    tgt = nf.DiagGaussTarget(torch.tensor(rng.standard_normal(d), dtype=torch.float32, device="cuda"),
+                             torch.tensor(rng.uniform(size=d) + 0.5, dtype=torch.float32, device="cuda"))
+    lib = nf.load_library()
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx_a, ctx_b = nf.Context(0, stream), nf.Context(0, stream)
+    vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    th_b, m_b, v_b, stats_b = _split_reference_steps(nf, flow, tgt, n, 77, 5, ctx_b)
+    th, m, v = flow.theta.clone(), torch.zeros_like(flow.theta), torch.zeros_like(flow.theta)
+    for step in range(5):
+        loss, gnorm = C.c_double(0), C.c_double(0)
+        want = step in (0, 4)  # steps 1..3 fully asynchronous (no host readback)
+        nf._lib.check(lib.nf_elbo_step(ctx_a.ptr, C.byref(flow.desc), C.byref(tgt.c), vp(th), vp(m), vp(v), n, 77, step, 1e-3, 0.9, 0.999,
+                                       1e-8, C.byref(loss) if want else None, C.byref(gnorm) if want else None))
+        if want:
+            assert loss.value == pytest.approx(stats_b[step][0], rel=1e-6)
+            assert gnorm.value == pytest.approx(stats_b[step][1], rel=1e-6)
+    torch.cuda.synchronize()
+    assert torch.equal(th, th_b) and torch.equal(m, m_b) and torch.equal(v, v_b)
+    # an in-place edit of theta between steps: declared with nf_ctx_weights_changed, the next step uses the edited weights
+    th.mul_(0.5)
+    nf._lib.check(lib.nf_ctx_weights_changed(ctx_a.ptr))
+    nf._lib.check(lib.nf_elbo_step(ctx_a.ptr, C.byref(flow.desc), C.byref(tgt.c), vp(th), vp(m), vp(v), n, 77, 5, 1e-3, 0.9, 0.999, 1e-8, None, None))
+    th_c, m_c, v_c = th_b * 0.5, m_b.clone(), v_b.clone()
+    out, gn = torch.empty(flow.P + 1, device="cuda"), torch.empty(1, device="cuda")
+    nf._lib.check(lib.nf_elbo_value_and_grad(ctx_b.ptr, C.byref(flow.desc), C.byref(tgt.c), vp(th_c), None, n, n, 77, 0, 5, vp(out)))
+    nf._lib.check(lib.nf_adam_update(ctx_b.ptr, 0, vp(th_c), vp(out), vp(m_c), vp(v_c), flow.P, 1e-3, 0.9, 0.999, 1e-8, 6, vp(gn)))
+    torch.cuda.synchronize()
+    assert torch.equal(th, th_c)
+    ctx_a.close()
+    ctx_b.close()
+
+
+def test_step_with_device_counter_replays_as_a_graph(nf):
+    """nf_elbo_step_enqueue: the step whose Philox stream id and Adam step count live in a device counter, captured once
+    into a hipGraph (torch.cuda.CUDAGraph on the context's stream) and replayed: same theta as the eager split calls."""
+    d, n = 64, 4096
+    flow = nf.realnvp(nf.MvNormal(d), (64, 64), 4, paramtype=torch.float32, seed=3)
+    rng = np.random.default_rng(0)
+    tgt = nf.DiagGaussTarget(torch.tensor(rng.standard_normal(d), dtype=torch.float32, device="cuda"),
+                             torch.tensor(rng.uniform(size=d) + 0.5, dtype=torch.float32, device="cuda"))
+    lib = nf.load_library()
+    vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    ctx_b = nf.Context(0, torch.cuda.current_stream().cuda_stream)
+    th_b, m_b, v_b, stats_b = _split_reference_steps(nf, flow, tgt, n, 5, 6, ctx_b)
+    th, m, v = flow.theta.clone(), torch.zeros_like(flow.theta), torch.zeros_like(flow.theta)
+    counter = torch.zeros(1, dtype=torch.int32, device="cuda")
+    stat = torch.zeros(2, dtype=torch.float32, device="cuda")
+    side = torch.cuda.Stream()
+    ctx_a = nf.Context(0, side.cuda_stream)
+
+    def enqueue():
+        nf._lib.check(lib.nf_elbo_step_enqueue(ctx_a.ptr, C.byref(flow.desc), C.byref(tgt.c), vp(th), vp(m), vp(v), n, 5, vp(counter),
+                                               1e-3, 0.9, 0.999, 1e-8, vp(stat)))
+
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        enqueue()  # step 0, eager: sizes the workspace, sets kernel attributes, packs the weights
+    side.synchronize()
+    assert int(counter[0]) == 1
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        enqueue()  # captured, not executed
+    for _ in range(5):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert int(counter[0]) == 6
+    assert torch.equal(th, th_b) and torch.equal(m, m_b)
+    assert float(stat[0]) == pytest.approx(stats_b[5][0], rel=1e-6) and float(stat[1]) == pytest.approx(stats_b[5][1], rel=1e-6)
+    ctx_a.close()
+    ctx_b.close()
