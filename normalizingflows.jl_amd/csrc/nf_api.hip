@@ -19,7 +19,7 @@ int nf_launch_target(nf_ctx *, int, const nf_target *, int, long, const void *, 
                      void *, double, void *, double *, double, int joint_d);
 long nf_sum2_nblocks(long N);
 int nf_launch_sum2(nf_ctx *, int, long, const void *, const void *, void *, double *, double);
-int nf_launch_finish_sum(nf_ctx *, const double *, long, int, double *, float *, double *);
+int nf_launch_finish_sum(nf_ctx *, const double *, long, int, double *, float *, double *, unsigned *bump = nullptr);
 int nf_launch_reduce_slabs(nf_ctx *, int, const void *, int, long, void *);
 long nf_adam_nblocks(long P);
 int nf_launch_adam(nf_ctx *, int, void *, const void *, void *, void *, long, double, double, double, double, long,
@@ -46,7 +46,7 @@ int nf_affine_chain_elbo(nf_ctx *, const nf_flow_desc *, long N, uint64_t seed, 
 long nf_affine_epilogue_blocks(const nf_flow_desc *desc);
 int nf_affine_epilogue(nf_ctx *, const nf_flow_desc *, int mode, const float *slab, int nslab, float *g, const double *lpart,
                        int nlpart, float *theta, float *m, float *v, double lr, double b1, double b2, double eps, unsigned t_val,
-                       unsigned *t_ptr, double *gpart, unsigned *counter);
+                       unsigned *t_ptr, double *gpart);
 size_t nf_affine_stash_floats(const nf_flow_desc *desc, long N);
 bool nf_affine_stash_pays(const nf_flow_desc *desc);
 int nf_affine_bwd_stashed(nf_ctx *, const nf_flow_desc *, float *stash, float *ybar, const float *lbar, float lbar_const, long N,
@@ -1895,10 +1895,10 @@ extern "C" int nf_sgd_update(nf_ctx *ctx, int32_t dtype, void *theta, const void
 }
 
 // ---- the fused training step of the LDS-resident RealNVP path -----------------------------------------------------
-// nf_elbo_step for cfg-2-like flows is THREE launches: k_affine_chain<FUSED, STASH> (draws + chain + target + ELBO sums,
-// leaving the activation stash), k_affine_bwd_stashed (reverse pass of every coupling) and k_affine_epilogue (slab sum ->
-// gradient, loss, Adam, ||g||, packed weight images of the UPDATED theta).  The packed images therefore survive from one
-// step to the next: no k_pack_net_images, no separate slab-reduction / Adam / norm launches.  With a communicator on the
+// nf_elbo_step for cfg-2-like flows is three launches plus a one-block finish: k_affine_chain<FUSED, STASH> (draws + chain +
+// target + ELBO sums, leaving the activation stash), k_affine_bwd_stashed (reverse pass of every coupling), k_affine_epilogue
+// (slab sum -> gradient, loss, Adam, partials of ||g||^2, packed weight images of the UPDATED theta) and k_finish_sum (||g||).
+// The packed images survive from one step to the next: no k_pack_net_images, no separate slab-reduction / Adam launches.  With a communicator on the
 // context (nf_comm_init_*) the step is the data-parallel one: this rank draws samples [rank N, (rank + 1) N) of a global
 // batch of N * nranks, the epilogue splits around ONE all-reduce of [grad ; loss] (P + 1 floats).
 // step_ptr != nullptr: the Philox stream id and Adam's step count come from that device counter, which the epilogue
@@ -1949,9 +1949,9 @@ static int elbo_step_fused(nf_ctx *ctx, const nf_flow_desc *desc, const nf_targe
   float *stash = cv.take<float>(stash_b / 4);
   double *gpart = cv.take<double>(eblocks);
   float *gbuf = (float *)ctx->gbuf;
-  unsigned *counter = (unsigned *)((char *)ctx->gbuf + gbuf_state_off(P, 4));
   // packed images: those the previous step's epilogue left, or a fresh pack
-  if (!(ctx->wimg && ctx->wimg_owner == (const void *)theta && ctx->wimg_sig == flow_sig(desc))) {
+  static const bool repack = std::getenv("NF_STEP_REPACK") != nullptr;  // A/B switch: pack every step
+  if (repack || !(ctx->wimg && ctx->wimg_owner == (const void *)theta && ctx->wimg_sig == flow_sig(desc))) {
     NF_TRY(coupling_pack(ctx, desc, theta));
   }
   long nslab = 0, npart = 0;
@@ -1966,14 +1966,16 @@ static int elbo_step_fused(nf_ctx *ctx, const nf_flow_desc *desc, const nf_targe
   }
   if (world == 1) {
     NF_TRY(nf_affine_epilogue(ctx, desc, 3, slab, (int)nslab, gbuf, partial, (int)npart, theta, m, v, lr, beta1, beta2, eps, step_val,
-                              step_ptr, gpart, counter));
+                              step_ptr, gpart));
   } else {
     NF_TRY(nf_affine_epilogue(ctx, desc, 1, slab, (int)nslab, gbuf, partial, (int)npart, nullptr, nullptr, nullptr, lr, beta1, beta2,
-                              eps, step_val, nullptr, gpart, counter));
+                              eps, step_val, nullptr, gpart));
     NF_TRY(nf_allreduce_grad_loss(ctx, NF_DTYPE_F32, gbuf, P + 1));
     NF_TRY(nf_affine_epilogue(ctx, desc, 2, nullptr, 0, gbuf, nullptr, 0, theta, m, v, lr, beta1, beta2, eps, step_val, step_ptr,
-                              gpart, counter));
+                              gpart));
   }
+  // norm(g) = sqrt of the epilogue's block partials (and, in the graph-replay form, the step counter's increment)
+  NF_TRY(nf_launch_finish_sum(ctx, gpart, eblocks, 1, nullptr, gbuf + P + 1, nullptr, step_ptr));
   ctx->wimg_owner = theta;
   ctx->wimg_sig = flow_sig(desc);
   return NF_OK;

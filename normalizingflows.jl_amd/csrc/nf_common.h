@@ -129,6 +129,19 @@ struct AttrOnce {
   }
 };
 
+// Optimisers.Adam (Optimisers.jl 0.4 `apply!`, reached from src/optimize.jl:99) for ONE parameter: shared by k_adam and the
+// fused step epilogue so that both produce the same bits (contraction off: the compiler may otherwise fuse b1 m + (1 - b1) g
+// differently at the two call sites).  c1 = 1 - b1^t, c2 = 1 - b2^t.
+template <class T>
+__device__ __forceinline__ void nf_adam_elem(T &theta, T &m, T &v, T g, T lr, T b1, T b2, T eps, T c1, T c2) {
+#pragma clang fp contract(off)
+  const T mi = b1 * m + ((T)1 - b1) * g;
+  const T vi = b2 * v + ((T)1 - b2) * g * g;
+  m = mi;
+  v = vi;
+  theta = theta - lr * (mi / c1) / (sqrt(vi / c2) + eps);
+}
+
 // layer bookkeeping shared by host code --------------------------------------------
 struct CouplingInfo {
   long theta_off;   // offset of this coupling's parameters in theta

@@ -9,6 +9,9 @@
 //
 // Work decomposition: one wavefront = one tile of 32 samples, activations chained through
 // the fp32 matrix pipe in registers (nf_mfma.h); weights of the coupling live in LDS.
+#include <cmath>
+#include <cstdlib>
+
 #include "nf_common.h"
 #include "nf_mfma.h"
 #include "nf_pack.h"
@@ -1140,7 +1143,7 @@ int nf_affine_reduce_slabs(nf_ctx *ctx, const nf_flow_desc *desc, const float *s
 long nf_affine_epilogue_blocks(const nf_flow_desc *desc) { return ((long)2 * desc->nlayers * 2 * geo_size(desc) + 63) / 64; }
 int nf_affine_epilogue(nf_ctx *ctx, const nf_flow_desc *desc, int mode, const float *slab, int nslab, float *g,
                        const double *lpart, int nlpart, float *theta, float *m, float *v, double lr, double b1, double b2,
-                       double eps, unsigned t_val, unsigned *t_ptr, double *gpart, unsigned *counter) {
+                       double eps, unsigned t_val, unsigned *t_ptr, double *gpart) {
   const int size = geo_size(desc);
   if (!size || !ctx->wimg) return NF_ERR_UNSUPPORTED;
   const PackArgs p = make_pack_args(desc);
@@ -1150,7 +1153,9 @@ int nf_affine_epilogue(nf_ctx *ctx, const nf_flow_desc *desc, int mode, const fl
   a.lpart = lpart; a.nlpart = nlpart;
   a.theta = theta; a.m = m; a.v = v; a.wimg = (float *)ctx->wimg;
   a.lr = (float)lr; a.b1 = (float)b1; a.b2 = (float)b2; a.eps = (float)eps; a.b1d = b1; a.b2d = b2;
-  a.t_val = t_val; a.t_ptr = t_ptr; a.gpart = gpart; a.counter = counter;
+  a.t_val = t_val; a.t_ptr = t_ptr; a.gpart = gpart;
+  a.c1 = (float)(1.0 - pow(b1, (double)t_val + 1.0));
+  a.c2 = (float)(1.0 - pow(b2, (double)t_val + 1.0));
   const unsigned grid = (unsigned)nf_affine_epilogue_blocks(desc);
   ProfScope ps(ctx, mode == 2 ? "adam" : "reduce_slabs");
   const bool h64 = size != NetGeo<1, 1, 1, 1>::SIZE;

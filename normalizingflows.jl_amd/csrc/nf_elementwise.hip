@@ -320,7 +320,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_sum2(long N, const T *__restrict__
 // dst_d (double*) and/or dst_f (float*, element `idx`) receive the result.
 __global__ __launch_bounds__(EW_BLOCK) void k_finish_sum(const double *__restrict__ partial, long n, int take_sqrt,
                                                          double *__restrict__ dst_d, float *__restrict__ dst_f,
-                                                         double *__restrict__ dst_d2) {
+                                                         double *__restrict__ dst_d2, unsigned *__restrict__ bump) {
   __shared__ double sm[EW_BLOCK / 64];
   double c = 0.0;
   for (long i = threadIdx.x; i < n; i += EW_BLOCK) c += partial[i];
@@ -330,6 +330,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_finish_sum(const double *__restric
     if (dst_d) *dst_d = s;
     if (dst_f) *dst_f = (float)s;
     if (dst_d2) *dst_d2 = s;
+    if (bump) *bump = *bump + 1u;  // the device-resident step counter of nf_elbo_step_enqueue
   }
 }
 
@@ -366,11 +367,11 @@ __global__ __launch_bounds__(EW_BLOCK) void k_adam(T *__restrict__ theta, const 
   double gg = 0.0;
   if (p < P) {
     const T gi = g[p];
-    const T mi = b1 * m[p] + ((T)1 - b1) * gi;
-    const T vi = b2 * v[p] + ((T)1 - b2) * gi * gi;
+    T th = theta[p], mi = m[p], vi = v[p];
+    nf_adam_elem<T>(th, mi, vi, gi, lr, b1, b2, eps, c1, c2);
     m[p] = mi;
     v[p] = vi;
-    theta[p] -= lr * (mi / c1) / (sqrt(vi / c2) + eps);
+    theta[p] = th;
     gg = (double)gi * (double)gi;
   }
   if (partial) {
@@ -658,8 +659,8 @@ int nf_launch_sum2(nf_ctx *ctx, int dtype, long N, const void *a, const void *b,
 }
 
 int nf_launch_finish_sum(nf_ctx *ctx, const double *partial, long n, int take_sqrt, double *dst_d, float *dst_f,
-                         double *dst_d2) {
-  hipLaunchKernelGGL(k_finish_sum, dim3(1), dim3(EW_BLOCK), 0, ctx->stream, partial, n, take_sqrt, dst_d, dst_f, dst_d2);
+                         double *dst_d2, unsigned *bump) {
+  hipLaunchKernelGGL(k_finish_sum, dim3(1), dim3(EW_BLOCK), 0, ctx->stream, partial, n, take_sqrt, dst_d, dst_f, dst_d2, bump);
   return (int)hipGetLastError();
 }
 

@@ -99,12 +99,11 @@ __global__ __launch_bounds__(64 * NF_REDUCE_WAVES) void k_reduce_image_slabs(Pac
 // One launch does what k_reduce_image_slabs + k_adam + k_finish_sum + the NEXT step's k_pack_net_images did in four:
 // every thread owns one element of the padded weight images, and the slab sum, the gradient, Adam
 // (Optimisers.update!, src/optimize.jl:99), the gradient-norm partial (src/optimize.jl:89) and the packed image of the
-// UPDATED theta are all element-wise in that index.  ||g|| is finished by the last block to arrive (completion
-// counter; partials summed in block order, so the result does not depend on which block that is).
+// UPDATED theta are all element-wise in that index; the blocks' partial sums of g^2 are finished by k_finish_sum.
 //   REDUCE: g <- sum of slabs (else g is read: the multi-GPU form, after the all-reduce of [grad ; loss])
 //   ADAM:   theta / m / v / wimg updated, g[P + 1] <- ||g||
-// Adam's step count t = step + 1 comes from a.t_val or, for hipGraph replay, from the device counter a.t_ptr, which
-// the last block increments.
+// Adam's step count t = step + 1 comes from a.t_val or, for hipGraph replay, from the device counter a.t_ptr (incremented
+// by the finishing launch, after every block of this one has read it).
 struct EpiArgs {
   const float *slab;
   int nslab;
@@ -116,10 +115,10 @@ struct EpiArgs {
   float *theta, *m, *v, *wimg;
   float lr, b1, b2, eps;
   double b1d, b2d;
+  float c1, c2;  // 1 - b1^t, 1 - b2^t for t = t_val + 1, computed on the host as nf_launch_adam does (t_ptr == nullptr)
   unsigned t_val;
   unsigned *t_ptr;
-  double *gpart;        // [gridDim.x]
-  unsigned *counter;    // zero on entry; reset by the last block
+  double *gpart;        // [gridDim.x] partial sums of g^2 (ADAM)
 };
 
 template <class G, bool REDUCE, bool ADAM, int WAVES>
@@ -152,6 +151,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_affine_epilogue(PackArgs p, EpiA
     const NetDims nd = make_net_dims(off, m, p.h1, p.h2, c);
     ti = e < G::B3 + 32 * G::CB ? image_theta_index<G>(nd, e) : -1;
   }
+  // Adam's operands are requested before the slab stream so that their latency hides behind it
+  float th = 0.f, mi = 0.f, vi = 0.f;
+  if (ADAM && q == 0 && ti >= 0) {
+    th = a.theta[ti];
+    mi = a.m[ti];
+    vi = a.v[ti];
+  }
   float gsum = 0.f;
   if (REDUCE) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -180,38 +186,27 @@ __global__ __launch_bounds__(64 * WAVES) void k_affine_epilogue(PackArgs p, EpiA
   if (ti >= 0) {
     if (REDUCE) a.g[ti] = gsum;
     if (ADAM) {
-      const unsigned t = (a.t_ptr ? *a.t_ptr : a.t_val) + 1u;
-      const float c1 = (float)(1.0 - pow(a.b1d, (double)t)), c2 = (float)(1.0 - pow(a.b2d, (double)t));
-      const float mi = a.b1 * a.m[ti] + (1.f - a.b1) * gsum;
-      const float vi = a.b2 * a.v[ti] + (1.f - a.b2) * gsum * gsum;
+      float c1 = a.c1, c2 = a.c2;
+      if (a.t_ptr) {  // graph replay: the step count lives on the device
+        const double t = (double)(*a.t_ptr + 1u);
+        c1 = (float)(1.0 - pow(a.b1d, t));
+        c2 = (float)(1.0 - pow(a.b2d, t));
+      }
+      nf_adam_elem<float>(th, mi, vi, gsum, a.lr, a.b1, a.b2, a.eps, c1, c2);
       a.m[ti] = mi;
       a.v[ti] = vi;
-      const float th = a.theta[ti] - a.lr * (mi / c1) / (sqrtf(vi / c2) + a.eps);
       a.theta[ti] = th;
       a.wimg[gid] = th;  // padding elements of the image stay zero from the first pack
       gg = (double)gsum * (double)gsum;
     }
   }
   if (!ADAM) return;
+  // norm(g): this block's partial of sum g^2; k_finish_sum (the step's last, one-block launch) adds the partials in
+  // block order and takes the root.  (A completion counter inside this kernel -- last block finishes -- was measured:
+  // 2 128 agent-scope atomics cost 12.5 us, acquire / release fences 65 us; the separate launch costs 4.)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) gg += __shfl_xor(gg, o, 64);
-  unsigned done = 0;
-  if (lane == 0) {
-    __hip_atomic_store(&a.gpart[blockIdx.x], gg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    done = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  done = __shfl(done, 0, 64);
-  if (done == gridDim.x - 1) {  // the last block to arrive: lane l sums partials l, l + 64, ... (fixed order), then the wave
-    double tot = 0.0;
-    for (unsigned b = lane; b < gridDim.x; b += 64) tot += __hip_atomic_load(&a.gpart[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
-    if (lane == 0) {
-      a.g[a.P + 1] = (float)sqrt(tot);
-      __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (a.t_ptr) *a.t_ptr = *a.t_ptr + 1u;
-    }
-  }
+  if (lane == 0) a.gpart[blockIdx.x] = gg;
 }
 
 static inline PackArgs make_pack_args(const nf_flow_desc *desc) {
