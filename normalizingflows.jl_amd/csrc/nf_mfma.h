@@ -40,6 +40,9 @@ __device__ __forceinline__ float nf_lrelu(float z) { return fmaxf(z, 0.01f * z);
 __device__ __forceinline__ float nf_fdiv(float x, float y) { return x * __builtin_amdgcn_rcpf(y); }
 
 __device__ __forceinline__ float nf_tanh(float x) {
+#ifdef NF_TANH_ACCURATE
+  return tanhf(x);
+#endif
   const float xc = fminf(fmaxf(x, -10.f), 10.f);
   const float e2 = __expf(2.f * xc);
   return nf_fdiv(e2 - 1.f, e2 + 1.f);
