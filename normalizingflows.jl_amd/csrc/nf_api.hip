@@ -76,17 +76,18 @@ size_t nf_wide_train_scratch_floats(nf_ctx *, const nf_flow_desc *, long N);
 // neural spline couplings (nf_rqs.hip)
 bool nf_rqs_supported(const nf_flow_desc *desc);
 int nf_rqs_pack(nf_ctx *, const nf_flow_desc *, const float *theta);
-int nf_rqs_chain(nf_ctx *, const nf_flow_desc *, bool inverse, float *xt, long N, float *ladj, int k_only);
+int nf_rqs_chain(nf_ctx *, const nf_flow_desc *, bool inverse, float *xt, long N, float *ladj, int k_only, void *tape = nullptr);
+size_t nf_rqs_tape_bytes(const nf_flow_desc *desc, long N);
 int nf_rqs_bwd_grid(nf_ctx *, long N);
 int nf_rqs_bwd(nf_ctx *, const nf_flow_desc *, int k, float *y, float *ybar, const float *lbar, float lbar_const, long N,
-               float *slab, long slab_stride, int grid, bool inv_dir = false);
+               float *slab, long slab_stride, int grid, bool inv_dir = false, void *tape = nullptr);
 long nf_rqs_slab_floats(const nf_flow_desc *desc);
 int nf_rqs_bwd_all(nf_ctx *, const nf_flow_desc *, float *y, float *ybar, const float *lbar, float lbar_const, long N,
-                   float *slab, long slab_stride, int grid, bool inv_dir = false);
+                   float *slab, long slab_stride, int grid, bool inv_dir = false, void *tape = nullptr);
 long nf_rqs_chain_grid(nf_ctx *, long N);
 int nf_rqs_chain_elbo(nf_ctx *, const nf_flow_desc *, long N, uint64_t seed, uint64_t off, uint32_t stream,
                       const float *mu, const float *var, float *yt, float *gt, double gscale, double *partial,
-                      double pscale);
+                      double pscale, void *tape = nullptr);
 int nf_rqs_reduce_slabs(nf_ctx *, const nf_flow_desc *, const float *slab, int nslab, float *g);
 
 // planar / radial / mean-field flows (nf_simple.hip)
@@ -595,9 +596,9 @@ static inline bool elbo_fusable(const nf_flow_desc *desc, const nf_target *targe
 static int fused_chain_elbo(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, long N, uint64_t seed,
                             uint64_t off, uint32_t stream_id, float *yt, float *gt, double gscale, double *partial,
                             double pscale, float *stash = nullptr) {
-  if (desc->kind == NF_KIND_NSF)
+  if (desc->kind == NF_KIND_NSF)  // `stash`: the spline tape (nf_rqs_tape_bytes)
     return nf_rqs_chain_elbo(ctx, desc, N, seed, off, stream_id, (const float *)target->p0, (const float *)target->p1, yt, gt,
-                             gscale, partial, pscale);
+                             gscale, partial, pscale, stash);
   return nf_affine_chain_elbo(ctx, desc, N, seed, off, stream_id, (const float *)target->p0, (const float *)target->p1, yt, gt,
                               gscale, partial, pscale, stash);
 }
@@ -648,15 +649,20 @@ extern "C" int nf_ctx_set_stash_budget(nf_ctx *ctx, int64_t max_bytes) {
   ctx->stash_budget = max_bytes < 0 ? -1 : max_bytes;
   return NF_OK;
 }
+// bytes of the spline tape of an MFMA-path NSF flow (0 for everything else)
+static inline size_t rqs_tape_b(const nf_flow_desc *desc, long N) {
+  return (desc->kind == NF_KIND_NSF && desc->dtype == NF_DTYPE_F32 && nf_rqs_supported(desc)) ? carve_bytes(nf_rqs_tape_bytes(desc, N)) : 0;
+}
 static long fused_chain_grid(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
   return desc->kind == NF_KIND_NSF ? nf_rqs_chain_grid(ctx, N) : nf_affine_chain_grid(ctx, N);
 }
 
 // all couplings (or one, if k_only >= 0) in execution order / inverse order, in place on `xt`
+// rqs_tape (NSF only, optional): the spline tape a later reverse pass of this chain needs (rqs_tape_b bytes)
 static int coupling_chain_tiled(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, const float *theta, float *xt,
-                                long N, float *ladj, int k_only) {
+                                long N, float *ladj, int k_only, void *rqs_tape = nullptr) {
   NF_TRY(coupling_pack(ctx, desc, theta));
-  if (is_nsf(desc)) return nf_rqs_chain(ctx, desc, inverse, xt, N, ladj, k_only);
+  if (is_nsf(desc)) return nf_rqs_chain(ctx, desc, inverse, xt, N, ladj, k_only, rqs_tape);
   if (is_wide(desc)) {
     if (k_only >= 0) return nf_wide_apply(ctx, desc, k_only, inverse, xt, N, ladj, 0);
     const int nc = 2 * desc->nlayers;
@@ -760,7 +766,7 @@ extern "C" int nf_layer_apply(nf_ctx *ctx, const nf_flow_desc *desc, int32_t lay
 // lpart/nlpart/lout: optional loss partials for the slab-reduction kernel to finish (resident RealNVP only)
 static int realnvp_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta, float *state, float *gbar,
                        const float *lbar, float lbar_const, long N, float *slab, int grid, float *g_out,
-                       const double *lpart = nullptr, int nlpart = 0, float *lout = nullptr) {
+                       const double *lpart = nullptr, int nlpart = 0, float *lout = nullptr, void *rqs_tape = nullptr) {
   if (is_wide(desc)) return nf_wide_bwd(ctx, desc, state, gbar, lbar, lbar_const, N, slab, g_out);
   const long stride = coupling_slab_floats(ctx, desc, N);
   const int nc = 2 * desc->nlayers;
@@ -775,9 +781,9 @@ static int realnvp_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta
   // launch gaps it saves (profiles/r2_cfg3_fused_vs_split.txt).
   static const bool fused = std::getenv("NF_RQS_BWD_FUSED") != nullptr;
   if (!fused) {
-    for (int k = 0; k < nc; ++k) NF_TRY(nf_rqs_bwd(ctx, desc, k, state, gbar, lbar, lbar_const, N, slab, stride, grid));
+    for (int k = 0; k < nc; ++k) NF_TRY(nf_rqs_bwd(ctx, desc, k, state, gbar, lbar, lbar_const, N, slab, stride, grid, false, rqs_tape));
   } else {
-    NF_TRY(nf_rqs_bwd_all(ctx, desc, state, gbar, lbar, lbar_const, N, slab, stride, grid));
+    NF_TRY(nf_rqs_bwd_all(ctx, desc, state, gbar, lbar, lbar_const, N, slab, stride, grid, false, rqs_tape));
   }
   return nf_rqs_reduce_slabs(ctx, desc, slab, grid, g_out);
 }
@@ -786,7 +792,7 @@ static int realnvp_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta
 // T^-1(data) on entry and the data on exit, `gbar` the cotangent of z; couplings in forward execution order
 static inline bool coupling_inv_bwd_tiled(const nf_flow_desc *desc) { return is_coupling(desc); }
 static int coupling_inv_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta, float *state, float *gbar,
-                            float lbar_const, long N, float *slab, int grid, float *g_out) {
+                            float lbar_const, long N, float *slab, int grid, float *g_out, void *rqs_tape = nullptr) {
   (void)theta;
   if (is_wide(desc)) return nf_wide_bwd(ctx, desc, state, gbar, nullptr, lbar_const, N, slab, g_out, true);
   if (desc->kind == NF_KIND_REALNVP && nf_affine_supported(desc)) {
@@ -797,7 +803,7 @@ static int coupling_inv_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const float *
   if (desc->kind == NF_KIND_NSF && nf_rqs_supported(desc)) {
     const long stride = coupling_slab_floats(ctx, desc, N);
     for (int k = 2 * desc->nlayers - 1; k >= 0; --k)  // forward execution order (one launch per coupling: see realnvp_bwd)
-      NF_TRY(nf_rqs_bwd(ctx, desc, k, state, gbar, nullptr, lbar_const, N, slab, stride, grid, true));
+      NF_TRY(nf_rqs_bwd(ctx, desc, k, state, gbar, nullptr, lbar_const, N, slab, stride, grid, true, rqs_tape));
     return nf_rqs_reduce_slabs(ctx, desc, slab, grid, g_out);
   }
   return NF_ERR_UNSUPPORTED;
@@ -832,7 +838,7 @@ static size_t tape_seg_bytes(nf_ctx *ctx, const nf_flow_desc *g, long N) {
   switch (tape_kind(ctx, g)) {
     case TAPE_X: return carve_bytes((size_t)N * g->d * esize(g->dtype));
     case TAPE_AFFINE_STASH: return carve_bytes(nf_affine_stash_floats(g, N) * 4);
-    case TAPE_TILED_Y: return carve_bytes(tiled_elems(g, N) * 4);
+    case TAPE_TILED_Y: return carve_bytes(tiled_elems(g, N) * 4) + rqs_tape_b(g, N);  // spline couplings: + bins and xi
     case TAPE_WIDE: return carve_bytes(nf_wide_fwd_stash_floats(ctx, g, N) * 4) + carve_bytes(tiled_elems(g, N) * 4);
   }
   return 0;
@@ -892,7 +898,8 @@ static int tape_fwd_seg(nf_ctx *ctx, const nf_flow_desc *g, const void *theta, c
     char *ty = (char *)tape + carve_bytes(nf_wide_fwd_stash_floats(ctx, g, N) * 4);
     NF_HIP(hipMemcpyAsync(ty, xt, te * 4, hipMemcpyDeviceToDevice, ctx->stream));
   } else {
-    NF_TRY(coupling_chain_tiled(ctx, g, false, (const float *)theta, xt, N, (float *)ladj, -1));
+    NF_TRY(coupling_chain_tiled(ctx, g, false, (const float *)theta, xt, N, (float *)ladj, -1,
+                                rqs_tape_b(g, N) ? (char *)tape + carve_bytes(te * 4) : nullptr));
     NF_HIP(hipMemcpyAsync(tape, xt, te * 4, hipMemcpyDeviceToDevice, ctx->stream));
   }
   return nf_launch_layout_convert(ctx, g->d, N, xt, (float *)y_out, 0);
@@ -933,7 +940,8 @@ static int tape_bwd_seg(nf_ctx *ctx, const nf_flow_desc *g, const void *theta, c
     float *slab = cv.take<float>((size_t)grid * coupling_slab_floats(ctx, g, N));
     NF_HIP(hipMemcpyAsync(state, tape, te * 4, hipMemcpyDeviceToDevice, ctx->stream));
     NF_TRY(realnvp_bwd(ctx, g, (const float *)theta, state, gt, (const float *)lbar, (float)lbar_const, N, slab, grid,
-                       (float *)gtheta_out));
+                       (float *)gtheta_out, nullptr, 0, nullptr,
+                       rqs_tape_b(g, N) ? (char *)const_cast<void *>(tape) + carve_bytes(te * 4) : nullptr));
   }
   return nf_launch_layout_convert(ctx, g->d, N, gt, (float *)xbar_out, 0);
 }
@@ -1199,8 +1207,9 @@ extern "C" int nf_loglikelihood_value_and_grad(nf_ctx *ctx, const nf_flow_desc *
   const size_t stash_b = stash_nc ? affine_stash_bytes(ctx, desc, stash_nc) : 0;
   const size_t slabf_all = tiled ? chunked_slab_floats(ctx, desc, N, stash_nc, coupling_slab_floats(ctx, desc, N)) : 0;
   (void)slabf; (void)stash_nch;
+  const size_t rqs_b = tiled ? rqs_tape_b(desc, N) : 0;
   const size_t need = 2 * carve_bytes(xe * es) + carve_bytes((size_t)N * es) + carve_bytes((size_t)nb * 8) +
-                      carve_bytes(2 * (size_t)desc->d * es) + carve_bytes(slabf_all * es) + carve_bytes(flat_ws) + carve_bytes(stash_b);
+                      carve_bytes(2 * (size_t)desc->d * es) + carve_bytes(slabf_all * es) + carve_bytes(flat_ws) + carve_bytes(stash_b) + rqs_b;
   NF_TRY(nf_ws_reserve(ctx, need));
   Carver cv(ctx->ws);
   char *z = cv.take<char>(xe * es);
@@ -1211,6 +1220,7 @@ extern "C" int nf_loglikelihood_value_and_grad(nf_ctx *ctx, const nf_flow_desc *
   char *slab = cv.take<char>(slabf_all * es);
   char *fws = cv.take<char>(flat_ws);
   float *stash = stash_b ? cv.take<float>(stash_b / 4) : nullptr;
+  void *rqs_tape = rqs_b ? (void *)cv.take<char>(rqs_b) : nullptr;
   nf_target q0;
   q0.kind = NF_TARGET_DIAGGAUSS;
   q0.p0 = q0par;
@@ -1240,10 +1250,10 @@ extern "C" int nf_loglikelihood_value_and_grad(nf_ctx *ctx, const nf_flow_desc *
       NF_TRY(nf_launch_finish_sum(ctx, partial, npart, 0, nullptr, (float *)out + P, nullptr));
       return nf_affine_reduce_slabs(ctx, desc, (const float *)slab, (int)nslab, (float *)out);
     }
-    NF_TRY(coupling_chain_tiled(ctx, desc, true, (const float *)theta, zt, N, (float *)ladj, -1));
+    NF_TRY(coupling_chain_tiled(ctx, desc, true, (const float *)theta, zt, N, (float *)ladj, -1, rqs_tape));
     NF_TRY(nf_launch_target_tiled(ctx, &q0, desc->d, N, zt, nullptr, (const float *)ladj, gt, -inv, nullptr, partial, -inv));
     NF_TRY(nf_launch_finish_sum(ctx, partial, nb, 0, nullptr, (float *)out + P, nullptr));
-    return coupling_inv_bwd(ctx, desc, (const float *)theta, zt, gt, (float)(-inv), N, (float *)slab, grid, (float *)out);
+    return coupling_inv_bwd(ctx, desc, (const float *)theta, zt, gt, (float)(-inv), N, (float *)slab, grid, (float *)out, rqs_tape);
   }
   if (hf) {  // every inverse layer of the Hamiltonian flow is explicit: differentiated directly (nf_hamiltonian.hip)
     NF_TRY(nf_hf_apply(ctx, desc, 0, nf_layer_count(desc), true, theta, ys, N, z, ladj));
@@ -1282,15 +1292,26 @@ static int inv_bwd_std(nf_ctx *ctx, const nf_flow_desc *g, const void *theta, co
     const int grid = coupling_bwd_grid(ctx, g, N);
     const size_t te = tiled_elems(g, N);
     const size_t slabf = (size_t)grid * coupling_slab_floats(ctx, g, N);
-    NF_TRY(nf_ws_reserve(ctx, 2 * carve_bytes(te * 4) + carve_bytes(slabf * 4)));
+    const size_t rqs_b = rqs_tape_b(g, N);
+    NF_TRY(nf_ws_reserve(ctx, 2 * carve_bytes(te * 4) + carve_bytes(slabf * 4) + rqs_b + (rqs_b ? carve_bytes((size_t)N * 4) : 0)));
     Carver cv(ctx->ws);
     float *state = cv.take<float>(te);
     float *gt = cv.take<float>(te);
     float *slab = cv.take<float>(slabf);
     NF_TRY(coupling_pack(ctx, g, (const float *)theta));
-    NF_TRY(nf_launch_layout_convert(ctx, g->d, N, (const float *)zout, state, 1));
+    void *rqs_tape = nullptr;
+    if (rqs_b) {
+      // spline couplings: the reverse pass differentiates the inverse chain's own bins (RqsTape, nf_rqs.hip), so the
+      // segment's inverse runs again from its input, leaving its output in the tiled state AND the tape
+      rqs_tape = cv.take<char>(rqs_b);
+      float *scr_ladj = cv.take<float>((size_t)N);
+      NF_TRY(nf_launch_layout_convert(ctx, g->d, N, (const float *)yin, state, 1));
+      NF_TRY(nf_rqs_chain(ctx, g, true, state, N, scr_ladj, -1, rqs_tape));
+    } else {
+      NF_TRY(nf_launch_layout_convert(ctx, g->d, N, (const float *)zout, state, 1));
+    }
     NF_TRY(nf_launch_layout_convert(ctx, g->d, N, (const float *)gbar, gt, 1));
-    NF_TRY(coupling_inv_bwd(ctx, g, (const float *)theta, state, gt, (float)lbar_const, N, slab, grid, (float *)gtheta_out));
+    NF_TRY(coupling_inv_bwd(ctx, g, (const float *)theta, state, gt, (float)lbar_const, N, slab, grid, (float *)gtheta_out, rqs_tape));
     return nf_launch_layout_convert(ctx, g->d, N, gt, (float *)gbar, 0);
   }
   if (g->kind == NF_KIND_HAMILTONIAN) {  // single-segment only (check_composite): the data cotangent is not needed
@@ -1718,8 +1739,9 @@ extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, con
   const size_t slabf = wide ? nf_wide_train_ws_floats(ctx, desc, N)
                             : cp ? chunked_slab_floats(ctx, desc, N, stash_nc, coupling_slab_floats(ctx, desc, N)) : 0;
   const size_t xe = cp ? tiled_elems(desc, N) : simple_step ? 0 : (size_t)N * desc->d;
+  const size_t rqs_b = cp ? rqs_tape_b(desc, N) : 0;
   const size_t need = 3 * carve_bytes(xe * es) + 2 * carve_bytes((size_t)N * es) + carve_bytes((size_t)nb_alloc * 8) +
-                      carve_bytes(64) + carve_bytes(slabf * es) + carve_bytes(simple_ws) + carve_bytes(stash_b);
+                      carve_bytes(64) + carve_bytes(slabf * es) + carve_bytes(simple_ws) + carve_bytes(stash_b) + rqs_b;
   NF_TRY(nf_ws_reserve(ctx, need));
   Carver cv(ctx->ws);
   char *x = cv.take<char>(xe * es);
@@ -1733,6 +1755,7 @@ extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, con
   char *slab = cv.take<char>(slabf * es);
   char *sws = cv.take<char>(simple_ws);
   float *stash = stash_b ? cv.take<float>(stash_b / 4) : nullptr;
+  void *rqs_tape = rqs_b ? (void *)cv.take<char>(rqs_b) : nullptr;  // spline couplings: the forward's bins and xi
 
   if (fusable) {
     float *xt = (float *)x, *gt = (float *)gbar;
@@ -1752,10 +1775,12 @@ extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, con
       }
       return nf_affine_reduce_slabs(ctx, desc, (const float *)slab, (int)nslab, (float *)out, partial, (int)npart, (float *)out + P);
     }
-    NF_TRY(fused_chain_elbo(ctx, desc, target, N, seed, sample_offset, stream_id, xt, gt, -inv, partial, -inv));
+    NF_TRY(fused_chain_elbo(ctx, desc, target, N, seed, sample_offset, stream_id, xt, gt, -inv, partial, -inv,
+                            is_nsf(desc) ? (float *)rqs_tape : nullptr));
     if (is_nsf(desc)) {
       NF_TRY(nf_launch_finish_sum(ctx, partial, fused_chain_grid(ctx, desc, N), 0, nullptr, (float *)out + P, nullptr));
-      return realnvp_bwd(ctx, desc, (const float *)theta, xt, gt, nullptr, (float)(-inv), N, (float *)slab, grid, (float *)out);
+      return realnvp_bwd(ctx, desc, (const float *)theta, xt, gt, nullptr, (float)(-inv), N, (float *)slab, grid, (float *)out,
+                         nullptr, 0, nullptr, rqs_tape);
     }
     // the loss partials of the fused forward are finished by the slab-reduction launch
     return realnvp_bwd(ctx, desc, (const float *)theta, xt, gt, nullptr, (float)(-inv), N, (float *)slab, grid, (float *)out,
@@ -1806,13 +1831,13 @@ extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, con
       NF_TRY(nf_launch_finish_sum(ctx, partial, npart, 0, nullptr, (float *)out + P, nullptr));
       return nf_affine_reduce_slabs(ctx, desc, (const float *)slab, (int)nslab, (float *)out);
     }
-    NF_TRY(coupling_chain_tiled(ctx, desc, false, (const float *)theta, xt, N, (float *)ladj, -1));
+    NF_TRY(coupling_chain_tiled(ctx, desc, false, (const float *)theta, xt, N, (float *)ladj, -1, rqs_tape));
     // gt = d(-elbo/Ng)/dy = -(1/Ng) grad logp(y);  partial sums of -elbo_j/Ng
     NF_TRY(nf_launch_target_tiled(ctx, target, desc->d, N, xt, (const float *)logq, (const float *)ladj, gt, -inv,
                                   nullptr, partial, -inv));
     NF_TRY(nf_launch_finish_sum(ctx, partial, nb, 0, nullptr, (float *)out + P, nullptr));
     NF_TRY(realnvp_bwd(ctx, desc, (const float *)theta, xt, gt, nullptr, (float)(-inv), N, (float *)slab, grid,
-                       (float *)out));
+                       (float *)out, nullptr, 0, nullptr, rqs_tape));
   } else {
     if (simple_step) {
       // planar / radial / mean-field: draws (or xs), chain, target, ELBO sums AND the reverse pass in one launch;
@@ -2100,7 +2125,8 @@ static size_t ws_need_bound(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
       const size_t flat_ws = tiled ? 0 : hf ? nf_hf_bwd_ws_bytes(desc, N) : coupling_kind ? nf_g64_bwd_inv_ws_bytes(desc, N)
                                                                                        : nf_simple_bwd_ws_bytes(ctx, desc, N);
       upd(2 * carve_bytes(xe * es) + cn + carve_bytes((size_t)nbt * 8) + carve_bytes(2 * (size_t)desc->d * es) +
-          carve_bytes(slabf * es) + carve_bytes(flat_ws) + carve_bytes(snc ? affine_stash_bytes(ctx, desc, snc) : 0));
+          carve_bytes(slabf * es) + carve_bytes(flat_ws) + carve_bytes(snc ? affine_stash_bytes(ctx, desc, snc) : 0) +
+          (tiled ? rqs_tape_b(desc, N) : 0));
     }
   }
   // nf_elbo_value_and_grad / nf_elbo_step (both the stash-free and the stash form of the simple flows)
@@ -2115,7 +2141,11 @@ static size_t ws_need_bound(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
       if (sw > simple_ws) simple_ws = sw;
     }
     upd(3 * carve_bytes(xe * es) + 2 * cn + carve_bytes((size_t)nb_alloc * 8) + carve_bytes(64) +
-        carve_bytes(slabf * es) + carve_bytes(simple_ws) + carve_bytes(snc ? affine_stash_bytes(ctx, desc, snc) : 0));
+        carve_bytes(slabf * es) + carve_bytes(simple_ws) + carve_bytes(snc ? affine_stash_bytes(ctx, desc, snc) : 0) +
+        (cp ? rqs_tape_b(desc, N) : 0));
+    // forward-KL over a general base / inside a composition: inv_bwd_std's own intermediates (spline couplings re-run
+    // their inverse chain with the tape)
+    if (cp) upd(2 * carve_bytes(te * 4) + carve_bytes(slab_pull * 4) + rqs_tape_b(desc, N) + cn);
   }
   return need;
 }

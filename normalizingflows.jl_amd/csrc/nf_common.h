@@ -129,6 +129,14 @@ struct AttrOnce {
   }
 };
 
+// natural log through v_log_f32 (log2, 1 ulp) and one multiply.  hipcc expands __logf into the denormal-safe,
+// extended-precision sequence of logf (14 instructions); every argument on this path is a normal positive number.
+#ifdef NF_LOG_PRECISE
+__device__ __forceinline__ float nf_log(float x) { return __logf(x); }
+#else
+__device__ __forceinline__ float nf_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+#endif
+
 // Optimisers.Adam (Optimisers.jl 0.4 `apply!`, reached from src/optimize.jl:99) for ONE parameter: shared by k_adam and the
 // fused step epilogue so that both produce the same bits (contraction off: the compiler may otherwise fuse b1 m + (1 - b1) g
 // differently at the two call sites).  c1 = 1 - b1^t, c2 = 1 - b2^t.

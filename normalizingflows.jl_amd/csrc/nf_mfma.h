@@ -175,6 +175,66 @@ __device__ __forceinline__ void dense_bwd_x(const float *__restrict__ w, const f
   }
 }
 
+// din = W^T * delta with the k-steps dealt round-robin to NS independent accumulators (summed at the end): a single
+// input block (IB = 1) otherwise makes every MFMA of the GEMM depend on the one before it -- measured on the NSF reverse
+// kernel (tools/trace_rqs.py): 103 cycles per MFMA in the one-accumulator chain against 81-85 where chains interleave.
+template <int IB, int OB, int S, int NS, int GK = 8, class SJ = NoSideJob>
+__device__ __forceinline__ void dense_bwd_x_split(const float *__restrict__ w, const f32x16 (&delta)[OB], f32x16 (&din)[IB],
+                                                  int l31, int hi, SJ sj = SJ()) {
+  // GK k-steps per pipeline group (a multiple of 4): the A operands of group g + 1 are requested GK MFMAs ahead
+  constexpr int NK = OB * 16, NG = NK / GK;
+  static_assert(NK % GK == 0 && GK % 4 == 0, "group size");
+  f32x16 part[NS][IB];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part[s][ib][r] = 0.f;
+  const float *wl = w + l31 * S + 4 * hi;
+  // k-step t (0 .. NK-1) contracts output o = 8 (t / 4) + (t % 4) + 4 hi: row offset 8 (t / 4) + (t % 4) from wl
+  float an[IB][GK], ac[IB][GK];
+#pragma unroll
+  for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+    for (int e = 0; e < GK; ++e) an[ib][e] = wl[ib * 32 * S + 8 * (e / 4) + (e % 4)];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+      for (int e = 0; e < GK; ++e) ac[ib][e] = an[ib][e];
+    if (g + 1 < NG) {
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+        for (int e = 0; e < GK; ++e) {
+          const int t = (g + 1) * GK + e;
+          an[ib][e] = wl[ib * 32 * S + 8 * (t / 4) + (t % 4)];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < GK; ++e)
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib) {
+        const int t = g * GK + e;
+        part[e % NS][ib] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[ib][e], delta[t / 16][t % 16], part[e % NS][ib], 0, 0, 0);
+        sj(t * IB + ib);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float t = part[0][ib][r];
+#pragma unroll
+      for (int s = 1; s < NS; ++s) t += part[s][ib][r];
+      din[ib][r] = t;
+    }
+}
+
 // ---- weight-gradient GEMM: contraction over SAMPLES -------------------------------
 // dW^T[i][o] += sum_j a[i][j] * delta[o][j].  Both operands must have lane <-> feature,
 // i.e. the transpose of the C layout, so they take one round trip through a per-wave

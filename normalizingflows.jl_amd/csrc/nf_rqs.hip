@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void k_rqs_reduce_slabs(RqsPackArgs p, const f
 // the spline, one (dim, sample) per lane, everything in registers
 // ---------------------------------------------------------------------------------------
 // softplus with hardware exp/log: abs error ~1e-7 (the derivatives it produces are O(1))
-__device__ __forceinline__ float softplus_f(float x) { return __logf(1.f + __expf(-fabsf(x))) + fmaxf(x, 0.f); }
+__device__ __forceinline__ float softplus_f(float x) { return nf_log(1.f + __expf(-fabsf(x))) + fmaxf(x, 0.f); }
 __device__ __forceinline__ float sigmoid_f(float x) {
   const float e = __expf(-fabsf(x));
   return x >= 0.f ? nf_fdiv(1.f, 1.f + e) : nf_fdiv(e, 1.f + e);
@@ -234,12 +234,41 @@ struct Bin {
   float xk, xk1, yk, yk1, d0, d1;
   bool ge[K + 1];
   bool inside;
+  unsigned code;  // bin index k (0 .. K-1), or NF_RQS_OUTSIDE: what the forward leaves behind for the reverse pass
 };
+#define NF_RQS_OUTSIDE 15u
 
-// bin with p[k] <= v < p[k+1] on the knot vector `p` (pX forward, pY inverse): one ascending select chain
-template <int K, bool LAZY = true>
-__device__ __forceinline__ void find_bin(const Knots<K> &kn, const float *p, float v, Bin<K> &b) {
-  b.inside = (v >= p[0]) && (v < p[K]);
+// The spline tape.  Which bin an element falls into is a DISCRETE decision, and the gradient of log S'(x) with respect
+// to the knot parameters jumps across a knot (S is only C^1).  A reverse pass that re-decides the bin on a float32
+// reconstruction of the element (inverting the coupling from its output) can land on the other side of a knot for an
+// element within ~1e-6 of it -- measured: one such element in a 77-sample batch moved the gradient of a coupling by
+// 2e-2 |g|inf.  The reference differentiates the forward's own tape (MonotonicSplines' rrule pullbacks receive the
+// forward's x), so the chain kernels leave, per slot = (tile, coupling), NE rows of 64 floats (NE = NCH * QCH elements per
+// lane, element e = chunk * QCH + local dim): base[(slot * NE + e) * 64 + lane] = k + xi, the bin index plus the in-bin
+// coordinate (clamped to [0, 1 - 2^-19] so that the sum keeps its integer part; xi then carries 19-20 bits, ~1e-6 of the
+// bin), or -1 outside the box.  One float per element: the chain kernels sit at their register budget, and a separate
+// word of packed bin codes cost them 240 bytes of scratch spills per lane.  The reverse kernels read it back instead of
+// searching and solving again (which also saves them the inverse's quadratic).
+struct RqsTape {
+  float *base;
+};
+__device__ __forceinline__ float rqs_tape_encode(unsigned code, float xi) {
+  const float t = (float)code + fminf(fmaxf(xi, 0.f), 0.99999809265f);
+  return code == NF_RQS_OUTSIDE ? -1.f : t;
+}
+__device__ __forceinline__ void rqs_tape_decode(float t, unsigned &code, float &xi) {
+  const float f = floorf(fmaxf(t, 0.f));
+  code = t < 0.f ? NF_RQS_OUTSIDE : (unsigned)f;
+  xi = t - f;
+}
+
+// bin with p[k] <= v < p[k+1] on the knot vector `p` (pX forward, pY inverse): one ascending select chain.
+// FROM_CODE: the conditions come from a recorded bin code instead of a search (v and p are not read).
+template <int K, bool LAZY = true, bool FROM_CODE = false>
+__device__ __forceinline__ void find_bin(const Knots<K> &kn, const float *p, float v, Bin<K> &b, unsigned code_in = 0u) {
+  static_assert(K <= 15, "bin codes are four bits");
+  b.inside = FROM_CODE ? (code_in != NF_RQS_OUTSIDE) : ((v >= p[0]) && (v < p[K]));
+  b.code = 0u;
   b.ge[0] = true;
   b.ge[K] = false;
   b.xk = kn.pX[0]; b.xk1 = kn.pX[1]; b.yk = kn.pY[0]; b.yk1 = kn.pY[1];
@@ -247,8 +276,9 @@ __device__ __forceinline__ void find_bin(const Knots<K> &kn, const float *p, flo
     float r0 = 0.f, r1 = kn.rawd[0];  // raw derivative parameters of knots k and k+1 (knot j <-> rawd[j-1])
 #pragma unroll
     for (int j = 1; j < K; ++j) {
-      const bool c = v >= p[j];
+      const bool c = FROM_CODE ? (code_in >= (unsigned)j) : (v >= p[j]);
       b.ge[j] = c;
+      if (!FROM_CODE) b.code = c ? (unsigned)j : b.code;
       b.xk = c ? kn.pX[j] : b.xk;
       b.xk1 = c ? kn.pX[j + 1] : b.xk1;
       b.yk = c ? kn.pY[j] : b.yk;
@@ -263,8 +293,9 @@ __device__ __forceinline__ void find_bin(const Knots<K> &kn, const float *p, flo
     b.d1 = kn.dd[1];
 #pragma unroll
     for (int j = 1; j < K; ++j) {
-      const bool c = v >= p[j];
+      const bool c = FROM_CODE ? (code_in >= (unsigned)j) : (v >= p[j]);
       b.ge[j] = c;
+      if (!FROM_CODE) b.code = c ? (unsigned)j : b.code;
       b.xk = c ? kn.pX[j] : b.xk;
       b.xk1 = c ? kn.pX[j + 1] : b.xk1;
       b.yk = c ? kn.pY[j] : b.yk;
@@ -273,24 +304,33 @@ __device__ __forceinline__ void find_bin(const Knots<K> &kn, const float *p, flo
       b.d1 = c ? kn.dd[j + 1] : b.d1;
     }
   }
+  b.code = FROM_CODE ? code_in : (b.inside ? b.code : NF_RQS_OUTSIDE);
 }
 
 __device__ __forceinline__ float rq_logderiv(float s, float d0, float d1, float xi) {
   const float om = 1.f - xi;
   const float den = s + (d1 + d0 - 2.f * s) * xi * om;
-  return 2.f * __logf(s) + __logf(d1 * xi * xi + 2.f * s * xi * om + d0 * om * om) - 2.f * __logf(den);
+  // 2 log s + log(nd) - 2 log den as ONE logarithm: log(s^2 nd / den^2) (one v_rcp + one v_log instead of three logs)
+  const float nd = d1 * xi * xi + 2.f * s * xi * om + d0 * om * om;
+#ifdef RQS_THREE_LOGS
+  return 2.f * nf_log(s) + nf_log(nd) - 2.f * nf_log(den);
+#else
+  return nf_log(nf_fdiv(s * s * nd, den * den));
+#endif
 }
 
 // rqs_forward for one element: returns y, adds log dy/dx to logd
 template <int K>
-__device__ __forceinline__ float rqs_fwd_elem(const Knots<K> &kn, float x, float &logd) {
+__device__ __forceinline__ float rqs_fwd_elem(const Knots<K> &kn, float x, float &logd, unsigned &code_out, float &xi_out) {
   Bin<K> b;
   find_bin<K>(kn, kn.pX, x, b);
+  code_out = b.code;
   const float dx = b.xk1 - b.xk, dy = b.yk1 - b.yk;
   const float s = nf_fdiv(dy, dx);
   const float xi = nf_fdiv(x - b.xk, dx), om = 1.f - xi;
   const float den = s + (b.d1 + b.d0 - 2.f * s) * xi * om;
   const float y = b.yk + nf_fdiv(dy * (s * xi * xi + b.d0 * xi * om), den);
+  xi_out = xi;
   logd += b.inside ? rq_logderiv(s, b.d0, b.d1, xi) : 0.f;
   return b.inside ? y : x;
 }
@@ -408,6 +448,7 @@ __device__ __forceinline__ void chunk_put(f32x16 (&out)[G::OBC], int ql, const f
 // whole-flow forward / inverse in one launch (same structure as k_affine_chain)
 // ---------------------------------------------------------------------------------------
 struct RqsChainArgs {
+  RqsTape tape;       // spline tape to leave behind (training), or null pointers
   const float *wimg;  // [coupling][G::SIZE]
   int d, ncoup;
   int k_only;  // -1: every coupling; otherwise only the coupling with this flat index
@@ -415,9 +456,13 @@ struct RqsChainArgs {
   long N;
 };
 
+// tape: buffer descriptor of this (tile, coupling)'s slot of the spline tape; extent 0 (no tape wanted, or an idle wave)
+// drops the stores in hardware, so the step has no branch on it and needs no per-lane 64-bit address
 template <class G, bool INVERSE>
 __device__ __forceinline__ float rqs_coupling_step(const float *__restrict__ img, f32x16 (&x1)[G::CB],
-                                                   const f32x16 (&xb)[G::MB], int c, float B, int l31, int hi) {
+                                                   const f32x16 (&xb)[G::MB], int c, float B, int l31, int hi,
+                                                   __amdgpu_buffer_rsrc_t tape) {
+  const int tvoff = (hi * 32 + l31) * 4;
   f32x16 a2[G::H2B];
   {
     f32x16 a1[G::H1B];
@@ -446,17 +491,20 @@ __device__ __forceinline__ float rqs_coupling_step(const float *__restrict__ img
       Knots<G::K> kn;
       build_knots<G::K>(raw, B, kn);
       const float v = x1[q / 16][q % 16];
-      float logd = 0.f, res;
+      float logd = 0.f, res, xi;
+      unsigned code;
       if (INVERSE) {
         Bin<G::K> bn;
-        float xi;
         res = rqs_inv_elem<G::K>(kn, v, logd, bn, xi);
+        code = bn.code;
       } else {
-        res = rqs_fwd_elem<G::K>(kn, v, logd);
+        res = rqs_fwd_elem<G::K>(kn, v, logd, code, xi);
       }
       const bool ok = p < c;  // padded dims: keep the zero, contribute nothing
       x1[q / 16][q % 16] = ok ? res : v;
       lsum += ok ? logd : 0.f;
+      const float tv = rqs_tape_encode(code, xi);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tv), tape, tvoff, q * 256, 0);
     }
   }
   return lsum;
@@ -581,10 +629,14 @@ __global__ __launch_bounds__(512) void k_rqs_chain(RqsChainArgs a, float *xt, fl
         const float *img = lds + buf * G::SIZE;
         // forward: position 0 is the last flat coupling (odd index, mask 2:2:d): x1 = O
         if (a.k_only < 0 || a.k_only == coupling_at(pos)) {
+          constexpr int ROWS = G::NCH * G::QCH;
+          const long slot = tl * a.ncoup + coupling_at(pos);
+          const __amdgpu_buffer_rsrc_t tp = __builtin_amdgcn_make_buffer_rsrc(
+              a.tape.base + (a.tape.base ? slot * (ROWS * 64) : 0), 0, (a.tape.base && live) ? ROWS * 256 : 0, 0x00020000);
           if (INVERSE ? (half == 1) : (half == 0))
-            lsum += rqs_coupling_step<G, INVERSE>(img, O, E, c_even, a.B, l31, hi);
+            lsum += rqs_coupling_step<G, INVERSE>(img, O, E, c_even, a.B, l31, hi, tp);
           else
-            lsum += rqs_coupling_step<G, INVERSE>(img, E, O, c_odd, a.B, l31, hi);
+            lsum += rqs_coupling_step<G, INVERSE>(img, E, O, c_odd, a.B, l31, hi, tp);
         }
         __syncthreads();
         buf ^= 1;
@@ -647,6 +699,8 @@ __global__ __launch_bounds__(512) void k_rqs_chain(RqsChainArgs a, float *xt, fl
 // reverse pass of one coupling (invertible recompute), one net
 // ---------------------------------------------------------------------------------------
 struct RqsBwdArgs {
+  RqsTape tape;      // the forward's spline tape (required)
+  int k, ncoup;      // this coupling's flat index / couplings of the flow (tape addressing)
   const float *img;  // packed image of this coupling
   int d, c, m, par_t;
   float B;
@@ -711,6 +765,9 @@ __device__ __forceinline__ void rqs_fold(float *__restrict__ w, float *__restric
 #ifndef RQS_BWD_LAZY
 #define RQS_BWD_LAZY false
 #endif
+#ifndef RQS_DX3_SPLIT
+#define RQS_DX3_SPLIT 2  // independent accumulators of the cooperative kernel's dX3 GEMM (1 = the single chain)
+#endif
 #ifndef RQS_COOP_LAZY
 #define RQS_COOP_LAZY true  // the cooperative kernel has the registers for the lazy knot derivatives
 #endif
@@ -739,6 +796,8 @@ __device__ __forceinline__ void rqs_bwd_tile(const RqsBwdArgs &a, const float *_
 
   unsigned m1[G::H1B], m2[G::H2B];
   f32x16 a2[G::H2B];
+  constexpr int ROWS = G::NCH * G::QCH;
+  const float *trow = a.tape.base + (tile * a.ncoup + a.k) * (ROWS * 64) + (hi * 32 + l31);
   {
     f32x16 xb[G::MB];
 #pragma unroll
@@ -802,21 +861,24 @@ __device__ __forceinline__ void rqs_bwd_tile(const RqsBwdArgs &a, const float *_
       build_knots<G::K, RQS_BWD_LAZY>(raw, a.B, kn);
       const float yv = yq[ql];
       const float gv = ok ? gq[ql] : 0.f;
-      // invert to the coupling input (src/flows/neuralspline.jl:134-140), then differentiate the
-      // forward map at that point
-      float dummy = 0.f, xi;
+      // the element's bin and in-bin coordinate as the FORWARD found them (spline tape), the bin's knots from the
+      // recomputed parameters; then the coupling input (forward chain: x = xi dx + xk; inverse chain: the state holds
+      // the spline's input and is advanced through the spline) and the reverse pass of the forward map at that point
       Bin<G::K> bn;
+      unsigned code;
+      float xi;
+      rqs_tape_decode(trow[q * 64], code, xi);
+      find_bin<G::K, RQS_BWD_LAZY, true>(kn, kn.pX, 0.f, bn, code);
       float xv;
-      if (INVD) {  // the point is already the spline's input: locate it, and advance the state through the spline
-        find_bin<G::K, RQS_BWD_LAZY>(kn, kn.pX, yv, bn);
+      {
         const float dx = bn.xk1 - bn.xk, dy = bn.yk1 - bn.yk;
-        const float sl = nf_fdiv(dy, dx);
-        xi = nf_fdiv(yv - bn.xk, dx);
-        const float om = 1.f - xi;
-        const float den = sl + (bn.d1 + bn.d0 - 2.f * sl) * xi * om;
-        xv = bn.inside ? bn.yk + nf_fdiv(dy * (sl * xi * xi + bn.d0 * xi * om), den) : yv;
-      } else {
-        xv = rqs_inv_elem<G::K, false, RQS_BWD_LAZY>(kn, yv, dummy, bn, xi);
+        if (INVD) {
+          const float sl = nf_fdiv(dy, dx), om = 1.f - xi;
+          const float den = sl + (bn.d1 + bn.d0 - 2.f * sl) * xi * om;
+          xv = bn.inside ? bn.yk + nf_fdiv(dy * (sl * xi * xi + bn.d0 * xi * om), den) : yv;
+        } else {
+          xv = bn.inside ? fmaf(xi, dx, bn.xk) : yv;
+        }
       }
       const float xbar = rqs_bwd_elem<G::K, INVD>(kn, bn, xi, a.B, gv, ok ? lb : 0.f, thb);  // gv, lb are 0 when !ok
       chunk_put<G>(out, ql, thb);
@@ -941,6 +1003,7 @@ __global__ __launch_bounds__(256, 1) void k_rqs_bwd(RqsBwdArgs a, float *__restr
 // never change hands and coupling k + 1 only reads what the same wave wrote for coupling k (y <- x, ybar <- xbar),
 // so each workgroup walks the couplings on its own -- seven launch gaps and ramp-up / tail phases less per step.
 struct RqsBwdAllArgs {
+  RqsTape tape;
   const float *wimg;  // [coupling][G::SIZE]
   long long *trace;
   int d, ncoup;
@@ -956,6 +1019,9 @@ __global__ __launch_bounds__(256, 1) void k_rqs_bwd_all(RqsBwdAllArgs aa, float 
   for (int step = 0; step < aa.ncoup; ++step) {
     const int k = INVD ? aa.ncoup - 1 - step : step;  // the inverse chain's reverse pass runs in execution order
     RqsBwdArgs a;
+    a.tape = aa.tape;
+    a.k = k;
+    a.ncoup = aa.ncoup;
     a.img = aa.wimg + (size_t)k * G::SIZE;
     a.d = aa.d;
     a.par_t = k & 1;
@@ -996,7 +1062,11 @@ struct RqsCoopLds {
   static constexpr int DBLK = (G::H1B > G::H2B ? G::H1B : G::H2B);  // delta tile: one block for dW3, a whole hidden layer for dW2 / dW1
   static constexpr int SCRATCH = OFF_D + DBLK * 32 * NF_TS;
   static constexpr int SLOT = G::H2B * 16 * 64;  // one partial d2 in register-dump order
-  static constexpr size_t BYTES = (size_t)(G::SIZE + 4 * SCRATCH + 4 * SLOT) * sizeof(float);
+  // two sets of slots (tile t uses set t & 1) let the chunk phase run with ONE workgroup barrier per tile: the home wave
+  // sums tile t's partials while the others already work on tile t + 1.  160 KB of LDS hold them for K = 8 only.
+  static constexpr bool TWO_SETS = (size_t)(G::SIZE + 4 * SCRATCH + 8 * SLOT) * sizeof(float) <= 160 * 1024;
+  static constexpr int NSETS = TWO_SETS ? 2 : 1;
+  static constexpr size_t BYTES = (size_t)(G::SIZE + 4 * SCRATCH + 4 * NSETS * SLOT) * sizeof(float);
 };
 
 template <class G>
@@ -1018,7 +1088,7 @@ __device__ __forceinline__ void rqs_bwd_coop_coupling(const RqsBwdArgs &a, float
   const int l31 = lane & 31, hi = lane >> 5;
   float *sc_all = lds + G::SIZE;
   float *sc = sc_all + wave * L::SCRATCH;          // this wave's tiles
-  float *slots = sc_all + 4 * L::SCRATCH;          // [4][SLOT]
+  float *slots = sc_all + 4 * L::SCRATCH;          // [NSETS][4][SLOT]
   float *sd = sc + L::OFF_D;
   const long ntiles = (a.N + NF_TILE - 1) / NF_TILE;
   const long ngroups = (ntiles + 3) / 4;
@@ -1030,8 +1100,36 @@ __device__ __forceinline__ void rqs_bwd_coop_coupling(const RqsBwdArgs &a, float
   rqs_zero(acc.w1, acc.b1);
   rqs_zero(acc.w2, acc.b2);
   rqs_zero(acc.w3, acc.b3);
+  // The conditioner half of a group's home tile is requested ONE GROUP AHEAD (right after barrier B0, when the registers
+  // are free again): with one wave per SIMD nothing else hides the HBM latency of these loads -- the home phase took
+  // 9.1 k cycles for 2 k cycles of MFMA work before (tools/trace_rqs.py).
+  f32x16 xb[G::MB];
+  auto load_home = [&](long g) {
+    const long tile_ = g * 4 + wave;
+    const bool live_ = tile_ < ntiles;
+    const long tl_ = live_ ? tile_ : 0;
+    const bool valid_ = live_ && tl_ * NF_TILE + l31 < a.N;
+    const TileIO yio_ = make_tile_io(y, tl_, a.d, l31, hi);
+#pragma unroll
+    for (int b = 0; b < G::MB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = tile_load(yio_, tile_soff(b, r, par_c));
+        xb[b][r] = valid_ ? v : 0.f;
+      }
+  };
+#ifndef RQS_NO_PREFETCH
+  if ((long)blockIdx.x < ngroups) load_home(blockIdx.x);
+#endif
+#ifdef NF_KERNEL_TRACE
+  long long *tr = (a.trace && blockIdx.x == 0 && tid == 0) ? a.trace : nullptr;
+#define COOP_STAMP(slot) do { if (tr && grp == (long)blockIdx.x) { __builtin_amdgcn_sched_barrier(0); tr[slot] = clock64(); } } while (0)
+#else
+#define COOP_STAMP(slot) do { } while (0)
+#endif
 #pragma unroll 1
   for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    COOP_STAMP(0);
     // ---------------- home phase: layers 1-2 of this wave's own tile ----------------
     const long tile = grp * 4 + wave;
     const bool live = tile < ntiles;               // wave-uniform; every barrier below is reached by all waves
@@ -1041,15 +1139,11 @@ __device__ __forceinline__ void rqs_bwd_coop_coupling(const RqsBwdArgs &a, float
     const TileIO yio = make_tile_io(y, tl, a.d, l31, hi);
     const TileIO gio = make_tile_io(ybar, tl, a.d, l31, hi);
     unsigned m1[G::H1B], m2[G::H2B];
+    (void)yio;
+#ifdef RQS_NO_PREFETCH
+    load_home(grp);
+#endif
     if (live) {
-      f32x16 xb[G::MB];
-#pragma unroll
-      for (int b = 0; b < G::MB; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = tile_load(yio, tile_soff(b, r, par_c));
-          xb[b][r] = valid ? v : 0.f;
-        }
       tile_to_scratch<G::MB>(sc + L::OFF_X, xb, l31, hi);
       f32x16 a1[G::H1B];
       dense_fwd<G::MB, G::H1B>(img + G::W1, img + G::B1, xb, a1, l31, hi);
@@ -1070,7 +1164,12 @@ __device__ __forceinline__ void rqs_bwd_coop_coupling(const RqsBwdArgs &a, float
       }
       tile_to_scratch<G::H2B>(sc + L::OFF_A2, a2, l31, hi);
     }
+    COOP_STAMP(1);
     __syncthreads();  // B0: every home tile's a2 is in LDS
+    COOP_STAMP(2);
+#ifndef RQS_NO_PREFETCH
+    if (grp + gridDim.x < ngroups) load_home(grp + gridDim.x);  // next group's home tile: in flight during the chunk phase
+#endif
 
     // ---------------- chunk phase: this wave's chunk of the output layer, for each tile of the group ----------------
     f32x16 d2[G::H2B];  // the home tile's summed cotangent of a2 (filled when t == wave)
@@ -1089,12 +1188,15 @@ __device__ __forceinline__ void rqs_bwd_coop_coupling(const RqsBwdArgs &a, float
         const TileIO yt = make_tile_io(y, tt, a.d, l31, hi);
         const TileIO gt = make_tile_io(ybar, tt, a.d, l31, hi);
         const float lb = tvalid ? (lbar ? lbar[jt] : lbar_const) : 0.f;
-        float yq[G::QCH], gq[G::QCH];
+        float yq[G::QCH], gq[G::QCH], xiq[G::QCH];
+        constexpr int ROWS = G::NCH * G::QCH;
+        const float *trow = a.tape.base + (tt * a.ncoup + a.k) * (ROWS * 64) + lane;
 #pragma unroll
         for (int ql = 0; ql < G::QCH; ++ql) {
           const int q = ch * G::QCH + ql;
           yq[ql] = tile_load(yt, tile_soff(q / 16, q % 16, a.par_t));
           gq[ql] = tile_load(gt, tile_soff(q / 16, q % 16, a.par_t));
+          xiq[ql] = trow[q * 64];
         }
         f32x16 out[G::OBC];
         {
@@ -1105,6 +1207,7 @@ __device__ __forceinline__ void rqs_bwd_coop_coupling(const RqsBwdArgs &a, float
             for (int r = 0; r < 16; ++r) a2c[b][r] = sct[L::OFF_A2 + (b * 32 + nf_row(r, hi)) * NF_TS + l31];
           dense_fwd<G::H2B, G::OBC, G::S3>(img + G::W3 + ch * G::OBC * 32, img + G::B3 + ch * G::OBC * 32, a2c, out, l31, hi);
         }
+        COOP_STAMP(3 + 6 * t);
 #pragma unroll
         for (int ql = 0; ql < G::QCH; ++ql) {
           const int q = ch * G::QCH + ql;
@@ -1116,19 +1219,22 @@ __device__ __forceinline__ void rqs_bwd_coop_coupling(const RqsBwdArgs &a, float
           build_knots<G::K, RQS_COOP_LAZY>(raw, a.B, kn);
           const float yv = yq[ql];
           const float gv = ok ? gq[ql] : 0.f;
-          float dummy = 0.f, xi;
+          // bin and in-bin coordinate from the forward's spline tape (see RqsTape), knots from the recomputed parameters
           Bin<G::K> bn;
+          unsigned code;
+          float xi;
+          rqs_tape_decode(xiq[ql], code, xi);
+          find_bin<G::K, RQS_COOP_LAZY, true>(kn, kn.pX, 0.f, bn, code);
           float xv;
-          if (INVD) {
-            find_bin<G::K, RQS_COOP_LAZY>(kn, kn.pX, yv, bn);
+          {
             const float dx = bn.xk1 - bn.xk, dy = bn.yk1 - bn.yk;
-            const float sl = nf_fdiv(dy, dx);
-            xi = nf_fdiv(yv - bn.xk, dx);
-            const float om = 1.f - xi;
-            const float den = sl + (bn.d1 + bn.d0 - 2.f * sl) * xi * om;
-            xv = bn.inside ? bn.yk + nf_fdiv(dy * (sl * xi * xi + bn.d0 * xi * om), den) : yv;
-          } else {
-            xv = rqs_inv_elem<G::K, false, RQS_COOP_LAZY>(kn, yv, dummy, bn, xi);
+            if (INVD) {
+              const float sl = nf_fdiv(dy, dx), om = 1.f - xi;
+              const float den = sl + (bn.d1 + bn.d0 - 2.f * sl) * xi * om;
+              xv = bn.inside ? bn.yk + nf_fdiv(dy * (sl * xi * xi + bn.d0 * xi * om), den) : yv;
+            } else {
+              xv = bn.inside ? fmaf(xi, dx, bn.xk) : yv;
+            }
           }
           const float xbar = rqs_bwd_elem<G::K, INVD>(kn, bn, xi, a.B, gv, ok ? lb : 0.f, thb);
           chunk_put<G>(out, ql, thb);
@@ -1137,16 +1243,22 @@ __device__ __forceinline__ void rqs_bwd_coop_coupling(const RqsBwdArgs &a, float
         }
 #pragma unroll
         for (int slot = G::QCH * G::P; slot < G::OBC * 16; ++slot) out[slot / 16][slot % 16] = 0.f;
+        COOP_STAMP(4 + 6 * t);
         // this chunk's share of dX3 -> the home wave's slot
         {
           f32x16 d2p[G::H2B];
+#ifdef RQS_OLD_DX3
           dense_bwd_x<G::H2B, G::OBC, G::S3>(img + G::W3 + ch * G::OBC * 32, out, d2p, l31, hi);
-          float *mys = slots + wave * L::SLOT;
+#else
+          dense_bwd_x_split<G::H2B, G::OBC, G::S3, RQS_DX3_SPLIT>(img + G::W3 + ch * G::OBC * 32, out, d2p, l31, hi);
+#endif
+          float *mys = slots + ((L::NSETS == 2 ? (t & 1) : 0) * 4 + wave) * L::SLOT;
 #pragma unroll
           for (int b = 0; b < G::H2B; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mys[(b * 16 + r) * 64 + lane] = d2p[b][r];
         }
+        COOP_STAMP(5 + 6 * t);
         // this chunk's columns of dW3^T: one block of delta at a time through the wave's own transpose tile
 #pragma unroll
         for (int pc = 0; pc < G::OBC; ++pc) {
@@ -1156,17 +1268,23 @@ __device__ __forceinline__ void rqs_bwd_coop_coupling(const RqsBwdArgs &a, float
           dw_accumulate_at<G::H2B, 1, G::OBC>(sct + L::OFF_A2, sd, acc.w3, acc.b3, pc, l31, hi);
           wave_lds_fence();
         }
+        COOP_STAMP(6 + 6 * t);
       }
       __syncthreads();  // B1: the four partial d2 of tile t are in the slots
       if (tlive && t == wave) {
+        const float *set = slots + (L::NSETS == 2 ? (t & 1) : 0) * 4 * L::SLOT;
 #pragma unroll
         for (int w = 0; w < 4; ++w)  // fixed order: deterministic
 #pragma unroll
           for (int b = 0; b < G::H2B; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) d2[b][r] += slots[w * L::SLOT + (b * 16 + r) * 64 + lane];
+            for (int r = 0; r < 16; ++r) d2[b][r] += set[w * L::SLOT + (b * 16 + r) * 64 + lane];
       }
-      __syncthreads();  // B2: slots free for tile t + 1
+      COOP_STAMP(7 + 6 * t);
+      // B2 (slots free for tile t + 1) only with ONE set of slots: with two, tile t + 1 writes the other set, and
+      // tile t + 2 writes this one after B1 of tile t + 1, which the home wave reaches only after the sum above
+      if (L::NSETS == 1) __syncthreads();
+      COOP_STAMP(8 + 6 * t);
     }
 
     // ---------------- home phase: layers 2 and 1 of this wave's own tile ----------------
@@ -1200,6 +1318,7 @@ __device__ __forceinline__ void rqs_bwd_coop_coupling(const RqsBwdArgs &a, float
 #pragma unroll
         for (int r = 0; r < 16; ++r) tile_store(gio, tile_soff(b, r, par_c), gold[b][r] + g2[b][r]);
     }
+    COOP_STAMP(27);
     // no barrier here: the next group's home phase writes only this wave's own tiles, which the other waves stopped
     // reading at the last B2, and B0 orders those writes before anybody reads them
   }
@@ -1223,8 +1342,18 @@ __device__ __forceinline__ void rqs_bwd_coop_coupling(const RqsBwdArgs &a, float
   __syncthreads();
 }
 
+// Register budget.  With one wave per SIMD (launch bound 1) a wave may use 512 registers and hipcc splits them into 256
+// VGPRs + 256 AGPRs, selecting the AGPR form for EVERY MFMA of the kernel: each forward / dX result then has to be read
+// back with v_accvgpr_read before the VALU can touch it (447 of this kernel's 3 400 instructions were AGPR <-> VGPR
+// moves).  The cooperative kernel needs only 80 accumulator registers, so for K = 8 the whole working set fits 256
+// VGPRs (234 used, no scratch): declaring a budget of two waves per SIMD makes hipcc select the VGPR form of the MFMAs and
+// drop the AGPR file altogether -- 3 062 instructions instead of 3 399.  (LDS still admits one workgroup per CU; the
+// second argument is a register budget here, not an occupancy.)  K = 10 would spill 88 bytes per lane and keeps the split.
+#ifndef RQS_COOP_WAVES_PER_SIMD
+#define RQS_COOP_WAVES_PER_SIMD(G) (G::K <= 8 ? 2 : 1)
+#endif
 template <class G, bool INVD>
-__global__ __launch_bounds__(256, 1) void k_rqs_bwd_coop(RqsBwdArgs a, float *__restrict__ y, float *__restrict__ ybar,
+__global__ __launch_bounds__(256, RQS_COOP_WAVES_PER_SIMD(G)) void k_rqs_bwd_coop(RqsBwdArgs a, float *__restrict__ y, float *__restrict__ ybar,
                                                          const float *__restrict__ lbar, float lbar_const,
                                                          float *__restrict__ slab, long slab_stride) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1273,6 +1402,24 @@ static RqsPackArgs rqs_pack_args(const nf_flow_desc *desc) {
   return p;
 }
 
+// the spline tape of a batch of N: [tile][coupling][NE rows][64 lanes] floats (RqsTape)
+static int rqs_ne(const nf_flow_desc *desc) {
+  const int id = rqs_geo_id(desc);
+  return id == 1 ? GeoK8::NCH * GeoK8::QCH : id == 2 ? GeoK10::NCH * GeoK10::QCH : GeoK10L::NCH * GeoK10L::QCH;
+}
+size_t nf_rqs_tape_bytes(const nf_flow_desc *desc, long N) {
+  if (!rqs_geo_id(desc)) return 0;
+  const size_t slots = (size_t)((N + NF_TILE - 1) / NF_TILE) * (size_t)(2 * desc->nlayers);
+  return slots * 64 * 4 * (size_t)rqs_ne(desc);
+}
+static RqsTape rqs_tape_at(const nf_flow_desc *desc, long N, void *tape) {
+  (void)desc;
+  (void)N;
+  RqsTape t;
+  t.base = (float *)tape;
+  return t;
+}
+
 long nf_rqs_slab_floats(const nf_flow_desc *desc) { return (long)2 * desc->nlayers * rqs_geo_size(desc); }
 
 size_t nf_rqs_wimg_bytes(const nf_flow_desc *desc) { return (size_t)2 * desc->nlayers * rqs_geo_size(desc) * sizeof(float); }
@@ -1309,7 +1456,7 @@ int nf_rqs_reduce_slabs(nf_ctx *ctx, const nf_flow_desc *desc, const float *slab
 
 template <class G>
 static int launch_rqs_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, float *xt, long N, float *ladj,
-                            int k_only, const RqsFusedArgs *fused = nullptr) {
+                            int k_only, const RqsFusedArgs *fused = nullptr, void *tape = nullptr) {
   // two double-buffered images + target parameters and per-wave sums of the fused variant
   const size_t lds = (2 * (size_t)G::SIZE + 2 * 64 * G::CB + 2) * sizeof(float) + 8 * sizeof(double);
   static AttrOnce attr_once;  // once per device: a context on another GPU needs its own
@@ -1320,6 +1467,7 @@ static int launch_rqs_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse,
     return NF_OK;
   }));
   RqsChainArgs a;
+  a.tape = rqs_tape_at(desc, N, tape);
   a.wimg = (const float *)ctx->wimg;
   a.d = desc->d; a.ncoup = 2 * desc->nlayers; a.B = desc->B; a.N = N; a.k_only = k_only;
   const long ngroups = ((N + NF_TILE - 1) / NF_TILE + 7) / 8;
@@ -1347,22 +1495,23 @@ long nf_rqs_chain_grid(nf_ctx *ctx, long N) {
 // of pscale * elbo_j.
 int nf_rqs_chain_elbo(nf_ctx *ctx, const nf_flow_desc *desc, long N, uint64_t seed, uint64_t off, uint32_t stream,
                       const float *mu, const float *var, float *yt, float *gt, double gscale, double *partial,
-                      double pscale) {
+                      double pscale, void *tape) {
   const int id = rqs_geo_id(desc);
   if (!id || !ctx->wimg) return NF_ERR_UNSUPPORTED;
   RqsFusedArgs fa;
   fa.k0 = (uint32_t)seed; fa.k1 = (uint32_t)(seed >> 32); fa.stream = stream; fa.off = off;
   fa.mu = mu; fa.var = var; fa.gt = gt; fa.gscale = (float)gscale; fa.partial = partial; fa.pscale = pscale;
-#define RQS_CALL(G) launch_rqs_chain<G>(ctx, desc, false, yt, N, nullptr, -1, &fa)
+#define RQS_CALL(G) launch_rqs_chain<G>(ctx, desc, false, yt, N, nullptr, -1, &fa, tape)
   return RQS_DISPATCH(id, RQS_CALL);
 #undef RQS_CALL
 }
 
 // whole chain (k_only < 0) or a single coupling (flat index k_only), in place on the tiled buffer
-int nf_rqs_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, float *xt, long N, float *ladj, int k_only) {
+// tape (optional): the spline tape the reverse kernels need (nf_rqs_tape_bytes)
+int nf_rqs_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, float *xt, long N, float *ladj, int k_only, void *tape) {
   const int id = rqs_geo_id(desc);
   if (!id || !ctx->wimg) return NF_ERR_UNSUPPORTED;
-#define RQS_CALL(G) launch_rqs_chain<G>(ctx, desc, inverse, xt, N, ladj, k_only)
+#define RQS_CALL(G) launch_rqs_chain<G>(ctx, desc, inverse, xt, N, ladj, k_only, nullptr, tape)
   return RQS_DISPATCH(id, RQS_CALL);
 #undef RQS_CALL
 }
@@ -1376,7 +1525,7 @@ int nf_rqs_bwd_grid(nf_ctx *ctx, long N) {
 
 template <class G, bool INVD>
 static int launch_rqs_bwd_coop(nf_ctx *ctx, const nf_flow_desc *desc, int k, float *y, float *ybar, const float *lbar,
-                               float lbar_const, long N, float *slab, long slab_stride, int grid) {
+                               float lbar_const, long N, float *slab, long slab_stride, int grid, void *tape) {
   const size_t lds = RqsCoopLds<G>::BYTES;
   static AttrOnce attr_once;  // once per device
   NF_TRY(attr_once.run(ctx->device, [&]() -> int {
@@ -1385,9 +1534,12 @@ static int launch_rqs_bwd_coop(nf_ctx *ctx, const nf_flow_desc *desc, int k, flo
   }));
   const CouplingInfo ci = nf_coupling_info(desc, k);
   RqsBwdArgs a;
+  a.tape = rqs_tape_at(desc, N, tape);
+  a.k = k;
+  a.ncoup = 2 * desc->nlayers;
   a.img = (const float *)ctx->wimg + (size_t)k * G::SIZE;
   a.d = desc->d; a.c = ci.c; a.m = ci.m; a.par_t = ci.par_t; a.B = desc->B; a.N = N;
-  a.trace = nullptr;
+  a.trace = (long long *)ctx->trace;
   ProfScope ps(ctx, INVD ? "rqs_bwd_inv" : "rqs_bwd");
   hipLaunchKernelGGL((k_rqs_bwd_coop<G, INVD>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, y, ybar, lbar, lbar_const,
                      slab + (long)k * G::SIZE, slab_stride);
@@ -1396,10 +1548,11 @@ static int launch_rqs_bwd_coop(nf_ctx *ctx, const nf_flow_desc *desc, int k, flo
 
 template <class G, bool INVD>
 static int launch_rqs_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, float *y, float *ybar, const float *lbar,
-                          float lbar_const, long N, float *slab, long slab_stride, int grid) {
+                          float lbar_const, long N, float *slab, long slab_stride, int grid, void *tape) {
+  if (!tape) return NF_ERR_ARG;  // the reverse kernels differentiate the forward's own bins (RqsTape)
   if constexpr (G::NCH == 4) {
     static const bool old_form = std::getenv("NF_RQS_BWD_PERWAVE") != nullptr;  // A/B switch: the per-wave-tile kernel
-    if (!old_form || G::OB3 > 12) return launch_rqs_bwd_coop<G, INVD>(ctx, desc, k, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid);
+    if (!old_form || G::OB3 > 12) return launch_rqs_bwd_coop<G, INVD>(ctx, desc, k, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid, tape);
   }
   if constexpr (G::OB3 > 12) {  // the per-wave-tile kernel would need more accumulators than there are registers
     return NF_ERR_UNSUPPORTED;
@@ -1412,6 +1565,9 @@ static int launch_rqs_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, float *y
   }));
   const CouplingInfo ci = nf_coupling_info(desc, k);
   RqsBwdArgs a;
+  a.tape = rqs_tape_at(desc, N, tape);
+  a.k = k;
+  a.ncoup = 2 * desc->nlayers;
   a.img = (const float *)ctx->wimg + (size_t)k * G::SIZE;
   a.d = desc->d; a.c = ci.c; a.m = ci.m; a.par_t = ci.par_t; a.B = desc->B; a.N = N;
   a.trace = (long long *)ctx->trace;
@@ -1424,20 +1580,21 @@ static int launch_rqs_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, float *y
 
 // inv_dir: reverse pass of the INVERSE coupling k at its output (see rqs_bwd_tile)
 int nf_rqs_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, float *y, float *ybar, const float *lbar, float lbar_const,
-               long N, float *slab, long slab_stride, int grid, bool inv_dir) {
+               long N, float *slab, long slab_stride, int grid, bool inv_dir, void *tape) {
   const int id = rqs_geo_id(desc);
   if (!id || !ctx->wimg) return NF_ERR_UNSUPPORTED;
-#define RQS_CALL(G) launch_rqs_bwd<G, true>(ctx, desc, k, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid)
+#define RQS_CALL(G) launch_rqs_bwd<G, true>(ctx, desc, k, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid, tape)
   if (inv_dir) return RQS_DISPATCH(id, RQS_CALL);
 #undef RQS_CALL
-#define RQS_CALL(G) launch_rqs_bwd<G, false>(ctx, desc, k, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid)
+#define RQS_CALL(G) launch_rqs_bwd<G, false>(ctx, desc, k, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid, tape)
   return RQS_DISPATCH(id, RQS_CALL);
 #undef RQS_CALL
 }
 
 template <class G, bool INVD>
 static int launch_rqs_bwd_all(nf_ctx *ctx, const nf_flow_desc *desc, float *y, float *ybar, const float *lbar,
-                              float lbar_const, long N, float *slab, long slab_stride, int grid) {
+                              float lbar_const, long N, float *slab, long slab_stride, int grid, void *tape) {
+  if (!tape) return NF_ERR_ARG;
   const size_t lds = RqsLds<G>::BYTES;
   static AttrOnce attr_once;  // once per device
   NF_TRY(attr_once.run(ctx->device, [&]() -> int {
@@ -1445,6 +1602,7 @@ static int launch_rqs_bwd_all(nf_ctx *ctx, const nf_flow_desc *desc, float *y, f
     return NF_OK;
   }));
   RqsBwdAllArgs aa;
+  aa.tape = rqs_tape_at(desc, N, tape);
   aa.wimg = (const float *)ctx->wimg;
   aa.trace = (long long *)ctx->trace;
   aa.d = desc->d; aa.ncoup = 2 * desc->nlayers; aa.B = desc->B; aa.N = N;
@@ -1456,14 +1614,14 @@ static int launch_rqs_bwd_all(nf_ctx *ctx, const nf_flow_desc *desc, float *y, f
 
 // every coupling of the chain in one launch (flat order; inv_dir: forward execution order, see rqs_bwd_tile)
 int nf_rqs_bwd_all(nf_ctx *ctx, const nf_flow_desc *desc, float *y, float *ybar, const float *lbar, float lbar_const,
-                   long N, float *slab, long slab_stride, int grid, bool inv_dir) {
+                   long N, float *slab, long slab_stride, int grid, bool inv_dir, void *tape) {
   const int id = rqs_geo_id(desc);
   if (!id || !ctx->wimg) return NF_ERR_UNSUPPORTED;
   if (id == 3) return NF_ERR_UNSUPPORTED;  // GeoK10L: cooperative per-coupling launches only
   if (inv_dir) {
-    if (id == 1) return launch_rqs_bwd_all<GeoK8, true>(ctx, desc, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid);
-    return launch_rqs_bwd_all<GeoK10, true>(ctx, desc, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid);
+    if (id == 1) return launch_rqs_bwd_all<GeoK8, true>(ctx, desc, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid, tape);
+    return launch_rqs_bwd_all<GeoK10, true>(ctx, desc, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid, tape);
   }
-  if (id == 1) return launch_rqs_bwd_all<GeoK8, false>(ctx, desc, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid);
-  return launch_rqs_bwd_all<GeoK10, false>(ctx, desc, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid);
+  if (id == 1) return launch_rqs_bwd_all<GeoK8, false>(ctx, desc, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid, tape);
+  return launch_rqs_bwd_all<GeoK10, false>(ctx, desc, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid, tape);
 }

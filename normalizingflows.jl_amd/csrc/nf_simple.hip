@@ -81,8 +81,8 @@ struct Fm<float> {
     const float e = __expf(2.f * x);  // inf -> 1, 0 -> -1
     return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
   }
-  static __device__ __forceinline__ float log_(float x) { return __logf(x); }
-  static __device__ __forceinline__ float log1p_(float x) { return __logf(1.f + x); }
+  static __device__ __forceinline__ float log_(float x) { return nf_log(x); }
+  static __device__ __forceinline__ float log1p_(float x) { return nf_log(1.f + x); }
   static __device__ __forceinline__ float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
   static __device__ __forceinline__ float div_(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 };

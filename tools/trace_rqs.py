@@ -25,6 +25,24 @@ lib.nf_elbo_value_and_grad(ctx.ptr, C.byref(flow.desc), C.byref(tgt.c), vp(flow.
 buf = (C.c_int64 * 128)()
 lib.nf_debug_trace(ctx.ptr, 0, buf, 128)
 t = list(buf)
+if os.environ.get("NF_RQS_BWD_PERWAVE") is None:
+    # cooperative kernel (the default): block 0 / wave 0, first tile group
+    print(f"home: loads + L1 + L2 + transposes   +{t[1] - t[0]:7d}   (MFMA-ideal 2048)")
+    print(f"barrier B0                           +{t[2] - t[1]:7d}")
+    prev = t[2]
+    for k in range(4):
+        b = 3 + 6 * k
+        print(f"tile {k}: a2 reload + L3 chunk GEMM     +{t[b] - prev:7d}   (3072)")
+        print(f"        spline inverse + reverse (x2)  +{t[b + 1] - t[b]:7d}")
+        print(f"        dX3 chunk + slot write         +{t[b + 2] - t[b + 1]:7d}   (3072)")
+        print(f"        dW3 (3 x transpose + GEMM)     +{t[b + 3] - t[b + 2]:7d}   (3072)")
+        print(f"        barrier B1 + d2 sum            +{t[b + 4] - t[b + 3]:7d}")
+        print(f"        barrier B2                     +{t[b + 5] - t[b + 4]:7d}")
+        prev = t[b + 5]
+    print(f"home: layers 2 and 1 + stores        +{t[27] - prev:7d}   (MFMA-ideal 4096)")
+    print(f"group total {t[27] - t[0]}  (MFMA-ideal {672 * 64})")
+    sys.exit(0)
+
 print(f"loads + L1 + L2 (+stash)        +{t[1] - t[0]:7d}   (MFMA-ideal 2048)")
 for ch in range(4):
     b = 2 + 4 * ch
