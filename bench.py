@@ -86,7 +86,8 @@ def select_cfg3(world: int):
     FLOPS_STEP_PER_SAMPLE = 638976
     WORKLOAD_TEXT = ("reverse-KL ELBO step: NSF d=32, 8 rational-quadratic spline couplings (K=8, B=5), conditioner 16-32-32-368 "
                      "(hdims [32,32]), diag-Gaussian target, Philox base draws, Adam")
-    DOMINANT = (b"rqs_bwd", "k_rqs_bwd (reverse pass of the spline couplings: recompute + spline reverse + dX + dW)")
+    DOMINANT = (b"rqs_bwd", "k_rqs_bwd_coop (reverse pass of one spline coupling per launch: conditioner recompute, spline reverse "
+                            "pass at the forward's taped bins, dX + dW)")
     KERNEL_NAMES = (b"base_sample", b"pack_weights", b"rqs_chain", b"target", b"rqs_bwd", b"reduce_slabs", b"adam")
 
 
