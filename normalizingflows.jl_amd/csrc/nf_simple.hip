@@ -558,6 +558,106 @@ __device__ __forceinline__ void layer_bwd(int lk, const T *c, int d, int i0, int
   }
 }
 
+// ---- k_simple_step's form of the two layers: ONE stashed scalar per (sample, layer) ----------------------------------
+// A planar layer's input is recoverable from its output and t = tanh(w'z + b):  z = y - uhat t;  a radial layer's from
+// r = ||z - z0||:  z = z0 + (y - z0) / (1 + beta_hat h), h = 1 / (alpha + r).  So the training step keeps t (resp. r)
+// of every layer -- one register per layer instead of DPL -- walks the state back alongside the cotangent, and the reverse
+// pass starts from the stashed scalar instead of recomputing the dot product / norm, its lane reduction and the tanh /
+// sqrt.  Both maps are smooth, so the reconstruction (one rounding per layer) moves nothing discretely.
+template <class T, int DPL>
+__device__ __forceinline__ T layer_forward_s(int lk, const T *c, int d, int i0, bool vec, T (&z)[DPL], T &keep) {
+  T p0[DPL];
+  row_load<T, DPL>(c, i0, d, vec, p0);
+  if (lk == LK_PLANAR) {
+    T dot = 0;
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) dot += p0[k] * z[k];
+    const T t = Fm<T>::tanh_(g16sum(dot) + c[2 * d]);
+    keep = t;
+    T uh[DPL];
+    row_load<T, DPL>(c + d, i0, d, vec, uh);
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) z[k] += uh[k] * t;
+    return Fm<T>::log_(c[2 * d + 1] * ((T)1 - t * t) + t * t);
+  }
+  const T alpha = c[d], bh = c[d + 1];
+  T ss = 0;
+#pragma unroll
+  for (int k = 0; k < DPL; ++k) {
+    const T dl = (i0 + k < d) ? z[k] - p0[k] : (T)0;
+    ss += dl * dl;
+  }
+  const T r = Fm<T>::sqrt_(g16sum(ss));
+  keep = r;
+  const T h = Fm<T>::div_((T)1, alpha + r);
+#pragma unroll
+  for (int k = 0; k < DPL; ++k)
+    if (i0 + k < d) z[k] += bh * h * (z[k] - p0[k]);
+  return (T)(d - 1) * Fm<T>::log1p_(bh * h) + Fm<T>::log1p_(bh * h - bh * h * h * r);
+}
+
+// z: the layer's OUTPUT on entry, its INPUT on exit;  g: dL/d(output) -> dL/d(input);  parameter sums as layer_bwd
+template <class T, int DPL>
+__device__ __forceinline__ void layer_bwd_s(int lk, const T *c, int d, int i0, int q, bool vec, T (&z)[DPL], T (&g)[DPL], T lb,
+                                            T keep, T (&acc0)[DPL], T (&acc1)[DPL], T &s0, T &s1) {
+  T p0[DPL];
+  row_load<T, DPL>(c, i0, d, vec, p0);
+  if (lk == LK_PLANAR) {
+    T uh[DPL];
+    row_load<T, DPL>(c + d, i0, d, vec, uh);
+    const T t = keep;
+    T ug = 0;
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) {
+      z[k] -= uh[k] * t;  // the layer input
+      ug += uh[k] * g[k];
+    }
+    const T sp = c[2 * d + 1], cc = sp - (T)1;
+    ug = g16sum(ug);
+    const T gg = (T)1 - t * t, D = sp * gg + t * t, iD = Fm<T>::div_((T)1, D);
+    const T ab = ug * gg - (T)2 * lb * cc * t * gg * iD;
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) {
+      acc0[k] += ab * z[k];  // wbar_raw
+      acc1[k] += t * g[k];   // uhat_bar
+      g[k] += p0[k] * ab;    // zbar
+    }
+    if (q == 0) {
+      s0 += ab;            // bbar
+      s1 += lb * gg * iD;  // cbar
+    }
+    return;
+  }
+  const T alpha = c[d], bh = c[d + 1];
+  const T r = keep;
+  const T h = Fm<T>::div_((T)1, alpha + r);
+  const T qq = bh * h, bah2 = bh * alpha * h * h;
+  const T iq = Fm<T>::div_((T)1, (T)1 + qq), ib = Fm<T>::div_((T)1, (T)1 + bah2), ir = r > (T)0 ? Fm<T>::div_((T)1, r) : (T)0;
+  T dl[DPL], yd = 0;
+#pragma unroll
+  for (int k = 0; k < DPL; ++k) {
+    dl[k] = (i0 + k < d) ? (z[k] - p0[k]) * iq : (T)0;  // y - z0 = delta (1 + beta_hat h)
+    if (i0 + k < d) z[k] = p0[k] + dl[k];               // the layer input
+    yd += g[k] * dl[k];
+  }
+  yd = g16sum(yd);
+  const T dL_dh = (T)(d - 1) * bh * iq + (T)2 * bh * alpha * h * ib;
+  const T dL_db = (T)(d - 1) * h * iq + alpha * h * h * ib;
+  const T dL_da = bh * h * h * ib;
+  const T hbar = bh * yd + lb * dL_dh;
+  const T rbar_over_r = -h * h * hbar * ir;
+#pragma unroll
+  for (int k = 0; k < DPL; ++k) {
+    const T db = qq * g[k] + rbar_over_r * dl[k];
+    acc0[k] -= db;  // z0bar
+    g[k] += db;     // zbar
+  }
+  if (q == 0) {
+    s0 += -h * h * hbar + lb * dL_da;  // alpha_bar
+    s1 += h * yd + lb * dL_db;         // betahat_bar
+  }
+}
+
 // layers per pass of the reverse kernel: as many as ~64 accumulator registers per thread allow (at most 4)
 template <class T, int DPL>
 struct BwdCfg {
@@ -710,15 +810,22 @@ __global__ __launch_bounds__(SB, 2) void k_simple_step(SimpleArgs a, const T *__
 #pragma unroll
     for (int k = 0; k < DPL; ++k) ss += z[k] * z[k];
     const T logq = (T)(-0.5 * 1.8378770664093453 * d) - (T)0.5 * g16sum(ss);
-    // forward: layers execute last-listed first (src/flows/utils.jl:23-26); zs[l] = input of flat layer l
-    T zs[NLMAX][DPL];
+    // forward: layers execute last-listed first (src/flows/utils.jl:23-26).  Planar / radial: one scalar per layer is
+    // kept (layer_forward_s); mean-field: zs[l] = input of flat layer l (two trivial layers)
+    constexpr bool SCALAR = KIND != NF_KIND_MEANFIELD;
+    T zs[SCALAR ? 1 : NLMAX][DPL];
+    T ks[SCALAR ? NLMAX : 1];
     T lsum = 0;
 #pragma unroll
     for (int l = NLMAX - 1; l >= 0; --l) {
       if (l < nl) {
+        if constexpr (SCALAR) {
+          lsum += layer_forward_s<T, DPL>(layer_kind(KIND, l), cache + (long)l * LP, d, i0, vec, z, ks[l]);
+        } else {
 #pragma unroll
-        for (int k = 0; k < DPL; ++k) zs[l][k] = z[k];
-        lsum += layer_forward<T, DPL>(layer_kind(KIND, l), cache + (long)l * LP, d, i0, vec, z);
+          for (int k = 0; k < DPL; ++k) zs[l][k] = z[k];
+          lsum += layer_forward<T, DPL>(layer_kind(KIND, l), cache + (long)l * LP, d, i0, vec, z);
+        }
       }
     }
     // target log-density, ybar = gscale * grad log p(y), ELBO term
@@ -753,12 +860,18 @@ __global__ __launch_bounds__(SB, 2) void k_simple_step(SimpleArgs a, const T *__
       acc = g16sum(acc);
       if (q == 0) contrib += fu.pscale * (double)(acc - logq + lsum);
     }
-    // reverse: flat order = reverse of execution order; the cotangent never leaves the registers
+    // reverse: flat order = reverse of execution order; the cotangent never leaves the registers, and (planar / radial)
+    // the state z walks back from the flow output to the base draw alongside it
 #pragma unroll
     for (int l = 0; l < NLMAX; ++l) {
-      if (l < nl)
-        layer_bwd<T, DPL, false>(layer_kind(KIND, l), cache + (long)l * LP, d, i0, q, vec, zs[l], g, lbar_const, acc0[l],
-                                 acc1[l], s0[l], s1[l]);
+      if (l < nl) {
+        if constexpr (SCALAR)
+          layer_bwd_s<T, DPL>(layer_kind(KIND, l), cache + (long)l * LP, d, i0, q, vec, z, g, lbar_const, ks[l], acc0[l],
+                              acc1[l], s0[l], s1[l]);
+        else
+          layer_bwd<T, DPL, false>(layer_kind(KIND, l), cache + (long)l * LP, d, i0, q, vec, zs[l], g, lbar_const, acc0[l],
+                                   acc1[l], s0[l], s1[l]);
+      }
     }
   }
   // deterministic block reduction of the parameter sums: the wave's 4 sample groups by shuffles, then the 4 waves
@@ -1139,7 +1252,9 @@ static int step_launch(nf_ctx *ctx, SimpleArgs a, const void *theta, const void 
 }
 
 // smallest unroll bound that holds nl layers
-static inline int step_bound(int nl) { return nl <= 4 ? 4 : 12; }  // two unroll bounds keep the instantiation count (and the build time) down
+// three unroll bounds (4, 10, 12): unused slots still cost their accumulator registers, and ten layers is the shape of
+// BASELINE cfg 1 and of the reference's planar / radial tests (test/flow.jl:137,203)
+static inline int step_bound(int nl) { return nl <= 4 ? 4 : nl <= 10 ? 10 : 12; }
 
 template <class T, int DPL, int KIND>
 static int step_dpl(nf_ctx *ctx, const SimpleArgs &a, const void *theta, const void *xs, const SimpleFused &fu,
@@ -1149,6 +1264,8 @@ static int step_dpl(nf_ctx *ctx, const SimpleArgs &a, const void *theta, const v
   if constexpr (KIND == NF_KIND_MEANFIELD) return step_launch<T, DPL, KIND, 2>(ctx, a, theta, xs, fu, lbar_const, slabs, nb_out);
   if constexpr (BUDGET >= 4)
     if (nb == 4) return step_launch<T, DPL, KIND, 4>(ctx, a, theta, xs, fu, lbar_const, slabs, nb_out);
+  if constexpr (BUDGET >= 10)
+    if (nb == 10) return step_launch<T, DPL, KIND, 10>(ctx, a, theta, xs, fu, lbar_const, slabs, nb_out);
   if constexpr (BUDGET >= 12)
     if (nb == 12) return step_launch<T, DPL, KIND, 12>(ctx, a, theta, xs, fu, lbar_const, slabs, nb_out);
   return NF_ERR_UNSUPPORTED;
@@ -1170,7 +1287,7 @@ static int step_kind(nf_ctx *ctx, const SimpleArgs &a, const void *theta, const 
 static int step_nlmax(const nf_flow_desc *desc) {
   if (desc->kind == NF_KIND_MEANFIELD) return 2;
   const int budget = (desc->dtype == NF_DTYPE_F64 ? 32 : 64) / dpl_for(desc->d);
-  return budget >= 12 ? 12 : budget >= 4 ? 4 : 0;
+  return budget >= 12 ? 12 : budget >= 10 ? 10 : budget >= 4 ? 4 : 0;
 }
 
 // flows whose every layer input fits the register budget of k_simple_step and whose caches + reduction rows fit LDS
