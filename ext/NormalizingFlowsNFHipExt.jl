@@ -145,10 +145,11 @@ function desc_of(flow::Bijectors.TransformedDistribution)
 end
 
 # Mixed bijector families: maximal runs of one family become the segments of an NF_KIND_COMPOSITE descriptor (flat
-# order, first = outermost).  The segment array must outlive the descriptor: SEGMENT_ROOTS keeps it (descriptors are
-# tiny and flows are few; a finaliser-free global is the simplest correct owner).
+# order, first = outermost).  The segment array must outlive the descriptor: SEGMENT_ROOTS owns ONE array per distinct
+# segment list (keyed by the segments' own bits -- desc_of runs on every rand / nfhip(flow) call, and a push-only list
+# would grow without bound in a sampling loop).
 const NF_KIND_COMPOSITE = Int32(6)
-const SEGMENT_ROOTS = Vector{NFDesc}[]
+const SEGMENT_ROOTS = Dict{Vector{NFDesc},Vector{NFDesc}}()
 family(l) = l isa Bijectors.PlanarLayer ? :planar : l isa Bijectors.RadialLayer ? :radial : l isa AffineCoupling ? :realnvp :
             l isa NeuralSplineCoupling ? :nsf : error("nfhip: no device kernels for a $(typeof(l)) layer")
 function composite_desc(Ls, ::Type{T}, d::Int32) where {T}
@@ -162,7 +163,7 @@ function composite_desc(Ls, ::Type{T}, d::Int32) where {T}
         push!(segs, desc_of(fake))          # a single-family run: one of the branches above
         i = j + 1
     end
-    push!(SEGMENT_ROOTS, segs)
+    segs = get!(SEGMENT_ROOTS, segs, segs)   # the array whose pointer goes into the descriptor stays rooted here
     nohid = ntuple(_ -> Int32(0), 4)
     return NFDesc(NF_KIND_COMPOSITE, dtype_code(T), d, Int32(1), 0, nohid, 0, 0.0f0, C_NULL, C_NULL,
                   Int32(length(segs)), Ptr{Cvoid}(pointer(segs)))

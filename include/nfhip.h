@@ -222,7 +222,8 @@ int nf_layer_apply(nf_ctx *ctx, const nf_flow_desc *desc, int32_t layer, int32_t
  * the flow in float32), leaves the tape intact (it may be called again) and costs what the built-in training step's
  * reverse pass costs.  nf_tape_bytes depends on the context's nf_ctx_set_stash_budget setting (0 = keep only the flow
  * output and recompute by inversion): both calls must run under the setting the size was queried with.
- * y_out may alias x_in; xbar_out may alias ybar; gtheta_out[P] is overwritten. */
+ * y_out may alias x_in; xbar_out may alias ybar, or be NULL for a single-family float32 coupling flow on the MFMA
+ * kernels when only the parameter gradient is wanted (NF_ERR_ARG otherwise); gtheta_out[P] is overwritten. */
 int64_t nf_tape_bytes(nf_ctx *ctx, const nf_flow_desc *desc, int64_t N);
 int nf_flow_fwd_keep(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *x_in, int64_t N,
                      void *y_out, void *ladj_out, void *tape, size_t tape_bytes);

@@ -943,6 +943,7 @@ static int tape_bwd_seg(nf_ctx *ctx, const nf_flow_desc *g, const void *theta, c
                        (float *)gtheta_out, nullptr, 0, nullptr,
                        rqs_tape_b(g, N) ? (char *)const_cast<void *>(tape) + carve_bytes(te * 4) : nullptr));
   }
+  if (!xbar_out) return NF_OK;  // the caller wants the parameter gradient only (the base draws are constants, elbo.jl:94)
   return nf_launch_layout_convert(ctx, g->d, N, gt, (float *)xbar_out, 0);
 }
 
@@ -1013,8 +1014,11 @@ extern "C" int nf_flow_fwd_keep(nf_ctx *ctx, const nf_flow_desc *desc, const voi
 
 extern "C" int nf_flow_bwd_kept(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *tape, size_t tape_bytes,
                                 const void *ybar, const void *lbar, int64_t N, void *xbar_out, void *gtheta_out) {
-  if (!ctx || !theta || !tape || !ybar || !lbar || !xbar_out || !gtheta_out || N < 0 || ((uintptr_t)tape & 255)) return NF_ERR_ARG;
+  if (!ctx || !theta || !tape || !ybar || !lbar || !gtheta_out || N < 0 || ((uintptr_t)tape & 255)) return NF_ERR_ARG;
   NF_TRY(check_desc(desc));
+  // xbar_out == NULL (parameter gradient only) is accepted where the cotangent lives in the tiled layout anyway: single-
+  // family coupling flows on the MFMA kernels; it saves the layout conversion of a d x N matrix nobody reads
+  if (!xbar_out && (is_composite(desc) || !is_coupling(desc))) return NF_ERR_ARG;
   NF_HIP(hipSetDevice(ctx->device));
   if (N == 0) return nf_launch_fill(ctx, desc->dtype, gtheta_out, nf_param_count(desc), 0.0);
   if (tape_bytes < tape_bytes_of(ctx, desc, N)) return NF_ERR_WORKSPACE;

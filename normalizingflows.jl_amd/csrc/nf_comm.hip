@@ -33,7 +33,8 @@ struct RcclApi {
 
 RcclApi g_api;
 std::once_flag g_once;
-char g_last_error[256] = "nfhip: librccl.so.1 not found";
+// per thread: the header allows one host thread per GPU, and concurrent RCCL failures must not mix their messages
+thread_local char g_last_error[256] = "nfhip: librccl.so.1 not found";
 
 void load_rccl() {
   void *h = nullptr;

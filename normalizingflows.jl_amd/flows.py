@@ -319,15 +319,24 @@ def rrule_with_logabsdet_jacobian(t: Transform, x: torch.Tensor):
     check(ctx.lib.nf_flow_fwd_keep(ctx.ptr, C.byref(flow.desc), _ptr(theta), _ptr(xm), n, _ptr(y), _ptr(ladj), _ptr(tape),
                                    nbytes))
 
-    def pullback(ybar: torch.Tensor, lbar: torch.Tensor):
+    def pullback(ybar: torch.Tensor, lbar: torch.Tensor, want_xbar: bool = True):
+        """(xbar, gtheta); want_xbar=False returns (None, gtheta) and skips the cotangent's layout conversion where the
+        library allows it (the reverse-KL loss does not differentiate through the base draws, src/objectives/elbo.jl:94)."""
         yb, _ = as_batch(ybar.to(dt))
         lb = lbar.to(dt).reshape(-1).contiguous()
-        xbar = new_batch(d, n, dt, dev)
         g = torch.empty(flow.P, dtype=dt, device=dev)
         c = flow.ctx
+        if not want_xbar:
+            code = c.lib.nf_flow_bwd_kept(c.ptr, C.byref(flow.desc), _ptr(theta), _ptr(tape), nbytes, _ptr(yb), _ptr(lb), n,
+                                          _ptr(None), _ptr(g))
+            if code == 0:
+                return None, g
+            if code != -1:  # NF_ERR_ARG: this flow needs the buffer (composition, or not on the tiled kernels)
+                check(code)
+        xbar = new_batch(d, n, dt, dev)
         check(c.lib.nf_flow_bwd_kept(c.ptr, C.byref(flow.desc), _ptr(theta), _ptr(tape), nbytes, _ptr(yb), _ptr(lb), n,
                                      _ptr(xbar), _ptr(g)))
-        return (xbar[:, 0] if vec else xbar), g
+        return (xbar[:, 0] if vec else xbar) if want_xbar else None, g
 
     if vec:
         return (y[:, 0], ladj[0]), pullback

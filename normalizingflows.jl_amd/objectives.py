@@ -171,7 +171,7 @@ def value_and_gradient(vo, flow: Flow, logp, xs_or_n, rng: Optional[PhiloxRNG] =
     (glp,) = torch.autograd.grad(lp.sum(), yreq)
     elbos = lp.detach() - base_logpdf(flow.dist, xm) + ladj
     lbar = torch.full((n,), -1.0 / ng, dtype=dt, device=dev)
-    _, g = pullback(-glp / ng, lbar)
+    _, g = pullback(-glp / ng, lbar, want_xbar=False)
     return float(-elbos.double().sum() / ng), g
 
 

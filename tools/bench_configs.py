@@ -8,6 +8,11 @@ cfg3  NSF d=32, 8 RQ-spline couplings, K=8, B=5, h=32, batch 131072    (ELBO ste
 cfg4  RealNVP d=256, 16 couplings, h=256, batch 32768 = one GPU's shard of 262144/8  (ELBO step)
 cfg5  RealNVP d=64 inverse + logdet + log q0 on 1 M samples           (loglikelihood)
 cfg5t the same data set, one forward-KL TRAINING step (value + gradient of -loglikelihood, Adam)
+cfg2c cfg 2 with the target as an arbitrary torch `logp` closure: nf_flow_fwd_keep + torch autograd of logp + nf_flow_bwd_kept
+      (the path every user-defined target takes), next to the built-in-target step on the same flow
+gen   the GENERAL coupling kernels (nf_generic64.hip: one thread per sample, scalar loops, atomics) on a shape the MFMA
+      kernels do not build: NSF d=32, hidden [64,64] (the reference's docstring example nsf(q0, [64,64], 8, 3.0, 6),
+      src/flows/neuralspline.jl:215), K=8, batch 131072 -- so that the cost of falling off the MFMA path is on record
 """
 import argparse
 import ctypes as C
@@ -52,8 +57,8 @@ def time_step(flow, tgt, n, steps, warmup=5):
         step(warmup + steps + i)
     torch.cuda.synchronize()
     kern = {}
-    for name in (b"base_sample", b"pack_weights", b"affine_chain", b"rqs_chain", b"simple_apply", b"target", b"affine_bwd",
-                 b"rqs_bwd", b"simple_bwd", b"wide_apply", b"wide_bwd", b"wide_dw", b"reduce_slabs", b"adam"):
+    for name in (b"base_sample", b"pack_weights", b"affine_chain", b"rqs_chain", b"simple_apply", b"simple_step", b"target", b"affine_bwd",
+                 b"rqs_bwd", b"simple_bwd", b"wide_apply", b"wide_bwd", b"wide_dw", b"g64_apply", b"g64_bwd", b"reduce_slabs", b"adam"):
         a, c = C.c_double(0.0), C.c_int64(0)
         lib.nf_prof_read(ctx.ptr, name, C.byref(a), C.byref(c))
         if c.value:
@@ -89,6 +94,72 @@ def main():
     if want("cfg4"):
         flow = nf.realnvp(nf.MvNormal(256), (256, 256), 8, paramtype=torch.float32, device=dev, seed=123)
         res["cfg4_realnvp_d256_h256_n32768_per_gpu"] = time_step(flow, dg(256), 32768, max(5, args.steps // 3), warmup=3)
+    if want("cfg2c"):
+        flow = nf.realnvp(nf.MvNormal(64), (64, 64), 4, paramtype=torch.float32, device=dev, seed=123)
+        tgt = dg(64)
+        mu_t, var_t = tgt.mu, tgt.var
+        c0 = float(-0.5 * torch.log(2 * torch.pi * var_t).sum())
+
+        def logp(ys):  # the same density as the built-in target, written by the "user" in torch
+            return c0 - 0.5 * ((ys - mu_t[:, None]) ** 2 / var_t[:, None]).sum(0)
+
+        n = 65536
+        st = nf.setup(nf.Adam(1e-3), flow.theta)
+        rng = nf.PhiloxRNG(123)
+
+        def closure_step():
+            l, g = nf.value_and_gradient(nf.elbo_batch, flow, logp, n, rng=rng)
+            nf.adam_update(nf.Adam(1e-3), st, flow.theta, g)
+
+        for _ in range(5):
+            closure_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            closure_step()
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / args.steps
+        builtin = time_step(nf.realnvp(nf.MvNormal(64), (64, 64), 4, paramtype=torch.float32, device=dev, seed=123), tgt, n, args.steps)
+        # the built-in target through the SAME Python call (value_and_gradient returns the loss as a host float: one
+        # synchronisation per step in both forms)
+        flow_b = nf.realnvp(nf.MvNormal(64), (64, 64), 4, paramtype=torch.float32, device=dev, seed=123)
+        st_b = nf.setup(nf.Adam(1e-3), flow_b.theta)
+
+        def builtin_step():
+            l, g = nf.value_and_gradient(nf.elbo_batch, flow_b, tgt, n, rng=rng)
+            nf.adam_update(nf.Adam(1e-3), st_b, flow_b.theta, g)
+
+        for _ in range(5):
+            builtin_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            builtin_step()
+        torch.cuda.synchronize()
+        el_b = (time.perf_counter() - t0) / args.steps
+        # the library's share of the closure step, kernel by kernel
+        ctx = nf.context_for(dev)
+        lib.nf_prof_enable(ctx.ptr, 2)
+        for _ in range(3):
+            closure_step()
+        torch.cuda.synchronize()
+        kern = {}
+        for name in (b"base_sample", b"base_logpdf", b"layout_convert", b"pack_weights", b"affine_chain", b"affine_bwd", b"reduce_slabs", b"adam"):
+            a_, c_ = C.c_double(0.0), C.c_int64(0)
+            lib.nf_prof_read(ctx.ptr, name, C.byref(a_), C.byref(c_))
+            if c_.value:
+                kern[name.decode()] = [round(1e3 * a_.value, 1), c_.value // 3]
+        lib.nf_prof_enable(ctx.ptr, 0)
+        res["cfg2c_realnvp_d64_h64_n65536_torch_closure_target"] = {
+            "ms_per_step": round(1e3 * el, 4), "samples_per_s": round(n / el),
+            "builtin_target_same_python_call_ms_per_step": round(1e3 * el_b, 4),
+            "builtin_target_raw_abi_async_ms_per_step": builtin["ms_per_step"],
+            "closure_over_builtin_same_call": round(el / el_b, 3), "library_kernels_us": kern,
+            "note": "closure step = base draws + nf_flow_fwd_keep + the user's torch logp and its autograd + nf_flow_bwd_kept + Adam; "
+                    "both Python forms read the loss back to the host every step"}
+    if want("gen"):
+        flow = nf.nsf(nf.MvNormal(32), (64, 64), 8, 3.0, 3, paramtype=torch.float32, device=dev, seed=123)
+        res["gen_nsf_d32_h64_k8_n131072_general_kernels"] = time_step(flow, dg(32), 131072, max(3, args.steps // 10), warmup=2)
     if not want("cfg5"):
         for k, v in res.items():
             print(k, json.dumps(v))
