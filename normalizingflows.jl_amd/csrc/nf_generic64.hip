@@ -9,7 +9,10 @@
 // (Optimisers.destructure order: Dense weight out x in column-major, i.e. W[i * nout + j]), the
 // spline in the flow's element type.  It is a correctness path for the sizes such flows are used at
 // (tests, small problems) -- not tuned, and never on the benchmark path.  Parameter gradients are
-// accumulated with atomics (summation order is not fixed).
+// DETERMINISTIC since round 3: a workgroup is one wavefront, every dW element is summed over the wave's 64 samples by a
+// fixed shuffle tree and written (lane 0) to the workgroup's own slab; k_reduce_slabs adds the slabs in order.  (Rounds
+// 1-2 issued one atomicAdd per parameter per sample: 60 ms per coupling at NSF d=32 / hidden 64 / 131 072 samples, and a
+// summation order that changed from run to run.)
 //
 // Reference arithmetic: src/flows/realnvp.jl:57-110, src/flows/neuralspline.jl:65-140,
 // src/flows/utils.jl:71-100; MonotonicSplines 0.3.3 as restated in oracle/nf_oracle.py.
@@ -57,24 +60,43 @@ __device__ void g64_net_fwd(const T *__restrict__ th, const G64Net &n, const T *
   }
 }
 
-// reverse pass of g64_net_fwd: delta (cotangent of the output, overwritten) -> din; parameter
-// gradients are added atomically to g
+// sum over the 64 lanes (= samples) of the wavefront, the same tree on every run
+template <class T>
+__device__ __forceinline__ T g64_wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// reverse pass of g64_net_fwd: delta (cotangent of the output, overwritten) -> din; parameter gradients: the wave's
+// sum over its samples goes to slab[theta index - slab_off] (this workgroup's slab; `first`: overwrite, else add --
+// a workgroup that walks several sample tiles accumulates in its slab).  Must be called by all 64 lanes (lanes
+// without a sample carry delta = 0).
 template <class T, class SZ>
 __device__ void g64_net_bwd(const T *__restrict__ th, const G64Net &n, const T *in,
-                            T (*acts)[SZ::MAXH], T *delta, T *din, T *__restrict__ g) {
+                            T (*acts)[SZ::MAXH], T *delta, T *din, T *__restrict__ slab, long slab_off, bool first) {
   T tmp[SZ::MAXH];
+  const bool writer = (threadIdx.x & 63) == 0;
   for (int l = n.nl - 1; l >= 0; --l) {
     const int nin = n.dims[l], nout = n.dims[l + 1];
     const T *W = th + n.w[l];
     const T *prev = (l == 0) ? in : acts[l - 1];
-    for (int j = 0; j < nout; ++j)
-      if (delta[j] != (T)0.0) atomicAdd(g + n.b[l] + j, delta[j]);
+    for (int j = 0; j < nout; ++j) {
+      const T v = g64_wave_sum(delta[j]);
+      if (writer) {
+        T *p = slab + (n.b[l] + j - slab_off);
+        *p = first ? v : *p + v;
+      }
+    }
     for (int i = 0; i < nin; ++i) {
       T s = (T)0.0;
       for (int j = 0; j < nout; ++j) {
         s += W[(long)i * nout + j] * delta[j];
-        const T gw = prev[i] * delta[j];
-        if (gw != (T)0.0) atomicAdd(g + n.w[l] + (long)i * nout + j, gw);
+        const T v = g64_wave_sum(prev[i] * delta[j]);
+        if (writer) {
+          T *p = slab + (n.w[l] + (long)i * nout + j - slab_off);
+          *p = first ? v : *p + v;
+        }
       }
       if (l == 0) din[i] = s;
       else tmp[i] = s * (acts[l - 1][i] > (T)0.0 ? (T)1.0 : (T)0.01);  // leaky-ReLU' from the post-activation sign
@@ -245,48 +267,63 @@ __global__ __launch_bounds__(G64_BLOCK) void k_g64_apply(G64Args a, int inverse,
 // reverse pass of one coupling at its INPUT x: gbar holds ybar on entry, xbar on exit.
 // inv != 0: reverse pass of the INVERSE coupling at its OUTPUT x (same point): gbar holds the cotangent of
 // x on entry and of the inverse's input on exit, lbar is the cotangent of ladj_inv.
+// A workgroup (one wavefront) walks sample tiles blockIdx.x, blockIdx.x + gridDim.x, ...; slab: [gridDim.x][Pc] partial
+// parameter gradients of THIS coupling (Pc parameters starting at theta index slab_off).
 template <class T, class SZ>
 __global__ __launch_bounds__(G64_BLOCK) void k_g64_bwd(G64Args a, int inv, const T *__restrict__ theta,
                                                       const T *__restrict__ x, T *gbar,
                                                       const T *__restrict__ lbar, T lbar_const,
-                                                      T *__restrict__ g) {
-  const long j = (long)blockIdx.x * G64_BLOCK + threadIdx.x;
-  if (j >= a.N) return;
-  const T *xr = x + j * a.d;
-  T *gr = gbar + j * a.d;
-  const T lb = lbar ? lbar[j] : lbar_const;
+                                                      T *__restrict__ slabs, long Pc, long slab_off) {
+  static_assert(G64_BLOCK == 64, "one wavefront per workgroup: g64_net_bwd sums over the wave");
+  T *slab = slabs + (long)blockIdx.x * Pc;
+  const long ntiles = (a.N + G64_BLOCK - 1) / G64_BLOCK;
+  bool first = true;
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x, first = false) {
+  const long j = tile * G64_BLOCK + threadIdx.x;
+  const bool valid = j < a.N;  // lanes without a sample run along with zero cotangents (the wave sums need all lanes)
+  const long jr = valid ? j : a.N - 1;
+  const T *xr = x + jr * a.d;
+  T *gr = gbar + jr * a.d;
+  const T vm = valid ? (T)1.0 : (T)0.0;
+  const T lb = (lbar ? lbar[jr] : lbar_const) * vm;
+  auto gld = [&](int idx) { return gr[idx] * vm; };
+  auto gst = [&](int idx, T v) { if (valid) gr[idx] = v; };
   T x2[SZ::MAXC], acts[NF_MAX_HIDDEN][SZ::MAXH], out[SZ::MAXO], din[SZ::MAXC];
   const int par_c = 1 - a.par_t;
   for (int q = 0; q < a.m; ++q) x2[q] = xr[2 * q + par_c];
   if (a.kind == NF_KIND_REALNVP && inv) {
     // x1 = (v1 - t) exp(-s), ladj_inv = -sum s:  v1bar = x1bar exp(-s), sbar = -x1bar x1 - lbar, tbar = -v1bar
+    T v1b[SZ::MAXC];
     g64_net_fwd<T, SZ>(theta, a.net[0], x2, acts, out);
     for (int p = 0; p < a.c; ++p) {
-      const T s = tanh(out[p]), x1 = xr[2 * p + a.par_t], xb = gr[2 * p + a.par_t];
-      gr[2 * p + a.par_t] = xb * exp(-s);
+      const T s = tanh(out[p]), x1 = xr[2 * p + a.par_t], xb = gld(2 * p + a.par_t);
+      v1b[p] = xb * exp(-s);
+      gst(2 * p + a.par_t, v1b[p]);
       out[p] = (-xb * x1 - lb) * ((T)1.0 - s * s);
     }
-    g64_net_bwd<T, SZ>(theta, a.net[0], x2, acts, out, din, g);
-    for (int q = 0; q < a.m; ++q) gr[2 * q + par_c] += din[q];
+    g64_net_bwd<T, SZ>(theta, a.net[0], x2, acts, out, din, slab, slab_off, first);
+    T acc2[SZ::MAXC];
+    for (int q = 0; q < a.m; ++q) acc2[q] = gld(2 * q + par_c) + din[q];
     g64_net_fwd<T, SZ>(theta, a.net[1], x2, acts, out);
-    for (int p = 0; p < a.c; ++p) out[p] = -gr[2 * p + a.par_t];
-    g64_net_bwd<T, SZ>(theta, a.net[1], x2, acts, out, din, g);
-    for (int q = 0; q < a.m; ++q) gr[2 * q + par_c] += din[q];
+    for (int p = 0; p < a.c; ++p) out[p] = -v1b[p];
+    g64_net_bwd<T, SZ>(theta, a.net[1], x2, acts, out, din, slab, slab_off, first);
+    for (int q = 0; q < a.m; ++q) gst(2 * q + par_c, acc2[q] + din[q]);
   } else if (a.kind == NF_KIND_REALNVP) {
     // t net: y1 = x1 exp(s) + t  =>  tbar = ybar1
     g64_net_fwd<T, SZ>(theta, a.net[1], x2, acts, out);
-    for (int p = 0; p < a.c; ++p) out[p] = gr[2 * p + a.par_t];
-    g64_net_bwd<T, SZ>(theta, a.net[1], x2, acts, out, din, g);
-    for (int q = 0; q < a.m; ++q) gr[2 * q + par_c] += din[q];
+    for (int p = 0; p < a.c; ++p) out[p] = gld(2 * p + a.par_t);
+    g64_net_bwd<T, SZ>(theta, a.net[1], x2, acts, out, din, slab, slab_off, first);
+    T acc2[SZ::MAXC];
+    for (int q = 0; q < a.m; ++q) acc2[q] = gld(2 * q + par_c) + din[q];
     // s net: sbar = ybar1 x1 exp(s) + lbar, through tanh
     g64_net_fwd<T, SZ>(theta, a.net[0], x2, acts, out);
     for (int p = 0; p < a.c; ++p) {
-      const T s = tanh(out[p]), es = exp(s), x1 = xr[2 * p + a.par_t], yb = gr[2 * p + a.par_t];
-      gr[2 * p + a.par_t] = yb * es;
+      const T s = tanh(out[p]), es = exp(s), x1 = xr[2 * p + a.par_t], yb = gld(2 * p + a.par_t);
+      gst(2 * p + a.par_t, yb * es);
       out[p] = (yb * x1 * es + lb) * ((T)1.0 - s * s);
     }
-    g64_net_bwd<T, SZ>(theta, a.net[0], x2, acts, out, din, g);
-    for (int q = 0; q < a.m; ++q) gr[2 * q + par_c] += din[q];
+    g64_net_bwd<T, SZ>(theta, a.net[0], x2, acts, out, din, slab, slab_off, first);
+    for (int q = 0; q < a.m; ++q) gst(2 * q + par_c, acc2[q] + din[q]);
   } else {
     g64_net_fwd<T, SZ>(theta, a.net[0], x2, acts, out);
     const int P = 3 * a.K - 1;
@@ -294,12 +331,13 @@ __global__ __launch_bounds__(G64_BLOCK) void k_g64_bwd(G64Args a, int inv, const
     T thb[3 * G64_MAXK];
     for (int p = 0; p < a.c; ++p) {
       g64_build<T>(out + p * P, a.K, (T)a.B, sp);
-      const T xb = g64_spline_bwd<T>(sp, out + p * P, a.K, (T)a.B, xr[2 * p + a.par_t], gr[2 * p + a.par_t], lb, thb, inv != 0);
-      gr[2 * p + a.par_t] = xb;
-      for (int i = 0; i < P; ++i) out[p * P + i] = thb[i];
+      const T xb = g64_spline_bwd<T>(sp, out + p * P, a.K, (T)a.B, xr[2 * p + a.par_t], gld(2 * p + a.par_t), lb, thb, inv != 0);
+      gst(2 * p + a.par_t, xb);
+      for (int i = 0; i < P; ++i) out[p * P + i] = thb[i] * vm;
     }
-    g64_net_bwd<T, SZ>(theta, a.net[0], x2, acts, out, din, g);
-    for (int q = 0; q < a.m; ++q) gr[2 * q + par_c] += din[q];
+    g64_net_bwd<T, SZ>(theta, a.net[0], x2, acts, out, din, slab, slab_off, first);
+    for (int q = 0; q < a.m; ++q) gst(2 * q + par_c, gld(2 * q + par_c) + din[q]);
+  }
   }
 }
 
@@ -361,13 +399,43 @@ static void g64_launch_apply(nf_ctx *ctx, const nf_flow_desc *desc, unsigned gri
   else
     hipLaunchKernelGGL((k_g64_apply<T, G64Large>), dim3(grid), dim3(G64_BLOCK), 0, ctx->stream, a, inverse, theta, x, y, ladj);
 }
+// workgroups (= gradient slabs) of the reverse kernel: one per 64-sample tile up to a cap that keeps the slab area of
+// the largest coupling under 256 MB (a workgroup then walks several tiles, accumulating in its slab)
+static long g64_coupling_params(const nf_flow_desc *desc) {
+  long m = 0;
+  for (int k = 0; k < 2 && k < 2 * desc->nlayers; ++k) {
+    const long p = nf_coupling_info(desc, k).nparams;
+    if (p > m) m = p;
+  }
+  return m;
+}
+static unsigned g64_bwd_blocks(const nf_flow_desc *desc, long N) {
+  const size_t es = desc->dtype == NF_DTYPE_F64 ? 8 : 4;
+  long cap = (long)((size_t)256 << 20) / (long)(g64_coupling_params(desc) * es + 1);
+  cap = cap < 64 ? 64 : cap > 2048 ? 2048 : cap;
+  long nb = (N + G64_BLOCK - 1) / G64_BLOCK;
+  nb = nb > cap ? cap : nb;
+  return (unsigned)(nb < 1 ? 1 : nb);
+}
+static size_t g64_slab_bytes(const nf_flow_desc *desc, long N) {
+  return (((size_t)g64_bwd_blocks(desc, N) * g64_coupling_params(desc) * sizeof(double)) + 255) / 256 * 256;  // sized for f64
+}
+int nf_launch_reduce_slabs(nf_ctx *, int, const void *, int, long, void *);
+
+// reverse kernel of coupling k (partial gradients into `slabs`) + the ordered sum of the slabs into g[theta_off ...]
 template <class T>
-static void g64_launch_bwd(nf_ctx *ctx, const nf_flow_desc *desc, unsigned grid, const G64Args &a, int inv, const T *theta,
-                           const T *x, T *gbar, const T *lbar, T lbar_const, T *g) {
+static int g64_launch_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &a, int inv, const T *theta,
+                          const T *x, T *gbar, const T *lbar, T lbar_const, T *g, T *slabs) {
+  const CouplingInfo ci = nf_coupling_info(desc, k);
+  const unsigned grid = g64_bwd_blocks(desc, a.N);
   if (g64_fits<G64Small>(desc))
-    hipLaunchKernelGGL((k_g64_bwd<T, G64Small>), dim3(grid), dim3(G64_BLOCK), 0, ctx->stream, a, inv, theta, x, gbar, lbar, lbar_const, g);
+    hipLaunchKernelGGL((k_g64_bwd<T, G64Small>), dim3(grid), dim3(G64_BLOCK), 0, ctx->stream, a, inv, theta, x, gbar, lbar, lbar_const,
+                       slabs, ci.nparams, ci.theta_off);
   else
-    hipLaunchKernelGGL((k_g64_bwd<T, G64Large>), dim3(grid), dim3(G64_BLOCK), 0, ctx->stream, a, inv, theta, x, gbar, lbar, lbar_const, g);
+    hipLaunchKernelGGL((k_g64_bwd<T, G64Large>), dim3(grid), dim3(G64_BLOCK), 0, ctx->stream, a, inv, theta, x, gbar, lbar, lbar_const,
+                       slabs, ci.nparams, ci.theta_off);
+  NF_HIP(hipGetLastError());
+  return nf_launch_reduce_slabs(ctx, sizeof(T) == 8 ? NF_DTYPE_F64 : NF_DTYPE_F32, slabs, (int)grid, ci.nparams, g + ci.theta_off);
 }
 
 // couplings [layer_lo, layer_hi) in flat order (forward: applied last-listed first); y may alias x
@@ -394,7 +462,8 @@ int nf_g64_apply(nf_ctx *ctx, const nf_flow_desc *desc, int layer_lo, int layer_
 
 // workspace: the input of every coupling (nc * N * d doubles)
 size_t nf_g64_bwd_ws_bytes(const nf_flow_desc *desc, long N) {
-  return (size_t)2 * desc->nlayers * (size_t)N * desc->d * sizeof(double) + (size_t)N * sizeof(double);  // sized for f64
+  const size_t a = (size_t)2 * desc->nlayers * (size_t)N * desc->d * sizeof(double) + (size_t)N * sizeof(double);  // sized for f64
+  return (a + 255) / 256 * 256 + g64_slab_bytes(desc, N);
 }
 
 // x = flow input; ybar -> xbar_out (may alias), gtheta_out <- dL/dtheta
@@ -405,6 +474,7 @@ static int g64_bwd_t(nf_ctx *ctx, const nf_flow_desc *desc, const T *theta, cons
   const size_t nd = (size_t)N * desc->d;
   T *inputs = (T *)ws;
   T *scr_ladj = inputs + (size_t)nc * nd;
+  T *slabs = (T *)((char *)ws + (((size_t)nc * nd * sizeof(double) + (size_t)N * sizeof(double)) + 255) / 256 * 256);
   const CouplingInfo last = nf_coupling_info(desc, nc - 1);
   const long P = last.theta_off + last.nparams;
   NF_HIP(hipMemsetAsync(gtheta_out, 0, (size_t)P * sizeof(T), ctx->stream));
@@ -428,8 +498,7 @@ static int g64_bwd_t(nf_ctx *ctx, const nf_flow_desc *desc, const T *theta, cons
   for (int k = 0; k < nc; ++k) {  // reverse of execution order
     const G64Args a = make_g64_args(desc, k, N);
     ProfScope ps(ctx, "g64_bwd");
-    g64_launch_bwd<T>(ctx, desc, grid, a, 0, theta, (const T *)(inputs + (size_t)k * nd), xbar_out, lbar, (T)lbar_const, gtheta_out);
-    NF_HIP(hipGetLastError());
+    NF_TRY(g64_launch_bwd<T>(ctx, desc, k, a, 0, theta, (const T *)(inputs + (size_t)k * nd), xbar_out, lbar, (T)lbar_const, gtheta_out, slabs));
   }
   return NF_OK;
 }
@@ -456,14 +525,14 @@ static int g64_bwd_inv_t(nf_ctx *ctx, const nf_flow_desc *desc, const T *theta, 
   NF_HIP(hipMemsetAsync(gtheta_out, 0, (size_t)P * sizeof(T), ctx->stream));
   if (N <= 0) return NF_OK;
   T *scr_ladj = (T *)ws;
+  T *slabs = (T *)((char *)ws + ((size_t)N * sizeof(double) + 255) / 256 * 256);
   NF_HIP(hipMemsetAsync(scr_ladj, 0, (size_t)N * sizeof(T), ctx->stream));
   const unsigned grid = (unsigned)((N + G64_BLOCK - 1) / G64_BLOCK);
   for (int k = nc - 1; k >= 0; --k) {
     const G64Args a = make_g64_args(desc, k, N);
     {
       ProfScope ps(ctx, "g64_bwd");
-      g64_launch_bwd<T>(ctx, desc, grid, a, 1, theta, (const T *)z, gbar, (const T *)nullptr, (T)lbar_const, gtheta_out);
-      NF_HIP(hipGetLastError());
+      NF_TRY(g64_launch_bwd<T>(ctx, desc, k, a, 1, theta, (const T *)z, gbar, (const T *)nullptr, (T)lbar_const, gtheta_out, slabs));
     }
     g64_launch_apply<T>(ctx, desc, grid, a, 0, theta, (const T *)z, z, scr_ladj);
     NF_HIP(hipGetLastError());
@@ -471,7 +540,9 @@ static int g64_bwd_inv_t(nf_ctx *ctx, const nf_flow_desc *desc, const T *theta, 
   return NF_OK;
 }
 
-size_t nf_g64_bwd_inv_ws_bytes(const nf_flow_desc *, long N) { return (size_t)N * sizeof(double); }
+size_t nf_g64_bwd_inv_ws_bytes(const nf_flow_desc *desc, long N) {
+  return ((size_t)N * sizeof(double) + 255) / 256 * 256 + g64_slab_bytes(desc, N);
+}
 
 int nf_g64_bwd_inv(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, void *z, void *gbar, double lbar_const, long N,
                    void *gtheta_out, void *ws) {
