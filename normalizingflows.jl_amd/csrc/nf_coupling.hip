@@ -163,6 +163,16 @@ struct StashGeo {
   static constexpr int SIZE = NET0 + 2 * NETSZ;  // floats per (tile, coupling), a multiple of 4
 };
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// A buffer store of more than 64 bits must not be followed directly by a VALU write of its data registers.  hipcc's hazard
+// recognizer inserts the wait state only when the instruction's soffset is NOT an SGPR (the ISA manual exempts the SGPR
+// form).  Measured on MI355X, the SGPR form races as well: in k_affine_chain<hidden 32, FUSED, STASH> the mask store was
+// followed by `v_add_u32` into its first data register, and lanes 12-15 of every 16-lane row of that word arrived in
+// memory as the sum -- an LDS address -- in most runs with 8 live waves per workgroup (tools/kernel_resources.py,
+// DESIGN.md section 5).  So wide stores pass their whole offset through the VGPR / immediate fields and soffset = 0, which
+// puts them under the compiler's own guard.
+__device__ __forceinline__ void nf_buffer_store_b128(u32x4 v, __amdgpu_buffer_rsrc_t rs, int voff, int coff) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff + coff, 0, 0);
+}
 struct StashIO {
   __amdgpu_buffer_rsrc_t rs;
   int vT, vL;  // per-lane byte offsets: T-layout element stores (C-layout lane), lane-layout rows
@@ -197,7 +207,7 @@ __device__ __forceinline__ void stash_put_lane(const StashIO &st, int base, cons
         const float val = v[b][4 * q + e];
         w[e] = __builtin_bit_cast(unsigned, val);
       }
-      __builtin_amdgcn_raw_buffer_store_b128(w, st.rs, st.vL, (base + b * 1024) * 4 + q * 16, 0);
+      nf_buffer_store_b128(w, st.rs, st.vL, (base + b * 1024) * 4 + q * 16);
     }
 }
 
@@ -228,7 +238,7 @@ __device__ __forceinline__ void net_forward_stash(const float *__restrict__ img,
   dense_fwd<G::H2B, G::CB>(img + G::W3, img + G::B3, a2, out, l31, hi,
                            [&](int e) { stash_put_T<G::H2B>(st, nbase + SG::A2, a2, e); });
   const u32x4 mk = {m1[0], m1[1], m2[0], m2[1]};
-  __builtin_amdgcn_raw_buffer_store_b128(mk, st.rs, (hi * 32 + l31) * 16, (nbase + SG::MSK) * 4, 0);
+  nf_buffer_store_b128(mk, st.rs, (hi * 32 + l31) * 16, (nbase + SG::MSK) * 4);
 }
 
 // forward coupling of the training step: as coupling_step<G, false>, leaving the reverse pass's operands behind
@@ -502,7 +512,7 @@ __device__ __forceinline__ void zero_acc(f32x16 (&a)[IB][OB], float (&b)[OB]) {
 template <int IB, int OB>
 __device__ __forceinline__ void fold_acc(float *__restrict__ w, float *__restrict__ b, const f32x16 (&a)[IB][OB],
                                          const float (&bs)[OB], bool first, int l31, int hi) {
-  constexpr int S = 32 * OB + 1;
+  constexpr int S = 32 * OB + NF_IMG_PAD;
 #pragma unroll
   for (int i = 0; i < IB; ++i)
 #pragma unroll

@@ -92,10 +92,31 @@ struct DenseLds {
 // place them: measured on MI355X, PINNING a VALU/LDS instruction between two fp32 MFMAs costs more
 // than it hides (+6 % on the reverse pass), because back-to-back MFMAs on one accumulator lose their
 // fast issue path -- so this only removes separate loops, it does not buy overlap.
+// Row padding of every LDS weight image, in floats.  4 keeps rows 16-byte aligned, so the transposed (dX) operand fetch
+// is ONE ds_read_b128 per four k-steps (lane <-> row: 8 consecutive rows cover the 32 banks), while the forward fetch
+// (lanes along a row, rows 4 apart for the two half-waves: 4 * S = 16 banks apart) stays conflict-free with ds_read_b32.
+// 1 is the rounds-1/2 odd stride (four ds_read_b32 per four k-steps in the dX GEMMs), kept for A/B measurements.
+#ifndef NF_IMG_PAD
+#define NF_IMG_PAD 4
+#endif
+template <int S>
+__device__ __forceinline__ void nf_ld4(const float *__restrict__ p, float &a, float &b, float &c, float &d) {
+#ifdef NF_LD4_SCALAR
+  if constexpr (false) {
+#else
+  if constexpr (S % 4 == 0) {
+#endif
+    const float4 v = *reinterpret_cast<const float4 *>(p);
+    a = v.x; b = v.y; c = v.z; d = v.w;
+  } else {
+    a = p[0]; b = p[1]; c = p[2]; d = p[3];
+  }
+}
+
 struct NoSideJob {
   __device__ __forceinline__ void operator()(int) const {}
 };
-template <int IB, int OB, int S = 32 * OB + 1, class SJ = NoSideJob>
+template <int IB, int OB, int S = 32 * OB + NF_IMG_PAD, class SJ = NoSideJob>
 __device__ __forceinline__ void dense_fwd(const float *__restrict__ w, const float *__restrict__ b,
                                           const f32x16 (&in)[IB], f32x16 (&out)[OB], int l31, int hi,
                                           SJ sj = SJ()) {
@@ -135,7 +156,7 @@ __device__ __forceinline__ void dense_fwd(const float *__restrict__ w, const flo
 }
 
 // din[ib] = W^T * delta : the dX GEMM of the reverse pass, same register chaining.
-template <int IB, int OB, int S = 32 * OB + 1, bool ACCUM = false, class SJ = NoSideJob>
+template <int IB, int OB, int S = 32 * OB + NF_IMG_PAD, bool ACCUM = false, class SJ = NoSideJob>
 __device__ __forceinline__ void dense_bwd_x(const float *__restrict__ w, const f32x16 (&delta)[OB],
                                             f32x16 (&din)[IB], int l31, int hi, SJ sj = SJ()) {
   constexpr int NG = OB * 4;
@@ -148,9 +169,7 @@ __device__ __forceinline__ void dense_bwd_x(const float *__restrict__ w, const f
   const float *wl = w + l31 * S + 4 * hi;
   float an[IB][4], ac[IB][4];
 #pragma unroll
-  for (int ib = 0; ib < IB; ++ib)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) an[ib][e] = wl[ib * 32 * S + e];
+  for (int ib = 0; ib < IB; ++ib) nf_ld4<S>(wl + ib * 32 * S, an[ib][0], an[ib][1], an[ib][2], an[ib][3]);
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
 #pragma unroll
@@ -159,9 +178,7 @@ __device__ __forceinline__ void dense_bwd_x(const float *__restrict__ w, const f
       for (int e = 0; e < 4; ++e) ac[ib][e] = an[ib][e];
     if (g + 1 < NG) {
 #pragma unroll
-      for (int ib = 0; ib < IB; ++ib)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) an[ib][e] = wl[ib * 32 * S + (g + 1) * 8 + e];
+      for (int ib = 0; ib < IB; ++ib) nf_ld4<S>(wl + ib * 32 * S + (g + 1) * 8, an[ib][0], an[ib][1], an[ib][2], an[ib][3]);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -197,7 +214,7 @@ __device__ __forceinline__ void dense_bwd_x_split(const float *__restrict__ w, c
 #pragma unroll
   for (int ib = 0; ib < IB; ++ib)
 #pragma unroll
-    for (int e = 0; e < GK; ++e) an[ib][e] = wl[ib * 32 * S + 8 * (e / 4) + (e % 4)];
+    for (int e = 0; e < GK; e += 4) nf_ld4<S>(wl + ib * 32 * S + 8 * (e / 4), an[ib][e], an[ib][e + 1], an[ib][e + 2], an[ib][e + 3]);
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
 #pragma unroll
@@ -208,9 +225,9 @@ __device__ __forceinline__ void dense_bwd_x_split(const float *__restrict__ w, c
 #pragma unroll
       for (int ib = 0; ib < IB; ++ib)
 #pragma unroll
-        for (int e = 0; e < GK; ++e) {
+        for (int e = 0; e < GK; e += 4) {
           const int t = (g + 1) * GK + e;
-          an[ib][e] = wl[ib * 32 * S + 8 * (t / 4) + (t % 4)];
+          nf_ld4<S>(wl + ib * 32 * S + 8 * (t / 4), an[ib][e], an[ib][e + 1], an[ib][e + 2], an[ib][e + 3]);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -369,7 +386,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 // Geometry in blocks of 32: MB (conditioner inputs), H1B, H2B (hidden), CB (outputs).
 // PAD = row padding in floats (odd for the 32-sample kernels; 4 for the 16-sample kernel, which
 // reads four consecutive rows' worth of one column group with ds_read_b128).
-template <int MB_, int H1B_, int H2B_, int CB_, int PAD_ = 1>
+template <int MB_, int H1B_, int H2B_, int CB_, int PAD_ = NF_IMG_PAD>
 struct NetGeo {
   static constexpr int MB = MB_, H1B = H1B_, H2B = H2B_, CB = CB_, PAD = PAD_;
   static constexpr int S1 = 32 * H1B + PAD, S2 = 32 * H2B + PAD, S3 = 32 * CB + PAD;

@@ -34,7 +34,7 @@ struct RqsGeo {
   static constexpr int OB3 = OBC * NCH;          // output blocks of the last layer
   static constexpr int NCOLS = OB3 * 32;
   static constexpr int CMAX = 2 * QCH * NCH;     // transformed dims covered
-  static constexpr int S1 = 32 * H1B + 1, S2 = 32 * H2B + 1, S3 = NCOLS + 1;
+  static constexpr int S1 = 32 * H1B + NF_IMG_PAD, S2 = 32 * H2B + NF_IMG_PAD, S3 = NCOLS + NF_IMG_PAD;
   static constexpr int W1 = 0;
   static constexpr int B1 = W1 + 32 * MB * S1;
   static constexpr int W2 = B1 + 32 * H1B;

@@ -110,15 +110,13 @@ __device__ __forceinline__ void wide_bwdx_chunk(const float *__restrict__ ch, co
   float an[4], ac[4];
 #pragma unroll
   for (int r = 0; r < 16; ++r) din[r] = 0.f;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) an[e] = wl[e];
+  nf_ld4<S>(wl, an[0], an[1], an[2], an[3]);
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) ac[e] = an[e];
     if (g + 1 < NG) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) an[e] = wl[(g + 1) * 8 + e];
+      nf_ld4<S>(wl + (g + 1) * 8, an[0], an[1], an[2], an[3]);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
