@@ -16,6 +16,7 @@
 #include <type_traits>
 
 #include "nf_common.h"
+#include "nf_mfma.h"
 #include "nf_philox.h"
 #include "nf_targets.h"
 
@@ -932,6 +933,440 @@ __global__ __launch_bounds__(SB, 2) void k_simple_step(SimpleArgs a, const T *__
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Planar training step on the matrix pipe (k_planar_step): d <= 64, up to 16 layers, Float32.
+// ------------------------------------------------------------------------------------------------------------------
+// A planar layer adds a multiple of ONE fixed vector: z_{e+1} = z_e + uhat_e tanh(w_e'z_e + b_e)
+// (src/flows/planar_radial.jl:21-29, Bijectors.PlanarLayer).  With the layers in flat order (flat layer nl-1 executes
+// first, src/flows/utils.jl:23-26) the state in front of layer l is z0 + sum_{m>l} uhat_m t_m, so
+//     a_l  = w_l'z0 + b_l + sum_{m>l} C[l][m] t_m,     C[l][m] = w_l'uhat_m,        t_l = tanh(a_l),
+//     y    = z0 + Uhat t,
+// and in the reverse sweep (cotangent in front of layer l's output: ybar + sum_{m<l} w_m abar_m)
+//     ug_l   = uhat_l'ybar + sum_{m<l} C[m][l] abar_m,      abar_l = ug_l (1 - t_l^2) + lbar dladj_l/da_l,
+//     wbar_l = sum_j abar_l^j z_l^j   = [Z0 Abar']_l + sum_{m>l} uhat_m G[l][m],    G[l][m] = sum_j abar_l^j t_m^j,
+//     ubar_l = sum_j t_l^j gbar_l^j   = [Ybar T']_l  + sum_{m<l} w_m G[m][l].
+// Every d-length dot product, the state update and every sum over samples is therefore a GEMM with a 32-sample tile on
+// one side -- W Z0, Uhat T, Uhat'Ybar, Z0 Abar', Ybar T', Abar T' -- and what is left per sample is a triangular recurrence
+// over nl scalars.  k_simple_step (16 lanes per sample, DPP reductions, 16-fold redundant scalar math) needs ~1 900
+// VALU instructions per four samples at d = 64 x 10 layers; here a wave issues ~160 MFMAs and ~1 800 VALU instructions
+// per THIRTY-TWO samples (over half of those are the Philox / Box-Muller draws).  Same arithmetic as the reference up to
+// the order of the additions (z_l is never formed; its inner product with w_l is summed term by term).
+//
+// Layout.  A lane holds sample l31 of the tile and the features of the MFMA C layout, f = 32 blk + nf_row(r, hi): whole
+// Philox groups of four, and z0 is at once the B operand of W Z0 and the accumulator that Uhat T is added to.  The
+// K = samples GEMMs need lane <-> feature operands: z0 and ybar take one trip through a per-wave LDS tile (stride 33).
+// The recurrences run in both half-waves (each lane all layers of its sample; v_permlane32_swap gathers the rows the
+// other half holds).  Parameter sums stay in MFMA accumulators over the wave's tiles; the block epilogue adds the waves in
+// a fixed order, applies the two triangular corrections and writes k_simple_step's slab layout (k_simple_finalize).
+template <int DB_, int NLR_>
+struct PlanarGeo {
+  static constexpr int DB = DB_, NLR = NLR_;
+  static constexpr int FD = 32 * DB;                                   // padded feature count
+  static constexpr int NL = NLR <= 4 ? 2 * NLR : NLR <= 6 ? 10 : NLR <= 8 ? 16 : 32;  // layers carried (rows 0 .. NL-1)
+  static constexpr int ECOLS = 8 * ((NLR + 3) / 4);                    // layer columns of the Uhat[f][e] image
+  static constexpr int SW = FD + 4;                                    // row stride of W[e][f], Uhat'[e][f]
+  static constexpr int SU = ECOLS + 4;                                 // row stride of Uhat[f][e]
+  static constexpr int OFF_W = 0;
+  static constexpr int OFF_UT = OFF_W + NL * SW;
+  static constexpr int OFF_U = OFF_UT + NL * SW;
+  static constexpr int OFF_C = OFF_U + FD * SU;                        // C[l][m], NL x NL
+  static constexpr int OFF_B = OFF_C + NL * NL;                        // b[l]
+  static constexpr int OFF_SP = OFF_B + NL;                            // 1 + c_l = softplus(w'u)
+  static constexpr int OFF_TG = OFF_SP + NL;                           // target: mu[f] | 1/var[f] | log 2pi + log var[f]
+  static constexpr int SHARED = ((OFF_TG + 3 * FD + 3) / 4) * 4;
+  static constexpr int OFF_X = 0;                                      // per wave: [FD][33] transposition tile
+  static constexpr int OFF_A = OFF_X + FD * NF_TS;                     //           abar[l][s]
+  static constexpr int OFF_T = OFF_A + NL * NF_TS;                     //           t[l][s]
+  static constexpr int WAVE = ((OFF_T + NL * NF_TS + 3) / 4) * 4;
+  // block epilogue (aliases the waves' tiles): per wave M1[l][f] | M2[l][f] | G[l][m] | s0[l] | s1[l]
+  static constexpr int R_M1 = 0, R_M2 = NL * FD, R_G = 2 * NL * FD, R_S = R_G + NL * NL, REGION = R_S + 2 * NL;
+  static_assert(REGION <= WAVE, "epilogue region must fit a wave's tiles");
+  static constexpr size_t lds_floats(int nl, int lp) { return (size_t)SHARED + 4 * (size_t)WAVE + (size_t)nl * lp; }
+};
+
+__device__ __forceinline__ void planar_gather(float v, float &lo, float &hi) {
+  // lo = the value lane (l31, 0) holds, hi = the value lane (l31, 1) holds, in both half-waves: v_permlane32_swap_b32 of two
+  // copies ([a.lo | b.lo], [a.hi | b.hi]; tools/probe/permlane_probe.hip).  Two things hipcc 7.2 does not do by itself:
+  // the copy must be opaque (identical arguments are folded into one register), and a VALU read of the results needs wait
+  // states after the swap -- without the s_nop the recurrences read stale rows on MI355X (loss 30.6 instead of 42.3 at
+  // d = 64 x 10 layers).
+  unsigned va = __builtin_bit_cast(unsigned, v), vb = va;
+  asm volatile("" : "+v"(vb));
+  const auto r = __builtin_amdgcn_permlane32_swap(va, vb, false, false);
+  unsigned r0 = r[0], r1 = r[1];
+  asm volatile("s_nop 1" : "+v"(r0), "+v"(r1));
+  lo = __builtin_bit_cast(float, r0);
+  hi = __builtin_bit_cast(float, r1);
+}
+__device__ __forceinline__ float planar_xhalf_sum(float v) {
+  float lo, hi;
+  planar_gather(v, lo, hi);
+  return lo + hi;
+}
+
+template <class PG>
+__global__ __launch_bounds__(SB, (PG::NLR <= 6 ? 2 : 1)) void k_planar_step(SimpleArgs a, const float *__restrict__ theta,
+                                                                           const float *__restrict__ xs, SimpleFused fu,
+                                                                           float lbar_const, float *__restrict__ slabs,
+                                                                           long slab_stride) {
+  constexpr int DB = PG::DB, NLR = PG::NLR, NL = PG::NL, FD = PG::FD, SW = PG::SW, SU = PG::SU;
+  extern __shared__ __attribute__((aligned(16))) float psm[];
+  const int d = a.d, nl = a.nl, LP = lp_of(d);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  float *sh = psm;
+  float *wv = psm + PG::SHARED + wave * PG::WAVE;
+  float *cache = psm + PG::SHARED + 4 * PG::WAVE;  // [nl][LP]: w | uhat | b | 1 + c  (build_layer_cache)
+  build_layer_cache<float>(cache, a, theta);
+  __syncthreads();
+  // operand images (zero outside the flow's layers / features: they sit on contraction axes)
+  for (int i = tid; i < NL * SW; i += SB) {
+    const int e = i / SW, f = i - e * SW;
+    const bool in = e < nl && f < d;
+    sh[PG::OFF_W + i] = in ? cache[e * LP + f] : 0.f;
+    sh[PG::OFF_UT + i] = in ? cache[e * LP + d + f] : 0.f;
+  }
+  for (int i = tid; i < FD * SU; i += SB) {
+    const int f = i / SU, e = i - f * SU;
+    sh[PG::OFF_U + i] = (e < nl && f < d) ? cache[e * LP + d + f] : 0.f;
+  }
+  for (int i = tid; i < NL * NL; i += SB) {
+    const int l = i / NL, m = i - l * NL;
+    float c = 0.f;
+    if (l < nl && m < nl)
+      for (int f = 0; f < d; ++f) c += cache[l * LP + f] * cache[m * LP + d + f];
+    sh[PG::OFF_C + i] = c;
+  }
+  for (int i = tid; i < NL; i += SB) {
+    sh[PG::OFF_B + i] = i < nl ? cache[i * LP + 2 * d] : 0.f;
+    sh[PG::OFF_SP + i] = i < nl ? cache[i * LP + 2 * d + 1] : 1.f;
+  }
+  if (fu.tkind == NF_TARGET_DIAGGAUSS)
+    for (int i = tid; i < FD; i += SB) {
+      const float vv = i < d ? ((const float *)fu.var)[i] : 1.f;
+      sh[PG::OFF_TG + i] = i < d ? ((const float *)fu.mu)[i] : 0.f;
+      sh[PG::OFF_TG + FD + i] = i < d ? 1.f / vv : 0.f;
+      sh[PG::OFF_TG + 2 * FD + i] = i < d ? 1.8378770664093453f + logf(vv) : 0.f;
+    }
+  __syncthreads();
+  // wave-uniform scalars of the recurrences, read once: SGPRs (readfirstlane marks them uniform; both sweeps use the
+  // strict upper triangle of C only)
+  auto sc = [&](int off) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sh[off]))); };
+  float Cu[NL][NL], bs[NL], sps[NL];
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    bs[l] = sc(PG::OFF_B + l);
+    sps[l] = sc(PG::OFF_SP + l);
+#pragma unroll
+    for (int m = l + 1; m < NL; ++m) Cu[l][m] = sc(PG::OFF_C + l * NL + m);
+  }
+
+  f32x16 M1[DB], M2[DB], G;
+  float s0[NL], s1[NL];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    G[r] = 0.f;
+#pragma unroll
+    for (int b = 0; b < DB; ++b) M1[b][r] = M2[b][r] = 0.f;
+  }
+#pragma unroll
+  for (int l = 0; l < NL; ++l) s0[l] = s1[l] = 0.f;
+  double contrib = 0.0;
+  const int erow = l31 < NL ? l31 : NL - 1;  // layer row this lane fetches as an A / B operand (rows >= NL: unused columns)
+  const long ntiles = (a.N + 31) / 32;
+  for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+    asm volatile("" ::: "memory");  // keep the operand fetches inside the loop (hoisting them costs the registers)
+    const long j = tile * 32 + l31;
+    const bool valid = j < a.N;
+    // ---- base draws (or the caller's): features f = 32 blk + 8 q + 4 hi + e <-> C register 4 q + e
+    f32x16 z[DB];
+    float ss = 0.f;
+#pragma unroll
+    for (int b = 0; b < DB; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int f0 = 32 * b + 8 * q + 4 * hi;
+        float n4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (f0 < d && valid) {
+          if (fu.draw) {
+            philox_normals4<float>(fu.off + (uint64_t)j, (uint32_t)(f0 >> 2), fu.stream, fu.k0, fu.k1, n4);
+          } else {
+            const float *row = xs + j * d + f0;
+            if (a.vec) {
+              const float4 v = *reinterpret_cast<const float4 *>(row);
+              n4[0] = v.x; n4[1] = v.y; n4[2] = v.z; n4[3] = v.w;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) n4[e] = f0 + e < d ? row[e] : 0.f;
+            }
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = (f0 + e < d) ? n4[e] : 0.f;
+          z[b][4 * q + e] = v;
+          ss += v * v;
+        }
+      }
+    // ---- z0 through the transposition tile: zt[blk][t] = z0[feature 32 blk + l31][sample 2 t + hi]
+    float zt[DB][16];
+#pragma unroll
+    for (int b = 0; b < DB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) wv[PG::OFF_X + (32 * b + nf_row(r, hi)) * NF_TS + l31] = z[b][r];
+    wave_lds_fence();
+#pragma unroll
+    for (int b = 0; b < DB; ++b)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) zt[b][t] = wv[PG::OFF_X + (32 * b + l31) * NF_TS + 2 * t + hi];
+    // ---- A0[e][s] = w_e'z0_s
+    f32x16 c0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c0[r] = 0.f;
+    {
+      const float *wl = sh + PG::OFF_W + erow * SW + 4 * hi;
+#pragma unroll
+      for (int b = 0; b < DB; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float w4[4];
+          nf_ld4<SW>(wl + 32 * b + 8 * g, w4[0], w4[1], w4[2], w4[3]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[e], z[b][4 * g + e], c0, 0, 0, 0);
+        }
+    }
+    // ---- forward recurrence: every lane all layers of its sample
+    float A[NL], tl[NL];
+#pragma unroll
+    for (int r = 0; r < NLR; ++r) {
+      float lo, hh;
+      planar_gather(c0[r], lo, hh);
+      if (nf_row(r, 0) < NL) A[nf_row(r, 0)] = lo;
+      if (nf_row(r, 1) < NL) A[nf_row(r, 1)] = hh;
+    }
+    float lsum = 0.f;
+#pragma unroll
+    for (int l = NL - 1; l >= 0; --l) {
+      tl[l] = 0.f;
+      if (l < nl) {
+        float av = A[l] + bs[l];
+#pragma unroll
+        for (int m = l + 1; m < NL; ++m) av += Cu[l][m] * tl[m];
+        const float t = Fm<float>::tanh_(av);
+        tl[l] = t;
+        lsum += Fm<float>::log_(sps[l] * (1.f - t * t) + t * t);
+      }
+    }
+    // ---- y = z0 + Uhat t   (B operand: this lane's C rows of t)
+    {
+      float tb[NLR];
+#pragma unroll
+      for (int r = 0; r < NLR; ++r) {
+        const float t0 = nf_row(r, 0) < NL ? tl[nf_row(r, 0)] : 0.f, t1 = nf_row(r, 1) < NL ? tl[nf_row(r, 1)] : 0.f;
+        tb[r] = hi ? t1 : t0;
+      }
+#pragma unroll
+      for (int b = 0; b < DB; ++b) {
+        const float *ul = sh + PG::OFF_U + (32 * b + l31) * SU + 4 * hi;
+#pragma unroll
+        for (int g = 0; g < (NLR + 3) / 4; ++g) {
+          float u4[4];
+          nf_ld4<SU>(ul + 8 * g, u4[0], u4[1], u4[2], u4[3]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (4 * g + e < NLR) z[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(u4[e], tb[4 * g + e], z[b], 0, 0, 0);
+        }
+      }
+    }
+    // ---- target: log p(y), ybar = gscale grad log p(y)   (z <- ybar)
+    float acc = 0.f;
+    {
+      float y0, y1, dummy;
+      planar_gather(z[0][0], y0, dummy);
+      planar_gather(z[0][1], y1, dummy);
+      float s2 = 0.f;
+      if (fu.tkind == NF_TARGET_FUNNEL) {
+#pragma unroll
+        for (int b = 0; b < DB; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s2 += (32 * b + nf_row(r, hi) >= 1) ? z[b][r] * z[b][r] : 0.f;
+        s2 = planar_xhalf_sum(s2);
+      }
+      auto run = [&](auto kc) {
+        constexpr int KD = decltype(kc)::value;
+#pragma unroll
+        for (int b = 0; b < DB; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int f = 32 * b + nf_row(r, hi);
+            float gk = 0.f;
+            if constexpr (KD == NF_TARGET_DIAGGAUSS) {
+              const float rr = z[b][r] - sh[PG::OFF_TG + f], iv = sh[PG::OFF_TG + FD + f];
+              acc -= 0.5f * (sh[PG::OFF_TG + 2 * FD + f] + rr * rr * iv);
+              gk = -rr * iv;
+            } else {
+              if (f < d)
+                acc += target_term<KD, float>(d, f, z[b][r], y0, y1, s2, (const float *)fu.mu, (const float *)fu.var, (float)fu.s0,
+                                              (float)fu.s1, gk);
+            }
+            z[b][r] = valid ? (float)fu.gscale * gk : 0.f;
+          }
+      };
+      switch (fu.tkind) {
+        case NF_TARGET_DIAGGAUSS: run(std::integral_constant<int, NF_TARGET_DIAGGAUSS>{}); break;
+        case NF_TARGET_BANANA: run(std::integral_constant<int, NF_TARGET_BANANA>{}); break;
+        case NF_TARGET_FUNNEL: run(std::integral_constant<int, NF_TARGET_FUNNEL>{}); break;
+        case NF_TARGET_WARPED: run(std::integral_constant<int, NF_TARGET_WARPED>{}); break;
+        default: run(std::integral_constant<int, NF_TARGET_CROSS>{}); break;
+      }
+      acc = planar_xhalf_sum(acc);
+      ss = planar_xhalf_sum(ss);
+      const float logq = (float)(-0.5 * 1.8378770664093453 * d) - 0.5f * ss;
+      if (valid && hi == 0) contrib += fu.pscale * (double)(acc - logq + lsum);
+    }
+    // ---- ybar into the tile (the A operand of Ybar T'), UG0[e][s] = uhat_e'ybar_s
+    wave_lds_fence();  // every zt read of the tile is complete (same wave: program order through the LDS queue)
+#pragma unroll
+    for (int b = 0; b < DB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) wv[PG::OFF_X + (32 * b + nf_row(r, hi)) * NF_TS + l31] = z[b][r];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c0[r] = 0.f;
+    {
+      const float *ul = sh + PG::OFF_UT + erow * SW + 4 * hi;
+#pragma unroll
+      for (int b = 0; b < DB; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float w4[4];
+          nf_ld4<SW>(ul + 32 * b + 8 * g, w4[0], w4[1], w4[2], w4[3]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[e], z[b][4 * g + e], c0, 0, 0, 0);
+        }
+    }
+    // ---- reverse recurrence
+    float ab[NL];
+    {
+      float UG[NL];
+#pragma unroll
+      for (int r = 0; r < NLR; ++r) {
+        float lo, hh;
+        planar_gather(c0[r], lo, hh);
+        if (nf_row(r, 0) < NL) UG[nf_row(r, 0)] = lo;
+        if (nf_row(r, 1) < NL) UG[nf_row(r, 1)] = hh;
+      }
+      const float lb = valid ? lbar_const : 0.f;
+      const float once = hi == 0 ? 1.f : 0.f;  // both half-waves carry the sample: count its scalars once
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        ab[l] = 0.f;
+        if (l < nl) {
+          float ug = UG[l];
+#pragma unroll
+          for (int m = 0; m < l; ++m) ug += Cu[m][l] * ab[m];
+          const float t = tl[l], sp = sps[l], cc = sp - 1.f;
+          const float gg = 1.f - t * t, D = sp * gg + t * t, iD = Fm<float>::div_(1.f, D);
+          const float av = ug * gg - 2.f * lb * cc * t * gg * iD;
+          ab[l] = av;
+          s0[l] += once * av;
+          s1[l] += once * lb * gg * iD;
+        }
+      }
+    }
+    // ---- abar, t as [layer][sample] tiles; the three K = samples GEMMs
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      if (hi == 0) wv[PG::OFF_A + l * NF_TS + l31] = ab[l];
+      else wv[PG::OFF_T + l * NF_TS + l31] = tl[l];
+    }
+    wave_lds_fence();
+    {
+      const float *pa = wv + PG::OFF_A + erow * NF_TS + hi, *pt = wv + PG::OFF_T + erow * NF_TS + hi;
+      const float *px = wv + PG::OFF_X + l31 * NF_TS + hi;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const float av = pa[2 * t], tv = pt[2 * t];
+        G = __builtin_amdgcn_mfma_f32_32x32x2f32(av, tv, G, 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < DB; ++b) {
+          M1[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(zt[b][t], av, M1[b], 0, 0, 0);
+          M2[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(px[32 * b * NF_TS + 2 * t], tv, M2[b], 0, 0, 0);
+        }
+      }
+    }
+    wave_lds_fence();  // the next tile overwrites X / A / T
+  }
+  // ---- block epilogue: waves in a fixed order, triangular corrections, slabs in k_simple_step's layout
+  __syncthreads();
+  {
+    float *rg = psm + PG::SHARED + wave * PG::WAVE;
+    if (l31 < NL) {
+#pragma unroll
+      for (int b = 0; b < DB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          rg[PG::R_M1 + l31 * FD + 32 * b + nf_row(r, hi)] = M1[b][r];
+          rg[PG::R_M2 + l31 * FD + 32 * b + nf_row(r, hi)] = M2[b][r];
+        }
+#pragma unroll
+      for (int r = 0; r < NLR; ++r)
+        if (nf_row(r, hi) < NL) rg[PG::R_G + nf_row(r, hi) * NL + l31] = G[r];
+    }
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      float v0 = s0[l], v1 = s1[l];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        v0 += __shfl_xor(v0, o, 64);
+        v1 += __shfl_xor(v1, o, 64);
+      }
+      if (lane == 0) {
+        rg[PG::R_S + l] = v0;
+        rg[PG::R_S + NL + l] = v1;
+      }
+    }
+  }
+  __syncthreads();
+  {
+    float *r0 = psm + PG::SHARED;
+    for (int i = tid; i < PG::REGION; i += SB) {
+      float v = r0[i];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) v += r0[w * PG::WAVE + i];
+      r0[i] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < nl * d; i += SB) {
+      const int l = i / d, f = i - l * d;
+      float wb = r0[PG::R_M1 + l * FD + f], ub = r0[PG::R_M2 + l * FD + f];
+      for (int m = l + 1; m < nl; ++m) wb += cache[m * LP + d + f] * r0[PG::R_G + l * NL + m];
+      for (int m = 0; m < l; ++m) ub += cache[m * LP + f] * r0[PG::R_G + m * NL + l];
+      float *out = slabs + (long)l * slab_stride + (long)blockIdx.x * LP;
+      out[f] = wb;
+      out[d + f] = ub;
+    }
+    for (int l = tid; l < nl; l += SB) {
+      float *out = slabs + (long)l * slab_stride + (long)blockIdx.x * LP;
+      out[2 * d] = r0[PG::R_S + l];
+      out[2 * d + 1] = r0[PG::R_S + NL + l];
+    }
+  }
+  {  // deterministic block sum of the ELBO terms
+    __shared__ double sm[SB / 64];
+    double c = contrib;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (lane == 0) sm[wave] = c;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+#pragma unroll
+      for (int w = 0; w < SB / 64; ++w) t += sm[w];
+      fu.partial[blockIdx.x] = t;
+    }
+  }
+}
+
 // sums the per-block slabs of every layer and applies the parameter-space chain rule
 // (get_u_hat for planar, softplus re-parameterisation for radial).  One block of FB threads per layer: FB / 64
 // row groups each sum every (FB/64)-th slab with 64 consecutive columns per wave (coalesced, independent loads),
@@ -1251,6 +1686,46 @@ static int step_launch(nf_ctx *ctx, SimpleArgs a, const void *theta, const void 
   return (int)hipGetLastError();
 }
 
+// ---- the planar step on the matrix pipe (k_planar_step) ------------------------------------------------------------
+#ifndef NF_PLANAR_MFMA_MIN_D
+#define NF_PLANAR_MFMA_MIN_D 2
+#endif
+static bool planar_mfma_ok(const nf_flow_desc *desc) {
+  static const bool off = std::getenv("NF_PLANAR_NO_MFMA") != nullptr;  // A/B switch: k_simple_step
+  return !off && desc->kind == NF_KIND_PLANAR && desc->dtype == NF_DTYPE_F32 && desc->d >= NF_PLANAR_MFMA_MIN_D && desc->d <= 64 &&
+         desc->nlayers >= 1 && desc->nlayers <= 16;
+}
+template <class PG>
+static int planar_launch(nf_ctx *ctx, SimpleArgs a, const void *theta, const void *xs, const SimpleFused &fu, double lbar_const,
+                         float *slabs, int *nb_out) {
+  const size_t LP = lp_of(a.d);
+  const size_t lds = PG::lds_floats(a.nl, (int)LP) * sizeof(float);
+  static AttrOnce attr_once;  // once per device
+  NF_TRY(attr_once.run(ctx->device, [&]() -> int {
+    NF_HIP(hipFuncSetAttribute((const void *)k_planar_step<PG>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    return NF_OK;
+  }));
+  a.vec = (xs && a.d % 4 == 0 && (uintptr_t)xs % 16 == 0) ? 1 : 0;
+  long nb = ((a.N + 31) / 32 + 3) / 4;
+  const long res = resident_blocks(ctx, k_planar_step<PG>, lds);
+  if (nb > res) nb = res;
+  if (nb < 1) nb = 1;
+  *nb_out = (int)nb;
+  ProfScope ps(ctx, "planar_step");
+  hipLaunchKernelGGL((k_planar_step<PG>), dim3((unsigned)nb), dim3(SB), lds, ctx->stream, a, (const float *)theta, (const float *)xs, fu,
+                     (float)lbar_const, slabs, (long)nb * (long)LP);
+  return (int)hipGetLastError();
+}
+static int planar_step(nf_ctx *ctx, const SimpleArgs &a, const void *theta, const void *xs, const SimpleFused &fu, double lbar_const,
+                       float *slabs, int *nb_out) {
+  const bool wide = a.d > 32;
+  if (a.nl <= 10)
+    return wide ? planar_launch<PlanarGeo<2, 6>>(ctx, a, theta, xs, fu, lbar_const, slabs, nb_out)
+                : planar_launch<PlanarGeo<1, 6>>(ctx, a, theta, xs, fu, lbar_const, slabs, nb_out);
+  return wide ? planar_launch<PlanarGeo<2, 8>>(ctx, a, theta, xs, fu, lbar_const, slabs, nb_out)
+              : planar_launch<PlanarGeo<1, 8>>(ctx, a, theta, xs, fu, lbar_const, slabs, nb_out);
+}
+
 // smallest unroll bound that holds nl layers
 // three unroll bounds (4, 10, 12): unused slots still cost their accumulator registers, and ten layers is the shape of
 // BASELINE cfg 1 and of the reference's planar / radial tests (test/flow.jl:137,203)
@@ -1292,6 +1767,7 @@ static int step_nlmax(const nf_flow_desc *desc) {
 
 // flows whose every layer input fits the register budget of k_simple_step and whose caches + reduction rows fit LDS
 bool nf_simple_step_supported(const nf_flow_desc *desc) {
+  if (planar_mfma_ok(desc)) return true;
   if (!nf_simple_supported(desc) || dpl_for(desc->d) > 16) return false;
   const int nl = desc->kind == NF_KIND_MEANFIELD ? 2 : desc->nlayers;
   const size_t es = desc->dtype == NF_DTYPE_F64 ? 8 : 4;
@@ -1328,6 +1804,16 @@ static int step_t(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target
   T *slabs = (T *)ws;
   int nb = 0;
   int st;
+  if constexpr (std::is_same<T, float>::value) {
+    if (planar_mfma_ok(desc)) {
+      NF_TRY(planar_step(ctx, a, theta, xs, fu, lbar_const, slabs, &nb));
+      *npartial = nb;
+      ProfScope pf(ctx, "simple_finalize");
+      hipLaunchKernelGGL(k_simple_finalize<T>, dim3(nl), dim3(FB), (size_t)(1 + FB / 64) * lp_of(a.d) * sizeof(T), ctx->stream, a,
+                         (const T *)theta, (const T *)slabs, nb, (T *)gtheta_out);
+      return (int)hipGetLastError();
+    }
+  }
   if (desc->kind == NF_KIND_PLANAR) st = step_kind<T, NF_KIND_PLANAR>(ctx, a, theta, xs, fu, lbar_const, slabs, &nb);
   else if (desc->kind == NF_KIND_RADIAL) st = step_kind<T, NF_KIND_RADIAL>(ctx, a, theta, xs, fu, lbar_const, slabs, &nb);
   else st = step_kind<T, NF_KIND_MEANFIELD>(ctx, a, theta, xs, fu, lbar_const, slabs, &nb);
