@@ -947,7 +947,8 @@ __global__ __launch_bounds__(SB, 2) void k_simple_step(SimpleArgs a, const T *__
 //     ubar_l = sum_j t_l^j gbar_l^j   = [Ybar T']_l  + sum_{m<l} w_m G[m][l].
 // Every d-length dot product, the state update and every sum over samples is therefore a GEMM with a 32-sample tile on
 // one side -- W Z0, Uhat T, Uhat'Ybar, Z0 Abar', Ybar T', Abar T' -- and what is left per sample is a triangular recurrence
-// over nl scalars.  k_simple_step (16 lanes per sample, DPP reductions, 16-fold redundant scalar math) needs ~1 900
+// over nl scalars.  The two per-layer scalar sums ride along: with q_l = lbar dladj_l/d(1+c_l) stacked under abar and a row
+// of ones under t, G' = [Abar; Q] [T; 1]' holds G, bbar_l = sum_j abar_l^j (last column) and the sum of q_l.  k_simple_step (16 lanes per sample, DPP reductions, 16-fold redundant scalar math) needs ~1 900
 // VALU instructions per four samples at d = 64 x 10 layers; here a wave issues ~160 MFMAs and ~1 800 VALU instructions
 // per THIRTY-TWO samples (over half of those are the Philox / Box-Muller draws).  Same arithmetic as the reference up to
 // the order of the additions (z_l is never formed; its inner product with w_l is summed term by term).
@@ -975,11 +976,14 @@ struct PlanarGeo {
   static constexpr int OFF_TG = OFF_SP + NL;                           // target: mu[f] | 1/var[f] | log 2pi + log var[f]
   static constexpr int SHARED = ((OFF_TG + 3 * FD + 3) / 4) * 4;
   static constexpr int OFF_X = 0;                                      // per wave: [FD][33] transposition tile
-  static constexpr int OFF_A = OFF_X + FD * NF_TS;                     //           abar[l][s]
-  static constexpr int OFF_T = OFF_A + NL * NF_TS;                     //           t[l][s]
-  static constexpr int WAVE = ((OFF_T + NL * NF_TS + 3) / 4) * 4;
-  // block epilogue (aliases the waves' tiles): per wave M1[l][f] | M2[l][f] | G[l][m] | s0[l] | s1[l]
-  static constexpr int R_M1 = 0, R_M2 = NL * FD, R_G = 2 * NL * FD, R_S = R_G + NL * NL, REGION = R_S + 2 * NL;
+  static constexpr int AR = 2 * NL, TR = NL + 1;                       // rows of the two [layer][sample] tiles (below)
+  static constexpr int OFF_A = OFF_X + FD * NF_TS;                     //           abar[l][s] | q[l][s]
+  static constexpr int OFF_T = OFF_A + AR * NF_TS;                     //           t[l][s] | ones
+  static constexpr int WAVE = ((OFF_T + TR * NF_TS + 3) / 4) * 4;
+  // block epilogue (aliases the waves' tiles): per wave M1[l][f] | M2[l][f] | G'[2 NL][NL + 1]
+  static constexpr int R_M1 = 0, R_M2 = NL * FD, R_G = 2 * NL * FD, REGION = R_G + AR * TR;
+  static constexpr int GR = AR <= 8 ? 4 : AR <= 16 ? 8 : AR <= 24 ? 12 : 16;  // C registers of G' that carry rows < 2 NL
+  static_assert(AR <= 32, "abar and q rows share one 32-row operand");
   static_assert(REGION <= WAVE, "epilogue region must fit a wave's tiles");
   static constexpr size_t lds_floats(int nl, int lp) { return (size_t)SHARED + 4 * (size_t)WAVE + (size_t)nl * lp; }
 };
@@ -1004,7 +1008,28 @@ __device__ __forceinline__ float planar_xhalf_sum(float v) {
   return lo + hi;
 }
 
-template <class PG>
+// out[e][s] = sum_f rows[e][f] v[f][s]: `rowp` = this lane's row of a [layer][feature] image (+ 4 hi), v in the C layout.
+// Four k-steps per ds_read_b128, the next group requested while the matrix pipe works on this one.
+template <int DB, int S>
+__device__ __forceinline__ void planar_rows_gemm(const float *__restrict__ rowp, const f32x16 (&v)[DB], f32x16 &out) {
+  constexpr int NG = 4 * DB;
+  float wn[4], wc[4];
+  nf_ld4<S>(rowp, wn[0], wn[1], wn[2], wn[3]);
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wc[e] = wn[e];
+    if (g + 1 < NG) nf_ld4<S>(rowp + 8 * (g + 1), wn[0], wn[1], wn[2], wn[3]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) out = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[e], v[g / 4][4 * (g % 4) + e], out, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// DIAG: the diagonal-Gaussian target has its own instantiation -- with the five targets behind one switch the register
+// allocator sizes the kernel for the 2-d targets' atan2 / exp chains and spills the GEMM accumulators around the draws.
+template <class PG, bool DIAG>
 __global__ __launch_bounds__(SB, (PG::NLR <= 6 ? 2 : 1)) void k_planar_step(SimpleArgs a, const float *__restrict__ theta,
                                                                            const float *__restrict__ xs, SimpleFused fu,
                                                                            float lbar_const, float *__restrict__ slabs,
@@ -1041,7 +1066,7 @@ __global__ __launch_bounds__(SB, (PG::NLR <= 6 ? 2 : 1)) void k_planar_step(Simp
     sh[PG::OFF_B + i] = i < nl ? cache[i * LP + 2 * d] : 0.f;
     sh[PG::OFF_SP + i] = i < nl ? cache[i * LP + 2 * d + 1] : 1.f;
   }
-  if (fu.tkind == NF_TARGET_DIAGGAUSS)
+  if (DIAG)
     for (int i = tid; i < FD; i += SB) {
       const float vv = i < d ? ((const float *)fu.var)[i] : 1.f;
       sh[PG::OFF_TG + i] = i < d ? ((const float *)fu.mu)[i] : 0.f;
@@ -1062,17 +1087,16 @@ __global__ __launch_bounds__(SB, (PG::NLR <= 6 ? 2 : 1)) void k_planar_step(Simp
   }
 
   f32x16 M1[DB], M2[DB], G;
-  float s0[NL], s1[NL];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     G[r] = 0.f;
 #pragma unroll
     for (int b = 0; b < DB; ++b) M1[b][r] = M2[b][r] = 0.f;
   }
-#pragma unroll
-  for (int l = 0; l < NL; ++l) s0[l] = s1[l] = 0.f;
   double contrib = 0.0;
-  const int erow = l31 < NL ? l31 : NL - 1;  // layer row this lane fetches as an A / B operand (rows >= NL: unused columns)
+  // layer rows this lane fetches as A / B operands (clamped rows feed output columns nobody reads)
+  const int erow = l31 < NL ? l31 : NL - 1, arow = l31 < PG::AR ? l31 : PG::AR - 1, trow = l31 < PG::TR ? l31 : PG::TR - 1;
+  if (hi == 0) wv[PG::OFF_T + NL * NF_TS + l31] = 1.f;  // the ones row (the tiles are not touched until the epilogue)
   const long ntiles = (a.N + 31) / 32;
   for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
     asm volatile("" ::: "memory");  // keep the operand fetches inside the loop (hoisting them costs the registers)
@@ -1123,18 +1147,7 @@ __global__ __launch_bounds__(SB, (PG::NLR <= 6 ? 2 : 1)) void k_planar_step(Simp
     f32x16 c0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) c0[r] = 0.f;
-    {
-      const float *wl = sh + PG::OFF_W + erow * SW + 4 * hi;
-#pragma unroll
-      for (int b = 0; b < DB; ++b)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float w4[4];
-          nf_ld4<SW>(wl + 32 * b + 8 * g, w4[0], w4[1], w4[2], w4[3]);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[e], z[b][4 * g + e], c0, 0, 0, 0);
-        }
-    }
+    planar_rows_gemm<DB, SW>(sh + PG::OFF_W + erow * SW + 4 * hi, z, c0);
     // ---- forward recurrence: every lane all layers of its sample
     float A[NL], tl[NL];
 #pragma unroll
@@ -1185,7 +1198,7 @@ __global__ __launch_bounds__(SB, (PG::NLR <= 6 ? 2 : 1)) void k_planar_step(Simp
       planar_gather(z[0][0], y0, dummy);
       planar_gather(z[0][1], y1, dummy);
       float s2 = 0.f;
-      if (fu.tkind == NF_TARGET_FUNNEL) {
+      if (!DIAG && fu.tkind == NF_TARGET_FUNNEL) {
 #pragma unroll
         for (int b = 0; b < DB; ++b)
 #pragma unroll
@@ -1212,12 +1225,15 @@ __global__ __launch_bounds__(SB, (PG::NLR <= 6 ? 2 : 1)) void k_planar_step(Simp
             z[b][r] = valid ? (float)fu.gscale * gk : 0.f;
           }
       };
-      switch (fu.tkind) {
-        case NF_TARGET_DIAGGAUSS: run(std::integral_constant<int, NF_TARGET_DIAGGAUSS>{}); break;
-        case NF_TARGET_BANANA: run(std::integral_constant<int, NF_TARGET_BANANA>{}); break;
-        case NF_TARGET_FUNNEL: run(std::integral_constant<int, NF_TARGET_FUNNEL>{}); break;
-        case NF_TARGET_WARPED: run(std::integral_constant<int, NF_TARGET_WARPED>{}); break;
-        default: run(std::integral_constant<int, NF_TARGET_CROSS>{}); break;
+      if constexpr (DIAG) {
+        run(std::integral_constant<int, NF_TARGET_DIAGGAUSS>{});
+      } else {
+        switch (fu.tkind) {
+          case NF_TARGET_BANANA: run(std::integral_constant<int, NF_TARGET_BANANA>{}); break;
+          case NF_TARGET_FUNNEL: run(std::integral_constant<int, NF_TARGET_FUNNEL>{}); break;
+          case NF_TARGET_WARPED: run(std::integral_constant<int, NF_TARGET_WARPED>{}); break;
+          default: run(std::integral_constant<int, NF_TARGET_CROSS>{}); break;
+        }
       }
       acc = planar_xhalf_sum(acc);
       ss = planar_xhalf_sum(ss);
@@ -1232,20 +1248,9 @@ __global__ __launch_bounds__(SB, (PG::NLR <= 6 ? 2 : 1)) void k_planar_step(Simp
       for (int r = 0; r < 16; ++r) wv[PG::OFF_X + (32 * b + nf_row(r, hi)) * NF_TS + l31] = z[b][r];
 #pragma unroll
     for (int r = 0; r < 16; ++r) c0[r] = 0.f;
-    {
-      const float *ul = sh + PG::OFF_UT + erow * SW + 4 * hi;
-#pragma unroll
-      for (int b = 0; b < DB; ++b)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float w4[4];
-          nf_ld4<SW>(ul + 32 * b + 8 * g, w4[0], w4[1], w4[2], w4[3]);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[e], z[b][4 * g + e], c0, 0, 0, 0);
-        }
-    }
+    planar_rows_gemm<DB, SW>(sh + PG::OFF_UT + erow * SW + 4 * hi, z, c0);
     // ---- reverse recurrence
-    float ab[NL];
+    float ab[NL], qv[NL];
     {
       float UG[NL];
 #pragma unroll
@@ -1256,10 +1261,9 @@ __global__ __launch_bounds__(SB, (PG::NLR <= 6 ? 2 : 1)) void k_planar_step(Simp
         if (nf_row(r, 1) < NL) UG[nf_row(r, 1)] = hh;
       }
       const float lb = valid ? lbar_const : 0.f;
-      const float once = hi == 0 ? 1.f : 0.f;  // both half-waves carry the sample: count its scalars once
 #pragma unroll
       for (int l = 0; l < NL; ++l) {
-        ab[l] = 0.f;
+        ab[l] = qv[l] = 0.f;
         if (l < nl) {
           float ug = UG[l];
 #pragma unroll
@@ -1268,30 +1272,62 @@ __global__ __launch_bounds__(SB, (PG::NLR <= 6 ? 2 : 1)) void k_planar_step(Simp
           const float gg = 1.f - t * t, D = sp * gg + t * t, iD = Fm<float>::div_(1.f, D);
           const float av = ug * gg - 2.f * lb * cc * t * gg * iD;
           ab[l] = av;
-          s0[l] += once * av;
-          s1[l] += once * lb * gg * iD;
+          qv[l] = lb * gg * iD;
         }
       }
     }
     // ---- abar, t as [layer][sample] tiles; the three K = samples GEMMs
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
-      if (hi == 0) wv[PG::OFF_A + l * NF_TS + l31] = ab[l];
-      else wv[PG::OFF_T + l * NF_TS + l31] = tl[l];
+      if (hi == 0) {
+        wv[PG::OFF_A + l * NF_TS + l31] = ab[l];
+        wv[PG::OFF_T + l * NF_TS + l31] = tl[l];
+      } else {
+        wv[PG::OFF_A + (NL + l) * NF_TS + l31] = qv[l];
+      }
     }
     wave_lds_fence();
     {
-      const float *pa = wv + PG::OFF_A + erow * NF_TS + hi, *pt = wv + PG::OFF_T + erow * NF_TS + hi;
+      const float *pa = wv + PG::OFF_A + arow * NF_TS + hi, *pt = wv + PG::OFF_T + trow * NF_TS + hi;
       const float *px = wv + PG::OFF_X + l31 * NF_TS + hi;
+      // groups of four k-steps (sample pairs), the next group's operands requested while the matrix pipe works on this one
+      float an[4], tn[4], xn[DB][4], ac[4], tc[4], xc[DB][4];
 #pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const float av = pa[2 * t], tv = pt[2 * t];
-        G = __builtin_amdgcn_mfma_f32_32x32x2f32(av, tv, G, 0, 0, 0);
+      for (int e = 0; e < 4; ++e) {
+        an[e] = pa[2 * e];
+        tn[e] = pt[2 * e];
 #pragma unroll
-        for (int b = 0; b < DB; ++b) {
-          M1[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(zt[b][t], av, M1[b], 0, 0, 0);
-          M2[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(px[32 * b * NF_TS + 2 * t], tv, M2[b], 0, 0, 0);
+        for (int b = 0; b < DB; ++b) xn[b][e] = px[32 * b * NF_TS + 2 * e];
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ac[e] = an[e];
+          tc[e] = tn[e];
+#pragma unroll
+          for (int b = 0; b < DB; ++b) xc[b][e] = xn[b][e];
         }
+        if (g + 1 < 4) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            an[e] = pa[2 * (4 * (g + 1) + e)];
+            tn[e] = pt[2 * (4 * (g + 1) + e)];
+#pragma unroll
+            for (int b = 0; b < DB; ++b) xn[b][e] = px[32 * b * NF_TS + 2 * (4 * (g + 1) + e)];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          G = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[e], tc[e], G, 0, 0, 0);
+#pragma unroll
+          for (int b = 0; b < DB; ++b) {
+            M1[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(zt[b][4 * g + e], ac[e], M1[b], 0, 0, 0);
+            M2[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xc[b][e], tc[e], M2[b], 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     wave_lds_fence();  // the next tile overwrites X / A / T
@@ -1308,22 +1344,11 @@ __global__ __launch_bounds__(SB, (PG::NLR <= 6 ? 2 : 1)) void k_planar_step(Simp
           rg[PG::R_M1 + l31 * FD + 32 * b + nf_row(r, hi)] = M1[b][r];
           rg[PG::R_M2 + l31 * FD + 32 * b + nf_row(r, hi)] = M2[b][r];
         }
-#pragma unroll
-      for (int r = 0; r < NLR; ++r)
-        if (nf_row(r, hi) < NL) rg[PG::R_G + nf_row(r, hi) * NL + l31] = G[r];
     }
+    if (l31 < PG::TR) {
 #pragma unroll
-    for (int l = 0; l < NL; ++l) {
-      float v0 = s0[l], v1 = s1[l];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        v0 += __shfl_xor(v0, o, 64);
-        v1 += __shfl_xor(v1, o, 64);
-      }
-      if (lane == 0) {
-        rg[PG::R_S + l] = v0;
-        rg[PG::R_S + NL + l] = v1;
-      }
+      for (int r = 0; r < PG::GR; ++r)
+        if (nf_row(r, hi) < PG::AR) rg[PG::R_G + nf_row(r, hi) * PG::TR + l31] = G[r];
     }
   }
   __syncthreads();
@@ -1339,16 +1364,16 @@ __global__ __launch_bounds__(SB, (PG::NLR <= 6 ? 2 : 1)) void k_planar_step(Simp
     for (int i = tid; i < nl * d; i += SB) {
       const int l = i / d, f = i - l * d;
       float wb = r0[PG::R_M1 + l * FD + f], ub = r0[PG::R_M2 + l * FD + f];
-      for (int m = l + 1; m < nl; ++m) wb += cache[m * LP + d + f] * r0[PG::R_G + l * NL + m];
-      for (int m = 0; m < l; ++m) ub += cache[m * LP + f] * r0[PG::R_G + m * NL + l];
+      for (int m = l + 1; m < nl; ++m) wb += cache[m * LP + d + f] * r0[PG::R_G + l * PG::TR + m];
+      for (int m = 0; m < l; ++m) ub += cache[m * LP + f] * r0[PG::R_G + m * PG::TR + l];
       float *out = slabs + (long)l * slab_stride + (long)blockIdx.x * LP;
       out[f] = wb;
       out[d + f] = ub;
     }
     for (int l = tid; l < nl; l += SB) {
       float *out = slabs + (long)l * slab_stride + (long)blockIdx.x * LP;
-      out[2 * d] = r0[PG::R_S + l];
-      out[2 * d + 1] = r0[PG::R_S + NL + l];
+      out[2 * d] = r0[PG::R_G + l * PG::TR + NL];             // bbar_l = sum_j abar_l^j
+      out[2 * d + 1] = r0[PG::R_G + (NL + l) * PG::TR + NL];  // sum_j q_l^j
     }
   }
   {  // deterministic block sum of the ELBO terms
@@ -1695,26 +1720,32 @@ static bool planar_mfma_ok(const nf_flow_desc *desc) {
   return !off && desc->kind == NF_KIND_PLANAR && desc->dtype == NF_DTYPE_F32 && desc->d >= NF_PLANAR_MFMA_MIN_D && desc->d <= 64 &&
          desc->nlayers >= 1 && desc->nlayers <= 16;
 }
-template <class PG>
-static int planar_launch(nf_ctx *ctx, SimpleArgs a, const void *theta, const void *xs, const SimpleFused &fu, double lbar_const,
+template <class PG, bool DIAG>
+static int planar_launch_t(nf_ctx *ctx, SimpleArgs a, const void *theta, const void *xs, const SimpleFused &fu, double lbar_const,
                          float *slabs, int *nb_out) {
   const size_t LP = lp_of(a.d);
   const size_t lds = PG::lds_floats(a.nl, (int)LP) * sizeof(float);
   static AttrOnce attr_once;  // once per device
   NF_TRY(attr_once.run(ctx->device, [&]() -> int {
-    NF_HIP(hipFuncSetAttribute((const void *)k_planar_step<PG>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    NF_HIP(hipFuncSetAttribute((const void *)k_planar_step<PG, DIAG>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     return NF_OK;
   }));
   a.vec = (xs && a.d % 4 == 0 && (uintptr_t)xs % 16 == 0) ? 1 : 0;
   long nb = ((a.N + 31) / 32 + 3) / 4;
-  const long res = resident_blocks(ctx, k_planar_step<PG>, lds);
+  const long res = resident_blocks(ctx, k_planar_step<PG, DIAG>, lds);
   if (nb > res) nb = res;
   if (nb < 1) nb = 1;
   *nb_out = (int)nb;
   ProfScope ps(ctx, "planar_step");
-  hipLaunchKernelGGL((k_planar_step<PG>), dim3((unsigned)nb), dim3(SB), lds, ctx->stream, a, (const float *)theta, (const float *)xs, fu,
+  hipLaunchKernelGGL((k_planar_step<PG, DIAG>), dim3((unsigned)nb), dim3(SB), lds, ctx->stream, a, (const float *)theta, (const float *)xs, fu,
                      (float)lbar_const, slabs, (long)nb * (long)LP);
   return (int)hipGetLastError();
+}
+template <class PG>
+static int planar_launch(nf_ctx *ctx, const SimpleArgs &a, const void *theta, const void *xs, const SimpleFused &fu, double lbar_const,
+                         float *slabs, int *nb_out) {
+  return fu.tkind == NF_TARGET_DIAGGAUSS ? planar_launch_t<PG, true>(ctx, a, theta, xs, fu, lbar_const, slabs, nb_out)
+                                         : planar_launch_t<PG, false>(ctx, a, theta, xs, fu, lbar_const, slabs, nb_out);
 }
 static int planar_step(nf_ctx *ctx, const SimpleArgs &a, const void *theta, const void *xs, const SimpleFused &fu, double lbar_const,
                        float *slabs, int *nb_out) {

@@ -46,11 +46,15 @@ for kind in ("planar", "radial"):
     need = {"simple_apply": row * (nl + 1), "simple_bwd": row * (nl + 2 * -(-nl // lpp))}
     print(f"{kind} d={d} layers={nl} N={N}: {1e3 * el:.3f} ms/step = {N / el / 1e6:.1f} M samples/s, loss {float(out[-1]):.4f}")
     a, c = C.c_double(0.0), C.c_int64(0)
+    kname = "simple_step"
     lib.nf_prof_read(ctx.ptr, b"simple_step", C.byref(a), C.byref(c))
+    if not c.value:  # planar, d <= 64, <= 16 layers: the matrix-pipe step (k_planar_step)
+        kname = "planar_step"
+        lib.nf_prof_read(ctx.ptr, b"planar_step", C.byref(a), C.byref(c))
     if c.value:  # the stash-free step: one launch, no activation traffic; SURVEY 8(d) algorithmic bytes: 8d + 4 per sample
         alg = N * (8 * d + 4)
-        print(f"   simple_step: {1e3 * a.value:.1f} us; algorithmic {alg / 1e6:.0f} MB -> {alg / (a.value * 1e-3) / 1e12:.2f} TB/s "
-              f"= {100 * alg / (a.value * 1e-3) / 8e12:.1f} % of the 8 TB/s HBM roofline (the kernel moves only parameter slabs: VALU-bound)")
+        print(f"   {kname}: {1e3 * a.value:.1f} us; algorithmic {alg / 1e6:.0f} MB -> {alg / (a.value * 1e-3) / 1e12:.2f} TB/s "
+              f"= {100 * alg / (a.value * 1e-3) / 8e12:.1f} % of the 8 TB/s HBM roofline (the kernel moves only parameter slabs: issue-bound)")
     for name, b in need.items():
         a, c = C.c_double(0.0), C.c_int64(0)
         lib.nf_prof_read(ctx.ptr, name.encode(), C.byref(a), C.byref(c))
