@@ -896,6 +896,33 @@ __global__ __launch_bounds__(256) void k_wide_reduce(NetDims nd, const float *__
   g[ti] = (a0 + a1) + (a2 + a3);
 }
 
+// The training step's form: every (coupling, net) of the reverse pass leaves its split-K partials in its own slab
+// region, and ONE launch at the end sums them all (blockIdx.y = 2 * coupling + phase; phase 0 = t net, 1 = s net).
+template <class G>
+__global__ __launch_bounds__(256) void k_wide_reduce_all(PackArgs p, const float *__restrict__ slab, int nslab, long slab_stride,
+                                                         float *__restrict__ g) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= G::B3 + 32 * G::CB) return;
+  const int job = blockIdx.y, k = job >> 1, phase = job & 1;
+  const int c = (k & 1) ? p.d / 2 : (p.d + 1) / 2, m = p.d - c;
+  long off = (long)(k >> 1) * p.pair_params + ((k & 1) ? p.odd_params : 0);
+  if (phase == 0) off += net_param_count(m, p.h1, p.h2, c);
+  const NetDims nd = make_net_dims(off, m, p.h1, p.h2, c);
+  const long ti = image_theta_index<G>(nd, e);
+  if (ti < 0) return;
+  slab += (size_t)job * nslab * slab_stride;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int s = 0;
+  for (; s + 3 < nslab; s += 4) {  // the order of k_wide_reduce
+    a0 += slab[(long)s * slab_stride + e];
+    a1 += slab[(long)(s + 1) * slab_stride + e];
+    a2 += slab[(long)(s + 2) * slab_stride + e];
+    a3 += slab[(long)(s + 3) * slab_stride + e];
+  }
+  for (; s < nslab; ++s) a0 += slab[(long)s * slab_stride + e];
+  g[ti] = (a0 + a1) + (a2 + a3);
+}
+
 // ------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------
@@ -1110,7 +1137,7 @@ static size_t wide_train_ws_floats(nf_ctx *ctx, const nf_flow_desc *desc, long N
   const size_t fwd = (size_t)2 * desc->nlayers * 2 * fwd_stash_floats_per_net(ntiles);
   const size_t dstash = (size_t)ntiles * NF_TILE * 32 * (G::H1B + G::H2B + G::CB);
   const int ks = wide_ksplit(ctx, ntiles, wide_njobs());
-  return fwd + dstash + (size_t)ks * G::SIZE + 1024;
+  return fwd + dstash + (size_t)4 * desc->nlayers * ks * G::SIZE + 1024;  // one slab region per (coupling, net)
 }
 
 // whole chain forward on a base draw (in place on xt), stashing for the reverse pass
@@ -1176,7 +1203,7 @@ static int wide_train_backward(nf_ctx *ctx, const nf_flow_desc *desc, float *sta
   long grid = wide_groups(N);
   if (grid > ctx->num_cu) grid = ctx->num_cu;
   if (grid < 1) grid = 1;
-  const int h1 = desc->hdims[0], h2 = desc->hdims[1];
+  (void)0;
   for (int k = 0; k < nc; ++k) {  // flat order = reverse of execution order
     const WideArgs a = make_wide_args(ctx, desc, k, N);
     const CouplingInfo ci = nf_coupling_info(desc, k);
@@ -1201,19 +1228,18 @@ static int wide_train_backward(nf_ctx *ctx, const nf_flow_desc *desc, float *sta
       da.slab_stride = G::SIZE;
       {
         ProfScope ps(ctx, "wide_dw");
-        hipLaunchKernelGGL(k_wide_dw, dim3((unsigned)(da.njobs * ks)), dim3(256), lds_dw, ctx->stream, da, slab);
-        NF_HIP(hipGetLastError());
-      }
-      long off = ci.theta_off;
-      if (phase == 0) off += net_param_count(ci.m, h1, h2, ci.c);
-      const NetDims nd = make_net_dims(off, ci.m, h1, h2, ci.c);
-      {
-        ProfScope ps(ctx, "reduce_slabs");
-        constexpr int NE = G::B3 + 32 * G::CB;
-        hipLaunchKernelGGL((k_wide_reduce<G>), dim3((NE + 255) / 256), dim3(256), 0, ctx->stream, nd, slab, ks, (long)G::SIZE, g_out);
+        hipLaunchKernelGGL(k_wide_dw, dim3((unsigned)(da.njobs * ks)), dim3(256), lds_dw, ctx->stream, da,
+                           slab + (size_t)(2 * k + phase) * ks * G::SIZE);
         NF_HIP(hipGetLastError());
       }
     }
+  }
+  {
+    ProfScope ps(ctx, "reduce_slabs");
+    constexpr int NE = G::B3 + 32 * G::CB;
+    hipLaunchKernelGGL((k_wide_reduce_all<G>), dim3((NE + 255) / 256, 2 * nc), dim3(256), 0, ctx->stream, make_pack_args(desc), slab, ks,
+                       (long)G::SIZE, g_out);
+    NF_HIP(hipGetLastError());
   }
   return NF_OK;
 }
