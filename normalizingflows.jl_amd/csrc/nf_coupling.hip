@@ -1116,6 +1116,215 @@ __global__ __launch_bounds__(256, 1) void k_affine_bwd_stashed(BwdAllArgs aa, fl
 }
 
 // ------------------------------------------------------------------------------------
+// reverse pass from the stash, TWO wavefronts per tile (k_affine_bwd_pair)
+// ------------------------------------------------------------------------------------
+// k_affine_bwd_stashed runs one wavefront per SIMD (its 128 dW accumulator registers plus the delta / operand tiles
+// need the whole 512-register file), so nothing fills the matrix pipe while that wave fetches operands, scales deltas
+// or waits for its stash loads: 0.55 MFMA-busy (profiles/r3a_pmc_summary.json).  Here a tile is shared by a PRODUCER
+// wave, which walks the delta chain (element-wise stage, dX3, dX2, dX1: 128 MFMAs, no accumulators) and leaves every
+// delta tile in LDS, and a CONSUMER wave on the same SIMD, which owns the net's dW accumulators and contracts the
+// stashed activations with those tiles (dW3, dW2, dW1: 128 MFMAs).  Both fit 256 registers, so the SIMD holds both, and
+// the three workgroup barriers per tile line the two up GEMM by GEMM with equal MFMA counts on either side
+// (32 | 64 | 32): whatever one wave does besides MFMAs is covered by the other's.
+//   producer: d3 -> LDS | B1 | dX3, d2 -> LDS | B2 | dX2, d1 -> LDS | B3 | dX1, x2bar
+//   consumer: a2 loads  | B1 | dW3 (d3)       | B2 | dW2 (d2)       | B3 | dW1 (d1)
+// One buffer per delta suffices: d3 of the next tile is written after B3, when dW3 has long read it (before B2), etc.
+// Whole tiles only (d = 64, N a multiple of 32) and every pair the same number of tiles (barriers inside the tile loop).
+template <class G>
+struct BwdPairLds {
+  static constexpr int D3 = 0, D2 = D3 + G::CB * 32 * NF_TS, D1 = D2 + G::H2B * 32 * NF_TS, PAIR = D1 + G::H1B * 32 * NF_TS;
+  static constexpr int PAIRS = 4;
+  static constexpr int FLOATS = (G::SIZE + PAIRS * PAIR) > PAIRS * G::SIZE ? (G::SIZE + PAIRS * PAIR) : PAIRS * G::SIZE;
+  static constexpr size_t BYTES = (size_t)FLOATS * sizeof(float);  // the fold at the end of a phase needs 4 images
+};
+
+template <class G, bool PHASE_S>
+__device__ __forceinline__ void pair_produce(const CouplingArgs &a, const float *__restrict__ img, float *__restrict__ sp,
+                                             StashFirst<G> &f, float *stash, int k, int ncoup, float *__restrict__ ybar,
+                                             const float *__restrict__ lbar, float lbar_const, long tile, long next_tile,
+                                             int l31, int hi) {
+  using SG = StashGeo<G>;
+  using L = BwdPairLds<G>;
+  const long j = tile * NF_TILE + l31;
+  const int par_c = 1 - a.par_t;
+  const TileIO gio = make_tile_io(ybar, tile, a.d, l31, hi);
+  const StashIO st = make_stash_io(stash, tile * ncoup + k, SG::SIZE, true, l31, hi);
+  constexpr int nbase = SG::NET0 + (PHASE_S ? 0 : SG::NETSZ);
+  f32x16 g1[G::CB];
+#pragma unroll
+  for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g1[b][r] = tile_load(gio, tile_soff(b, r, a.par_t));
+  const u32x4 mk = __builtin_amdgcn_raw_buffer_load_b128(st.rs, (hi * 32 + l31) * 16, (nbase + SG::MSK) * 4, 0);
+  f32x16 gold[G::MB];
+#pragma unroll
+  for (int b = 0; b < G::MB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gold[b][r] = tile_load(gio, tile_soff(b, r, par_c));
+  const float lb = lbar ? lbar[j] : lbar_const;
+  f32x16 d3[G::CB];
+#pragma unroll
+  for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool ok = b * 32 + nf_row(r, hi) < a.c;
+      const float gv = g1[b][r];
+      if (!PHASE_S) {
+        d3[b][r] = ok ? gv : 0.f;  // T-bar = ybar1
+      } else {
+        const float sv = f.sv[b][r];
+        tile_store(gio, tile_soff(b, r, a.par_t), gv * nf_exp(sv));        // x1bar
+        d3[b][r] = ok ? (gv * f.uv[b][r] + lb) * (1.f - sv * sv) : 0.f;  // S-bar through tanh
+      }
+    }
+  tile_to_scratch<G::CB>(sp + L::D3, d3, l31, hi);
+  const unsigned m1[2] = {mk[0], mk[1]}, m2[2] = {mk[2], mk[3]};
+  __syncthreads();  // B1: d3 is in LDS (and the consumer is done with the previous tile's d1)
+  f32x16 d2[G::H2B];
+  dense_bwd_x<G::H2B, G::CB>(img + G::W3, d3, d2, l31, hi);
+  apply_lrelu_grad<G::H2B>(d2, m2);
+  tile_to_scratch<G::H2B>(sp + L::D2, d2, l31, hi);
+  __syncthreads();  // B2
+  f32x16 d1[G::H1B];
+  dense_bwd_x<G::H1B, G::H2B>(img + G::W2, d2, d1, l31, hi);
+  apply_lrelu_grad<G::H1B>(d1, m1);
+  tile_to_scratch<G::H1B>(sp + L::D1, d1, l31, hi);
+  __syncthreads();  // B3
+  if (PHASE_S && next_tile >= 0) stash_issue_first<G>(f, stash, k, ncoup, next_tile, l31, hi);
+  f32x16 g2[G::MB];
+  dense_bwd_x<G::MB, G::H1B>(img + G::W1, d1, g2, l31, hi);
+#pragma unroll
+  for (int b = 0; b < G::MB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tile_store(gio, tile_soff(b, r, par_c), gold[b][r] + g2[b][r]);
+}
+
+template <class G>
+__device__ __forceinline__ void pair_consume(const float *__restrict__ sp, BwdAcc<G> &acc, float *stash, int k, int ncoup,
+                                             long tile, int nbase, int l31, int hi) {
+  using SG = StashGeo<G>;
+  using L = BwdPairLds<G>;
+  const StashIO st = make_stash_io(stash, tile * ncoup + k, SG::SIZE, true, l31, hi);
+  const int vT = (l31 * 32 + hi * 16) * 4;
+  {
+    float a2t[G::H2B][16];
+    stash_get_T<G::H2B>(st, nbase + SG::A2, vT, a2t);
+    __syncthreads();  // B1
+    dw_accumulate_reg<G::H2B, G::CB>(a2t, sp + L::D3, acc.w3, acc.b3, l31, hi);
+  }
+  {
+    float a1t[G::H1B][16];
+    stash_get_T<G::H1B>(st, nbase + SG::A1, vT, a1t);
+    __syncthreads();  // B2
+    dw_accumulate_reg<G::H1B, G::H2B>(a1t, sp + L::D2, acc.w2, acc.b2, l31, hi);
+  }
+  {
+    float x2t[G::MB][16];
+    stash_get_T<G::MB>(st, SG::XT, vT, x2t);
+    __syncthreads();  // B3
+    dw_accumulate_reg<G::MB, G::H1B>(x2t, sp + L::D1, acc.w1, acc.b1, l31, hi);
+  }
+}
+
+// the two roles' common steps of a phase: staging the net's image, and the slab write after the consumers' fold
+template <class G>
+__device__ __forceinline__ void pair_slab_write(const float *__restrict__ lds, float *__restrict__ dstf, int tid) {
+  const float4 *c0 = reinterpret_cast<const float4 *>(lds);
+  float4 *dst = reinterpret_cast<float4 *>(dstf);
+  constexpr int NV4 = G::SIZE / 4;
+  for (int i = tid; i < NV4; i += 512) {
+    const float4 p0 = c0[i], p1 = c0[i + NV4], p2 = c0[i + 2 * NV4], p3 = c0[i + 3 * NV4];
+    float4 r;
+    r.x = (p0.x + p1.x) + (p2.x + p3.x);
+    r.y = (p0.y + p1.y) + (p2.y + p3.y);
+    r.z = (p0.z + p1.z) + (p2.z + p3.z);
+    r.w = (p0.w + p1.w) + (p2.w + p3.w);
+    dst[i] = r;
+  }
+}
+
+// The role branch is the OUTERMOST statement: the producer's prefetch registers and the consumer's accumulators then
+// never count against the other role's 256 registers (inside the coupling loop both are live across either branch).
+// Every wave executes the same barriers: per phase 1 (image staged) + 3 per tile + 3 (tiles done, folded, slab written).
+template <class G>
+__global__ __launch_bounds__(512) void k_affine_bwd_pair(BwdAllArgs aa, float *stash, float *__restrict__ ybar,
+                                                         const float *__restrict__ lbar, float lbar_const,
+                                                         float *__restrict__ slab, long slab_stride) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *img = lds;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pair = wave & 3, role = wave >> 2;  // waves p and p + 4 sit on the same SIMD; role 0 produces, 1 consumes
+  const int l31 = lane & 31, hi = lane >> 5;
+  float *sp = lds + G::SIZE + pair * BwdPairLds<G>::PAIR;
+  const long ntiles = aa.N / NF_TILE;
+  const long tile0 = (long)blockIdx.x * 4 + pair, tstride = (long)gridDim.x * 4;
+  if (role == 0) {
+    StashFirst<G> f;
+#pragma unroll 1
+    for (int k = 0; k < aa.ncoup; ++k) {
+      CouplingArgs a;
+      a.theta = nullptr;
+      a.img_s = aa.wimg + (size_t)(2 * k) * G::SIZE;
+      a.img_t = a.img_s + G::SIZE;
+      a.trace = nullptr;
+      a.d = aa.d;
+      a.par_t = k & 1;
+      a.c = (k & 1) ? aa.d / 2 : (aa.d + 1) / 2;
+      a.m = aa.d - a.c;
+      a.N = aa.N;
+#pragma unroll 1
+      for (int phase = 0; phase < 2; ++phase) {
+        const bool is_s = phase == 1;
+        stage_packed<G::SIZE, 512>(img, is_s ? a.img_s : a.img_t, tid);
+        __syncthreads();
+#pragma unroll 1
+        for (long tile = tile0; tile < ntiles; tile += tstride) {
+          const long nt = tile + tstride < ntiles ? tile + tstride : -1;
+          if (!is_s) pair_produce<G, false>(a, img, sp, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, l31, hi);
+          else pair_produce<G, true>(a, img, sp, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, l31, hi);
+        }
+        __syncthreads();  // every wave is done with the weight image and the delta tiles
+        // s and u of the next phase-S's first tile fly behind the fold, the slab write and the staging of the next image
+        if (tile0 < ntiles && !is_s) stash_issue_first<G>(f, stash, k, aa.ncoup, tile0, l31, hi);
+        __syncthreads();  // the consumers have folded
+        pair_slab_write<G>(lds, slab + (long)k * 2 * G::SIZE + ((long)blockIdx.x * slab_stride + (is_s ? 0 : 1) * (long)G::SIZE), tid);
+        __syncthreads();
+      }
+    }
+  } else {
+#pragma unroll 1
+    for (int k = 0; k < aa.ncoup; ++k) {
+      const float *img_s = aa.wimg + (size_t)(2 * k) * G::SIZE;
+#pragma unroll 1
+      for (int phase = 0; phase < 2; ++phase) {
+        const bool is_s = phase == 1;
+        stage_packed<G::SIZE, 512>(img, is_s ? img_s : img_s + G::SIZE, tid);
+        __syncthreads();
+        BwdAcc<G> acc;
+        zero_acc(acc.w1, acc.b1);
+        zero_acc(acc.w2, acc.b2);
+        zero_acc(acc.w3, acc.b3);
+#pragma unroll 1
+        for (long tile = tile0; tile < ntiles; tile += tstride) {
+          pair_consume<G>(sp, acc, stash, k, aa.ncoup, tile, StashGeo<G>::NET0 + (is_s ? 0 : StashGeo<G>::NETSZ), l31, hi);
+        }
+        __syncthreads();  // every wave is done with the weight image and the delta tiles
+        {
+          float *mine = lds + pair * G::SIZE;
+          fold_acc(mine + G::W1, mine + G::B1, acc.w1, acc.b1, true, l31, hi);
+          fold_acc(mine + G::W2, mine + G::B2, acc.w2, acc.b2, true, l31, hi);
+          fold_acc(mine + G::W3, mine + G::B3, acc.w3, acc.b3, true, l31, hi);
+        }
+        __syncthreads();
+        pair_slab_write<G>(lds, slab + (long)k * 2 * G::SIZE + ((long)blockIdx.x * slab_stride + (is_s ? 0 : 1) * (long)G::SIZE), tid);
+        __syncthreads();
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------
 static inline int blocks32(int n) { return (n + 31) / 32; }
@@ -1453,6 +1662,21 @@ static int launch_bwd_stashed_v(nf_ctx *ctx, const BwdAllArgs &aa, float *stash,
   return (int)hipGetLastError();
 }
 
+template <class G>
+static int launch_bwd_pair(nf_ctx *ctx, const BwdAllArgs &aa, float *stash, float *ybar, const float *lbar, float lbar_const,
+                           float *slab, long slab_stride, int grid) {
+  const size_t lds = BwdPairLds<G>::BYTES;
+  static AttrOnce attr_once;  // once per device
+  NF_TRY(attr_once.run(ctx->device, [&]() -> int {
+    NF_HIP(hipFuncSetAttribute((const void *)k_affine_bwd_pair<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return NF_OK;
+  }));
+  ProfScope ps(ctx, "affine_bwd");
+  hipLaunchKernelGGL((k_affine_bwd_pair<G>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, aa, stash, ybar, lbar, lbar_const, slab,
+                     slab_stride);
+  return (int)hipGetLastError();
+}
+
 // reverse pass of all couplings from the stash nf_affine_chain_elbo(..., stash) left (same slab layout as
 // nf_affine_bwd_all; ybar: cotangent of the flow output on entry, of the flow input on exit)
 int nf_affine_bwd_stashed(nf_ctx *ctx, const nf_flow_desc *desc, float *stash, float *ybar, const float *lbar, float lbar_const,
@@ -1473,6 +1697,10 @@ int nf_affine_bwd_stashed(nf_ctx *ctx, const nf_flow_desc *desc, float *stash, f
                   : launch_bwd_stashed_v<NetGeo<1, 2, 2, 1>, false, true>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid);
     return launch_bwd_stashed_v<NetGeo<1, 1, 1, 1>, false, true>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid);
   }
+  // whole tiles, dealt evenly to the workgroups' four wave pairs: the two-waves-per-tile kernel
+  static const bool no_pair = std::getenv("NF_BWD_NO_PAIR") != nullptr;  // A/B switch: k_affine_bwd_stashed
+  if (h64 && full && !no_pair && (N / NF_TILE) % ((long)grid * 4) == 0)
+    return launch_bwd_pair<NetGeo<1, 2, 2, 1>>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid);
   if (h64)
     return full ? launch_bwd_stashed_v<NetGeo<1, 2, 2, 1>, true>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid)
                 : launch_bwd_stashed_v<NetGeo<1, 2, 2, 1>, false>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid);
