@@ -49,8 +49,10 @@ FLOPS_STEP_PER_SAMPLE = 786432
 WORKLOAD_TEXT = ("reverse-KL ELBO step: RealNVP d=64, 8 affine couplings, conditioner 32-64-64-32 "
                  "(hdims [64,64]), diag-Gaussian target, Philox base draws, Adam")
 STASHED = not os.environ.get("NF_AFFINE_NO_STASH")  # the library's A/B switch back to the recompute kernel
-DOMINANT = (b"affine_bwd", "k_affine_bwd_stashed (reverse pass of all 8 couplings in one launch from the forward's activation "
-                           "stash: dX + dW, nothing recomputed)" if STASHED else
+PAIR = STASHED and not os.environ.get("NF_BWD_NO_PAIR")  # the library's A/B switch back to one wavefront per tile
+DOMINANT = (b"affine_bwd", ("k_affine_bwd_pair" if PAIR else "k_affine_bwd_stashed") +
+            " (reverse pass of all 8 couplings in one launch from the forward's activation stash: dX + dW, nothing recomputed" +
+            ("; a producer and a consumer wavefront per tile)" if PAIR else ")") if STASHED else
             "k_affine_bwd_all (reverse pass of all 8 couplings in one launch: recompute + dX + dW)")
 KERNEL_NAMES = (b"base_sample", b"pack_weights", b"affine_chain", b"target", b"affine_bwd", b"reduce_slabs", b"adam")
 
@@ -346,7 +348,7 @@ def run_once(args, world, world_observed, rank, dev, dist, damp, state):
         achieved = flop_per_launch / (avg_ms.value * 1e-3) / 1e12 if avg_ms.value > 0 else 0.0
         traffic, traffic_src = (None, None)
         if n_local == BATCH and args.workload in ("cfg2", "cfg3"):
-            traffic, traffic_src = pmc_traffic(("k_affine_bwd_stashed" if STASHED else "k_affine_bwd_all") if args.workload == "cfg2" else "k_rqs_bwd")
+            traffic, traffic_src = pmc_traffic(("k_affine_bwd_pair" if PAIR else "k_affine_bwd_stashed" if STASHED else "k_affine_bwd_all") if args.workload == "cfg2" else "k_rqs_bwd")
         rec = {
             "metric": "elbo_samples_per_sec",
             "value": value,

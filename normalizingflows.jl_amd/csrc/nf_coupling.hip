@@ -1142,9 +1142,10 @@ template <class G, bool PHASE_S>
 __device__ __forceinline__ void pair_produce(const CouplingArgs &a, const float *__restrict__ img, float *__restrict__ sp,
                                              StashFirst<G> &f, float *stash, int k, int ncoup, float *__restrict__ ybar,
                                              const float *__restrict__ lbar, float lbar_const, long tile, long next_tile,
-                                             int l31, int hi) {
+                                             int l31, int hi, long long *tr = nullptr) {
   using SG = StashGeo<G>;
   using L = BwdPairLds<G>;
+  NF_TS_STAMP(0);
   const long j = tile * NF_TILE + l31;
   const int par_c = 1 - a.par_t;
   const TileIO gio = make_tile_io(ybar, tile, a.d, l31, hi);
@@ -1179,17 +1180,23 @@ __device__ __forceinline__ void pair_produce(const CouplingArgs &a, const float 
     }
   tile_to_scratch<G::CB>(sp + L::D3, d3, l31, hi);
   const unsigned m1[2] = {mk[0], mk[1]}, m2[2] = {mk[2], mk[3]};
+  NF_TS_STAMP(1);
   __syncthreads();  // B1: d3 is in LDS (and the consumer is done with the previous tile's d1)
+  NF_TS_STAMP(2);
   f32x16 d2[G::H2B];
   dense_bwd_x<G::H2B, G::CB>(img + G::W3, d3, d2, l31, hi);
   apply_lrelu_grad<G::H2B>(d2, m2);
   tile_to_scratch<G::H2B>(sp + L::D2, d2, l31, hi);
+  NF_TS_STAMP(3);
   __syncthreads();  // B2
+  NF_TS_STAMP(4);
   f32x16 d1[G::H1B];
   dense_bwd_x<G::H1B, G::H2B>(img + G::W2, d2, d1, l31, hi);
   apply_lrelu_grad<G::H1B>(d1, m1);
   tile_to_scratch<G::H1B>(sp + L::D1, d1, l31, hi);
+  NF_TS_STAMP(5);
   __syncthreads();  // B3
+  NF_TS_STAMP(6);
   if (PHASE_S && next_tile >= 0) stash_issue_first<G>(f, stash, k, ncoup, next_tile, l31, hi);
   f32x16 g2[G::MB];
   dense_bwd_x<G::MB, G::H1B>(img + G::W1, d1, g2, l31, hi);
@@ -1197,33 +1204,43 @@ __device__ __forceinline__ void pair_produce(const CouplingArgs &a, const float 
   for (int b = 0; b < G::MB; ++b)
 #pragma unroll
     for (int r = 0; r < 16; ++r) tile_store(gio, tile_soff(b, r, par_c), gold[b][r] + g2[b][r]);
+  NF_TS_STAMP(7);
 }
 
-template <class G>
-__device__ __forceinline__ void pair_consume(const float *__restrict__ sp, BwdAcc<G> &acc, float *stash, int k, int ncoup,
-                                             long tile, int nbase, int l31, int hi) {
+// LATE (A/B switch NF_BWD_PAIR_LATE, off): dW1 of a tile in front of the NEXT tile's first barrier, where the producer has
+// no MFMAs of its own.  Measured slower (374-379 us against 366 in the same run), kept for the record.
+template <class G, bool LATE>
+__device__ __forceinline__ void pair_consume(const float *__restrict__ sp, BwdAcc<G> &acc, float (&x2t)[G::MB][16], bool have_prev,
+                                             float *stash, int k, int ncoup, long tile, int nbase, int l31, int hi,
+                                             long long *tr = nullptr) {
   using SG = StashGeo<G>;
   using L = BwdPairLds<G>;
+  NF_TS_STAMP(0);
   const StashIO st = make_stash_io(stash, tile * ncoup + k, SG::SIZE, true, l31, hi);
   const int vT = (l31 * 32 + hi * 16) * 4;
   {
     float a2t[G::H2B][16];
     stash_get_T<G::H2B>(st, nbase + SG::A2, vT, a2t);
+    if (LATE && have_prev) dw_accumulate_reg<G::MB, G::H1B>(x2t, sp + L::D1, acc.w1, acc.b1, l31, hi);
+    NF_TS_STAMP(1);
     __syncthreads();  // B1
+    NF_TS_STAMP(2);
     dw_accumulate_reg<G::H2B, G::CB>(a2t, sp + L::D3, acc.w3, acc.b3, l31, hi);
   }
   {
     float a1t[G::H1B][16];
     stash_get_T<G::H1B>(st, nbase + SG::A1, vT, a1t);
+    NF_TS_STAMP(3);
     __syncthreads();  // B2
+    NF_TS_STAMP(4);
     dw_accumulate_reg<G::H1B, G::H2B>(a1t, sp + L::D2, acc.w2, acc.b2, l31, hi);
   }
-  {
-    float x2t[G::MB][16];
-    stash_get_T<G::MB>(st, SG::XT, vT, x2t);
-    __syncthreads();  // B3
-    dw_accumulate_reg<G::MB, G::H1B>(x2t, sp + L::D1, acc.w1, acc.b1, l31, hi);
-  }
+  stash_get_T<G::MB>(st, SG::XT, vT, x2t);
+  NF_TS_STAMP(5);
+  __syncthreads();  // B3
+  NF_TS_STAMP(6);
+  if (!LATE) dw_accumulate_reg<G::MB, G::H1B>(x2t, sp + L::D1, acc.w1, acc.b1, l31, hi);
+  NF_TS_STAMP(7);
 }
 
 // the two roles' common steps of a phase: staging the net's image, and the slab write after the consumers' fold
@@ -1246,7 +1263,7 @@ __device__ __forceinline__ void pair_slab_write(const float *__restrict__ lds, f
 // The role branch is the OUTERMOST statement: the producer's prefetch registers and the consumer's accumulators then
 // never count against the other role's 256 registers (inside the coupling loop both are live across either branch).
 // Every wave executes the same barriers: per phase 1 (image staged) + 3 per tile + 3 (tiles done, folded, slab written).
-template <class G>
+template <class G, bool LATE>
 __global__ __launch_bounds__(512) void k_affine_bwd_pair(BwdAllArgs aa, float *stash, float *__restrict__ ybar,
                                                          const float *__restrict__ lbar, float lbar_const,
                                                          float *__restrict__ slab, long slab_stride) {
@@ -1281,8 +1298,14 @@ __global__ __launch_bounds__(512) void k_affine_bwd_pair(BwdAllArgs aa, float *s
 #pragma unroll 1
         for (long tile = tile0; tile < ntiles; tile += tstride) {
           const long nt = tile + tstride < ntiles ? tile + tstride : -1;
-          if (!is_s) pair_produce<G, false>(a, img, sp, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, l31, hi);
-          else pair_produce<G, true>(a, img, sp, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, l31, hi);
+#ifdef NF_KERNEL_TRACE  // tools/trace_bwd_pair.py: block 0, pair 0, coupling 0; producer stamps [phase 16 + tile 8 + 0..7]
+          const long ti = (tile - tile0) / tstride;
+          long long *tr = (aa.trace && blockIdx.x == 0 && tid == 0 && k == 0 && ti < 2) ? aa.trace + phase * 16 + ti * 8 : nullptr;
+#else
+          long long *tr = nullptr;
+#endif
+          if (!is_s) pair_produce<G, false>(a, img, sp, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, l31, hi, tr);
+          else pair_produce<G, true>(a, img, sp, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, l31, hi, tr);
         }
         __syncthreads();  // every wave is done with the weight image and the delta tiles
         // s and u of the next phase-S's first tile fly behind the fold, the slab write and the staging of the next image
@@ -1305,10 +1328,20 @@ __global__ __launch_bounds__(512) void k_affine_bwd_pair(BwdAllArgs aa, float *s
         zero_acc(acc.w1, acc.b1);
         zero_acc(acc.w2, acc.b2);
         zero_acc(acc.w3, acc.b3);
+        float x2t[G::MB][16];
+        bool have_prev = false;
 #pragma unroll 1
         for (long tile = tile0; tile < ntiles; tile += tstride) {
-          pair_consume<G>(sp, acc, stash, k, aa.ncoup, tile, StashGeo<G>::NET0 + (is_s ? 0 : StashGeo<G>::NETSZ), l31, hi);
+#ifdef NF_KERNEL_TRACE  // consumer stamps at [64 + ...]
+          const long ti = (tile - tile0) / tstride;
+          long long *tr = (aa.trace && blockIdx.x == 0 && tid == 256 && k == 0 && ti < 2) ? aa.trace + 64 + phase * 16 + ti * 8 : nullptr;
+#else
+          long long *tr = nullptr;
+#endif
+          pair_consume<G, LATE>(sp, acc, x2t, have_prev, stash, k, aa.ncoup, tile, StashGeo<G>::NET0 + (is_s ? 0 : StashGeo<G>::NETSZ), l31, hi, tr);
+          have_prev = true;
         }
+        if (LATE && have_prev) dw_accumulate_reg<G::MB, G::H1B>(x2t, sp + BwdPairLds<G>::D1, acc.w1, acc.b1, l31, hi);  // the last tile's dW1
         __syncthreads();  // every wave is done with the weight image and the delta tiles
         {
           float *mine = lds + pair * G::SIZE;
@@ -1662,19 +1695,26 @@ static int launch_bwd_stashed_v(nf_ctx *ctx, const BwdAllArgs &aa, float *stash,
   return (int)hipGetLastError();
 }
 
-template <class G>
-static int launch_bwd_pair(nf_ctx *ctx, const BwdAllArgs &aa, float *stash, float *ybar, const float *lbar, float lbar_const,
-                           float *slab, long slab_stride, int grid) {
+template <class G, bool LATE>
+static int launch_bwd_pair_t(nf_ctx *ctx, const BwdAllArgs &aa, float *stash, float *ybar, const float *lbar, float lbar_const,
+                             float *slab, long slab_stride, int grid) {
   const size_t lds = BwdPairLds<G>::BYTES;
   static AttrOnce attr_once;  // once per device
   NF_TRY(attr_once.run(ctx->device, [&]() -> int {
-    NF_HIP(hipFuncSetAttribute((const void *)k_affine_bwd_pair<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NF_HIP(hipFuncSetAttribute((const void *)k_affine_bwd_pair<G, LATE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return NF_OK;
   }));
   ProfScope ps(ctx, "affine_bwd");
-  hipLaunchKernelGGL((k_affine_bwd_pair<G>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, aa, stash, ybar, lbar, lbar_const, slab,
-                     slab_stride);
+  hipLaunchKernelGGL((k_affine_bwd_pair<G, LATE>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, aa, stash, ybar, lbar, lbar_const,
+                     slab, slab_stride);
   return (int)hipGetLastError();
+}
+template <class G>
+static int launch_bwd_pair(nf_ctx *ctx, const BwdAllArgs &aa, float *stash, float *ybar, const float *lbar, float lbar_const,
+                           float *slab, long slab_stride, int grid) {
+  static const bool late = std::getenv("NF_BWD_PAIR_LATE") != nullptr;  // A/B switch, see pair_consume
+  return late ? launch_bwd_pair_t<G, true>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid)
+              : launch_bwd_pair_t<G, false>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid);
 }
 
 // reverse pass of all couplings from the stash nf_affine_chain_elbo(..., stash) left (same slab layout as
