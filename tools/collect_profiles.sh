@@ -31,9 +31,13 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ
 # issue-side counters of the planar / radial step (missing 5): where k_simple_step's time goes
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS SQ_INSTS_SALU -d "$OUT/pmc_simple_issue" -o pmc --output-format csv -- python3 tools/bench_simple.py 262144 > "$OUT/pmc_simple_issue.log" 2>&1
 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_WAIT_INST_LDS -d "$OUT/pmc_simple_issue2" -o pmc --output-format csv -- python3 tools/bench_simple.py 262144 > "$OUT/pmc_simple_issue2.log" 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 -d "$OUT/pmc_simple_mfma" -o pmc --output-format csv -- python3 tools/bench_simple.py 1048576 > "$OUT/pmc_simple_mfma.log" 2>&1
 # the three forms of the cfg-2 step: nf_elbo_step (default), split calls, hipGraph replay
 python3 bench.py --no-cpu-baseline --split-calls > "$OUT/bench_default_split_calls.json" 2>> "$OUT/bench_default.err"
 python3 bench.py --no-cpu-baseline --graph > "$OUT/bench_default_graph.json" 2>> "$OUT/bench_default.err"
+# A/B of the cfg-2 reverse kernel on this box: one wavefront per tile (k_affine_bwd_stashed) instead of the pair kernel
+NF_BWD_NO_PAIR=1 python3 bench.py --no-cpu-baseline > "$OUT/bench_default_one_wave_per_tile.json" 2>> "$OUT/bench_default.err"
+NF_PLANAR_NO_MFMA=1 python3 tools/bench_simple.py > "$OUT/simple_no_mfma.txt" 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 -d "$OUT/pmc_cfg4_mfma" -o pmc --output-format csv -- python3 bench.py --workload cfg4 --batch 32768 --steps 3 --warmup 1 --no-kernel-events > "$OUT/pmc_cfg4_mfma.log" 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C -d "$OUT/pmc_cfg4_$C" -o pmc --output-format csv -- python3 bench.py --workload cfg4 --batch 32768 --steps 3 --warmup 1 --no-kernel-events > "$OUT/pmc_cfg4_$C.log" 2>&1
