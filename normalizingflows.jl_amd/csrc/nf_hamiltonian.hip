@@ -171,28 +171,45 @@ __device__ void hf_leapfrog_bwd(const HfArgs &a, const T *eps, T *tr, T *xb, T *
   }
 }
 
-// reverse pass of the whole chain at the flow INPUT x0: ybar -> xbar (in gbar), dL/dtheta added to g.
+// Parameter gradients without atomics (round 3): a workgroup is one wavefront; every contribution is summed over the wave's
+// 64 samples (fixed butterfly order) and added by lane 0 to the workgroup's accumulator row in LDS; after the wave's last
+// tile the row goes to slab[blockIdx.x][P], and nf_launch_reduce_slabs adds the slabs in block order: deterministic.
+template <class T>
+__device__ __forceinline__ void hf_acc(T *__restrict__ row, long idx, T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if (threadIdx.x == 0) row[idx] += v;
+}
+#define HF_MAX_BLOCKS 2048
+
+// reverse pass of the whole chain at the flow INPUT x0: ybar -> xbar (in gbar), dL/dtheta to slab[blockIdx.x][P].
 // ws: [n][N][2D] inputs of every block (written here).
 template <class T>
 __global__ __launch_bounds__(HF_BLOCK) void k_hf_bwd(HfArgs a, const T *__restrict__ theta, const T *__restrict__ x0,
                                                      T *gbar, const T *__restrict__ lbar, T lbar_const,
-                                                     T *__restrict__ ws, T *__restrict__ g) {
-  const long j = (long)blockIdx.x * HF_BLOCK + threadIdx.x;
-  if (j >= a.N) return;
+                                                     T *__restrict__ ws, T *__restrict__ slab, long P) {
+  extern __shared__ __attribute__((aligned(16))) char hf_smem[];
+  T *g = (T *)hf_smem;  // [P] this workgroup's sums
+  for (long i = threadIdx.x; i < P; i += HF_BLOCK) g[i] = 0;
+  __syncthreads();
   const int D = a.D, d2 = 2 * D, n = a.n;
-  const T lb = lbar ? lbar[j] : lbar_const;
+  for (long j0 = (long)blockIdx.x * HF_BLOCK; j0 < a.N; j0 += (long)gridDim.x * HF_BLOCK) {
+  const bool valid = j0 + threadIdx.x < a.N;
+  const long j = valid ? j0 + threadIdx.x : a.N - 1;  // idle lanes shadow the last sample with zero cotangents
+  const T lb = valid ? (lbar ? lbar[j] : lbar_const) : (T)0;
   T z[2 * HF_MAXD];
   const T *sh0 = theta, *sc0 = theta + d2;
   for (int i = 0; i < d2; ++i) z[i] = sh0[i] + sc0[i] * x0[j * d2 + i];
   for (int bi = n - 1; bi >= 0; --bi) {  // forward, remembering what enters each block
     T *slot = ws + ((long)bi * a.N + j) * d2;
-    for (int i = 0; i < d2; ++i) slot[i] = z[i];
+    if (valid)
+      for (int i = 0; i < d2; ++i) slot[i] = z[i];
     const T *shr = theta + 4 * D + 3 * D * bi, *scr = shr + D, *leps = scr + D;
     hf_leapfrog<T>(a, leps, (T)1, z, z + D, nullptr);
     for (int i = 0; i < D; ++i) z[D + i] = shr[i] + scr[i] * z[D + i];
   }
   T zb[2 * HF_MAXD], tr[(HF_MAXL + 1) * 3 * HF_MAXD], eps[HF_MAXD], ebar[HF_MAXD];
-  for (int i = 0; i < d2; ++i) zb[i] = gbar[j * d2 + i];
+  for (int i = 0; i < d2; ++i) zb[i] = valid ? gbar[j * d2 + i] : (T)0;
   for (int bi = 0; bi < n; ++bi) {  // reverse of execution order
     const long o0 = 4 * D + 3 * D * bi;
     const T *shr = theta + o0, *scr = shr + D, *leps = scr + D;
@@ -203,19 +220,22 @@ __global__ __launch_bounds__(HF_BLOCK) void k_hf_bwd(HfArgs a, const T *__restri
     for (int i = 0; i < D; ++i) {
       eps[i] = exp(leps[i]);
       ebar[i] = 0;
-      atomicAdd(g + o0 + i, vb[i]);                              // shift_rho
-      atomicAdd(g + o0 + D + i, vb[i] * z[D + i] + lb / scr[i]);  // scale_rho (+ d ladj / d scale)
+      hf_acc<T>(g, o0 + i, vb[i]);                              // shift_rho
+      hf_acc<T>(g, o0 + D + i, vb[i] * z[D + i] + lb / scr[i]);  // scale_rho (+ d ladj / d scale)
       vb[i] *= scr[i];
     }
     hf_leapfrog_bwd<T>(a, eps, tr, xb, vb, ebar);
-    for (int i = 0; i < D; ++i) atomicAdd(g + o0 + 2 * D + i, ebar[i] * eps[i]);  // d/d log_eps
+    for (int i = 0; i < D; ++i) hf_acc<T>(g, o0 + 2 * D + i, ebar[i] * eps[i]);  // d/d log_eps
   }
   for (int i = 0; i < d2; ++i) {  // reference map
     const T xi = x0[j * d2 + i];
-    atomicAdd(g + i, zb[i]);
-    atomicAdd(g + d2 + i, zb[i] * xi + lb / sc0[i]);
-    gbar[j * d2 + i] = zb[i] * sc0[i];
+    hf_acc<T>(g, i, zb[i]);
+    hf_acc<T>(g, d2 + i, zb[i] * xi + lb / sc0[i]);
+    if (valid) gbar[j * d2 + i] = zb[i] * sc0[i];
   }
+  }
+  __syncthreads();
+  for (long i = threadIdx.x; i < P; i += HF_BLOCK) slab[(long)blockIdx.x * P + i] = g[i];
 }
 
 // Reverse pass of the INVERSE chain (forward-KL training, `train_flow(loglikelihood, flow, xs)`).  The inverse of
@@ -224,16 +244,23 @@ __global__ __launch_bounds__(HF_BLOCK) void k_hf_bwd(HfArgs a, const T *__restri
 // point x0 = T^-1(u), lb = cotangent of ladj_inv = -sum log|scale|.  ws: [n][N][2D] inputs of every inverse block.
 template <class T>
 __global__ __launch_bounds__(HF_BLOCK) void k_hf_bwd_inv(HfArgs a, const T *__restrict__ theta, const T *__restrict__ u,
-                                                         const T *__restrict__ gbar, T lb, T *__restrict__ ws,
-                                                         T *__restrict__ g) {
-  const long j = (long)blockIdx.x * HF_BLOCK + threadIdx.x;
-  if (j >= a.N) return;
+                                                         const T *__restrict__ gbar, T lb_all, T *__restrict__ ws,
+                                                         T *__restrict__ slab, long P) {
+  extern __shared__ __attribute__((aligned(16))) char hf_smem[];
+  T *g = (T *)hf_smem;  // [P] this workgroup's sums
+  for (long i = threadIdx.x; i < P; i += HF_BLOCK) g[i] = 0;
+  __syncthreads();
   const int D = a.D, d2 = 2 * D, n = a.n;
+  for (long j0 = (long)blockIdx.x * HF_BLOCK; j0 < a.N; j0 += (long)gridDim.x * HF_BLOCK) {
+  const bool valid = j0 + threadIdx.x < a.N;
+  const long j = valid ? j0 + threadIdx.x : a.N - 1;
+  const T lb = valid ? lb_all : (T)0;
   T z[2 * HF_MAXD];
   for (int i = 0; i < d2; ++i) z[i] = u[j * d2 + i];
   for (int bi = 0; bi < n; ++bi) {  // inverse chain: flat blocks 0 .. n-1, then the reference map
     T *slot = ws + ((long)bi * a.N + j) * d2;
-    for (int i = 0; i < d2; ++i) slot[i] = z[i];
+    if (valid)
+      for (int i = 0; i < d2; ++i) slot[i] = z[i];
     const T *shr = theta + 4 * D + 3 * D * bi, *scr = shr + D, *leps = scr + D;
     for (int i = 0; i < D; ++i) z[D + i] = (z[D + i] - shr[i]) / scr[i];
     hf_leapfrog<T>(a, leps, -(T)1, z, z + D, nullptr);
@@ -242,9 +269,9 @@ __global__ __launch_bounds__(HF_BLOCK) void k_hf_bwd_inv(HfArgs a, const T *__re
   T zb[2 * HF_MAXD], tr[(HF_MAXL + 1) * 3 * HF_MAXD], eps[HF_MAXD], ebar[HF_MAXD];
   for (int i = 0; i < d2; ++i) {  // x0 = (z - sh0) / sc0
     const T x0 = (z[i] - sh0[i]) / sc0[i];
-    const T b = gbar[j * d2 + i] / sc0[i];
-    atomicAdd(g + i, -b);
-    atomicAdd(g + d2 + i, -b * x0 - lb / sc0[i]);
+    const T b = valid ? gbar[j * d2 + i] / sc0[i] : (T)0;
+    hf_acc<T>(g, i, -b);
+    hf_acc<T>(g, d2 + i, -b * x0 - lb / sc0[i]);
     zb[i] = b;
   }
   for (int bi = n - 1; bi >= 0; --bi) {
@@ -263,13 +290,16 @@ __global__ __launch_bounds__(HF_BLOCK) void k_hf_bwd_inv(HfArgs a, const T *__re
     T *xb = zb, *vb = zb + D;
     hf_leapfrog_bwd<T>(a, eps, tr, xb, vb, ebar);
     for (int i = 0; i < D; ++i) {
-      atomicAdd(g + o0 + 2 * D + i, ebar[i] * eps[i]);  // d(-exp(log_eps)) / d log_eps = eps (signed)
+      hf_acc<T>(g, o0 + 2 * D + i, ebar[i] * eps[i]);  // d(-exp(log_eps)) / d log_eps = eps (signed)
       const T b = vb[i] / scr[i];
-      atomicAdd(g + o0 + i, -b);
-      atomicAdd(g + o0 + D + i, -b * rp[i] - lb / scr[i]);
+      hf_acc<T>(g, o0 + i, -b);
+      hf_acc<T>(g, o0 + D + i, -b * rp[i] - lb / scr[i]);
       vb[i] = b;
     }
   }
+  }
+  __syncthreads();
+  for (long i = threadIdx.x; i < P; i += HF_BLOCK) slab[(long)blockIdx.x * P + i] = g[i];
 }
 
 // ---- host side --------------------------------------------------------------------------------
@@ -306,42 +336,64 @@ int nf_hf_apply(nf_ctx *ctx, const nf_flow_desc *desc, int lo, int hi, bool inve
   return (int)hipGetLastError();
 }
 
-size_t nf_hf_bwd_ws_bytes(const nf_flow_desc *desc, long N) { return (size_t)desc->nlayers * (size_t)N * desc->d * sizeof(double); }
+static inline long hf_param_count(const nf_flow_desc *desc) { return 2L * desc->d + 3L * (desc->d / 2) * desc->nlayers; }
+static inline unsigned hf_bwd_grid(long N) {
+  const long nb = (N + HF_BLOCK - 1) / HF_BLOCK;
+  return (unsigned)(nb < HF_MAX_BLOCKS ? (nb < 1 ? 1 : nb) : HF_MAX_BLOCKS);
+}
+// the blocks' remembered inputs [n][N][2D], then the gradient slabs [blocks][P] (element size of the widest type)
+static inline size_t hf_stash_bytes(const nf_flow_desc *desc, long N) { return (((size_t)desc->nlayers * (size_t)N * desc->d * sizeof(double)) + 255) / 256 * 256; }
+size_t nf_hf_bwd_ws_bytes(const nf_flow_desc *desc, long N) {
+  return hf_stash_bytes(desc, N) + (size_t)hf_bwd_grid(N) * (size_t)hf_param_count(desc) * sizeof(double);
+}
+int nf_launch_reduce_slabs(nf_ctx *ctx, int dtype, const void *slab, int nslab, long P, void *g);
 
 int nf_hf_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *x, const void *ybar, const void *lbar,
               double lbar_const, long N, void *xbar_out, void *gtheta_out, void *ws) {
   const size_t es = desc->dtype == NF_DTYPE_F64 ? 8 : 4;
-  const long P = 2L * desc->d + 3L * (desc->d / 2) * desc->nlayers;
-  NF_HIP(hipMemsetAsync(gtheta_out, 0, (size_t)P * es, ctx->stream));
-  if (N <= 0) return NF_OK;
+  const long P = hf_param_count(desc);
+  if (N <= 0) {
+    NF_HIP(hipMemsetAsync(gtheta_out, 0, (size_t)P * es, ctx->stream));
+    return NF_OK;
+  }
   if (xbar_out != ybar) NF_HIP(hipMemcpyAsync(xbar_out, ybar, (size_t)N * desc->d * es, hipMemcpyDeviceToDevice, ctx->stream));
   const HfArgs a = make_hf_args(desc, N);
-  const unsigned grid = (unsigned)((N + HF_BLOCK - 1) / HF_BLOCK);
-  ProfScope ps(ctx, "hf_bwd");
-  if (desc->dtype == NF_DTYPE_F64)
-    hipLaunchKernelGGL(k_hf_bwd<double>, dim3(grid), dim3(HF_BLOCK), 0, ctx->stream, a, (const double *)theta,
-                       (const double *)x, (double *)xbar_out, (const double *)lbar, lbar_const, (double *)ws, (double *)gtheta_out);
-  else
-    hipLaunchKernelGGL(k_hf_bwd<float>, dim3(grid), dim3(HF_BLOCK), 0, ctx->stream, a, (const float *)theta,
-                       (const float *)x, (float *)xbar_out, (const float *)lbar, (float)lbar_const, (float *)ws, (float *)gtheta_out);
-  return (int)hipGetLastError();
+  const unsigned grid = hf_bwd_grid(N);
+  char *slab = (char *)ws + hf_stash_bytes(desc, N);
+  {
+    ProfScope ps(ctx, "hf_bwd");
+    if (desc->dtype == NF_DTYPE_F64)
+      hipLaunchKernelGGL(k_hf_bwd<double>, dim3(grid), dim3(HF_BLOCK), (size_t)P * 8, ctx->stream, a, (const double *)theta,
+                         (const double *)x, (double *)xbar_out, (const double *)lbar, lbar_const, (double *)ws, (double *)slab, P);
+    else
+      hipLaunchKernelGGL(k_hf_bwd<float>, dim3(grid), dim3(HF_BLOCK), (size_t)P * 4, ctx->stream, a, (const float *)theta,
+                         (const float *)x, (float *)xbar_out, (const float *)lbar, (float)lbar_const, (float *)ws, (float *)slab, P);
+    NF_HIP(hipGetLastError());
+  }
+  return nf_launch_reduce_slabs(ctx, desc->dtype, slab, (int)grid, P, gtheta_out);
 }
 
 // forward-KL reverse pass: u = data (d x N), gbar = cotangent of T^-1(u), lbar_const = cotangent of ladj_inv
 int nf_hf_bwd_inv(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *u, const void *gbar, double lbar_const,
                   long N, void *gtheta_out, void *ws) {
   const size_t es = desc->dtype == NF_DTYPE_F64 ? 8 : 4;
-  const long P = 2L * desc->d + 3L * (desc->d / 2) * desc->nlayers;
-  NF_HIP(hipMemsetAsync(gtheta_out, 0, (size_t)P * es, ctx->stream));
-  if (N <= 0) return NF_OK;
+  const long P = hf_param_count(desc);
+  if (N <= 0) {
+    NF_HIP(hipMemsetAsync(gtheta_out, 0, (size_t)P * es, ctx->stream));
+    return NF_OK;
+  }
   const HfArgs a = make_hf_args(desc, N);
-  const unsigned grid = (unsigned)((N + HF_BLOCK - 1) / HF_BLOCK);
-  ProfScope ps(ctx, "hf_bwd");
-  if (desc->dtype == NF_DTYPE_F64)
-    hipLaunchKernelGGL(k_hf_bwd_inv<double>, dim3(grid), dim3(HF_BLOCK), 0, ctx->stream, a, (const double *)theta,
-                       (const double *)u, (const double *)gbar, lbar_const, (double *)ws, (double *)gtheta_out);
-  else
-    hipLaunchKernelGGL(k_hf_bwd_inv<float>, dim3(grid), dim3(HF_BLOCK), 0, ctx->stream, a, (const float *)theta,
-                       (const float *)u, (const float *)gbar, (float)lbar_const, (float *)ws, (float *)gtheta_out);
-  return (int)hipGetLastError();
+  const unsigned grid = hf_bwd_grid(N);
+  char *slab = (char *)ws + hf_stash_bytes(desc, N);
+  {
+    ProfScope ps(ctx, "hf_bwd");
+    if (desc->dtype == NF_DTYPE_F64)
+      hipLaunchKernelGGL(k_hf_bwd_inv<double>, dim3(grid), dim3(HF_BLOCK), (size_t)P * 8, ctx->stream, a, (const double *)theta,
+                         (const double *)u, (const double *)gbar, lbar_const, (double *)ws, (double *)slab, P);
+    else
+      hipLaunchKernelGGL(k_hf_bwd_inv<float>, dim3(grid), dim3(HF_BLOCK), (size_t)P * 4, ctx->stream, a, (const float *)theta,
+                         (const float *)u, (const float *)gbar, (float)lbar_const, (float *)ws, (float *)slab, P);
+    NF_HIP(hipGetLastError());
+  }
+  return nf_launch_reduce_slabs(ctx, desc->dtype, slab, (int)grid, P, gtheta_out);
 }

@@ -152,12 +152,11 @@ def test_caller_provided_arena_covers_every_entry_point(name):
     try:
         nf._lib.check(lib.nf_ctx_set_arena(ctx.ptr, C.c_void_p(base), need))
         got = run_everything()
-        # the general one-thread-per-sample kernels (Float64 / odd shapes) sum parameter gradients with atomics: equal up
-        # to summation order; every other path is deterministic and must reproduce bit for bit
-        atomic = flow.kind in ("realnvp", "nsf") and name in ("realnvp_f64", "nsf_general")
+        # every path sums parameter gradients in a fixed order (round 3: the general one-thread-per-sample kernels too,
+        # wave sums into workgroup slabs): the arena run must reproduce the owned-memory run bit for bit
 
         def same(a, b):
-            return torch.allclose(a, b, rtol=1e-5 if dt == torch.float32 else 1e-12, atol=1e-6 if dt == torch.float32 else 1e-13) if atomic else torch.equal(a, b)
+            return torch.equal(a, b)
 
         for k in ref:
             assert same(ref[k], got[k]), (name, k)

@@ -822,6 +822,9 @@ def test_hamiltonian_flow_matches_oracle(nf, tname, dtn):
     lr, gr = o.hflow_neg_elbo_value_and_grad(D, n, L, th64, otgt, x064)
     P.scalar(f"{tag}: loss", loss, lr, 10 * rt)
     P.gradient(f"{tag}: grad", g, gr, 1e-9 if dtn == "float64" else P.GRAD_RTOL)
+    # round 3: no atomics in the reverse kernels (wave sums into workgroup slabs, reduced in block order): same bits again
+    loss2, g2 = nf.value_and_gradient(nf.elbo_batch, flow, tgt, cm(x0, dt))
+    assert torch.equal(g, g2) and loss == loss2
 
 
 def test_hamiltonian_theta_order_reference_map_first(nf):
