@@ -1138,15 +1138,25 @@ struct BwdPairLds {
   static constexpr size_t BYTES = (size_t)FLOATS * sizeof(float);  // the fold at the end of a phase needs 4 images
 };
 
-template <class G, bool PHASE_S>
+// FULL: d = 64 and N a multiple of the tile (no sample / feature masks).  INVD: reverse pass of the INVERSE coupling
+// (forward-KL training; algebra of bwd_tile_stashed: phase S first, the UV slot holds w1).  live: this pair has a tile in
+// this round of the workgroup's tile loop -- a pair without one only keeps the barrier count.
+template <class G, bool PHASE_S, bool FULL, bool INVD>
 __device__ __forceinline__ void pair_produce(const CouplingArgs &a, const float *__restrict__ img, float *__restrict__ sp,
                                              StashFirst<G> &f, float *stash, int k, int ncoup, float *__restrict__ ybar,
                                              const float *__restrict__ lbar, float lbar_const, long tile, long next_tile,
-                                             int l31, int hi, long long *tr = nullptr) {
+                                             bool live, int l31, int hi, long long *tr = nullptr) {
   using SG = StashGeo<G>;
   using L = BwdPairLds<G>;
+  if (!live) {
+    __syncthreads();
+    __syncthreads();
+    __syncthreads();
+    return;
+  }
   NF_TS_STAMP(0);
   const long j = tile * NF_TILE + l31;
+  const bool valid = FULL ? true : j < a.N;
   const int par_c = 1 - a.par_t;
   const TileIO gio = make_tile_io(ybar, tile, a.d, l31, hi);
   const StashIO st = make_stash_io(stash, tile * ncoup + k, SG::SIZE, true, l31, hi);
@@ -1162,16 +1172,20 @@ __device__ __forceinline__ void pair_produce(const CouplingArgs &a, const float 
   for (int b = 0; b < G::MB; ++b)
 #pragma unroll
     for (int r = 0; r < 16; ++r) gold[b][r] = tile_load(gio, tile_soff(b, r, par_c));
-  const float lb = lbar ? lbar[j] : lbar_const;
+  const float lb = valid ? (lbar ? lbar[FULL ? j : (j < a.N ? j : 0)] : lbar_const) : 0.f;
   f32x16 d3[G::CB];
 #pragma unroll
   for (int b = 0; b < G::CB; ++b)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const bool ok = b * 32 + nf_row(r, hi) < a.c;
+      const bool ok = (b * 32 + nf_row(r, hi) < a.c) && valid;
       const float gv = g1[b][r];
       if (!PHASE_S) {
-        d3[b][r] = ok ? gv : 0.f;  // T-bar = ybar1
+        d3[b][r] = ok ? (INVD ? -gv : gv) : 0.f;  // T-bar = ybar1 (inverse: -v1bar)
+      } else if (INVD) {
+        const float sv = f.sv[b][r];
+        tile_store(gio, tile_soff(b, r, a.par_t), nf_fdiv(gv, nf_exp(sv)));  // v1bar
+        d3[b][r] = ok ? -(gv * f.uv[b][r] + lb) * (1.f - sv * sv) : 0.f;    // S-bar through tanh (uv = w1)
       } else {
         const float sv = f.sv[b][r];
         tile_store(gio, tile_soff(b, r, a.par_t), gv * nf_exp(sv));        // x1bar
@@ -1207,21 +1221,25 @@ __device__ __forceinline__ void pair_produce(const CouplingArgs &a, const float 
   NF_TS_STAMP(7);
 }
 
-// LATE (A/B switch NF_BWD_PAIR_LATE, off): dW1 of a tile in front of the NEXT tile's first barrier, where the producer has
-// no MFMAs of its own.  Measured slower (374-379 us against 366 in the same run), kept for the record.
-template <class G, bool LATE>
-__device__ __forceinline__ void pair_consume(const float *__restrict__ sp, BwdAcc<G> &acc, float (&x2t)[G::MB][16], bool have_prev,
-                                             float *stash, int k, int ncoup, long tile, int nbase, int l31, int hi,
-                                             long long *tr = nullptr) {
+// (Measured and removed: dW1 of a tile moved in front of the NEXT tile's first barrier, where the producer issues no
+// MFMAs -- 374-379 us against 366 in one process; and the producer's next-unit operands requested behind B3 -- 370.)
+template <class G>
+__device__ __forceinline__ void pair_consume(const float *__restrict__ sp, BwdAcc<G> &acc, float *stash, int k, int ncoup,
+                                             long tile, int nbase, bool live, int l31, int hi, long long *tr = nullptr) {
   using SG = StashGeo<G>;
   using L = BwdPairLds<G>;
+  if (!live) {
+    __syncthreads();
+    __syncthreads();
+    __syncthreads();
+    return;
+  }
   NF_TS_STAMP(0);
   const StashIO st = make_stash_io(stash, tile * ncoup + k, SG::SIZE, true, l31, hi);
   const int vT = (l31 * 32 + hi * 16) * 4;
   {
     float a2t[G::H2B][16];
     stash_get_T<G::H2B>(st, nbase + SG::A2, vT, a2t);
-    if (LATE && have_prev) dw_accumulate_reg<G::MB, G::H1B>(x2t, sp + L::D1, acc.w1, acc.b1, l31, hi);
     NF_TS_STAMP(1);
     __syncthreads();  // B1
     NF_TS_STAMP(2);
@@ -1235,15 +1253,18 @@ __device__ __forceinline__ void pair_consume(const float *__restrict__ sp, BwdAc
     NF_TS_STAMP(4);
     dw_accumulate_reg<G::H1B, G::H2B>(a1t, sp + L::D2, acc.w2, acc.b2, l31, hi);
   }
-  stash_get_T<G::MB>(st, SG::XT, vT, x2t);
-  NF_TS_STAMP(5);
-  __syncthreads();  // B3
-  NF_TS_STAMP(6);
-  if (!LATE) dw_accumulate_reg<G::MB, G::H1B>(x2t, sp + L::D1, acc.w1, acc.b1, l31, hi);
-  NF_TS_STAMP(7);
+  {
+    float x2t[G::MB][16];
+    stash_get_T<G::MB>(st, SG::XT, vT, x2t);
+    NF_TS_STAMP(5);
+    __syncthreads();  // B3
+    NF_TS_STAMP(6);
+    dw_accumulate_reg<G::MB, G::H1B>(x2t, sp + L::D1, acc.w1, acc.b1, l31, hi);
+    NF_TS_STAMP(7);
+  }
 }
 
-// the two roles' common steps of a phase: staging the net's image, and the slab write after the consumers' fold
+// the two roles' common step of a phase: the slab write after the consumers' fold
 template <class G>
 __device__ __forceinline__ void pair_slab_write(const float *__restrict__ lds, float *__restrict__ dstf, int tid) {
   const float4 *c0 = reinterpret_cast<const float4 *>(lds);
@@ -1262,8 +1283,9 @@ __device__ __forceinline__ void pair_slab_write(const float *__restrict__ lds, f
 
 // The role branch is the OUTERMOST statement: the producer's prefetch registers and the consumer's accumulators then
 // never count against the other role's 256 registers (inside the coupling loop both are live across either branch).
-// Every wave executes the same barriers: per phase 1 (image staged) + 3 per tile + 3 (tiles done, folded, slab written).
-template <class G, bool LATE>
+// Every wave executes the same barriers: per phase 1 (image staged) + 3 per round of the tile loop + 3 (tiles done,
+// folded, slab written); the tile loop runs as many rounds as the workgroup's first pair needs.
+template <class G, bool FULL, bool INVD>
 __global__ __launch_bounds__(512) void k_affine_bwd_pair(BwdAllArgs aa, float *stash, float *__restrict__ ybar,
                                                          const float *__restrict__ lbar, float lbar_const,
                                                          float *__restrict__ slab, long slab_stride) {
@@ -1274,12 +1296,16 @@ __global__ __launch_bounds__(512) void k_affine_bwd_pair(BwdAllArgs aa, float *s
   const int pair = wave & 3, role = wave >> 2;  // waves p and p + 4 sit on the same SIMD; role 0 produces, 1 consumes
   const int l31 = lane & 31, hi = lane >> 5;
   float *sp = lds + G::SIZE + pair * BwdPairLds<G>::PAIR;
-  const long ntiles = aa.N / NF_TILE;
+  const long ntiles = (aa.N + NF_TILE - 1) / NF_TILE;
   const long tile0 = (long)blockIdx.x * 4 + pair, tstride = (long)gridDim.x * 4;
+  const long wg0 = (long)blockIdx.x * 4;
+  const int rounds = wg0 < ntiles ? (int)((ntiles - wg0 + tstride - 1) / tstride) : 0;
   if (role == 0) {
     StashFirst<G> f;
+    if (INVD && tile0 < ntiles) stash_issue_first<G>(f, stash, aa.ncoup - 1, aa.ncoup, tile0, l31, hi);  // S runs first
 #pragma unroll 1
-    for (int k = 0; k < aa.ncoup; ++k) {
+    for (int step = 0; step < aa.ncoup; ++step) {
+      const int k = INVD ? aa.ncoup - 1 - step : step;  // the inverse chain's reverse pass runs in execution order
       CouplingArgs a;
       a.theta = nullptr;
       a.img_s = aa.wimg + (size_t)(2 * k) * G::SIZE;
@@ -1292,24 +1318,27 @@ __global__ __launch_bounds__(512) void k_affine_bwd_pair(BwdAllArgs aa, float *s
       a.N = aa.N;
 #pragma unroll 1
       for (int phase = 0; phase < 2; ++phase) {
-        const bool is_s = phase == 1;
+        const bool is_s = INVD ? phase == 0 : phase == 1;
         stage_packed<G::SIZE, 512>(img, is_s ? a.img_s : a.img_t, tid);
         __syncthreads();
 #pragma unroll 1
-        for (long tile = tile0; tile < ntiles; tile += tstride) {
+        for (int it = 0; it < rounds; ++it) {
+          const long tile = tile0 + (long)it * tstride;
           const long nt = tile + tstride < ntiles ? tile + tstride : -1;
-#ifdef NF_KERNEL_TRACE  // tools/trace_bwd_pair.py: block 0, pair 0, coupling 0; producer stamps [phase 16 + tile 8 + 0..7]
-          const long ti = (tile - tile0) / tstride;
-          long long *tr = (aa.trace && blockIdx.x == 0 && tid == 0 && k == 0 && ti < 2) ? aa.trace + phase * 16 + ti * 8 : nullptr;
+#ifdef NF_KERNEL_TRACE  // tools/trace_bwd_pair.py: block 0, pair 0, first coupling; producer stamps [phase 16 + tile 8 + 0..7]
+          long long *tr = (aa.trace && blockIdx.x == 0 && tid == 0 && step == 0 && it < 2) ? aa.trace + phase * 16 + it * 8 : nullptr;
 #else
           long long *tr = nullptr;
 #endif
-          if (!is_s) pair_produce<G, false>(a, img, sp, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, l31, hi, tr);
-          else pair_produce<G, true>(a, img, sp, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, l31, hi, tr);
+          if (!is_s) pair_produce<G, false, FULL, INVD>(a, img, sp, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, tile < ntiles, l31, hi, tr);
+          else pair_produce<G, true, FULL, INVD>(a, img, sp, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, tile < ntiles, l31, hi, tr);
         }
         __syncthreads();  // every wave is done with the weight image and the delta tiles
         // s and u of the next phase-S's first tile fly behind the fold, the slab write and the staging of the next image
-        if (tile0 < ntiles && !is_s) stash_issue_first<G>(f, stash, k, aa.ncoup, tile0, l31, hi);
+        if (tile0 < ntiles) {
+          if (!INVD && !is_s) stash_issue_first<G>(f, stash, k, aa.ncoup, tile0, l31, hi);
+          if (INVD && !is_s && step + 1 < aa.ncoup) stash_issue_first<G>(f, stash, k - 1, aa.ncoup, tile0, l31, hi);
+        }
         __syncthreads();  // the consumers have folded
         pair_slab_write<G>(lds, slab + (long)k * 2 * G::SIZE + ((long)blockIdx.x * slab_stride + (is_s ? 0 : 1) * (long)G::SIZE), tid);
         __syncthreads();
@@ -1317,31 +1346,28 @@ __global__ __launch_bounds__(512) void k_affine_bwd_pair(BwdAllArgs aa, float *s
     }
   } else {
 #pragma unroll 1
-    for (int k = 0; k < aa.ncoup; ++k) {
+    for (int step = 0; step < aa.ncoup; ++step) {
+      const int k = INVD ? aa.ncoup - 1 - step : step;
       const float *img_s = aa.wimg + (size_t)(2 * k) * G::SIZE;
 #pragma unroll 1
       for (int phase = 0; phase < 2; ++phase) {
-        const bool is_s = phase == 1;
+        const bool is_s = INVD ? phase == 0 : phase == 1;
         stage_packed<G::SIZE, 512>(img, is_s ? img_s : img_s + G::SIZE, tid);
         __syncthreads();
         BwdAcc<G> acc;
         zero_acc(acc.w1, acc.b1);
         zero_acc(acc.w2, acc.b2);
         zero_acc(acc.w3, acc.b3);
-        float x2t[G::MB][16];
-        bool have_prev = false;
 #pragma unroll 1
-        for (long tile = tile0; tile < ntiles; tile += tstride) {
+        for (int it = 0; it < rounds; ++it) {
+          const long tile = tile0 + (long)it * tstride;
 #ifdef NF_KERNEL_TRACE  // consumer stamps at [64 + ...]
-          const long ti = (tile - tile0) / tstride;
-          long long *tr = (aa.trace && blockIdx.x == 0 && tid == 256 && k == 0 && ti < 2) ? aa.trace + 64 + phase * 16 + ti * 8 : nullptr;
+          long long *tr = (aa.trace && blockIdx.x == 0 && tid == 256 && step == 0 && it < 2) ? aa.trace + 64 + phase * 16 + it * 8 : nullptr;
 #else
           long long *tr = nullptr;
 #endif
-          pair_consume<G, LATE>(sp, acc, x2t, have_prev, stash, k, aa.ncoup, tile, StashGeo<G>::NET0 + (is_s ? 0 : StashGeo<G>::NETSZ), l31, hi, tr);
-          have_prev = true;
+          pair_consume<G>(sp, acc, stash, k, aa.ncoup, tile, StashGeo<G>::NET0 + (is_s ? 0 : StashGeo<G>::NETSZ), tile < ntiles, l31, hi, tr);
         }
-        if (LATE && have_prev) dw_accumulate_reg<G::MB, G::H1B>(x2t, sp + BwdPairLds<G>::D1, acc.w1, acc.b1, l31, hi);  // the last tile's dW1
         __syncthreads();  // every wave is done with the weight image and the delta tiles
         {
           float *mine = lds + pair * G::SIZE;
@@ -1695,26 +1721,19 @@ static int launch_bwd_stashed_v(nf_ctx *ctx, const BwdAllArgs &aa, float *stash,
   return (int)hipGetLastError();
 }
 
-template <class G, bool LATE>
-static int launch_bwd_pair_t(nf_ctx *ctx, const BwdAllArgs &aa, float *stash, float *ybar, const float *lbar, float lbar_const,
-                             float *slab, long slab_stride, int grid) {
+template <class G, bool FULL, bool INVD>
+static int launch_bwd_pair(nf_ctx *ctx, const BwdAllArgs &aa, float *stash, float *ybar, const float *lbar, float lbar_const,
+                           float *slab, long slab_stride, int grid) {
   const size_t lds = BwdPairLds<G>::BYTES;
   static AttrOnce attr_once;  // once per device
   NF_TRY(attr_once.run(ctx->device, [&]() -> int {
-    NF_HIP(hipFuncSetAttribute((const void *)k_affine_bwd_pair<G, LATE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NF_HIP(hipFuncSetAttribute((const void *)k_affine_bwd_pair<G, FULL, INVD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return NF_OK;
   }));
-  ProfScope ps(ctx, "affine_bwd");
-  hipLaunchKernelGGL((k_affine_bwd_pair<G, LATE>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, aa, stash, ybar, lbar, lbar_const,
-                     slab, slab_stride);
+  ProfScope ps(ctx, INVD ? "affine_bwd_inv" : "affine_bwd");
+  hipLaunchKernelGGL((k_affine_bwd_pair<G, FULL, INVD>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, aa, stash, ybar, lbar,
+                     lbar_const, slab, slab_stride);
   return (int)hipGetLastError();
-}
-template <class G>
-static int launch_bwd_pair(nf_ctx *ctx, const BwdAllArgs &aa, float *stash, float *ybar, const float *lbar, float lbar_const,
-                           float *slab, long slab_stride, int grid) {
-  static const bool late = std::getenv("NF_BWD_PAIR_LATE") != nullptr;  // A/B switch, see pair_consume
-  return late ? launch_bwd_pair_t<G, true>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid)
-              : launch_bwd_pair_t<G, false>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid);
 }
 
 // reverse pass of all couplings from the stash nf_affine_chain_elbo(..., stash) left (same slab layout as
@@ -1731,16 +1750,22 @@ int nf_affine_bwd_stashed(nf_ctx *ctx, const nf_flow_desc *desc, float *stash, f
   aa.N = N;
   const bool h64 = size != NetGeo<1, 1, 1, 1>::SIZE;
   const bool full = desc->d == 64 && N % NF_TILE == 0;
+  // hidden 33-64: the two-waves-per-tile kernel (both directions, ragged batches and d < 64 included)
+  static const bool no_pair = std::getenv("NF_BWD_NO_PAIR") != nullptr;  // A/B switch: k_affine_bwd_stashed
+  if (h64 && !no_pair) {
+    using GP = NetGeo<1, 2, 2, 1>;
+    if (inv_dir)
+      return full ? launch_bwd_pair<GP, true, true>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid)
+                  : launch_bwd_pair<GP, false, true>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid);
+    return full ? launch_bwd_pair<GP, true, false>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid)
+                : launch_bwd_pair<GP, false, false>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid);
+  }
   if (inv_dir) {  // forward-KL training: the stash of the inverse chain (nf_affine_chain(inverse, stash))
     if (h64)
       return full ? launch_bwd_stashed_v<NetGeo<1, 2, 2, 1>, true, true>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid)
                   : launch_bwd_stashed_v<NetGeo<1, 2, 2, 1>, false, true>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid);
     return launch_bwd_stashed_v<NetGeo<1, 1, 1, 1>, false, true>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid);
   }
-  // whole tiles, dealt evenly to the workgroups' four wave pairs: the two-waves-per-tile kernel
-  static const bool no_pair = std::getenv("NF_BWD_NO_PAIR") != nullptr;  // A/B switch: k_affine_bwd_stashed
-  if (h64 && full && !no_pair && (N / NF_TILE) % ((long)grid * 4) == 0)
-    return launch_bwd_pair<NetGeo<1, 2, 2, 1>>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid);
   if (h64)
     return full ? launch_bwd_stashed_v<NetGeo<1, 2, 2, 1>, true>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid)
                 : launch_bwd_stashed_v<NetGeo<1, 2, 2, 1>, false>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid);
