@@ -1193,7 +1193,11 @@ __device__ __forceinline__ void pair_produce(const CouplingArgs &a, const float 
       }
     }
   tile_to_scratch<G::CB>(sp + L::D3, d3, l31, hi);
-  const unsigned m1[2] = {mk[0], mk[1]}, m2[2] = {mk[2], mk[3]};
+  unsigned m1[G::H1B], m2[G::H2B];
+#pragma unroll
+  for (int b = 0; b < G::H1B; ++b) m1[b] = mk[b];
+#pragma unroll
+  for (int b = 0; b < G::H2B; ++b) m2[b] = mk[2 + b];
   NF_TS_STAMP(1);
   __syncthreads();  // B1: d3 is in LDS (and the consumer is done with the previous tile's d1)
   NF_TS_STAMP(2);
@@ -1752,6 +1756,7 @@ int nf_affine_bwd_stashed(nf_ctx *ctx, const nf_flow_desc *desc, float *stash, f
   const bool full = desc->d == 64 && N % NF_TILE == 0;
   // hidden 33-64: the two-waves-per-tile kernel (both directions, ragged batches and d < 64 included)
   static const bool no_pair = std::getenv("NF_BWD_NO_PAIR") != nullptr;  // A/B switch: k_affine_bwd_stashed
+  // (hidden <= 32 was measured with this kernel too: 226.9 against 227.8 us at d = 64, batch 65 536 -- no gain, not instantiated)
   if (h64 && !no_pair) {
     using GP = NetGeo<1, 2, 2, 1>;
     if (inv_dir)
