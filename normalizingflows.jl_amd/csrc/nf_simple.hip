@@ -1392,6 +1392,324 @@ __global__ __launch_bounds__(SB, (PG::NLR <= 6 ? 2 : 1)) void k_planar_step(Simp
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Radial training step, one lane per (sample, feature half) (k_radial_step): d <= 64, up to 16 layers, Float32.
+// ------------------------------------------------------------------------------------------------------------------
+// Same layout as k_planar_step -- a lane holds sample l31 of a 32-sample tile and the C-layout features of its half-wave
+// (whole Philox groups) -- but no GEMMs: a radial layer's update direction z - z0 changes with the sample, so the planar
+// reformulation does not carry over.  What the layout buys here is the scalar math once per sample
+// instead of sixteen times (sqrt, the reciprocals, the log terms, the reverse pass's chain of scalars), norms and dot
+// products as 32 in-lane FMAs + one half-wave exchange instead of four DPP steps per four features, and ONE stashed scalar
+// per layer.  The only cross-sample sums, z0bar_l[f] = -sum_j db_j[f], are 32 values per lane to be summed over the 32
+// lanes of a half-wave: wave_transpose_reduce32 leaves the sum of value i in lane i (v_permlane16_swap across the two
+// rows, then DPP row_ror:8, row_half_mirror, quad_perm xor 2, xor 1 with the lane's own bits selecting what it keeps:
+// 77 instructions; tools/probe/transpose_reduce_probe.hip), so the accumulators cost one register per layer.
+__device__ __forceinline__ float radial_dpp(float v, int stage) {
+  const int b = __builtin_bit_cast(int, v);
+  switch (stage) {
+    case 0: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, b, 0x128, 0xF, 0xF, false));  // row_ror:8
+    case 1: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, b, 0x141, 0xF, 0xF, false));  // row_half_mirror
+    case 2: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, b, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+    default: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, b, 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
+  }
+}
+// v[16 b + r]: 32 values per lane; returns, in lane l31 of either half-wave, the sum over that half's 32 lanes of v[l31]
+__device__ __forceinline__ float wave_transpose_reduce32(const float (&v)[32], int lane) {
+  float w[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const unsigned a = __builtin_bit_cast(unsigned, v[i]), b = __builtin_bit_cast(unsigned, v[i + 16]);
+    const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);  // [a.row0 b.row0 a.row2 b.row2], [a.row1 b.row1 ...]
+    unsigned r0 = r[0], r1 = r[1];
+    asm volatile("s_nop 1" : "+v"(r0), "+v"(r1));  // as v_permlane32_swap: a VALU read of the results needs wait states
+    w[i] = __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+  }
+  float u[8], t[4], q[2];
+  const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) u[i] = (b3 ? w[i + 8] : w[i]) + radial_dpp(b3 ? w[i] : w[i + 8], 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) t[i] = (b2 ? u[i + 4] : u[i]) + radial_dpp(b2 ? u[i] : u[i + 4], 1);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) q[i] = (b1 ? t[i + 2] : t[i]) + radial_dpp(b1 ? t[i] : t[i + 2], 2);
+  return (b0 ? q[1] : q[0]) + radial_dpp(b0 ? q[0] : q[1], 3);
+}
+
+template <int DB_, int NL_>
+struct RadialGeo {
+  static constexpr int DB = DB_, NL = NL_, FD = 32 * DB;
+  static constexpr int OFF_C = 0;                   // centres z0_l[f], [NL][FD], zero beyond d / nl
+  static constexpr int OFF_A = OFF_C + NL * FD;     // alpha_l
+  static constexpr int OFF_BH = OFF_A + NL;         // beta_hat_l
+  static constexpr int OFF_TG = ((OFF_BH + NL + 3) / 4) * 4;  // target: mu[f] | 1/var[f] | log 2pi + log var[f]
+  static constexpr int SHARED = OFF_TG + 3 * FD;
+  static constexpr int ROW = NL * FD + 2 * NL;      // per wave, block epilogue: z0bar[l][f] | alpha_bar[l] | betahat_bar[l]
+  static constexpr size_t lds_floats(int nl, int lp) { return (size_t)SHARED + 4 * (size_t)ROW + (size_t)nl * lp; }
+};
+
+template <class RG, bool DIAG>
+__global__ __launch_bounds__(SB, 2) void k_radial_step(SimpleArgs a, const float *__restrict__ theta, const float *__restrict__ xs,
+                                                       SimpleFused fu, float lbar_const, float *__restrict__ slabs,
+                                                       long slab_stride) {
+  constexpr int DB = RG::DB, NL = RG::NL, FD = RG::FD;
+  extern __shared__ __attribute__((aligned(16))) float rsm[];
+  const int d = a.d, nl = a.nl, LP = lp_of(d);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  float *sh = rsm;
+  float *cache = rsm + RG::SHARED + 4 * RG::ROW;  // [nl][LP]: z0 | alpha | beta_hat  (build_layer_cache)
+  build_layer_cache<float>(cache, a, theta);
+  __syncthreads();
+  for (int i = tid; i < NL * FD; i += SB) {
+    const int l = i / FD, f = i - l * FD;
+    sh[RG::OFF_C + i] = (l < nl && f < d) ? cache[l * LP + f] : 0.f;
+  }
+  for (int i = tid; i < NL; i += SB) {
+    sh[RG::OFF_A + i] = i < nl ? cache[i * LP + d] : 1.f;
+    sh[RG::OFF_BH + i] = i < nl ? cache[i * LP + d + 1] : 0.f;
+  }
+  if (DIAG)
+    for (int i = tid; i < FD; i += SB) {
+      const float vv = i < d ? ((const float *)fu.var)[i] : 1.f;
+      sh[RG::OFF_TG + i] = i < d ? ((const float *)fu.mu)[i] : 0.f;
+      sh[RG::OFF_TG + FD + i] = i < d ? 1.f / vv : 0.f;
+      sh[RG::OFF_TG + 2 * FD + i] = i < d ? 1.8378770664093453f + logf(vv) : 0.f;
+    }
+  __syncthreads();
+  auto sc = [&](int off) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sh[off]))); };
+  float al[NL], bhv[NL];
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    al[l] = sc(RG::OFF_A + l);
+    bhv[l] = sc(RG::OFF_BH + l);
+  }
+  float acc[NL], sa[NL], sb[NL];
+#pragma unroll
+  for (int l = 0; l < NL; ++l) acc[l] = sa[l] = sb[l] = 0.f;
+  double contrib = 0.0;
+  const float dm1 = (float)(d - 1);
+  const long ntiles = (a.N + 31) / 32;
+  for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+    asm volatile("" ::: "memory");  // keep the centre fetches inside the loop
+    const long j = tile * 32 + l31;
+    const bool valid = j < a.N;
+    f32x16 z[DB];
+    float ss = 0.f;
+#pragma unroll
+    for (int b = 0; b < DB; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int f0 = 32 * b + 8 * q + 4 * hi;
+        float n4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (f0 < d && valid) {
+          if (fu.draw) {
+            philox_normals4<float>(fu.off + (uint64_t)j, (uint32_t)(f0 >> 2), fu.stream, fu.k0, fu.k1, n4);
+          } else {
+            const float *row = xs + j * d + f0;
+            if (a.vec) {
+              const float4 v = *reinterpret_cast<const float4 *>(row);
+              n4[0] = v.x; n4[1] = v.y; n4[2] = v.z; n4[3] = v.w;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) n4[e] = f0 + e < d ? row[e] : 0.f;
+            }
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = (f0 + e < d) ? n4[e] : 0.f;
+          z[b][4 * q + e] = v;
+          ss += v * v;
+        }
+      }
+    // ---- forward: r_l is all that is kept of a layer
+    float rs[NL];
+    float lsum = 0.f;
+#pragma unroll
+    for (int l = NL - 1; l >= 0; --l) {
+      rs[l] = 0.f;
+      if (l < nl) {
+        const float *cl = sh + RG::OFF_C + l * FD + 4 * hi;
+        f32x16 dl[DB];
+        float s2 = 0.f;
+#pragma unroll
+        for (int b = 0; b < DB; ++b)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float c4[4];
+            nf_ld4<FD>(cl + 32 * b + 8 * q, c4[0], c4[1], c4[2], c4[3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float dv = z[b][4 * q + e] - c4[e];  // features beyond d: 0 - 0
+              dl[b][4 * q + e] = dv;
+              s2 += dv * dv;
+            }
+          }
+        const float r = Fm<float>::sqrt_(planar_xhalf_sum(s2));
+        const float h = Fm<float>::div_(1.f, al[l] + r), qv = bhv[l] * h;
+#pragma unroll
+        for (int b = 0; b < DB; ++b)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) z[b][e] += qv * dl[b][e];
+        lsum += dm1 * Fm<float>::log1p_(qv) + Fm<float>::log1p_(qv - qv * h * r);
+        rs[l] = r;
+      }
+    }
+    // ---- target: log p(y), g = gscale grad log p(y)
+    f32x16 g[DB];
+    float tacc = 0.f;
+    {
+      float y0, y1, dummy;
+      planar_gather(z[0][0], y0, dummy);
+      planar_gather(z[0][1], y1, dummy);
+      float s2 = 0.f;
+      if (!DIAG && fu.tkind == NF_TARGET_FUNNEL) {
+#pragma unroll
+        for (int b = 0; b < DB; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s2 += (32 * b + nf_row(r, hi) >= 1) ? z[b][r] * z[b][r] : 0.f;
+        s2 = planar_xhalf_sum(s2);
+      }
+      auto run = [&](auto kc) {
+        constexpr int KD = decltype(kc)::value;
+#pragma unroll
+        for (int b = 0; b < DB; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int f = 32 * b + nf_row(r, hi);
+            float gk = 0.f;
+            if constexpr (KD == NF_TARGET_DIAGGAUSS) {
+              const float rr = z[b][r] - sh[RG::OFF_TG + f], iv = sh[RG::OFF_TG + FD + f];
+              tacc -= 0.5f * (sh[RG::OFF_TG + 2 * FD + f] + rr * rr * iv);
+              gk = -rr * iv;
+            } else {
+              if (f < d)
+                tacc += target_term<KD, float>(d, f, z[b][r], y0, y1, s2, (const float *)fu.mu, (const float *)fu.var, (float)fu.s0,
+                                               (float)fu.s1, gk);
+            }
+            g[b][r] = valid ? (float)fu.gscale * gk : 0.f;
+          }
+      };
+      if constexpr (DIAG) {
+        run(std::integral_constant<int, NF_TARGET_DIAGGAUSS>{});
+      } else {
+        switch (fu.tkind) {
+          case NF_TARGET_BANANA: run(std::integral_constant<int, NF_TARGET_BANANA>{}); break;
+          case NF_TARGET_FUNNEL: run(std::integral_constant<int, NF_TARGET_FUNNEL>{}); break;
+          case NF_TARGET_WARPED: run(std::integral_constant<int, NF_TARGET_WARPED>{}); break;
+          default: run(std::integral_constant<int, NF_TARGET_CROSS>{}); break;
+        }
+      }
+      tacc = planar_xhalf_sum(tacc);
+      ss = planar_xhalf_sum(ss);
+      const float logq = (float)(-0.5 * 1.8378770664093453 * d) - 0.5f * ss;
+      if (valid && hi == 0) contrib += fu.pscale * (double)(tacc - logq + lsum);
+    }
+    // ---- reverse: the state walks back alongside the cotangent (layer_bwd_s's algebra, once per sample)
+    const float lb = valid ? lbar_const : 0.f;
+    const float once = hi == 0 ? 1.f : 0.f;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      if (l < nl) {
+        const float alpha = al[l], bh = bhv[l], r = rs[l];
+        const float h = Fm<float>::div_(1.f, alpha + r), qq = bh * h, bah2 = bh * alpha * h * h;
+        const float iq = Fm<float>::div_(1.f, 1.f + qq), ib = Fm<float>::div_(1.f, 1.f + bah2), ir = r > 0.f ? Fm<float>::div_(1.f, r) : 0.f;
+        const float *cl = sh + RG::OFF_C + l * FD + 4 * hi;
+        float dl[32];
+        float yd = 0.f;
+#pragma unroll
+        for (int b = 0; b < DB; ++b)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float c4[4];
+            nf_ld4<FD>(cl + 32 * b + 8 * q, c4[0], c4[1], c4[2], c4[3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float dv = (z[b][4 * q + e] - c4[e]) * iq;  // y - z0 = delta (1 + beta_hat h)
+              z[b][4 * q + e] = c4[e] + dv;                    // the layer input
+              dl[16 * b + 4 * q + e] = dv;
+              yd += g[b][4 * q + e] * dv;
+            }
+          }
+#pragma unroll
+        for (int i = 16 * DB; i < 32; ++i) dl[i] = 0.f;
+        yd = planar_xhalf_sum(yd);
+        const float dL_dh = dm1 * bh * iq + 2.f * bh * alpha * h * ib;
+        const float dL_db = dm1 * h * iq + alpha * h * h * ib;
+        const float dL_da = bh * h * h * ib;
+        const float hbar = bh * yd + lb * dL_dh;
+        const float rho = -h * h * hbar * ir;
+#pragma unroll
+        for (int b = 0; b < DB; ++b)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const float dbv = qq * g[b][e] + rho * dl[16 * b + e];
+            dl[16 * b + e] = dbv;
+            g[b][e] += dbv;
+          }
+        acc[l] -= wave_transpose_reduce32(dl, lane);  // z0bar
+        sa[l] += once * (-h * h * hbar + lb * dL_da);
+        sb[l] += once * (h * yd + lb * dL_db);
+      }
+    }
+  }
+  // ---- block epilogue: waves in a fixed order, slabs in k_simple_step's layout (z0bar | - | alpha_bar | betahat_bar)
+  {
+    float *rg = rsm + RG::SHARED + wave * RG::ROW;
+    const int facc = 32 * (l31 >> 4) + nf_row(l31 & 15, hi);  // the feature whose sum wave_transpose_reduce32 left in this lane
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      if (facc < FD) rg[l * FD + facc] = acc[l];
+      float v0 = sa[l], v1 = sb[l];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        v0 += __shfl_xor(v0, o, 64);
+        v1 += __shfl_xor(v1, o, 64);
+      }
+      if (lane == 0) {
+        rg[NL * FD + l] = v0;
+        rg[NL * FD + NL + l] = v1;
+      }
+    }
+  }
+  __syncthreads();
+  {
+    float *r0 = rsm + RG::SHARED;
+    for (int i = tid; i < RG::ROW; i += SB) {
+      float v = r0[i];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) v += r0[w * RG::ROW + i];
+      r0[i] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < nl * d; i += SB) {
+      const int l = i / d, f = i - l * d;
+      float *out = slabs + (long)l * slab_stride + (long)blockIdx.x * LP;
+      out[f] = r0[l * FD + f];
+      out[d + f] = 0.f;
+    }
+    for (int l = tid; l < nl; l += SB) {
+      float *out = slabs + (long)l * slab_stride + (long)blockIdx.x * LP;
+      out[2 * d] = r0[NL * FD + l];
+      out[2 * d + 1] = r0[NL * FD + NL + l];
+    }
+  }
+  {  // deterministic block sum of the ELBO terms
+    __shared__ double sm[SB / 64];
+    double c = contrib;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (lane == 0) sm[wave] = c;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+#pragma unroll
+      for (int w = 0; w < SB / 64; ++w) t += sm[w];
+      fu.partial[blockIdx.x] = t;
+    }
+  }
+}
+
 // sums the per-block slabs of every layer and applies the parameter-space chain rule
 // (get_u_hat for planar, softplus re-parameterisation for radial).  One block of FB threads per layer: FB / 64
 // row groups each sum every (FB/64)-th slab with 64 consecutive columns per wave (coalesced, independent loads),
@@ -1757,6 +2075,49 @@ static int planar_step(nf_ctx *ctx, const SimpleArgs &a, const void *theta, cons
               : planar_launch<PlanarGeo<1, 8>>(ctx, a, theta, xs, fu, lbar_const, slabs, nb_out);
 }
 
+// ---- the radial step, one lane per (sample, feature half) (k_radial_step) -------------------------------------------
+static bool radial_lane_ok(const nf_flow_desc *desc) {
+  static const bool off = std::getenv("NF_RADIAL_NO_LANE") != nullptr;  // A/B switch: k_simple_step
+  return !off && desc->kind == NF_KIND_RADIAL && desc->dtype == NF_DTYPE_F32 && desc->d >= 8 && desc->d <= 64 &&
+         desc->nlayers >= 1 && desc->nlayers <= 16;
+}
+template <class RG, bool DIAG>
+static int radial_launch_t(nf_ctx *ctx, SimpleArgs a, const void *theta, const void *xs, const SimpleFused &fu, double lbar_const,
+                           float *slabs, int *nb_out) {
+  const size_t LP = lp_of(a.d);
+  const size_t lds = RG::lds_floats(a.nl, (int)LP) * sizeof(float);
+  static AttrOnce attr_once;  // once per device
+  NF_TRY(attr_once.run(ctx->device, [&]() -> int {
+    NF_HIP(hipFuncSetAttribute((const void *)k_radial_step<RG, DIAG>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    return NF_OK;
+  }));
+  a.vec = (xs && a.d % 4 == 0 && (uintptr_t)xs % 16 == 0) ? 1 : 0;
+  long nb = ((a.N + 31) / 32 + 3) / 4;
+  const long res = resident_blocks(ctx, k_radial_step<RG, DIAG>, lds);
+  if (nb > res) nb = res;
+  if (nb < 1) nb = 1;
+  *nb_out = (int)nb;
+  ProfScope ps(ctx, "radial_step");
+  hipLaunchKernelGGL((k_radial_step<RG, DIAG>), dim3((unsigned)nb), dim3(SB), lds, ctx->stream, a, (const float *)theta, (const float *)xs,
+                     fu, (float)lbar_const, slabs, (long)nb * (long)LP);
+  return (int)hipGetLastError();
+}
+template <class RG>
+static int radial_launch(nf_ctx *ctx, const SimpleArgs &a, const void *theta, const void *xs, const SimpleFused &fu, double lbar_const,
+                         float *slabs, int *nb_out) {
+  return fu.tkind == NF_TARGET_DIAGGAUSS ? radial_launch_t<RG, true>(ctx, a, theta, xs, fu, lbar_const, slabs, nb_out)
+                                         : radial_launch_t<RG, false>(ctx, a, theta, xs, fu, lbar_const, slabs, nb_out);
+}
+static int radial_step(nf_ctx *ctx, const SimpleArgs &a, const void *theta, const void *xs, const SimpleFused &fu, double lbar_const,
+                       float *slabs, int *nb_out) {
+  const bool wide = a.d > 32;
+  if (a.nl <= 10)
+    return wide ? radial_launch<RadialGeo<2, 10>>(ctx, a, theta, xs, fu, lbar_const, slabs, nb_out)
+                : radial_launch<RadialGeo<1, 10>>(ctx, a, theta, xs, fu, lbar_const, slabs, nb_out);
+  return wide ? radial_launch<RadialGeo<2, 16>>(ctx, a, theta, xs, fu, lbar_const, slabs, nb_out)
+              : radial_launch<RadialGeo<1, 16>>(ctx, a, theta, xs, fu, lbar_const, slabs, nb_out);
+}
+
 // smallest unroll bound that holds nl layers
 // three unroll bounds (4, 10, 12): unused slots still cost their accumulator registers, and ten layers is the shape of
 // BASELINE cfg 1 and of the reference's planar / radial tests (test/flow.jl:137,203)
@@ -1798,7 +2159,7 @@ static int step_nlmax(const nf_flow_desc *desc) {
 
 // flows whose every layer input fits the register budget of k_simple_step and whose caches + reduction rows fit LDS
 bool nf_simple_step_supported(const nf_flow_desc *desc) {
-  if (planar_mfma_ok(desc)) return true;
+  if (planar_mfma_ok(desc) || radial_lane_ok(desc)) return true;
   if (!nf_simple_supported(desc) || dpl_for(desc->d) > 16) return false;
   const int nl = desc->kind == NF_KIND_MEANFIELD ? 2 : desc->nlayers;
   const size_t es = desc->dtype == NF_DTYPE_F64 ? 8 : 4;
@@ -1836,8 +2197,9 @@ static int step_t(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target
   int nb = 0;
   int st;
   if constexpr (std::is_same<T, float>::value) {
-    if (planar_mfma_ok(desc)) {
-      NF_TRY(planar_step(ctx, a, theta, xs, fu, lbar_const, slabs, &nb));
+    if (planar_mfma_ok(desc) || radial_lane_ok(desc)) {
+      NF_TRY(planar_mfma_ok(desc) ? planar_step(ctx, a, theta, xs, fu, lbar_const, slabs, &nb)
+                                  : radial_step(ctx, a, theta, xs, fu, lbar_const, slabs, &nb));
       *npartial = nb;
       ProfScope pf(ctx, "simple_finalize");
       hipLaunchKernelGGL(k_simple_finalize<T>, dim3(nl), dim3(FB), (size_t)(1 + FB / 64) * lp_of(a.d) * sizeof(T), ctx->stream, a,

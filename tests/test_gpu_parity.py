@@ -630,6 +630,42 @@ def test_synthetic_targets_logp_and_score(nf, name, dtn):
         P.gradient(f"target {name}: realnvp grad", g2, gr2)
 
 
+@pytest.mark.parametrize("kind,d,nl,n", [("planar", 9, 3, 45), ("planar", 33, 10, 1000), ("planar", 64, 16, 333), ("planar", 64, 10, 4099),
+                                         ("radial", 9, 3, 45), ("radial", 33, 10, 1000), ("radial", 64, 16, 333), ("radial", 64, 10, 4099)])
+@pytest.mark.parametrize("tname", ["diaggauss", "banana", "funnel"])
+def test_planar_radial_lane_per_sample_steps_against_oracle(nf, kind, d, nl, n, tname):
+    """Round 3: Float32 planar (k_planar_step: the step as GEMMs on the matrix pipe) and radial (k_radial_step: one lane per
+    sample and feature half, transpose-reduce for the centre gradients) training steps for d <= 64, <= 16 layers -- loss and
+    gradient with in-library draws and with supplied draws against the oracle (src/flows/planar_radial.jl:21-29,52-60 under
+    src/objectives/elbo.jl:93-97), ragged batches, one and two feature blocks, both unroll bounds, and the targets with
+    cross-feature terms."""
+    rng = np.random.default_rng(d + nl)
+    if tname == "diaggauss":
+        mu, var = rng.standard_normal(d).astype(np.float32), (rng.uniform(size=d) + 0.5).astype(np.float32)
+        tgt = nf.DiagGaussTarget(torch.tensor(mu, device="cuda"), torch.tensor(var, device="cuda"))
+        otgt = ("diaggauss", mu.astype(np.float64), var.astype(np.float64))
+    elif tname == "banana":
+        tgt, otgt = nf.BananaTarget(d, 0.3, 4.0), ("banana", 0.3, 4.0)
+    else:
+        tgt, otgt = nf.FunnelTarget(d, -1.0, 1.5), ("funnel", -1.0, 1.5)
+    flow = (nf.planarflow if kind == "planar" else nf.radialflow)(nf.MvNormal(d), nl, paramtype=torch.float32, seed=3)
+    flow = flow.with_theta(flow.theta * 0.3)
+    spec = o.FlowSpec(kind, d, nl)
+    th64 = flow.theta.cpu().numpy().astype(np.float64)
+    xs = nf.device_specific_rand(nf.PhiloxRNG(17), flow.dist, n)
+    xs64 = xs.cpu().numpy().astype(np.float64)
+    lo, go = o.neg_elbo_value_and_grad(spec, th64, otgt, xs64)
+    _, g32 = o.neg_elbo_value_and_grad(spec, P.f32(th64), P.f32(otgt), P.f32(xs64))
+    for form, arg in (("rng", n), ("xs", xs)):
+        loss, g = nf.value_and_gradient(nf.elbo_batch, flow, tgt, arg, rng=nf.PhiloxRNG(17))
+        tag = f"{kind} d{d} x{nl} n{n} {tname} ({form})"
+        P.scalar(f"{tag}: step loss", loss, lo)
+        P.gradient(f"{tag}: step grad", g, go, floor=g32)
+    # deterministic: same bits again
+    l2, g2 = nf.value_and_gradient(nf.elbo_batch, flow, tgt, n, rng=nf.PhiloxRNG(17))
+    assert torch.equal(g, nf.value_and_gradient(nf.elbo_batch, flow, tgt, xs)[1]) and torch.equal(g2, nf.value_and_gradient(nf.elbo_batch, flow, tgt, n, rng=nf.PhiloxRNG(17))[1])
+
+
 def test_target_argument_conventions(nf):
     """Constructor checks of the reference's target types (banana.jl:40-44, neal_funnel.jl:31-35,
     warped_gaussian.jl:29-33) and the dimension contract of the 2-d targets."""

@@ -48,7 +48,10 @@ for kind in ("planar", "radial"):
     a, c = C.c_double(0.0), C.c_int64(0)
     kname = "simple_step"
     lib.nf_prof_read(ctx.ptr, b"simple_step", C.byref(a), C.byref(c))
-    if not c.value:  # planar, d <= 64, <= 16 layers: the matrix-pipe step (k_planar_step)
+    if not c.value:  # planar, d <= 64, <= 16 layers: the matrix-pipe step (k_planar_step); radial: k_radial_step
+        kname = "radial_step"
+        lib.nf_prof_read(ctx.ptr, b"radial_step", C.byref(a), C.byref(c))
+    if not c.value:
         kname = "planar_step"
         lib.nf_prof_read(ctx.ptr, b"planar_step", C.byref(a), C.byref(c))
     if c.value:  # the stash-free step: one launch, no activation traffic; SURVEY 8(d) algorithmic bytes: 8d + 4 per sample
