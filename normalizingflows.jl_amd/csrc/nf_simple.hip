@@ -1483,9 +1483,11 @@ __global__ __launch_bounds__(SB, 2) void k_radial_step(SimpleArgs a, const float
     al[l] = sc(RG::OFF_A + l);
     bhv[l] = sc(RG::OFF_BH + l);
   }
-  float acc[NL], sa[NL], sb[NL];
+  // acc: z0bar of the feature wave_transpose_reduce32 leaves in this lane; sab: both half-waves carry every sample, so the
+  // lower half sums the samples' alpha_bar terms and the upper half their betahat_bar terms (one register per layer)
+  float acc[NL], sab[NL];
 #pragma unroll
-  for (int l = 0; l < NL; ++l) acc[l] = sa[l] = sb[l] = 0.f;
+  for (int l = 0; l < NL; ++l) acc[l] = sab[l] = 0.f;
   double contrib = 0.0;
   const float dm1 = (float)(d - 1);
   const long ntiles = (a.N + 31) / 32;
@@ -1607,7 +1609,6 @@ __global__ __launch_bounds__(SB, 2) void k_radial_step(SimpleArgs a, const float
     }
     // ---- reverse: the state walks back alongside the cotangent (layer_bwd_s's algebra, once per sample)
     const float lb = valid ? lbar_const : 0.f;
-    const float once = hi == 0 ? 1.f : 0.f;
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
       if (l < nl) {
@@ -1648,8 +1649,7 @@ __global__ __launch_bounds__(SB, 2) void k_radial_step(SimpleArgs a, const float
             g[b][e] += dbv;
           }
         acc[l] -= wave_transpose_reduce32(dl, lane);  // z0bar
-        sa[l] += once * (-h * h * hbar + lb * dL_da);
-        sb[l] += once * (h * yd + lb * dL_db);
+        sab[l] += hi ? (h * yd + lb * dL_db) : (-h * h * hbar + lb * dL_da);
       }
     }
   }
@@ -1660,16 +1660,10 @@ __global__ __launch_bounds__(SB, 2) void k_radial_step(SimpleArgs a, const float
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
       if (facc < FD) rg[l * FD + facc] = acc[l];
-      float v0 = sa[l], v1 = sb[l];
+      float v0 = sab[l];
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        v0 += __shfl_xor(v0, o, 64);
-        v1 += __shfl_xor(v1, o, 64);
-      }
-      if (lane == 0) {
-        rg[NL * FD + l] = v0;
-        rg[NL * FD + NL + l] = v1;
-      }
+      for (int o = 16; o > 0; o >>= 1) v0 += __shfl_xor(v0, o, 64);  // within the half-wave
+      if (l31 == 0) rg[NL * FD + hi * NL + l] = v0;
     }
   }
   __syncthreads();
