@@ -37,7 +37,7 @@ python3 bench.py --no-cpu-baseline --split-calls > "$OUT/bench_default_split_cal
 python3 bench.py --no-cpu-baseline --graph > "$OUT/bench_default_graph.json" 2>> "$OUT/bench_default.err"
 # A/B of the cfg-2 reverse kernel on this box: one wavefront per tile (k_affine_bwd_stashed) instead of the pair kernel
 NF_BWD_NO_PAIR=1 python3 bench.py --no-cpu-baseline > "$OUT/bench_default_one_wave_per_tile.json" 2>> "$OUT/bench_default.err"
-NF_PLANAR_NO_MFMA=1 python3 tools/bench_simple.py > "$OUT/simple_no_mfma.txt" 2>&1
+NF_PLANAR_NO_MFMA=1 NF_RADIAL_NO_LANE=1 python3 tools/bench_simple.py > "$OUT/simple_no_mfma.txt" 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 -d "$OUT/pmc_cfg4_mfma" -o pmc --output-format csv -- python3 bench.py --workload cfg4 --batch 32768 --steps 3 --warmup 1 --no-kernel-events > "$OUT/pmc_cfg4_mfma.log" 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C -d "$OUT/pmc_cfg4_$C" -o pmc --output-format csv -- python3 bench.py --workload cfg4 --batch 32768 --steps 3 --warmup 1 --no-kernel-events > "$OUT/pmc_cfg4_$C.log" 2>&1
