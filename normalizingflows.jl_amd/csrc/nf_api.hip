@@ -2086,6 +2086,7 @@ extern "C" int nf_elbo_step_enqueue(nf_ctx *ctx, const nf_flow_desc *desc, const
 // GPU test runs every entry point against exactly this bound, so a formula that drifts fails loudly with
 // NF_ERR_WORKSPACE), the optimiser's norm partials, the packed weight images and the nf_elbo_step buffer.
 size_t nf_affine_wimg_bytes(const nf_flow_desc *desc);
+size_t nf_l64_scratch_bytes(const nf_flow_desc *desc, long N);
 size_t nf_rqs_wimg_bytes(const nf_flow_desc *desc);
 size_t nf_wide_wimg_bytes(nf_ctx *, const nf_flow_desc *desc);
 
@@ -2189,14 +2190,14 @@ extern "C" int64_t nf_workspace_bytes(nf_ctx *ctx, const nf_flow_desc *desc, int
   // packed weight images, nf_elbo_step's [grad ; loss ; norm] buffer
   size_t wimg = 0;
   auto wimg_of = [&](const nf_flow_desc *g) -> size_t {
-    if (!is_coupling(g)) return 0;
+    if (!is_coupling(g)) return nf_l64_scratch_bytes(g, N);  // general Float32 couplings: the MFMA MLP's activation tiles
     return is_wide(g) ? nf_wide_wimg_bytes(ctx, g) : is_nsf(g) ? nf_rqs_wimg_bytes(g) : nf_affine_wimg_bytes(g);
   };
   if (is_composite(desc)) {
     for (int sgi = 0; sgi < desc->nsegments; ++sgi) {
       wimg += carve_bytes(wimg_of(&desc->segments[sgi]));  // grow-only tail carves: a later, larger segment carves again
     }
-  } else if (cp) {
+  } else {
     wimg = wimg_of(desc);
   }
   need += carve_bytes(wimg) + carve_bytes(gbuf_need(P, es)) + 4096;

@@ -16,6 +16,8 @@
 //
 // Reference arithmetic: src/flows/realnvp.jl:57-110, src/flows/neuralspline.jl:65-140,
 // src/flows/utils.jl:71-100; MonotonicSplines 0.3.3 as restated in oracle/nf_oracle.py.
+#include <cstdlib>
+
 #include "nf_common.h"
 
 // Two size classes (per-thread scratch arrays are sized at compile time): SMALL keeps the shapes such flows are
@@ -341,6 +343,276 @@ __global__ __launch_bounds__(G64_BLOCK) void k_g64_bwd(G64Args a, int inv, const
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// "l64": the conditioner MLP of the general coupling kernels on the matrix pipe (Float32; round 3)
+// ------------------------------------------------------------------------------------------------------------------
+// The thread-per-sample kernels above spend their time in the MLP (one scalar FMA per weight load: 22.8 ms per coupling
+// for the reverse pass at NSF d = 32, hidden [64, 64], K = 8, N = 131 072).  For Float32 flows whose layer INPUTS are at
+// most 64 wide (d <= 128, hidden <= 64; any depth 1-4, any K) the MLP runs layer by layer on fp32 MFMAs instead, with the
+// primitives of the resident kernels (dense_fwd / dense_bwd_x / dw_accumulate, nf_mfma.h): a layer's weight block is staged
+// from theta (Dense weight out x in column-major = W[i][o] row-major, no packing) into LDS, a wavefront owns 32-sample
+// tiles, activations travel between launches in the tiled layout [tile][row][32 samples] of a scratch buffer (the
+// context's image buffer, nf_wimg_reserve).  The coupling arithmetic itself (tanh / exp, the spline in the element type
+// with run-time K) stays what it was -- the same device functions, one thread per sample -- reading the net outputs from
+// the tiles.  So every entry point that reaches nf_g64_apply / g64_launch_bwd (forward, inverse, rand, ELBO, training
+// step, forward-KL, pullbacks, compositions) takes this path for those shapes; Float64 and wider nets keep the scalar MLP.
+#include "nf_mfma.h"
+
+#define L64_TILE 32
+struct L64Layer {
+  long w_off, b_off;  // theta offsets of W (nin x nout, row-major) and b
+  int nin, nout;      // real sizes
+  int o0;             // first output column of this launch's block group
+};
+// a [rows][samples] operand: tiled scratch (F rows per tile) or, for a first layer, the conditioner half of the state in the
+// standard layout (x[j * d + 2 q + par]; d > 0 selects it)
+struct L64Src {
+  const float *p;
+  int F, row0;   // tiled: rows per tile, first row
+  int d, par;    // standard layout: feature count and parity of the rows
+};
+__device__ __forceinline__ float l64_get(const L64Src &s, long tile, int row, int l31, long N, int nrows) {
+  const long j = tile * L64_TILE + l31;
+  if (s.d > 0) return (row < nrows && j < N) ? s.p[j * s.d + 2 * row + s.par] : 0.f;
+  return s.p[((tile * s.F + s.row0 + row) * L64_TILE) + l31];
+}
+template <int NB>
+__device__ __forceinline__ void l64_load(const L64Src &s, long tile, int l31, int hi, long N, int nrows, f32x16 (&v)[NB]) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[b][r] = l64_get(s, tile, 32 * b + nf_row(r, hi), l31, N, nrows);
+}
+// stage W[i][o0 + o] (i < 32 IB, o < 32 OB) and b[o0 + o] from theta, zero outside the layer
+template <int IB, int OB>
+__device__ __forceinline__ void l64_stage(float *__restrict__ w, float *__restrict__ b, const float *__restrict__ theta,
+                                          const L64Layer &L, int tid, int nthreads) {
+  constexpr int S = 32 * OB + NF_IMG_PAD;
+  for (int e = tid; e < 32 * IB * 32 * OB; e += nthreads) {
+    const int i = e / (32 * OB), o = e - i * (32 * OB);
+    w[i * S + o] = (i < L.nin && L.o0 + o < L.nout) ? theta[L.w_off + (long)i * L.nout + L.o0 + o] : 0.f;
+  }
+  for (int o = tid; o < 32 * OB; o += nthreads) b[o] = (L.o0 + o < L.nout) ? theta[L.b_off + L.o0 + o] : 0.f;
+}
+
+// out rows [o0, o0 + 32 OB) of dst <- W' in + b (leaky-ReLU if act)
+template <int IB, int OB>
+__global__ __launch_bounds__(256) void k_l64_fwd(const float *__restrict__ theta, L64Layer L, L64Src src, float *__restrict__ dst, int Fd,
+                                                 long N, int act) {
+  constexpr int S = 32 * OB + NF_IMG_PAD;
+  __shared__ __attribute__((aligned(16))) float w[32 * IB * S + 32 * OB];
+  float *b = w + 32 * IB * S;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  l64_stage<IB, OB>(w, b, theta, L, tid, 256);
+  __syncthreads();
+  const long ntiles = (N + L64_TILE - 1) / L64_TILE;
+  for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+    f32x16 in[IB], out[OB];
+    l64_load<IB>(src, tile, l31, hi, N, L.nin, in);
+    dense_fwd<IB, OB, S>(w, b, in, out, l31, hi);
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = out[ob][r];
+        dst[((tile * Fd + L.o0 + 32 * ob + nf_row(r, hi)) * L64_TILE) + l31] = act ? nf_lrelu(v) : v;
+      }
+  }
+}
+
+// delta of a layer's output rows: the stored cotangent, times leaky-ReLU' from the sign of the stashed post-activation
+template <int OB>
+__device__ __forceinline__ void l64_delta(const L64Src &g, const float *__restrict__ act, int Fa, int o0, long tile, int l31, int hi,
+                                          long N, f32x16 (&dl)[OB]) {
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = 32 * ob + nf_row(r, hi);
+      float v = g.p[((tile * g.F + g.row0 + row) * L64_TILE) + l31];
+      if (act) v *= act[((tile * Fa + o0 + row) * L64_TILE) + l31] > 0.f ? 1.f : 0.01f;
+      dl[ob][r] = v;
+    }
+}
+
+// din (+)= W[:, o0 : o0 + 32 OB] delta.  dst tiled (Fd rows; accumulate: add to what is there) or, with xd > 0, the
+// conditioner half of the standard-layout cotangent gbar[j * xd + 2 q + par] (always accumulated: x2bar += din)
+template <int IB, int OB>
+__global__ __launch_bounds__(256) void k_l64_bwdx(const float *__restrict__ theta, L64Layer L, L64Src g, const float *__restrict__ act,
+                                                  int Fa, float *__restrict__ dst, int Fd, int accumulate, int xd, int xpar, long N) {
+  constexpr int S = 32 * OB + NF_IMG_PAD;
+  __shared__ __attribute__((aligned(16))) float w[32 * IB * S + 32 * OB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  l64_stage<IB, OB>(w, w + 32 * IB * S, theta, L, tid, 256);
+  __syncthreads();
+  const long ntiles = (N + L64_TILE - 1) / L64_TILE;
+  for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+    f32x16 dl[OB], din[IB];
+    l64_delta<OB>(g, act, Fa, L.o0, tile, l31, hi, N, dl);
+    dense_bwd_x<IB, OB, S>(w, dl, din, l31, hi);
+    const long j = tile * L64_TILE + l31;
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * ib + nf_row(r, hi);
+        if (xd > 0) {
+          if (row < L.nin && j < N) dst[j * xd + 2 * row + xpar] += din[ib][r];
+        } else {
+          float *p = dst + ((tile * Fd + row) * L64_TILE) + l31;
+          *p = accumulate ? *p + din[ib][r] : din[ib][r];
+        }
+      }
+  }
+}
+
+// this workgroup's partial of dW[:, o0 : o0 + 32 OB] = sum_j a_j delta_j' and db, written in theta order into its slab
+template <int IB, int OB>
+__global__ __launch_bounds__(256) void k_l64_dw(L64Layer L, L64Src a, L64Src g, const float *__restrict__ act, int Fa, long N,
+                                                float *__restrict__ slabs, long Pc, long slab_off) {
+  constexpr int SA = IB * 32 * NF_TS, SD = OB * 32 * NF_TS;
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // 4 (SA + SD) floats (beyond the 64 KB static limit at IB = OB = 2)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  float *sa = sm + wave * (SA + SD), *sd = sa + SA;
+  f32x16 acc[IB][OB];
+  float bsum[OB];
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob) {
+    bsum[ob] = 0.f;
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ib][ob][r] = 0.f;
+  }
+  const long ntiles = (N + L64_TILE - 1) / L64_TILE;
+  for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+    f32x16 av[IB], dl[OB];
+    l64_load<IB>(a, tile, l31, hi, N, L.nin, av);
+    l64_delta<OB>(g, act, Fa, L.o0, tile, l31, hi, N, dl);
+    tile_to_scratch<IB>(sa, av, l31, hi);
+    tile_to_scratch<OB>(sd, dl, l31, hi);
+    wave_lds_fence();
+    dw_accumulate<IB, OB>(sa, sd, acc, bsum, l31, hi);
+    wave_lds_fence();
+  }
+  // waves in a fixed order through one [32 IB][32 OB] image (+ bias row) in LDS, then the slab in theta order
+  __syncthreads();
+  float *img = sm;  // stride 32 OB; the per-wave tiles are dead
+  constexpr int SI = 32 * OB;
+  for (int wv = 0; wv < 4; ++wv) {
+    if (wave == wv) {
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float *p = img + (32 * ib + nf_row(r, hi)) * SI + 32 * ob + l31;
+            *p = wv == 0 ? acc[ib][ob][r] : *p + acc[ib][ob][r];
+          }
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob) {
+        const float v = bsum[ob] + __shfl_xor(bsum[ob], 32);
+        if (hi == 0) {
+          float *p = img + 32 * IB * SI + 32 * ob + l31;
+          *p = wv == 0 ? v : *p + v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float *slab = slabs + (long)blockIdx.x * Pc - slab_off;
+  for (int e = tid; e < 32 * IB * SI; e += 256) {
+    const int i = e / SI, o = e - i * SI;
+    if (i < L.nin && L.o0 + o < L.nout) slab[L.w_off + (long)i * L.nout + L.o0 + o] = img[e];
+  }
+  for (int o = tid; o < SI; o += 256)
+    if (L.o0 + o < L.nout) slab[L.b_off + L.o0 + o] = img[32 * IB * SI + o];
+}
+
+// ---- the coupling arithmetic on net outputs held in tiles (one thread per sample; as k_g64_apply / k_g64_bwd) -------
+__device__ __forceinline__ float l64_out(const float *__restrict__ buf, int F, long j, int row) {
+  return buf[(((j >> 5) * F + row) << 5) + (j & 31)];
+}
+__global__ __launch_bounds__(256) void k_l64_couple_fwd(G64Args a, int inverse, const float *__restrict__ os, int Fs,
+                                                        const float *__restrict__ ot, int Ft, float *xy, float *__restrict__ ladj) {
+  const long j = (long)blockIdx.x * 256 + threadIdx.x;
+  if (j >= a.N) return;
+  float *r = xy + j * a.d;
+  float lsum = 0.f;
+  if (a.kind == NF_KIND_REALNVP) {
+    for (int p = 0; p < a.c; ++p) {
+      const float s = tanh(l64_out(os, Fs, j, p)), t = l64_out(ot, Ft, j, p), v = r[2 * p + a.par_t];
+      r[2 * p + a.par_t] = inverse ? (v - t) * exp(-s) : v * exp(s) + t;
+      lsum += inverse ? -s : s;
+    }
+  } else {
+    const int P = 3 * a.K - 1;
+    G64Spline<float> sp;
+    float raw[3 * G64_MAXK];
+    for (int p = 0; p < a.c; ++p) {
+      for (int i = 0; i < P; ++i) raw[i] = l64_out(os, Fs, j, p * P + i);
+      g64_build<float>(raw, a.K, (float)a.B, sp);
+      const float v = r[2 * p + a.par_t];
+      r[2 * p + a.par_t] = inverse ? g64_spline_inv(sp, a.K, v, lsum) : g64_spline_fwd(sp, a.K, v, lsum);
+    }
+  }
+  ladj[j] += lsum;
+}
+// x: the coupling's input (inv: the point the inverse is differentiated at); gbar: ybar -> cotangent of the transformed half;
+// ds / dt <- cotangents of the nets' outputs (tiles)
+__global__ __launch_bounds__(256) void k_l64_couple_bwd(G64Args a, int inv, const float *__restrict__ os, int Fs, const float *__restrict__ x,
+                                                        float *gbar, const float *__restrict__ lbar, float lbar_const,
+                                                        float *__restrict__ ds, float *__restrict__ dt, int Ft) {
+  const long j = (long)blockIdx.x * 256 + threadIdx.x;
+  const long jt = (a.N + 31) / 32 * 32;
+  if (j >= jt) return;
+  const bool valid = j < a.N;
+  auto put = [&](float *buf, int F, int row, float v) { buf[(((j >> 5) * F + row) << 5) + (j & 31)] = v; };
+  if (!valid) {  // padding samples of the last tile: zero cotangents
+    for (int p = 0; p < Fs; ++p) put(ds, Fs, p, 0.f);
+    if (a.kind == NF_KIND_REALNVP)
+      for (int p = 0; p < Ft; ++p) put(dt, Ft, p, 0.f);
+    return;
+  }
+  {  // rows beyond the net's outputs sit on the next GEMM's contraction axis: zero, not whatever the buffer held
+    const int rows = a.kind == NF_KIND_REALNVP ? a.c : (3 * a.K - 1) * a.c;
+    for (int p = rows; p < Fs; ++p) put(ds, Fs, p, 0.f);
+    if (a.kind == NF_KIND_REALNVP)
+      for (int p = rows; p < Ft; ++p) put(dt, Ft, p, 0.f);
+  }
+  const float *xr = x + j * a.d;
+  float *gr = gbar + j * a.d;
+  const float lb = lbar ? lbar[j] : lbar_const;
+  if (a.kind == NF_KIND_REALNVP && inv) {
+    for (int p = 0; p < a.c; ++p) {
+      const float s = tanh(l64_out(os, Fs, j, p)), x1 = xr[2 * p + a.par_t], xb = gr[2 * p + a.par_t];
+      const float v1b = xb * exp(-s);
+      gr[2 * p + a.par_t] = v1b;
+      put(ds, Fs, p, (-xb * x1 - lb) * (1.f - s * s));
+      put(dt, Ft, p, -v1b);
+    }
+  } else if (a.kind == NF_KIND_REALNVP) {
+    for (int p = 0; p < a.c; ++p) {
+      const float s = tanh(l64_out(os, Fs, j, p)), es = exp(s), x1 = xr[2 * p + a.par_t], yb = gr[2 * p + a.par_t];
+      put(dt, Ft, p, yb);
+      gr[2 * p + a.par_t] = yb * es;
+      put(ds, Fs, p, (yb * x1 * es + lb) * (1.f - s * s));
+    }
+  } else {
+    const int P = 3 * a.K - 1;
+    G64Spline<float> sp;
+    float raw[3 * G64_MAXK], thb[3 * G64_MAXK];
+    for (int p = 0; p < a.c; ++p) {
+      for (int i = 0; i < P; ++i) raw[i] = l64_out(os, Fs, j, p * P + i);
+      g64_build<float>(raw, a.K, (float)a.B, sp);
+      const float xb = g64_spline_bwd<float>(sp, raw, a.K, (float)a.B, xr[2 * p + a.par_t], gr[2 * p + a.par_t], lb, thb, inv != 0);
+      gr[2 * p + a.par_t] = xb;
+      for (int i = 0; i < P; ++i) put(ds, Fs, p * P + i, thb[i]);
+    }
+  }
+}
+
 // ---- host side --------------------------------------------------------------------------------
 template <class SZ>
 static bool g64_fits(const nf_flow_desc *desc) {
@@ -390,10 +662,22 @@ static G64Args make_g64_args(const nf_flow_desc *desc, int k, long N) {
   return a;
 }
 
-// launches of the two kernels in the size class the flow fits
+// launches of the two kernels in the size class the flow fits (Float32 flows whose layers are at most 64 wide: the MLP on
+// the matrix pipe, "l64" above)
+static bool l64_ok(const nf_flow_desc *desc);
+static int l64_apply(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a, int inverse, const float *theta, float *xy, float *ladj);
+static int l64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &a, int inv, const float *theta, const float *x, float *gbar,
+                   const float *lbar, float lbar_const, float *g, float *slabs);
 template <class T>
 static void g64_launch_apply(nf_ctx *ctx, const nf_flow_desc *desc, unsigned grid, const G64Args &a, int inverse, const T *theta,
                              const T *x, T *y, T *ladj) {
+  if constexpr (sizeof(T) == 4) {
+    if (l64_ok(desc)) {
+      if (y != x) (void)hipMemcpyAsync(y, x, (size_t)a.N * a.d * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream);
+      (void)l64_apply(ctx, desc, a, inverse, theta, y, ladj);
+      return;
+    }
+  }
   if (g64_fits<G64Small>(desc))
     hipLaunchKernelGGL((k_g64_apply<T, G64Small>), dim3(grid), dim3(G64_BLOCK), 0, ctx->stream, a, inverse, theta, x, y, ladj);
   else
@@ -426,6 +710,9 @@ int nf_launch_reduce_slabs(nf_ctx *, int, const void *, int, long, void *);
 template <class T>
 static int g64_launch_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &a, int inv, const T *theta,
                           const T *x, T *gbar, const T *lbar, T lbar_const, T *g, T *slabs) {
+  if constexpr (sizeof(T) == 4) {
+    if (l64_ok(desc)) return l64_bwd(ctx, desc, k, a, inv, theta, x, gbar, lbar, lbar_const, g, slabs);
+  }
   const CouplingInfo ci = nf_coupling_info(desc, k);
   const unsigned grid = g64_bwd_blocks(desc, a.N);
   if (g64_fits<G64Small>(desc))
@@ -436,6 +723,177 @@ static int g64_launch_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G6
                        slabs, ci.nparams, ci.theta_off);
   NF_HIP(hipGetLastError());
   return nf_launch_reduce_slabs(ctx, sizeof(T) == 8 ? NF_DTYPE_F64 : NF_DTYPE_F32, slabs, (int)grid, ci.nparams, g + ci.theta_off);
+}
+
+// ---- l64 host side ---------------------------------------------------------------------------------------------
+int nf_wimg_reserve(nf_ctx *ctx, size_t bytes);
+static inline int l64_pad32(int n) { return (n + 31) / 32 * 32; }
+static bool l64_ok(const nf_flow_desc *desc) {
+  static const bool off = std::getenv("NF_G64_NO_MFMA") != nullptr;  // A/B switch: the scalar MLP
+  if (off || desc->dtype != NF_DTYPE_F32 || (desc->kind != NF_KIND_REALNVP && desc->kind != NF_KIND_NSF)) return false;
+  if (desc->n_hidden < 1 || desc->n_hidden > NF_MAX_HIDDEN || desc->d < 2 || (desc->d + 1) / 2 > 64) return false;
+  for (int i = 0; i < desc->n_hidden; ++i)
+    if (desc->hdims[i] > 64 || desc->hdims[i] < 1) return false;
+  if (desc->kind == NF_KIND_NSF && (desc->K < 1 || desc->K > G64_MAXK)) return false;
+  const int nout = desc->kind == NF_KIND_REALNVP ? (desc->d + 1) / 2 : (3 * desc->K - 1) * ((desc->d + 1) / 2);
+  return nout <= G64Large::MAXO;
+}
+// scratch floats per sample of ONE coupling call: per net the stashed layer outputs, the output cotangent; two hidden
+// cotangent buffers
+static size_t l64_floats_per_sample(const nf_flow_desc *desc) {
+  const int c = (desc->d + 1) / 2;
+  const int nout = desc->kind == NF_KIND_REALNVP ? c : (3 * desc->K - 1) * c;
+  size_t per_net = 2 * (size_t)l64_pad32(nout);
+  for (int i = 0; i < desc->n_hidden; ++i) per_net += l64_pad32(desc->hdims[i]);
+  return (desc->kind == NF_KIND_REALNVP ? 2 : 1) * per_net + 2 * 64;
+}
+size_t nf_l64_scratch_bytes(const nf_flow_desc *desc, long N) {
+  if (!l64_ok(desc)) return 0;
+  return ((size_t)((N + 31) / 32) * 32 * l64_floats_per_sample(desc) * sizeof(float) + 255) / 256 * 256;
+}
+struct L64Bufs {
+  float *act[2][NF_MAX_HIDDEN + 1];  // [net][layer]: tiled outputs (the last one: the net's output)
+  int F[NF_MAX_HIDDEN + 1];          // rows of those tiles
+  float *dout[2], *gh[2];            // output cotangents per net; two hidden cotangent buffers of 64 rows
+  int nets, nl;
+};
+static int l64_bufs(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a, L64Bufs *b) {
+  NF_TRY(nf_wimg_reserve(ctx, nf_l64_scratch_bytes(desc, a.N)));
+  const size_t Np = (size_t)((a.N + 31) / 32) * 32;
+  b->nets = desc->kind == NF_KIND_REALNVP ? 2 : 1;
+  b->nl = a.net[0].nl;
+  float *p = (float *)ctx->wimg;
+  for (int l = 0; l < b->nl; ++l) b->F[l] = l64_pad32(a.net[0].dims[l + 1]);
+  for (int n = 0; n < b->nets; ++n) {
+    for (int l = 0; l < b->nl; ++l) { b->act[n][l] = p; p += Np * b->F[l]; }
+    b->dout[n] = p; p += Np * b->F[b->nl - 1];
+  }
+  b->gh[0] = p; p += Np * 64;
+  b->gh[1] = p;
+  return NF_OK;
+}
+static inline unsigned l64_grid(nf_ctx *ctx, long N, long cap) {
+  long nb = ((N + 31) / 32 + 3) / 4;
+  if (nb > cap) nb = cap;
+  return (unsigned)(nb < 1 ? 1 : nb);
+}
+// block sizes: layer inputs are at most 64 wide (IB 1 or 2); outputs go in groups of 1, 2 or 4 blocks
+#define L64_DISPATCH(IBv, OBv, CALL)                                   \
+  do {                                                                \
+    if ((IBv) == 1 && (OBv) == 1) { CALL(1, 1); } else if ((IBv) == 1 && (OBv) == 2) { CALL(1, 2); } \
+    else if ((IBv) == 1) { CALL(1, 4); } else if ((OBv) == 1) { CALL(2, 1); } else if ((OBv) == 2) { CALL(2, 2); } else { CALL(2, 4); } \
+  } while (0)
+static inline int l64_group(int blocks_left, int maxg) { return blocks_left >= 4 && maxg >= 4 ? 4 : blocks_left >= 2 && maxg >= 2 ? 2 : 1; }
+
+// the nets of one coupling, layer by layer, on the conditioner half of `x` (standard layout); outputs stay in b->act
+static int l64_nets_fwd(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a, const float *theta, const float *x, const L64Bufs &b) {
+  const unsigned grid = l64_grid(ctx, a.N, 2L * ctx->num_cu);
+  for (int n = 0; n < b.nets; ++n) {
+    const G64Net &net = a.net[n];
+    for (int l = 0; l < net.nl; ++l) {
+      const int nin = net.dims[l], nout = net.dims[l + 1];
+      const int IB = (nin + 31) / 32, blocks = (nout + 31) / 32;
+      L64Src src;
+      if (l == 0) src = L64Src{x, 0, 0, a.d, 1 - a.par_t};
+      else src = L64Src{b.act[n][l - 1], b.F[l - 1], 0, 0, 0};
+      for (int ob0 = 0; ob0 < blocks;) {
+        const int OB = l64_group(blocks - ob0, 4);
+        const L64Layer L{net.w[l], net.b[l], nin, nout, 32 * ob0};
+        ProfScope ps(ctx, "l64_fwd");
+#define CALL(I, O) hipLaunchKernelGGL((k_l64_fwd<I, O>), dim3(grid), dim3(256), 0, ctx->stream, theta, L, src, b.act[n][l], b.F[l], a.N, l < net.nl - 1 ? 1 : 0)
+        L64_DISPATCH(IB, OB, CALL);
+#undef CALL
+        NF_HIP(hipGetLastError());
+        ob0 += OB;
+      }
+    }
+  }
+  return NF_OK;
+}
+static int l64_apply(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a, int inverse, const float *theta, float *xy, float *ladj) {
+  L64Bufs b;
+  NF_TRY(l64_bufs(ctx, desc, a, &b));
+  NF_TRY(l64_nets_fwd(ctx, desc, a, theta, xy, b));
+  ProfScope ps(ctx, "l64_couple");
+  const int last = b.nl - 1;
+  hipLaunchKernelGGL(k_l64_couple_fwd, dim3((unsigned)((a.N + 255) / 256)), dim3(256), 0, ctx->stream, a, inverse, (const float *)b.act[0][last],
+                     b.F[last], (const float *)b.act[b.nets - 1][last], b.F[last], xy, ladj);
+  return (int)hipGetLastError();
+}
+template <int IB, int OB>
+static int l64_dw_launch(nf_ctx *ctx, unsigned grid, const L64Layer &L, const L64Src &av, const L64Src &g, const float *act, int Fa, long N,
+                         float *slabs, long Pc, long slab_off) {
+  const size_t lds = (size_t)4 * (IB + OB) * 32 * NF_TS * sizeof(float);
+  static AttrOnce attr_once;
+  NF_TRY(attr_once.run(ctx->device, [&]() -> int {
+    NF_HIP(hipFuncSetAttribute((const void *)k_l64_dw<IB, OB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return NF_OK;
+  }));
+  hipLaunchKernelGGL((k_l64_dw<IB, OB>), dim3(grid), dim3(256), lds, ctx->stream, L, av, g, act, Fa, N, slabs, Pc, slab_off);
+  return (int)hipGetLastError();
+}
+// reverse pass of coupling k at x (forward: its input; inv: the inverse's output): gbar updated in place, this coupling's
+// parameter gradient in g[theta_off ...] through per-workgroup slabs
+static int l64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &a, int inv, const float *theta, const float *x, float *gbar,
+                   const float *lbar, float lbar_const, float *g, float *slabs) {
+  const CouplingInfo ci = nf_coupling_info(desc, k);
+  L64Bufs b;
+  NF_TRY(l64_bufs(ctx, desc, a, &b));
+  NF_TRY(l64_nets_fwd(ctx, desc, a, theta, x, b));
+  const int last = b.nl - 1;
+  {
+    ProfScope ps(ctx, "l64_couple");
+    const long Np = (a.N + 31) / 32 * 32;
+    hipLaunchKernelGGL(k_l64_couple_bwd, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, ctx->stream, a, inv, (const float *)b.act[0][last],
+                       b.F[last], x, gbar, lbar, lbar_const, b.dout[0], b.dout[b.nets - 1], b.F[last]);
+    NF_HIP(hipGetLastError());
+  }
+  const unsigned grid = l64_grid(ctx, a.N, 2L * ctx->num_cu);
+  const unsigned gridw = l64_grid(ctx, a.N, (long)g64_bwd_blocks(desc, a.N));
+  for (int n = 0; n < b.nets; ++n) {
+    const G64Net &net = a.net[n];
+    for (int l = net.nl - 1; l >= 0; --l) {
+      const int nin = net.dims[l], nout = net.dims[l + 1];
+      const int IB = (nin + 31) / 32, blocks = (nout + 31) / 32;
+      // delta of this layer's outputs: the net output's cotangent as is; a hidden layer's through leaky-ReLU'
+      const bool top = l == net.nl - 1;
+      const float *gsrc = top ? b.dout[n] : b.gh[(net.nl - 1 - l) & 1];
+      const int Fg = top ? b.F[last] : 64;
+      const float *act = top ? nullptr : b.act[n][l];
+      float *gdst = b.gh[(net.nl - l) & 1];  // cotangent of this layer's inputs (l > 0)
+      L64Src av;
+      if (l == 0) av = L64Src{x, 0, 0, a.d, 1 - a.par_t};
+      else av = L64Src{b.act[n][l - 1], b.F[l - 1], 0, 0, 0};
+      for (int ob0 = 0; ob0 < blocks;) {
+        const int OBw = l64_group(blocks - ob0, 2);
+        const L64Layer L{net.w[l], net.b[l], nin, nout, 32 * ob0};
+        const L64Src gs{gsrc, Fg, 32 * ob0, 0, 0};
+        ProfScope ps(ctx, "l64_dw");
+#define CALL(I, O) NF_TRY((l64_dw_launch<I, O>(ctx, gridw, L, av, gs, act, b.F[l], a.N, slabs, ci.nparams, ci.theta_off)))
+        L64_DISPATCH(IB, OBw, CALL);
+#undef CALL
+        ob0 += OBw;
+      }
+      for (int ob0 = 0, first = 1; ob0 < blocks; first = 0) {
+        const int OB = l64_group(blocks - ob0, 4);
+        const L64Layer L{net.w[l], net.b[l], nin, nout, 32 * ob0};
+        const L64Src gs{gsrc, Fg, 32 * ob0, 0, 0};
+        ProfScope ps(ctx, "l64_bwdx");
+        if (l == 0) {
+#define CALL(I, O) hipLaunchKernelGGL((k_l64_bwdx<I, O>), dim3(grid), dim3(256), 0, ctx->stream, theta, L, gs, act, b.F[l], gbar, 0, 1, a.d, 1 - a.par_t, a.N)
+          L64_DISPATCH(IB, OB, CALL);
+#undef CALL
+        } else {
+#define CALL(I, O) hipLaunchKernelGGL((k_l64_bwdx<I, O>), dim3(grid), dim3(256), 0, ctx->stream, theta, L, gs, act, b.F[l], gdst, 64, first ? 0 : 1, 0, 0, a.N)
+          L64_DISPATCH(IB, OB, CALL);
+#undef CALL
+        }
+        NF_HIP(hipGetLastError());
+        ob0 += OB;
+      }
+    }
+  }
+  return nf_launch_reduce_slabs(ctx, NF_DTYPE_F32, slabs, (int)gridw, ci.nparams, g + ci.theta_off);
 }
 
 // couplings [layer_lo, layer_hi) in flat order (forward: applied last-listed first); y may alias x
