@@ -347,8 +347,8 @@ __global__ __launch_bounds__(G64_BLOCK) void k_g64_bwd(G64Args a, int inv, const
 // "l64": the conditioner MLP of the general coupling kernels on the matrix pipe (Float32; round 3)
 // ------------------------------------------------------------------------------------------------------------------
 // The thread-per-sample kernels above spend their time in the MLP (one scalar FMA per weight load: 22.8 ms per coupling
-// for the reverse pass at NSF d = 32, hidden [64, 64], K = 8, N = 131 072).  For Float32 flows whose layer INPUTS are at
-// most 64 wide (d <= 128, hidden <= 64; any depth 1-4, any K) the MLP runs layer by layer on fp32 MFMAs instead, with the
+// for the reverse pass at NSF d = 32, hidden [64, 64], K = 8, N = 131 072).  For every Float32 flow of this family's
+// envelope (d <= 256, hidden <= 256, depth 1-4, K <= 16) the MLP runs layer by layer on fp32 MFMAs instead, with the
 // primitives of the resident kernels (dense_fwd / dense_bwd_x / dw_accumulate, nf_mfma.h): a layer's weight block is staged
 // from theta (Dense weight out x in column-major = W[i][o] row-major, no packing) into LDS, a wavefront owns 32-sample
 // tiles, activations travel between launches in the tiled layout [tile][row][32 samples] of a scratch buffer (the
@@ -374,7 +374,7 @@ struct L64Src {
 __device__ __forceinline__ float l64_get(const L64Src &s, long tile, int row, int l31, long N, int nrows) {
   const long j = tile * L64_TILE + l31;
   if (s.d > 0) return (row < nrows && j < N) ? s.p[j * s.d + 2 * row + s.par] : 0.f;
-  return s.p[((tile * s.F + s.row0 + row) * L64_TILE) + l31];
+  return (s.row0 + row < s.F) ? s.p[((tile * s.F + s.row0 + row) * L64_TILE) + l31] : 0.f;  // IB may be padded past the buffer
 }
 template <int NB>
 __device__ __forceinline__ void l64_load(const L64Src &s, long tile, int l31, int hi, long N, int nrows, f32x16 (&v)[NB]) {
@@ -459,8 +459,10 @@ __global__ __launch_bounds__(256) void k_l64_bwdx(const float *__restrict__ thet
         if (xd > 0) {
           if (row < L.nin && j < N) dst[j * xd + 2 * row + xpar] += din[ib][r];
         } else {
-          float *p = dst + ((tile * Fd + row) * L64_TILE) + l31;
-          *p = accumulate ? *p + din[ib][r] : din[ib][r];
+          if (row < Fd) {  // IB may be padded past the buffer's rows
+            float *p = dst + ((tile * Fd + row) * L64_TILE) + l31;
+            *p = accumulate ? *p + din[ib][r] : din[ib][r];
+          }
         }
       }
   }
@@ -534,58 +536,69 @@ __global__ __launch_bounds__(256) void k_l64_dw(L64Layer L, L64Src a, L64Src g, 
 __device__ __forceinline__ float l64_out(const float *__restrict__ buf, int F, long j, int row) {
   return buf[(((j >> 5) * F + row) << 5) + (j & 31)];
 }
+// A workgroup is one 32-sample tile x 8 dimension lanes: thread (sample = tid & 31, lane = tid >> 5) walks the transformed
+// dimensions lane, lane + 8, ... (a spline is 3K - 1 parameters, two softmaxes and a handful of logs per dimension: one thread
+// per SAMPLE, as in k_g64_apply, leaves 16 of them in a row on a thread and the chip a quarter full at N = 131 072 --
+// 516 + 788 us per coupling against 120 us of MFMA layers).  The log-det terms are added over the 8 lanes in a fixed order.
+#define L64_DL 8
 __global__ __launch_bounds__(256) void k_l64_couple_fwd(G64Args a, int inverse, const float *__restrict__ os, int Fs,
                                                         const float *__restrict__ ot, int Ft, float *xy, float *__restrict__ ladj) {
-  const long j = (long)blockIdx.x * 256 + threadIdx.x;
-  if (j >= a.N) return;
-  float *r = xy + j * a.d;
+  __shared__ float part[L64_DL][32];
+  const int smp = threadIdx.x & 31, dl = threadIdx.x >> 5;
+  const long j = (long)blockIdx.x * 32 + smp;
+  const bool valid = j < a.N;
   float lsum = 0.f;
-  if (a.kind == NF_KIND_REALNVP) {
-    for (int p = 0; p < a.c; ++p) {
-      const float s = tanh(l64_out(os, Fs, j, p)), t = l64_out(ot, Ft, j, p), v = r[2 * p + a.par_t];
-      r[2 * p + a.par_t] = inverse ? (v - t) * exp(-s) : v * exp(s) + t;
-      lsum += inverse ? -s : s;
-    }
-  } else {
-    const int P = 3 * a.K - 1;
-    G64Spline<float> sp;
-    float raw[3 * G64_MAXK];
-    for (int p = 0; p < a.c; ++p) {
-      for (int i = 0; i < P; ++i) raw[i] = l64_out(os, Fs, j, p * P + i);
-      g64_build<float>(raw, a.K, (float)a.B, sp);
-      const float v = r[2 * p + a.par_t];
-      r[2 * p + a.par_t] = inverse ? g64_spline_inv(sp, a.K, v, lsum) : g64_spline_fwd(sp, a.K, v, lsum);
+  if (valid) {
+    float *r = xy + j * a.d;
+    if (a.kind == NF_KIND_REALNVP) {
+      for (int p = dl; p < a.c; p += L64_DL) {
+        const float s = tanh(l64_out(os, Fs, j, p)), t = l64_out(ot, Ft, j, p), v = r[2 * p + a.par_t];
+        r[2 * p + a.par_t] = inverse ? (v - t) * exp(-s) : v * exp(s) + t;
+        lsum += inverse ? -s : s;
+      }
+    } else {
+      const int P = 3 * a.K - 1;
+      G64Spline<float> sp;
+      float raw[3 * G64_MAXK];
+      for (int p = dl; p < a.c; p += L64_DL) {
+        for (int i = 0; i < P; ++i) raw[i] = l64_out(os, Fs, j, p * P + i);
+        g64_build<float>(raw, a.K, (float)a.B, sp);
+        const float v = r[2 * p + a.par_t];
+        r[2 * p + a.par_t] = inverse ? g64_spline_inv(sp, a.K, v, lsum) : g64_spline_fwd(sp, a.K, v, lsum);
+      }
     }
   }
-  ladj[j] += lsum;
+  part[dl][smp] = lsum;
+  __syncthreads();
+  if (dl == 0 && valid) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < L64_DL; ++q) t += part[q][smp];
+    ladj[j] += t;
+  }
 }
 // x: the coupling's input (inv: the point the inverse is differentiated at); gbar: ybar -> cotangent of the transformed half;
 // ds / dt <- cotangents of the nets' outputs (tiles)
 __global__ __launch_bounds__(256) void k_l64_couple_bwd(G64Args a, int inv, const float *__restrict__ os, int Fs, const float *__restrict__ x,
                                                         float *gbar, const float *__restrict__ lbar, float lbar_const,
                                                         float *__restrict__ ds, float *__restrict__ dt, int Ft) {
-  const long j = (long)blockIdx.x * 256 + threadIdx.x;
-  const long jt = (a.N + 31) / 32 * 32;
-  if (j >= jt) return;
+  const int smp = threadIdx.x & 31, dl = threadIdx.x >> 5;
+  const long j = (long)blockIdx.x * 32 + smp;
   const bool valid = j < a.N;
   auto put = [&](float *buf, int F, int row, float v) { buf[(((j >> 5) * F + row) << 5) + (j & 31)] = v; };
-  if (!valid) {  // padding samples of the last tile: zero cotangents
-    for (int p = 0; p < Fs; ++p) put(ds, Fs, p, 0.f);
-    if (a.kind == NF_KIND_REALNVP)
-      for (int p = 0; p < Ft; ++p) put(dt, Ft, p, 0.f);
-    return;
-  }
-  {  // rows beyond the net's outputs sit on the next GEMM's contraction axis: zero, not whatever the buffer held
-    const int rows = a.kind == NF_KIND_REALNVP ? a.c : (3 * a.K - 1) * a.c;
-    for (int p = rows; p < Fs; ++p) put(ds, Fs, p, 0.f);
-    if (a.kind == NF_KIND_REALNVP)
-      for (int p = rows; p < Ft; ++p) put(dt, Ft, p, 0.f);
-  }
+  const int P = 3 * a.K - 1;
+  const int rows = a.kind == NF_KIND_REALNVP ? a.c : P * a.c;
+  // rows beyond the net's outputs sit on the next GEMM's contraction axis, and so do the padding samples of the last tile:
+  // zero, not whatever the buffer held
+  for (int p = (valid ? rows : 0) + dl; p < Fs; p += L64_DL) put(ds, Fs, p, 0.f);
+  if (a.kind == NF_KIND_REALNVP)
+    for (int p = (valid ? rows : 0) + dl; p < Ft; p += L64_DL) put(dt, Ft, p, 0.f);
+  if (!valid) return;
   const float *xr = x + j * a.d;
   float *gr = gbar + j * a.d;
   const float lb = lbar ? lbar[j] : lbar_const;
   if (a.kind == NF_KIND_REALNVP && inv) {
-    for (int p = 0; p < a.c; ++p) {
+    for (int p = dl; p < a.c; p += L64_DL) {
       const float s = tanh(l64_out(os, Fs, j, p)), x1 = xr[2 * p + a.par_t], xb = gr[2 * p + a.par_t];
       const float v1b = xb * exp(-s);
       gr[2 * p + a.par_t] = v1b;
@@ -593,17 +606,16 @@ __global__ __launch_bounds__(256) void k_l64_couple_bwd(G64Args a, int inv, cons
       put(dt, Ft, p, -v1b);
     }
   } else if (a.kind == NF_KIND_REALNVP) {
-    for (int p = 0; p < a.c; ++p) {
+    for (int p = dl; p < a.c; p += L64_DL) {
       const float s = tanh(l64_out(os, Fs, j, p)), es = exp(s), x1 = xr[2 * p + a.par_t], yb = gr[2 * p + a.par_t];
       put(dt, Ft, p, yb);
       gr[2 * p + a.par_t] = yb * es;
       put(ds, Fs, p, (yb * x1 * es + lb) * (1.f - s * s));
     }
   } else {
-    const int P = 3 * a.K - 1;
     G64Spline<float> sp;
     float raw[3 * G64_MAXK], thb[3 * G64_MAXK];
-    for (int p = 0; p < a.c; ++p) {
+    for (int p = dl; p < a.c; p += L64_DL) {
       for (int i = 0; i < P; ++i) raw[i] = l64_out(os, Fs, j, p * P + i);
       g64_build<float>(raw, a.K, (float)a.B, sp);
       const float xb = g64_spline_bwd<float>(sp, raw, a.K, (float)a.B, xr[2 * p + a.par_t], gr[2 * p + a.par_t], lb, thb, inv != 0);
@@ -662,8 +674,7 @@ static G64Args make_g64_args(const nf_flow_desc *desc, int k, long N) {
   return a;
 }
 
-// launches of the two kernels in the size class the flow fits (Float32 flows whose layers are at most 64 wide: the MLP on
-// the matrix pipe, "l64" above)
+// launches of the two kernels in the size class the flow fits (Float32 flows: the MLP on the matrix pipe, "l64" above)
 static bool l64_ok(const nf_flow_desc *desc);
 static int l64_apply(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a, int inverse, const float *theta, float *xy, float *ladj);
 static int l64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &a, int inv, const float *theta, const float *x, float *gbar,
@@ -731,12 +742,17 @@ static inline int l64_pad32(int n) { return (n + 31) / 32 * 32; }
 static bool l64_ok(const nf_flow_desc *desc) {
   static const bool off = std::getenv("NF_G64_NO_MFMA") != nullptr;  // A/B switch: the scalar MLP
   if (off || desc->dtype != NF_DTYPE_F32 || (desc->kind != NF_KIND_REALNVP && desc->kind != NF_KIND_NSF)) return false;
-  if (desc->n_hidden < 1 || desc->n_hidden > NF_MAX_HIDDEN || desc->d < 2 || (desc->d + 1) / 2 > 64) return false;
+  if (desc->n_hidden < 1 || desc->n_hidden > NF_MAX_HIDDEN || desc->d < 2 || desc->d > 256) return false;
   for (int i = 0; i < desc->n_hidden; ++i)
-    if (desc->hdims[i] > 64 || desc->hdims[i] < 1) return false;
+    if (desc->hdims[i] > 256 || desc->hdims[i] < 1) return false;
   if (desc->kind == NF_KIND_NSF && (desc->K < 1 || desc->K > G64_MAXK)) return false;
   const int nout = desc->kind == NF_KIND_REALNVP ? (desc->d + 1) / 2 : (3 * desc->K - 1) * ((desc->d + 1) / 2);
   return nout <= G64Large::MAXO;
+}
+static int l64_gh_rows(const nf_flow_desc *desc) {  // rows of the two hidden-cotangent buffers: the widest hidden layer
+  int m = 32;
+  for (int i = 0; i < desc->n_hidden; ++i) m = desc->hdims[i] > m ? desc->hdims[i] : m;
+  return l64_pad32(m);
 }
 // scratch floats per sample of ONE coupling call: per net the stashed layer outputs, the output cotangent; two hidden
 // cotangent buffers
@@ -745,7 +761,7 @@ static size_t l64_floats_per_sample(const nf_flow_desc *desc) {
   const int nout = desc->kind == NF_KIND_REALNVP ? c : (3 * desc->K - 1) * c;
   size_t per_net = 2 * (size_t)l64_pad32(nout);
   for (int i = 0; i < desc->n_hidden; ++i) per_net += l64_pad32(desc->hdims[i]);
-  return (desc->kind == NF_KIND_REALNVP ? 2 : 1) * per_net + 2 * 64;
+  return (desc->kind == NF_KIND_REALNVP ? 2 : 1) * per_net + 2 * (size_t)l64_gh_rows(desc);
 }
 size_t nf_l64_scratch_bytes(const nf_flow_desc *desc, long N) {
   if (!l64_ok(desc)) return 0;
@@ -754,8 +770,8 @@ size_t nf_l64_scratch_bytes(const nf_flow_desc *desc, long N) {
 struct L64Bufs {
   float *act[2][NF_MAX_HIDDEN + 1];  // [net][layer]: tiled outputs (the last one: the net's output)
   int F[NF_MAX_HIDDEN + 1];          // rows of those tiles
-  float *dout[2], *gh[2];            // output cotangents per net; two hidden cotangent buffers of 64 rows
-  int nets, nl;
+  float *dout[2], *gh[2];            // output cotangents per net; two hidden cotangent buffers of GH rows
+  int nets, nl, GH;
 };
 static int l64_bufs(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a, L64Bufs *b) {
   NF_TRY(nf_wimg_reserve(ctx, nf_l64_scratch_bytes(desc, a.N)));
@@ -768,7 +784,8 @@ static int l64_bufs(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a, L64
     for (int l = 0; l < b->nl; ++l) { b->act[n][l] = p; p += Np * b->F[l]; }
     b->dout[n] = p; p += Np * b->F[b->nl - 1];
   }
-  b->gh[0] = p; p += Np * 64;
+  b->GH = l64_gh_rows(desc);
+  b->gh[0] = p; p += Np * b->GH;
   b->gh[1] = p;
   return NF_OK;
 }
@@ -777,11 +794,18 @@ static inline unsigned l64_grid(nf_ctx *ctx, long N, long cap) {
   if (nb > cap) nb = cap;
   return (unsigned)(nb < 1 ? 1 : nb);
 }
-// block sizes: layer inputs are at most 64 wide (IB 1 or 2); outputs go in groups of 1, 2 or 4 blocks
-#define L64_DISPATCH(IBv, OBv, CALL)                                   \
-  do {                                                                \
-    if ((IBv) == 1 && (OBv) == 1) { CALL(1, 1); } else if ((IBv) == 1 && (OBv) == 2) { CALL(1, 2); } \
-    else if ((IBv) == 1) { CALL(1, 4); } else if ((OBv) == 1) { CALL(2, 1); } else if ((OBv) == 2) { CALL(2, 2); } else { CALL(2, 4); } \
+// block sizes: a layer's inputs are padded to 1, 2, 4 or 8 blocks of 32; its outputs go in groups of 1, 2 or 4 blocks,
+// smaller the wider the input (the weight block [32 IB][32 OB] and, for dW, the operand tiles must fit LDS)
+static inline int l64_ibp(int nin) { const int b = (nin + 31) / 32; return b <= 1 ? 1 : b <= 2 ? 2 : b <= 4 ? 4 : 8; }
+static inline int l64_maxg(int ibp, bool dw) { return ibp <= 2 ? (dw ? 2 : 4) : ibp == 4 ? 2 : 1; }
+#define L64_DISPATCH(IBv, OBv, CALL)                                                                  \
+  do {                                                                                               \
+    switch ((IBv) * 8 + (OBv)) {                                                                     \
+      case 8 + 1: CALL(1, 1); break;  case 8 + 2: CALL(1, 2); break;  case 8 + 4: CALL(1, 4); break;  \
+      case 16 + 1: CALL(2, 1); break; case 16 + 2: CALL(2, 2); break; case 16 + 4: CALL(2, 4); break; \
+      case 32 + 1: CALL(4, 1); break; case 32 + 2: CALL(4, 2); break;                                 \
+      default: CALL(8, 1); break;                                                                    \
+    }                                                                                                \
   } while (0)
 static inline int l64_group(int blocks_left, int maxg) { return blocks_left >= 4 && maxg >= 4 ? 4 : blocks_left >= 2 && maxg >= 2 ? 2 : 1; }
 
@@ -792,12 +816,12 @@ static int l64_nets_fwd(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a,
     const G64Net &net = a.net[n];
     for (int l = 0; l < net.nl; ++l) {
       const int nin = net.dims[l], nout = net.dims[l + 1];
-      const int IB = (nin + 31) / 32, blocks = (nout + 31) / 32;
+      const int IB = l64_ibp(nin), blocks = (nout + 31) / 32;
       L64Src src;
       if (l == 0) src = L64Src{x, 0, 0, a.d, 1 - a.par_t};
       else src = L64Src{b.act[n][l - 1], b.F[l - 1], 0, 0, 0};
       for (int ob0 = 0; ob0 < blocks;) {
-        const int OB = l64_group(blocks - ob0, 4);
+        const int OB = l64_group(blocks - ob0, l64_maxg(IB, false));
         const L64Layer L{net.w[l], net.b[l], nin, nout, 32 * ob0};
         ProfScope ps(ctx, "l64_fwd");
 #define CALL(I, O) hipLaunchKernelGGL((k_l64_fwd<I, O>), dim3(grid), dim3(256), 0, ctx->stream, theta, L, src, b.act[n][l], b.F[l], a.N, l < net.nl - 1 ? 1 : 0)
@@ -816,7 +840,7 @@ static int l64_apply(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a, in
   NF_TRY(l64_nets_fwd(ctx, desc, a, theta, xy, b));
   ProfScope ps(ctx, "l64_couple");
   const int last = b.nl - 1;
-  hipLaunchKernelGGL(k_l64_couple_fwd, dim3((unsigned)((a.N + 255) / 256)), dim3(256), 0, ctx->stream, a, inverse, (const float *)b.act[0][last],
+  hipLaunchKernelGGL(k_l64_couple_fwd, dim3((unsigned)((a.N + 31) / 32)), dim3(256), 0, ctx->stream, a, inverse, (const float *)b.act[0][last],
                      b.F[last], (const float *)b.act[b.nets - 1][last], b.F[last], xy, ladj);
   return (int)hipGetLastError();
 }
@@ -843,8 +867,7 @@ static int l64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &
   const int last = b.nl - 1;
   {
     ProfScope ps(ctx, "l64_couple");
-    const long Np = (a.N + 31) / 32 * 32;
-    hipLaunchKernelGGL(k_l64_couple_bwd, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, ctx->stream, a, inv, (const float *)b.act[0][last],
+    hipLaunchKernelGGL(k_l64_couple_bwd, dim3((unsigned)((a.N + 31) / 32)), dim3(256), 0, ctx->stream, a, inv, (const float *)b.act[0][last],
                        b.F[last], x, gbar, lbar, lbar_const, b.dout[0], b.dout[b.nets - 1], b.F[last]);
     NF_HIP(hipGetLastError());
   }
@@ -854,18 +877,18 @@ static int l64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &
     const G64Net &net = a.net[n];
     for (int l = net.nl - 1; l >= 0; --l) {
       const int nin = net.dims[l], nout = net.dims[l + 1];
-      const int IB = (nin + 31) / 32, blocks = (nout + 31) / 32;
+      const int IB = l64_ibp(nin), blocks = (nout + 31) / 32;
       // delta of this layer's outputs: the net output's cotangent as is; a hidden layer's through leaky-ReLU'
       const bool top = l == net.nl - 1;
       const float *gsrc = top ? b.dout[n] : b.gh[(net.nl - 1 - l) & 1];
-      const int Fg = top ? b.F[last] : 64;
+      const int Fg = top ? b.F[last] : b.GH;
       const float *act = top ? nullptr : b.act[n][l];
       float *gdst = b.gh[(net.nl - l) & 1];  // cotangent of this layer's inputs (l > 0)
       L64Src av;
       if (l == 0) av = L64Src{x, 0, 0, a.d, 1 - a.par_t};
       else av = L64Src{b.act[n][l - 1], b.F[l - 1], 0, 0, 0};
       for (int ob0 = 0; ob0 < blocks;) {
-        const int OBw = l64_group(blocks - ob0, 2);
+        const int OBw = l64_group(blocks - ob0, l64_maxg(IB, true));
         const L64Layer L{net.w[l], net.b[l], nin, nout, 32 * ob0};
         const L64Src gs{gsrc, Fg, 32 * ob0, 0, 0};
         ProfScope ps(ctx, "l64_dw");
@@ -875,7 +898,7 @@ static int l64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &
         ob0 += OBw;
       }
       for (int ob0 = 0, first = 1; ob0 < blocks; first = 0) {
-        const int OB = l64_group(blocks - ob0, 4);
+        const int OB = l64_group(blocks - ob0, l64_maxg(IB, false));
         const L64Layer L{net.w[l], net.b[l], nin, nout, 32 * ob0};
         const L64Src gs{gsrc, Fg, 32 * ob0, 0, 0};
         ProfScope ps(ctx, "l64_bwdx");
@@ -884,7 +907,7 @@ static int l64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &
           L64_DISPATCH(IB, OB, CALL);
 #undef CALL
         } else {
-#define CALL(I, O) hipLaunchKernelGGL((k_l64_bwdx<I, O>), dim3(grid), dim3(256), 0, ctx->stream, theta, L, gs, act, b.F[l], gdst, 64, first ? 0 : 1, 0, 0, a.N)
+#define CALL(I, O) hipLaunchKernelGGL((k_l64_bwdx<I, O>), dim3(grid), dim3(256), 0, ctx->stream, theta, L, gs, act, b.F[l], gdst, b.GH, first ? 0 : 1, 0, 0, a.N)
           L64_DISPATCH(IB, OB, CALL);
 #undef CALL
         }
