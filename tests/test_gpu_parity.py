@@ -666,6 +666,62 @@ def test_planar_radial_lane_per_sample_steps_against_oracle(nf, kind, d, nl, n, 
     assert torch.equal(g, nf.value_and_gradient(nf.elbo_batch, flow, tgt, xs)[1]) and torch.equal(g2, nf.value_and_gradient(nf.elbo_batch, flow, tgt, n, rng=nf.PhiloxRNG(17))[1])
 
 
+@pytest.mark.parametrize("kind,d,hd,nl,K,n", [
+    ("nsf", 32, (64, 64), 2, 8, 333),       # the reference docstring's nsf(q0, [64, 64], 8, 3.0, .) widths (neuralspline.jl:215)
+    ("nsf", 9, (48,), 1, 5, 1000),          # one hidden layer, K outside {8, 10}
+    ("nsf", 20, (40, 33, 17), 1, 12, 257),  # three hidden layers
+    ("realnvp", 64, (48,), 2, 0, 1000),     # one hidden layer
+    ("realnvp", 37, (64, 33, 17), 2, 0, 333),
+    ("realnvp", 16, (20, 20, 20, 20), 1, 0, 65),
+    ("realnvp", 70, (130, 96, 200), 1, 0, 100),  # wide layers beyond two hidden: 4- and 8-block inputs
+])
+def test_general_float32_couplings_run_their_mlp_on_mfma(nf, kind, d, hd, nl, K, n):
+    """Round 3: `fnn` accepts any hdims (src/flows/utils.jl:71-100).  Float32 shapes outside the fused
+    kernels (NSF hidden > 32 or K not in {8, 10}; RealNVP with 1 / 3 / 4 hidden layers) run the conditioner MLP layer by layer
+    on MFMAs (nf_generic64.hip, "l64").  Forward, inverse round trip, ELBO loss / gradient (both draw forms) and the
+    forward-KL gradient against the oracle; the kernels that ran are checked by name."""
+    import ctypes as C
+    lib = nf.load_library()
+    if kind == "nsf":
+        flow, spec = nf.nsf(nf.MvNormal(d), list(hd), K, 3.0, nl, paramtype=torch.float32, seed=7), o.FlowSpec("nsf", d, nl, hd, K, 3.0)
+    else:
+        flow, spec = nf.realnvp(nf.MvNormal(d), list(hd), nl, paramtype=torch.float32, seed=7), o.FlowSpec("realnvp", d, nl, hd)
+    rng = np.random.default_rng(d)
+    mu, var = rng.standard_normal(d).astype(np.float32), (rng.uniform(size=d) + 0.5).astype(np.float32)
+    tgt = nf.DiagGaussTarget(torch.tensor(mu, device="cuda"), torch.tensor(var, device="cuda"))
+    otgt = ("diaggauss", mu.astype(np.float64), var.astype(np.float64))
+    th64 = flow.theta.cpu().numpy().astype(np.float64)
+    xs = nf.device_specific_rand(nf.PhiloxRNG(5), flow.dist, n)
+    xs64 = xs.cpu().numpy().astype(np.float64)
+    tag = f"general {kind} d{d} h{hd} x{nl} K{K}"
+    ctx = flow.ctx
+    lib.nf_prof_enable(ctx.ptr, 2)
+    ys, ladj = nf.with_logabsdet_jacobian(flow.transform, xs)
+    y_ref, l_ref = o.flow_fwd(spec, th64, xs64)
+    fl = o.flow_fwd(spec, *P.f32(th64, xs64))
+    P.elementwise(f"{tag}: ys", ys, y_ref, P.Y_RTOL, P.Y_ATOL, fl[0])
+    P.elementwise(f"{tag}: ladj", ladj, l_ref, P.Y_RTOL, P.Y_ATOL, fl[1])
+    xr, _ = nf.with_logabsdet_jacobian(nf.inverse(flow.transform), ys)
+    P.isapprox(f"{tag}: round trip", xr, xs64, P.INV_RTOL["nsf" if kind == "nsf" else "realnvp"] * 10)
+    lo, go = o.neg_elbo_value_and_grad(spec, th64, otgt, xs64)
+    _, g32 = o.neg_elbo_value_and_grad(spec, P.f32(th64), P.f32(otgt), P.f32(xs64))
+    for form, arg in (("rng", n), ("xs", xs)):
+        loss, g = nf.value_and_gradient(nf.elbo_batch, flow, tgt, arg, rng=nf.PhiloxRNG(5))
+        P.scalar(f"{tag} ({form}): step loss", loss, lo)
+        P.gradient(f"{tag} ({form}): step grad", g, go, floor=g32)
+    lk, gk = nf.loglikelihood_value_and_gradient(flow, ys)
+    lkr, gkr = o.neg_loglik_value_and_grad(spec, th64, ys.cpu().numpy().astype(np.float64))
+    P.scalar(f"{tag}: forward-KL loss", lk, lkr, 10 * P.LOSS_RTOL)
+    P.gradient(f"{tag}: forward-KL grad", gk, gkr, 10 * P.GRAD_RTOL)
+    ran = {}
+    for name in (b"l64_fwd", b"l64_dw", b"l64_bwdx", b"l64_couple"):
+        a, c = C.c_double(0.0), C.c_int64(0)
+        lib.nf_prof_read(ctx.ptr, name, C.byref(a), C.byref(c))
+        ran[name] = c.value
+    lib.nf_prof_enable(ctx.ptr, 0)
+    assert all(v > 0 for v in ran.values()), ran  # the MFMA layer kernels, not the scalar MLP
+
+
 def test_target_argument_conventions(nf):
     """Constructor checks of the reference's target types (banana.jl:40-44, neal_funnel.jl:31-35,
     warped_gaussian.jl:29-33) and the dimension contract of the 2-d targets."""
