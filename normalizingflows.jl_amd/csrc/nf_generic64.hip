@@ -536,6 +536,154 @@ __global__ __launch_bounds__(256) void k_l64_dw(L64Layer L, L64Src a, L64Src g, 
 __device__ __forceinline__ float l64_out(const float *__restrict__ buf, int F, long j, int row) {
   return buf[(((j >> 5) * F + row) << 5) + (j & 31)];
 }
+// ---- the spline of one (dimension, sample) without per-thread arrays ---------------------------------------------------
+// g64_build / g64_spline_* keep knots, softmax terms and cotangents in arrays indexed by the (run-time) bin: with K a
+// run-time value those live in scratch memory (544 / 736 bytes per thread, every access a memory operation).  The tiles
+// make a cheaper form possible: the 3K - 1 raw parameters of a dimension are K rows apart in L1-resident memory, so the
+// softmax statistics, the walk to the bin and the cotangents are PASSES over those rows with a handful of scalars each.
+// Same formulas as above (MonotonicSplines 0.3.3 as restated in oracle/nf_oracle.py); sm_i = exp(v_i - max) / sum.
+struct L64Bin {
+  int k;            // bin, -1: outside [-B, B)
+  float x0, x1;     // knots p[k], p[k + 1]
+  float sm;         // softmax term of the bin
+};
+struct L64Raw {
+  const float *base;  // tile base of this (tile, dimension): element i at base[i * 32] (row stride of the tile)
+  __device__ __forceinline__ float operator()(int i) const { return base[(long)i << 5]; }
+};
+__device__ __forceinline__ void l64_softmax_stats(const L64Raw &raw, int off, int K, float &mx, float &inv) {
+  mx = raw(off);
+  for (int i = 1; i < K; ++i) mx = fmaxf(mx, raw(off + i));
+  float sum = 0.f;
+  for (int i = 0; i < K; ++i) sum += expf(raw(off + i) - mx);
+  inv = 1.f / sum;
+}
+// the bin of v among the knots p[j] = -B + 2B cumsum(sm)[j] (g64_bin: the count of interior knots <= v)
+__device__ __forceinline__ L64Bin l64_find(const L64Raw &raw, int off, int K, float B, float mx, float inv, float v) {
+  L64Bin b{-1, 0.f, 0.f, 0.f};
+  float cs = 0.f, left = -B;
+  int k = 0;
+  float x0 = -B, x1 = -B, smk = 0.f, pK = -B;
+  for (int i = 0; i < K; ++i) {
+    const float sm = expf(raw(off + i) - mx) * inv;
+    cs += sm;
+    const float right = -B + 2.f * B * cs;
+    // bin i holds v when i is the number of interior knots (p[1] .. p[K-1]) that are <= v
+    const bool take = (i == 0 || v >= left) && (i == K - 1 || !(v >= right));
+    if (take) { k = i; x0 = left; x1 = right; smk = sm; }
+    left = right;
+    pK = right;
+  }
+  if (v >= -B && v < pK) { b.k = k; b.x0 = x0; b.x1 = x1; b.sm = smk; }
+  return b;
+}
+// knots k, k + 1 of the OTHER axis for a known bin
+__device__ __forceinline__ void l64_knots_at(const L64Raw &raw, int off, int K, float B, float mx, float inv, int k, float &y0, float &y1,
+                                             float &smk) {
+  float cs = 0.f;
+  y0 = -B; y1 = -B; smk = 0.f;
+  for (int i = 0; i <= k; ++i) {
+    const float sm = expf(raw(off + i) - mx) * inv;
+    if (i == k) { y0 = -B + 2.f * B * cs; smk = sm; }
+    cs += sm;
+  }
+  y1 = -B + 2.f * B * cs;
+}
+__device__ __forceinline__ float l64_softplus(float x) { return log1pf(expf(-fabsf(x))) + fmaxf(x, 0.f); }
+__device__ __forceinline__ float l64_sigmoid(float x) {
+  const float e = expf(-fabsf(x));
+  return x >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+}
+// forward / inverse of one dimension; logd accumulates log S'(x) (forward) or -log S'(x) (inverse)
+__device__ __forceinline__ float l64_spline_apply(const L64Raw &raw, int K, float B, float v, bool inverse, float &logd) {
+  float mxw, invw, mxh, invh;
+  l64_softmax_stats(raw, 0, K, mxw, invw);
+  l64_softmax_stats(raw, K, K, mxh, invh);
+  float x0, x1, y0, y1, dummy;
+  int k;
+  if (!inverse) {
+    const L64Bin b = l64_find(raw, 0, K, B, mxw, invw, v);
+    if (b.k < 0) return v;
+    k = b.k; x0 = b.x0; x1 = b.x1;
+    l64_knots_at(raw, K, K, B, mxh, invh, k, y0, y1, dummy);
+  } else {
+    const L64Bin b = l64_find(raw, K, K, B, mxh, invh, v);
+    if (b.k < 0) return v;
+    k = b.k; y0 = b.x0; y1 = b.x1;
+    l64_knots_at(raw, 0, K, B, mxw, invw, k, x0, x1, dummy);
+  }
+  const float d0 = k >= 1 ? l64_softplus(raw(2 * K + k - 1)) : 1.f, d1 = k + 1 <= K - 1 ? l64_softplus(raw(2 * K + k)) : 1.f;
+  const float dx = x1 - x0, dy = y1 - y0, sl = dy / dx;
+  if (!inverse) {
+    const float xi = (v - x0) / dx, om = 1.f - xi, den = sl + (d1 + d0 - 2.f * sl) * xi * om;
+    logd += g64_logderiv(sl, d0, d1, xi);
+    return y0 + dy * (sl * xi * xi + d0 * xi * om) / den;
+  }
+  const float yy = v - y0, q = d1 + d0 - 2.f * sl;
+  const float aa = dy * (sl - d0) + yy * q, bb = dy * d0 - yy * q, cc = -sl * yy;
+  const float disc = fmaxf(bb * bb - 4.f * aa * cc, 0.f);
+  const float xi = 2.f * cc / (-bb - sqrtf(disc));
+  logd -= g64_logderiv(sl, d0, d1, xi);
+  return xi * dx + x0;
+}
+// reverse pass at x (g64_spline_bwd's algebra); writes the 3K - 1 parameter cotangents to out (tile rows, stride 32) and
+// returns xbar (inv: the cotangent of the inverse's input, see g64_spline_bwd)
+__device__ __forceinline__ float l64_spline_bwd(const L64Raw &raw, float *__restrict__ out, int K, float B, float x, float ybar, float lbar,
+                                                bool inv) {
+  const int P = 3 * K - 1;
+  float mxw, invw, mxh, invh;
+  l64_softmax_stats(raw, 0, K, mxw, invw);
+  l64_softmax_stats(raw, K, K, mxh, invh);
+  const L64Bin b = l64_find(raw, 0, K, B, mxw, invw, x);
+  if (b.k < 0) {
+    for (int i = 0; i < P; ++i) out[(long)i << 5] = 0.f;
+    return ybar;
+  }
+  const int k = b.k;
+  float y0, y1, smh_k;
+  l64_knots_at(raw, K, K, B, mxh, invh, k, y0, y1, smh_k);
+  const float d0 = k >= 1 ? l64_softplus(raw(2 * K + k - 1)) : 1.f, d1 = k + 1 <= K - 1 ? l64_softplus(raw(2 * K + k)) : 1.f;
+  const float dx = b.x1 - b.x0, dy = y1 - y0;
+  const float s = dy / dx, xi = (x - b.x0) / dx, om = 1.f - xi, q = d1 + d0 - 2.f * s;
+  const float den = s + q * xi * om, num = s * xi * xi + d0 * xi * om;
+  const float nd = d1 * xi * xi + 2.f * s * xi * om + d0 * om * om;
+  const float dnum_dxi = 2.f * s * xi + d0 * (1.f - 2.f * xi), dden_dxi = q * (1.f - 2.f * xi);
+  const float dnd_dxi = 2.f * d1 * xi + 2.f * s * (1.f - 2.f * xi) - 2.f * d0 * om;
+  const float dy_dxi = dy * (dnum_dxi * den - num * dden_dxi) / (den * den);
+  const float dL_dxi = dnd_dxi / nd - 2.f * dden_dxi / den;
+  float vbar = 0.f;
+  if (inv) {
+    vbar = (ybar - lbar * dL_dxi / dx) / (dy_dxi / dx);
+    ybar = -vbar;
+    lbar = -lbar;
+  }
+  const float dden_ds = 1.f - 2.f * xi * om;
+  const float dy_ds = dy * (xi * xi * den - num * dden_ds) / (den * den);
+  const float dL_ds = 2.f / s + 2.f * xi * om / nd - 2.f * dden_ds / den;
+  const float dy_dd0 = dy * (xi * om * den - num * xi * om) / (den * den), dL_dd0 = om * om / nd - 2.f * xi * om / den;
+  const float dy_dd1 = dy * (-num * xi * om) / (den * den), dL_dd1 = xi * xi / nd - 2.f * xi * om / den;
+  const float xibar = ybar * dy_dxi + lbar * dL_dxi, sbar = ybar * dy_ds + lbar * dL_ds;
+  const float d0bar = ybar * dy_dd0 + lbar * dL_dd0, d1bar = ybar * dy_dd1 + lbar * dL_dd1;
+  const float dybar = ybar * num / den + sbar / dx;
+  const float dxbar = -sbar * s / dx - xibar * xi / dx;
+  const float xkbar = -xibar / dx - dxbar, xk1bar = dxbar, ykbar = ybar - dybar, yk1bar = dybar;
+  // sbw_i = 2B (i < k ? xkbar + xk1bar : i == k ? xk1bar : 0);  dotw = sum_i sbw_i sm_i with sum_{i<k} sm_i = (p[k] + B) / 2B
+  const float aw = 2.f * B * (xkbar + xk1bar), bw = 2.f * B * xk1bar, ah = 2.f * B * (ykbar + yk1bar), bh = 2.f * B * yk1bar;
+  const float dotw = aw * (b.x0 + B) / (2.f * B) + bw * b.sm, doth = ah * (y0 + B) / (2.f * B) + bh * smh_k;
+  for (int i = 0; i < K; ++i) {
+    const float smw = expf(raw(i) - mxw) * invw, smh = expf(raw(K + i) - mxh) * invh;
+    out[(long)i << 5] = smw * ((i < k ? aw : i == k ? bw : 0.f) - dotw);
+    out[(long)(K + i) << 5] = smh * ((i < k ? ah : i == k ? bh : 0.f) - doth);
+  }
+  for (int i = 0; i < K - 1; ++i) {
+    float t = 0.f;
+    if (i == k - 1) t = d0bar * l64_sigmoid(raw(2 * K + i));
+    if (i == k) t = d1bar * l64_sigmoid(raw(2 * K + i));
+    out[(long)(2 * K + i) << 5] = t;
+  }
+  return inv ? vbar : xibar / dx;
+}
+
 // A workgroup is one 32-sample tile x 8 dimension lanes: thread (sample = tid & 31, lane = tid >> 5) walks the transformed
 // dimensions lane, lane + 8, ... (a spline is 3K - 1 parameters, two softmaxes and a handful of logs per dimension: one thread
 // per SAMPLE, as in k_g64_apply, leaves 16 of them in a row on a thread and the chip a quarter full at N = 131 072 --
@@ -558,13 +706,10 @@ __global__ __launch_bounds__(256) void k_l64_couple_fwd(G64Args a, int inverse, 
       }
     } else {
       const int P = 3 * a.K - 1;
-      G64Spline<float> sp;
-      float raw[3 * G64_MAXK];
       for (int p = dl; p < a.c; p += L64_DL) {
-        for (int i = 0; i < P; ++i) raw[i] = l64_out(os, Fs, j, p * P + i);
-        g64_build<float>(raw, a.K, (float)a.B, sp);
+        const L64Raw raw{os + ((((j >> 5) * Fs + (long)p * P) << 5) + (j & 31))};
         const float v = r[2 * p + a.par_t];
-        r[2 * p + a.par_t] = inverse ? g64_spline_inv(sp, a.K, v, lsum) : g64_spline_fwd(sp, a.K, v, lsum);
+        r[2 * p + a.par_t] = l64_spline_apply(raw, a.K, (float)a.B, v, inverse != 0, lsum);
       }
     }
   }
@@ -613,14 +758,10 @@ __global__ __launch_bounds__(256) void k_l64_couple_bwd(G64Args a, int inv, cons
       put(ds, Fs, p, (yb * x1 * es + lb) * (1.f - s * s));
     }
   } else {
-    G64Spline<float> sp;
-    float raw[3 * G64_MAXK], thb[3 * G64_MAXK];
     for (int p = dl; p < a.c; p += L64_DL) {
-      for (int i = 0; i < P; ++i) raw[i] = l64_out(os, Fs, j, p * P + i);
-      g64_build<float>(raw, a.K, (float)a.B, sp);
-      const float xb = g64_spline_bwd<float>(sp, raw, a.K, (float)a.B, xr[2 * p + a.par_t], gr[2 * p + a.par_t], lb, thb, inv != 0);
-      gr[2 * p + a.par_t] = xb;
-      for (int i = 0; i < P; ++i) put(ds, Fs, p * P + i, thb[i]);
+      const long e0 = (((j >> 5) * Fs + (long)p * P) << 5) + (j & 31);
+      const L64Raw raw{os + e0};
+      gr[2 * p + a.par_t] = l64_spline_bwd(raw, ds + e0, a.K, (float)a.B, xr[2 * p + a.par_t], gr[2 * p + a.par_t], lb, inv != 0);
     }
   }
 }
