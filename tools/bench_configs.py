@@ -160,6 +160,10 @@ def main():
     if want("gen"):
         flow = nf.nsf(nf.MvNormal(32), (64, 64), 8, 3.0, 3, paramtype=torch.float32, device=dev, seed=123)
         res["gen_nsf_d32_h64_k8_n131072_general_kernels"] = time_step(flow, dg(32), 131072, max(3, args.steps // 10), warmup=2)
+        flow = nf.realnvp(nf.MvNormal(64), (64, 64, 64), 4, paramtype=torch.float32, device=dev, seed=123)  # cfg 2 with a third hidden layer
+        res["gen_realnvp_d64_h64x3_n65536_general_kernels"] = time_step(flow, dg(64), 65536, max(3, args.steps // 10), warmup=2)
+        flow = nf.realnvp(nf.MvNormal(64), (64,), 4, paramtype=torch.float32, device=dev, seed=123)  # ... and with one
+        res["gen_realnvp_d64_h64x1_n65536_general_kernels"] = time_step(flow, dg(64), 65536, max(3, args.steps // 10), warmup=2)
     if not want("cfg5"):
         for k, v in res.items():
             print(k, json.dumps(v))
