@@ -916,6 +916,7 @@ struct L64Bufs {
 };
 static int l64_bufs(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a, L64Bufs *b) {
   NF_TRY(nf_wimg_reserve(ctx, nf_l64_scratch_bytes(desc, a.N)));
+  ctx->wimg_owner = nullptr;  // the buffer doubles as the fused kernels' packed-image store: whatever it cached is gone
   const size_t Np = (size_t)((a.N + 31) / 32) * 32;
   b->nets = desc->kind == NF_KIND_REALNVP ? 2 : 1;
   b->nl = a.net[0].nl;
