@@ -91,6 +91,16 @@ ARENA_FLOWS = {
     "planar_many_layers": lambda nf: nf.planarflow(nf.MvNormal(40), 20, paramtype=torch.float32, seed=6),  # beyond k_simple_step
     "radial_f64": lambda nf: nf.radialflow(nf.MvNormal(7), 4, paramtype=torch.float64, seed=7),
     "meanfield": lambda nf: nf.meanfield(nf.MvNormal(4), paramtype=torch.float32),
+    "realnvp_three_hidden": lambda nf: nf.realnvp(nf.MvNormal(10), [40, 33, 17], 2, paramtype=torch.float32, seed=8),  # MFMA layer kernels (l64)
+    "nsf_hidden64": lambda nf: nf.nsf(nf.MvNormal(12), [64, 64], 8, 3.0, 1, paramtype=torch.float32, seed=9),
+    "composite_nsf_wide_general_segments": lambda nf: nf.create_flow(
+        [nf.nsf(nf.MvNormal(8), [32, 32], 8, 4.0, 1, paramtype=torch.float32, seed=1), nf.realnvp(nf.MvNormal(8), [96, 70], 1, paramtype=torch.float32, seed=2),
+         nf.nsf(nf.MvNormal(8), [24, 16, 8], 6, 4.0, 1, paramtype=torch.float32, seed=3), nf.realnvp(nf.MvNormal(8), [20], 1, paramtype=torch.float32, seed=4)],
+        nf.MvNormal(torch.randn(8, device="cuda"), torch.rand(8, device="cuda") + 0.5)),
+    "composite_f64_general_base": lambda nf: nf.create_flow(
+        [nf.realnvp(nf.MvNormal(6), [16, 16], 1, paramtype=torch.float64, seed=2), nf.nsf(nf.MvNormal(6), [12, 12], 5, 4.0, 1, paramtype=torch.float64, seed=3),
+         nf.radialflow(nf.MvNormal(6), 2, paramtype=torch.float64, seed=1)],
+        nf.MvNormal(torch.randn(6, dtype=torch.float64, device="cuda"), torch.rand(6, dtype=torch.float64, device="cuda") + 0.5)),
     "composite_general_base": lambda nf: nf.create_flow(
         [nf.radialflow(nf.MvNormal(6), 2, paramtype=torch.float32, seed=1), nf.realnvp(nf.MvNormal(6), [16, 16], 1, paramtype=torch.float32, seed=2),
          nf.planarflow(nf.MvNormal(6), 2, paramtype=torch.float32, seed=3)],
@@ -106,7 +116,7 @@ def test_caller_provided_arena_covers_every_entry_point(name):
     nf = load_package()
     lib = nf.load_library()
     flow = ARENA_FLOWS[name](nf)
-    if name.startswith("planar") or name.startswith("radial") or name.startswith("composite"):
+    if name.startswith("planar") or name.startswith("radial") or name == "composite_general_base":
         flow = flow.with_theta(flow.theta * 0.3)
     dt, d, n = flow.theta.dtype, flow.dist.d, 333
     ctx = flow.ctx
