@@ -241,18 +241,25 @@ __device__ __forceinline__ void net_forward_stash(const float *__restrict__ img,
   nf_buffer_store_b128(mk, st.rs, (hi * 32 + l31) * 16, (nbase + SG::MSK) * 4);
 }
 
+#ifdef NF_KERNEL_TRACE
+#define NF_CH_STAMP(tr, slot) do { if (tr) { __builtin_amdgcn_sched_barrier(0); (tr)[slot] = clock64(); } } while (0)
+#else
+#define NF_CH_STAMP(tr, slot) do { } while (0)
+#endif
 // forward coupling of the training step: as coupling_step<G, false>, leaving the reverse pass's operands behind
 // INVERSE (forward-KL training: the chain runs data -> base): w1 = (v1 - t) exp(-s); the UV slot then holds w1, which is
 // what the reverse pass of the inverse coupling needs next to s (bwd_tile's INVD algebra)
 template <class G, bool INVERSE = false>
 __device__ __forceinline__ float coupling_step_stash(const float *__restrict__ img_s, const float *__restrict__ img_t,
                                                      f32x16 (&x1)[G::CB], const f32x16 (&xb)[G::MB], int l31, int hi,
-                                                     const StashIO &st) {
+                                                     const StashIO &st, long long *tr = nullptr) {
   using SG = StashGeo<G>;
   static_assert(G::H1B <= 2 && G::H2B <= 2, "mask words");
   f32x16 S[G::CB], T[G::CB];
   net_forward_stash<G, true>(img_s, xb, S, l31, hi, st, SG::NET0);
+  NF_CH_STAMP(tr, 1);
   net_forward_stash<G, false>(img_t, xb, T, l31, hi, st, SG::NET0 + SG::NETSZ);
+  NF_CH_STAMP(tr, 2);
   float lsum = 0.f;
 #pragma unroll
   for (int b = 0; b < G::CB; ++b)
@@ -291,6 +298,7 @@ struct FusedArgs {
   double *partial;        // [gridDim.x] out
   double pscale;
   float *stash;           // STASH: [tile][coupling][StashGeo<G>::SIZE] out
+  long long *trace;       // NF_KERNEL_TRACE builds: clock stamps for tools/trace_chain.py, else unused
 };
 
 template <class G, bool INVERSE, bool FUSED = false, bool STASH = false>
@@ -409,8 +417,20 @@ __global__ __launch_bounds__(512) void k_affine_chain(ChainArgs a, float *xt, fl
         float ls;
         if (STASH) {
           const StashIO st = make_stash_io(fa.stash, tl * a.ncoup + coupling_at(pos), StashGeo<G>::SIZE, live, l31, hi);
-          if (INVERSE ? (half == 1) : (half == 0)) ls = coupling_step_stash<G, INVERSE>(img_s, img_t, O, E, l31, hi, st);
-          else ls = coupling_step_stash<G, INVERSE>(img_s, img_t, E, O, l31, hi, st);
+#ifdef NF_KERNEL_TRACE  // tools/trace_chain.py: block 0, waves 0 and 4 (one SIMD), stamps [32 + wave/4 * 64 + position * 4 + 0..3]
+          // (the slots the reverse kernels of the same step leave alone)
+          long long *tr = (fa.trace && blockIdx.x == 0 && (tid & 255) == 0 && pos < 8) ? fa.trace + 32 + (tid >> 8) * 64 + pos * 4 - 1 : nullptr;
+#else
+          long long *tr = nullptr;
+#endif
+          if (INVERSE ? (half == 1) : (half == 0)) ls = coupling_step_stash<G, INVERSE>(img_s, img_t, O, E, l31, hi, st, tr);
+          else ls = coupling_step_stash<G, INVERSE>(img_s, img_t, E, O, l31, hi, st, tr);
+          NF_CH_STAMP(tr, 3);
+          lsum += ls;
+          __syncthreads();
+          NF_CH_STAMP(tr, 4);
+          buf ^= 1;
+          continue;
         } else if (INVERSE ? (half == 1) : (half == 0)) {
           (void)x1_is_O;
           ls = coupling_step<G, INVERSE>(img_s, img_t, O, E, l31, hi);
@@ -1609,6 +1629,7 @@ int nf_affine_chain_elbo(nf_ctx *ctx, const nf_flow_desc *desc, long N, uint64_t
   if (!size || !ctx->wimg) return NF_ERR_UNSUPPORTED;
   FusedArgs fa;
   fa.stash = stash;
+  fa.trace = (long long *)ctx->trace;
   fa.stream_ptr = stream_ptr;
   fa.k0 = (uint32_t)seed; fa.k1 = (uint32_t)(seed >> 32); fa.stream = stream; fa.off = off;
   fa.mu = mu; fa.var = var; fa.gt = gt; fa.gscale = (float)gscale; fa.partial = partial; fa.pscale = pscale;
