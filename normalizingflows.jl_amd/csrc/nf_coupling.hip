@@ -223,16 +223,14 @@ __device__ __forceinline__ void net_forward_stash(const float *__restrict__ img,
     dense_fwd<G::MB, G::H1B>(img + G::W1, img + G::B1, x, a1, l31, hi);
 #pragma unroll
   for (int b = 0; b < G::H1B; ++b) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) a1[b][r] = nf_lrelu(a1[b][r]);
+    nf_lrelu16(a1[b]);
     m1[b] = nf_sign_mask16(a1[b]);
   }
   dense_fwd<G::H1B, G::H2B>(img + G::W2, img + G::B2, a1, a2, l31, hi,
                             [&](int e) { stash_put_T<G::H1B>(st, nbase + SG::A1, a1, e); });
 #pragma unroll
   for (int b = 0; b < G::H2B; ++b) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) a2[b][r] = nf_lrelu(a2[b][r]);
+    nf_lrelu16(a2[b]);
     m2[b] = nf_sign_mask16(a2[b]);
   }
   dense_fwd<G::H2B, G::CB>(img + G::W3, img + G::B3, a2, out, l31, hi,
@@ -647,16 +645,14 @@ __device__ __forceinline__ void bwd_tile(const CouplingArgs &a, const float *__r
                              [&](int e) { scratch_put<G::MB>(sc + L::OFF_X, xb, e, l31, hi); });
 #pragma unroll
     for (int b = 0; b < G::H1B; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) a1[b][r] = nf_lrelu(a1[b][r]);
+      nf_lrelu16(a1[b]);
     sign_masks<G::H1B>(a1, m1);
     f32x16 a2[G::H2B];
     dense_fwd<G::H1B, G::H2B>(img + G::W2, img + G::B2, a1, a2, l31, hi,
                               [&](int e) { scratch_put<G::H1B>(sc + L::OFF_A1, a1, e, l31, hi); });
 #pragma unroll
     for (int b = 0; b < G::H2B; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) a2[b][r] = nf_lrelu(a2[b][r]);
+      nf_lrelu16(a2[b]);
     sign_masks<G::H2B>(a2, m2);
     // operands of the element-wise stage: issued here, consumed after the last forward layer
 #pragma unroll

@@ -28,8 +28,29 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ int nf_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
-// Flux.leakyrelu, slope 0.01: max(z, 0.01 z) (2 VALU ops; identical to z > 0 ? z : 0.01 z)
-__device__ __forceinline__ float nf_lrelu(float z) { return fmaxf(z, 0.01f * z); }
+// Flux.leakyrelu, slope 0.01: max(z, 0.01 z) (identical to z > 0 ? z : 0.01 z).  fmaxf() costs a third instruction under
+// hipcc: IEEE mode makes it quiet a possible signalling NaN first (`v_max_f32 z, z, z`), 128 of them per coupling in the
+// cfg-2 forward; the instruction itself is what is wanted.
+__device__ __forceinline__ float nf_vmax(float a, float b) {
+#ifdef NF_LRELU_FMAX  // A/B switch: the compiler's own three-instruction form
+  return fmaxf(a, b);
+#endif
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float nf_lrelu(float z) { return nf_vmax(z, 0.01f * z); }
+// a whole accumulator block: the products two per instruction (v_pk_mul_f32), 1.5 VALU ops per element
+__device__ __forceinline__ void nf_lrelu16(f32x16 &a) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    const f32x2 p = {a[r], a[r + 1]};
+    const f32x2 m = p * 0.01f;
+    a[r] = nf_vmax(p[0], m[0]);
+    a[r + 1] = nf_vmax(p[1], m[1]);
+  }
+}
 
 // tanh / exp for the coupling's scale branch (s = tanh(.), exp(+-s); src/flows/realnvp.jl:50,79).
 // Hardware exp2-based forms: absolute error of tanh < 1e-7 (the reference itself runs NNlib's
@@ -491,13 +512,11 @@ __device__ __forceinline__ void net_forward(const float *__restrict__ img, const
   dense_fwd<G::MB, G::H1B>(img + G::W1, img + G::B1, x, a1, l31, hi);
 #pragma unroll
   for (int b = 0; b < G::H1B; ++b)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) a1[b][r] = nf_lrelu(a1[b][r]);
+    nf_lrelu16(a1[b]);
   dense_fwd<G::H1B, G::H2B>(img + G::W2, img + G::B2, a1, a2, l31, hi);
 #pragma unroll
   for (int b = 0; b < G::H2B; ++b)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) a2[b][r] = nf_lrelu(a2[b][r]);
+    nf_lrelu16(a2[b]);
   dense_fwd<G::H2B, G::CB>(img + G::W3, img + G::B3, a2, out, l31, hi);
 }
 

@@ -469,13 +469,11 @@ __device__ __forceinline__ float rqs_coupling_step(const float *__restrict__ img
     dense_fwd<G::MB, G::H1B>(img + G::W1, img + G::B1, xb, a1, l31, hi);
 #pragma unroll
     for (int b = 0; b < G::H1B; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) a1[b][r] = nf_lrelu(a1[b][r]);
+      nf_lrelu16(a1[b]);
     dense_fwd<G::H1B, G::H2B>(img + G::W2, img + G::B2, a1, a2, l31, hi);
 #pragma unroll
     for (int b = 0; b < G::H2B; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) a2[b][r] = nf_lrelu(a2[b][r]);
+      nf_lrelu16(a2[b]);
   }
   float lsum = 0.f;
 #pragma unroll
@@ -812,16 +810,14 @@ __device__ __forceinline__ void rqs_bwd_tile(const RqsBwdArgs &a, const float *_
     dense_fwd<G::MB, G::H1B>(img + G::W1, img + G::B1, xb, a1, l31, hi);
 #pragma unroll
     for (int b = 0; b < G::H1B; ++b) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) a1[b][r] = nf_lrelu(a1[b][r]);
+      nf_lrelu16(a1[b]);
       m1[b] = nf_sign_mask16(a1[b]);  // bit set <=> slope 0.01
     }
     tile_to_scratch<G::H1B>(sc + L::OFF_A1, a1, l31, hi);
     dense_fwd<G::H1B, G::H2B>(img + G::W2, img + G::B2, a1, a2, l31, hi);
 #pragma unroll
     for (int b = 0; b < G::H2B; ++b) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) a2[b][r] = nf_lrelu(a2[b][r]);
+      nf_lrelu16(a2[b]);
       m2[b] = nf_sign_mask16(a2[b]);
     }
     tile_to_scratch<G::H2B>(sc + L::OFF_A2, a2, l31, hi);
@@ -1149,8 +1145,7 @@ __device__ __forceinline__ void rqs_bwd_coop_coupling(const RqsBwdArgs &a, float
       dense_fwd<G::MB, G::H1B>(img + G::W1, img + G::B1, xb, a1, l31, hi);
 #pragma unroll
       for (int b = 0; b < G::H1B; ++b) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a1[b][r] = nf_lrelu(a1[b][r]);
+        nf_lrelu16(a1[b]);
         m1[b] = nf_sign_mask16(a1[b]);
       }
       tile_to_scratch<G::H1B>(sc + L::OFF_A1, a1, l31, hi);
@@ -1158,8 +1153,7 @@ __device__ __forceinline__ void rqs_bwd_coop_coupling(const RqsBwdArgs &a, float
       dense_fwd<G::H1B, G::H2B>(img + G::W2, img + G::B2, a1, a2, l31, hi);
 #pragma unroll
       for (int b = 0; b < G::H2B; ++b) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a2[b][r] = nf_lrelu(a2[b][r]);
+        nf_lrelu16(a2[b]);
         m2[b] = nf_sign_mask16(a2[b]);
       }
       tile_to_scratch<G::H2B>(sc + L::OFF_A2, a2, l31, hi);

@@ -174,8 +174,7 @@ __device__ __forceinline__ void wide_net_fwd(wide_img_t img, const float *__rest
   }
 #pragma unroll
   for (int b = 0; b < G::H1B; ++b)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) a1[b][r] = nf_lrelu(a1[b][r]);
+    nf_lrelu16(a1[b]);
   WIDE_STAMP(2);
   hk.after_l1(a1);
   WIDE_STAMP(3);
@@ -195,8 +194,7 @@ __device__ __forceinline__ void wide_net_fwd(wide_img_t img, const float *__rest
   }
 #pragma unroll
   for (int b = 0; b < G::H2B; ++b)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) a2[b][r] = nf_lrelu(a2[b][r]);
+    nf_lrelu16(a2[b]);
   WIDE_STAMP(4);
   hk.after_l2(a2);
   WIDE_STAMP(5);
