@@ -119,6 +119,7 @@ bool nf_g64_supported(const nf_flow_desc *desc);
 int nf_g64_apply(nf_ctx *, const nf_flow_desc *, int layer_lo, int layer_hi, bool inverse, const void *theta,
                  const void *x, long N, void *y, void *ladj);
 size_t nf_g64_bwd_ws_bytes(const nf_flow_desc *desc, long N);
+int nf_g64_apply_keep(nf_ctx *, const nf_flow_desc *, const void *theta, const void *x, long N, void *y, void *ladj, void *ws);
 int nf_g64_bwd(nf_ctx *, const nf_flow_desc *, const void *theta, const void *x, const void *ybar, const void *lbar,
                double lbar_const, long N, void *xbar_out, void *gtheta_out, void *ws);
 
@@ -1871,9 +1872,12 @@ extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, con
       NF_TRY(nf_launch_base_sample(ctx, dt, desc->d, N, seed, sample_offset, stream_id, x0, logq));
     }
     {
-      NF_TRY(flat_apply(ctx, desc, 0, nf_layer_count(desc), false, theta, x0, N, x, ladj));
+      // general couplings: the forward leaves every coupling's input in the reverse pass's workspace (no second forward)
+      const bool keep = is_g64(desc);
+      if (keep) NF_TRY(nf_g64_apply_keep(ctx, desc, theta, x0, N, x, ladj, sws));
+      else NF_TRY(flat_apply(ctx, desc, 0, nf_layer_count(desc), false, theta, x0, N, x, ladj));
       NF_TRY(nf_launch_target(ctx, dt, target, desc->d, N, x, logq, ladj, nullptr, gbar, -inv, nullptr, partial, -inv, joint_dims(desc)));
-      NF_TRY(flat_bwd(ctx, desc, theta, x0, gbar, nullptr, -inv, N, gbar, out, sws));
+      NF_TRY(flat_bwd(ctx, desc, theta, keep ? nullptr : x0, gbar, nullptr, -inv, N, gbar, out, sws));
     }
   }
   if (cp) return NF_OK;

@@ -1090,6 +1090,40 @@ size_t nf_g64_bwd_ws_bytes(const nf_flow_desc *desc, long N) {
 }
 
 // x = flow input; ybar -> xbar_out (may alias), gtheta_out <- dL/dtheta
+// the chain from x with the input of coupling k kept in inputs[k] (execution order k = nc-1 ... 0); the last coupling's
+// output goes to y_last, or is not computed when that is null; ladj accumulates (zeroed by the caller)
+template <class T>
+static int g64_forward_keep(nf_ctx *ctx, const nf_flow_desc *desc, const T *theta, const T *x, long N, T *inputs, T *y_last, T *ladj) {
+  const int nc = 2 * desc->nlayers;
+  const size_t nd = (size_t)N * desc->d;
+  const unsigned grid = (unsigned)((N + G64_BLOCK - 1) / G64_BLOCK);
+  const T *cur = x;
+  for (int k = nc - 1; k >= 0; --k) {
+    T *slot = inputs + (size_t)k * nd;
+    if (cur != slot) NF_HIP(hipMemcpyAsync(slot, cur, nd * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+    T *next = k > 0 ? inputs + (size_t)(k - 1) * nd : y_last;
+    if (next) {
+      const G64Args a = make_g64_args(desc, k, N);
+      ProfScope ps(ctx, "g64_apply");
+      g64_launch_apply<T>(ctx, desc, grid, a, 0, theta, (const T *)slot, next, ladj);
+      NF_HIP(hipGetLastError());
+      cur = next;
+    }
+  }
+  return NF_OK;
+}
+
+// the whole flow forward, keeping every coupling's input in `ws` in nf_g64_bwd's layout: nf_g64_bwd(x = nullptr) on the
+// same ws is then the reverse pass of THIS forward (no second forward from x).  y must not alias ws.
+int nf_g64_apply_keep(nf_ctx *ctx, const nf_flow_desc *desc, const void *theta, const void *x, long N, void *y, void *ladj, void *ws) {
+  if (N <= 0) return NF_OK;
+  const size_t es = desc->dtype == NF_DTYPE_F64 ? 8 : 4;
+  NF_HIP(hipMemsetAsync(ladj, 0, (size_t)N * es, ctx->stream));
+  if (desc->dtype == NF_DTYPE_F64)
+    return g64_forward_keep<double>(ctx, desc, (const double *)theta, (const double *)x, N, (double *)ws, (double *)y, (double *)ladj);
+  return g64_forward_keep<float>(ctx, desc, (const float *)theta, (const float *)x, N, (float *)ws, (float *)y, (float *)ladj);
+}
+
 template <class T>
 static int g64_bwd_t(nf_ctx *ctx, const nf_flow_desc *desc, const T *theta, const T *x, const T *ybar, const T *lbar,
                      double lbar_const, long N, T *xbar_out, T *gtheta_out, void *ws) {
@@ -1102,20 +1136,11 @@ static int g64_bwd_t(nf_ctx *ctx, const nf_flow_desc *desc, const T *theta, cons
   const long P = last.theta_off + last.nparams;
   NF_HIP(hipMemsetAsync(gtheta_out, 0, (size_t)P * sizeof(T), ctx->stream));
   if (N <= 0) return NF_OK;
-  const unsigned grid = (unsigned)((N + G64_BLOCK - 1) / G64_BLOCK);
   // forward, keeping the input of each coupling: execution order k = nc-1 ... 0
-  NF_HIP(hipMemsetAsync(scr_ladj, 0, (size_t)N * sizeof(T), ctx->stream));
-  const T *cur = x;
-  for (int k = nc - 1; k >= 0; --k) {
-    T *slot = inputs + (size_t)k * nd;
-    if (cur != slot) NF_HIP(hipMemcpyAsync(slot, cur, nd * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
-    if (k > 0) {
-      T *next = inputs + (size_t)(k - 1) * nd;
-      const G64Args a = make_g64_args(desc, k, N);
-      g64_launch_apply<T>(ctx, desc, grid, a, 0, theta, (const T *)slot, next, scr_ladj);
-      NF_HIP(hipGetLastError());
-      cur = next;
-    }
+  // (x == nullptr: nf_g64_apply_keep left them there -- the training step's own forward is the tape)
+  if (x) {
+    NF_HIP(hipMemsetAsync(scr_ladj, 0, (size_t)N * sizeof(T), ctx->stream));
+    NF_TRY(g64_forward_keep<T>(ctx, desc, theta, x, N, inputs, nullptr, scr_ladj));
   }
   if (xbar_out != ybar) NF_HIP(hipMemcpyAsync(xbar_out, ybar, nd * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
   for (int k = 0; k < nc; ++k) {  // reverse of execution order
