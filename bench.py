@@ -214,7 +214,8 @@ def run_once(args, world, world_observed, rank, dev, dist, damp, state):
     if damp is not None:
         theta.mul_(damp)
     lib_comm = state.get("lib_comm", False)
-    if dist is not None and args.collective == "nfhip" and os.environ.get("NF_BENCH_ONE_DEVICE") != "1" and not lib_comm:
+    if (dist is not None and args.collective == "nfhip" and os.environ.get("NF_BENCH_ONE_DEVICE") != "1" and not lib_comm
+            and not state.get("lib_comm_failed")):
         # the library's own RCCL communicator: rank 0's unique id travels through the process group
         idbuf = torch.zeros(128, dtype=torch.uint8)
         if rank == 0:
@@ -224,9 +225,22 @@ def run_once(args, world, world_observed, rank, dev, dist, damp, state):
         idbuf = idbuf.to(dev)
         dist.broadcast(idbuf, 0)
         raw = (C.c_char * 128).from_buffer_copy(idbuf.cpu().numpy().tobytes())
-        nf._lib.check(lib.nf_comm_init_rank(ctx.ptr, raw, world, rank))
-        lib_comm = True
-        state["lib_comm"] = True
+        # every rank must take the same route: if the library's communicator does not come up on ANY rank (it has never met
+        # a multi-GPU node), all ranks keep the process group's RCCL all-reduce and the output says so
+        ok = torch.ones(1, dtype=torch.int32, device=dev)
+        try:
+            nf._lib.check(lib.nf_comm_init_rank(ctx.ptr, raw, world, rank))
+        except Exception as e:  # noqa: BLE001
+            ok.zero_()
+            state["lib_comm_error"] = f"rank {rank}: {e}"
+            print(f"[bench] nf_comm_init_rank failed on rank {rank}: {e}", file=sys.stderr, flush=True)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        lib_comm = bool(int(ok.item()))
+        state["lib_comm"] = lib_comm
+        if not lib_comm:
+            state["lib_comm_failed"] = True
+            if int(lib.nf_comm_size(ctx.ptr)) > 1:
+                lib.nf_comm_destroy(ctx.ptr)
     comm_size = int(lib.nf_comm_size(ctx.ptr))
     if lib_comm and comm_size != world:
         raise SystemExit(f"library communicator has {comm_size} ranks, the process group {world}")
@@ -369,7 +383,9 @@ def run_once(args, world, world_observed, rank, dev, dist, damp, state):
                 "global_batch": n_global,
                 "params": P,
                 "parallelism": f"dp{world_observed} (sample-sharded, one all-reduce of P+1 floats per step"
-                               + (", issued by libnfhip's RCCL communicator)" if lib_comm else ", torch.distributed RCCL)" if dist is not None else ")"),
+                               + (", issued by libnfhip's RCCL communicator)" if lib_comm
+                                  else ", torch.distributed RCCL; libnfhip's communicator failed to initialise)" if state.get("lib_comm_failed")
+                                  else ", torch.distributed RCCL)" if dist is not None else ")"),
                 "nf_comm_size": comm_size,
                 "step_form": ("hipGraph replay of nf_elbo_step_enqueue" if use_graph else "nf_elbo_step (whole iteration inside the library)"
                               if fused_step else "nf_elbo_value_and_grad + nf_adam_update (split calls)"),
