@@ -821,19 +821,20 @@ static int l64_apply(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a, in
 static int l64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &a, int inv, const float *theta, const float *x, float *gbar,
                    const float *lbar, float lbar_const, float *g, float *slabs);
 template <class T>
-static void g64_launch_apply(nf_ctx *ctx, const nf_flow_desc *desc, unsigned grid, const G64Args &a, int inverse, const T *theta,
-                             const T *x, T *y, T *ladj) {
+static int g64_launch_apply(nf_ctx *ctx, const nf_flow_desc *desc, unsigned grid, const G64Args &a, int inverse, const T *theta,
+                            const T *x, T *y, T *ladj) {
   if constexpr (sizeof(T) == 4) {
     if (l64_ok(desc)) {
-      if (y != x) (void)hipMemcpyAsync(y, x, (size_t)a.N * a.d * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream);
-      (void)l64_apply(ctx, desc, a, inverse, theta, y, ladj);
-      return;
+      if (y != x) NF_HIP(hipMemcpyAsync(y, x, (size_t)a.N * a.d * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+      return l64_apply(ctx, desc, a, inverse, theta, y, ladj);  // (its scratch reservation can fail in a caller's arena)
     }
   }
   if (g64_fits<G64Small>(desc))
     hipLaunchKernelGGL((k_g64_apply<T, G64Small>), dim3(grid), dim3(G64_BLOCK), 0, ctx->stream, a, inverse, theta, x, y, ladj);
   else
     hipLaunchKernelGGL((k_g64_apply<T, G64Large>), dim3(grid), dim3(G64_BLOCK), 0, ctx->stream, a, inverse, theta, x, y, ladj);
+  NF_HIP(hipGetLastError());
+  return NF_OK;
 }
 // workgroups (= gradient slabs) of the reverse kernel: one per 64-sample tile up to a cap that keeps the slab area of
 // the largest coupling under 256 MB (a workgroup then walks several tiles, accumulating in its slab)
@@ -1075,10 +1076,9 @@ int nf_g64_apply(nf_ctx *ctx, const nf_flow_desc *desc, int layer_lo, int layer_
     const G64Args a = make_g64_args(desc, k, N);
     ProfScope ps(ctx, "g64_apply");
     if (f64)
-      g64_launch_apply<double>(ctx, desc, grid, a, inverse ? 1 : 0, (const double *)theta, (const double *)y, (double *)y, (double *)ladj);
+      NF_TRY(g64_launch_apply<double>(ctx, desc, grid, a, inverse ? 1 : 0, (const double *)theta, (const double *)y, (double *)y, (double *)ladj));
     else
-      g64_launch_apply<float>(ctx, desc, grid, a, inverse ? 1 : 0, (const float *)theta, (const float *)y, (float *)y, (float *)ladj);
-    NF_HIP(hipGetLastError());
+      NF_TRY(g64_launch_apply<float>(ctx, desc, grid, a, inverse ? 1 : 0, (const float *)theta, (const float *)y, (float *)y, (float *)ladj));
   }
   return NF_OK;
 }
@@ -1105,8 +1105,7 @@ static int g64_forward_keep(nf_ctx *ctx, const nf_flow_desc *desc, const T *thet
     if (next) {
       const G64Args a = make_g64_args(desc, k, N);
       ProfScope ps(ctx, "g64_apply");
-      g64_launch_apply<T>(ctx, desc, grid, a, 0, theta, (const T *)slot, next, ladj);
-      NF_HIP(hipGetLastError());
+      NF_TRY(g64_launch_apply<T>(ctx, desc, grid, a, 0, theta, (const T *)slot, next, ladj));
       cur = next;
     }
   }
@@ -1182,8 +1181,7 @@ static int g64_bwd_inv_t(nf_ctx *ctx, const nf_flow_desc *desc, const T *theta, 
       ProfScope ps(ctx, "g64_bwd");
       NF_TRY(g64_launch_bwd<T>(ctx, desc, k, a, 1, theta, (const T *)z, gbar, (const T *)nullptr, (T)lbar_const, gtheta_out, slabs));
     }
-    g64_launch_apply<T>(ctx, desc, grid, a, 0, theta, (const T *)z, z, scr_ladj);
-    NF_HIP(hipGetLastError());
+    NF_TRY(g64_launch_apply<T>(ctx, desc, grid, a, 0, theta, (const T *)z, z, scr_ladj));
   }
   return NF_OK;
 }
