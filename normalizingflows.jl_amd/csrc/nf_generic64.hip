@@ -817,16 +817,17 @@ static G64Args make_g64_args(const nf_flow_desc *desc, int k, long N) {
 
 // launches of the two kernels in the size class the flow fits (Float32 flows: the MLP on the matrix pipe, "l64" above)
 static bool l64_ok(const nf_flow_desc *desc);
-static int l64_apply(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a, int inverse, const float *theta, float *xy, float *ladj);
+static int l64_apply(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a, int inverse, const float *theta, float *xy, float *ladj,
+                     int slot);
 static int l64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &a, int inv, const float *theta, const float *x, float *gbar,
-                   const float *lbar, float lbar_const, float *g, float *slabs);
+                   const float *lbar, float lbar_const, float *g, float *slabs, bool kept);
 template <class T>
 static int g64_launch_apply(nf_ctx *ctx, const nf_flow_desc *desc, unsigned grid, const G64Args &a, int inverse, const T *theta,
-                            const T *x, T *y, T *ladj) {
+                            const T *x, T *y, T *ladj, int slot = 0) {
   if constexpr (sizeof(T) == 4) {
     if (l64_ok(desc)) {
       if (y != x) NF_HIP(hipMemcpyAsync(y, x, (size_t)a.N * a.d * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
-      return l64_apply(ctx, desc, a, inverse, theta, y, ladj);  // (its scratch reservation can fail in a caller's arena)
+      return l64_apply(ctx, desc, a, inverse, theta, y, ladj, slot);  // (its scratch reservation can fail in a caller's arena)
     }
   }
   if (g64_fits<G64Small>(desc))
@@ -862,9 +863,9 @@ int nf_launch_reduce_slabs(nf_ctx *, int, const void *, int, long, void *);
 // reverse kernel of coupling k (partial gradients into `slabs`) + the ordered sum of the slabs into g[theta_off ...]
 template <class T>
 static int g64_launch_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &a, int inv, const T *theta,
-                          const T *x, T *gbar, const T *lbar, T lbar_const, T *g, T *slabs) {
+                          const T *x, T *gbar, const T *lbar, T lbar_const, T *g, T *slabs, bool kept = false) {
   if constexpr (sizeof(T) == 4) {
-    if (l64_ok(desc)) return l64_bwd(ctx, desc, k, a, inv, theta, x, gbar, lbar, lbar_const, g, slabs);
+    if (l64_ok(desc)) return l64_bwd(ctx, desc, k, a, inv, theta, x, gbar, lbar, lbar_const, g, slabs, kept);
   }
   const CouplingInfo ci = nf_coupling_info(desc, k);
   const unsigned grid = g64_bwd_blocks(desc, a.N);
@@ -896,18 +897,25 @@ static int l64_gh_rows(const nf_flow_desc *desc) {  // rows of the two hidden-co
   for (int i = 0; i < desc->n_hidden; ++i) m = desc->hdims[i] > m ? desc->hdims[i] : m;
   return l64_pad32(m);
 }
-// scratch floats per sample of ONE coupling call: per net the stashed layer outputs, the output cotangent; two hidden
-// cotangent buffers
-static size_t l64_floats_per_sample(const nf_flow_desc *desc) {
+// scratch floats per sample: per COUPLING the nets' stashed layer outputs (a reverse pass that follows a kept forward --
+// g64_forward_keep -- reads them back instead of evaluating the nets again, so every coupling has its own slot); shared by
+// all couplings: the output cotangents per net and two hidden cotangent buffers
+static size_t l64_act_floats_per_sample(const nf_flow_desc *desc) {
   const int c = (desc->d + 1) / 2;
   const int nout = desc->kind == NF_KIND_REALNVP ? c : (3 * desc->K - 1) * c;
-  size_t per_net = 2 * (size_t)l64_pad32(nout);
+  size_t per_net = (size_t)l64_pad32(nout);
   for (int i = 0; i < desc->n_hidden; ++i) per_net += l64_pad32(desc->hdims[i]);
-  return (desc->kind == NF_KIND_REALNVP ? 2 : 1) * per_net + 2 * (size_t)l64_gh_rows(desc);
+  return (desc->kind == NF_KIND_REALNVP ? 2 : 1) * per_net;
+}
+static size_t l64_shared_floats_per_sample(const nf_flow_desc *desc) {
+  const int c = (desc->d + 1) / 2;
+  const int nout = desc->kind == NF_KIND_REALNVP ? c : (3 * desc->K - 1) * c;
+  return (desc->kind == NF_KIND_REALNVP ? 2 : 1) * (size_t)l64_pad32(nout) + 2 * (size_t)l64_gh_rows(desc);
 }
 size_t nf_l64_scratch_bytes(const nf_flow_desc *desc, long N) {
   if (!l64_ok(desc)) return 0;
-  return ((size_t)((N + 31) / 32) * 32 * l64_floats_per_sample(desc) * sizeof(float) + 255) / 256 * 256;
+  const size_t per = (size_t)2 * desc->nlayers * l64_act_floats_per_sample(desc) + l64_shared_floats_per_sample(desc);
+  return ((size_t)((N + 31) / 32) * 32 * per * sizeof(float) + 255) / 256 * 256;
 }
 struct L64Bufs {
   float *act[2][NF_MAX_HIDDEN + 1];  // [net][layer]: tiled outputs (the last one: the net's output)
@@ -915,18 +923,21 @@ struct L64Bufs {
   float *dout[2], *gh[2];            // output cotangents per net; two hidden cotangent buffers of GH rows
   int nets, nl, GH;
 };
-static int l64_bufs(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a, L64Bufs *b) {
+// slot: the coupling whose activation area the call uses (flat index; stand-alone calls use any, they do not look back)
+static int l64_bufs(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a, L64Bufs *b, int slot) {
   NF_TRY(nf_wimg_reserve(ctx, nf_l64_scratch_bytes(desc, a.N)));
   ctx->wimg_owner = nullptr;  // the buffer doubles as the fused kernels' packed-image store: whatever it cached is gone
   const size_t Np = (size_t)((a.N + 31) / 32) * 32;
+  const int nc = 2 * desc->nlayers;
   b->nets = desc->kind == NF_KIND_REALNVP ? 2 : 1;
   b->nl = a.net[0].nl;
-  float *p = (float *)ctx->wimg;
+  const size_t actf = l64_act_floats_per_sample(desc);
+  float *p = (float *)ctx->wimg + (size_t)(slot < 0 || slot >= nc ? 0 : slot) * Np * actf;
   for (int l = 0; l < b->nl; ++l) b->F[l] = l64_pad32(a.net[0].dims[l + 1]);
-  for (int n = 0; n < b->nets; ++n) {
+  for (int n = 0; n < b->nets; ++n)
     for (int l = 0; l < b->nl; ++l) { b->act[n][l] = p; p += Np * b->F[l]; }
-    b->dout[n] = p; p += Np * b->F[b->nl - 1];
-  }
+  p = (float *)ctx->wimg + (size_t)nc * Np * actf;
+  for (int n = 0; n < b->nets; ++n) { b->dout[n] = p; p += Np * b->F[b->nl - 1]; }
   b->GH = l64_gh_rows(desc);
   b->gh[0] = p; p += Np * b->GH;
   b->gh[1] = p;
@@ -977,9 +988,10 @@ static int l64_nets_fwd(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a,
   }
   return NF_OK;
 }
-static int l64_apply(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a, int inverse, const float *theta, float *xy, float *ladj) {
+static int l64_apply(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a, int inverse, const float *theta, float *xy, float *ladj,
+                     int slot) {
   L64Bufs b;
-  NF_TRY(l64_bufs(ctx, desc, a, &b));
+  NF_TRY(l64_bufs(ctx, desc, a, &b, slot));
   NF_TRY(l64_nets_fwd(ctx, desc, a, theta, xy, b));
   ProfScope ps(ctx, "l64_couple");
   const int last = b.nl - 1;
@@ -1002,11 +1014,12 @@ static int l64_dw_launch(nf_ctx *ctx, unsigned grid, const L64Layer &L, const L6
 // reverse pass of coupling k at x (forward: its input; inv: the inverse's output): gbar updated in place, this coupling's
 // parameter gradient in g[theta_off ...] through per-workgroup slabs
 static int l64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &a, int inv, const float *theta, const float *x, float *gbar,
-                   const float *lbar, float lbar_const, float *g, float *slabs) {
+                   const float *lbar, float lbar_const, float *g, float *slabs, bool kept) {
   const CouplingInfo ci = nf_coupling_info(desc, k);
   L64Bufs b;
-  NF_TRY(l64_bufs(ctx, desc, a, &b));
-  NF_TRY(l64_nets_fwd(ctx, desc, a, theta, x, b));
+  NF_TRY(l64_bufs(ctx, desc, a, &b, k));
+  // kept: the forward of this very pass (g64_forward_keep) left this coupling's layer outputs in its slot
+  if (!kept) NF_TRY(l64_nets_fwd(ctx, desc, a, theta, x, b));
   const int last = b.nl - 1;
   {
     ProfScope ps(ctx, "l64_couple");
@@ -1105,7 +1118,7 @@ static int g64_forward_keep(nf_ctx *ctx, const nf_flow_desc *desc, const T *thet
     if (next) {
       const G64Args a = make_g64_args(desc, k, N);
       ProfScope ps(ctx, "g64_apply");
-      NF_TRY(g64_launch_apply<T>(ctx, desc, grid, a, 0, theta, (const T *)slot, next, ladj));
+      NF_TRY(g64_launch_apply<T>(ctx, desc, grid, a, 0, theta, (const T *)slot, next, ladj, k));
       cur = next;
     }
   }
@@ -1145,7 +1158,9 @@ static int g64_bwd_t(nf_ctx *ctx, const nf_flow_desc *desc, const T *theta, cons
   for (int k = 0; k < nc; ++k) {  // reverse of execution order
     const G64Args a = make_g64_args(desc, k, N);
     ProfScope ps(ctx, "g64_bwd");
-    NF_TRY(g64_launch_bwd<T>(ctx, desc, k, a, 0, theta, (const T *)(inputs + (size_t)k * nd), xbar_out, lbar, (T)lbar_const, gtheta_out, slabs));
+    // the forward above (or nf_g64_apply_keep) evaluated coupling k's nets unless it stopped short of the last coupling
+    const bool kept = k > 0 || x == nullptr;
+    NF_TRY(g64_launch_bwd<T>(ctx, desc, k, a, 0, theta, (const T *)(inputs + (size_t)k * nd), xbar_out, lbar, (T)lbar_const, gtheta_out, slabs, kept));
   }
   return NF_OK;
 }
