@@ -52,6 +52,17 @@ __device__ __forceinline__ void nf_lrelu16(f32x16 &a) {
   }
 }
 
+// sum of 16 values as a balanced tree: the same 15 additions as a running sum, with error growing with log n instead
+// of n (the log-det of a wide coupling is a sum of 128 values of both signs)
+__device__ __forceinline__ float nf_tree_sum16(const float (&v)[16]) {
+  float a[8], b[4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = v[2 * i] + v[2 * i + 1];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) b[i] = a[2 * i] + a[2 * i + 1];
+  return (b[0] + b[1]) + (b[2] + b[3]);
+}
+
 // tanh / exp for the coupling's scale branch (s = tanh(.), exp(+-s); src/flows/realnvp.jl:50,79).
 // Hardware exp2-based forms: absolute error of tanh < 1e-7 (the reference itself runs NNlib's
 // rational tanh_fast, a few ulp from libm), relative error of exp ~1 ulp -- far inside the

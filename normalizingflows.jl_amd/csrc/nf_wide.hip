@@ -392,17 +392,24 @@ __global__ __launch_bounds__(256, 1) void k_wide_apply(WideArgs a, float *xt, fl
       wide_net_fwd<G>(img_t, bias + W::NBIAS, cb, buf, img_s, G::W1, more ? W::CF1 : 0, xb, T, wave, lane, hk);
       if (STASH) stash_store<G::CB>(make_stash_io(fs.out[1], tl, live ? 32 * G::CB : 0, l31, hi), T);
     }
-    float lsum = 0.f;
+    float lpart[G::CB];
 #pragma unroll
-    for (int b = 0; b < G::CB; ++b)
+    for (int b = 0; b < G::CB; ++b) {
+      float sv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float s = nf_tanh(S[b][r]);  // padded rows: zero weights and bias => s = 0
         const float v = x1[b][r];
         const float o = INVERSE ? nf_fdiv(v - T[b][r], nf_exp(s)) : v * nf_exp(s) + T[b][r];
         if (live) tile_store(io, tile_soff(b, r, a.par_t), o);  // rows >= c fall outside the descriptor
-        lsum += s;
+        sv[r] = s;
       }
+      lpart[b] = nf_tree_sum16(sv);
+    }
+    float lsum = lpart[0];
+    if (G::CB == 2) lsum = lpart[0] + lpart[1];
+    if (G::CB == 4) lsum = (lpart[0] + lpart[1]) + (lpart[2] + lpart[3]);
+    static_assert(G::CB == 1 || G::CB == 2 || G::CB == 4, "log-det tree");
     lsum += __shfl_xor(lsum, 32);
     if (hi == 0 && valid) {
       const float base = accumulate ? ladj[j] : 0.f;
