@@ -1,9 +1,11 @@
 // nf_common.h -- context, status handling and launch helpers shared by the
 // translation units of libnfhip.so (gfx950 only).
 #pragma once
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -92,10 +94,39 @@ inline size_t carve_bytes(size_t nbytes) { return ((nbytes + 255) / 256) * 256; 
 // profiling bracket: records a pair of pooled HIP events on ctx->stream around a launch.
 // prof_mode 1 brackets only the dominant kernel ("affine_bwd" / "rqs_bwd" / "wide_bwd"), 2 brackets all,
 // 3 brackets every 4th launch of the dominant kernel (lowest perturbation of a timed region).
+// roctx ranges around the library's launch sites (tracing): with NF_ROCTX=1 in the environment every
+// ProfScope pushes / pops a named range, which `rocprofv3 --marker-trace --kernel-trace` shows next to the kernels.  The
+// marker library is bound at run time (as librccl is in nf_comm.hip): no link-time dependency, nothing happens without it.
+struct NfRoctx {
+  int (*push)(const char *) = nullptr;
+  int (*pop)() = nullptr;
+};
+inline const NfRoctx &nf_roctx() {
+  static const NfRoctx r = [] {
+    NfRoctx x;
+    if (!std::getenv("NF_ROCTX")) return x;
+    for (const char *name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+      void *h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (!h) continue;
+      x.push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+      x.pop = (int (*)())dlsym(h, "roctxRangePop");
+      if (x.push && x.pop) break;
+      x = NfRoctx();
+    }
+    return x;
+  }();
+  return r;
+}
+
 struct ProfScope {
   nf_ctx *ctx;
   hipEvent_t b = nullptr;
+  bool ranged = false;
   ProfScope(nf_ctx *c, const char *name) : ctx(c) {
+    if (nf_roctx().push) {
+      nf_roctx().push(name);
+      ranged = true;
+    }
     if (!ctx->prof_mode) return;
     if (ctx->prof_mode != 2) {
       if (std::strcmp(name, "affine_bwd") != 0 && std::strcmp(name, "rqs_bwd") != 0 && std::strcmp(name, "wide_bwd") != 0)
@@ -110,6 +141,7 @@ struct ProfScope {
   }
   ~ProfScope() {
     if (b) hipEventRecord(b, ctx->stream);
+    if (ranged) nf_roctx().pop();
   }
 };
 
