@@ -40,6 +40,20 @@ def test_bench_launcher_starts_the_ranks_itself():
     assert two["config"]["final_loss"] == pytest.approx(one["config"]["final_loss"], rel=1e-5)
 
 
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs on the node (the pool's test boxes have one)")
+def test_two_real_gpus_run_the_librarys_own_rccl_all_reduce():
+    """On a node with >= 2 GPUs: `bench.py --gpus 2` must bring up libnfhip's communicator over RCCL (not fall back to the
+    process group's all-reduce), run the whole iteration inside nf_elbo_step, and reproduce the 1-rank loss at the same
+    global batch (the shards' draws are the same global Philox columns; the all-reduce only changes the summation order)."""
+    common = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-kernel-events"]
+    two = _bench(["--gpus", "2", "--batch", "2048"] + common)
+    assert two["n_gpus"] == 2 and two["config"]["nf_comm_size"] == 2
+    assert "libnfhip's RCCL communicator)" in two["config"]["parallelism"], two["config"]["parallelism"]
+    assert two["config"]["step_form"].startswith("nf_elbo_step")
+    one = _bench(["--gpus", "1", "--batch", "4096"] + common)
+    assert two["config"]["final_loss"] == pytest.approx(one["config"]["final_loss"], rel=1e-5)
+
+
 def test_bench_refuses_a_world_size_that_is_not_gpus():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
