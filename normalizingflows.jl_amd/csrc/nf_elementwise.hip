@@ -355,6 +355,40 @@ __global__ __launch_bounds__(EW_BLOCK) void k_reduce_slabs(const T *__restrict__
   g[p] = (a0 + a1) + (a2 + a3);
 }
 
+// Many slabs, few parameters (the general couplings' per-coupling sums: 1 024 slabs x 29 k floats): one thread per
+// parameter is a chain of nslab dependent-latency loads on a third of the chip.  Here a block takes RS_PW parameters and
+// splits the slab range over RS_PARTS thread rows -- each row the same four-accumulator walk over its contiguous share --
+// and the rows are added in a fixed tree: the order depends on (nslab, P) only, so the sum stays reproducible.
+#define RS_PW 32
+#define RS_PARTS 8
+template <class T>
+__global__ __launch_bounds__(RS_PW * RS_PARTS) void k_reduce_slabs_split(const T *__restrict__ slab, int nslab, long P,
+                                                                         T *__restrict__ g) {
+  __shared__ T part[RS_PARTS][RS_PW];
+  const int col = threadIdx.x % RS_PW, row = threadIdx.x / RS_PW;
+  const long p = (long)blockIdx.x * RS_PW + col;
+  const int per = (nslab + RS_PARTS - 1) / RS_PARTS;
+  const int s0 = row * per, s1 = s0 + per < nslab ? s0 + per : nslab;
+  T a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  if (p < P) {
+    int s = s0;
+    for (; s + 3 < s1; s += 4) {
+      a0 += slab[(long)s * P + p];
+      a1 += slab[(long)(s + 1) * P + p];
+      a2 += slab[(long)(s + 2) * P + p];
+      a3 += slab[(long)(s + 3) * P + p];
+    }
+    for (; s < s1; ++s) a0 += slab[(long)s * P + p];
+  }
+  part[row][col] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (row == 0 && p < P) {
+    static_assert(RS_PARTS == 8, "fixed tree");
+    g[p] = ((part[0][col] + part[1][col]) + (part[2][col] + part[3][col])) +
+           ((part[4][col] + part[5][col]) + (part[6][col] + part[7][col]));
+  }
+}
+
 // Optimisers.Adam (Optimisers.jl 0.4 `apply!`): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // theta -= lr * (m / (1 - b1^t)) / (sqrt(v / (1 - b2^t)) + eps).  Also block partials of g^2
 // for gradient_norm (src/optimize.jl:89).
@@ -666,6 +700,16 @@ int nf_launch_finish_sum(nf_ctx *ctx, const double *partial, long n, int take_sq
 
 int nf_launch_reduce_slabs(nf_ctx *ctx, int dtype, const void *slab, int nslab, long P, void *g) {
   ProfScope ps(ctx, "reduce_slabs");
+  if (nslab >= 64 && P < (long)ctx->num_cu * 1024) {  // one thread per parameter would leave most of the chip idle
+    const unsigned grid = (unsigned)nblk(P, RS_PW);
+    if (dtype == NF_DTYPE_F32)
+      hipLaunchKernelGGL(k_reduce_slabs_split<float>, dim3(grid), dim3(RS_PW * RS_PARTS), 0, ctx->stream, (const float *)slab, nslab, P,
+                         (float *)g);
+    else
+      hipLaunchKernelGGL(k_reduce_slabs_split<double>, dim3(grid), dim3(RS_PW * RS_PARTS), 0, ctx->stream, (const double *)slab, nslab,
+                         P, (double *)g);
+    return (int)hipGetLastError();
+  }
   if (dtype == NF_DTYPE_F32)
     hipLaunchKernelGGL(k_reduce_slabs<float>, dim3(nblk(P, EW_BLOCK)), dim3(EW_BLOCK), 0, ctx->stream,
                        (const float *)slab, nslab, P, (float *)g);
