@@ -536,11 +536,14 @@ __global__ __launch_bounds__(256) void k_l64_dw(L64Layer L, L64Src a, L64Src g, 
 __device__ __forceinline__ float l64_out(const float *__restrict__ buf, int F, long j, int row) {
   return buf[(((j >> 5) * F + row) << 5) + (j & 31)];
 }
-// ---- the spline of one (dimension, sample) without per-thread arrays ---------------------------------------------------
+// ---- the spline of one (dimension, sample) in registers ---------------------------------------------------------------
 // g64_build / g64_spline_* keep knots, softmax terms and cotangents in arrays indexed by the (run-time) bin: with K a
-// run-time value those live in scratch memory (544 / 736 bytes per thread, every access a memory operation).  The tiles
-// make a cheaper form possible: the 3K - 1 raw parameters of a dimension are K rows apart in L1-resident memory, so the
-// softmax statistics, the walk to the bin and the cotangents are PASSES over those rows with a handful of scalars each.
+// run-time value those live in scratch memory (544 / 736 bytes per thread, every access a memory operation).  Here the
+// 3K - 1 raw parameters of a dimension (K rows apart in the tile) are loaded ONCE into arrays of a compile-time size
+// KM >= K and every loop over bins is unrolled to KM with wave-uniform `i < K` guards: all indexing is static, so the
+// arrays are registers, the loads of a pass are issued together, and nothing is read twice.  (The first form of round 3
+// walked the rows in run-time loops, a load -> use chain per bin and pass: 127 / 262 us per coupling at the docstring
+// shape.)  The bin itself stays a run-time value, compared against the unrolled index.
 // Same formulas as above (MonotonicSplines 0.3.3 as restated in oracle/nf_oracle.py); sm_i = exp(v_i - max) / sum.
 struct L64Bin {
   int k;            // bin, -1: outside [-B, B)
@@ -551,42 +554,66 @@ struct L64Raw {
   const float *base;  // tile base of this (tile, dimension): element i at base[i * 32] (row stride of the tile)
   __device__ __forceinline__ float operator()(int i) const { return base[(long)i << 5]; }
 };
-__device__ __forceinline__ void l64_softmax_stats(const L64Raw &raw, int off, int K, float &mx, float &inv) {
-  mx = raw(off);
-  for (int i = 1; i < K; ++i) mx = fmaxf(mx, raw(off + i));
+template <int KM>
+struct L64Par {
+  float w[KM], h[KM], dv[KM];  // widths, heights, interior derivatives (K - 1 of them) as the net wrote them
+};
+template <int KM>
+__device__ __forceinline__ void l64_load_par(const L64Raw &raw, int K, L64Par<KM> &q) {
+#pragma unroll
+  for (int i = 0; i < KM; ++i) {
+    q.w[i] = i < K ? raw(i) : 0.f;
+    q.h[i] = i < K ? raw(K + i) : 0.f;
+    q.dv[i] = i < K - 1 ? raw(2 * K + i) : 0.f;
+  }
+}
+template <int KM>
+__device__ __forceinline__ void l64_softmax_stats(const float (&v)[KM], int K, float &mx, float &inv) {
+  mx = v[0];
+#pragma unroll
+  for (int i = 1; i < KM; ++i)
+    if (i < K) mx = fmaxf(mx, v[i]);
   float sum = 0.f;
-  for (int i = 0; i < K; ++i) sum += expf(raw(off + i) - mx);
+#pragma unroll
+  for (int i = 0; i < KM; ++i)
+    if (i < K) sum += expf(v[i] - mx);
   inv = 1.f / sum;
 }
 // the bin of v among the knots p[j] = -B + 2B cumsum(sm)[j] (g64_bin: the count of interior knots <= v)
-__device__ __forceinline__ L64Bin l64_find(const L64Raw &raw, int off, int K, float B, float mx, float inv, float v) {
+template <int KM>
+__device__ __forceinline__ L64Bin l64_find(const float (&r)[KM], int K, float B, float mx, float inv, float v) {
   L64Bin b{-1, 0.f, 0.f, 0.f};
   float cs = 0.f, left = -B;
   int k = 0;
   float x0 = -B, x1 = -B, smk = 0.f, pK = -B;
-  for (int i = 0; i < K; ++i) {
-    const float sm = expf(raw(off + i) - mx) * inv;
-    cs += sm;
-    const float right = -B + 2.f * B * cs;
-    // bin i holds v when i is the number of interior knots (p[1] .. p[K-1]) that are <= v
-    const bool take = (i == 0 || v >= left) && (i == K - 1 || !(v >= right));
-    if (take) { k = i; x0 = left; x1 = right; smk = sm; }
-    left = right;
-    pK = right;
-  }
+#pragma unroll
+  for (int i = 0; i < KM; ++i)
+    if (i < K) {
+      const float sm = expf(r[i] - mx) * inv;
+      cs += sm;
+      const float right = -B + 2.f * B * cs;
+      // bin i holds v when i is the number of interior knots (p[1] .. p[K-1]) that are <= v
+      const bool take = (i == 0 || v >= left) && (i == K - 1 || !(v >= right));
+      if (take) { k = i; x0 = left; x1 = right; smk = sm; }
+      left = right;
+      pK = right;
+    }
   if (v >= -B && v < pK) { b.k = k; b.x0 = x0; b.x1 = x1; b.sm = smk; }
   return b;
 }
 // knots k, k + 1 of the OTHER axis for a known bin
-__device__ __forceinline__ void l64_knots_at(const L64Raw &raw, int off, int K, float B, float mx, float inv, int k, float &y0, float &y1,
+template <int KM>
+__device__ __forceinline__ void l64_knots_at(const float (&r)[KM], int K, float B, float mx, float inv, int k, float &y0, float &y1,
                                              float &smk) {
   float cs = 0.f;
   y0 = -B; y1 = -B; smk = 0.f;
-  for (int i = 0; i <= k; ++i) {
-    const float sm = expf(raw(off + i) - mx) * inv;
-    if (i == k) { y0 = -B + 2.f * B * cs; smk = sm; }
-    cs += sm;
-  }
+#pragma unroll
+  for (int i = 0; i < KM; ++i)
+    if (i < K) {
+      const float sm = expf(r[i] - mx) * inv;
+      if (i == k) { y0 = -B + 2.f * B * cs; smk = sm; }
+      if (i <= k) cs += sm;
+    }
   y1 = -B + 2.f * B * cs;
 }
 __device__ __forceinline__ float l64_softplus(float x) { return log1pf(expf(-fabsf(x))) + fmaxf(x, 0.f); }
@@ -594,33 +621,48 @@ __device__ __forceinline__ float l64_sigmoid(float x) {
   const float e = expf(-fabsf(x));
   return x >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
 }
+// raw interior derivatives number k - 1 and k (the bin's two ends; whichever exists)
+template <int KM>
+__device__ __forceinline__ void l64_dv_at(const float (&dv)[KM], int k, float &r0, float &r1) {
+  r0 = 0.f; r1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < KM; ++i) {
+    if (i == k - 1) r0 = dv[i];
+    if (i == k) r1 = dv[i];
+  }
+}
 // forward / inverse of one dimension; logd accumulates log S'(x) (forward) or -log S'(x) (inverse)
+template <int KM>
 __device__ __forceinline__ float l64_spline_apply(const L64Raw &raw, int K, float B, float v, bool inverse, float &logd) {
+  L64Par<KM> q;
+  l64_load_par<KM>(raw, K, q);
   float mxw, invw, mxh, invh;
-  l64_softmax_stats(raw, 0, K, mxw, invw);
-  l64_softmax_stats(raw, K, K, mxh, invh);
+  l64_softmax_stats<KM>(q.w, K, mxw, invw);
+  l64_softmax_stats<KM>(q.h, K, mxh, invh);
   float x0, x1, y0, y1, dummy;
   int k;
   if (!inverse) {
-    const L64Bin b = l64_find(raw, 0, K, B, mxw, invw, v);
+    const L64Bin b = l64_find<KM>(q.w, K, B, mxw, invw, v);
     if (b.k < 0) return v;
     k = b.k; x0 = b.x0; x1 = b.x1;
-    l64_knots_at(raw, K, K, B, mxh, invh, k, y0, y1, dummy);
+    l64_knots_at<KM>(q.h, K, B, mxh, invh, k, y0, y1, dummy);
   } else {
-    const L64Bin b = l64_find(raw, K, K, B, mxh, invh, v);
+    const L64Bin b = l64_find<KM>(q.h, K, B, mxh, invh, v);
     if (b.k < 0) return v;
     k = b.k; y0 = b.x0; y1 = b.x1;
-    l64_knots_at(raw, 0, K, B, mxw, invw, k, x0, x1, dummy);
+    l64_knots_at<KM>(q.w, K, B, mxw, invw, k, x0, x1, dummy);
   }
-  const float d0 = k >= 1 ? l64_softplus(raw(2 * K + k - 1)) : 1.f, d1 = k + 1 <= K - 1 ? l64_softplus(raw(2 * K + k)) : 1.f;
+  float r0, r1;
+  l64_dv_at<KM>(q.dv, k, r0, r1);
+  const float d0 = k >= 1 ? l64_softplus(r0) : 1.f, d1 = k + 1 <= K - 1 ? l64_softplus(r1) : 1.f;
   const float dx = x1 - x0, dy = y1 - y0, sl = dy / dx;
   if (!inverse) {
     const float xi = (v - x0) / dx, om = 1.f - xi, den = sl + (d1 + d0 - 2.f * sl) * xi * om;
     logd += g64_logderiv(sl, d0, d1, xi);
     return y0 + dy * (sl * xi * xi + d0 * xi * om) / den;
   }
-  const float yy = v - y0, q = d1 + d0 - 2.f * sl;
-  const float aa = dy * (sl - d0) + yy * q, bb = dy * d0 - yy * q, cc = -sl * yy;
+  const float yy = v - y0, qq = d1 + d0 - 2.f * sl;
+  const float aa = dy * (sl - d0) + yy * qq, bb = dy * d0 - yy * qq, cc = -sl * yy;
   const float disc = fmaxf(bb * bb - 4.f * aa * cc, 0.f);
   const float xi = 2.f * cc / (-bb - sqrtf(disc));
   logd -= g64_logderiv(sl, d0, d1, xi);
@@ -628,26 +670,34 @@ __device__ __forceinline__ float l64_spline_apply(const L64Raw &raw, int K, floa
 }
 // reverse pass at x (g64_spline_bwd's algebra); writes the 3K - 1 parameter cotangents to out (tile rows, stride 32) and
 // returns xbar (inv: the cotangent of the inverse's input, see g64_spline_bwd)
+template <int KM>
 __device__ __forceinline__ float l64_spline_bwd(const L64Raw &raw, float *__restrict__ out, int K, float B, float x, float ybar, float lbar,
                                                 bool inv) {
-  const int P = 3 * K - 1;
+  L64Par<KM> q;
+  l64_load_par<KM>(raw, K, q);
   float mxw, invw, mxh, invh;
-  l64_softmax_stats(raw, 0, K, mxw, invw);
-  l64_softmax_stats(raw, K, K, mxh, invh);
-  const L64Bin b = l64_find(raw, 0, K, B, mxw, invw, x);
+  l64_softmax_stats<KM>(q.w, K, mxw, invw);
+  l64_softmax_stats<KM>(q.h, K, mxh, invh);
+  const L64Bin b = l64_find<KM>(q.w, K, B, mxw, invw, x);
   if (b.k < 0) {
-    for (int i = 0; i < P; ++i) out[(long)i << 5] = 0.f;
+#pragma unroll
+    for (int i = 0; i < KM; ++i) {
+      if (i < K) { out[(long)i << 5] = 0.f; out[(long)(K + i) << 5] = 0.f; }
+      if (i < K - 1) out[(long)(2 * K + i) << 5] = 0.f;
+    }
     return ybar;
   }
   const int k = b.k;
   float y0, y1, smh_k;
-  l64_knots_at(raw, K, K, B, mxh, invh, k, y0, y1, smh_k);
-  const float d0 = k >= 1 ? l64_softplus(raw(2 * K + k - 1)) : 1.f, d1 = k + 1 <= K - 1 ? l64_softplus(raw(2 * K + k)) : 1.f;
+  l64_knots_at<KM>(q.h, K, B, mxh, invh, k, y0, y1, smh_k);
+  float r0, r1;
+  l64_dv_at<KM>(q.dv, k, r0, r1);
+  const float d0 = k >= 1 ? l64_softplus(r0) : 1.f, d1 = k + 1 <= K - 1 ? l64_softplus(r1) : 1.f;
   const float dx = b.x1 - b.x0, dy = y1 - y0;
-  const float s = dy / dx, xi = (x - b.x0) / dx, om = 1.f - xi, q = d1 + d0 - 2.f * s;
-  const float den = s + q * xi * om, num = s * xi * xi + d0 * xi * om;
+  const float s = dy / dx, xi = (x - b.x0) / dx, om = 1.f - xi, qd = d1 + d0 - 2.f * s;
+  const float den = s + qd * xi * om, num = s * xi * xi + d0 * xi * om;
   const float nd = d1 * xi * xi + 2.f * s * xi * om + d0 * om * om;
-  const float dnum_dxi = 2.f * s * xi + d0 * (1.f - 2.f * xi), dden_dxi = q * (1.f - 2.f * xi);
+  const float dnum_dxi = 2.f * s * xi + d0 * (1.f - 2.f * xi), dden_dxi = qd * (1.f - 2.f * xi);
   const float dnd_dxi = 2.f * d1 * xi + 2.f * s * (1.f - 2.f * xi) - 2.f * d0 * om;
   const float dy_dxi = dy * (dnum_dxi * den - num * dden_dxi) / (den * den);
   const float dL_dxi = dnd_dxi / nd - 2.f * dden_dxi / den;
@@ -670,17 +720,21 @@ __device__ __forceinline__ float l64_spline_bwd(const L64Raw &raw, float *__rest
   // sbw_i = 2B (i < k ? xkbar + xk1bar : i == k ? xk1bar : 0);  dotw = sum_i sbw_i sm_i with sum_{i<k} sm_i = (p[k] + B) / 2B
   const float aw = 2.f * B * (xkbar + xk1bar), bw = 2.f * B * xk1bar, ah = 2.f * B * (ykbar + yk1bar), bh = 2.f * B * yk1bar;
   const float dotw = aw * (b.x0 + B) / (2.f * B) + bw * b.sm, doth = ah * (y0 + B) / (2.f * B) + bh * smh_k;
-  for (int i = 0; i < K; ++i) {
-    const float smw = expf(raw(i) - mxw) * invw, smh = expf(raw(K + i) - mxh) * invh;
-    out[(long)i << 5] = smw * ((i < k ? aw : i == k ? bw : 0.f) - dotw);
-    out[(long)(K + i) << 5] = smh * ((i < k ? ah : i == k ? bh : 0.f) - doth);
-  }
-  for (int i = 0; i < K - 1; ++i) {
-    float t = 0.f;
-    if (i == k - 1) t = d0bar * l64_sigmoid(raw(2 * K + i));
-    if (i == k) t = d1bar * l64_sigmoid(raw(2 * K + i));
-    out[(long)(2 * K + i) << 5] = t;
-  }
+#pragma unroll
+  for (int i = 0; i < KM; ++i)
+    if (i < K) {
+      const float smw = expf(q.w[i] - mxw) * invw, smh = expf(q.h[i] - mxh) * invh;
+      out[(long)i << 5] = smw * ((i < k ? aw : i == k ? bw : 0.f) - dotw);
+      out[(long)(K + i) << 5] = smh * ((i < k ? ah : i == k ? bh : 0.f) - doth);
+    }
+#pragma unroll
+  for (int i = 0; i < KM; ++i)
+    if (i < K - 1) {
+      float t = 0.f;
+      if (i == k - 1) t = d0bar * l64_sigmoid(q.dv[i]);
+      if (i == k) t = d1bar * l64_sigmoid(q.dv[i]);
+      out[(long)(2 * K + i) << 5] = t;
+    }
   return inv ? vbar : xibar / dx;
 }
 
@@ -689,6 +743,7 @@ __device__ __forceinline__ float l64_spline_bwd(const L64Raw &raw, float *__rest
 // per SAMPLE, as in k_g64_apply, leaves 16 of them in a row on a thread and the chip a quarter full at N = 131 072 --
 // 516 + 788 us per coupling against 120 us of MFMA layers).  The log-det terms are added over the 8 lanes in a fixed order.
 #define L64_DL 8
+template <int KM>
 __global__ __launch_bounds__(256) void k_l64_couple_fwd(G64Args a, int inverse, const float *__restrict__ os, int Fs,
                                                         const float *__restrict__ ot, int Ft, float *xy, float *__restrict__ ladj) {
   __shared__ float part[L64_DL][32];
@@ -709,7 +764,7 @@ __global__ __launch_bounds__(256) void k_l64_couple_fwd(G64Args a, int inverse, 
       for (int p = dl; p < a.c; p += L64_DL) {
         const L64Raw raw{os + ((((j >> 5) * Fs + (long)p * P) << 5) + (j & 31))};
         const float v = r[2 * p + a.par_t];
-        r[2 * p + a.par_t] = l64_spline_apply(raw, a.K, (float)a.B, v, inverse != 0, lsum);
+        r[2 * p + a.par_t] = l64_spline_apply<KM>(raw, a.K, (float)a.B, v, inverse != 0, lsum);
       }
     }
   }
@@ -724,6 +779,7 @@ __global__ __launch_bounds__(256) void k_l64_couple_fwd(G64Args a, int inverse, 
 }
 // x: the coupling's input (inv: the point the inverse is differentiated at); gbar: ybar -> cotangent of the transformed half;
 // ds / dt <- cotangents of the nets' outputs (tiles)
+template <int KM>
 __global__ __launch_bounds__(256) void k_l64_couple_bwd(G64Args a, int inv, const float *__restrict__ os, int Fs, const float *__restrict__ x,
                                                         float *gbar, const float *__restrict__ lbar, float lbar_const,
                                                         float *__restrict__ ds, float *__restrict__ dt, int Ft) {
@@ -761,7 +817,7 @@ __global__ __launch_bounds__(256) void k_l64_couple_bwd(G64Args a, int inv, cons
     for (int p = dl; p < a.c; p += L64_DL) {
       const long e0 = (((j >> 5) * Fs + (long)p * P) << 5) + (j & 31);
       const L64Raw raw{os + e0};
-      gr[2 * p + a.par_t] = l64_spline_bwd(raw, ds + e0, a.K, (float)a.B, xr[2 * p + a.par_t], gr[2 * p + a.par_t], lb, inv != 0);
+      gr[2 * p + a.par_t] = l64_spline_bwd<KM>(raw, ds + e0, a.K, (float)a.B, xr[2 * p + a.par_t], gr[2 * p + a.par_t], lb, inv != 0);
     }
   }
 }
@@ -995,8 +1051,12 @@ static int l64_apply(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a, in
   NF_TRY(l64_nets_fwd(ctx, desc, a, theta, xy, b));
   ProfScope ps(ctx, "l64_couple");
   const int last = b.nl - 1;
-  hipLaunchKernelGGL(k_l64_couple_fwd, dim3((unsigned)((a.N + 31) / 32)), dim3(256), 0, ctx->stream, a, inverse, (const float *)b.act[0][last],
-                     b.F[last], (const float *)b.act[b.nets - 1][last], b.F[last], xy, ladj);
+  if (a.K <= 8)
+    hipLaunchKernelGGL(k_l64_couple_fwd<8>, dim3((unsigned)((a.N + 31) / 32)), dim3(256), 0, ctx->stream, a, inverse,
+                       (const float *)b.act[0][last], b.F[last], (const float *)b.act[b.nets - 1][last], b.F[last], xy, ladj);
+  else
+    hipLaunchKernelGGL(k_l64_couple_fwd<G64_MAXK>, dim3((unsigned)((a.N + 31) / 32)), dim3(256), 0, ctx->stream, a, inverse,
+                       (const float *)b.act[0][last], b.F[last], (const float *)b.act[b.nets - 1][last], b.F[last], xy, ladj);
   return (int)hipGetLastError();
 }
 template <int IB, int OB>
@@ -1023,8 +1083,12 @@ static int l64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &
   const int last = b.nl - 1;
   {
     ProfScope ps(ctx, "l64_couple");
-    hipLaunchKernelGGL(k_l64_couple_bwd, dim3((unsigned)((a.N + 31) / 32)), dim3(256), 0, ctx->stream, a, inv, (const float *)b.act[0][last],
-                       b.F[last], x, gbar, lbar, lbar_const, b.dout[0], b.dout[b.nets - 1], b.F[last]);
+    if (a.K <= 8)
+      hipLaunchKernelGGL(k_l64_couple_bwd<8>, dim3((unsigned)((a.N + 31) / 32)), dim3(256), 0, ctx->stream, a, inv,
+                         (const float *)b.act[0][last], b.F[last], x, gbar, lbar, lbar_const, b.dout[0], b.dout[b.nets - 1], b.F[last]);
+    else
+      hipLaunchKernelGGL(k_l64_couple_bwd<G64_MAXK>, dim3((unsigned)((a.N + 31) / 32)), dim3(256), 0, ctx->stream, a, inv,
+                         (const float *)b.act[0][last], b.F[last], x, gbar, lbar, lbar_const, b.dout[0], b.dout[b.nets - 1], b.F[last]);
     NF_HIP(hipGetLastError());
   }
   const unsigned grid = l64_grid(ctx, a.N, 2L * ctx->num_cu);
