@@ -968,10 +968,14 @@ static size_t l64_shared_floats_per_sample(const nf_flow_desc *desc) {
   const int nout = desc->kind == NF_KIND_REALNVP ? c : (3 * desc->K - 1) * c;
   return (desc->kind == NF_KIND_REALNVP ? 2 : 1) * (size_t)l64_pad32(nout) + 2 * (size_t)l64_gh_rows(desc);
 }
-size_t nf_l64_scratch_bytes(const nf_flow_desc *desc, long N) {
-  if (!l64_ok(desc)) return 0;
-  const size_t per = (size_t)2 * desc->nlayers * l64_act_floats_per_sample(desc) + l64_shared_floats_per_sample(desc);
+// layout: [shared | slot 0 | slot 1 | ...]; `slots` of them (a stand-alone forward needs one, a kept forward all 2 nlayers)
+static size_t l64_scratch_bytes_for(const nf_flow_desc *desc, long N, int slots) {
+  const size_t per = (size_t)slots * l64_act_floats_per_sample(desc) + l64_shared_floats_per_sample(desc);
   return ((size_t)((N + 31) / 32) * 32 * per * sizeof(float) + 255) / 256 * 256;
+}
+size_t nf_l64_scratch_bytes(const nf_flow_desc *desc, long N) {  // what nf_workspace_bytes plans for: the training step's need
+  if (!l64_ok(desc)) return 0;
+  return l64_scratch_bytes_for(desc, N, 2 * desc->nlayers);
 }
 struct L64Bufs {
   float *act[2][NF_MAX_HIDDEN + 1];  // [net][layer]: tiled outputs (the last one: the net's output)
@@ -981,22 +985,28 @@ struct L64Bufs {
 };
 // slot: the coupling whose activation area the call uses (flat index; stand-alone calls use any, they do not look back)
 static int l64_bufs(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a, L64Bufs *b, int slot) {
-  NF_TRY(nf_wimg_reserve(ctx, nf_l64_scratch_bytes(desc, a.N)));
+  const int nc = 2 * desc->nlayers;
+  if (slot < 0 || slot >= nc) slot = 0;
+  // own (grow-only) buffer: as many slots as this call reaches -- a kept forward starts at the LAST slot, so the buffer has
+  // its full size before anything is left in it; a caller's arena is carved once, at the size nf_workspace_bytes planned
+  NF_TRY(nf_wimg_reserve(ctx, l64_scratch_bytes_for(desc, a.N, ctx->arena ? nc : slot + 1)));
   ctx->wimg_owner = nullptr;  // the buffer doubles as the fused kernels' packed-image store: whatever it cached is gone
   const size_t Np = (size_t)((a.N + 31) / 32) * 32;
-  const int nc = 2 * desc->nlayers;
   b->nets = desc->kind == NF_KIND_REALNVP ? 2 : 1;
   b->nl = a.net[0].nl;
-  const size_t actf = l64_act_floats_per_sample(desc);
-  float *p = (float *)ctx->wimg + (size_t)(slot < 0 || slot >= nc ? 0 : slot) * Np * actf;
   for (int l = 0; l < b->nl; ++l) b->F[l] = l64_pad32(a.net[0].dims[l + 1]);
-  for (int n = 0; n < b->nets; ++n)
-    for (int l = 0; l < b->nl; ++l) { b->act[n][l] = p; p += Np * b->F[l]; }
-  p = (float *)ctx->wimg + (size_t)nc * Np * actf;
-  for (int n = 0; n < b->nets; ++n) { b->dout[n] = p; p += Np * b->F[b->nl - 1]; }
+  // region sizes come from the DESCRIPTOR (the wider of the two masks' couplings: c = ceil(d / 2)), not from this coupling's
+  // own widths -- every coupling must find the shared buffers and its slot at the same place
+  const int cmax = (desc->d + 1) / 2;
+  const size_t out_rows = (size_t)l64_pad32(desc->kind == NF_KIND_REALNVP ? cmax : (3 * desc->K - 1) * cmax);
+  float *p = (float *)ctx->wimg;
+  for (int n = 0; n < b->nets; ++n) { b->dout[n] = p; p += Np * out_rows; }
   b->GH = l64_gh_rows(desc);
   b->gh[0] = p; p += Np * b->GH;
-  b->gh[1] = p;
+  b->gh[1] = p; p += Np * b->GH;
+  p += (size_t)slot * Np * l64_act_floats_per_sample(desc);
+  for (int n = 0; n < b->nets; ++n)
+    for (int l = 0; l < b->nl; ++l) { b->act[n][l] = p; p += Np * b->F[l]; }
   return NF_OK;
 }
 static inline unsigned l64_grid(nf_ctx *ctx, long N, long cap) {
