@@ -371,17 +371,58 @@ struct L64Src {
   int F, row0;   // tiled: rows per tile, first row
   int d, par;    // standard layout: feature count and parity of the rows
 };
-__device__ __forceinline__ float l64_get(const L64Src &s, long tile, int row, int l31, long N, int nrows) {
-  const long j = tile * L64_TILE + l31;
-  if (s.d > 0) return (row < nrows && j < N) ? s.p[j * s.d + 2 * row + s.par] : 0.f;
-  return (s.row0 + row < s.F) ? s.p[((tile * s.F + s.row0 + row) * L64_TILE) + l31] : 0.f;  // IB may be padded past the buffer
+// Tile I/O through buffer descriptors (as the fused kernels' tile_load / tile_store, nf_mfma.h): one descriptor per (operand,
+// tile) in scalar registers, one lane offset, and the row of a register as a compile-time scalar offset -- no 64-bit address
+// per element (the first form computed one for each of up to 128 loads in flight: 478 registers for a [64 -> 128] block,
+// one wavefront per SIMD).  Rows and samples outside the descriptor's extent read as 0 and are dropped on a store, which is
+// what the padding needs.
+struct L64Io {
+  __amdgpu_buffer_rsrc_t rs;
+  int voff;
+};
+// the constant part of a register's row: row(b, r, hi) = l64_rc(b, r) + 4 hi
+__device__ __forceinline__ constexpr int l64_rc(int b, int r) { return 32 * b + (r & 3) + 8 * (r >> 2); }
+// tiled operand [tile][F rows][32 samples], rows from row0 on
+__device__ __forceinline__ L64Io l64_io_tiled(const float *p, int F, int row0, long tile, int l31, int hi) {
+  L64Io io;
+  const int rows = F - row0 > 0 ? F - row0 : 0;
+  io.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p) + (tile * F + row0) * L64_TILE, 0, rows * L64_TILE * 4, 0x00020000);
+  io.voff = (4 * hi * L64_TILE + l31) * 4;
+  return io;
+}
+// the conditioner half of the standard-layout state, x[j * d + 2 row + par], samples of one tile (those < N)
+__device__ __forceinline__ L64Io l64_io_std(const float *p, int d, int par, long tile, long N, int l31, int hi) {
+  L64Io io;
+  long rem = N - tile * L64_TILE;
+  rem = rem < 0 ? 0 : rem > L64_TILE ? L64_TILE : rem;
+  io.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p) + tile * L64_TILE * d, 0, (int)rem * d * 4, 0x00020000);
+  io.voff = (l31 * d + 8 * hi + par) * 4;
+  return io;
+}
+__device__ __forceinline__ float l64_ld(const L64Io &io, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(io.rs, io.voff, soff, 0));
+}
+__device__ __forceinline__ void l64_st(const L64Io &io, int soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), io.rs, io.voff, soff, 0);
 }
 template <int NB>
 __device__ __forceinline__ void l64_load(const L64Src &s, long tile, int l31, int hi, long N, int nrows, f32x16 (&v)[NB]) {
+  if (s.d > 0) {
+    const L64Io io = l64_io_std(s.p, s.d, s.par, tile, N, l31, hi);
 #pragma unroll
-  for (int b = 0; b < NB; ++b)
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[b][r] = l64_get(s, tile, 32 * b + nf_row(r, hi), l31, N, nrows);
+      for (int r = 0; r < 16; ++r) {
+        const float x = l64_ld(io, l64_rc(b, r) * 8);
+        v[b][r] = l64_rc(b, r) + 4 * hi < nrows ? x : 0.f;  // past the half's rows sits the next sample
+      }
+  } else {
+    const L64Io io = l64_io_tiled(s.p, s.F, s.row0, tile, l31, hi);
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[b][r] = l64_ld(io, l64_rc(b, r) * (L64_TILE * 4));
+  }
 }
 // stage W[i][o0 + o] (i < 32 IB, o < 32 OB) and b[o0 + o] from theta, zero outside the layer
 template <int IB, int OB>
@@ -410,12 +451,13 @@ __global__ __launch_bounds__(256) void k_l64_fwd(const float *__restrict__ theta
     f32x16 in[IB], out[OB];
     l64_load<IB>(src, tile, l31, hi, N, L.nin, in);
     dense_fwd<IB, OB, S>(w, b, in, out, l31, hi);
+    const L64Io od = l64_io_tiled(dst, Fd, L.o0, tile, l31, hi);
 #pragma unroll
     for (int ob = 0; ob < OB; ++ob)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float v = out[ob][r];
-        dst[((tile * Fd + L.o0 + 32 * ob + nf_row(r, hi)) * L64_TILE) + l31] = act ? nf_lrelu(v) : v;
+        l64_st(od, l64_rc(ob, r) * (L64_TILE * 4), act ? nf_lrelu(v) : v);
       }
   }
 }
@@ -424,15 +466,56 @@ __global__ __launch_bounds__(256) void k_l64_fwd(const float *__restrict__ theta
 template <int OB>
 __device__ __forceinline__ void l64_delta(const L64Src &g, const float *__restrict__ act, int Fa, int o0, long tile, int l31, int hi,
                                           long N, f32x16 (&dl)[OB]) {
+  const L64Io gi = l64_io_tiled(g.p, g.F, g.row0, tile, l31, hi);
 #pragma unroll
   for (int ob = 0; ob < OB; ++ob)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = 32 * ob + nf_row(r, hi);
-      float v = g.p[((tile * g.F + g.row0 + row) * L64_TILE) + l31];
-      if (act) v *= act[((tile * Fa + o0 + row) * L64_TILE) + l31] > 0.f ? 1.f : 0.01f;
-      dl[ob][r] = v;
+    for (int r = 0; r < 16; ++r) dl[ob][r] = l64_ld(gi, l64_rc(ob, r) * (L64_TILE * 4));
+  if (act) {
+    const L64Io ai = l64_io_tiled(act, Fa, o0, tile, l31, hi);
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dl[ob][r] *= l64_ld(ai, l64_rc(ob, r) * (L64_TILE * 4)) > 0.f ? 1.f : 0.01f;
+  }
+}
+
+// the input cotangent of a layer: into the tiled buffer (Fd rows; accumulate: added to what is there) or, with xd > 0, added
+// to the conditioner half of the standard-layout cotangent gbar[j * xd + 2 row + par]
+template <int IB>
+__device__ __forceinline__ void l64_store_din(const f32x16 (&din)[IB], float *__restrict__ dst, int Fd, int accumulate, int xd, int xpar,
+                                              int nin, long tile, long N, int l31, int hi) {
+  if (xd > 0) {
+    const L64Io io = l64_io_std(dst, xd, xpar, tile, N, l31, hi);
+    float old[IB][16];
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) old[ib][r] = l64_ld(io, l64_rc(ib, r) * 8);
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (l64_rc(ib, r) + 4 * hi < nin) l64_st(io, l64_rc(ib, r) * 8, old[ib][r] + din[ib][r]);
+  } else {
+    const L64Io io = l64_io_tiled(dst, Fd, 0, tile, l31, hi);
+    if (accumulate) {
+      float old[IB][16];
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[ib][r] = l64_ld(io, l64_rc(ib, r) * (L64_TILE * 4));
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) l64_st(io, l64_rc(ib, r) * (L64_TILE * 4), old[ib][r] + din[ib][r]);
+    } else {
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) l64_st(io, l64_rc(ib, r) * (L64_TILE * 4), din[ib][r]);
     }
+  }
 }
 
 // din (+)= W[:, o0 : o0 + 32 OB] delta.  dst tiled (Fd rows; accumulate: add to what is there) or, with xd > 0, the
@@ -450,21 +533,42 @@ __global__ __launch_bounds__(256) void k_l64_bwdx(const float *__restrict__ thet
     f32x16 dl[OB], din[IB];
     l64_delta<OB>(g, act, Fa, L.o0, tile, l31, hi, N, dl);
     dense_bwd_x<IB, OB, S>(w, dl, din, l31, hi);
-    const long j = tile * L64_TILE + l31;
-#pragma unroll
-    for (int ib = 0; ib < IB; ++ib)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = 32 * ib + nf_row(r, hi);
-        if (xd > 0) {
-          if (row < L.nin && j < N) dst[j * xd + 2 * row + xpar] += din[ib][r];
-        } else {
-          if (row < Fd) {  // IB may be padded past the buffer's rows
-            float *p = dst + ((tile * Fd + row) * L64_TILE) + l31;
-            *p = accumulate ? *p + din[ib][r] : din[ib][r];
-          }
-        }
-      }
+    l64_store_din<IB>(din, dst, Fd, accumulate, xd, xpar, L.nin, tile, N, l31, hi);
+  }
+}
+
+// The same product over ALL output rows of the layer in one launch: the NG groups' weight blocks sit side by side in LDS
+// (dynamic; the caller checks the size), a tile's input cotangent is accumulated over the groups in registers and stored
+// once -- a wide layer (the spline's 3K - 1 parameters per dimension: 12 blocks at the docstring shape) otherwise re-reads
+// and re-writes the 64-row destination once per group.  Eight waves per workgroup share the staged weights.
+template <int IB, int OB>
+__global__ __launch_bounds__(512) void k_l64_bwdx_all(const float *__restrict__ theta, L64Layer L, int NG, L64Src g, const float *__restrict__ act,
+                                                      int Fa, float *__restrict__ dst, int Fd, int xd, int xpar, long N) {
+  constexpr int S = 32 * OB + NF_IMG_PAD, WG = 32 * IB * S + 32 * OB;
+  extern __shared__ __attribute__((aligned(16))) float wdyn[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  for (int q = 0; q < NG; ++q) {
+    L64Layer Lq = L;
+    Lq.o0 = 32 * OB * q;
+    l64_stage<IB, OB>(wdyn + q * WG, wdyn + q * WG + 32 * IB * S, theta, Lq, tid, 512);
+  }
+  __syncthreads();
+  const long ntiles = (N + L64_TILE - 1) / L64_TILE;
+  for (long tile = (long)blockIdx.x * 8 + wave; tile < ntiles; tile += (long)gridDim.x * 8) {
+    f32x16 dl[OB], din[IB];
+    {
+      L64Src gq = g;
+      l64_delta<OB>(gq, act, Fa, 0, tile, l31, hi, N, dl);
+      dense_bwd_x<IB, OB, S, false>(wdyn, dl, din, l31, hi);
+    }
+#pragma unroll 1
+    for (int q = 1; q < NG; ++q) {
+      L64Src gq = g;
+      gq.row0 = g.row0 + 32 * OB * q;
+      l64_delta<OB>(gq, act, Fa, 32 * OB * q, tile, l31, hi, N, dl);
+      dense_bwd_x<IB, OB, S, true>(wdyn + q * WG, dl, din, l31, hi);
+    }
+    l64_store_din<IB>(din, dst, Fd, 0, xd, xpar, L.nin, tile, N, l31, hi);
   }
 }
 
@@ -1031,7 +1135,7 @@ static inline int l64_group(int blocks_left, int maxg) { return blocks_left >= 4
 
 // the nets of one coupling, layer by layer, on the conditioner half of `x` (standard layout); outputs stay in b->act
 static int l64_nets_fwd(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a, const float *theta, const float *x, const L64Bufs &b) {
-  const unsigned grid = l64_grid(ctx, a.N, 2L * ctx->num_cu);
+  const unsigned grid = l64_grid(ctx, a.N, 4L * ctx->num_cu);
   for (int n = 0; n < b.nets; ++n) {
     const G64Net &net = a.net[n];
     for (int l = 0; l < net.nl; ++l) {
@@ -1081,6 +1185,17 @@ static int l64_dw_launch(nf_ctx *ctx, unsigned grid, const L64Layer &L, const L6
   hipLaunchKernelGGL((k_l64_dw<IB, OB>), dim3(grid), dim3(256), lds, ctx->stream, L, av, g, act, Fa, N, slabs, Pc, slab_off);
   return (int)hipGetLastError();
 }
+template <int IB, int OB>
+static int l64_bwdx_all_launch(nf_ctx *ctx, unsigned grid, size_t lds, const float *theta, const L64Layer &L, int NG, const L64Src &g,
+                               const float *act, int Fa, float *dst, int Fd, int xd, int xpar, long N) {
+  static AttrOnce attr_once;
+  NF_TRY(attr_once.run(ctx->device, [&]() -> int {
+    NF_HIP(hipFuncSetAttribute((const void *)k_l64_bwdx_all<IB, OB>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+    return NF_OK;
+  }));
+  hipLaunchKernelGGL((k_l64_bwdx_all<IB, OB>), dim3(grid), dim3(512), lds, ctx->stream, theta, L, NG, g, act, Fa, dst, Fd, xd, xpar, N);
+  return (int)hipGetLastError();
+}
 // reverse pass of coupling k at x (forward: its input; inv: the inverse's output): gbar updated in place, this coupling's
 // parameter gradient in g[theta_off ...] through per-workgroup slabs
 static int l64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &a, int inv, const float *theta, const float *x, float *gbar,
@@ -1101,7 +1216,7 @@ static int l64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &
                          (const float *)b.act[0][last], b.F[last], x, gbar, lbar, lbar_const, b.dout[0], b.dout[b.nets - 1], b.F[last]);
     NF_HIP(hipGetLastError());
   }
-  const unsigned grid = l64_grid(ctx, a.N, 2L * ctx->num_cu);
+  const unsigned grid = l64_grid(ctx, a.N, 4L * ctx->num_cu);
   const unsigned gridw = l64_grid(ctx, a.N, (long)g64_bwd_blocks(desc, a.N));
   for (int n = 0; n < b.nets; ++n) {
     const G64Net &net = a.net[n];
@@ -1127,6 +1242,21 @@ static int l64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &
 #undef CALL
         ob0 += OBw;
       }
+      // every output block in one launch when the layer's weight blocks fit LDS side by side
+      const int OBa = l64_maxg(IB, false) >= 4 ? 4 : l64_maxg(IB, false);
+      const int NGa = (blocks + OBa - 1) / OBa;
+      const size_t lds_all = (size_t)NGa * (32 * IB * (32 * OBa + NF_IMG_PAD) + 32 * OBa) * sizeof(float);
+      static const bool no_all = std::getenv("NF_L64_NO_BWDX_ALL") != nullptr;  // A/B switch
+      if (NGa >= 2 && lds_all <= 144 * 1024 && !no_all) {
+        const L64Layer L{net.w[l], net.b[l], nin, nout, 0};
+        const L64Src gs{gsrc, Fg, 0, 0, 0};
+        const unsigned grid8 = (unsigned)std::min<long>(((a.N + 31) / 32 + 7) / 8, (long)ctx->num_cu);
+        ProfScope ps(ctx, "l64_bwdx");
+#define CALL(I, O) NF_TRY((l64_bwdx_all_launch<I, O>(ctx, grid8, lds_all, theta, L, NGa, gs, act, b.F[l], l == 0 ? gbar : gdst, \
+                                                       l == 0 ? 0 : b.GH, l == 0 ? a.d : 0, l == 0 ? 1 - a.par_t : 0, a.N)))
+        L64_DISPATCH(IB, OBa, CALL);
+#undef CALL
+      } else
       for (int ob0 = 0, first = 1; ob0 < blocks; first = 0) {
         const int OB = l64_group(blocks - ob0, l64_maxg(IB, false));
         const L64Layer L{net.w[l], net.b[l], nin, nout, 32 * ob0};
