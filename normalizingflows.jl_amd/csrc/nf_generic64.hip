@@ -636,6 +636,60 @@ __global__ __launch_bounds__(256) void k_l64_dw(L64Layer L, L64Src a, L64Src g, 
     if (L.o0 + o < L.nout) slab[L.b_off + L.o0 + o] = img[32 * IB * SI + o];
 }
 
+// dW of a WIDE layer in one launch: wave w of every workgroup owns the output columns [32 OB w, 32 OB (w + 1)) and all four
+// waves walk the workgroup's tiles together, so the activation operand leaves HBM once per tile and every delta once in
+// total (k_l64_dw over column groups re-reads the activations per group: six launches for the spline layer's 12 blocks).
+// Each wave accumulates its own [32 IB][32 OB] block and writes it from its registers -- columns are disjoint, there is no
+// cross-wave fold.  Needs 4 OB >= the layer's blocks.
+template <int IB, int OB>
+__global__ __launch_bounds__(256) void k_l64_dw_cols(L64Layer L, L64Src a, L64Src g, const float *__restrict__ act, int Fa, long N,
+                                                     float *__restrict__ slabs, long Pc, long slab_off) {
+  constexpr int SA = IB * 32 * NF_TS, SD = OB * 32 * NF_TS;
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // 4 (SA + SD) floats
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  float *sa = sm + wave * (SA + SD), *sd = sa + SA;
+  const int o0w = 32 * OB * wave;
+  f32x16 acc[IB][OB];
+  float bsum[OB];
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob) {
+    bsum[ob] = 0.f;
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ib][ob][r] = 0.f;
+  }
+  L64Src gw = g;
+  gw.row0 = g.row0 + o0w;
+  const long ntiles = (N + L64_TILE - 1) / L64_TILE;
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    f32x16 av[IB], dl[OB];
+    l64_load<IB>(a, tile, l31, hi, N, L.nin, av);
+    l64_delta<OB>(gw, act, Fa, L.o0 + o0w, tile, l31, hi, N, dl);
+    tile_to_scratch<IB>(sa, av, l31, hi);
+    tile_to_scratch<OB>(sd, dl, l31, hi);
+    wave_lds_fence();
+    dw_accumulate<IB, OB>(sa, sd, acc, bsum, l31, hi);
+    wave_lds_fence();
+  }
+  float *slab = slabs + (long)blockIdx.x * Pc - slab_off;
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob) {
+    const int o = L.o0 + o0w + 32 * ob + l31;
+    if (o < L.nout) {
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = 32 * ib + nf_row(r, hi);
+          if (i < L.nin) slab[L.w_off + (long)i * L.nout + o] = acc[ib][ob][r];
+        }
+    }
+    const float v = bsum[ob] + __shfl_xor(bsum[ob], 32);
+    if (hi == 0 && o < L.nout) slab[L.b_off + o] = v;
+  }
+}
+
 // ---- the coupling arithmetic on net outputs held in tiles (one thread per sample; as k_g64_apply / k_g64_bwd) -------
 __device__ __forceinline__ float l64_out(const float *__restrict__ buf, int F, long j, int row) {
   return buf[(((j >> 5) * F + row) << 5) + (j & 31)];
@@ -1186,6 +1240,18 @@ static int l64_dw_launch(nf_ctx *ctx, unsigned grid, const L64Layer &L, const L6
   return (int)hipGetLastError();
 }
 template <int IB, int OB>
+static int l64_dw_cols_launch(nf_ctx *ctx, unsigned grid, const L64Layer &L, const L64Src &av, const L64Src &g, const float *act, int Fa, long N,
+                              float *slabs, long Pc, long slab_off) {
+  const size_t lds = (size_t)4 * (IB + OB) * 32 * NF_TS * sizeof(float);
+  static AttrOnce attr_once;
+  NF_TRY(attr_once.run(ctx->device, [&]() -> int {
+    NF_HIP(hipFuncSetAttribute((const void *)k_l64_dw_cols<IB, OB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return NF_OK;
+  }));
+  hipLaunchKernelGGL((k_l64_dw_cols<IB, OB>), dim3(grid), dim3(256), lds, ctx->stream, L, av, g, act, Fa, N, slabs, Pc, slab_off);
+  return (int)hipGetLastError();
+}
+template <int IB, int OB>
 static int l64_bwdx_all_launch(nf_ctx *ctx, unsigned grid, size_t lds, const float *theta, const L64Layer &L, int NG, const L64Src &g,
                                const float *act, int Fa, float *dst, int Fd, int xd, int xpar, long N) {
   static AttrOnce attr_once;
@@ -1232,6 +1298,22 @@ static int l64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &
       L64Src av;
       if (l == 0) av = L64Src{x, 0, 0, a.d, 1 - a.par_t};
       else av = L64Src{b.act[n][l - 1], b.F[l - 1], 0, 0, 0};
+      // a layer wider than one launch of k_l64_dw takes: all its columns at once, a column range per wave
+      const int OBc = (blocks + 3) / 4;
+      static const bool no_cols = std::getenv("NF_L64_NO_DW_COLS") != nullptr;  // A/B switch
+      if (blocks > l64_maxg(IB, true) && IB * OBc <= 8 && OBc <= 4 && !no_cols) {
+        const L64Layer L{net.w[l], net.b[l], nin, nout, 0};
+        const L64Src gs{gsrc, Fg, 0, 0, 0};
+        ProfScope ps(ctx, "l64_dw");
+#define CALLC(I, O) NF_TRY((l64_dw_cols_launch<I, O>(ctx, gridw, L, av, gs, act, b.F[l], a.N, slabs, ci.nparams, ci.theta_off)))
+        switch (IB * 8 + OBc) {
+          case 8 + 1: CALLC(1, 1); break;  case 8 + 2: CALLC(1, 2); break;  case 8 + 3: CALLC(1, 3); break;  case 8 + 4: CALLC(1, 4); break;
+          case 16 + 1: CALLC(2, 1); break; case 16 + 2: CALLC(2, 2); break; case 16 + 3: CALLC(2, 3); break; case 16 + 4: CALLC(2, 4); break;
+          case 32 + 1: CALLC(4, 1); break; case 32 + 2: CALLC(4, 2); break; case 64 + 1: CALLC(8, 1); break;
+          default: return NF_ERR_UNSUPPORTED;  // (unreachable: IB in {1, 2, 4, 8}, IB * OBc <= 8)
+        }
+#undef CALLC
+      } else
       for (int ob0 = 0; ob0 < blocks;) {
         const int OBw = l64_group(blocks - ob0, l64_maxg(IB, true));
         const L64Layer L{net.w[l], net.b[l], nin, nout, 32 * ob0};
