@@ -462,6 +462,40 @@ __global__ __launch_bounds__(256) void k_l64_fwd(const float *__restrict__ theta
   }
 }
 
+// ALL output rows of a wide layer in one launch (as k_l64_bwdx_all): the NG groups' weight blocks side by side in LDS
+// (dynamic), the input tile read once, eight waves per workgroup.
+template <int IB, int OB>
+__global__ __launch_bounds__(512) void k_l64_fwd_all(const float *__restrict__ theta, L64Layer L, int NG, L64Src src, float *__restrict__ dst,
+                                                     int Fd, long N, int act) {
+  constexpr int S = 32 * OB + NF_IMG_PAD, WG = 32 * IB * S + 32 * OB;
+  extern __shared__ __attribute__((aligned(16))) float wdyn[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  for (int q = 0; q < NG; ++q) {
+    L64Layer Lq = L;
+    Lq.o0 = 32 * OB * q;
+    l64_stage<IB, OB>(wdyn + q * WG, wdyn + q * WG + 32 * IB * S, theta, Lq, tid, 512);
+  }
+  __syncthreads();
+  const long ntiles = (N + L64_TILE - 1) / L64_TILE;
+  for (long tile = (long)blockIdx.x * 8 + wave; tile < ntiles; tile += (long)gridDim.x * 8) {
+    f32x16 in[IB];
+    l64_load<IB>(src, tile, l31, hi, N, L.nin, in);
+#pragma unroll 1
+    for (int q = 0; q < NG; ++q) {
+      f32x16 out[OB];
+      dense_fwd<IB, OB, S>(wdyn + q * WG, wdyn + q * WG + 32 * IB * S, in, out, l31, hi);
+      const L64Io od = l64_io_tiled(dst, Fd, 32 * OB * q, tile, l31, hi);
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = out[ob][r];
+          l64_st(od, l64_rc(ob, r) * (L64_TILE * 4), act ? nf_lrelu(v) : v);
+        }
+    }
+  }
+}
+
 // delta of a layer's output rows: the stored cotangent, times leaky-ReLU' from the sign of the stashed post-activation
 template <int OB>
 __device__ __forceinline__ void l64_delta(const L64Src &g, const float *__restrict__ act, int Fa, int o0, long tile, int l31, int hi,
@@ -1187,6 +1221,17 @@ static inline int l64_maxg(int ibp, bool dw) { return ibp <= 2 ? (dw ? 2 : 4) : 
   } while (0)
 static inline int l64_group(int blocks_left, int maxg) { return blocks_left >= 4 && maxg >= 4 ? 4 : blocks_left >= 2 && maxg >= 2 ? 2 : 1; }
 
+template <int IB, int OB>
+static int l64_fwd_all_launch(nf_ctx *ctx, unsigned grid, size_t lds, const float *theta, const L64Layer &L, int NG, const L64Src &src,
+                              float *dst, int Fd, long N, int act) {
+  static AttrOnce attr_once;
+  NF_TRY(attr_once.run(ctx->device, [&]() -> int {
+    NF_HIP(hipFuncSetAttribute((const void *)k_l64_fwd_all<IB, OB>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+    return NF_OK;
+  }));
+  hipLaunchKernelGGL((k_l64_fwd_all<IB, OB>), dim3(grid), dim3(512), lds, ctx->stream, theta, L, NG, src, dst, Fd, N, act);
+  return (int)hipGetLastError();
+}
 // the nets of one coupling, layer by layer, on the conditioner half of `x` (standard layout); outputs stay in b->act
 static int l64_nets_fwd(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a, const float *theta, const float *x, const L64Bufs &b) {
   const unsigned grid = l64_grid(ctx, a.N, 4L * ctx->num_cu);
@@ -1198,6 +1243,18 @@ static int l64_nets_fwd(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a,
       L64Src src;
       if (l == 0) src = L64Src{x, 0, 0, a.d, 1 - a.par_t};
       else src = L64Src{b.act[n][l - 1], b.F[l - 1], 0, 0, 0};
+      const int OBa = l64_maxg(IB, false) >= 4 ? 4 : l64_maxg(IB, false);
+      const int NGa = (blocks + OBa - 1) / OBa;
+      const size_t lds_all = (size_t)NGa * (32 * IB * (32 * OBa + NF_IMG_PAD) + 32 * OBa) * sizeof(float);
+      static const bool no_all = std::getenv("NF_L64_NO_FWD_ALL") != nullptr;  // A/B switch
+      if (NGa >= 2 && lds_all <= 144 * 1024 && !no_all) {  // every output block of a wide layer in one launch
+        const L64Layer L{net.w[l], net.b[l], nin, nout, 0};
+        const unsigned grid8 = (unsigned)std::min<long>(((a.N + 31) / 32 + 7) / 8, (long)ctx->num_cu);
+        ProfScope ps(ctx, "l64_fwd");
+#define CALL(I, O) NF_TRY((l64_fwd_all_launch<I, O>(ctx, grid8, lds_all, theta, L, NGa, src, b.act[n][l], b.F[l], a.N, l < net.nl - 1 ? 1 : 0)))
+        L64_DISPATCH(IB, OBa, CALL);
+#undef CALL
+      } else
       for (int ob0 = 0; ob0 < blocks;) {
         const int OB = l64_group(blocks - ob0, l64_maxg(IB, false));
         const L64Layer L{net.w[l], net.b[l], nin, nout, 32 * ob0};
