@@ -380,6 +380,11 @@ struct L64Io {
   __amdgpu_buffer_rsrc_t rs;
   int voff;
 };
+// blockIdx.y = net (RealNVP's s and t nets have the same shapes: one launch serves both): theta offsets and the three
+// operand pointers of a kernel move by these strides per net (0 for an operand the nets share)
+struct L64Y {
+  long dtheta, da, db, dc;
+};
 // the constant part of a register's row: row(b, r, hi) = l64_rc(b, r) + 4 hi
 __device__ __forceinline__ constexpr int l64_rc(int b, int r) { return 32 * b + (r & 3) + 8 * (r >> 2); }
 // tiled operand [tile][F rows][32 samples], rows from row0 on
@@ -439,8 +444,9 @@ __device__ __forceinline__ void l64_stage(float *__restrict__ w, float *__restri
 // out rows [o0, o0 + 32 OB) of dst <- W' in + b (leaky-ReLU if act)
 template <int IB, int OB>
 __global__ __launch_bounds__(256) void k_l64_fwd(const float *__restrict__ theta, L64Layer L, L64Src src, float *__restrict__ dst, int Fd,
-                                                 long N, int act) {
+                                                 long N, int act, L64Y yy) {
   constexpr int S = 32 * OB + NF_IMG_PAD;
+  L.w_off += blockIdx.y * yy.dtheta; L.b_off += blockIdx.y * yy.dtheta; src.p += blockIdx.y * yy.da; dst += blockIdx.y * yy.db;
   __shared__ __attribute__((aligned(16))) float w[32 * IB * S + 32 * OB];
   float *b = w + 32 * IB * S;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
@@ -466,8 +472,9 @@ __global__ __launch_bounds__(256) void k_l64_fwd(const float *__restrict__ theta
 // (dynamic), the input tile read once, eight waves per workgroup.
 template <int IB, int OB>
 __global__ __launch_bounds__(512) void k_l64_fwd_all(const float *__restrict__ theta, L64Layer L, int NG, L64Src src, float *__restrict__ dst,
-                                                     int Fd, long N, int act) {
+                                                     int Fd, long N, int act, L64Y yy) {
   constexpr int S = 32 * OB + NF_IMG_PAD, WG = 32 * IB * S + 32 * OB;
+  L.w_off += blockIdx.y * yy.dtheta; L.b_off += blockIdx.y * yy.dtheta; src.p += blockIdx.y * yy.da; dst += blockIdx.y * yy.db;
   extern __shared__ __attribute__((aligned(16))) float wdyn[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   for (int q = 0; q < NG; ++q) {
@@ -556,8 +563,10 @@ __device__ __forceinline__ void l64_store_din(const f32x16 (&din)[IB], float *__
 // conditioner half of the standard-layout cotangent gbar[j * xd + 2 q + par] (always accumulated: x2bar += din)
 template <int IB, int OB>
 __global__ __launch_bounds__(256) void k_l64_bwdx(const float *__restrict__ theta, L64Layer L, L64Src g, const float *__restrict__ act,
-                                                  int Fa, float *__restrict__ dst, int Fd, int accumulate, int xd, int xpar, long N) {
+                                                  int Fa, float *__restrict__ dst, int Fd, int accumulate, int xd, int xpar, long N, L64Y yy) {
   constexpr int S = 32 * OB + NF_IMG_PAD;
+  L.w_off += blockIdx.y * yy.dtheta; L.b_off += blockIdx.y * yy.dtheta; g.p += blockIdx.y * yy.da; dst += blockIdx.y * yy.dc;
+  if (act) act += blockIdx.y * yy.db;
   __shared__ __attribute__((aligned(16))) float w[32 * IB * S + 32 * OB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   l64_stage<IB, OB>(w, w + 32 * IB * S, theta, L, tid, 256);
@@ -577,8 +586,10 @@ __global__ __launch_bounds__(256) void k_l64_bwdx(const float *__restrict__ thet
 // and re-writes the 64-row destination once per group.  Eight waves per workgroup share the staged weights.
 template <int IB, int OB>
 __global__ __launch_bounds__(512) void k_l64_bwdx_all(const float *__restrict__ theta, L64Layer L, int NG, L64Src g, const float *__restrict__ act,
-                                                      int Fa, float *__restrict__ dst, int Fd, int xd, int xpar, long N) {
+                                                      int Fa, float *__restrict__ dst, int Fd, int xd, int xpar, long N, L64Y yy) {
   constexpr int S = 32 * OB + NF_IMG_PAD, WG = 32 * IB * S + 32 * OB;
+  L.w_off += blockIdx.y * yy.dtheta; L.b_off += blockIdx.y * yy.dtheta; g.p += blockIdx.y * yy.da; dst += blockIdx.y * yy.dc;
+  if (act) act += blockIdx.y * yy.db;
   extern __shared__ __attribute__((aligned(16))) float wdyn[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   for (int q = 0; q < NG; ++q) {
@@ -609,8 +620,10 @@ __global__ __launch_bounds__(512) void k_l64_bwdx_all(const float *__restrict__ 
 // this workgroup's partial of dW[:, o0 : o0 + 32 OB] = sum_j a_j delta_j' and db, written in theta order into its slab
 template <int IB, int OB>
 __global__ __launch_bounds__(256) void k_l64_dw(L64Layer L, L64Src a, L64Src g, const float *__restrict__ act, int Fa, long N,
-                                                float *__restrict__ slabs, long Pc, long slab_off) {
+                                                float *__restrict__ slabs, long Pc, long slab_off, L64Y yy) {
   constexpr int SA = IB * 32 * NF_TS, SD = OB * 32 * NF_TS;
+  L.w_off += blockIdx.y * yy.dtheta; L.b_off += blockIdx.y * yy.dtheta; a.p += blockIdx.y * yy.da; g.p += blockIdx.y * yy.db;
+  if (act) act += blockIdx.y * yy.dc;
   extern __shared__ __attribute__((aligned(16))) float sm[];  // 4 (SA + SD) floats (beyond the 64 KB static limit at IB = OB = 2)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   float *sa = sm + wave * (SA + SD), *sd = sa + SA;
@@ -677,8 +690,10 @@ __global__ __launch_bounds__(256) void k_l64_dw(L64Layer L, L64Src a, L64Src g, 
 // cross-wave fold.  Needs 4 OB >= the layer's blocks.
 template <int IB, int OB>
 __global__ __launch_bounds__(256) void k_l64_dw_cols(L64Layer L, L64Src a, L64Src g, const float *__restrict__ act, int Fa, long N,
-                                                     float *__restrict__ slabs, long Pc, long slab_off) {
+                                                     float *__restrict__ slabs, long Pc, long slab_off, L64Y yy) {
   constexpr int SA = IB * 32 * NF_TS, SD = OB * 32 * NF_TS;
+  L.w_off += blockIdx.y * yy.dtheta; L.b_off += blockIdx.y * yy.dtheta; a.p += blockIdx.y * yy.da; g.p += blockIdx.y * yy.db;
+  if (act) act += blockIdx.y * yy.dc;
   extern __shared__ __attribute__((aligned(16))) float sm[];  // 4 (SA + SD) floats
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   float *sa = sm + wave * (SA + SD), *sd = sa + SA;
@@ -1147,7 +1162,7 @@ static int l64_gh_rows(const nf_flow_desc *desc) {  // rows of the two hidden-co
 }
 // scratch floats per sample: per COUPLING the nets' stashed layer outputs (a reverse pass that follows a kept forward --
 // g64_forward_keep -- reads them back instead of evaluating the nets again, so every coupling has its own slot); shared by
-// all couplings: the output cotangents per net and two hidden cotangent buffers
+// all couplings: per net the output cotangent and two hidden cotangent buffers (the nets' reverse passes run side by side)
 static size_t l64_act_floats_per_sample(const nf_flow_desc *desc) {
   const int c = (desc->d + 1) / 2;
   const int nout = desc->kind == NF_KIND_REALNVP ? c : (3 * desc->K - 1) * c;
@@ -1158,7 +1173,8 @@ static size_t l64_act_floats_per_sample(const nf_flow_desc *desc) {
 static size_t l64_shared_floats_per_sample(const nf_flow_desc *desc) {
   const int c = (desc->d + 1) / 2;
   const int nout = desc->kind == NF_KIND_REALNVP ? c : (3 * desc->K - 1) * c;
-  return (desc->kind == NF_KIND_REALNVP ? 2 : 1) * (size_t)l64_pad32(nout) + 2 * (size_t)l64_gh_rows(desc);
+  const int nets = desc->kind == NF_KIND_REALNVP ? 2 : 1;
+  return nets * ((size_t)l64_pad32(nout) + 2 * (size_t)l64_gh_rows(desc));
 }
 // layout: [shared | slot 0 | slot 1 | ...]; `slots` of them (a stand-alone forward needs one, a kept forward all 2 nlayers)
 static size_t l64_scratch_bytes_for(const nf_flow_desc *desc, long N, int slots) {
@@ -1172,7 +1188,7 @@ size_t nf_l64_scratch_bytes(const nf_flow_desc *desc, long N) {  // what nf_work
 struct L64Bufs {
   float *act[2][NF_MAX_HIDDEN + 1];  // [net][layer]: tiled outputs (the last one: the net's output)
   int F[NF_MAX_HIDDEN + 1];          // rows of those tiles
-  float *dout[2], *gh[2];            // output cotangents per net; two hidden cotangent buffers of GH rows
+  float *dout[2], *gh[2][2];         // per net: output cotangent; two hidden cotangent buffers of GH rows
   int nets, nl, GH;
 };
 // slot: the coupling whose activation area the call uses (flat index; stand-alone calls use any, they do not look back)
@@ -1194,8 +1210,8 @@ static int l64_bufs(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a, L64
   float *p = (float *)ctx->wimg;
   for (int n = 0; n < b->nets; ++n) { b->dout[n] = p; p += Np * out_rows; }
   b->GH = l64_gh_rows(desc);
-  b->gh[0] = p; p += Np * b->GH;
-  b->gh[1] = p; p += Np * b->GH;
+  for (int n = 0; n < b->nets; ++n)
+    for (int i = 0; i < 2; ++i) { b->gh[n][i] = p; p += Np * b->GH; }
   p += (size_t)slot * Np * l64_act_floats_per_sample(desc);
   for (int n = 0; n < b->nets; ++n)
     for (int l = 0; l < b->nl; ++l) { b->act[n][l] = p; p += Np * b->F[l]; }
@@ -1221,21 +1237,33 @@ static inline int l64_maxg(int ibp, bool dw) { return ibp <= 2 ? (dw ? 2 : 4) : 
   } while (0)
 static inline int l64_group(int blocks_left, int maxg) { return blocks_left >= 4 && maxg >= 4 ? 4 : blocks_left >= 2 && maxg >= 2 ? 2 : 1; }
 
+// 2 when the coupling's two nets can share launches: same layer sizes, one constant theta stride, one constant buffer stride
+static int l64_nets_merge(const G64Args &a, const L64Bufs &b) {
+  static const bool off = std::getenv("NF_L64_NO_NET_MERGE") != nullptr;  // A/B switch
+  if (b.nets != 2 || off || a.net[0].nl != a.net[1].nl) return 1;
+  const long dth = a.net[1].w[0] - a.net[0].w[0];
+  for (int l = 0; l < a.net[0].nl; ++l) {
+    if (a.net[0].dims[l] != a.net[1].dims[l] || a.net[0].dims[l + 1] != a.net[1].dims[l + 1]) return 1;
+    if (a.net[1].w[l] - a.net[0].w[l] != dth || a.net[1].b[l] - a.net[0].b[l] != dth) return 1;
+  }
+  return 2;
+}
 template <int IB, int OB>
 static int l64_fwd_all_launch(nf_ctx *ctx, unsigned grid, size_t lds, const float *theta, const L64Layer &L, int NG, const L64Src &src,
-                              float *dst, int Fd, long N, int act) {
+                              float *dst, int Fd, long N, int act, int ny, const L64Y &yy) {
   static AttrOnce attr_once;
   NF_TRY(attr_once.run(ctx->device, [&]() -> int {
     NF_HIP(hipFuncSetAttribute((const void *)k_l64_fwd_all<IB, OB>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
     return NF_OK;
   }));
-  hipLaunchKernelGGL((k_l64_fwd_all<IB, OB>), dim3(grid), dim3(512), lds, ctx->stream, theta, L, NG, src, dst, Fd, N, act);
+  hipLaunchKernelGGL((k_l64_fwd_all<IB, OB>), dim3(grid, ny), dim3(512), lds, ctx->stream, theta, L, NG, src, dst, Fd, N, act, yy);
   return (int)hipGetLastError();
 }
 // the nets of one coupling, layer by layer, on the conditioner half of `x` (standard layout); outputs stay in b->act
 static int l64_nets_fwd(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a, const float *theta, const float *x, const L64Bufs &b) {
   const unsigned grid = l64_grid(ctx, a.N, 4L * ctx->num_cu);
-  for (int n = 0; n < b.nets; ++n) {
+  const int ny = l64_nets_merge(a, b);  // RealNVP: both nets in one launch (blockIdx.y), per-net strides in yy
+  for (int n = 0; n < b.nets; n += ny) {
     const G64Net &net = a.net[n];
     for (int l = 0; l < net.nl; ++l) {
       const int nin = net.dims[l], nout = net.dims[l + 1];
@@ -1243,6 +1271,8 @@ static int l64_nets_fwd(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a,
       L64Src src;
       if (l == 0) src = L64Src{x, 0, 0, a.d, 1 - a.par_t};
       else src = L64Src{b.act[n][l - 1], b.F[l - 1], 0, 0, 0};
+      L64Y yy{0, 0, 0, 0};
+      if (ny == 2) yy = L64Y{a.net[1].w[l] - a.net[0].w[l], l == 0 ? 0 : b.act[1][l - 1] - b.act[0][l - 1], b.act[1][l] - b.act[0][l], 0};
       const int OBa = l64_maxg(IB, false) >= 4 ? 4 : l64_maxg(IB, false);
       const int NGa = (blocks + OBa - 1) / OBa;
       const size_t lds_all = (size_t)NGa * (32 * IB * (32 * OBa + NF_IMG_PAD) + 32 * OBa) * sizeof(float);
@@ -1251,7 +1281,7 @@ static int l64_nets_fwd(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a,
         const L64Layer L{net.w[l], net.b[l], nin, nout, 0};
         const unsigned grid8 = (unsigned)std::min<long>(((a.N + 31) / 32 + 7) / 8, (long)ctx->num_cu);
         ProfScope ps(ctx, "l64_fwd");
-#define CALL(I, O) NF_TRY((l64_fwd_all_launch<I, O>(ctx, grid8, lds_all, theta, L, NGa, src, b.act[n][l], b.F[l], a.N, l < net.nl - 1 ? 1 : 0)))
+#define CALL(I, O) NF_TRY((l64_fwd_all_launch<I, O>(ctx, grid8, lds_all, theta, L, NGa, src, b.act[n][l], b.F[l], a.N, l < net.nl - 1 ? 1 : 0, ny, yy)))
         L64_DISPATCH(IB, OBa, CALL);
 #undef CALL
       } else
@@ -1259,7 +1289,7 @@ static int l64_nets_fwd(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a,
         const int OB = l64_group(blocks - ob0, l64_maxg(IB, false));
         const L64Layer L{net.w[l], net.b[l], nin, nout, 32 * ob0};
         ProfScope ps(ctx, "l64_fwd");
-#define CALL(I, O) hipLaunchKernelGGL((k_l64_fwd<I, O>), dim3(grid), dim3(256), 0, ctx->stream, theta, L, src, b.act[n][l], b.F[l], a.N, l < net.nl - 1 ? 1 : 0)
+#define CALL(I, O) hipLaunchKernelGGL((k_l64_fwd<I, O>), dim3(grid, ny), dim3(256), 0, ctx->stream, theta, L, src, b.act[n][l], b.F[l], a.N, l < net.nl - 1 ? 1 : 0, yy)
         L64_DISPATCH(IB, OB, CALL);
 #undef CALL
         NF_HIP(hipGetLastError());
@@ -1286,37 +1316,37 @@ static int l64_apply(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a, in
 }
 template <int IB, int OB>
 static int l64_dw_launch(nf_ctx *ctx, unsigned grid, const L64Layer &L, const L64Src &av, const L64Src &g, const float *act, int Fa, long N,
-                         float *slabs, long Pc, long slab_off) {
+                         float *slabs, long Pc, long slab_off, int ny, const L64Y &yy) {
   const size_t lds = (size_t)4 * (IB + OB) * 32 * NF_TS * sizeof(float);
   static AttrOnce attr_once;
   NF_TRY(attr_once.run(ctx->device, [&]() -> int {
     NF_HIP(hipFuncSetAttribute((const void *)k_l64_dw<IB, OB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return NF_OK;
   }));
-  hipLaunchKernelGGL((k_l64_dw<IB, OB>), dim3(grid), dim3(256), lds, ctx->stream, L, av, g, act, Fa, N, slabs, Pc, slab_off);
+  hipLaunchKernelGGL((k_l64_dw<IB, OB>), dim3(grid, ny), dim3(256), lds, ctx->stream, L, av, g, act, Fa, N, slabs, Pc, slab_off, yy);
   return (int)hipGetLastError();
 }
 template <int IB, int OB>
 static int l64_dw_cols_launch(nf_ctx *ctx, unsigned grid, const L64Layer &L, const L64Src &av, const L64Src &g, const float *act, int Fa, long N,
-                              float *slabs, long Pc, long slab_off) {
+                              float *slabs, long Pc, long slab_off, int ny, const L64Y &yy) {
   const size_t lds = (size_t)4 * (IB + OB) * 32 * NF_TS * sizeof(float);
   static AttrOnce attr_once;
   NF_TRY(attr_once.run(ctx->device, [&]() -> int {
     NF_HIP(hipFuncSetAttribute((const void *)k_l64_dw_cols<IB, OB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return NF_OK;
   }));
-  hipLaunchKernelGGL((k_l64_dw_cols<IB, OB>), dim3(grid), dim3(256), lds, ctx->stream, L, av, g, act, Fa, N, slabs, Pc, slab_off);
+  hipLaunchKernelGGL((k_l64_dw_cols<IB, OB>), dim3(grid, ny), dim3(256), lds, ctx->stream, L, av, g, act, Fa, N, slabs, Pc, slab_off, yy);
   return (int)hipGetLastError();
 }
 template <int IB, int OB>
 static int l64_bwdx_all_launch(nf_ctx *ctx, unsigned grid, size_t lds, const float *theta, const L64Layer &L, int NG, const L64Src &g,
-                               const float *act, int Fa, float *dst, int Fd, int xd, int xpar, long N) {
+                               const float *act, int Fa, float *dst, int Fd, int xd, int xpar, long N, int ny, const L64Y &yy) {
   static AttrOnce attr_once;
   NF_TRY(attr_once.run(ctx->device, [&]() -> int {
     NF_HIP(hipFuncSetAttribute((const void *)k_l64_bwdx_all<IB, OB>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
     return NF_OK;
   }));
-  hipLaunchKernelGGL((k_l64_bwdx_all<IB, OB>), dim3(grid), dim3(512), lds, ctx->stream, theta, L, NG, g, act, Fa, dst, Fd, xd, xpar, N);
+  hipLaunchKernelGGL((k_l64_bwdx_all<IB, OB>), dim3(grid, ny), dim3(512), lds, ctx->stream, theta, L, NG, g, act, Fa, dst, Fd, xd, xpar, N, yy);
   return (int)hipGetLastError();
 }
 // reverse pass of coupling k at x (forward: its input; inv: the inverse's output): gbar updated in place, this coupling's
@@ -1341,20 +1371,30 @@ static int l64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &
   }
   const unsigned grid = l64_grid(ctx, a.N, 4L * ctx->num_cu);
   const unsigned gridw = l64_grid(ctx, a.N, (long)g64_bwd_blocks(desc, a.N));
-  for (int n = 0; n < b.nets; ++n) {
+  const int nym = l64_nets_merge(a, b);
+  for (int n = 0; n < b.nets; n += nym) {
     const G64Net &net = a.net[n];
     for (int l = net.nl - 1; l >= 0; --l) {
       const int nin = net.dims[l], nout = net.dims[l + 1];
       const int IB = l64_ibp(nin), blocks = (nout + 31) / 32;
       // delta of this layer's outputs: the net output's cotangent as is; a hidden layer's through leaky-ReLU'
       const bool top = l == net.nl - 1;
-      const float *gsrc = top ? b.dout[n] : b.gh[(net.nl - 1 - l) & 1];
+      const float *gsrc = top ? b.dout[n] : b.gh[n][(net.nl - 1 - l) & 1];
       const int Fg = top ? b.F[last] : b.GH;
       const float *act = top ? nullptr : b.act[n][l];
-      float *gdst = b.gh[(net.nl - l) & 1];  // cotangent of this layer's inputs (l > 0)
+      float *gdst = b.gh[n][(net.nl - l) & 1];  // cotangent of this layer's inputs (l > 0)
       L64Src av;
       if (l == 0) av = L64Src{x, 0, 0, a.d, 1 - a.par_t};
       else av = L64Src{b.act[n][l - 1], b.F[l - 1], 0, 0, 0};
+      // per-net strides (blockIdx.y): dW kernels (a, g, act), input-cotangent kernels (g, act, dst)
+      const long dth = nym == 2 ? a.net[1].w[l] - a.net[0].w[l] : 0;
+      const long dgs = nym == 2 ? (top ? b.dout[1] - b.dout[0] : b.gh[1][0] - b.gh[0][0]) : 0;
+      const long dac = nym == 2 && !top ? b.act[1][l] - b.act[0][l] : 0;
+      const L64Y yw{dth, nym == 2 && l > 0 ? b.act[1][l - 1] - b.act[0][l - 1] : 0, dgs, dac};
+      const L64Y yx{dth, dgs, dac, nym == 2 ? b.gh[1][0] - b.gh[0][0] : 0};
+      const L64Y y0{0, 0, 0, 0};
+      // the first layer's input cotangent is ADDED to the one conditioner half both nets share: one net after the other
+      const int nyx = l == 0 ? 1 : nym;
       // a layer wider than one launch of k_l64_dw takes: all its columns at once, a column range per wave
       const int OBc = (blocks + 3) / 4;
       static const bool no_cols = std::getenv("NF_L64_NO_DW_COLS") != nullptr;  // A/B switch
@@ -1362,7 +1402,7 @@ static int l64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &
         const L64Layer L{net.w[l], net.b[l], nin, nout, 0};
         const L64Src gs{gsrc, Fg, 0, 0, 0};
         ProfScope ps(ctx, "l64_dw");
-#define CALLC(I, O) NF_TRY((l64_dw_cols_launch<I, O>(ctx, gridw, L, av, gs, act, b.F[l], a.N, slabs, ci.nparams, ci.theta_off)))
+#define CALLC(I, O) NF_TRY((l64_dw_cols_launch<I, O>(ctx, gridw, L, av, gs, act, b.F[l], a.N, slabs, ci.nparams, ci.theta_off, nym, yw)))
         switch (IB * 8 + OBc) {
           case 8 + 1: CALLC(1, 1); break;  case 8 + 2: CALLC(1, 2); break;  case 8 + 3: CALLC(1, 3); break;  case 8 + 4: CALLC(1, 4); break;
           case 16 + 1: CALLC(2, 1); break; case 16 + 2: CALLC(2, 2); break; case 16 + 3: CALLC(2, 3); break; case 16 + 4: CALLC(2, 4); break;
@@ -1376,7 +1416,7 @@ static int l64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &
         const L64Layer L{net.w[l], net.b[l], nin, nout, 32 * ob0};
         const L64Src gs{gsrc, Fg, 32 * ob0, 0, 0};
         ProfScope ps(ctx, "l64_dw");
-#define CALL(I, O) NF_TRY((l64_dw_launch<I, O>(ctx, gridw, L, av, gs, act, b.F[l], a.N, slabs, ci.nparams, ci.theta_off)))
+#define CALL(I, O) NF_TRY((l64_dw_launch<I, O>(ctx, gridw, L, av, gs, act, b.F[l], a.N, slabs, ci.nparams, ci.theta_off, nym, yw)))
         L64_DISPATCH(IB, OBw, CALL);
 #undef CALL
         ob0 += OBw;
@@ -1386,32 +1426,39 @@ static int l64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &
       const int NGa = (blocks + OBa - 1) / OBa;
       const size_t lds_all = (size_t)NGa * (32 * IB * (32 * OBa + NF_IMG_PAD) + 32 * OBa) * sizeof(float);
       static const bool no_all = std::getenv("NF_L64_NO_BWDX_ALL") != nullptr;  // A/B switch
-      if (NGa >= 2 && lds_all <= 144 * 1024 && !no_all) {
-        const L64Layer L{net.w[l], net.b[l], nin, nout, 0};
-        const L64Src gs{gsrc, Fg, 0, 0, 0};
-        const unsigned grid8 = (unsigned)std::min<long>(((a.N + 31) / 32 + 7) / 8, (long)ctx->num_cu);
-        ProfScope ps(ctx, "l64_bwdx");
-#define CALL(I, O) NF_TRY((l64_bwdx_all_launch<I, O>(ctx, grid8, lds_all, theta, L, NGa, gs, act, b.F[l], l == 0 ? gbar : gdst, \
-                                                       l == 0 ? 0 : b.GH, l == 0 ? a.d : 0, l == 0 ? 1 - a.par_t : 0, a.N)))
-        L64_DISPATCH(IB, OBa, CALL);
+      for (int m = 0; m < (l == 0 ? nym : 1); ++m) {  // l == 0: net by net (nyx = 1); else one launch for both (m = 0 only)
+        const G64Net &nm = a.net[n + m];
+        const float *gsrc_m = top ? b.dout[n + m] : b.gh[n + m][(net.nl - 1 - l) & 1];
+        const float *act_m = top ? nullptr : b.act[n + m][l];
+        float *gdst_m = b.gh[n + m][(net.nl - l) & 1];
+        const L64Y &yq = l == 0 ? y0 : yx;
+        if (NGa >= 2 && lds_all <= 144 * 1024 && !no_all) {
+          const L64Layer L{nm.w[l], nm.b[l], nin, nout, 0};
+          const L64Src gs{gsrc_m, Fg, 0, 0, 0};
+          const unsigned grid8 = (unsigned)std::min<long>(((a.N + 31) / 32 + 7) / 8, (long)ctx->num_cu);
+          ProfScope ps(ctx, "l64_bwdx");
+#define CALL(I, O) NF_TRY((l64_bwdx_all_launch<I, O>(ctx, grid8, lds_all, theta, L, NGa, gs, act_m, b.F[l], l == 0 ? gbar : gdst_m, \
+                                                       l == 0 ? 0 : b.GH, l == 0 ? a.d : 0, l == 0 ? 1 - a.par_t : 0, a.N, nyx, yq)))
+          L64_DISPATCH(IB, OBa, CALL);
 #undef CALL
-      } else
-      for (int ob0 = 0, first = 1; ob0 < blocks; first = 0) {
-        const int OB = l64_group(blocks - ob0, l64_maxg(IB, false));
-        const L64Layer L{net.w[l], net.b[l], nin, nout, 32 * ob0};
-        const L64Src gs{gsrc, Fg, 32 * ob0, 0, 0};
-        ProfScope ps(ctx, "l64_bwdx");
-        if (l == 0) {
-#define CALL(I, O) hipLaunchKernelGGL((k_l64_bwdx<I, O>), dim3(grid), dim3(256), 0, ctx->stream, theta, L, gs, act, b.F[l], gbar, 0, 1, a.d, 1 - a.par_t, a.N)
-          L64_DISPATCH(IB, OB, CALL);
+        } else
+        for (int ob0 = 0, first = 1; ob0 < blocks; first = 0) {
+          const int OB = l64_group(blocks - ob0, l64_maxg(IB, false));
+          const L64Layer L{nm.w[l], nm.b[l], nin, nout, 32 * ob0};
+          const L64Src gs{gsrc_m, Fg, 32 * ob0, 0, 0};
+          ProfScope ps(ctx, "l64_bwdx");
+          if (l == 0) {
+#define CALL(I, O) hipLaunchKernelGGL((k_l64_bwdx<I, O>), dim3(grid, nyx), dim3(256), 0, ctx->stream, theta, L, gs, act_m, b.F[l], gbar, 0, 1, a.d, 1 - a.par_t, a.N, yq)
+            L64_DISPATCH(IB, OB, CALL);
 #undef CALL
-        } else {
-#define CALL(I, O) hipLaunchKernelGGL((k_l64_bwdx<I, O>), dim3(grid), dim3(256), 0, ctx->stream, theta, L, gs, act, b.F[l], gdst, b.GH, first ? 0 : 1, 0, 0, a.N)
-          L64_DISPATCH(IB, OB, CALL);
+          } else {
+#define CALL(I, O) hipLaunchKernelGGL((k_l64_bwdx<I, O>), dim3(grid, nyx), dim3(256), 0, ctx->stream, theta, L, gs, act_m, b.F[l], gdst_m, b.GH, first ? 0 : 1, 0, 0, a.N, yq)
+            L64_DISPATCH(IB, OB, CALL);
 #undef CALL
+          }
+          NF_HIP(hipGetLastError());
+          ob0 += OB;
         }
-        NF_HIP(hipGetLastError());
-        ob0 += OB;
       }
     }
   }
