@@ -15,6 +15,12 @@ Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the coupl
 pass, fp32 MFMA bound); `cpu_baseline` is the reference's step under torch-CPU autograd on all host
 cores at the SAME batch (oracle/nf_torch_cpu.py; the Julia reference cannot run on this box).
 
+Timing: W untimed warm-up steps, then -- untimed as well -- the K steps a cold GPU would have been timed on (reported as
+`cold_start`) and `prewarm_steps` more, then EXACTLY K steps between barrier + synchronize: `value`.  A freshly leased
+MI355X needs ~60 cfg-2 steps (40 ms of load) to reach its sustained clocks (tools/bench_ramp.py, profiles/r3n_step_ramp.txt);
+with `--steps 20 --warmup 5` and no pre-warm the timed region is that ramp (0.72 ms per step against 0.62 on the same box).
+`--prewarm 0` gives the old behaviour.
+
 Multi-GPU: one process per GPU.  Under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`
 the ranks come from the environment; a bare `python bench.py --gpus N` starts the N ranks itself (the parent
 never touches a GPU, a failed rank fails the run).  `n_gpus` in the output is the world size the collective
@@ -275,6 +281,11 @@ def run_once(args, world, world_observed, rank, dev, dist, damp, state):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    if not args.no_kernel_events:
+        # create the library's event pool NOW: doing it between the pre-warm and the timed region leaves the GPU idle for
+        # milliseconds, long enough for its clocks to fall back
+        nf._lib.check(lib.nf_prof_enable(ctx.ptr, 1))
+        nf._lib.check(lib.nf_prof_enable(ctx.ptr, 0))
     graph = None
     if use_graph:
         # warm-up eagerly through the device-counter form (sizes the workspace, sets kernel attributes, packs the weights),
@@ -302,14 +313,30 @@ def run_once(args, world, world_observed, rank, dev, dist, damp, state):
         for i in range(args.warmup):
             step(i)
     barrier()
+    first = args.warmup  # index of the first timed step
+    cold_ms = None
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # (before the pre-warm: no idle gap after it)
+    if args.prewarm > 0:
+        # The K steps straight after the W warm-ups, timed like the reported ones: on a freshly leased GPU they ride the clock
+        # ramp (reported as cold_start, never as `value`).  Then the pre-warm steps, untimed.
+        t0c = time.perf_counter()
+        for k in range(args.steps):
+            step(first + k)
+        barrier()
+        cold_ms = 1e3 * (time.perf_counter() - t0c) / args.steps
+        for i in range(args.prewarm):
+            step(first + args.steps + i)
+        first += args.steps + args.prewarm
+        barrier()
     if not args.no_kernel_events and not use_graph:
         # HIP events on the launch stream, over the timed region, around the dominant kernel only
         # (cfg 2: one launch per step; cfg 4: every 4th of its 32 launches per step)
-        nf._lib.check(lib.nf_prof_enable(ctx.ptr, 3 if args.workload == "cfg4" else 1))
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        # mode 3: every 4th launch of the dominant kernel (an event pair between two kernels of one stream drains the queue:
+        # ~30 us per bracketed cfg-2 step, measured A/B with --no-kernel-events; a quarter of the steps carry it now)
+        nf._lib.check(lib.nf_prof_enable(ctx.ptr, 1 if os.environ.get("NF_BENCH_EVENTS_EVERY_STEP") else 3))
     t0 = time.perf_counter()
     marks[0].record()
-    for k, i in enumerate(range(args.warmup, args.warmup + args.steps)):
+    for k, i in enumerate(range(first, first + args.steps)):
         step(i, read_stats=(k == args.steps - 1))
         marks[k + 1].record()  # same stream as the library's launches: per-step device time for the median
     barrier()
@@ -336,7 +363,7 @@ def run_once(args, world, world_observed, rank, dev, dist, damp, state):
     nbreak = 5
     nf._lib.check(lib.nf_prof_enable(ctx.ptr, 2))
     for i in range(nbreak):
-        step(args.warmup + args.steps + i)
+        step(first + args.steps + i)
     torch.cuda.synchronize(dev)
     for name in KERNEL_NAMES:
         a, c = C.c_double(0.0), C.c_int64(0)
@@ -370,6 +397,12 @@ def run_once(args, world, world_observed, rank, dev, dist, damp, state):
             "n_gpus": world_observed,
             "steps": args.steps,
             "warmup": args.warmup,
+            "prewarm_steps": args.prewarm,
+            "cold_start": None if cold_ms is None else {
+                "ms_per_step": cold_ms,
+                "what": f"the {args.steps} steps straight after the {args.warmup} warm-ups, before the {args.prewarm} untimed pre-warm steps: "
+                        "on a freshly leased GPU the clocks are still ramping (steady after ~60 cfg-2 steps, profiles/r3n_step_ramp.txt); "
+                        "`value` is the K steps after the pre-warm"},
             "ms_per_step": ms_per_step,
             "ms_per_step_median": step_ms[len(step_ms) // 2],
             "higher_is_better": True,
@@ -422,6 +455,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--prewarm", type=int, default=None,
+                    help="untimed steps run BEFORE the timed K to bring the GPU's clocks to their sustained state (a cold MI355X "
+                         "needs ~60 cfg-2 steps, profiles/r3n_step_ramp.txt); default per workload (cfg2 120, cfg3 60, cfg4 4), "
+                         "0 = none.  The K steps straight after the W warm-ups are timed as well and reported as cold_start")
     ap.add_argument("--batch", type=int, default=None, help="samples per GPU per step")
     ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg4"), default="cfg2",
                     help="cfg2 = the headline line (default); cfg3 = NSF d=32 K=8, 131072 per GPU; "
@@ -441,6 +478,8 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket kernels with HIP events in the timed region (roofline object is then empty)")
     args = ap.parse_args()
+    if args.prewarm is None:
+        args.prewarm = {"cfg2": 120, "cfg3": 60, "cfg4": 4}[args.workload]
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus))  # the parent only supervises; ranks are fresh processes

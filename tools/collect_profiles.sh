@@ -9,6 +9,10 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 python3 bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
+# the driver's own command line, and the same without the clock pre-warm (what rounds 1-2 reported)
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver_cmd.json" 2>> "$OUT/bench_default.err"
+python3 bench.py --gpus 1 --steps 20 --warmup 5 --prewarm 0 --no-cpu-baseline > "$OUT/bench_driver_cmd_no_prewarm.json" 2>> "$OUT/bench_default.err"
+python3 tools/bench_ramp.py > "$OUT/step_ramp.txt" 2>&1
 python3 bench.py --workload cfg3 --steps 50 --no-cpu-baseline > "$OUT/bench_cfg3.json" 2>> "$OUT/bench_default.err"
 python3 bench.py --workload cfg4 --steps 5 --warmup 2 > "$OUT/bench_cfg4_1gpu_262144.json" 2>> "$OUT/bench_default.err"
 python3 bench.py --workload cfg4 --batch 32768 --steps 10 --warmup 3 > "$OUT/bench_cfg4_shard_32768.json" 2>> "$OUT/bench_default.err"

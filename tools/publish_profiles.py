@@ -20,7 +20,8 @@ copies = [("bench_default.json", "bench_default.json"), ("bench_cfg3.json", "ben
           ("bench_cfg4_1gpu_262144.json", "bench_cfg4_1gpu_262144.json"), ("bench_cfg4_shard_32768.json", "bench_cfg4_shard32768.json"),
           ("configs.txt", "configs.txt"), ("simple.txt", "simple_hbm.txt"),
           ("bench_default_split_calls.json", "bench_default_split_calls.json"), ("bench_default_graph.json", "bench_default_graph.json"),
-          ("bench_default_one_wave_per_tile.json", "bench_default_one_wave_per_tile.json"), ("simple_no_mfma.txt", "simple_no_mfma.txt")]
+          ("bench_default_one_wave_per_tile.json", "bench_default_one_wave_per_tile.json"), ("simple_no_mfma.txt", "simple_no_mfma.txt"),
+          ("bench_driver_cmd.json", "bench_driver_cmd.json"), ("bench_driver_cmd_no_prewarm.json", "bench_driver_cmd_no_prewarm.json")]
 for w in ("cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "simple"):
     copies.append((f"kt_{w}/{w}_kernel_stats.csv", f"kernel_stats_{w}.csv"))
 for a, b in copies:
