@@ -757,10 +757,25 @@ struct L64Bin {
   float x0, x1;     // knots p[k], p[k + 1]
   float sm;         // softmax term of the bin
 };
+// the 3K - 1 rows of one (tile, dimension) through a buffer descriptor of the tile (wave-uniform) and a per-lane offset to
+// this thread's dimension and sample: row i at scalar offset i * 128 bytes; the same addressing for the cotangent rows
 struct L64Raw {
-  const float *base;  // tile base of this (tile, dimension): element i at base[i * 32] (row stride of the tile)
-  __device__ __forceinline__ float operator()(int i) const { return base[(long)i << 5]; }
+  __amdgpu_buffer_rsrc_t rs;
+  int voff;
+  __device__ __forceinline__ float operator()(int i) const {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, i * (L64_TILE * 4), 0));
+  }
+  __device__ __forceinline__ void put(int i, float v) const {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, i * (L64_TILE * 4), 0);
+  }
 };
+// rows [row0, ...) of tile `tile` of a tiled buffer with F rows, for the thread of sample `smp`
+__device__ __forceinline__ L64Raw l64_raw(const float *buf, int F, long tile, int row0, int smp) {
+  L64Raw r;
+  r.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(buf) + tile * F * L64_TILE, 0, F * L64_TILE * 4, 0x00020000);
+  r.voff = (row0 * L64_TILE + smp) * 4;
+  return r;
+}
 template <int KM>
 struct L64Par {
   float w[KM], h[KM], dv[KM];  // widths, heights, interior derivatives (K - 1 of them) as the net wrote them
@@ -878,7 +893,7 @@ __device__ __forceinline__ float l64_spline_apply(const L64Raw &raw, int K, floa
 // reverse pass at x (g64_spline_bwd's algebra); writes the 3K - 1 parameter cotangents to out (tile rows, stride 32) and
 // returns xbar (inv: the cotangent of the inverse's input, see g64_spline_bwd)
 template <int KM>
-__device__ __forceinline__ float l64_spline_bwd(const L64Raw &raw, float *__restrict__ out, int K, float B, float x, float ybar, float lbar,
+__device__ __forceinline__ float l64_spline_bwd(const L64Raw &raw, const L64Raw &out, int K, float B, float x, float ybar, float lbar,
                                                 bool inv) {
   L64Par<KM> q;
   l64_load_par<KM>(raw, K, q);
@@ -889,8 +904,8 @@ __device__ __forceinline__ float l64_spline_bwd(const L64Raw &raw, float *__rest
   if (b.k < 0) {
 #pragma unroll
     for (int i = 0; i < KM; ++i) {
-      if (i < K) { out[(long)i << 5] = 0.f; out[(long)(K + i) << 5] = 0.f; }
-      if (i < K - 1) out[(long)(2 * K + i) << 5] = 0.f;
+      if (i < K) { out.put(i, 0.f); out.put(K + i, 0.f); }
+      if (i < K - 1) out.put(2 * K + i, 0.f);
     }
     return ybar;
   }
@@ -931,8 +946,8 @@ __device__ __forceinline__ float l64_spline_bwd(const L64Raw &raw, float *__rest
   for (int i = 0; i < KM; ++i)
     if (i < K) {
       const float smw = expf(q.w[i] - mxw) * invw, smh = expf(q.h[i] - mxh) * invh;
-      out[(long)i << 5] = smw * ((i < k ? aw : i == k ? bw : 0.f) - dotw);
-      out[(long)(K + i) << 5] = smh * ((i < k ? ah : i == k ? bh : 0.f) - doth);
+      out.put(i, smw * ((i < k ? aw : i == k ? bw : 0.f) - dotw));
+      out.put(K + i, smh * ((i < k ? ah : i == k ? bh : 0.f) - doth));
     }
 #pragma unroll
   for (int i = 0; i < KM; ++i)
@@ -940,7 +955,7 @@ __device__ __forceinline__ float l64_spline_bwd(const L64Raw &raw, float *__rest
       float t = 0.f;
       if (i == k - 1) t = d0bar * l64_sigmoid(q.dv[i]);
       if (i == k) t = d1bar * l64_sigmoid(q.dv[i]);
-      out[(long)(2 * K + i) << 5] = t;
+      out.put(2 * K + i, t);
     }
   return inv ? vbar : xibar / dx;
 }
@@ -969,7 +984,7 @@ __global__ __launch_bounds__(256) void k_l64_couple_fwd(G64Args a, int inverse, 
     } else {
       const int P = 3 * a.K - 1;
       for (int p = dl; p < a.c; p += L64_DL) {
-        const L64Raw raw{os + ((((j >> 5) * Fs + (long)p * P) << 5) + (j & 31))};
+        const L64Raw raw = l64_raw(os, Fs, blockIdx.x, p * P, smp);
         const float v = r[2 * p + a.par_t];
         r[2 * p + a.par_t] = l64_spline_apply<KM>(raw, a.K, (float)a.B, v, inverse != 0, lsum);
       }
@@ -1022,9 +1037,8 @@ __global__ __launch_bounds__(256) void k_l64_couple_bwd(G64Args a, int inv, cons
     }
   } else {
     for (int p = dl; p < a.c; p += L64_DL) {
-      const long e0 = (((j >> 5) * Fs + (long)p * P) << 5) + (j & 31);
-      const L64Raw raw{os + e0};
-      gr[2 * p + a.par_t] = l64_spline_bwd<KM>(raw, ds + e0, a.K, (float)a.B, xr[2 * p + a.par_t], gr[2 * p + a.par_t], lb, inv != 0);
+      const L64Raw raw = l64_raw(os, Fs, blockIdx.x, p * P, smp), out = l64_raw(ds, Fs, blockIdx.x, p * P, smp);
+      gr[2 * p + a.par_t] = l64_spline_bwd<KM>(raw, out, a.K, (float)a.B, xr[2 * p + a.par_t], gr[2 * p + a.par_t], lb, inv != 0);
     }
   }
 }
