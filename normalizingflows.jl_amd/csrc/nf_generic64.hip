@@ -694,9 +694,9 @@ __global__ __launch_bounds__(256) void k_l64_dw_cols(L64Layer L, L64Src a, L64Sr
   constexpr int SA = IB * 32 * NF_TS, SD = OB * 32 * NF_TS;
   L.w_off += blockIdx.y * yy.dtheta; L.b_off += blockIdx.y * yy.dtheta; a.p += blockIdx.y * yy.da; g.p += blockIdx.y * yy.db;
   if (act) act += blockIdx.y * yy.dc;
-  extern __shared__ __attribute__((aligned(16))) float sm[];  // 4 (SA + SD) floats
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // SA + 4 SD floats: ONE activation tile, a delta tile per wave
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-  float *sa = sm + wave * (SA + SD), *sd = sa + SA;
+  float *sa = sm, *sd = sm + SA + wave * SD;
   const int o0w = 32 * OB * wave;
   f32x16 acc[IB][OB];
   float bsum[OB];
@@ -712,14 +712,35 @@ __global__ __launch_bounds__(256) void k_l64_dw_cols(L64Layer L, L64Src a, L64Sr
   gw.row0 = g.row0 + o0w;
   const long ntiles = (N + L64_TILE - 1) / L64_TILE;
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    f32x16 av[IB], dl[OB];
-    l64_load<IB>(a, tile, l31, hi, N, L.nin, av);
+    // the activation tile is shared: wave w fetches and places registers 4w .. 4w+3 of every block (rows 8w + {0..3} + 4 hi)
+    float aq[IB][4];
+    if (a.d > 0) {
+      const L64Io io = l64_io_std(a.p, a.d, a.par, tile, N, l31, hi);
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int rc = 32 * ib + 8 * wave + e;
+          const float x = l64_ld(io, rc * 8);
+          aq[ib][e] = rc + 4 * hi < L.nin ? x : 0.f;
+        }
+    } else {
+      const L64Io io = l64_io_tiled(a.p, a.F, a.row0, tile, l31, hi);
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) aq[ib][e] = l64_ld(io, (32 * ib + 8 * wave + e) * (L64_TILE * 4));
+    }
+    f32x16 dl[OB];
     l64_delta<OB>(gw, act, Fa, L.o0 + o0w, tile, l31, hi, N, dl);
-    tile_to_scratch<IB>(sa, av, l31, hi);
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sa[(32 * ib + 8 * wave + e + 4 * hi) * NF_TS + l31] = aq[ib][e];
     tile_to_scratch<OB>(sd, dl, l31, hi);
-    wave_lds_fence();
+    __syncthreads();
     dw_accumulate<IB, OB>(sa, sd, acc, bsum, l31, hi);
-    wave_lds_fence();
+    __syncthreads();  // every wave is done with the shared tile before the next one lands
   }
   float *slab = slabs + (long)blockIdx.x * Pc - slab_off;
 #pragma unroll
@@ -1343,7 +1364,7 @@ static int l64_dw_launch(nf_ctx *ctx, unsigned grid, const L64Layer &L, const L6
 template <int IB, int OB>
 static int l64_dw_cols_launch(nf_ctx *ctx, unsigned grid, const L64Layer &L, const L64Src &av, const L64Src &g, const float *act, int Fa, long N,
                               float *slabs, long Pc, long slab_off, int ny, const L64Y &yy) {
-  const size_t lds = (size_t)4 * (IB + OB) * 32 * NF_TS * sizeof(float);
+  const size_t lds = (size_t)(IB + 4 * OB) * 32 * NF_TS * sizeof(float);
   static AttrOnce attr_once;
   NF_TRY(attr_once.run(ctx->device, [&]() -> int {
     NF_HIP(hipFuncSetAttribute((const void *)k_l64_dw_cols<IB, OB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
