@@ -503,6 +503,49 @@ __global__ __launch_bounds__(512) void k_l64_fwd_all(const float *__restrict__ t
   }
 }
 
+// Consecutive NARROW layers (every width <= 64) of a net in one launch: all their weight blocks in LDS, a tile's activations
+// chained through registers from layer to layer (each layer's output still goes to its tile buffer -- the reverse pass reads
+// it), eight waves per workgroup.  (Tried in the first form of these kernels, one wavefront per SIMD and 64-bit addressing:
+// no gain; with the buffer-descriptor I/O the launches it saves count.)
+#define L64_CHAIN_MAX (NF_MAX_HIDDEN + 1)
+struct L64Chain {
+  int nl;
+  long w_off[L64_CHAIN_MAX], b_off[L64_CHAIN_MAX];
+  int nin[L64_CHAIN_MAX], nout[L64_CHAIN_MAX], act[L64_CHAIN_MAX], F[L64_CHAIN_MAX];
+  float *dst[L64_CHAIN_MAX];
+};
+__global__ __launch_bounds__(512) void k_l64_fwd_chain(const float *__restrict__ theta, L64Chain ch, L64Src src, long N, L64Y yy) {
+  constexpr int S = 64 + NF_IMG_PAD, WG = 64 * S + 64;
+  extern __shared__ __attribute__((aligned(16))) float wdyn[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  src.p += blockIdx.y * yy.da;
+  for (int l = 0; l < ch.nl; ++l) {
+    const L64Layer L{ch.w_off[l] + (long)blockIdx.y * yy.dtheta, ch.b_off[l] + (long)blockIdx.y * yy.dtheta, ch.nin[l], ch.nout[l], 0};
+    l64_stage<2, 2>(wdyn + l * WG, wdyn + l * WG + 64 * S, theta, L, tid, 512);
+  }
+  __syncthreads();
+  const long ntiles = (N + L64_TILE - 1) / L64_TILE;
+  for (long tile = (long)blockIdx.x * 8 + wave; tile < ntiles; tile += (long)gridDim.x * 8) {
+    f32x16 cur[2];
+    l64_load<2>(src, tile, l31, hi, N, ch.nin[0], cur);
+#pragma unroll 1
+    for (int l = 0; l < ch.nl; ++l) {
+      f32x16 out[2];
+      dense_fwd<2, 2, S>(wdyn + l * WG, wdyn + l * WG + 64 * S, cur, out, l31, hi);
+      const L64Io od = l64_io_tiled(ch.dst[l] + blockIdx.y * yy.db, ch.F[l], 0, tile, l31, hi);
+      const int act = ch.act[l];
+#pragma unroll
+      for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = act ? nf_lrelu(out[ob][r]) : out[ob][r];
+          cur[ob][r] = v;  // rows past the layer's outputs are 0 (zero weights, zero bias): the next layer's padding
+          l64_st(od, l64_rc(ob, r) * (L64_TILE * 4), v);
+        }
+    }
+  }
+}
+
 // delta of a layer's output rows: the stored cotangent, times leaky-ReLU' from the sign of the stashed post-activation
 template <int OB>
 __device__ __forceinline__ void l64_delta(const L64Src &g, const float *__restrict__ act, int Fa, int o0, long tile, int l31, int hi,
@@ -614,6 +657,53 @@ __global__ __launch_bounds__(512) void k_l64_bwdx_all(const float *__restrict__ 
       dense_bwd_x<IB, OB, S, true>(wdyn + q * WG, dl, din, l31, hi);
     }
     l64_store_din<IB>(din, dst, Fd, 0, xd, xpar, L.nin, tile, N, l31, hi);
+  }
+}
+
+// The input cotangents of consecutive NARROW layers (widths <= 64), top down, in one launch: layer q's delta from the cotangent
+// in registers and the sign of its stashed outputs, din = W' delta, stored (the dW kernel of the layer below reads it) and
+// carried on as the next layer's cotangent.  Entry 0 of the chain is the highest layer.
+struct L64BChain {
+  int nl;
+  long w_off[L64_CHAIN_MAX];
+  int nin[L64_CHAIN_MAX], nout[L64_CHAIN_MAX], Fa[L64_CHAIN_MAX];
+  const float *act[L64_CHAIN_MAX];  // the layer's stashed outputs (null: the net's output layer, no activation)
+  float *dst[L64_CHAIN_MAX];        // cotangent of the layer's inputs (Fd rows)
+};
+__global__ __launch_bounds__(512) void k_l64_bwdx_chain(const float *__restrict__ theta, L64BChain ch, L64Src gtop, int Fd, long N, L64Y yy) {
+  constexpr int S = 64 + NF_IMG_PAD, WG = 64 * S + 64;
+  extern __shared__ __attribute__((aligned(16))) float wdyn[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  gtop.p += blockIdx.y * yy.da;
+  for (int q = 0; q < ch.nl; ++q) {
+    const L64Layer L{ch.w_off[q] + (long)blockIdx.y * yy.dtheta, 0, ch.nin[q], ch.nout[q], 0};
+    l64_stage<2, 2>(wdyn + q * WG, wdyn + q * WG + 64 * S, theta, L, tid, 512);  // (the bias row is staged and not used)
+  }
+  __syncthreads();
+  const long ntiles = (N + L64_TILE - 1) / L64_TILE;
+  for (long tile = (long)blockIdx.x * 8 + wave; tile < ntiles; tile += (long)gridDim.x * 8) {
+    f32x16 g[2];
+    l64_load<2>(gtop, tile, l31, hi, N, 64, g);
+#pragma unroll 1
+    for (int q = 0; q < ch.nl; ++q) {
+      if (ch.act[q]) {
+        const L64Io ai = l64_io_tiled(ch.act[q] + blockIdx.y * yy.db, ch.Fa[q], 0, tile, l31, hi);
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) g[ob][r] *= l64_ld(ai, l64_rc(ob, r) * (L64_TILE * 4)) > 0.f ? 1.f : 0.01f;
+      }
+      f32x16 din[2];
+      dense_bwd_x<2, 2, S, false>(wdyn + q * WG, g, din, l31, hi);
+      const L64Io od = l64_io_tiled(ch.dst[q] + blockIdx.y * yy.dc, Fd, 0, tile, l31, hi);
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          l64_st(od, l64_rc(ib, r) * (L64_TILE * 4), din[ib][r]);
+          g[ib][r] = din[ib][r];
+        }
+    }
   }
 }
 
@@ -1197,7 +1287,8 @@ static int l64_gh_rows(const nf_flow_desc *desc) {  // rows of the two hidden-co
 }
 // scratch floats per sample: per COUPLING the nets' stashed layer outputs (a reverse pass that follows a kept forward --
 // g64_forward_keep -- reads them back instead of evaluating the nets again, so every coupling has its own slot); shared by
-// all couplings: per net the output cotangent and two hidden cotangent buffers (the nets' reverse passes run side by side)
+// all couplings: per net the output cotangent and one cotangent buffer per hidden layer (the nets' reverse passes run side by side,
+// and the input-cotangent chain of the narrow layers leaves all of them behind at once)
 static size_t l64_act_floats_per_sample(const nf_flow_desc *desc) {
   const int c = (desc->d + 1) / 2;
   const int nout = desc->kind == NF_KIND_REALNVP ? c : (3 * desc->K - 1) * c;
@@ -1209,7 +1300,7 @@ static size_t l64_shared_floats_per_sample(const nf_flow_desc *desc) {
   const int c = (desc->d + 1) / 2;
   const int nout = desc->kind == NF_KIND_REALNVP ? c : (3 * desc->K - 1) * c;
   const int nets = desc->kind == NF_KIND_REALNVP ? 2 : 1;
-  return nets * ((size_t)l64_pad32(nout) + 2 * (size_t)l64_gh_rows(desc));
+  return nets * ((size_t)l64_pad32(nout) + (size_t)desc->n_hidden * l64_gh_rows(desc));
 }
 // layout: [shared | slot 0 | slot 1 | ...]; `slots` of them (a stand-alone forward needs one, a kept forward all 2 nlayers)
 static size_t l64_scratch_bytes_for(const nf_flow_desc *desc, long N, int slots) {
@@ -1223,7 +1314,7 @@ size_t nf_l64_scratch_bytes(const nf_flow_desc *desc, long N) {  // what nf_work
 struct L64Bufs {
   float *act[2][NF_MAX_HIDDEN + 1];  // [net][layer]: tiled outputs (the last one: the net's output)
   int F[NF_MAX_HIDDEN + 1];          // rows of those tiles
-  float *dout[2], *gh[2][2];         // per net: output cotangent; two hidden cotangent buffers of GH rows
+  float *dout[2], *gh[2][NF_MAX_HIDDEN];  // per net: output cotangent; gh[n][l] = cotangent of hidden layer l's outputs (GH rows)
   int nets, nl, GH;
 };
 // slot: the coupling whose activation area the call uses (flat index; stand-alone calls use any, they do not look back)
@@ -1246,7 +1337,7 @@ static int l64_bufs(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a, L64
   for (int n = 0; n < b->nets; ++n) { b->dout[n] = p; p += Np * out_rows; }
   b->GH = l64_gh_rows(desc);
   for (int n = 0; n < b->nets; ++n)
-    for (int i = 0; i < 2; ++i) { b->gh[n][i] = p; p += Np * b->GH; }
+    for (int i = 0; i < desc->n_hidden; ++i) { b->gh[n][i] = p; p += Np * b->GH; }
   p += (size_t)slot * Np * l64_act_floats_per_sample(desc);
   for (int n = 0; n < b->nets; ++n)
     for (int l = 0; l < b->nl; ++l) { b->act[n][l] = p; p += Np * b->F[l]; }
@@ -1300,7 +1391,32 @@ static int l64_nets_fwd(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a,
   const int ny = l64_nets_merge(a, b);  // RealNVP: both nets in one launch (blockIdx.y), per-net strides in yy
   for (int n = 0; n < b.nets; n += ny) {
     const G64Net &net = a.net[n];
-    for (int l = 0; l < net.nl; ++l) {
+    // the leading run of narrow layers (widths <= 64) in one launch
+    int lc = 0;
+    static const bool no_chain = std::getenv("NF_L64_NO_FWD_CHAIN") != nullptr;  // A/B switch
+    while (lc < net.nl && net.dims[lc] <= 64 && net.dims[lc + 1] <= 64) ++lc;
+    if (lc < 2 || no_chain) lc = 0;
+    if (lc) {
+      L64Chain ch;
+      ch.nl = lc;
+      for (int l = 0; l < lc; ++l) {
+        ch.w_off[l] = net.w[l]; ch.b_off[l] = net.b[l]; ch.nin[l] = net.dims[l]; ch.nout[l] = net.dims[l + 1];
+        ch.act[l] = l < net.nl - 1 ? 1 : 0; ch.F[l] = b.F[l]; ch.dst[l] = b.act[n][l];
+      }
+      const L64Src src{x, 0, 0, a.d, 1 - a.par_t};
+      const L64Y yy{ny == 2 ? a.net[1].w[0] - a.net[0].w[0] : 0, 0, ny == 2 ? b.act[1][0] - b.act[0][0] : 0, 0};
+      const size_t lds = (size_t)lc * (64 * (64 + NF_IMG_PAD) + 64) * sizeof(float);
+      static AttrOnce attr_once;
+      NF_TRY(attr_once.run(ctx->device, [&]() -> int {
+        NF_HIP(hipFuncSetAttribute((const void *)k_l64_fwd_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+        return NF_OK;
+      }));
+      const unsigned grid8 = (unsigned)std::min<long>(((a.N + 31) / 32 + 7) / 8, 2L * ctx->num_cu);
+      ProfScope ps(ctx, "l64_fwd");
+      hipLaunchKernelGGL(k_l64_fwd_chain, dim3(grid8, ny), dim3(512), lds, ctx->stream, theta, ch, src, a.N, yy);
+      NF_HIP(hipGetLastError());
+    }
+    for (int l = lc; l < net.nl; ++l) {
       const int nin = net.dims[l], nout = net.dims[l + 1];
       const int IB = l64_ibp(nin), blocks = (nout + 31) / 32;
       L64Src src;
@@ -1409,15 +1525,20 @@ static int l64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &
   const int nym = l64_nets_merge(a, b);
   for (int n = 0; n < b.nets; n += nym) {
     const G64Net &net = a.net[n];
+    // layers 1 .. ct are narrow (widths <= 64): their input cotangents in one launch (k_l64_bwdx_chain)
+    int ct = 0;
+    static const bool no_bchain = std::getenv("NF_L64_NO_BWDX_CHAIN") != nullptr;  // A/B switch
+    while (ct + 1 < net.nl && net.dims[ct + 1] <= 64 && net.dims[ct + 2] <= 64) ++ct;
+    if (ct < 2 || no_bchain) ct = 0;
     for (int l = net.nl - 1; l >= 0; --l) {
       const int nin = net.dims[l], nout = net.dims[l + 1];
       const int IB = l64_ibp(nin), blocks = (nout + 31) / 32;
       // delta of this layer's outputs: the net output's cotangent as is; a hidden layer's through leaky-ReLU'
       const bool top = l == net.nl - 1;
-      const float *gsrc = top ? b.dout[n] : b.gh[n][(net.nl - 1 - l) & 1];
+      const float *gsrc = top ? b.dout[n] : b.gh[n][l];
       const int Fg = top ? b.F[last] : b.GH;
       const float *act = top ? nullptr : b.act[n][l];
-      float *gdst = b.gh[n][(net.nl - l) & 1];  // cotangent of this layer's inputs (l > 0)
+      float *gdst = l > 0 ? b.gh[n][l - 1] : nullptr;  // cotangent of this layer's inputs = of layer l - 1's outputs
       L64Src av;
       if (l == 0) av = L64Src{x, 0, 0, a.d, 1 - a.par_t};
       else av = L64Src{b.act[n][l - 1], b.F[l - 1], 0, 0, 0};
@@ -1456,6 +1577,30 @@ static int l64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &
 #undef CALL
         ob0 += OBw;
       }
+      if (ct && l >= 1 && l <= ct) {
+        if (l == ct) {  // the chain, once, from its highest layer down to layer 1
+          L64BChain ch;
+          ch.nl = ct;
+          for (int q = 0; q < ct; ++q) {
+            const int lq = ct - q;
+            ch.w_off[q] = net.w[lq]; ch.nin[q] = net.dims[lq]; ch.nout[q] = net.dims[lq + 1];
+            ch.act[q] = lq == net.nl - 1 ? nullptr : b.act[n][lq]; ch.Fa[q] = b.F[lq]; ch.dst[q] = b.gh[n][lq - 1];
+          }
+          const L64Src gtop{gsrc, Fg, 0, 0, 0};
+          const L64Y yc{dth, dgs, nym == 2 ? b.act[1][0] - b.act[0][0] : 0, nym == 2 ? b.gh[1][0] - b.gh[0][0] : 0};
+          const size_t lds = (size_t)ct * (64 * (64 + NF_IMG_PAD) + 64) * sizeof(float);
+          static AttrOnce attr_once;
+          NF_TRY(attr_once.run(ctx->device, [&]() -> int {
+            NF_HIP(hipFuncSetAttribute((const void *)k_l64_bwdx_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+            return NF_OK;
+          }));
+          const unsigned grid8 = (unsigned)std::min<long>(((a.N + 31) / 32 + 7) / 8, 2L * ctx->num_cu);
+          ProfScope ps(ctx, "l64_bwdx");
+          hipLaunchKernelGGL(k_l64_bwdx_chain, dim3(grid8, nym), dim3(512), lds, ctx->stream, theta, ch, gtop, b.GH, a.N, yc);
+          NF_HIP(hipGetLastError());
+        }
+        continue;
+      }
       // every output block in one launch when the layer's weight blocks fit LDS side by side
       const int OBa = l64_maxg(IB, false) >= 4 ? 4 : l64_maxg(IB, false);
       const int NGa = (blocks + OBa - 1) / OBa;
@@ -1463,9 +1608,9 @@ static int l64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &
       static const bool no_all = std::getenv("NF_L64_NO_BWDX_ALL") != nullptr;  // A/B switch
       for (int m = 0; m < (l == 0 ? nym : 1); ++m) {  // l == 0: net by net (nyx = 1); else one launch for both (m = 0 only)
         const G64Net &nm = a.net[n + m];
-        const float *gsrc_m = top ? b.dout[n + m] : b.gh[n + m][(net.nl - 1 - l) & 1];
+        const float *gsrc_m = top ? b.dout[n + m] : b.gh[n + m][l];
         const float *act_m = top ? nullptr : b.act[n + m][l];
-        float *gdst_m = b.gh[n + m][(net.nl - l) & 1];
+        float *gdst_m = l > 0 ? b.gh[n + m][l - 1] : nullptr;
         const L64Y &yq = l == 0 ? y0 : yx;
         if (NGa >= 2 && lds_all <= 144 * 1024 && !no_all) {
           const L64Layer L{nm.w[l], nm.b[l], nin, nout, 0};
