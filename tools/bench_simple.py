@@ -28,16 +28,21 @@ for kind in ("planar", "radial"):
     def step(i):
         nf._lib.check(lib.nf_elbo_value_and_grad(ctx.ptr, C.byref(flow.desc), C.byref(tgt.c), vp(flow.theta), None, N, N, 1, 0, i, vp(out)))
 
-    for i in range(3):
+    # the event pool first (its creation idles the GPU for milliseconds), then enough steps for the clocks to reach their
+    # sustained state (a cold MI355X needs ~40 ms of load: profiles/r3n_step_ramp.txt), then the timed steps
+    lib.nf_prof_enable(ctx.ptr, 2)
+    lib.nf_prof_enable(ctx.ptr, 0)
+    for i in range(300):
         step(i)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(10):
-        step(3 + i)
+    for i in range(100):
+        step(300 + i)
     torch.cuda.synchronize()
-    el = (time.perf_counter() - t0) / 10
+    el = (time.perf_counter() - t0) / 100
     lib.nf_prof_enable(ctx.ptr, 2)
-    step(20)
+    for i in range(20):
+        step(400 + i)
     torch.cuda.synchronize()
     row = N * d * 4
     lpp = 4  # layers per pass of the reverse kernel (float, d = 64)
