@@ -15,11 +15,13 @@ Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the coupl
 pass, fp32 MFMA bound); `cpu_baseline` is the reference's step under torch-CPU autograd on all host
 cores at the SAME batch (oracle/nf_torch_cpu.py; the Julia reference cannot run on this box).
 
-Timing: W untimed warm-up steps, then -- untimed as well -- the K steps a cold GPU would have been timed on (reported as
-`cold_start`) and `prewarm_steps` more, then EXACTLY K steps between barrier + synchronize: `value`.  A freshly leased
-MI355X needs ~60 cfg-2 steps (40 ms of load) to reach its sustained clocks (tools/bench_ramp.py, profiles/r3n_step_ramp.txt);
-with `--steps 20 --warmup 5` and no pre-warm the timed region is that ramp (0.72 ms per step against 0.62 on the same box).
-`--prewarm 0` gives the old behaviour.
+Timing: W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize: `value`, `ms_per_step` and
+`roofline.frac` are those K steps -- the driver's protocol, nothing inserted.  On an MI355X that has been idle (even for 50 ms)
+the shader clock DROPS from 2.4 GHz to 1.6-2.0 GHz when the load arrives and takes ~40 cfg-2 steps (25 ms) to come back
+(tools/bench_ramp.py reads the clock next to every step: profiles/r4a_step_ramp_clocks.txt; step time x clock is constant), so
+with `--steps 20 --warmup 5` the timed region rides that ramp.  What a training run of thousands of steps sees is reported
+NEXT to it, never as `value`: after the timed region `--prewarm` more untimed steps and K more timed ones ->
+`value_sustained_clock`, `ms_per_step_sustained_clock`, `roofline.frac_sustained_clock` (`--prewarm 0` skips that).
 
 Multi-GPU: one process per GPU.  Under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`
 the ranks come from the environment; a bare `python bench.py --gpus N` starts the N ranks itself (the parent
@@ -195,8 +197,7 @@ def launch_ranks(n: int) -> int:
 
 
 def run_once(args, world, world_observed, rank, dev, dist, damp, state):
-    """One timed run of the selected workload; rank 0 prints one JSON line.  `state` carries the library communicator
-    from one run to the next (cfg 4 prints two lines: bench initialisation and the damped one the parity tests judge)."""
+    """One timed run of the selected workload; rank 0 prints one JSON line."""
     nf = load_package()
     lib = nf.load_library()
     n_local, n_global = args.batch, args.batch * world
@@ -209,6 +210,8 @@ def run_once(args, world, world_observed, rank, dev, dist, damp, state):
     var = (torch.rand(D, generator=g0) + 1e-3).to(dev)
     target = nf.DiagGaussTarget(mu, var)
     ctx = nf.context_for(dev)
+    # the timed loop owns theta between steps, exactly like train_flow's (objectives._optimize_fused), and opts in the same way
+    nf._lib.check(lib.nf_ctx_set_weight_cache(ctx.ptr, 1))
     P = flow.P
     theta = flow.theta.clone()
     m, v = torch.zeros_like(theta), torch.zeros_like(theta)
@@ -234,18 +237,36 @@ def run_once(args, world, world_observed, rank, dev, dist, damp, state):
         # every rank must take the same route: if the library's communicator does not come up on ANY rank (it has never met
         # a multi-GPU node), all ranks keep the process group's RCCL all-reduce and the output says so
         ok = torch.ones(1, dtype=torch.int32, device=dev)
-        try:
-            nf._lib.check(lib.nf_comm_init_rank(ctx.ptr, raw, world, rank))
-        except Exception as e:  # noqa: BLE001
+        # the init runs in a watchdog thread (ctypes releases the GIL): ncclCommInitRank is collective, so a rank that cannot
+        # join would otherwise block every other rank inside it for ever.  A rank whose init has not returned after
+        # NF_COMM_INIT_TIMEOUT seconds votes "failed" below and abandons the thread; the run then ends with os._exit.
+        import threading
+
+        res = {}
+
+        def _init():
+            try:
+                nf._lib.check(lib.nf_comm_init_rank(ctx.ptr, raw, world, rank))
+                res["ok"] = True
+            except Exception as e:  # noqa: BLE001
+                res["err"] = str(e)
+
+        th = threading.Thread(target=_init, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("NF_COMM_INIT_TIMEOUT", "120")))
+        if th.is_alive():
+            res["err"] = "nf_comm_init_rank did not return (timeout)"
+            state["lib_comm_hung"] = True
+        if "err" in res:
             ok.zero_()
-            state["lib_comm_error"] = f"rank {rank}: {e}"
-            print(f"[bench] nf_comm_init_rank failed on rank {rank}: {e}", file=sys.stderr, flush=True)
+            state["lib_comm_error"] = f"rank {rank}: {res['err']}"
+            print(f"[bench] nf_comm_init_rank failed on rank {rank}: {res['err']}", file=sys.stderr, flush=True)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         lib_comm = bool(int(ok.item()))
         state["lib_comm"] = lib_comm
         if not lib_comm:
             state["lib_comm_failed"] = True
-            if int(lib.nf_comm_size(ctx.ptr)) > 1:
+            if not state.get("lib_comm_hung") and int(lib.nf_comm_size(ctx.ptr)) > 1:
                 lib.nf_comm_destroy(ctx.ptr)
     comm_size = int(lib.nf_comm_size(ctx.ptr))
     if lib_comm and comm_size != world:
@@ -314,38 +335,41 @@ def run_once(args, world, world_observed, rank, dev, dist, damp, state):
             step(i)
     barrier()
     first = args.warmup  # index of the first timed step
-    cold_ms = None
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # (before the pre-warm: no idle gap after it)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(2 * (args.steps + 1))]
+
+    def timed_region(first_step: int, marks_off: int):
+        """EXACTLY K steps between barrier + synchronize (max over ranks), with the dominant kernel bracketed by HIP events on
+        the launch stream (every 4th launch: an event pair between two kernels of one stream drains the queue, ~30 us per
+        bracketed cfg-2 step, measured A/B with --no-kernel-events).  Returns (elapsed s, sorted per-step ms, kernel avg ms, n)."""
+        if not args.no_kernel_events and not use_graph:
+            nf._lib.check(lib.nf_prof_enable(ctx.ptr, 1 if os.environ.get("NF_BENCH_EVENTS_EVERY_STEP") else 3))
+        barrier()
+        t0 = time.perf_counter()
+        marks[marks_off].record()
+        for k, i in enumerate(range(first_step, first_step + args.steps)):
+            step(i, read_stats=(k == args.steps - 1))
+            marks[marks_off + k + 1].record()  # same stream as the library's launches: per-step device time for the median
+        barrier()
+        el = time.perf_counter() - t0
+        per_step = sorted(marks[marks_off + k].elapsed_time(marks[marks_off + k + 1]) for k in range(args.steps))
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t[0])
+        a_ms, c_n = C.c_double(0.0), C.c_int64(0)
+        nf._lib.check(lib.nf_prof_read(ctx.ptr, DOMINANT[0], C.byref(a_ms), C.byref(c_n)))
+        return el, per_step, a_ms.value, c_n.value
+
+    elapsed, step_ms, dom_ms, dom_cnt = timed_region(first, 0)
+    first += args.steps
+    sustained = None
     if args.prewarm > 0:
-        # The K steps straight after the W warm-ups, timed like the reported ones: on a freshly leased GPU they ride the clock
-        # ramp (reported as cold_start, never as `value`).  Then the pre-warm steps, untimed.
-        t0c = time.perf_counter()
-        for k in range(args.steps):
-            step(first + k)
-        barrier()
-        cold_ms = 1e3 * (time.perf_counter() - t0c) / args.steps
         for i in range(args.prewarm):
-            step(first + args.steps + i)
-        first += args.steps + args.prewarm
-        barrier()
-    if not args.no_kernel_events and not use_graph:
-        # HIP events on the launch stream, over the timed region, around the dominant kernel only
-        # (cfg 2: one launch per step; cfg 4: every 4th of its 32 launches per step)
-        # mode 3: every 4th launch of the dominant kernel (an event pair between two kernels of one stream drains the queue:
-        # ~30 us per bracketed cfg-2 step, measured A/B with --no-kernel-events; a quarter of the steps carry it now)
-        nf._lib.check(lib.nf_prof_enable(ctx.ptr, 1 if os.environ.get("NF_BENCH_EVENTS_EVERY_STEP") else 3))
-    t0 = time.perf_counter()
-    marks[0].record()
-    for k, i in enumerate(range(first, first + args.steps)):
-        step(i, read_stats=(k == args.steps - 1))
-        marks[k + 1].record()  # same stream as the library's launches: per-step device time for the median
-    barrier()
-    elapsed = time.perf_counter() - t0
-    step_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+            step(first + i)
+        first += args.prewarm
+        sustained = timed_region(first, args.steps + 1)
+        first += args.steps
+    avg_ms, cnt = C.c_double(dom_ms), C.c_int64(dom_cnt)
     if use_graph:
         loss, gnorm_v = float(stat_dev[0]), float(stat_dev[1])
         step = _eager_step  # the per-kernel breakdown below runs eagerly
@@ -356,14 +380,12 @@ def run_once(args, world, world_observed, rank, dev, dist, damp, state):
         loss, gnorm_v = float(out[P]), float(gnorm)
     assert np.isfinite(loss) and np.isfinite(gnorm_v), "non-finite loss / gradient norm"
 
-    avg_ms, cnt = C.c_double(0.0), C.c_int64(0)
-    nf._lib.check(lib.nf_prof_read(ctx.ptr, DOMINANT[0], C.byref(avg_ms), C.byref(cnt)))
     # per-kernel breakdown: a few extra, UNTIMED steps with every kernel bracketed
     kernel_ms = {}
     nbreak = 5
     nf._lib.check(lib.nf_prof_enable(ctx.ptr, 2))
     for i in range(nbreak):
-        step(first + args.steps + i)
+        step(first + i)
     torch.cuda.synchronize(dev)
     for name in KERNEL_NAMES:
         a, c = C.c_double(0.0), C.c_int64(0)
@@ -397,14 +419,10 @@ def run_once(args, world, world_observed, rank, dev, dist, damp, state):
             "n_gpus": world_observed,
             "steps": args.steps,
             "warmup": args.warmup,
-            "prewarm_steps": args.prewarm,
-            "cold_start": None if cold_ms is None else {
-                "ms_per_step": cold_ms,
-                "what": f"the {args.steps} steps straight after the {args.warmup} warm-ups, before the {args.prewarm} untimed pre-warm steps: "
-                        "on a freshly leased GPU the clocks are still ramping (steady after ~60 cfg-2 steps, profiles/r3n_step_ramp.txt); "
-                        "`value` is the K steps after the pre-warm"},
             "ms_per_step": ms_per_step,
             "ms_per_step_median": step_ms[len(step_ms) // 2],
+            "value_sustained_clock": None if sustained is None else n_global * args.steps / sustained[0],
+            "ms_per_step_sustained_clock": None if sustained is None else 1e3 * sustained[0] / args.steps,
             "higher_is_better": True,
             "scaling": "strong" if args.workload == "cfg4" else "weak",
             "vs_baseline": None,
@@ -425,6 +443,15 @@ def run_once(args, world, world_observed, rank, dev, dist, damp, state):
                 "init": "Glorot-uniform weights, zero biases (Flux default)" + (f", theta scaled by {damp}" if damp is not None else ""),
                 "final_loss": loss,
                 "final_gradient_norm": gnorm_v,
+                "timing": (f"value / ms_per_step / roofline.frac: the {args.steps} steps straight after the {args.warmup} warm-ups "
+                           "(the command's protocol; after any idle an MI355X drops its shader clock to 1.6-2.0 GHz when load arrives "
+                           "and needs ~40 cfg-2 steps to return to 2.4 GHz: profiles/r4a_step_ramp_clocks.txt).  "
+                           + ("" if sustained is None else
+                              f"*_sustained_clock: {args.steps} more steps timed the same way after {args.prewarm} further untimed "
+                              "steps, i.e. what step 200 of a training run costs")),
+                "untimed_steps_before_value": args.warmup,
+                "untimed_steps_before_value_sustained_clock": None if sustained is None else args.warmup + args.steps + args.prewarm,
+                "weight_cache": "nf_ctx_set_weight_cache(ctx, 1), as train_flow's loop sets it" if fused_step else "not used",
             },
             "roofline": {
                 "kernel": DOMINANT[1],
@@ -441,6 +468,9 @@ def run_once(args, world, world_observed, rank, dev, dist, damp, state):
                 "timed_inside_the_timed_region": events_in_timed_region,
                 "algorithmic_flop_per_launch": flop_per_launch,
                 "whole_step_tflops": FLOPS_STEP_PER_SAMPLE * n_local / (ms_per_step * 1e-3) / 1e12,
+                "frac_sustained_clock": None if sustained is None or sustained[2] <= 0 else
+                                        flop_per_launch / (sustained[2] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                "avg_launch_ms_sustained_clock": None if sustained is None else sustained[2],
             },
             "kernels": kernel_ms,
         }
@@ -456,9 +486,9 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--prewarm", type=int, default=None,
-                    help="untimed steps run BEFORE the timed K to bring the GPU's clocks to their sustained state (a cold MI355X "
-                         "needs ~60 cfg-2 steps, profiles/r3n_step_ramp.txt); default per workload (cfg2 120, cfg3 60, cfg4 4), "
-                         "0 = none.  The K steps straight after the W warm-ups are timed as well and reported as cold_start")
+                    help="untimed steps AFTER the timed K, followed by K more timed steps reported as *_sustained_clock (the GPU's "
+                         "shader clock needs ~40 cfg-2 steps under load to return to 2.4 GHz, profiles/r4a_step_ramp_clocks.txt); "
+                         "default per workload (cfg2 120, cfg3 60, cfg4 4), 0 = no sustained-clock figure.  Never affects `value`")
     ap.add_argument("--batch", type=int, default=None, help="samples per GPU per step")
     ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg4"), default="cfg2",
                     help="cfg2 = the headline line (default); cfg3 = NSF d=32 K=8, 131072 per GPU; "
@@ -472,8 +502,8 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="1 GPU, cfg2: capture nf_elbo_step_enqueue into a hipGraph once and time K replays")
     ap.add_argument("--damp", type=float, default=None,
-                    help="scale the Glorot-initialised theta (cfg4: 0.5 is the contraction the parity tests judge; default: both "
-                         "initialisations, two JSON lines)")
+                    help="scale the Glorot-initialised theta (cfg4: --damp 0.5 is the contraction the parity tests judge; the "
+                         "default is the Flux initialisation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket kernels with HIP events in the timed region (roofline object is then empty)")
@@ -517,12 +547,14 @@ def main():
         select_cfg3(world)
     if args.batch is None:
         args.batch = BATCH
-    damps = [args.damp] if args.damp is not None else ([None, 0.5] if args.workload == "cfg4" else [None])
     state = {}
-    for damp in damps:
-        run_once(args, world, world_observed, rank, dev, dist, damp, state)
+    run_once(args, world, world_observed, rank, dev, dist, args.damp, state)  # ONE JSON line per invocation
     if dist is not None:
         dist.barrier()
+        if state.get("lib_comm_hung"):  # a thread of this process is still inside RCCL's init: do not wait for it at exit
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
         dist.destroy_process_group()
 
 

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NF_ABI_VERSION 3
+#define NF_ABI_VERSION 4
 
 /* status codes (< 0: library errors; > 0: hipError_t) */
 #define NF_OK 0
@@ -306,13 +306,23 @@ int nf_sgd_update(nf_ctx *ctx, int32_t dtype, void *theta, const void *g, void *
  * [rank * N, (rank + 1) * N) of a global batch of N * nranks, and the one all-reduce of [grad ; loss] happens inside.
  * LDS-resident RealNVP flows with a diagonal-Gaussian target (BASELINE cfg 2) run as three launches -- fused forward,
  * reverse pass, fused epilogue (slab sum, loss, Adam, norm, and the packed weight images of the UPDATED theta for the
- * next step).  Contract of that cache: between consecutive nf_elbo_step calls on one context with the same theta
- * pointer, theta is modified by nobody else; a caller that edits theta in place (clipping, re-initialisation) calls
- * nf_ctx_weights_changed(ctx) first.  Any other library call that packs weights drops the cache by itself. */
+ * next step).  BY DEFAULT every call packs its weight images from theta (one small launch): whatever happened to theta
+ * between two calls -- an in-place edit, a free and a re-allocation at the same address -- the step runs on the weights
+ * theta holds now.  A training loop that OWNS theta (src/optimize.jl:85-99 does: nobody else touches theta between
+ * Optimisers.update! and the next gradient) may opt in to reusing the images the previous step's epilogue wrote:
+ *   nf_ctx_set_weight_cache(ctx, 1)  -- the caller promises that between consecutive nf_elbo_step /
+ *       nf_elbo_step_enqueue calls on this context with the same theta pointer and flow, theta is modified by nobody
+ *       else; the cache is keyed on (theta pointer, hash of the descriptor's shape fields) and dropped by
+ *       nf_ctx_weights_changed, nf_ctx_set_stream, nf_ctx_set_arena, nf_ctx_set_weight_cache itself and by every other
+ *       library call that packs weights;
+ *   nf_ctx_weights_changed(ctx)      -- declares an edit of theta made under that promise (clipping, a callback).
+ * `train_flow` of the Python mirror (and ext/NormalizingFlowsNFHipExt.jl) opt in for the duration of their loop and
+ * opt out on return. */
 int nf_elbo_step(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, void *theta,
                  void *m, void *v, int64_t N, uint64_t seed, uint32_t step, double lr,
                  double beta1, double beta2, double eps, double *loss_host, double *gnorm_host);
 int nf_ctx_weights_changed(nf_ctx *ctx);
+int nf_ctx_set_weight_cache(nf_ctx *ctx, int32_t enable);
 /* The same step with NO per-step host values, for hipGraph capture and replay: *step_device (uint32, device memory,
  * caller-owned, initialised to the first step index) supplies the Philox stream id and Adam's t - 1 and is incremented
  * by the step; out_loss_gnorm_device (optional, 2 elements of the flow's type) receives [loss ; norm(g)].  After one

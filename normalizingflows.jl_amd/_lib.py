@@ -15,6 +15,7 @@ NF_KIND = {"planar": 0, "radial": 1, "realnvp": 2, "nsf": 3, "meanfield": 4, "ha
 NF_DTYPE_F32, NF_DTYPE_F64 = 0, 1
 NF_TARGET_DIAGGAUSS, NF_TARGET_BANANA, NF_TARGET_FUNNEL, NF_TARGET_WARPED, NF_TARGET_CROSS = 0, 1, 2, 3, 4
 NF_MAX_HIDDEN = 4
+NF_ERR_NONFINITE = -4
 
 
 class NFHipError(RuntimeError):
@@ -99,6 +100,7 @@ SYMBOLS = {
     "nf_sgd_update": (C.c_int, [_P, _I32, _P, _P, _P, _I64, _D, _D, _P]),
     "nf_elbo_step": (C.c_int, [_P, _DESC, _TGT, _P, _P, _P, _I64, _U64, _U32, _D, _D, _D, _D, _PD, _PD]),
     "nf_ctx_weights_changed": (C.c_int, [_P]),
+    "nf_ctx_set_weight_cache": (C.c_int, [_P, C.c_int32]),
     "nf_elbo_step_enqueue": (C.c_int, [_P, _DESC, _TGT, _P, _P, _P, _I64, _U64, _P, _D, _D, _D, _D, _P]),
     "nf_comm_get_unique_id": (C.c_int, [_P]),
     "nf_comm_init_rank": (C.c_int, [_P, _P, _I32, _I32]),
@@ -130,7 +132,7 @@ def load_library():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.nf_abi_version() != 3:
+    if lib.nf_abi_version() != 4:
         raise NFHipError("libnfhip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -336,6 +336,7 @@ extern "C" int nf_ctx_destroy(nf_ctx *ctx) {
 extern "C" int nf_ctx_set_stream(nf_ctx *ctx, void *hip_stream) {
   if (!ctx) return NF_ERR_ARG;
   ctx->stream = (hipStream_t)hip_stream;
+  ctx->wimg_owner = nullptr;  // cached weight images are only ordered against the stream they were written on
   return NF_OK;
 }
 
@@ -1938,8 +1939,16 @@ extern "C" int nf_sgd_update(nf_ctx *ctx, int32_t dtype, void *theta, const void
 // increments -- every launch argument is then the same from step to step, so one call can be captured into a hipGraph
 // and replayed (nf_elbo_step_enqueue).
 static inline unsigned long long flow_sig(const nf_flow_desc *d) {
-  return ((unsigned long long)d->d << 40) ^ ((unsigned long long)d->nlayers << 24) ^ ((unsigned long long)d->hdims[0] << 12) ^
-         (unsigned long long)d->hdims[1] ^ (1ull << 63);
+  // FNV-1a over every descriptor field the packed images depend on (kind, element type, d, depth, conditioner shape)
+  unsigned long long h = 1469598103934665603ull;
+  auto mix = [&](unsigned long long v) { h = (h ^ v) * 1099511628211ull; };
+  mix((unsigned long long)d->kind);
+  mix((unsigned long long)d->dtype);
+  mix((unsigned long long)d->d);
+  mix((unsigned long long)d->nlayers);
+  mix((unsigned long long)d->n_hidden);
+  for (int i = 0; i < d->n_hidden && i < 4; ++i) mix((unsigned long long)d->hdims[i]);
+  return h | (1ull << 63);
 }
 static bool step_fusable(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, long N) {
   static const bool off = std::getenv("NF_STEP_UNFUSED") != nullptr;  // A/B switch: the six-launch form
@@ -1983,8 +1992,11 @@ static int elbo_step_fused(nf_ctx *ctx, const nf_flow_desc *desc, const nf_targe
   double *gpart = cv.take<double>(eblocks);
   float *gbuf = (float *)ctx->gbuf;
   // packed images: those the previous step's epilogue left, or a fresh pack
+  // (ONLY under nf_ctx_set_weight_cache(ctx, 1): by default every step packs from theta, one 8 us launch, so a theta
+  // that was edited in place, or freed and re-allocated at the same address, can never meet stale images)
   static const bool repack = std::getenv("NF_STEP_REPACK") != nullptr;  // A/B switch: pack every step
-  if (repack || !(ctx->wimg && ctx->wimg_owner == (const void *)theta && ctx->wimg_sig == flow_sig(desc))) {
+  if (repack || !ctx->wimg_cache ||
+      !(ctx->wimg && ctx->wimg_owner == (const void *)theta && ctx->wimg_sig == flow_sig(desc))) {
     NF_TRY(coupling_pack(ctx, desc, theta));
   }
   long nslab = 0, npart = 0;
@@ -2017,6 +2029,13 @@ static int elbo_step_fused(nf_ctx *ctx, const nf_flow_desc *desc, const nf_targe
 extern "C" int nf_ctx_weights_changed(nf_ctx *ctx) {
   if (!ctx) return NF_ERR_ARG;
   ctx->wimg_owner = nullptr;
+  return NF_OK;
+}
+
+extern "C" int nf_ctx_set_weight_cache(nf_ctx *ctx, int32_t enable) {
+  if (!ctx) return NF_ERR_ARG;
+  ctx->wimg_cache = enable != 0;
+  ctx->wimg_owner = nullptr;  // either way the next step packs from theta
   return NF_OK;
 }
 

@@ -66,6 +66,7 @@ struct nf_ctx {
   // and wimg_sig == the flow's signature; every other pack, a reallocation of wimg and nf_ctx_weights_changed reset it
   const void *wimg_owner = nullptr;
   unsigned long long wimg_sig = 0;
+  bool wimg_cache = false;  // nf_ctx_set_weight_cache: off by default (every nf_elbo_step packs from theta)
   // RCCL communicator of this context (nf_comm.hip); null for single-GPU use
   void *comm = nullptr;
   int comm_size = 1, comm_rank = 0;

@@ -294,18 +294,84 @@ def optimize(loss_and_grad: Callable, theta0: torch.Tensor, reconstruct, *, max_
     return theta, opt_stats, st
 
 
+def _fused_steps_apply(vo, flow: Flow, rest, rng: PhiloxRNG, optimiser, kwargs) -> bool:
+    """True when a training run is what nf_elbo_step computes in one call per iteration: reverse KL on in-library draws
+    of the whole batch, a built-in device target, Adam, no data-parallel hook, and the draw counter in step with Adam's
+    step count (a fresh run, or `state` and `rng` continued together) -- nf_elbo_step uses ONE index for both."""
+    if vo not in (elbo, elbo_batch) or len(rest) != 2 or not isinstance(rest[1], int):
+        return False
+    if not (optimiser is None or isinstance(optimiser, Adam)) or kwargs.get("all_reduce") is not None:
+        return False
+    st = kwargs.get("state")
+    if st is not None and not isinstance(st, AdamState):
+        return False
+    if rng.sample_offset != 0 or rng.stream != (st.t if st is not None else 0):
+        return False
+    return _builtin(flow, rest[0])
+
+
+def _optimize_fused(flow: Flow, theta0: torch.Tensor, reconstruct, rng: PhiloxRNG, logp, n: int, *, max_iters: int,
+                    optimiser: Adam, show_progress: bool = False, callback=None, hasconverged=None, all_reduce=None,
+                    state=None):
+    """The loop of `optimize` (src/optimize.jl:85-104) with each iteration ONE library call: nf_elbo_step = draws,
+    forward, reverse pass, Adam, norm(g) (three launches for the LDS-resident RealNVP shapes, what bench.py times).  The
+    loop owns theta between steps, so it opts in to the library's packed-weight cache (nf_ctx_set_weight_cache) and out
+    again on return; a user `hasconverged` sees the live theta and is followed by nf_ctx_weights_changed.  Same numbers
+    as `optimize` over value_and_gradient + update (tests/test_gpu_tape.py)."""
+    from ._lib import NF_ERR_NONFINITE
+
+    theta = theta0.clone()
+    st = state if state is not None else setup(optimiser, theta)
+    ctx, lib = flow.ctx, flow.ctx.lib
+    opt_stats = []
+    converged = False
+    i = 1
+    loss, gn = _host_double(), _host_double()
+    check(lib.nf_ctx_set_weight_cache(ctx.ptr, 1))
+    try:
+        while i <= max_iters and not converged:
+            theta_before = theta.clone() if callback is not None else None
+            code = lib.nf_elbo_step(ctx.ptr, C.byref(flow.desc), C.byref(logp.c), _ptr(theta), _ptr(st.m), _ptr(st.v), n,
+                                    rng.seed, rng.next_stream(), optimiser.eta, optimiser.beta[0], optimiser.beta[1],
+                                    optimiser.epsilon, C.byref(loss), C.byref(gn))
+            if code != NF_ERR_NONFINITE:  # a non-finite loss is recorded, as the reference's loop would record it
+                check(code)
+            st.t += 1
+            stat = {"iteration": i, "loss": loss.value, "gradient_norm": gn.value}
+            if callback is not None:
+                new_stat = callback(i, opt_stats, reconstruct, theta_before)
+                if new_stat is not None:
+                    stat.update(new_stat)
+            opt_stats.append(stat)
+            i += 1
+            if hasconverged is not None:
+                converged = hasconverged(i, stat, reconstruct, theta, st)
+                check(lib.nf_ctx_weights_changed(ctx.ptr))  # it was handed the live theta
+            if show_progress and (i % 100 == 0):
+                print(f"Training iter {i}: loss {stat['loss']:.6g} |g| {stat['gradient_norm']:.3g}")
+    finally:
+        lib.nf_ctx_set_weight_cache(ctx.ptr, 0)
+    return theta, opt_stats, st
+
+
 def train_flow(*args, max_iters: int = 1000, optimiser: Adam = None, ADbackend=None, **kwargs):
     """train_flow([rng,] vo, flow, args...; max_iters, optimiser, ADbackend, kwargs...)
     (src/NormalizingFlows.jl:51-86) -> (flow_trained, opt_stats, st).
 
     `ADbackend` is accepted for signature compatibility; gradients come from the library's
-    hand-derived reverse pass (the role a custom ADTypes backend plays in the reference)."""
+    hand-derived reverse pass (the role a custom ADTypes backend plays in the reference).  Reverse-KL runs on a
+    built-in target with Adam go through nf_elbo_step, one library call per iteration (`_optimize_fused`); everything
+    else through `optimize` over value_and_gradient + update."""
     if isinstance(args[0], PhiloxRNG):
         rng, vo, flow, *rest = args
     else:
         rng = PhiloxRNG(0)
         vo, flow, *rest = args
     theta_flat, re = flow.destructure()
+    if _fused_steps_apply(vo, flow, rest, rng, optimiser, kwargs):
+        theta, stats, st = _optimize_fused(flow, theta_flat, re, rng, rest[0], rest[1], max_iters=max_iters,
+                                           optimiser=optimiser or Adam(), **kwargs)
+        return re(theta), stats, st
 
     def loss_and_grad(theta):
         f = re(theta)

@@ -27,7 +27,7 @@ def test_header_symbols_all_exported(nf):
     for name in declared:
         assert hasattr(lib, name), f"libnfhip.so does not export {name}"
     assert declared == set(nf.SYMBOLS), declared ^ set(nf.SYMBOLS)
-    assert nf.load_library().nf_abi_version() == 3
+    assert nf.load_library().nf_abi_version() == 4
 
 
 def _desc(nf, kind, d, nlayers, hdims=(), K=0, B=0.0, dtype=0):

@@ -276,12 +276,15 @@ def _split_reference_steps(nf, flow, tgt, n, seed, nsteps, ctx):
     return th, m, v, stats
 
 
+@pytest.mark.parametrize("cache", [False, True])
 @pytest.mark.parametrize("shape", ["d64_h64", "d20_h32"])
-def test_three_launch_step_equals_split_calls_over_consecutive_steps(nf, shape):
-    """nf_elbo_step on an LDS-resident RealNVP flow = fused forward + reverse pass + fused epilogue, the packed weight
-    images carried from step to step.  Five consecutive steps (so steps 2..5 run on images written by the previous
-    epilogue, never re-packed) against nf_elbo_value_and_grad + nf_adam_update on another context: theta, m, v bit for
-    bit, loss and norm(g) to float rounding.  Then nf_ctx_weights_changed after an in-place edit of theta."""
+def test_three_launch_step_equals_split_calls_over_consecutive_steps(nf, shape, cache):
+    """nf_elbo_step on an LDS-resident RealNVP flow = fused forward + reverse pass + fused epilogue.  Five consecutive
+    steps against nf_elbo_value_and_grad + nf_adam_update on another context: theta, m, v bit for bit, loss and norm(g)
+    to float rounding.  cache=True (nf_ctx_set_weight_cache(ctx, 1), what train_flow opts in to): steps 2..5 run on the
+    packed weight images the previous epilogue wrote, never re-packed, and an in-place edit of theta is declared with
+    nf_ctx_weights_changed.  cache=False (the default): every step packs from theta, so the SAME edit needs no
+    declaration -- nor does a theta that was freed and re-allocated at the same address."""
     d, hd, nl, n = {"d64_h64": (64, (64, 64), 4, 4096 + 5), "d20_h32": (20, (32, 32), 2, 777)}[shape]
     flow = nf.realnvp(nf.MvNormal(d), hd, nl, paramtype=torch.float32, seed=3)
     rng = np.random.default_rng(0)
@@ -290,6 +293,8 @@ def test_three_launch_step_equals_split_calls_over_consecutive_steps(nf, shape):
     lib = nf.load_library()
     stream = torch.cuda.current_stream().cuda_stream
     ctx_a, ctx_b = nf.Context(0, stream), nf.Context(0, stream)
+    if cache:
+        nf._lib.check(lib.nf_ctx_set_weight_cache(ctx_a.ptr, 1))
     vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
     th_b, m_b, v_b, stats_b = _split_reference_steps(nf, flow, tgt, n, 77, 5, ctx_b)
     th, m, v = flow.theta.clone(), torch.zeros_like(flow.theta), torch.zeros_like(flow.theta)
@@ -305,7 +310,8 @@ def test_three_launch_step_equals_split_calls_over_consecutive_steps(nf, shape):
     assert torch.equal(th, th_b) and torch.equal(m, m_b) and torch.equal(v, v_b)
     # an in-place edit of theta between steps: declared with nf_ctx_weights_changed, the next step uses the edited weights
     th.mul_(0.5)
-    nf._lib.check(lib.nf_ctx_weights_changed(ctx_a.ptr))
+    if cache:
+        nf._lib.check(lib.nf_ctx_weights_changed(ctx_a.ptr))
     nf._lib.check(lib.nf_elbo_step(ctx_a.ptr, C.byref(flow.desc), C.byref(tgt.c), vp(th), vp(m), vp(v), n, 77, 5, 1e-3, 0.9, 0.999, 1e-8, None, None))
     th_c, m_c, v_c = th_b * 0.5, m_b.clone(), v_b.clone()
     out, gn = torch.empty(flow.P + 1, device="cuda"), torch.empty(1, device="cuda")
@@ -355,3 +361,51 @@ def test_step_with_device_counter_replays_as_a_graph(nf):
     assert float(stat[0]) == pytest.approx(stats_b[5][0], rel=1e-6) and float(stat[1]) == pytest.approx(stats_b[5][1], rel=1e-6)
     ctx_a.close()
     ctx_b.close()
+
+
+@pytest.mark.parametrize("kind", ["realnvp_resident", "planar", "nsf"])
+def test_train_flow_runs_one_library_call_per_iteration_and_equals_the_split_loop(nf, kind):
+    """train_flow on a built-in target with Adam goes through nf_elbo_step (objectives._optimize_fused: what bench.py
+    times is what a user gets) -- same theta, Adam state and stat tuples as `optimize` over
+    nf_elbo_value_and_grad + nf_adam_update, also when continued from the returned `st`, with a callback (which must
+    see the parameters BEFORE the update, src/optimize.jl:88-99) and with a user `hasconverged`."""
+    from normalizingflows_jl_amd import objectives as ob
+
+    if kind == "realnvp_resident":
+        flow = nf.realnvp(nf.MvNormal(64), (64, 64), 2, paramtype=torch.float32, seed=5)
+    elif kind == "planar":
+        flow = nf.planarflow(nf.MvNormal(6), 5, paramtype=torch.float32, seed=5)
+    else:
+        flow = nf.nsf(nf.MvNormal(8), (32, 32), 8, 5.0, 2, paramtype=torch.float32, seed=5)
+    d = flow.dist.d
+    rng = np.random.default_rng(0)
+    tgt = nf.DiagGaussTarget(torch.tensor(rng.standard_normal(d), dtype=torch.float32, device="cuda"),
+                             torch.tensor(rng.uniform(size=d) + 0.5, dtype=torch.float32, device="cuda"))
+    n = 1000
+    seen = []
+
+    def cb(i, stats, re, theta):
+        seen.append(theta.clone())
+        return {"extra": i}
+
+    assert ob._fused_steps_apply(nf.elbo_batch, flow, [tgt, n], nf.PhiloxRNG(9), None, {})
+    fa, sa, sta = nf.train_flow(nf.PhiloxRNG(9), nf.elbo_batch, flow, tgt, n, max_iters=6, optimiser=nf.Adam(2e-3), callback=cb)
+    seen_a, seen = seen, []
+    # the split loop: the same objective through optimize()
+    theta0, re = flow.destructure()
+    rng_b = nf.PhiloxRNG(9)
+    tb, sb, stb = nf.optimize(lambda th: nf.value_and_gradient(nf.elbo_batch, re(th), tgt, n, rng_b), theta0, re, max_iters=6,
+                              optimiser=nf.Adam(2e-3), callback=cb)
+    assert torch.equal(fa.theta, tb) and torch.equal(sta.m, stb.m) and torch.equal(sta.v, stb.v) and sta.t == stb.t == 6
+    for a, b in zip(sa, sb):
+        assert a["iteration"] == b["iteration"] and a["extra"] == b["extra"]
+        assert a["loss"] == pytest.approx(b["loss"], rel=1e-6) and a["gradient_norm"] == pytest.approx(b["gradient_norm"], rel=1e-6)
+    assert all(torch.equal(x, y) for x, y in zip(seen_a, seen)) and torch.equal(seen_a[0], theta0)
+    # continuation: 3 + 3 steps = 6 steps, with a user hasconverged looking at the live theta
+    rng_c = nf.PhiloxRNG(9)
+    f3, _, st3 = nf.train_flow(rng_c, nf.elbo_batch, flow, tgt, n, max_iters=3, optimiser=nf.Adam(2e-3))
+    f33, s33, st33 = nf.train_flow(rng_c, nf.elbo_batch, f3, tgt, n, max_iters=100, optimiser=nf.Adam(2e-3), state=st3,
+                                   hasconverged=lambda i, stat, re, th, st: st.t >= 6)
+    assert st33.t == 6 and torch.equal(f33.theta, tb)
+    # a draw counter out of step with Adam's count cannot be one nf_elbo_step index: the split loop takes it
+    assert not ob._fused_steps_apply(nf.elbo_batch, flow, [tgt, n], nf.PhiloxRNG(9), None, {"state": st3})
