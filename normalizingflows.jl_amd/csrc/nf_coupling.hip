@@ -153,13 +153,19 @@ __device__ __forceinline__ float coupling_step(const float *__restrict__ img_s, 
 //     that owns feature f in the dW GEMM reads its 16 k-steps (samples 2t + parity) as four 16-byte loads;
 //   "lane layout" (s, u, masks -- element-wise operands in the MFMA C layout): [lane 64][16] per block.
 // 46 KiB per (tile, coupling) for d = 64 / hidden 64: 772 MB per step at cfg 2, written once and read once.
-template <class G>
+// SLIM (round 4; optional, NF_STASH_SLIM=1 -- see stash_slim() for the measurement that keeps it off): WITHOUT a1.  The first hidden layer's activations are 35 %
+// of the full stash (128 of 368 floats per sample and coupling) and the cheapest thing in it to rebuild: the consumer wave
+// recomputes a1^T = leakyrelu(W1 x2 + b1) from x2 -- kept a second time in the MFMA C layout (XL), which is the A operand
+// of that product -- with 32 MFMAs per net and tile while the producer wave is in its MFMA-free prologue.  34 KiB instead
+// of 46 KiB per (tile, coupling): 570 instead of 772 MB per cfg-2 step, written once and read once.
+template <class G, bool SLIM = false>
 struct StashGeo {
   static constexpr int XT = 0;
-  static constexpr int SV = XT + G::MB * 1024;
+  static constexpr int XL = XT + G::MB * 1024;  // SLIM only: x2 in the C ("lane") layout
+  static constexpr int SV = XL + (SLIM ? G::MB * 1024 : 0);
   static constexpr int UV = SV + G::CB * 1024;
   static constexpr int NET0 = UV + G::CB * 1024;  // net 0 = s, net 1 = t
-  static constexpr int A1 = 0, A2 = G::H1B * 1024, MSK = A2 + G::H2B * 1024, NETSZ = MSK + 256;
+  static constexpr int A1 = 0, A2 = SLIM ? 0 : G::H1B * 1024, MSK = A2 + G::H2B * 1024, NETSZ = MSK + 256;
   static constexpr int SIZE = NET0 + 2 * NETSZ;  // floats per (tile, coupling), a multiple of 4
 };
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -211,23 +217,27 @@ __device__ __forceinline__ void stash_put_lane(const StashIO &st, int base, cons
     }
 }
 
-template <class G, bool STORE_X>
+template <class G, bool STORE_X, bool SLIM = false>
 __device__ __forceinline__ void net_forward_stash(const float *__restrict__ img, const f32x16 (&x)[G::MB], f32x16 (&out)[G::CB],
                                                   int l31, int hi, const StashIO &st, int nbase) {
-  using SG = StashGeo<G>;
+  using SG = StashGeo<G, SLIM>;
   f32x16 a1[G::H1B], a2[G::H2B];
   unsigned m1[2] = {0u, 0u}, m2[2] = {0u, 0u};
-  if (STORE_X)
+  if (STORE_X) {
+    if (SLIM) stash_put_lane<G::MB>(st, SG::XL, x);
     dense_fwd<G::MB, G::H1B>(img + G::W1, img + G::B1, x, a1, l31, hi, [&](int e) { stash_put_T<G::MB>(st, SG::XT, x, e); });
-  else
+  } else
     dense_fwd<G::MB, G::H1B>(img + G::W1, img + G::B1, x, a1, l31, hi);
 #pragma unroll
   for (int b = 0; b < G::H1B; ++b) {
     nf_lrelu16(a1[b]);
     m1[b] = nf_sign_mask16(a1[b]);
   }
-  dense_fwd<G::H1B, G::H2B>(img + G::W2, img + G::B2, a1, a2, l31, hi,
-                            [&](int e) { stash_put_T<G::H1B>(st, nbase + SG::A1, a1, e); });
+  if (SLIM)
+    dense_fwd<G::H1B, G::H2B>(img + G::W2, img + G::B2, a1, a2, l31, hi);
+  else
+    dense_fwd<G::H1B, G::H2B>(img + G::W2, img + G::B2, a1, a2, l31, hi,
+                              [&](int e) { stash_put_T<G::H1B>(st, nbase + SG::A1, a1, e); });
 #pragma unroll
   for (int b = 0; b < G::H2B; ++b) {
     nf_lrelu16(a2[b]);
@@ -247,16 +257,16 @@ __device__ __forceinline__ void net_forward_stash(const float *__restrict__ img,
 // forward coupling of the training step: as coupling_step<G, false>, leaving the reverse pass's operands behind
 // INVERSE (forward-KL training: the chain runs data -> base): w1 = (v1 - t) exp(-s); the UV slot then holds w1, which is
 // what the reverse pass of the inverse coupling needs next to s (bwd_tile's INVD algebra)
-template <class G, bool INVERSE = false>
+template <class G, bool INVERSE = false, bool SLIM = false>
 __device__ __forceinline__ float coupling_step_stash(const float *__restrict__ img_s, const float *__restrict__ img_t,
                                                      f32x16 (&x1)[G::CB], const f32x16 (&xb)[G::MB], int l31, int hi,
                                                      const StashIO &st, long long *tr = nullptr) {
-  using SG = StashGeo<G>;
+  using SG = StashGeo<G, SLIM>;
   static_assert(G::H1B <= 2 && G::H2B <= 2, "mask words");
   f32x16 S[G::CB], T[G::CB];
-  net_forward_stash<G, true>(img_s, xb, S, l31, hi, st, SG::NET0);
+  net_forward_stash<G, true, SLIM>(img_s, xb, S, l31, hi, st, SG::NET0);
   NF_CH_STAMP(tr, 1);
-  net_forward_stash<G, false>(img_t, xb, T, l31, hi, st, SG::NET0 + SG::NETSZ);
+  net_forward_stash<G, false, SLIM>(img_t, xb, T, l31, hi, st, SG::NET0 + SG::NETSZ);
   NF_CH_STAMP(tr, 2);
   float lsum = 0.f;
 #pragma unroll
@@ -299,8 +309,9 @@ struct FusedArgs {
   long long *trace;       // NF_KERNEL_TRACE builds: clock stamps for tools/trace_chain.py, else unused
 };
 
-template <class G, bool INVERSE, bool FUSED = false, bool STASH = false>
+template <class G, bool INVERSE, bool FUSED = false, bool STASH = false, bool SLIM = false>
 __global__ __launch_bounds__(512) void k_affine_chain(ChainArgs a, float *xt, float *__restrict__ ladj, FusedArgs fa) {
+  static_assert(STASH || !SLIM, "SLIM is a stash layout");
   static_assert(!STASH || !FUSED || !INVERSE, "the fused ELBO forward runs base -> data");
   static_assert(G::MB == G::CB, "parity blocks must have equal padded size");
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -414,15 +425,15 @@ __global__ __launch_bounds__(512) void k_affine_chain(ChainArgs a, float *xt, fl
         const bool x1_is_O = (coupling_at(pos) & 1) != 0;  // compile-time per (INVERSE, half) when ncoup is even
         float ls;
         if (STASH) {
-          const StashIO st = make_stash_io(fa.stash, tl * a.ncoup + coupling_at(pos), StashGeo<G>::SIZE, live, l31, hi);
+          const StashIO st = make_stash_io(fa.stash, tl * a.ncoup + coupling_at(pos), StashGeo<G, SLIM>::SIZE, live, l31, hi);
 #ifdef NF_KERNEL_TRACE  // tools/trace_chain.py: block 0, waves 0 and 4 (one SIMD), stamps [32 + wave/4 * 64 + position * 4 + 0..3]
           // (the slots the reverse kernels of the same step leave alone)
           long long *tr = (fa.trace && blockIdx.x == 0 && (tid & 255) == 0 && pos < 8) ? fa.trace + 32 + (tid >> 8) * 64 + pos * 4 - 1 : nullptr;
 #else
           long long *tr = nullptr;
 #endif
-          if (INVERSE ? (half == 1) : (half == 0)) ls = coupling_step_stash<G, INVERSE>(img_s, img_t, O, E, l31, hi, st, tr);
-          else ls = coupling_step_stash<G, INVERSE>(img_s, img_t, E, O, l31, hi, st, tr);
+          if (INVERSE ? (half == 1) : (half == 0)) ls = coupling_step_stash<G, INVERSE, SLIM>(img_s, img_t, O, E, l31, hi, st, tr);
+          else ls = coupling_step_stash<G, INVERSE, SLIM>(img_s, img_t, E, O, l31, hi, st, tr);
           NF_CH_STAMP(tr, 3);
           lsum += ls;
           __syncthreads();
@@ -879,16 +890,20 @@ __device__ __forceinline__ void stash_get_lane(const StashIO &st, int base, f32x
 }
 
 // dW^T accumulation with the activation operand in registers: at[ib][t] = a[feature ib*32 + l31][sample 2t + hi]
-template <int IB, int OB, class SJ = NoSideJob>
+// CORDER: k-step t contracts the sample (t & 3) + 8 (t >> 2) + 4 hi instead -- the order in which the MFMA C layout holds
+// the rows of a recomputed operand (recompute_a1t); the delta tile is read in the same order, the sum is the same sum.
+template <bool CORDER>
+__device__ __forceinline__ constexpr int dw_sample(int t) { return CORDER ? (t & 3) + 8 * (t >> 2) : 2 * t; }
+template <int IB, int OB, class SJ = NoSideJob, bool CORDER = false>
 __device__ __forceinline__ void dw_accumulate_reg(const float (&at)[IB][16], const float *__restrict__ sd,
                                                   f32x16 (&acc)[IB][OB], float (&bsum)[OB], int l31, int hi, SJ sj = SJ()) {
   constexpr int TG = 2, NG = 16 / TG;
-  const float *pd = sd + l31 * NF_TS + hi;
+  const float *pd = sd + l31 * NF_TS + (CORDER ? 4 * hi : hi);
   float dn[TG][OB], dc[TG][OB];
 #pragma unroll
   for (int u = 0; u < TG; ++u)
 #pragma unroll
-    for (int ob = 0; ob < OB; ++ob) dn[u][ob] = pd[ob * 32 * NF_TS + 2 * u];
+    for (int ob = 0; ob < OB; ++ob) dn[u][ob] = pd[ob * 32 * NF_TS + dw_sample<CORDER>(u)];
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
 #pragma unroll
@@ -899,7 +914,7 @@ __device__ __forceinline__ void dw_accumulate_reg(const float (&at)[IB][16], con
 #pragma unroll
       for (int u = 0; u < TG; ++u)
 #pragma unroll
-        for (int ob = 0; ob < OB; ++ob) dn[u][ob] = pd[ob * 32 * NF_TS + 2 * ((g + 1) * TG + u)];
+        for (int ob = 0; ob < OB; ++ob) dn[u][ob] = pd[ob * 32 * NF_TS + dw_sample<CORDER>((g + 1) * TG + u)];
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -915,6 +930,55 @@ __device__ __forceinline__ void dw_accumulate_reg(const float (&at)[IB][16], con
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// a1^T = leakyrelu(W1 x2 + b1) as the dW2 GEMM wants it -- lane <-> hidden unit, register r <-> sample
+// (r & 3) + 8 (r >> 2) + 4 hi (dw_accumulate_reg<..., CORDER>) -- from the conditioner input in the MFMA C layout:
+// D' = x2^T W1^T, i.e. dense_fwd with the operand roles swapped (A: the input's registers, B: the weight image's rows, lanes
+// along a row as in the forward fetch).  Same k order and operand values as the forward's own first layer.
+template <class G>
+__device__ __forceinline__ void recompute_a1t(const float *__restrict__ img, const f32x16 (&x2c)[G::MB], float (&a1t)[G::H1B][16],
+                                              int l31, int hi) {
+  constexpr int NG = G::MB * 4, S = G::S1, OB = G::H1B;
+  f32x16 z[OB];
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob) {
+    const float bias = img[G::B1 + ob * 32 + l31];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[ob][r] = bias;
+  }
+  const float *wl = img + G::W1 + (4 * hi) * S + l31;
+  float wn[OB][4], wc[OB][4];
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wn[ob][e] = wl[e * S + ob * 32];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) wc[ob][e] = wn[ob][e];
+    if (g + 1 < NG) {
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wn[ob][e] = wl[((g + 1) * 8 + e) * S + ob * 32];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob)
+        z[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(x2c[g / 4][(g % 4) * 4 + e], wc[ob][e], z[ob], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob) {
+    nf_lrelu16(z[ob]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a1t[ob][r] = z[ob][r];
   }
 }
 
@@ -934,9 +998,9 @@ template <class G>
 struct StashFirst {
   f32x16 sv[G::CB], uv[G::CB];
 };
-template <class G>
+template <class G, bool SLIM = false>
 __device__ __forceinline__ void stash_issue_first(StashFirst<G> &f, float *stash, int k, int ncoup, long tile, int l31, int hi) {
-  using SG = StashGeo<G>;
+  using SG = StashGeo<G, SLIM>;
   const StashIO st = make_stash_io(stash, tile * ncoup + k, SG::SIZE, true, l31, hi);
   stash_get_lane<G::CB>(st, SG::SV, f.sv);
   stash_get_lane<G::CB>(st, SG::UV, f.uv);
@@ -1157,12 +1221,12 @@ struct BwdPairLds {
 // FULL: d = 64 and N a multiple of the tile (no sample / feature masks).  INVD: reverse pass of the INVERSE coupling
 // (forward-KL training; algebra of bwd_tile_stashed: phase S first, the UV slot holds w1).  live: this pair has a tile in
 // this round of the workgroup's tile loop -- a pair without one only keeps the barrier count.
-template <class G, bool PHASE_S, bool FULL, bool INVD>
+template <class G, bool PHASE_S, bool FULL, bool INVD, bool SLIM>
 __device__ __forceinline__ void pair_produce(const CouplingArgs &a, const float *__restrict__ img, float *__restrict__ sp,
                                              StashFirst<G> &f, float *stash, int k, int ncoup, float *__restrict__ ybar,
                                              const float *__restrict__ lbar, float lbar_const, long tile, long next_tile,
                                              bool live, int l31, int hi, long long *tr = nullptr) {
-  using SG = StashGeo<G>;
+  using SG = StashGeo<G, SLIM>;
   using L = BwdPairLds<G>;
   if (!live) {
     __syncthreads();
@@ -1231,7 +1295,7 @@ __device__ __forceinline__ void pair_produce(const CouplingArgs &a, const float 
   NF_TS_STAMP(5);
   __syncthreads();  // B3
   NF_TS_STAMP(6);
-  if (PHASE_S && next_tile >= 0) stash_issue_first<G>(f, stash, k, ncoup, next_tile, l31, hi);
+  if (PHASE_S && next_tile >= 0) stash_issue_first<G, SLIM>(f, stash, k, ncoup, next_tile, l31, hi);
   f32x16 g2[G::MB];
   dense_bwd_x<G::MB, G::H1B>(img + G::W1, d1, g2, l31, hi);
 #pragma unroll
@@ -1243,10 +1307,11 @@ __device__ __forceinline__ void pair_produce(const CouplingArgs &a, const float 
 
 // (Measured and removed: dW1 of a tile moved in front of the NEXT tile's first barrier, where the producer issues no
 // MFMAs -- 374-379 us against 366 in one process; and the producer's next-unit operands requested behind B3 -- 370.)
-template <class G>
-__device__ __forceinline__ void pair_consume(const float *__restrict__ sp, BwdAcc<G> &acc, float *stash, int k, int ncoup,
-                                             long tile, int nbase, bool live, int l31, int hi, long long *tr = nullptr) {
-  using SG = StashGeo<G>;
+template <class G, bool SLIM>
+__device__ __forceinline__ void pair_consume(const float *__restrict__ img, const float *__restrict__ sp, BwdAcc<G> &acc, float *stash,
+                                             int k, int ncoup, long tile, bool is_s, bool live, int l31, int hi,
+                                             long long *tr = nullptr) {
+  using SG = StashGeo<G, SLIM>;
   using L = BwdPairLds<G>;
   if (!live) {
     __syncthreads();
@@ -1255,8 +1320,29 @@ __device__ __forceinline__ void pair_consume(const float *__restrict__ sp, BwdAc
     return;
   }
   NF_TS_STAMP(0);
+  const int nbase = SG::NET0 + (is_s ? 0 : SG::NETSZ);
   const StashIO st = make_stash_io(stash, tile * ncoup + k, SG::SIZE, true, l31, hi);
   const int vT = (l31 * 32 + hi * 16) * 4;
+  if constexpr (SLIM) {
+    // a1 is not in the stash: rebuilt here, in this wave's MFMA-free prologue (the producer is in its own: operand loads,
+    // element-wise stage, d3 -> LDS), from x2 in the C layout and the W1 rows of the staged image
+    float a1t[G::H1B][16];
+    {
+      f32x16 x2c[G::MB];
+      stash_get_lane<G::MB>(st, SG::XL, x2c);
+      float a2t[G::H2B][16];
+      stash_get_T<G::H2B>(st, nbase + SG::A2, vT, a2t);
+      recompute_a1t<G>(img, x2c, a1t, l31, hi);
+      NF_TS_STAMP(1);
+      __syncthreads();  // B1
+      NF_TS_STAMP(2);
+      dw_accumulate_reg<G::H2B, G::CB>(a2t, sp + L::D3, acc.w3, acc.b3, l31, hi);
+    }
+    NF_TS_STAMP(3);
+    __syncthreads();  // B2
+    NF_TS_STAMP(4);
+    dw_accumulate_reg<G::H1B, G::H2B, NoSideJob, true>(a1t, sp + L::D2, acc.w2, acc.b2, l31, hi);
+  } else {
   {
     float a2t[G::H2B][16];
     stash_get_T<G::H2B>(st, nbase + SG::A2, vT, a2t);
@@ -1272,6 +1358,7 @@ __device__ __forceinline__ void pair_consume(const float *__restrict__ sp, BwdAc
     __syncthreads();  // B2
     NF_TS_STAMP(4);
     dw_accumulate_reg<G::H1B, G::H2B>(a1t, sp + L::D2, acc.w2, acc.b2, l31, hi);
+  }
   }
   {
     float x2t[G::MB][16];
@@ -1305,7 +1392,7 @@ __device__ __forceinline__ void pair_slab_write(const float *__restrict__ lds, f
 // never count against the other role's 256 registers (inside the coupling loop both are live across either branch).
 // Every wave executes the same barriers: per phase 1 (image staged) + 3 per round of the tile loop + 3 (tiles done,
 // folded, slab written); the tile loop runs as many rounds as the workgroup's first pair needs.
-template <class G, bool FULL, bool INVD>
+template <class G, bool FULL, bool INVD, bool SLIM>
 __global__ __launch_bounds__(512) void k_affine_bwd_pair(BwdAllArgs aa, float *stash, float *__restrict__ ybar,
                                                          const float *__restrict__ lbar, float lbar_const,
                                                          float *__restrict__ slab, long slab_stride) {
@@ -1322,7 +1409,7 @@ __global__ __launch_bounds__(512) void k_affine_bwd_pair(BwdAllArgs aa, float *s
   const int rounds = wg0 < ntiles ? (int)((ntiles - wg0 + tstride - 1) / tstride) : 0;
   if (role == 0) {
     StashFirst<G> f;
-    if (INVD && tile0 < ntiles) stash_issue_first<G>(f, stash, aa.ncoup - 1, aa.ncoup, tile0, l31, hi);  // S runs first
+    if (INVD && tile0 < ntiles) stash_issue_first<G, SLIM>(f, stash, aa.ncoup - 1, aa.ncoup, tile0, l31, hi);  // S runs first
 #pragma unroll 1
     for (int step = 0; step < aa.ncoup; ++step) {
       const int k = INVD ? aa.ncoup - 1 - step : step;  // the inverse chain's reverse pass runs in execution order
@@ -1350,14 +1437,14 @@ __global__ __launch_bounds__(512) void k_affine_bwd_pair(BwdAllArgs aa, float *s
 #else
           long long *tr = nullptr;
 #endif
-          if (!is_s) pair_produce<G, false, FULL, INVD>(a, img, sp, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, tile < ntiles, l31, hi, tr);
-          else pair_produce<G, true, FULL, INVD>(a, img, sp, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, tile < ntiles, l31, hi, tr);
+          if (!is_s) pair_produce<G, false, FULL, INVD, SLIM>(a, img, sp, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, tile < ntiles, l31, hi, tr);
+          else pair_produce<G, true, FULL, INVD, SLIM>(a, img, sp, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, tile < ntiles, l31, hi, tr);
         }
         __syncthreads();  // every wave is done with the weight image and the delta tiles
         // s and u of the next phase-S's first tile fly behind the fold, the slab write and the staging of the next image
         if (tile0 < ntiles) {
-          if (!INVD && !is_s) stash_issue_first<G>(f, stash, k, aa.ncoup, tile0, l31, hi);
-          if (INVD && !is_s && step + 1 < aa.ncoup) stash_issue_first<G>(f, stash, k - 1, aa.ncoup, tile0, l31, hi);
+          if (!INVD && !is_s) stash_issue_first<G, SLIM>(f, stash, k, aa.ncoup, tile0, l31, hi);
+          if (INVD && !is_s && step + 1 < aa.ncoup) stash_issue_first<G, SLIM>(f, stash, k - 1, aa.ncoup, tile0, l31, hi);
         }
         __syncthreads();  // the consumers have folded
         pair_slab_write<G>(lds, slab + (long)k * 2 * G::SIZE + ((long)blockIdx.x * slab_stride + (is_s ? 0 : 1) * (long)G::SIZE), tid);
@@ -1386,7 +1473,7 @@ __global__ __launch_bounds__(512) void k_affine_bwd_pair(BwdAllArgs aa, float *s
 #else
           long long *tr = nullptr;
 #endif
-          pair_consume<G>(sp, acc, stash, k, aa.ncoup, tile, StashGeo<G>::NET0 + (is_s ? 0 : StashGeo<G>::NETSZ), tile < ntiles, l31, hi, tr);
+          pair_consume<G, SLIM>(img, sp, acc, stash, k, aa.ncoup, tile, is_s, tile < ntiles, l31, hi, tr);
         }
         __syncthreads();  // every wave is done with the weight image and the delta tiles
         {
@@ -1565,7 +1652,18 @@ static int launch_bwd_v(nf_ctx *ctx, const CouplingArgs &a, float *y, float *yba
                      lbar_const, slab, slab_stride);
   return (int)hipGetLastError();
 }
-template <class G>
+// Which stash layout the training step of this flow uses (forward writer and reverse reader must agree).  SLIM is OFF by
+// default: measured A/B in one process on one box (cfg 2, driver's command, profiles/r4c_stash_slim_ab.txt) the forward gains
+// 4 us of 199 (it is issue-bound, not write-bound: 124 fewer store instructions per coupling buy 2 %), the reverse kernel
+// LOSES 52 us of 369 -- the 32 extra MFMAs per net and tile do not hide in the consumer's prologue, they wait there for x2 --
+// 0.730 against 0.691 ms per step.  NF_STASH_SLIM=1 selects it where the two-waves-per-tile kernel reads the stash (hidden
+// 33-64): 26 % less stash memory and HBM traffic for 5 % more time.
+static bool stash_slim(int size) {
+  static const bool no_pair = std::getenv("NF_BWD_NO_PAIR") != nullptr, slim = std::getenv("NF_STASH_SLIM") != nullptr;
+  return size == NetGeo<1, 2, 2, 1>::SIZE && !no_pair && slim;
+}
+
+template <class G, bool SLIM = false>
 static int launch_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, float *xt, long N, float *ladj,
                         const FusedArgs *fused = nullptr, float *stash_plain = nullptr) {
   // two double-buffered (s,t) image pairs + target parameters and per-wave sums of the fused variant
@@ -1575,9 +1673,9 @@ static int launch_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, flo
     NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false, true, true, SLIM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false, false, true, SLIM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, true, false, true, SLIM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return NF_OK;
   }));
   ChainArgs a;
@@ -1591,17 +1689,17 @@ static int launch_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, flo
   ProfScope ps(ctx, "affine_chain");
   FusedArgs none{};
   if (fused && fused->stash)
-    hipLaunchKernelGGL((k_affine_chain<G, false, true, true>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, *fused);
+    hipLaunchKernelGGL((k_affine_chain<G, false, true, true, SLIM>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, *fused);
   else if (fused)
     hipLaunchKernelGGL((k_affine_chain<G, false, true>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, *fused);
   else if (inverse && stash_plain) {  // forward-KL training: the inverse chain leaves the stash of ITS reverse pass
     none.stash = stash_plain;
-    hipLaunchKernelGGL((k_affine_chain<G, true, false, true>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, none);
+    hipLaunchKernelGGL((k_affine_chain<G, true, false, true, SLIM>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, none);
   } else if (inverse)
     hipLaunchKernelGGL((k_affine_chain<G, true>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, none);
   else if (stash_plain) {  // caller-supplied draws: the plain forward chain, leaving the stash behind
     none.stash = stash_plain;
-    hipLaunchKernelGGL((k_affine_chain<G, false, false, true>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, none);
+    hipLaunchKernelGGL((k_affine_chain<G, false, false, true, SLIM>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, none);
   }
   else
     hipLaunchKernelGGL((k_affine_chain<G, false>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, none);
@@ -1630,6 +1728,7 @@ int nf_affine_chain_elbo(nf_ctx *ctx, const nf_flow_desc *desc, long N, uint64_t
   fa.k0 = (uint32_t)seed; fa.k1 = (uint32_t)(seed >> 32); fa.stream = stream; fa.off = off;
   fa.mu = mu; fa.var = var; fa.gt = gt; fa.gscale = (float)gscale; fa.partial = partial; fa.pscale = pscale;
   if (size == NetGeo<1, 1, 1, 1>::SIZE) return launch_chain<NetGeo<1, 1, 1, 1>>(ctx, desc, false, yt, N, nullptr, &fa);
+  if (stash && stash_slim(size)) return launch_chain<NetGeo<1, 2, 2, 1>, true>(ctx, desc, false, yt, N, nullptr, &fa);
   return launch_chain<NetGeo<1, 2, 2, 1>>(ctx, desc, false, yt, N, nullptr, &fa);
 }
 
@@ -1638,6 +1737,7 @@ int nf_affine_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, float *
   const int size = geo_size(desc);
   if (!size || !ctx->wimg) return NF_ERR_UNSUPPORTED;
   if (size == NetGeo<1, 1, 1, 1>::SIZE) return launch_chain<NetGeo<1, 1, 1, 1>>(ctx, desc, inverse, xt, N, ladj, nullptr, stash);
+  if (stash && stash_slim(size)) return launch_chain<NetGeo<1, 2, 2, 1>, true>(ctx, desc, inverse, xt, N, ladj, nullptr, stash);
   return launch_chain<NetGeo<1, 2, 2, 1>>(ctx, desc, inverse, xt, N, ladj, nullptr, stash);
 }
 
@@ -1718,7 +1818,8 @@ size_t nf_affine_stash_floats(const nf_flow_desc *desc, long N) {
   const int size = geo_size(desc);
   if (!size || desc->n_hidden != 2) return 0;
   const size_t ntiles = (size_t)((N + NF_TILE - 1) / NF_TILE);
-  const size_t per = size == NetGeo<1, 1, 1, 1>::SIZE ? StashGeo<NetGeo<1, 1, 1, 1>>::SIZE : StashGeo<NetGeo<1, 2, 2, 1>>::SIZE;
+  const size_t per = size == NetGeo<1, 1, 1, 1>::SIZE ? StashGeo<NetGeo<1, 1, 1, 1>>::SIZE
+                     : stash_slim(size) ? StashGeo<NetGeo<1, 2, 2, 1>, true>::SIZE : StashGeo<NetGeo<1, 2, 2, 1>>::SIZE;
   return ntiles * (size_t)(2 * desc->nlayers) * per;
 }
 
@@ -1742,19 +1843,25 @@ static int launch_bwd_stashed_v(nf_ctx *ctx, const BwdAllArgs &aa, float *stash,
   return (int)hipGetLastError();
 }
 
-template <class G, bool FULL, bool INVD>
-static int launch_bwd_pair(nf_ctx *ctx, const BwdAllArgs &aa, float *stash, float *ybar, const float *lbar, float lbar_const,
-                           float *slab, long slab_stride, int grid) {
+template <class G, bool FULL, bool INVD, bool SLIM>
+static int launch_bwd_pair_v(nf_ctx *ctx, const BwdAllArgs &aa, float *stash, float *ybar, const float *lbar, float lbar_const,
+                             float *slab, long slab_stride, int grid) {
   const size_t lds = BwdPairLds<G>::BYTES;
   static AttrOnce attr_once;  // once per device
   NF_TRY(attr_once.run(ctx->device, [&]() -> int {
-    NF_HIP(hipFuncSetAttribute((const void *)k_affine_bwd_pair<G, FULL, INVD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NF_HIP(hipFuncSetAttribute((const void *)k_affine_bwd_pair<G, FULL, INVD, SLIM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return NF_OK;
   }));
   ProfScope ps(ctx, INVD ? "affine_bwd_inv" : "affine_bwd");
-  hipLaunchKernelGGL((k_affine_bwd_pair<G, FULL, INVD>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, aa, stash, ybar, lbar,
+  hipLaunchKernelGGL((k_affine_bwd_pair<G, FULL, INVD, SLIM>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, aa, stash, ybar, lbar,
                      lbar_const, slab, slab_stride);
   return (int)hipGetLastError();
+}
+template <class G, bool FULL, bool INVD>
+static int launch_bwd_pair(nf_ctx *ctx, const BwdAllArgs &aa, float *stash, float *ybar, const float *lbar, float lbar_const,
+                           float *slab, long slab_stride, int grid) {
+  return stash_slim(G::SIZE) ? launch_bwd_pair_v<G, FULL, INVD, true>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid)
+                             : launch_bwd_pair_v<G, FULL, INVD, false>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid);
 }
 
 // reverse pass of all couplings from the stash nf_affine_chain_elbo(..., stash) left (same slab layout as

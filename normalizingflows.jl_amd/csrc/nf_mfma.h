@@ -187,6 +187,47 @@ __device__ __forceinline__ void dense_fwd(const float *__restrict__ w, const flo
   }
 }
 
+// dense_fwd with a run-time number of ACTIVE k-groups (a group = four k-steps = input features 8g .. 8g+7): inputs beyond
+// the layer's real fan-in are zero padding, so their k-steps contribute nothing and are skipped (a wave-uniform branch per
+// group).  The spline couplings' first layer has fan-in d - c = 16 of a 32-wide block at cfg 3: 8 MFMAs instead of 16.
+template <int IB, int OB, int S = 32 * OB + NF_IMG_PAD>
+__device__ __forceinline__ void dense_fwd_dyn(const float *__restrict__ w, const float *__restrict__ b,
+                                              const f32x16 (&in)[IB], f32x16 (&out)[OB], int l31, int hi, int nga) {
+  constexpr int NG = IB * 4;
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[ob][r] = b[ob * 32 + nf_row(r, hi)];
+  const float *wl = w + (4 * hi) * S + l31;
+  float an[OB][4], ac[OB][4];
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) an[ob][e] = wl[e * S + ob * 32];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    if (g < nga) {
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ac[ob][e] = an[ob][e];
+      if (g + 1 < NG) {
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) an[ob][e] = wl[((g + 1) * 8 + e) * S + ob * 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob)
+          out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[ob][e], in[g / 4][(g % 4) * 4 + e], out[ob], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 // din[ib] = W^T * delta : the dX GEMM of the reverse pass, same register chaining.
 template <int IB, int OB, int S = 32 * OB + NF_IMG_PAD, bool ACCUM = false, class SJ = NoSideJob>
 __device__ __forceinline__ void dense_bwd_x(const float *__restrict__ w, const f32x16 (&delta)[OB],

@@ -460,13 +460,17 @@ struct RqsChainArgs {
 // drops the stores in hardware, so the step has no branch on it and needs no per-lane 64-bit address
 template <class G, bool INVERSE>
 __device__ __forceinline__ float rqs_coupling_step(const float *__restrict__ img, f32x16 (&x1)[G::CB],
-                                                   const f32x16 (&xb)[G::MB], int c, float B, int l31, int hi,
+                                                   const f32x16 (&xb)[G::MB], int c, int m, float B, int l31, int hi,
                                                    __amdgpu_buffer_rsrc_t tape) {
   const int tvoff = (hi * 32 + l31) * 4;
   f32x16 a2[G::H2B];
   {
     f32x16 a1[G::H1B];
+#ifdef RQS_COOP_R3
     dense_fwd<G::MB, G::H1B>(img + G::W1, img + G::B1, xb, a1, l31, hi);
+#else
+    dense_fwd_dyn<G::MB, G::H1B>(img + G::W1, img + G::B1, xb, a1, l31, hi, (m + 7) >> 3);
+#endif
 #pragma unroll
     for (int b = 0; b < G::H1B; ++b)
       nf_lrelu16(a1[b]);
@@ -632,9 +636,9 @@ __global__ __launch_bounds__(512) void k_rqs_chain(RqsChainArgs a, float *xt, fl
           const __amdgpu_buffer_rsrc_t tp = __builtin_amdgcn_make_buffer_rsrc(
               a.tape.base + (a.tape.base ? slot * (ROWS * 64) : 0), 0, (a.tape.base && live) ? ROWS * 256 : 0, 0x00020000);
           if (INVERSE ? (half == 1) : (half == 0))
-            lsum += rqs_coupling_step<G, INVERSE>(img, O, E, c_even, a.B, l31, hi, tp);
+            lsum += rqs_coupling_step<G, INVERSE>(img, O, E, c_even, a.d - c_even, a.B, l31, hi, tp);
           else
-            lsum += rqs_coupling_step<G, INVERSE>(img, E, O, c_odd, a.B, l31, hi, tp);
+            lsum += rqs_coupling_step<G, INVERSE>(img, E, O, c_odd, a.d - c_odd, a.B, l31, hi, tp);
         }
         __syncthreads();
         buf ^= 1;
@@ -1065,6 +1069,71 @@ struct RqsCoopLds {
   static constexpr size_t BYTES = (size_t)(G::SIZE + 4 * SCRATCH + 4 * NSETS * SLOT) * sizeof(float);
 };
 
+
+// Orders a wave's own LDS accesses for the COMPILER only.  The hardware needs nothing: a wave's LDS instructions execute in
+// issue order, so a ds_read issued after a ds_write of the same wave sees it (and a ds_write after a ds_read cannot
+// overtake it).  wave_lds_fence() (nf_mfma.h) additionally makes the wave WAIT for its outstanding LDS traffic
+// (s_waitcnt lgkmcnt(0)), which the transpose round trips below do not need: the consumer of the read has its own wait.
+__device__ __forceinline__ void wave_lds_order() {
+#ifdef RQS_COOP_R3
+  wave_lds_fence();
+#else
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+#endif
+}
+
+// dW3^T of one (tile, chunk): acc[ib][pc] += a2^T x delta_pc^T for the chunk's OBC blocks of delta (`out` after the spline's
+// reverse pass), bsum[pc] += row sums of delta.  Round 4 form: the a2^T operand (16 k-steps = the tile's 32 samples) is
+// fetched ONCE and serves all OBC blocks (round 3 fetched it per block), a block's whole delta^T operand is fetched in one
+// go, so that the NEXT block's transpose write is already under way while this block's MFMAs run (the wave's transpose
+// tile holds one block), and the bias sums are pairwise trees of two-wide adds instead of a 16-long chain.
+template <class G>
+__device__ __forceinline__ void rqs_dw3_chunk(const float *__restrict__ sa2, float *__restrict__ sd, const f32x16 (&out)[G::OBC],
+                                              f32x16 (&acc)[G::H2B][G::OBC], float (&bsum)[G::OBC], int l31, int hi) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const float *pa = sa2 + l31 * NF_TS + hi;
+  const float *pd = sd + l31 * NF_TS + hi;
+  float aT[G::H2B][16];
+#pragma unroll
+  for (int ib = 0; ib < G::H2B; ++ib)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) aT[ib][t] = pa[ib * 32 * NF_TS + 2 * t];
+  {
+    f32x16 one[1] = {out[0]};
+    tile_to_scratch<1>(sd, one, l31, hi);
+  }
+#pragma unroll
+  for (int pc = 0; pc < G::OBC; ++pc) {
+    wave_lds_order();
+    float dT[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) dT[t] = pd[2 * t];
+    wave_lds_order();
+    if (pc + 1 < G::OBC) {
+      f32x16 one[1] = {out[pc + 1]};
+      tile_to_scratch<1>(sd, one, l31, hi);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x2 s2[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) s2[t] = f32x2{dT[2 * t], dT[2 * t + 1]};
+#pragma unroll
+    for (int w = 4; w >= 1; w >>= 1)
+#pragma unroll
+      for (int t = 0; t < w; ++t) s2[t] += s2[t + w];
+    bsum[pc] += s2[0][0] + s2[0][1];
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+      for (int ib = 0; ib < G::H2B; ++ib)
+        acc[ib][pc] = __builtin_amdgcn_mfma_f32_32x32x2f32(aT[ib][t], dT[t], acc[ib][pc], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  wave_lds_order();
+}
+
 template <class G>
 struct RqsCoopAcc {
   f32x16 w1[G::MB][G::H1B];
@@ -1078,11 +1147,20 @@ __device__ __forceinline__ void rqs_bwd_coop_coupling(const RqsBwdArgs &a, float
                                                       const float *__restrict__ lbar, float lbar_const,
                                                       float *__restrict__ slab, long slab_stride, float *lds) {
   using L = RqsCoopLds<G>;
-  float *img = lds;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
+  // LDS map: the waves' transpose tiles FIRST, then the partial-d2 slots, the weight image last.  A ds instruction carries a
+  // 16-bit byte offset; with the 60 KB image in front (round 3) the rows of a transpose tile straddled the 64 KB mark and
+  // hipcc materialised a separate address register for most of them (131 v_add_u32 in the kernel, 59 per tile of the chunk
+  // phase).  The image is addressed through one per-lane pointer plus row offsets below 50 KB wherever it sits.
+#ifdef RQS_COOP_R3
+  float *img = lds;
   float *sc_all = lds + G::SIZE;
+#else
+  float *sc_all = lds;
+  float *img = lds + 4 * L::SCRATCH + 4 * L::NSETS * L::SLOT;
+#endif
   float *sc = sc_all + wave * L::SCRATCH;          // this wave's tiles
   float *slots = sc_all + 4 * L::SCRATCH;          // [NSETS][4][SLOT]
   float *sd = sc + L::OFF_D;
@@ -1099,19 +1177,25 @@ __device__ __forceinline__ void rqs_bwd_coop_coupling(const RqsBwdArgs &a, float
   // The conditioner half of a group's home tile is requested ONE GROUP AHEAD (right after barrier B0, when the registers
   // are free again): with one wave per SIMD nothing else hides the HBM latency of these loads -- the home phase took
   // 9.1 k cycles for 2 k cycles of MFMA work before (tools/trace_rqs.py).
+  // (round 4: the loads stay RAW here and padding samples are zeroed where the tile is consumed, one group later.  With the
+  // select next to the loads hipcc waited for all sixteen of them -- a full HBM round trip -- at the head of the closing
+  // home phase, the very latency the prefetch is there to hide: ISA of round 3, `s_waitcnt vmcnt(15..0)` + v_cndmask pairs.)
   f32x16 xb[G::MB];
   auto load_home = [&](long g) {
     const long tile_ = g * 4 + wave;
     const bool live_ = tile_ < ntiles;
     const long tl_ = live_ ? tile_ : 0;
-    const bool valid_ = live_ && tl_ * NF_TILE + l31 < a.N;
     const TileIO yio_ = make_tile_io(y, tl_, a.d, l31, hi);
 #pragma unroll
     for (int b = 0; b < G::MB; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float v = tile_load(yio_, tile_soff(b, r, par_c));
-        xb[b][r] = valid_ ? v : 0.f;
+#ifdef RQS_COOP_R3
+        xb[b][r] = (live_ && tl_ * NF_TILE + l31 < a.N) ? v : 0.f;
+#else
+        xb[b][r] = v;
+#endif
       }
   };
 #ifndef RQS_NO_PREFETCH
@@ -1119,6 +1203,7 @@ __device__ __forceinline__ void rqs_bwd_coop_coupling(const RqsBwdArgs &a, float
 #endif
 #ifdef NF_KERNEL_TRACE
   long long *tr = (a.trace && blockIdx.x == 0 && tid == 0) ? a.trace : nullptr;
+  if (tr) { tr[100] = clock64(); tr[101] = wall_clock64(); }  // shader clock against the constant 100 MHz counter: the clock the kernel ran at
 #define COOP_STAMP(slot) do { if (tr && grp == (long)blockIdx.x) { __builtin_amdgcn_sched_barrier(0); tr[slot] = clock64(); } } while (0)
 #else
 #define COOP_STAMP(slot) do { } while (0)
@@ -1140,9 +1225,19 @@ __device__ __forceinline__ void rqs_bwd_coop_coupling(const RqsBwdArgs &a, float
     load_home(grp);
 #endif
     if (live) {
+#ifndef RQS_COOP_R3
+#pragma unroll
+      for (int b = 0; b < G::MB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xb[b][r] = valid ? xb[b][r] : 0.f;
+#endif
       tile_to_scratch<G::MB>(sc + L::OFF_X, xb, l31, hi);
       f32x16 a1[G::H1B];
+#ifdef RQS_COOP_R3
       dense_fwd<G::MB, G::H1B>(img + G::W1, img + G::B1, xb, a1, l31, hi);
+#else
+      dense_fwd_dyn<G::MB, G::H1B>(img + G::W1, img + G::B1, xb, a1, l31, hi, (a.m + 7) >> 3);
+#endif
 #pragma unroll
       for (int b = 0; b < G::H1B; ++b) {
         nf_lrelu16(a1[b]);
@@ -1254,6 +1349,7 @@ __device__ __forceinline__ void rqs_bwd_coop_coupling(const RqsBwdArgs &a, float
         }
         COOP_STAMP(5 + 6 * t);
         // this chunk's columns of dW3^T: one block of delta at a time through the wave's own transpose tile
+#if defined(RQS_COOP_R3) || defined(RQS_COOP_OLD_DW3)
 #pragma unroll
         for (int pc = 0; pc < G::OBC; ++pc) {
           f32x16 one[1] = {out[pc]};
@@ -1262,6 +1358,9 @@ __device__ __forceinline__ void rqs_bwd_coop_coupling(const RqsBwdArgs &a, float
           dw_accumulate_at<G::H2B, 1, G::OBC>(sct + L::OFF_A2, sd, acc.w3, acc.b3, pc, l31, hi);
           wave_lds_fence();
         }
+#else
+        rqs_dw3_chunk<G>(sct + L::OFF_A2, sd, out, acc.w3, acc.b3, l31, hi);
+#endif
         COOP_STAMP(6 + 6 * t);
       }
       __syncthreads();  // B1: the four partial d2 of tile t are in the slots
@@ -1291,34 +1390,55 @@ __device__ __forceinline__ void rqs_bwd_coop_coupling(const RqsBwdArgs &a, float
 #pragma unroll
         for (int r = 0; r < 16; ++r) d2[b][r] *= nf_mask_slope(m2[b], r);
       tile_to_scratch<G::H2B>(sd, d2, l31, hi);
-      wave_lds_fence();
+      wave_lds_order();
       dw_accumulate<G::H1B, G::H2B>(sc + L::OFF_A1, sd, acc.w2, acc.b2, l31, hi);
       f32x16 d1[G::H1B];
       dense_bwd_x<G::H1B, G::H2B>(img + G::W2, d2, d1, l31, hi);
+#if !defined(RQS_COOP_R3) && !defined(RQS_COOP_GOLD_LATE)
+      // the conditioner half of the cotangent tile is the accumulator the dX1 GEMM starts from.  Requested here, two GEMMs
+      // ahead of its use (d2 is dead now; held from the start of the phase it cost 250-320 bytes of scratch spills)
+      f32x16 g2[G::MB];
+#pragma unroll
+      for (int b = 0; b < G::MB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g2[b][r] = tile_load(gio, tile_soff(b, r, par_c));
+#endif
 #pragma unroll
       for (int b = 0; b < G::H1B; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) d1[b][r] *= nf_mask_slope(m1[b], r);
-      wave_lds_fence();
+      wave_lds_order();
       tile_to_scratch<G::H1B>(sd, d1, l31, hi);
-      wave_lds_fence();
+      wave_lds_order();
       dw_accumulate<G::MB, G::H1B>(sc + L::OFF_X, sd, acc.w1, acc.b1, l31, hi);
+#if defined(RQS_COOP_R3) || defined(RQS_COOP_GOLD_LATE)
       f32x16 g2[G::MB], gold[G::MB];
 #pragma unroll
       for (int b = 0; b < G::MB; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) gold[b][r] = tile_load(gio, tile_soff(b, r, par_c));
       dense_bwd_x<G::MB, G::H1B>(img + G::W1, d1, g2, l31, hi);
-      wave_lds_fence();
+      wave_lds_order();
 #pragma unroll
       for (int b = 0; b < G::MB; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) tile_store(gio, tile_soff(b, r, par_c), gold[b][r] + g2[b][r]);
+#else
+      dense_bwd_x<G::MB, G::H1B, G::S1, true>(img + G::W1, d1, g2, l31, hi);
+      wave_lds_order();
+#pragma unroll
+      for (int b = 0; b < G::MB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tile_store(gio, tile_soff(b, r, par_c), g2[b][r]);
+#endif
     }
     COOP_STAMP(27);
     // no barrier here: the next group's home phase writes only this wave's own tiles, which the other waves stopped
     // reading at the last B2, and B0 orders those writes before anybody reads them
   }
+#ifdef NF_KERNEL_TRACE
+  if (tr) { tr[102] = clock64(); tr[103] = wall_clock64(); }
+#endif
   __syncthreads();  // the weight image is dead: it becomes the fold target
   // layers 1 and 2: four partial sums (one per wave), added in wave order; output layer: each wave owns its columns
 #pragma unroll 1

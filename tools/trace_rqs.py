@@ -41,6 +41,8 @@ if os.environ.get("NF_RQS_BWD_PERWAVE") is None:
         prev = t[b + 5]
     print(f"home: layers 2 and 1 + stores        +{t[27] - prev:7d}   (MFMA-ideal 4096)")
     print(f"group total {t[27] - t[0]}  (MFMA-ideal {672 * 64})")
+    if t[103] > t[101]:
+        print(f"all groups of workgroup 0: {t[102] - t[100]} shader clocks in {(t[103] - t[101]) / 100:.1f} us = {100.0 * (t[102] - t[100]) / (t[103] - t[101]):.0f} MHz while the kernel ran")
     sys.exit(0)
 
 print(f"loads + L1 + L2 (+stash)        +{t[1] - t[0]:7d}   (MFMA-ideal 2048)")
