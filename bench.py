@@ -438,6 +438,9 @@ def run_once(args, world, world_observed, rank, dev, dist, damp, state):
                                   else ", torch.distributed RCCL; libnfhip's communicator failed to initialise)" if state.get("lib_comm_failed")
                                   else ", torch.distributed RCCL)" if dist is not None else ")"),
                 "nf_comm_size": comm_size,
+                # messages the step's one logical all-reduce of [grad ; loss] travels as (nf_comm_bucket_count: buckets of whole
+                # couplings on a second stream for cfg 4's 16.9 MB, one message for cfg 2's 0.5 MB; 0 = no communicator)
+                "all_reduce_messages_per_step": int(lib.nf_comm_bucket_count(ctx.ptr, desc)) if lib_comm else (1 if dist is not None else 0),
                 "step_form": ("hipGraph replay of nf_elbo_step_enqueue" if use_graph else "nf_elbo_step (whole iteration inside the library)"
                               if fused_step else "nf_elbo_value_and_grad + nf_adam_update (split calls)"),
                 "init": "Glorot-uniform weights, zero biases (Flux default)" + (f", theta scaled by {damp}" if damp is not None else ""),

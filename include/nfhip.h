@@ -350,6 +350,15 @@ int nf_comm_get_unique_id(void *id_out_host);
 int nf_comm_init_rank(nf_ctx *ctx, const void *id_host, int32_t nranks, int32_t rank);
 int nf_comm_init_all(nf_ctx **ctxs, int32_t ngpus);
 int nf_comm_size(nf_ctx *ctx); /* ranks of the context's communicator (1 if none) */
+/* The step's one logical all-reduce may travel as several messages: under a communicator nf_elbo_step sends the gradient
+ * of a weight-streaming RealNVP flow (BASELINE cfg 4: P + 1 = 4 214 785 floats, 16.9 MB) in buckets of whole couplings
+ * (contiguous theta ranges, Optimisers.destructure order) on a second stream, each as soon as its couplings' reverse pass
+ * and slab sum are done, and joins before the optimiser update; every rank issues the same buckets in the same order and
+ * receives the same reduced bits.  bucket_bytes < 0: automatic (4 MiB, the default), 0: always one message, > 0: target
+ * bucket size.  Gradients smaller than two buckets (cfg 2: 0.5 MB) always travel as one message.
+ * nf_comm_bucket_count: all-reduce calls nf_elbo_step issues per step for this flow (0 without a communicator). */
+int nf_ctx_set_comm_bucket_bytes(nf_ctx *ctx, int64_t bucket_bytes);
+int nf_comm_bucket_count(nf_ctx *ctx, const nf_flow_desc *desc);
 /* in place: buf[0..count) <- sum over ranks; count = P + 1 for the training step */
 int nf_allreduce_grad_loss(nf_ctx *ctx, int32_t dtype, void *buf, int64_t count);
 int nf_allreduce_grad_loss_all(nf_ctx **ctxs, int32_t ngpus, int32_t dtype, void **bufs, int64_t count);

@@ -8,7 +8,7 @@ from ._lib import LIB_PATH, SYMBOLS, Context, NFHipError, context_for, load_libr
 from .flows import (BananaTarget, CompositeFlow, CrossTarget, DiagGaussTarget, FunnelTarget, WarpedGaussTarget, Flow, MvNormal, create_flow, PhiloxRNG, Transform, as_batch, base_logpdf,
                     device_specific_rand, hamiltonianflow, inverse, layer, logpdf, meanfield, new_batch, nsf, planarflow, radialflow,
                     rand, realnvp, rrule_with_logabsdet_jacobian, target_logp, transform, with_logabsdet_jacobian)
-from .parallel import ShardedObjective, allreduce_grad_loss, make_gpu_forward_kl_local_step, make_gpu_local_step, shard_range
+from .parallel import ShardedObjective, allreduce_grad_loss, allreduce_grad_loss_bucketed, bucket_bounds, make_gpu_forward_kl_local_step, make_gpu_local_step, shard_range
 from .objectives import (Adam, AdamState, Descent, Momentum, SGDState, adam_update, setup, update, batched_elbos, elbo, elbo_batch, loglikelihood, loglikelihood_value_and_gradient, optimize,
                          train_flow, value_and_gradient)
 

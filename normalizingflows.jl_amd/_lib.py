@@ -106,6 +106,8 @@ SYMBOLS = {
     "nf_comm_init_rank": (C.c_int, [_P, _P, _I32, _I32]),
     "nf_comm_init_all": (C.c_int, [C.POINTER(_P), _I32]),
     "nf_comm_size": (C.c_int, [_P]),
+    "nf_ctx_set_comm_bucket_bytes": (C.c_int, [_P, _I64]),
+    "nf_comm_bucket_count": (C.c_int, [_P, _DESC]),
     "nf_allreduce_grad_loss": (C.c_int, [_P, _I32, _P, _I64]),
     "nf_allreduce_grad_loss_all": (C.c_int, [C.POINTER(_P), _I32, _I32, C.POINTER(_P), _I64]),
     "nf_comm_destroy": (C.c_int, [_P]),

@@ -2059,6 +2059,29 @@ static int step_readback(nf_ctx *ctx, const nf_flow_desc *desc, long P, double *
   return NF_OK;
 }
 
+// couplings per all-reduce bucket for this flow under the context's communicator; 0: one message (no communicator, a flow
+// whose reverse pass does not finish coupling by coupling on the host side, or a gradient smaller than two buckets)
+static int comm_bucket_couplings(nf_ctx *ctx, const nf_flow_desc *desc) {
+  if (!ctx->comm || ctx->comm_bucket_bytes == 0) return 0;
+  if (flow_base(desc) || is_composite(desc) || desc->dtype != NF_DTYPE_F32 || !is_coupling(desc) || !is_wide(desc)) return 0;
+  const long long bytes = ctx->comm_bucket_bytes < 0 ? (4ll << 20) : ctx->comm_bucket_bytes;
+  const int nc = 2 * desc->nlayers;
+  const long long per = (long long)nf_param_count(desc) * 4 / nc;  // bytes of one coupling's parameters
+  if (per * nc < 2 * bytes) return 0;
+  long long c = (bytes + per / 2) / per;
+  if (c < 1) c = 1;
+  return c >= nc ? 0 : (int)c;
+}
+
+extern "C" int nf_comm_bucket_count(nf_ctx *ctx, const nf_flow_desc *desc) {
+  if (!ctx) return NF_ERR_ARG;
+  const int st = check_desc(desc);
+  if (st != NF_OK) return st;
+  const int cpb = comm_bucket_couplings(ctx, desc);
+  if (cpb <= 0) return ctx->comm ? 1 : 0;
+  return (2 * desc->nlayers + cpb - 1) / cpb;
+}
+
 extern "C" int nf_elbo_step(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, void *theta, void *m,
                             void *v, int64_t N, uint64_t seed, uint32_t step, double lr, double beta1, double beta2,
                             double eps, double *loss_host, double *gnorm_host) {
@@ -2074,8 +2097,17 @@ extern "C" int nf_elbo_step(nf_ctx *ctx, const nf_flow_desc *desc, const nf_targ
   } else {
     const int world = ctx->comm ? ctx->comm_size : 1;
     const uint64_t off = (uint64_t)(ctx->comm ? ctx->comm_rank : 0) * (uint64_t)N;
-    NF_TRY(nf_elbo_value_and_grad(ctx, desc, target, theta, nullptr, N, N * world, seed, off, step, gbuf));
-    if (world > 1) NF_TRY(nf_allreduce_grad_loss(ctx, desc->dtype, gbuf, P + 1));
+    // weight-streaming RealNVP with many parameters (cfg 4: 16.9 MB): the all-reduce goes out in buckets of whole couplings
+    // on the second stream as the reverse pass produces them (nf_comm.hip); everything else: one message after the gradient
+    const int cpb = comm_bucket_couplings(ctx, desc);
+    ctx->bucket.on = cpb > 0;
+    ctx->bucket.couplings = cpb;
+    ctx->bucket.issued = 0;
+    const int st_vg = nf_elbo_value_and_grad(ctx, desc, target, theta, nullptr, N, N * world, seed, off, step, gbuf);
+    ctx->bucket.on = false;
+    NF_TRY(st_vg);
+    if (cpb > 0) NF_TRY(nf_comm_bucket_join(ctx));
+    else if (world > 1) NF_TRY(nf_allreduce_grad_loss(ctx, desc->dtype, gbuf, P + 1));
     char *gnorm_dev = (char *)gbuf + (size_t)(P + 1) * es;
     NF_TRY(nf_adam_update(ctx, desc->dtype, theta, gbuf, m, v, P, lr, beta1, beta2, eps, (int64_t)step + 1, gnorm_dev));
   }

@@ -139,8 +139,54 @@ extern "C" int nf_allreduce_grad_loss_all(nf_ctx **ctxs, int32_t ngpus, int32_t 
   return st != NF_OK ? st : ge;
 }
 
+// ---- bucketed form ---------------------------------------------------------------------------------------
+// The step's all-reduce of [grad ; loss] is ONE logical collective (every rank adds the same P + 1 numbers), but nothing
+// forces it to be one message: the gradient of coupling k is final as soon as that coupling's reverse pass and slab sum are
+// done, 15 couplings before the last one at cfg 4.  A bucket = the theta range of a few whole couplings (contiguous in
+// Optimisers.destructure order); its all-reduce is issued on the context's SECOND stream behind an event, so xGMI moves it
+// while the matrix pipe runs the next couplings, and the optimiser update waits for the join.  Every rank issues the same
+// buckets in the same order (the schedule depends on the flow shape only), every rank receives the same reduced bits, so
+// replicas stay bit-identical with each other.
+int nf_comm_bucket_issue(nf_ctx *ctx, int32_t dtype, void *buf, int64_t count) {
+  if (!ctx || !ctx->comm || !buf || count < 0) return NF_ERR_ARG;
+  NF_TRY(api());
+  if (!ctx->comm_stream) NF_HIP(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+  if (ctx->comm_events.empty()) {
+    ctx->comm_events.resize(65);
+    for (auto &e : ctx->comm_events) NF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  if (ctx->comm_event_next >= ctx->comm_events.size()) ctx->comm_event_next = 1;  // 64 buckets in flight at most; a step has <= 32
+  hipEvent_t ready = ctx->comm_events[ctx->comm_event_next++];
+  NF_HIP(hipEventRecord(ready, ctx->stream));
+  NF_HIP(hipStreamWaitEvent(ctx->comm_stream, ready, 0));
+  ctx->bucket.issued++;
+  return rccl_status(g_api.AllReduce(buf, buf, (size_t)count, rccl_dtype(dtype), RCCL_SUM, ctx->comm, ctx->comm_stream));
+}
+
+int nf_comm_bucket_join(nf_ctx *ctx) {
+  if (!ctx) return NF_ERR_ARG;
+  if (!ctx->comm_stream || ctx->comm_events.empty()) return NF_OK;
+  NF_HIP(hipEventRecord(ctx->comm_events[0], ctx->comm_stream));
+  NF_HIP(hipStreamWaitEvent(ctx->stream, ctx->comm_events[0], 0));
+  return NF_OK;
+}
+
+extern "C" int nf_ctx_set_comm_bucket_bytes(nf_ctx *ctx, int64_t bytes) {
+  if (!ctx) return NF_ERR_ARG;
+  ctx->comm_bucket_bytes = bytes;
+  return NF_OK;
+}
+
 extern "C" int nf_comm_destroy(nf_ctx *ctx) {
   if (!ctx) return NF_ERR_ARG;
+  if (ctx->comm_stream) {
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->comm_stream);
+    for (auto &e : ctx->comm_events) hipEventDestroy(e);
+    ctx->comm_events.clear();
+    hipStreamDestroy(ctx->comm_stream);
+    ctx->comm_stream = nullptr;
+  }
   if (!ctx->comm) return NF_OK;
   NF_TRY(api());
   hipSetDevice(ctx->device);

@@ -70,9 +70,24 @@ struct nf_ctx {
   // RCCL communicator of this context (nf_comm.hip); null for single-GPU use
   void *comm = nullptr;
   int comm_size = 1, comm_rank = 0;
+  // bucketed all-reduce (nf_comm.hip): the gradient of a flow with many parameters travels in buckets of whole couplings
+  // on a second stream while the reverse pass of the next couplings runs (cfg 4, 16.9 MB per step)
+  hipStream_t comm_stream = nullptr;
+  std::vector<hipEvent_t> comm_events;  // pooled; [0] is the join event
+  size_t comm_event_next = 1;
+  long long comm_bucket_bytes = -1;     // nf_ctx_set_comm_bucket_bytes: < 0 automatic (4 MiB), 0 never bucket
+  struct {
+    bool on = false;      // set by nf_elbo_step around its gradient call
+    int couplings = 0;    // couplings per bucket
+    int issued = 0;       // all-reduces issued for the current step
+  } bucket;
 };
 
 const char *nf_comm_last_error();
+// bucketed form of the step's one logical all-reduce (nf_comm.hip): `count` elements at `buf` are final on ctx->stream now;
+// the all-reduce runs on the context's second stream.  nf_comm_bucket_join makes ctx->stream wait for every issued bucket.
+int nf_comm_bucket_issue(nf_ctx *ctx, int32_t dtype, void *buf, int64_t count);
+int nf_comm_bucket_join(nf_ctx *ctx);
 
 int nf_ws_reserve(nf_ctx *ctx, size_t bytes);
 // packed weight images (ctx->wimg) of at least `bytes`: grow-only allocation, or a tail carve of the caller's arena

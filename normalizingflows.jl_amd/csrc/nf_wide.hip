@@ -905,10 +905,10 @@ __global__ __launch_bounds__(256) void k_wide_reduce(NetDims nd, const float *__
 // region, and ONE launch at the end sums them all (blockIdx.y = 2 * coupling + phase; phase 0 = t net, 1 = s net).
 template <class G>
 __global__ __launch_bounds__(256) void k_wide_reduce_all(PackArgs p, const float *__restrict__ slab, int nslab, long slab_stride,
-                                                         float *__restrict__ g) {
+                                                         float *__restrict__ g, int job0) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= G::B3 + 32 * G::CB) return;
-  const int job = blockIdx.y, k = job >> 1, phase = job & 1;
+  const int job = blockIdx.y + job0, k = job >> 1, phase = job & 1;  // job0: first job of a gradient bucket (0: all at once)
   const int c = (k & 1) ? p.d / 2 : (p.d + 1) / 2, m = p.d - c;
   long off = (long)(k >> 1) * p.pair_params + ((k & 1) ? p.odd_params : 0);
   if (phase == 0) off += net_param_count(m, p.h1, p.h2, c);
@@ -1238,12 +1238,28 @@ static int wide_train_backward(nf_ctx *ctx, const nf_flow_desc *desc, float *sta
         NF_HIP(hipGetLastError());
       }
     }
+    // Data-parallel step with a bucketed all-reduce (nf_elbo_step under a communicator): the couplings [k0, k] are final --
+    // sum their split-K partials now and hand their theta range (contiguous: flat coupling order IS destructure order) to
+    // the second stream; the last bucket carries the loss at g_out[P] along.
+    if (ctx->bucket.on && ((k + 1) % ctx->bucket.couplings == 0 || k == nc - 1)) {
+      const int k0 = (k / ctx->bucket.couplings) * ctx->bucket.couplings;
+      {
+        ProfScope ps(ctx, "reduce_slabs");
+        constexpr int NE = G::B3 + 32 * G::CB;
+        hipLaunchKernelGGL((k_wide_reduce_all<G>), dim3((NE + 255) / 256, 2 * (k + 1 - k0)), dim3(256), 0, ctx->stream, make_pack_args(desc),
+                           slab, ks, (long)G::SIZE, g_out, 2 * k0);
+        NF_HIP(hipGetLastError());
+      }
+      const long lo = nf_coupling_info(desc, k0).theta_off;
+      const long hi = k == nc - 1 ? nf_param_count(desc) + 1 : nf_coupling_info(desc, k + 1).theta_off;
+      NF_TRY(nf_comm_bucket_issue(ctx, NF_DTYPE_F32, g_out + lo, hi - lo));
+    }
   }
-  {
+  if (!ctx->bucket.on) {
     ProfScope ps(ctx, "reduce_slabs");
     constexpr int NE = G::B3 + 32 * G::CB;
     hipLaunchKernelGGL((k_wide_reduce_all<G>), dim3((NE + 255) / 256, 2 * nc), dim3(256), 0, ctx->stream, make_pack_args(desc), slab, ks,
-                       (long)G::SIZE, g_out);
+                       (long)G::SIZE, g_out, 0);
     NF_HIP(hipGetLastError());
   }
   return NF_OK;

@@ -32,21 +32,52 @@ def allreduce_grad_loss(buf, group=None):
     return buf
 
 
+def bucket_bounds(coupling_offsets, n_params: int, couplings_per_bucket: int):
+    """Bucket boundaries of the packed [grad ; loss] buffer for a bucketed all-reduce: `coupling_offsets[k]` is the
+    theta offset of flat coupling k (ascending: flat coupling order is Optimisers.destructure order), buckets hold
+    `couplings_per_bucket` whole couplings, the last one also the loss at index n_params.  Returns [(lo, hi), ...]
+    covering [0, n_params + 1) -- the schedule nf_elbo_step uses under a communicator (nf_comm.hip)."""
+    offs = list(coupling_offsets)
+    if not offs or offs[0] != 0 or any(b <= a for a, b in zip(offs, offs[1:])) or offs[-1] >= n_params or couplings_per_bucket < 1:
+        raise ValueError("bad coupling offsets")
+    starts = offs[::couplings_per_bucket]
+    return [(lo, hi) for lo, hi in zip(starts, starts[1:] + [n_params + 1])]
+
+
+def allreduce_grad_loss_bucketed(buf, bounds, group=None):
+    """The same logical collective as allreduce_grad_loss, sent as one message per bucket (asynchronously, joined before
+    returning): every rank issues the same buckets in the same order and receives the same reduced bits."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return buf
+    if bounds[0][0] != 0 or bounds[-1][1] != buf.numel() or any(a[1] != b[0] for a, b in zip(bounds, bounds[1:])):
+        raise ValueError("buckets must tile the buffer")
+    works = [dist.all_reduce(buf[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True) for lo, hi in bounds]
+    for w in works:
+        w.wait()
+    return buf
+
+
 class ShardedObjective:
     """loss_and_grad(theta) for `optimize`: evaluates this rank's shard with `local_step` and
     all-reduces.  `local_step(theta, offset, count, n_global, step) -> tensor[P + 1]` is
     nf_elbo_value_and_grad on the GPU path (see make_gpu_local_step) or any function with the same
     contract (the CPU tests use the oracle)."""
 
-    def __init__(self, local_step, n_global: int, rank: int, world: int, group=None):
+    def __init__(self, local_step, n_global: int, rank: int, world: int, group=None, buckets=None):
         self.local_step, self.n_global, self.rank, self.world, self.group = local_step, n_global, rank, world, group
         self.offset, self.count = shard_range(n_global, rank, world)
         self.step = 0
+        self.buckets = buckets  # None: one message; else [(lo, hi), ...] from bucket_bounds
 
     def __call__(self, theta):
         buf = self.local_step(theta, self.offset, self.count, self.n_global, self.step)
         self.step += 1
-        allreduce_grad_loss(buf, self.group)
+        if self.buckets:
+            allreduce_grad_loss_bucketed(buf, self.buckets, self.group)
+        else:
+            allreduce_grad_loss(buf, self.group)
         return float(buf[-1]), buf[:-1]
 
 

@@ -95,6 +95,97 @@ def test_library_rccl_entry_points_world_size_one():
         ctx.close()
 
 
+def test_bucketed_all_reduce_equals_one_message_under_a_communicator():
+    """nf_elbo_step under a communicator, weight-streaming RealNVP (the cfg-4 family): the gradient leaves in buckets of
+    whole couplings on the context's second stream (nf_comm_bucket_count > 1) and the optimiser update waits for the
+    join.  With one rank every all-reduce is the identity, so theta / m / v after three steps must equal, bit for bit,
+    both the single-message form (bucket bytes 0) and a context without a communicator -- what the test pins is the
+    schedule: bucket boundaries on coupling boundaries, the loss in the last bucket, events and the join in order."""
+    nf = load_package()
+    lib = nf.load_library()
+    flow = nf.realnvp(nf.MvNormal(256), [256, 256], 3, paramtype=torch.float32, seed=4)  # 6 couplings, P = 1.58 M (6.3 MB)
+    rng = np.random.default_rng(0)
+    tgt = nf.DiagGaussTarget(torch.tensor(rng.standard_normal(256), dtype=torch.float32, device="cuda"),
+                             torch.tensor(rng.uniform(size=256) + 0.5, dtype=torch.float32, device="cuda"))
+    vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    n = 1000
+    stream = torch.cuda.current_stream(0).cuda_stream
+
+    def run(comm, bucket_bytes):
+        ctx = nf._lib.Context(0, stream)
+        try:
+            if comm:
+                raw = (C.c_char * 128)()
+                nf._lib.check(lib.nf_comm_get_unique_id(raw))
+                nf._lib.check(lib.nf_comm_init_rank(ctx.ptr, raw, 1, 0))
+                nf._lib.check(lib.nf_ctx_set_comm_bucket_bytes(ctx.ptr, bucket_bytes))
+            nb = lib.nf_comm_bucket_count(ctx.ptr, C.byref(flow.desc))
+            th, m, v = flow.theta.clone(), torch.zeros_like(flow.theta), torch.zeros_like(flow.theta)
+            stats = []
+            for step in range(3):
+                loss, gn = C.c_double(0), C.c_double(0)
+                nf._lib.check(lib.nf_elbo_step(ctx.ptr, C.byref(flow.desc), C.byref(tgt.c), vp(th), vp(m), vp(v), n, 7, step, 1e-3, 0.9,
+                                               0.999, 1e-8, C.byref(loss), C.byref(gn)))
+                stats.append((loss.value, gn.value))
+            torch.cuda.synchronize()
+            return nb, th, m, v, stats
+        finally:
+            ctx.close()
+
+    nb0, th0, m0, v0, st0 = run(False, 0)
+    nb1, th1, m1, v1, st1 = run(True, 0)            # one message
+    nb2, th2, m2, v2, st2 = run(True, 2 << 20)      # 2 MiB buckets: two couplings (2.1 MB) each -> 3 buckets
+    nb3, th3, m3, v3, st3 = run(True, 1 << 20)      # 1 MiB: one coupling per bucket -> 6
+    nb4, _, _, _, _ = run(True, -1)                 # automatic (4 MiB): 6.3 MB < two buckets -> one message
+    assert (nb0, nb1, nb2, nb3, nb4) == (0, 1, 3, 6, 1)
+    for th, m, v, st in ((th1, m1, v1, st1), (th2, m2, v2, st2), (th3, m3, v3, st3)):
+        assert torch.equal(th, th0) and torch.equal(m, m0) and torch.equal(v, v0) and st == st0
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs on the node (the pool's test boxes have one)")
+def test_one_process_two_devices_all_reduce():
+    """The single-process form of the collective (one host thread, G contexts: nf_comm_init_all +
+    nf_allreduce_grad_loss_all) over two real devices: each context computes its shard of one global batch, the grouped
+    all-reduce leaves the same [grad ; loss] on both, and it equals the one-device gradient of the whole batch."""
+    nf = load_package()
+    lib = nf.load_library()
+    G = 2
+    flows, tgts, ctxs, outs = [], [], [], []
+    rng = np.random.default_rng(0)
+    mu, var = rng.standard_normal(64).astype(np.float32), (rng.uniform(size=64) + 0.5).astype(np.float32)
+    n = 2048
+    for g in range(G):
+        dev = torch.device("cuda", g)
+        with torch.cuda.device(dev):
+            flows.append(nf.realnvp(nf.MvNormal(64), [64, 64], 2, paramtype=torch.float32, device=dev, seed=3))
+            tgts.append(nf.DiagGaussTarget(torch.tensor(mu, device=dev), torch.tensor(var, device=dev)))
+            ctxs.append(nf._lib.Context(g, torch.cuda.current_stream(g).cuda_stream))
+            outs.append(torch.zeros(flows[g].P + 1, dtype=torch.float32, device=dev))
+    try:
+        arr = (C.c_void_p * G)(*[c.ptr for c in ctxs])
+        nf._lib.check(lib.nf_comm_init_all(arr, G))
+        assert all(lib.nf_comm_size(c.ptr) == G for c in ctxs)
+        for g in range(G):
+            nf._lib.check(lib.nf_elbo_value_and_grad(ctxs[g].ptr, C.byref(flows[g].desc), C.byref(tgts[g].c), C.c_void_p(flows[g].theta.data_ptr()),
+                                                     None, n, G * n, 11, g * n, 0, C.c_void_p(outs[g].data_ptr())))
+        bufs = (C.c_void_p * G)(*[o.data_ptr() for o in outs])
+        nf._lib.check(lib.nf_allreduce_grad_loss_all(arr, G, 0, bufs, outs[0].numel()))
+        for g in range(G):
+            torch.cuda.synchronize(g)
+        assert torch.equal(outs[0].cpu(), outs[1].cpu())
+        ref = torch.zeros_like(outs[0])
+        ctx1 = nf._lib.Context(0, torch.cuda.current_stream(0).cuda_stream)
+        nf._lib.check(lib.nf_elbo_value_and_grad(ctx1.ptr, C.byref(flows[0].desc), C.byref(tgts[0].c), C.c_void_p(flows[0].theta.data_ptr()),
+                                                 None, G * n, G * n, 11, 0, 0, C.c_void_p(ref.data_ptr())))
+        torch.cuda.synchronize(0)
+        ctx1.close()
+        scale = float(ref[:-1].abs().max())
+        assert float((outs[0] - ref)[:-1].abs().max()) <= 1e-5 * scale and float(outs[0][-1]) == pytest.approx(float(ref[-1]), rel=1e-5)
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 ARENA_FLOWS = {
     "realnvp_resident": lambda nf: nf.realnvp(nf.MvNormal(8), [32, 32], 2, paramtype=torch.float32, seed=1),
     "realnvp_wide": lambda nf: nf.realnvp(nf.MvNormal(100), [96, 130], 1, paramtype=torch.float32, seed=2),

@@ -43,11 +43,21 @@ def _oracle_local_step(theta, offset, count, n_global, step):
     return torch.tensor(np.concatenate([grad, [-elbos.sum() / n_global]]))
 
 
-def _worker(rank, world, port, ret):
+def _coupling_offsets():
+    """theta offset of every flat coupling of SPEC (the oracle's own parameter walk)."""
+    P = o.param_count(SPEC)
+    nc = 2 * SPEC.nlayers
+    per_pair = P // SPEC.nlayers
+    odd = o.param_count(o.FlowSpec("realnvp", SPEC.d, 1, SPEC.hdims)) // 2  # d even: both couplings of a layer are the same size
+    return [(k >> 1) * per_pair + (odd if (k & 1) else 0) for k in range(nc)]
+
+
+def _worker(rank, world, port, ret, bucketed=False):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     nf = load_package()
-    obj = nf.ShardedObjective(_oracle_local_step, N_GLOBAL, rank, world)
+    buckets = nf.bucket_bounds(_coupling_offsets(), o.param_count(SPEC), 1) if bucketed else None
+    obj = nf.ShardedObjective(_oracle_local_step, N_GLOBAL, rank, world, buckets=buckets)
     theta = torch.tensor(_theta0())
     m, v = np.zeros(theta.numel()), np.zeros(theta.numel())
     losses = []
@@ -95,6 +105,31 @@ def test_two_rank_gloo_matches_single_rank():
         np.testing.assert_allclose(res[r][0], ref_losses, rtol=1e-12)
         np.testing.assert_allclose(res[r][1], theta, rtol=1e-10, atol=1e-12)
     np.testing.assert_array_equal(res[0][1], res[1][1])  # replicas bit-identical
+
+
+def test_bucketed_all_reduce_equals_the_single_message():
+    """The bucketed schedule (one all-reduce per coupling's theta range on its way, the loss in the last bucket, all
+    joined before the update -- what nf_elbo_step does for large gradients under a communicator) through
+    ShardedObjective with gloo at world size 2: same losses and parameters as the one-message run on every rank, and
+    the replicas identical to each other."""
+    nf = load_package()
+    P = o.param_count(SPEC)
+    offs = _coupling_offsets()
+    bounds = nf.bucket_bounds(offs, P, 1)
+    assert bounds[0][0] == 0 and bounds[-1][1] == P + 1 and len(bounds) == 2 * SPEC.nlayers
+    assert all(a[1] == b[0] for a, b in zip(bounds, bounds[1:]))
+    assert nf.bucket_bounds(offs, P, 2) == [(0, P + 1)]
+    world = 2
+    res = {}
+    for bucketed in (False, True):
+        with mp.Manager() as mgr:
+            ret = mgr.dict()
+            mp.spawn(_worker, args=(world, _free_port(), ret, bucketed), nprocs=world, join=True)
+            res[bucketed] = dict(ret)
+    for r in range(world):
+        assert res[True][r][0] == res[False][r][0]
+        np.testing.assert_array_equal(res[True][r][1], res[False][r][1])
+    np.testing.assert_array_equal(res[True][0][1], res[True][1][1])
 
 
 # ---- forward KL: the data set (not the base draws) is what is sharded ---------------------------------
