@@ -307,6 +307,9 @@ def run_once(args, world, world_observed, rank, dev, dist, damp, state):
         # milliseconds, long enough for its clocks to fall back
         nf._lib.check(lib.nf_prof_enable(ctx.ptr, 1))
         nf._lib.check(lib.nf_prof_enable(ctx.ptr, 0))
+    # (created BEFORE the warm-up: whatever the host does between the warm-up and the timed region is GPU idle time, and the
+    # shader clock falls back during idle time -- tools/bench_ramp.py)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(2 * (args.steps + 1))]
     graph = None
     if use_graph:
         # warm-up eagerly through the device-counter form (sizes the workspace, sets kernel attributes, packs the weights),
@@ -335,7 +338,6 @@ def run_once(args, world, world_observed, rank, dev, dist, damp, state):
             step(i)
     barrier()
     first = args.warmup  # index of the first timed step
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(2 * (args.steps + 1))]
 
     def timed_region(first_step: int, marks_off: int):
         """EXACTLY K steps between barrier + synchronize (max over ranks), with the dominant kernel bracketed by HIP events on

@@ -168,52 +168,57 @@ __device__ __forceinline__ float sigmoid_f(float x) {
   return x >= 0.f ? nf_fdiv(1.f, 1.f + e) : nf_fdiv(e, 1.f + e);
 }
 
-// Knot positions and the softmax weights behind them.  The knot DERIVATIVES are never built as a vector: only
-// the two at the ends of the bin an element falls into are used (forward, inverse and reverse pass alike), so
-// find_bin selects their raw parameters and evaluates those two softplus' -- 4 transcendentals instead of 2(K-1),
-// at 16 clocks each on kernels that are VALU-bound.
+// The knots of one (dim, sample), UNNORMALISED and in (width, height) pairs (round 4).  With e_k = exp(raw_k - max) and
+// the inclusive prefix sums cs_k = e_0 + .. + e_k (cs_{K-1} = the softmax denominator), knot j is
+//     p_j = -B + 2B cs_{j-1} / cs_{K-1} = fma(cs_{j-1}, sc, -B),   sc = 2B / cs_{K-1},   p_0 = -B, p_K = B,
+// and bin k spans [p_k, p_k + e_k sc).  Nothing else is ever formed: no normalised softmax vector (the reverse pass folds
+// 1 / cs_{K-1} into three coefficients instead of into K weights), no knot vector (the bin search compares the element,
+// mapped into prefix-sum space once, with the prefix sums; only the bin's own two knots are evaluated).  Widths and heights
+// go through identical arithmetic, so they are carried as two-wide values and hipcc issues v_pk_fma / v_pk_add / v_pk_mul
+// for them: 24 packed + 18 scalar VALU instructions and 18 transcendentals per element, against 106 + 18 before
+// (softmax x2: max, exp, sum, normalise, cumsum, knots).  The kernels that evaluate splines are VALU-issue-bound next to
+// their MFMAs (fp32 MFMA and VALU do not overlap), so instructions are what counts.
+// The knot DERIVATIVES are never built as a vector either: only the two at the ends of the bin an element falls into are
+// used, so find_bin selects their raw parameters and evaluates those two softplus' (LAZY; EAGER: see build_knots).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int K>
 struct Knots {
-  float pX[K + 1], pY[K + 1], smw[K], smh[K];
+  f32x2 e[K], cs[K];  // (width, height) pairs
+  f32x2 sc;           // 2B / cs[K-1]
+  f32x2 usc;          // cs[K-1] / 2B: element -> prefix-sum space, u = (v + B) * usc
+  float B;
   const float *rawd;  // raw[2K .. 3K-2]: interior derivative parameters (registers, compile-time indexed)
-  float dd[K + 1];    // EAGER mode only (the reverse kernel): all knot derivatives, see build_knots
+  float dd[K + 1];    // EAGER mode only (the per-wave reverse kernel): all knot derivatives
 };
 
 constexpr float NF_LOG2E = 1.4426950408889634f;
 
-template <int K>
-__device__ __forceinline__ void softmax_knots(const float *v, float B, float *sm, float *p) {
-  float mx = v[0];
-#pragma unroll
-  for (int k = 1; k < K; ++k) mx = fmaxf(mx, v[k]);
-  const float nmx = -mx * NF_LOG2E;
-  float sum = 0.f;
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    sm[k] = __builtin_amdgcn_exp2f(fmaf(v[k], NF_LOG2E, nmx));  // exp(v - max): one fma + v_exp_f32
-    sum += sm[k];
-  }
-  const float inv = nf_fdiv(1.f, sum);
-  const float twoB = 2.f * B;
-  float cs = 0.f;
-  p[0] = -B;
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    sm[k] *= inv;
-    cs += sm[k];
-    p[k + 1] = fmaf(twoB, cs, -B);
-  }
-}
-
 // raw[0:K] widths, raw[K:2K] heights, raw[2K:3K-1] interior derivatives.
-// LAZY (forward / inverse chain): the two derivatives an element needs are evaluated by find_bin.  EAGER (reverse
-// kernel): all of them here -- measured on the reverse kernel, the lazy form keeps the raw derivative parameters
-// live through the bin search and tips hipcc's allocation over the register wall (224 dW accumulators): 496 B of
-// scratch spills, 204 instead of 166 us per launch, although it executes 10 % fewer instructions.
+// LAZY (forward / inverse chain, cooperative reverse kernel): the two derivatives an element needs are evaluated by
+// find_bin.  EAGER (per-wave reverse kernel): all of them here -- measured on that kernel, the lazy form keeps the raw
+// derivative parameters live through the bin selection and tips hipcc's allocation over the register wall (224 dW
+// accumulators): 496 B of scratch spills, 204 instead of 166 us per launch, although it executes 10 % fewer instructions.
 template <int K, bool LAZY = true>
 __device__ __forceinline__ void build_knots(const float *raw, float B, Knots<K> &kn) {
-  softmax_knots<K>(raw, B, kn.smw, kn.pX);
-  softmax_knots<K>(raw + K, B, kn.smh, kn.pY);
+  float mw = raw[0], mh = raw[K];
+#pragma unroll
+  for (int k = 1; k < K; ++k) {
+    mw = fmaxf(mw, raw[k]);
+    mh = fmaxf(mh, raw[K + k]);
+  }
+  const f32x2 nm = f32x2{-mw, -mh} * NF_LOG2E;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const f32x2 arg = f32x2{raw[k], raw[K + k]} * NF_LOG2E + nm;  // (v - max) log2 e: one packed fma
+    kn.e[k] = f32x2{__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+  }
+  kn.cs[0] = kn.e[0];
+#pragma unroll
+  for (int k = 1; k < K; ++k) kn.cs[k] = kn.cs[k - 1] + kn.e[k];
+  const f32x2 inv = f32x2{__builtin_amdgcn_rcpf(kn.cs[K - 1][0]), __builtin_amdgcn_rcpf(kn.cs[K - 1][1])};
+  kn.sc = inv * (2.f * B);
+  kn.usc = kn.cs[K - 1] * nf_fdiv(0.5f, B);
+  kn.B = B;
   kn.rawd = raw + 2 * K;
   if (!LAZY) {
     kn.dd[0] = 1.f;
@@ -223,15 +228,15 @@ __device__ __forceinline__ void build_knots(const float *raw, float B, Knots<K> 
   }
 }
 
-// The bin an element falls into, as the bin search leaves it: the knots at both ends, the two knot derivatives,
-// and the search CONDITIONS ge[j] <=> v >= p[j] (ge[0] = true, ge[K] = false).  The knot vector is increasing,
+// The bin an element falls into: its left knots (xk, yk), its extent (dx, dy), the two knot derivatives, and the
+// CONDITIONS ge[j] <=> "the element is at or beyond knot j" (ge[0] = true, ge[K] = false).  The knot vector is increasing,
 // so the bin index is k = #{j in 1..K-1 : ge[j]} and
 //     i <  k  <=>  ge[i + 1],        i == k  <=>  ge[i] && !ge[i + 1]
 // -- every "is this the bin / is this left of the bin" test of the reverse pass is one of these lane masks,
 // already sitting in scalar registers; no integer index is ever formed or compared.
 template <int K>
 struct Bin {
-  float xk, xk1, yk, yk1, d0, d1;
+  float xk, dx, yk, dy, d0, d1;
   bool ge[K + 1];
   bool inside;
   unsigned code;  // bin index k (0 .. K-1), or NF_RQS_OUTSIDE: what the forward leaves behind for the reverse pass
@@ -262,47 +267,46 @@ __device__ __forceinline__ void rqs_tape_decode(float t, unsigned &code, float &
   xi = t - f;
 }
 
-// bin with p[k] <= v < p[k+1] on the knot vector `p` (pX forward, pY inverse): one ascending select chain.
-// FROM_CODE: the conditions come from a recorded bin code instead of a search (v and p are not read).
-template <int K, bool LAZY = true, bool FROM_CODE = false>
-__device__ __forceinline__ void find_bin(const Knots<K> &kn, const float *p, float v, Bin<K> &b, unsigned code_in = 0u) {
+// bin with p[k] <= v < p[k+1] along AXIS (0: the x knots, forward; 1: the y knots, inverse): one ascending select chain
+// over the prefix sums.  FROM_CODE: the conditions come from a recorded bin code instead of a search (v is not read).
+template <int K, bool LAZY = true, bool FROM_CODE = false, int AXIS = 0>
+__device__ __forceinline__ void find_bin(const Knots<K> &kn, float v, Bin<K> &b, unsigned code_in = 0u) {
   static_assert(K <= 15, "bin codes are four bits");
-  b.inside = FROM_CODE ? (code_in != NF_RQS_OUTSIDE) : ((v >= p[0]) && (v < p[K]));
+  const float B = kn.B;
+  b.inside = FROM_CODE ? (code_in != NF_RQS_OUTSIDE) : ((v >= -B) && (v < B));
   b.code = 0u;
   b.ge[0] = true;
   b.ge[K] = false;
-  b.xk = kn.pX[0]; b.xk1 = kn.pX[1]; b.yk = kn.pY[0]; b.yk1 = kn.pY[1];
-  if (LAZY) {
-    float r0 = 0.f, r1 = kn.rawd[0];  // raw derivative parameters of knots k and k+1 (knot j <-> rawd[j-1])
-#pragma unroll
-    for (int j = 1; j < K; ++j) {
-      const bool c = FROM_CODE ? (code_in >= (unsigned)j) : (v >= p[j]);
-      b.ge[j] = c;
-      if (!FROM_CODE) b.code = c ? (unsigned)j : b.code;
-      b.xk = c ? kn.pX[j] : b.xk;
-      b.xk1 = c ? kn.pX[j + 1] : b.xk1;
-      b.yk = c ? kn.pY[j] : b.yk;
-      b.yk1 = c ? kn.pY[j + 1] : b.yk1;
-      r0 = c ? kn.rawd[j - 1] : r0;
-      if (j < K - 1) r1 = c ? kn.rawd[j] : r1;
-    }
-    b.d0 = b.ge[1] ? softplus_f(r0) : 1.f;      // k == 0: boundary derivative 1
-    b.d1 = b.ge[K - 1] ? 1.f : softplus_f(r1);  // k == K-1: boundary derivative 1
-  } else {
+  const float u = FROM_CODE ? 0.f : (v + B) * kn.usc[AXIS];  // v >= knot j  <=>  u >= cs[j-1]
+  f32x2 csp = {0.f, 0.f}, ek = kn.e[0];
+  float r0 = 0.f, r1 = LAZY ? kn.rawd[0] : 0.f;  // raw derivative parameters of knots k and k+1 (knot j <-> rawd[j-1])
+  if (!LAZY) {
     b.d0 = kn.dd[0];
     b.d1 = kn.dd[1];
+  }
 #pragma unroll
-    for (int j = 1; j < K; ++j) {
-      const bool c = FROM_CODE ? (code_in >= (unsigned)j) : (v >= p[j]);
-      b.ge[j] = c;
-      if (!FROM_CODE) b.code = c ? (unsigned)j : b.code;
-      b.xk = c ? kn.pX[j] : b.xk;
-      b.xk1 = c ? kn.pX[j + 1] : b.xk1;
-      b.yk = c ? kn.pY[j] : b.yk;
-      b.yk1 = c ? kn.pY[j + 1] : b.yk1;
+  for (int j = 1; j < K; ++j) {
+    const bool c = FROM_CODE ? (code_in >= (unsigned)j) : (u >= kn.cs[j - 1][AXIS]);
+    b.ge[j] = c;
+    if (!FROM_CODE) b.code = c ? (unsigned)j : b.code;
+    csp[0] = c ? kn.cs[j - 1][0] : csp[0];
+    csp[1] = c ? kn.cs[j - 1][1] : csp[1];
+    ek[0] = c ? kn.e[j][0] : ek[0];
+    ek[1] = c ? kn.e[j][1] : ek[1];
+    if (LAZY) {
+      r0 = c ? kn.rawd[j - 1] : r0;
+      if (j < K - 1) r1 = c ? kn.rawd[j] : r1;
+    } else {
       b.d0 = c ? kn.dd[j] : b.d0;
       b.d1 = c ? kn.dd[j + 1] : b.d1;
     }
+  }
+  const f32x2 pk = csp * kn.sc - B, dk = ek * kn.sc;
+  b.xk = pk[0]; b.yk = pk[1];
+  b.dx = dk[0]; b.dy = dk[1];
+  if (LAZY) {
+    b.d0 = b.ge[1] ? softplus_f(r0) : 1.f;      // k == 0: boundary derivative 1
+    b.d1 = b.ge[K - 1] ? 1.f : softplus_f(r1);  // k == K-1: boundary derivative 1
   }
   b.code = FROM_CODE ? code_in : (b.inside ? b.code : NF_RQS_OUTSIDE);
 }
@@ -323,9 +327,9 @@ __device__ __forceinline__ float rq_logderiv(float s, float d0, float d1, float 
 template <int K>
 __device__ __forceinline__ float rqs_fwd_elem(const Knots<K> &kn, float x, float &logd, unsigned &code_out, float &xi_out) {
   Bin<K> b;
-  find_bin<K>(kn, kn.pX, x, b);
+  find_bin<K>(kn, x, b);
   code_out = b.code;
-  const float dx = b.xk1 - b.xk, dy = b.yk1 - b.yk;
+  const float dx = b.dx, dy = b.dy;
   const float s = nf_fdiv(dy, dx);
   const float xi = nf_fdiv(x - b.xk, dx), om = 1.f - xi;
   const float den = s + (b.d1 + b.d0 - 2.f * s) * xi * om;
@@ -338,8 +342,8 @@ __device__ __forceinline__ float rqs_fwd_elem(const Knots<K> &kn, float x, float
 // rqs_inverse for one element: returns x and the bin / xi it lies in; adds -log dy/dx to logd when WANT_LOGD
 template <int K, bool WANT_LOGD = true, bool LAZY = true>
 __device__ __forceinline__ float rqs_inv_elem(const Knots<K> &kn, float y, float &logd, Bin<K> &b, float &xi_out) {
-  find_bin<K, LAZY>(kn, kn.pY, y, b);
-  const float dx = b.xk1 - b.xk, dy = b.yk1 - b.yk;
+  find_bin<K, LAZY, false, 1>(kn, y, b);
+  const float dx = b.dx, dy = b.dy;
   const float s = nf_fdiv(dy, dx);
   const float yy = y - b.yk;
   const float q = b.d1 + b.d0 - 2.f * s;
@@ -360,7 +364,7 @@ __device__ __forceinline__ float rqs_inv_elem(const Knots<K> &kn, float y, float
 template <int K, bool INVD = false>
 __device__ __forceinline__ float rqs_bwd_elem(const Knots<K> &kn, const Bin<K> &b, float xi, float B, float ybar,
                                               float lbar, float *thbar) {
-  const float dx = b.xk1 - b.xk, dy = b.yk1 - b.yk;
+  const float dx = b.dx, dy = b.dy;
   const float s = nf_fdiv(dy, dx), om = 1.f - xi;
   const float d0 = b.d0, d1 = b.d1;
   const float q = d1 + d0 - 2.f * s;
@@ -404,19 +408,27 @@ __device__ __forceinline__ float rqs_bwd_elem(const Knots<K> &kn, const Bin<K> &
   const float ykbar = yb - dybar, yk1bar = dybar;
   // knots: p[j] = -B + 2B sum_{i<j} sm_i  =>  dL/dsm_i = 2B * (pbar[k] + pbar[k+1]) for i < k, 2B * pbar[k+1] for
   // i == k, 0 beyond.  The softmax pullback needs dot = sum_i dL/dsm_i * sm_i, which has a closed form:
-  // sum_{i<k} sm_i = (p[k] + B) / 2B and sm_k = (p[k+1] - p[k]) / 2B, both already in hand.
+  // sum_{i<k} sm_i = (p[k] + B) / 2B and sm_k = (p[k+1] - p[k]) / 2B, both already in hand.  The raw-parameter cotangent
+  // is sm_i (dL/dsm_i - dot) with sm_i = e_i / cs_{K-1}: the normalisation goes into the three values the bracket can take
+  // (i < k, i == k, i > k), and with L_i = [i < k] as a float the bracket is  c_gt + L_i (c_lt - c_eq) + L_{i-1} (c_eq - c_gt)
+  // -- two packed fma and one packed multiply per i for widths and heights together, K - 1 selects for the L's.
   const float twoB = 2.f * B;
   const float aw = xkbar + xk1bar, ah = ykbar + yk1bar;
   const float dotw = fmaf(aw, b.xk + B, xk1bar * dx);
   const float doth = fmaf(ah, b.yk + B, yk1bar * dy);
-  const float aw2 = twoB * aw - dotw, bw2 = twoB * xk1bar - dotw;  // (dL/dsm_i - dot) for i < k, i == k; -dot beyond
-  const float ah2 = twoB * ah - doth, bh2 = twoB * yk1bar - doth;
+  const f32x2 inv = kn.sc * nf_fdiv(1.f, twoB);  // 1 / cs[K-1]
+  const f32x2 c_lt = f32x2{twoB * aw - dotw, twoB * ah - doth} * inv;
+  const f32x2 c_eq = f32x2{twoB * xk1bar - dotw, twoB * yk1bar - doth} * inv;
+  const f32x2 c_gt = f32x2{-dotw, -doth} * inv;
+  const f32x2 d_le = c_lt - c_eq, d_eg = c_eq - c_gt;
+  float Lprev = 1.f;  // L_{-1}
 #pragma unroll
   for (int i = 0; i < K; ++i) {
-    const float sw = b.ge[i + 1] ? aw2 : (b.ge[i] ? bw2 : -dotw);
-    const float sh = b.ge[i + 1] ? ah2 : (b.ge[i] ? bh2 : -doth);
-    thbar[i] = kn.smw[i] * sw;
-    thbar[K + i] = kn.smh[i] * sh;
+    const float Li = (i + 1 < K) ? (b.ge[i + 1] ? 1.f : 0.f) : 0.f;
+    const f32x2 t = kn.e[i] * ((c_gt + d_le * Li) + d_eg * Lprev);
+    thbar[i] = t[0];
+    thbar[K + i] = t[1];
+    Lprev = Li;
   }
   // d/draw softplus = sigmoid(raw) = 1 - exp(-softplus(raw)); only knots k and k+1 carry a cotangent:
   // knot j is the bin's left end iff ge[j] && !ge[j+1], its right end iff ge[j-1] && !ge[j]
@@ -868,10 +880,10 @@ __device__ __forceinline__ void rqs_bwd_tile(const RqsBwdArgs &a, const float *_
       unsigned code;
       float xi;
       rqs_tape_decode(trow[q * 64], code, xi);
-      find_bin<G::K, RQS_BWD_LAZY, true>(kn, kn.pX, 0.f, bn, code);
+      find_bin<G::K, RQS_BWD_LAZY, true>(kn, 0.f, bn, code);
       float xv;
       {
-        const float dx = bn.xk1 - bn.xk, dy = bn.yk1 - bn.yk;
+        const float dx = bn.dx, dy = bn.dy;
         if (INVD) {
           const float sl = nf_fdiv(dy, dx), om = 1.f - xi;
           const float den = sl + (bn.d1 + bn.d0 - 2.f * sl) * xi * om;
@@ -1313,10 +1325,10 @@ __device__ __forceinline__ void rqs_bwd_coop_coupling(const RqsBwdArgs &a, float
           unsigned code;
           float xi;
           rqs_tape_decode(xiq[ql], code, xi);
-          find_bin<G::K, RQS_COOP_LAZY, true>(kn, kn.pX, 0.f, bn, code);
+          find_bin<G::K, RQS_COOP_LAZY, true>(kn, 0.f, bn, code);
           float xv;
           {
-            const float dx = bn.xk1 - bn.xk, dy = bn.yk1 - bn.yk;
+            const float dx = bn.dx, dy = bn.dy;
             if (INVD) {
               const float sl = nf_fdiv(dy, dx), om = 1.f - xi;
               const float den = sl + (bn.d1 + bn.d0 - 2.f * sl) * xi * om;

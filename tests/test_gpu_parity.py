@@ -1424,3 +1424,30 @@ def test_hamiltonian_flow_forward_kl_gradient(nf, tname):
         l32, g32 = nf.loglikelihood_value_and_gradient(f32, cm(us, torch.float32))
         assert l32 == pytest.approx(loss, rel=5e-5)
         assert float((g32.double() - g).abs().max()) <= 2e-3 * max(1.0, float(g.abs().max()))
+
+
+def test_cfg1_at_its_full_batch_float64_against_the_oracle(nf):
+    """BASELINE cfg 1 at the size it is quoted on (exercised at N = 64 by the golden, timed at 1 024,
+    never compared at 1 024): planarflow(MvNormal(zeros(2), ones(2)), 10; paramtype = Float64) on Banana(2, 1.0, 10.0)
+    (example/demo_planar_flow.jl:16-25), batch 1 024, draws of the library's Philox stream seed 123 -- forward, per-sample
+    log-det, elbo_batch and the gradient of -elbo_batch against the float64 oracle at SURVEY 8(d)'s 1e-12."""
+    d, nl, n = 2, 10, 1024
+    spec = o.FlowSpec("planar", d, nl)
+    th = o.init_params(spec, np.random.default_rng(123))
+    flow = nf.Flow("planar", nf.MvNormal(d), nl, dtype=torch.float64, device="cuda", theta=torch.tensor(th, dtype=torch.float64, device="cuda"))
+    tgt = nf.BananaTarget(d, 1.0, 10.0)
+    xs = nf.device_specific_rand(nf.PhiloxRNG(123), flow.dist, n, dtype=torch.float64)
+    x64 = xs.cpu().numpy()
+    np.testing.assert_allclose(x64, o.base_sample(d, n, seed=123, stream=0, dtype=np.float64, precision="f64"), rtol=0, atol=1e-13)
+    ys, ladj = nf.with_logabsdet_jacobian(flow.transform, xs)
+    y_ref, l_ref, _ = o.flow_fwd(spec, th, x64, keep=True)
+    np.testing.assert_allclose(ys.cpu().numpy(), y_ref, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(ladj.cpu().numpy(), l_ref, rtol=1e-12, atol=1e-12)
+    otgt = ("banana", 1.0, 10.0)
+    el = nf.elbo_batch(flow, tgt, xs)
+    el_ref = float(np.mean(o.target_logp(otgt, y_ref) - o.std_normal_logpdf(x64) + l_ref))
+    assert el == pytest.approx(el_ref, rel=1e-12, abs=1e-12)
+    loss, g = nf.value_and_gradient(nf.elbo_batch, flow, tgt, xs)
+    lr, gr = o.neg_elbo_value_and_grad(spec, th, otgt, x64)
+    assert loss == pytest.approx(lr, rel=1e-12, abs=1e-12)
+    assert float(np.abs(g.cpu().numpy() - gr).max()) <= 1e-11 * max(1.0, float(np.abs(gr).max()))
