@@ -389,6 +389,7 @@ static int arena_tail_take(nf_ctx *ctx, size_t bytes, void **out) {
 }
 
 int nf_wimg_reserve(nf_ctx *ctx, size_t bytes) {
+  ctx->wimg_gen++;  // every writer of packed weights comes through here first: derived copies (B6 images) are stale
   if (bytes <= ctx->wimg_bytes) return NF_OK;
   if (ctx->arena) {
     NF_TRY(arena_tail_take(ctx, bytes, &ctx->wimg));

@@ -67,6 +67,8 @@ struct nf_ctx {
   const void *wimg_owner = nullptr;
   unsigned long long wimg_sig = 0;
   bool wimg_cache = false;  // nf_ctx_set_weight_cache: off by default (every nf_elbo_step packs from theta)
+  // generation of the fp32 weight images (bumped by every writer) and the one the bf16-triple copies were built from
+  unsigned long long wimg_gen = 1, b6_gen = 0;
   // RCCL communicator of this context (nf_comm.hip); null for single-GPU use
   void *comm = nullptr;
   int comm_size = 1, comm_rank = 0;

@@ -112,21 +112,51 @@ __global__ __launch_bounds__(512) void k_affine_apply(CouplingArgs a, const floa
 // coupling computes, into the other half of a double-buffered LDS image.
 struct ChainArgs {
   const float *wimg;  // [coupling][s|t][G::SIZE] packed images
+  const unsigned char *wimg_b6;  // [coupling][s|t][B6Geo<G>::BYTES]: the same weights as bf16 triples (B6 kernels)
   int d, ncoup;
   long N;
 };
 
-template <class G, bool INVERSE>
+// the conditioner net on the bf16 matrix cores (nf_mfma.h "B6"): same layers, the image is a B6Geo<G> image
+template <class G>
+__device__ __forceinline__ void net_forward_b6(const float *__restrict__ img, const f32x16 (&x)[G::MB], f32x16 (&out)[G::CB],
+                                               int l31, int hi) {
+  using B = B6Geo<G>;
+  const nf_u32x4 *w = reinterpret_cast<const nf_u32x4 *>(img);
+  const float *bias = reinterpret_cast<const float *>(w + B::BIAS);
+  f32x16 a1[G::H1B], a2[G::H2B];
+  dense_fwd_b6<G::MB, G::H1B>(w + B::L1, bias + B::B1, x, a1, l31, hi);
+#pragma unroll
+  for (int b = 0; b < G::H1B; ++b) nf_lrelu16(a1[b]);
+  dense_fwd_b6<G::H1B, G::H2B>(w + B::L2, bias + B::B2, a1, a2, l31, hi);
+#pragma unroll
+  for (int b = 0; b < G::H2B; ++b) nf_lrelu16(a2[b]);
+  dense_fwd_b6<G::H2B, G::CB>(w + B::L3, bias + B::B3, a2, out, l31, hi);
+}
+
+struct NoBetween {
+  __device__ __forceinline__ void operator()() const {}
+};
+// B6: img_s / img_t are B6 images; `between` runs between the two nets (the B6 chain kernel's image rotation: a workgroup
+// barrier and the request for the image after next)
+template <class G, bool INVERSE, bool B6 = false, class BT = NoBetween>
 __device__ __forceinline__ float coupling_step(const float *__restrict__ img_s, const float *__restrict__ img_t,
-                                               f32x16 (&x1)[G::CB], const f32x16 (&xb)[G::MB], int l31, int hi) {
+                                               f32x16 (&x1)[G::CB], const f32x16 (&xb)[G::MB], int l31, int hi, BT between = BT()) {
   f32x16 S[G::CB], T[G::CB];
+  if constexpr (B6) {
+    net_forward_b6<G>(img_s, xb, S, l31, hi);
+    between();
+    net_forward_b6<G>(img_t, xb, T, l31, hi);
+  } else {
   {
     f32x16 a1[G::H1B], a2[G::H2B];
     net_forward<G>(img_s, xb, a1, a2, S, l31, hi);
   }
+  between();
   {
     f32x16 a1[G::H1B], a2[G::H2B];
     net_forward<G>(img_t, xb, a1, a2, T, l31, hi);
+  }
   }
   float lsum = 0.f;
 #pragma unroll
@@ -217,12 +247,42 @@ __device__ __forceinline__ void stash_put_lane(const StashIO &st, int base, cons
     }
 }
 
-template <class G, bool STORE_X, bool SLIM = false>
+template <class G, bool STORE_X, bool SLIM = false, bool B6 = false>
 __device__ __forceinline__ void net_forward_stash(const float *__restrict__ img, const f32x16 (&x)[G::MB], f32x16 (&out)[G::CB],
                                                   int l31, int hi, const StashIO &st, int nbase) {
   using SG = StashGeo<G, SLIM>;
   f32x16 a1[G::H1B], a2[G::H2B];
   unsigned m1[2] = {0u, 0u}, m2[2] = {0u, 0u};
+  if constexpr (B6) {  // the same stores ride on the bf16 product's (fewer) MFMAs: two side-job slots per instruction
+    using B = B6Geo<G>;
+    const nf_u32x4 *w = reinterpret_cast<const nf_u32x4 *>(img);
+    const float *bias = reinterpret_cast<const float *>(w + B::BIAS);
+    if (STORE_X) {
+      if (SLIM) stash_put_lane<G::MB>(st, SG::XL, x);
+      dense_fwd_b6<G::MB, G::H1B>(w + B::L1, bias + B::B1, x, a1, l31, hi, [&](int e) { stash_put_T<G::MB>(st, SG::XT, x, e); });
+    } else
+      dense_fwd_b6<G::MB, G::H1B>(w + B::L1, bias + B::B1, x, a1, l31, hi);
+#pragma unroll
+    for (int b = 0; b < G::H1B; ++b) {
+      nf_lrelu16(a1[b]);
+      m1[b] = nf_sign_mask16(a1[b]);
+    }
+    if (SLIM)
+      dense_fwd_b6<G::H1B, G::H2B>(w + B::L2, bias + B::B2, a1, a2, l31, hi);
+    else
+      dense_fwd_b6<G::H1B, G::H2B>(w + B::L2, bias + B::B2, a1, a2, l31, hi,
+                                   [&](int e) { stash_put_T<G::H1B>(st, nbase + SG::A1, a1, e); });
+#pragma unroll
+    for (int b = 0; b < G::H2B; ++b) {
+      nf_lrelu16(a2[b]);
+      m2[b] = nf_sign_mask16(a2[b]);
+    }
+    dense_fwd_b6<G::H2B, G::CB>(w + B::L3, bias + B::B3, a2, out, l31, hi,
+                                [&](int e) { stash_put_T<G::H2B>(st, nbase + SG::A2, a2, e); });
+    const u32x4 mkb = {m1[0], m1[1], m2[0], m2[1]};
+    nf_buffer_store_b128(mkb, st.rs, (hi * 32 + l31) * 16, (nbase + SG::MSK) * 4);
+    return;
+  }
   if (STORE_X) {
     if (SLIM) stash_put_lane<G::MB>(st, SG::XL, x);
     dense_fwd<G::MB, G::H1B>(img + G::W1, img + G::B1, x, a1, l31, hi, [&](int e) { stash_put_T<G::MB>(st, SG::XT, x, e); });
@@ -257,16 +317,17 @@ __device__ __forceinline__ void net_forward_stash(const float *__restrict__ img,
 // forward coupling of the training step: as coupling_step<G, false>, leaving the reverse pass's operands behind
 // INVERSE (forward-KL training: the chain runs data -> base): w1 = (v1 - t) exp(-s); the UV slot then holds w1, which is
 // what the reverse pass of the inverse coupling needs next to s (bwd_tile's INVD algebra)
-template <class G, bool INVERSE = false, bool SLIM = false>
+template <class G, bool INVERSE = false, bool SLIM = false, bool B6 = false, class BT = NoBetween>
 __device__ __forceinline__ float coupling_step_stash(const float *__restrict__ img_s, const float *__restrict__ img_t,
                                                      f32x16 (&x1)[G::CB], const f32x16 (&xb)[G::MB], int l31, int hi,
-                                                     const StashIO &st, long long *tr = nullptr) {
+                                                     const StashIO &st, long long *tr = nullptr, BT between = BT()) {
   using SG = StashGeo<G, SLIM>;
   static_assert(G::H1B <= 2 && G::H2B <= 2, "mask words");
   f32x16 S[G::CB], T[G::CB];
-  net_forward_stash<G, true, SLIM>(img_s, xb, S, l31, hi, st, SG::NET0);
+  net_forward_stash<G, true, SLIM, B6>(img_s, xb, S, l31, hi, st, SG::NET0);
   NF_CH_STAMP(tr, 1);
-  net_forward_stash<G, false, SLIM>(img_t, xb, T, l31, hi, st, SG::NET0 + SG::NETSZ);
+  between();
+  net_forward_stash<G, false, SLIM, B6>(img_t, xb, T, l31, hi, st, SG::NET0 + SG::NETSZ);
   NF_CH_STAMP(tr, 2);
   float lsum = 0.f;
 #pragma unroll
@@ -309,7 +370,12 @@ struct FusedArgs {
   long long *trace;       // NF_KERNEL_TRACE builds: clock stamps for tools/trace_chain.py, else unused
 };
 
-template <class G, bool INVERSE, bool FUSED = false, bool STASH = false, bool SLIM = false>
+// B6 (round 4, the default): the conditioner GEMMs on the bf16 matrix cores with six-term products (nf_mfma.h), 2.67 x
+// the fp32 MFMA's rate at fp32 accuracy.  The B6 images are 1.5 x the fp32 ones (49 KB per net at hidden 64), so the LDS
+// holds THREE of them and rotates per NET instead of two (s, t) pairs per coupling: image i of the workgroup's sequence
+// s(c0), t(c0), s(c1), ... lives in slot i mod 3; the phase of image i starts with a workgroup barrier (image i complete,
+// everybody done with image i - 1) and then requests image i + 2 into the slot image i - 1 just left.
+template <class G, bool INVERSE, bool FUSED = false, bool STASH = false, bool SLIM = false, bool B6 = false>
 __global__ __launch_bounds__(512) void k_affine_chain(ChainArgs a, float *xt, float *__restrict__ ladj, FusedArgs fa) {
   static_assert(STASH || !SLIM, "SLIM is a stash layout");
   static_assert(!STASH || !FUSED || !INVERSE, "the fused ELBO forward runs base -> data");
@@ -325,15 +391,41 @@ __global__ __launch_bounds__(512) void k_affine_chain(ChainArgs a, float *xt, fl
   // coupling executed at position s of the chain: forward applies the LAST flat coupling first
   auto coupling_at = [&](int s) { return INVERSE ? s : a.ncoup - 1 - s; };
 
+  using BG = B6Geo<G>;
+  constexpr int B6F = BG::BYTES / 4;  // floats per B6 image
+  // B6: image i of this workgroup's sequence (position (i mod 2 ncoup) / 2 of the chain, net i & 1) -> LDS slot i mod 3, by
+  // LDS-DMA; complete at the next workgroup barrier (s_waitcnt vmcnt(0) of every wave for its own pieces)
+  const int my_groups = (long)blockIdx.x < ngroups ? (int)((ngroups - blockIdx.x + gridDim.x - 1) / gridDim.x) : 0;
+  const int my_images = my_groups * 2 * a.ncoup;
+  int req = 0, req_idx = 0, req_slot = 0;  // images requested so far, the next one's index in the chain and its slot
+  auto b6_request_next = [&]() {  // requests are issued strictly in sequence order: no division, three small counters
+    if (req >= my_images) return;
+    typedef __attribute__((address_space(3))) void lds_void_t;
+    const int kk = coupling_at(req_idx >> 1);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char *>(a.wimg_b6) + (size_t)(2 * kk + (req_idx & 1)) * BG::BYTES, 0, BG::BYTES, 0x00020000);
+    float *dstb = lds + req_slot * B6F;
+    constexpr int NP = (BG::BYTES + 1023) / 1024;
+    for (int p = wave; p < NP; p += 8)
+      if (p * 1024 + lane * 16 < BG::BYTES)  // the last piece is partial: its idle lanes must not write
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t *)(dstb + p * 256), 16, lane * 16, p * 1024, 0, 0);
+    ++req;
+    req_idx = req_idx + 1 == 2 * a.ncoup ? 0 : req_idx + 1;
+    req_slot = req_slot == 2 ? 0 : req_slot + 1;
+  };
+  int cur_slot = 0;  // B6: slot of the next image to be used
   // prologue: image of the first coupling -> buffer 0
-  {
+  if constexpr (B6) {
+    b6_request_next();
+    b6_request_next();
+  } else {
     const float4 *src = reinterpret_cast<const float4 *>(a.wimg + (long)coupling_at(0) * IMG2);
     float4 *dst = reinterpret_cast<float4 *>(lds);
     for (int i = tid; i < NV4; i += 512) dst[i] = src[i];
   }
   // FUSED: target parameters by feature, zero padded: tmu[f], tiv[f] = 1/var[f]; tc0 = d log 2pi + sum log var
   constexpr int TP = 64 * G::CB;  // padded feature count (E and O halves)
-  float *tmu = lds + 2 * IMG2, *tiv = tmu + TP, *tc0 = tiv + TP;
+  float *tmu = lds + (B6 ? 3 * B6F : 2 * IMG2), *tiv = tmu + TP, *tc0 = tiv + TP;
   double *wsum = reinterpret_cast<double *>(tc0 + 2);  // [8] per-wave partial sums (8-byte aligned: TP even)
   if (FUSED) {
     for (int i = tid; i < TP; i += 512) {
@@ -405,6 +497,44 @@ __global__ __launch_bounds__(512) void k_affine_chain(ChainArgs a, float *xt, fl
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const int pos = s + half;
+        if constexpr (B6) {
+          // The phase barrier must see this wave's pieces of the image DMA complete -- NOT its stash stores: the vector-memory
+          // counter is in order, and at least 64 stores follow every DMA request of a stashing kernel (81 per s net, 73 per
+          // t net and tile), so "at most 60 operations outstanding" already implies the DMA is done, while __syncthreads()
+          // (vmcnt(0)) would drain the stores to HBM twice per coupling.  Kernels without a stash wait for everything.
+          auto phase_barrier = [&](bool first_of_group = false) {
+#ifndef NF_B6_FULL_DRAIN
+            if (STASH && !first_of_group) {  // (a tile group's first image may have nothing but the DMA behind it)
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_s_waitcnt(0xC07C);  // vmcnt(60) lgkmcnt(0)
+              __builtin_amdgcn_s_barrier();
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            } else
+#endif
+              __syncthreads();
+          };
+          phase_barrier(s == 0 && half == 0);  // this coupling's s image is complete, every wave is done with the image before it
+          b6_request_next();  // the image after next, into the slot just vacated
+          const int slot_t = cur_slot == 2 ? 0 : cur_slot + 1;
+          const float *img_s = lds + cur_slot * B6F, *img_t = lds + slot_t * B6F;
+          auto between = [&]() {
+            phase_barrier();  // the t image is complete, every wave is done with the s image
+            b6_request_next();
+          };
+          float ls;
+          if (STASH) {
+            const StashIO st = make_stash_io(fa.stash, tl * a.ncoup + coupling_at(pos), StashGeo<G, SLIM>::SIZE, live, l31, hi);
+            if (INVERSE ? (half == 1) : (half == 0)) ls = coupling_step_stash<G, INVERSE, SLIM, true>(img_s, img_t, O, E, l31, hi, st, nullptr, between);
+            else ls = coupling_step_stash<G, INVERSE, SLIM, true>(img_s, img_t, E, O, l31, hi, st, nullptr, between);
+          } else if (INVERSE ? (half == 1) : (half == 0)) {
+            ls = coupling_step<G, INVERSE, true>(img_s, img_t, O, E, l31, hi, between);
+          } else {
+            ls = coupling_step<G, INVERSE, true>(img_s, img_t, E, O, l31, hi, between);
+          }
+          lsum += ls;
+          cur_slot = slot_t == 2 ? 0 : slot_t + 1;
+          continue;
+        }
         // prefetch the next coupling's images (wraps to the first coupling for the next tile group)
         const bool have_next = pos + 1 < a.ncoup || more_groups;
         const int knext = coupling_at(pos + 1 < a.ncoup ? pos + 1 : 0);
@@ -1542,6 +1672,7 @@ int nf_affine_epilogue(nf_ctx *ctx, const nf_flow_desc *desc, int mode, const fl
   a.c1 = (float)(1.0 - pow(b1, (double)t_val + 1.0));
   a.c2 = (float)(1.0 - pow(b2, (double)t_val + 1.0));
   const unsigned grid = (unsigned)nf_affine_epilogue_blocks(desc);
+  if (mode != 1) ctx->wimg_gen++;  // the fp32 images are rewritten (Adam's theta): B6 copies are stale
   ProfScope ps(ctx, mode == 2 ? "adam" : "reduce_slabs");
   const bool h64 = size != NetGeo<1, 1, 1, 1>::SIZE;
 #define NF_EPI(GEO)                                                                                                          \
@@ -1556,24 +1687,63 @@ int nf_affine_epilogue(nf_ctx *ctx, const nf_flow_desc *desc, int mode, const fl
 }
 
 // packs every net of the flow into ctx->wimg (grow-only) -- call once per API entry
-size_t nf_affine_wimg_bytes(const nf_flow_desc *desc) { return (size_t)2 * desc->nlayers * 2 * geo_size(desc) * sizeof(float); }
+// Where the B6 images sit: behind the fp32 images of the same flow in ctx->wimg (nf_affine_wimg_bytes covers both).
+template <class G>
+static size_t b6_offset_bytes(const nf_flow_desc *desc) { return (size_t)2 * desc->nlayers * 2 * G::SIZE * sizeof(float); }
+// Which chain launches take the bf16 six-term products (B6).  Measured A/B on one box (profiles/r4i_b6_ab.txt):
+//   * chains WITHOUT a stash (nf_flow_fwd / nf_flow_inv, nf_elbo_batch, nf_loglikelihood: BASELINE cfg 5, 1 M samples):
+//     1.69 against 2.46 ms = 1.45 x, 620 M samples/s, 1.03 of the fp32-MFMA roofline -- ON by default, NF_FWD_FP32=1 is the
+//     A/B switch back;
+//   * the training step's stashing forward (cfg 2): 207-210 against 195 us, AND the unchanged reverse kernel behind it runs
+//     400 instead of 362 us (the chip's power management couples consecutive kernels: tools/bench_ramp.py shows the clock is
+//     set by the load of the last milliseconds) -- 0.659 against 0.612 ms per step: OFF by default, NF_FWD_B6_STASH=1 turns
+//     it on (120 bytes of scratch spills in that variant are the first thing to remove).
+static bool fwd_b6(bool stashing = false) {
+  static const bool off = std::getenv("NF_FWD_FP32") != nullptr, stash_on = std::getenv("NF_FWD_B6_STASH") != nullptr;
+  return !off && (!stashing || stash_on);
+}
+
+static size_t b6_image_bytes(int size) { return size == NetGeo<1, 1, 1, 1>::SIZE ? B6Geo<NetGeo<1, 1, 1, 1>>::BYTES : B6Geo<NetGeo<1, 2, 2, 1>>::BYTES; }
+size_t nf_affine_wimg_bytes(const nf_flow_desc *desc) {
+  const int size = geo_size(desc);
+  return (size_t)2 * desc->nlayers * 2 * ((size_t)size * sizeof(float) + (size ? b6_image_bytes(size) : 0));
+}
+
+// the bf16-triple images of the chain kernels that use the six-term products (B6), rebuilt from the fp32 images when those
+// have been rewritten since (ctx->wimg_gen): behind the fp32 images in ctx->wimg
+template <class G>
+static int b6_refresh(nf_ctx *ctx, const nf_flow_desc *desc) {
+  if (ctx->b6_gen == ctx->wimg_gen) return NF_OK;
+  using B = B6Geo<G>;
+  const int nimg = 2 * desc->nlayers * 2;
+  constexpr long PER = 2 * G::MB * 2 * B::R1 + 2 * G::H1B * 2 * B::R2 + 2 * G::H2B * 2 * B::R3 + B::R1 + B::R2 + B::R3;
+  const long total = (long)nimg * PER;
+  ProfScope ps(ctx, "pack_weights");
+  hipLaunchKernelGGL((k_b6_from_images<G>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, nimg, (const float *)ctx->wimg,
+                     (unsigned char *)ctx->wimg + b6_offset_bytes<G>(desc));
+  NF_HIP(hipGetLastError());
+  ctx->b6_gen = ctx->wimg_gen;
+  return NF_OK;
+}
 
 int nf_affine_pack(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta) {
   if (desc->n_hidden != 2) return NF_ERR_UNSUPPORTED;
   const int size = geo_size(desc);
   if (!size) return NF_ERR_UNSUPPORTED;
   const int nc = 2 * desc->nlayers;
-  const size_t bytes = (size_t)nc * 2 * size * sizeof(float);
-  NF_TRY(nf_wimg_reserve(ctx, bytes));
+  NF_TRY(nf_wimg_reserve(ctx, nf_affine_wimg_bytes(desc)));
   const PackArgs p = make_pack_args(desc);
   const long total = (long)nc * 2 * size;
   const unsigned grid = (unsigned)((total + 255) / 256);
-  ProfScope ps(ctx, "pack_weights");
-  if (size == NetGeo<1, 1, 1, 1>::SIZE)
-    hipLaunchKernelGGL((k_pack_net_images<NetGeo<1, 1, 1, 1>>), dim3(grid), dim3(256), 0, ctx->stream, p, theta, (float *)ctx->wimg);
-  else
-    hipLaunchKernelGGL((k_pack_net_images<NetGeo<1, 2, 2, 1>>), dim3(grid), dim3(256), 0, ctx->stream, p, theta, (float *)ctx->wimg);
-  return (int)hipGetLastError();
+  {
+    ProfScope ps(ctx, "pack_weights");
+    if (size == NetGeo<1, 1, 1, 1>::SIZE)
+      hipLaunchKernelGGL((k_pack_net_images<NetGeo<1, 1, 1, 1>>), dim3(grid), dim3(256), 0, ctx->stream, p, theta, (float *)ctx->wimg);
+    else
+      hipLaunchKernelGGL((k_pack_net_images<NetGeo<1, 2, 2, 1>>), dim3(grid), dim3(256), 0, ctx->stream, p, theta, (float *)ctx->wimg);
+    NF_HIP(hipGetLastError());
+  }
+  return NF_OK;
 }
 
 static int make_args(nf_ctx *ctx, const nf_flow_desc *desc, int k, const float *theta, long N, CouplingArgs *out) {
@@ -1663,23 +1833,26 @@ static bool stash_slim(int size) {
   return size == NetGeo<1, 2, 2, 1>::SIZE && !no_pair && slim;
 }
 
-template <class G, bool SLIM = false>
+template <class G, bool SLIM = false, bool B6 = false>
 static int launch_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, float *xt, long N, float *ladj,
                         const FusedArgs *fused = nullptr, float *stash_plain = nullptr) {
-  // two double-buffered (s,t) image pairs + target parameters and per-wave sums of the fused variant
-  const size_t lds = (4 * (size_t)G::SIZE + 2 * 64 * G::CB + 2) * sizeof(float) + 8 * sizeof(double);
+  // two double-buffered (s,t) image pairs (B6: three single images) + target parameters and per-wave sums of the fused variant
+  const size_t lds = (B6 ? (size_t)3 * B6Geo<G>::BYTES : 4 * (size_t)G::SIZE * sizeof(float)) + (2 * 64 * G::CB + 2) * sizeof(float) +
+                     8 * sizeof(double);
   static AttrOnce attr_once;  // once per device: a context on another GPU needs its own
   NF_TRY(attr_once.run(ctx->device, [&]() -> int {
-    NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false, true, true, SLIM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false, false, true, SLIM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, true, false, true, SLIM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false, false, false, false, B6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, true, false, false, false, B6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false, true, false, false, B6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false, true, true, SLIM, B6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false, false, true, SLIM, B6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, true, false, true, SLIM, B6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return NF_OK;
   }));
+  if (B6) NF_TRY(b6_refresh<G>(ctx, desc));
   ChainArgs a;
   a.wimg = (const float *)ctx->wimg;
+  a.wimg_b6 = (const unsigned char *)ctx->wimg + b6_offset_bytes<G>(desc);
   a.d = desc->d;
   a.ncoup = 2 * desc->nlayers;
   a.N = N;
@@ -1689,20 +1862,20 @@ static int launch_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, flo
   ProfScope ps(ctx, "affine_chain");
   FusedArgs none{};
   if (fused && fused->stash)
-    hipLaunchKernelGGL((k_affine_chain<G, false, true, true, SLIM>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, *fused);
+    hipLaunchKernelGGL((k_affine_chain<G, false, true, true, SLIM, B6>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, *fused);
   else if (fused)
-    hipLaunchKernelGGL((k_affine_chain<G, false, true>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, *fused);
+    hipLaunchKernelGGL((k_affine_chain<G, false, true, false, false, B6>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, *fused);
   else if (inverse && stash_plain) {  // forward-KL training: the inverse chain leaves the stash of ITS reverse pass
     none.stash = stash_plain;
-    hipLaunchKernelGGL((k_affine_chain<G, true, false, true, SLIM>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, none);
+    hipLaunchKernelGGL((k_affine_chain<G, true, false, true, SLIM, B6>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, none);
   } else if (inverse)
-    hipLaunchKernelGGL((k_affine_chain<G, true>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, none);
+    hipLaunchKernelGGL((k_affine_chain<G, true, false, false, false, B6>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, none);
   else if (stash_plain) {  // caller-supplied draws: the plain forward chain, leaving the stash behind
     none.stash = stash_plain;
-    hipLaunchKernelGGL((k_affine_chain<G, false, false, true, SLIM>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, none);
+    hipLaunchKernelGGL((k_affine_chain<G, false, false, true, SLIM, B6>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, none);
   }
   else
-    hipLaunchKernelGGL((k_affine_chain<G, false>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, none);
+    hipLaunchKernelGGL((k_affine_chain<G, false, false, false, false, B6>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, none);
   return (int)hipGetLastError();
 }
 
@@ -1727,18 +1900,30 @@ int nf_affine_chain_elbo(nf_ctx *ctx, const nf_flow_desc *desc, long N, uint64_t
   fa.stream_ptr = stream_ptr;
   fa.k0 = (uint32_t)seed; fa.k1 = (uint32_t)(seed >> 32); fa.stream = stream; fa.off = off;
   fa.mu = mu; fa.var = var; fa.gt = gt; fa.gscale = (float)gscale; fa.partial = partial; fa.pscale = pscale;
-  if (size == NetGeo<1, 1, 1, 1>::SIZE) return launch_chain<NetGeo<1, 1, 1, 1>>(ctx, desc, false, yt, N, nullptr, &fa);
-  if (stash && stash_slim(size)) return launch_chain<NetGeo<1, 2, 2, 1>, true>(ctx, desc, false, yt, N, nullptr, &fa);
-  return launch_chain<NetGeo<1, 2, 2, 1>>(ctx, desc, false, yt, N, nullptr, &fa);
+  const bool b6 = fwd_b6(stash != nullptr);
+  if (size == NetGeo<1, 1, 1, 1>::SIZE)
+    return b6 ? launch_chain<NetGeo<1, 1, 1, 1>, false, true>(ctx, desc, false, yt, N, nullptr, &fa)
+              : launch_chain<NetGeo<1, 1, 1, 1>>(ctx, desc, false, yt, N, nullptr, &fa);
+  if (stash && stash_slim(size))
+    return b6 ? launch_chain<NetGeo<1, 2, 2, 1>, true, true>(ctx, desc, false, yt, N, nullptr, &fa)
+              : launch_chain<NetGeo<1, 2, 2, 1>, true>(ctx, desc, false, yt, N, nullptr, &fa);
+  return b6 ? launch_chain<NetGeo<1, 2, 2, 1>, false, true>(ctx, desc, false, yt, N, nullptr, &fa)
+            : launch_chain<NetGeo<1, 2, 2, 1>>(ctx, desc, false, yt, N, nullptr, &fa);
 }
 
 // whole chain in one launch, in place on the tiled buffer (packed images must be current)
 int nf_affine_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, float *xt, long N, float *ladj, float *stash) {
   const int size = geo_size(desc);
   if (!size || !ctx->wimg) return NF_ERR_UNSUPPORTED;
-  if (size == NetGeo<1, 1, 1, 1>::SIZE) return launch_chain<NetGeo<1, 1, 1, 1>>(ctx, desc, inverse, xt, N, ladj, nullptr, stash);
-  if (stash && stash_slim(size)) return launch_chain<NetGeo<1, 2, 2, 1>, true>(ctx, desc, inverse, xt, N, ladj, nullptr, stash);
-  return launch_chain<NetGeo<1, 2, 2, 1>>(ctx, desc, inverse, xt, N, ladj, nullptr, stash);
+  const bool b6 = fwd_b6(stash != nullptr);
+  if (size == NetGeo<1, 1, 1, 1>::SIZE)
+    return b6 ? launch_chain<NetGeo<1, 1, 1, 1>, false, true>(ctx, desc, inverse, xt, N, ladj, nullptr, stash)
+              : launch_chain<NetGeo<1, 1, 1, 1>>(ctx, desc, inverse, xt, N, ladj, nullptr, stash);
+  if (stash && stash_slim(size))
+    return b6 ? launch_chain<NetGeo<1, 2, 2, 1>, true, true>(ctx, desc, inverse, xt, N, ladj, nullptr, stash)
+              : launch_chain<NetGeo<1, 2, 2, 1>, true>(ctx, desc, inverse, xt, N, ladj, nullptr, stash);
+  return b6 ? launch_chain<NetGeo<1, 2, 2, 1>, false, true>(ctx, desc, inverse, xt, N, ladj, nullptr, stash)
+            : launch_chain<NetGeo<1, 2, 2, 1>>(ctx, desc, inverse, xt, N, ladj, nullptr, stash);
 }
 
 template <class G>

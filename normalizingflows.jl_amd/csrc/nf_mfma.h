@@ -572,6 +572,104 @@ __device__ __forceinline__ void net_forward(const float *__restrict__ img, const
   dense_fwd<G::H2B, G::CB>(img + G::W3, img + G::B3, a2, out, l31, hi);
 }
 
+// ---- fp32-grade GEMMs on the bf16 matrix cores ("B6": six bf16 products per fp32 product) -------------------------
+// v_mfma_f32_32x32x16_bf16 does 16 384 MACs in 32 clocks, v_mfma_f32_32x32x2_f32 2 048 in 64 (tools/probe/bf16x6_probe.hip,
+// measured): sixteen times the rate.  An fp32 value is EXACTLY the sum of three bf16 values (8 + 8 + 8 significant bits:
+// x = xh + xm + xl by two truncations and two exact subtractions), so x w = sum of nine bf16 x bf16 products, each exact in
+// the instruction's fp32 accumulator; the three smallest (xm wl, xl wm, xl wl: <= 2^-23 of the product together) are
+// dropped, the other six -- smallest first -- give an error of 1.0e-7 of sum |terms| at K = 64 against 1.7e-7 for the fp32
+// MFMA chain itself (same probe).  Six instructions of 32 clocks replace eight of 64 per 16 k-steps: 2.67 x the matrix-pipe
+// rate of the fp32 path, paid for with ~3.5 VALU instructions per ACTIVATION for the split (the weights are split once,
+// when theta is packed).  Round 4 uses it in the forward chain; the reverse GEMMs keep fp32 operands.
+//
+// Operand layout of the instruction (A: 32 x 16, B: 16 x 32): lane <-> row / column l & 31, the lane's eight bf16 are
+// k = 8 (lane >> 5) + j.  The register chaining of nf_mfma.h carries over: a lane of half `hi` holds, of a 32-feature
+// block in the C layout, the features (r & 3) + 8 (r >> 2) + 4 hi, r = 0 .. 15; registers 8 g .. 8 g + 7 are therefore the
+// eight k-values of that lane for k-group g (16 features) of the block, with the contraction order
+//     feature(g, hi, j) = 16 g + (j & 3) + 8 (j >> 2) + 4 hi,
+// and the weight image stores each row's eight weights in exactly that order, so an A operand is one ds_read_b128.
+typedef unsigned nf_u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 nf_bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void nf_split8(const float (&v)[8], nf_u32x4 &h, nf_u32x4 &m, nf_u32x4 &l) {
+  unsigned hb[8], mb[8], lb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const unsigned xb = __float_as_uint(v[j]);
+    const float r1 = v[j] - __uint_as_float(xb & 0xFFFF0000u);  // exact
+    const unsigned rb = __float_as_uint(r1);
+    const float lo = r1 - __uint_as_float(rb & 0xFFFF0000u);    // exact, at most 8 significant bits
+    hb[j] = xb; mb[j] = rb; lb[j] = __float_as_uint(lo);
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {  // dword p = (upper half of value 2p + 1) : (upper half of value 2p)
+    h[p] = __builtin_amdgcn_perm(hb[2 * p + 1], hb[2 * p], 0x07060302u);
+    m[p] = __builtin_amdgcn_perm(mb[2 * p + 1], mb[2 * p], 0x07060302u);
+    l[p] = __builtin_amdgcn_perm(lb[2 * p + 1], lb[2 * p], 0x07060302u);
+  }
+}
+__device__ __forceinline__ f32x16 nf_mfma_bf16(nf_u32x4 a, nf_u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nf_bf16x8, a), __builtin_bit_cast(nf_bf16x8, b), c, 0, 0, 0);
+}
+
+// B6 image of one net (geometry G = NetGeo<..>), in 16-byte units: per layer [k-group][component h|m|l][half][row][8 bf16],
+// rows = padded fan-out, k-groups = 2 x input blocks; then the three bias vectors in fp32.
+template <class G>
+struct B6Geo {
+  static constexpr int R1 = 32 * G::H1B, R2 = 32 * G::H2B, R3 = 32 * G::CB;   // rows (outputs) per layer
+  static constexpr int L1 = 0;
+  static constexpr int L2 = L1 + 2 * G::MB * 6 * R1;
+  static constexpr int L3 = L2 + 2 * G::H1B * 6 * R2;
+  static constexpr int BIAS = L3 + 2 * G::H2B * 6 * R3;                       // 16-byte units up to here
+  static constexpr int B1 = 0, B2 = R1, B3 = R1 + R2;                         // float offsets inside the bias block
+  static constexpr int U4 = BIAS + (R1 + R2 + R3 + 3) / 4;                    // size in 16-byte units
+  static constexpr int BYTES = U4 * 16;
+};
+
+// out[ob] = W in + b through the six-term bf16 product.  `w`: the layer's part of a B6 image (LDS), ROWS = 32 * OB.
+// Pipeline unit = one (k-group, output block): its three A operands (12 registers) are requested one unit ahead, behind
+// the six MFMAs (192 clocks) of the unit before.
+template <int IB, int OB, class SJ = NoSideJob>
+__device__ __forceinline__ void dense_fwd_b6(const nf_u32x4 *__restrict__ w, const float *__restrict__ b, const f32x16 (&in)[IB],
+                                             f32x16 (&out)[OB], int l31, int hi, SJ sj = SJ()) {
+  constexpr int ROWS = 32 * OB, NKG = 2 * IB, NU = NKG * OB;
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[ob][r] = b[ob * 32 + nf_row(r, hi)];
+  const nf_u32x4 *wl = w + hi * ROWS + l31;  // lane part of the address; (k-group, component, block) are immediates
+  nf_u32x4 an[3], ac[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) an[c] = wl[c * 2 * ROWS];
+  nf_u32x4 xh, xm, xl;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int kg = u / OB, ob = u % OB;
+    if (ob == 0) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = in[kg >> 1][8 * (kg & 1) + j];
+      nf_split8(v, xh, xm, xl);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ac[c] = an[c];
+    if (u + 1 < NU) {
+      const int kg1 = (u + 1) / OB, ob1 = (u + 1) % OB;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) an[c] = wl[(kg1 * 3 + c) * 2 * ROWS + ob1 * 32];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // smallest terms first: wl xh, wh xl, wm xm, wm xh, wh xm, wh xh
+    out[ob] = nf_mfma_bf16(ac[2], xh, out[ob]); sj(12 * u + 0); sj(12 * u + 1);
+    out[ob] = nf_mfma_bf16(ac[0], xl, out[ob]); sj(12 * u + 2); sj(12 * u + 3);
+    out[ob] = nf_mfma_bf16(ac[1], xm, out[ob]); sj(12 * u + 4); sj(12 * u + 5);
+    out[ob] = nf_mfma_bf16(ac[1], xh, out[ob]); sj(12 * u + 6); sj(12 * u + 7);
+    out[ob] = nf_mfma_bf16(ac[0], xm, out[ob]); sj(12 * u + 8); sj(12 * u + 9);
+    out[ob] = nf_mfma_bf16(ac[0], xh, out[ob]); sj(12 * u + 10); sj(12 * u + 11);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // ---- tile I/O through buffer descriptors ---------------------------------------------------
 // One descriptor per (array, tile): base = array + tile * d * 32 floats (wave-uniform), extent =
 // d * 32 floats.  Element (feature f, lane's sample) is at byte f * 128 + (lane & 31) * 4, and in

@@ -30,6 +30,57 @@ __global__ __launch_bounds__(256) void k_pack_net_images(PackArgs p, const float
   out[gid] = ti >= 0 ? theta[ti] : 0.f;
 }
 
+// B6 images (nf_mfma.h, B6Geo) FROM the fp32 images: every weight split into three bf16, rows of eight in the MFMA's k
+// order.  The fp32 images are what every writer of weights maintains (k_pack_net_images, the fused epilogue); the chain
+// launches that use the bf16 products rebuild their B6 copy from them when the images have changed since (ctx->wimg_gen).
+// One thread per (image, layer, k-group, half, row): eight weights in, 3 x 16 bytes out; one more per bias element.
+template <class G>
+__global__ __launch_bounds__(256) void k_b6_from_images(int nimg, const float *__restrict__ wimg, unsigned char *__restrict__ out) {
+  using B = B6Geo<G>;
+  constexpr int N1 = 2 * G::MB * 2 * B::R1, N2 = 2 * G::H1B * 2 * B::R2, N3 = 2 * G::H2B * 2 * B::R3;  // (kg, hi, row) triples
+  constexpr int NB = B::R1 + B::R2 + B::R3;
+  constexpr int PER = N1 + N2 + N3 + NB;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long)nimg * PER) return;
+  const int img = (int)(gid / PER);
+  int e = (int)(gid - (long)img * PER);
+  const float *src = wimg + (size_t)img * G::SIZE;
+  unsigned char *base = out + (size_t)img * B::BYTES;
+  int lay, rows, wsrc, S;
+  if (e < N1) { lay = B::L1; rows = B::R1; wsrc = G::W1; S = G::S1; }
+  else if (e < N1 + N2) { e -= N1; lay = B::L2; rows = B::R2; wsrc = G::W2; S = G::S2; }
+  else if (e < N1 + N2 + N3) { e -= N1 + N2; lay = B::L3; rows = B::R3; wsrc = G::W3; S = G::S3; }
+  else {  // bias element (fp32): the three bias vectors back to back
+    e -= N1 + N2 + N3;
+    const float v = e < B::R1 ? src[G::B1 + e] : e < B::R1 + B::R2 ? src[G::B2 + e - B::R1] : src[G::B3 + e - B::R1 - B::R2];
+    reinterpret_cast<float *>(base + (size_t)B::BIAS * 16)[e] = v;
+    return;
+  }
+  const int row = e % rows, hi = (e / rows) & 1, kg = e / (2 * rows);
+  unsigned short h[8], mi[8], l[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int f = 16 * kg + (j & 3) + 8 * (j >> 2) + 4 * hi;  // input feature of k-slot (kg, hi, j)
+    const float w = src[wsrc + f * S + row];                   // image element [in f][out row], zero padded
+    const unsigned xb = __float_as_uint(w);
+    const float r1 = w - __uint_as_float(xb & 0xFFFF0000u);
+    const unsigned rb = __float_as_uint(r1);
+    const float lo = r1 - __uint_as_float(rb & 0xFFFF0000u);
+    h[j] = (unsigned short)(xb >> 16);
+    mi[j] = (unsigned short)(rb >> 16);
+    l[j] = (unsigned short)(__float_as_uint(lo) >> 16);
+  }
+  auto put = [&](int comp, const unsigned short(&v)[8]) {
+    nf_u32x4 q;
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) q[pp] = (unsigned)v[2 * pp] | ((unsigned)v[2 * pp + 1] << 16);
+    reinterpret_cast<nf_u32x4 *>(base)[lay + ((kg * 3 + comp) * 2 + hi) * rows + row] = q;
+  };
+  put(0, h);
+  put(1, mi);
+  put(2, l);
+}
+
 // g[theta index] = sum over workgroup slabs of the image-layout partial gradients
 // Block 0 can also finish a deterministic sum of `nlpart` double partials into *lout (the step's loss:
 // saves a separate one-block launch in the training step).

@@ -7,6 +7,7 @@ must meet the PLAIN gradient tolerance (1e-4 |g|inf, or 3 x the IEEE-float32 ora
 invertible-recompute allowance of round 2 (2e-3) does not apply to any default path any more.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -409,3 +410,58 @@ def test_train_flow_runs_one_library_call_per_iteration_and_equals_the_split_loo
     assert st33.t == 6 and torch.equal(f33.theta, tb)
     # a draw counter out of step with Adam's count cannot be one nf_elbo_step index: the split loop takes it
     assert not ob._fused_steps_apply(nf.elbo_batch, flow, [tgt, n], nf.PhiloxRNG(9), None, {"state": st3})
+
+
+_VARIANT_SNIPPET = r"""
+import ctypes as C, json, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.environ["NF_ROOT"]); sys.path.insert(0, os.path.join(os.environ["NF_ROOT"], "oracle"))
+from __graft_entry__ import load_package
+import nf_oracle as o
+nf = load_package()
+d, n = 64, 333
+flow = nf.realnvp(nf.MvNormal(d), (64, 64), 2, paramtype=torch.float32, seed=5)
+rng = np.random.default_rng(0)
+mu, var = rng.standard_normal(d), rng.uniform(size=d) + 0.5
+tgt = nf.DiagGaussTarget(torch.tensor(mu, dtype=torch.float32, device="cuda"), torch.tensor(var, dtype=torch.float32, device="cuda"))
+xs = nf.device_specific_rand(nf.PhiloxRNG(3), flow.dist, n)
+l_in, g_in = nf.value_and_gradient(nf.elbo_batch, flow, tgt, n, rng=nf.PhiloxRNG(3))   # in-library draws: fused forward + stash
+l_xs, g_xs = nf.value_and_gradient(nf.elbo_batch, flow, tgt, xs)                        # supplied draws: plain chain + stash
+ll = nf.loglikelihood(None, flow, xs)                                                   # inverse chain, no stash
+ys, ladj = nf.with_logabsdet_jacobian(flow.transform, xs)
+spec = o.FlowSpec("realnvp", d, 2, (64, 64))
+th = flow.theta.cpu().numpy().astype(np.float64)
+x64 = xs.cpu().numpy().astype(np.float64)
+lr, gr = o.neg_elbo_value_and_grad(spec, th, ("diaggauss", mu, var), x64)
+yr, ladr = o.flow_fwd(spec, th, x64)[:2]
+llr = o.loglikelihood(spec, th, x64)
+sc = float(np.abs(gr).max())
+print(json.dumps({"l_in": l_in, "l_xs": l_xs, "l_ref": lr, "g_in": float(np.abs(g_in.cpu().numpy() - gr).max() / sc),
+                  "g_xs": float(np.abs(g_xs.cpu().numpy() - gr).max() / sc), "y": float(np.abs(ys.cpu().numpy() - yr).max()),
+                  "ladj": float(np.abs(ladj.cpu().numpy() - ladr).max()), "ll": ll, "ll_ref": llr}))
+"""
+
+
+@pytest.mark.parametrize("env", [{}, {"NF_FWD_FP32": "1"}, {"NF_FWD_B6_STASH": "1"}, {"NF_STASH_SLIM": "1"}, {"NF_STASH_SLIM": "1", "NF_FWD_B6_STASH": "1"}],
+                         ids=["default", "fp32_forward", "b6_stashing_forward", "slim_stash", "slim_stash_b6"])
+def test_kernel_variants_behind_environment_switches_keep_parity(env):
+    """The measured-and-kept alternatives of round 4 are selected once per process by environment switches (the bf16
+    six-term forward for stashing chains, the fp32 forward everywhere, the stash without a1): each must give the oracle's
+    loss, gradient, forward and log-likelihood at the tolerances of the default path -- run in a subprocess per switch."""
+    import json
+    import subprocess
+    import sys
+
+    from __graft_entry__ import ROOT
+
+    e = dict(os.environ, NF_ROOT=ROOT, **env)
+    for k in ("NF_FWD_FP32", "NF_FWD_B6_STASH", "NF_STASH_SLIM"):
+        if k not in env:
+            e.pop(k, None)
+    p = subprocess.run([sys.executable, "-c", _VARIANT_SNIPPET], env=e, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r["l_in"] == pytest.approx(r["l_ref"], rel=P.LOSS_RTOL) and r["l_xs"] == pytest.approx(r["l_ref"], rel=P.LOSS_RTOL)
+    assert r["g_in"] <= P.GRAD_RTOL and r["g_xs"] <= P.GRAD_RTOL
+    assert r["y"] <= 2e-5 and r["ladj"] <= 2e-5
+    assert r["ll"] == pytest.approx(r["ll_ref"], rel=P.LOSS_RTOL)
