@@ -68,7 +68,7 @@ struct nf_ctx {
   unsigned long long wimg_sig = 0;
   bool wimg_cache = false;  // nf_ctx_set_weight_cache: off by default (every nf_elbo_step packs from theta)
   // generation of the fp32 weight images (bumped by every writer) and the one the bf16-triple copies were built from
-  unsigned long long wimg_gen = 1, b6_gen = 0;
+  unsigned long long wimg_gen = 1, b6_gen = 0, b6t_gen = 0;
   // RCCL communicator of this context (nf_comm.hip); null for single-GPU use
   void *comm = nullptr;
   int comm_size = 1, comm_rank = 0;

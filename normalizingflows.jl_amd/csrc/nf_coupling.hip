@@ -953,6 +953,7 @@ __global__ __launch_bounds__(256, 1) void k_affine_bwd(CouplingArgs a, float *__
 // gap and the ramp-up / tail of seven launches per step.
 struct BwdAllArgs {
   const float *wimg;  // [coupling][s|t][G::SIZE]
+  const unsigned char *wimg_b6t;  // [coupling][s|t][B6TGeo<G>::BYTES]: the bf16-triple images of the dX GEMMs (pair kernel, PB6)
   long long *trace;
   int d, ncoup;
   long N;
@@ -1063,6 +1064,72 @@ __device__ __forceinline__ void dw_accumulate_reg(const float (&at)[IB][16], con
   }
 }
 
+// dW^T accumulation on the bf16 matrix cores (six-term products, nf_mfma.h "B6"): same operands as dw_accumulate_reg -- the
+// activation operand in registers, at[ib][t] = a[feature][sample 2t + hi], the delta operand from the LDS tile at the same
+// samples -- with the sample <-> k-slot assignment  slot (g, hi, j) <-> sample 2 (8 g + j) + hi : registers 8g .. 8g+7 of `at`
+// ARE the lane's eight k-values of group g, and the delta reads are the ones the fp32 form issues.  Both operands are split
+// here (8 values -> 3 x 4 registers each); 12 bf16 MFMAs of 32 clocks replace 16 fp32 ones of 64 per (ib, ob) block pair.
+// The bias gradient stays the fp32 sum of the deltas.
+template <int IB>
+struct SplitT {  // the activation operand of a dW GEMM as bf16 triples: [block][sample group] x (h, m, l)
+  nf_u32x4 h[IB][2], m[IB][2], l[IB][2];
+};
+template <int IB>
+__device__ __forceinline__ void split_T(const float (&at)[IB][16], SplitT<IB> &s) {
+#pragma unroll
+  for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = at[ib][8 * g + j];
+      nf_split8(v, s.h[ib][g], s.m[ib][g], s.l[ib][g]);
+      __builtin_amdgcn_sched_barrier(0);  // one split at a time: interleaved, their temporaries (3 x 8 each) spill the accumulators
+    }
+}
+// The activation operand arrives already split (split_T, done by the consumer while it waits for the producer's delta tile:
+// 48 registers per 32-feature block pair instead of 32 fp32 + the splits of the group in flight); one delta block's eight
+// values and their split are live at a time, the next unit's delta values are requested behind the current unit's MFMAs.
+// Pipeline unit = (sample group g, delta block ob).
+template <int IB, int OB, class SJ = NoSideJob>
+__device__ __forceinline__ void dw_accumulate_reg_b6(const SplitT<IB> &as, const float *__restrict__ sd, f32x16 (&acc)[IB][OB],
+                                                     float (&bsum)[OB], int l31, int hi, SJ sj = SJ()) {
+  const float *pd = sd + l31 * NF_TS + hi;
+  constexpr int NU = 2 * OB;
+  float dn[8], dc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dn[j] = pd[2 * j];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int g = u / OB, ob = u % OB;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dc[j] = dn[j];
+    if (u + 1 < NU) {
+      const int g1 = (u + 1) / OB, ob1 = (u + 1) % OB;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dn[j] = pd[ob1 * 32 * NF_TS + 2 * (8 * g1 + j)];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bsum[ob] += dc[j];
+    nf_u32x4 dh, dm, dl;
+    nf_split8(dc, dh, dm, dl);
+    __builtin_amdgcn_sched_barrier(0);
+    // smallest terms first (as dense_fwd_b6): al dh, ah dl, am dm, am dh, ah dm, ah dh -- the IB accumulators interleaved
+#pragma unroll
+    for (int term = 0; term < 6; ++term)
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib) {
+        const nf_u32x4 &a = term == 0 ? as.l[ib][g] : (term == 2 || term == 3) ? as.m[ib][g] : as.h[ib][g];
+        const nf_u32x4 &d = term == 1 ? dl : (term == 2 || term == 4) ? dm : dh;
+        acc[ib][ob] = nf_mfma_bf16(a, d, acc[ib][ob]);
+        const int c = (u * 6 + term) * IB + ib;  // running MFMA index: two side-job slots each
+        sj(2 * c);
+        sj(2 * c + 1);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // a1^T = leakyrelu(W1 x2 + b1) as the dW2 GEMM wants it -- lane <-> hidden unit, register r <-> sample
 // (r & 3) + 8 (r >> 2) + 4 hi (dw_accumulate_reg<..., CORDER>) -- from the conditioner input in the MFMA C layout:
 // D' = x2^T W1^T, i.e. dense_fwd with the operand roles swapped (A: the input's registers, B: the weight image's rows, lanes
@@ -1117,7 +1184,8 @@ struct BwdStashLds {
   static constexpr int DROWS = BwdLds<G>::DROWS;
   static constexpr int SCRATCH = DROWS * 32 * NF_TS;  // one delta tile per wave
   static constexpr int WAVES = 4;
-  static constexpr int FLOATS = (G::SIZE + WAVES * SCRATCH) > WAVES * G::SIZE ? (G::SIZE + WAVES * SCRATCH) : WAVES * G::SIZE;
+  static constexpr int IMGMAX = B6TGeo<G>::BYTES / 4 > G::SIZE ? B6TGeo<G>::BYTES / 4 : G::SIZE;  // fp32 or B6T image
+  static constexpr int FLOATS = (IMGMAX + WAVES * SCRATCH) > WAVES * G::SIZE ? (IMGMAX + WAVES * SCRATCH) : WAVES * G::SIZE;
   static constexpr size_t BYTES = (size_t)FLOATS * sizeof(float);  // the fold at the end of a phase needs 4 images
 };
 
@@ -1138,7 +1206,9 @@ __device__ __forceinline__ void stash_issue_first(StashFirst<G> &f, float *stash
 
 // INVD: reverse pass of the INVERSE coupling (forward-KL training; algebra as in bwd_tile): the UV slot holds w1, phase S
 // runs first (it needs w1bar and w1 and leaves v1bar = w1bar exp(-s) behind), phase T seeds with -v1bar.
-template <class G, bool PHASE_S, bool FULL, bool INVD = false>
+// SB6 (round 4): all six GEMMs of the tile on the bf16 matrix cores (dense_bwd_x_b6 / dw_accumulate_reg_b6); `img` is then
+// the net's B6T image.  One wave per SIMD: 512 registers, the split operands fit next to the 128 accumulators here.
+template <class G, bool PHASE_S, bool FULL, bool INVD = false, bool SB6 = false>
 __device__ __forceinline__ void bwd_tile_stashed(const CouplingArgs &a, const float *__restrict__ img, float *__restrict__ sd,
                                                  BwdAcc<G> &acc, StashFirst<G> &f, float *stash, int k, int ncoup,
                                                  float *__restrict__ ybar, const float *__restrict__ lbar, float lbar_const,
@@ -1191,26 +1261,41 @@ __device__ __forceinline__ void bwd_tile_stashed(const CouplingArgs &a, const fl
   NF_TS_STAMP(2);
   // ---- layer 3
   f32x16 d2[G::H2B];
-  dense_bwd_x<G::H2B, G::CB>(img + G::W3, d3, d2, l31, hi, [&](int e) { scratch_put<G::CB>(sd, d3, e, l31, hi); });
+  const nf_u32x4 *wt = reinterpret_cast<const nf_u32x4 *>(img);  // SB6: the staged image is the net's B6T image
+  if constexpr (SB6) dense_bwd_x_b6<G::H2B, G::CB>(wt + B6TGeo<G>::T3, d3, d2, l31, hi, [&](int e) { scratch_put<G::CB>(sd, d3, e, l31, hi); });
+  else dense_bwd_x<G::H2B, G::CB>(img + G::W3, d3, d2, l31, hi, [&](int e) { scratch_put<G::CB>(sd, d3, e, l31, hi); });
   float a1t[G::H1B][16];
   stash_get_T<G::H1B>(st, nbase + SG::A1, vT, a1t);
   NF_TS_STAMP(3);
   wave_lds_fence();
-  dw_accumulate_reg<G::H2B, G::CB>(a2t, sd, acc.w3, acc.b3, l31, hi, [&](int e) {
+  auto sj3 = [&](int e) {
     if (e < G::H2B * 16) d2[e >> 4][e & 15] *= lrelu_slope(m2[e >> 4], e & 15);
-  });
+  };
+  if constexpr (SB6) {
+    SplitT<G::H2B> a2s;
+    split_T<G::H2B>(a2t, a2s);
+    dw_accumulate_reg_b6<G::H2B, G::CB>(a2s, sd, acc.w3, acc.b3, l31, hi, sj3);
+  } else
+    dw_accumulate_reg<G::H2B, G::CB>(a2t, sd, acc.w3, acc.b3, l31, hi, sj3);
   NF_TS_STAMP(4);
   wave_lds_fence();
   // ---- layer 2
   f32x16 d1[G::H1B];
-  dense_bwd_x<G::H1B, G::H2B>(img + G::W2, d2, d1, l31, hi, [&](int e) { scratch_put<G::H2B>(sd, d2, e, l31, hi); });
+  if constexpr (SB6) dense_bwd_x_b6<G::H1B, G::H2B>(wt + B6TGeo<G>::T2, d2, d1, l31, hi, [&](int e) { scratch_put<G::H2B>(sd, d2, e, l31, hi); });
+  else dense_bwd_x<G::H1B, G::H2B>(img + G::W2, d2, d1, l31, hi, [&](int e) { scratch_put<G::H2B>(sd, d2, e, l31, hi); });
   float x2t[G::MB][16];
   stash_get_T<G::MB>(st, SG::XT, vT, x2t);
   NF_TS_STAMP(5);
   wave_lds_fence();
-  dw_accumulate_reg<G::H1B, G::H2B>(a1t, sd, acc.w2, acc.b2, l31, hi, [&](int e) {
+  auto sj2 = [&](int e) {
     if (e < G::H1B * 16) d1[e >> 4][e & 15] *= lrelu_slope(m1[e >> 4], e & 15);
-  });
+  };
+  if constexpr (SB6) {
+    SplitT<G::H1B> a1s;
+    split_T<G::H1B>(a1t, a1s);
+    dw_accumulate_reg_b6<G::H1B, G::H2B>(a1s, sd, acc.w2, acc.b2, l31, hi, sj2);
+  } else
+    dw_accumulate_reg<G::H1B, G::H2B>(a1t, sd, acc.w2, acc.b2, l31, hi, sj2);
   NF_TS_STAMP(6);
   wave_lds_fence();
   // ---- layer 1: x2bar accumulates ybar2 + W1t^T d1t (phase T) + W1s^T d1s (phase S)
@@ -1220,17 +1305,24 @@ __device__ __forceinline__ void bwd_tile_stashed(const CouplingArgs &a, const fl
 #pragma unroll
     for (int r = 0; r < 16; ++r) gold[b][r] = tile_load(gio, tile_soff(b, r, par_c));
   if (PHASE_S && next_tile >= 0) stash_issue_first<G>(f, stash, k, ncoup, next_tile, l31, hi);
-  dense_bwd_x<G::MB, G::H1B>(img + G::W1, d1, g2, l31, hi, [&](int e) { scratch_put<G::H1B>(sd, d1, e, l31, hi); });
+  if constexpr (SB6) dense_bwd_x_b6<G::MB, G::H1B>(wt + B6TGeo<G>::T1, d1, g2, l31, hi, [&](int e) { scratch_put<G::H1B>(sd, d1, e, l31, hi); });
+  else dense_bwd_x<G::MB, G::H1B>(img + G::W1, d1, g2, l31, hi, [&](int e) { scratch_put<G::H1B>(sd, d1, e, l31, hi); });
   NF_TS_STAMP(7);
   wave_lds_fence();
-  dw_accumulate_reg<G::MB, G::H1B>(x2t, sd, acc.w1, acc.b1, l31, hi, [&](int e) {
+  auto sj1 = [&](int e) {
     if (e < G::MB * 16) tile_store(gio, tile_soff(e >> 4, e & 15, par_c), gold[e >> 4][e & 15] + g2[e >> 4][e & 15]);
-  });
+  };
+  if constexpr (SB6) {
+    SplitT<G::MB> x2s;
+    split_T<G::MB>(x2t, x2s);
+    dw_accumulate_reg_b6<G::MB, G::H1B>(x2s, sd, acc.w1, acc.b1, l31, hi, sj1);
+  } else
+    dw_accumulate_reg<G::MB, G::H1B>(x2t, sd, acc.w1, acc.b1, l31, hi, sj1);
   wave_lds_fence();
   NF_TS_STAMP(8);
 }
 
-template <class G, bool FULL, bool INVD = false>
+template <class G, bool FULL, bool INVD = false, bool SB6 = false>
 __global__ __launch_bounds__(256, 1) void k_affine_bwd_stashed(BwdAllArgs aa, float *stash, float *__restrict__ ybar,
                                                                const float *__restrict__ lbar, float lbar_const,
                                                                float *__restrict__ slab, long slab_stride) {
@@ -1239,7 +1331,8 @@ __global__ __launch_bounds__(256, 1) void k_affine_bwd_stashed(BwdAllArgs aa, fl
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
-  float *sd = lds + G::SIZE + wave * BwdStashLds<G>::SCRATCH;
+  constexpr int IMGF = SB6 ? B6TGeo<G>::BYTES / 4 : G::SIZE;  // floats of the staged weight image (fp32, or B6T)
+  float *sd = lds + IMGF + wave * BwdStashLds<G>::SCRATCH;
   const long ntiles = (aa.N + NF_TILE - 1) / NF_TILE;
   const long tile0 = (long)blockIdx.x * 4 + wave, tstride = (long)gridDim.x * 4;
   StashFirst<G> f;
@@ -1271,7 +1364,10 @@ __global__ __launch_bounds__(256, 1) void k_affine_bwd_stashed(BwdAllArgs aa, fl
 #pragma unroll 1
     for (int phase = 0; phase < 2; ++phase) {
       const bool is_s = INVD ? phase == 0 : phase == 1;
-      stage_packed<G::SIZE, 256>(img, is_s ? a.img_s : a.img_t, tid);
+      if constexpr (SB6)
+        stage_packed<IMGF, 256>(img, reinterpret_cast<const float *>(aa.wimg_b6t + (size_t)(2 * k + (is_s ? 0 : 1)) * B6TGeo<G>::BYTES), tid);
+      else
+        stage_packed<G::SIZE, 256>(img, is_s ? a.img_s : a.img_t, tid);
       __syncthreads();
       BwdAcc<G> acc;
       zero_acc(acc.w1, acc.b1);
@@ -1287,8 +1383,8 @@ __global__ __launch_bounds__(256, 1) void k_affine_bwd_stashed(BwdAllArgs aa, fl
 #else
         long long *tr = nullptr;
 #endif
-        if (!is_s) bwd_tile_stashed<G, false, FULL, INVD>(a, img, sd, acc, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, l31, hi, tr);
-        else bwd_tile_stashed<G, true, FULL, INVD>(a, img, sd, acc, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, l31, hi, tr);
+        if (!is_s) bwd_tile_stashed<G, false, FULL, INVD, SB6>(a, img, sd, acc, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, l31, hi, tr);
+        else bwd_tile_stashed<G, true, FULL, INVD, SB6>(a, img, sd, acc, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, l31, hi, tr);
       }
       NF_ST_STAMP(2 + phase * 4);
       __syncthreads();  // every wave is done with the weight image and its scratch
@@ -1340,24 +1436,33 @@ __global__ __launch_bounds__(256, 1) void k_affine_bwd_stashed(BwdAllArgs aa, fl
 //   consumer: a2 loads  | B1 | dW3 (d3)       | B2 | dW2 (d2)       | B3 | dW1 (d1)
 // One buffer per delta suffices: d3 of the next tile is written after B3, when dW3 has long read it (before B2), etc.
 // Whole tiles only (d = 64, N a multiple of 32) and every pair the same number of tiles (barriers inside the tile loop).
-template <class G>
+#ifndef NF_PAIR_DW_B6
+#define NF_PAIR_DW_B6 0  // bit mask: which of the consumer's dW GEMMs (1: dW3, 2: dW2, 4: dW1) run on the bf16 matrix cores as well.
+// Measured (profiles/r4m_pair_b6_ab.txt): 7 -> 613 us per launch (392 bytes of scratch: the consumer holds 128 accumulators and the
+// split operands do not fit the remaining registers), 6 -> 591, 4 -> 338, 0 -> 334 (the producer's dX GEMMs only; fp32: 365).
+#endif
+// PB6 (round 4): the producer's three dX GEMMs on the bf16 matrix cores (dense_bwd_x_b6); the LDS then holds the net's
+// B6T image instead of the fp32 one -- nobody else reads weights in this kernel (the consumer contracts activations with
+// deltas), except the SLIM stash's a1 recompute, which therefore keeps the fp32 image.
+template <class G, bool PB6 = false>
 struct BwdPairLds {
   static constexpr int D3 = 0, D2 = D3 + G::CB * 32 * NF_TS, D1 = D2 + G::H2B * 32 * NF_TS, PAIR = D1 + G::H1B * 32 * NF_TS;
   static constexpr int PAIRS = 4;
-  static constexpr int FLOATS = (G::SIZE + PAIRS * PAIR) > PAIRS * G::SIZE ? (G::SIZE + PAIRS * PAIR) : PAIRS * G::SIZE;
+  static constexpr int IMG = PB6 ? B6TGeo<G>::BYTES / 4 : G::SIZE;  // floats of the staged weight image
+  static constexpr int FLOATS = (IMG + PAIRS * PAIR) > PAIRS * G::SIZE ? (IMG + PAIRS * PAIR) : PAIRS * G::SIZE;
   static constexpr size_t BYTES = (size_t)FLOATS * sizeof(float);  // the fold at the end of a phase needs 4 images
 };
 
 // FULL: d = 64 and N a multiple of the tile (no sample / feature masks).  INVD: reverse pass of the INVERSE coupling
 // (forward-KL training; algebra of bwd_tile_stashed: phase S first, the UV slot holds w1).  live: this pair has a tile in
 // this round of the workgroup's tile loop -- a pair without one only keeps the barrier count.
-template <class G, bool PHASE_S, bool FULL, bool INVD, bool SLIM>
+template <class G, bool PHASE_S, bool FULL, bool INVD, bool SLIM, bool PB6 = false>
 __device__ __forceinline__ void pair_produce(const CouplingArgs &a, const float *__restrict__ img, float *__restrict__ sp,
                                              StashFirst<G> &f, float *stash, int k, int ncoup, float *__restrict__ ybar,
                                              const float *__restrict__ lbar, float lbar_const, long tile, long next_tile,
                                              bool live, int l31, int hi, long long *tr = nullptr) {
   using SG = StashGeo<G, SLIM>;
-  using L = BwdPairLds<G>;
+  using L = BwdPairLds<G, PB6>;
   if (!live) {
     __syncthreads();
     __syncthreads();
@@ -1412,14 +1517,17 @@ __device__ __forceinline__ void pair_produce(const CouplingArgs &a, const float 
   __syncthreads();  // B1: d3 is in LDS (and the consumer is done with the previous tile's d1)
   NF_TS_STAMP(2);
   f32x16 d2[G::H2B];
-  dense_bwd_x<G::H2B, G::CB>(img + G::W3, d3, d2, l31, hi);
+  const nf_u32x4 *wt = reinterpret_cast<const nf_u32x4 *>(img);  // PB6: the staged image is the net's B6T image
+  if constexpr (PB6) dense_bwd_x_b6<G::H2B, G::CB>(wt + B6TGeo<G>::T3, d3, d2, l31, hi);
+  else dense_bwd_x<G::H2B, G::CB>(img + G::W3, d3, d2, l31, hi);
   apply_lrelu_grad<G::H2B>(d2, m2);
   tile_to_scratch<G::H2B>(sp + L::D2, d2, l31, hi);
   NF_TS_STAMP(3);
   __syncthreads();  // B2
   NF_TS_STAMP(4);
   f32x16 d1[G::H1B];
-  dense_bwd_x<G::H1B, G::H2B>(img + G::W2, d2, d1, l31, hi);
+  if constexpr (PB6) dense_bwd_x_b6<G::H1B, G::H2B>(wt + B6TGeo<G>::T2, d2, d1, l31, hi);
+  else dense_bwd_x<G::H1B, G::H2B>(img + G::W2, d2, d1, l31, hi);
   apply_lrelu_grad<G::H1B>(d1, m1);
   tile_to_scratch<G::H1B>(sp + L::D1, d1, l31, hi);
   NF_TS_STAMP(5);
@@ -1427,7 +1535,8 @@ __device__ __forceinline__ void pair_produce(const CouplingArgs &a, const float 
   NF_TS_STAMP(6);
   if (PHASE_S && next_tile >= 0) stash_issue_first<G, SLIM>(f, stash, k, ncoup, next_tile, l31, hi);
   f32x16 g2[G::MB];
-  dense_bwd_x<G::MB, G::H1B>(img + G::W1, d1, g2, l31, hi);
+  if constexpr (PB6) dense_bwd_x_b6<G::MB, G::H1B>(wt + B6TGeo<G>::T1, d1, g2, l31, hi);
+  else dense_bwd_x<G::MB, G::H1B>(img + G::W1, d1, g2, l31, hi);
 #pragma unroll
   for (int b = 0; b < G::MB; ++b)
 #pragma unroll
@@ -1437,12 +1546,12 @@ __device__ __forceinline__ void pair_produce(const CouplingArgs &a, const float 
 
 // (Measured and removed: dW1 of a tile moved in front of the NEXT tile's first barrier, where the producer issues no
 // MFMAs -- 374-379 us against 366 in one process; and the producer's next-unit operands requested behind B3 -- 370.)
-template <class G, bool SLIM>
+template <class G, bool SLIM, bool PB6 = false>
 __device__ __forceinline__ void pair_consume(const float *__restrict__ img, const float *__restrict__ sp, BwdAcc<G> &acc, float *stash,
                                              int k, int ncoup, long tile, bool is_s, bool live, int l31, int hi,
                                              long long *tr = nullptr) {
   using SG = StashGeo<G, SLIM>;
-  using L = BwdPairLds<G>;
+  using L = BwdPairLds<G, PB6>;
   if (!live) {
     __syncthreads();
     __syncthreads();
@@ -1476,27 +1585,56 @@ __device__ __forceinline__ void pair_consume(const float *__restrict__ img, cons
   {
     float a2t[G::H2B][16];
     stash_get_T<G::H2B>(st, nbase + SG::A2, vT, a2t);
+    if constexpr (PB6 && (NF_PAIR_DW_B6 & 1)) {
+      SplitT<G::H2B> a2s;
+      split_T<G::H2B>(a2t, a2s);
+      NF_TS_STAMP(1);
+      __syncthreads();  // B1
+      NF_TS_STAMP(2);
+      dw_accumulate_reg_b6<G::H2B, G::CB>(a2s, sp + L::D3, acc.w3, acc.b3, l31, hi);
+    } else {
     NF_TS_STAMP(1);
     __syncthreads();  // B1
     NF_TS_STAMP(2);
     dw_accumulate_reg<G::H2B, G::CB>(a2t, sp + L::D3, acc.w3, acc.b3, l31, hi);
+    }
   }
+  if constexpr (PB6 && NF_PAIR_DW_B6 != 0) __builtin_amdgcn_sched_barrier(0);  // the next operand block is requested AFTER this GEMM: registers
   {
     float a1t[G::H1B][16];
     stash_get_T<G::H1B>(st, nbase + SG::A1, vT, a1t);
+    if constexpr (PB6 && (NF_PAIR_DW_B6 & 2)) {
+      SplitT<G::H1B> a1s;
+      split_T<G::H1B>(a1t, a1s);
+      NF_TS_STAMP(3);
+      __syncthreads();  // B2
+      NF_TS_STAMP(4);
+      dw_accumulate_reg_b6<G::H1B, G::H2B>(a1s, sp + L::D2, acc.w2, acc.b2, l31, hi);
+    } else {
     NF_TS_STAMP(3);
     __syncthreads();  // B2
     NF_TS_STAMP(4);
     dw_accumulate_reg<G::H1B, G::H2B>(a1t, sp + L::D2, acc.w2, acc.b2, l31, hi);
+    }
   }
   }
+  if constexpr (PB6 && NF_PAIR_DW_B6 != 0) __builtin_amdgcn_sched_barrier(0);
   {
     float x2t[G::MB][16];
     stash_get_T<G::MB>(st, SG::XT, vT, x2t);
+    if constexpr (PB6 && (NF_PAIR_DW_B6 & 4)) {
+      SplitT<G::MB> x2s;
+      split_T<G::MB>(x2t, x2s);
+      NF_TS_STAMP(5);
+      __syncthreads();  // B3
+      NF_TS_STAMP(6);
+      dw_accumulate_reg_b6<G::MB, G::H1B>(x2s, sp + L::D1, acc.w1, acc.b1, l31, hi);
+    } else {
     NF_TS_STAMP(5);
     __syncthreads();  // B3
     NF_TS_STAMP(6);
     dw_accumulate_reg<G::MB, G::H1B>(x2t, sp + L::D1, acc.w1, acc.b1, l31, hi);
+    }
     NF_TS_STAMP(7);
   }
 }
@@ -1522,7 +1660,7 @@ __device__ __forceinline__ void pair_slab_write(const float *__restrict__ lds, f
 // never count against the other role's 256 registers (inside the coupling loop both are live across either branch).
 // Every wave executes the same barriers: per phase 1 (image staged) + 3 per round of the tile loop + 3 (tiles done,
 // folded, slab written); the tile loop runs as many rounds as the workgroup's first pair needs.
-template <class G, bool FULL, bool INVD, bool SLIM>
+template <class G, bool FULL, bool INVD, bool SLIM, bool PB6 = false>
 __global__ __launch_bounds__(512) void k_affine_bwd_pair(BwdAllArgs aa, float *stash, float *__restrict__ ybar,
                                                          const float *__restrict__ lbar, float lbar_const,
                                                          float *__restrict__ slab, long slab_stride) {
@@ -1532,7 +1670,16 @@ __global__ __launch_bounds__(512) void k_affine_bwd_pair(BwdAllArgs aa, float *s
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pair = wave & 3, role = wave >> 2;  // waves p and p + 4 sit on the same SIMD; role 0 produces, 1 consumes
   const int l31 = lane & 31, hi = lane >> 5;
-  float *sp = lds + G::SIZE + pair * BwdPairLds<G>::PAIR;
+  static_assert(!(SLIM && PB6), "the SLIM stash's a1 recompute reads the fp32 image");
+  using PL = BwdPairLds<G, PB6>;
+  using BT = B6TGeo<G>;
+  float *sp = lds + PL::IMG + pair * PL::PAIR;
+  auto stage_image = [&](int k, bool is_s) {  // the net's weight image of this phase -> LDS (fp32, or B6T for the producer's dX GEMMs)
+    if constexpr (PB6)
+      stage_packed<BT::BYTES / 4, 512>(img, reinterpret_cast<const float *>(aa.wimg_b6t + (size_t)(2 * k + (is_s ? 0 : 1)) * BT::BYTES), tid);
+    else
+      stage_packed<G::SIZE, 512>(img, aa.wimg + (size_t)(2 * k + (is_s ? 0 : 1)) * G::SIZE, tid);
+  };
   const long ntiles = (aa.N + NF_TILE - 1) / NF_TILE;
   const long tile0 = (long)blockIdx.x * 4 + pair, tstride = (long)gridDim.x * 4;
   const long wg0 = (long)blockIdx.x * 4;
@@ -1556,7 +1703,7 @@ __global__ __launch_bounds__(512) void k_affine_bwd_pair(BwdAllArgs aa, float *s
 #pragma unroll 1
       for (int phase = 0; phase < 2; ++phase) {
         const bool is_s = INVD ? phase == 0 : phase == 1;
-        stage_packed<G::SIZE, 512>(img, is_s ? a.img_s : a.img_t, tid);
+        stage_image(k, is_s);
         __syncthreads();
 #pragma unroll 1
         for (int it = 0; it < rounds; ++it) {
@@ -1567,8 +1714,8 @@ __global__ __launch_bounds__(512) void k_affine_bwd_pair(BwdAllArgs aa, float *s
 #else
           long long *tr = nullptr;
 #endif
-          if (!is_s) pair_produce<G, false, FULL, INVD, SLIM>(a, img, sp, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, tile < ntiles, l31, hi, tr);
-          else pair_produce<G, true, FULL, INVD, SLIM>(a, img, sp, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, tile < ntiles, l31, hi, tr);
+          if (!is_s) pair_produce<G, false, FULL, INVD, SLIM, PB6>(a, img, sp, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, tile < ntiles, l31, hi, tr);
+          else pair_produce<G, true, FULL, INVD, SLIM, PB6>(a, img, sp, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, tile < ntiles, l31, hi, tr);
         }
         __syncthreads();  // every wave is done with the weight image and the delta tiles
         // s and u of the next phase-S's first tile fly behind the fold, the slab write and the staging of the next image
@@ -1589,7 +1736,7 @@ __global__ __launch_bounds__(512) void k_affine_bwd_pair(BwdAllArgs aa, float *s
 #pragma unroll 1
       for (int phase = 0; phase < 2; ++phase) {
         const bool is_s = INVD ? phase == 0 : phase == 1;
-        stage_packed<G::SIZE, 512>(img, is_s ? img_s : img_s + G::SIZE, tid);
+        stage_image(k, is_s);
         __syncthreads();
         BwdAcc<G> acc;
         zero_acc(acc.w1, acc.b1);
@@ -1603,7 +1750,7 @@ __global__ __launch_bounds__(512) void k_affine_bwd_pair(BwdAllArgs aa, float *s
 #else
           long long *tr = nullptr;
 #endif
-          pair_consume<G, SLIM>(img, sp, acc, stash, k, aa.ncoup, tile, is_s, tile < ntiles, l31, hi, tr);
+          pair_consume<G, SLIM, PB6>(img, sp, acc, stash, k, aa.ncoup, tile, is_s, tile < ntiles, l31, hi, tr);
         }
         __syncthreads();  // every wave is done with the weight image and the delta tiles
         {
@@ -1704,9 +1851,27 @@ static bool fwd_b6(bool stashing = false) {
 }
 
 static size_t b6_image_bytes(int size) { return size == NetGeo<1, 1, 1, 1>::SIZE ? B6Geo<NetGeo<1, 1, 1, 1>>::BYTES : B6Geo<NetGeo<1, 2, 2, 1>>::BYTES; }
+static size_t b6t_image_bytes(int size) { return size == NetGeo<1, 1, 1, 1>::SIZE ? B6TGeo<NetGeo<1, 1, 1, 1>>::BYTES : B6TGeo<NetGeo<1, 2, 2, 1>>::BYTES; }
+// ctx->wimg of a resident RealNVP flow: [fp32 images][B6 images (forward chain)][B6T images (pair kernel's dX GEMMs)]
 size_t nf_affine_wimg_bytes(const nf_flow_desc *desc) {
   const int size = geo_size(desc);
-  return (size_t)2 * desc->nlayers * 2 * ((size_t)size * sizeof(float) + (size ? b6_image_bytes(size) : 0));
+  return (size_t)2 * desc->nlayers * 2 * ((size_t)size * sizeof(float) + (size ? b6_image_bytes(size) + b6t_image_bytes(size) : 0));
+}
+template <class G>
+static size_t b6t_offset_bytes(const nf_flow_desc *desc) { return b6_offset_bytes<G>(desc) + (size_t)2 * desc->nlayers * 2 * B6Geo<G>::BYTES; }
+template <class G>
+static int b6t_refresh(nf_ctx *ctx, const nf_flow_desc *desc) {
+  if (ctx->b6t_gen == ctx->wimg_gen) return NF_OK;
+  using B = B6TGeo<G>;
+  const int nimg = 2 * desc->nlayers * 2;
+  constexpr long PER = 2 * G::CB * 2 * B::R3 + 2 * G::H2B * 2 * B::R2 + 2 * G::H1B * 2 * B::R1;
+  const long total = (long)nimg * PER;
+  ProfScope ps(ctx, "pack_weights");
+  hipLaunchKernelGGL((k_b6t_from_images<G>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, nimg, (const float *)ctx->wimg,
+                     (unsigned char *)ctx->wimg + b6t_offset_bytes<G>(desc));
+  NF_HIP(hipGetLastError());
+  ctx->b6t_gen = ctx->wimg_gen;
+  return NF_OK;
 }
 
 // the bf16-triple images of the chain kernels that use the six-term products (B6), rebuilt from the fp32 images when those
@@ -1979,6 +2144,7 @@ int nf_affine_bwd_all(nf_ctx *ctx, const nf_flow_desc *desc, float *y, float *yb
   if (!size || !ctx->wimg || desc->n_hidden != 2) return NF_ERR_UNSUPPORTED;
   BwdAllArgs aa;
   aa.wimg = (const float *)ctx->wimg;
+  aa.wimg_b6t = nullptr;
   aa.trace = (long long *)ctx->trace;
   aa.d = desc->d;
   aa.ncoup = 2 * desc->nlayers;
@@ -2014,39 +2180,56 @@ size_t nf_affine_stash_floats(const nf_flow_desc *desc, long N) {
 bool nf_affine_stash_pays(const nf_flow_desc *desc) { return geo_size(desc) == NetGeo<1, 2, 2, 1>::SIZE; }
 
 template <class G, bool FULL, bool INVD = false>
-static int launch_bwd_stashed_v(nf_ctx *ctx, const BwdAllArgs &aa, float *stash, float *ybar, const float *lbar, float lbar_const,
-                                float *slab, long slab_stride, int grid) {
+static int launch_bwd_stashed_v(nf_ctx *ctx, const BwdAllArgs &aa0, float *stash, float *ybar, const float *lbar, float lbar_const,
+                                float *slab, long slab_stride, int grid, const nf_flow_desc *desc = nullptr) {
   const size_t lds = BwdStashLds<G>::BYTES;
   static AttrOnce attr_once;  // once per device
   NF_TRY(attr_once.run(ctx->device, [&]() -> int {
     NF_HIP(hipFuncSetAttribute((const void *)k_affine_bwd_stashed<G, FULL, INVD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NF_HIP(hipFuncSetAttribute((const void *)k_affine_bwd_stashed<G, FULL, INVD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return NF_OK;
   }));
+  // NF_BWD_ONE_WAVE_B6=1 (with NF_BWD_NO_PAIR=1 for hidden 33-64): every GEMM of the one-wave kernel on the bf16 matrix cores
+  static const bool sb6 = std::getenv("NF_BWD_ONE_WAVE_B6") != nullptr;
+  BwdAllArgs aa = aa0;
   ProfScope ps(ctx, INVD ? "affine_bwd_inv" : "affine_bwd");
-  hipLaunchKernelGGL((k_affine_bwd_stashed<G, FULL, INVD>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, aa, stash, ybar, lbar,
-                     lbar_const, slab, slab_stride);
+  if (sb6 && desc) {
+    NF_TRY(b6t_refresh<G>(ctx, desc));
+    aa.wimg_b6t = (const unsigned char *)ctx->wimg + b6t_offset_bytes<G>(desc);
+    hipLaunchKernelGGL((k_affine_bwd_stashed<G, FULL, INVD, true>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, aa, stash, ybar, lbar,
+                       lbar_const, slab, slab_stride);
+  } else
+    hipLaunchKernelGGL((k_affine_bwd_stashed<G, FULL, INVD>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, aa, stash, ybar, lbar,
+                       lbar_const, slab, slab_stride);
   return (int)hipGetLastError();
 }
 
-template <class G, bool FULL, bool INVD, bool SLIM>
-static int launch_bwd_pair_v(nf_ctx *ctx, const BwdAllArgs &aa, float *stash, float *ybar, const float *lbar, float lbar_const,
-                             float *slab, long slab_stride, int grid) {
-  const size_t lds = BwdPairLds<G>::BYTES;
+template <class G, bool FULL, bool INVD, bool SLIM, bool PB6>
+static int launch_bwd_pair_v(nf_ctx *ctx, const nf_flow_desc *desc, BwdAllArgs aa, float *stash, float *ybar, const float *lbar,
+                             float lbar_const, float *slab, long slab_stride, int grid) {
+  const size_t lds = BwdPairLds<G, PB6>::BYTES;
   static AttrOnce attr_once;  // once per device
   NF_TRY(attr_once.run(ctx->device, [&]() -> int {
-    NF_HIP(hipFuncSetAttribute((const void *)k_affine_bwd_pair<G, FULL, INVD, SLIM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NF_HIP(hipFuncSetAttribute((const void *)k_affine_bwd_pair<G, FULL, INVD, SLIM, PB6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return NF_OK;
   }));
+  if (PB6) {
+    NF_TRY(b6t_refresh<G>(ctx, desc));
+    aa.wimg_b6t = (const unsigned char *)ctx->wimg + b6t_offset_bytes<G>(desc);
+  }
   ProfScope ps(ctx, INVD ? "affine_bwd_inv" : "affine_bwd");
-  hipLaunchKernelGGL((k_affine_bwd_pair<G, FULL, INVD, SLIM>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, aa, stash, ybar, lbar,
+  hipLaunchKernelGGL((k_affine_bwd_pair<G, FULL, INVD, SLIM, PB6>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, aa, stash, ybar, lbar,
                      lbar_const, slab, slab_stride);
   return (int)hipGetLastError();
 }
+// NF_BWD_FP32=1: the A/B switch back to fp32-MFMA dX GEMMs in the pair kernel's producer
 template <class G, bool FULL, bool INVD>
-static int launch_bwd_pair(nf_ctx *ctx, const BwdAllArgs &aa, float *stash, float *ybar, const float *lbar, float lbar_const,
-                           float *slab, long slab_stride, int grid) {
-  return stash_slim(G::SIZE) ? launch_bwd_pair_v<G, FULL, INVD, true>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid)
-                             : launch_bwd_pair_v<G, FULL, INVD, false>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid);
+static int launch_bwd_pair(nf_ctx *ctx, const nf_flow_desc *desc, const BwdAllArgs &aa, float *stash, float *ybar, const float *lbar,
+                           float lbar_const, float *slab, long slab_stride, int grid) {
+  static const bool fp32 = std::getenv("NF_BWD_FP32") != nullptr;
+  if (stash_slim(G::SIZE)) return launch_bwd_pair_v<G, FULL, INVD, true, false>(ctx, desc, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid);
+  return fp32 ? launch_bwd_pair_v<G, FULL, INVD, false, false>(ctx, desc, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid)
+              : launch_bwd_pair_v<G, FULL, INVD, false, true>(ctx, desc, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid);
 }
 
 // reverse pass of all couplings from the stash nf_affine_chain_elbo(..., stash) left (same slab layout as
@@ -2057,6 +2240,7 @@ int nf_affine_bwd_stashed(nf_ctx *ctx, const nf_flow_desc *desc, float *stash, f
   if (!size || !ctx->wimg || desc->n_hidden != 2 || !stash) return NF_ERR_UNSUPPORTED;
   BwdAllArgs aa;
   aa.wimg = (const float *)ctx->wimg;
+  aa.wimg_b6t = nullptr;
   aa.trace = (long long *)ctx->trace;
   aa.d = desc->d;
   aa.ncoup = 2 * desc->nlayers;
@@ -2069,22 +2253,22 @@ int nf_affine_bwd_stashed(nf_ctx *ctx, const nf_flow_desc *desc, float *stash, f
   if (h64 && !no_pair) {
     using GP = NetGeo<1, 2, 2, 1>;
     if (inv_dir)
-      return full ? launch_bwd_pair<GP, true, true>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid)
-                  : launch_bwd_pair<GP, false, true>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid);
-    return full ? launch_bwd_pair<GP, true, false>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid)
-                : launch_bwd_pair<GP, false, false>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid);
+      return full ? launch_bwd_pair<GP, true, true>(ctx, desc, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid)
+                  : launch_bwd_pair<GP, false, true>(ctx, desc, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid);
+    return full ? launch_bwd_pair<GP, true, false>(ctx, desc, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid)
+                : launch_bwd_pair<GP, false, false>(ctx, desc, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid);
   }
   if (inv_dir) {  // forward-KL training: the stash of the inverse chain (nf_affine_chain(inverse, stash))
     if (h64)
-      return full ? launch_bwd_stashed_v<NetGeo<1, 2, 2, 1>, true, true>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid)
-                  : launch_bwd_stashed_v<NetGeo<1, 2, 2, 1>, false, true>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid);
-    return launch_bwd_stashed_v<NetGeo<1, 1, 1, 1>, false, true>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid);
+      return full ? launch_bwd_stashed_v<NetGeo<1, 2, 2, 1>, true, true>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid, desc)
+                  : launch_bwd_stashed_v<NetGeo<1, 2, 2, 1>, false, true>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid, desc);
+    return launch_bwd_stashed_v<NetGeo<1, 1, 1, 1>, false, true>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid, desc);
   }
   if (h64)
-    return full ? launch_bwd_stashed_v<NetGeo<1, 2, 2, 1>, true>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid)
-                : launch_bwd_stashed_v<NetGeo<1, 2, 2, 1>, false>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid);
-  return full ? launch_bwd_stashed_v<NetGeo<1, 1, 1, 1>, true>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid)
-              : launch_bwd_stashed_v<NetGeo<1, 1, 1, 1>, false>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid);
+    return full ? launch_bwd_stashed_v<NetGeo<1, 2, 2, 1>, true>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid, desc)
+                : launch_bwd_stashed_v<NetGeo<1, 2, 2, 1>, false>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid, desc);
+  return full ? launch_bwd_stashed_v<NetGeo<1, 1, 1, 1>, true>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid, desc)
+              : launch_bwd_stashed_v<NetGeo<1, 1, 1, 1>, false>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid, desc);
 }
 
 bool nf_affine_supported(const nf_flow_desc *desc) {

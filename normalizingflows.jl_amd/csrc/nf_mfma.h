@@ -592,20 +592,20 @@ typedef unsigned nf_u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 nf_bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ void nf_split8(const float (&v)[8], nf_u32x4 &h, nf_u32x4 &m, nf_u32x4 &l) {
-  unsigned hb[8], mb[8], lb[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const unsigned xb = __float_as_uint(v[j]);
-    const float r1 = v[j] - __uint_as_float(xb & 0xFFFF0000u);  // exact
-    const unsigned rb = __float_as_uint(r1);
-    const float lo = r1 - __uint_as_float(rb & 0xFFFF0000u);    // exact, at most 8 significant bits
-    hb[j] = xb; mb[j] = rb; lb[j] = __float_as_uint(lo);
-  }
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {  // dword p = (upper half of value 2p + 1) : (upper half of value 2p)
-    h[p] = __builtin_amdgcn_perm(hb[2 * p + 1], hb[2 * p], 0x07060302u);
-    m[p] = __builtin_amdgcn_perm(mb[2 * p + 1], mb[2 * p], 0x07060302u);
-    l[p] = __builtin_amdgcn_perm(lb[2 * p + 1], lb[2 * p], 0x07060302u);
+  for (int p = 0; p < 4; ++p) {  // two values -> one dword per component: (upper half of value 2p + 1) : (upper half of value 2p)
+    const unsigned x0 = __float_as_uint(v[2 * p]), x1 = __float_as_uint(v[2 * p + 1]);
+    const float r0 = v[2 * p] - __uint_as_float(x0 & 0xFFFF0000u);      // exact
+    const float r1 = v[2 * p + 1] - __uint_as_float(x1 & 0xFFFF0000u);
+    const unsigned q0 = __float_as_uint(r0), q1 = __float_as_uint(r1);
+    const float l0 = r0 - __uint_as_float(q0 & 0xFFFF0000u);            // exact, at most 8 significant bits
+    const float l1 = r1 - __uint_as_float(q1 & 0xFFFF0000u);
+    h[p] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+    m[p] = __builtin_amdgcn_perm(q1, q0, 0x07060302u);
+    l[p] = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
+#ifdef NF_SPLIT_PINNED
+    __builtin_amdgcn_sched_barrier(0);  // (a pair at a time: 6 temporaries instead of 24)
+#endif
   }
 }
 __device__ __forceinline__ f32x16 nf_mfma_bf16(nf_u32x4 a, nf_u32x4 b, f32x16 c) {
@@ -666,6 +666,60 @@ __device__ __forceinline__ void dense_fwd_b6(const nf_u32x4 *__restrict__ w, con
     out[ob] = nf_mfma_bf16(ac[1], xh, out[ob]); sj(12 * u + 6); sj(12 * u + 7);
     out[ob] = nf_mfma_bf16(ac[0], xm, out[ob]); sj(12 * u + 8); sj(12 * u + 9);
     out[ob] = nf_mfma_bf16(ac[0], xh, out[ob]); sj(12 * u + 10); sj(12 * u + 11);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// The transposed counterpart for the dX GEMMs of the reverse pass (din = W^T delta): rows = the layer's INPUT features, the
+// k-groups run over its OUTPUT features, in the order the cotangent's C-layout registers hold them (same mapping as above).
+// Per layer [k-group][component][half][row][8 bf16]; no biases.  T3 serves dX3 (rows: a2 features), T2 dX2, T1 dX1.
+template <class G>
+struct B6TGeo {
+  static constexpr int R3 = 32 * G::H2B, R2 = 32 * G::H1B, R1 = 32 * G::MB;  // rows per layer
+  static constexpr int T3 = 0;
+  static constexpr int T2 = T3 + 2 * G::CB * 6 * R3;
+  static constexpr int T1 = T2 + 2 * G::H2B * 6 * R2;
+  static constexpr int U4 = T1 + 2 * G::H1B * 6 * R1;  // 16-byte units
+  static constexpr int BYTES = U4 * 16;
+};
+
+// din[ib] = W^T delta through the six-term bf16 product; `w`: the layer's part of a B6T image (LDS), ROWS = 32 * IB.
+template <int IB, int OB, class SJ = NoSideJob>
+__device__ __forceinline__ void dense_bwd_x_b6(const nf_u32x4 *__restrict__ w, const f32x16 (&delta)[OB], f32x16 (&din)[IB], int l31,
+                                               int hi, SJ sj = SJ()) {
+  constexpr int ROWS = 32 * IB, NKG = 2 * OB, NU = NKG * IB;
+#pragma unroll
+  for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) din[ib][r] = 0.f;
+  const nf_u32x4 *wl = w + hi * ROWS + l31;
+  nf_u32x4 an[3], ac[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) an[c] = wl[c * 2 * ROWS];
+  nf_u32x4 xh, xm, xl;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int kg = u / IB, ib = u % IB;
+    if (ib == 0) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = delta[kg >> 1][8 * (kg & 1) + j];
+      nf_split8(v, xh, xm, xl);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ac[c] = an[c];
+    if (u + 1 < NU) {
+      const int kg1 = (u + 1) / IB, ib1 = (u + 1) % IB;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) an[c] = wl[(kg1 * 3 + c) * 2 * ROWS + ib1 * 32];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    din[ib] = nf_mfma_bf16(ac[2], xh, din[ib]); sj(12 * u + 0); sj(12 * u + 1);
+    din[ib] = nf_mfma_bf16(ac[0], xl, din[ib]); sj(12 * u + 2); sj(12 * u + 3);
+    din[ib] = nf_mfma_bf16(ac[1], xm, din[ib]); sj(12 * u + 4); sj(12 * u + 5);
+    din[ib] = nf_mfma_bf16(ac[1], xh, din[ib]); sj(12 * u + 6); sj(12 * u + 7);
+    din[ib] = nf_mfma_bf16(ac[0], xm, din[ib]); sj(12 * u + 8); sj(12 * u + 9);
+    din[ib] = nf_mfma_bf16(ac[0], xh, din[ib]); sj(12 * u + 10); sj(12 * u + 11);
     __builtin_amdgcn_sched_barrier(0);
   }
 }

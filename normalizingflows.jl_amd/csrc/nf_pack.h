@@ -81,6 +81,47 @@ __global__ __launch_bounds__(256) void k_b6_from_images(int nimg, const float *_
   put(2, l);
 }
 
+// B6T images (nf_mfma.h, B6TGeo) from the fp32 images: the same weights, rows = a layer's inputs, k over its outputs.
+template <class G>
+__global__ __launch_bounds__(256) void k_b6t_from_images(int nimg, const float *__restrict__ wimg, unsigned char *__restrict__ out) {
+  using B = B6TGeo<G>;
+  constexpr int N3 = 2 * G::CB * 2 * B::R3, N2 = 2 * G::H2B * 2 * B::R2, N1 = 2 * G::H1B * 2 * B::R1;  // (kg, hi, row) triples
+  constexpr int PER = N3 + N2 + N1;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long)nimg * PER) return;
+  const int img = (int)(gid / PER);
+  int e = (int)(gid - (long)img * PER);
+  const float *src = wimg + (size_t)img * G::SIZE;
+  unsigned char *base = out + (size_t)img * B::BYTES;
+  int lay, rows, wsrc, S;
+  if (e < N3) { lay = B::T3; rows = B::R3; wsrc = G::W3; S = G::S3; }
+  else if (e < N3 + N2) { e -= N3; lay = B::T2; rows = B::R2; wsrc = G::W2; S = G::S2; }
+  else { e -= N3 + N2; lay = B::T1; rows = B::R1; wsrc = G::W1; S = G::S1; }
+  const int row = e % rows, hi = (e / rows) & 1, kg = e / (2 * rows);
+  unsigned short h[8], mi[8], l[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int o = 16 * kg + (j & 3) + 8 * (j >> 2) + 4 * hi;  // output feature of k-slot (kg, hi, j)
+    const float w = src[wsrc + row * S + o];                   // image element [in row][out o]
+    const unsigned xb = __float_as_uint(w);
+    const float r1 = w - __uint_as_float(xb & 0xFFFF0000u);
+    const unsigned rb = __float_as_uint(r1);
+    const float lo = r1 - __uint_as_float(rb & 0xFFFF0000u);
+    h[j] = (unsigned short)(xb >> 16);
+    mi[j] = (unsigned short)(rb >> 16);
+    l[j] = (unsigned short)(__float_as_uint(lo) >> 16);
+  }
+  auto put = [&](int comp, const unsigned short(&v)[8]) {
+    nf_u32x4 q;
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) q[pp] = (unsigned)v[2 * pp] | ((unsigned)v[2 * pp + 1] << 16);
+    reinterpret_cast<nf_u32x4 *>(base)[lay + ((kg * 3 + comp) * 2 + hi) * rows + row] = q;
+  };
+  put(0, h);
+  put(1, mi);
+  put(2, l);
+}
+
 // g[theta index] = sum over workgroup slabs of the image-layout partial gradients
 // Block 0 can also finish a deterministic sum of `nlpart` double partials into *lout (the step's loss:
 // saves a separate one-block launch in the training step).
