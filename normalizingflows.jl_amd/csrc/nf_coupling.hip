@@ -257,28 +257,29 @@ __device__ __forceinline__ void net_forward_stash(const float *__restrict__ img,
     using B = B6Geo<G>;
     const nf_u32x4 *w = reinterpret_cast<const nf_u32x4 *>(img);
     const float *bias = reinterpret_cast<const float *>(w + B::BIAS);
+    auto sjx = [&](int e) { stash_put_T<G::MB>(st, SG::XT, x, e); };
+    auto sj1 = [&](int e) { stash_put_T<G::H1B>(st, nbase + SG::A1, a1, e); };
+    auto sj2 = [&](int e) { stash_put_T<G::H2B>(st, nbase + SG::A2, a2, e); };
     if (STORE_X) {
       if (SLIM) stash_put_lane<G::MB>(st, SG::XL, x);
-      dense_fwd_b6<G::MB, G::H1B>(w + B::L1, bias + B::B1, x, a1, l31, hi, [&](int e) { stash_put_T<G::MB>(st, SG::XT, x, e); });
+      dense_fwd_b6<G::MB, G::H1B, decltype(sjx), true>(w + B::L1, bias + B::B1, x, a1, l31, hi, sjx);
     } else
-      dense_fwd_b6<G::MB, G::H1B>(w + B::L1, bias + B::B1, x, a1, l31, hi);
+      dense_fwd_b6<G::MB, G::H1B, NoSideJob, true>(w + B::L1, bias + B::B1, x, a1, l31, hi);
 #pragma unroll
     for (int b = 0; b < G::H1B; ++b) {
       nf_lrelu16(a1[b]);
       m1[b] = nf_sign_mask16(a1[b]);
     }
     if (SLIM)
-      dense_fwd_b6<G::H1B, G::H2B>(w + B::L2, bias + B::B2, a1, a2, l31, hi);
+      dense_fwd_b6<G::H1B, G::H2B, NoSideJob, true>(w + B::L2, bias + B::B2, a1, a2, l31, hi);
     else
-      dense_fwd_b6<G::H1B, G::H2B>(w + B::L2, bias + B::B2, a1, a2, l31, hi,
-                                   [&](int e) { stash_put_T<G::H1B>(st, nbase + SG::A1, a1, e); });
+      dense_fwd_b6<G::H1B, G::H2B, decltype(sj1), true>(w + B::L2, bias + B::B2, a1, a2, l31, hi, sj1);
 #pragma unroll
     for (int b = 0; b < G::H2B; ++b) {
       nf_lrelu16(a2[b]);
       m2[b] = nf_sign_mask16(a2[b]);
     }
-    dense_fwd_b6<G::H2B, G::CB>(w + B::L3, bias + B::B3, a2, out, l31, hi,
-                                [&](int e) { stash_put_T<G::H2B>(st, nbase + SG::A2, a2, e); });
+    dense_fwd_b6<G::H2B, G::CB, decltype(sj2), true>(w + B::L3, bias + B::B3, a2, out, l31, hi, sj2);
     const u32x4 mkb = {m1[0], m1[1], m2[0], m2[1]};
     nf_buffer_store_b128(mkb, st.rs, (hi * 32 + l31) * 16, (nbase + SG::MSK) * 4);
     return;

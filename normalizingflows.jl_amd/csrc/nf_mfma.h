@@ -629,7 +629,9 @@ struct B6Geo {
 // out[ob] = W in + b through the six-term bf16 product.  `w`: the layer's part of a B6 image (LDS), ROWS = 32 * OB.
 // Pipeline unit = one (k-group, output block): its three A operands (12 registers) are requested one unit ahead, behind
 // the six MFMAs (192 clocks) of the unit before.
-template <int IB, int OB, class SJ = NoSideJob>
+// LEAN: no operand double buffer (the unit's three A operands are requested when the unit starts): 12 registers less, the
+// LDS latency is left to the other wave of the SIMD -- for kernels at their register wall (the stashing forward).
+template <int IB, int OB, class SJ = NoSideJob, bool LEAN = false>
 __device__ __forceinline__ void dense_fwd_b6(const nf_u32x4 *__restrict__ w, const float *__restrict__ b, const f32x16 (&in)[IB],
                                              f32x16 (&out)[OB], int l31, int hi, SJ sj = SJ()) {
   constexpr int ROWS = 32 * OB, NKG = 2 * IB, NU = NKG * OB;
@@ -639,24 +641,32 @@ __device__ __forceinline__ void dense_fwd_b6(const nf_u32x4 *__restrict__ w, con
     for (int r = 0; r < 16; ++r) out[ob][r] = b[ob * 32 + nf_row(r, hi)];
   const nf_u32x4 *wl = w + hi * ROWS + l31;  // lane part of the address; (k-group, component, block) are immediates
   nf_u32x4 an[3], ac[3];
+  if (!LEAN) {
 #pragma unroll
-  for (int c = 0; c < 3; ++c) an[c] = wl[c * 2 * ROWS];
+    for (int c = 0; c < 3; ++c) an[c] = wl[c * 2 * ROWS];
+  }
   nf_u32x4 xh, xm, xl;
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     const int kg = u / OB, ob = u % OB;
+    if (LEAN) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) ac[c] = wl[(kg * 3 + c) * 2 * ROWS + ob * 32];
+    }
     if (ob == 0) {
       float v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = in[kg >> 1][8 * (kg & 1) + j];
       nf_split8(v, xh, xm, xl);
     }
+    if (!LEAN) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) ac[c] = an[c];
-    if (u + 1 < NU) {
-      const int kg1 = (u + 1) / OB, ob1 = (u + 1) % OB;
+      for (int c = 0; c < 3; ++c) ac[c] = an[c];
+      if (u + 1 < NU) {
+        const int kg1 = (u + 1) / OB, ob1 = (u + 1) % OB;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) an[c] = wl[(kg1 * 3 + c) * 2 * ROWS + ob1 * 32];
+        for (int c = 0; c < 3; ++c) an[c] = wl[(kg1 * 3 + c) * 2 * ROWS + ob1 * 32];
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     // smallest terms first: wl xh, wh xl, wm xm, wm xh, wh xm, wh xh

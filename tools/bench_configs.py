@@ -10,6 +10,8 @@ cfg5  RealNVP d=64 inverse + logdet + log q0 on 1 M samples           (loglikeli
 cfg5t the same data set, one forward-KL TRAINING step (value + gradient of -loglikelihood, Adam)
 cfg2c cfg 2 with the target as an arbitrary torch `logp` closure: nf_flow_fwd_keep + torch autograd of logp + nf_flow_bwd_kept
       (the path every user-defined target takes), next to the built-in-target step on the same flow
+f64   Float64 coupling flows (scalar MLP, one thread per sample): the reference's own Float64 test shapes, timed
+fwd   forward-only elbo_batch(rng, ...) evaluation of cfg 2 / cfg 3 (no gradient)
 gen   the GENERAL coupling kernels (nf_generic64.hip: one thread per sample, scalar loops, atomics) on a shape the MFMA
       kernels do not build: NSF d=32, hidden [64,64] (the reference's docstring example nsf(q0, [64,64], 8, 3.0, 6),
       src/flows/neuralspline.jl:215), K=8, batch 131072 -- so that the cost of falling off the MFMA path is on record
@@ -171,6 +173,36 @@ def main():
         res["gen_realnvp_d64_h64x3_n65536_general_kernels"] = time_step(flow, dg(64), 65536, max(3, args.steps // 10), warmup=2)
         flow = nf.realnvp(nf.MvNormal(64), (64,), 4, paramtype=torch.float32, device=dev, seed=123)  # ... and with one
         res["gen_realnvp_d64_h64x1_n65536_general_kernels"] = time_step(flow, dg(64), 65536, max(3, args.steps // 10), warmup=2)
+    if want("f64"):
+        # Float64 coupling flows (test/flow.jl:7,72 runs RealNVP and NSF in Float64): the general kernels' scalar MLP, one thread
+        # per sample -- the reference's test shape and a d = 64 case, so that the cost of this path is on record
+        flow = nf.realnvp(nf.MvNormal(5), (32, 32), 2, paramtype=torch.float64, device=dev, seed=123)
+        res["f64_realnvp_d5_h32_n65536_scalar_mlp"] = time_step(flow, dg(5, torch.float64), 65536, max(3, args.steps // 10), warmup=2)
+        flow = nf.realnvp(nf.MvNormal(64), (64, 64), 4, paramtype=torch.float64, device=dev, seed=123)
+        res["f64_realnvp_d64_h64_n65536_scalar_mlp"] = time_step(flow, dg(64, torch.float64), 65536, max(3, args.steps // 10), warmup=2)
+        flow = nf.nsf(nf.MvNormal(5), (32, 32), 10, 30.0, 2, paramtype=torch.float64, device=dev, seed=123)
+        res["f64_nsf_d5_h32_k10_n65536_scalar_mlp"] = time_step(flow, dg(5, torch.float64), 65536, max(3, args.steps // 10), warmup=2)
+    if want("fwd"):
+        # forward-only objective evaluation, elbo_batch(rng, flow, logp, n) (src/objectives/elbo.jl:93-97): SURVEY 8(d)'s
+        # "forward-only ELBO samples/s" -- draws + chain + target + mean in one launch, no stash (the B6 chain for RealNVP)
+        for name, flow, n in (("fwd_cfg2_realnvp_d64_h64_n65536", nf.realnvp(nf.MvNormal(64), (64, 64), 4, paramtype=torch.float32, device=dev, seed=123), 65536),
+                              ("fwd_cfg2_realnvp_d64_h64_n1M", nf.realnvp(nf.MvNormal(64), (64, 64), 4, paramtype=torch.float32, device=dev, seed=123), 1 << 20),
+                              ("fwd_cfg3_nsf_d32_k8_n131072", nf.nsf(nf.MvNormal(32), (32, 32), 8, 5.0, 4, paramtype=torch.float32, device=dev, seed=123), 131072)):
+            tgt = dg(flow.dist.d)
+            ctx = nf.context_for(dev)
+            val = C.c_double(0.0)
+            for i in range(5):
+                nf._lib.check(lib.nf_elbo_batch_rng(ctx.ptr, C.byref(flow.desc), C.byref(tgt.c), vp(flow.theta), n, 123, 0, i, C.byref(val)))
+            els = []
+            for r in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(20):
+                    nf._lib.check(lib.nf_elbo_batch_rng(ctx.ptr, C.byref(flow.desc), C.byref(tgt.c), vp(flow.theta), n, 123, 0, 5 + 20 * r + i, C.byref(val)))
+                torch.cuda.synchronize()
+                els.append((time.perf_counter() - t0) / 20)
+            res[name] = {"ms_per_call": round(1e3 * min(els), 4), "samples_per_s": round(n / min(els)), "elbo": val.value,
+                         "note": "each call reads the scalar back (one synchronisation per call)"}
     if not want("cfg5"):
         for k, v in res.items():
             print(k, json.dumps(v))

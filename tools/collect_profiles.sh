@@ -9,10 +9,10 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 python3 bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
-# the driver's own command line, and the same without the clock pre-warm (what rounds 1-2 reported)
+# the driver's own command line (value = the 20 steps after 5 warm-ups; *_sustained_clock beside it)
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver_cmd.json" 2>> "$OUT/bench_default.err"
-python3 bench.py --gpus 1 --steps 20 --warmup 5 --prewarm 0 --no-cpu-baseline > "$OUT/bench_driver_cmd_no_prewarm.json" 2>> "$OUT/bench_default.err"
-python3 tools/bench_ramp.py > "$OUT/step_ramp.txt" 2>&1
+# per-step time WITH the shader clock next to every step, three phases (fresh, after 3 s idle, after 50 ms idle)
+python3 tools/bench_ramp.py 200 3 > "$OUT/step_ramp_clocks.txt" 2>&1
 python3 bench.py --workload cfg3 --steps 50 --no-cpu-baseline > "$OUT/bench_cfg3.json" 2>> "$OUT/bench_default.err"
 python3 bench.py --workload cfg4 --steps 5 --warmup 2 > "$OUT/bench_cfg4_1gpu_262144.json" 2>> "$OUT/bench_default.err"
 python3 bench.py --workload cfg4 --batch 32768 --steps 10 --warmup 3 > "$OUT/bench_cfg4_shard_32768.json" 2>> "$OUT/bench_default.err"
@@ -30,6 +30,8 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C -d "$OUT/pmc_simple_$C" -o pmc --output-format csv -- python3 tools/bench_simple.py 262144 > "$OUT/pmc_simple_$C.log" 2>&1
 done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 -d "$OUT/pmc_cfg2_mfma" -o pmc --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_cfg2_mfma.log" 2>&1
+# (round 4: part of the GEMMs run on the bf16 matrix cores -- their MFMA ops are counted by a counter of their own)
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA -d "$OUT/pmc_cfg2_mfma_bf16" -o pmc --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_cfg2_mfma_bf16.log" 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 -d "$OUT/pmc_cfg3_mfma" -o pmc --output-format csv -- python3 bench.py --workload cfg3 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_cfg3_mfma.log" 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU -d "$OUT/pmc_cfg3_valu" -o pmc --output-format csv -- python3 bench.py --workload cfg3 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_cfg3_valu.log" 2>&1
 # issue-side counters of the planar / radial step (missing 5): where k_simple_step's time goes
@@ -41,6 +43,10 @@ python3 bench.py --no-cpu-baseline --split-calls > "$OUT/bench_default_split_cal
 python3 bench.py --no-cpu-baseline --graph > "$OUT/bench_default_graph.json" 2>> "$OUT/bench_default.err"
 # A/B of the cfg-2 reverse kernel on this box: one wavefront per tile (k_affine_bwd_stashed) instead of the pair kernel
 NF_BWD_NO_PAIR=1 python3 bench.py --no-cpu-baseline > "$OUT/bench_default_one_wave_per_tile.json" 2>> "$OUT/bench_default.err"
+# round 4 A/B switches: fp32 MFMAs everywhere (the round-3 arithmetic), the bf16 six-term products also in the stashing forward
+NF_BWD_FP32=1 NF_FWD_FP32=1 python3 bench.py --no-cpu-baseline > "$OUT/bench_default_fp32_mfma_everywhere.json" 2>> "$OUT/bench_default.err"
+NF_FWD_B6_STASH=1 python3 bench.py --no-cpu-baseline > "$OUT/bench_default_b6_stashing_forward.json" 2>> "$OUT/bench_default.err"
+NF_FWD_FP32=1 python3 tools/bench_configs.py --only cfg5,fwd --steps 10 > "$OUT/configs_fp32_forward.txt" 2>&1
 NF_PLANAR_NO_MFMA=1 NF_RADIAL_NO_LANE=1 python3 tools/bench_simple.py > "$OUT/simple_no_mfma.txt" 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 -d "$OUT/pmc_cfg4_mfma" -o pmc --output-format csv -- python3 bench.py --workload cfg4 --batch 32768 --steps 3 --warmup 1 --no-kernel-events > "$OUT/pmc_cfg4_mfma.log" 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
