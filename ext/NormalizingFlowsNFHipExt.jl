@@ -453,5 +453,51 @@ end
 comm_init_rank(id::Vector{UInt8}, nranks::Integer, rank::Integer) =
     check(ccall((:nf_comm_init_rank, libnfhip), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Int32, Int32), context(), id, nranks, rank))
 comm_destroy() = check(ccall((:nf_comm_destroy, libnfhip), Cint, (Ptr{Cvoid},), context()))
+# ABI v4: the step's one logical all-reduce may travel in buckets of whole couplings on a second stream (large gradients only,
+# 4 MiB by default); bytes < 0 automatic, 0 one message.  comm_bucket_count(flow): messages nf_elbo_step issues per step.
+comm_bucket_bytes!(bytes::Integer) =
+    check(ccall((:nf_ctx_set_comm_bucket_bytes, libnfhip), Cint, (Ptr{Cvoid}, Int64), context(), bytes))
+comm_bucket_count(flow::DeviceFlow) =
+    ccall((:nf_comm_bucket_count, libnfhip), Cint, (Ptr{Cvoid}, Ref{NFDesc}), context(), flow.transform.desc)
+
+# ------------------------------------------------------------------------------------------------------------
+# ABI v4: the whole iteration of src/optimize.jl:85-99 in ONE call (nf_elbo_step: draws, forward, reverse pass, [all-reduce,]
+# Adam, norm(g)) -- what bench.py times and what the Python mirror's train_flow runs for built-in targets.  The loop owns θ
+# between iterations, so it may opt in to the library's packed-weight cache (nf_ctx_set_weight_cache) and must opt out when
+# it returns; by default every nf_elbo_step packs from θ, so a θ edited or re-allocated behind the library's back is safe.
+# ------------------------------------------------------------------------------------------------------------
+weight_cache!(on::Bool) = check(ccall((:nf_ctx_set_weight_cache, libnfhip), Cint, (Ptr{Cvoid}, Int32), context(), on ? 1 : 0))
+weights_changed!() = check(ccall((:nf_ctx_weights_changed, libnfhip), Cint, (Ptr{Cvoid},), context()))
+
+function elbo_step!(θ::ROCVector{T}, m::ROCVector{T}, v::ROCVector{T}, desc::NFDesc, logp::NFHipTarget, n::Integer, rng::NFHipRNG,
+                    step::Integer, rule::Optimisers.Adam) where {T}
+    loss, gnorm = Ref{Cdouble}(0), Ref{Cdouble}(0)
+    check(ccall((:nf_elbo_step, libnfhip), Cint,
+                (Ptr{Cvoid}, Ref{NFDesc}, Ref{NFTarget}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, UInt64, UInt32,
+                 Cdouble, Cdouble, Cdouble, Cdouble, Ref{Cdouble}, Ref{Cdouble}),
+                context(), desc, c_target(logp), devptr(θ), devptr(m), devptr(v), n, rng.seed, step,
+                rule.eta, rule.beta[1], rule.beta[2], rule.epsilon, loss, gnorm))
+    return loss[], gnorm[]
+end
+
+# train_flow_fused(rng, flow, logp, n; max_iters, optimiser::Adam): the fused loop for a built-in target (same numbers as
+# train_flow over AutoNFHip; tests/test_gpu_tape.py checks that equality through the Python mirror of this function).
+function train_flow_fused(rng::NFHipRNG, flow::Bijectors.TransformedDistribution, logp::NFHipTarget, n::Integer;
+                          max_iters::Int=1000, optimiser::Optimisers.Adam=Optimisers.Adam())
+    dflow = flow isa DeviceFlow ? flow : nfhip(flow)
+    t = dflow.transform
+    θ = copy(t.θ); m = zero(θ); v = zero(θ)
+    stats = NamedTuple[]
+    weight_cache!(true)
+    try
+        for i in 1:max_iters
+            ls, gn = elbo_step!(θ, m, v, t.desc, logp, n, rng, next_stream!(rng), optimiser)
+            push!(stats, (iteration=i, loss=ls, gradient_norm=gn))
+        end
+    finally
+        weight_cache!(false)
+    end
+    return Bijectors.transformed(dflow.dist, NFHipTransform(θ, t.desc, t.re, false, t.keep)), stats, (m=m, v=v, t=max_iters)
+end
 
 end # module

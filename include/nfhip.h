@@ -316,8 +316,8 @@ int nf_sgd_update(nf_ctx *ctx, int32_t dtype, void *theta, const void *g, void *
  *       nf_ctx_weights_changed, nf_ctx_set_stream, nf_ctx_set_arena, nf_ctx_set_weight_cache itself and by every other
  *       library call that packs weights;
  *   nf_ctx_weights_changed(ctx)      -- declares an edit of theta made under that promise (clipping, a callback).
- * `train_flow` of the Python mirror (and ext/NormalizingFlowsNFHipExt.jl) opt in for the duration of their loop and
- * opt out on return. */
+ * `train_flow` of the Python mirror (objectives._optimize_fused) and `train_flow_fused` of ext/NormalizingFlowsNFHipExt.jl
+ * opt in for the duration of their loop and opt out on return. */
 int nf_elbo_step(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, void *theta,
                  void *m, void *v, int64_t N, uint64_t seed, uint32_t step, double lr,
                  double beta1, double beta2, double eps, double *loss_host, double *gnorm_host);
