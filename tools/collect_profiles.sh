@@ -16,8 +16,10 @@ python3 tools/bench_ramp.py 200 3 > "$OUT/step_ramp_clocks.txt" 2>&1
 python3 bench.py --workload cfg3 --steps 50 --no-cpu-baseline > "$OUT/bench_cfg3.json" 2>> "$OUT/bench_default.err"
 python3 bench.py --workload cfg4 --steps 5 --warmup 2 > "$OUT/bench_cfg4_1gpu_262144.json" 2>> "$OUT/bench_default.err"
 python3 bench.py --workload cfg4 --batch 32768 --steps 10 --warmup 3 > "$OUT/bench_cfg4_shard_32768.json" 2>> "$OUT/bench_default.err"
-python3 tools/bench_configs.py --steps 30 > "$OUT/configs.txt" 2>&1
+# (planar / radial BEFORE the configuration table: on one box of round 4 everything measured after the table's Float64 rows --
+# 114 ms steps of scalar fp64 -- ran 20-100 % slower for minutes, radial 397 instead of 330 us; a fresh box gave the usual numbers)
 python3 tools/bench_simple.py > "$OUT/simple.txt" 2>&1
+python3 tools/bench_configs.py --steps 30 > "$OUT/configs.txt" 2>&1
 rocprofv3 --kernel-trace --stats -d "$OUT/kt_cfg2" -o cfg2 --output-format csv -- python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-kernel-events > "$OUT/kt_cfg2.log" 2>&1
 rocprofv3 --kernel-trace --stats -d "$OUT/kt_cfg3" -o cfg3 --output-format csv -- python3 bench.py --workload cfg3 --steps 30 --warmup 5 --no-cpu-baseline --no-kernel-events > "$OUT/kt_cfg3.log" 2>&1
 rocprofv3 --kernel-trace --stats -d "$OUT/kt_cfg4" -o cfg4 --output-format csv -- python3 bench.py --workload cfg4 --batch 32768 --steps 5 --warmup 2 --no-kernel-events > "$OUT/kt_cfg4.log" 2>&1
