@@ -1071,23 +1071,6 @@ __device__ __forceinline__ void dw_accumulate_reg(const float (&at)[IB][16], con
 // ARE the lane's eight k-values of group g, and the delta reads are the ones the fp32 form issues.  Both operands are split
 // here (8 values -> 3 x 4 registers each); 12 bf16 MFMAs of 32 clocks replace 16 fp32 ones of 64 per (ib, ob) block pair.
 // The bias gradient stays the fp32 sum of the deltas.
-template <int IB>
-struct SplitT {  // the activation operand of a dW GEMM as bf16 triples: [block][sample group] x (h, m, l)
-  nf_u32x4 h[IB][2], m[IB][2], l[IB][2];
-};
-template <int IB>
-__device__ __forceinline__ void split_T(const float (&at)[IB][16], SplitT<IB> &s) {
-#pragma unroll
-  for (int ib = 0; ib < IB; ++ib)
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = at[ib][8 * g + j];
-      nf_split8(v, s.h[ib][g], s.m[ib][g], s.l[ib][g]);
-      __builtin_amdgcn_sched_barrier(0);  // one split at a time: interleaved, their temporaries (3 x 8 each) spill the accumulators
-    }
-}
 // The activation operand arrives already split (split_T, done by the consumer while it waits for the producer's delta tile:
 // 48 registers per 32-feature block pair instead of 32 fp32 + the splits of the group in flight); one delta block's eight
 // values and their split are live at a time, the next unit's delta values are requested behind the current unit's MFMAs.
@@ -1445,9 +1428,15 @@ __global__ __launch_bounds__(256, 1) void k_affine_bwd_stashed(BwdAllArgs aa, fl
 // PB6 (round 4): the producer's three dX GEMMs on the bf16 matrix cores (dense_bwd_x_b6); the LDS then holds the net's
 // B6T image instead of the fp32 one -- nobody else reads weights in this kernel (the consumer contracts activations with
 // deltas), except the SLIM stash's a1 recompute, which therefore keeps the fp32 image.
-template <class G, bool PB6 = false>
+// DW6 (with PB6): the consumer's dW GEMMs on the bf16 cores as well.  The producer splits every cotangent once (it needs the
+// triples for its own dX GEMM), leaves them in LDS transposed (split_to_lds) instead of the fp32 tile, and the consumer splits
+// only the stashed activations.  Two triple buffers per pair, used alternately (d3 | d2 | d1 | next d3 | ...): a buffer is
+// rewritten two barriers after the GEMM that read it.
+template <class G, bool PB6 = false, bool DW6 = false>
 struct BwdPairLds {
-  static constexpr int D3 = 0, D2 = D3 + G::CB * 32 * NF_TS, D1 = D2 + G::H2B * 32 * NF_TS, PAIR = D1 + G::H1B * 32 * NF_TS;
+  static_assert(!DW6 || (PB6 && G::CB <= 2 && G::H1B <= 2 && G::H2B <= 2), "triple buffers hold two blocks");
+  static constexpr int D3 = 0, D2 = D3 + G::CB * 32 * NF_TS, D1 = D2 + G::H2B * 32 * NF_TS;
+  static constexpr int PAIR = DW6 ? 2 * D6_BUF / 4 : D1 + G::H1B * 32 * NF_TS;
   static constexpr int PAIRS = 4;
   static constexpr int IMG = PB6 ? B6TGeo<G>::BYTES / 4 : G::SIZE;  // floats of the staged weight image
   static constexpr int FLOATS = (IMG + PAIRS * PAIR) > PAIRS * G::SIZE ? (IMG + PAIRS * PAIR) : PAIRS * G::SIZE;
@@ -1457,13 +1446,14 @@ struct BwdPairLds {
 // FULL: d = 64 and N a multiple of the tile (no sample / feature masks).  INVD: reverse pass of the INVERSE coupling
 // (forward-KL training; algebra of bwd_tile_stashed: phase S first, the UV slot holds w1).  live: this pair has a tile in
 // this round of the workgroup's tile loop -- a pair without one only keeps the barrier count.
-template <class G, bool PHASE_S, bool FULL, bool INVD, bool SLIM, bool PB6 = false>
+template <class G, bool PHASE_S, bool FULL, bool INVD, bool SLIM, bool PB6 = false, bool DW6 = false>
 __device__ __forceinline__ void pair_produce(const CouplingArgs &a, const float *__restrict__ img, float *__restrict__ sp,
                                              StashFirst<G> &f, float *stash, int k, int ncoup, float *__restrict__ ybar,
                                              const float *__restrict__ lbar, float lbar_const, long tile, long next_tile,
-                                             bool live, int l31, int hi, long long *tr = nullptr) {
+                                             bool live, int l31, int hi, int par, long long *tr = nullptr) {
   using SG = StashGeo<G, SLIM>;
-  using L = BwdPairLds<G, PB6>;
+  using L = BwdPairLds<G, PB6, DW6>;
+  char *bufa = reinterpret_cast<char *>(sp) + par * D6_BUF, *bufb = reinterpret_cast<char *>(sp) + (par ^ 1) * D6_BUF;  // DW6
   if (!live) {
     __syncthreads();
     __syncthreads();
@@ -1508,7 +1498,13 @@ __device__ __forceinline__ void pair_produce(const CouplingArgs &a, const float 
         d3[b][r] = ok ? (gv * f.uv[b][r] + lb) * (1.f - sv * sv) : 0.f;  // S-bar through tanh
       }
     }
-  tile_to_scratch<G::CB>(sp + L::D3, d3, l31, hi);
+  SplitC<DW6 ? G::CB : 1> s3;
+  if constexpr (DW6) {
+    split_C<G::CB>(d3, s3);
+    split_to_lds<G::CB>(bufa, s3, l31, hi);
+  } else {
+    tile_to_scratch<G::CB>(sp + L::D3, d3, l31, hi);
+  }
   unsigned m1[G::H1B], m2[G::H2B];
 #pragma unroll
   for (int b = 0; b < G::H1B; ++b) m1[b] = mk[b];
@@ -1519,24 +1515,40 @@ __device__ __forceinline__ void pair_produce(const CouplingArgs &a, const float 
   NF_TS_STAMP(2);
   f32x16 d2[G::H2B];
   const nf_u32x4 *wt = reinterpret_cast<const nf_u32x4 *>(img);  // PB6: the staged image is the net's B6T image
-  if constexpr (PB6) dense_bwd_x_b6<G::H2B, G::CB>(wt + B6TGeo<G>::T3, d3, d2, l31, hi);
+  if constexpr (DW6) dense_bwd_x_b6s<G::H2B, G::CB>(wt + B6TGeo<G>::T3, s3, d2, l31, hi);
+  else if constexpr (PB6) dense_bwd_x_b6<G::H2B, G::CB>(wt + B6TGeo<G>::T3, d3, d2, l31, hi);
   else dense_bwd_x<G::H2B, G::CB>(img + G::W3, d3, d2, l31, hi);
   apply_lrelu_grad<G::H2B>(d2, m2);
-  tile_to_scratch<G::H2B>(sp + L::D2, d2, l31, hi);
+  SplitC<DW6 ? G::H2B : 1> s2;
+  if constexpr (DW6) {
+    split_C<G::H2B>(d2, s2);
+    split_to_lds<G::H2B>(bufb, s2, l31, hi);
+
+  } else {
+    tile_to_scratch<G::H2B>(sp + L::D2, d2, l31, hi);
+  }
   NF_TS_STAMP(3);
   __syncthreads();  // B2
   NF_TS_STAMP(4);
   f32x16 d1[G::H1B];
-  if constexpr (PB6) dense_bwd_x_b6<G::H1B, G::H2B>(wt + B6TGeo<G>::T2, d2, d1, l31, hi);
+  if constexpr (DW6) dense_bwd_x_b6s<G::H1B, G::H2B>(wt + B6TGeo<G>::T2, s2, d1, l31, hi);
+  else if constexpr (PB6) dense_bwd_x_b6<G::H1B, G::H2B>(wt + B6TGeo<G>::T2, d2, d1, l31, hi);
   else dense_bwd_x<G::H1B, G::H2B>(img + G::W2, d2, d1, l31, hi);
   apply_lrelu_grad<G::H1B>(d1, m1);
-  tile_to_scratch<G::H1B>(sp + L::D1, d1, l31, hi);
+  SplitC<DW6 ? G::H1B : 1> s1;
+  if constexpr (DW6) {
+    split_C<G::H1B>(d1, s1);
+    split_to_lds<G::H1B>(bufa, s1, l31, hi);
+  } else {
+    tile_to_scratch<G::H1B>(sp + L::D1, d1, l31, hi);
+  }
   NF_TS_STAMP(5);
   __syncthreads();  // B3
   NF_TS_STAMP(6);
   if (PHASE_S && next_tile >= 0) stash_issue_first<G, SLIM>(f, stash, k, ncoup, next_tile, l31, hi);
   f32x16 g2[G::MB];
-  if constexpr (PB6) dense_bwd_x_b6<G::MB, G::H1B>(wt + B6TGeo<G>::T1, d1, g2, l31, hi);
+  if constexpr (DW6) dense_bwd_x_b6s<G::MB, G::H1B>(wt + B6TGeo<G>::T1, s1, g2, l31, hi);
+  else if constexpr (PB6) dense_bwd_x_b6<G::MB, G::H1B>(wt + B6TGeo<G>::T1, d1, g2, l31, hi);
   else dense_bwd_x<G::MB, G::H1B>(img + G::W1, d1, g2, l31, hi);
 #pragma unroll
   for (int b = 0; b < G::MB; ++b)
@@ -1547,12 +1559,14 @@ __device__ __forceinline__ void pair_produce(const CouplingArgs &a, const float 
 
 // (Measured and removed: dW1 of a tile moved in front of the NEXT tile's first barrier, where the producer issues no
 // MFMAs -- 374-379 us against 366 in one process; and the producer's next-unit operands requested behind B3 -- 370.)
-template <class G, bool SLIM, bool PB6 = false>
-__device__ __forceinline__ void pair_consume(const float *__restrict__ img, const float *__restrict__ sp, BwdAcc<G> &acc, float *stash,
-                                             int k, int ncoup, long tile, bool is_s, bool live, int l31, int hi,
+template <class G, bool SLIM, bool PB6 = false, bool DW6 = false>
+// (`sp` is NOT __restrict__: the DW6 triple buffers are rewritten by the producer between this wave's GEMMs, and through a
+// const restrict pointer hipcc reuses the registers of an earlier read of the same address across the barriers.)
+__device__ __forceinline__ void pair_consume(const float *__restrict__ img, const float *sp, BwdAcc<G> &acc, float *stash,
+                                             int k, int ncoup, long tile, bool is_s, bool live, int l31, int hi, int par,
                                              long long *tr = nullptr) {
   using SG = StashGeo<G, SLIM>;
-  using L = BwdPairLds<G, PB6>;
+  using L = BwdPairLds<G, PB6, DW6>;
   if (!live) {
     __syncthreads();
     __syncthreads();
@@ -1563,7 +1577,45 @@ __device__ __forceinline__ void pair_consume(const float *__restrict__ img, cons
   const int nbase = SG::NET0 + (is_s ? 0 : SG::NETSZ);
   const StashIO st = make_stash_io(stash, tile * ncoup + k, SG::SIZE, true, l31, hi);
   const int vT = (l31 * 32 + hi * 16) * 4;
-  if constexpr (SLIM) {
+  if constexpr (DW6) {
+    const char *bufa = reinterpret_cast<const char *>(sp) + par * D6_BUF, *bufb = reinterpret_cast<const char *>(sp) + (par ^ 1) * D6_BUF;
+    float a1t[G::H1B][16];
+    {
+      // (Measured and removed: the NEXT tile's a2 requested behind B3 -- 32 more registers across the loop's back edge, which
+      // hipcc spills to scratch right behind the loads: 428 us per launch against 345.)
+      SplitT<G::H2B> a2s;
+      {
+        float a2t[G::H2B][16];
+        stash_get_T<G::H2B>(st, nbase + SG::A2, vT, a2t);
+        split_T<G::H2B>(a2t, a2s);
+      }
+      stash_get_T<G::H1B>(st, nbase + SG::A1, vT, a1t);  // in flight behind dW3
+      NF_TS_STAMP(1);
+      __syncthreads();  // B1
+      NF_TS_STAMP(2);
+      dw_accumulate_t6<G::H2B, G::CB>(a2s, bufa, acc.w3, acc.b3, l31, hi);
+    }
+    float x2t[G::MB][16];
+    {
+      SplitT<G::H1B> a1s;
+      split_T<G::H1B>(a1t, a1s);
+      stash_get_T<G::MB>(st, SG::XT, vT, x2t);
+      NF_TS_STAMP(3);
+      __syncthreads();  // B2
+      NF_TS_STAMP(4);
+      dw_accumulate_t6<G::H1B, G::H2B>(a1s, bufb, acc.w2, acc.b2, l31, hi);
+    }
+    {
+      SplitT<G::MB> x2s;
+      split_T<G::MB>(x2t, x2s);
+      NF_TS_STAMP(5);
+      __syncthreads();  // B3
+      NF_TS_STAMP(6);
+      dw_accumulate_t6<G::MB, G::H1B>(x2s, bufa, acc.w1, acc.b1, l31, hi);
+      NF_TS_STAMP(7);
+    }
+    return;  // (the dW1 block below belongs to the two fp32-tile forms)
+  } else if constexpr (SLIM) {
     // a1 is not in the stash: rebuilt here, in this wave's MFMA-free prologue (the producer is in its own: operand loads,
     // element-wise stage, d3 -> LDS), from x2 in the C layout and the W1 rows of the staged image
     float a1t[G::H1B][16];
@@ -1661,7 +1713,7 @@ __device__ __forceinline__ void pair_slab_write(const float *__restrict__ lds, f
 // never count against the other role's 256 registers (inside the coupling loop both are live across either branch).
 // Every wave executes the same barriers: per phase 1 (image staged) + 3 per round of the tile loop + 3 (tiles done,
 // folded, slab written); the tile loop runs as many rounds as the workgroup's first pair needs.
-template <class G, bool FULL, bool INVD, bool SLIM, bool PB6 = false>
+template <class G, bool FULL, bool INVD, bool SLIM, bool PB6 = false, bool DW6 = false>
 __global__ __launch_bounds__(512) void k_affine_bwd_pair(BwdAllArgs aa, float *stash, float *__restrict__ ybar,
                                                          const float *__restrict__ lbar, float lbar_const,
                                                          float *__restrict__ slab, long slab_stride) {
@@ -1672,7 +1724,7 @@ __global__ __launch_bounds__(512) void k_affine_bwd_pair(BwdAllArgs aa, float *s
   const int pair = wave & 3, role = wave >> 2;  // waves p and p + 4 sit on the same SIMD; role 0 produces, 1 consumes
   const int l31 = lane & 31, hi = lane >> 5;
   static_assert(!(SLIM && PB6), "the SLIM stash's a1 recompute reads the fp32 image");
-  using PL = BwdPairLds<G, PB6>;
+  using PL = BwdPairLds<G, PB6, DW6>;
   using BT = B6TGeo<G>;
   float *sp = lds + PL::IMG + pair * PL::PAIR;
   auto stage_image = [&](int k, bool is_s) {  // the net's weight image of this phase -> LDS (fp32, or B6T for the producer's dX GEMMs)
@@ -1715,8 +1767,8 @@ __global__ __launch_bounds__(512) void k_affine_bwd_pair(BwdAllArgs aa, float *s
 #else
           long long *tr = nullptr;
 #endif
-          if (!is_s) pair_produce<G, false, FULL, INVD, SLIM, PB6>(a, img, sp, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, tile < ntiles, l31, hi, tr);
-          else pair_produce<G, true, FULL, INVD, SLIM, PB6>(a, img, sp, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, tile < ntiles, l31, hi, tr);
+          if (!is_s) pair_produce<G, false, FULL, INVD, SLIM, PB6, DW6>(a, img, sp, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, tile < ntiles, l31, hi, it & 1, tr);
+          else pair_produce<G, true, FULL, INVD, SLIM, PB6, DW6>(a, img, sp, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, tile < ntiles, l31, hi, it & 1, tr);
         }
         __syncthreads();  // every wave is done with the weight image and the delta tiles
         // s and u of the next phase-S's first tile fly behind the fold, the slab write and the staging of the next image
@@ -1751,7 +1803,7 @@ __global__ __launch_bounds__(512) void k_affine_bwd_pair(BwdAllArgs aa, float *s
 #else
           long long *tr = nullptr;
 #endif
-          pair_consume<G, SLIM, PB6>(img, sp, acc, stash, k, aa.ncoup, tile, is_s, tile < ntiles, l31, hi, tr);
+          pair_consume<G, SLIM, PB6, DW6>(img, sp, acc, stash, k, aa.ncoup, tile, is_s, tile < ntiles, l31, hi, it & 1, tr);
         }
         __syncthreads();  // every wave is done with the weight image and the delta tiles
         {
@@ -2205,13 +2257,13 @@ static int launch_bwd_stashed_v(nf_ctx *ctx, const BwdAllArgs &aa0, float *stash
   return (int)hipGetLastError();
 }
 
-template <class G, bool FULL, bool INVD, bool SLIM, bool PB6>
+template <class G, bool FULL, bool INVD, bool SLIM, bool PB6, bool DW6 = false>
 static int launch_bwd_pair_v(nf_ctx *ctx, const nf_flow_desc *desc, BwdAllArgs aa, float *stash, float *ybar, const float *lbar,
                              float lbar_const, float *slab, long slab_stride, int grid) {
-  const size_t lds = BwdPairLds<G, PB6>::BYTES;
+  const size_t lds = BwdPairLds<G, PB6, DW6>::BYTES;
   static AttrOnce attr_once;  // once per device
   NF_TRY(attr_once.run(ctx->device, [&]() -> int {
-    NF_HIP(hipFuncSetAttribute((const void *)k_affine_bwd_pair<G, FULL, INVD, SLIM, PB6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NF_HIP(hipFuncSetAttribute((const void *)k_affine_bwd_pair<G, FULL, INVD, SLIM, PB6, DW6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return NF_OK;
   }));
   if (PB6) {
@@ -2219,18 +2271,20 @@ static int launch_bwd_pair_v(nf_ctx *ctx, const nf_flow_desc *desc, BwdAllArgs a
     aa.wimg_b6t = (const unsigned char *)ctx->wimg + b6t_offset_bytes<G>(desc);
   }
   ProfScope ps(ctx, INVD ? "affine_bwd_inv" : "affine_bwd");
-  hipLaunchKernelGGL((k_affine_bwd_pair<G, FULL, INVD, SLIM, PB6>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, aa, stash, ybar, lbar,
+  hipLaunchKernelGGL((k_affine_bwd_pair<G, FULL, INVD, SLIM, PB6, DW6>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, aa, stash, ybar, lbar,
                      lbar_const, slab, slab_stride);
   return (int)hipGetLastError();
 }
-// NF_BWD_FP32=1: the A/B switch back to fp32-MFMA dX GEMMs in the pair kernel's producer
+// NF_BWD_FP32=1: the A/B switch back to fp32-MFMA GEMMs in the pair kernel; NF_BWD_DW_FP32=1: only the consumer's dW GEMMs
 template <class G, bool FULL, bool INVD>
 static int launch_bwd_pair(nf_ctx *ctx, const nf_flow_desc *desc, const BwdAllArgs &aa, float *stash, float *ybar, const float *lbar,
                            float lbar_const, float *slab, long slab_stride, int grid) {
   static const bool fp32 = std::getenv("NF_BWD_FP32") != nullptr;
   if (stash_slim(G::SIZE)) return launch_bwd_pair_v<G, FULL, INVD, true, false>(ctx, desc, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid);
-  return fp32 ? launch_bwd_pair_v<G, FULL, INVD, false, false>(ctx, desc, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid)
-              : launch_bwd_pair_v<G, FULL, INVD, false, true>(ctx, desc, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid);
+  static const bool dw_fp32 = std::getenv("NF_BWD_DW_FP32") != nullptr;
+  if (fp32) return launch_bwd_pair_v<G, FULL, INVD, false, false>(ctx, desc, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid);
+  return dw_fp32 ? launch_bwd_pair_v<G, FULL, INVD, false, true>(ctx, desc, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid)
+                 : launch_bwd_pair_v<G, FULL, INVD, false, true, true>(ctx, desc, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid);
 }
 
 // reverse pass of all couplings from the stash nf_affine_chain_elbo(..., stash) left (same slab layout as

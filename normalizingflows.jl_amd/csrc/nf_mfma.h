@@ -734,6 +734,155 @@ __device__ __forceinline__ void dense_bwd_x_b6(const nf_u32x4 *__restrict__ w, c
   }
 }
 
+// A C-layout tensor split ONCE into its bf16 triples, per k-group kg = 2 * block + (register >> 3): what dense_bwd_x_b6 does
+// inside its loop, kept -- the producer of the pair kernel hands the same triples to the consumer's dW GEMM through LDS.
+template <int NB>
+struct SplitC {
+  nf_u32x4 h[2 * NB], m[2 * NB], l[2 * NB];
+};
+template <int NB>
+__device__ __forceinline__ void split_C(const f32x16 (&d)[NB], SplitC<NB> &s) {
+#pragma unroll
+  for (int kg = 0; kg < 2 * NB; ++kg) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = d[kg >> 1][8 * (kg & 1) + j];
+    nf_split8(v, s.h[kg], s.m[kg], s.l[kg]);
+  }
+}
+// dense_bwd_x_b6 on a cotangent that arrives split
+template <int IB, int OB, class SJ = NoSideJob>
+__device__ __forceinline__ void dense_bwd_x_b6s(const nf_u32x4 *__restrict__ w, const SplitC<OB> &ds, f32x16 (&din)[IB], int l31,
+                                                int hi, SJ sj = SJ()) {
+  constexpr int ROWS = 32 * IB, NKG = 2 * OB, NU = NKG * IB;
+#pragma unroll
+  for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) din[ib][r] = 0.f;
+  const nf_u32x4 *wl = w + hi * ROWS + l31;
+  nf_u32x4 an[3], ac[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) an[c] = wl[c * 2 * ROWS];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int kg = u / IB, ib = u % IB;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ac[c] = an[c];
+    if (u + 1 < NU) {
+      const int kg1 = (u + 1) / IB, ib1 = (u + 1) % IB;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) an[c] = wl[(kg1 * 3 + c) * 2 * ROWS + ib1 * 32];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    din[ib] = nf_mfma_bf16(ac[2], ds.h[kg], din[ib]); sj(12 * u + 0); sj(12 * u + 1);
+    din[ib] = nf_mfma_bf16(ac[0], ds.l[kg], din[ib]); sj(12 * u + 2); sj(12 * u + 3);
+    din[ib] = nf_mfma_bf16(ac[1], ds.m[kg], din[ib]); sj(12 * u + 4); sj(12 * u + 5);
+    din[ib] = nf_mfma_bf16(ac[1], ds.h[kg], din[ib]); sj(12 * u + 6); sj(12 * u + 7);
+    din[ib] = nf_mfma_bf16(ac[0], ds.m[kg], din[ib]); sj(12 * u + 8); sj(12 * u + 9);
+    din[ib] = nf_mfma_bf16(ac[0], ds.h[kg], din[ib]); sj(12 * u + 10); sj(12 * u + 11);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// The transposed hand-over of such triples: the dW GEMM contracts over SAMPLES, so its delta operand wants lane <-> feature
+// and a lane's eight k-values = eight samples.  LDS tile of one cotangent tensor: row = feature (D6_ROW bytes: three
+// components x 64 bytes + 16 of padding -- 52 dwords, so eight consecutive rows' 16-byte reads cover the 32 banks once),
+// inside a component [sample group g][sample parity][j] x 2 bytes with sample = 2 (8 g + j) + parity: the order the T layout
+// of the stash gives the activation operand (dw_accumulate_reg_b6).  The writer holds a sample per lane and two features
+// per packed register: one ds_write_b16 for the low half, one ds_write_b16_d16_hi for the high half, no unpacking.
+constexpr int D6_ROW = 208, D6_BUF = 64 * D6_ROW;
+template <int NB>
+__device__ __forceinline__ void split_to_lds(char *__restrict__ buf, const SplitC<NB> &s, int l31, int hi) {
+  const int t = l31 >> 1;
+  char *p = buf + (4 * hi) * D6_ROW + (t >> 3) * 32 + (l31 & 1) * 16 + (t & 7) * 2;
+#pragma unroll
+  for (int kg = 0; kg < 2 * NB; ++kg)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const nf_u32x4 &v = c == 0 ? s.h[kg] : c == 1 ? s.m[kg] : s.l[kg];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int j0 = 2 * q, j1 = 2 * q + 1;
+        const int f0 = 16 * kg + (j0 & 3) + 8 * (j0 >> 2), f1 = 16 * kg + (j1 & 3) + 8 * (j1 >> 2);
+        *reinterpret_cast<unsigned short *>(p + f0 * D6_ROW + c * 64) = (unsigned short)v[q];
+        *reinterpret_cast<unsigned short *>(p + f1 * D6_ROW + c * 64) = (unsigned short)(v[q] >> 16);
+      }
+    }
+}
+
+// The activation operand of a dW GEMM (T layout of the stash: at[ib][t] = a[feature ib * 32 + l31][sample 2 t + hi]) as triples
+template <int IB>
+struct SplitT {  // the activation operand of a dW GEMM as bf16 triples: [block][sample group] x (h, m, l)
+  nf_u32x4 h[IB][2], m[IB][2], l[IB][2];
+};
+template <int IB>
+__device__ __forceinline__ void split_T(const float (&at)[IB][16], SplitT<IB> &s) {
+#pragma unroll
+  for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = at[ib][8 * g + j];
+      nf_split8(v, s.h[ib][g], s.m[ib][g], s.l[ib][g]);
+      __builtin_amdgcn_sched_barrier(0);  // one split at a time: interleaved, their temporaries (3 x 8 each) spill the accumulators
+    }
+}
+
+// Both operands arrive split: the activation from split_T, the cotangent as the bf16 triples the PRODUCER wave made for its own
+// dX GEMM and left in LDS transposed (split_to_lds, nf_mfma.h): three ds_read_b128 per (sample group, delta block) and no
+// VALU work on the cotangent at all.  The bias gradient is the sum of the triples' components: v_dot2c_f32_bf16 against
+// (1, 1) adds two bf16 values into an fp32 register per instruction.  Inline asm: with the literal as an operand hipcc 7.0's
+// __builtin_amdgcn_fdot2_f32_bf16 emits the FIRST register of a vector for all four of its elements (seen in the ISA, and as
+// NaN gradients on the device).
+__device__ __forceinline__ float nf_dot2_bf16(unsigned x, unsigned y, float acc) {
+  asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(x), "v"(y));
+  return acc;
+}
+template <int IB, int OB, bool LEAN = false>
+__device__ __forceinline__ void dw_accumulate_t6(const SplitT<IB> &as, const char *buf, f32x16 (&acc)[IB][OB],
+                                                 float (&bsum)[OB], int l31, int hi) {
+  const nf_u32x4 *pd = reinterpret_cast<const nf_u32x4 *>(buf + l31 * D6_ROW + hi * 16);
+  constexpr int NU = 2 * OB, RB = 32 * D6_ROW / 16;  // 16-byte units per block of 32 rows
+  nf_u32x4 dn[3], dc[3];
+  const unsigned ones = 0x3F803F80u;  // bf16 (1, 1)
+  if (!LEAN) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dn[c] = pd[c * 4];
+  }
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int g = u / OB, ob = u % OB;
+    if (LEAN) {  // no operand double buffer: 12 registers less, the LDS latency is left to the other wave of the SIMD
+#pragma unroll
+      for (int c = 0; c < 3; ++c) dc[c] = pd[ob * RB + c * 4 + g * 2];
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) dc[c] = dn[c];
+      if (u + 1 < NU) {
+        const int g1 = (u + 1) / OB, ob1 = (u + 1) % OB;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dn[c] = pd[ob1 * RB + c * 4 + g1 * 2];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int term = 0; term < 6; ++term)
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib) {
+        const nf_u32x4 &a = term == 0 ? as.l[ib][g] : (term == 2 || term == 3) ? as.m[ib][g] : as.h[ib][g];
+        const nf_u32x4 &d = term == 1 ? dc[2] : (term == 2 || term == 4) ? dc[1] : dc[0];
+        acc[ib][ob] = nf_mfma_bf16(a, d, acc[ib][ob]);
+        if (term * IB + ib < 6) {  // the twelve bias-sum instructions ride between the unit's first MFMAs
+          const int i0 = 2 * (term * IB + ib);
+#pragma unroll
+          for (int i = i0; i < i0 + 2; ++i) bsum[ob] = nf_dot2_bf16(dc[2 - i / 4][i % 4], ones, bsum[ob]);
+        }
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // ---- tile I/O through buffer descriptors ---------------------------------------------------
 // One descriptor per (array, tile): base = array + tile * d * 32 floats (wave-uniform), extent =
 // d * 32 floats.  Element (feature f, lane's sample) is at byte f * 128 + (lane & 31) * 4, and in

@@ -45,6 +45,22 @@ struct Wide {
   static constexpr int WAVES = 4;
   static constexpr size_t LDS_APPLY = (size_t)(2 * CHBUF + 2 * NBIAS) * sizeof(float);
   static constexpr size_t LDS_BWD = (size_t)(2 * CHBUF + NBIAS) * sizeof(float);
+  // B6 (round 4): the forward's GEMMs as six bf16 products of exactly split operands (nf_mfma.h); the streamed image is
+  // the net's B6 image (bf16 triples, [k-group][component][half][row][8]), a chunk = the two k-groups of one input block:
+  // 2 x 6 x rows x 16 bytes, contiguous.
+  using B = B6Geo<G>;
+  static constexpr int BF1 = 48 * B::R1, BF2 = 48 * B::R2, BF3 = 48 * B::R3;  // chunk sizes in floats (whole 1-KiB pieces)
+  static constexpr int BFMAX = BF1 > BF2 ? (BF1 > BF3 ? BF1 : BF3) : (BF2 > BF3 ? BF2 : BF3);
+  static constexpr size_t LDS_APPLY_B6 = (size_t)(2 * BFMAX + 2 * NBIAS) * sizeof(float);
+};
+// offsets (floats into the streamed image) and sizes of the chunks of the three layers, fp32 image or B6 image
+template <class G, bool B6>
+struct WideChunks {
+  using W = Wide<G>;
+  static constexpr int CHBUF = B6 ? W::BFMAX : W::CHBUF;
+  static constexpr int N1 = B6 ? W::BF1 : W::CF1, N2 = B6 ? W::BF2 : W::CF2, N3 = B6 ? W::BF3 : W::CF3;
+  static constexpr int O1 = B6 ? B6Geo<G>::L1 * 4 : G::W1, O2 = B6 ? B6Geo<G>::L2 * 4 : G::W2, O3 = B6 ? B6Geo<G>::L3 * 4 : G::W3;
+  static constexpr int IMG_FLOATS = B6 ? B6Geo<G>::BYTES / 4 : G::SIZE;
 };
 
 // DMA one chunk global -> LDS (buffer_load_dwordx4 ... lds): 1 KiB (64 lanes x 16 B) per
@@ -96,6 +112,45 @@ __device__ __forceinline__ void wide_fwd_chunk(const float *__restrict__ ch, con
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ob = 0; ob < OB; ++ob) out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[ob], in[t], out[ob], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// The same chunk GEMM on the bf16 matrix cores: `ch` holds the two k-groups of this input block as bf16 triples, the input
+// block is split here (16 values -> 2 x 3 x 4 registers); pipeline unit = (k-group, output block), its three A operands
+// requested one unit ahead (dense_fwd_b6 of nf_mfma.h without the bias start).
+template <int OB>
+__device__ __forceinline__ void wide_fwd_chunk_b6(const float *__restrict__ ch, const f32x16 &in, f32x16 (&out)[OB], int l31,
+                                                  int hi, const DmaJob &dma) {
+  dma.issue();
+  constexpr int ROWS = 32 * OB, NU = 2 * OB;
+  const nf_u32x4 *wl = reinterpret_cast<const nf_u32x4 *>(ch) + hi * ROWS + l31;
+  nf_u32x4 an[3], ac[3], xh, xm, xl;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) an[c] = wl[c * 2 * ROWS];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int kg = u / OB, ob = u % OB;
+    if (ob == 0) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = in[8 * kg + j];
+      nf_split8(v, xh, xm, xl);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ac[c] = an[c];
+    if (u + 1 < NU) {
+      const int kg1 = (u + 1) / OB, ob1 = (u + 1) % OB;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) an[c] = wl[(kg1 * 3 + c) * 2 * ROWS + ob1 * 32];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    out[ob] = nf_mfma_bf16(ac[2], xh, out[ob]);  // smallest terms first: wl xh, wh xl, wm xm, wm xh, wh xm, wh xh
+    out[ob] = nf_mfma_bf16(ac[0], xl, out[ob]);
+    out[ob] = nf_mfma_bf16(ac[1], xm, out[ob]);
+    out[ob] = nf_mfma_bf16(ac[1], xh, out[ob]);
+    out[ob] = nf_mfma_bf16(ac[0], xm, out[ob]);
+    out[ob] = nf_mfma_bf16(ac[0], xh, out[ob]);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -152,12 +207,12 @@ __device__ __forceinline__ void init_bias(f32x16 (&v)[NB], const float *__restri
 // Streams one net forward.  On entry the chunk (W1, rows 0..31) of `img` is resident in
 // cb[buf]; on exit the chunk (next_src, next_floats) is resident in cb[buf] (or nothing if
 // next_floats == 0).
-template <class G, class HK>
+template <class G, class HK, bool B6 = false>
 __device__ __forceinline__ void wide_net_fwd(wide_img_t img, const float *__restrict__ bias, float *cb, int &buf,
                                              wide_img_t next_img, int next_off, int next_floats,
                                              const f32x16 (&xb)[G::MB], f32x16 (&out)[G::CB], int wave, int lane, HK &hk,
                                              long long *tr = nullptr) {
-  using W = Wide<G>;
+  using C = WideChunks<G, B6>;
   const int l31 = lane & 31, hi = lane >> 5;
   f32x16 a1[G::H1B];
   init_bias<G::H1B>(a1, bias, hi);
@@ -165,10 +220,11 @@ __device__ __forceinline__ void wide_net_fwd(wide_img_t img, const float *__rest
   for (int ib = 0; ib < G::MB; ++ib) {
     DmaJob dj{img, 0, 0, cb, wave, lane};
     if (ib + 1 < G::MB)
-      dj = DmaJob{img, G::W1 + (ib + 1) * W::CF1, W::CF1, cb + (buf ^ 1) * W::CHBUF, wave, lane};
+      dj = DmaJob{img, C::O1 + (ib + 1) * C::N1, C::N1, cb + (buf ^ 1) * C::CHBUF, wave, lane};
     else
-      dj = DmaJob{img, G::W2, W::CF2, cb + (buf ^ 1) * W::CHBUF, wave, lane};
-    wide_fwd_chunk<G::H1B, G::S1>(cb + buf * W::CHBUF, xb[ib], a1, l31, hi, dj);
+      dj = DmaJob{img, C::O2, C::N2, cb + (buf ^ 1) * C::CHBUF, wave, lane};
+    if constexpr (B6) wide_fwd_chunk_b6<G::H1B>(cb + buf * C::CHBUF, xb[ib], a1, l31, hi, dj);
+    else wide_fwd_chunk<G::H1B, G::S1>(cb + buf * C::CHBUF, xb[ib], a1, l31, hi, dj);
     __syncthreads();
     buf ^= 1;
   }
@@ -184,11 +240,12 @@ __device__ __forceinline__ void wide_net_fwd(wide_img_t img, const float *__rest
   for (int ib = 0; ib < G::H1B; ++ib) {
     DmaJob dj{img, 0, 0, cb, wave, lane};
     if (ib + 1 < G::H1B)
-      dj = DmaJob{img, G::W2 + (ib + 1) * W::CF2, W::CF2, cb + (buf ^ 1) * W::CHBUF, wave, lane};
+      dj = DmaJob{img, C::O2 + (ib + 1) * C::N2, C::N2, cb + (buf ^ 1) * C::CHBUF, wave, lane};
     else
-      dj = DmaJob{img, G::W3, W::CF3, cb + (buf ^ 1) * W::CHBUF, wave, lane};
+      dj = DmaJob{img, C::O3, C::N3, cb + (buf ^ 1) * C::CHBUF, wave, lane};
     hk.l2_step(ib, a1);
-    wide_fwd_chunk<G::H2B, G::S2>(cb + buf * W::CHBUF, a1[ib], a2, l31, hi, dj);
+    if constexpr (B6) wide_fwd_chunk_b6<G::H2B>(cb + buf * C::CHBUF, a1[ib], a2, l31, hi, dj);
+    else wide_fwd_chunk<G::H2B, G::S2>(cb + buf * C::CHBUF, a1[ib], a2, l31, hi, dj);
     __syncthreads();
     buf ^= 1;
   }
@@ -203,11 +260,12 @@ __device__ __forceinline__ void wide_net_fwd(wide_img_t img, const float *__rest
   for (int ib = 0; ib < G::H2B; ++ib) {
     DmaJob dj{img, 0, 0, cb, wave, lane};
     if (ib + 1 < G::H2B)
-      dj = DmaJob{img, G::W3 + (ib + 1) * W::CF3, W::CF3, cb + (buf ^ 1) * W::CHBUF, wave, lane};
+      dj = DmaJob{img, C::O3 + (ib + 1) * C::N3, C::N3, cb + (buf ^ 1) * C::CHBUF, wave, lane};
     else if (next_floats)
-      dj = DmaJob{next_img, next_off, next_floats, cb + (buf ^ 1) * W::CHBUF, wave, lane};
+      dj = DmaJob{next_img, next_off, next_floats, cb + (buf ^ 1) * C::CHBUF, wave, lane};
     hk.l3_step(ib, a2);
-    wide_fwd_chunk<G::CB, G::S3>(cb + buf * W::CHBUF, a2[ib], out, l31, hi, dj);
+    if constexpr (B6) wide_fwd_chunk_b6<G::CB>(cb + buf * C::CHBUF, a2[ib], out, l31, hi, dj);
+    else wide_fwd_chunk<G::CB, G::S3>(cb + buf * C::CHBUF, a2[ib], out, l31, hi, dj);
     __syncthreads();
     buf ^= 1;
   }
@@ -226,6 +284,7 @@ __device__ __forceinline__ void stage_biases(float *__restrict__ dst, const floa
 
 struct WideArgs {
   const float *img_s, *img_t;
+  const unsigned char *b6_s, *b6_t;  // the nets' B6 images (k_wide_apply<..., B6 = true>), or nullptr
   long long *trace;  // optional clock stamps of block 0 / wave 0 (nf_debug_trace)
   int d, c, m, par_t;
   long N;
@@ -330,13 +389,14 @@ struct FwdStash {
   unsigned *mask[2];
 };
 
-template <class G, bool INVERSE, bool STASH = false>
+template <class G, bool INVERSE, bool STASH = false, bool B6 = false>
 __global__ __launch_bounds__(256, 1) void k_wide_apply(WideArgs a, float *xt, float *__restrict__ ladj, int accumulate,
                                                        FwdStash fs) {
   using W = Wide<G>;
+  using C = WideChunks<G, B6>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *cb = lds;
-  float *bias = lds + 2 * W::CHBUF;
+  float *bias = lds + 2 * C::CHBUF;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
@@ -344,8 +404,9 @@ __global__ __launch_bounds__(256, 1) void k_wide_apply(WideArgs a, float *xt, fl
   const long ntiles = (a.N + NF_TILE - 1) / NF_TILE;
   const long ngroups = (ntiles + 3) / 4;
 
-  const wide_img_t img_s = make_img(a.img_s, G::SIZE), img_t = make_img(a.img_t, G::SIZE);
-  issue_chunk(img_s, G::W1, W::CF1, cb, wave, lane);
+  const wide_img_t img_s = make_img(B6 ? reinterpret_cast<const float *>(a.b6_s) : a.img_s, C::IMG_FLOATS),
+                   img_t = make_img(B6 ? reinterpret_cast<const float *>(a.b6_t) : a.img_t, C::IMG_FLOATS);
+  issue_chunk(img_s, C::O1, C::N1, cb, wave, lane);
   stage_biases<G>(bias, a.img_s, tid);
   stage_biases<G>(bias + W::NBIAS, a.img_t, tid);
   __syncthreads();
@@ -372,7 +433,7 @@ __global__ __launch_bounds__(256, 1) void k_wide_apply(WideArgs a, float *xt, fl
       ApplyHooks<G, STASH> hk{make_stash_io(fs.a1[0], tl, (STASH && live) ? 32 * G::H1B : 0, l31, hi),
                               make_stash_io(fs.a2[0], tl, (STASH && live) ? 32 * G::H2B : 0, l31, hi),
                               (STASH && live) ? fs.mask[0] + tl * (16 * 64) + lane : nullptr, nullptr, nullptr, 0};
-      wide_net_fwd<G>(img_s, bias, cb, buf, img_t, G::W1, W::CF1, xb, S, wave, lane, hk);
+      wide_net_fwd<G, ApplyHooks<G, STASH>, B6>(img_s, bias, cb, buf, img_t, C::O1, C::N1, xb, S, wave, lane, hk);
       if (STASH) stash_store<G::CB>(make_stash_io(fs.out[0], tl, live ? 32 * G::CB : 0, l31, hi), S);
     }
     {
@@ -389,7 +450,7 @@ __global__ __launch_bounds__(256, 1) void k_wide_apply(WideArgs a, float *xt, fl
       ApplyHooks<G, STASH> hk{make_stash_io(fs.a1[1], tl, (STASH && live) ? 32 * G::H1B : 0, l31, hi),
                               make_stash_io(fs.a2[1], tl, (STASH && live) ? 32 * G::H2B : 0, l31, hi),
                               (STASH && live) ? fs.mask[1] + tl * (16 * 64) + lane : nullptr, &io, &x1, a.par_t};
-      wide_net_fwd<G>(img_t, bias + W::NBIAS, cb, buf, img_s, G::W1, more ? W::CF1 : 0, xb, T, wave, lane, hk);
+      wide_net_fwd<G, ApplyHooks<G, STASH>, B6>(img_t, bias + W::NBIAS, cb, buf, img_s, C::O1, more ? C::N1 : 0, xb, T, wave, lane, hk);
       if (STASH) stash_store<G::CB>(make_stash_io(fs.out[1], tl, live ? 32 * G::CB : 0, l31, hi), T);
     }
     float lpart[G::CB];
@@ -943,13 +1004,36 @@ bool nf_wide_supported(const nf_flow_desc *desc) {
 template <class G>
 struct WideHost {
 // packed images of every net: [coupling][s|t][G::SIZE] in ctx->wimg, plus DMA slack at the end
-static size_t wide_wimg_bytes(nf_ctx *, const nf_flow_desc *desc) { return (size_t)2 * desc->nlayers * 2 * G::SIZE * sizeof(float) + 4096; }
+// and behind them, 256-byte aligned, their B6 copies (bf16 triples; rebuilt from the fp32 images when those changed)
+static size_t wide_b6_offset(const nf_flow_desc *desc) {
+  return (((size_t)2 * desc->nlayers * 2 * G::SIZE * sizeof(float) + 4096) + 255) / 256 * 256;
+}
+static size_t wide_wimg_bytes(nf_ctx *, const nf_flow_desc *desc) {
+  return wide_b6_offset(desc) + (size_t)2 * desc->nlayers * 2 * B6Geo<G>::BYTES + 4096;
+}
+// NF_WIDE_FP32=1: the forward kernels on fp32 MFMAs (A/B switch)
+static bool wide_b6() {
+  static const bool fp32 = std::getenv("NF_WIDE_FP32") != nullptr;
+  return !fp32;
+}
+static int wide_b6_refresh(nf_ctx *ctx, const nf_flow_desc *desc) {
+  if (ctx->b6_gen == ctx->wimg_gen) return NF_OK;
+  using B = B6Geo<G>;
+  const int nimg = 2 * desc->nlayers * 2;
+  constexpr long PER = 2 * G::MB * 2 * B::R1 + 2 * G::H1B * 2 * B::R2 + 2 * G::H2B * 2 * B::R3 + B::R1 + B::R2 + B::R3;
+  const long total = (long)nimg * PER;
+  ProfScope ps(ctx, "pack_weights");
+  hipLaunchKernelGGL((k_b6_from_images<G>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, nimg, (const float *)ctx->wimg,
+                     (unsigned char *)ctx->wimg + wide_b6_offset(desc));
+  NF_HIP(hipGetLastError());
+  ctx->b6_gen = ctx->wimg_gen;
+  return NF_OK;
+}
 
 static int wide_pack(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta) {
   if (!nf_wide_supported(desc)) return NF_ERR_UNSUPPORTED;
   const int nc = 2 * desc->nlayers;
-  const size_t bytes = (size_t)nc * 2 * G::SIZE * sizeof(float) + 4096;
-  NF_TRY(nf_wimg_reserve(ctx, bytes));
+  NF_TRY(nf_wimg_reserve(ctx, wide_wimg_bytes(ctx, desc)));
   const PackArgs p = make_pack_args(desc);
   const long total = (long)nc * 2 * G::SIZE;
   ProfScope ps(ctx, "pack_weights");
@@ -963,6 +1047,8 @@ static WideArgs make_wide_args(nf_ctx *ctx, const nf_flow_desc *desc, int k, lon
   WideArgs a;
   a.img_s = (const float *)ctx->wimg + (size_t)(2 * k) * G::SIZE;
   a.img_t = a.img_s + G::SIZE;
+  a.b6_s = (const unsigned char *)ctx->wimg + wide_b6_offset(desc) + (size_t)(2 * k) * B6Geo<G>::BYTES;
+  a.b6_t = a.b6_s + B6Geo<G>::BYTES;
   a.trace = (long long *)ctx->trace;
   a.d = desc->d; a.c = ci.c; a.m = ci.m; a.par_t = ci.par_t; a.N = N;
   return a;
@@ -974,11 +1060,15 @@ static int wide_apply(nf_ctx *ctx, const nf_flow_desc *desc, int k, bool inverse
                   int accumulate) {
   if (!ctx->wimg) return NF_ERR_UNSUPPORTED;
   const WideArgs a = make_wide_args(ctx, desc, k, N);
-  const size_t lds = Wide<G>::LDS_APPLY;
+  const bool b6 = wide_b6();
+  if (b6) NF_TRY(wide_b6_refresh(ctx, desc));
+  const size_t lds = b6 ? Wide<G>::LDS_APPLY_B6 : Wide<G>::LDS_APPLY;
   static AttrOnce attr_once;  // once per device: a context on another GPU needs its own
   NF_TRY(attr_once.run(ctx->device, [&]() -> int {
-    NF_HIP(hipFuncSetAttribute((const void *)k_wide_apply<G, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    NF_HIP(hipFuncSetAttribute((const void *)k_wide_apply<G, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NF_HIP(hipFuncSetAttribute((const void *)k_wide_apply<G, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Wide<G>::LDS_APPLY));
+    NF_HIP(hipFuncSetAttribute((const void *)k_wide_apply<G, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Wide<G>::LDS_APPLY));
+    NF_HIP(hipFuncSetAttribute((const void *)k_wide_apply<G, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Wide<G>::LDS_APPLY_B6));
+    NF_HIP(hipFuncSetAttribute((const void *)k_wide_apply<G, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Wide<G>::LDS_APPLY_B6));
     return NF_OK;
   }));
   long grid = wide_groups(N);
@@ -986,7 +1076,11 @@ static int wide_apply(nf_ctx *ctx, const nf_flow_desc *desc, int k, bool inverse
   if (grid < 1) grid = 1;
   ProfScope ps(ctx, "wide_apply");
   const FwdStash none{};
-  if (inverse)
+  if (b6 && inverse)
+    hipLaunchKernelGGL((k_wide_apply<G, true, false, true>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, xt, ladj, accumulate, none);
+  else if (b6)
+    hipLaunchKernelGGL((k_wide_apply<G, false, false, true>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, xt, ladj, accumulate, none);
+  else if (inverse)
     hipLaunchKernelGGL((k_wide_apply<G, true>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, xt, ladj, accumulate, none);
   else
     hipLaunchKernelGGL((k_wide_apply<G, false>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, xt, ladj, accumulate, none);
@@ -1149,10 +1243,13 @@ static size_t wide_train_ws_floats(nf_ctx *ctx, const nf_flow_desc *desc, long N
 static int wide_train_forward(nf_ctx *ctx, const nf_flow_desc *desc, float *xt, long N, float *ladj, float *ws) {
   if (!ctx->wimg) return NF_ERR_UNSUPPORTED;
   const long ntiles = (N + NF_TILE - 1) / NF_TILE;
-  const size_t lds = Wide<G>::LDS_APPLY;
+  const bool b6 = wide_b6();
+  if (b6) NF_TRY(wide_b6_refresh(ctx, desc));
+  const size_t lds = b6 ? Wide<G>::LDS_APPLY_B6 : Wide<G>::LDS_APPLY;
   static AttrOnce attr_once;  // once per device: a context on another GPU needs its own
   NF_TRY(attr_once.run(ctx->device, [&]() -> int {
-    NF_HIP(hipFuncSetAttribute((const void *)k_wide_apply<G, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NF_HIP(hipFuncSetAttribute((const void *)k_wide_apply<G, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Wide<G>::LDS_APPLY));
+    NF_HIP(hipFuncSetAttribute((const void *)k_wide_apply<G, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Wide<G>::LDS_APPLY_B6));
     return NF_OK;
   }));
   long grid = wide_groups(N);
@@ -1164,7 +1261,10 @@ static int wide_train_forward(nf_ctx *ctx, const nf_flow_desc *desc, float *xt, 
     const WideArgs a = make_wide_args(ctx, desc, k, N);
     const FwdStash fs = fwd_stash_at(ws, ntiles, k);
     ProfScope ps(ctx, "wide_apply");
-    hipLaunchKernelGGL((k_wide_apply<G, false, true>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, xt, ladj, s > 0 ? 1 : 0, fs);
+    if (b6)
+      hipLaunchKernelGGL((k_wide_apply<G, false, true, true>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, xt, ladj, s > 0 ? 1 : 0, fs);
+    else
+      hipLaunchKernelGGL((k_wide_apply<G, false, true>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, xt, ladj, s > 0 ? 1 : 0, fs);
     NF_HIP(hipGetLastError());
   }
   return NF_OK;

@@ -443,12 +443,14 @@ print(json.dumps({"l_in": l_in, "l_xs": l_xs, "l_ref": lr, "g_in": float(np.abs(
 
 
 @pytest.mark.parametrize("env", [{}, {"NF_FWD_FP32": "1", "NF_BWD_FP32": "1"}, {"NF_FWD_B6_STASH": "1"}, {"NF_STASH_SLIM": "1"},
-                                 {"NF_STASH_SLIM": "1", "NF_FWD_B6_STASH": "1"}, {"NF_BWD_NO_PAIR": "1"}, {"NF_BWD_NO_PAIR": "1", "NF_BWD_ONE_WAVE_B6": "1"}],
-                         ids=["default", "fp32_everywhere", "b6_stashing_forward", "slim_stash", "slim_stash_b6", "one_wave_fp32", "one_wave_b6"])
+                                 {"NF_STASH_SLIM": "1", "NF_FWD_B6_STASH": "1"}, {"NF_BWD_NO_PAIR": "1"}, {"NF_BWD_NO_PAIR": "1", "NF_BWD_ONE_WAVE_B6": "1"},
+                                 {"NF_BWD_DW_FP32": "1"}],
+                         ids=["default", "fp32_everywhere", "b6_stashing_forward", "slim_stash", "slim_stash_b6", "one_wave_fp32", "one_wave_b6",
+                              "pair_dw_fp32"])
 def test_kernel_variants_behind_environment_switches_keep_parity(env):
     """The measured-and-kept alternatives of round 4 are selected once per process by environment switches (fp32 MFMAs
     everywhere; the bf16 six-term products also in the stashing forward; the stash without a1; the one-wave reverse kernel
-    in fp32 and with all six GEMMs on the bf16 cores): each must give the oracle's loss, gradient, forward and
+    in fp32 and with all six GEMMs on the bf16 cores; the pair kernel with fp32 dW GEMMs): each must give the oracle's loss, gradient, forward and
     log-likelihood at the tolerances of the default path -- run in a subprocess per switch."""
     import json
     import subprocess
@@ -457,7 +459,7 @@ def test_kernel_variants_behind_environment_switches_keep_parity(env):
     from __graft_entry__ import ROOT
 
     e = dict(os.environ, NF_ROOT=ROOT, **env)
-    for k in ("NF_FWD_FP32", "NF_BWD_FP32", "NF_FWD_B6_STASH", "NF_STASH_SLIM", "NF_BWD_NO_PAIR", "NF_BWD_ONE_WAVE_B6"):
+    for k in ("NF_FWD_FP32", "NF_BWD_FP32", "NF_FWD_B6_STASH", "NF_STASH_SLIM", "NF_BWD_NO_PAIR", "NF_BWD_ONE_WAVE_B6", "NF_BWD_DW_FP32"):
         if k not in env:
             e.pop(k, None)
     p = subprocess.run([sys.executable, "-c", _VARIANT_SNIPPET], env=e, capture_output=True, text=True, timeout=600)
