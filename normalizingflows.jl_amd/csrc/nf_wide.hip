@@ -186,6 +186,7 @@ __device__ __forceinline__ void wide_bwdx_chunk(const float *__restrict__ ch, co
 // to trickle its stash stores and tile loads out a few per chunk, so that they drain behind the
 // matrix pipe instead of in one HBM-bound burst.
 struct NoHooks {
+  static constexpr int YOUNG = 0;
   template <class T>
   __device__ __forceinline__ void after_l1(T &) const {}
   template <class T>
@@ -195,6 +196,24 @@ struct NoHooks {
   template <class T>
   __device__ __forceinline__ void l3_step(int, T &) const {}
 };
+
+// The barrier behind a chunk: every wave is done with the chunk, and the NEXT chunk's DMA (issued in front of this chunk's
+// hook and GEMM) has landed.  YOUNG = vector-memory operations a hook issues per chunk BEHIND that DMA (the stash stores
+// trickled out 16 per chunk): the counter retires in order, so "at most YOUNG outstanding" already implies the DMA is done,
+// while __syncthreads() (vmcnt(0)) would also wait for those stores' round trip to HBM -- affordable behind 128 fp32 MFMAs
+// of 64 clocks, not behind 96 bf16 ones of 32.
+template <int YOUNG>
+__device__ __forceinline__ void wide_chunk_barrier() {
+  if constexpr (YOUNG == 0) {
+    __syncthreads();
+  } else {
+    static_assert(YOUNG < 64, "vmcnt has six bits");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt((YOUNG & 0xF) | 0x70 | ((YOUNG >> 4) << 14));  // vmcnt(YOUNG) lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
 
 template <int NB>
 __device__ __forceinline__ void init_bias(f32x16 (&v)[NB], const float *__restrict__ b, int hi) {
@@ -243,10 +262,17 @@ __device__ __forceinline__ void wide_net_fwd(wide_img_t img, const float *__rest
       dj = DmaJob{img, C::O2 + (ib + 1) * C::N2, C::N2, cb + (buf ^ 1) * C::CHBUF, wave, lane};
     else
       dj = DmaJob{img, C::O3, C::N3, cb + (buf ^ 1) * C::CHBUF, wave, lane};
-    hk.l2_step(ib, a1);
-    if constexpr (B6) wide_fwd_chunk_b6<G::H2B>(cb + buf * C::CHBUF, a1[ib], a2, l31, hi, dj);
-    else wide_fwd_chunk<G::H2B, G::S2>(cb + buf * C::CHBUF, a1[ib], a2, l31, hi, dj);
-    __syncthreads();
+    const DmaJob none{img, 0, 0, cb, wave, lane};
+    if constexpr (B6) {  // the DMA in front of the hook's stores (wide_chunk_barrier)
+      dj.issue();
+      hk.l2_step(ib, a1);
+      wide_fwd_chunk_b6<G::H2B>(cb + buf * C::CHBUF, a1[ib], a2, l31, hi, none);
+      wide_chunk_barrier<HK::YOUNG>();
+    } else {
+      hk.l2_step(ib, a1);
+      wide_fwd_chunk<G::H2B, G::S2>(cb + buf * C::CHBUF, a1[ib], a2, l31, hi, dj);
+      __syncthreads();
+    }
     buf ^= 1;
   }
 #pragma unroll
@@ -263,10 +289,17 @@ __device__ __forceinline__ void wide_net_fwd(wide_img_t img, const float *__rest
       dj = DmaJob{img, C::O3 + (ib + 1) * C::N3, C::N3, cb + (buf ^ 1) * C::CHBUF, wave, lane};
     else if (next_floats)
       dj = DmaJob{next_img, next_off, next_floats, cb + (buf ^ 1) * C::CHBUF, wave, lane};
-    hk.l3_step(ib, a2);
-    if constexpr (B6) wide_fwd_chunk_b6<G::CB>(cb + buf * C::CHBUF, a2[ib], out, l31, hi, dj);
-    else wide_fwd_chunk<G::CB, G::S3>(cb + buf * C::CHBUF, a2[ib], out, l31, hi, dj);
-    __syncthreads();
+    const DmaJob none{img, 0, 0, cb, wave, lane};
+    if constexpr (B6) {
+      dj.issue();
+      hk.l3_step(ib, a2);
+      wide_fwd_chunk_b6<G::CB>(cb + buf * C::CHBUF, a2[ib], out, l31, hi, none);
+      wide_chunk_barrier<HK::YOUNG>();
+    } else {
+      hk.l3_step(ib, a2);
+      wide_fwd_chunk<G::CB, G::S3>(cb + buf * C::CHBUF, a2[ib], out, l31, hi, dj);
+      __syncthreads();
+    }
     buf ^= 1;
   }
 }
@@ -285,6 +318,7 @@ __device__ __forceinline__ void stage_biases(float *__restrict__ dst, const floa
 struct WideArgs {
   const float *img_s, *img_t;
   const unsigned char *b6_s, *b6_t;  // the nets' B6 images (k_wide_apply<..., B6 = true>), or nullptr
+  const unsigned char *b6t_s, *b6t_t;  // their transposed B6T images (k_wide_bwd_stashed_b6)
   long long *trace;  // optional clock stamps of block 0 / wave 0 (nf_debug_trace)
   int d, c, m, par_t;
   long N;
@@ -341,6 +375,7 @@ __device__ __forceinline__ void wide_sign_masks(const f32x16 (&v)[NB], unsigned 
 // transformed half x1 behind the last layer
 template <class G, bool STASH>
 struct ApplyHooks {
+  static constexpr int YOUNG = STASH ? 16 : 0;  // stash stores per l2_step / l3_step (wide_chunk_barrier)
   StashIO sa1, sa2;
   unsigned *mask;  // this lane's slot in the tile's mask block, or nullptr
   const TileIO *io;
@@ -421,6 +456,12 @@ __global__ __launch_bounds__(256, 1) void k_wide_apply(WideArgs a, float *xt, fl
     const bool more = grp + gridDim.x < ngroups;
     const TileIO io = make_tile_io(xt, tl, a.d, l31, hi);
     f32x16 S[G::CB], T[G::CB], x1[G::CB];
+#ifdef NF_KERNEL_TRACE  // tools/trace_wide_apply.py: block 0, wave 0, first tile group; s net at [0..6], t net at [16..22], end at [23]
+    long long *tr = (a.trace && blockIdx.x == 0 && tid == 0 && grp == blockIdx.x) ? a.trace : nullptr;
+#else
+    long long *tr = nullptr;
+#endif
+    WIDE_STAMP(0);
     {
       f32x16 xb[G::MB];
 #pragma unroll
@@ -433,7 +474,9 @@ __global__ __launch_bounds__(256, 1) void k_wide_apply(WideArgs a, float *xt, fl
       ApplyHooks<G, STASH> hk{make_stash_io(fs.a1[0], tl, (STASH && live) ? 32 * G::H1B : 0, l31, hi),
                               make_stash_io(fs.a2[0], tl, (STASH && live) ? 32 * G::H2B : 0, l31, hi),
                               (STASH && live) ? fs.mask[0] + tl * (16 * 64) + lane : nullptr, nullptr, nullptr, 0};
-      wide_net_fwd<G, ApplyHooks<G, STASH>, B6>(img_s, bias, cb, buf, img_t, C::O1, C::N1, xb, S, wave, lane, hk);
+      WIDE_STAMP(1);
+      wide_net_fwd<G, ApplyHooks<G, STASH>, B6>(img_s, bias, cb, buf, img_t, C::O1, C::N1, xb, S, wave, lane, hk, tr);
+      WIDE_STAMP(6);
       if (STASH) stash_store<G::CB>(make_stash_io(fs.out[0], tl, live ? 32 * G::CB : 0, l31, hi), S);
     }
     {
@@ -450,7 +493,9 @@ __global__ __launch_bounds__(256, 1) void k_wide_apply(WideArgs a, float *xt, fl
       ApplyHooks<G, STASH> hk{make_stash_io(fs.a1[1], tl, (STASH && live) ? 32 * G::H1B : 0, l31, hi),
                               make_stash_io(fs.a2[1], tl, (STASH && live) ? 32 * G::H2B : 0, l31, hi),
                               (STASH && live) ? fs.mask[1] + tl * (16 * 64) + lane : nullptr, &io, &x1, a.par_t};
-      wide_net_fwd<G, ApplyHooks<G, STASH>, B6>(img_t, bias + W::NBIAS, cb, buf, img_s, C::O1, more ? C::N1 : 0, xb, T, wave, lane, hk);
+      WIDE_STAMP(17);
+      wide_net_fwd<G, ApplyHooks<G, STASH>, B6>(img_t, bias + W::NBIAS, cb, buf, img_s, C::O1, more ? C::N1 : 0, xb, T, wave, lane, hk, tr ? tr + 16 : nullptr);
+      WIDE_STAMP(22);
       if (STASH) stash_store<G::CB>(make_stash_io(fs.out[1], tl, live ? 32 * G::CB : 0, l31, hi), T);
     }
     float lpart[G::CB];
@@ -476,6 +521,7 @@ __global__ __launch_bounds__(256, 1) void k_wide_apply(WideArgs a, float *xt, fl
       const float base = accumulate ? ladj[j] : 0.f;
       ladj[j] = INVERSE ? base - lsum : base + lsum;
     }
+    WIDE_STAMP(23);
   }
 }
 
@@ -770,6 +816,167 @@ __global__ __launch_bounds__(256, 1) void k_wide_bwd_stashed(WideArgs a, float *
   }
 }
 
+// The same reverse pass with its dX GEMMs on the bf16 matrix cores (round 4).  The streamed image is the net's B6T image
+// (rows = a layer's INPUT features, k-groups over its OUTPUT features), so a dX GEMM is the forward chunk routine run
+// through the transposed net: a chunk = the two k-groups of ONE cotangent block (split once, when its chunk arrives) and
+// all rows, every output block of the layer accumulates at once (128 accumulator registers; one wave per SIMD has 512).
+// The fp32 form chunks over output rows instead -- one accumulator block, every cotangent block live -- and would have
+// to split the whole cotangent again for every chunk.  A finished tensor's stash stores trickle out 16 per chunk of the
+// NEXT GEMM, behind that chunk's DMA (wide_chunk_barrier).
+template <class G>
+struct WideT {
+  using T = B6TGeo<G>;
+  static constexpr int N3 = 48 * T::R3, N2 = 48 * T::R2, N1 = 48 * T::R1;  // chunk sizes in floats
+  static constexpr int O3 = T::T3 * 4, O2 = T::T2 * 4, O1 = T::T1 * 4;     // layer offsets in floats
+  static constexpr int CH = N3 > N2 ? (N3 > N1 ? N3 : N1) : (N2 > N1 ? N2 : N1);
+  static constexpr size_t LDS = (size_t)2 * CH * sizeof(float);
+};
+
+template <class G>
+__device__ __forceinline__ void wide_dx_chain_b6(wide_img_t img, float *cb, int &buf, f32x16 (&d3)[G::CB],
+                                                 const unsigned (&m1)[G::H1B], const unsigned (&m2)[G::H2B],
+                                                 const StashIO &sd1, const StashIO &sd2, const StashIO &sd3,
+                                                 const TileIO &gio, int par_c, bool live, int next_floats, int wave, int lane) {
+  using WT = WideT<G>;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const DmaJob none{img, 0, 0, cb, wave, lane};
+  static_assert(G::CB * 16 == 16 * G::CB, "");
+  f32x16 d2[G::H2B];
+#pragma unroll
+  for (int b = 0; b < G::H2B; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d2[b][r] = 0.f;
+#pragma unroll
+  for (int ob = 0; ob < G::CB; ++ob) {  // dX3: d2 += W3^T[:, block ob] d3[ob]
+    if (ob + 1 < G::CB) issue_chunk(img, WT::O3 + (ob + 1) * WT::N3, WT::N3, cb + (buf ^ 1) * WT::CH, wave, lane);
+    else issue_chunk(img, WT::O2, WT::N2, cb + (buf ^ 1) * WT::CH, wave, lane);
+    stash_store_range<G::CB>(sd3, d3, ob * 16, 16);
+    wide_fwd_chunk_b6<G::H2B>(cb + buf * WT::CH, d3[ob], d2, l31, hi, none);
+    wide_chunk_barrier<16>();
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int b = 0; b < G::H2B; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d2[b][r] *= nf_mask_slope(m2[b], r);
+  f32x16 d1[G::H1B];
+#pragma unroll
+  for (int b = 0; b < G::H1B; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d1[b][r] = 0.f;
+#pragma unroll
+  for (int ob = 0; ob < G::H2B; ++ob) {  // dX2
+    if (ob + 1 < G::H2B) issue_chunk(img, WT::O2 + (ob + 1) * WT::N2, WT::N2, cb + (buf ^ 1) * WT::CH, wave, lane);
+    else issue_chunk(img, WT::O1, WT::N1, cb + (buf ^ 1) * WT::CH, wave, lane);
+    stash_store_range<G::H2B>(sd2, d2, ob * 16, 16);
+    wide_fwd_chunk_b6<G::H1B>(cb + buf * WT::CH, d2[ob], d1, l31, hi, none);
+    wide_chunk_barrier<16>();
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int b = 0; b < G::H1B; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d1[b][r] *= nf_mask_slope(m1[b], r);
+  f32x16 g2[G::MB];  // starts from the cotangent's conditioner half: x2bar = ybar2 + W1^T d1
+#pragma unroll
+  for (int ob = 0; ob < G::H1B; ++ob) {  // dX1
+    if (ob + 1 < G::H1B) issue_chunk(img, WT::O1 + (ob + 1) * WT::N1, WT::N1, cb + (buf ^ 1) * WT::CH, wave, lane);
+    else if (next_floats) issue_chunk(img, WT::O3, next_floats, cb + (buf ^ 1) * WT::CH, wave, lane);
+    stash_store_range<G::H1B>(sd1, d1, ob * 16, 16);
+    if (ob == 0) {
+#pragma unroll
+      for (int b = 0; b < G::MB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g2[b][r] = tile_load(gio, tile_soff(b, r, par_c));
+    }
+    wide_fwd_chunk_b6<G::MB>(cb + buf * WT::CH, d1[ob], g2, l31, hi, none);
+    wide_chunk_barrier<16>();
+    buf ^= 1;
+  }
+  if (live) {
+#pragma unroll
+    for (int b = 0; b < G::MB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tile_store(gio, tile_soff(b, r, par_c), g2[b][r]);
+  }
+}
+
+template <class G, bool PHASE_S>
+__global__ __launch_bounds__(256, 1) void k_wide_bwd_stashed_b6(WideArgs a, float *__restrict__ y, float *__restrict__ ybar,
+                                                                const float *__restrict__ lbar, float lbar_const,
+                                                                WideStash st, const float *__restrict__ fout,
+                                                                const unsigned *__restrict__ fmask) {
+  using WT = WideT<G>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *cb = lds;
+  const wide_img_t img = make_img(reinterpret_cast<const float *>(PHASE_S ? a.b6t_s : a.b6t_t), B6TGeo<G>::BYTES / 4);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int par_c = 1 - a.par_t;
+  const long ntiles = (a.N + NF_TILE - 1) / NF_TILE;
+  const long ngroups = (ntiles + 3) / 4;
+
+  issue_chunk(img, WT::O3, WT::N3, cb, wave, lane);
+  __syncthreads();
+  int buf = 0;
+
+  for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const long tile = grp * 4 + wave;
+    const bool live = tile < ntiles;
+    const long tl = live ? tile : 0;
+    const long j = tl * NF_TILE + l31;
+    const bool valid = live && j < a.N;
+    const bool more = grp + gridDim.x < ngroups;
+    const TileIO yio = make_tile_io(y, tl, a.d, l31, hi);
+    const TileIO gio = make_tile_io(ybar, tl, a.d, l31, hi);
+    const StashIO sd1 = make_stash_io(st.d1, tl, live ? 32 * G::H1B : 0, l31, hi);
+    const StashIO sd2 = make_stash_io(st.d2, tl, live ? 32 * G::H2B : 0, l31, hi);
+    const StashIO sd3 = make_stash_io(st.d3, tl, live ? 32 * G::CB : 0, l31, hi);
+    const StashIO so = make_stash_io(const_cast<float *>(fout), tl, 32 * G::CB, l31, hi);
+
+    unsigned m1[G::H1B], m2[G::H2B];
+    {
+      const unsigned *mp = fmask + tl * (16 * 64) + lane;
+#pragma unroll
+      for (int b = 0; b < G::H1B; ++b) m1[b] = mp[b * 64];
+#pragma unroll
+      for (int b = 0; b < G::H2B; ++b) m2[b] = mp[(8 + b) * 64];
+    }
+    f32x16 d3[G::CB], y1[G::CB], g1[G::CB];
+#pragma unroll
+    for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        d3[b][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(so.rs, so.voff, (b * 32 + (r & 3) + 8 * (r >> 2)) * (NF_TILE * 4), 0));
+        y1[b][r] = tile_load(yio, tile_soff(b, r, a.par_t));
+        g1[b][r] = tile_load(gio, tile_soff(b, r, a.par_t));
+      }
+    const float lb = valid ? (lbar ? lbar[j] : lbar_const) : 0.f;
+#pragma unroll
+    for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int p = b * 32 + nf_row(r, hi);
+        const bool ok = (p < a.c) && valid;
+        const float yv = y1[b][r], gv = g1[b][r];
+        if (!PHASE_S) {
+          if (live) tile_store(yio, tile_soff(b, r, a.par_t), yv - d3[b][r]);  // u = x1 * exp(S)
+          d3[b][r] = ok ? gv : 0.f;
+        } else {
+          const float s = nf_tanh(d3[b][r]);
+          const float es = nf_exp(s);
+          if (live) {
+            tile_store(yio, tile_soff(b, r, a.par_t), nf_fdiv(yv, es));  // x1 = u * exp(-s)
+            tile_store(gio, tile_soff(b, r, a.par_t), gv * es);             // x1bar
+          }
+          d3[b][r] = ok ? (gv * yv + lb) * (1.f - s * s) : 0.f;
+        }
+      }
+    wide_dx_chain_b6<G>(img, cb, buf, d3, m1, m2, sd1, sd2, sd3, gio, par_c, live, more ? WT::N3 : 0, wave, lane);
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // weight gradients from the stash: split-K GEMM  dW^T[i][o] = sum_samples A[i][j] D[o][j]
 // ------------------------------------------------------------------------------------
@@ -805,6 +1012,15 @@ struct DwArgs {
 #define DW_TS 33
 #define DW_ROWS 384
 
+// A tile's base address is wave-uniform (tile and job are), but hipcc does the 64-bit multiply on the vector ALU and then
+// wraps every buffer load in a waterfall loop over "the lanes' descriptors" (12 loops of 18 instructions per tile): hand it
+// the address back through SGPRs.
+__device__ __forceinline__ float *wave_uniform_ptr(const float *p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<float *>(((unsigned long long)hi << 32) | lo);
+}
+
 template <int WI, int WO>
 __device__ __forceinline__ void dw_job(const DwJob &jb, const DwArgs &a, int ks, float *__restrict__ out, float *lds) {
   constexpr int AROWS = 128 * WI;
@@ -826,8 +1042,8 @@ __device__ __forceinline__ void dw_job(const DwJob &jb, const DwArgs &a, int ks,
 
   float4 stg[NLD];
   auto load_tile = [&](long tile) {
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(jb.A) + tile * jb.a_tile_stride, 0, jb.a_extent, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(jb.D) + tile * jb.d_tile_stride, 0, jb.d_extent, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(wave_uniform_ptr(jb.A + tile * jb.a_tile_stride), 0, jb.a_extent, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(wave_uniform_ptr(jb.D + tile * jb.d_tile_stride), 0, jb.d_extent, 0x00020000);
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
       const int row = lrow + 32 * k;
@@ -931,6 +1147,172 @@ __device__ __forceinline__ void dw_job(const DwJob &jb, const DwArgs &a, int ks,
   }
 }
 
+// The same job on the bf16 matrix cores (round 4).  Both operands come from the stash in fp32; they are split ONCE per tile,
+// by the thread that brought them in, on their way into LDS (a row's 32 samples as bf16 triples in the D6 layout of
+// nf_mfma.h: [component][sample group][parity][8] x 2 bytes, sample = 2 (8 g + j) + parity -- a thread's four consecutive
+// samples are two (even, odd) pairs of neighbouring k-slots, i.e. two packed dwords per component), so the GEMM loop is
+// 16-byte LDS reads and MFMAs only: 96 bf16 MFMAs of 32 clocks per wave and tile instead of 128 fp32 ones of 64.  One LDS
+// buffer (384 rows x 208 bytes = 78 KB); the next tile waits in registers while the matrix pipe works on this one.
+__device__ __forceinline__ void nf_split2(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
+  const unsigned b0 = __float_as_uint(x0), b1 = __float_as_uint(x1);
+  const float r0 = x0 - __uint_as_float(b0 & 0xFFFF0000u), r1 = x1 - __uint_as_float(b1 & 0xFFFF0000u);
+  const unsigned q0 = __float_as_uint(r0), q1 = __float_as_uint(r1);
+  const float l0 = r0 - __uint_as_float(q0 & 0xFFFF0000u), l1 = r1 - __uint_as_float(q1 & 0xFFFF0000u);
+  h = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+  m = __builtin_amdgcn_perm(q1, q0, 0x07060302u);
+  l = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
+}
+
+template <int WI, int WO>
+__device__ __forceinline__ void dw_job_b6(const DwJob &jb, const DwArgs &a, int ks, float *__restrict__ out, char *lds) {
+  constexpr int AROWS = 128 * WI;
+  constexpr int NLD = DW_ROWS * 8 / 256;  // 16-byte loads per thread per tile = 12
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wi = wave / WO, wo = wave % WO;
+  const int lrow = tid >> 3, part = tid & 7;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+  f32x16 acc[4][2];
+  float bsum[2] = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][o][r] = 0.f;
+
+  u32x4 stg[NLD];
+  auto load_tile = [&](long tile) {
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(wave_uniform_ptr(jb.A + tile * jb.a_tile_stride), 0, jb.a_extent, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(wave_uniform_ptr(jb.D + tile * jb.d_tile_stride), 0, jb.d_extent, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int row = lrow + 32 * k;
+      if (32 * k < AROWS)
+        stg[k] = __builtin_amdgcn_raw_buffer_load_b128(ra, ((jb.a_row0 + row) * jb.a_rstride + jb.a_roff) * 128 + part * 16, 0, 0);
+      else
+        stg[k] = __builtin_amdgcn_raw_buffer_load_b128(rd, (jb.d_row0 + row - AROWS) * 128 + part * 16, 0, 0);
+    }
+  };
+  // samples 4 part .. 4 part + 3 of a row: the even pair is slots j, j + 1 of (group part >> 2, parity 0), the odd pair of parity 1
+  char *pp = lds + lrow * D6_ROW + (part >> 2) * 32 + (part & 3) * 4;
+  auto put_tile = [&]() {
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const unsigned v0 = stg[k].x, v1 = stg[k].y, v2 = stg[k].z, v3 = stg[k].w;  // (bit_cast of a vector-element expression reads element 0)
+      unsigned eh, em, el, oh, om, ol;
+      nf_split2(__uint_as_float(v0), __uint_as_float(v2), eh, em, el);
+      nf_split2(__uint_as_float(v1), __uint_as_float(v3), oh, om, ol);
+      unsigned *p = reinterpret_cast<unsigned *>(pp + 32 * k * D6_ROW);
+      p[0] = eh; p[4] = oh;          // component h: parity 0 at +0, parity 1 at +16 bytes
+      p[16] = em; p[20] = om;        // component m at +64 bytes
+      p[32] = el; p[36] = ol;        // component l at +128 bytes
+    }
+  };
+
+  long tile = ks;
+  if (tile < a.ntiles) {
+    load_tile(tile);
+    put_tile();
+  }
+  __syncthreads();
+  const nf_u32x4 *pa = reinterpret_cast<const nf_u32x4 *>(lds + (wi * 128 + l31) * D6_ROW + hi * 16);
+  const nf_u32x4 *pd = reinterpret_cast<const nf_u32x4 *>(lds + (AROWS + wo * 64 + l31) * D6_ROW + hi * 16);
+  constexpr int RB = 32 * D6_ROW / 16;  // 16-byte units per block of 32 rows
+  const unsigned ones = 0x3F803F80u;
+  const bool need_bias = jb.b_off >= 0 && wi == 0;
+  for (; tile < a.ntiles; tile += a.ksplit) {
+    const bool has_next = tile + a.ksplit < a.ntiles;
+    if (has_next) load_tile(tile + a.ksplit);
+    nf_u32x4 An[4][3], Dn[2][3];  // the operands of the sample group after this one: requested behind its 48 MFMAs
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) An[ib][c] = pa[ib * RB + c * 4];
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Dn[ob][c] = pd[ob * RB + c * 4];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      nf_u32x4 A[4][3], D[2][3];
+#pragma unroll
+      for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) A[ib][c] = An[ib][c];
+#pragma unroll
+      for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) D[ob][c] = Dn[ob][c];
+      if (g == 0) {
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) An[ib][c] = pa[ib * RB + c * 4 + 2];
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) Dn[ob][c] = pd[ob * RB + c * 4 + 2];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ob = 0; ob < 2; ++ob) {
+        if (need_bias)  // (wave-uniform: the job owns the bias block and this wave's rows are its first)
+#pragma unroll
+          for (int i = 0; i < 12; ++i) bsum[ob] = nf_dot2_bf16(D[ob][2 - i / 4][i % 4], ones, bsum[ob]);
+#pragma unroll
+        for (int term = 0; term < 6; ++term)  // smallest first: al dh, ah dl, am dm, am dh, ah dm, ah dh
+#pragma unroll
+          for (int ib = 0; ib < 4; ++ib) {
+            const nf_u32x4 &av = term == 0 ? A[ib][2] : (term == 2 || term == 3) ? A[ib][1] : A[ib][0];
+            const nf_u32x4 &dv = term == 1 ? D[ob][2] : (term == 2 || term == 4) ? D[ob][1] : D[ob][0];
+            acc[ib][ob] = nf_mfma_bf16(av, dv, acc[ib][ob]);
+          }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();  // every wave is done reading this tile
+    if (has_next) put_tile();
+    __syncthreads();
+  }
+
+  // partial result in image layout
+#pragma unroll
+  for (int ib = 0; ib < 4; ++ib) {
+    const int iblk = jb.a_row0 / 32 + wi * 4 + ib;
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob) {
+      const int oblk = jb.d_row0 / 32 + wo * 2 + ob;
+      if (iblk < jb.ib_tot && oblk < jb.ob_tot) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          out[jb.w_off + (iblk * 32 + nf_row(r, hi)) * jb.w_stride + oblk * 32 + l31] = acc[ib][ob][r];
+      }
+    }
+  }
+  if (jb.b_off >= 0 && wi == 0) {
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob) {
+      const int oblk = jb.d_row0 / 32 + wo * 2 + ob;
+      const float v = bsum[ob] + __shfl_xor(bsum[ob], 32);
+      if (hi == 0 && oblk < jb.ob_tot) out[jb.b_off + oblk * 32 + l31] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void k_wide_dw_b6(DwArgs a, float *__restrict__ slab) {
+  extern __shared__ __attribute__((aligned(16))) char lds_b[];
+  const int j = blockIdx.x % a.njobs, ks = blockIdx.x / a.njobs;
+  const DwJob &jb = a.job[j];
+  float *out = slab + (long)ks * a.slab_stride;
+  if (jb.cfg == 0)
+    dw_job_b6<1, 4>(jb, a, ks, out, lds_b);
+  else
+    dw_job_b6<2, 2>(jb, a, ks, out, lds_b);
+}
+
 __global__ __launch_bounds__(256, 1) void k_wide_dw(DwArgs a, float *__restrict__ slab) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int j = blockIdx.x % a.njobs, ks = blockIdx.x / a.njobs;
@@ -1008,8 +1390,24 @@ struct WideHost {
 static size_t wide_b6_offset(const nf_flow_desc *desc) {
   return (((size_t)2 * desc->nlayers * 2 * G::SIZE * sizeof(float) + 4096) + 255) / 256 * 256;
 }
+static size_t wide_b6t_offset(const nf_flow_desc *desc) {
+  return ((wide_b6_offset(desc) + (size_t)2 * desc->nlayers * 2 * B6Geo<G>::BYTES + 4096) + 255) / 256 * 256;
+}
 static size_t wide_wimg_bytes(nf_ctx *, const nf_flow_desc *desc) {
-  return wide_b6_offset(desc) + (size_t)2 * desc->nlayers * 2 * B6Geo<G>::BYTES + 4096;
+  return wide_b6t_offset(desc) + (size_t)2 * desc->nlayers * 2 * B6TGeo<G>::BYTES + 4096;
+}
+static int wide_b6t_refresh(nf_ctx *ctx, const nf_flow_desc *desc) {
+  if (ctx->b6t_gen == ctx->wimg_gen) return NF_OK;
+  using T = B6TGeo<G>;
+  const int nimg = 2 * desc->nlayers * 2;
+  constexpr long PER = 2 * G::CB * 2 * T::R3 + 2 * G::H2B * 2 * T::R2 + 2 * G::H1B * 2 * T::R1;
+  const long total = (long)nimg * PER;
+  ProfScope ps(ctx, "pack_weights");
+  hipLaunchKernelGGL((k_b6t_from_images<G>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, nimg, (const float *)ctx->wimg,
+                     (unsigned char *)ctx->wimg + wide_b6t_offset(desc));
+  NF_HIP(hipGetLastError());
+  ctx->b6t_gen = ctx->wimg_gen;
+  return NF_OK;
 }
 // NF_WIDE_FP32=1: the forward kernels on fp32 MFMAs (A/B switch)
 static bool wide_b6() {
@@ -1049,6 +1447,8 @@ static WideArgs make_wide_args(nf_ctx *ctx, const nf_flow_desc *desc, int k, lon
   a.img_t = a.img_s + G::SIZE;
   a.b6_s = (const unsigned char *)ctx->wimg + wide_b6_offset(desc) + (size_t)(2 * k) * B6Geo<G>::BYTES;
   a.b6_t = a.b6_s + B6Geo<G>::BYTES;
+  a.b6t_s = (const unsigned char *)ctx->wimg + wide_b6t_offset(desc) + (size_t)(2 * k) * B6TGeo<G>::BYTES;
+  a.b6t_t = a.b6t_s + B6TGeo<G>::BYTES;
   a.trace = (long long *)ctx->trace;
   a.d = desc->d; a.c = ci.c; a.m = ci.m; a.par_t = ci.par_t; a.N = N;
   return a;
@@ -1162,6 +1562,7 @@ static int wide_bwd(nf_ctx *ctx, const nf_flow_desc *desc, float *state, float *
     NF_HIP(hipFuncSetAttribute((const void *)k_wide_bwd<G, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bwd));
     NF_HIP(hipFuncSetAttribute((const void *)k_wide_bwd<G, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bwd));
     NF_HIP(hipFuncSetAttribute((const void *)k_wide_dw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dw));
+    NF_HIP(hipFuncSetAttribute((const void *)k_wide_dw_b6, hipFuncAttributeMaxDynamicSharedMemorySize, DW_ROWS * D6_ROW));
     return NF_OK;
   }));
   long grid = wide_groups(N);
@@ -1194,7 +1595,10 @@ static int wide_bwd(nf_ctx *ctx, const nf_flow_desc *desc, float *state, float *
       da.slab_stride = G::SIZE;
       {
         ProfScope ps(ctx, "wide_dw");
-        hipLaunchKernelGGL(k_wide_dw, dim3((unsigned)(da.njobs * ks)), dim3(256), lds_dw, ctx->stream, da, slab);
+        if (wide_b6())
+          hipLaunchKernelGGL(k_wide_dw_b6, dim3((unsigned)(da.njobs * ks)), dim3(256), DW_ROWS * D6_ROW, ctx->stream, da, slab);
+        else
+          hipLaunchKernelGGL(k_wide_dw, dim3((unsigned)(da.njobs * ks)), dim3(256), lds_dw, ctx->stream, da, slab);
         NF_HIP(hipGetLastError());
       }
       long off = ci.theta_off;
@@ -1302,13 +1706,17 @@ static int wide_train_backward(nf_ctx *ctx, const nf_flow_desc *desc, float *sta
   NF_TRY(attr_once.run(ctx->device, [&]() -> int {
     NF_HIP(hipFuncSetAttribute((const void *)k_wide_bwd_stashed<G, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bwd));
     NF_HIP(hipFuncSetAttribute((const void *)k_wide_bwd_stashed<G, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bwd));
+    NF_HIP(hipFuncSetAttribute((const void *)k_wide_bwd_stashed_b6<G, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideT<G>::LDS));
+    NF_HIP(hipFuncSetAttribute((const void *)k_wide_bwd_stashed_b6<G, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideT<G>::LDS));
     NF_HIP(hipFuncSetAttribute((const void *)k_wide_dw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dw));
+    NF_HIP(hipFuncSetAttribute((const void *)k_wide_dw_b6, hipFuncAttributeMaxDynamicSharedMemorySize, DW_ROWS * D6_ROW));
     return NF_OK;
   }));
   long grid = wide_groups(N);
   if (grid > ctx->num_cu) grid = ctx->num_cu;
   if (grid < 1) grid = 1;
-  (void)0;
+  const bool b6 = wide_b6();
+  if (b6) NF_TRY(wide_b6t_refresh(ctx, desc));
   for (int k = 0; k < nc; ++k) {  // flat order = reverse of execution order
     const WideArgs a = make_wide_args(ctx, desc, k, N);
     const CouplingInfo ci = nf_coupling_info(desc, k);
@@ -1317,7 +1725,11 @@ static int wide_train_backward(nf_ctx *ctx, const nf_flow_desc *desc, float *sta
       const int net = phase == 0 ? 1 : 0;
       {
         ProfScope ps(ctx, "wide_bwd");
-        if (phase == 0)
+        if (b6 && phase == 0)
+          hipLaunchKernelGGL((k_wide_bwd_stashed_b6<G, false>), dim3((unsigned)grid), dim3(256), WideT<G>::LDS, ctx->stream, a, state, gbar, lbar, lbar_const, st, (const float *)fs.out[net], (const unsigned *)fs.mask[net]);
+        else if (b6)
+          hipLaunchKernelGGL((k_wide_bwd_stashed_b6<G, true>), dim3((unsigned)grid), dim3(256), WideT<G>::LDS, ctx->stream, a, state, gbar, lbar, lbar_const, st, (const float *)fs.out[net], (const unsigned *)fs.mask[net]);
+        else if (phase == 0)
           hipLaunchKernelGGL((k_wide_bwd_stashed<G, false>), dim3((unsigned)grid), dim3(256), lds_bwd, ctx->stream, a, state, gbar, lbar, lbar_const, st, (const float *)fs.out[net], (const unsigned *)fs.mask[net]);
         else
           hipLaunchKernelGGL((k_wide_bwd_stashed<G, true>), dim3((unsigned)grid), dim3(256), lds_bwd, ctx->stream, a, state, gbar, lbar, lbar_const, st, (const float *)fs.out[net], (const unsigned *)fs.mask[net]);
@@ -1333,8 +1745,12 @@ static int wide_train_backward(nf_ctx *ctx, const nf_flow_desc *desc, float *sta
       da.slab_stride = G::SIZE;
       {
         ProfScope ps(ctx, "wide_dw");
-        hipLaunchKernelGGL(k_wide_dw, dim3((unsigned)(da.njobs * ks)), dim3(256), lds_dw, ctx->stream, da,
-                           slab + (size_t)(2 * k + phase) * ks * G::SIZE);
+        if (wide_b6())
+          hipLaunchKernelGGL(k_wide_dw_b6, dim3((unsigned)(da.njobs * ks)), dim3(256), DW_ROWS * D6_ROW, ctx->stream, da,
+                             slab + (size_t)(2 * k + phase) * ks * G::SIZE);
+        else
+          hipLaunchKernelGGL(k_wide_dw, dim3((unsigned)(da.njobs * ks)), dim3(256), lds_dw, ctx->stream, da,
+                             slab + (size_t)(2 * k + phase) * ks * G::SIZE);
         NF_HIP(hipGetLastError());
       }
     }
