@@ -48,6 +48,14 @@ from __graft_entry__ import load_package  # noqa: E402
 
 D, HDIMS, NLAYERS, BATCH = 64, (64, 64), 4, 65536
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16: 16 384 MACs per 32 clocks per CU-SIMD)
+# How the dominant kernel's GEMMs are executed since round 4 (DESIGN section 4 "B6"): fp32 operands as exact bf16 triples,
+# six bf16 x bf16 MFMA products per fp32 product.  `roofline.achieved / peak / frac` stay ALGORITHMIC fp32 flops against the
+# fp32-MFMA peak (the figure rounds 1-3 reported, and the only fp32-grade matrix instruction the chip has); the executed bf16
+# flops against the bf16 peak are reported beside it.  cfg 3's kernel still issues fp32 MFMAs.
+BF16X6 = {"cfg2": os.environ.get("NF_BWD_FP32") is None and os.environ.get("NF_BWD_NO_PAIR") is None
+                  and os.environ.get("NF_BWD_DW_FP32") is None and os.environ.get("NF_AFFINE_NO_STASH") is None,
+          "cfg4": os.environ.get("NF_WIDE_FP32") is None, "cfg3": False}
 # algorithmic flops of ONE coupling's reverse pass per sample (step 786 432 =
 # fwd 262 144 + dX 262 144 + dW 262 144 over 8 couplings; recompute is not counted)
 MACS_NET = 32 * 64 + 64 * 64 + 64 * 32
@@ -78,7 +86,8 @@ def select_cfg4(world: int):
     FLOPS_STEP_PER_SAMPLE = 16 * 2 * 3 * 2 * MACS_NET  # 16 couplings x 2 nets x (fwd + dX + dW)
     WORKLOAD_TEXT = ("reverse-KL ELBO step: RealNVP d=256, 16 affine couplings, conditioner 128-256-256-128 "
                      "(hdims [256,256]), diag-Gaussian target, Philox base draws, Adam; 262144 samples in total")
-    DOMINANT = (b"wide_bwd", "k_wide_bwd (reverse pass of one conditioner net: recompute + dX chain; dW is k_wide_dw)")
+    DOMINANT = (b"wide_bwd", "k_wide_bwd_stashed_b6 / k_wide_bwd_stashed (reverse pass of one conditioner net from the forward's stash: "
+                             "element-wise stage + dX chain on streamed weights; its dW GEMM is k_wide_dw)")
     KERNEL_NAMES = (b"base_sample", b"pack_weights", b"wide_apply", b"target", b"wide_bwd", b"wide_dw", b"reduce_slabs", b"adam")
 
 
@@ -465,6 +474,11 @@ def run_once(args, world, world_observed, rank, dev, dist, damp, state):
                 "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                "mfma_form": ("bf16x6: every fp32 product as six bf16 MFMA products of exactly split operands (fp32-grade, "
+                              "tools/probe/bf16x6_probe.hip); achieved / peak / frac above are ALGORITHMIC fp32 flops over the fp32-MFMA peak"
+                              if BF16X6[args.workload] else "fp32 MFMA (v_mfma_f32_32x32x2_f32)"),
+                "executed_bf16_tflops": 6.0 * achieved if BF16X6[args.workload] else None,
+                "executed_frac_of_bf16_peak": 6.0 * achieved / PEAK_BF16_MFMA_TFLOPS if BF16X6[args.workload] else None,
                 "traffic": traffic,
                 "traffic_unit": "bytes per launch (HBM: 2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC, gfx950 correction)",
                 "traffic_source": traffic_src,

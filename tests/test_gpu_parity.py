@@ -568,6 +568,23 @@ def test_wide_realnvp_matches_oracle(nf, d, hd, nl, n):
     P.scalar(f"{tag}: loglikelihood", ll, ll_ref, 1e-4, 1e-4)
 
 
+def test_wide_kernels_on_fp32_mfmas_keep_parity():
+    """NF_WIDE_FP32=1 (read once per process) switches the weight-streaming kernels back from the six-term bf16 products to
+    fp32 MFMAs -- the round-3 kernels, kept for A/B runs: the wide oracle test's two geometries run under it in a subprocess
+    (training step with in-library draws included, so the stashing forward, the stashed dX chain and the dW GEMM all run)."""
+    import subprocess
+    import sys
+
+    from __graft_entry__ import ROOT
+
+    env = dict(os.environ, NF_WIDE_FP32="1")
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-q", "-x",
+                        "-k", "test_wide_realnvp_matches_oracle and (cfg4_d256_h256 or mid_d120_h128_100) or test_wide_cfg4_shard_properties",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert " passed" in p.stdout and "failed" not in p.stdout, p.stdout[-2000:]
+
+
 def test_wide_cfg4_shard_properties(nf):
     """BASELINE cfg 4 geometry (d=256, hidden [256,256]) at one GPU's shard size of the 8-GPU job
     (32768 samples), with 2 of the 16 couplings to bound the run time: round trip, and the gradient

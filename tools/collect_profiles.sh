@@ -19,7 +19,8 @@ python3 bench.py --workload cfg4 --batch 32768 --steps 10 --warmup 3 > "$OUT/ben
 # (planar / radial BEFORE the configuration table: on one box of round 4 everything measured after the table's Float64 rows --
 # 114 ms steps of scalar fp64 -- ran 20-100 % slower for minutes, radial 397 instead of 330 us; a fresh box gave the usual numbers)
 python3 tools/bench_simple.py > "$OUT/simple.txt" 2>&1
-python3 tools/bench_configs.py --steps 30 > "$OUT/configs.txt" 2>&1
+# (the Float64 rows of the table run LAST, at the end of this script, for the same reason)
+python3 tools/bench_configs.py --steps 30 --only cfg1,cfg2_,cfg2b,cfg3,cfg4,cfg2c,cfg5,gen,fwd > "$OUT/configs.txt" 2>&1
 rocprofv3 --kernel-trace --stats -d "$OUT/kt_cfg2" -o cfg2 --output-format csv -- python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-kernel-events > "$OUT/kt_cfg2.log" 2>&1
 rocprofv3 --kernel-trace --stats -d "$OUT/kt_cfg3" -o cfg3 --output-format csv -- python3 bench.py --workload cfg3 --steps 30 --warmup 5 --no-cpu-baseline --no-kernel-events > "$OUT/kt_cfg3.log" 2>&1
 rocprofv3 --kernel-trace --stats -d "$OUT/kt_cfg4" -o cfg4 --output-format csv -- python3 bench.py --workload cfg4 --batch 32768 --steps 5 --warmup 2 --no-kernel-events > "$OUT/kt_cfg4.log" 2>&1
@@ -48,12 +49,17 @@ NF_BWD_NO_PAIR=1 python3 bench.py --no-cpu-baseline > "$OUT/bench_default_one_wa
 # round 4 A/B switches: fp32 MFMAs everywhere (the round-3 arithmetic), the bf16 six-term products also in the stashing forward
 NF_BWD_FP32=1 NF_FWD_FP32=1 python3 bench.py --no-cpu-baseline > "$OUT/bench_default_fp32_mfma_everywhere.json" 2>> "$OUT/bench_default.err"
 NF_FWD_B6_STASH=1 python3 bench.py --no-cpu-baseline > "$OUT/bench_default_b6_stashing_forward.json" 2>> "$OUT/bench_default.err"
+# the pair kernel with fp32 dW GEMMs (the producer's dX GEMMs alone on the bf16 cores), and the wide path on fp32 MFMAs
+NF_BWD_DW_FP32=1 python3 bench.py --no-cpu-baseline > "$OUT/bench_default_pair_dw_fp32.json" 2>> "$OUT/bench_default.err"
+NF_WIDE_FP32=1 python3 bench.py --workload cfg4 --batch 32768 --steps 10 --warmup 3 > "$OUT/bench_cfg4_shard_32768_fp32_mfma.json" 2>> "$OUT/bench_default.err"
+NF_WIDE_FP32=1 python3 bench.py --workload cfg4 --steps 5 --warmup 2 > "$OUT/bench_cfg4_1gpu_262144_fp32_mfma.json" 2>> "$OUT/bench_default.err"
 NF_FWD_FP32=1 python3 tools/bench_configs.py --only cfg5,fwd --steps 10 > "$OUT/configs_fp32_forward.txt" 2>&1
 NF_PLANAR_NO_MFMA=1 NF_RADIAL_NO_LANE=1 python3 tools/bench_simple.py > "$OUT/simple_no_mfma.txt" 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 -d "$OUT/pmc_cfg4_mfma" -o pmc --output-format csv -- python3 bench.py --workload cfg4 --batch 32768 --steps 3 --warmup 1 --no-kernel-events > "$OUT/pmc_cfg4_mfma.log" 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C -d "$OUT/pmc_cfg4_$C" -o pmc --output-format csv -- python3 bench.py --workload cfg4 --batch 32768 --steps 3 --warmup 1 --no-kernel-events > "$OUT/pmc_cfg4_$C.log" 2>&1
 done
+python3 tools/bench_configs.py --steps 30 --only f64 >> "$OUT/configs.txt" 2>&1
 # keep the merge-back small: per-dispatch traces can be large
 find "$OUT" -name "*kernel_trace.csv" -size +4M -delete
 find "$OUT" -name "*.csv" | head -60

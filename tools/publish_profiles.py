@@ -23,7 +23,10 @@ copies = [("bench_default.json", "bench_default.json"), ("bench_cfg3.json", "ben
           ("bench_default_one_wave_per_tile.json", "bench_default_one_wave_per_tile.json"), ("simple_no_mfma.txt", "simple_no_mfma.txt"),
           ("bench_driver_cmd.json", "bench_driver_cmd.json"), ("step_ramp_clocks.txt", "step_ramp_clocks.txt"),
           ("bench_default_fp32_mfma_everywhere.json", "bench_default_fp32_mfma_everywhere.json"),
-          ("bench_default_b6_stashing_forward.json", "bench_default_b6_stashing_forward.json"), ("configs_fp32_forward.txt", "configs_fp32_forward.txt")]
+          ("bench_default_b6_stashing_forward.json", "bench_default_b6_stashing_forward.json"), ("configs_fp32_forward.txt", "configs_fp32_forward.txt"),
+          ("bench_default_pair_dw_fp32.json", "bench_default_pair_dw_fp32.json"),
+          ("bench_cfg4_shard_32768_fp32_mfma.json", "bench_cfg4_shard32768_fp32_mfma.json"),
+          ("bench_cfg4_1gpu_262144_fp32_mfma.json", "bench_cfg4_1gpu_262144_fp32_mfma.json")]
 for w in ("cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "simple"):
     copies.append((f"kt_{w}/{w}_kernel_stats.csv", f"kernel_stats_{w}.csv"))
 for a, b in copies:
