@@ -591,23 +591,49 @@ __device__ __forceinline__ void net_forward(const float *__restrict__ img, const
 typedef unsigned nf_u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 nf_bf16x8 __attribute__((ext_vector_type(8)));
 
+// (The two subtractions of a pair of values are written on a two-element vector: hipcc issues ONE v_pk_add_f32 for both --
+// 36 instead of 44 instructions per eight values, and the splits are most of the VALU work of the bf16-form kernels.)
+typedef float nf_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned nf_u32x2 __attribute__((ext_vector_type(2)));
+#ifdef NF_SPLIT_SCALAR  // the subtractions one value at a time (A/B)
 __device__ __forceinline__ void nf_split8(const float (&v)[8], nf_u32x4 &h, nf_u32x4 &m, nf_u32x4 &l) {
+#pragma clang fp contract(off)
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {  // two values -> one dword per component: (upper half of value 2p + 1) : (upper half of value 2p)
+  for (int p = 0; p < 4; ++p) {
     const unsigned x0 = __float_as_uint(v[2 * p]), x1 = __float_as_uint(v[2 * p + 1]);
-    const float r0 = v[2 * p] - __uint_as_float(x0 & 0xFFFF0000u);      // exact
+    const float r0 = v[2 * p] - __uint_as_float(x0 & 0xFFFF0000u);
     const float r1 = v[2 * p + 1] - __uint_as_float(x1 & 0xFFFF0000u);
     const unsigned q0 = __float_as_uint(r0), q1 = __float_as_uint(r1);
-    const float l0 = r0 - __uint_as_float(q0 & 0xFFFF0000u);            // exact, at most 8 significant bits
+    const float l0 = r0 - __uint_as_float(q0 & 0xFFFF0000u);
     const float l1 = r1 - __uint_as_float(q1 & 0xFFFF0000u);
     h[p] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
     m[p] = __builtin_amdgcn_perm(q1, q0, 0x07060302u);
     l[p] = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
+  }
+}
+#else
+__device__ __forceinline__ void nf_split8(const float (&v)[8], nf_u32x4 &h, nf_u32x4 &m, nf_u32x4 &l) {
+// No contraction in here: with -ffp-contract=fast hipcc folds a multiply that PRODUCED v into the first subtraction (an fma on
+// the unrounded product), so h + m + l is then not the v every other user of the register sees -- measured as 4.5 x the
+// round-trip error of the 1 M-sample inverse / forward pair of cfg 5.
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {  // two values -> one dword per component: (upper half of value 2p + 1) : (upper half of value 2p)
+    const nf_f32x2 x = {v[2 * p], v[2 * p + 1]};
+    const nf_u32x2 xb = __builtin_bit_cast(nf_u32x2, x);
+    const nf_f32x2 r = x - __builtin_bit_cast(nf_f32x2, xb & 0xFFFF0000u);  // exact
+    const nf_u32x2 rb = __builtin_bit_cast(nf_u32x2, r);
+    const nf_f32x2 lo = r - __builtin_bit_cast(nf_f32x2, rb & 0xFFFF0000u);  // exact, at most 8 significant bits
+    const nf_u32x2 lb = __builtin_bit_cast(nf_u32x2, lo);
+    h[p] = __builtin_amdgcn_perm(xb.y, xb.x, 0x07060302u);
+    m[p] = __builtin_amdgcn_perm(rb.y, rb.x, 0x07060302u);
+    l[p] = __builtin_amdgcn_perm(lb.y, lb.x, 0x07060302u);
 #ifdef NF_SPLIT_PINNED
     __builtin_amdgcn_sched_barrier(0);  // (a pair at a time: 6 temporaries instead of 24)
 #endif
   }
 }
+#endif
 __device__ __forceinline__ f32x16 nf_mfma_bf16(nf_u32x4 a, nf_u32x4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nf_bf16x8, a), __builtin_bit_cast(nf_bf16x8, b), c, 0, 0, 0);
 }

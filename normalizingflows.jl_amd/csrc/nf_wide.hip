@@ -1154,13 +1154,16 @@ __device__ __forceinline__ void dw_job(const DwJob &jb, const DwArgs &a, int ks,
 // 16-byte LDS reads and MFMAs only: 96 bf16 MFMAs of 32 clocks per wave and tile instead of 128 fp32 ones of 64.  One LDS
 // buffer (384 rows x 208 bytes = 78 KB); the next tile waits in registers while the matrix pipe works on this one.
 __device__ __forceinline__ void nf_split2(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
-  const unsigned b0 = __float_as_uint(x0), b1 = __float_as_uint(x1);
-  const float r0 = x0 - __uint_as_float(b0 & 0xFFFF0000u), r1 = x1 - __uint_as_float(b1 & 0xFFFF0000u);
-  const unsigned q0 = __float_as_uint(r0), q1 = __float_as_uint(r1);
-  const float l0 = r0 - __uint_as_float(q0 & 0xFFFF0000u), l1 = r1 - __uint_as_float(q1 & 0xFFFF0000u);
-  h = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
-  m = __builtin_amdgcn_perm(q1, q0, 0x07060302u);
-  l = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
+#pragma clang fp contract(off)
+  const nf_f32x2 x = {x0, x1};
+  const nf_u32x2 xb = __builtin_bit_cast(nf_u32x2, x);
+  const nf_f32x2 r = x - __builtin_bit_cast(nf_f32x2, xb & 0xFFFF0000u);
+  const nf_u32x2 rb = __builtin_bit_cast(nf_u32x2, r);
+  const nf_f32x2 lo = r - __builtin_bit_cast(nf_f32x2, rb & 0xFFFF0000u);
+  const nf_u32x2 lb = __builtin_bit_cast(nf_u32x2, lo);
+  h = __builtin_amdgcn_perm(xb.y, xb.x, 0x07060302u);
+  m = __builtin_amdgcn_perm(rb.y, rb.x, 0x07060302u);
+  l = __builtin_amdgcn_perm(lb.y, lb.x, 0x07060302u);
 }
 
 template <int WI, int WO>
