@@ -119,6 +119,10 @@ __device__ __forceinline__ void wide_fwd_chunk(const float *__restrict__ ch, con
 // The same chunk GEMM on the bf16 matrix cores: `ch` holds the two k-groups of this input block as bf16 triples, the input
 // block is split here (16 values -> 2 x 3 x 4 registers); pipeline unit = (k-group, output block), its three A operands
 // requested one unit ahead (dense_fwd_b6 of nf_mfma.h without the bias start).
+// (Measured and removed: the next chunk's DMA spread over the units instead of issued in one block in front of the loop.  The
+// block costs ~900 clocks per 48-KB chunk -- 12 LDS-DMA instructions per wave through the CU's one texture-address path -- but
+// inside the loop every piece delays the dependent MFMA chain by ~40 clocks: 4.35 k against 4.68 k clocks per chunk in the
+// trace, 115 / 80 us per launch against 114 / 77 for forward / reverse in the untraced kernels.)
 template <int OB>
 __device__ __forceinline__ void wide_fwd_chunk_b6(const float *__restrict__ ch, const f32x16 &in, f32x16 (&out)[OB], int l31,
                                                   int hi, const DmaJob &dma) {
@@ -264,10 +268,14 @@ __device__ __forceinline__ void wide_net_fwd(wide_img_t img, const float *__rest
       dj = DmaJob{img, C::O3, C::N3, cb + (buf ^ 1) * C::CHBUF, wave, lane};
     const DmaJob none{img, 0, 0, cb, wave, lane};
     if constexpr (B6) {  // the DMA in front of the hook's stores (wide_chunk_barrier)
+      if (ib < 4) WIDE_STAMP(32 + 4 * ib);  // (tools/trace_wide_apply.py: inside the first chunks of layer 2)
       dj.issue();
       hk.l2_step(ib, a1);
+      if (ib < 4) WIDE_STAMP(33 + 4 * ib);
       wide_fwd_chunk_b6<G::H2B>(cb + buf * C::CHBUF, a1[ib], a2, l31, hi, none);
+      if (ib < 4) WIDE_STAMP(34 + 4 * ib);
       wide_chunk_barrier<HK::YOUNG>();
+      if (ib < 4) WIDE_STAMP(35 + 4 * ib);
     } else {
       hk.l2_step(ib, a1);
       wide_fwd_chunk<G::H2B, G::S2>(cb + buf * C::CHBUF, a1[ib], a2, l31, hi, dj);

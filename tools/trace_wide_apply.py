@@ -48,4 +48,9 @@ for base, net in ((0, "s net"), (16, "t net")):
         print(f"   {names[k]:30s} +{t[base + k] - prev:7d}")
         prev = t[base + k]
 print(f"   element-wise, stores            +{t[23] - t[22]:7d}")
+if t[32]:
+    print("inside layer 2 of the t net's... last traced net, chunks 0-3: DMA issue + stash stores | GEMM (96 bf16 MFMAs = 3072) | barrier wait")
+    for ib in range(4):
+        b = 32 + 4 * ib
+        print(f"   chunk {ib}: +{t[b + 1] - t[b]:6d} | +{t[b + 2] - t[b + 1]:6d} | +{t[b + 3] - t[b + 2]:6d}")
 print(f"group total {t[23] - t[0]} clocks; bf16 MFMAs alone 2 x 1536 x 32 = 98304, fp32 MFMAs alone 2 x 2048 x 64 = 262144")
