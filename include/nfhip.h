@@ -221,7 +221,9 @@ int nf_layer_apply(nf_ctx *ctx, const nf_flow_desc *desc, int32_t layer, int32_t
  * The pullback differentiates the forward's OWN activations and leaky-ReLU slopes (nothing is re-derived by inverting
  * the flow in float32), leaves the tape intact (it may be called again) and costs what the built-in training step's
  * reverse pass costs.  nf_tape_bytes depends on the context's nf_ctx_set_stash_budget setting (0 = keep only the flow
- * output and recompute by inversion): both calls must run under the setting the size was queried with.
+ * output and recompute by inversion; a positive budget -- or the default 4 GiB -- smaller than the activations of THIS
+ * batch does the same for it: the tape never exceeds the budget, callers who want the forward's own activations for a
+ * larger batch split it): both calls must run under the setting the size was queried with.
  * y_out may alias x_in; xbar_out may alias ybar, or be NULL for a single-family float32 coupling flow on the MFMA
  * kernels when only the parameter gradient is wanted (NF_ERR_ARG otherwise); gtheta_out[P] is overwritten. */
 int64_t nf_tape_bytes(nf_ctx *ctx, const nf_flow_desc *desc, int64_t N);

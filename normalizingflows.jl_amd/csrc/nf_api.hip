@@ -831,14 +831,18 @@ static inline bool affine_stash_off(nf_ctx *ctx) {
   static const bool env_off = std::getenv("NF_AFFINE_NO_STASH") != nullptr;
   return ctx->stash_budget == 0 || (ctx->stash_budget < 0 && env_off);
 }
-static TapeKind tape_kind(nf_ctx *ctx, const nf_flow_desc *g) {
+// The activation stash is kept only while it passes the SAME budget test as the training step's (nf_ctx_set_stash_budget, or
+// NF_AFFINE_STASH_MAX_MB: default 4 GiB): a batch whose stash would exceed it keeps the tiled flow output instead and its
+// pullback recomputes (these entry points used to size the stash for the whole batch whatever the budget said --
+// 12 GiB at N = 1 M).  Forward and pullback of one tape must see the same budget.
+static TapeKind tape_kind(nf_ctx *ctx, const nf_flow_desc *g, long N) {
   if (!is_coupling(g)) return TAPE_X;
   if (is_wide(g)) return TAPE_WIDE;
   if (is_nsf(g)) return TAPE_TILED_Y;
-  return affine_stash_off(ctx) ? TAPE_TILED_Y : TAPE_AFFINE_STASH;
+  return affine_stash_bytes(ctx, g, N) ? TAPE_AFFINE_STASH : TAPE_TILED_Y;
 }
 static size_t tape_seg_bytes(nf_ctx *ctx, const nf_flow_desc *g, long N) {
-  switch (tape_kind(ctx, g)) {
+  switch (tape_kind(ctx, g, N)) {
     case TAPE_X: return carve_bytes((size_t)N * g->d * esize(g->dtype));
     case TAPE_AFFINE_STASH: return carve_bytes(nf_affine_stash_floats(g, N) * 4);
     case TAPE_TILED_Y: return carve_bytes(tiled_elems(g, N) * 4) + rqs_tape_b(g, N);  // spline couplings: + bins and xi
@@ -858,7 +862,7 @@ static size_t tape_fwd_need_seg(nf_ctx *, const nf_flow_desc *g, long N) {
 }
 static size_t tape_bwd_need_seg(nf_ctx *ctx, const nf_flow_desc *g, long N) {
   const size_t tb = is_coupling(g) ? carve_bytes(tiled_elems(g, N) * 4) : 0;
-  switch (tape_kind(ctx, g)) {
+  switch (tape_kind(ctx, g, N)) {
     case TAPE_X: return flat_bwd_ws_bytes(ctx, g, N);
     case TAPE_AFFINE_STASH: return tb + carve_bytes((size_t)coupling_bwd_grid(ctx, g, N) * coupling_slab_floats(ctx, g, N) * 4);
     case TAPE_TILED_Y: return 2 * tb + carve_bytes((size_t)coupling_bwd_grid(ctx, g, N) * coupling_slab_floats(ctx, g, N) * 4);
@@ -884,7 +888,7 @@ static size_t tape_need(nf_ctx *ctx, const nf_flow_desc *desc, long N, bool bwd)
 // forward of ONE homogeneous segment, leaving its tape; y_out may alias x_in
 static int tape_fwd_seg(nf_ctx *ctx, const nf_flow_desc *g, const void *theta, const void *x_in, long N, void *y_out, void *ladj,
                         void *tape) {
-  const TapeKind tk = tape_kind(ctx, g);
+  const TapeKind tk = tape_kind(ctx, g, N);
   if (tk == TAPE_X) {
     NF_HIP(hipMemcpyAsync(tape, x_in, (size_t)N * g->d * esize(g->dtype), hipMemcpyDeviceToDevice, ctx->stream));
     return flat_apply(ctx, g, 0, nf_layer_count(g), false, theta, x_in, N, y_out, ladj);
@@ -912,7 +916,7 @@ static int tape_fwd_seg(nf_ctx *ctx, const nf_flow_desc *g, const void *theta, c
 // log-det cotangent is lbar_const.  The tape is left intact (a pullback may be called more than once).
 static int tape_bwd_seg(nf_ctx *ctx, const nf_flow_desc *g, const void *theta, const void *tape, const void *ybar,
                         const void *lbar, double lbar_const, long N, void *xbar_out, void *gtheta_out) {
-  const TapeKind tk = tape_kind(ctx, g);
+  const TapeKind tk = tape_kind(ctx, g, N);
   if (tk == TAPE_X) {
     NF_TRY(nf_ws_reserve(ctx, flat_bwd_ws_bytes(ctx, g, N)));
     return flat_bwd(ctx, g, theta, tape, ybar, lbar, lbar_const, N, xbar_out, gtheta_out, ctx->ws);

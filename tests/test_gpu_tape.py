@@ -120,6 +120,15 @@ def test_tape_size_follows_the_stash_setting_and_short_tapes_are_refused(nf):
         err = float(np.abs(g.cpu().numpy() - g_ref).max() / np.abs(g_ref).max())
         P.record("tape realnvp_d64_h64 stash_budget(0) (explicit recompute): pullback gtheta [max abs err / |g|inf]", err)
         assert err < 5e-3
+        # a POSITIVE budget below this batch's stash is honoured by the tape entry points too (they used to size the
+        # stash for the whole batch whatever the budget said): the tape shrinks to the tiled output, the pullback recomputes
+        nf._lib.check(lib.nf_ctx_set_stash_budget(ctx.ptr, nb // 2))
+        assert int(lib.nf_tape_bytes(ctx.ptr, C.byref(flow.desc), n)) == nb0
+        (y, ladj), pullback = nf.flows.rrule_with_logabsdet_jacobian(flow.transform, cm(xs, dt))
+        _, g = pullback(cm(ybar, dt), torch.tensor(lbar, dtype=dt, device="cuda"))
+        assert float(np.abs(g.cpu().numpy() - g_ref).max() / np.abs(g_ref).max()) < 5e-3
+        nf._lib.check(lib.nf_ctx_set_stash_budget(ctx.ptr, nb))  # ... and a budget that holds it keeps the stash
+        assert int(lib.nf_tape_bytes(ctx.ptr, C.byref(flow.desc), n)) == nb
     finally:
         nf._lib.check(lib.nf_ctx_set_stash_budget(ctx.ptr, -1))
     x_t = cm(xs, dt)
