@@ -286,6 +286,41 @@ def _split_reference_steps(nf, flow, tgt, n, seed, nsteps, ctx):
     return th, m, v, stats
 
 
+@pytest.mark.parametrize("kind", ["realnvp", "realnvp_wide", "nsf", "planar"])
+def test_empty_batches_and_empty_shards(nf, kind):
+    """The reference's batched calls accept a d x 0 matrix (an empty `xs` gives empty `ys` / `ladj`), and a sample-sharded
+    step can leave a rank with NO samples (n_global < world size, or a ragged tail): every entry point takes N = 0 -- nothing
+    is written to the outputs of a transform and a shard's [grad ; loss] contribution is exactly zero (nf_elbo_value_and_grad,
+    the entry point with explicit shard arguments)."""
+    d, flow = {"realnvp": (64, lambda: nf.realnvp(nf.MvNormal(64), (64, 64), 2, paramtype=torch.float32, seed=1)),
+               "realnvp_wide": (96, lambda: nf.realnvp(nf.MvNormal(96), (128, 100), 1, paramtype=torch.float32, seed=1)),
+               "nsf": (32, lambda: nf.nsf(nf.MvNormal(32), (32, 32), 8, 5.0, 2, paramtype=torch.float32, seed=1)),
+               "planar": (64, lambda: nf.planarflow(nf.MvNormal(64), 4, paramtype=torch.float32, seed=1))}[kind]
+    flow = flow()
+    lib, ctx = nf.load_library(), flow.ctx
+    vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    x = torch.full((d,), 7.0, device="cuda")
+    y, ladj = torch.full((d,), 3.0, device="cuda"), torch.full((1,), 5.0, device="cuda")
+    nf._lib.check(lib.nf_flow_fwd(ctx.ptr, C.byref(flow.desc), vp(flow.theta), vp(x), 0, vp(y), vp(ladj)))
+    nf._lib.check(lib.nf_flow_inv(ctx.ptr, C.byref(flow.desc), vp(flow.theta), vp(x), 0, vp(y), vp(ladj)))
+    torch.cuda.synchronize()
+    assert float(y[0]) == 3.0 and float(ladj[0]) == 5.0  # untouched
+    rng = np.random.default_rng(0)
+    tgt = nf.DiagGaussTarget(torch.tensor(rng.standard_normal(d), dtype=torch.float32, device="cuda"),
+                             torch.tensor(rng.uniform(size=d) + 0.5, dtype=torch.float32, device="cuda"))
+    out = torch.full((flow.P + 1,), 9.0, device="cuda")
+    # an empty shard of a 1000-sample global batch
+    nf._lib.check(lib.nf_elbo_value_and_grad(ctx.ptr, C.byref(flow.desc), C.byref(tgt.c), vp(flow.theta), None, 0, 1000, 1, 1000, 0, vp(out)))
+    assert float(out.abs().max()) == 0.0
+    # nf_elbo_step shards equally (N = every rank's batch): an empty batch there is an argument error, not a silent no-op
+    th, m, v = flow.theta.clone(), torch.zeros_like(flow.theta), torch.zeros_like(flow.theta)
+    assert lib.nf_elbo_step(ctx.ptr, C.byref(flow.desc), C.byref(tgt.c), vp(th), vp(m), vp(v), 0, 1, 0, 1e-3, 0.9, 0.999, 1e-8, None, None) == -1  # NF_ERR_ARG (include/nfhip.h)
+    assert torch.equal(th, flow.theta)
+    # the host mirror's shard arithmetic: more ranks than samples
+    from normalizingflows_jl_amd.parallel import shard_range
+    assert [shard_range(3, r, 8) for r in range(8)] == [(0, 1), (1, 1), (2, 1), (3, 0), (3, 0), (3, 0), (3, 0), (3, 0)]
+
+
 @pytest.mark.parametrize("cache", [False, True])
 @pytest.mark.parametrize("shape", ["d64_h64", "d20_h32"])
 def test_three_launch_step_equals_split_calls_over_consecutive_steps(nf, shape, cache):
