@@ -1159,8 +1159,9 @@ __device__ __forceinline__ void dw_job(const DwJob &jb, const DwArgs &a, int ks,
 // by the thread that brought them in, on their way into LDS (a row's 32 samples as bf16 triples in the D6 layout of
 // nf_mfma.h: [component][sample group][parity][8] x 2 bytes, sample = 2 (8 g + j) + parity -- a thread's four consecutive
 // samples are two (even, odd) pairs of neighbouring k-slots, i.e. two packed dwords per component), so the GEMM loop is
-// 16-byte LDS reads and MFMAs only: 96 bf16 MFMAs of 32 clocks per wave and tile instead of 128 fp32 ones of 64.  One LDS
-// buffer (384 rows x 208 bytes = 78 KB); the next tile waits in registers while the matrix pipe works on this one.
+// 16-byte LDS reads and MFMAs only: 96 bf16 MFMAs of 32 clocks per wave and tile instead of 128 fp32 ones of 64.  Two LDS
+// buffers (384 rows x 208 bytes = 78 KB each, 156 of the CU's 160 KB): the next tile is fetched into registers behind the
+// MFMAs, split and stored into the other buffer, one barrier per tile.
 __device__ __forceinline__ void nf_split2(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
 #pragma clang fp contract(off)
   const nf_f32x2 x = {x0, x1};
@@ -1182,8 +1183,9 @@ __device__ __forceinline__ void dw_job_b6(const DwJob &jb, const DwArgs &a, int 
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
   const int wi = wave / WO, wo = wave % WO;
-  const int lrow = tid >> 3, part = tid & 7;
+  const int lrow = tid >> 2, part = tid & 3;  // a thread brings in EIGHT consecutive samples of a row (two 16-byte loads)
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
   f32x16 acc[4][2];
   float bsum[2] = {0.f, 0.f};
@@ -1200,43 +1202,49 @@ __device__ __forceinline__ void dw_job_b6(const DwJob &jb, const DwArgs &a, int 
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(wave_uniform_ptr(jb.D + tile * jb.d_tile_stride), 0, jb.d_extent, 0x00020000);
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
-      const int row = lrow + 32 * k;
-      if (32 * k < AROWS)
-        stg[k] = __builtin_amdgcn_raw_buffer_load_b128(ra, ((jb.a_row0 + row) * jb.a_rstride + jb.a_roff) * 128 + part * 16, 0, 0);
+      const int row = lrow + 64 * (k >> 1), seg = part * 32 + (k & 1) * 16;
+      if (64 * (k >> 1) < AROWS)
+        stg[k] = __builtin_amdgcn_raw_buffer_load_b128(ra, ((jb.a_row0 + row) * jb.a_rstride + jb.a_roff) * 128 + seg, 0, 0);
       else
-        stg[k] = __builtin_amdgcn_raw_buffer_load_b128(rd, (jb.d_row0 + row - AROWS) * 128 + part * 16, 0, 0);
+        stg[k] = __builtin_amdgcn_raw_buffer_load_b128(rd, (jb.d_row0 + row - AROWS) * 128 + seg, 0, 0);
     }
   };
-  // samples 4 part .. 4 part + 3 of a row: the even pair is slots j, j + 1 of (group part >> 2, parity 0), the odd pair of parity 1
-  char *pp = lds + lrow * D6_ROW + (part >> 2) * 32 + (part & 3) * 4;
-  auto put_tile = [&]() {
+  // samples 8 part .. 8 part + 7 of a row: the four even ones are slots j .. j + 3 of (group part >> 1, parity 0) -- two packed
+  // dwords side by side, one ds_write_b64 per component --, the four odd ones the same slots of parity 1
+  const int poff = lrow * D6_ROW + (part >> 1) * 32 + (part & 1) * 8;
+  auto put_tile = [&](char *dst) {
 #pragma unroll
-    for (int k = 0; k < NLD; ++k) {
-      const unsigned v0 = stg[k].x, v1 = stg[k].y, v2 = stg[k].z, v3 = stg[k].w;  // (bit_cast of a vector-element expression reads element 0)
-      unsigned eh, em, el, oh, om, ol;
-      nf_split2(__uint_as_float(v0), __uint_as_float(v2), eh, em, el);
-      nf_split2(__uint_as_float(v1), __uint_as_float(v3), oh, om, ol);
-      unsigned *p = reinterpret_cast<unsigned *>(pp + 32 * k * D6_ROW);
-      p[0] = eh; p[4] = oh;          // component h: parity 0 at +0, parity 1 at +16 bytes
-      p[16] = em; p[20] = om;        // component m at +64 bytes
-      p[32] = el; p[36] = ol;        // component l at +128 bytes
+    for (int k = 0; k < NLD; k += 2) {
+      const unsigned a0 = stg[k].x, a1 = stg[k].y, a2 = stg[k].z, a3 = stg[k].w;  // (bit_cast of a vector-element expression reads element 0)
+      const unsigned b0 = stg[k + 1].x, b1 = stg[k + 1].y, b2 = stg[k + 1].z, b3 = stg[k + 1].w;
+      unsigned eh0, em0, el0, eh1, em1, el1, oh0, om0, ol0, oh1, om1, ol1;
+      nf_split2(__uint_as_float(a0), __uint_as_float(a2), eh0, em0, el0);
+      nf_split2(__uint_as_float(b0), __uint_as_float(b2), eh1, em1, el1);
+      nf_split2(__uint_as_float(a1), __uint_as_float(a3), oh0, om0, ol0);
+      nf_split2(__uint_as_float(b1), __uint_as_float(b3), oh1, om1, ol1);
+      u32x2 *p = reinterpret_cast<u32x2 *>(dst + poff + 64 * (k >> 1) * D6_ROW);
+      p[0] = u32x2{eh0, eh1}; p[2] = u32x2{oh0, oh1};      // component h: parity 0 at +0, parity 1 at +16 bytes
+      p[8] = u32x2{em0, em1}; p[10] = u32x2{om0, om1};     // component m at +64 bytes
+      p[16] = u32x2{el0, el1}; p[18] = u32x2{ol0, ol1};    // component l at +128 bytes
     }
   };
 
   long tile = ks;
   if (tile < a.ntiles) {
     load_tile(tile);
-    put_tile();
+    put_tile(lds);
   }
   __syncthreads();
-  const nf_u32x4 *pa = reinterpret_cast<const nf_u32x4 *>(lds + (wi * 128 + l31) * D6_ROW + hi * 16);
-  const nf_u32x4 *pd = reinterpret_cast<const nf_u32x4 *>(lds + (AROWS + wo * 64 + l31) * D6_ROW + hi * 16);
+  int buf = 0;
   constexpr int RB = 32 * D6_ROW / 16;  // 16-byte units per block of 32 rows
   const unsigned ones = 0x3F803F80u;
   const bool need_bias = jb.b_off >= 0 && wi == 0;
   for (; tile < a.ntiles; tile += a.ksplit) {
     const bool has_next = tile + a.ksplit < a.ntiles;
     if (has_next) load_tile(tile + a.ksplit);
+    const char *cur = lds + buf * (DW_ROWS * D6_ROW);
+    const nf_u32x4 *pa = reinterpret_cast<const nf_u32x4 *>(cur + (wi * 128 + l31) * D6_ROW + hi * 16);
+    const nf_u32x4 *pd = reinterpret_cast<const nf_u32x4 *>(cur + (AROWS + wo * 64 + l31) * D6_ROW + hi * 16);
     nf_u32x4 An[4][3], Dn[2][3];  // the operands of the sample group after this one: requested behind its 48 MFMAs
 #pragma unroll
     for (int ib = 0; ib < 4; ++ib)
@@ -1284,9 +1292,9 @@ __device__ __forceinline__ void dw_job_b6(const DwJob &jb, const DwArgs &a, int 
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();  // every wave is done reading this tile
-    if (has_next) put_tile();
+    if (has_next) put_tile(lds + (buf ^ 1) * (DW_ROWS * D6_ROW));  // the other buffer: nobody reads it before the barrier
     __syncthreads();
+    buf ^= 1;
   }
 
   // partial result in image layout
@@ -1573,7 +1581,7 @@ static int wide_bwd(nf_ctx *ctx, const nf_flow_desc *desc, float *state, float *
     NF_HIP(hipFuncSetAttribute((const void *)k_wide_bwd<G, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bwd));
     NF_HIP(hipFuncSetAttribute((const void *)k_wide_bwd<G, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bwd));
     NF_HIP(hipFuncSetAttribute((const void *)k_wide_dw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dw));
-    NF_HIP(hipFuncSetAttribute((const void *)k_wide_dw_b6, hipFuncAttributeMaxDynamicSharedMemorySize, DW_ROWS * D6_ROW));
+    NF_HIP(hipFuncSetAttribute((const void *)k_wide_dw_b6, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DW_ROWS * D6_ROW));
     return NF_OK;
   }));
   long grid = wide_groups(N);
@@ -1607,7 +1615,7 @@ static int wide_bwd(nf_ctx *ctx, const nf_flow_desc *desc, float *state, float *
       {
         ProfScope ps(ctx, "wide_dw");
         if (wide_b6())
-          hipLaunchKernelGGL(k_wide_dw_b6, dim3((unsigned)(da.njobs * ks)), dim3(256), DW_ROWS * D6_ROW, ctx->stream, da, slab);
+          hipLaunchKernelGGL(k_wide_dw_b6, dim3((unsigned)(da.njobs * ks)), dim3(256), 2 * DW_ROWS * D6_ROW, ctx->stream, da, slab);
         else
           hipLaunchKernelGGL(k_wide_dw, dim3((unsigned)(da.njobs * ks)), dim3(256), lds_dw, ctx->stream, da, slab);
         NF_HIP(hipGetLastError());
@@ -1720,7 +1728,7 @@ static int wide_train_backward(nf_ctx *ctx, const nf_flow_desc *desc, float *sta
     NF_HIP(hipFuncSetAttribute((const void *)k_wide_bwd_stashed_b6<G, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideT<G>::LDS));
     NF_HIP(hipFuncSetAttribute((const void *)k_wide_bwd_stashed_b6<G, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideT<G>::LDS));
     NF_HIP(hipFuncSetAttribute((const void *)k_wide_dw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dw));
-    NF_HIP(hipFuncSetAttribute((const void *)k_wide_dw_b6, hipFuncAttributeMaxDynamicSharedMemorySize, DW_ROWS * D6_ROW));
+    NF_HIP(hipFuncSetAttribute((const void *)k_wide_dw_b6, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DW_ROWS * D6_ROW));
     return NF_OK;
   }));
   long grid = wide_groups(N);
@@ -1757,7 +1765,7 @@ static int wide_train_backward(nf_ctx *ctx, const nf_flow_desc *desc, float *sta
       {
         ProfScope ps(ctx, "wide_dw");
         if (wide_b6())
-          hipLaunchKernelGGL(k_wide_dw_b6, dim3((unsigned)(da.njobs * ks)), dim3(256), DW_ROWS * D6_ROW, ctx->stream, da,
+          hipLaunchKernelGGL(k_wide_dw_b6, dim3((unsigned)(da.njobs * ks)), dim3(256), 2 * DW_ROWS * D6_ROW, ctx->stream, da,
                              slab + (size_t)(2 * k + phase) * ks * G::SIZE);
         else
           hipLaunchKernelGGL(k_wide_dw, dim3((unsigned)(da.njobs * ks)), dim3(256), lds_dw, ctx->stream, da,
