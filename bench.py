@@ -482,6 +482,10 @@ def run_once(args, world, world_observed, rank, dev, dist, damp, state):
                 "traffic": traffic,
                 "traffic_unit": "bytes per launch (HBM: 2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC, gfx950 correction)",
                 "traffic_source": traffic_src,
+                # the implementation's HBM bytes over the launch time: what the kernel actually pulls (the activation stash), next to
+                # what a plain copy / read / write loop reaches on an MI355X of this pool (tools/probe/peaks_probe.hip)
+                "traffic_rate_TBps": None if not traffic or avg_ms.value <= 0 else traffic / (avg_ms.value * 1e-3) / 1e12,
+                "measured_hbm_TBps": {"copy": 4.66, "read": 6.29, "write": 3.91, "source": "profiles/r4w_peaks_probe.txt"},
                 "avg_launch_ms": avg_ms.value,
                 "launches_timed": cnt.value,
                 "timed_inside_the_timed_region": events_in_timed_region,
