@@ -257,6 +257,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_affine_epilogue(PackArgs p, EpiA
       constexpr int W = WAVES;
       int s = q;
       // eight loads in flight per thread (same summation order as the four-way loop below: 39-41 -> 37 us at cfg 2)
+      // (round 4, measured and removed: four elements per thread with 16-byte loads -- 35.6-36.2 us, no change; 16 waves per
+      // block instead of 4 -- 45 us)
       for (; s + 7 * W < a.nslab; s += 8 * W) {
         const float v0 = a.slab[(long)s * a.slab_stride + gid], v1 = a.slab[(long)(s + W) * a.slab_stride + gid];
         const float v2 = a.slab[(long)(s + 2 * W) * a.slab_stride + gid], v3 = a.slab[(long)(s + 3 * W) * a.slab_stride + gid];
