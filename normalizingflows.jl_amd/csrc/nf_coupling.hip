@@ -1179,6 +1179,9 @@ struct BwdStashLds {
 // s and u of a phase-S tile are loaded one tile ahead, into the same registers, while the previous tile runs its last
 // two GEMMs: every wave of the chip asks for its tile's operands at the same moment (25 MB at once), and without the
 // head start the element-wise stage waits 3.5-6.7 k cycles for them (tools/trace_bwd_stashed.py).
+// (Round 4, measured and removed: the tile's two cotangent halves requested the same way in the pair kernel's phase S -- 32
+// more registers in the producer, no spills, 339-341 us per launch against 338-342 without, and the inverse-direction kernel
+// 1 944 us per chunk against 1 680.)
 template <class G>
 struct StashFirst {
   f32x16 sv[G::CB], uv[G::CB];
