@@ -90,14 +90,53 @@ __device__ void g64_net_bwd(const T *__restrict__ th, const G64Net &n, const T *
         *p = first ? v : *p + v;
       }
     }
+    constexpr bool F64_MFMA = sizeof(T) == 8 && G64_BLOCK == 64;
+    if constexpr (F64_MFMA) {
+      // Float64 (round 4): the weight gradient of the layer, dW[i][j] = sum over the wave's 64 samples of prev_s[i] delta_s[j], is
+      // a GEMM with K = samples.  One wave sum per element (12 cross-lane steps each) was nine tenths of the Float64 step;
+      // here the samples' rows go through LDS -- prev in chunks of 64 inputs, delta in chunks of 16 outputs -- and a 16 x 16
+      // block of dW is 16 v_mfma_f64_16x16x4_f64 (lane l supplies A[l & 15][l >> 4], B[l >> 4][l & 15] and receives
+      // D[(l >> 4) + 4 r][l & 15], r = 0 .. 3: tools/probe/mfma_f64_probe.hip).  The sum over samples is the instruction's
+      // (a fixed order); every lane writes its four elements of the block.
+      typedef double f64x4 __attribute__((ext_vector_type(4)));
+      __shared__ double pbuf[64 * 65], dbuf[64 * 17];
+      const int lane = threadIdx.x & 63, c16 = lane & 15, kq = lane >> 4;
+      for (int i0 = 0; i0 < nin; i0 += 64) {
+        __syncthreads();
+        for (int ii = 0; ii < 64; ++ii) pbuf[lane * 65 + ii] = i0 + ii < nin ? (double)prev[i0 + ii] : 0.0;
+        for (int j0 = 0; j0 < nout; j0 += 16) {
+          __syncthreads();
+          for (int jj = 0; jj < 16; ++jj) dbuf[lane * 17 + jj] = j0 + jj < nout ? (double)delta[j0 + jj] : 0.0;
+          __syncthreads();
+          for (int ib = 0; ib < 4 && i0 + 16 * ib < nin; ++ib) {
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks)
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pbuf[(4 * ks + kq) * 65 + 16 * ib + c16], dbuf[(4 * ks + kq) * 17 + c16], acc, 0, 0, 0);
+            const int j = j0 + c16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int i = i0 + 16 * ib + kq + 4 * r;
+              if (i < nin && j < nout) {
+                T *p = slab + (n.w[l] + (long)i * nout + j - slab_off);
+                *p = first ? (T)acc[r] : *p + (T)acc[r];
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
     for (int i = 0; i < nin; ++i) {
       T s = (T)0.0;
       for (int j = 0; j < nout; ++j) {
         s += W[(long)i * nout + j] * delta[j];
-        const T v = g64_wave_sum(prev[i] * delta[j]);
-        if (writer) {
-          T *p = slab + (n.w[l] + (long)i * nout + j - slab_off);
-          *p = first ? v : *p + v;
+        if constexpr (!F64_MFMA) {
+          const T v = g64_wave_sum(prev[i] * delta[j]);
+          if (writer) {
+            T *p = slab + (n.w[l] + (long)i * nout + j - slab_off);
+            *p = first ? v : *p + v;
+          }
         }
       }
       if (l == 0) din[i] = s;
