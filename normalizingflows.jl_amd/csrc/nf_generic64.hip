@@ -53,9 +53,9 @@ __device__ void g64_net_fwd(const T *__restrict__ th, const G64Net &n, const T *
     const int nin = n.dims[l], nout = n.dims[l + 1];
     const T *W = th + n.w[l], *b = th + n.b[l];
     T *dst = (l < n.nl - 1) ? acts[l] : out;
-    // eight outputs at a time: an input (a per-thread array: scratch memory) is fetched once per eight FMAs instead of once
+    // sixteen outputs at a time: an input (a per-thread array: scratch memory) is fetched once per sixteen FMAs instead of once
     // per FMA; every output is still the sum over i in ascending order, bit for bit what the one-at-a-time loop gave
-    constexpr int JB = 8;
+    constexpr int JB = 16;
     for (int j0 = 0; j0 < nout; j0 += JB) {
       T acc[JB];
 #pragma unroll
@@ -106,25 +106,28 @@ __device__ void g64_net_bwd(const T *__restrict__ th, const G64Net &n, const T *
     if constexpr (F64_MFMA) {
       // Float64 (round 4): the weight gradient of the layer, dW[i][j] = sum over the wave's 64 samples of prev_s[i] delta_s[j], is
       // a GEMM with K = samples.  One wave sum per element (12 cross-lane steps each) was nine tenths of the Float64 step;
-      // here the samples' rows go through LDS -- prev in chunks of 64 inputs, delta in chunks of 16 outputs -- and a 16 x 16
+      // here the samples' rows go through LDS -- prev in chunks of 32 inputs, delta in chunks of 16 outputs (25 KB: six waves
+      // per CU; with 64-input chunks it was 42 KB and three, and the scratch-bound GEMVs around this ran with nothing to hide
+      // their latency behind) -- and a 16 x 16
       // block of dW is 16 v_mfma_f64_16x16x4_f64 (lane l supplies A[l & 15][l >> 4], B[l >> 4][l & 15] and receives
       // D[(l >> 4) + 4 r][l & 15], r = 0 .. 3: tools/probe/mfma_f64_probe.hip).  The sum over samples is the instruction's
       // (a fixed order); every lane writes its four elements of the block.
       typedef double f64x4 __attribute__((ext_vector_type(4)));
-      __shared__ double pbuf[64 * 65], dbuf[64 * 17];
+      constexpr int PC = 16;  // inputs per staged chunk
+      __shared__ double pbuf[64 * (PC + 1)], dbuf[64 * 17];
       const int lane = threadIdx.x & 63, c16 = lane & 15, kq = lane >> 4;
-      for (int i0 = 0; i0 < nin; i0 += 64) {
+      for (int i0 = 0; i0 < nin; i0 += PC) {
         __syncthreads();
-        for (int ii = 0; ii < 64; ++ii) pbuf[lane * 65 + ii] = i0 + ii < nin ? (double)prev[i0 + ii] : 0.0;
+        for (int ii = 0; ii < PC; ++ii) pbuf[lane * (PC + 1) + ii] = i0 + ii < nin ? (double)prev[i0 + ii] : 0.0;
         for (int j0 = 0; j0 < nout; j0 += 16) {
           __syncthreads();
           for (int jj = 0; jj < 16; ++jj) dbuf[lane * 17 + jj] = j0 + jj < nout ? (double)delta[j0 + jj] : 0.0;
           __syncthreads();
-          for (int ib = 0; ib < 4 && i0 + 16 * ib < nin; ++ib) {
+          for (int ib = 0; ib < PC / 16 && i0 + 16 * ib < nin; ++ib) {
             f64x4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks)
-              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pbuf[(4 * ks + kq) * 65 + 16 * ib + c16], dbuf[(4 * ks + kq) * 17 + c16], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pbuf[(4 * ks + kq) * (PC + 1) + 16 * ib + c16], dbuf[(4 * ks + kq) * 17 + c16], acc, 0, 0, 0);
             const int j = j0 + c16;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
