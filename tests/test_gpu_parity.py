@@ -568,6 +568,24 @@ def test_wide_realnvp_matches_oracle(nf, d, hd, nl, n):
     P.scalar(f"{tag}: loglikelihood", ll, ll_ref, 1e-4, 1e-4)
 
 
+def test_float64_general_path_with_several_sample_tiles_per_workgroup(nf):
+    """Float64 RealNVP with 200-wide nets at N = 50 000: the reverse kernel's grid is capped by its slab memory (388 workgroups
+    here), so every workgroup walks two 64-sample tiles and ACCUMULATES into its slab -- the `first == false` branch of the
+    weight-gradient GEMM (v_mfma_f64_16x16x4_f64 since round 4) and of the bias sums, which the small fixtures never reach."""
+    d, hd, nl, n = 16, (200, 200), 1, 50000
+    spec = o.FlowSpec("realnvp", d, nl, hd)
+    rng = np.random.default_rng(3)
+    th = o.init_params(spec, rng) + 0.02 * rng.standard_normal(o.param_count(spec))
+    flow = nf.Flow("realnvp", nf.MvNormal(d), nl, hd, dtype=torch.float64, device="cuda", theta=torch.tensor(th, device="cuda"))
+    xs = rng.standard_normal((d, n))
+    mu, var = rng.standard_normal(d), rng.uniform(size=d) + 0.5
+    tgt = nf.DiagGaussTarget(torch.tensor(mu, device="cuda"), torch.tensor(var, device="cuda"))
+    loss, g = nf.value_and_gradient(nf.elbo_batch, flow, tgt, cm(xs, torch.float64))
+    lr, gr = o.neg_elbo_value_and_grad(spec, th, ("diaggauss", mu, var), xs)
+    P.scalar("f64 several tiles per workgroup: loss", loss, lr, P.F64_RTOL)
+    P.gradient("f64 several tiles per workgroup: grad", g, gr, P.F64_GRAD)
+
+
 def test_wide_kernels_on_fp32_mfmas_keep_parity():
     """NF_WIDE_FP32=1 (read once per process) switches the weight-streaming kernels back from the six-term bf16 products to
     fp32 MFMAs -- the round-3 kernels, kept for A/B runs: the wide oracle test's two geometries run under it in a subprocess
