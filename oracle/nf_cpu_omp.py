@@ -3,8 +3,8 @@
 TEST / MEASUREMENT INFRASTRUCTURE ONLY: imported by tests/ (pinned against nf_oracle.py) and by bench.py's
 `cpu_baseline` leg.  The shared object is compiled at run time ON THE BOX WHOSE CORES ARE TIMED (`g++ -O3 -march=native
 -fno-math-errno -fopenmp`), into a temporary directory -- a binary built in the (different) build container could use
-instructions the GPU box's host lacks, or miss its AVX-512.  No -ffast-math (it would switch the importing process to
-flush-to-zero).
+instructions the GPU box's host lacks, or miss its AVX-512.  Compiled with -ffast-math (vectorised exp / tanh / log), LINKED
+without it (the link step is what would pull in crtfastmath.o and switch the importing process to flush-to-zero).
 """
 from __future__ import annotations
 
