@@ -62,13 +62,7 @@ __global__ __launch_bounds__(256) void k_b6_from_images(int nimg, const float *_
   for (int j = 0; j < 8; ++j) {
     const int f = 16 * kg + (j & 3) + 8 * (j >> 2) + 4 * hi;  // input feature of k-slot (kg, hi, j)
     const float w = src[wsrc + f * S + row];                   // image element [in f][out row], zero padded
-    const unsigned xb = __float_as_uint(w);
-    const float r1 = w - __uint_as_float(xb & 0xFFFF0000u);
-    const unsigned rb = __float_as_uint(r1);
-    const float lo = r1 - __uint_as_float(rb & 0xFFFF0000u);
-    h[j] = (unsigned short)(xb >> 16);
-    mi[j] = (unsigned short)(rb >> 16);
-    l[j] = (unsigned short)(__float_as_uint(lo) >> 16);
+    nf_split1(w, h[j], mi[j], l[j]);  // round-to-nearest parts, as the activations' (nf_mfma.h)
   }
   auto put = [&](int comp, const unsigned short(&v)[8]) {
     nf_u32x4 q;
@@ -103,13 +97,7 @@ __global__ __launch_bounds__(256) void k_b6t_from_images(int nimg, const float *
   for (int j = 0; j < 8; ++j) {
     const int o = 16 * kg + (j & 3) + 8 * (j >> 2) + 4 * hi;  // output feature of k-slot (kg, hi, j)
     const float w = src[wsrc + row * S + o];                   // image element [in row][out o]
-    const unsigned xb = __float_as_uint(w);
-    const float r1 = w - __uint_as_float(xb & 0xFFFF0000u);
-    const unsigned rb = __float_as_uint(r1);
-    const float lo = r1 - __uint_as_float(rb & 0xFFFF0000u);
-    h[j] = (unsigned short)(xb >> 16);
-    mi[j] = (unsigned short)(rb >> 16);
-    l[j] = (unsigned short)(__float_as_uint(lo) >> 16);
+    nf_split1(w, h[j], mi[j], l[j]);  // round-to-nearest parts, as the activations' (nf_mfma.h)
   }
   auto put = [&](int comp, const unsigned short(&v)[8]) {
     nf_u32x4 q;

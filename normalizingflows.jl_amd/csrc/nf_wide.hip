@@ -1162,19 +1162,7 @@ __device__ __forceinline__ void dw_job(const DwJob &jb, const DwArgs &a, int ks,
 // 16-byte LDS reads and MFMAs only: 96 bf16 MFMAs of 32 clocks per wave and tile instead of 128 fp32 ones of 64.  Two LDS
 // buffers (384 rows x 208 bytes = 78 KB each, 156 of the CU's 160 KB): the next tile is fetched into registers behind the
 // MFMAs, split and stored into the other buffer, one barrier per tile.
-__device__ __forceinline__ void nf_split2(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
-#pragma clang fp contract(off)
-  const nf_f32x2 x = {x0, x1};
-  const nf_u32x2 xb = __builtin_bit_cast(nf_u32x2, x);
-  const nf_f32x2 r = x - __builtin_bit_cast(nf_f32x2, xb & 0xFFFF0000u);
-  const nf_u32x2 rb = __builtin_bit_cast(nf_u32x2, r);
-  const nf_f32x2 lo = r - __builtin_bit_cast(nf_f32x2, rb & 0xFFFF0000u);
-  const nf_u32x2 lb = __builtin_bit_cast(nf_u32x2, lo);
-  h = __builtin_amdgcn_perm(xb.y, xb.x, 0x07060302u);
-  m = __builtin_amdgcn_perm(rb.y, rb.x, 0x07060302u);
-  l = __builtin_amdgcn_perm(lb.y, lb.x, 0x07060302u);
-}
-
+// (the split itself: nf_split2, nf_mfma.h)
 template <int WI, int WO>
 __device__ __forceinline__ void dw_job_b6(const DwJob &jb, const DwArgs &a, int ks, float *__restrict__ out, char *lds) {
   constexpr int AROWS = 128 * WI;

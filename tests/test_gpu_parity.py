@@ -1284,14 +1284,19 @@ def test_heterogeneous_create_flow(nf, dtn, general_base):
     assert isinstance(trained, nf.CompositeFlow) and stats[-1]["loss"] < stats[0]["loss"] and st.t == 5
 
 
-def fp32_recompute_floor(spec, th64, otgt, xs64):
+def fp32_recompute_floor(spec, th64, otgt, xs64, jitter_seed=None):
     """The float32 oracle's gradient with every layer input RECONSTRUCTED by inverting the chain from its output in
     float32 -- what an invertible-recompute reverse pass (k_affine_bwd_all) differentiates.  Its distance from the float64
-    gradient grows with depth like the float32 round-trip error of the flow; the stashed pass does not have that term."""
+    gradient grows with depth like the float32 round-trip error of the flow; the stashed pass does not have that term.
+    `jitter_seed`: the forward's output moved by N(0, 2^-24) relative first -- a forward that rounds its last bit
+    differently (another summation order, fp32 MFMA chain vs six-term bf16 product, truncating vs rounding split)."""
     th32, xs32 = P.f32(th64, xs64)
     t32 = P.f32(otgt)
     n = xs32.shape[1]
     y32, _ = o.flow_fwd(spec, th32, xs32)
+    if jitter_seed is not None:
+        z = np.random.default_rng(jitter_seed).standard_normal(y32.shape).astype(np.float32)
+        y32 = (y32 * (np.float32(1) + np.float32(2.0 ** -24) * z)).astype(np.float32)
     order = list(reversed(o.layers_flat_order(spec)))
     rec, cur = [None] * (len(order) + 1), y32
     rec[len(order)] = y32
@@ -1301,6 +1306,20 @@ def fp32_recompute_floor(spec, th64, otgt, xs64):
     ybar = (-o.target_grad(t32, y32) / n).astype(np.float32)
     lbar = np.full(n, -1.0 / n, dtype=np.float32)
     return o.flow_bwd(spec, th32, rec, ybar, lbar)[1]
+
+
+def fp32_recompute_kink_floor(spec, th64, otgt, xs64, gref, nseeds=12):
+    """Worst gradient error (max abs / |g|inf) of the float32 reconstruct-by-inversion oracle over `nseeds` last-bit jitters
+    of the forward output.  The error of an invertible-recompute reverse pass is not a smooth function of the forward's
+    rounding: a hidden unit within the reconstruction error (2e-5 ... 9e-5) of its leaky-ReLU kink takes the other slope,
+    a jump of |delta a| / n per (sample, unit).  On the d = 64, 8-coupling case below the SAME numpy code lands on 1e-6,
+    2.2e-4 or 9e-3 of |g|inf depending on the jitter seed (measured, round 5) -- the device's own roundings pick one of those
+    outcomes, which one changes with every change of the forward's arithmetic (round 4's truncating split: 3.3e-4; round
+    5's rounding split: 3.0e-3; fp32 MFMAs: 3.1e-4).  So the recompute tests bound the device by this measured
+    distribution instead of a constant."""
+    scale = float(np.abs(gref).max())
+    errs = [float(np.abs(fp32_recompute_floor(spec, th64, otgt, xs64, s) - gref).max() / scale) for s in [None] + list(range(nseeds))]
+    return max(errs), errs[0]
 
 
 @pytest.mark.parametrize("shape", ["d64_h64", "d20_h32", "d63_h40x64"])
@@ -1325,7 +1344,7 @@ def test_realnvp_step_stash_and_recompute_reverse_passes_against_oracle(nf, shap
     otgt = ("diaggauss", mu.astype(np.float64), var.astype(np.float64))
     lo, go = o.neg_elbo_value_and_grad(spec, th64, otgt, xs64)
     _, g32 = o.neg_elbo_value_and_grad(spec, P.f32(th64), P.f32(otgt), P.f32(xs64))
-    g32_rec = fp32_recompute_floor(spec, th64, otgt, xs64)
+    kink, frec = fp32_recompute_kink_floor(spec, th64, otgt, xs64, go)
     lib, ctx = nf.load_library(), flow.ctx
     need = {}
     try:
@@ -1340,15 +1359,15 @@ def test_realnvp_step_stash_and_recompute_reverse_passes_against_oracle(nf, shap
                 else:
                     # Invertible recompute re-derives every hidden activation from a float32 reconstruction of the layer
                     # input (error 2e-5 ... 9e-5 here); a unit within that distance of its leaky-ReLU kink takes the other
-                    # slope, a discrete change of about |delta a| / n per (sample, unit).  The float64 oracle with its
-                    # states perturbed by 1e-6 shows the same 3e-3 |g|inf jumps in the first-applied couplings.
-                    # Bound: the larger of the tolerance, the float32 reconstruct-by-inversion oracle's own error, 2e-3.
+                    # slope, a discrete change of about |delta a| / n per (sample, unit).  Bound: the larger of
+                    # the tolerance and CFLOOR x the worst the float32 reconstruct-by-inversion oracle shows over twelve
+                    # last-bit jitters of the forward output (fp32_recompute_kink_floor; both recorded).
                     gnp, ref = g.cpu().numpy().astype(np.float64), go
                     err = float(np.abs(gnp - ref).max() / np.abs(ref).max())
-                    frec = float(np.abs(g32_rec - ref).max() / np.abs(ref).max())
                     P.record(f"realnvp {shape} {mode} ({form}): step grad [max abs err / |g|inf]", err)
                     P.record(f"realnvp {shape} {mode} ({form}): step grad [fp32 reconstruct-by-inversion oracle, max abs err / |g|inf]", frec)
-                    assert err <= max(P.GRAD_RTOL, P.CFLOOR * frec, 2e-3), (shape, form, err, frec)
+                    P.record(f"realnvp {shape} {mode} ({form}): step grad [same oracle, worst of 12 last-bit jitters of the forward output]", kink)
+                    assert err <= max(P.GRAD_RTOL, P.CFLOOR * kink), (shape, form, err, frec, kink)
     finally:
         nf._lib.check(lib.nf_ctx_set_stash_budget(ctx.ptr, -1))
     assert need["stash"] > need["recompute"] > 0
