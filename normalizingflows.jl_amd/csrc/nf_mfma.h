@@ -64,20 +64,33 @@ __device__ __forceinline__ float nf_tree_sum16(const float (&v)[16]) {
 }
 
 // tanh / exp for the coupling's scale branch (s = tanh(.), exp(+-s); src/flows/realnvp.jl:50,79).
-// Hardware exp2-based forms: absolute error of tanh < 1e-7 (the reference itself runs NNlib's
-// rational tanh_fast, a few ulp from libm), relative error of exp ~1 ulp -- far inside the
-// stated 2e-5 parity tolerance, and ~4x fewer VALU instructions than the libm-accurate calls.
 // x / y through the hardware reciprocal (v_rcp_f32, 1 ulp): two instructions.  hipcc lowers
 // __fdividef to the full IEEE sequence (div_scale x2, rcp, 4 fma, div_fmas, div_fixup).
 __device__ __forceinline__ float nf_fdiv(float x, float y) { return x * __builtin_amdgcn_rcpf(y); }
 
+// tanh.  Round 5: the rational approximation the REFERENCE itself evaluates -- Flux's Dense applies NNlib.fast_act(tanh),
+// which for Float32 arrays is NNlib.tanh_fast: x n(x^2) / d(x^2) with two quartics, +-1 beyond x^2 = 66 (NNlib.jl
+// src/activations.jl, third-party, restated from the published source; the coefficients below reproduce tanh to 3.2e-7
+// absolute over the whole line and to 2e-9 rms below |x| = 0.05, checked against float64 tanh).  Eight FMAs, one v_rcp_f32.
+// Rounds 1-4 evaluated (e^2x - 1) / (e^2x + 1) with the hardware exp2: as accurate at its worst point (1.3e-7), but the
+// hardware exponential errs to ONE side -- tools/probe/split_bias_probe.hip: mean error -4e-10 ... -3.6e-9 against +-1e-11
+// for the rational -- and the log-determinant of a coupling is a SUM of c such values: at d = 256 (2 048 terms per sample)
+// that bias was the larger part of cfg 4's ladj error (mean -0.21 of the tolerance for fp32 MFMAs against +0.002 for
+// numpy's float32; tools/parity_ab.py).
 __device__ __forceinline__ float nf_tanh(float x) {
 #ifdef NF_TANH_ACCURATE
   return tanhf(x);
 #endif
-  const float xc = fminf(fmaxf(x, -10.f), 10.f);
-  const float e2 = __expf(2.f * xc);
+#ifdef NF_TANH_EXP2  // the rounds-1-4 form (A/B)
+  const float xe = fminf(fmaxf(x, -10.f), 10.f);
+  const float e2 = __expf(2.f * xe);
   return nf_fdiv(e2 - 1.f, e2 + 1.f);
+#endif
+  const float xc = __builtin_amdgcn_fmed3f(x, -8.124f, 8.124f);  // beyond x^2 = 66 the reference returns sign(x); the rational is 1 - 2e-7 there
+  const float z = xc * xc;
+  const float n = fmaf(fmaf(fmaf(fmaf(1.587199e-8f, z, 2.2332108e-5f), z, 0.0035974074f), z, 0.1346604f), z, 1.f);
+  const float d = fmaf(fmaf(fmaf(fmaf(8.7767893e-7f, z, 0.0003453992f), z, 0.026262015f), z, 0.4679937f), z, 1.f);
+  return xc * nf_fdiv(n, d);
 }
 
 // Leaky-ReLU sign masks: one v_alignbit per element shifts the sign bit of v[r] into the mask, so

@@ -716,6 +716,7 @@ struct RqsBwdArgs {
   RqsTape tape;      // the forward's spline tape (required)
   int k, ncoup;      // this coupling's flat index / couplings of the flow (tape addressing)
   const float *img;  // packed image of this coupling
+  const nf_u32x4 *img6;  // its output layer as bf16 triples (RqsB6Geo), or null
   int d, c, m, par_t;
   float B;
   long N;
@@ -1035,6 +1036,7 @@ __global__ __launch_bounds__(256, 1) void k_rqs_bwd_all(RqsBwdAllArgs aa, float 
     a.k = k;
     a.ncoup = aa.ncoup;
     a.img = aa.wimg + (size_t)k * G::SIZE;
+    a.img6 = nullptr;
     a.d = aa.d;
     a.par_t = k & 1;
     a.c = (k & 1) ? aa.d / 2 : (aa.d + 1) / 2;
@@ -1490,6 +1492,455 @@ __global__ __launch_bounds__(256, RQS_COOP_WAVES_PER_SIMD(G)) void k_rqs_bwd_coo
 }
 
 // ---------------------------------------------------------------------------------------
+// cooperative reverse pass, output layer on the bf16 matrix cores (round 5)
+// ---------------------------------------------------------------------------------------
+// The three GEMMs of the chunk phase -- raw-parameter recompute W3 a2 (32 -> OBC x 32 columns), dX3 = W3^T delta and
+// dW3^T = a2 delta^T -- are 576 of the group's 664 fp32 MFMAs (43 k of its 68 k clocks, DESIGN section 4 "cfg 3").  Here they
+// run as six-term bf16 products (nf_mfma.h "B6": 108 instructions of 32 clocks instead of 144 of 64 per tile and chunk).
+// What made that not fit in round 4 was the weight operand: W3 as bf16 triples in two orientations is 2 x 74 KB and the LDS
+// was full.  But a wave of this kernel owns ONE chunk of the output layer for the whole launch -- its weights never change:
+// they are loaded ONCE per launch from the triple images in global memory (RqsB6Geo, written by k_rqs_b6_from_images
+// behind the fp32 images) into REGISTERS, 18 + 18 sixteen-byte vectors = 144 registers per lane (one wave per SIMD owns
+// 512), and the fp32 W3 image (50 KB) leaves the LDS altogether.  The operands that change per tile:
+//   a2 (B operand of the recompute, lane <-> sample)    split once by the tile's HOME wave, six 16-byte stores, read by
+//                                                       the four chunk waves with six ds_read_b128;
+//   a2^T (A operand of dW3, lane <-> feature)           the same triples, stored transposed by the home wave (D6 layout of
+//                                                       nf_mfma.h: one ds_write_b16 per value and component);
+//   delta (B operand of dX3, lane <-> sample)           the chunk's spline cotangents, split k-group by k-group;
+//   delta^T (B operand of dW3, lane <-> column)         those very triples through a two-block D6 ring in LDS -- the
+//                                                       dX3 MFMAs of block pc + 1 run beside the dW3 MFMAs of block pc.
+// x2 and a1 of the home tile wait in registers for the closing home phase (their transpose tiles alias the delta ring),
+// which together with the missing W3 image leaves room for both sets of partial-d2 slots at every geometry.
+template <class G>
+struct RqsB6Geo {  // 16-byte units; per coupling [chunk][k-group][component][half][row]
+  static constexpr int FROWS = G::OBC * 32, FKG = 2 * G::H2B;  // recompute: rows = the chunk's columns, k over a2's features
+  static constexpr int TROWS = 32 * G::H2B, TKG = 2 * G::OBC;  // dX3: rows = a2's features, k over the chunk's columns
+  static constexpr int F_CH = FKG * 3 * 2 * FROWS, T_CH = TKG * 3 * 2 * TROWS;
+  static constexpr int OFF_T = G::NCH * F_CH;
+  static constexpr int U4 = G::NCH * (F_CH + T_CH);
+  static constexpr size_t BYTES = (size_t)U4 * 16;
+};
+
+template <class G>
+__global__ __launch_bounds__(256) void k_rqs_b6_from_images(int nimg, const float *__restrict__ wimg, nf_u32x4 *__restrict__ out) {
+  using B = RqsB6Geo<G>;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long)nimg * B::U4) return;
+  const int img = (int)(gid / B::U4);
+  int e = (int)(gid - (long)img * B::U4);
+  const float *src = wimg + (size_t)img * G::SIZE + G::W3;
+  const bool tr = e >= B::OFF_T;
+  if (tr) e -= B::OFF_T;
+  const int rows = tr ? B::TROWS : B::FROWS, nkg = tr ? B::TKG : B::FKG;
+  const int row = e % rows, hi = (e / rows) & 1, comp = (e / (2 * rows)) % 3, kg = (e / (6 * rows)) % nkg, ch = e / (6 * rows * nkg);
+  unsigned short part[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int kf = 16 * kg + (j & 3) + 8 * (j >> 2) + 4 * hi;  // k-slot (kg, hi, j) in the C-layout register order
+    const float w = tr ? src[row * G::S3 + ch * G::OBC * 32 + kf]    // [in = row][column kf of the chunk]
+                       : src[kf * G::S3 + ch * G::OBC * 32 + row];   // [in = kf][column row of the chunk]
+    unsigned short h, m, l;
+    nf_split1(w, h, m, l);
+    part[j] = comp == 0 ? h : comp == 1 ? m : l;
+  }
+  nf_u32x4 q;
+#pragma unroll
+  for (int pp = 0; pp < 4; ++pp) q[pp] = (unsigned)part[2 * pp] | ((unsigned)part[2 * pp + 1] << 16);
+  out[gid] = q;
+}
+
+template <class G>
+struct RqsCoop6Lds {
+  static_assert(G::NCH == 4, "one chunk per wave");
+  static constexpr int DBLK = (G::H1B > G::H2B ? G::H1B : G::H2B);
+  // per wave, bytes
+  static constexpr int A2C = 0;                                   // a2 triples, B-operand order: [k-group][component][lane] x 16 B
+  static constexpr int A2C_BYTES = 2 * G::H2B * 3 * 64 * 16;
+  static constexpr int A2T = A2C + A2C_BYTES;                     // a2 triples transposed (D6 rows, one per feature)
+  static constexpr int A2T_BYTES = 32 * G::H2B * D6_ROW;
+  static constexpr int DT = A2T + A2T_BYTES;                      // ring of two delta blocks (D6 rows); closing home phase: fp32 tiles
+  static constexpr int RING_BYTES = 2 * 32 * D6_ROW;
+  static constexpr int TILE_X = 0, TILE_A1 = G::MB * 32 * NF_TS, TILE_D = TILE_A1 + G::H1B * 32 * NF_TS;  // floats from DT
+  static constexpr int TILES_BYTES = (TILE_D + DBLK * 32 * NF_TS) * 4;
+  static constexpr int WAVE_BYTES = ((DT + (RING_BYTES > TILES_BYTES ? RING_BYTES : TILES_BYTES)) + 15) / 16 * 16;
+  static constexpr int SLOT = G::H2B * 16 * 64;                   // floats: one partial d2 in register-dump order
+  static constexpr int IMG = G::W3 + G::NCOLS;                    // floats: W1, b1, W2, b2 of the fp32 image, then b3
+  static constexpr size_t WORK_BYTES = (size_t)4 * WAVE_BYTES + (size_t)8 * SLOT * 4 + (size_t)IMG * 4;
+  static constexpr size_t FOLD_BYTES = (size_t)G::SIZE * 4;       // the slab image the accumulators are folded into at the end
+  static constexpr size_t BYTES = WORK_BYTES > FOLD_BYTES ? WORK_BYTES : FOLD_BYTES;
+  // (K = 10 at d = 32 -- 4 output blocks per chunk, 192 weight registers -- spills 390 bytes per lane: it keeps the fp32 kernel)
+  static constexpr bool FITS = BYTES <= 160 * 1024 && G::OBC <= 3;
+};
+
+// one k-group of a split cotangent block -> its rows of a D6 tile (the per-k-group form of split_to_lds, nf_mfma.h):
+// `blk` = the tile of the block the k-group belongs to, g = k-group within the block (0 / 1)
+__device__ __forceinline__ void rqs_kg_to_d6(char *__restrict__ blk, int g, const nf_u32x4 &h, const nf_u32x4 &m, const nf_u32x4 &l, int l31, int hi) {
+  const int t = l31 >> 1;
+  char *p = blk + (4 * hi + 16 * g) * D6_ROW + (t >> 3) * 32 + (l31 & 1) * 16 + (t & 7) * 2;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const nf_u32x4 &v = c == 0 ? h : c == 1 ? m : l;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j0 = 2 * q, j1 = 2 * q + 1;
+      const int f0 = (j0 & 3) + 8 * (j0 >> 2), f1 = (j1 & 3) + 8 * (j1 >> 2);
+      *reinterpret_cast<unsigned short *>(p + f0 * D6_ROW + c * 64) = (unsigned short)v[q];
+      *reinterpret_cast<unsigned short *>(p + f1 * D6_ROW + c * 64) = (unsigned short)(v[q] >> 16);
+    }
+  }
+}
+
+// this wave's weights of the output layer, in registers for the whole launch
+template <class G>
+struct RqsW6 {
+  nf_u32x4 f[2 * G::H2B][G::OBC][3];  // recompute: [k-group over a2's features][output block of the chunk][h, m, l]
+  nf_u32x4 t[2 * G::OBC][G::H2B][3];  // dX3: [k-group over the chunk's columns][a2 block][h, m, l]
+};
+
+template <class G, bool INVD>
+__device__ __forceinline__ void rqs_bwd_coop6_coupling(const RqsBwdArgs &a, float *__restrict__ y, float *__restrict__ ybar,
+                                                       const float *__restrict__ lbar, float lbar_const,
+                                                       float *__restrict__ slab, long slab_stride, char *lds) {
+  using L = RqsCoop6Lds<G>;
+  using B = RqsB6Geo<G>;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  char *wv = lds + wave * L::WAVE_BYTES;                                   // this wave's region
+  float *slots = reinterpret_cast<float *>(lds + 4 * L::WAVE_BYTES);       // [2][4][SLOT]
+  float *img = slots + 8 * L::SLOT;                                        // W1, b1, W2, b2 at their image offsets; b3 at G::W3
+  const float *b3 = img + G::W3;
+  const long ntiles = (a.N + NF_TILE - 1) / NF_TILE;
+  const long ngroups = (ntiles + 3) / 4;
+  const int par_c = 1 - a.par_t;
+  const int ch = wave;
+  {  // stage layers 1-2 and the output layer's bias (16-byte vectors; G::W3 and G::B3 are multiples of 4)
+    const float4 *s0 = reinterpret_cast<const float4 *>(a.img);
+    float4 *d0 = reinterpret_cast<float4 *>(img);
+    for (int i = tid; i < G::W3 / 4; i += 256) d0[i] = s0[i];
+    const float4 *s1 = reinterpret_cast<const float4 *>(a.img + G::B3);
+    float4 *d1 = reinterpret_cast<float4 *>(img + G::W3);
+    for (int i = tid; i < G::NCOLS / 4; i += 256) d1[i] = s1[i];
+  }
+  RqsW6<G> W;
+  {
+    const nf_u32x4 *wf = a.img6 + (size_t)ch * B::F_CH + hi * B::FROWS + l31;
+#pragma unroll
+    for (int kg = 0; kg < B::FKG; ++kg)
+#pragma unroll
+      for (int ob = 0; ob < G::OBC; ++ob)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) W.f[kg][ob][c] = wf[((kg * 3 + c) * 2) * B::FROWS + ob * 32];
+    const nf_u32x4 *wt = a.img6 + B::OFF_T + (size_t)ch * B::T_CH + hi * B::TROWS + l31;
+#pragma unroll
+    for (int kg = 0; kg < B::TKG; ++kg)
+#pragma unroll
+      for (int ib = 0; ib < G::H2B; ++ib)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) W.t[kg][ib][c] = wt[((kg * 3 + c) * 2) * B::TROWS + ib * 32];
+  }
+  __syncthreads();
+  RqsCoopAcc<G> acc;
+  rqs_zero(acc.w1, acc.b1);
+  rqs_zero(acc.w2, acc.b2);
+  rqs_zero(acc.w3, acc.b3);
+  f32x16 xb[G::MB];
+  auto load_home = [&](long g) {
+    const long tile_ = g * 4 + wave;
+    const long tl_ = tile_ < ntiles ? tile_ : 0;
+    const TileIO yio_ = make_tile_io(y, tl_, a.d, l31, hi);
+#pragma unroll
+    for (int b = 0; b < G::MB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xb[b][r] = tile_load(yio_, tile_soff(b, r, par_c));
+  };
+  if ((long)blockIdx.x < ngroups) load_home(blockIdx.x);
+  float *tiles = reinterpret_cast<float *>(wv + L::DT);  // closing home phase: x2^T, a1^T, delta^T (fp32, row stride 33)
+#pragma unroll 1
+  for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    // ---------------- home phase: layers 1-2 of this wave's own tile ----------------
+    const long tile = grp * 4 + wave;
+    const bool live = tile < ntiles;
+    const long tl = live ? tile : 0;
+    const long j = tl * NF_TILE + l31;
+    const bool valid = live && j < a.N;
+    const TileIO gio = make_tile_io(ybar, tl, a.d, l31, hi);
+    unsigned m1[G::H1B], m2[G::H2B];
+    f32x16 a1[G::H1B];
+    if (live) {
+#pragma unroll
+      for (int b = 0; b < G::MB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xb[b][r] = valid ? xb[b][r] : 0.f;
+      dense_fwd_dyn<G::MB, G::H1B>(img + G::W1, img + G::B1, xb, a1, l31, hi, (a.m + 7) >> 3);
+#pragma unroll
+      for (int b = 0; b < G::H1B; ++b) {
+        nf_lrelu16(a1[b]);
+        m1[b] = nf_sign_mask16(a1[b]);
+      }
+      f32x16 a2[G::H2B];
+      dense_fwd<G::H1B, G::H2B>(img + G::W2, img + G::B2, a1, a2, l31, hi);
+#pragma unroll
+      for (int b = 0; b < G::H2B; ++b) {
+        nf_lrelu16(a2[b]);
+        m2[b] = nf_sign_mask16(a2[b]);
+      }
+      // a2 as bf16 triples, once for the four chunk waves: in B-operand order and transposed
+      SplitC<G::H2B> s2;
+      split_C<G::H2B>(a2, s2);
+      nf_u32x4 *pc_ = reinterpret_cast<nf_u32x4 *>(wv + L::A2C) + lane;
+#pragma unroll
+      for (int kg = 0; kg < 2 * G::H2B; ++kg) {
+        pc_[(kg * 3 + 0) * 64] = s2.h[kg];
+        pc_[(kg * 3 + 1) * 64] = s2.m[kg];
+        pc_[(kg * 3 + 2) * 64] = s2.l[kg];
+      }
+      split_to_lds<G::H2B>(wv + L::A2T, s2, l31, hi);
+    }
+    __syncthreads();  // B0: every home tile's a2 triples are in LDS
+
+    // ---------------- chunk phase ----------------
+    f32x16 d2[G::H2B];
+#pragma unroll
+    for (int b = 0; b < G::H2B; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) d2[b][r] = 0.f;
+#pragma unroll 1
+    for (int t = 0; t < 4; ++t) {
+      const long tt = grp * 4 + t;
+      const bool tlive = tt < ntiles;
+      if (tlive) {
+        const char *wt_ = lds + t * L::WAVE_BYTES;  // wave t's region
+        const long jt = tt * NF_TILE + l31;
+        const bool tvalid = jt < a.N;
+        const TileIO yt = make_tile_io(y, tt, a.d, l31, hi);
+        const TileIO gt = make_tile_io(ybar, tt, a.d, l31, hi);
+        const float lb = tvalid ? (lbar ? lbar[jt] : lbar_const) : 0.f;
+        float yq[G::QCH], gq[G::QCH], xiq[G::QCH];
+        constexpr int ROWS = G::NCH * G::QCH;
+        const float *trow = a.tape.base + (tt * a.ncoup + a.k) * (ROWS * 64) + lane;
+#pragma unroll
+        for (int ql = 0; ql < G::QCH; ++ql) {
+          const int q = ch * G::QCH + ql;
+          yq[ql] = tile_load(yt, tile_soff(q / 16, q % 16, a.par_t));
+          gq[ql] = tile_load(gt, tile_soff(q / 16, q % 16, a.par_t));
+          xiq[ql] = trow[q * 64];
+        }
+        // ---- raw spline parameters of this chunk: out = W3[chunk] a2 + b3[chunk], six-term bf16 products
+        f32x16 out[G::OBC];
+#pragma unroll
+        for (int ob = 0; ob < G::OBC; ++ob)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) out[ob][r] = b3[(ch * G::OBC + ob) * 32 + nf_row(r, hi)];
+        {
+          const nf_u32x4 *pa = reinterpret_cast<const nf_u32x4 *>(wt_ + L::A2C) + lane;
+#pragma unroll
+          for (int kg = 0; kg < 2 * G::H2B; ++kg) {
+            const nf_u32x4 xh = pa[(kg * 3 + 0) * 64], xm = pa[(kg * 3 + 1) * 64], xl = pa[(kg * 3 + 2) * 64];
+#pragma unroll
+            for (int ob = 0; ob < G::OBC; ++ob) {  // smallest terms first, as dense_fwd_b6
+              out[ob] = nf_mfma_bf16(W.f[kg][ob][2], xh, out[ob]);
+              out[ob] = nf_mfma_bf16(W.f[kg][ob][0], xl, out[ob]);
+              out[ob] = nf_mfma_bf16(W.f[kg][ob][1], xm, out[ob]);
+              out[ob] = nf_mfma_bf16(W.f[kg][ob][1], xh, out[ob]);
+              out[ob] = nf_mfma_bf16(W.f[kg][ob][0], xm, out[ob]);
+              out[ob] = nf_mfma_bf16(W.f[kg][ob][0], xh, out[ob]);
+            }
+          }
+        }
+        // ---- the spline and its reverse pass, in place (as k_rqs_bwd_coop)
+#pragma unroll
+        for (int ql = 0; ql < G::QCH; ++ql) {
+          const int q = ch * G::QCH + ql;
+          const int p = (q & 3) + 8 * (q >> 2) + 4 * hi;
+          const bool ok = tvalid && p < a.c;
+          float raw[G::P], thb[G::P];
+          chunk_get<G>(out, ql, raw);
+          Knots<G::K> kn;
+          build_knots<G::K, RQS_COOP_LAZY>(raw, a.B, kn);
+          const float yv = yq[ql];
+          const float gv = ok ? gq[ql] : 0.f;
+          Bin<G::K> bn;
+          unsigned code;
+          float xi;
+          rqs_tape_decode(xiq[ql], code, xi);
+          find_bin<G::K, RQS_COOP_LAZY, true>(kn, 0.f, bn, code);
+          float xv;
+          {
+            const float dx = bn.dx, dy = bn.dy;
+            if (INVD) {
+              const float sl = nf_fdiv(dy, dx), om = 1.f - xi;
+              const float den = sl + (bn.d1 + bn.d0 - 2.f * sl) * xi * om;
+              xv = bn.inside ? bn.yk + nf_fdiv(dy * (sl * xi * xi + bn.d0 * xi * om), den) : yv;
+            } else {
+              xv = bn.inside ? fmaf(xi, dx, bn.xk) : yv;
+            }
+          }
+          const float xbar = rqs_bwd_elem<G::K, INVD>(kn, bn, xi, a.B, gv, ok ? lb : 0.f, thb);
+          chunk_put<G>(out, ql, thb);
+          tile_store(yt, tile_soff(q / 16, q % 16, a.par_t), xv);
+          tile_store(gt, tile_soff(q / 16, q % 16, a.par_t), xbar);
+        }
+#pragma unroll
+        for (int slot = G::QCH * G::P; slot < G::OBC * 16; ++slot) out[slot / 16][slot % 16] = 0.f;
+        // ---- dX3 (this chunk's share, to the home wave's slot) and dW3^T (this chunk's columns), block by block: the
+        // cotangent block is split once per k-group; the triples feed the dX3 MFMAs from registers and go to the D6 ring
+        // transposed, from where the dW3 MFMAs of the same block read them back
+        {
+          SplitT<G::H2B> a2t;  // tile t's a2^T triples (A operand of dW3)
+          {
+            const nf_u32x4 *pt = reinterpret_cast<const nf_u32x4 *>(wt_ + L::A2T + l31 * D6_ROW + hi * 16);
+            constexpr int RB = 32 * D6_ROW / 16;
+#pragma unroll
+            for (int ib = 0; ib < G::H2B; ++ib)
+#pragma unroll
+              for (int g = 0; g < 2; ++g) {
+                a2t.h[ib][g] = pt[ib * RB + 0 * 4 + g * 2];
+                a2t.m[ib][g] = pt[ib * RB + 1 * 4 + g * 2];
+                a2t.l[ib][g] = pt[ib * RB + 2 * 4 + g * 2];
+              }
+          }
+          f32x16 d2p[G::H2B];  // (one chain: the dW3 MFMAs of the previous block run beside it)
+#pragma unroll
+          for (int b = 0; b < G::H2B; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d2p[b][r] = 0.f;
+          const unsigned ones = 0x3F803F80u;  // bf16 (1, 1)
+#pragma unroll
+          for (int pc = 0; pc < G::OBC; ++pc) {
+            char *ring = wv + L::DT + (pc & 1) * (32 * D6_ROW);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+              const int kg = 2 * pc + g;
+              float v[8];
+#pragma unroll
+              for (int jj = 0; jj < 8; ++jj) v[jj] = out[pc][8 * g + jj];
+              nf_u32x4 dh, dm, dl;
+              nf_split8(v, dh, dm, dl);
+              rqs_kg_to_d6(ring, g, dh, dm, dl, l31, hi);
+#pragma unroll
+              for (int ib = 0; ib < G::H2B; ++ib) {
+                f32x16 &dd = d2p[ib];
+                dd = nf_mfma_bf16(W.t[kg][ib][2], dh, dd);
+                dd = nf_mfma_bf16(W.t[kg][ib][0], dl, dd);
+                dd = nf_mfma_bf16(W.t[kg][ib][1], dm, dd);
+                dd = nf_mfma_bf16(W.t[kg][ib][1], dh, dd);
+                dd = nf_mfma_bf16(W.t[kg][ib][0], dm, dd);
+                dd = nf_mfma_bf16(W.t[kg][ib][0], dh, dd);
+              }
+            }
+            wave_lds_order();
+            // dW3^T[:, block pc] += a2^T delta_pc^T, bias gradient = row sums of delta_pc
+            const nf_u32x4 *pd = reinterpret_cast<const nf_u32x4 *>(ring + l31 * D6_ROW + hi * 16);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+              const nf_u32x4 dc0 = pd[0 * 4 + g * 2], dc1 = pd[1 * 4 + g * 2], dc2 = pd[2 * 4 + g * 2];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                acc.b3[pc] = nf_dot2_bf16(dc0[i], ones, acc.b3[pc]);
+                acc.b3[pc] = nf_dot2_bf16(dc1[i], ones, acc.b3[pc]);
+                acc.b3[pc] = nf_dot2_bf16(dc2[i], ones, acc.b3[pc]);
+              }
+#pragma unroll
+              for (int ib = 0; ib < G::H2B; ++ib) {
+                f32x16 &ww = acc.w3[ib][pc];
+                ww = nf_mfma_bf16(a2t.l[ib][g], dc0, ww);
+                ww = nf_mfma_bf16(a2t.h[ib][g], dc2, ww);
+                ww = nf_mfma_bf16(a2t.m[ib][g], dc1, ww);
+                ww = nf_mfma_bf16(a2t.m[ib][g], dc0, ww);
+                ww = nf_mfma_bf16(a2t.h[ib][g], dc1, ww);
+                ww = nf_mfma_bf16(a2t.h[ib][g], dc0, ww);
+              }
+            }
+            wave_lds_order();
+          }
+          float *mys = slots + ((t & 1) * 4 + wave) * L::SLOT;
+#pragma unroll
+          for (int b = 0; b < G::H2B; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mys[(b * 16 + r) * 64 + lane] = d2p[b][r];
+        }
+      }
+      __syncthreads();  // B1: the four partial d2 of tile t are in the slots (set t & 1)
+      if (tlive && t == wave) {
+        const float *set = slots + (t & 1) * 4 * L::SLOT;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)  // fixed order: deterministic
+#pragma unroll
+          for (int b = 0; b < G::H2B; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d2[b][r] += set[w * L::SLOT + (b * 16 + r) * 64 + lane];
+      }
+    }
+
+    // ---------------- home phase: layers 2 and 1 of this wave's own tile ----------------
+    // (the wave's delta ring is dead until the next group's chunk phase: it holds the fp32 transpose tiles now)
+    if (live) {
+      tile_to_scratch<G::MB>(tiles + L::TILE_X, xb, l31, hi);
+      tile_to_scratch<G::H1B>(tiles + L::TILE_A1, a1, l31, hi);
+    }
+    if (grp + gridDim.x < ngroups) load_home(grp + gridDim.x);  // in flight behind the 64 MFMAs of this phase
+    if (live) {
+      float *sd = tiles + L::TILE_D;
+#pragma unroll
+      for (int b = 0; b < G::H2B; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d2[b][r] *= nf_mask_slope(m2[b], r);
+      tile_to_scratch<G::H2B>(sd, d2, l31, hi);
+      wave_lds_order();
+      dw_accumulate<G::H1B, G::H2B>(tiles + L::TILE_A1, sd, acc.w2, acc.b2, l31, hi);
+      f32x16 d1[G::H1B];
+      dense_bwd_x<G::H1B, G::H2B>(img + G::W2, d2, d1, l31, hi);
+      f32x16 g2[G::MB];
+#pragma unroll
+      for (int b = 0; b < G::MB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g2[b][r] = tile_load(gio, tile_soff(b, r, par_c));
+#pragma unroll
+      for (int b = 0; b < G::H1B; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d1[b][r] *= nf_mask_slope(m1[b], r);
+      wave_lds_order();
+      tile_to_scratch<G::H1B>(sd, d1, l31, hi);
+      wave_lds_order();
+      dw_accumulate<G::MB, G::H1B>(tiles + L::TILE_X, sd, acc.w1, acc.b1, l31, hi);
+      dense_bwd_x<G::MB, G::H1B, G::S1, true>(img + G::W1, d1, g2, l31, hi);
+      wave_lds_order();
+#pragma unroll
+      for (int b = 0; b < G::MB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tile_store(gio, tile_soff(b, r, par_c), g2[b][r]);
+    }
+  }
+  __syncthreads();  // every working area is dead: the LDS becomes the fold target (the slab image, G's fp32 layout)
+  float *fold = reinterpret_cast<float *>(lds);
+#pragma unroll 1
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+      rqs_fold<G::MB, G::H1B, G::S1>(fold + G::W1, fold + G::B1, acc.w1, acc.b1, w == 0, l31, hi);
+      rqs_fold<G::H1B, G::H2B, G::S2>(fold + G::W2, fold + G::B2, acc.w2, acc.b2, w == 0, l31, hi);
+    }
+    __syncthreads();
+  }
+  rqs_fold<G::H2B, G::OBC, G::S3>(fold + G::W3 + ch * G::OBC * 32, fold + G::B3 + ch * G::OBC * 32, acc.w3, acc.b3, true, l31, hi);
+  __syncthreads();
+  {
+    const float4 *c0 = reinterpret_cast<const float4 *>(fold);
+    float4 *dst = reinterpret_cast<float4 *>(slab + (long)blockIdx.x * slab_stride);
+    for (int i = tid; i < G::SIZE / 4; i += 256) dst[i] = c0[i];
+  }
+  __syncthreads();
+}
+
+template <class G, bool INVD>
+__global__ __launch_bounds__(256, 1) void k_rqs_bwd_coop6(RqsBwdArgs a, float *__restrict__ y, float *__restrict__ ybar,
+                                                          const float *__restrict__ lbar, float lbar_const,
+                                                          float *__restrict__ slab, long slab_stride) {
+  extern __shared__ __attribute__((aligned(16))) char lds6[];
+  rqs_bwd_coop6_coupling<G, INVD>(a, y, ybar, lbar, lbar_const, slab, slab_stride, lds6);
+}
+
+// ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
 using GeoK8 = RqsGeo<1, 1, 1, 8, 4>;    // d <= 32, hidden <= 32, K = 8   (cfg 3)
@@ -1551,15 +2002,39 @@ static RqsTape rqs_tape_at(const nf_flow_desc *desc, long N, void *tape) {
 
 long nf_rqs_slab_floats(const nf_flow_desc *desc) { return (long)2 * desc->nlayers * rqs_geo_size(desc); }
 
-size_t nf_rqs_wimg_bytes(const nf_flow_desc *desc) { return (size_t)2 * desc->nlayers * rqs_geo_size(desc) * sizeof(float); }
+// ctx->wimg of an NSF flow: [fp32 images][256-byte aligned: the output layers as bf16 triples (RqsB6Geo; the geometries whose
+// reverse pass runs the cooperative bf16 form)]
+static size_t rqs_fp32_bytes(const nf_flow_desc *desc) { return ((size_t)2 * desc->nlayers * rqs_geo_size(desc) * sizeof(float) + 255) / 256 * 256; }
+static size_t rqs_b6_bytes_per_coupling(const nf_flow_desc *desc) {
+  const int id = rqs_geo_id(desc);
+  return id == 1 ? RqsB6Geo<GeoK8>::BYTES : 0;
+}
+size_t nf_rqs_wimg_bytes(const nf_flow_desc *desc) { return rqs_fp32_bytes(desc) + (size_t)2 * desc->nlayers * rqs_b6_bytes_per_coupling(desc); }
+static bool rqs_bwd_b6() {
+  static const bool off = std::getenv("NF_RQS_BWD_FP32") != nullptr;  // A/B switch: the fp32-MFMA cooperative kernel of rounds 2-4
+  return !off;
+}
+// the triple images, rebuilt from the fp32 images when those have been rewritten since (ctx->wimg_gen)
+template <class G>
+static int rqs_b6_refresh(nf_ctx *ctx, const nf_flow_desc *desc) {
+  if (ctx->b6_gen == ctx->wimg_gen) return NF_OK;
+  using B = RqsB6Geo<G>;
+  const int nimg = 2 * desc->nlayers;
+  const long total = (long)nimg * B::U4;
+  ProfScope ps(ctx, "pack_weights");
+  hipLaunchKernelGGL((k_rqs_b6_from_images<G>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, nimg, (const float *)ctx->wimg,
+                     (nf_u32x4 *)((char *)ctx->wimg + rqs_fp32_bytes(desc)));
+  NF_HIP(hipGetLastError());
+  ctx->b6_gen = ctx->wimg_gen;
+  return NF_OK;
+}
 
 int nf_rqs_pack(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta) {
   const int id = rqs_geo_id(desc);
   if (!id) return NF_ERR_UNSUPPORTED;
   const int size = rqs_geo_size(desc);
   const int nc = 2 * desc->nlayers;
-  const size_t bytes = (size_t)nc * size * sizeof(float);
-  NF_TRY(nf_wimg_reserve(ctx, bytes));
+  NF_TRY(nf_wimg_reserve(ctx, nf_rqs_wimg_bytes(desc)));
   const RqsPackArgs p = rqs_pack_args(desc);
   const long total = (long)nc * size;
   const unsigned grid = (unsigned)((total + 255) / 256);
@@ -1667,6 +2142,7 @@ static int launch_rqs_bwd_coop(nf_ctx *ctx, const nf_flow_desc *desc, int k, flo
   a.k = k;
   a.ncoup = 2 * desc->nlayers;
   a.img = (const float *)ctx->wimg + (size_t)k * G::SIZE;
+  a.img6 = nullptr;
   a.d = desc->d; a.c = ci.c; a.m = ci.m; a.par_t = ci.par_t; a.B = desc->B; a.N = N;
   a.trace = (long long *)ctx->trace;
   ProfScope ps(ctx, INVD ? "rqs_bwd_inv" : "rqs_bwd");
@@ -1676,10 +2152,39 @@ static int launch_rqs_bwd_coop(nf_ctx *ctx, const nf_flow_desc *desc, int k, flo
 }
 
 template <class G, bool INVD>
+static int launch_rqs_bwd_coop6(nf_ctx *ctx, const nf_flow_desc *desc, int k, float *y, float *ybar, const float *lbar,
+                                float lbar_const, long N, float *slab, long slab_stride, int grid, void *tape) {
+  const size_t lds = RqsCoop6Lds<G>::BYTES;
+  static AttrOnce attr_once;  // once per device
+  NF_TRY(attr_once.run(ctx->device, [&]() -> int {
+    NF_HIP(hipFuncSetAttribute((const void *)k_rqs_bwd_coop6<G, INVD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return NF_OK;
+  }));
+  NF_TRY(rqs_b6_refresh<G>(ctx, desc));
+  const CouplingInfo ci = nf_coupling_info(desc, k);
+  RqsBwdArgs a;
+  a.tape = rqs_tape_at(desc, N, tape);
+  a.k = k;
+  a.ncoup = 2 * desc->nlayers;
+  a.img = (const float *)ctx->wimg + (size_t)k * G::SIZE;
+  a.img6 = (const nf_u32x4 *)((const char *)ctx->wimg + rqs_fp32_bytes(desc)) + (size_t)k * RqsB6Geo<G>::U4;
+  a.d = desc->d; a.c = ci.c; a.m = ci.m; a.par_t = ci.par_t; a.B = desc->B; a.N = N;
+  a.trace = (long long *)ctx->trace;
+  ProfScope ps(ctx, INVD ? "rqs_bwd_inv" : "rqs_bwd");
+  hipLaunchKernelGGL((k_rqs_bwd_coop6<G, INVD>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, y, ybar, lbar, lbar_const,
+                     slab + (long)k * G::SIZE, slab_stride);
+  return (int)hipGetLastError();
+}
+
+template <class G, bool INVD>
 static int launch_rqs_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, float *y, float *ybar, const float *lbar,
                           float lbar_const, long N, float *slab, long slab_stride, int grid, void *tape) {
   if (!tape) return NF_ERR_ARG;  // the reverse kernels differentiate the forward's own bins (RqsTape)
   if constexpr (G::NCH == 4) {
+    if constexpr (RqsCoop6Lds<G>::FITS) {
+      static const bool perwave = std::getenv("NF_RQS_BWD_PERWAVE") != nullptr;
+      if (rqs_bwd_b6() && !perwave) return launch_rqs_bwd_coop6<G, INVD>(ctx, desc, k, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid, tape);
+    }
     static const bool old_form = std::getenv("NF_RQS_BWD_PERWAVE") != nullptr;  // A/B switch: the per-wave-tile kernel
     if (!old_form || G::OB3 > 12) return launch_rqs_bwd_coop<G, INVD>(ctx, desc, k, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid, tape);
   }
@@ -1698,6 +2203,7 @@ static int launch_rqs_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, float *y
   a.k = k;
   a.ncoup = 2 * desc->nlayers;
   a.img = (const float *)ctx->wimg + (size_t)k * G::SIZE;
+  a.img6 = nullptr;
   a.d = desc->d; a.c = ci.c; a.m = ci.m; a.par_t = ci.par_t; a.B = desc->B; a.N = N;
   a.trace = (long long *)ctx->trace;
   ProfScope ps(ctx, INVD ? "rqs_bwd_inv" : "rqs_bwd");

@@ -123,9 +123,10 @@ __device__ __forceinline__ void wide_fwd_chunk(const float *__restrict__ ch, con
 // block costs ~900 clocks per 48-KB chunk -- 12 LDS-DMA instructions per wave through the CU's one texture-address path -- but
 // inside the loop every piece delays the dependent MFMA chain by ~40 clocks: 4.35 k against 4.68 k clocks per chunk in the
 // trace, 115 / 80 us per launch against 114 / 77 for forward / reverse in the untraced kernels.)
+// `neg`: contract with -in instead (a constant after unrolling; see FLIP3 of wide_net_fwd).
 template <int OB>
 __device__ __forceinline__ void wide_fwd_chunk_b6(const float *__restrict__ ch, const f32x16 &in, f32x16 (&out)[OB], int l31,
-                                                  int hi, const DmaJob &dma) {
+                                                  int hi, const DmaJob &dma, bool neg = false) {
   dma.issue();
   constexpr int ROWS = 32 * OB, NU = 2 * OB;
   const nf_u32x4 *wl = reinterpret_cast<const nf_u32x4 *>(ch) + hi * ROWS + l31;
@@ -138,7 +139,7 @@ __device__ __forceinline__ void wide_fwd_chunk_b6(const float *__restrict__ ch, 
     if (ob == 0) {
       float v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = in[8 * kg + j];
+      for (int j = 0; j < 8; ++j) v[j] = neg ? -in[8 * kg + j] : in[8 * kg + j];
       nf_split8(v, xh, xm, xl);
     }
 #pragma unroll
@@ -230,7 +231,15 @@ __device__ __forceinline__ void init_bias(f32x16 (&v)[NB], const float *__restri
 // Streams one net forward.  On entry the chunk (W1, rows 0..31) of `img` is resident in
 // cb[buf]; on exit the chunk (next_src, next_floats) is resident in cb[buf] (or nothing if
 // next_floats == 0).
-template <class G, class HK, bool B6 = false>
+// FLIP3 (bf16 form, the scale net): the output layer accumulates its first H2B / 2 input blocks as they are and the rest in
+// the NEGATED frame (accumulator and inputs negated at the half-way point, the result negated back at the end).  The bf16
+// MFMA's internal adder drops low bits toward minus infinity whatever the signs (tools/probe/split_bias_probe.hip: mean
+// error -0.017 of 2^-24 sum|terms| per output against +0.0003 for the fp32 chain; a twentieth of the rms error, invisible in
+// any single output) -- but log|det J| of a coupling is the SUM of c = 128 outputs' tanh, 2 048 per sample over cfg 4's 16
+// couplings, and a one-sided error grows with n where rounding grows with sqrt n: tools/parity_ab.py measured a mean of
+// -0.24 of the tolerance on cfg 4's ladj (rms 0.43) against +0.002 (0.25) for fp32 MFMAs.  Half the accumulation steps in
+// the negated frame make the drift cancel on average; cost: 2 x 16 CB sign flips per net and tile.
+template <class G, class HK, bool B6 = false, bool FLIP3 = false>
 __device__ __forceinline__ void wide_net_fwd(wide_img_t img, const float *__restrict__ bias, float *cb, int &buf,
                                              wide_img_t next_img, int next_off, int next_floats,
                                              const f32x16 (&xb)[G::MB], f32x16 (&out)[G::CB], int wave, int lane, HK &hk,
@@ -301,7 +310,16 @@ __device__ __forceinline__ void wide_net_fwd(wide_img_t img, const float *__rest
     if constexpr (B6) {
       dj.issue();
       hk.l3_step(ib, a2);
-      wide_fwd_chunk_b6<G::CB>(cb + buf * C::CHBUF, a2[ib], out, l31, hi, none);
+      constexpr bool FL = FLIP3 && G::H2B >= 2;
+      if (FL && ib == G::H2B / 2) {
+#pragma unroll
+        for (int ob = 0; ob < G::CB; ++ob) out[ob] = -out[ob];
+      }
+      wide_fwd_chunk_b6<G::CB>(cb + buf * C::CHBUF, a2[ib], out, l31, hi, none, FL && ib >= G::H2B / 2);
+      if (FL && ib == G::H2B - 1) {
+#pragma unroll
+        for (int ob = 0; ob < G::CB; ++ob) out[ob] = -out[ob];
+      }
       wide_chunk_barrier<HK::YOUNG>();
     } else {
       hk.l3_step(ib, a2);
@@ -483,7 +501,7 @@ __global__ __launch_bounds__(256, 1) void k_wide_apply(WideArgs a, float *xt, fl
                               make_stash_io(fs.a2[0], tl, (STASH && live) ? 32 * G::H2B : 0, l31, hi),
                               (STASH && live) ? fs.mask[0] + tl * (16 * 64) + lane : nullptr, nullptr, nullptr, 0};
       WIDE_STAMP(1);
-      wide_net_fwd<G, ApplyHooks<G, STASH>, B6>(img_s, bias, cb, buf, img_t, C::O1, C::N1, xb, S, wave, lane, hk, tr);
+      wide_net_fwd<G, ApplyHooks<G, STASH>, B6, B6>(img_s, bias, cb, buf, img_t, C::O1, C::N1, xb, S, wave, lane, hk, tr);
       WIDE_STAMP(6);
       if (STASH) stash_store<G::CB>(make_stash_io(fs.out[0], tl, live ? 32 * G::CB : 0, l31, hi), S);
     }
