@@ -224,9 +224,6 @@ __device__ __forceinline__ StashIO make_stash_io(float *stash, long slot, int si
 // element e (= block * 16 + reg) of a C-layout array into its T-layout slot
 template <int NB>
 __device__ __forceinline__ void stash_put_T(const StashIO &st, int base, const f32x16 (&v)[NB], int e) {
-#ifdef NF_CHAIN_EXPERIMENT_NO_T_STORES  // timing experiment only (wrong gradients): the forward without its 144 T-layout stores per tile and coupling
-  return;
-#endif
   if (e < NB * 16) {
     const int r = e & 15;
     const float val = v[e >> 4][r];  // (bit_cast straight on a vector element reads element 0 under hipcc 7.2)
@@ -1592,20 +1589,10 @@ __device__ __forceinline__ void pair_consume(const float *__restrict__ img, cons
       SplitT<G::H2B> a2s;
       {
         float a2t[G::H2B][16];
-#ifdef NF_PAIR_EXPERIMENT_NO_ACT_LOADS  // timing experiment only (wrong gradients): what the kernel costs WITHOUT its 40 KB of activation reads per tile and coupling
-        for (int b = 0; b < G::H2B; ++b)
-          for (int t = 0; t < 16; ++t) a2t[b][t] = 0.25f + 0.001f * (float)(l31 + t);
-#else
         stash_get_T<G::H2B>(st, nbase + SG::A2, vT, a2t);
-#endif
         split_T<G::H2B>(a2t, a2s);
       }
-#ifdef NF_PAIR_EXPERIMENT_NO_ACT_LOADS
-      for (int b = 0; b < G::H1B; ++b)
-        for (int t = 0; t < 16; ++t) a1t[b][t] = 0.5f - 0.002f * (float)(l31 + t);
-#else
       stash_get_T<G::H1B>(st, nbase + SG::A1, vT, a1t);  // in flight behind dW3
-#endif
       NF_TS_STAMP(1);
       __syncthreads();  // B1
       NF_TS_STAMP(2);
@@ -1615,12 +1602,7 @@ __device__ __forceinline__ void pair_consume(const float *__restrict__ img, cons
     {
       SplitT<G::H1B> a1s;
       split_T<G::H1B>(a1t, a1s);
-#ifdef NF_PAIR_EXPERIMENT_NO_ACT_LOADS
-      for (int b = 0; b < G::MB; ++b)
-        for (int t = 0; t < 16; ++t) x2t[b][t] = 0.125f + 0.003f * (float)(l31 - t);
-#else
       stash_get_T<G::MB>(st, SG::XT, vT, x2t);
-#endif
       NF_TS_STAMP(3);
       __syncthreads();  // B2
       NF_TS_STAMP(4);

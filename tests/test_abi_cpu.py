@@ -139,3 +139,22 @@ def test_no_wide_store_is_followed_by_a_write_of_its_data_registers(nf):
     assert len(bad) == 1
     assert not mod.scan("0000 <k>:\n\tbuffer_store_dwordx4 v[64:67], v109, s[96:99], 0 offen   // 0\n\ts_nop 0\n\tv_add_u32_e32 v64, 0x3600, v117\n")
     assert mod.main() == 0
+
+
+def test_shipped_kernels_carry_no_wrong_on_purpose_experiment_switches():
+    """round 4 kept two timing-only build macros in nf_coupling.hip that compile a library returning WRONG
+    gradients.  They live in tools/experiments/ as patches now; nothing under the product sources may mention an
+    `*_EXPERIMENT_*` switch, and the default build's flag list defines none."""
+    import re
+
+    from __graft_entry__ import CSRC, FLAGS, ROOT
+
+    for dirpath in (CSRC, os.path.join(ROOT, "include")):
+        for name in sorted(os.listdir(dirpath)):
+            if not os.path.isfile(os.path.join(dirpath, name)):
+                continue
+            text = open(os.path.join(dirpath, name), errors="replace").read()
+            assert not re.search(r"\b[A-Z0-9_]*EXPERIMENT[A-Z0-9_]*\b", text), name
+    assert not any("EXPERIMENT" in f for f in FLAGS)
+    for patch in ("coupling_pair_timing_experiments.patch", "rqs_coop6_pipelined_recompute.patch"):
+        assert os.path.isfile(os.path.join(ROOT, "tools", "experiments", patch))
