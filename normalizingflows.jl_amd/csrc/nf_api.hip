@@ -49,6 +49,7 @@ int nf_affine_epilogue(nf_ctx *, const nf_flow_desc *, int mode, const float *sl
                        unsigned *t_ptr, double *gpart);
 size_t nf_affine_stash_floats(const nf_flow_desc *desc, long N);
 bool nf_affine_stash_pays(const nf_flow_desc *desc);
+bool nf_affine_fused_ok(const nf_flow_desc *desc);
 int nf_affine_bwd_stashed(nf_ctx *, const nf_flow_desc *, float *stash, float *ybar, const float *lbar, float lbar_const, long N,
                           float *slab, long slab_stride, int grid, bool inv_dir = false);
 long nf_affine_slab_floats(const nf_flow_desc *desc);
@@ -591,7 +592,7 @@ static long coupling_slab_floats(nf_ctx *ctx, const nf_flow_desc *desc, long N) 
 // The ELBO forward of a training step fuses into ONE launch (draws + chain + target + partial sums)
 // when the draws are in-library, the nets are LDS-resident and the target is the diagonal Gaussian.
 static inline bool elbo_fusable(const nf_flow_desc *desc, const nf_target *target, const void *xs) {
-  const bool resident = (desc->kind == NF_KIND_REALNVP && nf_affine_supported(desc)) ||
+  const bool resident = (desc->kind == NF_KIND_REALNVP && nf_affine_supported(desc) && nf_affine_fused_ok(desc)) ||
                         (desc->kind == NF_KIND_NSF && nf_rqs_supported(desc));
   return !xs && desc->dtype == NF_DTYPE_F32 && resident && target->kind == NF_TARGET_DIAGGAUSS && target->p0 && target->p1;
 }

@@ -1827,10 +1827,23 @@ __global__ __launch_bounds__(512) void k_affine_bwd_pair(BwdAllArgs aa, float *s
 // host-side dispatch
 // ------------------------------------------------------------------------------------
 static inline int blocks32(int n) { return (n + 31) / 32; }
+// nets with 1, 3 or 4 hidden layers (nf_deep.hip): to nf_api.hip they are "resident RealNVP flows without a stash", so every
+// nf_affine_* entry point below hands them over first
+int nf_deep_geo_id(const nf_flow_desc *desc);
+int nf_deep_image_floats(const nf_flow_desc *desc);
+size_t nf_deep_wimg_bytes(const nf_flow_desc *desc);
+long nf_deep_slab_floats(const nf_flow_desc *desc);
+int nf_deep_pack(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta);
+int nf_deep_reduce_slabs(nf_ctx *ctx, const nf_flow_desc *desc, const float *slab, int nslab, float *g, const double *lpart, int nlpart,
+                         float *lout);
+int nf_deep_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, float *xt, long N, float *ladj, int k_only, int accumulate);
+int nf_deep_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k_lo, int k_hi, float *y, float *ybar, const float *lbar, float lbar_const,
+                long N, float *slab, long slab_stride, int grid, bool inv_dir);
 #define NF_GEO_H32 NetGeo<1, 1, 1, 1>
 #define NF_GEO_H64 NetGeo<1, 2, 2, 1>
 
 static int geo_size(const nf_flow_desc *desc) {
+  if (desc->n_hidden != 2) return 0;
   const int c = (desc->d + 1) / 2;
   const int mb = blocks32(c), h1b = blocks32(desc->hdims[0]), h2b = blocks32(desc->hdims[1]);
   if (mb == 1 && h1b == 1 && h2b == 1) return NetGeo<1, 1, 1, 1>::SIZE;
@@ -1839,10 +1852,14 @@ static int geo_size(const nf_flow_desc *desc) {
 }
 
 // floats of one workgroup's gradient slab (image layout): [coupling][net s|t][G::SIZE]
-long nf_affine_slab_floats(const nf_flow_desc *desc) { return (long)2 * desc->nlayers * 2 * geo_size(desc); }
+long nf_affine_slab_floats(const nf_flow_desc *desc) {
+  if (nf_deep_geo_id(desc)) return nf_deep_slab_floats(desc);
+  return (long)2 * desc->nlayers * 2 * geo_size(desc);
+}
 
 int nf_affine_reduce_slabs(nf_ctx *ctx, const nf_flow_desc *desc, const float *slab, int nslab, float *g,
                            const double *lpart, int nlpart, float *lout) {
+  if (nf_deep_geo_id(desc)) return nf_deep_reduce_slabs(ctx, desc, slab, nslab, g, lpart, nlpart, lout);
   const int size = geo_size(desc);
   if (!size) return NF_ERR_UNSUPPORTED;
   const PackArgs p = make_pack_args(desc);
@@ -1913,6 +1930,7 @@ static size_t b6_image_bytes(int size) { return size == NetGeo<1, 1, 1, 1>::SIZE
 static size_t b6t_image_bytes(int size) { return size == NetGeo<1, 1, 1, 1>::SIZE ? B6TGeo<NetGeo<1, 1, 1, 1>>::BYTES : B6TGeo<NetGeo<1, 2, 2, 1>>::BYTES; }
 // ctx->wimg of a resident RealNVP flow: [fp32 images][B6 images (forward chain)][B6T images (pair kernel's dX GEMMs)]
 size_t nf_affine_wimg_bytes(const nf_flow_desc *desc) {
+  if (nf_deep_geo_id(desc)) return nf_deep_wimg_bytes(desc);
   const int size = geo_size(desc);
   return (size_t)2 * desc->nlayers * 2 * ((size_t)size * sizeof(float) + (size ? b6_image_bytes(size) + b6t_image_bytes(size) : 0));
 }
@@ -1951,6 +1969,7 @@ static int b6_refresh(nf_ctx *ctx, const nf_flow_desc *desc) {
 }
 
 int nf_affine_pack(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta) {
+  if (nf_deep_geo_id(desc)) return nf_deep_pack(ctx, desc, theta);
   if (desc->n_hidden != 2) return NF_ERR_UNSUPPORTED;
   const int size = geo_size(desc);
   if (!size) return NF_ERR_UNSUPPORTED;
@@ -2020,6 +2039,10 @@ static int launch_apply(nf_ctx *ctx, const CouplingArgs &a, const float *x, floa
 
 int nf_affine_apply(nf_ctx *ctx, const nf_flow_desc *desc, int k, bool inverse, const float *theta, const float *x,
                     long N, float *y, float *ladj, int accumulate) {
+  if (nf_deep_geo_id(desc)) {
+    if (x != y) return NF_ERR_UNSUPPORTED;  // (every caller applies a coupling in place on the tiled buffer)
+    return nf_deep_chain(ctx, desc, inverse, y, N, ladj, k, accumulate);
+  }
   CouplingArgs a;
   NF_TRY(make_args(ctx, desc, k, theta, N, &a));
   const int mb = blocks32(a.m > a.c ? a.m : a.c), h1b = blocks32(desc->hdims[0]), h2b = blocks32(desc->hdims[1]), cb = mb;
@@ -2137,6 +2160,7 @@ int nf_affine_chain_elbo(nf_ctx *ctx, const nf_flow_desc *desc, long N, uint64_t
 
 // whole chain in one launch, in place on the tiled buffer (packed images must be current)
 int nf_affine_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, float *xt, long N, float *ladj, float *stash) {
+  if (nf_deep_geo_id(desc)) return stash ? NF_ERR_UNSUPPORTED : nf_deep_chain(ctx, desc, inverse, xt, N, ladj, -1, 0);
   const int size = geo_size(desc);
   if (!size || !ctx->wimg) return NF_ERR_UNSUPPORTED;
   const bool b6 = fwd_b6(stash != nullptr);
@@ -2169,6 +2193,7 @@ int nf_affine_bwd_grid(nf_ctx *ctx, long N) {
 
 int nf_affine_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const float *theta, float *y, float *ybar,
                   const float *lbar, float lbar_const, long N, float *slab, long slab_stride, int grid) {
+  if (nf_deep_geo_id(desc)) return nf_deep_bwd(ctx, desc, k, k + 1, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid, false);
   CouplingArgs a;
   NF_TRY(make_args(ctx, desc, k, theta, N, &a));
   const int mb = blocks32(a.m > a.c ? a.m : a.c), h1b = blocks32(desc->hdims[0]), h2b = blocks32(desc->hdims[1]), cb = mb;
@@ -2199,6 +2224,7 @@ static int launch_bwd_all_v(nf_ctx *ctx, const BwdAllArgs &aa, float *y, float *
 // inv_dir: reverse pass of the INVERSE chain instead (y: T^-1(data) -> data, couplings in execution order).
 int nf_affine_bwd_all(nf_ctx *ctx, const nf_flow_desc *desc, float *y, float *ybar, const float *lbar, float lbar_const,
                       long N, float *slab, long slab_stride, int grid, bool inv_dir) {
+  if (nf_deep_geo_id(desc)) return nf_deep_bwd(ctx, desc, 0, 2 * desc->nlayers, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid, inv_dir);
   const int size = geo_size(desc);
   if (!size || !ctx->wimg || desc->n_hidden != 2) return NF_ERR_UNSUPPORTED;
   BwdAllArgs aa;
@@ -2332,7 +2358,10 @@ int nf_affine_bwd_stashed(nf_ctx *ctx, const nf_flow_desc *desc, float *stash, f
               : launch_bwd_stashed_v<NetGeo<1, 1, 1, 1>, false>(ctx, aa, stash, ybar, lbar, lbar_const, slab, slab_stride, grid, desc);
 }
 
+// the two-hidden-layer kernels with their fused forward (draws + chain + target in one launch), stash and epilogue
+bool nf_affine_fused_ok(const nf_flow_desc *desc) { return geo_size(desc) != 0; }
 bool nf_affine_supported(const nf_flow_desc *desc) {
+  if (nf_deep_geo_id(desc)) return true;
   if (desc->n_hidden != 2) return false;
   const int c = (desc->d + 1) / 2;  // larger of the two partitions
   const int mb = blocks32(c), h1b = blocks32(desc->hdims[0]), h2b = blocks32(desc->hdims[1]), cb = mb;

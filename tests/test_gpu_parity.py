@@ -712,8 +712,8 @@ def test_planar_radial_lane_per_sample_steps_against_oracle(nf, kind, d, nl, n, 
 ])
 def test_general_float32_couplings_run_their_mlp_on_mfma(nf, kind, d, hd, nl, K, n):
     """Round 3: `fnn` accepts any hdims (src/flows/utils.jl:71-100).  Float32 shapes outside the fused
-    kernels (NSF hidden > 32 or K not in {8, 10}; RealNVP with 1 / 3 / 4 hidden layers) run the conditioner MLP layer by layer
-    on MFMAs (nf_generic64.hip, "l64").  Forward, inverse round trip, ELBO loss / gradient (both draw forms) and the
+    kernels (NSF hidden > 32 or K not in {8, 10}; RealNVP nets wider than 64 with 1 / 3 / 4 hidden layers) run the conditioner MLP
+    layer by layer on MFMAs (nf_generic64.hip, "l64"); round 5: RealNVP with 1 / 3 / 4 narrow hidden layers runs nf_deep.hip's fused kernels.  Forward, inverse round trip, ELBO loss / gradient (both draw forms) and the
     forward-KL gradient against the oracle; the kernels that ran are checked by name."""
     import ctypes as C
     lib = nf.load_library()
@@ -749,12 +749,18 @@ def test_general_float32_couplings_run_their_mlp_on_mfma(nf, kind, d, hd, nl, K,
     P.scalar(f"{tag}: forward-KL loss", lk, lkr, 10 * P.LOSS_RTOL)
     P.gradient(f"{tag}: forward-KL grad", gk, gkr, 10 * P.GRAD_RTOL)
     ran = {}
-    for name in (b"l64_fwd", b"l64_dw", b"l64_bwdx", b"l64_couple"):
+    for name in (b"l64_fwd", b"l64_dw", b"l64_bwdx", b"l64_couple", b"deep_chain", b"deep_bwd", b"deep_bwd_inv"):
         a, c = C.c_double(0.0), C.c_int64(0)
         lib.nf_prof_read(ctx.ptr, name, C.byref(a), C.byref(c))
         ran[name] = c.value
     lib.nf_prof_enable(ctx.ptr, 0)
-    assert all(v > 0 for v in ran.values()), ran  # the MFMA layer kernels, not the scalar MLP
+    # round 5: RealNVP with 1 / 3 hidden layers up to 64 wide (4 up to 32) at d <= 64 has fused LDS-resident kernels of its own
+    # (nf_deep.hip) -- no layer-by-layer launch may be left for those; everything else: the MFMA layer kernels, not the scalar MLP
+    deep = kind == "realnvp" and d <= 64 and max(hd) <= 64 and (len(hd) in (1, 3) or (len(hd) == 4 and max(hd) <= 32))
+    if deep:
+        assert all(ran[k] > 0 for k in (b"deep_chain", b"deep_bwd", b"deep_bwd_inv")) and not any(ran[k] for k in (b"l64_fwd", b"l64_dw", b"l64_bwdx", b"l64_couple")), ran
+    else:
+        assert all(ran[k] > 0 for k in (b"l64_fwd", b"l64_dw", b"l64_bwdx", b"l64_couple")) and not ran[b"deep_chain"], ran
 
 
 def test_target_argument_conventions(nf):

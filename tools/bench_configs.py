@@ -66,7 +66,7 @@ def time_step(flow, tgt, n, steps, warmup=5):
     torch.cuda.synchronize()
     kern = {}
     for name in (b"base_sample", b"pack_weights", b"affine_chain", b"rqs_chain", b"simple_apply", b"simple_step", b"planar_step", b"radial_step", b"simple_finalize", b"target", b"affine_bwd",
-                 b"rqs_bwd", b"simple_bwd", b"wide_apply", b"wide_bwd", b"wide_dw", b"g64_apply", b"g64_bwd", b"l64_fwd", b"l64_couple", b"l64_dw", b"l64_bwdx", b"reduce_slabs", b"adam"):
+                 b"rqs_bwd", b"simple_bwd", b"wide_apply", b"wide_bwd", b"wide_dw", b"deep_chain", b"deep_bwd", b"g64_apply", b"g64_bwd", b"l64_fwd", b"l64_couple", b"l64_dw", b"l64_bwdx", b"reduce_slabs", b"adam"):
         a, c = C.c_double(0.0), C.c_int64(0)
         lib.nf_prof_read(ctx.ptr, name, C.byref(a), C.byref(c))
         if c.value:
@@ -170,9 +170,9 @@ def main():
         flow = nf.nsf(nf.MvNormal(32), (64, 64), 8, 3.0, 3, paramtype=torch.float32, device=dev, seed=123)
         res["gen_nsf_d32_h64_k8_n131072_general_kernels"] = time_step(flow, dg(32), 131072, max(3, args.steps // 10), warmup=2)
         flow = nf.realnvp(nf.MvNormal(64), (64, 64, 64), 4, paramtype=torch.float32, device=dev, seed=123)  # cfg 2 with a third hidden layer
-        res["gen_realnvp_d64_h64x3_n65536_general_kernels"] = time_step(flow, dg(64), 65536, max(3, args.steps // 10), warmup=2)
+        res["gen_realnvp_d64_h64x3_n65536"] = time_step(flow, dg(64), 65536, max(3, args.steps // 10), warmup=2)
         flow = nf.realnvp(nf.MvNormal(64), (64,), 4, paramtype=torch.float32, device=dev, seed=123)  # ... and with one
-        res["gen_realnvp_d64_h64x1_n65536_general_kernels"] = time_step(flow, dg(64), 65536, max(3, args.steps // 10), warmup=2)
+        res["gen_realnvp_d64_h64x1_n65536"] = time_step(flow, dg(64), 65536, max(3, args.steps // 10), warmup=2)
     if want("f64"):
         # Float64 coupling flows (test/flow.jl:7,72 runs RealNVP and NSF in Float64): the general kernels' scalar MLP, one thread
         # per sample -- the reference's test shape and a d = 64 case, so that the cost of this path is on record
