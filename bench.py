@@ -53,9 +53,13 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16
 # six bf16 x bf16 MFMA products per fp32 product.  `roofline.achieved / peak / frac` stay ALGORITHMIC fp32 flops against the
 # fp32-MFMA peak (the figure rounds 1-3 reported, and the only fp32-grade matrix instruction the chip has); the executed bf16
 # flops against the bf16 peak are reported beside it.  cfg 3's kernel still issues fp32 MFMAs.
-BF16X6 = {"cfg2": os.environ.get("NF_BWD_FP32") is None and os.environ.get("NF_BWD_NO_PAIR") is None
-                  and os.environ.get("NF_BWD_DW_FP32") is None and os.environ.get("NF_AFFINE_NO_STASH") is None,
-          "cfg4": os.environ.get("NF_WIDE_FP32") is None, "cfg3": False}
+# (the environment switches that select another kernel or form turn the label off: NF_STASH_SLIM forces the fp32 pair kernel too)
+BF16X6 = {"cfg2": all(os.environ.get(k) is None for k in ("NF_BWD_FP32", "NF_BWD_NO_PAIR", "NF_BWD_DW_FP32", "NF_AFFINE_NO_STASH", "NF_STASH_SLIM")),
+          "cfg4": os.environ.get("NF_WIDE_FP32") is None,
+          # round 5: the NSF reverse kernel's three output-layer GEMMs (576 of its 664 MFMAs per tile group) are six-term bf16
+          # products, layers 1-2 (88) stay fp32 MFMAs: the output layer is 11 776 of the net's 13 312 MACs per sample
+          "cfg3": os.environ.get("NF_RQS_BWD_FP32") is None and os.environ.get("NF_RQS_BWD_PERWAVE") is None}
+BF16_SHARE = {"cfg2": 1.0, "cfg4": 1.0, "cfg3": 11776.0 / 13312.0}  # share of the dominant kernel's algorithmic flops executed as bf16x6
 # algorithmic flops of ONE coupling's reverse pass per sample (step 786 432 =
 # fwd 262 144 + dX 262 144 + dW 262 144 over 8 couplings; recompute is not counted)
 MACS_NET = 32 * 64 + 64 * 64 + 64 * 32
@@ -277,7 +281,8 @@ def run_once(args, world, world_observed, rank, dev, dist, damp, state):
             state["lib_comm_failed"] = True
             if not state.get("lib_comm_hung") and int(lib.nf_comm_size(ctx.ptr)) > 1:
                 lib.nf_comm_destroy(ctx.ptr)
-    comm_size = int(lib.nf_comm_size(ctx.ptr))
+    # (after a hung set-up the abandoned thread may still be writing the context's communicator: it is not read again -- ADVICE r4)
+    comm_size = 1 if state.get("lib_comm_hung") else int(lib.nf_comm_size(ctx.ptr))
     if lib_comm and comm_size != world:
         raise SystemExit(f"library communicator has {comm_size} ranks, the process group {world}")
     # nf_elbo_step runs the whole iteration inside the library (for cfg 2 as three launches; with a communicator on the
@@ -449,6 +454,7 @@ def run_once(args, world, world_observed, rank, dev, dist, damp, state):
                                   else ", torch.distributed RCCL; libnfhip's communicator failed to initialise)" if state.get("lib_comm_failed")
                                   else ", torch.distributed RCCL)" if dist is not None else ")"),
                 "nf_comm_size": comm_size,
+                "lib_comm_hung": bool(state.get("lib_comm_hung")),  # nf_comm_init_rank did not return within NF_COMM_INIT_TIMEOUT: the run fell back to torch's collective and EXITS NON-ZERO
                 # messages the step's one logical all-reduce of [grad ; loss] travels as (nf_comm_bucket_count: buckets of whole
                 # couplings on a second stream for cfg 4's 16.9 MB, one message for cfg 2's 0.5 MB; 0 = no communicator)
                 "all_reduce_messages_per_step": int(lib.nf_comm_bucket_count(ctx.ptr, desc)) if lib_comm else (1 if dist is not None else 0),
@@ -474,18 +480,26 @@ def run_once(args, world, world_observed, rank, dev, dist, damp, state):
                 "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                "mfma_form": ("bf16x6: every fp32 product as six bf16 MFMA products of exactly split operands (fp32-grade, "
-                              "tools/probe/bf16x6_probe.hip); achieved / peak / frac above are ALGORITHMIC fp32 flops over the fp32-MFMA peak"
+                "frac_basis": ("ALGORITHMIC fp32 flops per launch / launch time / the fp32-MFMA peak (SURVEY 8(d)); where the GEMMs execute "
+                               "as bf16x6 this can exceed 1 -- the fp32 instruction is then not the pipe the kernel runs on; see "
+                               "executed_frac_of_bf16_peak for the executed form"),
+                "mfma_form": (("bf16x6: every fp32 product as six bf16 MFMA products of exactly split operands, split by rounding to nearest "
+                               "(fp32-grade: tools/probe/split_bias_probe.hip, tools/parity_ab.py)"
+                               + ("" if BF16_SHARE[args.workload] == 1.0 else f"; {BF16_SHARE[args.workload]:.3f} of the kernel's algorithmic flops, the rest fp32 MFMAs"))
                               if BF16X6[args.workload] else "fp32 MFMA (v_mfma_f32_32x32x2_f32)"),
-                "executed_bf16_tflops": 6.0 * achieved if BF16X6[args.workload] else None,
-                "executed_frac_of_bf16_peak": 6.0 * achieved / PEAK_BF16_MFMA_TFLOPS if BF16X6[args.workload] else None,
+                "executed_bf16_tflops": 6.0 * BF16_SHARE[args.workload] * achieved if BF16X6[args.workload] else None,
+                "executed_frac_of_bf16_peak": 6.0 * BF16_SHARE[args.workload] * achieved / PEAK_BF16_MFMA_TFLOPS if BF16X6[args.workload] else None,
                 "traffic": traffic,
                 "traffic_unit": "bytes per launch (HBM: 2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC, gfx950 correction)",
                 "traffic_source": traffic_src,
                 # the implementation's HBM bytes over the launch time: what the kernel actually pulls (the activation stash), next to
                 # what a plain copy / read / write loop reaches on an MI355X of this pool (tools/probe/peaks_probe.hip)
                 "traffic_rate_TBps": None if not traffic or avg_ms.value <= 0 else traffic / (avg_ms.value * 1e-3) / 1e12,
-                "measured_hbm_TBps": {"copy": 4.66, "read": 6.29, "write": 3.91, "source": "profiles/r4w_peaks_probe.txt"},
+                "reference_hbm_TBps": {"copy": 4.66, "read": 6.29, "write": 3.91, "source": "profiles/r4w_peaks_probe.txt",
+                                       "note": "constants measured once on an MI355X of this pool (tools/probe/peaks_probe.hip), NOT in this run"},
+                # avg_launch_ms: the dominant kernel's launches INSIDE the timed region (the command's K steps, on the clock ramp when
+                # the GPU was idle a moment ago); avg_launch_ms_sustained_clock: the same kernel in the sustained-clock measurement
+                # afterwards -- that one, and the `kernels` table below, are what profiles/*_kernel_stats_*.csv reproduce
                 "avg_launch_ms": avg_ms.value,
                 "launches_timed": cnt.value,
                 "timed_inside_the_timed_region": events_in_timed_region,
@@ -496,6 +510,7 @@ def run_once(args, world, world_observed, rank, dev, dist, damp, state):
                 "avg_launch_ms_sustained_clock": None if sustained is None else sustained[2],
             },
             "kernels": kernel_ms,
+            "kernels_note": "per-kernel HIP-event averages of 5 extra steps AFTER the timed region and the sustained-clock measurement (post-run, sustained clock) -- compare with roofline.avg_launch_ms_sustained_clock, not with roofline.avg_launch_ms",
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == "cfg2":
             rec["cpu_baseline"] = cpu_baseline()
@@ -574,10 +589,10 @@ def main():
     run_once(args, world, world_observed, rank, dev, dist, args.damp, state)  # ONE JSON line per invocation
     if dist is not None:
         dist.barrier()
-        if state.get("lib_comm_hung"):  # a thread of this process is still inside RCCL's init: do not wait for it at exit
-            sys.stdout.flush()
+        if state.get("lib_comm_hung"):  # a thread of this process is still inside RCCL's init: do not wait for it at exit --
+            sys.stdout.flush()          # and do not report success: the line above carries lib_comm_hung, the exit code says so too
             sys.stderr.flush()
-            os._exit(0)
+            os._exit(3)
         dist.destroy_process_group()
 
 

@@ -480,24 +480,49 @@ function elbo_step!(θ::ROCVector{T}, m::ROCVector{T}, v::ROCVector{T}, desc::NF
     return loss[], gnorm[]
 end
 
-# train_flow_fused(rng, flow, logp, n; max_iters, optimiser::Adam): the fused loop for a built-in target (same numbers as
-# train_flow over AutoNFHip; tests/test_gpu_tape.py checks that equality through the Python mirror of this function).
+# train_flow_fused(rng, flow, logp, n; max_iters, optimiser::Adam, state): the fused loop for a built-in target (same numbers as
+# train_flow over AutoNFHip; tests/test_gpu_tape.py checks that equality through the Python mirror of this function,
+# objectives._optimize_fused / _fused_steps_apply).
+# nf_elbo_step uses ONE index for the Philox stream of the draws and for Adam's step count t - 1, and draws from sample offset
+# 0 of a single-rank context.  So the fused loop applies only when the two are in step -- a fresh rng (stream 0) with a fresh
+# state, or an rng and a `state` continued together (rng.stream == state.t) -- with rng.offset == 0 and no communicator on the
+# context; anything else is refused here and belongs to train_flow over AutoNFHip (ADVICE r4: an rng that had already drawn
+# started Adam at t = stream + 1 with m = v = 0, and the offset was dropped).  A non-finite loss is recorded, not thrown, as
+# the reference's loop would record it (src/optimize.jl:85-99); the returned state carries the real step count.
+const NF_ERR_NONFINITE = Cint(-4)  # include/nfhip.h
+comm_size() = ccall((:nf_comm_size, libnfhip), Cint, (Ptr{Cvoid},), context())
+function fused_steps_apply(rng::NFHipRNG, state)
+    t0 = state === nothing ? 0 : Int(state.t)
+    return rng.offset == 0 && Int(rng.stream) == t0 && comm_size() <= 1
+end
 function train_flow_fused(rng::NFHipRNG, flow::Bijectors.TransformedDistribution, logp::NFHipTarget, n::Integer;
-                          max_iters::Int=1000, optimiser::Optimisers.Adam=Optimisers.Adam())
+                          max_iters::Int=1000, optimiser::Optimisers.Adam=Optimisers.Adam(), state=nothing)
+    fused_steps_apply(rng, state) ||
+        error("nfhip: train_flow_fused needs rng.stream == state.t (0 for a fresh run), rng.offset == 0 and a single-rank context; use train_flow(rng, elbo_batch, flow, logp, n; ADbackend = AutoNFHip(...)) otherwise")
     dflow = flow isa DeviceFlow ? flow : nfhip(flow)
     t = dflow.transform
-    θ = copy(t.θ); m = zero(θ); v = zero(θ)
+    θ = copy(t.θ)
+    m = state === nothing ? zero(θ) : copy(state.m)
+    v = state === nothing ? zero(θ) : copy(state.v)
+    steps = state === nothing ? 0 : Int(state.t)
     stats = NamedTuple[]
     weight_cache!(true)
     try
         for i in 1:max_iters
-            ls, gn = elbo_step!(θ, m, v, t.desc, logp, n, rng, next_stream!(rng), optimiser)
-            push!(stats, (iteration=i, loss=ls, gradient_norm=gn))
+            loss, gnorm = Ref{Cdouble}(0), Ref{Cdouble}(0)
+            code = ccall((:nf_elbo_step, libnfhip), Cint,
+                         (Ptr{Cvoid}, Ref{NFDesc}, Ref{NFTarget}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, UInt64, UInt32,
+                          Cdouble, Cdouble, Cdouble, Cdouble, Ref{Cdouble}, Ref{Cdouble}),
+                         context(), t.desc, c_target(logp), devptr(θ), devptr(m), devptr(v), n, rng.seed, next_stream!(rng),
+                         optimiser.eta, optimiser.beta[1], optimiser.beta[2], optimiser.epsilon, loss, gnorm)
+            code == NF_ERR_NONFINITE || check(code)   # a non-finite loss is recorded
+            steps += 1
+            push!(stats, (iteration=i, loss=loss[], gradient_norm=gnorm[]))
         end
     finally
         weight_cache!(false)
     end
-    return Bijectors.transformed(dflow.dist, NFHipTransform(θ, t.desc, t.re, false, t.keep)), stats, (m=m, v=v, t=max_iters)
+    return Bijectors.transformed(dflow.dist, NFHipTransform(θ, t.desc, t.re, false, t.keep)), stats, (m=m, v=v, t=steps)
 end
 
 end # module

@@ -296,8 +296,8 @@ def optimize(loss_and_grad: Callable, theta0: torch.Tensor, reconstruct, *, max_
 
 def _fused_steps_apply(vo, flow: Flow, rest, rng: PhiloxRNG, optimiser, kwargs) -> bool:
     """True when a training run is what nf_elbo_step computes in one call per iteration: reverse KL on in-library draws
-    of the whole batch, a built-in device target, Adam, no data-parallel hook, and the draw counter in step with Adam's
-    step count (a fresh run, or `state` and `rng` continued together) -- nf_elbo_step uses ONE index for both."""
+    of the whole batch, a built-in device target, Adam, no data-parallel hook or communicator, and the draw counter in step
+    with Adam's step count (a fresh run, or `state` and `rng` continued together) -- nf_elbo_step uses ONE index for both."""
     if vo not in (elbo, elbo_batch) or len(rest) != 2 or not isinstance(rest[1], int):
         return False
     if not (optimiser is None or isinstance(optimiser, Adam)) or kwargs.get("all_reduce") is not None:
@@ -306,6 +306,10 @@ def _fused_steps_apply(vo, flow: Flow, rest, rng: PhiloxRNG, optimiser, kwargs) 
     if st is not None and not isinstance(st, AdamState):
         return False
     if rng.sample_offset != 0 or rng.stream != (st.t if st is not None else 0):
+        return False
+    # a context that holds a communicator makes nf_elbo_step data-parallel (draw offset rank * n, global batch n * world, the
+    # all-reduce inside the library): not the run `optimize` over value_and_gradient would be
+    if int(flow.ctx.lib.nf_comm_size(flow.ctx.ptr)) > 1:
         return False
     return _builtin(flow, rest[0])
 
