@@ -2111,9 +2111,21 @@ extern "C" int nf_elbo_step(nf_ctx *ctx, const nf_flow_desc *desc, const nf_targ
     ctx->bucket.issued = 0;
     const int st_vg = nf_elbo_value_and_grad(ctx, desc, target, theta, nullptr, N, N * world, seed, off, step, gbuf);
     ctx->bucket.on = false;
-    NF_TRY(st_vg);
-    if (cpb > 0) NF_TRY(nf_comm_bucket_join(ctx));
-    else if (world > 1) NF_TRY(nf_allreduce_grad_loss(ctx, desc->dtype, gbuf, P + 1));
+    if (cpb > 0) {
+      // Join whatever was issued even when the gradient failed on this rank: the compute stream must not run ahead
+      // of collectives still in flight on the second stream, and the caller must learn that the step's buckets are incomplete
+      // -- the peers have enqueued ALL of theirs and will wait in RCCL for the ones this rank never issued.  That state is not
+      // recoverable inside the library: the error is returned, the context's communicator is unusable from here on
+      // (nf_comm_destroy + a new nf_comm_init_rank on every rank), which the header says of any failed collective call.
+      const int st_join = nf_comm_bucket_join(ctx);
+      const int want = (2 * desc->nlayers + cpb - 1) / cpb;
+      if (st_vg != NF_OK) return st_vg;
+      NF_TRY(st_join);
+      if (ctx->bucket.issued != want) return NF_ERR_RCCL;  // a reverse pass that issued fewer messages than nf_comm_bucket_count promises
+    } else {
+      NF_TRY(st_vg);
+      if (world > 1) NF_TRY(nf_allreduce_grad_loss(ctx, desc->dtype, gbuf, P + 1));
+    }
     char *gnorm_dev = (char *)gbuf + (size_t)(P + 1) * es;
     NF_TRY(nf_adam_update(ctx, desc->dtype, theta, gbuf, m, v, P, lr, beta1, beta2, eps, (int64_t)step + 1, gnorm_dev));
   }
