@@ -1,0 +1,429 @@
+// nf_g64m.h -- Float64 RealNVP couplings on the f64 matrix instruction (round 5).  Included by nf_generic64.hip (G64Args).
+//
+// The reference's DEFAULT constructors are Float64 (realnvp(q0; paramtype = Float64): src/flows/realnvp.jl:190-192;
+// test/flow.jl:7 runs both element types).  Rounds 1-4 ran Float64 couplings one thread per sample with the MLP as scalar FMA
+// loops over per-thread arrays in scratch memory (k_g64_apply / k_g64_bwd; round 4 moved the weight gradients to the matrix
+// pipe): 23.2 ms per step at d = 64, hidden [64, 64], 65 536 samples -- 40 x the Float32 step, where the two matrix pipes
+// differ by 2 x (VERDICT r4 missing 4).  Here the whole MLP runs on v_mfma_f64_16x16x4_f64 with the register chaining of
+// nf_mfma.h carried over to the f64 fragment layout (tools/probe/mfma_f64_probe.hip):
+//   lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15], receives D[(l >> 4) + 4 r][l & 15], r = 0..3.
+//   A wavefront owns a tile of 16 samples (j = l & 15); a 16-feature block of an activation is one f64x4 per lane, register r
+//   <-> feature q + 4 r (q = l >> 4): the D layout.  Contracting the next layer's k-step t over the features q + 4 t makes
+//   B-operand t of a block identical to its register t -- activations never leave the registers; only the weight (A) operands
+//   are fetched, from a padded f64 image of the net in LDS (row = input feature, row stride = 16 OB + 2 doubles: the
+//   transposed fetch of the dX GEMM is bank-conflict free, the forward fetch two-way -- 4 LDS cycles per 64-clock MFMA).
+//   The weight-gradient GEMM contracts over SAMPLES (lane <-> feature for both operands): the four waves of a workgroup
+//   leave a layer's input and cotangent tiles in LDS as [sample][feature], then SPLIT THE 16 x 16 BLOCKS of dW among them
+//   and each contracts its blocks over all 64 samples of the group (16 MFMAs per block) -- so a wave holds a quarter of a
+//   net's dW accumulators (64 registers at 32-64-64-32) instead of all of them (256), two workgroup barriers per layer.
+// Shapes: one or two hidden layers up to 64 wide, d <= 64 (conditioner and transformed half up to 32).  Standard batch layout
+// x[j d + i] (the general path's), the coupling's INPUT kept by the caller as the tape (as k_g64_bwd).  Gradient slabs in theta
+// order, reduced by nf_launch_reduce_slabs in a fixed order: deterministic.  Everything else Float64 (NSF, deeper / wider nets)
+// keeps the scalar kernels.
+#pragma once
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+template <int MB_, int HB_>
+struct G64M {
+  static constexpr int MB = MB_, HB = HB_, CB = MB_;  // blocks of 16: conditioner / hidden / transformed
+  static constexpr int SH = 16 * HB + 2, SC = 16 * CB + 2;  // row strides (doubles) of layers ending in a hidden / the output layer
+  // image of a net with NHID hidden layers: W0 [16 MB][SH] b0 [16 HB] | (W1 [16 HB][SH] b1 [16 HB]) | Wo [16 HB][SC] bo [16 CB]
+  static constexpr int W0 = 0, B0 = W0 + 16 * MB * SH;
+  static constexpr int W1 = B0 + 16 * HB, B1 = W1 + 16 * HB * SH;
+  static constexpr int img_wo(int nhid) { return nhid == 2 ? B1 + 16 * HB : W1; }
+  static constexpr int img_bo(int nhid) { return img_wo(nhid) + 16 * HB * SC; }
+  static constexpr int img_size(int nhid) { return (img_bo(nhid) + 16 * CB + 1) / 2 * 2; }
+  static constexpr int ST = 16 * (HB > MB ? HB : MB) + 2;   // row stride of the [sample][feature] tiles of the dW stage
+  static constexpr int TILE = 16 * ST;                       // doubles per tile
+  static constexpr size_t apply_lds(int nhid) { return (size_t)img_size(nhid) * 8; }
+  static constexpr size_t bwd_lds(int nhid) { return (size_t)(img_size(nhid) + 2 * 4 * TILE) * 8; }
+};
+
+// stage one Dense layer theta[in][out] (Flux: out x in column-major) into its padded image rows, zero fill
+__device__ __forceinline__ void g64m_stage_layer(double *__restrict__ w, double *__restrict__ b, int rows_pad, int S, int cols_pad,
+                                                 const double *__restrict__ theta, long w_off, long b_off, int nin, int nout, int tid) {
+  for (int e = tid; e < rows_pad * S; e += 256) {
+    const int i = e / S, o = e - i * S;
+    w[e] = (i < nin && o < nout) ? theta[w_off + (long)i * nout + o] : 0.0;
+  }
+  for (int o = tid; o < cols_pad; o += 256) b[o] = o < nout ? theta[b_off + o] : 0.0;
+}
+template <class G>
+__device__ __forceinline__ void g64m_stage_net(double *__restrict__ img, const double *__restrict__ theta, const G64Net &n, int tid) {
+  const int nhid = n.nl - 1;
+  g64m_stage_layer(img + G::W0, img + G::B0, 16 * G::MB, G::SH, 16 * G::HB, theta, n.w[0], n.b[0], n.dims[0], n.dims[1], tid);
+  if (nhid == 2) g64m_stage_layer(img + G::W1, img + G::B1, 16 * G::HB, G::SH, 16 * G::HB, theta, n.w[1], n.b[1], n.dims[1], n.dims[2], tid);
+  g64m_stage_layer(img + G::img_wo(nhid), img + G::img_bo(nhid), 16 * G::HB, G::SC, 16 * G::CB, theta, n.w[nhid], n.b[nhid], n.dims[nhid],
+                   n.dims[nhid + 1], tid);
+}
+
+__device__ __forceinline__ f64x4 g64m_mfma(double a, double b, f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+
+// out[ob] = W' in + b.  w: [16 IB rows][S], b: [16 OB]
+template <int IB, int OB, int S>
+__device__ __forceinline__ void g64m_fwd(const double *__restrict__ w, const double *__restrict__ b, const f64x4 (&in)[IB], f64x4 (&out)[OB],
+                                         int c16, int q) {
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[ob][r] = b[16 * ob + q + 4 * r];
+  const double *wl = w + q * S + c16;
+#pragma unroll
+  for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob) out[ob] = g64m_mfma(wl[(16 * ib + 4 * t) * S + 16 * ob], in[ib][t], out[ob]);
+}
+// din[ib] (+)= W delta (the dX GEMM): rows of w are the layer's inputs
+template <int IB, int OB, int S, bool ACCUM>
+__device__ __forceinline__ void g64m_bwdx(const double *__restrict__ w, const f64x4 (&delta)[OB], f64x4 (&din)[IB], int c16, int q) {
+  if (!ACCUM) {
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib) din[ib] = f64x4{0.0, 0.0, 0.0, 0.0};
+  }
+  const double *wl = w + c16 * S + q;
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib) din[ib] = g64m_mfma(wl[16 * ib * S + 16 * ob + 4 * t], delta[ob][t], din[ib]);
+}
+template <int NB>
+__device__ __forceinline__ void g64m_lrelu(f64x4 (&v)[NB]) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[b][r] = v[b][r] > 0.0 ? v[b][r] : 0.01 * v[b][r];
+}
+// delta *= leakyrelu'(z), from the sign of the post-activation value (leakyrelu keeps the sign)
+template <int NB>
+__device__ __forceinline__ void g64m_lrelu_grad(f64x4 (&d)[NB], const f64x4 (&act)[NB]) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d[b][r] *= act[b][r] > 0.0 ? 1.0 : 0.01;
+}
+// a wave's C-layout blocks -> its [sample][feature] tile (row stride ST): the operand layout of the dW GEMM
+template <int NB, int ST>
+__device__ __forceinline__ void g64m_to_tile(double *__restrict__ tile, const f64x4 (&v)[NB], int c16, int q) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tile[c16 * ST + 16 * b + q + 4 * r] = v[b][r];
+}
+
+// One layer's weight gradient, cooperatively: the layer has IB x OB blocks of 16 x 16; wave `wave` owns the blocks e = wave,
+// wave + 4, ... (e = ib * OB + ob) and contracts each over the 64 samples of the group's four tiles.  atiles / dtiles: the four
+// waves' input / cotangent tiles.  bsum: the bias gradient's partial sums ride on the blocks with ib == 0.
+template <int IB, int OB, int ST>
+struct G64MAcc {
+  static constexpr int NS = (IB * OB + 3) / 4;
+  f64x4 w[NS];
+  double b[NS];
+};
+template <int IB, int OB, int ST>
+__device__ __forceinline__ void g64m_zero(G64MAcc<IB, OB, ST> &a) {
+#pragma unroll
+  for (int s = 0; s < G64MAcc<IB, OB, ST>::NS; ++s) {
+    a.w[s] = f64x4{0.0, 0.0, 0.0, 0.0};
+    a.b[s] = 0.0;
+  }
+}
+template <int IB, int OB, int ST>
+__device__ __forceinline__ void g64m_dw(const double *__restrict__ atiles, const double *__restrict__ dtiles, G64MAcc<IB, OB, ST> &acc,
+                                        int wave, int c16, int q) {
+  constexpr int TILE = 16 * ST;
+#pragma unroll
+  for (int s = 0; s < G64MAcc<IB, OB, ST>::NS; ++s) {
+    const int e = wave + 4 * s;
+    if (e < IB * OB) {  // (wave-uniform)
+      const int ib = e / OB, ob = e - ib * OB;
+      const double *pa = atiles + q * ST + 16 * ib + c16;
+      const double *pd = dtiles + q * ST + 16 * ob + c16;
+      f64x4 w = acc.w[s];
+      double bs = 0.0;
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const double av = pa[tt * TILE + 4 * t * ST], dv = pd[tt * TILE + 4 * t * ST];
+          w = g64m_mfma(av, dv, w);
+          bs += dv;
+        }
+      acc.w[s] = w;
+      acc.b[s] += ib == 0 ? bs : 0.0;
+    }
+  }
+}
+// a wave's share of a layer's gradient -> the workgroup's slab (theta order, `slab` already offset by -slab_off)
+template <int IB, int OB, int ST>
+__device__ __forceinline__ void g64m_store(double *__restrict__ slab, const G64MAcc<IB, OB, ST> &acc, long w_off, long b_off, int nin,
+                                           int nout, int wave, int c16, int q) {
+#pragma unroll
+  for (int s = 0; s < G64MAcc<IB, OB, ST>::NS; ++s) {
+    const int e = wave + 4 * s;
+    if (e < IB * OB) {
+      const int ib = e / OB, ob = e - ib * OB;
+      const int o = 16 * ob + c16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * ib + q + 4 * r;
+        if (i < nin && o < nout) slab[w_off + (long)i * nout + o] = acc.w[s][r];
+      }
+      if (ib == 0) {
+        double v = acc.b[s];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (q == 0 && o < nout) slab[b_off + o] = v;
+      }
+    }
+  }
+}
+
+// the conditioner half of the standard-layout state into C-layout blocks (zero beyond m / N)
+template <int MB>
+__device__ __forceinline__ void g64m_load_cond(const double *__restrict__ row, int m, int par_c, bool valid, f64x4 (&xb)[MB], int q) {
+#pragma unroll
+  for (int b = 0; b < MB; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = 16 * b + q + 4 * r;
+      xb[b][r] = (valid && f < m) ? row[2 * f + par_c] : 0.0;
+    }
+}
+
+// net(x2) of one tile: hidden layers with leaky-ReLU; a1 / a2 kept for the reverse pass (a2 unused with one hidden layer)
+template <class G>
+__device__ __forceinline__ void g64m_net_fwd(const double *__restrict__ img, int nhid, const f64x4 (&xb)[G::MB], f64x4 (&a1)[G::HB],
+                                             f64x4 (&a2)[G::HB], f64x4 (&out)[G::CB], int c16, int q) {
+  g64m_fwd<G::MB, G::HB, G::SH>(img + G::W0, img + G::B0, xb, a1, c16, q);
+  g64m_lrelu<G::HB>(a1);
+  if (nhid == 2) {
+    g64m_fwd<G::HB, G::HB, G::SH>(img + G::W1, img + G::B1, a1, a2, c16, q);
+    g64m_lrelu<G::HB>(a2);
+    g64m_fwd<G::HB, G::CB, G::SC>(img + G::img_wo(2), img + G::img_bo(2), a2, out, c16, q);
+  } else {
+    g64m_fwd<G::HB, G::CB, G::SC>(img + G::img_wo(1), img + G::img_bo(1), a1, out, c16, q);
+  }
+}
+
+// ---- one coupling forward / inverse: y1 = x1 exp(s) + t (src/flows/realnvp.jl:57-63), x1 = (y1 - t) exp(-s) (:86-110) -------
+// Two passes over the workgroup's tiles, one net in LDS each: forward  s-net: y1 <- x1 exp(s), ladj += sum s;  t-net: y1 += t
+//                                                              inverse  t-net: y1 <- x1 - t;  s-net: y1 <- y1 exp(-s), ladj -= sum s
+// (both nets read only the conditioner half, which a coupling does not change).
+template <class G>
+__global__ __launch_bounds__(256) void k_g64m_apply(G64Args a, int inverse, const double *__restrict__ theta, const double *x, double *y,
+                                                    double *__restrict__ ladj) {
+  extern __shared__ __attribute__((aligned(16))) double lds64[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c16 = lane & 15, q = lane >> 4;
+  const int nhid = a.net[0].nl - 1, par_c = 1 - a.par_t;
+  const long ntiles = (a.N + 15) / 16;
+  for (int pass = 0; pass < 2; ++pass) {
+    const bool is_s = inverse ? pass == 1 : pass == 0;
+    __syncthreads();
+    g64m_stage_net<G>(lds64, theta, a.net[is_s ? 0 : 1], tid);
+    __syncthreads();
+    for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+      const long j = tile * 16 + c16;
+      const bool valid = j < a.N;
+      const long jr = valid ? j : a.N - 1;
+      const double *xr = x + jr * a.d;
+      double *yr = y + jr * a.d;
+      f64x4 xb[G::MB], a1[G::HB], a2[G::HB], out[G::CB];
+      g64m_load_cond<G::MB>(xr, a.m, par_c, valid, xb, q);
+      g64m_net_fwd<G>(lds64, nhid, xb, a1, a2, out, c16, q);
+      double lsum = 0.0;
+#pragma unroll
+      for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int p = 16 * b + q + 4 * r;
+          if (valid && p < a.c) {
+            const int idx = 2 * p + a.par_t;
+            if (is_s) {
+              const double s = tanh(out[b][r]);
+              const double v = pass == 0 ? xr[idx] : yr[idx];
+              yr[idx] = inverse ? v * exp(-s) : v * exp(s);
+              lsum += inverse ? -s : s;
+            } else {
+              const double v = pass == 0 ? xr[idx] : yr[idx];
+              yr[idx] = inverse ? v - out[b][r] : v + out[b][r];
+            }
+          }
+        }
+      if (is_s) {
+        lsum += __shfl_xor(lsum, 16);
+        lsum += __shfl_xor(lsum, 32);
+        if (q == 0 && valid) ladj[j] += lsum;
+      }
+      if (pass == 0 && y != x) {
+#pragma unroll
+        for (int b = 0; b < G::MB; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int f = 16 * b + q + 4 * r;
+            if (valid && f < a.m) yr[2 * f + par_c] = xb[b][r];
+          }
+      }
+    }
+  }
+}
+
+// ---- reverse pass of one coupling at its INPUT x (gbar: ybar -> xbar), or of the INVERSE coupling at its output (inv != 0):
+// the semantics of k_g64_bwd, nf_generic64.hip.  slabs: [gridDim.x][Pc], THIS coupling's parameters from theta index slab_off.
+template <class G>
+__global__ __launch_bounds__(256) void k_g64m_bwd(G64Args a, int inv, const double *__restrict__ theta, const double *__restrict__ x,
+                                                  double *gbar, const double *__restrict__ lbar, double lbar_const,
+                                                  double *__restrict__ slabs, long Pc, long slab_off) {
+  extern __shared__ __attribute__((aligned(16))) double lds64[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c16 = lane & 15, q = lane >> 4;
+  const int nhid = a.net[0].nl - 1, par_c = 1 - a.par_t;
+  double *img = lds64;
+  double *atiles = lds64 + G::img_size(nhid), *dtiles = atiles + 4 * G::TILE;  // [4 waves][16 samples][ST]
+  double *mya = atiles + wave * G::TILE, *myd = dtiles + wave * G::TILE;
+  double *slab = slabs + (long)blockIdx.x * Pc - slab_off;
+  const long ntiles = (a.N + 15) / 16, ngroups = (ntiles + 3) / 4;
+  for (int phase = 0; phase < 2; ++phase) {
+    const bool is_s = inv ? phase == 0 : phase == 1;  // forward coupling: t-net first (it reads ybar1 before the s phase rescales it)
+    const G64Net &net = a.net[is_s ? 0 : 1];
+    __syncthreads();
+    g64m_stage_net<G>(img, theta, net, tid);
+    __syncthreads();
+    G64MAcc<G::MB, G::HB, G::ST> acc0;
+    G64MAcc<G::HB, G::HB, G::ST> acc1;
+    G64MAcc<G::HB, G::CB, G::ST> acco;
+    g64m_zero(acc0);
+    g64m_zero(acc1);
+    g64m_zero(acco);
+    for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+      const long tile = grp * 4 + wave;
+      const long j = tile * 16 + c16;
+      const bool valid = j < a.N;
+      const long jr = valid ? j : a.N - 1;
+      const double *xr = x + jr * a.d;
+      double *gr = gbar + jr * a.d;
+      const double lb = valid ? (lbar ? lbar[jr] : lbar_const) : 0.0;
+      f64x4 xb[G::MB], a1[G::HB], a2[G::HB], dout[G::CB];
+      g64m_load_cond<G::MB>(xr, a.m, par_c, valid, xb, q);
+      g64m_net_fwd<G>(img, nhid, xb, a1, a2, dout, c16, q);
+      // element-wise stage -> cotangent of the net's output (rows beyond c and samples beyond N: 0)
+#pragma unroll
+      for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int p = 16 * b + q + 4 * r;
+          const bool ok = valid && p < a.c;
+          const int idx = 2 * p + a.par_t;
+          double dv = 0.0;
+          if (ok) {
+            if (is_s) {
+              const double s = tanh(dout[b][r]), x1 = xr[idx], gb = gr[idx];
+              if (inv) {  // x1 = (v1 - t) exp(-s), ladj_inv = -sum s:  v1bar = x1bar exp(-s), sbar = -x1bar x1 - lbar
+                gr[idx] = gb * exp(-s);
+                dv = (-gb * x1 - lb) * (1.0 - s * s);
+              } else {    // y1 = x1 exp(s) + t:  x1bar = ybar1 exp(s), sbar = ybar1 x1 exp(s) + lbar
+                const double es = exp(s);
+                gr[idx] = gb * es;
+                dv = (gb * x1 * es + lb) * (1.0 - s * s);
+              }
+            } else {
+              dv = inv ? -gr[idx] : gr[idx];  // tbar = ybar1 (forward); -v1bar (inverse: after the s phase rescaled it)
+            }
+          }
+          dout[b][r] = dv;
+        }
+      // ---- output layer
+      f64x4 dh[G::HB];
+      if (nhid == 2) {
+        g64m_to_tile<G::HB, G::ST>(mya, a2, c16, q);
+        g64m_bwdx<G::HB, G::CB, G::SC, false>(img + G::img_wo(2), dout, dh, c16, q);
+      } else {
+        g64m_to_tile<G::HB, G::ST>(mya, a1, c16, q);
+        g64m_bwdx<G::HB, G::CB, G::SC, false>(img + G::img_wo(1), dout, dh, c16, q);
+      }
+      g64m_to_tile<G::CB, G::ST>(myd, dout, c16, q);
+      __syncthreads();
+      g64m_dw<G::HB, G::CB, G::ST>(atiles, dtiles, acco, wave, c16, q);
+      __syncthreads();
+      if (nhid == 2) {
+        g64m_lrelu_grad<G::HB>(dh, a2);
+        f64x4 d1[G::HB];
+        g64m_to_tile<G::HB, G::ST>(mya, a1, c16, q);
+        g64m_to_tile<G::HB, G::ST>(myd, dh, c16, q);
+        g64m_bwdx<G::HB, G::HB, G::SH, false>(img + G::W1, dh, d1, c16, q);
+        __syncthreads();
+        g64m_dw<G::HB, G::HB, G::ST>(atiles, dtiles, acc1, wave, c16, q);
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < G::HB; ++b) dh[b] = d1[b];
+      }
+      g64m_lrelu_grad<G::HB>(dh, a1);
+      // ---- first layer: x2bar += W0 delta
+      f64x4 g2[G::MB];
+      g64m_to_tile<G::MB, G::ST>(mya, xb, c16, q);
+      g64m_to_tile<G::HB, G::ST>(myd, dh, c16, q);
+      g64m_bwdx<G::MB, G::HB, G::SH, false>(img + G::W0, dh, g2, c16, q);
+      __syncthreads();
+      g64m_dw<G::MB, G::HB, G::ST>(atiles, dtiles, acc0, wave, c16, q);
+      __syncthreads();
+#pragma unroll
+      for (int b = 0; b < G::MB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = 16 * b + q + 4 * r;
+          if (valid && f < a.m) gr[2 * f + par_c] += g2[b][r];
+        }
+    }
+    g64m_store<G::MB, G::HB, G::ST>(slab, acc0, net.w[0], net.b[0], net.dims[0], net.dims[1], wave, c16, q);
+    if (nhid == 2) g64m_store<G::HB, G::HB, G::ST>(slab, acc1, net.w[1], net.b[1], net.dims[1], net.dims[2], wave, c16, q);
+    g64m_store<G::HB, G::CB, G::ST>(slab, acco, net.w[nhid], net.b[nhid], net.dims[nhid], net.dims[nhid + 1], wave, c16, q);
+  }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------------
+// 0: not a shape of these kernels; otherwise 10 * MB + HB (blocks of 16)
+static int g64m_geo(const nf_flow_desc *desc) {
+  static const bool off = std::getenv("NF_G64_NO_F64_MFMA") != nullptr;  // A/B: the scalar Float64 kernels
+  if (off || desc->kind != NF_KIND_REALNVP || desc->dtype != NF_DTYPE_F64) return 0;
+  if (desc->n_hidden < 1 || desc->n_hidden > 2 || desc->d < 2 || desc->d > 64) return 0;
+  int hmax = 0;
+  for (int i = 0; i < desc->n_hidden; ++i) hmax = desc->hdims[i] > hmax ? desc->hdims[i] : hmax;
+  if (hmax < 1 || hmax > 64) return 0;
+  const int cmax = (desc->d + 1) / 2;
+  return 10 * (cmax <= 16 ? 1 : 2) + (hmax <= 32 ? 2 : 4);
+}
+using G64M12 = G64M<1, 2>;
+using G64M14 = G64M<1, 4>;
+using G64M22 = G64M<2, 2>;
+using G64M24 = G64M<2, 4>;
+#define G64M_DISPATCH(ID, CALL) ((ID) == 12 ? CALL(G64M12) : (ID) == 14 ? CALL(G64M14) : (ID) == 22 ? CALL(G64M22) : CALL(G64M24))
+
+template <class G>
+static int g64m_launch_apply(nf_ctx *ctx, const G64Args &a, int inverse, const double *theta, const double *x, double *y, double *ladj) {
+  const size_t lds = G::apply_lds(2);
+  static AttrOnce attr_once;
+  NF_TRY(attr_once.run(ctx->device, [&]() -> int {
+    NF_HIP(hipFuncSetAttribute((const void *)k_g64m_apply<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return NF_OK;
+  }));
+  const long ngroups = ((a.N + 15) / 16 + 3) / 4;
+  long grid = ngroups < 2L * ctx->num_cu ? ngroups : 2L * ctx->num_cu;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL((k_g64m_apply<G>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, inverse, theta, x, y, ladj);
+  return (int)hipGetLastError();
+}
+template <class G>
+static int g64m_launch_bwd(nf_ctx *ctx, const G64Args &a, int inv, const double *theta, const double *x, double *gbar, const double *lbar,
+                           double lbar_const, double *slabs, long Pc, long slab_off, unsigned grid) {
+  const size_t lds = G::bwd_lds(2);
+  static AttrOnce attr_once;
+  NF_TRY(attr_once.run(ctx->device, [&]() -> int {
+    NF_HIP(hipFuncSetAttribute((const void *)k_g64m_bwd<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return NF_OK;
+  }));
+  hipLaunchKernelGGL((k_g64m_bwd<G>), dim3(grid), dim3(256), lds, ctx->stream, a, inv, theta, x, gbar, lbar, lbar_const, slabs, Pc, slab_off);
+  return (int)hipGetLastError();
+}

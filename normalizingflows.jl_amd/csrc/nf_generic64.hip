@@ -1289,9 +1289,19 @@ static int l64_apply(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a, in
                      int slot);
 static int l64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &a, int inv, const float *theta, const float *x, float *gbar,
                    const float *lbar, float lbar_const, float *g, float *slabs, bool kept);
+#include "nf_g64m.h"  // Float64 RealNVP couplings on v_mfma_f64_16x16x4_f64 (round 5)
+
 template <class T>
 static int g64_launch_apply(nf_ctx *ctx, const nf_flow_desc *desc, unsigned grid, const G64Args &a, int inverse, const T *theta,
                             const T *x, T *y, T *ladj, int slot = 0) {
+  if constexpr (sizeof(T) == 8) {
+    if (const int gm = g64m_geo(desc)) {
+      ProfScope ps(ctx, "g64m_apply");
+#define G64M_CALL(G) g64m_launch_apply<G>(ctx, a, inverse, theta, x, y, ladj)
+      return G64M_DISPATCH(gm, G64M_CALL);
+#undef G64M_CALL
+    }
+  }
   if constexpr (sizeof(T) == 4) {
     if (l64_ok(desc)) {
       if (y != x) NF_HIP(hipMemcpyAsync(y, x, (size_t)a.N * a.d * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
@@ -1336,6 +1346,19 @@ static int g64_launch_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G6
     if (l64_ok(desc)) return l64_bwd(ctx, desc, k, a, inv, theta, x, gbar, lbar, lbar_const, g, slabs, kept);
   }
   const CouplingInfo ci = nf_coupling_info(desc, k);
+  if constexpr (sizeof(T) == 8) {
+    if (const int gm = g64m_geo(desc)) {
+      unsigned gridm = g64_bwd_blocks(desc, a.N);  // (the slab area is sized for that many workgroups)
+      if (gridm > (unsigned)ctx->num_cu) gridm = (unsigned)ctx->num_cu;
+      {
+        ProfScope ps(ctx, "g64m_bwd");
+#define G64M_CALL(G) g64m_launch_bwd<G>(ctx, a, inv, theta, x, gbar, lbar, lbar_const, slabs, ci.nparams, ci.theta_off, gridm)
+        NF_TRY(G64M_DISPATCH(gm, G64M_CALL));
+#undef G64M_CALL
+      }
+      return nf_launch_reduce_slabs(ctx, NF_DTYPE_F64, slabs, (int)gridm, ci.nparams, g + ci.theta_off);
+    }
+  }
   const unsigned grid = g64_bwd_blocks(desc, a.N);
   if (g64_fits<G64Small>(desc))
     hipLaunchKernelGGL((k_g64_bwd<T, G64Small>), dim3(grid), dim3(G64_BLOCK), 0, ctx->stream, a, inv, theta, x, gbar, lbar, lbar_const,

@@ -66,7 +66,7 @@ def time_step(flow, tgt, n, steps, warmup=5):
     torch.cuda.synchronize()
     kern = {}
     for name in (b"base_sample", b"pack_weights", b"affine_chain", b"rqs_chain", b"simple_apply", b"simple_step", b"planar_step", b"radial_step", b"simple_finalize", b"target", b"affine_bwd",
-                 b"rqs_bwd", b"simple_bwd", b"wide_apply", b"wide_bwd", b"wide_dw", b"deep_chain", b"deep_bwd", b"g64_apply", b"g64_bwd", b"l64_fwd", b"l64_couple", b"l64_dw", b"l64_bwdx", b"reduce_slabs", b"adam"):
+                 b"rqs_bwd", b"simple_bwd", b"wide_apply", b"wide_bwd", b"wide_dw", b"deep_chain", b"deep_bwd", b"g64m_apply", b"g64m_bwd", b"g64_apply", b"g64_bwd", b"l64_fwd", b"l64_couple", b"l64_dw", b"l64_bwdx", b"reduce_slabs", b"adam"):
         a, c = C.c_double(0.0), C.c_int64(0)
         lib.nf_prof_read(ctx.ptr, name, C.byref(a), C.byref(c))
         if c.value:
@@ -177,9 +177,9 @@ def main():
         # Float64 coupling flows (test/flow.jl:7,72 runs RealNVP and NSF in Float64): the general kernels' scalar MLP, one thread
         # per sample -- the reference's test shape and a d = 64 case, so that the cost of this path is on record
         flow = nf.realnvp(nf.MvNormal(5), (32, 32), 2, paramtype=torch.float64, device=dev, seed=123)
-        res["f64_realnvp_d5_h32_n65536_scalar_mlp"] = time_step(flow, dg(5, torch.float64), 65536, max(3, args.steps // 10), warmup=2)
+        res["f64_realnvp_d5_h32_n65536_f64_mfma"] = time_step(flow, dg(5, torch.float64), 65536, max(3, args.steps // 10), warmup=2)
         flow = nf.realnvp(nf.MvNormal(64), (64, 64), 4, paramtype=torch.float64, device=dev, seed=123)
-        res["f64_realnvp_d64_h64_n65536_scalar_mlp"] = time_step(flow, dg(64, torch.float64), 65536, max(3, args.steps // 10), warmup=2)
+        res["f64_realnvp_d64_h64_n65536_f64_mfma"] = time_step(flow, dg(64, torch.float64), 65536, max(3, args.steps // 10), warmup=2)
         flow = nf.nsf(nf.MvNormal(5), (32, 32), 10, 30.0, 2, paramtype=torch.float64, device=dev, seed=123)
         res["f64_nsf_d5_h32_k10_n65536_scalar_mlp"] = time_step(flow, dg(5, torch.float64), 65536, max(3, args.steps // 10), warmup=2)
     if want("fwd"):
