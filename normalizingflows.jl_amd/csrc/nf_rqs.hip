@@ -20,6 +20,7 @@
 // The spline (softmax / cumsum / bin search / rational quadratic, and its hand-derived
 // reverse pass) then runs entirely in registers, one (dim, sample) per lane at a time.
 #include <cstdlib>
+#include <type_traits>
 
 #include "nf_common.h"
 #include "nf_mfma.h"
@@ -456,12 +457,53 @@ __device__ __forceinline__ void chunk_put(f32x16 (&out)[G::OBC], int ql, const f
   }
 }
 
+// the output layer of a coupling as bf16 triples (six-term products, nf_mfma.h "B6"): image layout and its pack kernel; used by
+// the chain kernel's B6 variant below and by the cooperative reverse kernel k_rqs_bwd_coop6 (where the design is described)
+template <class G>
+struct RqsB6Geo {  // 16-byte units; per coupling [chunk][k-group][component][half][row]
+  static constexpr int FROWS = G::OBC * 32, FKG = 2 * G::H2B;  // recompute: rows = the chunk's columns, k over a2's features
+  static constexpr int TROWS = 32 * G::H2B, TKG = 2 * G::OBC;  // dX3: rows = a2's features, k over the chunk's columns
+  static constexpr int F_CH = FKG * 3 * 2 * FROWS, T_CH = TKG * 3 * 2 * TROWS;
+  static constexpr int OFF_T = G::NCH * F_CH;
+  static constexpr int U4 = G::NCH * (F_CH + T_CH);
+  static constexpr size_t BYTES = (size_t)U4 * 16;
+};
+
+template <class G>
+__global__ __launch_bounds__(256) void k_rqs_b6_from_images(int nimg, const float *__restrict__ wimg, nf_u32x4 *__restrict__ out) {
+  using B = RqsB6Geo<G>;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long)nimg * B::U4) return;
+  const int img = (int)(gid / B::U4);
+  int e = (int)(gid - (long)img * B::U4);
+  const float *src = wimg + (size_t)img * G::SIZE + G::W3;
+  const bool tr = e >= B::OFF_T;
+  if (tr) e -= B::OFF_T;
+  const int rows = tr ? B::TROWS : B::FROWS, nkg = tr ? B::TKG : B::FKG;
+  const int row = e % rows, hi = (e / rows) & 1, comp = (e / (2 * rows)) % 3, kg = (e / (6 * rows)) % nkg, ch = e / (6 * rows * nkg);
+  unsigned short part[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int kf = 16 * kg + (j & 3) + 8 * (j >> 2) + 4 * hi;  // k-slot (kg, hi, j) in the C-layout register order
+    const float w = tr ? src[row * G::S3 + ch * G::OBC * 32 + kf]    // [in = row][column kf of the chunk]
+                       : src[kf * G::S3 + ch * G::OBC * 32 + row];   // [in = kf][column row of the chunk]
+    unsigned short h, m, l;
+    nf_split1(w, h, m, l);
+    part[j] = comp == 0 ? h : comp == 1 ? m : l;
+  }
+  nf_u32x4 q;
+#pragma unroll
+  for (int pp = 0; pp < 4; ++pp) q[pp] = (unsigned)part[2 * pp] | ((unsigned)part[2 * pp + 1] << 16);
+  out[gid] = q;
+}
+
 // ---------------------------------------------------------------------------------------
 // whole-flow forward / inverse in one launch (same structure as k_affine_chain)
 // ---------------------------------------------------------------------------------------
 struct RqsChainArgs {
   RqsTape tape;       // spline tape to leave behind (training), or null pointers
   const float *wimg;  // [coupling][G::SIZE]
+  const nf_u32x4 *wimg6;  // [coupling][RqsB6Geo<G>::U4]: the output layers as bf16 triples (B6 variant), or null
   int d, ncoup;
   int k_only;  // -1: every coupling; otherwise only the coupling with this flat index
   float B;
@@ -470,10 +512,13 @@ struct RqsChainArgs {
 
 // tape: buffer descriptor of this (tile, coupling)'s slot of the spline tape; extent 0 (no tape wanted, or an idle wave)
 // drops the stores in hardware, so the step has no branch on it and needs no per-lane 64-bit address
-template <class G, bool INVERSE>
+// B6: the output layer as six-term bf16 products.  `img` then holds only layers 1-2 at their image offsets and the output
+// layer's bias at G::W3 (the "small image"); `w6` = the coupling's forward triples [chunk][k-group][h | m | l][half][row] in
+// LDS, which the workgroup's DMA may still be bringing in while layers 1-2 run: the barrier in the middle is that hand-over.
+template <class G, bool INVERSE, bool B6 = false>
 __device__ __forceinline__ float rqs_coupling_step(const float *__restrict__ img, f32x16 (&x1)[G::CB],
                                                    const f32x16 (&xb)[G::MB], int c, int m, float B, int l31, int hi,
-                                                   __amdgpu_buffer_rsrc_t tape) {
+                                                   __amdgpu_buffer_rsrc_t tape, const nf_u32x4 *__restrict__ w6 = nullptr) {
   const int tvoff = (hi * 32 + l31) * 4;
   f32x16 a2[G::H2B];
   {
@@ -492,10 +537,39 @@ __device__ __forceinline__ float rqs_coupling_step(const float *__restrict__ img
       nf_lrelu16(a2[b]);
   }
   float lsum = 0.f;
+  SplitC<G::H2B> a2s;  // (B6) a2 as bf16 triples, split once for the four chunks
+  if constexpr (B6) {
+    split_C<G::H2B>(a2, a2s);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the triples' DMA have landed ...
+    __syncthreads();                                  // ... and every other wave's
+  }
 #pragma unroll
   for (int ch = 0; ch < G::NCH; ++ch) {
     f32x16 out[G::OBC];
-    dense_fwd<G::H2B, G::OBC, G::S3>(img + G::W3 + ch * G::OBC * 32, img + G::B3 + ch * G::OBC * 32, a2, out, l31, hi);
+    if constexpr (B6) {
+      using B6G = RqsB6Geo<G>;
+      const float *b3c = img + G::W3 + ch * G::OBC * 32;
+#pragma unroll
+      for (int ob = 0; ob < G::OBC; ++ob)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[ob][r] = b3c[ob * 32 + nf_row(r, hi)];
+      const nf_u32x4 *wl = w6 + ch * B6G::F_CH + hi * B6G::FROWS + l31;
+#pragma unroll
+      for (int kg = 0; kg < B6G::FKG; ++kg)
+#pragma unroll
+        for (int ob = 0; ob < G::OBC; ++ob) {  // smallest terms first, as dense_fwd_b6
+          const nf_u32x4 wh = wl[((kg * 3 + 0) * 2) * B6G::FROWS + ob * 32], wm = wl[((kg * 3 + 1) * 2) * B6G::FROWS + ob * 32],
+                         wlo = wl[((kg * 3 + 2) * 2) * B6G::FROWS + ob * 32];
+          out[ob] = nf_mfma_bf16(wlo, a2s.h[kg], out[ob]);
+          out[ob] = nf_mfma_bf16(wh, a2s.l[kg], out[ob]);
+          out[ob] = nf_mfma_bf16(wm, a2s.m[kg], out[ob]);
+          out[ob] = nf_mfma_bf16(wm, a2s.h[kg], out[ob]);
+          out[ob] = nf_mfma_bf16(wh, a2s.m[kg], out[ob]);
+          out[ob] = nf_mfma_bf16(wh, a2s.h[kg], out[ob]);
+        }
+    } else {
+      dense_fwd<G::H2B, G::OBC, G::S3>(img + G::W3 + ch * G::OBC * 32, img + G::B3 + ch * G::OBC * 32, a2, out, l31, hi);
+    }
 #pragma unroll
     for (int ql = 0; ql < G::QCH; ++ql) {
       const int q = ch * G::QCH + ql;            // register index of x1 (block q / 16)
@@ -539,9 +613,25 @@ struct RqsFusedArgs {
   double pscale;
 };
 
-template <class G, bool INVERSE, bool FUSED = false>
+// LDS map of the chain kernel, in floats: the weight area, then (FUSED) the target parameters and the per-wave sums.
+//   fp32 form: two whole images [2][G::SIZE], the next coupling's brought in by DMA while the current one computes.
+//   B6 form (round 5): two SMALL images [2][SMALL] (layers 1-2 at their image offsets, the output layer's bias at G::W3) and
+//   ONE copy of the output layer as bf16 triples (74 KB at K = 8: two would not fit).  The next coupling's triples can only
+//   be requested once every wave is done with the current ones (the barrier that ends a coupling), and are needed after the
+//   next coupling's layers 1-2 -- whose 24 fp32 MFMAs + activations cover most of the transfer; the barrier in the middle of
+//   rqs_coupling_step completes the hand-over.  Two workgroup barriers per coupling instead of one, 144 bf16 MFMAs of 32
+//   clocks instead of 192 fp32 ones of 64 per tile and coupling.
+template <class G, bool B6>
+struct RqsChainLds {
+  static constexpr int SMALL = G::W3 + G::NCOLS;
+  static constexpr int F_U4 = G::NCH * RqsB6Geo<G>::F_CH;  // the forward triples of one coupling, 16-byte units
+  static constexpr int WAREA = B6 ? 2 * SMALL + 4 * F_U4 : 2 * G::SIZE;
+  static constexpr size_t BYTES = (size_t)(WAREA + 2 * 64 * G::CB + 2) * sizeof(float) + 8 * sizeof(double);
+};
+template <class G, bool INVERSE, bool FUSED = false, bool B6 = false>
 __global__ __launch_bounds__(512) void k_rqs_chain(RqsChainArgs a, float *xt, float *__restrict__ ladj, RqsFusedArgs fa) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  using CL = RqsChainLds<G, B6>;
   constexpr int NV4 = G::SIZE / 4;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -549,14 +639,32 @@ __global__ __launch_bounds__(512) void k_rqs_chain(RqsChainArgs a, float *xt, fl
   const long ntiles = (a.N + NF_TILE - 1) / NF_TILE;
   const long ngroups = (ntiles + 7) / 8;
   auto coupling_at = [&](int s) { return INVERSE ? s : a.ncoup - 1 - s; };
-  {
+  // global -> LDS by DMA (buffer_load ... lds), 1 KB pieces dealt round-robin to the eight waves; complete at the issuing wave's
+  // next vmcnt(0) + a workgroup barrier
+  typedef __attribute__((address_space(3))) void lds_void_t;
+  auto dma = [&](float *dst, const void *src, int nbytes) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(src), 0, nbytes, 0x00020000);
+    const int np = (nbytes + 1023) / 1024;
+    for (int p = wave; p < np; p += 8)
+      if (p * 1024 + lane * 16 < nbytes)  // the last piece may be partial: its idle lanes must not write
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t *)(dst + p * 256), 16, lane * 16, p * 1024, 0, 0);
+  };
+  float *const t6 = lds + 2 * CL::SMALL;  // (B6) the triples
+  auto dma_small = [&](float *dst, int k) {  // layers 1-2 | output bias
+    dma(dst, a.wimg + (long)k * G::SIZE, G::W3 * 4);
+    dma(dst + G::W3, a.wimg + (long)k * G::SIZE + G::B3, G::NCOLS * 4);
+  };
+  if constexpr (B6) {
+    dma_small(lds, coupling_at(0));
+    dma(t6, a.wimg6 + (long)coupling_at(0) * RqsB6Geo<G>::U4, CL::F_U4 * 16);
+  } else {
     const float4 *src = reinterpret_cast<const float4 *>(a.wimg + (long)coupling_at(0) * G::SIZE);
     float4 *dst = reinterpret_cast<float4 *>(lds);
     for (int i = tid; i < NV4; i += 512) dst[i] = src[i];
   }
   // FUSED: target parameters by feature, zero padded: tmu[f], tiv[f] = 1/var[f]; tc0 = d log 2pi + sum log var
   constexpr int TP = 64 * G::CB;
-  float *tmu = lds + 2 * G::SIZE, *tiv = tmu + TP, *tc0 = tiv + TP;
+  float *tmu = lds + CL::WAREA, *tiv = tmu + TP, *tc0 = tiv + TP;
   double *wsum = reinterpret_cast<double *>(tc0 + 2);  // [8] per-wave partial sums (G::SIZE and TP are even)
   if (FUSED) {
     for (int i = tid; i < TP; i += 512) {
@@ -629,18 +737,11 @@ __global__ __launch_bounds__(512) void k_rqs_chain(RqsChainArgs a, float *xt, fl
         const int pos = s + half;
         const bool have_next = pos + 1 < a.ncoup || more_groups;
         const int knext = coupling_at(pos + 1 < a.ncoup ? pos + 1 : 0);
-        if (have_next) {
-          // LDS-DMA straight into the other image buffer (as in k_affine_chain); complete at the barrier below
-          typedef __attribute__((address_space(3))) void lds_void_t;
-          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wimg) + (long)knext * G::SIZE, 0, G::SIZE * 4, 0x00020000);
-          float *dstb = lds + (buf ^ 1) * G::SIZE;
-          constexpr int NP = (G::SIZE * 4 + 1023) / 1024;
-          const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-          for (int p = wave; p < NP; p += 8)
-            if (p * 1024 + lane * 16 < G::SIZE * 4)  // the last piece is partial: its idle lanes must not write
-              __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t *)(dstb + p * 256), 16, lane * 16, p * 1024, 0, 0);
+        if (have_next) {  // LDS-DMA straight into the other image buffer (as in k_affine_chain); complete at the barrier below
+          if constexpr (B6) dma_small(lds + (buf ^ 1) * CL::SMALL, knext);
+          else dma(lds + (buf ^ 1) * G::SIZE, a.wimg + (long)knext * G::SIZE, G::SIZE * 4);
         }
-        const float *img = lds + buf * G::SIZE;
+        const float *img = lds + buf * (B6 ? CL::SMALL : G::SIZE);
         // forward: position 0 is the last flat coupling (odd index, mask 2:2:d): x1 = O
         if (a.k_only < 0 || a.k_only == coupling_at(pos)) {
           constexpr int ROWS = G::NCH * G::QCH;
@@ -648,11 +749,14 @@ __global__ __launch_bounds__(512) void k_rqs_chain(RqsChainArgs a, float *xt, fl
           const __amdgpu_buffer_rsrc_t tp = __builtin_amdgcn_make_buffer_rsrc(
               a.tape.base + (a.tape.base ? slot * (ROWS * 64) : 0), 0, (a.tape.base && live) ? ROWS * 256 : 0, 0x00020000);
           if (INVERSE ? (half == 1) : (half == 0))
-            lsum += rqs_coupling_step<G, INVERSE>(img, O, E, c_even, a.d - c_even, a.B, l31, hi, tp);
+            lsum += rqs_coupling_step<G, INVERSE, B6>(img, O, E, c_even, a.d - c_even, a.B, l31, hi, tp, reinterpret_cast<const nf_u32x4 *>(t6));
           else
-            lsum += rqs_coupling_step<G, INVERSE>(img, E, O, c_odd, a.d - c_odd, a.B, l31, hi, tp);
+            lsum += rqs_coupling_step<G, INVERSE, B6>(img, E, O, c_odd, a.d - c_odd, a.B, l31, hi, tp, reinterpret_cast<const nf_u32x4 *>(t6));
         }
         __syncthreads();
+        if constexpr (B6) {  // every wave is done with this coupling's triples: the next coupling's may come
+          if (have_next) dma(t6, a.wimg6 + (long)knext * RqsB6Geo<G>::U4, CL::F_U4 * 16);
+        }
         buf ^= 1;
       }
     }
@@ -1512,44 +1616,6 @@ __global__ __launch_bounds__(256, RQS_COOP_WAVES_PER_SIMD(G)) void k_rqs_bwd_coo
 // x2 and a1 of the home tile wait in registers for the closing home phase (their transpose tiles alias the delta ring),
 // which together with the missing W3 image leaves room for both sets of partial-d2 slots at every geometry.
 template <class G>
-struct RqsB6Geo {  // 16-byte units; per coupling [chunk][k-group][component][half][row]
-  static constexpr int FROWS = G::OBC * 32, FKG = 2 * G::H2B;  // recompute: rows = the chunk's columns, k over a2's features
-  static constexpr int TROWS = 32 * G::H2B, TKG = 2 * G::OBC;  // dX3: rows = a2's features, k over the chunk's columns
-  static constexpr int F_CH = FKG * 3 * 2 * FROWS, T_CH = TKG * 3 * 2 * TROWS;
-  static constexpr int OFF_T = G::NCH * F_CH;
-  static constexpr int U4 = G::NCH * (F_CH + T_CH);
-  static constexpr size_t BYTES = (size_t)U4 * 16;
-};
-
-template <class G>
-__global__ __launch_bounds__(256) void k_rqs_b6_from_images(int nimg, const float *__restrict__ wimg, nf_u32x4 *__restrict__ out) {
-  using B = RqsB6Geo<G>;
-  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= (long)nimg * B::U4) return;
-  const int img = (int)(gid / B::U4);
-  int e = (int)(gid - (long)img * B::U4);
-  const float *src = wimg + (size_t)img * G::SIZE + G::W3;
-  const bool tr = e >= B::OFF_T;
-  if (tr) e -= B::OFF_T;
-  const int rows = tr ? B::TROWS : B::FROWS, nkg = tr ? B::TKG : B::FKG;
-  const int row = e % rows, hi = (e / rows) & 1, comp = (e / (2 * rows)) % 3, kg = (e / (6 * rows)) % nkg, ch = e / (6 * rows * nkg);
-  unsigned short part[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int kf = 16 * kg + (j & 3) + 8 * (j >> 2) + 4 * hi;  // k-slot (kg, hi, j) in the C-layout register order
-    const float w = tr ? src[row * G::S3 + ch * G::OBC * 32 + kf]    // [in = row][column kf of the chunk]
-                       : src[kf * G::S3 + ch * G::OBC * 32 + row];   // [in = kf][column row of the chunk]
-    unsigned short h, m, l;
-    nf_split1(w, h, m, l);
-    part[j] = comp == 0 ? h : comp == 1 ? m : l;
-  }
-  nf_u32x4 q;
-#pragma unroll
-  for (int pp = 0; pp < 4; ++pp) q[pp] = (unsigned)part[2 * pp] | ((unsigned)part[2 * pp + 1] << 16);
-  out[gid] = q;
-}
-
-template <class G>
 struct RqsCoop6Lds {
   static_assert(G::NCH == 4, "one chunk per wave");
   static constexpr int DBLK = (G::H1B > G::H2B ? G::H1B : G::H2B);
@@ -2058,11 +2124,47 @@ int nf_rqs_reduce_slabs(nf_ctx *ctx, const nf_flow_desc *desc, const float *slab
   return (int)hipGetLastError();
 }
 
+static bool rqs_fwd_b6() {
+  static const bool off = std::getenv("NF_RQS_FWD_FP32") != nullptr;  // A/B switch: the chain kernel's output layer on fp32 MFMAs
+  return !off;
+}
 template <class G>
 static int launch_rqs_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, float *xt, long N, float *ladj,
                             int k_only, const RqsFusedArgs *fused = nullptr, void *tape = nullptr) {
+  RqsChainArgs a;
+  a.tape = rqs_tape_at(desc, N, tape);
+  a.wimg = (const float *)ctx->wimg;
+  a.wimg6 = nullptr;
+  a.d = desc->d; a.ncoup = 2 * desc->nlayers; a.B = desc->B; a.N = N; a.k_only = k_only;
+  const long ngroups = ((N + NF_TILE - 1) / NF_TILE + 7) / 8;
+  long grid = ngroups < ctx->num_cu ? ngroups : ctx->num_cu;
+  if (grid < 1) grid = 1;
+  RqsFusedArgs none{};
+  // whole-chain launches of the K = 8 geometry (cfg 3): the output layer as six-term bf16 products from the triple images
+  if constexpr (std::is_same<G, GeoK8>::value) {
+    if (k_only < 0 && rqs_fwd_b6()) {
+      const size_t lds6 = RqsChainLds<G, true>::BYTES;
+      static AttrOnce attr_once6;  // once per device
+      NF_TRY(attr_once6.run(ctx->device, [&]() -> int {
+        NF_HIP(hipFuncSetAttribute((const void *)k_rqs_chain<G, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6));
+        NF_HIP(hipFuncSetAttribute((const void *)k_rqs_chain<G, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6));
+        NF_HIP(hipFuncSetAttribute((const void *)k_rqs_chain<G, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6));
+        return NF_OK;
+      }));
+      NF_TRY(rqs_b6_refresh<G>(ctx, desc));
+      a.wimg6 = (const nf_u32x4 *)((const char *)ctx->wimg + rqs_fp32_bytes(desc));
+      ProfScope ps(ctx, "rqs_chain");
+      if (fused)
+        hipLaunchKernelGGL((k_rqs_chain<G, false, true, true>), dim3((unsigned)grid), dim3(512), lds6, ctx->stream, a, xt, ladj, *fused);
+      else if (inverse)
+        hipLaunchKernelGGL((k_rqs_chain<G, true, false, true>), dim3((unsigned)grid), dim3(512), lds6, ctx->stream, a, xt, ladj, none);
+      else
+        hipLaunchKernelGGL((k_rqs_chain<G, false, false, true>), dim3((unsigned)grid), dim3(512), lds6, ctx->stream, a, xt, ladj, none);
+      return (int)hipGetLastError();
+    }
+  }
   // two double-buffered images + target parameters and per-wave sums of the fused variant
-  const size_t lds = (2 * (size_t)G::SIZE + 2 * 64 * G::CB + 2) * sizeof(float) + 8 * sizeof(double);
+  const size_t lds = RqsChainLds<G, false>::BYTES;
   static AttrOnce attr_once;  // once per device: a context on another GPU needs its own
   NF_TRY(attr_once.run(ctx->device, [&]() -> int {
     NF_HIP(hipFuncSetAttribute((const void *)k_rqs_chain<G, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2070,15 +2172,7 @@ static int launch_rqs_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse,
     NF_HIP(hipFuncSetAttribute((const void *)k_rqs_chain<G, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return NF_OK;
   }));
-  RqsChainArgs a;
-  a.tape = rqs_tape_at(desc, N, tape);
-  a.wimg = (const float *)ctx->wimg;
-  a.d = desc->d; a.ncoup = 2 * desc->nlayers; a.B = desc->B; a.N = N; a.k_only = k_only;
-  const long ngroups = ((N + NF_TILE - 1) / NF_TILE + 7) / 8;
-  long grid = ngroups < ctx->num_cu ? ngroups : ctx->num_cu;
-  if (grid < 1) grid = 1;
   ProfScope ps(ctx, "rqs_chain");
-  RqsFusedArgs none{};
   if (fused)
     hipLaunchKernelGGL((k_rqs_chain<G, false, true>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, *fused);
   else if (inverse)
