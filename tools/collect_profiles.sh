@@ -36,6 +36,19 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MO
 # (round 4: part of the GEMMs run on the bf16 matrix cores -- their MFMA ops are counted by a counter of their own)
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA -d "$OUT/pmc_cfg2_mfma_bf16" -o pmc --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_cfg2_mfma_bf16.log" 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 -d "$OUT/pmc_cfg3_mfma" -o pmc --output-format csv -- python3 bench.py --workload cfg3 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_cfg3_mfma.log" 2>&1
+# (round 5: the NSF kernels' output-layer GEMMs run on the bf16 matrix cores)
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA -d "$OUT/pmc_cfg3_mfma_bf16" -o pmc --output-format csv -- python3 bench.py --workload cfg3 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_cfg3_mfma_bf16.log" 2>&1
+# A/B of the cfg-3 kernels on this box: the fp32-MFMA reverse kernel / forward chain of rounds 2-4
+NF_RQS_BWD_FP32=1 python3 bench.py --workload cfg3 --steps 50 --no-cpu-baseline > "$OUT/bench_cfg3_bwd_fp32_mfma.json" 2>> "$OUT/bench_default.err"
+NF_RQS_FWD_FP32=1 python3 bench.py --workload cfg3 --steps 50 --no-cpu-baseline > "$OUT/bench_cfg3_fwd_fp32_mfma.json" 2>> "$OUT/bench_default.err"
+# the general layer-by-layer path for the shapes nf_deep.hip fuses since round 5, and the scalar Float64 kernels
+NF_DEEP_OFF=1 python3 tools/bench_configs.py --steps 30 --only gen_realnvp > "$OUT/configs_deep_off.txt" 2>&1
+# kernel-trace statistics of the deep / Float64 configurations (which kernels run)
+rocprofv3 --kernel-trace --stats -d "$OUT/kt_gen" -o gen --output-format csv -- python3 tools/bench_configs.py --only gen_realnvp,f64_realnvp --steps 30 > "$OUT/kt_gen.log" 2>&1
+# arithmetic A/B of the named parity arrays (tools/parity_ab.py): default and fp32 MFMA chains
+python3 tools/parity_ab.py "$OUT/parity_ab_default.json" > "$OUT/parity_ab_default.txt" 2>&1
+NF_FWD_FP32=1 NF_BWD_FP32=1 NF_WIDE_FP32=1 python3 tools/parity_ab.py "$OUT/parity_ab_fp32_mfma.json" > "$OUT/parity_ab_fp32_mfma.txt" 2>&1
+./tools/probe/split_bias_probe > "$OUT/split_bias_probe.txt" 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU -d "$OUT/pmc_cfg3_valu" -o pmc --output-format csv -- python3 bench.py --workload cfg3 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_cfg3_valu.log" 2>&1
 # issue-side counters of the planar / radial step (missing 5): where k_simple_step's time goes
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS SQ_INSTS_SALU -d "$OUT/pmc_simple_issue" -o pmc --output-format csv -- python3 tools/bench_simple.py 262144 > "$OUT/pmc_simple_issue.log" 2>&1
@@ -60,6 +73,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C -d "$OUT/pmc_cfg4_$C" -o pmc --output-format csv -- python3 bench.py --workload cfg4 --batch 32768 --steps 3 --warmup 1 --no-kernel-events > "$OUT/pmc_cfg4_$C.log" 2>&1
 done
 python3 tools/bench_configs.py --steps 30 --only f64 >> "$OUT/configs.txt" 2>&1
+NF_G64_NO_F64_MFMA=1 python3 tools/bench_configs.py --steps 30 --only f64_realnvp > "$OUT/configs_f64_scalar.txt" 2>&1
 # keep the merge-back small: per-dispatch traces can be large
 find "$OUT" -name "*kernel_trace.csv" -size +4M -delete
 find "$OUT" -name "*.csv" | head -60

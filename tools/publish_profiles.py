@@ -26,7 +26,13 @@ copies = [("bench_default.json", "bench_default.json"), ("bench_cfg3.json", "ben
           ("bench_default_b6_stashing_forward.json", "bench_default_b6_stashing_forward.json"), ("configs_fp32_forward.txt", "configs_fp32_forward.txt"),
           ("bench_default_pair_dw_fp32.json", "bench_default_pair_dw_fp32.json"),
           ("bench_cfg4_shard_32768_fp32_mfma.json", "bench_cfg4_shard32768_fp32_mfma.json"),
-          ("bench_cfg4_1gpu_262144_fp32_mfma.json", "bench_cfg4_1gpu_262144_fp32_mfma.json")]
+          ("bench_cfg4_1gpu_262144_fp32_mfma.json", "bench_cfg4_1gpu_262144_fp32_mfma.json"),
+          ("bench_cfg3_bwd_fp32_mfma.json", "bench_cfg3_bwd_fp32_mfma.json"), ("bench_cfg3_fwd_fp32_mfma.json", "bench_cfg3_fwd_fp32_mfma.json"),
+          ("configs_deep_off.txt", "configs_deep_off.txt"), ("configs_f64_scalar.txt", "configs_f64_scalar.txt"),
+          ("kt_gen/gen_kernel_stats.csv", "kernel_stats_deep_f64.csv"),
+          ("parity_ab_default.json", "parity_ab_default.json"), ("parity_ab_fp32_mfma.json", "parity_ab_fp32_mfma.json"),
+          ("parity_ab_default.txt", "parity_ab_default.txt"), ("parity_ab_fp32_mfma.txt", "parity_ab_fp32_mfma.txt"),
+          ("split_bias_probe.txt", "split_bias_probe.txt")]
 for w in ("cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "simple"):
     copies.append((f"kt_{w}/{w}_kernel_stats.csv", f"kernel_stats_{w}.csv"))
 for a, b in copies:
