@@ -42,9 +42,9 @@ rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA -d "$OUT/pmc_cfg3_mfm
 NF_RQS_BWD_FP32=1 python3 bench.py --workload cfg3 --steps 50 --no-cpu-baseline > "$OUT/bench_cfg3_bwd_fp32_mfma.json" 2>> "$OUT/bench_default.err"
 NF_RQS_FWD_FP32=1 python3 bench.py --workload cfg3 --steps 50 --no-cpu-baseline > "$OUT/bench_cfg3_fwd_fp32_mfma.json" 2>> "$OUT/bench_default.err"
 # the general layer-by-layer path for the shapes nf_deep.hip fuses since round 5, and the scalar Float64 kernels
-NF_DEEP_OFF=1 python3 tools/bench_configs.py --steps 30 --only gen_realnvp > "$OUT/configs_deep_off.txt" 2>&1
+NF_DEEP_OFF=1 python3 tools/bench_configs.py --steps 30 --only gen > "$OUT/configs_deep_off.txt" 2>&1
 # kernel-trace statistics of the deep / Float64 configurations (which kernels run)
-rocprofv3 --kernel-trace --stats -d "$OUT/kt_gen" -o gen --output-format csv -- python3 tools/bench_configs.py --only gen_realnvp,f64_realnvp --steps 30 > "$OUT/kt_gen.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$OUT/kt_gen" -o gen --output-format csv -- python3 tools/bench_configs.py --only gen,f64 --steps 30 > "$OUT/kt_gen.log" 2>&1
 # arithmetic A/B of the named parity arrays (tools/parity_ab.py): default and fp32 MFMA chains
 python3 tools/parity_ab.py "$OUT/parity_ab_default.json" > "$OUT/parity_ab_default.txt" 2>&1
 NF_FWD_FP32=1 NF_BWD_FP32=1 NF_WIDE_FP32=1 python3 tools/parity_ab.py "$OUT/parity_ab_fp32_mfma.json" > "$OUT/parity_ab_fp32_mfma.txt" 2>&1
@@ -73,7 +73,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C -d "$OUT/pmc_cfg4_$C" -o pmc --output-format csv -- python3 bench.py --workload cfg4 --batch 32768 --steps 3 --warmup 1 --no-kernel-events > "$OUT/pmc_cfg4_$C.log" 2>&1
 done
 python3 tools/bench_configs.py --steps 30 --only f64 >> "$OUT/configs.txt" 2>&1
-NF_G64_NO_F64_MFMA=1 python3 tools/bench_configs.py --steps 30 --only f64_realnvp > "$OUT/configs_f64_scalar.txt" 2>&1
+NF_G64_NO_F64_MFMA=1 python3 tools/bench_configs.py --steps 30 --only f64 > "$OUT/configs_f64_scalar.txt" 2>&1
 # keep the merge-back small: per-dispatch traces can be large
 find "$OUT" -name "*kernel_trace.csv" -size +4M -delete
 find "$OUT" -name "*.csv" | head -60
