@@ -35,6 +35,12 @@ CASES = {
     # weight-streaming kernels at a small padded shape (64-128-128-64 geometry), and an odd hidden-layer count
     "realnvp_d70_h65_33": (o.FlowSpec("realnvp", 70, 1, (65, 33)), 33, "diaggauss", np.float32),
     "realnvp_d9_3hidden": (o.FlowSpec("realnvp", 9, 1, (24, 16, 8)), 20, "diaggauss", np.float32),
+    # the shapes of the depth-generic resident RealNVP kernels (nf_deep.hip), of the Float64 matrix-instruction path
+    # (nf_g64m.h) and the reference's documented nsf(q0, [64, 64], 8, 3.0, ...) example (src/flows/neuralspline.jl:215)
+    "realnvp_d64_3hidden": (o.FlowSpec("realnvp", 64, 2, (64, 64, 64)), 40, "diaggauss", np.float32),
+    "realnvp_d64_1hidden": (o.FlowSpec("realnvp", 64, 2, (64,)), 40, "diaggauss", np.float32),
+    "realnvp_d64_h64_f64": (o.FlowSpec("realnvp", 64, 2, (64, 64)), 40, "diaggauss", np.float64),
+    "nsf_d32_h64_k8": (o.FlowSpec("nsf", 32, 1, (64, 64), K=8, B=3.0), 40, "diaggauss", np.float32),
     # demo targets (example/targets/*.jl)
     "planar_d5_funnel": (o.FlowSpec("planar", 5, 4), 32, "funnel", np.float64),
     "radial_d2_cross": (o.FlowSpec("radial", 2, 4), 32, "cross", np.float32),

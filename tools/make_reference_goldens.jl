@@ -48,6 +48,10 @@ const CASES = [
     "nsf_d5_k10_f64" => (:nsf, 5, 2, [32, 32], 10, 5.0, Float64, :diaggauss),
     "realnvp_d70_h65_33" => (:realnvp, 70, 1, [65, 33], 0, 0.0, Float32, :diaggauss),
     "realnvp_d9_3hidden" => (:realnvp, 9, 1, [24, 16, 8], 0, 0.0, Float32, :diaggauss),
+    "realnvp_d64_3hidden" => (:realnvp, 64, 2, [64, 64, 64], 0, 0.0, Float32, :diaggauss),
+    "realnvp_d64_1hidden" => (:realnvp, 64, 2, [64], 0, 0.0, Float32, :diaggauss),
+    "realnvp_d64_h64_f64" => (:realnvp, 64, 2, [64, 64], 0, 0.0, Float64, :diaggauss),
+    "nsf_d32_h64_k8" => (:nsf, 32, 1, [64, 64], 8, 3.0, Float32, :diaggauss),
     "planar_d5_funnel" => (:planar, 5, 4, Int[], 0, 0.0, Float64, :funnel),
     "radial_d2_cross" => (:radial, 2, 4, Int[], 0, 0.0, Float32, :cross),
     "planar_d2_warped" => (:planar, 2, 4, Int[], 0, 0.0, Float64, :warped),
