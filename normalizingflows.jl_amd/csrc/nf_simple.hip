@@ -953,11 +953,14 @@ __global__ __launch_bounds__(SB, 2) void k_simple_step(SimpleArgs a, const T *__
 // per THIRTY-TWO samples (over half of those are the Philox / Box-Muller draws).  Same arithmetic as the reference up to
 // the order of the additions (z_l is never formed; its inner product with w_l is summed term by term).
 //
-// Layout.  A lane holds sample l31 of the tile and the features of the MFMA C layout, f = 32 blk + nf_row(r, hi): whole
-// Philox groups of four, and z0 is at once the B operand of W Z0 and the accumulator that Uhat T is added to.  The
-// K = samples GEMMs need lane <-> feature operands: z0 and ybar take one trip through a per-wave LDS tile (stride 33).
-// The recurrences run in both half-waves (each lane all layers of its sample; v_permlane32_swap gathers the rows the
-// other half holds).  Parameter sums stay in MFMA accumulators over the wave's tiles; the block epilogue adds the waves in
+// Layout.  A lane holds sample l31 of the tile and the features f = 32 blk + nf_row(r, hi) (the 32 x 32 C layout): whole Philox
+// groups of four, and z0 is the accumulator that Uhat T is added to (v_mfma_f32_32x32x2_f32: all 32 rows are features there).
+// The five GEMMs with LAYERS on one side use v_mfma_f32_16x16x4_f32 (round 5; 32 clocks for a 16 x 16 block instead of 64 for a
+// 32 x 32 one of which 10 rows carried layers): W Z0 and Uhat'Ybar take their sample-side operand from the wave's
+// [sample][feature] LDS tile (z0 and ybar pass through it anyway: they are the lane <-> feature operands of the K = samples
+// GEMMs) and hand their 16 rows to the samples' lanes through a [sample][layer] tile; Z0 Abar', Ybar T' and Abar T' accumulate
+// in 16 x 16 blocks (lane = layer column, 4 registers per 16 features).  The recurrences run in both half-waves (each lane all
+// layers of its sample).  Parameter sums stay in MFMA accumulators over the wave's tiles; the block epilogue adds the waves in
 // a fixed order, applies the two triangular corrections and writes k_simple_step's slab layout (k_simple_finalize).
 template <int DB_, int NLR_>
 struct PlanarGeo {
@@ -975,15 +978,22 @@ struct PlanarGeo {
   static constexpr int OFF_SP = OFF_B + NL;                            // 1 + c_l = softplus(w'u)
   static constexpr int OFF_TG = OFF_SP + NL;                           // target: mu[f] | 1/var[f] | log 2pi + log var[f]
   static constexpr int SHARED = ((OFF_TG + 3 * FD + 3) / 4) * 4;
-  static constexpr int OFF_X = 0;                                      // per wave: [FD][33] transposition tile
-  static constexpr int AR = 2 * NL, TR = NL + 1;                       // rows of the two [layer][sample] tiles (below)
-  static constexpr int OFF_A = OFF_X + FD * NF_TS;                     //           abar[l][s] | q[l][s]
-  static constexpr int OFF_T = OFF_A + AR * NF_TS;                     //           t[l][s] | ones
-  static constexpr int WAVE = ((OFF_T + TR * NF_TS + 3) / 4) * 4;
+  // per wave (round 5, the 16x16x4 form): three [sample][row] tiles.  Row strides = 4 (mod 16) floats: rows stay 16-byte aligned
+  // (a lane's four consecutive features / layers move as one b128), and with the contraction order s(t, g) = (t & 3) +
+  // 16 (t >> 2) + 4 g of the K = samples GEMMs the four lane groups of a k-step sit 16 banks apart (4 g * stride = 16 g mod 64)
+  static constexpr int SX = FD + 4;                                    // [sample][feature]: z0, later ybar
+  static constexpr int AR = 2 * NL, TR = NL + 1;                       // entries of the two [sample][layer] tiles (below)
+  static constexpr int SLA = AR <= 20 ? 20 : 36, SLT = 20;
+  static constexpr int OFF_X = 0;
+  static constexpr int OFF_A = OFF_X + 32 * SX;                        //           abar[s][l] | q[s][NL + l]   (first: the gathered GEMM rows)
+  static constexpr int OFF_T = OFF_A + 32 * SLA;                       //           t[s][l] | 1
+  static constexpr int WAVE = ((OFF_T + 32 * SLT + 16 + 3) / 4) * 4;        // + 16: the second column block of G' reads past the last row
+  static constexpr int RB = FD / 16;                                   // 16-feature row blocks of M1 / M2
+  static constexpr int GRB = (AR + 15) / 16, GCB = (TR + 15) / 16;     // 16 x 16 blocks of G'
+  static_assert(TR <= SLT && AR <= SLA && NL <= 16, "tile strides");
   // block epilogue (aliases the waves' tiles): per wave M1[l][f] | M2[l][f] | G'[2 NL][NL + 1]
   static constexpr int R_M1 = 0, R_M2 = NL * FD, R_G = 2 * NL * FD, REGION = R_G + AR * TR;
-  static constexpr int GR = AR <= 8 ? 4 : AR <= 16 ? 8 : AR <= 24 ? 12 : 16;  // C registers of G' that carry rows < 2 NL
-  static_assert(AR <= 32, "abar and q rows share one 32-row operand");
+  static_assert(AR <= 32, "abar and q rows share one operand tile");
   static_assert(REGION <= WAVE, "epilogue region must fit a wave's tiles");
   static constexpr size_t lds_floats(int nl, int lp) { return (size_t)SHARED + 4 * (size_t)WAVE + (size_t)nl * lp; }
 };
@@ -1008,23 +1018,60 @@ __device__ __forceinline__ float planar_xhalf_sum(float v) {
   return lo + hi;
 }
 
-// out[e][s] = sum_f rows[e][f] v[f][s]: `rowp` = this lane's row of a [layer][feature] image (+ 4 hi), v in the C layout.
-// Four k-steps per ds_read_b128, the next group requested while the matrix pipe works on this one.
-template <int DB, int S>
-__device__ __forceinline__ void planar_rows_gemm(const float *__restrict__ rowp, const f32x16 (&v)[DB], f32x16 &out) {
-  constexpr int NG = 4 * DB;
-  float wn[4], wc[4];
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 planar_mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+// the contraction order of the K = samples GEMMs: k-step t, lane group g <-> sample planar_s(t) + 4 g
+__device__ __forceinline__ constexpr int planar_s(int t) { return (t & 3) + 16 * (t >> 2); }
+
+// out[T][r] = sum_f rows[4 g + r][f] X[f][s16 + 16 T] for the tile's two sample halves T, as v_mfma_f32_16x16x4_f32 leaves it
+// (column = lane & 15 = s16, rows 4 g .. 4 g + 3; g = lane >> 4).  `rowp` = row (lane & 15) of a [layer][feature] image + (FD / 4) g,
+// `xp` = row s16 of the wave's [sample][feature] tile + (FD / 4) g: lane group g contracts features (FD / 4) g .. (FD / 4)(g + 1) - 1,
+// four k-steps per ds_read_b128 on either side.  Round 5: with 10 (16) useful rows the 32 x 32 x 2 instruction spent 64 clocks on
+// a product of which 10 / 32 was used; this one spends 32 on 10 / 16.
+template <int FD, int S, int SX>
+__device__ __forceinline__ void planar_rows_gemm16(const float *__restrict__ rowp, const float *__restrict__ xp, f32x4 (&out)[2]) {
+  constexpr int NG = FD / 16;
+  float wn[4], an[4], bn[4], wc[4], ac[4], bc[4];
   nf_ld4<S>(rowp, wn[0], wn[1], wn[2], wn[3]);
+  nf_ld4<SX>(xp, an[0], an[1], an[2], an[3]);
+  nf_ld4<SX>(xp + 16 * SX, bn[0], bn[1], bn[2], bn[3]);
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) wc[e] = wn[e];
-    if (g + 1 < NG) nf_ld4<S>(rowp + 8 * (g + 1), wn[0], wn[1], wn[2], wn[3]);
+    for (int e = 0; e < 4; ++e) {
+      wc[e] = wn[e];
+      ac[e] = an[e];
+      bc[e] = bn[e];
+    }
+    if (g + 1 < NG) {
+      nf_ld4<S>(rowp + 4 * (g + 1), wn[0], wn[1], wn[2], wn[3]);
+      nf_ld4<SX>(xp + 4 * (g + 1), an[0], an[1], an[2], an[3]);
+      nf_ld4<SX>(xp + 16 * SX + 4 * (g + 1), bn[0], bn[1], bn[2], bn[3]);
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) out = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[e], v[g / 4][4 * (g % 4) + e], out, 0, 0, 0);
+    for (int e = 0; e < 4; ++e) {
+      out[0] = planar_mfma16(wc[e], ac[e], out[0]);
+      out[1] = planar_mfma16(wc[e], bc[e], out[1]);
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
+}
+// The rows of such a result to the two lanes of every sample (all NL of them: the recurrences run per sample), through the
+// [sample][layer] tile `gt` (the abar tile, idle at both call sites): one b128 write per half, NL / 4 b128 reads.
+template <class PG>
+__device__ __forceinline__ void planar_rows_to_lanes(float *__restrict__ gt, const f32x4 (&c)[2], int s16, int lg, int l31, float (&v)[PG::NL]) {
+  *reinterpret_cast<f32x4 *>(gt + s16 * PG::SLA + 4 * lg) = c[0];
+  *reinterpret_cast<f32x4 *>(gt + (s16 + 16) * PG::SLA + 4 * lg) = c[1];
+  wave_lds_fence();
+#pragma unroll
+  for (int q = 0; q < (PG::NL + 3) / 4; ++q) {
+    const f32x4 r = *reinterpret_cast<const f32x4 *>(gt + l31 * PG::SLA + 4 * q);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (4 * q + e < PG::NL) v[4 * q + e] = r[e];
+  }
+  wave_lds_fence();  // the tile is rewritten (abar | q) further down
 }
 
 // DIAG: the diagonal-Gaussian target has its own instantiation -- with the five targets behind one switch the register
@@ -1075,7 +1122,9 @@ __global__ __launch_bounds__(SB, (PG::NLR <= 6 ? 2 : 1)) void k_planar_step(Simp
     }
   __syncthreads();
   // wave-uniform scalars of the recurrences, read once: SGPRs (readfirstlane marks them uniform; both sweeps use the
-  // strict upper triangle of C only)
+  // strict upper triangle of C only).  (Round 5: with the 32 hoisted "feature < d" lane masks they overflow the scalar file and
+  // hipcc parks the excess in VGPR lanes -- 217 v_readlane_b32 per tile.  Reading C from LDS in the sweeps and keeping the masks
+  // from being hoisted removed 190 of them and changed nothing: 219.9 against 218.5 us.)
   auto sc = [&](int off) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sh[off]))); };
   float Cu[NL][NL], bs[NL], sps[NL];
 #pragma unroll
@@ -1086,17 +1135,21 @@ __global__ __launch_bounds__(SB, (PG::NLR <= 6 ? 2 : 1)) void k_planar_step(Simp
     for (int m = l + 1; m < NL; ++m) Cu[l][m] = sc(PG::OFF_C + l * NL + m);
   }
 
-  f32x16 M1[DB], M2[DB], G;
+  f32x4 M1[PG::RB], M2[PG::RB], G[PG::GRB][PG::GCB];  // lane (l = lane & 15, g): features 16 R + 4 g + r of layer l; G' rows 16 rb + 4 g + r
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    G[r] = 0.f;
+  for (int r = 0; r < 4; ++r) {
 #pragma unroll
-    for (int b = 0; b < DB; ++b) M1[b][r] = M2[b][r] = 0.f;
+    for (int b = 0; b < PG::RB; ++b) M1[b][r] = M2[b][r] = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < PG::GRB; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < PG::GCB; ++cb) G[rb][cb][r] = 0.f;
   }
   double contrib = 0.0;
   // layer rows this lane fetches as A / B operands (clamped rows feed output columns nobody reads)
-  const int erow = l31 < NL ? l31 : NL - 1, arow = l31 < PG::AR ? l31 : PG::AR - 1, trow = l31 < PG::TR ? l31 : PG::TR - 1;
-  if (hi == 0) wv[PG::OFF_T + NL * NF_TS + l31] = 1.f;  // the ones row (the tiles are not touched until the epilogue)
+  const int s16 = lane & 15, lg = lane >> 4;
+  const int erow = s16 < NL ? s16 : NL - 1;
+  if (hi == 0) wv[PG::OFF_T + l31 * PG::SLT + NL] = 1.f;  // the ones column (the tiles are not touched until the epilogue)
   const long ntiles = (a.N + 31) / 32;
   for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
     asm volatile("" ::: "memory");  // keep the operand fetches inside the loop (hoisting them costs the registers)
@@ -1132,31 +1185,29 @@ __global__ __launch_bounds__(SB, (PG::NLR <= 6 ? 2 : 1)) void k_planar_step(Simp
           ss += v * v;
         }
       }
-    // ---- z0 through the transposition tile: zt[blk][t] = z0[feature 32 blk + l31][sample 2 t + hi]
-    float zt[DB][16];
+    // ---- z0 into the [sample][feature] tile (a lane's Philox groups are four consecutive features: b128 writes).  It is the
+    //      B operand of W Z0 and, read back here before ybar replaces it, the A operand of Z0 Abar':
+    //      zt[R][t] = z0[feature 16 R + (lane & 15)][sample planar_s(t) + 4 g]
+    float zt[PG::RB][8];
+    float *const xw = wv + PG::OFF_X + l31 * PG::SX + 4 * hi;
 #pragma unroll
     for (int b = 0; b < DB; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) wv[PG::OFF_X + (32 * b + nf_row(r, hi)) * NF_TS + l31] = z[b][r];
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<f32x4 *>(xw + 32 * b + 8 * q) = f32x4{z[b][4 * q], z[b][4 * q + 1], z[b][4 * q + 2], z[b][4 * q + 3]};
     wave_lds_fence();
 #pragma unroll
-    for (int b = 0; b < DB; ++b)
+    for (int R = 0; R < PG::RB; ++R)
 #pragma unroll
-      for (int t = 0; t < 16; ++t) zt[b][t] = wv[PG::OFF_X + (32 * b + l31) * NF_TS + 2 * t + hi];
+      for (int t = 0; t < 8; ++t) zt[R][t] = wv[PG::OFF_X + (planar_s(t) + 4 * lg) * PG::SX + 16 * R + s16];
     // ---- A0[e][s] = w_e'z0_s
-    f32x16 c0;
+    f32x4 c0[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) c0[r] = 0.f;
-    planar_rows_gemm<DB, SW>(sh + PG::OFF_W + erow * SW + 4 * hi, z, c0);
+    for (int r = 0; r < 4; ++r) c0[0][r] = c0[1][r] = 0.f;
+    planar_rows_gemm16<FD, SW, PG::SX>(sh + PG::OFF_W + erow * SW + (FD / 4) * lg, wv + PG::OFF_X + s16 * PG::SX + (FD / 4) * lg, c0);
     // ---- forward recurrence: every lane all layers of its sample
     float A[NL], tl[NL];
-#pragma unroll
-    for (int r = 0; r < NLR; ++r) {
-      float lo, hh;
-      planar_gather(c0[r], lo, hh);
-      if (nf_row(r, 0) < NL) A[nf_row(r, 0)] = lo;
-      if (nf_row(r, 1) < NL) A[nf_row(r, 1)] = hh;
-    }
+    planar_rows_to_lanes<PG>(wv + PG::OFF_A, c0, s16, lg, l31, A);
     float lsum = 0.f;
 #pragma unroll
     for (int l = NL - 1; l >= 0; --l) {
@@ -1241,25 +1292,21 @@ __global__ __launch_bounds__(SB, (PG::NLR <= 6 ? 2 : 1)) void k_planar_step(Simp
       if (valid && hi == 0) contrib += fu.pscale * (double)(acc - logq + lsum);
     }
     // ---- ybar into the tile (the A operand of Ybar T'), UG0[e][s] = uhat_e'ybar_s
-    wave_lds_fence();  // every zt read of the tile is complete (same wave: program order through the LDS queue)
+    wave_lds_fence();  // every z0 read of the tile is complete (same wave: program order through the LDS queue)
 #pragma unroll
     for (int b = 0; b < DB; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) wv[PG::OFF_X + (32 * b + nf_row(r, hi)) * NF_TS + l31] = z[b][r];
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<f32x4 *>(xw + 32 * b + 8 * q) = f32x4{z[b][4 * q], z[b][4 * q + 1], z[b][4 * q + 2], z[b][4 * q + 3]};
+    wave_lds_fence();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) c0[r] = 0.f;
-    planar_rows_gemm<DB, SW>(sh + PG::OFF_UT + erow * SW + 4 * hi, z, c0);
+    for (int r = 0; r < 4; ++r) c0[0][r] = c0[1][r] = 0.f;
+    planar_rows_gemm16<FD, SW, PG::SX>(sh + PG::OFF_UT + erow * SW + (FD / 4) * lg, wv + PG::OFF_X + s16 * PG::SX + (FD / 4) * lg, c0);
     // ---- reverse recurrence
     float ab[NL], qv[NL];
     {
       float UG[NL];
-#pragma unroll
-      for (int r = 0; r < NLR; ++r) {
-        float lo, hh;
-        planar_gather(c0[r], lo, hh);
-        if (nf_row(r, 0) < NL) UG[nf_row(r, 0)] = lo;
-        if (nf_row(r, 1) < NL) UG[nf_row(r, 1)] = hh;
-      }
+      planar_rows_to_lanes<PG>(wv + PG::OFF_A, c0, s16, lg, l31, UG);
       const float lb = valid ? lbar_const : 0.f;
 #pragma unroll
       for (int l = 0; l < NL; ++l) {
@@ -1276,58 +1323,40 @@ __global__ __launch_bounds__(SB, (PG::NLR <= 6 ? 2 : 1)) void k_planar_step(Simp
         }
       }
     }
-    // ---- abar, t as [layer][sample] tiles; the three K = samples GEMMs
+    // ---- abar | q and t as [sample][layer] tiles; the three K = samples GEMMs: G' = [Abar; Q] [T; 1]', M1 = Z0 Abar', M2 = Ybar T'
+    {
+      float *ar = wv + PG::OFF_A + l31 * PG::SLA + (hi ? NL : 0), *tr = wv + PG::OFF_T + l31 * PG::SLT;
 #pragma unroll
-    for (int l = 0; l < NL; ++l) {
-      if (hi == 0) {
-        wv[PG::OFF_A + l * NF_TS + l31] = ab[l];
-        wv[PG::OFF_T + l * NF_TS + l31] = tl[l];
-      } else {
-        wv[PG::OFF_A + (NL + l) * NF_TS + l31] = qv[l];
+      for (int l = 0; l < NL; ++l) {
+        ar[l] = hi ? qv[l] : ab[l];
+        if (hi == 0) tr[l] = tl[l];
       }
     }
     wave_lds_fence();
     {
-      const float *pa = wv + PG::OFF_A + arow * NF_TS + hi, *pt = wv + PG::OFF_T + trow * NF_TS + hi;
-      const float *px = wv + PG::OFF_X + l31 * NF_TS + hi;
-      // groups of four k-steps (sample pairs), the next group's operands requested while the matrix pipe works on this one
-      float an[4], tn[4], xn[DB][4], ac[4], tc[4], xc[DB][4];
+      // lane (i = lane & 15, g): A operands = row i of a block, B operands = column i; k-step t <-> sample planar_s(t) + 4 g.
+      // Entries past a tile's row (rows >= 2 NL of G', columns >= NL of M1 / >= NL + 1 of G') read the neighbouring sample's:
+      // finite values that end up in result rows / columns nobody reads.
+      const float *pa = wv + PG::OFF_A + 4 * lg * PG::SLA + s16, *pt = wv + PG::OFF_T + 4 * lg * PG::SLT + s16;
+      const float *px = wv + PG::OFF_X + 4 * lg * PG::SX + s16;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        an[e] = pa[2 * e];
-        tn[e] = pt[2 * e];
+      for (int t = 0; t < 8; ++t) {
+        float av[PG::GRB], tv[PG::GCB], xv[PG::RB];
 #pragma unroll
-        for (int b = 0; b < DB; ++b) xn[b][e] = px[32 * b * NF_TS + 2 * e];
-      }
+        for (int rb = 0; rb < PG::GRB; ++rb) av[rb] = pa[planar_s(t) * PG::SLA + 16 * rb];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
+        for (int cb = 0; cb < PG::GCB; ++cb) tv[cb] = pt[planar_s(t) * PG::SLT + 16 * cb];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          ac[e] = an[e];
-          tc[e] = tn[e];
+        for (int R = 0; R < PG::RB; ++R) xv[R] = px[planar_s(t) * PG::SX + 16 * R];
 #pragma unroll
-          for (int b = 0; b < DB; ++b) xc[b][e] = xn[b][e];
+        for (int rb = 0; rb < PG::GRB; ++rb)
+#pragma unroll
+          for (int cb = 0; cb < PG::GCB; ++cb) G[rb][cb] = planar_mfma16(av[rb], tv[cb], G[rb][cb]);
+#pragma unroll
+        for (int R = 0; R < PG::RB; ++R) {
+          M1[R] = planar_mfma16(zt[R][t], av[0], M1[R]);
+          M2[R] = planar_mfma16(xv[R], tv[0], M2[R]);
         }
-        if (g + 1 < 4) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            an[e] = pa[2 * (4 * (g + 1) + e)];
-            tn[e] = pt[2 * (4 * (g + 1) + e)];
-#pragma unroll
-            for (int b = 0; b < DB; ++b) xn[b][e] = px[32 * b * NF_TS + 2 * (4 * (g + 1) + e)];
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          G = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[e], tc[e], G, 0, 0, 0);
-#pragma unroll
-          for (int b = 0; b < DB; ++b) {
-            M1[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(zt[b][4 * g + e], ac[e], M1[b], 0, 0, 0);
-            M2[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xc[b][e], tc[e], M2[b], 0, 0, 0);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
       }
     }
     wave_lds_fence();  // the next tile overwrites X / A / T
@@ -1336,20 +1365,24 @@ __global__ __launch_bounds__(SB, (PG::NLR <= 6 ? 2 : 1)) void k_planar_step(Simp
   __syncthreads();
   {
     float *rg = psm + PG::SHARED + wave * PG::WAVE;
-    if (l31 < NL) {
+    if (s16 < NL) {
 #pragma unroll
-      for (int b = 0; b < DB; ++b)
+      for (int R = 0; R < PG::RB; ++R)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          rg[PG::R_M1 + l31 * FD + 32 * b + nf_row(r, hi)] = M1[b][r];
-          rg[PG::R_M2 + l31 * FD + 32 * b + nf_row(r, hi)] = M2[b][r];
+        for (int r = 0; r < 4; ++r) {
+          rg[PG::R_M1 + s16 * FD + 16 * R + 4 * lg + r] = M1[R][r];
+          rg[PG::R_M2 + s16 * FD + 16 * R + 4 * lg + r] = M2[R][r];
         }
     }
-    if (l31 < PG::TR) {
 #pragma unroll
-      for (int r = 0; r < PG::GR; ++r)
-        if (nf_row(r, hi) < PG::AR) rg[PG::R_G + nf_row(r, hi) * PG::TR + l31] = G[r];
-    }
+    for (int rb = 0; rb < PG::GRB; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < PG::GCB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * rb + 4 * lg + r, col = 16 * cb + s16;
+          if (row < PG::AR && col < PG::TR) rg[PG::R_G + row * PG::TR + col] = G[rb][cb][r];
+        }
   }
   __syncthreads();
   {
