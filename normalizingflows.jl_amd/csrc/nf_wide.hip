@@ -1033,6 +1033,7 @@ struct DwArgs {
   int njobs, ksplit;
   long ntiles;
   long slab_stride;  // floats between ksplit partials
+  long long *trace;  // optional clock stamps of block 0 / wave 0 (nf_debug_trace, tools/trace_wide_dw.py)
 };
 
 #define DW_TS 33
@@ -1202,53 +1203,87 @@ __device__ __forceinline__ void dw_job_b6(const DwJob &jb, const DwArgs &a, int 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][o][r] = 0.f;
 
-  u32x4 stg[NLD];
-  auto load_tile = [&](long tile) {
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(wave_uniform_ptr(jb.A + tile * jb.a_tile_stride), 0, jb.a_extent, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(wave_uniform_ptr(jb.D + tile * jb.d_tile_stride), 0, jb.d_extent, 0x00020000);
-#pragma unroll
-    for (int k = 0; k < NLD; ++k) {
-      const int row = lrow + 64 * (k >> 1), seg = part * 32 + (k & 1) * 16;
-      if (64 * (k >> 1) < AROWS)
-        stg[k] = __builtin_amdgcn_raw_buffer_load_b128(ra, ((jb.a_row0 + row) * jb.a_rstride + jb.a_roff) * 128 + seg, 0, 0);
-      else
-        stg[k] = __builtin_amdgcn_raw_buffer_load_b128(rd, (jb.d_row0 + row - AROWS) * 128 + seg, 0, 0);
-    }
-  };
-  // samples 8 part .. 8 part + 7 of a row: the four even ones are slots j .. j + 3 of (group part >> 1, parity 0) -- two packed
-  // dwords side by side, one ds_write_b64 per component --, the four odd ones the same slots of parity 1
+  // Software pipeline (round 5).  The stamps of the one-stage form (tools/trace_wide_dw.py: per tile 0.9-3.0 k clocks to ISSUE the
+  // twelve 16-byte requests, 3.9 k for the 96 MFMAs, 0.3 k waiting, 1.9 k to split and store the next tile, 0.1 k at the barrier --
+  // 7.2-9.6 k, all of it one after the other in each wave's instruction stream) say where the time is: not in HBM latency but in
+  // three streams that never run at the same time.  Here they are woven together by hand, one small piece of each of the other
+  // two behind every four MFMAs (one term of the six for the four A blocks):
+  //   * the split + LDS stores of tile i + 1, which arrived during the previous iteration: one nf_split2 per quad, the six
+  //     ds_write_b64 of a row pair behind its fourth;
+  //   * the requests for tile i + 2, one per two quads from the fifth quad on (the address unit takes them at its own pace
+  //     under the MFMAs) -- each into the staging register whose tile i + 1 content the split has just consumed, so ONE set
+  //     of twelve staging registers carries both tiles (a second set pushed the kernel to 481 registers and the compiler to
+  //     ~370 AGPR <-> VGPR moves per tile);
+  //   * the MFMAs of tile i.
+  // A tile past the end is requested through descriptors of extent 0 (no memory access, zeros back) and its "split" is stored
+  // into the idle buffer: the request count of an iteration must not depend on a branch, or hipcc's wait-count pass falls
+  // back to s_waitcnt vmcnt(0) and waits for the stream.
   const int poff = lrow * D6_ROW + (part >> 1) * 32 + (part & 1) * 8;
-  auto put_tile = [&](char *dst) {
-#pragma unroll
-    for (int k = 0; k < NLD; k += 2) {
-      const unsigned a0 = stg[k].x, a1 = stg[k].y, a2 = stg[k].z, a3 = stg[k].w;  // (bit_cast of a vector-element expression reads element 0)
-      const unsigned b0 = stg[k + 1].x, b1 = stg[k + 1].y, b2 = stg[k + 1].z, b3 = stg[k + 1].w;
-      unsigned eh0, em0, el0, eh1, em1, el1, oh0, om0, ol0, oh1, om1, ol1;
-      nf_split2(__uint_as_float(a0), __uint_as_float(a2), eh0, em0, el0);
-      nf_split2(__uint_as_float(b0), __uint_as_float(b2), eh1, em1, el1);
-      nf_split2(__uint_as_float(a1), __uint_as_float(a3), oh0, om0, ol0);
-      nf_split2(__uint_as_float(b1), __uint_as_float(b3), oh1, om1, ol1);
-      u32x2 *p = reinterpret_cast<u32x2 *>(dst + poff + 64 * (k >> 1) * D6_ROW);
-      p[0] = u32x2{eh0, eh1}; p[2] = u32x2{oh0, oh1};      // component h: parity 0 at +0, parity 1 at +16 bytes
-      p[8] = u32x2{em0, em1}; p[10] = u32x2{om0, om1};     // component m at +64 bytes
-      p[16] = u32x2{el0, el1}; p[18] = u32x2{ol0, ol1};    // component l at +128 bytes
-    }
-  };
-
-  long tile = ks;
-  if (tile < a.ntiles) {
-    load_tile(tile);
-    put_tile(lds);
-  }
-  __syncthreads();
-  int buf = 0;
   constexpr int RB = 32 * D6_ROW / 16;  // 16-byte units per block of 32 rows
   const unsigned ones = 0x3F803F80u;
   const bool need_bias = jb.b_off >= 0 && wi == 0;
+  auto descriptors = [&](long tile, __amdgpu_buffer_rsrc_t &ra, __amdgpu_buffer_rsrc_t &rd) {
+    const bool in = tile < a.ntiles;
+    const long tl = in ? tile : 0;
+    ra = __builtin_amdgcn_make_buffer_rsrc(wave_uniform_ptr(jb.A + tl * jb.a_tile_stride), 0, in ? jb.a_extent : 0, 0x00020000);
+    rd = __builtin_amdgcn_make_buffer_rsrc(wave_uniform_ptr(jb.D + tl * jb.d_tile_stride), 0, in ? jb.d_extent : 0, 0x00020000);
+  };
+  // byte offset of load k within its tile: computed once (in the loop hipcc re-read the job's fields with s_load and waited
+  // on lgkmcnt(0) -- the LDS counter -- for each of them)
+  int voff[NLD];
+#pragma unroll
+  for (int k = 0; k < NLD; ++k) {
+    const int row = lrow + 64 * (k >> 1), seg = part * 32 + (k & 1) * 16;
+    voff[k] = 64 * (k >> 1) < AROWS ? ((jb.a_row0 + row) * jb.a_rstride + jb.a_roff) * 128 + seg : (jb.d_row0 + row - AROWS) * 128 + seg;
+  }
+  auto request = [&](const __amdgpu_buffer_rsrc_t &ra, const __amdgpu_buffer_rsrc_t &rd, int k) -> u32x4 {  // load k of a tile (k compile-time)
+    return __builtin_amdgcn_raw_buffer_load_b128(64 * (k >> 1) < AROWS ? ra : rd, voff[k], 0, 0);
+  };
+  // samples 8 part .. 8 part + 7 of a row: the four even ones are slots j .. j + 3 of (group part >> 1, parity 0) -- two packed
+  // dwords side by side, one ds_write_b64 per component --, the four odd ones the same slots of parity 1.
+  // piece j of row pair kp (loads 2 kp, 2 kp + 1): j = 0 .. 3 one split each, the stores behind the last
+  unsigned sp_[12];  // eh0 em0 el0 | eh1 em1 el1 | oh0 om0 ol0 | oh1 om1 ol1 of the row pair in progress
+  u32x4 stg[NLD];
+  auto put_piece = [&](char *dst, int kp, int j) {
+    const u32x4 &va = stg[2 * kp], &vb = stg[2 * kp + 1];
+    const unsigned a0 = va.x, a1 = va.y, a2 = va.z, a3 = va.w, b0 = vb.x, b1 = vb.y, b2 = vb.z, b3 = vb.w;
+    if (j == 0) nf_split2(__uint_as_float(a0), __uint_as_float(a2), sp_[0], sp_[1], sp_[2]);
+    if (j == 1) nf_split2(__uint_as_float(b0), __uint_as_float(b2), sp_[3], sp_[4], sp_[5]);
+    if (j == 2) nf_split2(__uint_as_float(a1), __uint_as_float(a3), sp_[6], sp_[7], sp_[8]);
+    if (j == 3) {
+      nf_split2(__uint_as_float(b1), __uint_as_float(b3), sp_[9], sp_[10], sp_[11]);
+      u32x2 *p = reinterpret_cast<u32x2 *>(dst + poff + 64 * kp * D6_ROW);
+      p[0] = u32x2{sp_[0], sp_[3]}; p[2] = u32x2{sp_[6], sp_[9]};      // component h: parity 0 at +0, parity 1 at +16 bytes
+      p[8] = u32x2{sp_[1], sp_[4]}; p[10] = u32x2{sp_[7], sp_[10]};    // component m at +64 bytes
+      p[16] = u32x2{sp_[2], sp_[5]}; p[18] = u32x2{sp_[8], sp_[11]};   // component l at +128 bytes
+    }
+  };
+  long long *tr = (a.trace && blockIdx.x == 0 && tid == 0) ? a.trace : nullptr;
+  int tslot = 0;  // seven stamps per tile for the first eight tiles (slots 1, 4, 5 unused in this form)
+  long tile = ks;
+  {
+    __amdgpu_buffer_rsrc_t ra, rd;
+    descriptors(tile, ra, rd);
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) stg[k] = request(ra, rd, k);
+#pragma unroll
+    for (int kp = 0; kp < NLD / 2; ++kp)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) put_piece(lds, kp, j);
+    descriptors(tile + a.ksplit, ra, rd);
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) stg[k] = request(ra, rd, k);
+  }
+  __syncthreads();
+  int buf = 0;
+  // one tile per iteration: MFMAs from buffer `buf`, tile + ksplit (in stg) split into the other buffer, tile + 2 ksplit requested
   for (; tile < a.ntiles; tile += a.ksplit) {
-    const bool has_next = tile + a.ksplit < a.ntiles;
-    if (has_next) load_tile(tile + a.ksplit);
     const char *cur = lds + buf * (DW_ROWS * D6_ROW);
+    char *nxt = lds + (buf ^ 1) * (DW_ROWS * D6_ROW);
+    if (tslot >= 56) tr = nullptr;
+    WIDE_STAMP(tslot + 0);
+    __amdgpu_buffer_rsrc_t ra, rd;
+    descriptors(tile + 2L * a.ksplit, ra, rd);
     const nf_u32x4 *pa = reinterpret_cast<const nf_u32x4 *>(cur + (wi * 128 + l31) * D6_ROW + hi * 16);
     const nf_u32x4 *pd = reinterpret_cast<const nf_u32x4 *>(cur + (AROWS + wo * 64 + l31) * D6_ROW + hi * 16);
     nf_u32x4 An[4][3], Dn[2][3];  // the operands of the sample group after this one: requested behind its 48 MFMAs
@@ -1288,18 +1323,37 @@ __device__ __forceinline__ void dw_job_b6(const DwJob &jb, const DwArgs &a, int 
 #pragma unroll
           for (int i = 0; i < 12; ++i) bsum[ob] = nf_dot2_bf16(D[ob][2 - i / 4][i % 4], ones, bsum[ob]);
 #pragma unroll
-        for (int term = 0; term < 6; ++term)  // smallest first: al dh, ah dl, am dm, am dh, ah dm, ah dh
+        for (int term = 0; term < 6; ++term) {  // smallest first: al dh, ah dl, am dm, am dh, ah dm, ah dh
 #pragma unroll
           for (int ib = 0; ib < 4; ++ib) {
             const nf_u32x4 &av = term == 0 ? A[ib][2] : (term == 2 || term == 3) ? A[ib][1] : A[ib][0];
             const nf_u32x4 &dv = term == 1 ? D[ob][2] : (term == 2 || term == 4) ? D[ob][1] : D[ob][0];
             acc[ib][ob] = nf_mfma_bf16(av, dv, acc[ib][ob]);
           }
+          const int q = (g * 2 + ob) * 6 + term;  // 0 .. 23
+          put_piece(nxt, q / 4, q % 4);
+          // request k goes out behind quad 2 k + 4 (row pair k / 2 was consumed by quad 2 k + 3 at the latest); the last two
+          // behind the last quad
+          if (q >= 4 && q % 2 == 0 && q < 23) stg[(q - 4) / 2] = request(ra, rd, (q - 4) / 2);
+          if (q == 23) {
+            stg[10] = request(ra, rd, 10);
+            stg[11] = request(ra, rd, 11);
+          }
+          // the piece's vector instructions in the shadows of the quad's MFMAs (an MFMA holds the matrix pipe for 32 clocks,
+          // the next one cannot issue before: room for seven VALU instructions), not behind the quad
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);  // up to seven VALU
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
-      __builtin_amdgcn_sched_barrier(0);
+      WIDE_STAMP(tslot + 2 + g);
     }
-    if (has_next) put_tile(lds + (buf ^ 1) * (DW_ROWS * D6_ROW));  // the other buffer: nobody reads it before the barrier
     __syncthreads();
+    WIDE_STAMP(tslot + 6);
+    tslot += 7;
     buf ^= 1;
   }
 
@@ -1618,6 +1672,7 @@ static int wide_bwd(nf_ctx *ctx, const nf_flow_desc *desc, float *state, float *
       da.ksplit = ks;
       da.ntiles = ntiles;
       da.slab_stride = G::SIZE;
+      da.trace = (long long *)ctx->trace;
       {
         ProfScope ps(ctx, "wide_dw");
         if (wide_b6())
@@ -1768,6 +1823,7 @@ static int wide_train_backward(nf_ctx *ctx, const nf_flow_desc *desc, float *sta
       da.ksplit = ks;
       da.ntiles = ntiles;
       da.slab_stride = G::SIZE;
+      da.trace = (long long *)ctx->trace;
       {
         ProfScope ps(ctx, "wide_dw");
         if (wide_b6())
