@@ -525,8 +525,15 @@ __global__ __launch_bounds__(512) void k_affine_chain(ChainArgs a, float *xt, fl
           float ls;
           if (STASH) {
             const StashIO st = make_stash_io(fa.stash, tl * a.ncoup + coupling_at(pos), StashGeo<G, SLIM>::SIZE, live, l31, hi);
-            if (INVERSE ? (half == 1) : (half == 0)) ls = coupling_step_stash<G, INVERSE, SLIM, true>(img_s, img_t, O, E, l31, hi, st, nullptr, between);
-            else ls = coupling_step_stash<G, INVERSE, SLIM, true>(img_s, img_t, E, O, l31, hi, st, nullptr, between);
+#ifdef NF_KERNEL_TRACE  // tools/trace_chain.py (as the fp32 form below; stamp 3 = end of the combine, 4 = the same: the barrier opens the NEXT position)
+            long long *tr = (fa.trace && blockIdx.x == 0 && (tid & 255) == 0 && pos < 8) ? fa.trace + 32 + (tid >> 8) * 64 + pos * 4 - 1 : nullptr;
+#else
+            long long *tr = nullptr;
+#endif
+            if (INVERSE ? (half == 1) : (half == 0)) ls = coupling_step_stash<G, INVERSE, SLIM, true>(img_s, img_t, O, E, l31, hi, st, tr, between);
+            else ls = coupling_step_stash<G, INVERSE, SLIM, true>(img_s, img_t, E, O, l31, hi, st, tr, between);
+            NF_CH_STAMP(tr, 3);
+            NF_CH_STAMP(tr, 4);
           } else if (INVERSE ? (half == 1) : (half == 0)) {
             ls = coupling_step<G, INVERSE, true>(img_s, img_t, O, E, l31, hi, between);
           } else {
