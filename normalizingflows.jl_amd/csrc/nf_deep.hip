@@ -268,15 +268,22 @@ __device__ __forceinline__ void deep_zero(f32x16 (&a)[IB][OB], float (&b)[OB]) {
 template <int IB, int OB, int S>
 __device__ __forceinline__ void deep_fold(float *__restrict__ w, float *__restrict__ b, const f32x16 (&a)[IB][OB], const float (&bs)[OB],
                                           bool first, int l31, int hi) {
+  // A block's sixteen partial sums are read in one go, then written back (round 5).  As one read-modify-write after the other
+  // (`*p = *p + a`) every LDS round trip was exposed: tools/trace_deep_bwd.py showed the fold at 15.0 k of a phase's 56.6 k
+  // clocks for one hidden layer of 64 and 52.8 k of 183 k for three -- more than a quarter of the reverse kernel.
 #pragma unroll
   for (int i = 0; i < IB; ++i)
 #pragma unroll
-    for (int o = 0; o < OB; ++o)
+    for (int o = 0; o < OB; ++o) {
+      float *p = w + (i * 32 + 4 * hi) * S + o * 32 + l31;  // row nf_row(r, hi) = (r & 3) + 8 (r >> 2) + 4 hi
+      float old[16];
+      if (!first) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float *p = w + (i * 32 + nf_row(r, hi)) * S + o * 32 + l31;
-        *p = first ? a[i][o][r] : *p + a[i][o][r];
+        for (int r = 0; r < 16; ++r) old[r] = p[((r & 3) + 8 * (r >> 2)) * S];
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) p[((r & 3) + 8 * (r >> 2)) * S] = first ? a[i][o][r] : old[r] + a[i][o][r];
+    }
 #pragma unroll
   for (int o = 0; o < OB; ++o) {
     const float v = bs[o] + __shfl_xor(bs[o], 32);
@@ -291,7 +298,13 @@ struct DeepBwdArgs {
   const float *wimg;
   int d, ncoup, k_lo, k_hi;  // flat couplings [k_lo, k_hi)
   long N;
+  long long *trace;  // NF_KERNEL_TRACE builds: clock stamps of workgroup 0 / wave 0 (tools/trace_deep_bwd.py), else unused
 };
+#ifdef NF_KERNEL_TRACE
+#define DEEP_STAMP(slot) do { if (tr) { __builtin_amdgcn_sched_barrier(0); tr[slot] = clock64(); } } while (0)
+#else
+#define DEEP_STAMP(slot) do { (void)tr; } while (0)
+#endif
 
 // reverse pass of one (tile, coupling, net).  PHASE_S / INVD as bwd_tile of nf_coupling.hip:
 //   forward chain:  phase T first (y1 <- u = y1 - T, T-bar = ybar1), then phase S (x1 = u exp(-s), x1bar = ybar1 exp(s),
@@ -301,8 +314,10 @@ struct DeepBwdArgs {
 template <class G, bool PHASE_S, bool INVD>
 __device__ __forceinline__ void deep_bwd_tile(const float *__restrict__ img, float *__restrict__ sc, DeepAcc<G> &acc,
                                               float *__restrict__ y, float *__restrict__ ybar, const float *__restrict__ lbar,
-                                              float lbar_const, int d, int c, int par_t, long N, long tile, int l31, int hi) {
+                                              float lbar_const, int d, int c, int par_t, long N, long tile, int l31, int hi,
+                                              long long *tr = nullptr) {
   using L = DeepLds<G>;
+  DEEP_STAMP(0);
   const long j = tile * NF_TILE + l31;
   const bool valid = j < N;
   const int par_c = 1 - par_t;
@@ -320,6 +335,7 @@ __device__ __forceinline__ void deep_bwd_tile(const float *__restrict__ img, flo
       const float v = tile_load(yio, tile_soff(0, r, par_c));  // features >= d read as 0
       xb[0][r] = valid ? v : 0.f;
     }
+    DEEP_STAMP(1);  // (the first use of xb forces the wait: x2 has arrived)
     tile_to_scratch<1>(sx, xb, l31, hi);
     dense_fwd<1, G::HB, G::SH>(img + G::W(0), img + G::B(0), xb, act[0], l31, hi);
   }
@@ -343,7 +359,9 @@ __device__ __forceinline__ void deep_bwd_tile(const float *__restrict__ img, flo
     y1[0][r] = tile_load(yio, tile_soff(0, r, par_t));
     g1[0][r] = tile_load(gio, tile_soff(0, r, par_t));
   }
+  DEEP_STAMP(2);
   dense_fwd<G::HB, 1, G::SO>(img + G::W(G::NH), img + G::B(G::NH), act[G::NH - 1], d3, l31, hi);
+  DEEP_STAMP(3);
 
   const float lb = valid ? (lbar ? lbar[j < N ? j : 0] : lbar_const) : 0.f;
 #pragma unroll
@@ -372,6 +390,7 @@ __device__ __forceinline__ void deep_bwd_tile(const float *__restrict__ img, flo
     }
   }
 
+  DEEP_STAMP(4);
   // ---- output layer: dX, then dW^T from the transposed operands
   f32x16 dh[G::HB];
   dense_bwd_x<G::HB, 1, G::SO>(img + G::W(G::NH), d3, dh, l31, hi);
@@ -384,6 +403,7 @@ __device__ __forceinline__ void deep_bwd_tile(const float *__restrict__ img, flo
 #pragma unroll
     for (int r = 0; r < 16; ++r) dh[b][r] *= nf_mask_slope(msk[G::NH - 1][b], r);
   wave_lds_fence();
+  DEEP_STAMP(5);
   // ---- hidden -> hidden layers, last to first
 #pragma unroll
   for (int l = G::NH - 1; l >= 1; --l) {
@@ -399,6 +419,7 @@ __device__ __forceinline__ void deep_bwd_tile(const float *__restrict__ img, flo
       for (int r = 0; r < 16; ++r) dh[b][r] = dp[b][r] * nf_mask_slope(msk[l - 1][b], r);
     wave_lds_fence();
   }
+  DEEP_STAMP(6);
   // ---- layer 0: x2bar accumulates ybar2 + W0t^T d (phase T) + W0s^T d (phase S)
   f32x16 g2[1];
 #pragma unroll
@@ -410,6 +431,7 @@ __device__ __forceinline__ void deep_bwd_tile(const float *__restrict__ img, flo
 #pragma unroll
   for (int r = 0; r < 16; ++r) tile_store(gio, tile_soff(0, r, par_c), g2[0][r]);
   wave_lds_fence();
+  DEEP_STAMP(7);
 }
 
 // Reverse pass of the couplings [k_lo, k_hi) in one launch: a wave's tiles never change hands and coupling k + 1 only reads what
@@ -434,8 +456,13 @@ __global__ __launch_bounds__(256, 1) void k_deep_bwd(DeepBwdArgs a, float *__res
 #pragma unroll 1
     for (int phase = 0; phase < 2; ++phase) {
       const bool is_s = INVD ? phase == 0 : phase == 1;  // forward chain: T then S; inverse chain: S then T
+      // stamps: [0..4] of the first phase: start, image staged, tiles done, folded, slab written; [8 + 8 i ..] tile i of that phase
+      long long *tr = (a.trace && blockIdx.x == 0 && tid == 0 && step == 0 && phase == 0) ? a.trace : nullptr;
+      DEEP_STAMP(0);
       stage_packed<G::SIZE, 256>(img, a.wimg + ((size_t)k * 2 + (is_s ? 0 : 1)) * G::SIZE, tid);
       __syncthreads();
+      DEEP_STAMP(1);
+      int tcount = 0;
       DeepAcc<G> acc;
       deep_zero(acc.w0, acc.b0);
 #pragma unroll
@@ -443,12 +470,15 @@ __global__ __launch_bounds__(256, 1) void k_deep_bwd(DeepBwdArgs a, float *__res
       deep_zero(acc.wo, acc.bo);
 #pragma unroll 1
       for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+        long long *trt = (tr && tcount < 8) ? tr + 8 + 8 * tcount : nullptr;
+        ++tcount;
         if (is_s)
-          deep_bwd_tile<G, true, INVD>(img, sc, acc, y, ybar, lbar, lbar_const, a.d, c, par_t, a.N, tile, l31, hi);
+          deep_bwd_tile<G, true, INVD>(img, sc, acc, y, ybar, lbar, lbar_const, a.d, c, par_t, a.N, tile, l31, hi, trt);
         else
-          deep_bwd_tile<G, false, INVD>(img, sc, acc, y, ybar, lbar, lbar_const, a.d, c, par_t, a.N, tile, l31, hi);
+          deep_bwd_tile<G, false, INVD>(img, sc, acc, y, ybar, lbar, lbar_const, a.d, c, par_t, a.N, tile, l31, hi, trt);
       }
       __syncthreads();  // the weight image is dead: it becomes the fold target (wave-ordered: deterministic)
+      DEEP_STAMP(2);
 #pragma unroll 1
       for (int w = 0; w < 4; ++w) {
         if (wave == w) {
@@ -460,6 +490,7 @@ __global__ __launch_bounds__(256, 1) void k_deep_bwd(DeepBwdArgs a, float *__res
         }
         __syncthreads();
       }
+      DEEP_STAMP(3);
       {
         const float4 *c0 = reinterpret_cast<const float4 *>(img);
         float4 *dst = reinterpret_cast<float4 *>(slab + (long)blockIdx.x * slab_stride + ((long)k * 2 + (is_s ? 0 : 1)) * G::SIZE);
@@ -467,6 +498,7 @@ __global__ __launch_bounds__(256, 1) void k_deep_bwd(DeepBwdArgs a, float *__res
       }
       __syncthreads();  // the image region is restaged by the next phase (its loads of y / ybar see this phase's stores:
                         // same wave, vmcnt(0) at the barrier, write-through L1 -- as k_affine_bwd_all)
+      DEEP_STAMP(4);
     }
   }
 }
@@ -604,6 +636,7 @@ int nf_deep_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k_lo, int k_hi, float
   DeepBwdArgs a;
   a.wimg = (const float *)ctx->wimg;
   a.d = desc->d; a.ncoup = 2 * desc->nlayers; a.k_lo = k_lo; a.k_hi = k_hi; a.N = N;
+  a.trace = (long long *)ctx->trace;
 #define DEEP_CALL(G) (inv_dir ? deep_launch_bwd<G, true>(ctx, a, y, ybar, lbar, lbar_const, slab, slab_stride, grid) \
                               : deep_launch_bwd<G, false>(ctx, a, y, ybar, lbar, lbar_const, slab, slab_stride, grid))
   return DEEP_DISPATCH(id, DEEP_CALL);

@@ -862,15 +862,21 @@ __device__ __forceinline__ void rqs_zero(f32x16 (&a)[IB][OB], float (&b)[OB]) {
 template <int IB, int OB, int S>
 __device__ __forceinline__ void rqs_fold(float *__restrict__ w, float *__restrict__ b, const f32x16 (&a)[IB][OB],
                                          const float (&bs)[OB], bool first, int l31, int hi) {
+  // a block's sixteen partial sums are read in one go, then written back: as one read-modify-write after the other every LDS
+  // round trip is exposed (round 5, tools/trace_deep_bwd.py on the same fold in nf_deep.hip)
 #pragma unroll
   for (int i = 0; i < IB; ++i)
 #pragma unroll
-    for (int o = 0; o < OB; ++o)
+    for (int o = 0; o < OB; ++o) {
+      float *p = w + (i * 32 + 4 * hi) * S + o * 32 + l31;  // row nf_row(r, hi) = (r & 3) + 8 (r >> 2) + 4 hi
+      float old[16];
+      if (!first) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float *p = w + (i * 32 + nf_row(r, hi)) * S + o * 32 + l31;
-        *p = first ? a[i][o][r] : *p + a[i][o][r];
+        for (int r = 0; r < 16; ++r) old[r] = p[((r & 3) + 8 * (r >> 2)) * S];
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) p[((r & 3) + 8 * (r >> 2)) * S] = first ? a[i][o][r] : old[r] + a[i][o][r];
+    }
 #pragma unroll
   for (int o = 0; o < OB; ++o) {
     const float v = bs[o] + __shfl_xor(bs[o], 32);
