@@ -265,12 +265,42 @@ __device__ __forceinline__ void deep_zero(f32x16 (&a)[IB][OB], float (&b)[OB]) {
 #pragma unroll
   for (int o = 0; o < OB; ++o) b[o] = 0.f;
 }
-template <int IB, int OB, int S>
+// The blocks of a layer whose running number (B0 + the block's index in the layer) is `sel` modulo 4: see the fold in k_deep_bwd.
+template <int IB, int OB, int S, int B0>
 __device__ __forceinline__ void deep_fold(float *__restrict__ w, float *__restrict__ b, const f32x16 (&a)[IB][OB], const float (&bs)[OB],
-                                          bool first, int l31, int hi) {
+                                          bool first, int sel, int l31, int hi) {
   // A block's sixteen partial sums are read in one go, then written back (round 5).  As one read-modify-write after the other
   // (`*p = *p + a`) every LDS round trip was exposed: tools/trace_deep_bwd.py showed the fold at 15.0 k of a phase's 56.6 k
   // clocks for one hidden layer of 64 and 52.8 k of 183 k for three -- more than a quarter of the reverse kernel.
+#pragma unroll
+  for (int i = 0; i < IB; ++i)
+#pragma unroll
+    for (int o = 0; o < OB; ++o) {
+      if (((B0 + i * OB + o) & 3) != sel) continue;  // (wave-uniform)
+      float *p = w + (i * 32 + 4 * hi) * S + o * 32 + l31;  // row nf_row(r, hi) = (r & 3) + 8 (r >> 2) + 4 hi
+      float old[16];
+      if (!first) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[r] = p[((r & 3) + 8 * (r >> 2)) * S];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) p[((r & 3) + 8 * (r >> 2)) * S] = first ? a[i][o][r] : old[r] + a[i][o][r];
+    }
+#pragma unroll
+  for (int o = 0; o < OB; ++o) {  // the bias sums travel with the layer's block (0, o)
+    if (((B0 + o) & 3) != sel) continue;
+    const float v = bs[o] + __shfl_xor(bs[o], 32);
+    if (hi == 0) {
+      float *p = b + o * 32 + l31;
+      *p = first ? v : *p + v;
+    }
+  }
+}
+
+// every block of a layer (the waves-in-turn fold)
+template <int IB, int OB, int S>
+__device__ __forceinline__ void deep_fold_all(float *__restrict__ w, float *__restrict__ b, const f32x16 (&a)[IB][OB], const float (&bs)[OB],
+                                              bool first, int l31, int hi) {
 #pragma unroll
   for (int i = 0; i < IB; ++i)
 #pragma unroll
@@ -477,18 +507,43 @@ __global__ __launch_bounds__(256, 1) void k_deep_bwd(DeepBwdArgs a, float *__res
         else
           deep_bwd_tile<G, false, INVD>(img, sc, acc, y, ybar, lbar, lbar_const, a.d, c, par_t, a.N, tile, l31, hi, trt);
       }
-      __syncthreads();  // the weight image is dead: it becomes the fold target (wave-ordered: deterministic)
+      __syncthreads();  // the weight image is dead: it becomes the fold target
       DEEP_STAMP(2);
+      // Four steps, every wave busy in each: in step s wave w adds its sums to the blocks numbered (w + s) mod 4 -- block b is
+      // written by wave b mod 4 first, then added to by waves b - 1, b - 2, b - 3 (mod 4): a fixed order per element, and the
+      // four waves one after the other over the WHOLE image took four times as long (hidden [64]: 364 -> 332 us per launch).
+      // Three hidden layers of 64 keep the waves-in-turn form (ROT = false): the kernel sits at 512 registers with scratch
+      // spills, and with the rotating fold hipcc's allocation of its TILE loop came out 11 % slower at 1 M samples
+      // (15.4 against 13.9 ms; tools/bench_deep_n.py, one box).
+      constexpr bool ROT = !(G::NH >= 3 && G::HB == 2);
+      if constexpr (ROT) {
 #pragma unroll 1
-      for (int w = 0; w < 4; ++w) {
-        if (wave == w) {
-          deep_fold<1, G::HB, G::SH>(img + G::W(0), img + G::B(0), acc.w0, acc.b0, w == 0, l31, hi);
+        for (int st = 0; st < 4; ++st) {
+          const int sel = (wave + st) & 3;
+          constexpr int NB0 = G::HB, NBH = G::HB * G::HB;  // blocks of layer 0 / of a hidden -> hidden layer
+          deep_fold<1, G::HB, G::SH, 0>(img + G::W(0), img + G::B(0), acc.w0, acc.b0, st == 0, sel, l31, hi);
 #pragma unroll
-          for (int l = 1; l < G::NH; ++l)
-            deep_fold<G::HB, G::HB, G::SH>(img + G::W(l), img + G::B(l), acc.wh[l - 1], acc.bh[l - 1], w == 0, l31, hi);
-          deep_fold<G::HB, 1, G::SO>(img + G::W(G::NH), img + G::B(G::NH), acc.wo, acc.bo, w == 0, l31, hi);
+          for (int l = 1; l < G::NH; ++l) {
+            // (B0 must be a constant expression: the layers are unrolled by hand for up to four hidden layers)
+            if (l == 1) deep_fold<G::HB, G::HB, G::SH, NB0>(img + G::W(1), img + G::B(1), acc.wh[0], acc.bh[0], st == 0, sel, l31, hi);
+            if (l == 2) deep_fold<G::HB, G::HB, G::SH, NB0 + NBH>(img + G::W(2), img + G::B(2), acc.wh[G::NH > 2 ? 1 : 0], acc.bh[G::NH > 2 ? 1 : 0], st == 0, sel, l31, hi);
+            if (l == 3) deep_fold<G::HB, G::HB, G::SH, NB0 + 2 * NBH>(img + G::W(3), img + G::B(3), acc.wh[G::NH > 3 ? 2 : 0], acc.bh[G::NH > 3 ? 2 : 0], st == 0, sel, l31, hi);
+          }
+          deep_fold<G::HB, 1, G::SO, NB0 + (G::NH - 1) * NBH>(img + G::W(G::NH), img + G::B(G::NH), acc.wo, acc.bo, st == 0, sel, l31, hi);
+          __syncthreads();
         }
-        __syncthreads();
+      } else {
+#pragma unroll 1
+        for (int w = 0; w < 4; ++w) {
+          if (wave == w) {
+            deep_fold_all<1, G::HB, G::SH>(img + G::W(0), img + G::B(0), acc.w0, acc.b0, w == 0, l31, hi);
+#pragma unroll
+            for (int l = 1; l < G::NH; ++l)
+              deep_fold_all<G::HB, G::HB, G::SH>(img + G::W(l), img + G::B(l), acc.wh[l - 1], acc.bh[l - 1], w == 0, l31, hi);
+            deep_fold_all<G::HB, 1, G::SO>(img + G::W(G::NH), img + G::B(G::NH), acc.wo, acc.bo, w == 0, l31, hi);
+          }
+          __syncthreads();
+        }
       }
       DEEP_STAMP(3);
       {
