@@ -125,13 +125,13 @@ __device__ __forceinline__ void net_forward_b6(const float *__restrict__ img, co
   const nf_u32x4 *w = reinterpret_cast<const nf_u32x4 *>(img);
   const float *bias = reinterpret_cast<const float *>(w + B::BIAS);
   f32x16 a1[G::H1B], a2[G::H2B];
-  dense_fwd_b6<G::MB, G::H1B>(w + B::L1, bias + B::B1, x, a1, l31, hi);
+  dense_fwd_b6p<G::MB, G::H1B>(w + B::L1, bias + B::B1, x, a1, l31, hi);
 #pragma unroll
   for (int b = 0; b < G::H1B; ++b) nf_lrelu16(a1[b]);
-  dense_fwd_b6<G::H1B, G::H2B>(w + B::L2, bias + B::B2, a1, a2, l31, hi);
+  dense_fwd_b6p<G::H1B, G::H2B>(w + B::L2, bias + B::B2, a1, a2, l31, hi);
 #pragma unroll
   for (int b = 0; b < G::H2B; ++b) nf_lrelu16(a2[b]);
-  dense_fwd_b6<G::H2B, G::CB>(w + B::L3, bias + B::B3, a2, out, l31, hi);
+  dense_fwd_b6p<G::H2B, G::CB>(w + B::L3, bias + B::B3, a2, out, l31, hi);
 }
 
 struct NoBetween {
@@ -139,14 +139,24 @@ struct NoBetween {
 };
 // B6: img_s / img_t are B6 images; `between` runs between the two nets (the B6 chain kernel's image rotation: a workgroup
 // barrier and the request for the image after next)
+#ifdef NF_KERNEL_TRACE
+#define NF_CS_STAMP(tr, slot) do { if (tr) { __builtin_amdgcn_sched_barrier(0); (tr)[slot] = clock64(); } } while (0)
+#else
+#define NF_CS_STAMP(tr, slot) do { } while (0)
+#endif
 template <class G, bool INVERSE, bool B6 = false, class BT = NoBetween>
 __device__ __forceinline__ float coupling_step(const float *__restrict__ img_s, const float *__restrict__ img_t,
-                                               f32x16 (&x1)[G::CB], const f32x16 (&xb)[G::MB], int l31, int hi, BT between = BT()) {
+                                               f32x16 (&x1)[G::CB], const f32x16 (&xb)[G::MB], int l31, int hi, BT between = BT(),
+                                               long long *tr = nullptr) {
   f32x16 S[G::CB], T[G::CB];
   if constexpr (B6) {
+    NF_CS_STAMP(tr, 0);  // tools/trace_chain.py (NOSTASH=1): after the phase barrier + the request for the image after next
     net_forward_b6<G>(img_s, xb, S, l31, hi);
+    NF_CS_STAMP(tr, 1);
     between();
+    NF_CS_STAMP(tr, 2);
     net_forward_b6<G>(img_t, xb, T, l31, hi);
+    NF_CS_STAMP(tr, 3);
   } else {
   {
     f32x16 a1[G::H1B], a2[G::H2B];
@@ -534,10 +544,16 @@ __global__ __launch_bounds__(512) void k_affine_chain(ChainArgs a, float *xt, fl
             else ls = coupling_step_stash<G, INVERSE, SLIM, true>(img_s, img_t, E, O, l31, hi, st, tr, between);
             NF_CH_STAMP(tr, 3);
             NF_CH_STAMP(tr, 4);
-          } else if (INVERSE ? (half == 1) : (half == 0)) {
-            ls = coupling_step<G, INVERSE, true>(img_s, img_t, O, E, l31, hi, between);
           } else {
-            ls = coupling_step<G, INVERSE, true>(img_s, img_t, E, O, l31, hi, between);
+#ifdef NF_KERNEL_TRACE  // stamps [32 + wave/4 * 64 + position * 5 + 0..4] of the second tile group (the first one's images arrive cold)
+            long long *tr = (fa.trace && blockIdx.x == 0 && (tid & 255) == 0 && pos < 8 && grp != (long)blockIdx.x && grp == (long)blockIdx.x + gridDim.x)
+                                ? fa.trace + 32 + (tid >> 8) * 48 + pos * 5 : nullptr;
+#else
+            long long *tr = nullptr;
+#endif
+            if (INVERSE ? (half == 1) : (half == 0)) ls = coupling_step<G, INVERSE, true>(img_s, img_t, O, E, l31, hi, between, tr);
+            else ls = coupling_step<G, INVERSE, true>(img_s, img_t, E, O, l31, hi, between, tr);
+            NF_CS_STAMP(tr, 4);
           }
           lsum += ls;
           cur_slot = slot_t == 2 ? 0 : slot_t + 1;
@@ -2115,6 +2131,7 @@ static int launch_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, flo
   if (grid < 1) grid = 1;
   ProfScope ps(ctx, "affine_chain");
   FusedArgs none{};
+  none.trace = (long long *)ctx->trace;
   if (fused && fused->stash)
     hipLaunchKernelGGL((k_affine_chain<G, false, true, true, SLIM, B6>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, *fused);
   else if (fused)

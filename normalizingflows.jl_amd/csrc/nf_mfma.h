@@ -736,6 +736,74 @@ __device__ __forceinline__ void dense_fwd_b6(const nf_u32x4 *__restrict__ w, con
   }
 }
 
+// The same product as a software pipeline (round 5; tools/trace_chain_b6.py).  In dense_fwd_b6 a k-group's split (45 vector
+// instructions) runs, then the six MFMAs of a unit wait for one another on one accumulator: a wave alone needs 6.6 k clocks for a
+// 32-64-64-32 net whose 96 MFMAs occupy the matrix pipe for 3.1 k, and the second wave of the SIMD only fills part of the gaps
+// (BASELINE cfg 5: 11.5 k per net and SIMD, 53 % of the pipe).  Here the k-group kg + 1 is split -- and its weights are
+// requested from LDS -- in the issue shadows of k-group kg's MFMAs (sched_group_barrier: one MFMA, a few VALU), and the OB
+// accumulators of a k-group alternate term by term, so that no MFMA waits for the one before it (OB = 2).  The order of the
+// terms of every accumulator is the one of dense_fwd_b6: bit-identical results.
+template <int IB, int OB>
+__device__ __forceinline__ void dense_fwd_b6p(const nf_u32x4 *__restrict__ w, const float *__restrict__ b, const f32x16 (&in)[IB],
+                                              f32x16 (&out)[OB], int l31, int hi) {
+  constexpr int ROWS = 32 * OB, NKG = 2 * IB;
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[ob][r] = b[ob * 32 + nf_row(r, hi)];
+  const nf_u32x4 *wl = w + hi * ROWS + l31;  // lane part of the address; (k-group, component, block) are immediates
+  nf_u32x4 an[OB][3], xn[3];
+  {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = in[0][j];
+    nf_split8(v, xn[0], xn[1], xn[2]);
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) an[ob][c] = wl[c * 2 * ROWS + ob * 32];
+  }
+#pragma unroll
+  for (int kg = 0; kg < NKG; ++kg) {
+    nf_u32x4 ac[OB][3], xc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      xc[c] = xn[c];
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob) ac[ob][c] = an[ob][c];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (kg + 1 < NKG) {
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) an[ob][c] = wl[((kg + 1) * 3 + c) * 2 * ROWS + ob * 32];
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = in[(kg + 1) >> 1][8 * ((kg + 1) & 1) + j];
+      nf_split8(v, xn[0], xn[1], xn[2]);
+    }
+    // smallest terms first: wl xh, wh xl, wm xm, wm xh, wh xm, wh xh (components: 0 = h, 1 = m, 2 = l)
+#pragma unroll
+    for (int term = 0; term < 6; ++term)
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob) {
+        const nf_u32x4 &av = term == 0 ? ac[ob][2] : (term == 2 || term == 3) ? ac[ob][1] : ac[ob][0];
+        const nf_u32x4 &xv = term == 1 ? xc[2] : (term == 2 || term == 4) ? xc[1] : xc[0];
+        out[ob] = nf_mfma_bf16(av, xv, out[ob]);
+      }
+    if (kg + 1 < NKG) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 3 * OB, 0);  // the next k-group's weights: requested first
+#pragma unroll
+      for (int i = 0; i < 6 * OB; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, OB == 1 ? 8 : 4, 0);  // its shadow: a slice of the next split
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // The transposed counterpart for the dX GEMMs of the reverse pass (din = W^T delta): rows = the layer's INPUT features, the
 // k-groups run over its OUTPUT features, in the order the cotangent's C-layout registers hold them (same mapping as above).
 // Per layer [k-group][component][half][row][8 bf16]; no biases.  T3 serves dX3 (rows: a2 features), T2 dX2, T1 dX1.
