@@ -638,6 +638,19 @@ __device__ __forceinline__ void nf_split2(float x0, float x1, unsigned &h, unsig
   const nf_f32x2 lo = r - __builtin_bit_cast(nf_f32x2, rb & 0xFFFF0000u);
   h = __builtin_amdgcn_perm(xb.y, xb.x, 0x07060302u);
   m = __builtin_amdgcn_perm(rb.y, rb.x, 0x07060302u);
+#elif defined(NF_SPLIT_SCALAR)  // A/B: the two subtractions as scalar v_sub_f32 pairs instead of v_pk_add_f32
+  h = nf_cvt_pk_bf16(x);
+  const nf_f32x2 hw = nf_widen_pk_bf16(h);
+  float r0 = x0 - hw.x, r1 = x1 - hw.y;
+  asm("" : "+v"(r0));
+  asm("" : "+v"(r1));
+  const nf_f32x2 r = {r0, r1};
+  m = nf_cvt_pk_bf16(r);
+  const nf_f32x2 mw = nf_widen_pk_bf16(m);
+  float l0 = r0 - mw.x, l1 = r1 - mw.y;
+  asm("" : "+v"(l0));
+  asm("" : "+v"(l1));
+  const nf_f32x2 lo = {l0, l1};
 #else
   h = nf_cvt_pk_bf16(x);
   const nf_f32x2 r = x - nf_widen_pk_bf16(h);   // exact

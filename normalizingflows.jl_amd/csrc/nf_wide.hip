@@ -19,6 +19,11 @@
 // per wave the way nf_coupling.hip keeps them, hence the stash.  Per sample and net it is
 // (2*h1 + 2*h2 + c) floats, written once and read once.
 #include "nf_common.h"
+// The split's two exact subtractions as scalar v_sub_f32 pairs in this file (nf_mfma.h: NF_SPLIT_SCALAR).  A packed f32 VALU
+// instruction next to bf16 MFMAs costs more than the issue slot it saves with one wave per SIMD (these kernels); measured on
+// one box, round 5: k_wide_dw_b6 56.2 -> 54.4 us, k_wide_bwd_stashed_b6 75.7 -> 74.4 us per launch.  The two-waves-per-SIMD
+// kernels keep v_pk_add_f32 (the cfg-2 pair kernel: 336-338 against 331-334 us with scalar subtractions).
+#define NF_SPLIT_SCALAR
 #include "nf_mfma.h"
 #include "nf_pack.h"
 
