@@ -40,22 +40,47 @@ struct G64M {
   static constexpr size_t bwd_lds(int nhid) { return (size_t)(img_size(nhid) + 2 * 4 * TILE) * 8; }
 };
 
-// stage one Dense layer theta[in][out] (Flux: out x in column-major) into its padded image rows, zero fill
-__device__ __forceinline__ void g64m_stage_layer(double *__restrict__ w, double *__restrict__ b, int rows_pad, int S, int cols_pad,
-                                                 const double *__restrict__ theta, long w_off, long b_off, int nin, int nout, int tid) {
-  for (int e = tid; e < rows_pad * S; e += 256) {
-    const int i = e / S, o = e - i * S;
-    w[e] = (i < nin && o < nout) ? theta[w_off + (long)i * nout + o] : 0.0;
+// Stage the Dense layers theta[in][out] (Flux: out x in column-major) of a net into their padded image rows, zero fill.
+// Sizes are template arguments, every thread's elements of ALL layers are requested before the first is stored (round 5): with
+// run-time sizes and one element per iteration every element cost an integer division and its own exposed round trip to L2 --
+// tools/trace_g64m.py showed the staging at 30 k of a pass's 70-84 k clocks in k_g64m_apply (39 % of the launch; all
+// workgroups read the same 64 KB at the same moment, so a round trip is ~2.5 k clocks).
+template <int ROWS, int S>
+struct G64MStage {
+  static constexpr int NE = ROWS * S, U = (NE + 255) / 256;
+  double v[U];
+  __device__ __forceinline__ void load(const double *__restrict__ theta, long w_off, int nin, int nout, int tid) {
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int e = tid + 256 * k, i = e / S, o = e - i * S;  // (S is a constant: multiply-shift)
+      v[k] = (e < NE && i < nin && o < nout) ? theta[w_off + (long)i * nout + o] : 0.0;
+    }
   }
-  for (int o = tid; o < cols_pad; o += 256) b[o] = o < nout ? theta[b_off + o] : 0.0;
+  __device__ __forceinline__ void store(double *__restrict__ w, int tid) const {
+#pragma unroll
+    for (int k = 0; k < U; ++k)
+      if (tid + 256 * k < NE) w[tid + 256 * k] = v[k];
+  }
+};
+template <int COLS>
+__device__ __forceinline__ void g64m_stage_bias(double *__restrict__ b, const double *__restrict__ theta, long b_off, int nout, int tid) {
+  for (int o = tid; o < COLS; o += 256) b[o] = o < nout ? theta[b_off + o] : 0.0;
 }
 template <class G>
 __device__ __forceinline__ void g64m_stage_net(double *__restrict__ img, const double *__restrict__ theta, const G64Net &n, int tid) {
   const int nhid = n.nl - 1;
-  g64m_stage_layer(img + G::W0, img + G::B0, 16 * G::MB, G::SH, 16 * G::HB, theta, n.w[0], n.b[0], n.dims[0], n.dims[1], tid);
-  if (nhid == 2) g64m_stage_layer(img + G::W1, img + G::B1, 16 * G::HB, G::SH, 16 * G::HB, theta, n.w[1], n.b[1], n.dims[1], n.dims[2], tid);
-  g64m_stage_layer(img + G::img_wo(nhid), img + G::img_bo(nhid), 16 * G::HB, G::SC, 16 * G::CB, theta, n.w[nhid], n.b[nhid], n.dims[nhid],
-                   n.dims[nhid + 1], tid);
+  G64MStage<16 * G::MB, G::SH> l0;
+  G64MStage<16 * G::HB, G::SH> l1;
+  G64MStage<16 * G::HB, G::SC> lo;
+  l0.load(theta, n.w[0], n.dims[0], n.dims[1], tid);
+  if (nhid == 2) l1.load(theta, n.w[1], n.dims[1], n.dims[2], tid);
+  lo.load(theta, n.w[nhid], n.dims[nhid], n.dims[nhid + 1], tid);
+  g64m_stage_bias<16 * G::HB>(img + G::B0, theta, n.b[0], n.dims[1], tid);
+  if (nhid == 2) g64m_stage_bias<16 * G::HB>(img + G::B1, theta, n.b[1], n.dims[2], tid);
+  g64m_stage_bias<16 * G::CB>(img + G::img_bo(nhid), theta, n.b[nhid], n.dims[nhid + 1], tid);
+  l0.store(img + G::W0, tid);
+  if (nhid == 2) l1.store(img + G::W1, tid);
+  lo.store(img + G::img_wo(nhid), tid);
 }
 
 __device__ __forceinline__ f64x4 g64m_mfma(double a, double b, f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
@@ -216,7 +241,13 @@ __device__ __forceinline__ void g64m_net_fwd(const double *__restrict__ img, int
 // (both nets read only the conditioner half, which a coupling does not change).
 template <class G>
 __global__ __launch_bounds__(256) void k_g64m_apply(G64Args a, int inverse, const double *__restrict__ theta, const double *x, double *y,
-                                                    double *__restrict__ ladj) {
+                                                    double *__restrict__ ladj, long long *trace) {
+#ifdef NF_KERNEL_TRACE  // tools/trace_g64m.py: workgroup 0 / wave 0; [16 pass + 0] start, [+1] net staged, [+2 + 4 i ..] tile i: x loaded, net done, element-wise done
+#define G64M_STAMP(slot) do { if (tr) { __builtin_amdgcn_sched_barrier(0); tr[slot] = clock64(); } } while (0)
+  long long *tr = (trace && blockIdx.x == 0 && threadIdx.x == 0) ? trace : nullptr;
+#else
+#define G64M_STAMP(slot) do { } while (0)
+#endif
   extern __shared__ __attribute__((aligned(16))) double lds64[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c16 = lane & 15, q = lane >> 4;
   const int nhid = a.net[0].nl - 1, par_c = 1 - a.par_t;
@@ -224,17 +255,25 @@ __global__ __launch_bounds__(256) void k_g64m_apply(G64Args a, int inverse, cons
   for (int pass = 0; pass < 2; ++pass) {
     const bool is_s = inverse ? pass == 1 : pass == 0;
     __syncthreads();
+    G64M_STAMP(16 * pass + 0);
     g64m_stage_net<G>(lds64, theta, a.net[is_s ? 0 : 1], tid);
     __syncthreads();
+    G64M_STAMP(16 * pass + 1);
+    int tcount = 0;
     for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+      const int tb = 16 * pass + 2 + 4 * (tcount < 3 ? tcount : 2);
+      ++tcount;
+      (void)tb;
       const long j = tile * 16 + c16;
       const bool valid = j < a.N;
       const long jr = valid ? j : a.N - 1;
       const double *xr = x + jr * a.d;
       double *yr = y + jr * a.d;
       f64x4 xb[G::MB], a1[G::HB], a2[G::HB], out[G::CB];
+      G64M_STAMP(tb + 0);
       g64m_load_cond<G::MB>(xr, a.m, par_c, valid, xb, q);
       g64m_net_fwd<G>(lds64, nhid, xb, a1, a2, out, c16, q);
+      G64M_STAMP(tb + 1);
       double lsum = 0.0;
 #pragma unroll
       for (int b = 0; b < G::CB; ++b)
@@ -268,7 +307,9 @@ __global__ __launch_bounds__(256) void k_g64m_apply(G64Args a, int inverse, cons
             if (valid && f < a.m) yr[2 * f + par_c] = xb[b][r];
           }
       }
+      G64M_STAMP(tb + 2);
     }
+    G64M_STAMP(16 * pass + 14);
   }
 }
 
@@ -409,10 +450,13 @@ static int g64m_launch_apply(nf_ctx *ctx, const G64Args &a, int inverse, const d
     NF_HIP(hipFuncSetAttribute((const void *)k_g64m_apply<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return NF_OK;
   }));
+  // as many workgroups as the device holds at once (a workgroup stages both nets' images: a second round of workgroups pays
+  // that again -- at d = 64 one workgroup fits a CU, and 2 num_cu of them ran as two rounds)
   const long ngroups = ((a.N + 15) / 16 + 3) / 4;
-  long grid = ngroups < 2L * ctx->num_cu ? ngroups : 2L * ctx->num_cu;
+  const long per_cu = lds > 80 * 1024 ? 1 : 2;  // 160 KB of LDS per CU
+  long grid = ngroups < per_cu * ctx->num_cu ? ngroups : per_cu * ctx->num_cu;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((k_g64m_apply<G>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, inverse, theta, x, y, ladj);
+  hipLaunchKernelGGL((k_g64m_apply<G>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, inverse, theta, x, y, ladj, (long long *)ctx->trace);
   return (int)hipGetLastError();
 }
 template <class G>
