@@ -513,10 +513,22 @@ __device__ __forceinline__ void l64_load(const L64Src &s, long tile, int l31, in
 template <int IB, int OB>
 __device__ __forceinline__ void l64_stage(float *__restrict__ w, float *__restrict__ b, const float *__restrict__ theta,
                                           const L64Layer &L, int tid, int nthreads) {
-  constexpr int S = 32 * OB + NF_IMG_PAD;
-  for (int e = tid; e < 32 * IB * 32 * OB; e += nthreads) {
-    const int i = e / (32 * OB), o = e - i * (32 * OB);
-    w[i * S + o] = (i < L.nin && L.o0 + o < L.nout) ? theta[L.w_off + (long)i * L.nout + L.o0 + o] : 0.f;
+  constexpr int S = 32 * OB + NF_IMG_PAD, NE = 32 * IB * 32 * OB, U = 16;
+  // sixteen requests per thread in flight at a time (round 5): one element per iteration exposed a round trip to L2 for each of
+  // a block's 16-64 elements per thread -- the same pattern cost k_g64m_apply 39 % of its launch (tools/trace_g64m.py)
+#pragma unroll 1
+  for (int e0 = tid; e0 < NE; e0 += nthreads * U) {
+    float v[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int e = e0 + nthreads * k, i = e / (32 * OB), o = e - i * (32 * OB);
+      v[k] = (e < NE && i < L.nin && L.o0 + o < L.nout) ? theta[L.w_off + (long)i * L.nout + L.o0 + o] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int e = e0 + nthreads * k, i = e / (32 * OB), o = e - i * (32 * OB);
+      if (e < NE) w[i * S + o] = v[k];
+    }
   }
   for (int o = tid; o < 32 * OB; o += nthreads) b[o] = (L.o0 + o < L.nout) ? theta[L.b_off + L.o0 + o] : 0.f;
 }
