@@ -318,9 +318,13 @@ __global__ __launch_bounds__(256) void k_g64m_apply(G64Args a, int inverse, cons
 template <class G>
 __global__ __launch_bounds__(256) void k_g64m_bwd(G64Args a, int inv, const double *__restrict__ theta, const double *__restrict__ x,
                                                   double *gbar, const double *__restrict__ lbar, double lbar_const,
-                                                  double *__restrict__ slabs, long Pc, long slab_off) {
+                                                  double *__restrict__ slabs, long Pc, long slab_off, long long *trace) {
   extern __shared__ __attribute__((aligned(16))) double lds64[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c16 = lane & 15, q = lane >> 4;
+#ifdef NF_KERNEL_TRACE  // tools/trace_g64m.py: [32 + 24 phase + ..]: 0 start, 1 staged, 2 + 5 g .. group g (forward + element-wise | output layer |
+                        // hidden layer | first layer + stores), 22 groups done, 23 stored
+  long long *tr = (trace && blockIdx.x == 0 && threadIdx.x == 0) ? trace + 32 : nullptr;
+#endif
   const int nhid = a.net[0].nl - 1, par_c = 1 - a.par_t;
   double *img = lds64;
   double *atiles = lds64 + G::img_size(nhid), *dtiles = atiles + 4 * G::TILE;  // [4 waves][16 samples][ST]
@@ -331,8 +335,11 @@ __global__ __launch_bounds__(256) void k_g64m_bwd(G64Args a, int inv, const doub
     const bool is_s = inv ? phase == 0 : phase == 1;  // forward coupling: t-net first (it reads ybar1 before the s phase rescales it)
     const G64Net &net = a.net[is_s ? 0 : 1];
     __syncthreads();
+    G64M_STAMP(24 * phase + 0);
     g64m_stage_net<G>(img, theta, net, tid);
     __syncthreads();
+    G64M_STAMP(24 * phase + 1);
+    int gcount = 0;
     G64MAcc<G::MB, G::HB, G::ST> acc0;
     G64MAcc<G::HB, G::HB, G::ST> acc1;
     G64MAcc<G::HB, G::CB, G::ST> acco;
@@ -340,6 +347,10 @@ __global__ __launch_bounds__(256) void k_g64m_bwd(G64Args a, int inv, const doub
     g64m_zero(acc1);
     g64m_zero(acco);
     for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+      const int gb = 24 * phase + 2 + 5 * (gcount < 4 ? gcount : 3);
+      ++gcount;
+      (void)gb;
+      G64M_STAMP(gb + 0);
       const long tile = grp * 4 + wave;
       const long j = tile * 16 + c16;
       const bool valid = j < a.N;
@@ -376,6 +387,7 @@ __global__ __launch_bounds__(256) void k_g64m_bwd(G64Args a, int inv, const doub
           }
           dout[b][r] = dv;
         }
+      G64M_STAMP(gb + 1);
       // ---- output layer
       f64x4 dh[G::HB];
       if (nhid == 2) {
@@ -389,6 +401,7 @@ __global__ __launch_bounds__(256) void k_g64m_bwd(G64Args a, int inv, const doub
       __syncthreads();
       g64m_dw<G::HB, G::CB, G::ST>(atiles, dtiles, acco, wave, c16, q);
       __syncthreads();
+      G64M_STAMP(gb + 2);
       if (nhid == 2) {
         g64m_lrelu_grad<G::HB>(dh, a2);
         f64x4 d1[G::HB];
@@ -401,6 +414,7 @@ __global__ __launch_bounds__(256) void k_g64m_bwd(G64Args a, int inv, const doub
 #pragma unroll
         for (int b = 0; b < G::HB; ++b) dh[b] = d1[b];
       }
+      G64M_STAMP(gb + 3);
       g64m_lrelu_grad<G::HB>(dh, a1);
       // ---- first layer: x2bar += W0 delta
       f64x4 g2[G::MB];
@@ -417,10 +431,13 @@ __global__ __launch_bounds__(256) void k_g64m_bwd(G64Args a, int inv, const doub
           const int f = 16 * b + q + 4 * r;
           if (valid && f < a.m) gr[2 * f + par_c] += g2[b][r];
         }
+      G64M_STAMP(gb + 4);
     }
+    G64M_STAMP(24 * phase + 22);
     g64m_store<G::MB, G::HB, G::ST>(slab, acc0, net.w[0], net.b[0], net.dims[0], net.dims[1], wave, c16, q);
     if (nhid == 2) g64m_store<G::HB, G::HB, G::ST>(slab, acc1, net.w[1], net.b[1], net.dims[1], net.dims[2], wave, c16, q);
     g64m_store<G::HB, G::CB, G::ST>(slab, acco, net.w[nhid], net.b[nhid], net.dims[nhid], net.dims[nhid + 1], wave, c16, q);
+    G64M_STAMP(24 * phase + 23);
   }
 }
 
@@ -468,6 +485,7 @@ static int g64m_launch_bwd(nf_ctx *ctx, const G64Args &a, int inv, const double 
     NF_HIP(hipFuncSetAttribute((const void *)k_g64m_bwd<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return NF_OK;
   }));
-  hipLaunchKernelGGL((k_g64m_bwd<G>), dim3(grid), dim3(256), lds, ctx->stream, a, inv, theta, x, gbar, lbar, lbar_const, slabs, Pc, slab_off);
+  hipLaunchKernelGGL((k_g64m_bwd<G>), dim3(grid), dim3(256), lds, ctx->stream, a, inv, theta, x, gbar, lbar, lbar_const, slabs, Pc, slab_off,
+                     (long long *)ctx->trace);
   return (int)hipGetLastError();
 }
