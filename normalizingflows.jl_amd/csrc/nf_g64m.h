@@ -24,9 +24,10 @@
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-template <int MB_, int HB_>
+template <int MB_, int HB_, int CB_ = MB_>
 struct G64M {
-  static constexpr int MB = MB_, HB = HB_, CB = MB_;  // blocks of 16: conditioner / hidden / transformed
+  static constexpr int MB = MB_, HB = HB_, CB = CB_;  // blocks of 16: conditioner / hidden / net outputs (RealNVP: the transformed
+                                                      // half, = MB; neural spline: (3K - 1) parameters per transformed dim)
   static constexpr int SH = 16 * HB + 2, SC = 16 * CB + 2;  // row strides (doubles) of layers ending in a hidden / the output layer
   // image of a net with NHID hidden layers: W0 [16 MB][SH] b0 [16 HB] | (W1 [16 HB][SH] b1 [16 HB]) | Wo [16 HB][SC] bo [16 CB]
   static constexpr int W0 = 0, B0 = W0 + 16 * MB * SH;
@@ -34,7 +35,7 @@ struct G64M {
   static constexpr int img_wo(int nhid) { return nhid == 2 ? B1 + 16 * HB : W1; }
   static constexpr int img_bo(int nhid) { return img_wo(nhid) + 16 * HB * SC; }
   static constexpr int img_size(int nhid) { return (img_bo(nhid) + 16 * CB + 1) / 2 * 2; }
-  static constexpr int ST = 16 * (HB > MB ? HB : MB) + 2;   // row stride of the [sample][feature] tiles of the dW stage
+  static constexpr int ST = 16 * ((HB > MB ? HB : MB) > CB ? (HB > MB ? HB : MB) : CB) + 2;  // row stride of the [sample][feature] tiles of the dW stage
   static constexpr int TILE = 16 * ST;                       // doubles per tile
   static constexpr size_t apply_lds(int nhid) { return (size_t)img_size(nhid) * 8; }
   static constexpr size_t bwd_lds(int nhid) { return (size_t)(img_size(nhid) + 2 * 4 * TILE) * 8; }
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(256) void k_g64m_apply(G64Args a, int inverse, cons
 
 // ---- reverse pass of one coupling at its INPUT x (gbar: ybar -> xbar), or of the INVERSE coupling at its output (inv != 0):
 // the semantics of k_g64_bwd, nf_generic64.hip.  slabs: [gridDim.x][Pc], THIS coupling's parameters from theta index slab_off.
-template <class G>
+template <class G, bool NSF = false>
 __global__ __launch_bounds__(256) void k_g64m_bwd(G64Args a, int inv, const double *__restrict__ theta, const double *__restrict__ x,
                                                   double *gbar, const double *__restrict__ lbar, double lbar_const,
                                                   double *__restrict__ slabs, long Pc, long slab_off, long long *trace) {
@@ -331,9 +332,9 @@ __global__ __launch_bounds__(256) void k_g64m_bwd(G64Args a, int inv, const doub
   double *mya = atiles + wave * G::TILE, *myd = dtiles + wave * G::TILE;
   double *slab = slabs + (long)blockIdx.x * Pc - slab_off;
   const long ntiles = (a.N + 15) / 16, ngroups = (ntiles + 3) / 4;
-  for (int phase = 0; phase < 2; ++phase) {
+  for (int phase = 0; phase < (NSF ? 1 : 2); ++phase) {  // a spline coupling has ONE net
     const bool is_s = inv ? phase == 0 : phase == 1;  // forward coupling: t-net first (it reads ybar1 before the s phase rescales it)
-    const G64Net &net = a.net[is_s ? 0 : 1];
+    const G64Net &net = a.net[NSF ? 0 : (is_s ? 0 : 1)];
     __syncthreads();
     G64M_STAMP(24 * phase + 0);
     g64m_stage_net<G>(img, theta, net, tid);
@@ -361,6 +362,33 @@ __global__ __launch_bounds__(256) void k_g64m_bwd(G64Args a, int inv, const doub
       f64x4 xb[G::MB], a1[G::HB], a2[G::HB], dout[G::CB];
       g64m_load_cond<G::MB>(xr, a.m, par_c, valid, xb, q);
       g64m_net_fwd<G>(img, nhid, xb, a1, a2, dout, c16, q);
+      if constexpr (NSF) {
+        // The net's outputs are the splines' raw parameters, (3K - 1) per transformed dim, consecutive per dim: through the
+        // wave's [sample][feature] tile (the dW stage's operand layout) a lane gets the ones of its (sample, dim) as one
+        // contiguous row -- lane group q takes dims q, q + 4, ... -- and the scalar spline code of the general kernels
+        // (g64_build / g64_spline_bwd, nf_generic64.hip) runs on them unchanged; its parameter cotangents go back the same way.
+        const int P = 3 * a.K - 1;
+        g64m_to_tile<G::CB, G::ST>(myd, dout, c16, q);
+        wave_lds_fence();
+        for (int p = q; p < a.c; p += 4) {
+          double *raw = myd + c16 * G::ST + p * P;
+          double thb[3 * G64_MAXK];
+          for (int i = 0; i < P; ++i) thb[i] = 0.0;
+          if (valid) {
+            G64Spline<double> sp;
+            g64_build<double>(raw, a.K, a.B, sp);
+            const int idx = 2 * p + a.par_t;
+            gr[idx] = g64_spline_bwd<double>(sp, raw, a.K, a.B, xr[idx], gr[idx], lb, thb, inv != 0);
+          }
+          for (int i = 0; i < P; ++i) raw[i] = thb[i];
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dout[b][r] = myd[c16 * G::ST + 16 * b + q + 4 * r];  // (columns past c (3K - 1): zero weights, zero bias: 0)
+        wave_lds_fence();
+      } else {
       // element-wise stage -> cotangent of the net's output (rows beyond c and samples beyond N: 0)
 #pragma unroll
       for (int b = 0; b < G::CB; ++b)
@@ -387,6 +415,7 @@ __global__ __launch_bounds__(256) void k_g64m_bwd(G64Args a, int inv, const doub
           }
           dout[b][r] = dv;
         }
+      }
       G64M_STAMP(gb + 1);
       // ---- output layer
       f64x4 dh[G::HB];
@@ -441,6 +470,53 @@ __global__ __launch_bounds__(256) void k_g64m_bwd(G64Args a, int inv, const doub
   }
 }
 
+// ---- neural spline coupling, forward or inverse: ONE net; its outputs reach the scalar spline code through the wave's tile ----
+template <class G>
+__global__ __launch_bounds__(256) void k_g64m_nsf_apply(G64Args a, int inverse, const double *__restrict__ theta, const double *x, double *y,
+                                                        double *__restrict__ ladj) {
+  extern __shared__ __attribute__((aligned(16))) double lds64[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c16 = lane & 15, q = lane >> 4;
+  const int nhid = a.net[0].nl - 1, par_c = 1 - a.par_t, P = 3 * a.K - 1;
+  const long ntiles = (a.N + 15) / 16;
+  double *mytile = lds64 + G::img_size(nhid) + wave * G::TILE;
+  g64m_stage_net<G>(lds64, theta, a.net[0], tid);
+  __syncthreads();
+  for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+    const long j = tile * 16 + c16;
+    const bool valid = j < a.N;
+    const long jr = valid ? j : a.N - 1;
+    const double *xr = x + jr * a.d;
+    double *yr = y + jr * a.d;
+    f64x4 xb[G::MB], a1[G::HB], a2[G::HB], out[G::CB];
+    g64m_load_cond<G::MB>(xr, a.m, par_c, valid, xb, q);
+    g64m_net_fwd<G>(lds64, nhid, xb, a1, a2, out, c16, q);
+    g64m_to_tile<G::CB, G::ST>(mytile, out, c16, q);
+    wave_lds_fence();
+    double lsum = 0.0;
+    if (valid)
+      for (int p = q; p < a.c; p += 4) {
+        G64Spline<double> sp;
+        g64_build<double>(mytile + c16 * G::ST + p * P, a.K, a.B, sp);
+        const int idx = 2 * p + a.par_t;
+        const double v = xr[idx];
+        yr[idx] = inverse ? g64_spline_inv(sp, a.K, v, lsum) : g64_spline_fwd(sp, a.K, v, lsum);
+      }
+    lsum += __shfl_xor(lsum, 16);
+    lsum += __shfl_xor(lsum, 32);
+    if (q == 0 && valid) ladj[j] += lsum;
+    if (y != x) {
+#pragma unroll
+      for (int b = 0; b < G::MB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = 16 * b + q + 4 * r;
+          if (valid && f < a.m) yr[2 * f + par_c] = xb[b][r];
+        }
+    }
+    wave_lds_fence();  // the next tile's outputs overwrite the tile
+  }
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------------------
 // 0: not a shape of these kernels; otherwise 10 * MB + HB (blocks of 16)
 static int g64m_geo(const nf_flow_desc *desc) {
@@ -458,6 +534,19 @@ using G64M14 = G64M<1, 4>;
 using G64M22 = G64M<2, 2>;
 using G64M24 = G64M<2, 4>;
 #define G64M_DISPATCH(ID, CALL) ((ID) == 12 ? CALL(G64M12) : (ID) == 14 ? CALL(G64M14) : (ID) == 22 ? CALL(G64M22) : CALL(G64M24))
+// Float64 neural spline couplings: conditioner <= 16 inputs, hidden <= 32, (3K - 1) ceil(d / 2) <= 96 net outputs -- the
+// reference's test shape nsf(q0; paramtype = Float64) at d = 5, K = 10, hidden [32, 32] (test/flow.jl:65-78) and its
+// neighbours (d <= 6 at K = 10, d <= 8 at K = 8); wider outputs do not fit the dW stage's tiles next to the image (160 KB).
+using G64MN = G64M<1, 2, 6>;
+static bool g64m_nsf_ok(const nf_flow_desc *desc) {
+  static const bool off = std::getenv("NF_G64_NO_F64_MFMA") != nullptr;
+  if (off || desc->kind != NF_KIND_NSF || desc->dtype != NF_DTYPE_F64) return false;
+  if (desc->n_hidden < 1 || desc->n_hidden > 2 || desc->d < 2 || desc->K < 1 || desc->K > G64_MAXK) return false;
+  for (int i = 0; i < desc->n_hidden; ++i)
+    if (desc->hdims[i] < 1 || desc->hdims[i] > 32) return false;
+  const int cmax = (desc->d + 1) / 2;
+  return cmax <= 16 && cmax * (3 * desc->K - 1) <= 16 * G64MN::CB;
+}
 
 template <class G>
 static int g64m_launch_apply(nf_ctx *ctx, const G64Args &a, int inverse, const double *theta, const double *x, double *y, double *ladj) {
@@ -474,6 +563,33 @@ static int g64m_launch_apply(nf_ctx *ctx, const G64Args &a, int inverse, const d
   long grid = ngroups < per_cu * ctx->num_cu ? ngroups : per_cu * ctx->num_cu;
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL((k_g64m_apply<G>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, inverse, theta, x, y, ladj, (long long *)ctx->trace);
+  return (int)hipGetLastError();
+}
+static int g64m_nsf_launch_apply(nf_ctx *ctx, const G64Args &a, int inverse, const double *theta, const double *x, double *y, double *ladj) {
+  using G = G64MN;
+  const size_t lds = (size_t)(G::img_size(2) + 4 * G::TILE) * 8;
+  static AttrOnce attr_once;
+  NF_TRY(attr_once.run(ctx->device, [&]() -> int {
+    NF_HIP(hipFuncSetAttribute((const void *)k_g64m_nsf_apply<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return NF_OK;
+  }));
+  const long ngroups = ((a.N + 15) / 16 + 3) / 4;
+  long grid = ngroups < (long)ctx->num_cu ? ngroups : (long)ctx->num_cu;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL((k_g64m_nsf_apply<G>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, inverse, theta, x, y, ladj);
+  return (int)hipGetLastError();
+}
+static int g64m_nsf_launch_bwd(nf_ctx *ctx, const G64Args &a, int inv, const double *theta, const double *x, double *gbar, const double *lbar,
+                               double lbar_const, double *slabs, long Pc, long slab_off, unsigned grid) {
+  using G = G64MN;
+  const size_t lds = G::bwd_lds(2);
+  static AttrOnce attr_once;
+  NF_TRY(attr_once.run(ctx->device, [&]() -> int {
+    NF_HIP(hipFuncSetAttribute((const void *)k_g64m_bwd<G, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return NF_OK;
+  }));
+  hipLaunchKernelGGL((k_g64m_bwd<G, true>), dim3(grid), dim3(256), lds, ctx->stream, a, inv, theta, x, gbar, lbar, lbar_const, slabs, Pc, slab_off,
+                     (long long *)ctx->trace);
   return (int)hipGetLastError();
 }
 template <class G>

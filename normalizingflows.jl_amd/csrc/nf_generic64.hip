@@ -1313,6 +1313,10 @@ static int g64_launch_apply(nf_ctx *ctx, const nf_flow_desc *desc, unsigned grid
       return G64M_DISPATCH(gm, G64M_CALL);
 #undef G64M_CALL
     }
+    if (g64m_nsf_ok(desc)) {
+      ProfScope ps(ctx, "g64m_apply");
+      return g64m_nsf_launch_apply(ctx, a, inverse, theta, x, y, ladj);
+    }
   }
   if constexpr (sizeof(T) == 4) {
     if (l64_ok(desc)) {
@@ -1367,6 +1371,15 @@ static int g64_launch_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G6
 #define G64M_CALL(G) g64m_launch_bwd<G>(ctx, a, inv, theta, x, gbar, lbar, lbar_const, slabs, ci.nparams, ci.theta_off, gridm)
         NF_TRY(G64M_DISPATCH(gm, G64M_CALL));
 #undef G64M_CALL
+      }
+      return nf_launch_reduce_slabs(ctx, NF_DTYPE_F64, slabs, (int)gridm, ci.nparams, g + ci.theta_off);
+    }
+    if (g64m_nsf_ok(desc)) {
+      unsigned gridm = g64_bwd_blocks(desc, a.N);
+      if (gridm > (unsigned)ctx->num_cu) gridm = (unsigned)ctx->num_cu;
+      {
+        ProfScope ps(ctx, "g64m_bwd");
+        NF_TRY(g64m_nsf_launch_bwd(ctx, a, inv, theta, x, gbar, lbar, lbar_const, slabs, ci.nparams, ci.theta_off, gridm));
       }
       return nf_launch_reduce_slabs(ctx, NF_DTYPE_F64, slabs, (int)gridm, ci.nparams, g + ci.theta_off);
     }

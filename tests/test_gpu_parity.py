@@ -1581,3 +1581,57 @@ def test_float64_realnvp_on_the_f64_matrix_instruction(nf, d, hd, nl, n):
         ran[name] = c.value
     lib.nf_prof_enable(ctx.ptr, 0)
     assert all(v > 0 for v in ran.values()), ran
+
+
+@pytest.mark.parametrize("d,hd,nl,K,B,n", [
+    (5, (32, 32), 2, 10, 5.0, 1000),  # test/flow.jl:65-78: nsf(q0; paramtype = Float64) -- 87 net outputs
+    (8, (32,), 1, 8, 3.0, 77),        # one hidden layer, 4 dims x 23 parameters = 92 outputs, ragged batch
+    (6, (17, 29), 2, 10, 5.0, 16),    # odd hidden widths, exactly one tile
+    (3, (32, 32), 2, 5, 2.0, 333),    # unequal partitions (2 | 1), K = 5
+])
+def test_float64_nsf_on_the_f64_matrix_instruction(nf, d, hd, nl, K, B, n):
+    """Round 5: Float64 neural spline couplings at the reference's test shape and its neighbours (conditioner <= 16 inputs,
+    hidden <= 32, (3K - 1) ceil(d / 2) <= 96 outputs) run their conditioner on v_mfma_f64_16x16x4_f64 (k_g64m_nsf_apply,
+    k_g64m_bwd<.., NSF>; the spline itself is the general kernels' scalar Float64 code, fed through the wave's LDS tile).
+    Forward, inverse round trip, per-sample ELBO terms, loss / gradient of both draw forms and the forward-KL pair against the
+    float64 oracle at the Float64 tolerances; the kernels that ran are checked by name."""
+    import ctypes as C
+    lib = nf.load_library()
+    flow = nf.nsf(nf.MvNormal(d), list(hd), K, B, nl, paramtype=torch.float64, seed=3)
+    gen = torch.Generator().manual_seed(d)
+    flow = flow.with_theta(flow.theta + 0.05 * torch.randn(flow.P, generator=gen, dtype=torch.float64).to("cuda"))
+    spec = o.FlowSpec("nsf", d, nl, hd, K=K, B=B)
+    th = flow.theta.cpu().numpy()
+    rng = np.random.default_rng(d)
+    mu, var = rng.standard_normal(d), rng.uniform(size=d) + 0.5
+    tgt = nf.DiagGaussTarget(torch.tensor(mu, device="cuda"), torch.tensor(var, device="cuda"))
+    otgt = ("diaggauss", mu, var)
+    xs = nf.device_specific_rand(nf.PhiloxRNG(5), flow.dist, n, dtype=torch.float64)
+    x64 = xs.cpu().numpy()
+    tag = f"f64 mfma nsf d{d} h{hd} x{nl} K{K}"
+    ctx = flow.ctx
+    lib.nf_prof_enable(ctx.ptr, 2)
+    ys, ladj = nf.with_logabsdet_jacobian(flow.transform, xs)
+    y_ref, l_ref = o.flow_fwd(spec, th, x64)
+    P.elementwise(f"{tag}: ys", ys, y_ref, P.F64_RTOL, 1e-12)
+    P.elementwise(f"{tag}: ladj", ladj, l_ref, P.F64_RTOL, 1e-12)
+    xr, lb = nf.with_logabsdet_jacobian(nf.inverse(flow.transform), ys)
+    P.isapprox(f"{tag}: round trip", xr, x64, P.F64_GRAD)
+    P.isapprox(f"{tag}: lj_fwd ~ -lj_bwd", lb, -ladj, P.F64_GRAD)
+    P.elementwise(f"{tag}: elbos", nf.batched_elbos(flow, tgt, xs), o.batched_elbos(spec, th, otgt, x64), P.F64_RTOL, 1e-12)
+    lo, go = o.neg_elbo_value_and_grad(spec, th, otgt, x64)
+    for form, arg in (("rng", n), ("xs", xs)):
+        loss, g = nf.value_and_gradient(nf.elbo_batch, flow, tgt, arg, rng=nf.PhiloxRNG(5))
+        P.scalar(f"{tag} ({form}): step loss", loss, lo, P.F64_RTOL)
+        P.gradient(f"{tag} ({form}): step grad", g, go, P.F64_GRAD)
+    lk, gk = nf.loglikelihood_value_and_gradient(flow, ys)
+    lkr, gkr = o.neg_loglik_value_and_grad(spec, th, ys.cpu().numpy())
+    P.scalar(f"{tag}: forward-KL loss", lk, lkr, 10 * P.F64_RTOL)
+    P.gradient(f"{tag}: forward-KL grad", gk, gkr, 10 * P.F64_GRAD)
+    ran = {}
+    for name in (b"g64m_apply", b"g64m_bwd"):
+        a, c = C.c_double(0.0), C.c_int64(0)
+        lib.nf_prof_read(ctx.ptr, name, C.byref(a), C.byref(c))
+        ran[name] = c.value
+    lib.nf_prof_enable(ctx.ptr, 0)
+    assert all(v > 0 for v in ran.values()), ran
