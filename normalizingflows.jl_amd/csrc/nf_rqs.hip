@@ -1676,6 +1676,14 @@ __device__ __forceinline__ void rqs_bwd_coop6_coupling(const RqsBwdArgs &a, floa
   using L = RqsCoop6Lds<G>;
   using B = RqsB6Geo<G>;
   const int tid = threadIdx.x;
+#ifdef NF_KERNEL_TRACE  // tools/trace_rqs6.py: workgroup 0 / wave 0: [0] start, [1] prologue done, [2 + 12 g ..] group g: home forward done (B0), then per
+                        // tile t the chunk phase's end (B1) and the d2 sum's end, closing home phase done; [60] groups done, [61] folded, [62] slab written
+  long long *tr6 = (a.trace && blockIdx.x == 0 && tid == 0) ? a.trace : nullptr;
+#define C6_STAMP(slot) do { if (tr6) { __builtin_amdgcn_sched_barrier(0); tr6[slot] = clock64(); } } while (0)
+#else
+#define C6_STAMP(slot) do { } while (0)
+#endif
+  C6_STAMP(0);
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
   char *wv = lds + wave * L::WAVE_BYTES;                                   // this wave's region
@@ -1712,6 +1720,8 @@ __device__ __forceinline__ void rqs_bwd_coop6_coupling(const RqsBwdArgs &a, floa
         for (int c = 0; c < 3; ++c) W.t[kg][ib][c] = wt[((kg * 3 + c) * 2) * B::TROWS + ib * 32];
   }
   __syncthreads();
+  C6_STAMP(1);
+  int gcount6 = 0;
   RqsCoopAcc<G> acc;
   rqs_zero(acc.w1, acc.b1);
   rqs_zero(acc.w2, acc.b2);
@@ -1770,6 +1780,10 @@ __device__ __forceinline__ void rqs_bwd_coop6_coupling(const RqsBwdArgs &a, floa
       split_to_lds<G::H2B>(wv + L::A2T, s2, l31, hi);
     }
     __syncthreads();  // B0: every home tile's a2 triples are in LDS
+    const int gb6 = 2 + 12 * (gcount6 < 4 ? gcount6 : 3);
+    ++gcount6;
+    (void)gb6;
+    C6_STAMP(gb6 + 0);
 
     // ---------------- chunk phase ----------------
     f32x16 d2[G::H2B];
@@ -1934,6 +1948,7 @@ __device__ __forceinline__ void rqs_bwd_coop6_coupling(const RqsBwdArgs &a, floa
         }
       }
       __syncthreads();  // B1: the four partial d2 of tile t are in the slots (set t & 1)
+      C6_STAMP(gb6 + 1 + 2 * t);
       if (tlive && t == wave) {
         const float *set = slots + (t & 1) * 4 * L::SLOT;
 #pragma unroll
@@ -1943,6 +1958,7 @@ __device__ __forceinline__ void rqs_bwd_coop6_coupling(const RqsBwdArgs &a, floa
 #pragma unroll
             for (int r = 0; r < 16; ++r) d2[b][r] += set[w * L::SLOT + (b * 16 + r) * 64 + lane];
       }
+      C6_STAMP(gb6 + 2 + 2 * t);
     }
 
     // ---------------- home phase: layers 2 and 1 of this wave's own tile ----------------
@@ -1983,25 +1999,41 @@ __device__ __forceinline__ void rqs_bwd_coop6_coupling(const RqsBwdArgs &a, floa
 #pragma unroll
         for (int r = 0; r < 16; ++r) tile_store(gio, tile_soff(b, r, par_c), g2[b][r]);
     }
+    C6_STAMP(gb6 + 9);
   }
   __syncthreads();  // every working area is dead: the LDS becomes the fold target (the slab image, G's fp32 layout)
+  C6_STAMP(60);
+  // Layers 1-2: every wave leaves its own sums in its own copy of the image's first G::W3 floats (behind the slab image), and
+  // the slab write adds the four copies in wave order -- ((w0 + w1) + w2) + w3, the association of the waves-in-turn fold this
+  // replaces (round 5, tools/trace_rqs6.py: that fold and its four barriers were 6.5 k of a launch's 247 k clocks).  The
+  // output layer's chunk belongs to this wave alone.
   float *fold = reinterpret_cast<float *>(lds);
-#pragma unroll 1
-  for (int w = 0; w < 4; ++w) {
-    if (wave == w) {
-      rqs_fold<G::MB, G::H1B, G::S1>(fold + G::W1, fold + G::B1, acc.w1, acc.b1, w == 0, l31, hi);
-      rqs_fold<G::H1B, G::H2B, G::S2>(fold + G::W2, fold + G::B2, acc.w2, acc.b2, w == 0, l31, hi);
-    }
-    __syncthreads();
+  static_assert(((size_t)G::SIZE + 4 * (size_t)G::W3) * 4 <= L::BYTES && G::W3 % 4 == 0, "the four partial images fit behind the slab image");
+  {
+    float *mine = fold + G::SIZE + wave * G::W3;
+    rqs_fold<G::MB, G::H1B, G::S1>(mine + G::W1, mine + G::B1, acc.w1, acc.b1, true, l31, hi);
+    rqs_fold<G::H1B, G::H2B, G::S2>(mine + G::W2, mine + G::B2, acc.w2, acc.b2, true, l31, hi);
   }
   rqs_fold<G::H2B, G::OBC, G::S3>(fold + G::W3 + ch * G::OBC * 32, fold + G::B3 + ch * G::OBC * 32, acc.w3, acc.b3, true, l31, hi);
   __syncthreads();
+  C6_STAMP(61);
   {
-    const float4 *c0 = reinterpret_cast<const float4 *>(fold);
+    const float4 *c0 = reinterpret_cast<const float4 *>(fold), *p0 = reinterpret_cast<const float4 *>(fold + G::SIZE);
     float4 *dst = reinterpret_cast<float4 *>(slab + (long)blockIdx.x * slab_stride);
-    for (int i = tid; i < G::SIZE / 4; i += 256) dst[i] = c0[i];
+    constexpr int Q = G::W3 / 4;
+    for (int i = tid; i < G::SIZE / 4; i += 256) {
+      float4 v;
+      if (i < Q) {
+        const float4 u0 = p0[i], u1 = p0[Q + i], u2 = p0[2 * Q + i], u3 = p0[3 * Q + i];
+        v = float4{((u0.x + u1.x) + u2.x) + u3.x, ((u0.y + u1.y) + u2.y) + u3.y, ((u0.z + u1.z) + u2.z) + u3.z, ((u0.w + u1.w) + u2.w) + u3.w};
+      } else {
+        v = c0[i];
+      }
+      dst[i] = v;
+    }
   }
   __syncthreads();
+  C6_STAMP(62);
 }
 
 template <class G, bool INVD>
