@@ -508,6 +508,7 @@ struct RqsChainArgs {
   int k_only;  // -1: every coupling; otherwise only the coupling with this flat index
   float B;
   long N;
+  long long *trace;  // NF_KERNEL_TRACE builds: clock stamps for tools/trace_rqs_chain.py ([64 + 28 g ..], g = the workgroup's first two tile groups)
 };
 
 // tape: buffer descriptor of this (tile, coupling)'s slot of the spline tape; extent 0 (no tape wanted, or an idle wave)
@@ -682,6 +683,12 @@ __global__ __launch_bounds__(512) void k_rqs_chain(RqsChainArgs a, float *xt, fl
   const int c_odd = (a.d + 1) / 2, c_even = a.d / 2;  // mask 1:2:d / 2:2:d
   int buf = 0;
   for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+#ifdef NF_KERNEL_TRACE
+    if (a.trace && blockIdx.x == 0 && tid == 0 && (grp - blockIdx.x) / gridDim.x < 2) {
+      __builtin_amdgcn_sched_barrier(0);
+      a.trace[64 + 28 * (int)((grp - blockIdx.x) / gridDim.x)] = clock64();
+    }
+#endif
     const long tile = grp * 8 + wave;
     const bool live = tile < ntiles;
     const long tl = live ? tile : 0;
@@ -730,6 +737,14 @@ __global__ __launch_bounds__(512) void k_rqs_chain(RqsChainArgs a, float *xt, fl
     }
     float lsum = 0.f;
     const bool more_groups = grp + gridDim.x < ngroups;
+#ifdef NF_KERNEL_TRACE
+    const int gidx = (int)((grp - blockIdx.x) / gridDim.x);
+    long long *trc = (a.trace && blockIdx.x == 0 && tid == 0 && gidx < 2) ? a.trace + 64 + 28 * gidx : nullptr;
+#define RC_STAMP(slot) do { if (trc) { __builtin_amdgcn_sched_barrier(0); trc[slot] = clock64(); } } while (0)
+#else
+#define RC_STAMP(slot) do { } while (0)
+#endif
+    RC_STAMP(1);  // (the draws are done; [0] is stamped at the group's top)
 #pragma unroll 1
     for (int s = 0; s < a.ncoup; s += 2) {
 #pragma unroll
@@ -753,10 +768,13 @@ __global__ __launch_bounds__(512) void k_rqs_chain(RqsChainArgs a, float *xt, fl
           else
             lsum += rqs_coupling_step<G, INVERSE, B6>(img, E, O, c_odd, a.d - c_odd, a.B, l31, hi, tp, reinterpret_cast<const nf_u32x4 *>(t6));
         }
+        if (pos < 8) RC_STAMP(2 + 3 * pos);
         __syncthreads();
+        if (pos < 8) RC_STAMP(3 + 3 * pos);
         if constexpr (B6) {  // every wave is done with this coupling's triples: the next coupling's may come
           if (have_next) dma(t6, a.wimg6 + (long)knext * RqsB6Geo<G>::U4, CL::F_U4 * 16);
         }
+        if (pos < 8) RC_STAMP(4 + 3 * pos);
         buf ^= 1;
       }
     }
@@ -809,6 +827,7 @@ __global__ __launch_bounds__(512) void k_rqs_chain(RqsChainArgs a, float *xt, fl
       }
       __syncthreads();
     }
+    RC_STAMP(27);
   }
   if (FUSED && tid == 0) fa.partial[blockIdx.x] = wg_total;
 }
@@ -2174,6 +2193,7 @@ static int launch_rqs_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse,
   a.wimg = (const float *)ctx->wimg;
   a.wimg6 = nullptr;
   a.d = desc->d; a.ncoup = 2 * desc->nlayers; a.B = desc->B; a.N = N; a.k_only = k_only;
+  a.trace = (long long *)ctx->trace;
   const long ngroups = ((N + NF_TILE - 1) / NF_TILE + 7) / 8;
   long grid = ngroups < ctx->num_cu ? ngroups : ctx->num_cu;
   if (grid < 1) grid = 1;
