@@ -992,21 +992,23 @@ __device__ __forceinline__ void l64_load_par(const L64Raw &raw, int K, L64Par<KM
     q.dv[i] = i < K - 1 ? raw(2 * K + i) : 0.f;
   }
 }
+// v <- exp(v - max) in place, inv <- 1 / their sum: every later pass (bin search, knots, cotangents) multiplies these by inv
+// instead of evaluating the exponentials again (round 5: 48 -> 16 expf per dimension in the reverse pass; the same values)
 template <int KM>
-__device__ __forceinline__ void l64_softmax_stats(const float (&v)[KM], int K, float &mx, float &inv) {
-  mx = v[0];
+__device__ __forceinline__ void l64_softmax_exp(float (&v)[KM], int K, float &inv) {
+  float mx = v[0];
 #pragma unroll
   for (int i = 1; i < KM; ++i)
     if (i < K) mx = fmaxf(mx, v[i]);
   float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < KM; ++i)
-    if (i < K) sum += expf(v[i] - mx);
+    if (i < K) { v[i] = expf(v[i] - mx); sum += v[i]; }
   inv = 1.f / sum;
 }
 // the bin of v among the knots p[j] = -B + 2B cumsum(sm)[j] (g64_bin: the count of interior knots <= v)
 template <int KM>
-__device__ __forceinline__ L64Bin l64_find(const float (&r)[KM], int K, float B, float mx, float inv, float v) {
+__device__ __forceinline__ L64Bin l64_find(const float (&r)[KM], int K, float B, float inv, float v) {
   L64Bin b{-1, 0.f, 0.f, 0.f};
   float cs = 0.f, left = -B;
   int k = 0;
@@ -1014,7 +1016,7 @@ __device__ __forceinline__ L64Bin l64_find(const float (&r)[KM], int K, float B,
 #pragma unroll
   for (int i = 0; i < KM; ++i)
     if (i < K) {
-      const float sm = expf(r[i] - mx) * inv;
+      const float sm = r[i] * inv;
       cs += sm;
       const float right = -B + 2.f * B * cs;
       // bin i holds v when i is the number of interior knots (p[1] .. p[K-1]) that are <= v
@@ -1028,14 +1030,13 @@ __device__ __forceinline__ L64Bin l64_find(const float (&r)[KM], int K, float B,
 }
 // knots k, k + 1 of the OTHER axis for a known bin
 template <int KM>
-__device__ __forceinline__ void l64_knots_at(const float (&r)[KM], int K, float B, float mx, float inv, int k, float &y0, float &y1,
-                                             float &smk) {
+__device__ __forceinline__ void l64_knots_at(const float (&r)[KM], int K, float B, float inv, int k, float &y0, float &y1, float &smk) {
   float cs = 0.f;
   y0 = -B; y1 = -B; smk = 0.f;
 #pragma unroll
   for (int i = 0; i < KM; ++i)
     if (i < K) {
-      const float sm = expf(r[i] - mx) * inv;
+      const float sm = r[i] * inv;
       if (i == k) { y0 = -B + 2.f * B * cs; smk = sm; }
       if (i <= k) cs += sm;
     }
@@ -1061,21 +1062,21 @@ template <int KM>
 __device__ __forceinline__ float l64_spline_apply(const L64Raw &raw, int K, float B, float v, bool inverse, float &logd) {
   L64Par<KM> q;
   l64_load_par<KM>(raw, K, q);
-  float mxw, invw, mxh, invh;
-  l64_softmax_stats<KM>(q.w, K, mxw, invw);
-  l64_softmax_stats<KM>(q.h, K, mxh, invh);
+  float invw, invh;
+  l64_softmax_exp<KM>(q.w, K, invw);
+  l64_softmax_exp<KM>(q.h, K, invh);
   float x0, x1, y0, y1, dummy;
   int k;
   if (!inverse) {
-    const L64Bin b = l64_find<KM>(q.w, K, B, mxw, invw, v);
+    const L64Bin b = l64_find<KM>(q.w, K, B, invw, v);
     if (b.k < 0) return v;
     k = b.k; x0 = b.x0; x1 = b.x1;
-    l64_knots_at<KM>(q.h, K, B, mxh, invh, k, y0, y1, dummy);
+    l64_knots_at<KM>(q.h, K, B, invh, k, y0, y1, dummy);
   } else {
-    const L64Bin b = l64_find<KM>(q.h, K, B, mxh, invh, v);
+    const L64Bin b = l64_find<KM>(q.h, K, B, invh, v);
     if (b.k < 0) return v;
     k = b.k; y0 = b.x0; y1 = b.x1;
-    l64_knots_at<KM>(q.w, K, B, mxw, invw, k, x0, x1, dummy);
+    l64_knots_at<KM>(q.w, K, B, invw, k, x0, x1, dummy);
   }
   float r0, r1;
   l64_dv_at<KM>(q.dv, k, r0, r1);
@@ -1095,15 +1096,15 @@ __device__ __forceinline__ float l64_spline_apply(const L64Raw &raw, int K, floa
 }
 // reverse pass at x (g64_spline_bwd's algebra); writes the 3K - 1 parameter cotangents to out (tile rows, stride 32) and
 // returns xbar (inv: the cotangent of the inverse's input, see g64_spline_bwd)
-template <int KM>
-__device__ __forceinline__ float l64_spline_bwd(const L64Raw &raw, const L64Raw &out, int K, float B, float x, float ybar, float lbar,
+template <int KM, class Out = L64Raw>
+__device__ __forceinline__ float l64_spline_bwd(const L64Raw &raw, const Out &out, int K, float B, float x, float ybar, float lbar,
                                                 bool inv) {
   L64Par<KM> q;
   l64_load_par<KM>(raw, K, q);
-  float mxw, invw, mxh, invh;
-  l64_softmax_stats<KM>(q.w, K, mxw, invw);
-  l64_softmax_stats<KM>(q.h, K, mxh, invh);
-  const L64Bin b = l64_find<KM>(q.w, K, B, mxw, invw, x);
+  float invw, invh;
+  l64_softmax_exp<KM>(q.w, K, invw);
+  l64_softmax_exp<KM>(q.h, K, invh);
+  const L64Bin b = l64_find<KM>(q.w, K, B, invw, x);
   if (b.k < 0) {
 #pragma unroll
     for (int i = 0; i < KM; ++i) {
@@ -1114,7 +1115,7 @@ __device__ __forceinline__ float l64_spline_bwd(const L64Raw &raw, const L64Raw 
   }
   const int k = b.k;
   float y0, y1, smh_k;
-  l64_knots_at<KM>(q.h, K, B, mxh, invh, k, y0, y1, smh_k);
+  l64_knots_at<KM>(q.h, K, B, invh, k, y0, y1, smh_k);
   float r0, r1;
   l64_dv_at<KM>(q.dv, k, r0, r1);
   const float d0 = k >= 1 ? l64_softplus(r0) : 1.f, d1 = k + 1 <= K - 1 ? l64_softplus(r1) : 1.f;
@@ -1148,18 +1149,15 @@ __device__ __forceinline__ float l64_spline_bwd(const L64Raw &raw, const L64Raw 
 #pragma unroll
   for (int i = 0; i < KM; ++i)
     if (i < K) {
-      const float smw = expf(q.w[i] - mxw) * invw, smh = expf(q.h[i] - mxh) * invh;
+      const float smw = q.w[i] * invw, smh = q.h[i] * invh;
       out.put(i, smw * ((i < k ? aw : i == k ? bw : 0.f) - dotw));
       out.put(K + i, smh * ((i < k ? ah : i == k ? bh : 0.f) - doth));
     }
+  // (r0, r1 are q.dv[k - 1], q.dv[k]: two sigmoids, not one per unrolled comparison)
+  const float t0 = d0bar * l64_sigmoid(r0), t1 = d1bar * l64_sigmoid(r1);
 #pragma unroll
   for (int i = 0; i < KM; ++i)
-    if (i < K - 1) {
-      float t = 0.f;
-      if (i == k - 1) t = d0bar * l64_sigmoid(q.dv[i]);
-      if (i == k) t = d1bar * l64_sigmoid(q.dv[i]);
-      out.put(2 * K + i, t);
-    }
+    if (i < K - 1) out.put(2 * K + i, i == k ? t1 : i == k - 1 ? t0 : 0.f);
   return inv ? vbar : xibar / dx;
 }
 
@@ -1244,6 +1242,222 @@ __global__ __launch_bounds__(256) void k_l64_couple_bwd(G64Args a, int inv, cons
       gr[2 * p + a.par_t] = l64_spline_bwd<KM>(raw, out, a.K, (float)a.B, xr[2 * p + a.par_t], gr[2 * p + a.par_t], lb, inv != 0);
     }
   }
+}
+
+// The reverse pass of a spline coupling's OUTPUT layer in one kernel (round 5).  As separate launches the (3K - 1) c parameter
+// cotangents of every sample -- 368 floats at the docstring shape nsf(q0, [64, 64], 8, 3.0, 6), 193 MB per coupling at
+// N = 131 072 -- were written by k_l64_couple_bwd and read back twice (k_l64_dw_cols, k_l64_bwdx_all): three of the coupling's
+// six passes over a buffer of that size.  Here a workgroup of eight waves takes one 32-sample tile at a time:
+//   spline stage: every thread is one (sample, dimension): the spline's reverse (l64_spline_bwd, unchanged) with its 3K - 1
+//      cotangents written to an LDS tile [parameter row][sample] -- the layout dw_accumulate reads;
+//   matrix stage: waves 0-3: dW += a' delta for their 96 of the 384 columns (as k_l64_dw_cols: disjoint columns, no fold);
+//      waves 4-7: the same 96 columns' part of the input cotangent, W[:, cols] delta, with the weight slice held in
+//      REGISTERS (96 per lane: the 98 KB layer does not fit LDS beside the tiles) -- one dW and one dX wave per SIMD, 96
+//      fp32 matrix instructions each per tile;
+//   the four partial input cotangents are summed through LDS in a fixed order and stored as the tile the next layer's
+//      kernels read.
+// The stages of consecutive tiles overlap: between two barriers a dW wave runs [matrix stage of tile t, spline stage of
+// tile t + 1] and the dX wave on the same SIMD [spline stage of t + 1, matrix stage of t] -- one wave's matrix instructions
+// run under the other's spline arithmetic (tools/trace_l64_top.py: back to back the two stages took 16-19 k + 13 k clocks
+// per tile, the matrix pipe's own 12.3 k being the floor).  Hence two delta / activation tiles in LDS.
+// The two roles share one register array (accumulators / weight slice): as two arrays both would be live in every wave.
+// Needs nin <= 64, (3K - 1) c <= 384, c <= 16 (one dimension per thread); other shapes keep the three launches.
+// after each matrix instruction of the matrix stages: the wave idles for most of the instruction's 64 clocks instead of
+// presenting the next one at once -- a matrix instruction that waits for the pipe waits in the SIMD's vector issue stage, and
+// the other wave's spline arithmetic waits behind it (measured: its loads, requested at the start of the interval, were
+// consumed only when the matrix stage of the wave beside it had ended)
+struct L64Pace {
+  __device__ __forceinline__ void operator()(int) const {
+#ifndef NF_L64_NO_PACE
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 11" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+  }
+};
+struct L64LdsOut {
+  float *p;  // row 0 of this (dimension, sample) in the LDS tile
+  __device__ __forceinline__ void put(int i, float v) const { p[i * NF_TS] = v; }
+};
+#define L64_TOP_ROWS 384
+#define L64_TOP_LDS ((2 * L64_TOP_ROWS + 2 * 64 + 4 * 64) * NF_TS * 4)
+template <int KM>
+__global__ __launch_bounds__(512) void k_l64_nsf_top_bwd(G64Args a, int inv, const float *__restrict__ theta, L64Layer L,
+                                                         const float *__restrict__ os, int Fs, const float *__restrict__ hact, int Fh,
+                                                         const float *__restrict__ x, float *gbar, const float *__restrict__ lbar,
+                                                         float lbar_const, float *__restrict__ gdst, int Fd, float *__restrict__ slabs,
+                                                         long Pc, long slab_off, long long *trace) {
+#ifdef NF_KERNEL_TRACE  // tools/trace_l64_top.py: wave 0 (a dW wave) at [0 ...], wave 4 (a dX wave) at [64 ...] of workgroup 0
+  long long *tr = trace && blockIdx.x == 0 && (threadIdx.x & 255) == 0 ? trace + (threadIdx.x >> 8) * 64 : nullptr;
+#define L64T_STAMP(slot) do { if (tr) { __builtin_amdgcn_sched_barrier(0); tr[slot] = clock64(); } } while (0)
+#else
+#define L64T_STAMP(slot) do { } while (0)
+#endif
+  constexpr int SD = L64_TOP_ROWS * NF_TS, SA = 64 * NF_TS, WS = L64_TOP_ROWS + 1;
+  static_assert(64 * WS <= 2 * SD, "the prologue stages the whole layer in the two delta tiles");
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float *sdt = sm, *sat = sm + 2 * SD, *red = sat + 2 * SA;  // 2 delta tiles, 2 activation tiles, 4 partial cotangents
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int smp = tid & 31, dl = tid >> 5;
+  const bool dxw = wave >= 4;
+  const int o0w = 96 * (wave & 3);
+  L64T_STAMP(0);
+  // the layer through LDS (coalesced rows, sixteen requests per thread in flight), then each dX wave's slice into registers
+  {
+    constexpr int NE = 64 * L64_TOP_ROWS, U = 16;
+#pragma unroll 1
+    for (int e0 = tid; e0 < NE; e0 += 512 * U) {
+      float v[U];
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        const int e = e0 + 512 * k, i = e / L64_TOP_ROWS, o = e - i * L64_TOP_ROWS;
+        v[k] = (i < L.nin && o < L.nout) ? theta[L.w_off + (long)i * L.nout + o] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        const int e = e0 + 512 * k, i = e / L64_TOP_ROWS, o = e - i * L64_TOP_ROWS;
+        sm[i * WS + o] = v[k];
+      }
+    }
+  }
+  __syncthreads();
+  f32x16 R[2][3];  // dW waves: acc[ib][ob]; dX waves: W[32 ib + l31][o0w + 8 g + 4 hi + e] at flat index (ib * 12 + g) * 4 + e
+  float bsum[3] = {0.f, 0.f, 0.f};
+  if (dxw) {
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int g = 0; g < 12; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int f = (ib * 12 + g) * 4 + e;
+          R[f / 48][(f / 16) % 3][f % 16] = sm[(32 * ib + l31) * WS + o0w + 8 * g + 4 * hi + e];
+        }
+  } else {
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int ob = 0; ob < 3; ++ob)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) R[ib][ob][r] = 0.f;
+  }
+  __syncthreads();
+  const int P = 3 * a.K - 1, rows = P * a.c;
+  const long ntiles = (a.N + L64_TILE - 1) / L64_TILE;
+  L64T_STAMP(1);
+  int tslot = 2;
+  long tile = -1, nxt = blockIdx.x;
+  int cur = 0;  // the buffers of `tile`; the spline stage of `nxt` fills the other pair
+  for (;;) {
+    const bool have = tile >= 0, more = nxt < ntiles;  // workgroup-uniform
+    if (!have && !more) break;
+    float *sd = sdt + cur * SD, *sa = sat + cur * SA;
+    L64T_STAMP(tslot + 0);
+    if (have && !dxw) dw_accumulate<2, 3>(sa, sd + o0w * NF_TS, R, bsum, l31, hi, L64Pace());
+    L64T_STAMP(tslot + 1);
+    if (more) {
+      float *sdn = sdt + (cur ^ 1) * SD, *san = sat + (cur ^ 1) * SA;
+      const long j = nxt * L64_TILE + smp;
+      const bool valid = j < a.N;
+      // the activation tile: requested first, placed after the spline arithmetic
+      float av[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = tid + 512 * q, row = e >> 5;
+        av[q] = row < Fh ? hact[(nxt * Fh + row) * L64_TILE + (e & 31)] : 0.f;
+      }
+      // rows past the parameters (and every row of a padding sample) sit on the contraction axes: zero
+      for (int p = (valid ? rows : 0) + dl; p < L64_TOP_ROWS; p += 16) sdn[p * NF_TS + smp] = 0.f;
+      if (valid) {
+        const float *xr = x + j * a.d;
+        float *gr = gbar + j * a.d;
+        const float lb = lbar ? lbar[j] : lbar_const;
+        for (int p = dl; p < a.c; p += 16) {
+          const L64Raw raw = l64_raw(os, Fs, nxt, p * P, smp);
+#ifdef NF_KERNEL_TRACE  // (interval 1 only) [56]: the tile's loads have arrived -- a probe load and a full wait, trace builds only
+          if (tslot == 8) {
+            float probe = raw(0) + xr[2 * p + a.par_t] + gr[2 * p + a.par_t];
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(probe)::"memory");
+            L64T_STAMP(56);
+            if (probe == 1.2345e-30f) sdn[0] = probe;
+          }
+#endif
+          const L64LdsOut out{sdn + p * P * NF_TS + smp};
+          gr[2 * p + a.par_t] = l64_spline_bwd<KM>(raw, out, a.K, (float)a.B, xr[2 * p + a.par_t], gr[2 * p + a.par_t], lb, inv != 0);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = tid + 512 * q;
+        san[(e >> 5) * NF_TS + (e & 31)] = av[q];
+      }
+    }
+    L64T_STAMP(tslot + 2);
+    if (have && dxw) {
+      f32x16 dlr[3], din[2];
+#pragma unroll
+      for (int ob = 0; ob < 3; ++ob)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dlr[ob][r] = sd[(o0w + 32 * ob + nf_row(r, hi)) * NF_TS + l31];
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) din[ib][r] = 0.f;
+#pragma unroll
+      for (int g = 0; g < 12; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int ib = 0; ib < 2; ++ib) {
+            const int f = (ib * 12 + g) * 4 + e;
+            din[ib] = __builtin_amdgcn_mfma_f32_32x32x2f32(R[f / 48][(f / 16) % 3][f % 16], dlr[g / 4][(g % 4) * 4 + e], din[ib], 0, 0, 0);
+            L64Pace()(0);
+          }
+      float *mine = red + (wave & 3) * SA;
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[(32 * ib + nf_row(r, hi)) * NF_TS + l31] = din[ib][r];
+    }
+    L64T_STAMP(tslot + 3);
+    __syncthreads();
+    L64T_STAMP(tslot + 4);
+    if (have) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = tid + 512 * q, row = e >> 5, at = row * NF_TS + (e & 31);
+        const float v = ((red[at] + red[SA + at]) + red[2 * SA + at]) + red[3 * SA + at];
+        if (row < Fd) gdst[(tile * Fd + row) * L64_TILE + (e & 31)] = v;
+      }
+    }
+    __syncthreads();  // `red` is read before the next interval's dX waves write it
+    L64T_STAMP(tslot + 5);
+    if (tslot < 50) tslot += 6;
+    if (!more) break;
+    tile = nxt;
+    nxt += gridDim.x;
+    cur ^= 1;
+  }
+  L64T_STAMP(62);
+  if (!dxw) {
+    float *slab = slabs + (long)blockIdx.x * Pc - slab_off;
+#pragma unroll
+    for (int ob = 0; ob < 3; ++ob) {
+      const int o = o0w + 32 * ob + l31;
+      if (o < L.nout) {
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int i = 32 * ib + nf_row(r, hi);
+            if (i < L.nin) slab[L.w_off + (long)i * L.nout + o] = R[ib][ob][r];
+          }
+      }
+      const float v = bsum[ob] + __shfl_xor(bsum[ob], 32);
+      if (hi == 0 && o < L.nout) slab[L.b_off + o] = v;
+    }
+  }
+  L64T_STAMP(63);
 }
 
 // ---- host side --------------------------------------------------------------------------------
@@ -1638,7 +1852,29 @@ static int l64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &
   // kept: the forward of this very pass (g64_forward_keep) left this coupling's layer outputs in its slot
   if (!kept) NF_TRY(l64_nets_fwd(ctx, desc, a, theta, x, b));
   const int last = b.nl - 1;
-  {
+  const unsigned grid = l64_grid(ctx, a.N, 4L * ctx->num_cu);
+  unsigned gridw = l64_grid(ctx, a.N, (long)g64_bwd_blocks(desc, a.N));
+  // a spline coupling's output layer: the spline's reverse, dW and the input cotangent in one kernel (k_l64_nsf_top_bwd)
+  static const bool no_top = std::getenv("NF_L64_NO_TOP_FUSE") != nullptr;  // A/B switch: the three launches
+  const bool top_fused = !no_top && a.kind == NF_KIND_NSF && last >= 1 && a.K <= 8 && a.c <= 16 && a.net[0].dims[last] <= 64 &&
+                         a.net[0].dims[last + 1] <= L64_TOP_ROWS;
+  if (top_fused) {
+    // two workgroups per CU's worth of slabs: the fused kernel stages the whole layer per workgroup and writes a 96 KB slab
+    // (the coupling's other dW kernels share the count)
+    if (gridw > 2u * (unsigned)ctx->num_cu) gridw = 2u * (unsigned)ctx->num_cu;
+    const G64Net &net = a.net[0];
+    const L64Layer L{net.w[last], net.b[last], net.dims[last], net.dims[last + 1], 0};
+    static AttrOnce attr_once;
+    NF_TRY(attr_once.run(ctx->device, [&]() -> int {
+      NF_HIP(hipFuncSetAttribute((const void *)k_l64_nsf_top_bwd<8>, hipFuncAttributeMaxDynamicSharedMemorySize, L64_TOP_LDS));
+      return NF_OK;
+    }));
+    ProfScope ps(ctx, "l64_top_bwd");
+    hipLaunchKernelGGL(k_l64_nsf_top_bwd<8>, dim3(gridw), dim3(512), L64_TOP_LDS, ctx->stream, a, inv, theta, L, (const float *)b.act[0][last],
+                       b.F[last], (const float *)b.act[0][last - 1], b.F[last - 1], x, gbar, lbar, lbar_const, b.gh[0][last - 1], b.GH, slabs,
+                       (long)ci.nparams, (long)ci.theta_off, (long long *)ctx->trace);
+    NF_HIP(hipGetLastError());
+  } else {
     ProfScope ps(ctx, "l64_couple");
     if (a.K <= 8)
       hipLaunchKernelGGL(k_l64_couple_bwd<8>, dim3((unsigned)((a.N + 31) / 32)), dim3(256), 0, ctx->stream, a, inv,
@@ -1648,8 +1884,6 @@ static int l64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &
                          (const float *)b.act[0][last], b.F[last], x, gbar, lbar, lbar_const, b.dout[0], b.dout[b.nets - 1], b.F[last]);
     NF_HIP(hipGetLastError());
   }
-  const unsigned grid = l64_grid(ctx, a.N, 4L * ctx->num_cu);
-  const unsigned gridw = l64_grid(ctx, a.N, (long)g64_bwd_blocks(desc, a.N));
   const int nym = l64_nets_merge(a, b);
   for (int n = 0; n < b.nets; n += nym) {
     const G64Net &net = a.net[n];
@@ -1657,8 +1891,9 @@ static int l64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &
     int ct = 0;
     static const bool no_bchain = std::getenv("NF_L64_NO_BWDX_CHAIN") != nullptr;  // A/B switch
     while (ct + 1 < net.nl && net.dims[ct + 1] <= 64 && net.dims[ct + 2] <= 64) ++ct;
+    if (top_fused && ct == net.nl - 1) --ct;  // the output layer's input cotangent is already there
     if (ct < 2 || no_bchain) ct = 0;
-    for (int l = net.nl - 1; l >= 0; --l) {
+    for (int l = net.nl - 1 - (top_fused ? 1 : 0); l >= 0; --l) {
       const int nin = net.dims[l], nout = net.dims[l + 1];
       const int IB = l64_ibp(nin), blocks = (nout + 31) / 32;
       // delta of this layer's outputs: the net output's cotangent as is; a hidden layer's through leaky-ReLU'
