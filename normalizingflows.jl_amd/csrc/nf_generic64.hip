@@ -983,8 +983,8 @@ template <int KM>
 struct L64Par {
   float w[KM], h[KM], dv[KM];  // widths, heights, interior derivatives (K - 1 of them) as the net wrote them
 };
-template <int KM>
-__device__ __forceinline__ void l64_load_par(const L64Raw &raw, int K, L64Par<KM> &q) {
+template <int KM, class Raw>
+__device__ __forceinline__ void l64_load_par(const Raw &raw, int K, L64Par<KM> &q) {
 #pragma unroll
   for (int i = 0; i < KM; ++i) {
     q.w[i] = i < K ? raw(i) : 0.f;
@@ -1058,8 +1058,8 @@ __device__ __forceinline__ void l64_dv_at(const float (&dv)[KM], int k, float &r
   }
 }
 // forward / inverse of one dimension; logd accumulates log S'(x) (forward) or -log S'(x) (inverse)
-template <int KM>
-__device__ __forceinline__ float l64_spline_apply(const L64Raw &raw, int K, float B, float v, bool inverse, float &logd) {
+template <int KM, class Raw = L64Raw>
+__device__ __forceinline__ float l64_spline_apply(const Raw &raw, int K, float B, float v, bool inverse, float &logd) {
   L64Par<KM> q;
   l64_load_par<KM>(raw, K, q);
   float invw, invh;
@@ -1460,6 +1460,157 @@ __global__ __launch_bounds__(512) void k_l64_nsf_top_bwd(G64Args a, int inv, con
   L64T_STAMP(63);
 }
 
+// The FORWARD of a spline coupling's output layer with the spline itself (round 5): k_l64_fwd_all wrote the 3K - 1 raw
+// parameters per dimension and k_l64_couple_fwd read them back -- here they go to HBM once (the reverse pass reads them) and
+// to the spline through LDS.  A workgroup takes two 32-sample tiles at a time, four waves each: wave w of a tile owns output
+// columns [96 w, 96 w + 96) with its weight slice in registers (as the dX waves of k_l64_nsf_top_bwd), 96 fp32 matrix
+// instructions per tile; then the tile's 256 threads are (sample, dimension lane) exactly as k_l64_couple_fwd's -- the same
+// walk over the dimensions and the same fixed-order sum of the log-determinant terms, so the results are the same bits.
+struct L64LdsIn {
+  const float *p;  // row 0 of this (dimension, sample) in the LDS tile
+  __device__ __forceinline__ float operator()(int i) const { return p[i * NF_TS]; }
+};
+#define L64_TOPF_LDS ((2 * L64_TOP_ROWS + 2 * 64 + 2 * L64_DL) * NF_TS * 4 + L64_TOP_ROWS * 4)
+template <int KM>
+__global__ __launch_bounds__(512) void k_l64_nsf_top_fwd(G64Args a, int inverse, const float *__restrict__ theta, L64Layer L,
+                                                         const float *__restrict__ hact, int Fh, float *__restrict__ os, int Fs, float *xy,
+                                                         float *__restrict__ ladj, long long *trace) {
+#ifdef NF_KERNEL_TRACE  // tools/trace_l64_top.py: workgroup 0 / wave 0 at [0 ...]
+  long long *trf = trace && blockIdx.x == 0 && threadIdx.x == 0 ? trace : nullptr;
+#define L64F_STAMP(slot) do { if (trf) { __builtin_amdgcn_sched_barrier(0); trf[slot] = clock64(); } } while (0)
+#else
+#define L64F_STAMP(slot) do { } while (0)
+#endif
+  L64F_STAMP(0);
+  int fslot = 2;
+  constexpr int SD = L64_TOP_ROWS * NF_TS, SA = 64 * NF_TS, WS = L64_TOP_ROWS + 1;
+  static_assert(64 * WS <= 2 * SD, "the prologue stages the whole layer in the two parameter tiles");
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float *sdt = sm, *sat = sm + 2 * SD, *part = sat + 2 * SA, *bias = part + 2 * L64_DL * NF_TS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int half = tid >> 8, t256 = tid & 255, smp = tid & 31, dl = (tid >> 5) & 7;
+  const int o0w = 96 * (wave & 3);
+  {
+    constexpr int NE = 64 * L64_TOP_ROWS, U = 16;
+#pragma unroll 1
+    for (int e0 = tid; e0 < NE; e0 += 512 * U) {
+      float v[U];
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        const int e = e0 + 512 * k, i = e / L64_TOP_ROWS, o = e - i * L64_TOP_ROWS;
+        v[k] = (i < L.nin && o < L.nout) ? theta[L.w_off + (long)i * L.nout + o] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        const int e = e0 + 512 * k, i = e / L64_TOP_ROWS, o = e - i * L64_TOP_ROWS;
+        sm[i * WS + o] = v[k];
+      }
+    }
+    if (tid < L64_TOP_ROWS) bias[tid] = tid < L.nout ? theta[L.b_off + tid] : 0.f;
+  }
+  __syncthreads();
+  float W[3][32];  // W[2 kk + hi][o0w + 32 ob + l31]: the A operand of k-step kk for output block ob
+#pragma unroll
+  for (int ob = 0; ob < 3; ++ob)
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) W[ob][kk] = sm[(2 * kk + hi) * WS + o0w + 32 * ob + l31];
+  __syncthreads();
+  float *sd = sdt + half * SD, *sa = sat + half * SA, *pt = part + half * L64_DL * NF_TS;
+  const int P = 3 * a.K - 1;
+  const long ntiles = (a.N + L64_TILE - 1) / L64_TILE;
+  // a tile's activations [64][32] go through registers: requested an interval ahead (tools/trace_l64_top.py: 6 k of a pair's
+  // 40 k clocks were this load's round trip)
+  float hn[8];
+  auto request = [&](long t) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = t256 + 256 * q, row = e >> 5;
+      hn[q] = (t < ntiles && row < Fh) ? hact[(t * Fh + row) * L64_TILE + (e & 31)] : 0.f;
+    }
+  };
+  request(2 * (long)blockIdx.x + half);
+  L64F_STAMP(1);
+  for (long pair = blockIdx.x; 2 * pair < ntiles; pair += gridDim.x) {
+    const long tile = 2 * pair + half;
+    const bool live = tile < ntiles;  // (wave-uniform: the second tile of the last pair may not exist)
+    L64F_STAMP(fslot + 0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = t256 + 256 * q;
+      sa[(e >> 5) * NF_TS + (e & 31)] = hn[q];
+    }
+    request(2 * (pair + gridDim.x) + half);
+    // this tile's state and log-determinant values: requested now, used after the matrix stage
+    const long j = tile * L64_TILE + smp;
+    const bool valid = live && j < a.N;
+    float *xr = xy + j * a.d;
+    float xv[2] = {0.f, 0.f}, lold = 0.f;
+    if (valid) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (dl + L64_DL * u < a.c) xv[u] = xr[2 * (dl + L64_DL * u) + a.par_t];
+      if (dl == 0) lold = ladj[j];
+    }
+    __syncthreads();
+    L64F_STAMP(fslot + 1);
+    if (live) {
+      f32x16 out[3];
+#pragma unroll
+      for (int ob = 0; ob < 3; ++ob)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[ob][r] = bias[o0w + 32 * ob + nf_row(r, hi)];
+#pragma unroll
+      for (int kk = 0; kk < 32; ++kk) {
+        const float hb = sa[(2 * kk + hi) * NF_TS + l31];
+#pragma unroll
+        for (int ob = 0; ob < 3; ++ob) out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(W[ob][kk], hb, out[ob], 0, 0, 0);
+      }
+      L64F_STAMP(fslot + 2);
+#pragma unroll
+      for (int ob = 0; ob < 3; ++ob)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sd[(o0w + 32 * ob + nf_row(r, hi)) * NF_TS + l31] = out[ob][r];
+    }
+    L64F_STAMP(fslot + 3);
+    __syncthreads();
+    L64F_STAMP(fslot + 4);
+    if (live) {
+      // the raw parameters to HBM for the reverse pass: 16 bytes per lane from the LDS tile (as 4-byte stores straight from the
+      // accumulators this was 6 k clocks of the matrix stage: 384 store instructions per pair and CU, all workgroups at once)
+#pragma unroll
+      for (int q = 0; q < 12; ++q) {
+        const int idx = t256 + 256 * q, row = idx >> 3, g4 = idx & 7;
+        const float *src = sd + row * NF_TS + 4 * g4;
+        const float4 v = make_float4(src[0], src[1], src[2], src[3]);
+        if (row < Fs) *reinterpret_cast<float4 *>(os + (tile * Fs + row) * L64_TILE + 4 * g4) = v;
+      }
+    }
+    float lsum = 0.f;
+    if (valid) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int p = dl + L64_DL * u;
+        if (p < a.c) {
+          const L64LdsIn raw{sd + p * P * NF_TS + smp};
+          xr[2 * p + a.par_t] = l64_spline_apply<KM>(raw, a.K, (float)a.B, xv[u], inverse != 0, lsum);
+        }
+      }
+    }
+    pt[dl * NF_TS + smp] = lsum;
+    L64F_STAMP(fslot + 5);
+    __syncthreads();
+    if (dl == 0 && valid) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < L64_DL; ++q) t += pt[q * NF_TS + smp];
+      ladj[j] = lold + t;
+    }
+    L64F_STAMP(fslot + 6);
+    if (fslot < 50) fslot += 7;
+    // (the next pair's stores into sa / sd / part come after its first barrier or after this one: no wave still reads them)
+  }
+}
+
 // ---- host side --------------------------------------------------------------------------------
 template <class SZ>
 static bool g64_fits(const nf_flow_desc *desc) {
@@ -1727,8 +1878,16 @@ static int l64_fwd_all_launch(nf_ctx *ctx, unsigned grid, size_t lds, const floa
   hipLaunchKernelGGL((k_l64_fwd_all<IB, OB>), dim3(grid, ny), dim3(512), lds, ctx->stream, theta, L, NG, src, dst, Fd, N, act, yy);
   return (int)hipGetLastError();
 }
+// the fused output-layer kernels of a spline coupling (k_l64_nsf_top_fwd / k_l64_nsf_top_bwd) take: one hidden layer at least,
+// <= 64 inputs and <= 384 outputs in the output layer, K <= 8, <= 16 transformed dimensions
+static bool l64_top_fusable(const G64Args &a, int last) {
+  static const bool no_top = std::getenv("NF_L64_NO_TOP_FUSE") != nullptr;  // A/B switch: the separate launches
+  return !no_top && a.kind == NF_KIND_NSF && last >= 1 && a.K <= 8 && a.c <= 16 && a.net[0].dims[last] <= 64 &&
+         a.net[0].dims[last + 1] <= L64_TOP_ROWS;
+}
 // the nets of one coupling, layer by layer, on the conditioner half of `x` (standard layout); outputs stay in b->act
-static int l64_nets_fwd(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a, const float *theta, const float *x, const L64Bufs &b) {
+static int l64_nets_fwd(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a, const float *theta, const float *x, const L64Bufs &b,
+                        bool skip_top = false) {  // skip_top: the output layer is the caller's (k_l64_nsf_top_fwd)
   const unsigned grid = l64_grid(ctx, a.N, 4L * ctx->num_cu);
   const int ny = l64_nets_merge(a, b);  // RealNVP: both nets in one launch (blockIdx.y), per-net strides in yy
   for (int n = 0; n < b.nets; n += ny) {
@@ -1736,7 +1895,8 @@ static int l64_nets_fwd(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a,
     // the leading run of narrow layers (widths <= 64) in one launch
     int lc = 0;
     static const bool no_chain = std::getenv("NF_L64_NO_FWD_CHAIN") != nullptr;  // A/B switch
-    while (lc < net.nl && net.dims[lc] <= 64 && net.dims[lc + 1] <= 64) ++lc;
+    const int nlim = net.nl - (skip_top ? 1 : 0);
+    while (lc < nlim && net.dims[lc] <= 64 && net.dims[lc + 1] <= 64) ++lc;
     if (lc < 2 || no_chain) lc = 0;
     if (lc) {
       L64Chain ch;
@@ -1758,7 +1918,7 @@ static int l64_nets_fwd(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a,
       hipLaunchKernelGGL(k_l64_fwd_chain, dim3(grid8, ny), dim3(512), lds, ctx->stream, theta, ch, src, a.N, yy);
       NF_HIP(hipGetLastError());
     }
-    for (int l = lc; l < net.nl; ++l) {
+    for (int l = lc; l < nlim; ++l) {
       const int nin = net.dims[l], nout = net.dims[l + 1];
       const int IB = l64_ibp(nin), blocks = (nout + 31) / 32;
       L64Src src;
@@ -1796,9 +1956,25 @@ static int l64_apply(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a, in
                      int slot) {
   L64Bufs b;
   NF_TRY(l64_bufs(ctx, desc, a, &b, slot));
+  const int last = b.nl - 1;
+  if (l64_top_fusable(a, last)) {  // a spline coupling's output layer and the spline in one kernel
+    NF_TRY(l64_nets_fwd(ctx, desc, a, theta, xy, b, true));
+    const G64Net &net = a.net[0];
+    const L64Layer L{net.w[last], net.b[last], net.dims[last], net.dims[last + 1], 0};
+    static AttrOnce attr_once;
+    NF_TRY(attr_once.run(ctx->device, [&]() -> int {
+      NF_HIP(hipFuncSetAttribute((const void *)k_l64_nsf_top_fwd<8>, hipFuncAttributeMaxDynamicSharedMemorySize, L64_TOPF_LDS));
+      return NF_OK;
+    }));
+    const long pairs = ((a.N + 31) / 32 + 1) / 2;
+    const unsigned gridp = (unsigned)std::min<long>(pairs, (long)ctx->num_cu);
+    ProfScope ps(ctx, "l64_top_fwd");
+    hipLaunchKernelGGL(k_l64_nsf_top_fwd<8>, dim3(gridp), dim3(512), L64_TOPF_LDS, ctx->stream, a, inverse, theta, L,
+                       (const float *)b.act[0][last - 1], b.F[last - 1], b.act[0][last], b.F[last], xy, ladj, (long long *)ctx->trace);
+    return (int)hipGetLastError();
+  }
   NF_TRY(l64_nets_fwd(ctx, desc, a, theta, xy, b));
   ProfScope ps(ctx, "l64_couple");
-  const int last = b.nl - 1;
   if (a.K <= 8)
     hipLaunchKernelGGL(k_l64_couple_fwd<8>, dim3((unsigned)((a.N + 31) / 32)), dim3(256), 0, ctx->stream, a, inverse,
                        (const float *)b.act[0][last], b.F[last], (const float *)b.act[b.nets - 1][last], b.F[last], xy, ladj);
@@ -1855,13 +2031,11 @@ static int l64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &
   const unsigned grid = l64_grid(ctx, a.N, 4L * ctx->num_cu);
   unsigned gridw = l64_grid(ctx, a.N, (long)g64_bwd_blocks(desc, a.N));
   // a spline coupling's output layer: the spline's reverse, dW and the input cotangent in one kernel (k_l64_nsf_top_bwd)
-  static const bool no_top = std::getenv("NF_L64_NO_TOP_FUSE") != nullptr;  // A/B switch: the three launches
-  const bool top_fused = !no_top && a.kind == NF_KIND_NSF && last >= 1 && a.K <= 8 && a.c <= 16 && a.net[0].dims[last] <= 64 &&
-                         a.net[0].dims[last + 1] <= L64_TOP_ROWS;
+  const bool top_fused = l64_top_fusable(a, last);
   if (top_fused) {
-    // two workgroups per CU's worth of slabs: the fused kernel stages the whole layer per workgroup and writes a 96 KB slab
-    // (the coupling's other dW kernels share the count)
-    if (gridw > 2u * (unsigned)ctx->num_cu) gridw = 2u * (unsigned)ctx->num_cu;
+    // one workgroup (= one slab) per CU: the fused kernel stages the whole layer per workgroup and writes a 96 KB slab; the
+    // coupling's other dW kernels share the count (measured against two per CU: step 3.23 -> 3.17 ms at the docstring shape)
+    if (gridw > (unsigned)ctx->num_cu) gridw = (unsigned)ctx->num_cu;
     const G64Net &net = a.net[0];
     const L64Layer L{net.w[last], net.b[last], net.dims[last], net.dims[last + 1], 0};
     static AttrOnce attr_once;

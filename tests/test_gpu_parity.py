@@ -749,7 +749,8 @@ def test_general_float32_couplings_run_their_mlp_on_mfma(nf, kind, d, hd, nl, K,
     P.scalar(f"{tag}: forward-KL loss", lk, lkr, 10 * P.LOSS_RTOL)
     P.gradient(f"{tag}: forward-KL grad", gk, gkr, 10 * P.GRAD_RTOL)
     ran = {}
-    for name in (b"l64_fwd", b"l64_dw", b"l64_bwdx", b"l64_couple", b"deep_chain", b"deep_bwd", b"deep_bwd_inv"):
+    for name in (b"l64_fwd", b"l64_dw", b"l64_bwdx", b"l64_couple", b"l64_top_fwd", b"l64_top_bwd", b"deep_chain", b"deep_bwd",
+                 b"deep_bwd_inv"):
         a, c = C.c_double(0.0), C.c_int64(0)
         lib.nf_prof_read(ctx.ptr, name, C.byref(a), C.byref(c))
         ran[name] = c.value
@@ -760,7 +761,13 @@ def test_general_float32_couplings_run_their_mlp_on_mfma(nf, kind, d, hd, nl, K,
     if deep:
         assert all(ran[k] > 0 for k in (b"deep_chain", b"deep_bwd", b"deep_bwd_inv")) and not any(ran[k] for k in (b"l64_fwd", b"l64_dw", b"l64_bwdx", b"l64_couple")), ran
     else:
-        assert all(ran[k] > 0 for k in (b"l64_fwd", b"l64_dw", b"l64_bwdx", b"l64_couple")) and not ran[b"deep_chain"], ran
+        # a spline coupling's output layer (<= 64 inputs, K <= 8, <= 16 transformed dimensions) runs with the spline in one
+        # kernel each way (k_l64_nsf_top_fwd / k_l64_nsf_top_bwd) instead of a layer launch + k_l64_couple_*
+        top = kind == "nsf" and K <= 8 and (d + 1) // 2 <= 16 and hd[-1] <= 64
+        coupling = (b"l64_top_fwd", b"l64_top_bwd") if top else (b"l64_couple",)
+        assert all(ran[k] > 0 for k in (b"l64_fwd", b"l64_dw", b"l64_bwdx") + coupling) and not ran[b"deep_chain"], ran
+        if top:
+            assert not ran[b"l64_couple"], ran
 
 
 def test_target_argument_conventions(nf):

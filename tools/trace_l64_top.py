@@ -16,6 +16,22 @@ dev = torch.device("cuda", 0)
 D, N = int(os.environ.get("D", 32)), int(os.environ.get("N", 131072))
 flow = nf.nsf(nf.MvNormal(D), (64, 64), 8, 3.0, 6, paramtype=torch.float32, device=dev, seed=1)
 ctx = nf.context_for(dev)
+# ---- the forward kernel k_l64_nsf_top_fwd (workgroup 0 / wave 0; the last coupling applied remains)
+xs = nf.device_specific_rand(nf.PhiloxRNG(1), flow.dist, N)
+for i in range(3):
+    nf.with_logabsdet_jacobian(flow.transform, xs)
+lib.nf_debug_trace(ctx.ptr, 1, None, 0)
+nf.with_logabsdet_jacobian(flow.transform, xs)
+torch.cuda.synchronize()
+fb = (C.c_int64 * 128)()
+lib.nf_debug_trace(ctx.ptr, 0, fb, 128)
+f = list(fb)
+print(f"k_l64_nsf_top_fwd: prologue {f[1] - f[0]}")
+for i in range(8):
+    s = f[2 + 7 * i: 9 + 7 * i]
+    if s[6] > s[0] > 0:
+        print(f"   pair {i}: activations -> LDS + wait {s[1] - s[0]}  matrix stage {s[2] - s[1]}  stores {s[3] - s[2]}  wait {s[4] - s[3]}"
+              f"  spline {s[5] - s[4]}  wait + ladj {s[6] - s[5]}   total {s[6] - s[0]}")
 tgt = nf.DiagGaussTarget(torch.randn(D, device=dev), torch.rand(D, device=dev) + 0.5)
 out = torch.zeros(flow.P + 1, device=dev, dtype=torch.float32)
 vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
