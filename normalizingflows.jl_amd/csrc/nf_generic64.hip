@@ -1611,6 +1611,125 @@ __global__ __launch_bounds__(512) void k_l64_nsf_top_fwd(G64Args a, int inverse,
   }
 }
 
+// The reverse pass of a net's layers BELOW the output layer in one kernel (round 5; spline couplings whose output layer ran in
+// k_l64_nsf_top_bwd): per hidden layer the general path launched k_l64_dw and k_l64_bwdx -- four launches and eight passes
+// over 64-row tiles for two hidden layers.  Here a wave takes a 32-sample tile through all of them: delta = cotangent x
+// leaky-ReLU'(stashed output), dW += a' delta (operands through the wave's LDS scratch, as k_l64_dw), cotangent <- W delta
+// (weights of every layer in LDS), the first layer's input cotangent added to the conditioner half of gbar.  Each stashed
+// activation tile is read once (it is the mask of its own layer and the `a` operand of the one above).
+// NH hidden layers, every width <= 64; IB0 = 32-row blocks of the first layer's inputs.
+struct L64Hid {
+  long w_off[2], b_off[2];
+  int nin[2], nout[2], F[2];
+  const float *act[2];  // the layers' stashed outputs (tiles, F rows)
+};
+template <int IB, int OB>
+__device__ __forceinline__ void l64_fold_to_slab(float *img, const f32x16 (&acc)[IB][OB], const float (&bsum)[OB], long w_off, long b_off,
+                                                 int nin, int nout, float *slab, int tid, int wave, int l31, int hi) {
+  // waves in a fixed order through one [32 IB][32 OB] image (+ bias row) in LDS, then the slab in theta order (as k_l64_dw)
+  constexpr int SI = 32 * OB;
+  for (int wv = 0; wv < 4; ++wv) {
+    if (wave == wv) {
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float *p = img + (32 * ib + nf_row(r, hi)) * SI + 32 * ob + l31;
+            *p = wv == 0 ? acc[ib][ob][r] : *p + acc[ib][ob][r];
+          }
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob) {
+        const float v = bsum[ob] + __shfl_xor(bsum[ob], 32);
+        if (hi == 0) {
+          float *p = img + 32 * IB * SI + 32 * ob + l31;
+          *p = wv == 0 ? v : *p + v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < 32 * IB * SI; e += 256) {
+    const int i = e / SI, o = e - i * SI;
+    if (i < nin && o < nout) slab[w_off + (long)i * nout + o] = img[e];
+  }
+  for (int o = tid; o < SI; o += 256)
+    if (o < nout) slab[b_off + o] = img[32 * IB * SI + o];
+  __syncthreads();
+}
+template <int NH, int IB0>
+__global__ __launch_bounds__(256) void k_l64_hidden_bwd(const float *__restrict__ theta, L64Hid hd, const float *__restrict__ gtop, int Fg,
+                                                        L64Src xin, float *__restrict__ gbar, long N, float *__restrict__ slabs, long Pc,
+                                                        long slab_off) {
+  constexpr int S = 64 + NF_IMG_PAD, WG = 64 * S + 64, SC = 4 * 32 * NF_TS;
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // NH weight images, then a scratch pair per wave
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  for (int l = 0; l < NH; ++l) {
+    const L64Layer L{hd.w_off[l], hd.b_off[l], hd.nin[l], hd.nout[l], 0};
+    l64_stage<2, 2>(sm + l * WG, sm + l * WG + 64 * S, theta, L, tid, 256);  // (the bias row is staged and not used)
+  }
+  __syncthreads();
+  float *scr = sm + NH * WG, *sa = scr + wave * SC, *sd = sa + 2 * 32 * NF_TS;
+  f32x16 acc1[2][2], acc0[IB0][2];
+  float bs1[2] = {0.f, 0.f}, bs0[2] = {0.f, 0.f};
+#pragma unroll
+  for (int ob = 0; ob < 2; ++ob) {
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[ib][ob][r] = 0.f;
+#pragma unroll
+    for (int ib = 0; ib < IB0; ++ib)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc0[ib][ob][r] = 0.f;
+  }
+  const long ntiles = (N + L64_TILE - 1) / L64_TILE;
+  for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+    f32x16 g[2], hl[2];
+    l64_load<2>(L64Src{gtop, Fg, 0, 0, 0}, tile, l31, hi, N, 64, g);
+    l64_load<2>(L64Src{hd.act[NH - 1], hd.F[NH - 1], 0, 0, 0}, tile, l31, hi, N, 64, hl);
+    if (NH == 2) {
+      f32x16 av[2], din[2];
+      l64_load<2>(L64Src{hd.act[0], hd.F[0], 0, 0, 0}, tile, l31, hi, N, 64, av);
+#pragma unroll
+      for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[ob][r] *= hl[ob][r] > 0.f ? 1.f : 0.01f;
+      tile_to_scratch<2>(sa, av, l31, hi);
+      tile_to_scratch<2>(sd, g, l31, hi);
+      wave_lds_fence();
+      dw_accumulate<2, 2>(sa, sd, acc1, bs1, l31, hi);
+      wave_lds_fence();
+      dense_bwd_x<2, 2, S, false>(sm + WG, g, din, l31, hi);
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { g[ib][r] = din[ib][r]; hl[ib][r] = av[ib][r]; }
+    }
+    {
+      f32x16 av[IB0], din[IB0];
+      l64_load<IB0>(xin, tile, l31, hi, N, hd.nin[0], av);
+#pragma unroll
+      for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[ob][r] *= hl[ob][r] > 0.f ? 1.f : 0.01f;
+      tile_to_scratch<IB0>(sa, av, l31, hi);
+      tile_to_scratch<2>(sd, g, l31, hi);
+      wave_lds_fence();
+      dw_accumulate<IB0, 2>(sa, sd, acc0, bs0, l31, hi);
+      wave_lds_fence();
+      dense_bwd_x<IB0, 2, S, false>(sm, g, din, l31, hi);
+      l64_store_din<IB0>(din, gbar, 0, 1, xin.d, xin.par, hd.nin[0], tile, N, l31, hi);
+    }
+  }
+  __syncthreads();
+  float *slab = slabs + (long)blockIdx.x * Pc - slab_off;
+  if (NH == 2) l64_fold_to_slab<2, 2>(scr, acc1, bs1, hd.w_off[1], hd.b_off[1], hd.nin[1], hd.nout[1], slab, tid, wave, l31, hi);
+  l64_fold_to_slab<IB0, 2>(scr, acc0, bs0, hd.w_off[0], hd.b_off[0], hd.nin[0], hd.nout[0], slab, tid, wave, l31, hi);
+}
+#define L64_HID_LDS(NH) (((NH) * (64 * (64 + NF_IMG_PAD) + 64) + 4 * 4 * 32 * NF_TS) * 4)
+
 // ---- host side --------------------------------------------------------------------------------
 template <class SZ>
 static bool g64_fits(const nf_flow_desc *desc) {
@@ -2043,11 +2162,45 @@ static int l64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &
       NF_HIP(hipFuncSetAttribute((const void *)k_l64_nsf_top_bwd<8>, hipFuncAttributeMaxDynamicSharedMemorySize, L64_TOP_LDS));
       return NF_OK;
     }));
-    ProfScope ps(ctx, "l64_top_bwd");
-    hipLaunchKernelGGL(k_l64_nsf_top_bwd<8>, dim3(gridw), dim3(512), L64_TOP_LDS, ctx->stream, a, inv, theta, L, (const float *)b.act[0][last],
-                       b.F[last], (const float *)b.act[0][last - 1], b.F[last - 1], x, gbar, lbar, lbar_const, b.gh[0][last - 1], b.GH, slabs,
-                       (long)ci.nparams, (long)ci.theta_off, (long long *)ctx->trace);
-    NF_HIP(hipGetLastError());
+    {
+      ProfScope ps(ctx, "l64_top_bwd");
+      hipLaunchKernelGGL(k_l64_nsf_top_bwd<8>, dim3(gridw), dim3(512), L64_TOP_LDS, ctx->stream, a, inv, theta, L,
+                         (const float *)b.act[0][last], b.F[last], (const float *)b.act[0][last - 1], b.F[last - 1], x, gbar, lbar, lbar_const,
+                         b.gh[0][last - 1], b.GH, slabs, (long)ci.nparams, (long)ci.theta_off, (long long *)ctx->trace);
+      NF_HIP(hipGetLastError());
+    }
+    // the layers below it in one more launch when there are one or two, none wider than 64 (k_l64_hidden_bwd)
+    static const bool no_hid = std::getenv("NF_L64_NO_HIDDEN_FUSE") != nullptr;  // A/B switch: k_l64_dw / k_l64_bwdx per layer
+    bool narrow = !no_hid && last <= 2 && net.dims[0] <= 64;
+    for (int l = 0; l < last; ++l) narrow = narrow && net.dims[l + 1] <= 64;
+    if (narrow) {
+      L64Hid hd;
+      for (int l = 0; l < 2; ++l) {
+        const int q = l < last ? l : 0;
+        hd.w_off[l] = net.w[q]; hd.b_off[l] = net.b[q]; hd.nin[l] = net.dims[q]; hd.nout[l] = net.dims[q + 1]; hd.F[l] = b.F[q];
+        hd.act[l] = b.act[0][q];
+      }
+      const L64Src xin{x, 0, 0, a.d, 1 - a.par_t};
+      const int ib0 = net.dims[0] <= 32 ? 1 : 2;
+      ProfScope ps2(ctx, "l64_hidden_bwd");
+#define CALLH(NHv, IBv)                                                                                                                  \
+  do {                                                                                                                                   \
+    static AttrOnce once;                                                                                                                \
+    NF_TRY(once.run(ctx->device, [&]() -> int {                                                                                          \
+      NF_HIP(hipFuncSetAttribute((const void *)k_l64_hidden_bwd<NHv, IBv>, hipFuncAttributeMaxDynamicSharedMemorySize, L64_HID_LDS(NHv))); \
+      return NF_OK;                                                                                                                      \
+    }));                                                                                                                                 \
+    hipLaunchKernelGGL((k_l64_hidden_bwd<NHv, IBv>), dim3(gridw), dim3(256), L64_HID_LDS(NHv), ctx->stream, theta, hd,                   \
+                       (const float *)b.gh[0][last - 1], b.GH, xin, gbar, a.N, slabs, (long)ci.nparams, (long)ci.theta_off);             \
+  } while (0)
+      if (last == 2 && ib0 == 2) CALLH(2, 2);
+      else if (last == 2) CALLH(2, 1);
+      else if (ib0 == 2) CALLH(1, 2);
+      else CALLH(1, 1);
+#undef CALLH
+      NF_HIP(hipGetLastError());
+      return nf_launch_reduce_slabs(ctx, NF_DTYPE_F32, slabs, (int)gridw, ci.nparams, g + ci.theta_off);
+    }
   } else {
     ProfScope ps(ctx, "l64_couple");
     if (a.K <= 8)

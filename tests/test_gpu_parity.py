@@ -749,8 +749,8 @@ def test_general_float32_couplings_run_their_mlp_on_mfma(nf, kind, d, hd, nl, K,
     P.scalar(f"{tag}: forward-KL loss", lk, lkr, 10 * P.LOSS_RTOL)
     P.gradient(f"{tag}: forward-KL grad", gk, gkr, 10 * P.GRAD_RTOL)
     ran = {}
-    for name in (b"l64_fwd", b"l64_dw", b"l64_bwdx", b"l64_couple", b"l64_top_fwd", b"l64_top_bwd", b"deep_chain", b"deep_bwd",
-                 b"deep_bwd_inv"):
+    for name in (b"l64_fwd", b"l64_dw", b"l64_bwdx", b"l64_couple", b"l64_top_fwd", b"l64_top_bwd", b"l64_hidden_bwd", b"deep_chain",
+                 b"deep_bwd", b"deep_bwd_inv"):
         a, c = C.c_double(0.0), C.c_int64(0)
         lib.nf_prof_read(ctx.ptr, name, C.byref(a), C.byref(c))
         ran[name] = c.value
@@ -763,11 +763,16 @@ def test_general_float32_couplings_run_their_mlp_on_mfma(nf, kind, d, hd, nl, K,
     else:
         # a spline coupling's output layer (<= 64 inputs, K <= 8, <= 16 transformed dimensions) runs with the spline in one
         # kernel each way (k_l64_nsf_top_fwd / k_l64_nsf_top_bwd) instead of a layer launch + k_l64_couple_*
+        # -- and, with one or two hidden layers none wider than 64, the layers below it in one more (k_l64_hidden_bwd)
         top = kind == "nsf" and K <= 8 and (d + 1) // 2 <= 16 and hd[-1] <= 64
-        coupling = (b"l64_top_fwd", b"l64_top_bwd") if top else (b"l64_couple",)
-        assert all(ran[k] > 0 for k in (b"l64_fwd", b"l64_dw", b"l64_bwdx") + coupling) and not ran[b"deep_chain"], ran
+        below = top and len(hd) <= 2 and max(hd) <= 64 and d // 2 <= 64
+        expect = (b"l64_fwd",) + ((b"l64_top_fwd", b"l64_top_bwd") if top else (b"l64_couple",))
+        expect += (b"l64_hidden_bwd",) if below else (b"l64_dw", b"l64_bwdx")
+        assert all(ran[k] > 0 for k in expect) and not ran[b"deep_chain"], ran
         if top:
             assert not ran[b"l64_couple"], ran
+        if below:
+            assert not ran[b"l64_dw"] and not ran[b"l64_bwdx"], ran
 
 
 def test_target_argument_conventions(nf):

@@ -66,7 +66,7 @@ def time_step(flow, tgt, n, steps, warmup=5):
     torch.cuda.synchronize()
     kern = {}
     for name in (b"base_sample", b"pack_weights", b"affine_chain", b"rqs_chain", b"simple_apply", b"simple_step", b"planar_step", b"radial_step", b"simple_finalize", b"target", b"affine_bwd",
-                 b"rqs_bwd", b"simple_bwd", b"wide_apply", b"wide_bwd", b"wide_dw", b"deep_chain", b"deep_bwd", b"g64m_apply", b"g64m_bwd", b"g64_apply", b"g64_bwd", b"l64_fwd", b"l64_couple", b"l64_top_fwd", b"l64_top_bwd", b"l64_dw", b"l64_bwdx", b"reduce_slabs", b"adam"):
+                 b"rqs_bwd", b"simple_bwd", b"wide_apply", b"wide_bwd", b"wide_dw", b"deep_chain", b"deep_bwd", b"g64m_apply", b"g64m_bwd", b"g64_apply", b"g64_bwd", b"l64_fwd", b"l64_couple", b"l64_top_fwd", b"l64_top_bwd", b"l64_hidden_bwd", b"l64_dw", b"l64_bwdx", b"reduce_slabs", b"adam"):
         a, c = C.c_double(0.0), C.c_int64(0)
         lib.nf_prof_read(ctx.ptr, name, C.byref(a), C.byref(c))
         if c.value:
