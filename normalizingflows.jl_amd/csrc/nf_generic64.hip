@@ -437,6 +437,7 @@ __global__ __launch_bounds__(G64_BLOCK) void k_g64_bwd(G64Args a, int inv, const
 // the tiles.  So every entry point that reaches nf_g64_apply / g64_launch_bwd (forward, inverse, rand, ELBO, training
 // step, forward-KL, pullbacks, compositions) takes this path for those shapes; Float64 and wider nets keep the scalar MLP.
 #include "nf_mfma.h"
+#include "nf_rqs_elem.h"  // the fused spline kernels' element functions (K a compile-time 8): k_l64_nsf_top_fwd / _bwd
 
 #define L64_TILE 32
 struct L64Layer {
@@ -1281,7 +1282,10 @@ struct L64LdsOut {
 };
 #define L64_TOP_ROWS 384
 #define L64_TOP_LDS ((2 * L64_TOP_ROWS + 2 * 64 + 4 * 64) * NF_TS * 4)
-template <int KM>
+// KC = 8: K is 8 and the element arithmetic is nf_rqs_elem.h's (compile-time K, unnormalised prefix sums, packed width /
+// height pairs, hardware exp / log / rcp -- what the fused spline kernels of the hidden <= 32 shapes ship with): 16 k -> 9 k
+// clocks of spline stage per tile.  KC = 0: run-time K <= KM, l64_spline_bwd.
+template <int KM, int KC>
 __global__ __launch_bounds__(512) void k_l64_nsf_top_bwd(G64Args a, int inv, const float *__restrict__ theta, L64Layer L,
                                                          const float *__restrict__ os, int Fs, const float *__restrict__ hact, int Fh,
                                                          const float *__restrict__ x, float *gbar, const float *__restrict__ lbar,
@@ -1383,6 +1387,22 @@ __global__ __launch_bounds__(512) void k_l64_nsf_top_bwd(G64Args a, int inv, con
           }
 #endif
           const L64LdsOut out{sdn + p * P * NF_TS + smp};
+          if constexpr (KC == 8) {
+            float rw[23], thb[23];
+#pragma unroll
+            for (int i = 0; i < 23; ++i) rw[i] = raw(i);
+            Knots<8> kn;
+            build_knots<8>(rw, (float)a.B, kn);
+            Bin<8> bn;
+            const float xv = xr[2 * p + a.par_t], yb = gr[2 * p + a.par_t];
+            find_bin<8>(kn, xv, bn);
+            const float xi = nf_fdiv(xv - bn.xk, bn.dx);
+            const float xb = inv ? rqs_bwd_elem<8, true>(kn, bn, xi, (float)a.B, yb, lb, thb)
+                                 : rqs_bwd_elem<8, false>(kn, bn, xi, (float)a.B, yb, lb, thb);
+#pragma unroll
+            for (int i = 0; i < 23; ++i) out.put(i, thb[i]);
+            gr[2 * p + a.par_t] = xb;
+          } else
           gr[2 * p + a.par_t] = l64_spline_bwd<KM>(raw, out, a.K, (float)a.B, xr[2 * p + a.par_t], gr[2 * p + a.par_t], lb, inv != 0);
         }
       }
@@ -1471,7 +1491,7 @@ struct L64LdsIn {
   __device__ __forceinline__ float operator()(int i) const { return p[i * NF_TS]; }
 };
 #define L64_TOPF_LDS ((2 * L64_TOP_ROWS + 2 * 64 + 2 * L64_DL) * NF_TS * 4 + L64_TOP_ROWS * 4)
-template <int KM>
+template <int KM, int KC>  // KC: as k_l64_nsf_top_bwd
 __global__ __launch_bounds__(512) void k_l64_nsf_top_fwd(G64Args a, int inverse, const float *__restrict__ theta, L64Layer L,
                                                          const float *__restrict__ hact, int Fh, float *__restrict__ os, int Fs, float *xy,
                                                          float *__restrict__ ladj, long long *trace) {
@@ -1592,6 +1612,21 @@ __global__ __launch_bounds__(512) void k_l64_nsf_top_fwd(G64Args a, int inverse,
         const int p = dl + L64_DL * u;
         if (p < a.c) {
           const L64LdsIn raw{sd + p * P * NF_TS + smp};
+          if constexpr (KC == 8) {
+            float rw[23];
+#pragma unroll
+            for (int i = 0; i < 23; ++i) rw[i] = raw(i);
+            Knots<8> kn;
+            build_knots<8>(rw, (float)a.B, kn);
+            float xi;
+            if (!inverse) {
+              unsigned code;
+              xr[2 * p + a.par_t] = rqs_fwd_elem<8>(kn, xv[u], lsum, code, xi);
+            } else {
+              Bin<8> bn;
+              xr[2 * p + a.par_t] = rqs_inv_elem<8>(kn, xv[u], lsum, bn, xi);
+            }
+          } else
           xr[2 * p + a.par_t] = l64_spline_apply<KM>(raw, a.K, (float)a.B, xv[u], inverse != 0, lsum);
         }
       }
@@ -2004,6 +2039,11 @@ static bool l64_top_fusable(const G64Args &a, int last) {
   return !no_top && a.kind == NF_KIND_NSF && last >= 1 && a.K <= 8 && a.c <= 16 && a.net[0].dims[last] <= 64 &&
          a.net[0].dims[last + 1] <= L64_TOP_ROWS;
 }
+// K = 8: the fused kernels' element arithmetic is nf_rqs_elem.h's (compile-time K)
+static bool l64_top_k8(const G64Args &a) {
+  static const bool off = std::getenv("NF_L64_TOP_GENERIC_SPLINE") != nullptr;  // A/B switch: the run-time-K arithmetic
+  return a.K == 8 && !off;
+}
 // the nets of one coupling, layer by layer, on the conditioner half of `x` (standard layout); outputs stay in b->act
 static int l64_nets_fwd(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a, const float *theta, const float *x, const L64Bufs &b,
                         bool skip_top = false) {  // skip_top: the output layer is the caller's (k_l64_nsf_top_fwd)
@@ -2082,14 +2122,19 @@ static int l64_apply(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a, in
     const L64Layer L{net.w[last], net.b[last], net.dims[last], net.dims[last + 1], 0};
     static AttrOnce attr_once;
     NF_TRY(attr_once.run(ctx->device, [&]() -> int {
-      NF_HIP(hipFuncSetAttribute((const void *)k_l64_nsf_top_fwd<8>, hipFuncAttributeMaxDynamicSharedMemorySize, L64_TOPF_LDS));
+      NF_HIP(hipFuncSetAttribute((const void *)k_l64_nsf_top_fwd<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, L64_TOPF_LDS));
+      NF_HIP(hipFuncSetAttribute((const void *)k_l64_nsf_top_fwd<8, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, L64_TOPF_LDS));
       return NF_OK;
     }));
     const long pairs = ((a.N + 31) / 32 + 1) / 2;
     const unsigned gridp = (unsigned)std::min<long>(pairs, (long)ctx->num_cu);
     ProfScope ps(ctx, "l64_top_fwd");
-    hipLaunchKernelGGL(k_l64_nsf_top_fwd<8>, dim3(gridp), dim3(512), L64_TOPF_LDS, ctx->stream, a, inverse, theta, L,
-                       (const float *)b.act[0][last - 1], b.F[last - 1], b.act[0][last], b.F[last], xy, ladj, (long long *)ctx->trace);
+    if (l64_top_k8(a))
+      hipLaunchKernelGGL((k_l64_nsf_top_fwd<8, 8>), dim3(gridp), dim3(512), L64_TOPF_LDS, ctx->stream, a, inverse, theta, L,
+                         (const float *)b.act[0][last - 1], b.F[last - 1], b.act[0][last], b.F[last], xy, ladj, (long long *)ctx->trace);
+    else
+      hipLaunchKernelGGL((k_l64_nsf_top_fwd<8, 0>), dim3(gridp), dim3(512), L64_TOPF_LDS, ctx->stream, a, inverse, theta, L,
+                         (const float *)b.act[0][last - 1], b.F[last - 1], b.act[0][last], b.F[last], xy, ladj, (long long *)ctx->trace);
     return (int)hipGetLastError();
   }
   NF_TRY(l64_nets_fwd(ctx, desc, a, theta, xy, b));
@@ -2159,14 +2204,20 @@ static int l64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &
     const L64Layer L{net.w[last], net.b[last], net.dims[last], net.dims[last + 1], 0};
     static AttrOnce attr_once;
     NF_TRY(attr_once.run(ctx->device, [&]() -> int {
-      NF_HIP(hipFuncSetAttribute((const void *)k_l64_nsf_top_bwd<8>, hipFuncAttributeMaxDynamicSharedMemorySize, L64_TOP_LDS));
+      NF_HIP(hipFuncSetAttribute((const void *)k_l64_nsf_top_bwd<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, L64_TOP_LDS));
+      NF_HIP(hipFuncSetAttribute((const void *)k_l64_nsf_top_bwd<8, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, L64_TOP_LDS));
       return NF_OK;
     }));
     {
       ProfScope ps(ctx, "l64_top_bwd");
-      hipLaunchKernelGGL(k_l64_nsf_top_bwd<8>, dim3(gridw), dim3(512), L64_TOP_LDS, ctx->stream, a, inv, theta, L,
-                         (const float *)b.act[0][last], b.F[last], (const float *)b.act[0][last - 1], b.F[last - 1], x, gbar, lbar, lbar_const,
-                         b.gh[0][last - 1], b.GH, slabs, (long)ci.nparams, (long)ci.theta_off, (long long *)ctx->trace);
+      if (l64_top_k8(a))
+        hipLaunchKernelGGL((k_l64_nsf_top_bwd<8, 8>), dim3(gridw), dim3(512), L64_TOP_LDS, ctx->stream, a, inv, theta, L,
+                           (const float *)b.act[0][last], b.F[last], (const float *)b.act[0][last - 1], b.F[last - 1], x, gbar, lbar,
+                           lbar_const, b.gh[0][last - 1], b.GH, slabs, (long)ci.nparams, (long)ci.theta_off, (long long *)ctx->trace);
+      else
+        hipLaunchKernelGGL((k_l64_nsf_top_bwd<8, 0>), dim3(gridw), dim3(512), L64_TOP_LDS, ctx->stream, a, inv, theta, L,
+                           (const float *)b.act[0][last], b.F[last], (const float *)b.act[0][last - 1], b.F[last - 1], x, gbar, lbar,
+                           lbar_const, b.gh[0][last - 1], b.GH, slabs, (long)ci.nparams, (long)ci.theta_off, (long long *)ctx->trace);
       NF_HIP(hipGetLastError());
     }
     // the layers below it in one more launch when there are one or two, none wider than 64 (k_l64_hidden_bwd)
