@@ -63,11 +63,14 @@ def min_knot_distance(spec, th64, ys64):
 bad = 0
 only = int(os.environ.get("FUZZ_ONLY", "-1"))  # replay one case of a sweep with per-layer detail
 shape = os.environ.get("FUZZ_SHAPE", "")       # "kind,d,h1xh2,nl,K,n,f32|f64": force this shape in every case
+nsf_gen = os.environ.get("FUZZ_NSF_GEN") is not None  # every case a general-path spline flow
 for case in range(ncases):
     if only >= 0 and case != only:
         continue
     rng = np.random.default_rng([seed, case])  # one stream per case, so a case replays on its own
     kind = rng.choice(["realnvp", "realnvp", "realnvp", "nsf", "planar", "radial"])
+    if nsf_gen:
+        kind = "nsf"
     f64 = bool(rng.integers(0, 4) == 0)
     K, B = 0, 5.0
     if kind == "realnvp":
@@ -88,6 +91,14 @@ for case in range(ncases):
         d = int(rng.integers(2, 33 if K in (8, 10) else 17))
         hd = (int(rng.integers(1, 33)), int(rng.integers(1, 33)))
         nl = int(rng.integers(1, 3))
+        if nsf_gen:  # the general path's spline couplings (round 5: output layer fused with the spline, k_l64_nsf_top_*)
+            K = int(rng.choice([8, 8, 8, 2, 3, 5, 7, 10]))
+            d = int(rng.integers(2, 41))
+            nh = int(rng.choice([1, 2, 2, 3]))
+            hd = tuple(int(rng.integers(1, 65)) for _ in range(nh))
+            if nh == 2 and max(hd) <= 32 and K in (8, 10):
+                hd = (hd[0], int(rng.integers(33, 65)))  # (hidden <= 32 x 2 at K = 8 / 10 is the fused spline kernels' shape)
+            f64 = False
     else:
         d, hd, nl = int(rng.integers(1, 40)), (), int(rng.integers(1, 6))
     n = int(rng.choice([1, 5, 31, 32, 33, 64, 100, 257]))
