@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) void k_l64_fwd(const float *__restrict__ theta
   L.w_off += blockIdx.y * yy.dtheta; L.b_off += blockIdx.y * yy.dtheta; src.p += blockIdx.y * yy.da; dst += blockIdx.y * yy.db;
   __shared__ __attribute__((aligned(16))) float w[32 * IB * S + 32 * OB];
   float *b = w + 32 * IB * S;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
   l64_stage<IB, OB>(w, b, theta, L, tid, 256);
   __syncthreads();
   const long ntiles = (N + L64_TILE - 1) / L64_TILE;
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(512) void k_l64_fwd_all(const float *__restrict__ t
   constexpr int S = 32 * OB + NF_IMG_PAD, WG = 32 * IB * S + 32 * OB;
   L.w_off += blockIdx.y * yy.dtheta; L.b_off += blockIdx.y * yy.dtheta; src.p += blockIdx.y * yy.da; dst += blockIdx.y * yy.db;
   extern __shared__ __attribute__((aligned(16))) float wdyn[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
   for (int q = 0; q < NG; ++q) {
     L64Layer Lq = L;
     Lq.o0 = 32 * OB * q;
@@ -610,7 +610,7 @@ struct L64Chain {
 __global__ __launch_bounds__(512) void k_l64_fwd_chain(const float *__restrict__ theta, L64Chain ch, L64Src src, long N, L64Y yy) {
   constexpr int S = 64 + NF_IMG_PAD, WG = 64 * S + 64;
   extern __shared__ __attribute__((aligned(16))) float wdyn[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
   src.p += blockIdx.y * yy.da;
   for (int l = 0; l < ch.nl; ++l) {
     const L64Layer L{ch.w_off[l] + (long)blockIdx.y * yy.dtheta, ch.b_off[l] + (long)blockIdx.y * yy.dtheta, ch.nin[l], ch.nout[l], 0};
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(256) void k_l64_bwdx(const float *__restrict__ thet
   L.w_off += blockIdx.y * yy.dtheta; L.b_off += blockIdx.y * yy.dtheta; g.p += blockIdx.y * yy.da; dst += blockIdx.y * yy.dc;
   if (act) act += blockIdx.y * yy.db;
   __shared__ __attribute__((aligned(16))) float w[32 * IB * S + 32 * OB];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
   l64_stage<IB, OB>(w, w + 32 * IB * S, theta, L, tid, 256);
   __syncthreads();
   const long ntiles = (N + L64_TILE - 1) / L64_TILE;
@@ -727,7 +727,7 @@ __global__ __launch_bounds__(512) void k_l64_bwdx_all(const float *__restrict__ 
   L.w_off += blockIdx.y * yy.dtheta; L.b_off += blockIdx.y * yy.dtheta; g.p += blockIdx.y * yy.da; dst += blockIdx.y * yy.dc;
   if (act) act += blockIdx.y * yy.db;
   extern __shared__ __attribute__((aligned(16))) float wdyn[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
   for (int q = 0; q < NG; ++q) {
     L64Layer Lq = L;
     Lq.o0 = 32 * OB * q;
@@ -766,7 +766,7 @@ struct L64BChain {
 __global__ __launch_bounds__(512) void k_l64_bwdx_chain(const float *__restrict__ theta, L64BChain ch, L64Src gtop, int Fd, long N, L64Y yy) {
   constexpr int S = 64 + NF_IMG_PAD, WG = 64 * S + 64;
   extern __shared__ __attribute__((aligned(16))) float wdyn[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
   gtop.p += blockIdx.y * yy.da;
   for (int q = 0; q < ch.nl; ++q) {
     const L64Layer L{ch.w_off[q] + (long)blockIdx.y * yy.dtheta, 0, ch.nin[q], ch.nout[q], 0};
@@ -808,7 +808,7 @@ __global__ __launch_bounds__(256) void k_l64_dw(L64Layer L, L64Src a, L64Src g, 
   L.w_off += blockIdx.y * yy.dtheta; L.b_off += blockIdx.y * yy.dtheta; a.p += blockIdx.y * yy.da; g.p += blockIdx.y * yy.db;
   if (act) act += blockIdx.y * yy.dc;
   extern __shared__ __attribute__((aligned(16))) float sm[];  // 4 (SA + SD) floats (beyond the 64 KB static limit at IB = OB = 2)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
   float *sa = sm + wave * (SA + SD), *sd = sa + SA;
   f32x16 acc[IB][OB];
   float bsum[OB];
@@ -878,7 +878,7 @@ __global__ __launch_bounds__(256) void k_l64_dw_cols(L64Layer L, L64Src a, L64Sr
   L.w_off += blockIdx.y * yy.dtheta; L.b_off += blockIdx.y * yy.dtheta; a.p += blockIdx.y * yy.da; g.p += blockIdx.y * yy.db;
   if (act) act += blockIdx.y * yy.dc;
   extern __shared__ __attribute__((aligned(16))) float sm[];  // SA + 4 SD floats: ONE activation tile, a delta tile per wave
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
   float *sa = sm, *sd = sm + SA + wave * SD;
   const int o0w = 32 * OB * wave;
   f32x16 acc[IB][OB];
@@ -1301,7 +1301,7 @@ __global__ __launch_bounds__(512) void k_l64_nsf_top_bwd(G64Args a, int inv, con
   static_assert(64 * WS <= 2 * SD, "the prologue stages the whole layer in the two delta tiles");
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float *sdt = sm, *sat = sm + 2 * SD, *red = sat + 2 * SA;  // 2 delta tiles, 2 activation tiles, 4 partial cotangents
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
   const int smp = tid & 31, dl = tid >> 5;
   const bool dxw = wave >= 4;
   const int o0w = 96 * (wave & 3);
@@ -1507,7 +1507,7 @@ __global__ __launch_bounds__(512) void k_l64_nsf_top_fwd(G64Args a, int inverse,
   static_assert(64 * WS <= 2 * SD, "the prologue stages the whole layer in the two parameter tiles");
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float *sdt = sm, *sat = sm + 2 * SD, *part = sat + 2 * SA, *bias = part + 2 * L64_DL * NF_TS;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
   const int half = tid >> 8, t256 = tid & 255, smp = tid & 31, dl = (tid >> 5) & 7;
   const int o0w = 96 * (wave & 3);
   {
@@ -1699,7 +1699,7 @@ __global__ __launch_bounds__(256) void k_l64_hidden_bwd(const float *__restrict_
                                                         long slab_off) {
   constexpr int S = 64 + NF_IMG_PAD, WG = 64 * S + 64, SC = 4 * 32 * NF_TS;
   extern __shared__ __attribute__((aligned(16))) float sm[];  // NH weight images, then a scratch pair per wave
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
   for (int l = 0; l < NH; ++l) {
     const L64Layer L{hd.w_off[l], hd.b_off[l], hd.nin[l], hd.nout[l], 0};
     l64_stage<2, 2>(sm + l * WG, sm + l * WG + 64 * S, theta, L, tid, 256);  // (the bias row is staged and not used)
