@@ -1267,11 +1267,14 @@ __global__ __launch_bounds__(256) void k_l64_couple_bwd(G64Args a, int inv, cons
 // presenting the next one at once -- a matrix instruction that waits for the pipe waits in the SIMD's vector issue stage, and
 // the other wave's spline arithmetic waits behind it (measured: its loads, requested at the start of the interval, were
 // consumed only when the matrix stage of the wave beside it had ended)
+#ifndef NF_L64_PACE_NOP
+#define NF_L64_PACE_NOP 11  // 48 clocks of the instruction's 64 (9 / 13 / 15 measured beside it: see profiles/r5g)
+#endif
 struct L64Pace {
   __device__ __forceinline__ void operator()(int) const {
 #ifndef NF_L64_NO_PACE
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_nop 11" ::: "memory");
+    asm volatile("s_nop %0" ::"n"(NF_L64_PACE_NOP) : "memory");
     __builtin_amdgcn_sched_barrier(0);
 #endif
   }
