@@ -1295,7 +1295,11 @@ __global__ __launch_bounds__(512) void k_l64_nsf_top_bwd(G64Args a, int inv, con
                                                          float lbar_const, float *__restrict__ gdst, int Fd, float *__restrict__ slabs,
                                                          long Pc, long slab_off, long long *trace) {
 #ifdef NF_KERNEL_TRACE  // tools/trace_l64_top.py: wave 0 (a dW wave) at [0 ...], wave 4 (a dX wave) at [64 ...] of workgroup 0
+#ifdef NF_TRACE_HIDDEN  // (tools/trace_l64_top.py HIDDEN=1: the buffer is k_l64_hidden_bwd's)
+  long long *tr = nullptr;
+#else
   long long *tr = trace && blockIdx.x == 0 && (threadIdx.x & 255) == 0 ? trace + (threadIdx.x >> 8) * 64 : nullptr;
+#endif
 #define L64T_STAMP(slot) do { if (tr) { __builtin_amdgcn_sched_barrier(0); tr[slot] = clock64(); } } while (0)
 #else
 #define L64T_STAMP(slot) do { } while (0)
@@ -1699,7 +1703,15 @@ __device__ __forceinline__ void l64_fold_to_slab(float *img, const f32x16 (&acc)
 template <int NH, int IB0>
 __global__ __launch_bounds__(256) void k_l64_hidden_bwd(const float *__restrict__ theta, L64Hid hd, const float *__restrict__ gtop, int Fg,
                                                         L64Src xin, float *__restrict__ gbar, long N, float *__restrict__ slabs, long Pc,
-                                                        long slab_off) {
+                                                        long slab_off, long long *trace) {
+#if defined(NF_KERNEL_TRACE) && defined(NF_TRACE_HIDDEN)  // tools/trace_l64_top.py HIDDEN=1: workgroup 0 / wave 0
+  long long *trh = trace && blockIdx.x == 0 && threadIdx.x == 0 ? trace : nullptr;
+#define L64H_STAMP(slot) do { if (trh) { __builtin_amdgcn_sched_barrier(0); trh[slot] = clock64(); } } while (0)
+#else
+#define L64H_STAMP(slot) do { } while (0)
+#endif
+  L64H_STAMP(0);
+  int hslot = 2;
   constexpr int S = 64 + NF_IMG_PAD, WG = 64 * S + 64, SC = 4 * 32 * NF_TS;
   extern __shared__ __attribute__((aligned(16))) float sm[];  // NH weight images, then a scratch pair per wave
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
@@ -1723,10 +1735,23 @@ __global__ __launch_bounds__(256) void k_l64_hidden_bwd(const float *__restrict_
       for (int r = 0; r < 16; ++r) acc0[ib][ob][r] = 0.f;
   }
   const long ntiles = (N + L64_TILE - 1) / L64_TILE;
+  L64H_STAMP(1);
   for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+    L64H_STAMP(hslot + 0);
     f32x16 g[2], hl[2];
     l64_load<2>(L64Src{gtop, Fg, 0, 0, 0}, tile, l31, hi, N, 64, g);
     l64_load<2>(L64Src{hd.act[NH - 1], hd.F[NH - 1], 0, 0, 0}, tile, l31, hi, N, 64, hl);
+    // the first layer's inputs and the cotangent its result is added to: requested with the rest (the matrix stages between
+    // here and their use are fenced, so the compiler leaves a load where it is written: tools/trace_l64_top.py HIDDEN=1 had
+    // 2.2-3.3 k + 3-4 k clocks of a tile's 24 k in these two round trips)
+    f32x16 x0[IB0];
+    l64_load<IB0>(xin, tile, l31, hi, N, hd.nin[0], x0);
+    const L64Io gio = l64_io_std(gbar, xin.d, xin.par, tile, N, l31, hi);
+    float gold[IB0][16];
+#pragma unroll
+    for (int ib = 0; ib < IB0; ++ib)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gold[ib][r] = l64_ld(gio, l64_rc(ib, r) * 8);
     if (NH == 2) {
       f32x16 av[2], din[2];
       l64_load<2>(L64Src{hd.act[0], hd.F[0], 0, 0, 0}, tile, l31, hi, N, 64, av);
@@ -1734,37 +1759,52 @@ __global__ __launch_bounds__(256) void k_l64_hidden_bwd(const float *__restrict_
       for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
         for (int r = 0; r < 16; ++r) g[ob][r] *= hl[ob][r] > 0.f ? 1.f : 0.01f;
+      L64H_STAMP(hslot + 1);
       tile_to_scratch<2>(sa, av, l31, hi);
       tile_to_scratch<2>(sd, g, l31, hi);
       wave_lds_fence();
+      L64H_STAMP(hslot + 2);
       dw_accumulate<2, 2>(sa, sd, acc1, bs1, l31, hi);
       wave_lds_fence();
+      L64H_STAMP(hslot + 3);
       dense_bwd_x<2, 2, S, false>(sm + WG, g, din, l31, hi);
+      L64H_STAMP(hslot + 4);
 #pragma unroll
       for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { g[ib][r] = din[ib][r]; hl[ib][r] = av[ib][r]; }
     }
     {
-      f32x16 av[IB0], din[IB0];
-      l64_load<IB0>(xin, tile, l31, hi, N, hd.nin[0], av);
+      f32x16 din[IB0];
 #pragma unroll
       for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
         for (int r = 0; r < 16; ++r) g[ob][r] *= hl[ob][r] > 0.f ? 1.f : 0.01f;
-      tile_to_scratch<IB0>(sa, av, l31, hi);
+      L64H_STAMP(hslot + 5);
+      tile_to_scratch<IB0>(sa, x0, l31, hi);
       tile_to_scratch<2>(sd, g, l31, hi);
       wave_lds_fence();
       dw_accumulate<IB0, 2>(sa, sd, acc0, bs0, l31, hi);
       wave_lds_fence();
+      L64H_STAMP(hslot + 6);
       dense_bwd_x<IB0, 2, S, false>(sm, g, din, l31, hi);
-      l64_store_din<IB0>(din, gbar, 0, 1, xin.d, xin.par, hd.nin[0], tile, N, l31, hi);
+      L64H_STAMP(hslot + 7);
+#pragma unroll
+      for (int ib = 0; ib < IB0; ++ib)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (l64_rc(ib, r) + 4 * hi < hd.nin[0]) l64_st(gio, l64_rc(ib, r) * 8, gold[ib][r] + din[ib][r]);  // (as l64_store_din)
     }
+    L64H_STAMP(hslot + 8);
+    if (hslot < 40) hslot += 9;
   }
+  L64H_STAMP(60);
   __syncthreads();
+  L64H_STAMP(61);
   float *slab = slabs + (long)blockIdx.x * Pc - slab_off;
   if (NH == 2) l64_fold_to_slab<2, 2>(scr, acc1, bs1, hd.w_off[1], hd.b_off[1], hd.nin[1], hd.nout[1], slab, tid, wave, l31, hi);
   l64_fold_to_slab<IB0, 2>(scr, acc0, bs0, hd.w_off[0], hd.b_off[0], hd.nin[0], hd.nout[0], slab, tid, wave, l31, hi);
+  L64H_STAMP(62);
 }
 #define L64_HID_LDS(NH) (((NH) * (64 * (64 + NF_IMG_PAD) + 64) + 4 * 4 * 32 * NF_TS) * 4)
 
@@ -2245,7 +2285,8 @@ static int l64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &
       return NF_OK;                                                                                                                      \
     }));                                                                                                                                 \
     hipLaunchKernelGGL((k_l64_hidden_bwd<NHv, IBv>), dim3(gridw), dim3(256), L64_HID_LDS(NHv), ctx->stream, theta, hd,                   \
-                       (const float *)b.gh[0][last - 1], b.GH, xin, gbar, a.N, slabs, (long)ci.nparams, (long)ci.theta_off);             \
+                       (const float *)b.gh[0][last - 1], b.GH, xin, gbar, a.N, slabs, (long)ci.nparams, (long)ci.theta_off,              \
+                       (long long *)ctx->trace);                                                                                         \
   } while (0)
       if (last == 2 && ib0 == 2) CALLH(2, 2);
       else if (last == 2) CALLH(2, 1);

@@ -52,3 +52,13 @@ for w, name in ((0, "dW wave"), (1, "dX wave")):
         if s[5] > s[0] > 0:
             print(f"   interval {i}: dW {s[1] - s[0]}  spline of the next tile {s[2] - s[1]}  dX {s[3] - s[2]}  wait {s[4] - s[3]}"
                   f"  cotangent sum + store {s[5] - s[4]}   total {s[5] - s[0]}")
+
+# ---- HIDDEN=1 (library built with NF_KERNEL_TRACE and -DNF_TRACE_HIDDEN): the buffer is k_l64_hidden_bwd's, workgroup 0 / wave 0
+if os.environ.get("HIDDEN"):
+    b = t
+    print(f"k_l64_hidden_bwd: weights staged {b[1] - b[0]}, tiles {b[60] - b[1]}, wait {b[61] - b[60]}, folds + slab {b[62] - b[61]}, total {b[62] - b[0]}")
+    for i in range(5):
+        s = b[2 + 9 * i: 11 + 9 * i]
+        if s[8] > s[0] > 0:
+            print(f"   tile {i}: loads + mask {s[1] - s[0]}  scratch {s[2] - s[1]}  dW1 {s[3] - s[2]}  dX1 {s[4] - s[3]}  x load + mask {s[5] - s[4]}"
+                  f"  scratch + dW0 {s[6] - s[5]}  dX0 {s[7] - s[6]}  gbar += {s[8] - s[7]}   total {s[8] - s[0]}")
