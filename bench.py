@@ -32,6 +32,7 @@ from __future__ import annotations
 
 import argparse
 import ctypes as C
+import datetime
 import json
 import os
 import socket
@@ -568,7 +569,10 @@ def main():
             local_rank = 0
         torch.cuda.set_device(local_rank)
         if one_device:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            # gloo picks its interface by resolving the host name, which a container's may not do (or only after a long
+            # stall: one 600 s hang of this path on a reused test box in round 5); the ranks are on this host by construction
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
