@@ -749,9 +749,7 @@ __device__ __forceinline__ float lrelu_slope(unsigned mask, int r) { return nf_m
 template <int NB>
 __device__ __forceinline__ void apply_lrelu_grad(f32x16 (&d)[NB], const unsigned (&m)[NB]) {
 #pragma unroll
-  for (int b = 0; b < NB; ++b)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) d[b][r] *= lrelu_slope(m[b], r);
+  for (int b = 0; b < NB; ++b) nf_lrelu_grad16(d[b], m[b]);
 }
 
 // per-wave LDS scratch of the reverse pass, [feature][sample] tiles with row stride NF_TS:
@@ -1722,16 +1720,18 @@ __device__ __forceinline__ void pair_consume(const float *__restrict__ img, cons
 template <class G>
 __device__ __forceinline__ void pair_slab_write(const float *__restrict__ lds, float *__restrict__ dstf, int tid) {
   const float4 *c0 = reinterpret_cast<const float4 *>(lds);
-  float4 *dst = reinterpret_cast<float4 *>(dstf);
   constexpr int NV4 = G::SIZE / 4;
+  // through a buffer descriptor: the slab's base is wave-uniform and the element offset 32 bits wide -- as a flat pointer the
+  // 64-bit per-lane address of this loop cost the consumer two registers it does not have (12 bytes of scratch, round 5)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(dstf, 0, G::SIZE * 4, 0x00020000);
   for (int i = tid; i < NV4; i += 512) {
     const float4 p0 = c0[i], p1 = c0[i + NV4], p2 = c0[i + 2 * NV4], p3 = c0[i + 3 * NV4];
-    float4 r;
-    r.x = (p0.x + p1.x) + (p2.x + p3.x);
-    r.y = (p0.y + p1.y) + (p2.y + p3.y);
-    r.z = (p0.z + p1.z) + (p2.z + p3.z);
-    r.w = (p0.w + p1.w) + (p2.w + p3.w);
-    dst[i] = r;
+    u32x4 r;
+    r[0] = __builtin_bit_cast(unsigned, (p0.x + p1.x) + (p2.x + p3.x));
+    r[1] = __builtin_bit_cast(unsigned, (p0.y + p1.y) + (p2.y + p3.y));
+    r[2] = __builtin_bit_cast(unsigned, (p0.z + p1.z) + (p2.z + p3.z));
+    r[3] = __builtin_bit_cast(unsigned, (p0.w + p1.w) + (p2.w + p3.w));
+    nf_buffer_store_b128(r, rs, i * 16, 0);
   }
 }
 

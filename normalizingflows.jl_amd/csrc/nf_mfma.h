@@ -116,6 +116,28 @@ __device__ __forceinline__ float nf_mask_slope(unsigned mask, int r) {
 #endif
 }
 __device__ __forceinline__ float nf_exp(float x) { return __expf(x); }
+// a whole cotangent block times its slopes, 2.5 instructions per element and no more: v_bfe_i32 (0 / -1 from the element's mask
+// bit), v_bitop3_b32 ((t & (1.0 ^ 0.01)) ^ 1.0 -> the slope's bit pattern), one v_pk_mul_f32 per pair.  In inline asm because hipcc
+// 7.2, left to itself, evaluates the block TWICE when the product feeds both a conversion and an MFMA C operand (once with a
+// five-instruction slope), seen in the pair kernel's ISA: 9 instructions per element (round 6).
+__device__ __forceinline__ void nf_lrelu_grad16(f32x16 &d, unsigned mask) {
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const unsigned one = 0x3F800000u, flip = 0x3F800000u ^ 0x3C23D70Au;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    int t0, t1;
+    unsigned s0, s1;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(t0) : "v"(mask), "n"(15 - 2 * p));
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(t1) : "v"(mask), "n"(14 - 2 * p));
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x6c" : "=v"(s0) : "v"(t0), "v"(one), "v"(flip));
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x6c" : "=v"(s1) : "v"(t1), "v"(one), "v"(flip));
+    f32x2_t v = {d[2 * p], d[2 * p + 1]};
+    const f32x2_t sl = {__builtin_bit_cast(float, s0), __builtin_bit_cast(float, s1)};
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(v) : "v"(v), "v"(sl));
+    d[2 * p] = v.x;
+    d[2 * p + 1] = v.y;
+  }
+}
 
 // LDS image of one Dense layer: W[i][o] at w[i * S + o], S = 32*OB + 1 (odd stride so
 // that both the forward (lanes along o) and the transposed (lanes along i) operand
@@ -492,7 +514,7 @@ struct NetDims {
   long w1, b1, w2, b2, w3, b3;  // offsets into theta (Optimisers.destructure order)
 };
 
-__host__ __device__ inline NetDims make_net_dims(long off, int m, int h1, int h2, int c) {
+__host__ __device__ __forceinline__ NetDims make_net_dims(long off, int m, int h1, int h2, int c) {
   NetDims n;
   n.m = m; n.h1 = h1; n.h2 = h2; n.c = c;
   n.w1 = off; n.b1 = n.w1 + (long)m * h1;
@@ -500,7 +522,7 @@ __host__ __device__ inline NetDims make_net_dims(long off, int m, int h1, int h2
   n.w3 = n.b2 + h2; n.b3 = n.w3 + (long)h2 * c;
   return n;
 }
-__host__ __device__ inline long net_param_count(int m, int h1, int h2, int c) {
+__host__ __device__ __forceinline__ long net_param_count(int m, int h1, int h2, int c) {
   return (long)m * h1 + h1 + (long)h1 * h2 + h2 + (long)h2 * c + c;
 }
 
@@ -554,11 +576,18 @@ __device__ __forceinline__ void stage_packed(float *__restrict__ img, const floa
 // theta index of element `e` of a net's padded image, or -1 for padding
 template <class G>
 __device__ __forceinline__ long image_theta_index(const NetDims &nd, int e) {
-  int rows, S, nin, nout, base;
-  long w, b;
-  if (e < G::W2) { base = G::W1; rows = 32 * G::MB; S = G::S1; nin = nd.m; nout = nd.h1; w = nd.w1; b = nd.b1; }
-  else if (e < G::W3) { base = G::W2; rows = 32 * G::H1B; S = G::S2; nin = nd.h1; nout = nd.h2; w = nd.w2; b = nd.b2; }
-  else { base = G::W3; rows = 32 * G::H2B; S = G::S3; nin = nd.h2; nout = nd.c; w = nd.w3; b = nd.b3; }
+  // selects on VALUES: written as assignments inside an if-chain hipcc keeps the six offsets in a 48-byte scratch array and
+  // indexes it by layer (seen as private_segment_fixed_size 48 in every kernel that calls this; tests/test_kernel_resources_cpu.py)
+  const bool l1 = e < G::W2, l2 = e < G::W3;
+  const int base = l1 ? G::W1 : l2 ? G::W2 : G::W3;
+  const int rows = l1 ? 32 * G::MB : l2 ? 32 * G::H1B : 32 * G::H2B;
+  const int S = l1 ? G::S1 : l2 ? G::S2 : G::S3;
+  const int dm = nd.m, dh1 = nd.h1, dh2 = nd.h2, dc = nd.c;
+  const int nin = l1 ? dm : l2 ? dh1 : dh2;
+  const int nout = l1 ? dh1 : l2 ? dh2 : dc;
+  const long w1 = nd.w1, w2 = nd.w2, w3 = nd.w3, b1 = nd.b1, b2 = nd.b2, b3 = nd.b3;
+  const long w = l1 ? w1 : l2 ? w2 : w3;
+  const long b = l1 ? b1 : l2 ? b2 : b3;
   const int r = e - base;
   if (r < rows * S) {
     const int i = r / S, o = r - i * S;
@@ -679,6 +708,61 @@ __device__ __forceinline__ void nf_split8(const float (&v)[8], nf_u32x4 &h, nf_u
 }
 __device__ __forceinline__ f32x16 nf_mfma_bf16(nf_u32x4 a, nf_u32x4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nf_bf16x8, a), __builtin_bit_cast(nf_bf16x8, b), c, 0, 0, 0);
+}
+
+// ---- the split with its two exact subtractions ON THE MATRIX PIPE (round 6) -----------------------------------------------
+// nf_split2 spends 4.5 vector instructions per value, two thirds of them on r = x - h and l = r - m (widen h: shl + and per
+// pair, then v_pk_add_f32; the same for m).  Both differences are exact, and an MFMA computes exact differences for free:
+//     D = C + A B   with C = the fp32 block x (16 registers per lane, C layout), B = its packed bf16 part h (the very
+//                   registers the split produces), A = MINUS the selection matrix that maps B's k-order onto C's rows
+// gives D = x - h for the whole 32 x 32 block: every output is ONE product (-1 x h, exact) plus C, and x - h is a multiple
+// of ulp(x) below 2^-8 |x|, so the instruction's adder has nothing to drop (tools/probe/split_mfma_probe.hip compares all
+// three parts bit for bit with nf_split2 on random, tie, subnormal-adjacent and huge inputs).  A block of 16 values then
+// costs 8 + 8 + 8 conversions (1.5 instructions per value) and four v_mfma_f32_32x32x16_bf16 (two k-groups x two levels),
+// in kernels whose matrix pipe is a third busy and whose vector issue port is the bottleneck.
+// The selection operand: hardware k = 8 hi + j of k-group g is C row 16 g + (j & 3) + 8 (j >> 2) + 4 hi (nf_row(8 g + j, hi)),
+// so lane (row i = l31, half hi) holds -1 at element j iff i - 16 g - 4 hi = (j & 3) + 8 (j >> 2), zeros elsewhere.
+struct SplitSel {
+  nf_u32x4 a[2];  // A operands of the two k-groups
+};
+__device__ __forceinline__ SplitSel nf_split_sel(int l31, int hi) {
+  SplitSel s;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int q = l31 - 16 * g - 4 * hi;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int j0 = 2 * p, j1 = 2 * p + 1;
+      const unsigned lo = q == (j0 & 3) + 8 * (j0 >> 2) ? 0xBF80u : 0u, hv = q == (j1 & 3) + 8 * (j1 >> 2) ? 0xBF800000u : 0u;
+      s.a[g][p] = lo | hv;
+    }
+  }
+  // pinned: hipcc otherwise rematerialises the eight compares + selects in front of every use
+  asm volatile("" : "+v"(s.a[0]), "+v"(s.a[1]));
+  return s;
+}
+// one C-layout block (16 values per lane) -> its triples per k-group g = register >> 3: h[g], m[g], l[g]
+__device__ __forceinline__ void nf_split16_mfma(const SplitSel &sel, const f32x16 &x, nf_u32x4 (&h)[2], nf_u32x4 (&m)[2],
+                                                nf_u32x4 (&l)[2]) {
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) h[g][p] = nf_cvt_pk_bf16(nf_f32x2{x[8 * g + 2 * p], x[8 * g + 2 * p + 1]});
+  f32x16 r = nf_mfma_bf16(sel.a[0], h[0], x);
+  r = nf_mfma_bf16(sel.a[1], h[1], r);  // r = x - h
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) m[g][p] = nf_cvt_pk_bf16(nf_f32x2{r[8 * g + 2 * p], r[8 * g + 2 * p + 1]});
+  f32x16 lo = nf_mfma_bf16(sel.a[0], m[0], r);
+  lo = nf_mfma_bf16(sel.a[1], m[1], lo);  // lo = r - m: at most 8 significant bits, its upper half IS the value
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const float e0 = lo[8 * g + 2 * p], e1 = lo[8 * g + 2 * p + 1];  // (scalars first: bit_cast of a vector element, see nf_coupling.hip)
+      l[g][p] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, e1), __builtin_bit_cast(unsigned, e0), 0x07060302u);
+    }
 }
 
 // B6 image of one net (geometry G = NetGeo<..>), in 16-byte units: per layer [k-group][component h|m|l][half][row][8 bf16],
@@ -817,6 +901,84 @@ __device__ __forceinline__ void dense_fwd_b6p(const nf_u32x4 *__restrict__ w, co
   }
 }
 
+// The six-term layer with its input split on the matrix pipe (round 6; nf_split16_mfma in three stages).  A whole input block
+// (two k-groups) is split at a time, one block ahead of the GEMM: stage A (8 conversions, the two MFMAs of r = x - h) in front
+// of the current block's first k-group, stage B (8 conversions, l' = r - m) in front of its second, stage C (8 v_perm) behind
+// it -- every MFMA result is consumed a k-group (6 OB MFMAs) after its issue.  Per input block 24 vector instructions and 4
+// MFMAs instead of 72 vector instructions; the terms of every accumulator in dense_fwd_b6's order: bit-identical results.
+template <int IB, int OB>
+__device__ __forceinline__ void dense_fwd_b6m(const SplitSel &sel, const nf_u32x4 *__restrict__ w, const float *__restrict__ b,
+                                              const f32x16 (&in)[IB], f32x16 (&out)[OB], int l31, int hi) {
+  constexpr int ROWS = 32 * OB, NKG = 2 * IB;
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[ob][r] = b[ob * 32 + nf_row(r, hi)];
+  const nf_u32x4 *wl = w + hi * ROWS + l31;  // lane part of the address; (k-group, component, block) are immediates
+  nf_u32x4 an[OB][3];
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) an[ob][c] = wl[c * 2 * ROWS + ob * 32];
+  nf_u32x4 ch[2], cm[2], cl[2], nh[2], nm[2], nl[2];
+  nf_split16_mfma(sel, in[0], ch, cm, cl);
+  f32x16 res;  // the residual of the block being split: r after stage A, l' after stage B
+#pragma unroll
+  for (int kg = 0; kg < NKG; ++kg) {
+    const int ib = kg >> 1, g = kg & 1;
+    nf_u32x4 ac[OB][3];
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) ac[ob][c] = an[ob][c];
+    __builtin_amdgcn_sched_barrier(0);
+    if (kg + 1 < NKG) {
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) an[ob][c] = wl[((kg + 1) * 3 + c) * 2 * ROWS + ob * 32];
+    }
+    if (ib + 1 < IB) {
+      if (g == 0) {  // stage A
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int p = 0; p < 4; ++p) nh[q][p] = nf_cvt_pk_bf16(nf_f32x2{in[ib + 1][8 * q + 2 * p], in[ib + 1][8 * q + 2 * p + 1]});
+        res = nf_mfma_bf16(sel.a[0], nh[0], in[ib + 1]);
+        res = nf_mfma_bf16(sel.a[1], nh[1], res);
+      } else {  // stage B
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int p = 0; p < 4; ++p) nm[q][p] = nf_cvt_pk_bf16(nf_f32x2{res[8 * q + 2 * p], res[8 * q + 2 * p + 1]});
+        res = nf_mfma_bf16(sel.a[0], nm[0], res);
+        res = nf_mfma_bf16(sel.a[1], nm[1], res);
+      }
+    }
+    // smallest terms first: wl xh, wh xl, wm xm, wm xh, wh xm, wh xh (components: 0 = h, 1 = m, 2 = l)
+#pragma unroll
+    for (int term = 0; term < 6; ++term)
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob) {
+        const nf_u32x4 &av = term == 0 ? ac[ob][2] : (term == 2 || term == 3) ? ac[ob][1] : ac[ob][0];
+        const nf_u32x4 &xv = term == 1 ? cl[g] : (term == 2 || term == 4) ? cm[g] : ch[g];
+        out[ob] = nf_mfma_bf16(av, xv, out[ob]);
+      }
+    if (ib + 1 < IB && g == 1) {  // stage C, and the hand-over
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const float e0 = res[8 * q + 2 * p], e1 = res[8 * q + 2 * p + 1];
+          nl[q][p] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, e1), __builtin_bit_cast(unsigned, e0), 0x07060302u);
+        }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) { ch[q] = nh[q]; cm[q] = nm[q]; cl[q] = nl[q]; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // The transposed counterpart for the dX GEMMs of the reverse pass (din = W^T delta): rows = the layer's INPUT features, the
 // k-groups run over its OUTPUT features, in the order the cotangent's C-layout registers hold them (same mapping as above).
 // Per layer [k-group][component][half][row][8 bf16]; no biases.  T3 serves dX3 (rows: a2 features), T2 dX2, T1 dX1.
@@ -885,6 +1047,17 @@ __device__ __forceinline__ void split_C(const f32x16 (&d)[NB], SplitC<NB> &s) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = d[kg >> 1][8 * (kg & 1) + j];
     nf_split8(v, s.h[kg], s.m[kg], s.l[kg]);
+  }
+}
+// the same triples with the subtractions on the matrix pipe (nf_split16_mfma): 1.5 vector instructions per value instead of 4.5
+template <int NB>
+__device__ __forceinline__ void split_C(const SplitSel &sel, const f32x16 (&d)[NB], SplitC<NB> &s) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    nf_u32x4 h[2], m[2], l[2];
+    nf_split16_mfma(sel, d[b], h, m, l);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) { s.h[2 * b + g] = h[g]; s.m[2 * b + g] = m[g]; s.l[2 * b + g] = l[g]; }
   }
 }
 // dense_bwd_x_b6 on a cotangent that arrives split
@@ -964,6 +1137,17 @@ __device__ __forceinline__ void split_T(const float (&at)[IB][16], SplitT<IB> &s
       nf_split8(v, s.h[ib][g], s.m[ib][g], s.l[ib][g]);
       __builtin_amdgcn_sched_barrier(0);  // one split at a time: interleaved, their temporaries (3 x 8 each) spill the accumulators
     }
+}
+
+template <int IB>
+__device__ __forceinline__ void split_T(const SplitSel &sel, const float (&at)[IB][16], SplitT<IB> &s) {
+#pragma unroll
+  for (int ib = 0; ib < IB; ++ib) {
+    f32x16 x;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = at[ib][r];
+    nf_split16_mfma(sel, x, s.h[ib], s.m[ib], s.l[ib]);
+  }
 }
 
 // Both operands arrive split: the activation from split_T, the cotangent as the bf16 triples the PRODUCER wave made for its own

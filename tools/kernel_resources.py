@@ -9,10 +9,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin/"
 
 
-def main():
+def kernel_table(bdir=None):
+    """[(demangled name, agpr, vgpr, sgpr, scratch bytes, static LDS bytes)] of every kernel in the objects under `bdir`
+    (default: the in-tree build directory).  Needs only the LLVM binutils of the ROCm image: runs in the build container."""
     tmp = "/tmp/nfhip_co"
     os.makedirs(tmp, exist_ok=True)
-    bdir = os.path.join(ROOT, "normalizingflows.jl_amd", "build")
+    bdir = bdir or os.path.join(ROOT, "normalizingflows.jl_amd", "build")
     rows = []
     for obj in sorted(f for f in os.listdir(bdir) if f.endswith(".o")):
         fb, co = os.path.join(tmp, obj + ".fatbin"), os.path.join(tmp, obj + ".co")
@@ -26,10 +28,13 @@ def main():
             g = lambda k: (re.search(rf"\.{k}:\s*(\S+)", blk) or [None, "?"])[1]
             rows.append((g("name"), blk.split()[0], g("vgpr_count"), g("sgpr_count"), g("private_segment_fixed_size"), g("group_segment_fixed_size")))
     names = subprocess.run(["c++filt"], input="\n".join(r[0] for r in rows), capture_output=True, text=True).stdout.split("\n")
-    rows = [(n,) + r[1:] for n, r in zip(names, rows)]
+    return [(n,) + tuple(int(x) if x.isdigit() else x for x in r[1:]) for n, r in zip(names, rows)]
+
+
+def main():
     keys = sys.argv[1:]
     print(f"{'agpr':>5} {'vgpr':>5} {'sgpr':>5} {'scratch':>8} {'lds':>7}  kernel")
-    for name, ag, vg, sg, sc, lds in sorted(rows):
+    for name, ag, vg, sg, sc, lds in sorted(kernel_table()):
         if keys and not any(k in name for k in keys):
             continue
         print(f"{ag:>5} {vg:>5} {sg:>5} {sc:>8} {lds:>7}  {name[:150]}")
