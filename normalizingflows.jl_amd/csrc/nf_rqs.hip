@@ -24,6 +24,20 @@
 
 #include "nf_common.h"
 #include "nf_mfma.h"
+// k_rqs_bwd_coop6: the wave's weight triples as MFMA operands straight from the accumulation registers (nf_mfma_bf16_wa)
+#ifndef NF_RQS6_W_IN_ACC
+#define NF_RQS6_W_IN_ACC 1
+#endif
+#if NF_RQS6_W_IN_ACC
+#define RQS6_MFMA_W(a, b, c) nf_mfma_bf16_wa(a, b, c)
+#define RQS6_SETTLE(c) nf_mfma_settle(c)
+#else
+#define RQS6_MFMA_W(a, b, c) nf_mfma_bf16(a, b, c)
+#define RQS6_SETTLE(c) ((void)0)
+#endif
+#ifndef NF_RQS6_SPLIT_MFMA
+#define NF_RQS6_SPLIT_MFMA 0  // k_rqs_bwd_coop6: the splits' subtractions on the matrix pipe (nf_split16_mfma)
+#endif
 #include "nf_philox.h"
 
 template <int MB_, int H1B_, int H2B_, int K_, int NCH_, int QCH_ = 2>
@@ -517,13 +531,18 @@ __global__ __launch_bounds__(512) void k_rqs_chain(RqsChainArgs a, float *xt, fl
       // elbo_j = log p(y_j) - log q0(x_j) + ladj_j ;  ybar = gscale * grad log p(y)
       const TileIO gio = make_tile_io(fa.gt ? fa.gt : xt, tl, a.d, l31, hi);
       float t = 0.f;
+      // ONE lane-dependent base per table, made opaque here: the tables sit beyond the 64 KB a ds_read's immediate offset
+      // reaches, and hipcc otherwise materialises an address register per element in the kernel's prologue and keeps the
+      // thirty-two of them across the tile loop (fifteen in scratch: 64 bytes, round 5)
+      const float *tm = tmu + 8 * hi, *tv = tiv + 8 * hi;
+      asm volatile("" : "+v"(tm), "+v"(tv));
 #pragma unroll
       for (int b = 0; b < G::CB; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int fe = 2 * (b * 32 + nf_row(r, hi));
-          const float re = E[b][r] - tmu[fe], ro = O[b][r] - tmu[fe + 1];
-          const float ge = re * tiv[fe], go = ro * tiv[fe + 1];
+          const int fe = 2 * (b * 32 + (r & 3) + 8 * (r >> 2));  // + 8 hi: in the bases
+          const float re = E[b][r] - tm[fe], ro = O[b][r] - tm[fe + 1];
+          const float ge = re * tv[fe], go = ro * tv[fe + 1];
           t += re * ge + ro * go;
           if (fa.gt && live) {
             tile_store(gio, tile_soff(b, r, 0), valid ? -fa.gscale * ge : 0.f);
@@ -1443,6 +1462,9 @@ __device__ __forceinline__ void rqs_bwd_coop6_coupling(const RqsBwdArgs &a, floa
     float4 *d1 = reinterpret_cast<float4 *>(img + G::W3);
     for (int i = tid; i < G::NCOLS / 4; i += 256) d1[i] = s1[i];
   }
+#if NF_RQS6_SPLIT_MFMA
+  const SplitSel sel6 = nf_split_sel(l31, hi);
+#endif
   RqsW6<G> W;
   {
     const nf_u32x4 *wf = a.img6 + (size_t)ch * B::F_CH + hi * B::FROWS + l31;
@@ -1510,7 +1532,11 @@ __device__ __forceinline__ void rqs_bwd_coop6_coupling(const RqsBwdArgs &a, floa
       }
       // a2 as bf16 triples, once for the four chunk waves: in B-operand order and transposed
       SplitC<G::H2B> s2;
+#if NF_RQS6_SPLIT_MFMA
+      split_C<G::H2B>(sel6, a2, s2);
+#else
       split_C<G::H2B>(a2, s2);
+#endif
       nf_u32x4 *pc_ = reinterpret_cast<nf_u32x4 *>(wv + L::A2C) + lane;
 #pragma unroll
       for (int kg = 0; kg < 2 * G::H2B; ++kg) {
@@ -1566,14 +1592,15 @@ __device__ __forceinline__ void rqs_bwd_coop6_coupling(const RqsBwdArgs &a, floa
             const nf_u32x4 xh = pa[(kg * 3 + 0) * 64], xm = pa[(kg * 3 + 1) * 64], xl = pa[(kg * 3 + 2) * 64];
 #pragma unroll
             for (int ob = 0; ob < G::OBC; ++ob) {  // smallest terms first, as dense_fwd_b6
-              out[ob] = nf_mfma_bf16(W.f[kg][ob][2], xh, out[ob]);
-              out[ob] = nf_mfma_bf16(W.f[kg][ob][0], xl, out[ob]);
-              out[ob] = nf_mfma_bf16(W.f[kg][ob][1], xm, out[ob]);
-              out[ob] = nf_mfma_bf16(W.f[kg][ob][1], xh, out[ob]);
-              out[ob] = nf_mfma_bf16(W.f[kg][ob][0], xm, out[ob]);
-              out[ob] = nf_mfma_bf16(W.f[kg][ob][0], xh, out[ob]);
+              out[ob] = RQS6_MFMA_W(W.f[kg][ob][2], xh, out[ob]);
+              out[ob] = RQS6_MFMA_W(W.f[kg][ob][0], xl, out[ob]);
+              out[ob] = RQS6_MFMA_W(W.f[kg][ob][1], xm, out[ob]);
+              out[ob] = RQS6_MFMA_W(W.f[kg][ob][1], xh, out[ob]);
+              out[ob] = RQS6_MFMA_W(W.f[kg][ob][0], xm, out[ob]);
+              out[ob] = RQS6_MFMA_W(W.f[kg][ob][0], xh, out[ob]);
             }
           }
+          RQS6_SETTLE(out);
         }
         // ---- the spline and its reverse pass, in place (as k_rqs_bwd_coop)
 #pragma unroll
@@ -1636,24 +1663,32 @@ __device__ __forceinline__ void rqs_bwd_coop6_coupling(const RqsBwdArgs &a, floa
 #pragma unroll
           for (int pc = 0; pc < G::OBC; ++pc) {
             char *ring = wv + L::DT + (pc & 1) * (32 * D6_ROW);
+#if NF_RQS6_SPLIT_MFMA
+            nf_u32x4 bh[2], bm[2], bl[2];  // the block's triples, subtractions on the matrix pipe (nf_split16_mfma)
+            nf_split16_mfma(sel6, out[pc], bh, bm, bl);
+#endif
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
               const int kg = 2 * pc + g;
+#if NF_RQS6_SPLIT_MFMA
+              const nf_u32x4 dh = bh[g], dm = bm[g], dl = bl[g];
+#else
               float v[8];
 #pragma unroll
               for (int jj = 0; jj < 8; ++jj) v[jj] = out[pc][8 * g + jj];
               nf_u32x4 dh, dm, dl;
               nf_split8(v, dh, dm, dl);
+#endif
               rqs_kg_to_d6(ring, g, dh, dm, dl, l31, hi);
 #pragma unroll
               for (int ib = 0; ib < G::H2B; ++ib) {
                 f32x16 &dd = d2p[ib];
-                dd = nf_mfma_bf16(W.t[kg][ib][2], dh, dd);
-                dd = nf_mfma_bf16(W.t[kg][ib][0], dl, dd);
-                dd = nf_mfma_bf16(W.t[kg][ib][1], dm, dd);
-                dd = nf_mfma_bf16(W.t[kg][ib][1], dh, dd);
-                dd = nf_mfma_bf16(W.t[kg][ib][0], dm, dd);
-                dd = nf_mfma_bf16(W.t[kg][ib][0], dh, dd);
+                dd = RQS6_MFMA_W(W.t[kg][ib][2], dh, dd);
+                dd = RQS6_MFMA_W(W.t[kg][ib][0], dl, dd);
+                dd = RQS6_MFMA_W(W.t[kg][ib][1], dm, dd);
+                dd = RQS6_MFMA_W(W.t[kg][ib][1], dh, dd);
+                dd = RQS6_MFMA_W(W.t[kg][ib][0], dm, dd);
+                dd = RQS6_MFMA_W(W.t[kg][ib][0], dh, dd);
               }
             }
             wave_lds_order();
@@ -1681,6 +1716,7 @@ __device__ __forceinline__ void rqs_bwd_coop6_coupling(const RqsBwdArgs &a, floa
             }
             wave_lds_order();
           }
+          RQS6_SETTLE(d2p);
           float *mys = slots + ((t & 1) * 4 + wave) * L::SLOT;
 #pragma unroll
           for (int b = 0; b < G::H2B; ++b)

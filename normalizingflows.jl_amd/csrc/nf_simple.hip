@@ -1477,7 +1477,9 @@ struct RadialGeo {
   static constexpr int OFF_TG = ((OFF_BH + NL + 3) / 4) * 4;  // target: mu[f] | 1/var[f] | log 2pi + log var[f]
   static constexpr int SHARED = OFF_TG + 3 * FD;
   static constexpr int ROW = NL * FD + 2 * NL;      // per wave, block epilogue: z0bar[l][f] | alpha_bar[l] | betahat_bar[l]
-  static constexpr size_t lds_floats(int nl, int lp) { return (size_t)SHARED + 4 * (size_t)ROW + (size_t)nl * lp; }
+  static constexpr int RS = NL * 64;                // per wave: the stashed r_l of every layer, [NL][lane] (round 6: 20 registers
+                                                    // of the d = 64 instantiations went to scratch for them)
+  static constexpr size_t lds_floats(int nl, int lp) { return (size_t)SHARED + 4 * (size_t)ROW + (size_t)nl * lp + 4 * (size_t)RS; }
 };
 
 template <class RG, bool DIAG>
@@ -1510,12 +1512,8 @@ __global__ __launch_bounds__(SB, 2) void k_radial_step(SimpleArgs a, const float
     }
   __syncthreads();
   auto sc = [&](int off) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sh[off]))); };
-  float al[NL], bhv[NL];
-#pragma unroll
-  for (int l = 0; l < NL; ++l) {
-    al[l] = sc(RG::OFF_A + l);
-    bhv[l] = sc(RG::OFF_BH + l);
-  }
+  // (alpha_l, beta_hat_l are fetched where they are used, inside the tile loop: held in 2 NL registers across it they were what
+  // the d = 64 instantiations spilled -- 84 bytes of scratch at ten layers, round 5)
   // acc: z0bar of the feature wave_transpose_reduce32 leaves in this lane; sab: both half-waves carry every sample, so the
   // lower half sums the samples' alpha_bar terms and the upper half their betahat_bar terms (one register per layer)
   float acc[NL], sab[NL];
@@ -1558,11 +1556,10 @@ __global__ __launch_bounds__(SB, 2) void k_radial_step(SimpleArgs a, const float
         }
       }
     // ---- forward: r_l is all that is kept of a layer
-    float rs[NL];
+    float *rs = cache + nl * LP + wave * RG::RS + lane;  // rs[l * 64]: this lane's r_l, written and read by the same lane
     float lsum = 0.f;
 #pragma unroll
     for (int l = NL - 1; l >= 0; --l) {
-      rs[l] = 0.f;
       if (l < nl) {
         const float *cl = sh + RG::OFF_C + l * FD + 4 * hi;
         f32x16 dl[DB];
@@ -1581,13 +1578,13 @@ __global__ __launch_bounds__(SB, 2) void k_radial_step(SimpleArgs a, const float
             }
           }
         const float r = Fm<float>::sqrt_(planar_xhalf_sum(s2));
-        const float h = Fm<float>::div_(1.f, al[l] + r), qv = bhv[l] * h;
+        const float h = Fm<float>::div_(1.f, sc(RG::OFF_A + l) + r), qv = sc(RG::OFF_BH + l) * h;
 #pragma unroll
         for (int b = 0; b < DB; ++b)
 #pragma unroll
           for (int e = 0; e < 16; ++e) z[b][e] += qv * dl[b][e];
         lsum += dm1 * Fm<float>::log1p_(qv) + Fm<float>::log1p_(qv - qv * h * r);
-        rs[l] = r;
+        rs[l * 64] = r;
       }
     }
     // ---- target: log p(y), g = gscale grad log p(y)
@@ -1645,7 +1642,7 @@ __global__ __launch_bounds__(SB, 2) void k_radial_step(SimpleArgs a, const float
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
       if (l < nl) {
-        const float alpha = al[l], bh = bhv[l], r = rs[l];
+        const float alpha = sc(RG::OFF_A + l), bh = sc(RG::OFF_BH + l), r = rs[l * 64];
         const float h = Fm<float>::div_(1.f, alpha + r), qq = bh * h, bah2 = bh * alpha * h * h;
         const float iq = Fm<float>::div_(1.f, 1.f + qq), ib = Fm<float>::div_(1.f, 1.f + bah2), ir = r > 0.f ? Fm<float>::div_(1.f, r) : 0.f;
         const float *cl = sh + RG::OFF_C + l * FD + 4 * hi;

@@ -1340,6 +1340,15 @@ def fp32_recompute_kink_floor(spec, th64, otgt, xs64, gref, nseeds=12):
     return max(errs), errs[0]
 
 
+KINK_CAP = 1e-2  # no jitter outlier may license more than this: a recompute gradient off by > 1 % of |g|inf is wrong
+
+
+def recompute_bound(kink):
+    """The asserted bound of an invertible-recompute gradient: the stated tolerance, or CFLOOR x the measured kink floor, but
+    never more than KINK_CAP of |g|inf."""
+    return max(P.GRAD_RTOL, min(P.CFLOOR * kink, KINK_CAP))
+
+
 @pytest.mark.parametrize("shape", ["d64_h64", "d20_h32", "d63_h40x64"])
 def test_realnvp_step_stash_and_recompute_reverse_passes_against_oracle(nf, shape):
     """The LDS-resident RealNVP training step has two reverse passes: from the forward's activation stash
@@ -1385,10 +1394,49 @@ def test_realnvp_step_stash_and_recompute_reverse_passes_against_oracle(nf, shap
                     P.record(f"realnvp {shape} {mode} ({form}): step grad [max abs err / |g|inf]", err)
                     P.record(f"realnvp {shape} {mode} ({form}): step grad [fp32 reconstruct-by-inversion oracle, max abs err / |g|inf]", frec)
                     P.record(f"realnvp {shape} {mode} ({form}): step grad [same oracle, worst of 12 last-bit jitters of the forward output]", kink)
-                    assert err <= max(P.GRAD_RTOL, P.CFLOOR * kink), (shape, form, err, frec, kink)
+                    assert err <= recompute_bound(kink), (shape, form, err, frec, kink)
     finally:
         nf._lib.check(lib.nf_ctx_set_stash_budget(ctx.ptr, -1))
     assert need["stash"] > need["recompute"] > 0
+
+
+@pytest.mark.parametrize("hd", [(64, 64, 64), (64,)], ids=["3hidden", "1hidden"])
+def test_deep_realnvp_step_at_eight_couplings_and_a_large_batch_against_oracle(nf, hd):
+    """The fused kernels of nf_deep.hip (RealNVP nets with 1 / 3 / 4 hidden layers, src/flows/utils.jl:71-100) differentiate
+    an invertible RECOMPUTE of the forward -- they keep no activation stash (nf_affine_stash_floats = 0 for these shapes), so the
+    leaky-ReLU slopes of the reverse pass are re-decided on a float32 reconstruction of every coupling's input (DESIGN 5,
+    INTEGRATION: "deep shapes").  ADVICE r5: the benchmarked depth (8 couplings, d = 64) had no oracle check beyond 4 couplings
+    x 40 samples.  Here: 8 couplings, 8 197 samples (ragged), loss and gradient of the in-library-draws step against the float64
+    oracle, the gradient bounded by the measured kink floor of THIS shape (capped at 1 % of |g|inf), per-sample ys / ladj of the
+    forward against the oracle on 256 columns."""
+    d, nl, n = 64, 4, 8192 + 5
+    flow = nf.realnvp(nf.MvNormal(d), hd, nl, paramtype=torch.float32, seed=17)
+    gen = torch.Generator().manual_seed(5)
+    flow = flow.with_theta(flow.theta + 0.02 * torch.randn(flow.P, generator=gen).to("cuda"))
+    rng = np.random.default_rng(64 + len(hd))
+    mu, var = rng.standard_normal(d).astype(np.float32), (rng.uniform(size=d) + 0.5).astype(np.float32)
+    tgt = nf.DiagGaussTarget(torch.tensor(mu, device="cuda"), torch.tensor(var, device="cuda"))
+    spec = o.FlowSpec("realnvp", d, nl, hd)
+    th64 = flow.theta.cpu().numpy().astype(np.float64)
+    xs = nf.device_specific_rand(nf.PhiloxRNG(33), flow.dist, n)
+    xs64 = xs.cpu().numpy().astype(np.float64)
+    otgt = ("diaggauss", mu.astype(np.float64), var.astype(np.float64))
+    lo, go = o.neg_elbo_value_and_grad(spec, th64, otgt, xs64)
+    kink, frec = fp32_recompute_kink_floor(spec, th64, otgt, xs64, go, nseeds=6)
+    tag = f"deep realnvp d64 h{'x'.join(map(str, hd))} 8 couplings n={n}"
+    ys, ladj = nf.with_logabsdet_jacobian(flow.transform, xs)
+    cols = np.linspace(0, n - 1, 256).astype(int)
+    yo, lado = o.flow_fwd(spec, th64, xs64[:, cols])
+    y32, l32 = o.flow_fwd(spec, P.f32(th64), P.f32(xs64[:, cols]))
+    P.elementwise(f"{tag}: ys", ys.cpu().numpy()[:, cols], yo, floor=y32)
+    P.elementwise(f"{tag}: ladj", ladj.cpu().numpy()[cols], lado, floor=l32)
+    for form, arg in (("rng", n), ("xs", xs)):
+        loss, g = nf.value_and_gradient(nf.elbo_batch, flow, tgt, arg, rng=nf.PhiloxRNG(33))
+        P.scalar(f"{tag} ({form}): step loss", loss, lo)
+        err = float(np.abs(g.cpu().numpy().astype(np.float64) - go).max() / np.abs(go).max())
+        P.record(f"{tag} ({form}): step grad [max abs err / |g|inf]", err)
+        P.record(f"{tag} ({form}): step grad [fp32 reconstruct-by-inversion oracle, worst of 6 last-bit jitters]", kink)
+        assert err <= recompute_bound(kink), (hd, form, err, frec, kink)
 
 
 def test_realnvp_stash_in_chunks_equals_one_chunk(nf):

@@ -12,6 +12,43 @@ from __graft_entry__ import load_package
 
 nf = load_package()
 lib = nf.load_library()
+
+
+def issue_slots(kernel_key):
+    """Vector-issue slots of one pass through a kernel's code, from the built object's ISA (tools/isa_stats.py's extraction):
+    every v_* instruction one slot (2 clocks of a 32-lane SIMD per wave64 instruction; a packed-f32 instruction is one slot for
+    two values), quarter-rate transcendentals (exp, log, rcp, sqrt, rsq, sin, cos) four slots, fp32 matrix instructions their
+    pipe time in slots.  The lane-per-sample step kernels are one unrolled tile loop (every layer of
+    the instantiation written out, executed when nl = NL as here), so the static count is the count per 32-sample tile plus
+    a few hundred instructions of prologue / epilogue -- an over-estimate of the per-tile work by < 5 %.  None without
+    the LLVM binutils (this is a tuning aid, not a product path)."""
+    import re
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin/"
+    obj = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "normalizingflows.jl_amd", "build", "nf_simple.o")
+    try:
+        tmp = "/tmp/nfhip_isa_simple"
+        os.makedirs(tmp, exist_ok=True)
+        fb, co = os.path.join(tmp, "x.fatbin"), os.path.join(tmp, "x.co")
+        subprocess.run([llvm + "llvm-objcopy", "--dump-section", f".hip_fatbin={fb}", obj], check=True, capture_output=True)
+        subprocess.run([llvm + "clang-offload-bundler", "--unbundle", "--type=o", f"--input={fb}",
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True, capture_output=True)
+        dis = subprocess.run([llvm + "llvm-objdump", "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout
+    except Exception:  # noqa: BLE001
+        return None
+    syms = re.findall(r"^[0-9a-f]+ <(\S+)>:$", dis, flags=re.M)
+    dem = subprocess.run(["c++filt"], input="\n".join(syms), capture_output=True, text=True).stdout.split("\n")
+    for m, dn in zip(syms, dem):
+        if kernel_key in dn:
+            body = dis.split(f"<{m}>:\n", 1)[1].split("\n\n", 1)[0].splitlines()
+            ops = [l.split()[0] for l in body if l.strip()]
+            trans = sum(o.startswith(("v_exp", "v_log", "v_rcp", "v_sqrt", "v_rsq", "v_sin", "v_cos")) for o in ops)
+            valu = sum(o.startswith("v_") for o in ops) - trans
+            # fp32 matrix instructions in 2-clock slots of their pipe time (they share the SIMD with the vector stream): 32x32x2 64 clocks, 16x16x4 32
+            mf = 32 * sum(o.startswith("v_mfma_f32_32x32x2") for o in ops) + 16 * sum(o.startswith("v_mfma_f32_16x16x4") for o in ops)
+            nm = sum(o.startswith("v_mfma") for o in ops)
+            return valu - nm + 4 * trans + mf, valu - nm, trans, mf
+    return None
 dev = torch.device("cuda", 0)
 vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
@@ -63,6 +100,20 @@ for kind in ("planar", "radial"):
         alg = N * (8 * d + 4)
         print(f"   {kname}: {1e3 * a.value:.1f} us; algorithmic {alg / 1e6:.0f} MB -> {alg / (a.value * 1e-3) / 1e12:.2f} TB/s "
               f"= {100 * alg / (a.value * 1e-3) / 8e12:.1f} % of the 8 TB/s HBM roofline (the kernel moves only parameter slabs: issue-bound)")
+        # the second roofline: vector issue.  MI355X_MICROARCH.md: a wave64 fp32 vector instruction passes a SIMD
+        # in 2 clocks (32 lanes per clock: 157.3 TFLOP/s = 256 CUs x 4 SIMDs x 32 lanes x 2 flop x 2.4 GHz), a quarter-rate
+        # transcendental in 8, and ONE wave issues at most every ~4 clocks -- so with the two waves per SIMD these kernels run
+        # the floor of a launch is (tiles per SIMD) x (slots per tile) x 2 clocks.  (Rounds 3-5 priced a slot at 4 clocks and
+        # called these kernels "issue-bound at 0.88": that was the ONE-wave rate.  They run at half their issue roofline.)
+        key = {"radial_step": f"k_radial_step<RadialGeo<{(d + 31) // 32}, {10 if nl <= 10 else 16}>, true>",
+               "planar_step": f"k_planar_step<PlanarGeo<{(d + 31) // 32}, {6 if nl <= 10 else 8}>, true>"}.get(kname)
+        sl = issue_slots(key) if key else None
+        if sl:
+            tiles_per_simd = (N + 31) // 32 / (256 * 4)
+            for ghz in (2.4, 2.1):
+                t_issue = tiles_per_simd * sl[0] * 2 / (ghz * 1e9)
+                print(f"   {kname}: vector-issue floor at {ghz} GHz: ({sl[1]} + 4 x {sl[2]} + {sl[3]} matrix) slots per 32-sample tile x {tiles_per_simd:.0f} tiles per SIMD x 2 clk = "
+                      f"{1e6 * t_issue:.1f} us -> the launch runs at {t_issue / (a.value * 1e-3):.2f} of its vector-issue roofline")
     for name, b in need.items():
         a, c = C.c_double(0.0), C.c_int64(0)
         lib.nf_prof_read(ctx.ptr, name.encode(), C.byref(a), C.byref(c))
