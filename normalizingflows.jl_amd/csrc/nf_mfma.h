@@ -739,8 +739,11 @@ __device__ __forceinline__ void nf_mfma_settle(f32x16 (&c)[NB]) {
 // gives D = x - h for the whole 32 x 32 block: every output is ONE product (-1 x h, exact) plus C, and x - h is a multiple
 // of ulp(x) below 2^-8 |x|, so the instruction's adder has nothing to drop (tools/probe/split_mfma_probe.hip compares all
 // three parts bit for bit with nf_split2 on random, tie, subnormal-adjacent and huge inputs).  A block of 16 values then
-// costs 8 + 8 + 8 conversions (1.5 instructions per value) and four v_mfma_f32_32x32x16_bf16 (two k-groups x two levels),
-// in kernels whose matrix pipe is a third busy and whose vector issue port is the bottleneck.
+// costs 8 + 8 + 8 conversions (1.5 instructions per value) and four v_mfma_f32_32x32x16_bf16 (two k-groups x two levels).
+// MEASURED (round 6): bit-identical, halves the vector instructions of the cfg-2 reverse kernel -- and buys
+// nothing there, in the cfg-5 chain or in k_rqs_bwd_coop6 (the split's MFMAs join the dependent chain of the wave that was
+// already the slower of its SIMD's two; these kernels are not bound by vector issue).  The primitive and its probe stay for
+// the next kernel that IS; the call sites that were tried are tools/experiments/pair_chain_split_on_matrix_pipe.patch.
 // The selection operand: hardware k = 8 hi + j of k-group g is C row 16 g + (j & 3) + 8 (j >> 2) + 4 hi (nf_row(8 g + j, hi)),
 // so lane (row i = l31, half hi) holds -1 at element j iff i - 16 g - 4 hi = (j & 3) + 8 (j >> 2), zeros elsewhere.
 struct SplitSel {
@@ -922,84 +925,6 @@ __device__ __forceinline__ void dense_fwd_b6p(const nf_u32x4 *__restrict__ w, co
   }
 }
 
-// The six-term layer with its input split on the matrix pipe (round 6; nf_split16_mfma in three stages).  A whole input block
-// (two k-groups) is split at a time, one block ahead of the GEMM: stage A (8 conversions, the two MFMAs of r = x - h) in front
-// of the current block's first k-group, stage B (8 conversions, l' = r - m) in front of its second, stage C (8 v_perm) behind
-// it -- every MFMA result is consumed a k-group (6 OB MFMAs) after its issue.  Per input block 24 vector instructions and 4
-// MFMAs instead of 72 vector instructions; the terms of every accumulator in dense_fwd_b6's order: bit-identical results.
-template <int IB, int OB>
-__device__ __forceinline__ void dense_fwd_b6m(const SplitSel &sel, const nf_u32x4 *__restrict__ w, const float *__restrict__ b,
-                                              const f32x16 (&in)[IB], f32x16 (&out)[OB], int l31, int hi) {
-  constexpr int ROWS = 32 * OB, NKG = 2 * IB;
-#pragma unroll
-  for (int ob = 0; ob < OB; ++ob)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) out[ob][r] = b[ob * 32 + nf_row(r, hi)];
-  const nf_u32x4 *wl = w + hi * ROWS + l31;  // lane part of the address; (k-group, component, block) are immediates
-  nf_u32x4 an[OB][3];
-#pragma unroll
-  for (int ob = 0; ob < OB; ++ob)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) an[ob][c] = wl[c * 2 * ROWS + ob * 32];
-  nf_u32x4 ch[2], cm[2], cl[2], nh[2], nm[2], nl[2];
-  nf_split16_mfma(sel, in[0], ch, cm, cl);
-  f32x16 res;  // the residual of the block being split: r after stage A, l' after stage B
-#pragma unroll
-  for (int kg = 0; kg < NKG; ++kg) {
-    const int ib = kg >> 1, g = kg & 1;
-    nf_u32x4 ac[OB][3];
-#pragma unroll
-    for (int ob = 0; ob < OB; ++ob)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) ac[ob][c] = an[ob][c];
-    __builtin_amdgcn_sched_barrier(0);
-    if (kg + 1 < NKG) {
-#pragma unroll
-      for (int ob = 0; ob < OB; ++ob)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) an[ob][c] = wl[((kg + 1) * 3 + c) * 2 * ROWS + ob * 32];
-    }
-    if (ib + 1 < IB) {
-      if (g == 0) {  // stage A
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-          for (int p = 0; p < 4; ++p) nh[q][p] = nf_cvt_pk_bf16(nf_f32x2{in[ib + 1][8 * q + 2 * p], in[ib + 1][8 * q + 2 * p + 1]});
-        res = nf_mfma_bf16(sel.a[0], nh[0], in[ib + 1]);
-        res = nf_mfma_bf16(sel.a[1], nh[1], res);
-      } else {  // stage B
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-          for (int p = 0; p < 4; ++p) nm[q][p] = nf_cvt_pk_bf16(nf_f32x2{res[8 * q + 2 * p], res[8 * q + 2 * p + 1]});
-        res = nf_mfma_bf16(sel.a[0], nm[0], res);
-        res = nf_mfma_bf16(sel.a[1], nm[1], res);
-      }
-    }
-    // smallest terms first: wl xh, wh xl, wm xm, wm xh, wh xm, wh xh (components: 0 = h, 1 = m, 2 = l)
-#pragma unroll
-    for (int term = 0; term < 6; ++term)
-#pragma unroll
-      for (int ob = 0; ob < OB; ++ob) {
-        const nf_u32x4 &av = term == 0 ? ac[ob][2] : (term == 2 || term == 3) ? ac[ob][1] : ac[ob][0];
-        const nf_u32x4 &xv = term == 1 ? cl[g] : (term == 2 || term == 4) ? cm[g] : ch[g];
-        out[ob] = nf_mfma_bf16(av, xv, out[ob]);
-      }
-    if (ib + 1 < IB && g == 1) {  // stage C, and the hand-over
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          const float e0 = res[8 * q + 2 * p], e1 = res[8 * q + 2 * p + 1];
-          nl[q][p] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, e1), __builtin_bit_cast(unsigned, e0), 0x07060302u);
-        }
-#pragma unroll
-      for (int q = 0; q < 2; ++q) { ch[q] = nh[q]; cm[q] = nm[q]; cl[q] = nl[q]; }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
 // The transposed counterpart for the dX GEMMs of the reverse pass (din = W^T delta): rows = the layer's INPUT features, the
 // k-groups run over its OUTPUT features, in the order the cotangent's C-layout registers hold them (same mapping as above).
 // Per layer [k-group][component][half][row][8 bf16]; no biases.  T3 serves dX3 (rows: a2 features), T2 dX2, T1 dX1.
@@ -1068,17 +993,6 @@ __device__ __forceinline__ void split_C(const f32x16 (&d)[NB], SplitC<NB> &s) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = d[kg >> 1][8 * (kg & 1) + j];
     nf_split8(v, s.h[kg], s.m[kg], s.l[kg]);
-  }
-}
-// the same triples with the subtractions on the matrix pipe (nf_split16_mfma): 1.5 vector instructions per value instead of 4.5
-template <int NB>
-__device__ __forceinline__ void split_C(const SplitSel &sel, const f32x16 (&d)[NB], SplitC<NB> &s) {
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    nf_u32x4 h[2], m[2], l[2];
-    nf_split16_mfma(sel, d[b], h, m, l);
-#pragma unroll
-    for (int g = 0; g < 2; ++g) { s.h[2 * b + g] = h[g]; s.m[2 * b + g] = m[g]; s.l[2 * b + g] = l[g]; }
   }
 }
 // dense_bwd_x_b6 on a cotangent that arrives split
@@ -1158,17 +1072,6 @@ __device__ __forceinline__ void split_T(const float (&at)[IB][16], SplitT<IB> &s
       nf_split8(v, s.h[ib][g], s.m[ib][g], s.l[ib][g]);
       __builtin_amdgcn_sched_barrier(0);  // one split at a time: interleaved, their temporaries (3 x 8 each) spill the accumulators
     }
-}
-
-template <int IB>
-__device__ __forceinline__ void split_T(const SplitSel &sel, const float (&at)[IB][16], SplitT<IB> &s) {
-#pragma unroll
-  for (int ib = 0; ib < IB; ++ib) {
-    f32x16 x;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) x[r] = at[ib][r];
-    nf_split16_mfma(sel, x, s.h[ib], s.m[ib], s.l[ib]);
-  }
 }
 
 // Both operands arrive split: the activation from split_T, the cotangent as the bf16 triples the PRODUCER wave made for its own

@@ -24,20 +24,11 @@
 
 #include "nf_common.h"
 #include "nf_mfma.h"
-// k_rqs_bwd_coop6: the wave's weight triples as MFMA operands straight from the accumulation registers (nf_mfma_bf16_wa)
-#ifndef NF_RQS6_W_IN_ACC
-#define NF_RQS6_W_IN_ACC 1
-#endif
-#if NF_RQS6_W_IN_ACC
+// k_rqs_bwd_coop6: the wave's weight triples as MFMA operands straight from the accumulation registers (nf_mfma_bf16_wa,
+// nf_mfma.h; round 6: 289 -> 135 v_accvgpr_read in the kernel, none left in the chunk phase, scratch 28 -> 0 bytes,
+// 107.8 -> 107.3 us per launch on one box)
 #define RQS6_MFMA_W(a, b, c) nf_mfma_bf16_wa(a, b, c)
 #define RQS6_SETTLE(c) nf_mfma_settle(c)
-#else
-#define RQS6_MFMA_W(a, b, c) nf_mfma_bf16(a, b, c)
-#define RQS6_SETTLE(c) ((void)0)
-#endif
-#ifndef NF_RQS6_SPLIT_MFMA
-#define NF_RQS6_SPLIT_MFMA 0  // k_rqs_bwd_coop6: the splits' subtractions on the matrix pipe (nf_split16_mfma)
-#endif
 #include "nf_philox.h"
 
 template <int MB_, int H1B_, int H2B_, int K_, int NCH_, int QCH_ = 2>
@@ -1462,9 +1453,6 @@ __device__ __forceinline__ void rqs_bwd_coop6_coupling(const RqsBwdArgs &a, floa
     float4 *d1 = reinterpret_cast<float4 *>(img + G::W3);
     for (int i = tid; i < G::NCOLS / 4; i += 256) d1[i] = s1[i];
   }
-#if NF_RQS6_SPLIT_MFMA
-  const SplitSel sel6 = nf_split_sel(l31, hi);
-#endif
   RqsW6<G> W;
   {
     const nf_u32x4 *wf = a.img6 + (size_t)ch * B::F_CH + hi * B::FROWS + l31;
@@ -1532,11 +1520,7 @@ __device__ __forceinline__ void rqs_bwd_coop6_coupling(const RqsBwdArgs &a, floa
       }
       // a2 as bf16 triples, once for the four chunk waves: in B-operand order and transposed
       SplitC<G::H2B> s2;
-#if NF_RQS6_SPLIT_MFMA
-      split_C<G::H2B>(sel6, a2, s2);
-#else
       split_C<G::H2B>(a2, s2);
-#endif
       nf_u32x4 *pc_ = reinterpret_cast<nf_u32x4 *>(wv + L::A2C) + lane;
 #pragma unroll
       for (int kg = 0; kg < 2 * G::H2B; ++kg) {
@@ -1663,22 +1647,14 @@ __device__ __forceinline__ void rqs_bwd_coop6_coupling(const RqsBwdArgs &a, floa
 #pragma unroll
           for (int pc = 0; pc < G::OBC; ++pc) {
             char *ring = wv + L::DT + (pc & 1) * (32 * D6_ROW);
-#if NF_RQS6_SPLIT_MFMA
-            nf_u32x4 bh[2], bm[2], bl[2];  // the block's triples, subtractions on the matrix pipe (nf_split16_mfma)
-            nf_split16_mfma(sel6, out[pc], bh, bm, bl);
-#endif
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
               const int kg = 2 * pc + g;
-#if NF_RQS6_SPLIT_MFMA
-              const nf_u32x4 dh = bh[g], dm = bm[g], dl = bl[g];
-#else
               float v[8];
 #pragma unroll
               for (int jj = 0; jj < 8; ++jj) v[jj] = out[pc][8 * g + jj];
               nf_u32x4 dh, dm, dl;
               nf_split8(v, dh, dm, dl);
-#endif
               rqs_kg_to_d6(ring, g, dh, dm, dl, l31, hi);
 #pragma unroll
               for (int ib = 0; ib < G::H2B; ++ib) {
