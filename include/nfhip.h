@@ -44,7 +44,12 @@ extern "C" {
                                   tests require finite ELBOs, test/flow.jl:58-60)  */
 #define NF_ERR_WORKSPACE -7    /* the caller-provided arena (nf_ctx_set_arena) is too small         */
 #define NF_ERR_NO_RCCL -5      /* librccl.so.1 could not be loaded (multi-GPU entry points only) */
-#define NF_ERR_RCCL -6         /* an RCCL call failed; nf_strerror gives RCCL's message          */
+#define NF_ERR_RCCL -6         /* an RCCL call failed (nf_strerror gives RCCL's message), or a step left this rank's collective
+                                  sequence incomplete (nf_elbo_step with bucketed all-reduce: fewer messages issued than
+                                  nf_comm_bucket_count promises -- the peers wait in RCCL).  Either way the context's
+                                  communicator is unusable: every later collective call returns this code until
+                                  nf_comm_destroy + a new nf_comm_init_rank on EVERY rank.  Any other code from nf_elbo_step
+                                  under a communicator is a local failure with a complete collective sequence.          */
 
 /* flow kinds: the constructors of src/flows/*.jl */
 #define NF_KIND_PLANAR 0    /* planarflow  src/flows/planar_radial.jl:21-29        */

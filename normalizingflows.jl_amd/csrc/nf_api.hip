@@ -83,8 +83,6 @@ int nf_rqs_bwd_grid(nf_ctx *, long N);
 int nf_rqs_bwd(nf_ctx *, const nf_flow_desc *, int k, float *y, float *ybar, const float *lbar, float lbar_const, long N,
                float *slab, long slab_stride, int grid, bool inv_dir = false, void *tape = nullptr);
 long nf_rqs_slab_floats(const nf_flow_desc *desc);
-int nf_rqs_bwd_all(nf_ctx *, const nf_flow_desc *, float *y, float *ybar, const float *lbar, float lbar_const, long N,
-                   float *slab, long slab_stride, int grid, bool inv_dir = false, void *tape = nullptr);
 long nf_rqs_chain_grid(nf_ctx *, long N);
 int nf_rqs_chain_elbo(nf_ctx *, const nf_flow_desc *, long N, uint64_t seed, uint64_t off, uint32_t stream,
                       const float *mu, const float *var, float *yt, float *gt, double gscale, double *partial,
@@ -617,10 +615,16 @@ static size_t affine_stash_bytes(nf_ctx *ctx, const nf_flow_desc *desc, long N) 
     const char *e = std::getenv("NF_AFFINE_STASH_MAX_MB");
     return (size_t)(e ? std::atol(e) : 4096) << 20;
   }();
-  // default policy (round 3): every LDS-resident shape keeps the forward's activations -- the reverse pass then
-  // differentiates the forward's own tape, as the reference's AD does.  The invertible-recompute kernel is the explicit
+  // default policy (round 3): every LDS-resident shape WITH TWO HIDDEN LAYERS keeps the forward's activations -- the reverse
+  // pass then differentiates the forward's own tape, as the reference's AD does.  The invertible-recompute kernel is the explicit
   // nf_ctx_set_stash_budget(0) mode only (for hidden width 32 it is 3 % faster, and it re-decides leaky-ReLU slopes on a
   // float32 reconstruction: DESIGN.md section 5).
+  // EXCEPTION (round 5, stated here since round 6 -- ADVICE r5): nets with 1, 3 or 4 hidden layers (nf_deep.hip; also
+  // "supported" by nf_affine_supported) have NO stash mode: nf_affine_stash_floats() is 0 for them, k_deep_bwd always
+  // recomputes, and the stash budget has no effect.  Their gradient therefore carries the recompute's kink term
+  // (tests/test_gpu_parity.py::test_deep_realnvp_step_at_eight_couplings_and_a_large_batch_against_oracle measures and bounds it
+  // at 8 couplings x 8 197 samples); NF_DEEP_OFF=1 (read once per process) puts those shapes back on the layer-by-layer path,
+  // whose reverse pass reads the forward's kept activations.
   if (affine_stash_off(ctx)) return 0;
   const size_t cap = ctx->stash_budget > 0 ? (size_t)ctx->stash_budget : env_cap;
   const size_t b = nf_affine_stash_floats(desc, N) * sizeof(float);
@@ -778,17 +782,13 @@ static int realnvp_bwd(nf_ctx *ctx, const nf_flow_desc *desc, const float *theta
     NF_TRY(nf_affine_bwd_all(ctx, desc, state, gbar, lbar, lbar_const, N, slab, stride, grid));
     return nf_affine_reduce_slabs(ctx, desc, slab, grid, g_out, lpart, nlpart, lout);
   }
-  // Neural spline couplings: one launch per coupling.  The single-launch form exists (k_rqs_bwd_all, the structure of
+  // Neural spline couplings: one launch per coupling.  The single-launch form EXISTED through round 5 (k_rqs_bwd_all, the structure of
   // k_affine_bwd_all; NF_RQS_BWD_FUSED=1 selects it) but MEASURED SLOWER on this kernel, A/B on one box: 1329 us for
   // the 8 couplings against 8 x 159.5 us = 1276 us, step 1.729 vs 1.657 ms -- the kernel sits at the register wall
   // (256 VGPR + 256 AGPR), and the outer coupling loop costs it 40 more bytes of scratch spills per lane than the
   // launch gaps it saves (profiles/r2_cfg3_fused_vs_split.txt).
-  static const bool fused = std::getenv("NF_RQS_BWD_FUSED") != nullptr;
-  if (!fused) {
-    for (int k = 0; k < nc; ++k) NF_TRY(nf_rqs_bwd(ctx, desc, k, state, gbar, lbar, lbar_const, N, slab, stride, grid, false, rqs_tape));
-  } else {
-    NF_TRY(nf_rqs_bwd_all(ctx, desc, state, gbar, lbar, lbar_const, N, slab, stride, grid, false, rqs_tape));
-  }
+  // (round 6: k_rqs_bwd_all and its NF_RQS_BWD_FUSED switch are gone with the measurement above)
+  for (int k = 0; k < nc; ++k) NF_TRY(nf_rqs_bwd(ctx, desc, k, state, gbar, lbar, lbar_const, N, slab, stride, grid, false, rqs_tape));
   return nf_rqs_reduce_slabs(ctx, desc, slab, grid, g_out);
 }
 
@@ -1737,7 +1737,7 @@ extern "C" int nf_elbo_value_and_grad(nf_ctx *ctx, const nf_flow_desc *desc, con
   const int grid = cp ? coupling_bwd_grid(ctx, desc, N) : 0;
   const bool simple_kind = !cp && !is_g64(desc) && desc->kind != NF_KIND_HAMILTONIAN;
   // planar / radial / mean-field within the register budget: the whole step in one launch, nothing stashed
-  static const bool no_step = std::getenv("NF_SIMPLE_STASH") != nullptr;  // A/B switch: the two-kernel stash path
+  constexpr bool no_step = false;  // (round 6: the NF_SIMPLE_STASH A/B switch is retired -- its question is answered, README "switches")
   const bool simple_step = simple_kind && !no_step && nf_simple_step_supported(desc);
   const size_t simple_ws = cp ? 0 : simple_step ? nf_simple_step_ws_bytes(ctx, desc, N) : flat_bwd_ws_bytes(ctx, desc, N);
   // LDS-resident RealNVP: activation stash for the reverse pass, the batch in chunks if it exceeds the budget (in-library
@@ -1957,7 +1957,7 @@ static inline unsigned long long flow_sig(const nf_flow_desc *d) {
   return h | (1ull << 63);
 }
 static bool step_fusable(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, long N) {
-  static const bool off = std::getenv("NF_STEP_UNFUSED") != nullptr;  // A/B switch: the six-launch form
+  constexpr bool off = false;  // (round 6: the NF_STEP_UNFUSED A/B switch is retired -- its question is answered, README "switches")
   if (off || flow_base(desc) || is_composite(desc) || desc->dtype != NF_DTYPE_F32) return false;
   if (!(desc->kind == NF_KIND_REALNVP && nf_affine_supported(desc))) return false;
   if (!elbo_fusable(desc, target, nullptr)) return false;
@@ -2000,7 +2000,7 @@ static int elbo_step_fused(nf_ctx *ctx, const nf_flow_desc *desc, const nf_targe
   // packed images: those the previous step's epilogue left, or a fresh pack
   // (ONLY under nf_ctx_set_weight_cache(ctx, 1): by default every step packs from theta, one 8 us launch, so a theta
   // that was edited in place, or freed and re-allocated at the same address, can never meet stale images)
-  static const bool repack = std::getenv("NF_STEP_REPACK") != nullptr;  // A/B switch: pack every step
+  constexpr bool repack = false;  // (round 6: the NF_STEP_REPACK A/B switch is retired -- its question is answered, README "switches")
   if (repack || !ctx->wimg_cache ||
       !(ctx->wimg && ctx->wimg_owner == (const void *)theta && ctx->wimg_sig == flow_sig(desc))) {
     NF_TRY(coupling_pack(ctx, desc, theta));
@@ -2119,9 +2119,15 @@ extern "C" int nf_elbo_step(nf_ctx *ctx, const nf_flow_desc *desc, const nf_targ
       // (nf_comm_destroy + a new nf_comm_init_rank on every rank), which the header says of any failed collective call.
       const int st_join = nf_comm_bucket_join(ctx);
       const int want = (2 * desc->nlayers + cpb - 1) / cpb;
+      // whatever else went wrong, a rank that issued fewer messages than nf_comm_bucket_count promises leaves its
+      // peers waiting in RCCL -- that is a property of the COMMUNICATOR, reported as NF_ERR_RCCL and remembered (every later
+      // collective call on this context fails until nf_comm_destroy); a local failure with a complete sequence keeps its code
+      if (ctx->bucket.issued != want) {
+        ctx->comm_poisoned = true;
+        return NF_ERR_RCCL;
+      }
       if (st_vg != NF_OK) return st_vg;
       NF_TRY(st_join);
-      if (ctx->bucket.issued != want) return NF_ERR_RCCL;  // a reverse pass that issued fewer messages than nf_comm_bucket_count promises
     } else {
       NF_TRY(st_vg);
       if (world > 1) NF_TRY(nf_allreduce_grad_loss(ctx, desc->dtype, gbuf, P + 1));

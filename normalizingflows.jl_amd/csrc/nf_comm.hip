@@ -117,6 +117,7 @@ extern "C" int nf_allreduce_grad_loss(nf_ctx *ctx, int32_t dtype, void *buf, int
   if (!ctx || !buf || count < 0) return NF_ERR_ARG;
   if (dtype != NF_DTYPE_F32 && dtype != NF_DTYPE_F64) return NF_ERR_ARG;
   if (!ctx->comm) return NF_ERR_ARG;  // no communicator: a single-GPU caller simply does not call this
+  if (ctx->comm_poisoned) return NF_ERR_RCCL;  // an earlier step left a partly issued bucket sequence behind
   NF_TRY(api());
   NF_HIP(hipSetDevice(ctx->device));
   return rccl_status(g_api.AllReduce(buf, buf, (size_t)count, rccl_dtype(dtype), RCCL_SUM, ctx->comm, ctx->stream));
@@ -149,6 +150,7 @@ extern "C" int nf_allreduce_grad_loss_all(nf_ctx **ctxs, int32_t ngpus, int32_t 
 // replicas stay bit-identical with each other.
 int nf_comm_bucket_issue(nf_ctx *ctx, int32_t dtype, void *buf, int64_t count) {
   if (!ctx || !ctx->comm || !buf || count < 0) return NF_ERR_ARG;
+  if (ctx->comm_poisoned) return NF_ERR_RCCL;
   NF_TRY(api());
   if (!ctx->comm_stream) NF_HIP(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
   if (ctx->comm_events.empty()) {
@@ -195,5 +197,6 @@ extern "C" int nf_comm_destroy(nf_ctx *ctx) {
   ctx->comm = nullptr;
   ctx->comm_size = 1;
   ctx->comm_rank = 0;
+  ctx->comm_poisoned = false;
   return rccl_status(r);
 }

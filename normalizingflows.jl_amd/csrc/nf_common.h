@@ -78,6 +78,10 @@ struct nf_ctx {
   std::vector<hipEvent_t> comm_events;  // pooled; [0] is the join event
   size_t comm_event_next = 1;
   long long comm_bucket_bytes = -1;     // nf_ctx_set_comm_bucket_bytes: < 0 automatic (4 MiB), 0 never bucket
+  // set when a step left the communicator with a partly issued collective sequence (this rank issued fewer buckets than its
+  // peers wait for): every later collective call returns NF_ERR_RCCL until nf_comm_destroy + a new nf_comm_init_rank on
+  // every rank (a local gradient failure must be distinguishable from a communicator that has to be torn down)
+  bool comm_poisoned = false;
   struct {
     bool on = false;      // set by nf_elbo_step around its gradient call
     int couplings = 0;    // couplings per bucket

@@ -57,6 +57,14 @@ struct G64MStage {
       v[k] = (e < NE && i < nin && o < nout) ? theta[w_off + (long)i * nout + o] : 0.0;
     }
   }
+  // a window of the layer's columns: [c0, c0 + ncols) of `nout`, into image columns 0 .. ncols - 1 (zero beyond)
+  __device__ __forceinline__ void load_cols(const double *__restrict__ theta, long w_off, int nin, int nout, int c0, int ncols, int tid) {
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int e = tid + 256 * k, i = e / S, o = e - i * S;
+      v[k] = (e < NE && i < nin && o < ncols) ? theta[w_off + (long)i * nout + c0 + o] : 0.0;
+    }
+  }
   __device__ __forceinline__ void store(double *__restrict__ w, int tid) const {
 #pragma unroll
     for (int k = 0; k < U; ++k)
@@ -68,21 +76,39 @@ __device__ __forceinline__ void g64m_stage_bias(double *__restrict__ b, const do
   for (int o = tid; o < COLS; o += 256) b[o] = o < nout ? theta[b_off + o] : 0.0;
 }
 template <class G>
-__device__ __forceinline__ void g64m_stage_net(double *__restrict__ img, const double *__restrict__ theta, const G64Net &n, int tid) {
+__device__ __forceinline__ void g64m_stage_net(double *__restrict__ img, const double *__restrict__ theta, const G64Net &n, int tid,
+                                               bool with_out = true) {
   const int nhid = n.nl - 1;
   G64MStage<16 * G::MB, G::SH> l0;
   G64MStage<16 * G::HB, G::SH> l1;
   G64MStage<16 * G::HB, G::SC> lo;
   l0.load(theta, n.w[0], n.dims[0], n.dims[1], tid);
   if (nhid == 2) l1.load(theta, n.w[1], n.dims[1], n.dims[2], tid);
-  lo.load(theta, n.w[nhid], n.dims[nhid], n.dims[nhid + 1], tid);
+  if (with_out) lo.load(theta, n.w[nhid], n.dims[nhid], n.dims[nhid + 1], tid);
   g64m_stage_bias<16 * G::HB>(img + G::B0, theta, n.b[0], n.dims[1], tid);
   if (nhid == 2) g64m_stage_bias<16 * G::HB>(img + G::B1, theta, n.b[1], n.dims[2], tid);
-  g64m_stage_bias<16 * G::CB>(img + G::img_bo(nhid), theta, n.b[nhid], n.dims[nhid + 1], tid);
+  if (with_out) g64m_stage_bias<16 * G::CB>(img + G::img_bo(nhid), theta, n.b[nhid], n.dims[nhid + 1], tid);
   l0.store(img + G::W0, tid);
   if (nhid == 2) l1.store(img + G::W1, tid);
+  if (with_out) lo.store(img + G::img_wo(nhid), tid);
+}
+// Columns [c0, c0 + ncols) of the OUTPUT layer into the image's output-layer block (round 6: spline couplings whose
+// (3K - 1) c raw parameters exceed the block's 16 CB columns take the layer in passes of whole dimensions -- the
+// reference's default nsf(q0) = [32, 32], K = 10 has 29 per dimension, 464 at d = 32; src/flows/neuralspline.jl:232-234).
+// The caller brackets this with workgroup barriers.
+template <class G>
+__device__ __forceinline__ void g64m_stage_out_cols(double *__restrict__ img, const double *__restrict__ theta, const G64Net &n, int c0,
+                                                    int ncols, int tid) {
+  const int nhid = n.nl - 1, nout = n.dims[nhid + 1];
+  G64MStage<16 * G::HB, G::SC> lo;
+  lo.load_cols(theta, n.w[nhid], n.dims[nhid], nout, c0, ncols, tid);
+  double *b = img + G::img_bo(nhid);
+  for (int o = tid; o < 16 * G::CB; o += 256) b[o] = o < ncols ? theta[n.b[nhid] + c0 + o] : 0.0;
   lo.store(img + G::img_wo(nhid), tid);
 }
+// dimensions per pass / passes of a spline coupling with P = 3K - 1 parameters per dimension and c transformed dimensions
+template <class G>
+__device__ __host__ inline int g64m_nsf_dp(int P) { return (16 * G::CB) / P; }
 
 __device__ __forceinline__ f64x4 g64m_mfma(double a, double b, f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 
@@ -209,6 +235,32 @@ __device__ __forceinline__ void g64m_store(double *__restrict__ slab, const G64M
   }
 }
 
+// ... ADDED into the slab at a column window of the layer (the spline couplings' output layer taken in passes: a pass's block
+// of accumulators is summed over the group's 64 samples, added to the workgroup's slab -- which the kernel zeroed -- and reused)
+template <int IB, int OB, int ST>
+__device__ __forceinline__ void g64m_store_add(double *__restrict__ slab, const G64MAcc<IB, OB, ST> &acc, long w_off, long b_off, int nin,
+                                               int nout, int c0, int ncols, int wave, int c16, int q) {
+#pragma unroll
+  for (int s = 0; s < G64MAcc<IB, OB, ST>::NS; ++s) {
+    const int e = wave + 4 * s;
+    if (e < IB * OB) {
+      const int ib = e / OB, ob = e - ib * OB;
+      const int o = 16 * ob + c16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * ib + q + 4 * r;
+        if (i < nin && o < ncols) slab[w_off + (long)i * nout + c0 + o] += acc.w[s][r];
+      }
+      if (ib == 0) {
+        double v = acc.b[s];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (q == 0 && o < ncols) slab[b_off + c0 + o] += v;
+      }
+    }
+  }
+}
+
 // the conditioner half of the standard-layout state into C-layout blocks (zero beyond m / N)
 template <int MB>
 __device__ __forceinline__ void g64m_load_cond(const double *__restrict__ row, int m, int par_c, bool valid, f64x4 (&xb)[MB], int q) {
@@ -233,6 +285,18 @@ __device__ __forceinline__ void g64m_net_fwd(const double *__restrict__ img, int
     g64m_fwd<G::HB, G::CB, G::SC>(img + G::img_wo(2), img + G::img_bo(2), a2, out, c16, q);
   } else {
     g64m_fwd<G::HB, G::CB, G::SC>(img + G::img_wo(1), img + G::img_bo(1), a1, out, c16, q);
+  }
+}
+
+// the hidden layers only (the output layer is the caller's: spline couplings in passes)
+template <class G>
+__device__ __forceinline__ void g64m_hidden_fwd(const double *__restrict__ img, int nhid, const f64x4 (&xb)[G::MB], f64x4 (&a1)[G::HB],
+                                                f64x4 (&a2)[G::HB], int c16, int q) {
+  g64m_fwd<G::MB, G::HB, G::SH>(img + G::W0, img + G::B0, xb, a1, c16, q);
+  g64m_lrelu<G::HB>(a1);
+  if (nhid == 2) {
+    g64m_fwd<G::HB, G::HB, G::SH>(img + G::W1, img + G::B1, a1, a2, c16, q);
+    g64m_lrelu<G::HB>(a2);
   }
 }
 
@@ -337,7 +401,14 @@ __global__ __launch_bounds__(256) void k_g64m_bwd(G64Args a, int inv, const doub
     const G64Net &net = a.net[NSF ? 0 : (is_s ? 0 : 1)];
     __syncthreads();
     G64M_STAMP(24 * phase + 0);
-    g64m_stage_net<G>(img, theta, net, tid);
+    // spline couplings: P raw parameters per transformed dimension, DP whole dimensions per pass of the output layer
+    const int P = NSF ? 3 * a.K - 1 : 1, DP = NSF ? g64m_nsf_dp<G>(P) : 1, NP = NSF ? (a.c + DP - 1) / DP : 1;
+    g64m_stage_net<G>(img, theta, net, tid, !(NSF && NP > 1));
+    if (NSF && NP > 1) {  // the passes ADD their weight-gradient blocks into the slab
+      const long nwo = (long)net.dims[nhid] * net.dims[nhid + 1];
+      for (long i = tid; i < nwo; i += 256) slab[net.w[nhid] + i] = 0.0;
+      for (int i = tid; i < net.dims[nhid + 1]; i += 256) slab[net.b[nhid] + i] = 0.0;
+    }
     __syncthreads();
     G64M_STAMP(24 * phase + 1);
     int gcount = 0;
@@ -360,35 +431,64 @@ __global__ __launch_bounds__(256) void k_g64m_bwd(G64Args a, int inv, const doub
       double *gr = gbar + jr * a.d;
       const double lb = valid ? (lbar ? lbar[jr] : lbar_const) : 0.0;
       f64x4 xb[G::MB], a1[G::HB], a2[G::HB], dout[G::CB];
+      f64x4 dh[G::HB];
       g64m_load_cond<G::MB>(xr, a.m, par_c, valid, xb, q);
-      g64m_net_fwd<G>(img, nhid, xb, a1, a2, dout, c16, q);
       if constexpr (NSF) {
         // The net's outputs are the splines' raw parameters, (3K - 1) per transformed dim, consecutive per dim: through the
         // wave's [sample][feature] tile (the dW stage's operand layout) a lane gets the ones of its (sample, dim) as one
         // contiguous row -- lane group q takes dims q, q + 4, ... -- and the scalar spline code of the general kernels
         // (g64_build / g64_spline_bwd, nf_generic64.hip) runs on them unchanged; its parameter cotangents go back the same way.
-        const int P = 3 * a.K - 1;
-        g64m_to_tile<G::CB, G::ST>(myd, dout, c16, q);
-        wave_lds_fence();
-        for (int p = q; p < a.c; p += 4) {
-          double *raw = myd + c16 * G::ST + p * P;
-          double thb[3 * G64_MAXK];
-          for (int i = 0; i < P; ++i) thb[i] = 0.0;
-          if (valid) {
-            G64Spline<double> sp;
-            g64_build<double>(raw, a.K, a.B, sp);
-            const int idx = 2 * p + a.par_t;
-            gr[idx] = g64_spline_bwd<double>(sp, raw, a.K, a.B, xr[idx], gr[idx], lb, thb, inv != 0);
+        // Round 6: the output layer in NP passes of DP whole dimensions (<= 16 CB columns each): its slice of the weights is
+        // staged per (group, pass) into the image's output-layer block, the input cotangent accumulates over the passes, the
+        // pass's weight-gradient blocks are added to the slab.  One pass (NP = 1): round 5's kernel, resident accumulators.
+        g64m_hidden_fwd<G>(img, nhid, xb, a1, a2, c16, q);
+        const f64x4 (&hid)[G::HB] = nhid == 2 ? a2 : a1;
+        g64m_to_tile<G::HB, G::ST>(mya, hid, c16, q);  // the A operand of every pass's weight-gradient GEMM
+#pragma unroll
+        for (int b = 0; b < G::HB; ++b) dh[b] = f64x4{0.0, 0.0, 0.0, 0.0};
+        const double *wo = img + G::img_wo(nhid == 2 ? 2 : 1), *bo = img + G::img_bo(nhid == 2 ? 2 : 1);
+#pragma unroll 1
+        for (int ps = 0; ps < NP; ++ps) {
+          const int dim0 = ps * DP, nd = a.c - dim0 < DP ? a.c - dim0 : DP, c0 = dim0 * P, ncols = nd * P;
+          if (NP > 1) {
+            __syncthreads();  // every wave is done with the previous slice (and the previous pass's cotangent tiles)
+            g64m_stage_out_cols<G>(img, theta, net, c0, ncols, tid);
+            __syncthreads();
           }
-          for (int i = 0; i < P; ++i) raw[i] = thb[i];
+          g64m_fwd<G::HB, G::CB, G::SC>(wo, bo, hid, dout, c16, q);
+          g64m_to_tile<G::CB, G::ST>(myd, dout, c16, q);
+          wave_lds_fence();
+          for (int pl = q; pl < nd; pl += 4) {
+            double *raw = myd + c16 * G::ST + pl * P;
+            double thb[3 * G64_MAXK];
+            for (int i = 0; i < P; ++i) thb[i] = 0.0;
+            if (valid) {
+              G64Spline<double> sp;
+              g64_build<double>(raw, a.K, a.B, sp);
+              const int idx = 2 * (dim0 + pl) + a.par_t;
+              gr[idx] = g64_spline_bwd<double>(sp, raw, a.K, a.B, xr[idx], gr[idx], lb, thb, inv != 0);
+            }
+            for (int i = 0; i < P; ++i) raw[i] = thb[i];
+          }
+          wave_lds_fence();
+#pragma unroll
+          for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dout[b][r] = myd[c16 * G::ST + 16 * b + q + 4 * r];  // (columns past the slice: zero weights, zero bias: 0)
+          g64m_bwdx<G::HB, G::CB, G::SC, true>(wo, dout, dh, c16, q);
+          __syncthreads();
+          if (NP == 1) {
+            g64m_dw<G::HB, G::CB, G::ST>(atiles, dtiles, acco, wave, c16, q);
+          } else {
+            G64MAcc<G::HB, G::CB, G::ST> accp;
+            g64m_zero(accp);
+            g64m_dw<G::HB, G::CB, G::ST>(atiles, dtiles, accp, wave, c16, q);
+            g64m_store_add<G::HB, G::CB, G::ST>(slab, accp, net.w[nhid], net.b[nhid], net.dims[nhid], net.dims[nhid + 1], c0, ncols, wave, c16, q);
+          }
+          __syncthreads();
         }
-        wave_lds_fence();
-#pragma unroll
-        for (int b = 0; b < G::CB; ++b)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) dout[b][r] = myd[c16 * G::ST + 16 * b + q + 4 * r];  // (columns past c (3K - 1): zero weights, zero bias: 0)
-        wave_lds_fence();
       } else {
+      g64m_net_fwd<G>(img, nhid, xb, a1, a2, dout, c16, q);
       // element-wise stage -> cotangent of the net's output (rows beyond c and samples beyond N: 0)
 #pragma unroll
       for (int b = 0; b < G::CB; ++b)
@@ -417,19 +517,20 @@ __global__ __launch_bounds__(256) void k_g64m_bwd(G64Args a, int inv, const doub
         }
       }
       G64M_STAMP(gb + 1);
-      // ---- output layer
-      f64x4 dh[G::HB];
-      if (nhid == 2) {
-        g64m_to_tile<G::HB, G::ST>(mya, a2, c16, q);
-        g64m_bwdx<G::HB, G::CB, G::SC, false>(img + G::img_wo(2), dout, dh, c16, q);
-      } else {
-        g64m_to_tile<G::HB, G::ST>(mya, a1, c16, q);
-        g64m_bwdx<G::HB, G::CB, G::SC, false>(img + G::img_wo(1), dout, dh, c16, q);
+      // ---- output layer (spline couplings: done above, pass by pass)
+      if constexpr (!NSF) {
+        if (nhid == 2) {
+          g64m_to_tile<G::HB, G::ST>(mya, a2, c16, q);
+          g64m_bwdx<G::HB, G::CB, G::SC, false>(img + G::img_wo(2), dout, dh, c16, q);
+        } else {
+          g64m_to_tile<G::HB, G::ST>(mya, a1, c16, q);
+          g64m_bwdx<G::HB, G::CB, G::SC, false>(img + G::img_wo(1), dout, dh, c16, q);
+        }
+        g64m_to_tile<G::CB, G::ST>(myd, dout, c16, q);
+        __syncthreads();
+        g64m_dw<G::HB, G::CB, G::ST>(atiles, dtiles, acco, wave, c16, q);
+        __syncthreads();
       }
-      g64m_to_tile<G::CB, G::ST>(myd, dout, c16, q);
-      __syncthreads();
-      g64m_dw<G::HB, G::CB, G::ST>(atiles, dtiles, acco, wave, c16, q);
-      __syncthreads();
       G64M_STAMP(gb + 2);
       if (nhid == 2) {
         g64m_lrelu_grad<G::HB>(dh, a2);
@@ -465,7 +566,8 @@ __global__ __launch_bounds__(256) void k_g64m_bwd(G64Args a, int inv, const doub
     G64M_STAMP(24 * phase + 22);
     g64m_store<G::MB, G::HB, G::ST>(slab, acc0, net.w[0], net.b[0], net.dims[0], net.dims[1], wave, c16, q);
     if (nhid == 2) g64m_store<G::HB, G::HB, G::ST>(slab, acc1, net.w[1], net.b[1], net.dims[1], net.dims[2], wave, c16, q);
-    g64m_store<G::HB, G::CB, G::ST>(slab, acco, net.w[nhid], net.b[nhid], net.dims[nhid], net.dims[nhid + 1], wave, c16, q);
+    if (!(NSF && NP > 1))  // (in passes: already in the slab)
+      g64m_store<G::HB, G::CB, G::ST>(slab, acco, net.w[nhid], net.b[nhid], net.dims[nhid], net.dims[nhid + 1], wave, c16, q);
     G64M_STAMP(24 * phase + 23);
   }
 }
@@ -477,11 +579,16 @@ __global__ __launch_bounds__(256) void k_g64m_nsf_apply(G64Args a, int inverse, 
   extern __shared__ __attribute__((aligned(16))) double lds64[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c16 = lane & 15, q = lane >> 4;
   const int nhid = a.net[0].nl - 1, par_c = 1 - a.par_t, P = 3 * a.K - 1;
-  const long ntiles = (a.N + 15) / 16;
+  // the output layer in NP passes of DP whole dimensions (round 6; one pass: the whole layer stays staged, as in round 5)
+  const int DP = g64m_nsf_dp<G>(P), NP = (a.c + DP - 1) / DP;
+  const long ntiles = (a.N + 15) / 16, ngroups = (ntiles + 3) / 4;
   double *mytile = lds64 + G::img_size(nhid) + wave * G::TILE;
-  g64m_stage_net<G>(lds64, theta, a.net[0], tid);
+  const double *wo = lds64 + G::img_wo(nhid == 2 ? 2 : 1), *bo = lds64 + G::img_bo(nhid == 2 ? 2 : 1);
+  g64m_stage_net<G>(lds64, theta, a.net[0], tid, NP == 1);
   __syncthreads();
-  for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+  // (groups of four tiles, the four waves in step: the passes' staging needs workgroup barriers inside the loop)
+  for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const long tile = grp * 4 + wave;
     const long j = tile * 16 + c16;
     const bool valid = j < a.N;
     const long jr = valid ? j : a.N - 1;
@@ -489,18 +596,30 @@ __global__ __launch_bounds__(256) void k_g64m_nsf_apply(G64Args a, int inverse, 
     double *yr = y + jr * a.d;
     f64x4 xb[G::MB], a1[G::HB], a2[G::HB], out[G::CB];
     g64m_load_cond<G::MB>(xr, a.m, par_c, valid, xb, q);
-    g64m_net_fwd<G>(lds64, nhid, xb, a1, a2, out, c16, q);
-    g64m_to_tile<G::CB, G::ST>(mytile, out, c16, q);
-    wave_lds_fence();
+    g64m_hidden_fwd<G>(lds64, nhid, xb, a1, a2, c16, q);
+    const f64x4 (&hid)[G::HB] = nhid == 2 ? a2 : a1;
     double lsum = 0.0;
-    if (valid)
-      for (int p = q; p < a.c; p += 4) {
-        G64Spline<double> sp;
-        g64_build<double>(mytile + c16 * G::ST + p * P, a.K, a.B, sp);
-        const int idx = 2 * p + a.par_t;
-        const double v = xr[idx];
-        yr[idx] = inverse ? g64_spline_inv(sp, a.K, v, lsum) : g64_spline_fwd(sp, a.K, v, lsum);
+#pragma unroll 1
+    for (int ps = 0; ps < NP; ++ps) {
+      const int dim0 = ps * DP, nd = a.c - dim0 < DP ? a.c - dim0 : DP;
+      if (NP > 1) {
+        __syncthreads();  // every wave is done with the previous slice
+        g64m_stage_out_cols<G>(lds64, theta, a.net[0], dim0 * P, nd * P, tid);
+        __syncthreads();
       }
+      g64m_fwd<G::HB, G::CB, G::SC>(wo, bo, hid, out, c16, q);
+      g64m_to_tile<G::CB, G::ST>(mytile, out, c16, q);
+      wave_lds_fence();
+      if (valid)
+        for (int pl = q; pl < nd; pl += 4) {
+          G64Spline<double> sp;
+          g64_build<double>(mytile + c16 * G::ST + pl * P, a.K, a.B, sp);
+          const int idx = 2 * (dim0 + pl) + a.par_t;
+          const double v = xr[idx];
+          yr[idx] = inverse ? g64_spline_inv(sp, a.K, v, lsum) : g64_spline_fwd(sp, a.K, v, lsum);
+        }
+      wave_lds_fence();  // the next pass's (or tile's) outputs overwrite the tile
+    }
     lsum += __shfl_xor(lsum, 16);
     lsum += __shfl_xor(lsum, 32);
     if (q == 0 && valid) ladj[j] += lsum;
@@ -513,7 +632,6 @@ __global__ __launch_bounds__(256) void k_g64m_nsf_apply(G64Args a, int inverse, 
           if (valid && f < a.m) yr[2 * f + par_c] = xb[b][r];
         }
     }
-    wave_lds_fence();  // the next tile's outputs overwrite the tile
   }
 }
 
@@ -534,9 +652,11 @@ using G64M14 = G64M<1, 4>;
 using G64M22 = G64M<2, 2>;
 using G64M24 = G64M<2, 4>;
 #define G64M_DISPATCH(ID, CALL) ((ID) == 12 ? CALL(G64M12) : (ID) == 14 ? CALL(G64M14) : (ID) == 22 ? CALL(G64M22) : CALL(G64M24))
-// Float64 neural spline couplings: conditioner <= 16 inputs, hidden <= 32, (3K - 1) ceil(d / 2) <= 96 net outputs -- the
-// reference's test shape nsf(q0; paramtype = Float64) at d = 5, K = 10, hidden [32, 32] (test/flow.jl:65-78) and its
-// neighbours (d <= 6 at K = 10, d <= 8 at K = 8); wider outputs do not fit the dW stage's tiles next to the image (160 KB).
+// Float64 neural spline couplings: conditioner <= 16 inputs (d <= 32), hidden <= 32 -- the reference's test shape
+// nsf(q0; paramtype = Float64) at d = 5, K = 10, hidden [32, 32] (test/flow.jl:65-78) in ONE pass of the output layer
+// ((3K - 1) ceil(d / 2) <= 96 net outputs: round 5), and since round 6 every d <= 32 in passes of 96 / (3K - 1) whole
+// dimensions (the reference's DEFAULT constructor nsf(q0) = [32, 32], K = 10, B = 30, Float64, src/flows/neuralspline.jl:232-234:
+// 464 outputs at d = 32, six passes of three dimensions).
 using G64MN = G64M<1, 2, 6>;
 static bool g64m_nsf_ok(const nf_flow_desc *desc) {
   static const bool off = std::getenv("NF_G64_NO_F64_MFMA") != nullptr;
@@ -545,7 +665,9 @@ static bool g64m_nsf_ok(const nf_flow_desc *desc) {
   for (int i = 0; i < desc->n_hidden; ++i)
     if (desc->hdims[i] < 1 || desc->hdims[i] > 32) return false;
   const int cmax = (desc->d + 1) / 2;
-  return cmax <= 16 && cmax * (3 * desc->K - 1) <= 16 * G64MN::CB;
+  // (round 6: any number of transformed dimensions up to 16 -- the output layer is taken in passes of whole dimensions when its
+  // (3K - 1) c columns exceed the image's 16 CB: d <= 32 at every K <= 16, the reference's default nsf(q0) included)
+  return cmax <= 16 && (3 * desc->K - 1) <= 16 * G64MN::CB;
 }
 
 template <class G>

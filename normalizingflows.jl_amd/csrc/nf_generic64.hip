@@ -1961,7 +1961,7 @@ static int g64_launch_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G6
 int nf_wimg_reserve(nf_ctx *ctx, size_t bytes);
 static inline int l64_pad32(int n) { return (n + 31) / 32 * 32; }
 static bool l64_ok(const nf_flow_desc *desc) {
-  static const bool off = std::getenv("NF_G64_NO_MFMA") != nullptr;  // A/B switch: the scalar MLP
+  constexpr bool off = false;  // (round 6: the NF_G64_NO_MFMA A/B switch is retired -- its question is answered, README "switches")
   if (off || desc->dtype != NF_DTYPE_F32 || (desc->kind != NF_KIND_REALNVP && desc->kind != NF_KIND_NSF)) return false;
   if (desc->n_hidden < 1 || desc->n_hidden > NF_MAX_HIDDEN || desc->d < 2 || desc->d > 256) return false;
   for (int i = 0; i < desc->n_hidden; ++i)
@@ -2055,7 +2055,7 @@ static inline int l64_group(int blocks_left, int maxg) { return blocks_left >= 4
 
 // 2 when the coupling's two nets can share launches: same layer sizes, one constant theta stride, one constant buffer stride
 static int l64_nets_merge(const G64Args &a, const L64Bufs &b) {
-  static const bool off = std::getenv("NF_L64_NO_NET_MERGE") != nullptr;  // A/B switch
+  constexpr bool off = false;  // (round 6: the NF_L64_NO_NET_MERGE A/B switch is retired -- its question is answered, README "switches")
   if (b.nets != 2 || off || a.net[0].nl != a.net[1].nl) return 1;
   const long dth = a.net[1].w[0] - a.net[0].w[0];
   for (int l = 0; l < a.net[0].nl; ++l) {
@@ -2078,13 +2078,13 @@ static int l64_fwd_all_launch(nf_ctx *ctx, unsigned grid, size_t lds, const floa
 // the fused output-layer kernels of a spline coupling (k_l64_nsf_top_fwd / k_l64_nsf_top_bwd) take: one hidden layer at least,
 // <= 64 inputs and <= 384 outputs in the output layer, K <= 8, <= 16 transformed dimensions
 static bool l64_top_fusable(const G64Args &a, int last) {
-  static const bool no_top = std::getenv("NF_L64_NO_TOP_FUSE") != nullptr;  // A/B switch: the separate launches
+  constexpr bool no_top = false;  // (round 6: the NF_L64_NO_TOP_FUSE A/B switch is retired -- its question is answered, README "switches")
   return !no_top && a.kind == NF_KIND_NSF && last >= 1 && a.K <= 8 && a.c <= 16 && a.net[0].dims[last] <= 64 &&
          a.net[0].dims[last + 1] <= L64_TOP_ROWS;
 }
 // K = 8: the fused kernels' element arithmetic is nf_rqs_elem.h's (compile-time K)
 static bool l64_top_k8(const G64Args &a) {
-  static const bool off = std::getenv("NF_L64_TOP_GENERIC_SPLINE") != nullptr;  // A/B switch: the run-time-K arithmetic
+  constexpr bool off = false;  // (round 6: the NF_L64_TOP_GENERIC_SPLINE A/B switch is retired -- its question is answered, README "switches")
   return a.K == 8 && !off;
 }
 // the nets of one coupling, layer by layer, on the conditioner half of `x` (standard layout); outputs stay in b->act
@@ -2096,7 +2096,7 @@ static int l64_nets_fwd(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a,
     const G64Net &net = a.net[n];
     // the leading run of narrow layers (widths <= 64) in one launch
     int lc = 0;
-    static const bool no_chain = std::getenv("NF_L64_NO_FWD_CHAIN") != nullptr;  // A/B switch
+    constexpr bool no_chain = false;  // (round 6: the NF_L64_NO_FWD_CHAIN A/B switch is retired -- its question is answered, README "switches")
     const int nlim = net.nl - (skip_top ? 1 : 0);
     while (lc < nlim && net.dims[lc] <= 64 && net.dims[lc + 1] <= 64) ++lc;
     if (lc < 2 || no_chain) lc = 0;
@@ -2131,7 +2131,7 @@ static int l64_nets_fwd(nf_ctx *ctx, const nf_flow_desc *desc, const G64Args &a,
       const int OBa = l64_maxg(IB, false) >= 4 ? 4 : l64_maxg(IB, false);
       const int NGa = (blocks + OBa - 1) / OBa;
       const size_t lds_all = (size_t)NGa * (32 * IB * (32 * OBa + NF_IMG_PAD) + 32 * OBa) * sizeof(float);
-      static const bool no_all = std::getenv("NF_L64_NO_FWD_ALL") != nullptr;  // A/B switch
+      constexpr bool no_all = false;  // (round 6: the NF_L64_NO_FWD_ALL A/B switch is retired -- its question is answered, README "switches")
       if (NGa >= 2 && lds_all <= 144 * 1024 && !no_all) {  // every output block of a wide layer in one launch
         const L64Layer L{net.w[l], net.b[l], nin, nout, 0};
         const unsigned grid8 = (unsigned)std::min<long>(((a.N + 31) / 32 + 7) / 8, (long)ctx->num_cu);
@@ -2264,7 +2264,7 @@ static int l64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &
       NF_HIP(hipGetLastError());
     }
     // the layers below it in one more launch when there are one or two, none wider than 64 (k_l64_hidden_bwd)
-    static const bool no_hid = std::getenv("NF_L64_NO_HIDDEN_FUSE") != nullptr;  // A/B switch: k_l64_dw / k_l64_bwdx per layer
+    constexpr bool no_hid = false;  // (round 6: the NF_L64_NO_HIDDEN_FUSE A/B switch is retired -- its question is answered, README "switches")
     bool narrow = !no_hid && last <= 2 && net.dims[0] <= 64;
     for (int l = 0; l < last; ++l) narrow = narrow && net.dims[l + 1] <= 64;
     if (narrow) {
@@ -2311,7 +2311,7 @@ static int l64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &
     const G64Net &net = a.net[n];
     // layers 1 .. ct are narrow (widths <= 64): their input cotangents in one launch (k_l64_bwdx_chain)
     int ct = 0;
-    static const bool no_bchain = std::getenv("NF_L64_NO_BWDX_CHAIN") != nullptr;  // A/B switch
+    constexpr bool no_bchain = false;  // (round 6: the NF_L64_NO_BWDX_CHAIN A/B switch is retired -- its question is answered, README "switches")
     while (ct + 1 < net.nl && net.dims[ct + 1] <= 64 && net.dims[ct + 2] <= 64) ++ct;
     if (top_fused && ct == net.nl - 1) --ct;  // the output layer's input cotangent is already there
     if (ct < 2 || no_bchain) ct = 0;
@@ -2338,7 +2338,7 @@ static int l64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &
       const int nyx = l == 0 ? 1 : nym;
       // a layer wider than one launch of k_l64_dw takes: all its columns at once, a column range per wave
       const int OBc = (blocks + 3) / 4;
-      static const bool no_cols = std::getenv("NF_L64_NO_DW_COLS") != nullptr;  // A/B switch
+      constexpr bool no_cols = false;  // (round 6: the NF_L64_NO_DW_COLS A/B switch is retired -- its question is answered, README "switches")
       if (blocks > l64_maxg(IB, true) && IB * OBc <= 8 && OBc <= 4 && !no_cols) {
         const L64Layer L{net.w[l], net.b[l], nin, nout, 0};
         const L64Src gs{gsrc, Fg, 0, 0, 0};
@@ -2390,7 +2390,7 @@ static int l64_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, const G64Args &
       const int OBa = l64_maxg(IB, false) >= 4 ? 4 : l64_maxg(IB, false);
       const int NGa = (blocks + OBa - 1) / OBa;
       const size_t lds_all = (size_t)NGa * (32 * IB * (32 * OBa + NF_IMG_PAD) + 32 * OBa) * sizeof(float);
-      static const bool no_all = std::getenv("NF_L64_NO_BWDX_ALL") != nullptr;  // A/B switch
+      constexpr bool no_all = false;  // (round 6: the NF_L64_NO_BWDX_ALL A/B switch is retired -- its question is answered, README "switches")
       for (int m = 0; m < (l == 0 ? nym : 1); ++m) {  // l == 0: net by net (nyx = 1); else one launch for both (m = 0 only)
         const G64Net &nm = a.net[n + m];
         const float *gsrc_m = top ? b.dout[n + m] : b.gh[n + m][l];

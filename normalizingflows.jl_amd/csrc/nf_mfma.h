@@ -710,27 +710,6 @@ __device__ __forceinline__ f32x16 nf_mfma_bf16(nf_u32x4 a, nf_u32x4 b, f32x16 c)
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nf_bf16x8, a), __builtin_bit_cast(nf_bf16x8, b), c, 0, 0, 0);
 }
 
-// The same instruction with its A operand in the ACCUMULATION half of the register file (round 6).  A 512-register kernel
-// has 256 architectural and 256 accumulation registers; hipcc gives a long-lived MFMA operand (a wave's weights, kept for the
-// whole launch) a home in the accumulation half and then COPIES it into architectural registers in front of every MFMA that
-// reads it (v_accvgpr_read_b32: 600 of a tile's 2 200 vector instructions in k_rqs_bwd_coop6), although gfx950's MFMA takes
-// srcA / srcB from either half.  In inline asm the operand class can be stated ("a").  What the compiler then no longer
-// does is the wait states between a matrix instruction's write and an ordinary read of the same registers (it does not
-// look inside the asm): nf_mfma_settle() behind the LAST instruction of an accumulation chain supplies them (an 8-pass
-// instruction's result may be read by a vector / memory instruction 11 states later; dependent MFMAs on the same
-// accumulator need none).
-__device__ __forceinline__ f32x16 nf_mfma_bf16_wa(nf_u32x4 a_acc, nf_u32x4 b, f32x16 c) {
-  asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "a"(a_acc), "v"(b));
-  return c;
-}
-template <int NB>
-__device__ __forceinline__ void nf_mfma_settle(f32x16 (&c)[NB]) {
-  static_assert(NB >= 1 && NB <= 3, "one asm statement ties all blocks");
-  if constexpr (NB == 1) asm volatile("s_nop 11" : "+v"(c[0]));
-  if constexpr (NB == 2) asm volatile("s_nop 11" : "+v"(c[0]), "+v"(c[1]));
-  if constexpr (NB == 3) asm volatile("s_nop 11" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]));
-}
-
 // ---- the split with its two exact subtractions ON THE MATRIX PIPE (round 6) -----------------------------------------------
 // nf_split2 spends 4.5 vector instructions per value, two thirds of them on r = x - h and l = r - m (widen h: shl + and per
 // pair, then v_pk_add_f32; the same for m).  Both differences are exact, and an MFMA computes exact differences for free:

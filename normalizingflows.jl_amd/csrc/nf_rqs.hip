@@ -24,11 +24,17 @@
 
 #include "nf_common.h"
 #include "nf_mfma.h"
-// k_rqs_bwd_coop6: the wave's weight triples as MFMA operands straight from the accumulation registers (nf_mfma_bf16_wa,
-// nf_mfma.h; round 6: 289 -> 135 v_accvgpr_read in the kernel, none left in the chunk phase, scratch 28 -> 0 bytes,
-// 107.8 -> 107.3 us per launch on one box)
-#define RQS6_MFMA_W(a, b, c) nf_mfma_bf16_wa(a, b, c)
-#define RQS6_SETTLE(c) nf_mfma_settle(c)
+// k_rqs_bwd_coop6's matrix instructions on the wave's weight triples.  Round 6 tried them as inline asm with the A operand in
+// the accumulation half of the register file (what VERDICT r5 item 2 asked for: hipcc keeps the 144 weight registers there
+// and copies each operand into architectural registers next to the MFMA that reads it -- 289 v_accvgpr_read in the kernel):
+// the copies went away (289 -> 135, none in the chunk phase; scratch 28 -> 0 bytes), the kernel gained 0.5 % (107.8 -> 107.3 us)
+// -- and the gradient of golden nsf_d32_k8 came out 4 % wrong in the NEXT build, whose only difference was the address the
+// kernel was linked at (an unrelated kernel removed from the file; identical ISA, tools/isa_stats.py).  hipcc's hazard
+// recognizer does not look inside inline asm, so every wait state between a vector instruction and a matrix instruction that
+// shares a register with it is the author's to supply, and the set nf_mfma_settle() supplied (12 states behind an accumulation
+// chain) was evidently not the whole set.  Not shipped: the builtin, whose hazards the compiler handles.
+#define RQS6_MFMA_W(a, b, c) nf_mfma_bf16(a, b, c)
+#define RQS6_SETTLE(c) ((void)0)
 #include "nf_philox.h"
 
 template <int MB_, int H1B_, int H2B_, int K_, int NCH_, int QCH_ = 2>
@@ -876,41 +882,6 @@ __global__ __launch_bounds__(256, 1) void k_rqs_bwd(RqsBwdArgs a, float *__restr
 // The whole chain's reverse pass in ONE launch (the structure of k_affine_bwd_all, nf_coupling.hip): a wave's tiles
 // never change hands and coupling k + 1 only reads what the same wave wrote for coupling k (y <- x, ybar <- xbar),
 // so each workgroup walks the couplings on its own -- seven launch gaps and ramp-up / tail phases less per step.
-struct RqsBwdAllArgs {
-  RqsTape tape;
-  const float *wimg;  // [coupling][G::SIZE]
-  long long *trace;
-  int d, ncoup;
-  float B;
-  long N;
-};
-template <class G, bool INVD>
-__global__ __launch_bounds__(256, 1) void k_rqs_bwd_all(RqsBwdAllArgs aa, float *__restrict__ y, float *__restrict__ ybar,
-                                                        const float *__restrict__ lbar, float lbar_const,
-                                                        float *__restrict__ slab, long slab_stride) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-#pragma unroll 1
-  for (int step = 0; step < aa.ncoup; ++step) {
-    const int k = INVD ? aa.ncoup - 1 - step : step;  // the inverse chain's reverse pass runs in execution order
-    RqsBwdArgs a;
-    a.tape = aa.tape;
-    a.k = k;
-    a.ncoup = aa.ncoup;
-    a.img = aa.wimg + (size_t)k * G::SIZE;
-    a.img6 = nullptr;
-    a.d = aa.d;
-    a.par_t = k & 1;
-    a.c = (k & 1) ? aa.d / 2 : (aa.d + 1) / 2;
-    a.m = aa.d - a.c;
-    a.B = aa.B;
-    a.N = aa.N;
-    a.trace = k == 0 ? aa.trace : nullptr;
-    // coupling k + 1 loads this same wave's stores of coupling k: ordered by the barrier that ends
-    // rqs_bwd_coupling (s_waitcnt vmcnt(0)), the vector L1 is write-through -- as in k_affine_bwd_all
-    rqs_bwd_coupling<G, INVD>(a, y, ybar, lbar, lbar_const, slab + (long)k * G::SIZE, slab_stride, lds);
-  }
-}
-
 // ---------------------------------------------------------------------------------------
 // reverse pass of one coupling, COOPERATIVE form (geometries with NCH == 4 chunks)
 // ---------------------------------------------------------------------------------------
@@ -2112,37 +2083,3 @@ int nf_rqs_bwd(nf_ctx *ctx, const nf_flow_desc *desc, int k, float *y, float *yb
 #undef RQS_CALL
 }
 
-template <class G, bool INVD>
-static int launch_rqs_bwd_all(nf_ctx *ctx, const nf_flow_desc *desc, float *y, float *ybar, const float *lbar,
-                              float lbar_const, long N, float *slab, long slab_stride, int grid, void *tape) {
-  if (!tape) return NF_ERR_ARG;
-  const size_t lds = RqsLds<G>::BYTES;
-  static AttrOnce attr_once;  // once per device
-  NF_TRY(attr_once.run(ctx->device, [&]() -> int {
-    NF_HIP(hipFuncSetAttribute((const void *)k_rqs_bwd_all<G, INVD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    return NF_OK;
-  }));
-  RqsBwdAllArgs aa;
-  aa.tape = rqs_tape_at(desc, N, tape);
-  aa.wimg = (const float *)ctx->wimg;
-  aa.trace = (long long *)ctx->trace;
-  aa.d = desc->d; aa.ncoup = 2 * desc->nlayers; aa.B = desc->B; aa.N = N;
-  ProfScope ps(ctx, INVD ? "rqs_bwd_inv" : "rqs_bwd");
-  hipLaunchKernelGGL((k_rqs_bwd_all<G, INVD>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, aa, y, ybar, lbar,
-                     lbar_const, slab, slab_stride);
-  return (int)hipGetLastError();
-}
-
-// every coupling of the chain in one launch (flat order; inv_dir: forward execution order, see rqs_bwd_tile)
-int nf_rqs_bwd_all(nf_ctx *ctx, const nf_flow_desc *desc, float *y, float *ybar, const float *lbar, float lbar_const,
-                   long N, float *slab, long slab_stride, int grid, bool inv_dir, void *tape) {
-  const int id = rqs_geo_id(desc);
-  if (!id || !ctx->wimg) return NF_ERR_UNSUPPORTED;
-  if (id == 3) return NF_ERR_UNSUPPORTED;  // GeoK10L: cooperative per-coupling launches only
-  if (inv_dir) {
-    if (id == 1) return launch_rqs_bwd_all<GeoK8, true>(ctx, desc, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid, tape);
-    return launch_rqs_bwd_all<GeoK10, true>(ctx, desc, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid, tape);
-  }
-  if (id == 1) return launch_rqs_bwd_all<GeoK8, false>(ctx, desc, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid, tape);
-  return launch_rqs_bwd_all<GeoK10, false>(ctx, desc, y, ybar, lbar, lbar_const, N, slab, slab_stride, grid, tape);
-}

@@ -182,6 +182,10 @@ def main():
         res["f64_realnvp_d64_h64_n65536_f64_mfma"] = time_step(flow, dg(64, torch.float64), 65536, max(3, args.steps // 10), warmup=2)
         flow = nf.nsf(nf.MvNormal(5), (32, 32), 10, 30.0, 2, paramtype=torch.float64, device=dev, seed=123)
         res["f64_nsf_d5_h32_k10_n65536_f64_mfma"] = time_step(flow, dg(5, torch.float64), 65536, max(3, args.steps // 10), warmup=2)
+        # the reference's DEFAULT constructor nsf(q0) = nsf(q0, [32, 32], 10, 30.0, 10; paramtype = Float64) (neuralspline.jl:232-234) on a
+        # 32-dimensional base, two of its ten layers: 464 net outputs per coupling -- the output layer in six passes (round 6)
+        flow = nf.nsf(nf.MvNormal(32), (32, 32), 10, 30.0, 2, paramtype=torch.float64, device=dev, seed=123)
+        res["f64_nsf_d32_h32_k10_4couplings_n65536_f64_mfma"] = time_step(flow, dg(32, torch.float64), 65536, max(3, args.steps // 10), warmup=2)
     if want("fwd"):
         # forward-only objective evaluation, elbo_batch(rng, flow, logp, n) (src/objectives/elbo.jl:93-97): SURVEY 8(d)'s
         # "forward-only ELBO samples/s" -- draws + chain + target + mean in one launch, no stash (the B6 chain for RealNVP)
