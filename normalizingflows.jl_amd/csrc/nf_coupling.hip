@@ -1456,11 +1456,23 @@ __global__ __launch_bounds__(256, 1) void k_affine_bwd_stashed(BwdAllArgs aa, fl
 // triples for its own dX GEMM), leaves them in LDS transposed (split_to_lds) instead of the fp32 tile, and the consumer splits
 // only the stashed activations.  Two triple buffers per pair, used alternately (d3 | d2 | d1 | next d3 | ...): a buffer is
 // rewritten two barriers after the GEMM that read it.
+#ifndef NF_PAIR_TR
+#define NF_PAIR_TR 1  // the producer -> consumer hand-over of the cotangent triples through ds_read_b64_tr_b16 (nf_mfma.h, round 6); 0: split_to_lds
+#endif
+#if NF_PAIR_TR
+#define NF_PAIR_BUF TR_BUF
+#define NF_PAIR_PUT(NB, buf, s) split_to_lds_tr<NB>(buf, s, l31, hi)
+#define NF_PAIR_DW(IB, OB, as, buf, w, b) dw_accumulate_tr6<IB, OB>(as, buf, w, b, l31, hi)
+#else
+#define NF_PAIR_BUF D6_BUF
+#define NF_PAIR_PUT(NB, buf, s) split_to_lds<NB>(buf, s, l31, hi)
+#define NF_PAIR_DW(IB, OB, as, buf, w, b) dw_accumulate_t6<IB, OB>(as, buf, w, b, l31, hi)
+#endif
 template <class G, bool PB6 = false, bool DW6 = false>
 struct BwdPairLds {
   static_assert(!DW6 || (PB6 && G::CB <= 2 && G::H1B <= 2 && G::H2B <= 2), "triple buffers hold two blocks");
   static constexpr int D3 = 0, D2 = D3 + G::CB * 32 * NF_TS, D1 = D2 + G::H2B * 32 * NF_TS;
-  static constexpr int PAIR = DW6 ? 2 * D6_BUF / 4 : D1 + G::H1B * 32 * NF_TS;
+  static constexpr int PAIR = DW6 ? 2 * NF_PAIR_BUF / 4 : D1 + G::H1B * 32 * NF_TS;
   static constexpr int PAIRS = 4;
   static constexpr int IMG = PB6 ? B6TGeo<G>::BYTES / 4 : G::SIZE;  // floats of the staged weight image
   static constexpr int FLOATS = (IMG + PAIRS * PAIR) > PAIRS * G::SIZE ? (IMG + PAIRS * PAIR) : PAIRS * G::SIZE;
@@ -1477,7 +1489,7 @@ __device__ __forceinline__ void pair_produce(const CouplingArgs &a, const float 
                                              bool live, int l31, int hi, int par, long long *tr = nullptr) {
   using SG = StashGeo<G, SLIM>;
   using L = BwdPairLds<G, PB6, DW6>;
-  char *bufa = reinterpret_cast<char *>(sp) + par * D6_BUF, *bufb = reinterpret_cast<char *>(sp) + (par ^ 1) * D6_BUF;  // DW6
+  char *bufa = reinterpret_cast<char *>(sp) + par * NF_PAIR_BUF, *bufb = reinterpret_cast<char *>(sp) + (par ^ 1) * NF_PAIR_BUF;  // DW6
   if (!live) {
     __syncthreads();
     __syncthreads();
@@ -1525,7 +1537,7 @@ __device__ __forceinline__ void pair_produce(const CouplingArgs &a, const float 
   SplitC<DW6 ? G::CB : 1> s3;
   if constexpr (DW6) {
     split_C<G::CB>(d3, s3);
-    split_to_lds<G::CB>(bufa, s3, l31, hi);
+    NF_PAIR_PUT(G::CB, bufa, s3);
   } else {
     tile_to_scratch<G::CB>(sp + L::D3, d3, l31, hi);
   }
@@ -1539,32 +1551,53 @@ __device__ __forceinline__ void pair_produce(const CouplingArgs &a, const float 
   NF_TS_STAMP(2);
   f32x16 d2[G::H2B];
   const nf_u32x4 *wt = reinterpret_cast<const nf_u32x4 *>(img);  // PB6: the staged image is the net's B6T image
+  SplitC<DW6 ? G::H2B : 1> s2;
+#if NF_PAIR_TR
+  // (round 6) the GEMM block by block: what follows a finished block of d2 -- slopes, split, hand-over stores -- rides in the
+  // issue shadows of the next block's matrix instructions; only the last block's share is left behind the GEMM
+  const int xw = (l31 >> 2) & 3;
+  char *const pw0 = reinterpret_cast<char *>(sp) + l31 * 32 + 8 * (hi ^ xw), *const pw1 = reinterpret_cast<char *>(sp) + l31 * 32 + 8 * ((2 + hi) ^ xw);
+  if constexpr (DW6) {
+    const PairPost<G::H2B> post{d2, m2, s2, pw0 + (bufb - reinterpret_cast<char *>(sp)), pw1 + (bufb - reinterpret_cast<char *>(sp))};
+    dense_bwd_x_b6s_blocks<G::H2B, G::CB>(wt + B6TGeo<G>::T3, s3, d2, l31, hi, [&](int ib, int i) { if (ib > 0) post.template at_hook<24 * G::CB>(ib - 1, i); });
+    post.all(G::H2B - 1);
+  } else
+#endif
+  {
   if constexpr (DW6) dense_bwd_x_b6s<G::H2B, G::CB>(wt + B6TGeo<G>::T3, s3, d2, l31, hi);
   else if constexpr (PB6) dense_bwd_x_b6<G::H2B, G::CB>(wt + B6TGeo<G>::T3, d3, d2, l31, hi);
   else dense_bwd_x<G::H2B, G::CB>(img + G::W3, d3, d2, l31, hi);
   apply_lrelu_grad<G::H2B>(d2, m2);
-  SplitC<DW6 ? G::H2B : 1> s2;
   if constexpr (DW6) {
     split_C<G::H2B>(d2, s2);
-    split_to_lds<G::H2B>(bufb, s2, l31, hi);
-
+    NF_PAIR_PUT(G::H2B, bufb, s2);
   } else {
     tile_to_scratch<G::H2B>(sp + L::D2, d2, l31, hi);
+  }
   }
   NF_TS_STAMP(3);
   __syncthreads();  // B2
   NF_TS_STAMP(4);
   f32x16 d1[G::H1B];
+  SplitC<DW6 ? G::H1B : 1> s1;
+#if NF_PAIR_TR
+  if constexpr (DW6) {
+    const PairPost<G::H1B> post{d1, m1, s1, pw0 + (bufa - reinterpret_cast<char *>(sp)), pw1 + (bufa - reinterpret_cast<char *>(sp))};
+    dense_bwd_x_b6s_blocks<G::H1B, G::H2B>(wt + B6TGeo<G>::T2, s2, d1, l31, hi, [&](int ib, int i) { if (ib > 0) post.template at_hook<24 * G::H2B>(ib - 1, i); });
+    post.all(G::H1B - 1);
+  } else
+#endif
+  {
   if constexpr (DW6) dense_bwd_x_b6s<G::H1B, G::H2B>(wt + B6TGeo<G>::T2, s2, d1, l31, hi);
   else if constexpr (PB6) dense_bwd_x_b6<G::H1B, G::H2B>(wt + B6TGeo<G>::T2, d2, d1, l31, hi);
   else dense_bwd_x<G::H1B, G::H2B>(img + G::W2, d2, d1, l31, hi);
   apply_lrelu_grad<G::H1B>(d1, m1);
-  SplitC<DW6 ? G::H1B : 1> s1;
   if constexpr (DW6) {
     split_C<G::H1B>(d1, s1);
-    split_to_lds<G::H1B>(bufa, s1, l31, hi);
+    NF_PAIR_PUT(G::H1B, bufa, s1);
   } else {
     tile_to_scratch<G::H1B>(sp + L::D1, d1, l31, hi);
+  }
   }
   NF_TS_STAMP(5);
   __syncthreads();  // B3
@@ -1581,6 +1614,9 @@ __device__ __forceinline__ void pair_produce(const CouplingArgs &a, const float 
   NF_TS_STAMP(7);
 }
 
+// (Round 6, measured and removed: the consumer held back by s_sleep behind each barrier -- 256 / 512 / 768 clocks in stage 1,
+// twice that in stage 2 -- so that its matrix instructions would run beside the producer's vector tail instead of beside its
+// GEMM: 323.2-325.2 against 325.5 us on one box, nothing.  The older wave already wins the arbitration.)
 // (Measured and removed: dW1 of a tile moved in front of the NEXT tile's first barrier, where the producer issues no
 // MFMAs -- 374-379 us against 366 in one process; and the producer's next-unit operands requested behind B3 -- 370.)
 template <class G, bool SLIM, bool PB6 = false, bool DW6 = false>
@@ -1602,7 +1638,7 @@ __device__ __forceinline__ void pair_consume(const float *__restrict__ img, cons
   const StashIO st = make_stash_io(stash, tile * ncoup + k, SG::SIZE, true, l31, hi);
   const int vT = (l31 * 32 + hi * 16) * 4;
   if constexpr (DW6) {
-    const char *bufa = reinterpret_cast<const char *>(sp) + par * D6_BUF, *bufb = reinterpret_cast<const char *>(sp) + (par ^ 1) * D6_BUF;
+    const char *bufa = reinterpret_cast<const char *>(sp) + par * NF_PAIR_BUF, *bufb = reinterpret_cast<const char *>(sp) + (par ^ 1) * NF_PAIR_BUF;
     float a1t[G::H1B][16];
     {
       // (Measured and removed: the NEXT tile's a2 requested behind B3 -- 32 more registers across the loop's back edge, which
@@ -1617,7 +1653,7 @@ __device__ __forceinline__ void pair_consume(const float *__restrict__ img, cons
       NF_TS_STAMP(1);
       __syncthreads();  // B1
       NF_TS_STAMP(2);
-      dw_accumulate_t6<G::H2B, G::CB>(a2s, bufa, acc.w3, acc.b3, l31, hi);
+      NF_PAIR_DW(G::H2B, G::CB, a2s, bufa, acc.w3, acc.b3);
     }
     float x2t[G::MB][16];
     {
@@ -1627,7 +1663,7 @@ __device__ __forceinline__ void pair_consume(const float *__restrict__ img, cons
       NF_TS_STAMP(3);
       __syncthreads();  // B2
       NF_TS_STAMP(4);
-      dw_accumulate_t6<G::H1B, G::H2B>(a1s, bufb, acc.w2, acc.b2, l31, hi);
+      NF_PAIR_DW(G::H1B, G::H2B, a1s, bufb, acc.w2, acc.b2);
     }
     {
       SplitT<G::MB> x2s;
@@ -1635,7 +1671,7 @@ __device__ __forceinline__ void pair_consume(const float *__restrict__ img, cons
       NF_TS_STAMP(5);
       __syncthreads();  // B3
       NF_TS_STAMP(6);
-      dw_accumulate_t6<G::MB, G::H1B>(x2s, bufa, acc.w1, acc.b1, l31, hi);
+      NF_PAIR_DW(G::MB, G::H1B, x2s, bufa, acc.w1, acc.b1);
       NF_TS_STAMP(7);
     }
     return;  // (the dW1 block below belongs to the two fp32-tile forms)

@@ -1008,6 +1008,43 @@ __device__ __forceinline__ void dense_bwd_x_b6s(const nf_u32x4 *__restrict__ w, 
   }
 }
 
+// dense_bwd_x_b6s with the OUTPUT BLOCKS one after the other (round 6): block ib's matrix instructions carry a side job --
+// sj(ib, i), i = 0 .. 12 NKG - 1, two calls behind every MFMA -- so that what follows a finished block (leaky-ReLU slopes,
+// split, hand-over stores: PairPost below) runs in the issue shadows of the NEXT block's instructions instead of behind the
+// whole GEMM.  The same terms in the same order per accumulator as dense_bwd_x_b6s: identical bits.
+template <int IB, int OB, class SJ>
+__device__ __forceinline__ void dense_bwd_x_b6s_blocks(const nf_u32x4 *__restrict__ w, const SplitC<OB> &ds, f32x16 (&din)[IB], int l31,
+                                                       int hi, SJ sj) {
+  constexpr int ROWS = 32 * IB, NKG = 2 * OB, NU = NKG * IB;
+#pragma unroll
+  for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) din[ib][r] = 0.f;
+  const nf_u32x4 *wl = w + hi * ROWS + l31;
+  nf_u32x4 an[3], ac[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) an[c] = wl[c * 2 * ROWS];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int ib = u / NKG, kg = u % NKG;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ac[c] = an[c];
+    if (u + 1 < NU) {
+      const int ib1 = (u + 1) / NKG, kg1 = (u + 1) % NKG;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) an[c] = wl[(kg1 * 3 + c) * 2 * ROWS + ib1 * 32];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    din[ib] = nf_mfma_bf16(ac[2], ds.h[kg], din[ib]); sj(ib, 12 * kg + 0); sj(ib, 12 * kg + 1);
+    din[ib] = nf_mfma_bf16(ac[0], ds.l[kg], din[ib]); sj(ib, 12 * kg + 2); sj(ib, 12 * kg + 3);
+    din[ib] = nf_mfma_bf16(ac[1], ds.m[kg], din[ib]); sj(ib, 12 * kg + 4); sj(ib, 12 * kg + 5);
+    din[ib] = nf_mfma_bf16(ac[1], ds.h[kg], din[ib]); sj(ib, 12 * kg + 6); sj(ib, 12 * kg + 7);
+    din[ib] = nf_mfma_bf16(ac[0], ds.m[kg], din[ib]); sj(ib, 12 * kg + 8); sj(ib, 12 * kg + 9);
+    din[ib] = nf_mfma_bf16(ac[0], ds.h[kg], din[ib]); sj(ib, 12 * kg + 10); sj(ib, 12 * kg + 11);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // The transposed hand-over of such triples: the dW GEMM contracts over SAMPLES, so its delta operand wants lane <-> feature
 // and a lane's eight k-values = eight samples.  LDS tile of one cotangent tensor: row = feature (D6_ROW bytes: three
 // components x 64 bytes + 16 of padding -- 52 dwords, so eight consecutive rows' 16-byte reads cover the 32 banks once),
@@ -1089,6 +1126,130 @@ __device__ __forceinline__ void dw_accumulate_t6(const SplitT<IB> &as, const cha
         for (int c = 0; c < 3; ++c) dn[c] = pd[ob1 * RB + c * 4 + g1 * 2];
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int term = 0; term < 6; ++term)
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib) {
+        const nf_u32x4 &a = term == 0 ? as.l[ib][g] : (term == 2 || term == 3) ? as.m[ib][g] : as.h[ib][g];
+        const nf_u32x4 &d = term == 1 ? dc[2] : (term == 2 || term == 4) ? dc[1] : dc[0];
+        acc[ib][ob] = nf_mfma_bf16(a, d, acc[ib][ob]);
+        if (term * IB + ib < 6) {  // the twelve bias-sum instructions ride between the unit's first MFMAs
+          const int i0 = 2 * (term * IB + ib);
+#pragma unroll
+          for (int i = i0; i < i0 + 2; ++i) bsum[ob] = nf_dot2_bf16(dc[2 - i / 4][i % 4], ones, bsum[ob]);
+        }
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// ---- the same hand-over through gfx950's transposing LDS read (round 6) ------------------------------------------------
+// split_to_lds transposes on the WRITE side: 8 two-byte stores per (k-group, component) and lane, 96 store instructions for a
+// 64-feature cotangent -- at the end of the producer's stage, on the pair kernel's critical path, through a store path four
+// producers share.  ds_read_b64_tr_b16 transposes on the READ side for free: within a 16-lane group, lane c receives element
+// (c & 3) of what lane 4 j + (c >> 2) read, j = 0..3 (tools/probe/ds_read_tr_probe.hip) -- a 4 x 16 tile handed over
+// column-wise.  So the writer keeps its natural layout, [sample][16 features] rows of 32 bytes per (16-feature tile =
+// k-group, component): a lane holds, for its sample, features 4 hi .. 4 hi + 3 and 8 + 4 hi .. 8 + 4 hi + 3 of a k-group as
+// two register pairs = TWO 8-byte stores per (k-group, component), 24 instead of 96 for 64 features; and the reader's
+// lane (feature column c of its tile, jj = c >> 2, q = c & 3) reads the 8-byte chunk q of row hi + 16 g + 2 (jj + 4 r),
+// r = 0, 1 -- the samples the T layout of the stashed activations pairs with element j = jj + 4 r of sample group g -- and
+// receives its own column of those four rows: two reads per operand.  Chunk q of row s is stored at position q ^ ((s >> 2) & 3)
+// (each lane supplies its own address, so rows and chunks may sit anywhere): a 16-lane write group then covers 16 different
+// even banks, a read group 4 x 8 banks 16 apart, and with tiles 1 056 bytes apart the two groups of a half-wave interleave
+// -- both directions conflict-free.  Buffer of one tensor: [component 3][tile 4] x 1 056 bytes.
+constexpr int TR_TILE = 1056, TR_BUF = 12 * TR_TILE;
+typedef short nf_s16x4 __attribute__((ext_vector_type(4)));
+template <int NB>
+__device__ __forceinline__ void split_to_lds_tr(char *__restrict__ buf, const SplitC<NB> &s, int l31, int hi) {
+  const int x = (l31 >> 2) & 3;
+  char *p0 = buf + l31 * 32 + 8 * (hi ^ x), *p1 = buf + l31 * 32 + 8 * ((2 + hi) ^ x);
+#pragma unroll
+  for (int kg = 0; kg < 2 * NB; ++kg)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const nf_u32x4 &v = c == 0 ? s.h[kg] : c == 1 ? s.m[kg] : s.l[kg];
+      *reinterpret_cast<nf_u32x2 *>(p0 + (c * 4 + kg) * TR_TILE) = nf_u32x2{v[0], v[1]};
+      *reinterpret_cast<nf_u32x2 *>(p1 + (c * 4 + kg) * TR_TILE) = nf_u32x2{v[2], v[3]};
+    }
+}
+// What the pair kernel's producer does with a finished 32-feature block of a cotangent, in twenty steps of a few instructions
+// each (the side job of dense_bwd_x_b6s_blocks): steps 0..7 pair p of the block -- its two leaky-ReLU slopes from the mask
+// (nf_lrelu_grad16's form), the product, the three-way split of the pair; steps 8..19 the twelve 8-byte hand-over stores of
+// the block's two k-groups (split_to_lds_tr's).  Steps beyond 19 do nothing.  `i` is a constant after unrolling.
+template <int NB>
+struct PairPost {
+  f32x16 (&d)[NB];
+  const unsigned (&msk)[NB];
+  SplitC<NB> &s;
+  char *p0, *p1;  // the lane's two chunk addresses in the hand-over buffer (split_to_lds_tr)
+  __device__ __forceinline__ void step(int b, int i) const {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    if (i < 8) {
+      const int p = i, kg = 2 * b + (p >> 2), e = p & 3;
+      const unsigned one = 0x3F800000u, flip = 0x3F800000u ^ 0x3C23D70Au;
+      int t0, t1;
+      unsigned s0, s1;
+      asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(t0) : "v"(msk[b]), "n"(i < 8 ? 15 - 2 * i : 0));
+      asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(t1) : "v"(msk[b]), "n"(i < 8 ? 14 - 2 * i : 0));
+      asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x6c" : "=v"(s0) : "v"(t0), "v"(one), "v"(flip));
+      asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x6c" : "=v"(s1) : "v"(t1), "v"(one), "v"(flip));
+      f32x2_t v = {d[b][2 * p], d[b][2 * p + 1]};
+      const f32x2_t sl = {__builtin_bit_cast(float, s0), __builtin_bit_cast(float, s1)};
+      asm("v_pk_mul_f32 %0, %1, %2" : "=v"(v) : "v"(v), "v"(sl));
+      unsigned h, m, l;
+      nf_split2(v.x, v.y, h, m, l);
+      s.h[kg][e] = h; s.m[kg][e] = m; s.l[kg][e] = l;
+    } else if (i < 20) {
+      const int w = i - 8, kg = 2 * b + w / 6, c = (w % 6) / 2, half = w & 1;
+      const nf_u32x4 &v = c == 0 ? s.h[kg] : c == 1 ? s.m[kg] : s.l[kg];
+      char *q = (half ? p1 : p0) + (c * 4 + kg) * TR_TILE;
+      *reinterpret_cast<nf_u32x2 *>(q) = half ? nf_u32x2{v[2], v[3]} : nf_u32x2{v[0], v[1]};
+    }
+  }
+  __device__ __forceinline__ void all(int b) const {
+#pragma unroll
+    for (int i = 0; i < 20; ++i) step(b, i);
+  }
+  // hook h of NH (two behind every matrix instruction of the next block): the eight pair steps (14 instructions each) spread over
+  // the whole block, a k-group's six stores behind its fourth pair
+  template <int NH>
+  static constexpr int hook_of(int i) {
+    return i < 8 ? i * NH / 9 : i < 14 ? NH / 3 + 1 + (i - 8) * (NH / 3 - 1) / 6 : 7 * NH / 9 + 1 + (i - 14) * (NH - 7 * NH / 9 - 2) / 6;
+  }
+  template <int NH>
+  __device__ __forceinline__ void at_hook(int b, int h) const {
+#pragma unroll
+    for (int i = 0; i < 20; ++i)
+      if (hook_of<NH>(i) == h) step(b, i);
+  }
+};
+// one MFMA operand: the lane's feature column over the eight samples of sample group g (two transposing reads)
+__device__ __forceinline__ nf_u32x4 nf_tr_operand(const char *p0, const char *p1, int off) {
+  typedef __attribute__((address_space(3))) nf_s16x4 lds_s16x4;
+  const nf_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p0 + off));
+  const nf_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p1 + off));
+  const nf_u32x2 lo = __builtin_bit_cast(nf_u32x2, a), hi2 = __builtin_bit_cast(nf_u32x2, b);
+  return nf_u32x4{lo.x, lo.y, hi2.x, hi2.y};
+}
+// dw_accumulate_t6 on a cotangent left by split_to_lds_tr
+template <int IB, int OB>
+__device__ __forceinline__ void dw_accumulate_tr6(const SplitT<IB> &as, const char *buf, f32x16 (&acc)[IB][OB],
+                                                  float (&bsum)[OB], int l31, int hi) {
+  // lane offsets of the two reads: row hi + 2 jj (+ 8 for the second), chunk q at its swizzled position, the lane's tile of the pair
+  const int c16 = l31 & 15, jj = c16 >> 2, q = c16 & 3, r0 = hi + 2 * jj, r1 = r0 + 8;
+  const char *p0 = buf + (l31 >> 4) * TR_TILE + r0 * 32 + 8 * (q ^ ((r0 >> 2) & 3));
+  const char *p1 = buf + (l31 >> 4) * TR_TILE + r1 * 32 + 8 * (q ^ ((r1 >> 2) & 3));
+  constexpr int NU = 2 * OB;
+  nf_u32x4 dc[3];
+  const unsigned ones = 0x3F803F80u;  // bf16 (1, 1)
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int g = u / OB, ob = u % OB;
+    // (no operand double buffer: the consumer is at its 256 registers, and it is the wave with slack -- the twelve registers of a
+    // second operand set cost 28 bytes of scratch around the tile loop, the exposed LDS round trip per unit nothing measurable)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dc[c] = nf_tr_operand(p0, p1, (c * 4 + 2 * ob) * TR_TILE + 512 * g);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int term = 0; term < 6; ++term)

@@ -8,6 +8,10 @@ TAG=${1:-r2}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+# the probes are git-ignored binaries: build them here (a fresh checkout published "No such file" as a result)
+for P in split_bias_probe split_mfma_probe; do
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -I normalizingflows.jl_amd/csrc -I include tools/probe/$P.hip -o tools/probe/$P > "$OUT/build_$P.log" 2>&1
+done
 python3 bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 # the driver's own command line (value = the 20 steps after 5 warm-ups; *_sustained_clock beside it)
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver_cmd.json" 2>> "$OUT/bench_default.err"
@@ -48,7 +52,10 @@ rocprofv3 --kernel-trace --stats -d "$OUT/kt_gen" -o gen --output-format csv -- 
 # arithmetic A/B of the named parity arrays (tools/parity_ab.py): default and fp32 MFMA chains
 python3 tools/parity_ab.py "$OUT/parity_ab_default.json" > "$OUT/parity_ab_default.txt" 2>&1
 NF_FWD_FP32=1 NF_BWD_FP32=1 NF_WIDE_FP32=1 python3 tools/parity_ab.py "$OUT/parity_ab_fp32_mfma.json" > "$OUT/parity_ab_fp32_mfma.txt" 2>&1
-./tools/probe/split_bias_probe > "$OUT/split_bias_probe.txt" 2>&1
+[ -x ./tools/probe/split_bias_probe ] && ./tools/probe/split_bias_probe > "$OUT/split_bias_probe.txt" 2>&1
+[ -x ./tools/probe/split_mfma_probe ] && ./tools/probe/split_mfma_probe > "$OUT/split_mfma_probe.txt" 2>&1
+# issue-side counters of the cfg-2 kernels (vector instructions per launch next to the matrix pipe's busy time)
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU -d "$OUT/pmc_cfg2_valu" -o pmc --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_cfg2_valu.log" 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU -d "$OUT/pmc_cfg3_valu" -o pmc --output-format csv -- python3 bench.py --workload cfg3 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_cfg3_valu.log" 2>&1
 # issue-side counters of the planar / radial step (missing 5): where k_simple_step's time goes
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS SQ_INSTS_SALU -d "$OUT/pmc_simple_issue" -o pmc --output-format csv -- python3 tools/bench_simple.py 262144 > "$OUT/pmc_simple_issue.log" 2>&1
@@ -74,6 +81,12 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 python3 tools/bench_configs.py --steps 30 --only f64 >> "$OUT/configs.txt" 2>&1
 NF_G64_NO_F64_MFMA=1 python3 tools/bench_configs.py --steps 30 --only f64 > "$OUT/configs_f64_scalar.txt" 2>&1
+# the parity table of THIS build on THIS box (a collection without it is not published): the whole GPU suite;
+# tests/conftest.py writes gpurun_out/parity_measured.json at the end of the session
+timeout 1800 python3 -m pytest tests -m gpu -q > "$OUT/gpu_suite.txt" 2>&1
+tail -3 "$OUT/gpu_suite.txt"
+cp gpurun_out/parity_measured.json "$OUT/parity_measured.json" 2>/dev/null
+python3 tools/kernel_resources.py > "$OUT/kernel_resources.txt" 2>&1
 # keep the merge-back small: per-dispatch traces can be large
 find "$OUT" -name "*kernel_trace.csv" -size +4M -delete
 find "$OUT" -name "*.csv" | head -60

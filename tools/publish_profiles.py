@@ -15,6 +15,11 @@ from pmc_summary import summarize  # noqa: E402
 tag = sys.argv[1]
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
+# a collection is published WITH the parity table of the build it measured, or not at all
+pm = os.path.join(src, "parity_measured.json")
+if not (os.path.exists(pm) and os.path.getsize(pm) > 1000):
+    sys.exit(f"{pm} is missing: tools/collect_profiles.sh runs the GPU suite at its end -- a collection without the parity table "
+             "of its build is not published")
 
 copies = [("bench_default.json", "bench_default.json"), ("bench_cfg3.json", "bench_cfg3.json"),
           ("bench_cfg4_1gpu_262144.json", "bench_cfg4_1gpu_262144.json"), ("bench_cfg4_shard_32768.json", "bench_cfg4_shard32768.json"),
@@ -32,12 +37,13 @@ copies = [("bench_default.json", "bench_default.json"), ("bench_cfg3.json", "ben
           ("kt_gen/gen_kernel_stats.csv", "kernel_stats_deep_f64.csv"),
           ("parity_ab_default.json", "parity_ab_default.json"), ("parity_ab_fp32_mfma.json", "parity_ab_fp32_mfma.json"),
           ("parity_ab_default.txt", "parity_ab_default.txt"), ("parity_ab_fp32_mfma.txt", "parity_ab_fp32_mfma.txt"),
-          ("split_bias_probe.txt", "split_bias_probe.txt")]
+          ("split_bias_probe.txt", "split_bias_probe.txt"), ("split_mfma_probe.txt", "split_mfma_probe.txt"),
+          ("parity_measured.json", "parity_measured.json"), ("gpu_suite.txt", "gpu_suite.txt"), ("kernel_resources.txt", "kernel_resources.txt")]
 for w in ("cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "simple"):
     copies.append((f"kt_{w}/{w}_kernel_stats.csv", f"kernel_stats_{w}.csv"))
 for a, b in copies:
     p = os.path.join(src, a)
-    if os.path.exists(p):
+    if os.path.exists(p) and os.path.getsize(p) > 0:  # (two 0-byte files of a failed step were committed in round 5)
         shutil.copy(p, os.path.join(dst, f"{tag}_{b}"))
 
 summary = {}
