@@ -1160,8 +1160,10 @@ __device__ __forceinline__ void dw_accumulate_t6(const SplitT<IB> &as, const cha
 // -- both directions conflict-free.  Buffer of one tensor: [component 3][tile 4] x 1 056 bytes.
 constexpr int TR_TILE = 1056, TR_BUF = 12 * TR_TILE;
 typedef short nf_s16x4 __attribute__((ext_vector_type(4)));
-template <int NB>
+// NT: tiles per component of the buffer (the pair kernel's buffers hold up to two blocks: 4; k_rqs_bwd_coop6's hold one: 2)
+template <int NB, int NT = 4>
 __device__ __forceinline__ void split_to_lds_tr(char *__restrict__ buf, const SplitC<NB> &s, int l31, int hi) {
+  static_assert(2 * NB <= NT, "tiles per component");
   const int x = (l31 >> 2) & 3;
   char *p0 = buf + l31 * 32 + 8 * (hi ^ x), *p1 = buf + l31 * 32 + 8 * ((2 + hi) ^ x);
 #pragma unroll
@@ -1169,9 +1171,29 @@ __device__ __forceinline__ void split_to_lds_tr(char *__restrict__ buf, const Sp
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const nf_u32x4 &v = c == 0 ? s.h[kg] : c == 1 ? s.m[kg] : s.l[kg];
-      *reinterpret_cast<nf_u32x2 *>(p0 + (c * 4 + kg) * TR_TILE) = nf_u32x2{v[0], v[1]};
-      *reinterpret_cast<nf_u32x2 *>(p1 + (c * 4 + kg) * TR_TILE) = nf_u32x2{v[2], v[3]};
+      *reinterpret_cast<nf_u32x2 *>(p0 + (c * NT + kg) * TR_TILE) = nf_u32x2{v[0], v[1]};
+      *reinterpret_cast<nf_u32x2 *>(p1 + (c * NT + kg) * TR_TILE) = nf_u32x2{v[2], v[3]};
     }
+}
+// one k-group's triples into tile `t` of a buffer with NT tiles per component (the per-k-group form)
+template <int NT>
+__device__ __forceinline__ void kg_to_lds_tr(char *__restrict__ buf, int t, nf_u32x4 h, nf_u32x4 m, nf_u32x4 l, int l31, int hi) {
+  const int x = (l31 >> 2) & 3;
+  char *p0 = buf + l31 * 32 + 8 * (hi ^ x) + t * TR_TILE, *p1 = buf + l31 * 32 + 8 * ((2 + hi) ^ x) + t * TR_TILE;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const nf_u32x4 &v = c == 0 ? h : c == 1 ? m : l;
+    *reinterpret_cast<nf_u32x2 *>(p0 + c * NT * TR_TILE) = nf_u32x2{v[0], v[1]};
+    *reinterpret_cast<nf_u32x2 *>(p1 + c * NT * TR_TILE) = nf_u32x2{v[2], v[3]};
+  }
+}
+// the reader's two lane addresses in such a buffer (rows hi + 2 jj and + 8, chunk q at its swizzled position, the lane's tile of a block)
+struct TrLane {
+  const char *p0, *p1;
+};
+__device__ __forceinline__ TrLane nf_tr_lane(const char *buf, int l31, int hi) {
+  const int c16 = l31 & 15, jj = c16 >> 2, q = c16 & 3, r0 = hi + 2 * jj, r1 = r0 + 8;
+  return TrLane{buf + (l31 >> 4) * TR_TILE + r0 * 32 + 8 * (q ^ ((r0 >> 2) & 3)), buf + (l31 >> 4) * TR_TILE + r1 * 32 + 8 * (q ^ ((r1 >> 2) & 3))};
 }
 // What the pair kernel's producer does with a finished 32-feature block of a cotangent, in twenty steps of a few instructions
 // each (the side job of dense_bwd_x_b6s_blocks): steps 0..7 pair p of the block -- its two leaky-ReLU slopes from the mask

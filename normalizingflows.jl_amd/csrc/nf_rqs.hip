@@ -1350,10 +1350,13 @@ struct RqsCoop6Lds {
   // per wave, bytes
   static constexpr int A2C = 0;                                   // a2 triples, B-operand order: [k-group][component][lane] x 16 B
   static constexpr int A2C_BYTES = 2 * G::H2B * 3 * 64 * 16;
-  static constexpr int A2T = A2C + A2C_BYTES;                     // a2 triples transposed (D6 rows, one per feature)
-  static constexpr int A2T_BYTES = 32 * G::H2B * D6_ROW;
-  static constexpr int DT = A2T + A2T_BYTES;                      // ring of two delta blocks (D6 rows); closing home phase: fp32 tiles
-  static constexpr int RING_BYTES = 2 * 32 * D6_ROW;
+  // (round 6: both through gfx950's transposing LDS read -- the writers keep their natural [sample][16 features] rows, two 8-byte
+  // stores per (k-group, component) instead of eight 2-byte ones; nf_mfma.h "TR layout")
+  static constexpr int A2T = A2C + A2C_BYTES;                     // a2 triples for the A operand of dW3: [component][2 H2B tiles] x TR_TILE
+  static constexpr int A2T_BYTES = 3 * 2 * G::H2B * TR_TILE;
+  static constexpr int DT = A2T + A2T_BYTES;                      // ring of two delta blocks ([component][2 tiles] x TR_TILE each); closing home phase: fp32 tiles
+  static constexpr int RING_BLK = 3 * 2 * TR_TILE;
+  static constexpr int RING_BYTES = 2 * RING_BLK;
   static constexpr int TILE_X = 0, TILE_A1 = G::MB * 32 * NF_TS, TILE_D = TILE_A1 + G::H1B * 32 * NF_TS;  // floats from DT
   static constexpr int TILES_BYTES = (TILE_D + DBLK * 32 * NF_TS) * 4;
   static constexpr int WAVE_BYTES = ((DT + (RING_BYTES > TILES_BYTES ? RING_BYTES : TILES_BYTES)) + 15) / 16 * 16;
@@ -1365,24 +1368,6 @@ struct RqsCoop6Lds {
   // (K = 10 at d = 32 -- 4 output blocks per chunk, 192 weight registers -- spills 390 bytes per lane: it keeps the fp32 kernel)
   static constexpr bool FITS = BYTES <= 160 * 1024 && G::OBC <= 3;
 };
-
-// one k-group of a split cotangent block -> its rows of a D6 tile (the per-k-group form of split_to_lds, nf_mfma.h):
-// `blk` = the tile of the block the k-group belongs to, g = k-group within the block (0 / 1)
-__device__ __forceinline__ void rqs_kg_to_d6(char *__restrict__ blk, int g, const nf_u32x4 &h, const nf_u32x4 &m, const nf_u32x4 &l, int l31, int hi) {
-  const int t = l31 >> 1;
-  char *p = blk + (4 * hi + 16 * g) * D6_ROW + (t >> 3) * 32 + (l31 & 1) * 16 + (t & 7) * 2;
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const nf_u32x4 &v = c == 0 ? h : c == 1 ? m : l;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int j0 = 2 * q, j1 = 2 * q + 1;
-      const int f0 = (j0 & 3) + 8 * (j0 >> 2), f1 = (j1 & 3) + 8 * (j1 >> 2);
-      *reinterpret_cast<unsigned short *>(p + f0 * D6_ROW + c * 64) = (unsigned short)v[q];
-      *reinterpret_cast<unsigned short *>(p + f1 * D6_ROW + c * 64) = (unsigned short)(v[q] >> 16);
-    }
-  }
-}
 
 // this wave's weights of the output layer, in registers for the whole launch
 template <class G>
@@ -1499,7 +1484,7 @@ __device__ __forceinline__ void rqs_bwd_coop6_coupling(const RqsBwdArgs &a, floa
         pc_[(kg * 3 + 1) * 64] = s2.m[kg];
         pc_[(kg * 3 + 2) * 64] = s2.l[kg];
       }
-      split_to_lds<G::H2B>(wv + L::A2T, s2, l31, hi);
+      split_to_lds_tr<G::H2B, 2 * G::H2B>(wv + L::A2T, s2, l31, hi);
     }
     __syncthreads();  // B0: every home tile's a2 triples are in LDS
     const int gb6 = 2 + 12 * (gcount6 < 4 ? gcount6 : 3);
@@ -1598,15 +1583,15 @@ __device__ __forceinline__ void rqs_bwd_coop6_coupling(const RqsBwdArgs &a, floa
         {
           SplitT<G::H2B> a2t;  // tile t's a2^T triples (A operand of dW3)
           {
-            const nf_u32x4 *pt = reinterpret_cast<const nf_u32x4 *>(wt_ + L::A2T + l31 * D6_ROW + hi * 16);
-            constexpr int RB = 32 * D6_ROW / 16;
+            const TrLane ta = nf_tr_lane(wt_ + L::A2T, l31, hi);
+            constexpr int NT = 2 * G::H2B;
 #pragma unroll
             for (int ib = 0; ib < G::H2B; ++ib)
 #pragma unroll
               for (int g = 0; g < 2; ++g) {
-                a2t.h[ib][g] = pt[ib * RB + 0 * 4 + g * 2];
-                a2t.m[ib][g] = pt[ib * RB + 1 * 4 + g * 2];
-                a2t.l[ib][g] = pt[ib * RB + 2 * 4 + g * 2];
+                a2t.h[ib][g] = nf_tr_operand(ta.p0, ta.p1, (0 * NT + 2 * ib) * TR_TILE + 512 * g);
+                a2t.m[ib][g] = nf_tr_operand(ta.p0, ta.p1, (1 * NT + 2 * ib) * TR_TILE + 512 * g);
+                a2t.l[ib][g] = nf_tr_operand(ta.p0, ta.p1, (2 * NT + 2 * ib) * TR_TILE + 512 * g);
               }
           }
           f32x16 d2p[G::H2B];  // (one chain: the dW3 MFMAs of the previous block run beside it)
@@ -1617,7 +1602,7 @@ __device__ __forceinline__ void rqs_bwd_coop6_coupling(const RqsBwdArgs &a, floa
           const unsigned ones = 0x3F803F80u;  // bf16 (1, 1)
 #pragma unroll
           for (int pc = 0; pc < G::OBC; ++pc) {
-            char *ring = wv + L::DT + (pc & 1) * (32 * D6_ROW);
+            char *ring = wv + L::DT + (pc & 1) * L::RING_BLK;
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
               const int kg = 2 * pc + g;
@@ -1626,7 +1611,7 @@ __device__ __forceinline__ void rqs_bwd_coop6_coupling(const RqsBwdArgs &a, floa
               for (int jj = 0; jj < 8; ++jj) v[jj] = out[pc][8 * g + jj];
               nf_u32x4 dh, dm, dl;
               nf_split8(v, dh, dm, dl);
-              rqs_kg_to_d6(ring, g, dh, dm, dl, l31, hi);
+              kg_to_lds_tr<2>(ring, g, dh, dm, dl, l31, hi);
 #pragma unroll
               for (int ib = 0; ib < G::H2B; ++ib) {
                 f32x16 &dd = d2p[ib];
@@ -1640,10 +1625,11 @@ __device__ __forceinline__ void rqs_bwd_coop6_coupling(const RqsBwdArgs &a, floa
             }
             wave_lds_order();
             // dW3^T[:, block pc] += a2^T delta_pc^T, bias gradient = row sums of delta_pc
-            const nf_u32x4 *pd = reinterpret_cast<const nf_u32x4 *>(ring + l31 * D6_ROW + hi * 16);
+            const TrLane tr = nf_tr_lane(ring, l31, hi);
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
-              const nf_u32x4 dc0 = pd[0 * 4 + g * 2], dc1 = pd[1 * 4 + g * 2], dc2 = pd[2 * 4 + g * 2];
+              const nf_u32x4 dc0 = nf_tr_operand(tr.p0, tr.p1, 0 * 2 * TR_TILE + 512 * g), dc1 = nf_tr_operand(tr.p0, tr.p1, 1 * 2 * TR_TILE + 512 * g),
+                             dc2 = nf_tr_operand(tr.p0, tr.p1, 2 * 2 * TR_TILE + 512 * g);
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
                 acc.b3[pc] = nf_dot2_bf16(dc0[i], ones, acc.b3[pc]);
