@@ -27,9 +27,8 @@ ZERO = [
     # cfg 5: the six-term inverse chain; forward-KL's reverse pass of the inverse chain
     f"void k_affine_chain<{H64}, true, false, false, false, true>(",
     f"void k_affine_bwd_pair<{H64}, true, true, false, true, true>(",
-    # cfg 3: fused forward chain (six-term output layer) and the cooperative reverse kernel
+    # cfg 3: fused forward chain (six-term output layer); the cooperative reverse kernel is in KNOWN
     f"void k_rqs_chain<{RQ8}, false, true, true>(",
-    f"void k_rqs_bwd_coop6<{RQ8}, true>(",
     # cfg 4: the slab reduction (a pure streaming kernel), weight packing
     "void k_wide_reduce_all<",
     "void k_pack_net_images<",
@@ -43,9 +42,10 @@ ZERO = [
 
 # (prefix, ceiling in bytes, why)
 KNOWN = [
-    (f"void k_rqs_bwd_coop6<{RQ8}, false>(", 28,
-     "512 registers: the wave's 144 weight registers + accumulators + the spline's state; zero with the weights as inline-asm AGPR operands, "
-     "which is not shipped (a matrix-instruction hazard hipcc does not cover inside asm: nf_rqs.hip, RQS6_MFMA_W)"),
+    (f"void k_rqs_bwd_coop6<{RQ8}, ", 24,
+     "512 registers: the wave's 144 weight registers + accumulators + the spline's state.  Four or five accumulator dwords are stored once "
+     "before the tile-group loop and re-loaded in its closing phase (not in the chunk loop).  Zero with the weights as inline-asm AGPR "
+     "operands, which is not shipped (a matrix-instruction hazard hipcc does not cover inside asm: nf_rqs.hip, RQS6_MFMA_W)"),
     ("void k_deep_bwd<DeepGeo<3, 2>, ", 348,
      "three hidden layers of 64: 192 weight-gradient accumulators + the recompute's operands exceed 512 registers; the other DeepGeo shapes are scratch-free"),
     ("void k_g64m_bwd<G64M<1, 2, 6>, true>(", 1056,
