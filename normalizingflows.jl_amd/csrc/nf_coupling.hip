@@ -729,8 +729,13 @@ __device__ __forceinline__ void unstage_dense(const float *__restrict__ img, int
   do {                                                                     \
     if (tr) { __builtin_amdgcn_sched_barrier(0); tr[slot] = clock64(); }   \
   } while (0)
+#define NF_TSB(slot)                                                        \
+  do {                                                                      \
+    if (trb) { __builtin_amdgcn_sched_barrier(0); trb[slot] = clock64(); }  \
+  } while (0)
 #else
 #define NF_TS_STAMP(slot) do { (void)tr; } while (0)
+#define NF_TSB(slot) do { } while (0)
 #endif
 
 // Sign masks of the hidden pre-activations (bit r set <=> z[r] has its sign bit set, i.e. the
@@ -1818,8 +1823,14 @@ __global__ __launch_bounds__(512) void k_affine_bwd_pair(BwdAllArgs aa, float *s
 #pragma unroll 1
       for (int phase = 0; phase < 2; ++phase) {
         const bool is_s = INVD ? phase == 0 : phase == 1;
+#ifdef NF_KERNEL_TRACE  // the phase boundary: producer stamps [32 + phase 8 + 0..7], consumer [96 + ...]
+        long long *trb = (aa.trace && blockIdx.x == 0 && tid == 0 && step == 0) ? aa.trace + 32 + phase * 8 : nullptr;
+#endif
+        NF_TSB(0);
         stage_image(k, is_s);
+        NF_TSB(1);
         __syncthreads();
+        NF_TSB(2);
 #pragma unroll 1
         for (int it = 0; it < rounds; ++it) {
           const long tile = tile0 + (long)it * tstride;
@@ -1832,15 +1843,20 @@ __global__ __launch_bounds__(512) void k_affine_bwd_pair(BwdAllArgs aa, float *s
           if (!is_s) pair_produce<G, false, FULL, INVD, SLIM, PB6, DW6>(a, img, sp, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, tile < ntiles, l31, hi, it & 1, tr);
           else pair_produce<G, true, FULL, INVD, SLIM, PB6, DW6>(a, img, sp, f, stash, k, aa.ncoup, ybar, lbar, lbar_const, tile, nt, tile < ntiles, l31, hi, it & 1, tr);
         }
+        NF_TSB(3);
         __syncthreads();  // every wave is done with the weight image and the delta tiles
+        NF_TSB(4);
         // s and u of the next phase-S's first tile fly behind the fold, the slab write and the staging of the next image
         if (tile0 < ntiles) {
           if (!INVD && !is_s) stash_issue_first<G, SLIM>(f, stash, k, aa.ncoup, tile0, l31, hi);
           if (INVD && !is_s && step + 1 < aa.ncoup) stash_issue_first<G, SLIM>(f, stash, k - 1, aa.ncoup, tile0, l31, hi);
         }
         __syncthreads();  // the consumers have folded
+        NF_TSB(5);
         pair_slab_write<G>(lds, slab + (long)k * 2 * G::SIZE + ((long)blockIdx.x * slab_stride + (is_s ? 0 : 1) * (long)G::SIZE), tid);
+        NF_TSB(6);
         __syncthreads();
+        NF_TSB(7);
       }
     }
   } else {
@@ -1851,8 +1867,14 @@ __global__ __launch_bounds__(512) void k_affine_bwd_pair(BwdAllArgs aa, float *s
 #pragma unroll 1
       for (int phase = 0; phase < 2; ++phase) {
         const bool is_s = INVD ? phase == 0 : phase == 1;
+#ifdef NF_KERNEL_TRACE
+        long long *trb = (aa.trace && blockIdx.x == 0 && tid == 256 && step == 0) ? aa.trace + 96 + phase * 8 : nullptr;
+#endif
+        NF_TSB(0);
         stage_image(k, is_s);
+        NF_TSB(1);
         __syncthreads();
+        NF_TSB(2);
         BwdAcc<G> acc;
         zero_acc(acc.w1, acc.b1);
         zero_acc(acc.w2, acc.b2);
@@ -1867,7 +1889,9 @@ __global__ __launch_bounds__(512) void k_affine_bwd_pair(BwdAllArgs aa, float *s
 #endif
           pair_consume<G, SLIM, PB6, DW6>(img, sp, acc, stash, k, aa.ncoup, tile, is_s, tile < ntiles, l31, hi, it & 1, tr);
         }
+        NF_TSB(3);
         __syncthreads();  // every wave is done with the weight image and the delta tiles
+        NF_TSB(4);
         {
           float *mine = lds + pair * G::SIZE;
           fold_acc(mine + G::W1, mine + G::B1, acc.w1, acc.b1, true, l31, hi);
@@ -1875,8 +1899,11 @@ __global__ __launch_bounds__(512) void k_affine_bwd_pair(BwdAllArgs aa, float *s
           fold_acc(mine + G::W3, mine + G::B3, acc.w3, acc.b3, true, l31, hi);
         }
         __syncthreads();
+        NF_TSB(5);
         pair_slab_write<G>(lds, slab + (long)k * 2 * G::SIZE + ((long)blockIdx.x * slab_stride + (is_s ? 0 : 1) * (long)G::SIZE), tid);
+        NF_TSB(6);
         __syncthreads();
+        NF_TSB(7);
       }
     }
   }

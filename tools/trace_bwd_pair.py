@@ -38,4 +38,14 @@ for ph in range(2):
         print(f"phase {'TS'[ph]} tile {ti}: starts at +{a[0]-t0} (producer) / +{b[0]-t0} (consumer)")
         for i in range(7):
             print(f"   {names[i]:50s} producer +{a[i+1]-a[i]:6d}   consumer +{b[i+1]-b[i]:6d}")
+bn = ["stage the image (own share)", "wait: image staged", "TILES", "wait: all tiles done", "fold (consumer) | s, u requested; barrier",
+      "slab write (own share)", "wait: slab written"]
+for ph in range(2):
+    a, b = t[32 + ph * 8: 40 + ph * 8], t[96 + ph * 8: 104 + ph * 8]
+    if not a[0]:
+        continue
+    print(f"phase {'TS'[ph]} boundary stamps: phase starts at +{a[0]-t0} (producer) / +{b[0]-t0} (consumer)")
+    for i in range(7):
+        print(f"   {bn[i]:50s} producer +{a[i+1]-a[i]:6d}   consumer +{b[i+1]-b[i]:6d}")
+    print(f"   {'phase, first stamp -> last':50s} producer  {a[7]-a[0]:6d}   consumer  {b[7]-b[0]:6d}")
 print("first tile start -> last stamp:", max(t) - t0, "ticks")
