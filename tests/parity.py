@@ -67,11 +67,21 @@ def elementwise(key, got, ref, rtol=Y_RTOL, atol=Y_ATOL, floor=None):
     err = np.abs(got - ref)
     ratio = float((err / base).max())
     record(key + " [elementwise err / (atol + rtol|ref|)]", ratio)
+    # (round 6) the same errors as an rms over the array: the maximum above is one element's figure -- of a few hundred samples the
+    # one whose reference value happens to be nearest zero, where the relative tolerance vanishes -- and says little about whether
+    # the device arithmetic is worse than IEEE float32; the rms of the device next to the rms of the float32 oracle does
+    # (tools/r6_probe_wide_ladj.py)
+    rms = float(np.sqrt(np.mean((err / base) ** 2)))
+    record(key + " [rms of elementwise err / (atol + rtol|ref|)]", rms)
     extra = 0.0
     if floor is not None:
         ferr = np.abs(_np(floor) - ref)
         record(key + " [fp32-oracle floor / (atol + rtol|ref|)]", float((ferr / base).max()))
+        frms = float(np.sqrt(np.mean((ferr / base) ** 2)))
+        record(key + " [fp32-oracle floor, rms / (atol + rtol|ref|)]", frms)
         extra = CFLOOR * float(ferr.max())
+        assert rms <= max(1.0, CFLOOR * frms), (f"{key}: rms error {rms:.3f}x the tolerance against {frms:.3f}x for the float32 oracle "
+                                                f"on the same array")
     worst = float((err / (base + extra)).max())
     assert worst <= 1.0, (f"{key}: worst element is {ratio:.2f}x the plain tolerance (rtol {rtol}, atol {atol})"
                           + (f", {worst:.2f}x the fp32-floor-extended one" if floor is not None else ""))
