@@ -1461,6 +1461,11 @@ __global__ __launch_bounds__(256, 1) void k_affine_bwd_stashed(BwdAllArgs aa, fl
 // triples for its own dX GEMM), leaves them in LDS transposed (split_to_lds) instead of the fp32 tile, and the consumer splits
 // only the stashed activations.  Two triple buffers per pair, used alternately (d3 | d2 | d1 | next d3 | ...): a buffer is
 // rewritten two barriers after the GEMM that read it.
+#ifndef NF_PAIR_CONS_PRIO
+#define NF_PAIR_CONS_PRIO 0  // s_setprio of the consumer waves (A/B builds).  Measured (profiles/r6h_pair_consumer_prio_ab.txt): 1 and 3 alike
+// 331-338 us against 316-322 -- the consumer's stages shorten (dW3 3.7 -> 2.6 k clocks, dW2 5.3 -> 4.55 k) and the producer's grow by
+// more (prologue 3.6 -> 7.4 k, dX2 3.2 -> 5.4 k): the arbitration is all or nothing, and the two waves' issue work in a stage adds up
+#endif
 #ifndef NF_PAIR_TR
 #define NF_PAIR_TR 1  // the producer -> consumer hand-over of the cotangent triples through ds_read_b64_tr_b16 (nf_mfma.h, round 6); 0: split_to_lds
 #endif
@@ -1860,6 +1865,9 @@ __global__ __launch_bounds__(512) void k_affine_bwd_pair(BwdAllArgs aa, float *s
       }
     }
   } else {
+#if NF_PAIR_CONS_PRIO
+    __builtin_amdgcn_s_setprio(NF_PAIR_CONS_PRIO);
+#endif
 #pragma unroll 1
     for (int step = 0; step < aa.ncoup; ++step) {
       const int k = INVD ? aa.ncoup - 1 - step : step;
