@@ -1466,6 +1466,12 @@ __global__ __launch_bounds__(256, 1) void k_affine_bwd_stashed(BwdAllArgs aa, fl
 // 331-338 us against 316-322 -- the consumer's stages shorten (dW3 3.7 -> 2.6 k clocks, dW2 5.3 -> 4.55 k) and the producer's grow by
 // more (prologue 3.6 -> 7.4 k, dX2 3.2 -> 5.4 k): the arbitration is all or nothing, and the two waves' issue work in a stage adds up
 #endif
+#ifndef NF_PAIR_WEAVE
+#define NF_PAIR_WEAVE 1  // the consumer's splits of a1 / x2 in the issue shadows of dW3's / dW2's last matrix instructions (SplitTJob,
+// nf_mfma.h) instead of behind them: 301.7-305.3 against 305.7-309.8 us alternating on one box (profiles/r6j_pair_weave_ab.txt); the
+// same instructions on the same values, results bit-identical.  The traced stages barely move (dW3 3.7 k, dW2 5.1-5.3 k clocks): a
+// stage's length is the two waves' matrix instructions taking turns on the pipe, not either wave's vector work
+#endif
 #ifndef NF_PAIR_TR
 #define NF_PAIR_TR 1  // the producer -> consumer hand-over of the cotangent triples through ds_read_b64_tr_b16 (nf_mfma.h, round 6); 0: split_to_lds
 #endif
@@ -1663,6 +1669,34 @@ __device__ __forceinline__ void pair_consume(const float *__restrict__ img, cons
       NF_TS_STAMP(1);
       __syncthreads();  // B1
       NF_TS_STAMP(2);
+#if NF_PAIR_WEAVE && NF_PAIR_TR
+      // a1's split in the issue shadows of dW3's second half (24 matrix instructions, a1 arrives during the first)
+      SplitT<G::H1B> a1s;
+      {
+        constexpr int NH = 12 * G::H2B * G::CB, F1 = NH > 8 * G::H1B ? NH - 8 * G::H1B : 0;
+        const SplitTJob<G::H1B, F1, 1> job{a1t, a1s};
+        dw_accumulate_tr6<G::H2B, G::CB>(a2s, bufa, acc.w3, acc.b3, l31, hi, job);
+        job.template finish<NH>();
+      }
+      float x2t[G::MB][16];
+      stash_get_T<G::MB>(st, SG::XT, vT, x2t);
+      NF_TS_STAMP(3);
+      __syncthreads();  // B2
+      NF_TS_STAMP(4);
+      SplitT<G::MB> x2s;
+      {
+        constexpr int NH = 12 * G::H1B * G::H2B, F2 = NH > 16 * G::MB ? NH - 16 * G::MB : 0;
+        const SplitTJob<G::MB, F2, 2> job{x2t, x2s};
+        dw_accumulate_tr6<G::H1B, G::H2B>(a1s, bufb, acc.w2, acc.b2, l31, hi, job);
+        job.template finish<NH>();
+      }
+      NF_TS_STAMP(5);
+      __syncthreads();  // B3
+      NF_TS_STAMP(6);
+      NF_PAIR_DW(G::MB, G::H1B, x2s, bufa, acc.w1, acc.b1);
+      NF_TS_STAMP(7);
+      return;
+#endif
       NF_PAIR_DW(G::H2B, G::CB, a2s, bufa, acc.w3, acc.b3);
     }
     float x2t[G::MB][16];

@@ -1254,10 +1254,37 @@ __device__ __forceinline__ nf_u32x4 nf_tr_operand(const char *p0, const char *p1
   const nf_u32x2 lo = __builtin_bit_cast(nf_u32x2, a), hi2 = __builtin_bit_cast(nf_u32x2, b);
   return nf_u32x4{lo.x, lo.y, hi2.x, hi2.y};
 }
+// The split of the consumer's NEXT activation operand, a pair of values (nine vector instructions) per call, for the issue shadows of
+// the GEMM that runs while it arrives: pair p of `at` at hook FIRST + EVERY p.  finish() splits what the hooks did not reach.
+template <int IB, int FIRST, int EVERY>
+struct SplitTJob {
+  const float (&at)[IB][16];
+  SplitT<IB> &s;
+  __device__ __forceinline__ void pair(int p) const {
+    const int ib = p >> 3, g = (p >> 2) & 1, e = p & 3;
+    unsigned h, m, l;
+    nf_split2(at[ib][8 * g + 2 * e], at[ib][8 * g + 2 * e + 1], h, m, l);
+    s.h[ib][g][e] = h; s.m[ib][g][e] = m; s.l[ib][g][e] = l;
+  }
+  __device__ __forceinline__ void operator()(int i) const {
+    if (i >= FIRST && (i - FIRST) % EVERY == 0 && (i - FIRST) / EVERY < 8 * IB) {
+      pair((i - FIRST) / EVERY);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  template <int NH>  // NH: number of hooks the GEMM offered
+  __device__ __forceinline__ void finish() const {
+    constexpr int done = NH <= FIRST ? 0 : (NH - 1 - FIRST) / EVERY + 1;
+#pragma unroll
+    for (int p = done < 8 * IB ? done : 8 * IB; p < 8 * IB; ++p) pair(p);
+  }
+};
 // dw_accumulate_t6 on a cotangent left by split_to_lds_tr
-template <int IB, int OB>
+// (`sj(i)` is called behind the i-th of the 12 IB OB matrix instructions: the consumer's side job is the split of its NEXT
+// activation operand, SplitTJob below)
+template <int IB, int OB, class SJ = NoSideJob>
 __device__ __forceinline__ void dw_accumulate_tr6(const SplitT<IB> &as, const char *buf, f32x16 (&acc)[IB][OB],
-                                                  float (&bsum)[OB], int l31, int hi) {
+                                                  float (&bsum)[OB], int l31, int hi, SJ sj = SJ()) {
   // lane offsets of the two reads: row hi + 2 jj (+ 8 for the second), chunk q at its swizzled position, the lane's tile of the pair
   const int c16 = l31 & 15, jj = c16 >> 2, q = c16 & 3, r0 = hi + 2 * jj, r1 = r0 + 8;
   const char *p0 = buf + (l31 >> 4) * TR_TILE + r0 * 32 + 8 * (q ^ ((r0 >> 2) & 3));
@@ -1285,6 +1312,7 @@ __device__ __forceinline__ void dw_accumulate_tr6(const SplitT<IB> &as, const ch
 #pragma unroll
           for (int i = i0; i < i0 + 2; ++i) bsum[ob] = nf_dot2_bf16(dc[2 - i / 4][i % 4], ones, bsum[ob]);
         }
+        sj(u * 6 * IB + term * IB + ib);
       }
     __builtin_amdgcn_sched_barrier(0);
   }
