@@ -1466,6 +1466,9 @@ __global__ __launch_bounds__(256, 1) void k_affine_bwd_stashed(BwdAllArgs aa, fl
 // 331-338 us against 316-322 -- the consumer's stages shorten (dW3 3.7 -> 2.6 k clocks, dW2 5.3 -> 4.55 k) and the producer's grow by
 // more (prologue 3.6 -> 7.4 k, dX2 3.2 -> 5.4 k): the arbitration is all or nothing, and the two waves' issue work in a stage adds up
 #endif
+#ifndef NF_TRACE_PAIR
+#define NF_TRACE_PAIR 0  // trace builds: which of the workgroup's four pairs tools/trace_bwd_pair.py sees
+#endif
 #ifndef NF_PAIR_WEAVE
 #define NF_PAIR_WEAVE 1  // the consumer's splits of a1 / x2 in the issue shadows of dW3's / dW2's last matrix instructions (SplitTJob,
 // nf_mfma.h) instead of behind them: 301.7-305.3 against 305.7-309.8 us alternating on one box (profiles/r6j_pair_weave_ab.txt); the
@@ -1863,7 +1866,7 @@ __global__ __launch_bounds__(512) void k_affine_bwd_pair(BwdAllArgs aa, float *s
       for (int phase = 0; phase < 2; ++phase) {
         const bool is_s = INVD ? phase == 0 : phase == 1;
 #ifdef NF_KERNEL_TRACE  // the phase boundary: producer stamps [32 + phase 8 + 0..7], consumer [96 + ...]
-        long long *trb = (aa.trace && blockIdx.x == 0 && tid == 0 && step == 0) ? aa.trace + 32 + phase * 8 : nullptr;
+        long long *trb = (aa.trace && blockIdx.x == 0 && tid == 64 * NF_TRACE_PAIR && step == 0) ? aa.trace + 32 + phase * 8 : nullptr;
 #endif
         NF_TSB(0);
         stage_image(k, is_s);
@@ -1875,7 +1878,7 @@ __global__ __launch_bounds__(512) void k_affine_bwd_pair(BwdAllArgs aa, float *s
           const long tile = tile0 + (long)it * tstride;
           const long nt = tile + tstride < ntiles ? tile + tstride : -1;
 #ifdef NF_KERNEL_TRACE  // tools/trace_bwd_pair.py: block 0, pair 0, first coupling; producer stamps [phase 16 + tile 8 + 0..7]
-          long long *tr = (aa.trace && blockIdx.x == 0 && tid == 0 && step == 0 && it < 2) ? aa.trace + phase * 16 + it * 8 : nullptr;
+          long long *tr = (aa.trace && blockIdx.x == 0 && tid == 64 * NF_TRACE_PAIR && step == 0 && it < 2) ? aa.trace + phase * 16 + it * 8 : nullptr;
 #else
           long long *tr = nullptr;
 #endif
@@ -1910,7 +1913,7 @@ __global__ __launch_bounds__(512) void k_affine_bwd_pair(BwdAllArgs aa, float *s
       for (int phase = 0; phase < 2; ++phase) {
         const bool is_s = INVD ? phase == 0 : phase == 1;
 #ifdef NF_KERNEL_TRACE
-        long long *trb = (aa.trace && blockIdx.x == 0 && tid == 256 && step == 0) ? aa.trace + 96 + phase * 8 : nullptr;
+        long long *trb = (aa.trace && blockIdx.x == 0 && tid == 256 + 64 * NF_TRACE_PAIR && step == 0) ? aa.trace + 96 + phase * 8 : nullptr;
 #endif
         NF_TSB(0);
         stage_image(k, is_s);
@@ -1925,7 +1928,7 @@ __global__ __launch_bounds__(512) void k_affine_bwd_pair(BwdAllArgs aa, float *s
         for (int it = 0; it < rounds; ++it) {
           const long tile = tile0 + (long)it * tstride;
 #ifdef NF_KERNEL_TRACE  // consumer stamps at [64 + ...]
-          long long *tr = (aa.trace && blockIdx.x == 0 && tid == 256 && step == 0 && it < 2) ? aa.trace + 64 + phase * 16 + it * 8 : nullptr;
+          long long *tr = (aa.trace && blockIdx.x == 0 && tid == 256 + 64 * NF_TRACE_PAIR && step == 0 && it < 2) ? aa.trace + 64 + phase * 16 + it * 8 : nullptr;
 #else
           long long *tr = nullptr;
 #endif
