@@ -13,6 +13,16 @@
 #include <cstdlib>
 
 #include "nf_common.h"
+// A/B seams of this translation unit only (tools/ab_build.py): the split's subtractions / the leaky-ReLU slopes as scalar f32 instructions.
+// Packed f32 instructions do not overlap a matrix instruction in flight (tools/probe/mfma_valu_overlap_probe.hip: eight v_pk_add_f32
+// behind an MFMA cost 79.6 clocks against 42.4 for eight v_sub_f32), but here two scalar instructions per packed one buy nothing:
+// step 0.6042 / 0.6036 against 0.6040 ms over six alternating runs (profiles/r6l_pair_scalar_forms_ab2.txt)
+#ifdef NF_COUPLING_SPLIT_SCALAR
+#define NF_SPLIT_SCALAR
+#endif
+#ifdef NF_COUPLING_SLOPE_SCALAR
+#define NF_SLOPE_SCALAR
+#endif
 #include "nf_mfma.h"
 #include "nf_pack.h"
 #include "nf_philox.h"

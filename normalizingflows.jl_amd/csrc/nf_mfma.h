@@ -133,7 +133,12 @@ __device__ __forceinline__ void nf_lrelu_grad16(f32x16 &d, unsigned mask) {
     asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x6c" : "=v"(s1) : "v"(t1), "v"(one), "v"(flip));
     f32x2_t v = {d[2 * p], d[2 * p + 1]};
     const f32x2_t sl = {__builtin_bit_cast(float, s0), __builtin_bit_cast(float, s1)};
+#ifdef NF_SLOPE_SCALAR  // two v_mul_f32: a packed f32 instruction does not overlap a matrix instruction in flight (tools/probe/mfma_valu_overlap_probe.hip)
+    asm("v_mul_f32 %0, %1, %2" : "=v"(v.x) : "v"(v.x), "v"(sl.x));
+    asm("v_mul_f32 %0, %1, %2" : "=v"(v.y) : "v"(v.y), "v"(sl.y));
+#else
     asm("v_pk_mul_f32 %0, %1, %2" : "=v"(v) : "v"(v), "v"(sl));
+#endif
     d[2 * p] = v.x;
     d[2 * p + 1] = v.y;
   }
@@ -1218,7 +1223,12 @@ struct PairPost {
       asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x6c" : "=v"(s1) : "v"(t1), "v"(one), "v"(flip));
       f32x2_t v = {d[b][2 * p], d[b][2 * p + 1]};
       const f32x2_t sl = {__builtin_bit_cast(float, s0), __builtin_bit_cast(float, s1)};
+#ifdef NF_SLOPE_SCALAR
+      asm("v_mul_f32 %0, %1, %2" : "=v"(v.x) : "v"(v.x), "v"(sl.x));
+      asm("v_mul_f32 %0, %1, %2" : "=v"(v.y) : "v"(v.y), "v"(sl.y));
+#else
       asm("v_pk_mul_f32 %0, %1, %2" : "=v"(v) : "v"(v), "v"(sl));
+#endif
       unsigned h, m, l;
       nf_split2(v.x, v.y, h, m, l);
       s.h[kg][e] = h; s.m[kg][e] = m; s.l[kg][e] = l;
@@ -1310,6 +1320,8 @@ __device__ __forceinline__ void dw_accumulate_tr6(const SplitT<IB> &as, const ch
         if (term * IB + ib < 6) {  // the twelve bias-sum instructions ride between the unit's first MFMAs
           const int i0 = 2 * (term * IB + ib);
 #pragma unroll
+          // (v_dot2c_f32_bf16 does not overlap a matrix instruction in flight -- tools/probe/mfma_valu_overlap_probe.hip --, but the
+          // four-instruction widen-and-add form that does costs the consumer 92-200 bytes of scratch: 370 against 330 us)
           for (int i = i0; i < i0 + 2; ++i) bsum[ob] = nf_dot2_bf16(dc[2 - i / 4][i % 4], ones, bsum[ob]);
         }
         sj(u * 6 * IB + term * IB + ib);
