@@ -88,6 +88,9 @@ int nf_rqs_chain_elbo(nf_ctx *, const nf_flow_desc *, long N, uint64_t seed, uin
                       const float *mu, const float *var, float *yt, float *gt, double gscale, double *partial,
                       double pscale, void *tape = nullptr);
 int nf_rqs_reduce_slabs(nf_ctx *, const nf_flow_desc *, const float *slab, int nslab, float *g);
+long nf_rqs_epilogue_blocks(const nf_flow_desc *desc);
+int nf_rqs_epilogue(nf_ctx *, const nf_flow_desc *, const float *slab, int nslab, float *g, const double *lpart, int nlpart, float *theta,
+                    float *m, float *v, double lr, double b1, double b2, double eps, unsigned t_val, double *gpart);
 
 // planar / radial / mean-field flows (nf_simple.hip)
 bool nf_simple_supported(const nf_flow_desc *desc);
@@ -2032,6 +2035,58 @@ static int elbo_step_fused(nf_ctx *ctx, const nf_flow_desc *desc, const nf_targe
   return NF_OK;
 }
 
+// The same for LDS-resident spline couplings on ONE rank (round 6): fused forward (draws + chain + target + loss partials, leaving the
+// spline tape), one reverse launch per coupling, and nf_rqs_epilogue (loss, slab reduction, Adam, the updated images) -- four launches
+// fewer than nf_elbo_value_and_grad + nf_adam_update + the next step's pack.  Multi-rank contexts keep the generic sequence (the
+// all-reduce sits between the reduction and Adam).
+static bool step_fusable_rqs(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target) {
+#ifdef NF_STEP_RQS_UNFUSED  // A/B builds (tools/ab_build.py): the generic sequence
+  return false;
+#endif
+  if (ctx->comm || flow_base(desc) || is_composite(desc) || desc->dtype != NF_DTYPE_F32) return false;
+  return desc->kind == NF_KIND_NSF && nf_rqs_supported(desc) && elbo_fusable(desc, target, nullptr);
+}
+static size_t step_fused_need_rqs(nf_ctx *ctx, const nf_flow_desc *desc, long N) {
+  const size_t te = tiled_elems(desc, N);
+  const long nb = nf_target_tiled_nblocks(N);
+  const long nb_alloc = nb < ctx->num_cu ? ctx->num_cu : nb;
+  return 2 * carve_bytes(te * 4) + carve_bytes((size_t)nb_alloc * 8) +
+         carve_bytes((size_t)coupling_bwd_grid(ctx, desc, N) * coupling_slab_floats(ctx, desc, N) * 4) + rqs_tape_b(desc, N) +
+         carve_bytes((size_t)nf_rqs_epilogue_blocks(desc) * 8);
+}
+static int elbo_step_fused_rqs(nf_ctx *ctx, const nf_flow_desc *desc, const nf_target *target, float *theta, float *m, float *v, long N,
+                               uint64_t seed, uint32_t step_val, double lr, double beta1, double beta2, double eps) {
+  const long P = nf_param_count(desc);
+  const double inv = 1.0 / (double)N;
+  const size_t te = tiled_elems(desc, N);
+  const long nb = nf_target_tiled_nblocks(N);
+  const long nb_alloc = nb < ctx->num_cu ? ctx->num_cu : nb;
+  const int grid = coupling_bwd_grid(ctx, desc, N);
+  const long stride = coupling_slab_floats(ctx, desc, N);
+  const long eblocks = nf_rqs_epilogue_blocks(desc);
+  NF_TRY(nf_ws_reserve(ctx, step_fused_need_rqs(ctx, desc, N)));
+  Carver cv(ctx->ws);
+  float *xt = cv.take<float>(te);
+  float *gt = cv.take<float>(te);
+  double *partial = cv.take<double>(nb_alloc);
+  float *slab = cv.take<float>((size_t)grid * stride);
+  void *tape = (void *)cv.take<char>(rqs_tape_b(desc, N));
+  double *gpart = cv.take<double>(eblocks);
+  float *gbuf = (float *)ctx->gbuf;
+  // packed images: those the previous step's epilogue left (only under nf_ctx_set_weight_cache(ctx, 1)), or a fresh pack
+  if (!ctx->wimg_cache || !(ctx->wimg && ctx->wimg_owner == (const void *)theta && ctx->wimg_sig == flow_sig(desc)))
+    NF_TRY(coupling_pack(ctx, desc, theta));
+  NF_TRY(fused_chain_elbo(ctx, desc, target, N, seed, 0, step_val, xt, gt, -inv, partial, -inv, (float *)tape));
+  const int nc = 2 * desc->nlayers;
+  for (int k = 0; k < nc; ++k) NF_TRY(nf_rqs_bwd(ctx, desc, k, xt, gt, nullptr, (float)(-inv), N, slab, stride, grid, false, tape));
+  NF_TRY(nf_rqs_epilogue(ctx, desc, slab, grid, gbuf, partial, (int)fused_chain_grid(ctx, desc, N), theta, m, v, lr, beta1, beta2, eps,
+                         step_val, gpart));
+  NF_TRY(nf_launch_finish_sum(ctx, gpart, eblocks, 1, nullptr, gbuf + P + 1, nullptr, nullptr));
+  ctx->wimg_owner = theta;
+  ctx->wimg_sig = flow_sig(desc);
+  return NF_OK;
+}
+
 extern "C" int nf_ctx_weights_changed(nf_ctx *ctx) {
   if (!ctx) return NF_ERR_ARG;
   ctx->wimg_owner = nullptr;
@@ -2100,6 +2155,8 @@ extern "C" int nf_elbo_step(nf_ctx *ctx, const nf_flow_desc *desc, const nf_targ
   void *gbuf = ctx->gbuf;
   if (step_fusable(ctx, desc, target, N)) {
     NF_TRY(elbo_step_fused(ctx, desc, target, (float *)theta, (float *)m, (float *)v, N, seed, step, nullptr, lr, beta1, beta2, eps));
+  } else if (step_fusable_rqs(ctx, desc, target)) {
+    NF_TRY(elbo_step_fused_rqs(ctx, desc, target, (float *)theta, (float *)m, (float *)v, N, seed, step, lr, beta1, beta2, eps));
   } else {
     const int world = ctx->comm ? ctx->comm_size : 1;
     const uint64_t off = (uint64_t)(ctx->comm ? ctx->comm_rank : 0) * (uint64_t)N;
@@ -2262,6 +2319,10 @@ extern "C" int64_t nf_workspace_bytes(nf_ctx *ctx, const nf_flow_desc *desc, int
   if (desc->kind == NF_KIND_REALNVP && desc->dtype == NF_DTYPE_F32 && !is_composite(desc) && nf_affine_supported(desc) &&
       affine_stash_chunk(ctx, desc, N) > 0) {
     const size_t f = step_fused_need(ctx, desc, N);
+    if (f > need) need = f;
+  }
+  if (desc->kind == NF_KIND_NSF && desc->dtype == NF_DTYPE_F32 && !is_composite(desc) && !flow_base(desc) && nf_rqs_supported(desc)) {
+    const size_t f = step_fused_need_rqs(ctx, desc, N);
     if (f > need) need = f;
   }
   // nf_adam_update / nf_sgd_update: gradient-norm partials at the tail of the intermediates arena

@@ -170,6 +170,78 @@ __global__ __launch_bounds__(256) void k_rqs_reduce_slabs(RqsPackArgs p, const f
   if (q == 0 && ti >= 0) g[ti] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
+// The fused epilogue of nf_elbo_step for spline couplings (round 6; the structure of k_affine_epilogue, nf_pack.h): every thread of
+// wave 0 owns one element of the padded fp32 images -- slab sum (k_rqs_reduce_slabs's order, bit for bit), gradient, Adam
+// (Optimisers.update!, src/optimize.jl:99), the packed image of the UPDATED theta and the block's partial of sum g^2; block 0 also
+// finishes the forward's loss partials.  Replaces four launches of the step (loss sum, slab reduction, Adam, the next step's pack).
+struct RqsEpiArgs {
+  const float *slab;
+  int nslab;
+  long slab_stride;
+  float *g;             // [P + 2]: gradient, loss, gradient norm
+  long P;
+  const double *lpart;  // loss partials of the forward launch, finished into g[P]
+  int nlpart;
+  float *theta, *m, *v, *wimg;
+  float lr, b1, b2, eps, c1, c2;  // c1 = 1 - b1^t, c2 = 1 - b2^t, computed on the host as nf_launch_adam does
+  double *gpart;        // [gridDim.x] partial sums of g^2
+};
+template <class G>
+__global__ __launch_bounds__(256) void k_rqs_epilogue(RqsPackArgs p, RqsEpiArgs a) {
+  if (a.lpart && blockIdx.x == 0) {
+    __shared__ double sm[4];
+    double c = 0.0;
+    for (int i = threadIdx.x; i < a.nlpart; i += 256) c += a.lpart[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) a.g[a.P] = (float)((sm[0] + sm[1]) + (sm[2] + sm[3]));
+  }
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const long gid = (long)blockIdx.x * 64 + lane;
+  long ti = -1;
+  if (gid < (long)p.ncoup * G::SIZE) {
+    const int k = (int)(gid / G::SIZE), e = (int)(gid - (long)k * G::SIZE);
+    ti = rqs_image_theta_index<G>(rqs_dims_of<G>(p, k), e);
+  }
+  float th = 0.f, mi = 0.f, vi = 0.f;  // Adam's operands are requested before the slab stream
+  if (q == 0 && ti >= 0) {
+    th = a.theta[ti];
+    mi = a.m[ti];
+    vi = a.v[ti];
+  }
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (ti >= 0) {  // wave q sums slabs q, q + 4, q + 8, ... (k_rqs_reduce_slabs)
+    int s = q;
+    for (; s + 12 < a.nslab; s += 16) {
+      a0 += a.slab[(long)s * a.slab_stride + gid];
+      a1 += a.slab[(long)(s + 4) * a.slab_stride + gid];
+      a2 += a.slab[(long)(s + 8) * a.slab_stride + gid];
+      a3 += a.slab[(long)(s + 12) * a.slab_stride + gid];
+    }
+    for (; s < a.nslab; s += 4) a0 += a.slab[(long)s * a.slab_stride + gid];
+  }
+  part[q][lane] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (q != 0) return;
+  double gg = 0.0;
+  if (ti >= 0) {
+    const float gsum = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    a.g[ti] = gsum;
+    nf_adam_elem<float>(th, mi, vi, gsum, a.lr, a.b1, a.b2, a.eps, a.c1, a.c2);
+    a.m[ti] = mi;
+    a.v[ti] = vi;
+    a.theta[ti] = th;
+    a.wimg[gid] = th;  // padding elements of the image stay zero from the first pack
+    gg = (double)gsum * (double)gsum;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) gg += __shfl_xor(gg, o, 64);
+  if (lane == 0) a.gpart[blockIdx.x] = gg;
+}
+
 #include "nf_rqs_elem.h"  // the spline of one (dimension, sample): build_knots, find_bin, rqs_fwd_elem / rqs_inv_elem / rqs_bwd_elem
 
 // pull the P raw parameters of local dim `ql` of a chunk out of its accumulator blocks
@@ -1867,6 +1939,32 @@ int nf_rqs_reduce_slabs(nf_ctx *ctx, const nf_flow_desc *desc, const float *slab
   const unsigned grid = (unsigned)((total + 63) / 64);  // 64 elements per block
   ProfScope ps(ctx, "reduce_slabs");
 #define RQS_CALL(G) hipLaunchKernelGGL((k_rqs_reduce_slabs<G>), dim3(grid), dim3(256), 0, ctx->stream, p, slab, nslab, total, g)
+  RQS_DISPATCH_STMT(id, RQS_CALL);
+#undef RQS_CALL
+  return (int)hipGetLastError();
+}
+
+long nf_rqs_epilogue_blocks(const nf_flow_desc *desc) { return ((long)2 * desc->nlayers * rqs_geo_size(desc) + 63) / 64; }
+// reduce + Adam + the images of the updated theta in one launch (single-rank nf_elbo_step); gpart[nf_rqs_epilogue_blocks] receives the
+// blocks' partials of sum g^2 (finished by nf_launch_finish_sum), g[P] the loss
+int nf_rqs_epilogue(nf_ctx *ctx, const nf_flow_desc *desc, const float *slab, int nslab, float *g, const double *lpart, int nlpart,
+                    float *theta, float *m, float *v, double lr, double b1, double b2, double eps, unsigned t_val, double *gpart) {
+  const int id = rqs_geo_id(desc);
+  if (!id || !ctx->wimg) return NF_ERR_UNSUPPORTED;
+  const RqsPackArgs p = rqs_pack_args(desc);
+  RqsEpiArgs a;
+  a.slab = slab; a.nslab = nslab; a.slab_stride = (long)p.ncoup * rqs_geo_size(desc);
+  a.g = g; a.P = nf_param_count(desc);
+  a.lpart = lpart; a.nlpart = nlpart;
+  a.theta = theta; a.m = m; a.v = v; a.wimg = (float *)ctx->wimg;
+  a.lr = (float)lr; a.b1 = (float)b1; a.b2 = (float)b2; a.eps = (float)eps;
+  a.c1 = (float)(1.0 - pow(b1, (double)t_val + 1.0));
+  a.c2 = (float)(1.0 - pow(b2, (double)t_val + 1.0));
+  a.gpart = gpart;
+  const unsigned grid = (unsigned)nf_rqs_epilogue_blocks(desc);
+  ctx->wimg_gen++;  // the fp32 images are rewritten (Adam's theta): the triple images are stale
+  ProfScope ps(ctx, "reduce_slabs");
+#define RQS_CALL(G) hipLaunchKernelGGL((k_rqs_epilogue<G>), dim3(grid), dim3(256), 0, ctx->stream, p, a)
   RQS_DISPATCH_STMT(id, RQS_CALL);
 #undef RQS_CALL
   return (int)hipGetLastError();

@@ -322,16 +322,22 @@ def test_empty_batches_and_empty_shards(nf, kind):
 
 
 @pytest.mark.parametrize("cache", [False, True])
-@pytest.mark.parametrize("shape", ["d64_h64", "d20_h32"])
+@pytest.mark.parametrize("shape", ["d64_h64", "d20_h32", "nsf_d32_k8", "nsf_d9_k10"])
 def test_three_launch_step_equals_split_calls_over_consecutive_steps(nf, shape, cache):
-    """nf_elbo_step on an LDS-resident RealNVP flow = fused forward + reverse pass + fused epilogue.  Five consecutive
+    """nf_elbo_step on an LDS-resident RealNVP flow = fused forward + reverse pass + fused epilogue (spline couplings, round 6: fused
+    forward + one reverse launch per coupling + nf_rqs_epilogue -- the slab sum in k_rqs_reduce_slabs's order, Adam through the
+    same nf_adam_elem).  Five consecutive
     steps against nf_elbo_value_and_grad + nf_adam_update on another context: theta, m, v bit for bit, loss and norm(g)
     to float rounding.  cache=True (nf_ctx_set_weight_cache(ctx, 1), what train_flow opts in to): steps 2..5 run on the
     packed weight images the previous epilogue wrote, never re-packed, and an in-place edit of theta is declared with
     nf_ctx_weights_changed.  cache=False (the default): every step packs from theta, so the SAME edit needs no
     declaration -- nor does a theta that was freed and re-allocated at the same address."""
-    d, hd, nl, n = {"d64_h64": (64, (64, 64), 4, 4096 + 5), "d20_h32": (20, (32, 32), 2, 777)}[shape]
-    flow = nf.realnvp(nf.MvNormal(d), hd, nl, paramtype=torch.float32, seed=3)
+    d, hd, nl, n = {"d64_h64": (64, (64, 64), 4, 4096 + 5), "d20_h32": (20, (32, 32), 2, 777), "nsf_d32_k8": (32, (32, 32), 3, 2048 + 7),
+                    "nsf_d9_k10": (9, (24, 32), 2, 333)}[shape]
+    if shape.startswith("nsf"):
+        flow = nf.nsf(nf.MvNormal(d), hd, 8 if shape.endswith("k8") else 10, 5.0, nl, paramtype=torch.float32, seed=3)
+    else:
+        flow = nf.realnvp(nf.MvNormal(d), hd, nl, paramtype=torch.float32, seed=3)
     rng = np.random.default_rng(0)
     tgt = nf.DiagGaussTarget(torch.tensor(rng.standard_normal(d), dtype=torch.float32, device="cuda"),
                              torch.tensor(rng.uniform(size=d) + 0.5, dtype=torch.float32, device="cuda"))
