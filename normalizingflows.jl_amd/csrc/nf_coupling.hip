@@ -396,8 +396,9 @@ struct FusedArgs {
 // holds THREE of them and rotates per NET instead of two (s, t) pairs per coupling: image i of the workgroup's sequence
 // s(c0), t(c0), s(c1), ... lives in slot i mod 3; the phase of image i starts with a workgroup barrier (image i complete,
 // everybody done with image i - 1) and then requests image i + 2 into the slot image i - 1 just left.
-template <class G, bool INVERSE, bool FUSED = false, bool STASH = false, bool SLIM = false, bool B6 = false>
-__global__ __launch_bounds__(512) void k_affine_chain(ChainArgs a, float *xt, float *__restrict__ ladj, FusedArgs fa) {
+// NW: wavefronts (= tiles of a group) per workgroup; 12 (three per SIMD) where the instantiation fits 168 registers (round 6)
+template <class G, bool INVERSE, bool FUSED = false, bool STASH = false, bool SLIM = false, bool B6 = false, int NW = 8>
+__global__ __launch_bounds__(64 * NW) void k_affine_chain(ChainArgs a, float *xt, float *__restrict__ ladj, FusedArgs fa) {
   static_assert(STASH || !SLIM, "SLIM is a stash layout");
   static_assert(!STASH || !FUSED || !INVERSE, "the fused ELBO forward runs base -> data");
   static_assert(G::MB == G::CB, "parity blocks must have equal padded size");
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(512) void k_affine_chain(ChainArgs a, float *xt, fl
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
   const long ntiles = (a.N + NF_TILE - 1) / NF_TILE;
-  const long ngroups = (ntiles + 7) / 8;
+  const long ngroups = (ntiles + NW - 1) / NW;
   // coupling executed at position s of the chain: forward applies the LAST flat coupling first
   auto coupling_at = [&](int s) { return INVERSE ? s : a.ncoup - 1 - s; };
 
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(512) void k_affine_chain(ChainArgs a, float *xt, fl
         const_cast<unsigned char *>(a.wimg_b6) + (size_t)(2 * kk + (req_idx & 1)) * BG::BYTES, 0, BG::BYTES, 0x00020000);
     float *dstb = lds + req_slot * B6F;
     constexpr int NP = (BG::BYTES + 1023) / 1024;
-    for (int p = wave; p < NP; p += 8)
+    for (int p = wave; p < NP; p += NW)
       if (p * 1024 + lane * 16 < BG::BYTES)  // the last piece is partial: its idle lanes must not write
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t *)(dstb + p * 256), 16, lane * 16, p * 1024, 0, 0);
     ++req;
@@ -442,14 +443,14 @@ __global__ __launch_bounds__(512) void k_affine_chain(ChainArgs a, float *xt, fl
   } else {
     const float4 *src = reinterpret_cast<const float4 *>(a.wimg + (long)coupling_at(0) * IMG2);
     float4 *dst = reinterpret_cast<float4 *>(lds);
-    for (int i = tid; i < NV4; i += 512) dst[i] = src[i];
+    for (int i = tid; i < NV4; i += 64 * NW) dst[i] = src[i];
   }
   // FUSED: target parameters by feature, zero padded: tmu[f], tiv[f] = 1/var[f]; tc0 = d log 2pi + sum log var
   constexpr int TP = 64 * G::CB;  // padded feature count (E and O halves)
   float *tmu = lds + (B6 ? 3 * B6F : 2 * IMG2), *tiv = tmu + TP, *tc0 = tiv + TP;
-  double *wsum = reinterpret_cast<double *>(tc0 + 2);  // [8] per-wave partial sums (8-byte aligned: TP even)
+  double *wsum = reinterpret_cast<double *>(tc0 + 2);  // [NW] per-wave partial sums (8-byte aligned: TP even)
   if (FUSED) {
-    for (int i = tid; i < TP; i += 512) {
+    for (int i = tid; i < TP; i += 64 * NW) {
       tmu[i] = i < a.d ? fa.mu[i] : 0.f;
       tiv[i] = i < a.d ? 1.f / fa.var[i] : 0.f;
     }
@@ -464,7 +465,7 @@ __global__ __launch_bounds__(512) void k_affine_chain(ChainArgs a, float *xt, fl
 
   int buf = 0;
   for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    const long tile = grp * 8 + wave;
+    const long tile = grp * NW + wave;
     const bool live = tile < ntiles;          // wave-uniform
     const long tl = live ? tile : 0;
     const long j = tl * NF_TILE + l31;
@@ -579,7 +580,7 @@ __global__ __launch_bounds__(512) void k_affine_chain(ChainArgs a, float *xt, fl
           const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wimg) + (long)knext * IMG2, 0, IMG2 * 4, 0x00020000);
           float *dstb = lds + (buf ^ 1) * IMG2;
           constexpr int NP = (IMG2 * 4 + 1023) / 1024;
-          for (int p = wave; p < NP; p += 8)
+          for (int p = wave; p < NP; p += NW)
             if (p * 1024 + lane * 16 < IMG2 * 4)  // the last piece is partial: its idle lanes must not write
               __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t *)(dstb + p * 256), 16, lane * 16, p * 1024, 0, 0);
         }
@@ -659,7 +660,7 @@ __global__ __launch_bounds__(512) void k_affine_chain(ChainArgs a, float *xt, fl
       __syncthreads();
       if (tid == 0) {
         double sgrp = 0.0;
-        for (int w = 0; w < 8; ++w) sgrp += wsum[w];
+        for (int w = 0; w < NW; ++w) sgrp += wsum[w];
         wg_total += sgrp;
       }
       __syncthreads();
@@ -2226,7 +2227,15 @@ static int launch_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, flo
                         const FusedArgs *fused = nullptr, float *stash_plain = nullptr) {
   // two double-buffered (s,t) image pairs (B6: three single images) + target parameters and per-wave sums of the fused variant
   const size_t lds = (B6 ? (size_t)3 * B6Geo<G>::BYTES : 4 * (size_t)G::SIZE * sizeof(float)) + (2 * 64 * G::CB + 2) * sizeof(float) +
-                     8 * sizeof(double);
+                     12 * sizeof(double);
+  // (round 6, measured: NOT the default) the six-term chains WITHOUT a stash (nf_flow_fwd / nf_flow_inv, nf_loglikelihood: BASELINE cfg 5)
+  // with THREE wavefronts per SIMD -- twelve tiles per workgroup, NF_CHAIN_NW=12 at build time: the kernel is a serial chain per wave
+  // (GEMM -> split -> GEMM ...) at 53 % of the matrix pipe with two.  At hidden 64 the instantiation needs 212 registers; held to the 168
+  // of three waves it spills 180 bytes and cfg 5 runs 1.893 against 1.624 ms (profiles/r6r_chain_nw.txt).  Hidden 32 fits (156).
+#ifndef NF_CHAIN_NW
+#define NF_CHAIN_NW 8
+#endif
+  constexpr int NWP = B6 ? NF_CHAIN_NW : 8;  // waves per workgroup of the plain chains below
   static AttrOnce attr_once;  // once per device: a context on another GPU needs its own
   NF_TRY(attr_once.run(ctx->device, [&]() -> int {
     NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false, false, false, false, B6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2235,6 +2244,10 @@ static int launch_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, flo
     NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false, true, true, SLIM, B6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false, false, true, SLIM, B6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, true, false, true, SLIM, B6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (NWP != 8) {
+      NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false, false, false, false, B6, NWP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, true, false, false, false, B6, NWP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     return NF_OK;
   }));
   if (B6) NF_TRY(b6_refresh<G>(ctx, desc));
@@ -2257,14 +2270,20 @@ static int launch_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, flo
   else if (inverse && stash_plain) {  // forward-KL training: the inverse chain leaves the stash of ITS reverse pass
     none.stash = stash_plain;
     hipLaunchKernelGGL((k_affine_chain<G, true, false, true, SLIM, B6>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, none);
-  } else if (inverse)
-    hipLaunchKernelGGL((k_affine_chain<G, true, false, false, false, B6>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, none);
+  } else if (inverse) {
+    const long g12 = (((N + NF_TILE - 1) / NF_TILE + NWP - 1) / NWP);
+    const long gridp = g12 < 1 ? 1 : g12 < ctx->num_cu ? g12 : ctx->num_cu;
+    hipLaunchKernelGGL((k_affine_chain<G, true, false, false, false, B6, NWP>), dim3((unsigned)gridp), dim3(64 * NWP), lds, ctx->stream, a, xt, ladj, none);
+  }
   else if (stash_plain) {  // caller-supplied draws: the plain forward chain, leaving the stash behind
     none.stash = stash_plain;
     hipLaunchKernelGGL((k_affine_chain<G, false, false, true, SLIM, B6>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, none);
   }
-  else
-    hipLaunchKernelGGL((k_affine_chain<G, false, false, false, false, B6>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, none);
+  else {
+    const long g12 = (((N + NF_TILE - 1) / NF_TILE + NWP - 1) / NWP);
+    const long gridp = g12 < 1 ? 1 : g12 < ctx->num_cu ? g12 : ctx->num_cu;
+    hipLaunchKernelGGL((k_affine_chain<G, false, false, false, false, B6, NWP>), dim3((unsigned)gridp), dim3(64 * NWP), lds, ctx->stream, a, xt, ladj, none);
+  }
   return (int)hipGetLastError();
 }
 
