@@ -128,20 +128,27 @@ struct ChainArgs {
 };
 
 // the conditioner net on the bf16 matrix cores (nf_mfma.h "B6"): same layers, the image is a B6Geo<G> image
-template <class G>
+// PIPE: the layers as software pipelines (dense_fwd_b6p); false: the plain form, 44 registers less (three waves per SIMD)
+#ifndef NF_CHAIN_LEAN
+#define NF_CHAIN_LEAN false  // the plain form without its operand double buffer (12 registers less)
+#endif
+template <class G, bool PIPE = true>
 __device__ __forceinline__ void net_forward_b6(const float *__restrict__ img, const f32x16 (&x)[G::MB], f32x16 (&out)[G::CB],
                                                int l31, int hi) {
   using B = B6Geo<G>;
   const nf_u32x4 *w = reinterpret_cast<const nf_u32x4 *>(img);
   const float *bias = reinterpret_cast<const float *>(w + B::BIAS);
   f32x16 a1[G::H1B], a2[G::H2B];
-  dense_fwd_b6p<G::MB, G::H1B>(w + B::L1, bias + B::B1, x, a1, l31, hi);
+  if constexpr (PIPE) dense_fwd_b6p<G::MB, G::H1B>(w + B::L1, bias + B::B1, x, a1, l31, hi);
+  else dense_fwd_b6<G::MB, G::H1B, NoSideJob, NF_CHAIN_LEAN>(w + B::L1, bias + B::B1, x, a1, l31, hi);
 #pragma unroll
   for (int b = 0; b < G::H1B; ++b) nf_lrelu16(a1[b]);
-  dense_fwd_b6p<G::H1B, G::H2B>(w + B::L2, bias + B::B2, a1, a2, l31, hi);
+  if constexpr (PIPE) dense_fwd_b6p<G::H1B, G::H2B>(w + B::L2, bias + B::B2, a1, a2, l31, hi);
+  else dense_fwd_b6<G::H1B, G::H2B, NoSideJob, NF_CHAIN_LEAN>(w + B::L2, bias + B::B2, a1, a2, l31, hi);
 #pragma unroll
   for (int b = 0; b < G::H2B; ++b) nf_lrelu16(a2[b]);
-  dense_fwd_b6p<G::H2B, G::CB>(w + B::L3, bias + B::B3, a2, out, l31, hi);
+  if constexpr (PIPE) dense_fwd_b6p<G::H2B, G::CB>(w + B::L3, bias + B::B3, a2, out, l31, hi);
+  else dense_fwd_b6<G::H2B, G::CB, NoSideJob, NF_CHAIN_LEAN>(w + B::L3, bias + B::B3, a2, out, l31, hi);
 }
 
 struct NoBetween {
@@ -154,18 +161,18 @@ struct NoBetween {
 #else
 #define NF_CS_STAMP(tr, slot) do { } while (0)
 #endif
-template <class G, bool INVERSE, bool B6 = false, class BT = NoBetween>
+template <class G, bool INVERSE, bool B6 = false, class BT = NoBetween, bool PIPE = true>
 __device__ __forceinline__ float coupling_step(const float *__restrict__ img_s, const float *__restrict__ img_t,
                                                f32x16 (&x1)[G::CB], const f32x16 (&xb)[G::MB], int l31, int hi, BT between = BT(),
                                                long long *tr = nullptr) {
   f32x16 S[G::CB], T[G::CB];
   if constexpr (B6) {
     NF_CS_STAMP(tr, 0);  // tools/trace_chain.py (NOSTASH=1): after the phase barrier + the request for the image after next
-    net_forward_b6<G>(img_s, xb, S, l31, hi);
+    net_forward_b6<G, PIPE>(img_s, xb, S, l31, hi);
     NF_CS_STAMP(tr, 1);
     between();
     NF_CS_STAMP(tr, 2);
-    net_forward_b6<G>(img_t, xb, T, l31, hi);
+    net_forward_b6<G, PIPE>(img_t, xb, T, l31, hi);
     NF_CS_STAMP(tr, 3);
   } else {
   {
@@ -562,8 +569,8 @@ __global__ __launch_bounds__(64 * NW) void k_affine_chain(ChainArgs a, float *xt
 #else
             long long *tr = nullptr;
 #endif
-            if (INVERSE ? (half == 1) : (half == 0)) ls = coupling_step<G, INVERSE, true>(img_s, img_t, O, E, l31, hi, between, tr);
-            else ls = coupling_step<G, INVERSE, true>(img_s, img_t, E, O, l31, hi, between, tr);
+            if (INVERSE ? (half == 1) : (half == 0)) ls = coupling_step<G, INVERSE, true, decltype(between), NW == 8>(img_s, img_t, O, E, l31, hi, between, tr);
+            else ls = coupling_step<G, INVERSE, true, decltype(between), NW == 8>(img_s, img_t, E, O, l31, hi, between, tr);
             NF_CS_STAMP(tr, 4);
           }
           lsum += ls;
@@ -2231,7 +2238,8 @@ static int launch_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, flo
   // (round 6, measured: NOT the default) the six-term chains WITHOUT a stash (nf_flow_fwd / nf_flow_inv, nf_loglikelihood: BASELINE cfg 5)
   // with THREE wavefronts per SIMD -- twelve tiles per workgroup, NF_CHAIN_NW=12 at build time: the kernel is a serial chain per wave
   // (GEMM -> split -> GEMM ...) at 53 % of the matrix pipe with two.  At hidden 64 the instantiation needs 212 registers; held to the 168
-  // of three waves it spills 180 bytes and cfg 5 runs 1.893 against 1.624 ms (profiles/r6r_chain_nw.txt).  Hidden 32 fits (156).
+  // of three waves it spills 180 bytes and cfg 5 runs 1.893 against 1.624 ms; with the plain GEMM form (PIPE = false: 68 bytes) 1.747
+  // against 1.675 (profiles/r6r_chain_nw.txt).  Hidden 32 fits (156).
 #ifndef NF_CHAIN_NW
 #define NF_CHAIN_NW 8
 #endif
