@@ -141,6 +141,27 @@ def test_no_wide_store_is_followed_by_a_write_of_its_data_registers(nf):
     assert mod.main() == 0
 
 
+def test_no_matrix_instruction_is_issued_from_inline_asm():
+    """Hazard found in round 6: hipcc's hazard recognizer does not look inside inline asm, so a
+    `v_mfma_*` written there gets none of the wait states its neighbours need -- k_rqs_bwd_coop6 with its weight operands as inline-asm
+    AGPR sources passed the GPU suite twice and returned a 4 % wrong gradient one (unrelated) link later.  Matrix instructions go
+    through the builtins; no product source may spell one in an asm statement."""
+    import re
+
+    from __graft_entry__ import CSRC
+
+    bad = []
+    for f in sorted(os.listdir(CSRC)):
+        if not f.endswith((".hip", ".h")):
+            continue
+        text = open(os.path.join(CSRC, f)).read()
+        for m in re.finditer(r"\basm\b\s*(?:volatile)?\s*\(", text):
+            stmt = text[m.start(): text.find(";", m.start())]
+            if "v_mfma" in stmt or "v_smfmac" in stmt:
+                bad.append((f, text.count("\n", 0, m.start()) + 1))
+    assert not bad, f"matrix instructions in inline asm: {bad}"
+
+
 def test_shipped_kernels_carry_no_wrong_on_purpose_experiment_switches():
     """round 4 kept two timing-only build macros in nf_coupling.hip that compile a library returning WRONG
     gradients.  They live in tools/experiments/ as patches now; nothing under the product sources may mention an
