@@ -129,6 +129,9 @@ struct ChainArgs {
 
 // the conditioner net on the bf16 matrix cores (nf_mfma.h "B6"): same layers, the image is a B6Geo<G> image
 // PIPE: the layers as software pipelines (dense_fwd_b6p); false: the plain form, 44 registers less (three waves per SIMD)
+#ifndef NF_CHAIN_LRIN
+#define NF_CHAIN_LRIN 1
+#endif
 #ifndef NF_CHAIN_LEAN
 #define NF_CHAIN_LEAN false  // the plain form without its operand double buffer (12 registers less)
 #endif
@@ -139,6 +142,12 @@ __device__ __forceinline__ void net_forward_b6(const float *__restrict__ img, co
   const nf_u32x4 *w = reinterpret_cast<const nf_u32x4 *>(img);
   const float *bias = reinterpret_cast<const float *>(w + B::BIAS);
   f32x16 a1[G::H1B], a2[G::H2B];
+  if constexpr (PIPE && NF_CHAIN_LRIN) {  // the leaky ReLUs inside the next layer's splits (dense_fwd_b6p<..., LRIN>): same values, same bits
+    dense_fwd_b6p<G::MB, G::H1B>(w + B::L1, bias + B::B1, x, a1, l31, hi);
+    dense_fwd_b6p<G::H1B, G::H2B, true>(w + B::L2, bias + B::B2, a1, a2, l31, hi);
+    dense_fwd_b6p<G::H2B, G::CB, true>(w + B::L3, bias + B::B3, a2, out, l31, hi);
+    return;
+  }
   if constexpr (PIPE) dense_fwd_b6p<G::MB, G::H1B>(w + B::L1, bias + B::B1, x, a1, l31, hi);
   else dense_fwd_b6<G::MB, G::H1B, NoSideJob, NF_CHAIN_LEAN>(w + B::L1, bias + B::B1, x, a1, l31, hi);
 #pragma unroll
@@ -674,6 +683,145 @@ __global__ __launch_bounds__(64 * NW) void k_affine_chain(ChainArgs a, float *xt
     }
   }
   if (FUSED && tid == 0) fa.partial[blockIdx.x] = wg_total;
+}
+
+// ------------------------------------------------------------------------------------
+// the six-term chain WITHOUT a stash, two tiles per wavefront (round 6)
+// ------------------------------------------------------------------------------------
+// tools/trace_chain_b6.py on k_affine_chain<..., B6> at cfg 5: the two waves of a SIMD do not overlap -- the older one runs its net
+// in 5.4 k clocks (96 MFMAs = 3.1 k) and then waits 5 k at the phase barrier for the younger one, which only gets the issue slots the
+// older leaves (9-10 k per net): a phase is the SUM of the two.  Here ONE wave per SIMD (256 threads, up to 512 registers) carries two
+// tiles through every net with their instruction streams interleaved by construction (dense_fwd_b6p2): one tile's splits and layer
+// boundaries ride in the other's matrix instructions, the weight operands are read from LDS once for both.  Same images, same rotation
+// (three LDS slots, one per net), same per-accumulator term order: results bit-identical to k_affine_chain.
+template <class G>
+__device__ __forceinline__ void net_forward_b6_dual(const float *__restrict__ img, const f32x16 (&x0)[G::MB], const f32x16 (&x1)[G::MB],
+                                                    f32x16 (&out0)[G::CB], f32x16 (&out1)[G::CB], int l31, int hi) {
+  using B = B6Geo<G>;
+  const nf_u32x4 *w = reinterpret_cast<const nf_u32x4 *>(img);
+  const float *bias = reinterpret_cast<const float *>(w + B::BIAS);
+  f32x16 a10[G::H1B], a11[G::H1B], a20[G::H2B], a21[G::H2B];
+  dense_fwd_b6p2<G::MB, G::H1B>(w + B::L1, bias + B::B1, x0, x1, a10, a11, l31, hi);
+#pragma unroll
+  for (int b = 0; b < G::H1B; ++b) { nf_lrelu16(a10[b]); nf_lrelu16(a11[b]); }
+  dense_fwd_b6p2<G::H1B, G::H2B>(w + B::L2, bias + B::B2, a10, a11, a20, a21, l31, hi);
+#pragma unroll
+  for (int b = 0; b < G::H2B; ++b) { nf_lrelu16(a20[b]); nf_lrelu16(a21[b]); }
+  dense_fwd_b6p2<G::H2B, G::CB>(w + B::L3, bias + B::B3, a20, a21, out0, out1, l31, hi);
+}
+
+template <class G, bool INVERSE>
+__global__ __launch_bounds__(256, 1) void k_affine_chain_dual(ChainArgs a, float *xt, float *__restrict__ ladj) {
+  static_assert(G::MB == G::CB, "parity blocks must have equal padded size");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const long ntiles = (a.N + NF_TILE - 1) / NF_TILE;
+  const long ngroups = (ntiles + 7) / 8;
+  auto coupling_at = [&](int s) { return INVERSE ? s : a.ncoup - 1 - s; };
+  using BG = B6Geo<G>;
+  constexpr int B6F = BG::BYTES / 4;
+  const int my_groups = (long)blockIdx.x < ngroups ? (int)((ngroups - blockIdx.x + gridDim.x - 1) / gridDim.x) : 0;
+  const int my_images = my_groups * 2 * a.ncoup;
+  int req = 0, req_idx = 0, req_slot = 0;
+  auto b6_request_next = [&]() {  // as k_affine_chain's: image i of the sequence s(c0), t(c0), s(c1), ... -> slot i mod 3 by LDS-DMA
+    if (req >= my_images) return;
+    typedef __attribute__((address_space(3))) void lds_void_t;
+    const int kk = coupling_at(req_idx >> 1);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char *>(a.wimg_b6) + (size_t)(2 * kk + (req_idx & 1)) * BG::BYTES, 0, BG::BYTES, 0x00020000);
+    float *dstb = lds + req_slot * B6F;
+    constexpr int NP = (BG::BYTES + 1023) / 1024;
+    for (int p = wave; p < NP; p += 4)
+      if (p * 1024 + lane * 16 < BG::BYTES)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t *)(dstb + p * 256), 16, lane * 16, p * 1024, 0, 0);
+    ++req;
+    req_idx = req_idx + 1 == 2 * a.ncoup ? 0 : req_idx + 1;
+    req_slot = req_slot == 2 ? 0 : req_slot + 1;
+  };
+  int cur_slot = 0;
+  b6_request_next();
+  b6_request_next();
+  for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    f32x16 E[2][G::CB], O[2][G::MB];
+    TileIO io[2];
+    bool live[2], valid[2];
+    long jj[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const long tile = grp * 8 + 2 * wave + t;
+      live[t] = tile < ntiles;  // wave-uniform
+      const long tl = live[t] ? tile : 0;
+      jj[t] = tl * NF_TILE + l31;
+      valid[t] = live[t] && jj[t] < a.N;
+      io[t] = make_tile_io(xt, tl, a.d, l31, hi);
+#pragma unroll
+      for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = tile_load(io[t], tile_soff(b, r, 0));  // features >= d read as 0
+          const float o = tile_load(io[t], tile_soff(b, r, 1));
+          E[t][b][r] = valid[t] ? e : 0.f;
+          O[t][b][r] = valid[t] ? o : 0.f;
+        }
+    }
+    float lsum[2] = {0.f, 0.f};
+#pragma unroll 1
+    for (int s = 0; s < a.ncoup; s += 2) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        __syncthreads();    // this coupling's s image is complete, every wave is done with the image before it
+        b6_request_next();  // the image after next, into the slot just vacated
+        const int slot_t = cur_slot == 2 ? 0 : cur_slot + 1;
+        const float *img_s = lds + cur_slot * B6F, *img_t = lds + slot_t * B6F;
+        const bool x1_is_O = INVERSE ? (half == 1) : (half == 0);
+        f32x16 (&x10)[G::CB] = x1_is_O ? O[0] : E[0];
+        f32x16 (&x11)[G::CB] = x1_is_O ? O[1] : E[1];
+        const f32x16 (&xb0)[G::MB] = x1_is_O ? E[0] : O[0];
+        const f32x16 (&xb1)[G::MB] = x1_is_O ? E[1] : O[1];
+        f32x16 S0[G::CB], S1[G::CB], T0[G::CB], T1[G::CB];
+        float ls0 = 0.f, ls1 = 0.f;  // per coupling first, as coupling_step returns it: the same bits in ladj
+        net_forward_b6_dual<G>(img_s, xb0, xb1, S0, S1, l31, hi);
+        __syncthreads();  // the t image is complete, every wave is done with the s image
+        b6_request_next();
+        net_forward_b6_dual<G>(img_t, xb0, xb1, T0, T1, l31, hi);
+#pragma unroll
+        for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            // rows >= c have zero weights and biases in the packed image: s = 0, T = 0, x1 stays 0
+            const float s0 = nf_tanh(S0[b][r]), s1 = nf_tanh(S1[b][r]);
+            if (INVERSE) {
+              x10[b][r] = nf_fdiv(x10[b][r] - T0[b][r], nf_exp(s0));
+              x11[b][r] = nf_fdiv(x11[b][r] - T1[b][r], nf_exp(s1));
+            } else {
+              x10[b][r] = x10[b][r] * nf_exp(s0) + T0[b][r];
+              x11[b][r] = x11[b][r] * nf_exp(s1) + T1[b][r];
+            }
+            ls0 += s0;
+            ls1 += s1;
+          }
+        lsum[0] += ls0;
+        lsum[1] += ls1;
+        cur_slot = slot_t == 2 ? 0 : slot_t + 1;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (!live[t]) continue;
+#pragma unroll
+      for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          tile_store(io[t], tile_soff(b, r, 0), E[t][b][r]);
+          tile_store(io[t], tile_soff(b, r, 1), O[t][b][r]);
+        }
+      float ls = lsum[t];
+      ls += __shfl_xor(ls, 32);
+      if (hi == 0 && valid[t]) ladj[jj[t]] = INVERSE ? -ls : ls;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -2243,6 +2391,10 @@ static int launch_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, flo
 #ifndef NF_CHAIN_NW
 #define NF_CHAIN_NW 8
 #endif
+#ifndef NF_CHAIN_DUAL
+#define NF_CHAIN_DUAL 0  // 1: the plain six-term chains on k_affine_chain_dual (one wave per SIMD, two tiles per wave) -- measured slower:
+// cfg 5 1.72 against 1.63 ms (profiles/r6u_chain_dual.txt): with one wave per SIMD nothing covers the layer boundaries
+#endif
   constexpr int NWP = B6 ? NF_CHAIN_NW : 8;  // waves per workgroup of the plain chains below
   static AttrOnce attr_once;  // once per device: a context on another GPU needs its own
   NF_TRY(attr_once.run(ctx->device, [&]() -> int {
@@ -2252,6 +2404,10 @@ static int launch_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, flo
     NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false, true, true, SLIM, B6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false, false, true, SLIM, B6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, true, false, true, SLIM, B6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (B6 && NF_CHAIN_DUAL) {
+      NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain_dual<G, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain_dual<G, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     if (NWP != 8) {
       NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, false, false, false, false, B6, NWP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       NF_HIP(hipFuncSetAttribute((const void *)k_affine_chain<G, true, false, false, false, B6, NWP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2278,6 +2434,10 @@ static int launch_chain(nf_ctx *ctx, const nf_flow_desc *desc, bool inverse, flo
   else if (inverse && stash_plain) {  // forward-KL training: the inverse chain leaves the stash of ITS reverse pass
     none.stash = stash_plain;
     hipLaunchKernelGGL((k_affine_chain<G, true, false, true, SLIM, B6>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a, xt, ladj, none);
+  } else if (inverse && B6 && NF_CHAIN_DUAL) {
+    hipLaunchKernelGGL((k_affine_chain_dual<G, true>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, xt, ladj);
+  } else if (!inverse && !stash_plain && B6 && NF_CHAIN_DUAL) {
+    hipLaunchKernelGGL((k_affine_chain_dual<G, false>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, a, xt, ladj);
   } else if (inverse) {
     const long g12 = (((N + NF_TILE - 1) / NF_TILE + NWP - 1) / NWP);
     const long gridp = g12 < 1 ? 1 : g12 < ctx->num_cu ? g12 : ctx->num_cu;

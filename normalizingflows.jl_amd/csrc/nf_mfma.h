@@ -848,7 +848,9 @@ __device__ __forceinline__ void dense_fwd_b6(const nf_u32x4 *__restrict__ w, con
 // requested from LDS -- in the issue shadows of k-group kg's MFMAs (sched_group_barrier: one MFMA, a few VALU), and the OB
 // accumulators of a k-group alternate term by term, so that no MFMA waits for the one before it (OB = 2).  The order of the
 // terms of every accumulator is the one of dense_fwd_b6: bit-identical results.
-template <int IB, int OB>
+// LRIN: `in` holds PRE-activation values and the leaky ReLU is applied where a k-group's eight values are read for their split -- in the
+// issue shadows of the previous k-group's matrix instructions instead of as a pass of its own between two layers (chains without a stash)
+template <int IB, int OB, bool LRIN = false>
 __device__ __forceinline__ void dense_fwd_b6p(const nf_u32x4 *__restrict__ w, const float *__restrict__ b, const f32x16 (&in)[IB],
                                               f32x16 (&out)[OB], int l31, int hi) {
   constexpr int ROWS = 32 * OB, NKG = 2 * IB;
@@ -861,7 +863,7 @@ __device__ __forceinline__ void dense_fwd_b6p(const nf_u32x4 *__restrict__ w, co
   {
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = in[0][j];
+    for (int j = 0; j < 8; ++j) v[j] = LRIN ? nf_vmax(in[0][j], 0.01f * in[0][j]) : in[0][j];
     nf_split8(v, xn[0], xn[1], xn[2]);
 #pragma unroll
     for (int ob = 0; ob < OB; ++ob)
@@ -885,7 +887,10 @@ __device__ __forceinline__ void dense_fwd_b6p(const nf_u32x4 *__restrict__ w, co
         for (int c = 0; c < 3; ++c) an[ob][c] = wl[((kg + 1) * 3 + c) * 2 * ROWS + ob * 32];
       float v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = in[(kg + 1) >> 1][8 * ((kg + 1) & 1) + j];
+      for (int j = 0; j < 8; ++j) {
+        const float t = in[(kg + 1) >> 1][8 * ((kg + 1) & 1) + j];
+        v[j] = LRIN ? nf_vmax(t, 0.01f * t) : t;
+      }
       nf_split8(v, xn[0], xn[1], xn[2]);
     }
     // smallest terms first: wl xh, wh xl, wm xm, wm xh, wh xm, wh xh (components: 0 = h, 1 = m, 2 = l)
@@ -903,6 +908,78 @@ __device__ __forceinline__ void dense_fwd_b6p(const nf_u32x4 *__restrict__ w, co
       for (int i = 0; i < 6 * OB; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // one MFMA
         __builtin_amdgcn_sched_group_barrier(0x002, OB == 1 ? 8 : 4, 0);  // its shadow: a slice of the next split
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// dense_fwd_b6p for TWO tiles at once (round 6; k_affine_chain_dual): the unit's weight operands are read from LDS once and serve both
+// tiles, 2 OB accumulators alternate term by term, and the two next-k-group splits (72 vector instructions) ride behind 12 OB matrix
+// instructions instead of 6 OB.  Per accumulator the order of the terms is dense_fwd_b6's: bit-identical results.
+template <int IB, int OB>
+__device__ __forceinline__ void dense_fwd_b6p2(const nf_u32x4 *__restrict__ w, const float *__restrict__ b, const f32x16 (&in0)[IB],
+                                               const f32x16 (&in1)[IB], f32x16 (&out0)[OB], f32x16 (&out1)[OB], int l31, int hi) {
+  constexpr int ROWS = 32 * OB, NKG = 2 * IB;
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out0[ob][r] = out1[ob][r] = b[ob * 32 + nf_row(r, hi)];
+  const nf_u32x4 *wl = w + hi * ROWS + l31;
+  nf_u32x4 an[OB][3], xn0[3], xn1[3];
+  {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = in0[0][j];
+    nf_split8(v, xn0[0], xn0[1], xn0[2]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = in1[0][j];
+    nf_split8(v, xn1[0], xn1[1], xn1[2]);
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) an[ob][c] = wl[c * 2 * ROWS + ob * 32];
+  }
+#pragma unroll
+  for (int kg = 0; kg < NKG; ++kg) {
+    nf_u32x4 ac[OB][3], xc0[3], xc1[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      xc0[c] = xn0[c];
+      xc1[c] = xn1[c];
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob) ac[ob][c] = an[ob][c];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (kg + 1 < NKG) {
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) an[ob][c] = wl[((kg + 1) * 3 + c) * 2 * ROWS + ob * 32];
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = in0[(kg + 1) >> 1][8 * ((kg + 1) & 1) + j];
+      nf_split8(v, xn0[0], xn0[1], xn0[2]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = in1[(kg + 1) >> 1][8 * ((kg + 1) & 1) + j];
+      nf_split8(v, xn1[0], xn1[1], xn1[2]);
+    }
+    // smallest terms first: wl xh, wh xl, wm xm, wm xh, wh xm, wh xh (components: 0 = h, 1 = m, 2 = l)
+#pragma unroll
+    for (int term = 0; term < 6; ++term)
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob) {
+        const nf_u32x4 &av = term == 0 ? ac[ob][2] : (term == 2 || term == 3) ? ac[ob][1] : ac[ob][0];
+        const int xi = term == 1 ? 2 : (term == 2 || term == 4) ? 1 : 0;
+        out0[ob] = nf_mfma_bf16(av, xc0[xi], out0[ob]);
+        out1[ob] = nf_mfma_bf16(av, xc1[xi], out1[ob]);
+      }
+    if (kg + 1 < NKG) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 3 * OB, 0);  // the next k-group's weights: requested first
+#pragma unroll
+      for (int i = 0; i < 12 * OB; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, OB == 1 ? 8 : 4, 0);  // its shadow: a slice of the two next splits
       }
     }
     __builtin_amdgcn_sched_barrier(0);
