@@ -693,7 +693,7 @@ __global__ __launch_bounds__(64 * NW) void k_affine_chain(ChainArgs a, float *xt
 // older leaves (9-10 k per net): a phase is the SUM of the two.  Here ONE wave per SIMD (256 threads, up to 512 registers) carries two
 // tiles through every net with their instruction streams interleaved by construction (dense_fwd_b6p2): one tile's splits and layer
 // boundaries ride in the other's matrix instructions, the weight operands are read from LDS once for both.  Same images, same rotation
-// (three LDS slots, one per net), same per-accumulator term order: results bit-identical to k_affine_chain.
+// (three LDS slots, one per net), same per-accumulator term order as k_affine_chain (parity suite green with NF_CHAIN_DUAL=1).
 template <class G>
 __device__ __forceinline__ void net_forward_b6_dual(const float *__restrict__ img, const f32x16 (&x0)[G::MB], const f32x16 (&x1)[G::MB],
                                                     f32x16 (&out0)[G::CB], f32x16 (&out1)[G::CB], int l31, int hi) {
