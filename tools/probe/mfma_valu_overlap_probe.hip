@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256, 1) void one_wave(float *out, long long *cyc, i
 
 // two MFMA streams on one SIMD: the older wave (0-3) issues MFMA + KA8 x 8 fma per MFMA on NA accumulators, the younger (4-7) bare
 // MFMAs on NB accumulators -- does a chain on ONE accumulator lose time when the partner's MFMAs slip in between its links?
-template <int NA, int NB, int KA8>
+template <int NA, int NB, int KA8, int KB8 = 0>
 __global__ __launch_bounds__(512, 1) void two_chains(float *out, long long *cyc, int iters) {
   const int wave = threadIdx.x >> 6;
   f32x16 acc[4];
@@ -110,7 +110,13 @@ __global__ __launch_bounds__(512, 1) void two_chains(float *out, long long *cyc,
   } else {
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-      for (int m = 0; m < 16; ++m) acc[m % NB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc[m % NB], 0, 0, 0);
+      for (int m = 0; m < 16; ++m) {
+        acc[m % NB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc[m % NB], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < KB8; ++k) FMA8(v);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
   const long long t1 = clock64();
@@ -190,6 +196,12 @@ int main() {
   hipMemcpy(c, cyc, 16, hipMemcpyDeviceToHost);                                                                            \
   printf("two chains: older wave %d accumulator(s) + %2d fma per MFMA, younger wave %d accumulator(s) bare: older %6.1f, younger %6.1f clk per own MFMA\n", \
          NA, 8 * KA8, NB, (double)c[0] / (iters * 16.0), (double)c[1] / (iters * 16.0));
+#define CH2(KA8, KB8)                                                                                                      \
+  for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL((two_chains<2, 2, KA8, KB8>), dim3(256), dim3(512), 0, 0, out, cyc, iters); hipDeviceSynchronize(); } \
+  hipMemcpy(c, cyc, 16, hipMemcpyDeviceToHost);                                                                            \
+  printf("two mixed streams: older wave %2d fma per MFMA, younger wave %2d fma per MFMA: older %6.1f, younger %6.1f clk per own MFMA\n", \
+         8 * KA8, 8 * KB8, (double)c[0] / (iters * 16.0), (double)c[1] / (iters * 16.0));
+  CH2(1, 1) CH2(2, 2) CH2(1, 2) CH2(2, 1) CH2(3, 3)
   CH(1, 1, 0) CH(2, 2, 0) CH(1, 1, 1) CH(2, 2, 1) CH(4, 4, 1) CH(1, 2, 1) CH(2, 1, 1) CH(1, 1, 2) CH(2, 2, 2) CH(4, 4, 2)
 #define KIND(K, NAME)                                                                                                      \
   { long long cw, co;                                                                                                      \
