@@ -1635,6 +1635,14 @@ __global__ __launch_bounds__(256, 1) void k_affine_bwd_stashed(BwdAllArgs aa, fl
 #ifndef NF_TRACE_PAIR
 #define NF_TRACE_PAIR 0  // trace builds: which of the workgroup's four pairs tools/trace_bwd_pair.py sees
 #endif
+#ifndef NF_PAIR_ANTI
+#define NF_PAIR_ANTI 3  // bit 0: the producer's stages as [matrix burst | vector burst]; bit 1: the consumer's as [vector burst | matrix burst]
+// -- ANTI-PHASE instead of woven streams (the probe: two mixed streams on one SIMD add up, a matrix burst and a vector burst overlap).
+// Measured (profiles/r6w_pair_anti_phase_ab*.txt, alternating on one box): kernel 314.3 (0) / 320.5 (1) / 310.7 (2) / 307.7 us (3), step
+// 0.5775 -> 0.5737 ms over eight pairs of runs (3 against 0).  Far less than the probe's ideal: the consumer's stage is its own serial
+// [split 1.9 k | TR reads, 48 MFMAs, dots 2.6 k clocks] whatever the producer does beside it.  Same operations in the same order per
+// accumulator: bit-identical results.
+#endif
 #ifndef NF_PAIR_WEAVE
 #define NF_PAIR_WEAVE 1  // the consumer's splits of a1 / x2 in the issue shadows of dW3's / dW2's last matrix instructions (SplitTJob,
 // nf_mfma.h) instead of behind them: 301.7-305.3 against 305.7-309.8 us alternating on one box (profiles/r6j_pair_weave_ab.txt); the
@@ -1744,8 +1752,15 @@ __device__ __forceinline__ void pair_produce(const CouplingArgs &a, const float 
   char *const pw0 = reinterpret_cast<char *>(sp) + l31 * 32 + 8 * (hi ^ xw), *const pw1 = reinterpret_cast<char *>(sp) + l31 * 32 + 8 * ((2 + hi) ^ xw);
   if constexpr (DW6) {
     const PairPost<G::H2B> post{d2, m2, s2, pw0 + (bufb - reinterpret_cast<char *>(sp)), pw1 + (bufb - reinterpret_cast<char *>(sp))};
+#if NF_PAIR_ANTI & 1  // the GEMM as ONE burst of matrix instructions, then ONE burst of vector work (see NF_PAIR_ANTI)
+    dense_bwd_x_b6s<G::H2B, G::CB>(wt + B6TGeo<G>::T3, s3, d2, l31, hi);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int b = 0; b < G::H2B; ++b) post.all(b);
+#else
     dense_bwd_x_b6s_blocks<G::H2B, G::CB>(wt + B6TGeo<G>::T3, s3, d2, l31, hi, [&](int ib, int i) { if (ib > 0) post.template at_hook<24 * G::CB>(ib - 1, i); });
     post.all(G::H2B - 1);
+#endif
   } else
 #endif
   {
@@ -1768,8 +1783,15 @@ __device__ __forceinline__ void pair_produce(const CouplingArgs &a, const float 
 #if NF_PAIR_TR
   if constexpr (DW6) {
     const PairPost<G::H1B> post{d1, m1, s1, pw0 + (bufa - reinterpret_cast<char *>(sp)), pw1 + (bufa - reinterpret_cast<char *>(sp))};
+#if NF_PAIR_ANTI & 1
+    dense_bwd_x_b6s<G::H1B, G::H2B>(wt + B6TGeo<G>::T2, s2, d1, l31, hi);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int b = 0; b < G::H1B; ++b) post.all(b);
+#else
     dense_bwd_x_b6s_blocks<G::H1B, G::H2B>(wt + B6TGeo<G>::T2, s2, d1, l31, hi, [&](int ib, int i) { if (ib > 0) post.template at_hook<24 * G::H2B>(ib - 1, i); });
     post.all(G::H1B - 1);
+#endif
   } else
 #endif
   {
@@ -1825,6 +1847,48 @@ __device__ __forceinline__ void pair_consume(const float *__restrict__ img, cons
   if constexpr (DW6) {
     const char *bufa = reinterpret_cast<const char *>(sp) + par * NF_PAIR_BUF, *bufb = reinterpret_cast<const char *>(sp) + (par ^ 1) * NF_PAIR_BUF;
     float a1t[G::H1B][16];
+#if (NF_PAIR_ANTI & 2) && NF_PAIR_TR
+    // ANTI-PHASE (round 6): two MIXED matrix + vector streams on one SIMD add up, a matrix burst and a vector burst overlap
+    // (tools/probe/mfma_valu_overlap_probe.hip).  So every stage of this wave is [split the stage's own activation operand | dW GEMM],
+    // the producer's [dX GEMM | slopes, split, hand-over stores]: while one wave is in its matrix burst the other is in its vector
+    // burst.  The operand of stage k + 1 is requested at the head of stage k; only one operand's triples are live at a time.
+    {
+      float x2t[G::MB][16];
+      {
+        float a2t[G::H2B][16];
+        stash_get_T<G::H2B>(st, nbase + SG::A2, vT, a2t);
+        NF_TS_STAMP(1);
+        __syncthreads();  // B1
+        NF_TS_STAMP(2);
+        stash_get_T<G::H1B>(st, nbase + SG::A1, vT, a1t);
+        SplitT<G::H2B> a2s;
+        split_T<G::H2B>(a2t, a2s);
+        __builtin_amdgcn_sched_barrier(0);
+        NF_PAIR_DW(G::H2B, G::CB, a2s, bufa, acc.w3, acc.b3);
+      }
+      NF_TS_STAMP(3);
+      __syncthreads();  // B2
+      NF_TS_STAMP(4);
+      {
+        stash_get_T<G::MB>(st, SG::XT, vT, x2t);
+        SplitT<G::H1B> a1s;
+        split_T<G::H1B>(a1t, a1s);
+        __builtin_amdgcn_sched_barrier(0);
+        NF_PAIR_DW(G::H1B, G::H2B, a1s, bufb, acc.w2, acc.b2);
+      }
+      NF_TS_STAMP(5);
+      __syncthreads();  // B3
+      NF_TS_STAMP(6);
+      {
+        SplitT<G::MB> x2s;
+        split_T<G::MB>(x2t, x2s);
+        __builtin_amdgcn_sched_barrier(0);
+        NF_PAIR_DW(G::MB, G::H1B, x2s, bufa, acc.w1, acc.b1);
+      }
+      NF_TS_STAMP(7);
+      return;
+    }
+#endif
     {
       // (Measured and removed: the NEXT tile's a2 requested behind B3 -- 32 more registers across the loop's back edge, which
       // hipcc spills to scratch right behind the loads: 428 us per launch against 345.)

@@ -20,12 +20,12 @@ RQ8 = "RqsGeo<1, 1, 1, 8, 4, 2>"
 # kernel-name prefixes (demangled, as c++filt prints them) that must not use scratch
 ZERO = [
     # cfg 2: fused forward with the activation stash; reverse pass (FULL, forward direction, six-term products in both waves); epilogue
-    f"void k_affine_chain<{H64}, false, true, true, false, false>(",
+    f"void k_affine_chain<{H64}, false, true, true, false, false, 8>(",
     f"void k_affine_bwd_pair<{H64}, true, false, false, true, true>(",
     f"void k_affine_bwd_pair<{H64}, false, false, false, true, true>(",  # ragged batches / d < 64
     f"void k_affine_epilogue<{H64}, ",
     # cfg 5: the six-term inverse chain; forward-KL's reverse pass of the inverse chain
-    f"void k_affine_chain<{H64}, true, false, false, false, true>(",
+    f"void k_affine_chain<{H64}, true, false, false, false, true, 8>(",
     f"void k_affine_bwd_pair<{H64}, true, true, false, true, true>(",
     # cfg 3: fused forward chain (six-term output layer); the cooperative reverse kernel is in KNOWN
     f"void k_rqs_chain<{RQ8}, false, true, true>(",
