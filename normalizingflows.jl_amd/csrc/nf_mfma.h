@@ -1367,6 +1367,9 @@ struct SplitTJob {
   }
 };
 // dw_accumulate_t6 on a cotangent left by split_to_lds_tr
+#ifndef NF_DW_DBUF
+#define NF_DW_DBUF 0
+#endif
 // (`sj(i)` is called behind the i-th of the 12 IB OB matrix instructions: the consumer's side job is the split of its NEXT
 // activation operand, SplitTJob below)
 template <int IB, int OB, class SJ = NoSideJob>
@@ -1379,13 +1382,27 @@ __device__ __forceinline__ void dw_accumulate_tr6(const SplitT<IB> &as, const ch
   constexpr int NU = 2 * OB;
   nf_u32x4 dc[3];
   const unsigned ones = 0x3F803F80u;  // bf16 (1, 1)
+#if NF_DW_DBUF  // the next unit's operands requested behind the current unit's matrix instructions (a second operand set: 12 registers)
+  nf_u32x4 dn[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) dn[c] = nf_tr_operand(p0, p1, (c * 4) * TR_TILE);
+#endif
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     const int g = u / OB, ob = u % OB;
-    // (no operand double buffer: the consumer is at its 256 registers, and it is the wave with slack -- the twelve registers of a
-    // second operand set cost 28 bytes of scratch around the tile loop, the exposed LDS round trip per unit nothing measurable)
+#if NF_DW_DBUF
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dc[c] = dn[c];
+    if (u + 1 < NU) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) dn[c] = nf_tr_operand(p0, p1, (c * 4 + 2 * ((u + 1) % OB)) * TR_TILE + 512 * ((u + 1) / OB));
+    }
+#else
+    // (no operand double buffer: with the woven consumer of round 6's first half the twelve registers of a second operand set cost
+    // 28 bytes of scratch around the tile loop, the exposed LDS round trip per unit nothing measurable)
 #pragma unroll
     for (int c = 0; c < 3; ++c) dc[c] = nf_tr_operand(p0, p1, (c * 4 + 2 * ob) * TR_TILE + 512 * g);
+#endif
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int term = 0; term < 6; ++term)
