@@ -1635,6 +1635,9 @@ __global__ __launch_bounds__(256, 1) void k_affine_bwd_stashed(BwdAllArgs aa, fl
 #ifndef NF_TRACE_PAIR
 #define NF_TRACE_PAIR 0  // trace builds: which of the workgroup's four pairs tools/trace_bwd_pair.py sees
 #endif
+#ifndef NF_PAIR_MSPLIT
+#define NF_PAIR_MSPLIT 0  // bit 1: the anti-phase consumer's splits through nf_split16_mfma
+#endif
 #ifndef NF_PAIR_ANTI
 #define NF_PAIR_ANTI 3  // bit 0: the producer's stages as [matrix burst | vector burst]; bit 1: the consumer's as [vector burst | matrix burst]
 // -- ANTI-PHASE instead of woven streams (the probe: two mixed streams on one SIMD add up, a matrix burst and a vector burst overlap).
@@ -1853,6 +1856,17 @@ __device__ __forceinline__ void pair_consume(const float *__restrict__ img, cons
     // the producer's [dX GEMM | slopes, split, hand-over stores]: while one wave is in its matrix burst the other is in its vector
     // burst.  The operand of stage k + 1 is requested at the head of stage k; only one operand's triples are live at a time.
     {
+#if NF_PAIR_MSPLIT & 2  // the consumer's splits with their subtractions on the matrix pipe (nf_split16_mfma): a third of the vector work
+      const SplitSel sel = nf_split_sel(l31, hi);
+#define NF_CONS_SPLIT(NB, at, xs)                                              \
+  _Pragma("unroll") for (int ib_ = 0; ib_ < NB; ++ib_) {                       \
+    f32x16 v_;                                                               \
+    _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) v_[r_] = at[ib_][r_];    \
+    nf_split16_mfma(sel, v_, xs.h[ib_], xs.m[ib_], xs.l[ib_]);               \
+  }
+#else
+#define NF_CONS_SPLIT(NB, at, xs) split_T<NB>(at, xs)
+#endif
       float x2t[G::MB][16];
       {
         float a2t[G::H2B][16];
@@ -1862,7 +1876,7 @@ __device__ __forceinline__ void pair_consume(const float *__restrict__ img, cons
         NF_TS_STAMP(2);
         stash_get_T<G::H1B>(st, nbase + SG::A1, vT, a1t);
         SplitT<G::H2B> a2s;
-        split_T<G::H2B>(a2t, a2s);
+        NF_CONS_SPLIT(G::H2B, a2t, a2s);
         __builtin_amdgcn_sched_barrier(0);
         NF_PAIR_DW(G::H2B, G::CB, a2s, bufa, acc.w3, acc.b3);
       }
@@ -1872,7 +1886,7 @@ __device__ __forceinline__ void pair_consume(const float *__restrict__ img, cons
       {
         stash_get_T<G::MB>(st, SG::XT, vT, x2t);
         SplitT<G::H1B> a1s;
-        split_T<G::H1B>(a1t, a1s);
+        NF_CONS_SPLIT(G::H1B, a1t, a1s);
         __builtin_amdgcn_sched_barrier(0);
         NF_PAIR_DW(G::H1B, G::H2B, a1s, bufb, acc.w2, acc.b2);
       }
@@ -1881,7 +1895,7 @@ __device__ __forceinline__ void pair_consume(const float *__restrict__ img, cons
       NF_TS_STAMP(6);
       {
         SplitT<G::MB> x2s;
-        split_T<G::MB>(x2t, x2s);
+        NF_CONS_SPLIT(G::MB, x2t, x2s);
         __builtin_amdgcn_sched_barrier(0);
         NF_PAIR_DW(G::MB, G::H1B, x2s, bufa, acc.w1, acc.b1);
       }
