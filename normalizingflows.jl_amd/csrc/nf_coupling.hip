@@ -1635,6 +1635,9 @@ __global__ __launch_bounds__(256, 1) void k_affine_bwd_stashed(BwdAllArgs aa, fl
 #ifndef NF_TRACE_PAIR
 #define NF_TRACE_PAIR 0  // trace builds: which of the workgroup's four pairs tools/trace_bwd_pair.py sees
 #endif
+#ifndef NF_PAIR_SPREAD
+#define NF_PAIR_SPREAD 0
+#endif
 #ifndef NF_PAIR_MSPLIT
 #define NF_PAIR_MSPLIT 0  // bit 1: the anti-phase consumer's splits through nf_split16_mfma
 #endif
@@ -1824,6 +1827,31 @@ __device__ __forceinline__ void pair_produce(const CouplingArgs &a, const float 
   NF_TS_STAMP(7);
 }
 
+// split_T of one operand with the 4 NB requests of the next operand spread between its 2 NA k-group splits (NF_PAIR_SPREAD)
+template <int NA, int NB>
+__device__ __forceinline__ void consumer_split_and_request(const StashIO &st, int base, int voff, const float (&at)[NA][16], SplitT<NA> &s,
+                                                           float (&bt)[NB][16]) {
+  constexpr int NS = 2 * NA, NL = 4 * NB;
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int ib = i >> 1, g = i & 1;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = at[ib][8 * g + j];
+#pragma unroll
+    for (int l = i * NL / NS; l < (i + 1) * NL / NS; ++l) {  // this k-group's share of the requests, in front of its split
+      const int b = l >> 2, q = l & 3;
+      const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(st.rs, voff, (base + b * 1024) * 4 + q * 16, 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned bits = w[e];
+        bt[b][4 * q + e] = __builtin_bit_cast(float, bits);
+      }
+    }
+    nf_split8(v, s.h[ib][g], s.m[ib][g], s.l[ib][g]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
 // (Round 6, measured and removed: the consumer held back by s_sleep behind each barrier -- 256 / 512 / 768 clocks in stage 1,
 // twice that in stage 2 -- so that its matrix instructions would run beside the producer's vector tail instead of beside its
 // GEMM: 323.2-325.2 against 325.5 us on one box, nothing.  The older wave already wins the arbitration.)
@@ -1867,6 +1895,15 @@ __device__ __forceinline__ void pair_consume(const float *__restrict__ img, cons
 #else
 #define NF_CONS_SPLIT(NB, at, xs) split_T<NB>(at, xs)
 #endif
+      // the NEXT stage's operand is requested while this stage's is split.  NF_PAIR_SPREAD: its 16-byte requests go out one by one
+      // between the split's k-groups instead of in one batch behind the barrier -- there all eight waves of the CU issue theirs within
+      // the same few hundred clocks and a wave is held 590-780 clocks at ISSUE (64 bytes per clock and CU; tools/trace_bwd_pair.py)
+#if NF_PAIR_SPREAD
+#define NF_CONS_REQ_SPLIT(NA, at, xs, NBQ, baseq, bt) consumer_split_and_request<NA, NBQ>(st, baseq, vT, at, xs, bt)
+#else
+#define NF_CONS_REQ_SPLIT(NA, at, xs, NBQ, baseq, bt) \
+  do { stash_get_T<NBQ>(st, baseq, vT, bt); NF_CONS_SPLIT(NA, at, xs); } while (0)
+#endif
       float x2t[G::MB][16];
       {
         float a2t[G::H2B][16];
@@ -1874,9 +1911,8 @@ __device__ __forceinline__ void pair_consume(const float *__restrict__ img, cons
         NF_TS_STAMP(1);
         __syncthreads();  // B1
         NF_TS_STAMP(2);
-        stash_get_T<G::H1B>(st, nbase + SG::A1, vT, a1t);
         SplitT<G::H2B> a2s;
-        NF_CONS_SPLIT(G::H2B, a2t, a2s);
+        NF_CONS_REQ_SPLIT(G::H2B, a2t, a2s, G::H1B, nbase + SG::A1, a1t);
         __builtin_amdgcn_sched_barrier(0);
         NF_PAIR_DW(G::H2B, G::CB, a2s, bufa, acc.w3, acc.b3);
       }
@@ -1884,9 +1920,8 @@ __device__ __forceinline__ void pair_consume(const float *__restrict__ img, cons
       __syncthreads();  // B2
       NF_TS_STAMP(4);
       {
-        stash_get_T<G::MB>(st, SG::XT, vT, x2t);
         SplitT<G::H1B> a1s;
-        NF_CONS_SPLIT(G::H1B, a1t, a1s);
+        NF_CONS_REQ_SPLIT(G::H1B, a1t, a1s, G::MB, SG::XT, x2t);
         __builtin_amdgcn_sched_barrier(0);
         NF_PAIR_DW(G::H1B, G::H2B, a1s, bufb, acc.w2, acc.b2);
       }
